@@ -1,0 +1,226 @@
+"""Seeded synthetic inputs for the ORB front-end and the bundle-adjustment back-end.
+
+These are the workloads BASELINE.md / SURVEY.md 8(d) define (there are no datasets in
+the image and no network): u8 frames in three families, frame sequences that are pure
+translations of one canvas, KITTI-intrinsics pose problems and BA graphs.  numpy only.
+"""
+import numpy as np
+
+KITTI_K4 = np.array([718.856, 718.856, 607.1928, 185.2157], np.float64)  # reference configs/KITTI00-02.yaml:8-11
+
+
+# --------------------------------------------------------------------------- frames
+def _blocks(rng, w, h):
+    img = np.full((h, w), float(rng.integers(90, 160)), np.float32)
+    n = int(rng.integers(200, 600)) * max(1, (w * h) // (640 * 480))
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(n):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        hw, hh = rng.uniform(4, 40), rng.uniform(4, 40)
+        g = float(rng.integers(0, 256))
+        x0, x1 = int(max(0, cx - 60)), int(min(w, cx + 60))
+        y0, y1 = int(max(0, cy - 60)), int(min(h, cy + 60))
+        if x1 <= x0 or y1 <= y0:
+            continue
+        if rng.random() < 0.5:
+            th = 0.0
+        else:
+            th = rng.uniform(0, np.pi)
+        c, s = np.cos(th), np.sin(th)
+        X = xx[y0:y1, x0:x1] - cx
+        Y = yy[y0:y1, x0:x1] - cy
+        m = (np.abs(c * X + s * Y) <= hw) & (np.abs(-s * X + c * Y) <= hh)
+        img[y0:y1, x0:x1][m] = g
+    img += rng.normal(0, 2.0, img.shape).astype(np.float32)
+    return img
+
+
+def _checker(rng, w, h):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.full((h, w), 128.0)
+    for _ in range(3):
+        H = np.eye(3)
+        H[0, 0], H[1, 1] = rng.uniform(0.6, 1.4), rng.uniform(0.6, 1.4)
+        H[0, 1], H[1, 0] = rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3)
+        H[2, 0], H[2, 1] = rng.uniform(-6e-4, 6e-4), rng.uniform(-6e-4, 6e-4)
+        H[0, 2], H[1, 2] = rng.uniform(-50, 50), rng.uniform(-50, 50)
+        den = H[2, 0] * xx + H[2, 1] * yy + 1.0
+        u = (H[0, 0] * xx + H[0, 1] * yy + H[0, 2]) / den
+        v = (H[1, 0] * xx + H[1, 1] * yy + H[1, 2]) / den
+        sq = rng.uniform(14, 40)
+        par = (np.floor(u / sq) + np.floor(v / sq)).astype(np.int64) & 1
+        lo, hi = rng.integers(20, 100), rng.integers(150, 240)
+        layer = np.where(par == 1, float(hi), float(lo))
+        x0, x1 = sorted(rng.integers(0, w, 2)); y0, y1 = sorted(rng.integers(0, h, 2))
+        if x1 - x0 < w // 4:
+            x0, x1 = 0, w
+        if y1 - y0 < h // 4:
+            y0, y1 = 0, h
+        img[y0:y1, x0:x1] = layer[y0:y1, x0:x1]
+    img += rng.normal(0, 2.0, img.shape)
+    return img.astype(np.float32)
+
+
+def _flat(rng, w, h):
+    return (float(rng.integers(60, 200)) + rng.normal(0, 3.0, (h, w))).astype(np.float32)
+
+
+FAMILIES = ("blocks", "checker", "flat")
+
+
+def make_canvas(seed, w, h, family="blocks", margin=0):
+    """One u8 canvas of (h+2*margin) x (w+2*margin)."""
+    rng = np.random.default_rng(seed)
+    W, Hh = w + 2 * margin, h + 2 * margin
+    f = {"blocks": _blocks, "checker": _checker, "flat": _flat}[family](rng, W, Hh)
+    return np.clip(np.rint(f), 0, 255).astype(np.uint8)
+
+
+def make_frame(seed, w, h, family="blocks"):
+    return make_canvas(seed, w, h, family, 0)
+
+
+def make_sequence(seed, w, h, n, family="blocks", max_shift=8):
+    """n frames, frame t+1 = frame t translated by (dx,dy) in [-max_shift,max_shift]^2
+    (crops of one canvas, so true correspondences exist).  Returns (frames[n,h,w] u8, offsets[n,2])."""
+    rng = np.random.default_rng(seed + 7919)
+    m = max_shift * 4
+    canvas = make_canvas(seed, w, h, family, m)
+    ox, oy = m, m
+    frames = np.empty((n, h, w), np.uint8)
+    offs = np.zeros((n, 2), np.int32)
+    for t in range(n):
+        frames[t] = canvas[oy:oy + h, ox:ox + w]
+        offs[t] = (ox - m, oy - m)
+        dx, dy = rng.integers(-max_shift, max_shift + 1, 2)
+        ox = int(np.clip(ox + dx, 0, 2 * m)); oy = int(np.clip(oy + dy, 0, 2 * m))
+    return frames, offs
+
+
+# --------------------------------------------------------------------------- geometry
+def quat_from_rotvec(rv):
+    """[x,y,z,w] unit quaternion of a rotation vector."""
+    rv = np.asarray(rv, np.float64)
+    a = np.linalg.norm(rv)
+    if a < 1e-300:
+        return np.array([0, 0, 0, 1.0])
+    ax = rv / a
+    return np.concatenate([ax * np.sin(a / 2), [np.cos(a / 2)]])
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw,
+                     aw * bw - ax * bx - ay * by - az * bz])
+
+
+def quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def project(K4, pose7, X):
+    R = quat_to_R(pose7[3:7]); p = X @ R.T + pose7[:3]
+    return np.stack([K4[0] * p[:, 0] / p[:, 2] + K4[2], K4[1] * p[:, 1] / p[:, 2] + K4[3]], 1), p[:, 2]
+
+
+_SCALE = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+_QUOTA_P = np.array([434, 362, 302, 251, 209, 175, 145, 122], np.float64) / 2000.0
+
+
+def _octave_inv_sigma2(rng, n):
+    octv = rng.choice(8, size=n, p=_QUOTA_P / _QUOTA_P.sum())
+    sc = _SCALE[octv]
+    return octv, sc.astype(np.float64), (np.float32(1.0) / (sc * sc)).astype(np.float32)
+
+
+def make_pose_problem(seed, n=2000, outlier_frac=0.05, w=1241, h=376):
+    """C3: one KITTI camera, n observations, sigma = 1 px * scale[octave], gross outliers."""
+    rng = np.random.default_rng(seed)
+    K4 = KITTI_K4.copy()
+    q_gt = quat_from_rotvec(rng.normal(0, 0.05, 3)); t_gt = rng.normal(0, 0.3, 3)
+    pose_gt = np.concatenate([t_gt, q_gt])
+    uv = np.stack([rng.uniform(20, w - 20, n), rng.uniform(20, h - 20, n)], 1)
+    z = rng.uniform(4, 60, n)
+    pc = np.stack([(uv[:, 0] - K4[2]) / K4[0] * z, (uv[:, 1] - K4[3]) / K4[1] * z, z], 1)
+    R = quat_to_R(q_gt)
+    Xw = (pc - t_gt) @ R           # X = R^T (pc - t)
+    octv, sc, inv_sigma2 = _octave_inv_sigma2(rng, n)
+    obs = uv + rng.normal(0, 1.0, (n, 2)) * sc[:, None]
+    nout = int(round(outlier_frac * n))
+    if nout:
+        idx = rng.choice(n, nout, replace=False)
+        obs[idx] += rng.choice([-1, 1], (nout, 2)) * rng.uniform(30, 50, (nout, 2))
+    q0 = quat_mul(quat_from_rotvec(rng.normal(0, np.deg2rad(0.5), 3)), q_gt)
+    pose0 = np.concatenate([t_gt + rng.normal(0, 0.05, 3), q0])
+    return dict(K4=K4, pose0=pose0, pose_gt=pose_gt, Xw=Xw, uv=obs, inv_sigma2=inv_sigma2, octave=octv)
+
+
+def make_ba_graph(seed, ncam=100, npts=10000, nobs=50000, outlier_frac=0.05, noise=1.0, perturb=True,
+                  n_fixed=1, w=1241, h=376):
+    """C4/C5-style graph: forward-moving KITTI cameras, points in the frusta, each point seen by a
+    run of consecutive cameras (mean track length nobs/npts).  Camera 0..n_fixed-1 are fixed (gauge)."""
+    rng = np.random.default_rng(seed)
+    K4 = KITTI_K4.copy()
+    step = 0.8
+    poses_gt = np.zeros((ncam, 7))
+    yaw = np.cumsum(rng.normal(0, 0.01, ncam))
+    for c in range(ncam):
+        q = quat_from_rotvec([0, yaw[c], 0])
+        R = quat_to_R(q)
+        C = np.array([np.sum(np.sin(yaw[:c + 1])) * step * 0 + 0.02 * c * np.sin(yaw[c]), 0.0, step * c])
+        poses_gt[c, :3] = -R @ C        # Tcw: p_c = R X + t, camera centre C
+        poses_gt[c, 3:] = q
+    mean_len = nobs / npts
+    pts = np.zeros((npts, 3))
+    oc, op = [], []
+    lens = np.clip(rng.poisson(max(mean_len - 2, 0.0), npts) + 2, 2, ncam)
+    # adjust total to nobs exactly
+    diff = int(lens.sum() - nobs)
+    order = rng.permutation(npts)
+    i = 0
+    while diff != 0 and i < 50 * npts:
+        p = order[i % npts]
+        if diff > 0 and lens[p] > 2:
+            lens[p] -= 1; diff -= 1
+        elif diff < 0 and lens[p] < ncam:
+            lens[p] += 1; diff += 1
+        i += 1
+    for p in range(npts):
+        L = int(lens[p])
+        c0 = int(rng.integers(0, ncam - L + 1))
+        cm = c0 + L // 2
+        # place the point in the frustum of the middle camera, far enough to be seen by the run
+        u = rng.uniform(100, w - 100); v = rng.uniform(40, h - 40)
+        z = rng.uniform(4 + step * L, 60)
+        pc = np.array([(u - K4[2]) / K4[0] * z, (v - K4[3]) / K4[1] * z, z])
+        R = quat_to_R(poses_gt[cm, 3:])
+        pts[p] = R.T @ (pc - poses_gt[cm, :3])
+        for c in range(c0, c0 + L):
+            oc.append(c); op.append(p)
+    oc = np.array(oc, np.int32); op = np.array(op, np.int32)
+    n = len(oc)
+    uv = np.zeros((n, 2))
+    for c in range(ncam):
+        m = oc == c
+        if m.any():
+            uv[m], _ = project(K4, poses_gt[c], pts[op[m]])
+    octv, sc, inv_sigma2 = _octave_inv_sigma2(rng, n)
+    obs = uv + rng.normal(0, noise, (n, 2)) * sc[:, None]
+    nout = int(round(outlier_frac * n))
+    if nout:
+        idx = rng.choice(n, nout, replace=False)
+        obs[idx] += rng.choice([-1, 1], (nout, 2)) * rng.uniform(30, 50, (nout, 2))
+    poses0 = poses_gt.copy(); pts0 = pts.copy()
+    if perturb:
+        for c in range(n_fixed, ncam):
+            poses0[c, 3:] = quat_mul(quat_from_rotvec(rng.normal(0, np.deg2rad(0.5) / np.sqrt(3), 3)), poses_gt[c, 3:])
+            poses0[c, :3] += rng.normal(0, 0.05 / np.sqrt(3), 3)
+        pts0 += pts * rng.normal(0, 0.01, (npts, 1))
+    cam_fixed = np.zeros(ncam, np.uint8); cam_fixed[:n_fixed] = 1
+    return dict(K4=np.tile(K4, (ncam, 1)), poses0=poses0, poses_gt=poses_gt, cam_fixed=cam_fixed, pts0=pts0,
+                pts_gt=pts, obs_cam=oc, obs_pt=op, obs_uv=obs, obs_inv_sigma2=inv_sigma2, octave=octv)

@@ -1,0 +1,231 @@
+// ============================================================================
+// oracle/match_oracle.cpp -- CPU restatement of the reference ORB matcher core.
+//
+// TEST INFRASTRUCTURE ONLY (see oracle/orb_oracle.cpp header for the rule).
+// PARITY STATUS: integer arithmetic restated directly from the reference source
+// (src/ORBmatcher.cc, src/Frame.cc); no third-party arithmetic is involved, but
+// the reference ships no tests, so parity is pinned only by the known-answer
+// identities in tests/ (d(x,x)=0, d(0,~0)=256, popcount identity) -> "unpinned".
+// ============================================================================
+#include <cmath>
+#include <climits>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:35-37
+
+// DescriptorDistance (src/ORBmatcher.cc:1422-1437): SWAR popcount over 8 x u32
+int descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t pa, pb;
+    std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+    uint32_t v = pa ^ pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+// ComputeThreeMaxima (src/ORBmatcher.cc:1386-1418) on bin counts
+void three_maxima(const int* cnt, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  ind1 = ind2 = ind3 = -1;
+  for (int i = 0; i < L; i++) {
+    const int s = cnt[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// rotation-histogram bin idiom (e.g. src/ORBmatcher.cc:431-437)
+inline int rot_bin(float a1, float a2) {
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+// Frame grid (src/Frame.cc:158-173, 243-320), FRAME_GRID_COLS=64, FRAME_GRID_ROWS=48
+struct Grid {
+  static const int COLS = 64, ROWS = 48;
+  float min_x, min_y, winv, hinv;
+  std::vector<int> cell[COLS][ROWS];
+  const float* kps;   // n x 4 floats: x, y, octave, angle
+  int n;
+  void build(const float* k, int n_, float minx, float maxx, float miny, float maxy) {
+    kps = k; n = n_; min_x = minx; min_y = miny;
+    winv = static_cast<float>(COLS) / (maxx - minx);     // src/Frame.cc:130-133 (grid_element_*_inv_)
+    hinv = static_cast<float>(ROWS) / (maxy - miny);
+    for (int i = 0; i < n; i++) {
+      int px = (int)std::round((k[4 * i] - min_x) * winv);
+      int py = (int)std::round((k[4 * i + 1] - min_y) * hinv);
+      if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+      cell[px][py].push_back(i);
+    }
+  }
+  void features_in_area(float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const {
+    out.clear();
+    const int min_cx = std::max(0, (int)std::floor((x - min_x - r) * winv));
+    if (min_cx >= COLS) return;
+    const int max_cx = std::min(COLS - 1, (int)std::ceil((x - min_x + r) * winv));
+    if (max_cx < 0) return;
+    const int min_cy = std::max(0, (int)std::floor((y - min_y - r) * hinv));
+    if (min_cy >= ROWS) return;
+    const int max_cy = std::min(ROWS - 1, (int)std::ceil((y - min_y + r) * hinv));
+    if (max_cy < 0) return;
+    const bool check = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = min_cx; ix <= max_cx; ix++)
+      for (int iy = min_cy; iy <= max_cy; iy++)
+        for (int j : cell[ix][iy]) {
+          int oct = (int)kps[4 * j + 2];
+          if (check) {
+            if (oct < minLevel) continue;
+            if (maxLevel >= 0 && oct > maxLevel) continue;
+          }
+          const float dx = kps[4 * j] - x, dy = kps[4 * j + 1] - y;
+          if (std::fabs(dx) < r && std::fabs(dy) < r) out.push_back(j);
+        }
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+
+// best / second-best over candidates in candidate order, first minimum wins
+// (the `dist < bestDist ... else if dist < bestDist2` idiom, e.g. src/ORBmatcher.cc:201-207).
+// cand_offsets == NULL -> brute force over all nt targets in index order.
+// Outputs: best_idx (-1 if no candidate), best_d, second_d (256 = none).
+void orc_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint32_t* cand_offsets,
+                       const uint32_t* cand_idx, int32_t* best_idx, int32_t* best_d, int32_t* second_d) {
+  for (int i = 0; i < nq; i++) {
+    int b1 = 256, b2 = 256, bi = -1;
+    uint32_t lo = cand_offsets ? cand_offsets[i] : 0, hi = cand_offsets ? cand_offsets[i + 1] : (uint32_t)nt;
+    for (uint32_t c = lo; c < hi; c++) {
+      int j = cand_offsets ? (int)cand_idx[c] : (int)c;
+      int d = descriptor_distance(q + 32 * (size_t)i, t + 32 * (size_t)j);
+      if (d < b1) { b2 = b1; b1 = d; bi = j; }
+      else if (d < b2) { b2 = d; }
+    }
+    best_idx[i] = bi; best_d[i] = b1; second_d[i] = b2;
+  }
+}
+
+void orc_three_maxima(const int* cnt, int L, int* ind) { three_maxima(cnt, L, ind[0], ind[1], ind[2]); }
+int orc_rot_bin(float a1, float a2) { return rot_bin(a1, a2); }
+
+// The bench "match" workload: brute-force best/second-best of every query
+// against every target, accept iff best <= th and best < ratio*second
+// (SearchByBoW idiom, src/ORBmatcher.cc:210-212), then rotation-consistency filter
+// (histogram of angle differences, keep the top-3 bins; :217-252).
+// match12[i] = target index or -1.  Returns the number of surviving matches.
+int orc_match_frames(const uint8_t* d1, const float* ang1, int n1, const uint8_t* d2, const float* ang2, int n2,
+                     float ratio, int th, int check_ori, int32_t* match12) {
+  std::vector<int32_t> bi(n1), bd(n1), sd(n1);
+  orc_hamming_best2(d1, n1, d2, n2, nullptr, nullptr, bi.data(), bd.data(), sd.data());
+  int cnt[HISTO_LENGTH] = {0};
+  std::vector<int> bin(n1, -1);
+  int nm = 0;
+  for (int i = 0; i < n1; i++) {
+    match12[i] = -1;
+    if (bi[i] < 0) continue;
+    if (bd[i] <= th && static_cast<float>(bd[i]) < ratio * static_cast<float>(sd[i])) {
+      match12[i] = bi[i];
+      nm++;
+      if (check_ori) { bin[i] = rot_bin(ang1[i], ang2[bi[i]]); cnt[bin[i]]++; }
+    }
+  }
+  if (check_ori) {
+    int i1, i2, i3;
+    three_maxima(cnt, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < n1; i++)
+      if (match12[i] >= 0 && bin[i] != i1 && bin[i] != i2 && bin[i] != i3) { match12[i] = -1; nm--; }
+  }
+  return nm;
+}
+
+// candidate generation: Frame::GetFeaturesInArea for a list of queries -> CSR
+// kps = n x 4 floats (x, y, octave, angle).  Returns total candidates (cand_idx may be NULL to size).
+int orc_features_in_area(const float* kps, int n, const float* bounds /*minx,maxx,miny,maxy*/, const float* qxy,
+                         const float* qr, const int* qminl, const int* qmaxl, int nq, uint32_t* offsets,
+                         uint32_t* cand_idx, int cap) {
+  static Grid* G = nullptr;
+  delete G; G = new Grid();
+  G->build(kps, n, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<int> v;
+  int tot = 0;
+  for (int i = 0; i < nq; i++) {
+    offsets[i] = tot;
+    G->features_in_area(qxy[2 * i], qxy[2 * i + 1], qr[i], qminl[i], qmaxl[i], v);
+    for (int j : v) { if (cand_idx && tot < cap) cand_idx[tot] = j; tot++; }
+  }
+  offsets[nq] = tot;
+  return tot;
+}
+
+// SearchForInitialization (src/ORBmatcher.cc:363-468) on flattened frames.
+// kps1/kps2 = n x 4 floats (x,y,octave,angle) of the UNDISTORTED keypoints; prev_matched = n1 x 2 (in/out).
+int orc_search_for_initialization(const float* kps1, const uint8_t* d1, int n1, const float* kps2, const uint8_t* d2,
+                                  int n2, const float* bounds2, float* prev_matched, int window, float nnratio,
+                                  int check_ori, int32_t* matches12) {
+  Grid* G = new Grid();
+  G->build(kps2, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3]);
+  int nmatches = 0;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> matchedDist(n2, INT_MAX), matches21(n2, -1);
+  std::vector<int> cand;
+  for (int i1 = 0; i1 < n1; i1++) {
+    int level1 = (int)kps1[4 * i1 + 2];
+    if (level1 > 0) continue;
+    G->features_in_area(prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window, level1, level1, cand);
+    if (cand.empty()) continue;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int i2 : cand) {
+      int dist = descriptor_distance(d1 + 32 * (size_t)i1, d2 + 32 * (size_t)i2);
+      if (matchedDist[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * nnratio) {
+        if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+        matches12[i1] = bestIdx2; matches21[bestIdx2] = i1; matchedDist[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_ori) rotHist[rot_bin(kps1[4 * i1 + 3], kps2[4 * bestIdx2 + 3])].push_back(i1);
+      }
+    }
+  }
+  if (check_ori) {
+    int cnt[HISTO_LENGTH], i1, i2, i3;
+    for (int i = 0; i < HISTO_LENGTH; i++) cnt[i] = (int)rotHist[i].size();
+    three_maxima(cnt, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx1 : rotHist[i]) if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)
+    if (matches12[i1] >= 0) { prev_matched[2 * i1] = kps2[4 * matches12[i1]]; prev_matched[2 * i1 + 1] = kps2[4 * matches12[i1] + 1]; }
+  delete G;
+  return nmatches;
+}
+
+int orc_th_low() { return TH_LOW; }
+int orc_th_high() { return TH_HIGH; }
+int orc_histo_length() { return HISTO_LENGTH; }
+
+}  // extern "C"

@@ -1,0 +1,347 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liborb_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liborb_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp",
+                                             "orb_pattern_data.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_extract.restype = C.c_int
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_level_dims.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_level_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_level_num_candidates.argtypes = [C.c_void_p, C.c_int]
+        L.orc_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_level_num_keypoints.argtypes = [C.c_void_p, C.c_int]
+        L.orc_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_gauss7_taps.argtypes = [C.c_void_p]
+        L.orc_fast.restype = C.c_int
+        L.orc_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_octree.restype = C.c_int
+        L.orc_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_det_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orc_pattern.restype = C.c_void_p
+        # matcher
+        L.orc_descriptor_distance.restype = C.c_int
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_hamming_best2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_three_maxima.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_rot_bin.restype = C.c_int
+        L.orc_rot_bin.argtypes = [C.c_float, C.c_float]
+        L.orc_match_frames.restype = C.c_int
+        L.orc_match_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.orc_features_in_area.restype = C.c_int
+        L.orc_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_search_for_initialization.restype = C.c_int
+        L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        # BA
+        L.orc_ba_solve.restype = C.c_int
+        L.orc_ba_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_check_outlier.restype = C.c_int
+        L.orc_check_outlier.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_pose_optimization.restype = C.c_int
+        L.orc_pose_optimization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p]
+        L.orc_local_ba.restype = C.c_int
+        L.orc_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ba_eval_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_quat_plus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_quat_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class BaOpts(C.Structure):
+    _fields_ = [("max_iters", C.c_int), ("huber_delta", C.c_double), ("fix_points", C.c_int), ("stop", C.c_void_p)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int),
+                ("successful_steps", C.c_int), ("termination", C.c_int), ("final_radius", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class OracleExtractor:
+    """ORB_SLAM2::ORBextractor restated (reference include/ORBextractor.h:45-111)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        sc = np.zeros(nlevels, np.float32); isc = sc.copy(); s2 = sc.copy(); is2 = sc.copy()
+        q = np.zeros(nlevels, np.int32); um = np.zeros(16, np.int32)
+        self.L.orc_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(q), _p(um))
+        self.scale, self.inv_scale, self.sigma2, self.inv_sigma2, self.quota, self.umax = sc, isc, s2, is2, q, um
+
+    def __del__(self):
+        try:
+            self.L.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.orc_extract(self.h, _p(img), w, h, w, _p(kps), _p(desc), cap)
+        assert n >= 0
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level_image(self, level, blurred=False):
+        w = C.c_int(); h = C.c_int()
+        self.L.orc_level_dims(self.h, level, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.L.orc_level_image(self.h, level, int(blurred), _p(out))
+        return out
+
+    def level_candidates(self, level):
+        n = self.L.orc_level_num_candidates(self.h, level)
+        out = np.zeros((n, 3), np.int32)
+        if n:
+            self.L.orc_level_candidates(self.h, level, _p(out))
+        return out
+
+    def level_keypoints(self, level):
+        n = self.L.orc_level_num_keypoints(self.h, level)
+        out = np.zeros(n, KP_DTYPE)
+        if n:
+            self.L.orc_level_keypoints(self.h, level, _p(out))
+        return out
+
+
+def resize_linear_u8(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], _p(out), dw, dh)
+    return out
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    out = np.zeros_like(src)
+    lib().orc_gaussian_blur7(_p(src), src.shape[1], src.shape[0], _p(out))
+    return out
+
+
+def gauss7_taps():
+    t = np.zeros(7, np.int32)
+    lib().orc_gauss7_taps(_p(t))
+    return t
+
+
+def fast(src, threshold):
+    src = np.ascontiguousarray(src, np.uint8)
+    cap = src.size // 4 + 16
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast(_p(src), src.shape[1], src.shape[0], threshold, _p(out), cap)
+    return out[:n].copy()
+
+
+def octree(cands, minX, maxX, minY, maxY, N):
+    cands = np.ascontiguousarray(cands, np.int32)
+    cap = len(cands) + 8
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_octree(_p(cands), len(cands), minX, maxX, minY, maxY, N, _p(out), cap)
+    return out[:n].copy()
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(float(y), float(x))
+
+
+def det_sincos(x):
+    s = C.c_double(); c = C.c_double()
+    lib().orc_det_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def ic_angle(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orc_ic_angle(_p(img), img.shape[1], img.shape[0], int(x), int(y))
+
+
+def brief(img, x, y, angle_deg):
+    img = np.ascontiguousarray(img, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_brief(_p(img), img.shape[1], img.shape[0], int(x), int(y), float(angle_deg), _p(d))
+    return d
+
+
+def pattern():
+    return np.ctypeslib.as_array(C.cast(lib().orc_pattern(), C.POINTER(C.c_int8)), shape=(1024,)).copy()
+
+
+# ------------------------------- matcher -------------------------------------
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_best2(q, t, cand_offsets=None, cand_idx=None):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    nq, nt = len(q), len(t)
+    bi = np.zeros(nq, np.int32); bd = np.zeros(nq, np.int32); sd = np.zeros(nq, np.int32)
+    co = None if cand_offsets is None else np.ascontiguousarray(cand_offsets, np.uint32)
+    ci = None if cand_idx is None else np.ascontiguousarray(cand_idx, np.uint32)
+    lib().orc_hamming_best2(_p(q), nq, _p(t), nt, _p(co), _p(ci), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def three_maxima(cnt):
+    cnt = np.ascontiguousarray(cnt, np.int32)
+    ind = np.zeros(3, np.int32)
+    lib().orc_three_maxima(_p(cnt), len(cnt), _p(ind))
+    return ind
+
+
+def rot_bin(a1, a2):
+    return lib().orc_rot_bin(float(a1), float(a2))
+
+
+def match_frames(d1, ang1, d2, ang2, ratio=0.9, th=50, check_ori=True):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    a1 = np.ascontiguousarray(ang1, np.float32); a2 = np.ascontiguousarray(ang2, np.float32)
+    m = np.zeros(len(d1), np.int32)
+    n = lib().orc_match_frames(_p(d1), _p(a1), len(d1), _p(d2), _p(a2), len(d2), ratio, th, int(check_ori), _p(m))
+    return m, n
+
+
+def features_in_area(kps4, bounds, qxy, qr, qminl, qmaxl):
+    kps4 = np.ascontiguousarray(kps4, np.float32); bounds = np.ascontiguousarray(bounds, np.float32)
+    qxy = np.ascontiguousarray(qxy, np.float32); qr = np.ascontiguousarray(qr, np.float32)
+    qminl = np.ascontiguousarray(qminl, np.int32); qmaxl = np.ascontiguousarray(qmaxl, np.int32)
+    nq = len(qr)
+    off = np.zeros(nq + 1, np.uint32)
+    tot = lib().orc_features_in_area(_p(kps4), len(kps4), _p(bounds), _p(qxy), _p(qr), _p(qminl), _p(qmaxl), nq,
+                                     _p(off), None, 0)
+    idx = np.zeros(max(tot, 1), np.uint32)
+    lib().orc_features_in_area(_p(kps4), len(kps4), _p(bounds), _p(qxy), _p(qr), _p(qminl), _p(qmaxl), nq,
+                               _p(off), _p(idx), tot)
+    return off, idx[:tot]
+
+
+def search_for_initialization(kps1, d1, kps2, d2, bounds2, prev_matched, window=100, nnratio=0.9, check_ori=True):
+    kps1 = np.ascontiguousarray(kps1, np.float32); kps2 = np.ascontiguousarray(kps2, np.float32)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    b = np.ascontiguousarray(bounds2, np.float32)
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m = np.zeros(len(kps1), np.int32)
+    n = lib().orc_search_for_initialization(_p(kps1), _p(d1), len(kps1), _p(kps2), _p(d2), len(kps2), _p(b), _p(pm),
+                                            window, nnratio, int(check_ori), _p(m))
+    return m, n, pm
+
+
+# --------------------------------- BA ----------------------------------------
+def ba_solve(K4, poses7, cam_fixed, pts3, obs_cam, obs_pt, obs_uv, obs_w, obs_robust, max_iters,
+             huber_delta=np.sqrt(5.991), fix_points=False, stop=None):
+    K4 = np.ascontiguousarray(K4, np.float64); poses = np.ascontiguousarray(poses7, np.float64).copy()
+    cf = np.ascontiguousarray(cam_fixed, np.uint8); pts = np.ascontiguousarray(pts3, np.float64).copy()
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+    uv = np.ascontiguousarray(obs_uv, np.float64); w = np.ascontiguousarray(obs_w, np.float64)
+    rb = np.ascontiguousarray(obs_robust, np.uint8)
+    o = BaOpts(int(max_iters), float(huber_delta), int(fix_points), _p(stop) if stop is not None else None)
+    s = BaSummary()
+    lib().orc_ba_solve(_p(K4), _p(poses), _p(cf), len(cf), _p(pts), len(pts), _p(oc), _p(op), _p(uv), _p(w), _p(rb),
+                       len(oc), C.byref(o), C.byref(s))
+    return poses, pts, s.as_dict()
+
+
+def pose_optimization(K4, pose7, Xw, uv, inv_sigma2):
+    K4 = np.ascontiguousarray(K4, np.float64); pose = np.ascontiguousarray(pose7, np.float64).copy()
+    Xw = np.ascontiguousarray(Xw, np.float64); uv = np.ascontiguousarray(uv, np.float64)
+    isg = np.ascontiguousarray(inv_sigma2, np.float32)
+    out = np.zeros(len(Xw), np.uint8)
+    s = BaSummary()
+    n = lib().orc_pose_optimization(_p(K4), _p(pose), _p(Xw), _p(uv), _p(isg), len(Xw), _p(out), C.byref(s))
+    return n, pose, out, s.as_dict()
+
+
+def local_ba(K4, poses7, cam_fixed, cam_local, pts3, obs_cam, obs_pt, obs_uv, obs_inv_sigma2, stop=None,
+             duplicate_blocks=True):
+    K4 = np.ascontiguousarray(K4, np.float64); poses = np.ascontiguousarray(poses7, np.float64).copy()
+    cf = np.ascontiguousarray(cam_fixed, np.uint8); cl = np.ascontiguousarray(cam_local, np.uint8)
+    pts = np.ascontiguousarray(pts3, np.float64).copy()
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+    uv = np.ascontiguousarray(obs_uv, np.float64); isg = np.ascontiguousarray(obs_inv_sigma2, np.float32)
+    er = np.zeros(len(oc), np.uint8)
+    s1 = BaSummary(); s2 = BaSummary()
+    rc = lib().orc_local_ba(_p(K4), _p(poses), _p(cf), _p(cl), len(cf), _p(pts), len(pts), _p(oc), _p(op), _p(uv),
+                            _p(isg), len(oc), _p(stop) if stop is not None else None, int(duplicate_blocks), _p(er),
+                            C.byref(s1), C.byref(s2))
+    return rc, poses, pts, er, s1.as_dict(), s2.as_dict()
+
+
+def ba_eval_obs(K4, pose7, X, uv, w, robust=False, huber_delta=np.sqrt(5.991)):
+    K4 = np.ascontiguousarray(K4, np.float64); pose7 = np.ascontiguousarray(pose7, np.float64)
+    X = np.ascontiguousarray(X, np.float64); uv = np.ascontiguousarray(uv, np.float64)
+    r = np.zeros(2); Jc = np.zeros((2, 6)); Jp = np.zeros((2, 3)); rho = C.c_double()
+    lib().orc_ba_eval_obs(_p(K4), _p(pose7), _p(X), _p(uv), float(w), int(robust), float(huber_delta), _p(r), _p(Jc),
+                          _p(Jp), C.byref(rho))
+    return r, Jc, Jp, rho.value
+
+
+def quat_plus(q, d):
+    q = np.ascontiguousarray(q, np.float64); d = np.ascontiguousarray(d, np.float64); o = np.zeros(4)
+    lib().orc_quat_plus(_p(q), _p(d), _p(o))
+    return o
+
+
+def quat_rotate(q, v):
+    q = np.ascontiguousarray(q, np.float64); v = np.ascontiguousarray(v, np.float64); o = np.zeros(3)
+    lib().orc_quat_rotate(_p(q), _p(v), _p(o))
+    return o
