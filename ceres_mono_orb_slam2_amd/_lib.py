@@ -1,0 +1,94 @@
+"""ctypes loader for the in-tree HIP C-ABI library (include/orbslam_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails the product raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liborbslam_hip.so")
+
+# every symbol include/orbslam_hip.h declares (tests check that the library exports them all)
+SYMBOLS = [
+    "orbhip_last_error", "orbhip_device_count", "orbhip_version",
+    "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_tables", "orbx_max_keypoints", "orbx_extract",
+    "orbx_extract_batch_device", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
+    "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
+    "orbm_search_for_initialization",
+    "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
+    "ba_local_bundle_adjustment",
+]
+
+
+class OrbHipError(RuntimeError):
+    pass
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("huber_delta", C.c_double), ("fix_points", C.c_int32),
+                ("stop_flag", C.c_void_p)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int32),
+                ("successful_steps", C.c_int32), ("termination", C.c_int32), ("final_radius", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """Load liborbslam_hip.so (built by __graft_entry__.build()); raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbHipError("HIP library %s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+    L.orbhip_last_error.restype = C.c_char_p
+    L.orbhip_version.restype = C.c_char_p
+    L.orbx_create.argtypes = [i32, f32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.orbx_destroy.argtypes = [vp]
+    L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.orbx_max_keypoints.argtypes = [vp]
+    L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
+    L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, i32, vp, vp, i32, vp, vp]
+    L.orbx_get_level_image.argtypes = [vp, i32, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_get_level_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.orbx_get_level_selected.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.orbm_descriptor_distance.argtypes = [vp, vp]
+    L.orbm_hamming_best2_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.orbm_hamming_best2.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp]
+    L.orbm_match_frames_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, i32, f32, i32, i32, vp, vp, vp]
+    L.orbm_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, i32, vp, C.POINTER(i32)]
+    if hasattr(L, "ba_solve"):
+        L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
+        L.ba_pose_optimization_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+        L.ba_solve.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, C.POINTER(BaOptions),
+                               C.POINTER(BaSummary)]
+        L.ba_check_outlier.argtypes = [vp, vp, vp, vp, f64, f64, vp]
+        L.ba_local_bundle_adjustment.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp,
+                                                 C.POINTER(i32), C.POINTER(BaSummary), C.POINTER(BaSummary)]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().orbhip_last_error().decode("utf-8", "replace")
+        raise OrbHipError("%s failed (code %d): %s" % (what or "HIP call", rc, msg))
+
+
+def ptr(a):
+    """host numpy array or torch tensor -> void*"""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,1039 @@
+// ============================================================================
+// orb_extractor.hip -- MI355X (gfx950) ORB extractor behind the C ABI of
+// include/orbslam_hip.h.  Drop-in for ORB_SLAM2::ORBextractor
+// (reference include/ORBextractor.h:45-111, src/ORBextractor.cc).
+//
+// Pipeline for a batch of B same-sized frames, everything resident in HBM:
+//   k_resize        x (L-1)  level l from level l-1, fixed-point bilinear          (E2, :1107-1132)
+//   k_fast_cells    x 1      one workgroup per ~30x30 cell: FAST-9 score map in LDS,
+//                            3x3 NMS inside the cell, 20 -> 7 threshold fallback,
+//                            ordered (row-major) compaction into the cell's slot   (E3, :789-829)
+//   k_octree        x 1      one workgroup per (frame, level): DistributeOctTree in
+//                            its level-synchronous array form (tests/octree_twin.py) (E4, :539-763)
+//   k_blur7         x 1      separable 7x7 Gaussian, fixed-point taps, reflect-101  (E7, :1085-1086)
+//   k_describe      x 1      one wave per keypoint: intensity-centroid angle on the
+//                            un-blurred level, rotated BRIEF-256 on the blurred one,
+//                            cv::KeyPoint record                                     (E5,E6,E8,E9)
+// All integer stages are bit-exact by construction; the two float stages
+// (fastAtan2, rotated sampling coordinates) use explicit round-to-nearest ops
+// with no FMA contraction so they equal the canonical CPU definition
+// (SURVEY F11 / DESIGN.md).  No CPU fallback exists in this file.
+// ============================================================================
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <new>
+
+#include "common.h"
+#include "orb_pattern_data.h"
+
+namespace orbhip {
+
+static const int PATCH_SIZE = 31, HALF_PATCH = 15, EDGE_THRESHOLD = 19;
+static const int MAX_LEVELS = 16;
+static const int MAX_INI = 64;            // initial octree nodes per level (round(W/H))
+static const int KEYCAP_MAX = 32768;      // dense candidate capacity per (frame, level)
+
+struct LevelDev {
+  int w, h;
+  int pitch;            // bytes per row of the un-blurred level (level 0: the caller's stride)
+  int bpitch;           // bytes per row of the blurred level
+  long long pyr_off;    // byte offset inside one frame's pyramid block (levels >= 1)
+  long long blur_off;   // byte offset inside one frame's blurred block
+  int minBX, minBY, winW, winH;   // detection window origin and size (maxBorder - minBorder)
+  int cell_begin, ncells;
+  int quota;
+  int nIni; float hX;
+  int ini_x[MAX_INI + 1];
+  float scale; float patch;
+  int kcap; int key_off;          // dense key capacity / offset (in keys) inside one frame's key block
+};
+
+struct GeomDev {
+  int nlevels, ncells_total, cell_cap, sel_cap, keys_per_frame;
+  int tile_w, tile_h, tile_pitch;       // FAST LDS tile (max cell incl. apron)
+  int node_cap, max_cells_level;
+  long long pyr_frame_bytes, blur_frame_bytes;
+  LevelDev lv[MAX_LEVELS];
+};
+
+struct CellDesc { short level, x0, y0, x1, y1, offx, offy, pad; };
+struct BlurTile { short level, tx, ty, pad; };
+
+// ---------------------------------------------------------------------------- device helpers
+__device__ __forceinline__ const uint8_t* level_ptr(const GeomDev& G, int l, int f, const uint8_t* img0,
+                                                    long long img_frame_bytes, const uint8_t* pyr) {
+  return l == 0 ? img0 + (long long)f * img_frame_bytes
+                : pyr + (long long)f * G.pyr_frame_bytes + G.lv[l].pyr_off;
+}
+
+// ---------------------------------------------------------------------------- k_resize
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int spitch, long long sframe,
+                                                int sw, int sh, uint8_t* __restrict__ dst, int dpitch,
+                                                long long dframe, int dw, int dh, const int* __restrict__ xofs,
+                                                const short* __restrict__ ialpha, const int* __restrict__ yofs,
+                                                const short* __restrict__ ibeta) {
+  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  if (x4 >= dw || y >= dh) return;
+  int sy = yofs[y];
+  int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+  const uint8_t* S0 = src + (long long)f * sframe + (long long)sy0 * spitch;
+  const uint8_t* S1 = src + (long long)f * sframe + (long long)sy1 * spitch;
+  const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+  uint32_t out = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int dx = x4 + j;
+    if (dx < dw) {
+      int sx = xofs[dx];
+      int sx1 = min(sx + 1, sw - 1);
+      int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+      int H0 = S0[sx] * a0 + S0[sx1] * a1;
+      int H1 = S1[sx] * a0 + S1[sx1] * a1;
+      int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 255) << (8 * j);
+    }
+  }
+  *(uint32_t*)(dst + (long long)f * dframe + (long long)y * dpitch + x4) = out;
+}
+
+// ---------------------------------------------------------------------------- k_fast_cells
+// max over the sixteen 9-arcs of min over the arc of d[k]  (sliding-window min by doubling)
+__device__ __forceinline__ int arc9_maxmin(const int d[16]) {
+  int m2[16], m4[16], m8[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+  int best = -1000;
+#pragma unroll
+  for (int k = 0; k < 16; k++) best = max(best, min(m8[k], d[(k + 8) & 15]));
+  return best;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(GeomDev G, const CellDesc* __restrict__ cells,
+                                                    const uint8_t* __restrict__ img0, long long img_frame_bytes,
+                                                    const uint8_t* __restrict__ pyr, int* __restrict__ cell_cnt,
+                                                    uint32_t* __restrict__ cell_kps, int iniTh, int minTh) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int TP = G.tile_pitch;
+  uint8_t* tile = smem;                               // [tile_h][TP]
+  uint8_t* score = smem + (size_t)G.tile_h * TP;      // [tile_h][TP]
+  uint8_t* flag = score + (size_t)G.tile_h * TP;      // [tile_h][TP]
+  __shared__ int s_n20, s_wcnt[4], s_base;
+  const int tid = threadIdx.x;
+  const int ci = blockIdx.x, f = blockIdx.y;
+  const CellDesc c = cells[ci];
+  const LevelDev& L = G.lv[c.level];
+  const uint8_t* src = level_ptr(G, c.level, f, img0, img_frame_bytes, pyr);
+  const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
+  if (tid == 0) { s_n20 = 0; s_base = 0; }
+  // ---- stage the cell (incl. its 3-px apron) in LDS ----------------------------------------
+  for (int i = tid; i < tw * th; i += 256) {
+    int y = i / tw, x = i - y * tw;
+    tile[y * TP + x] = src[(long long)(c.y0 + y) * L.pitch + c.x0 + x];
+    score[y * TP + x] = 0;
+    flag[y * TP + x] = 0;
+  }
+  __syncthreads();
+  const int iw = tw - 6, ih = th - 6;
+  const int npx = (iw > 0 && ih > 0) ? iw * ih : 0;
+  // ---- FAST-9 score at the LOW threshold; one map serves both thresholds --------
+  for (int i = tid; i < npx; i += 256) {
+    int iy = i / iw, ix = i - iy * iw;
+    const uint8_t* p = tile + (iy + 3) * TP + ix + 3;
+    const int v = p[0];
+    // compass pre-test: any 9-arc contains >= 2 adjacent compass points
+    int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
+    int hi = v + minTh, lo = v - minTh;
+    int nb = (c0 > hi) + (c4 > hi) + (c8 > hi) + (c12 > hi);
+    int nd = (c0 < lo) + (c4 < lo) + (c8 < lo) + (c12 < lo);
+    if (nb < 2 && nd < 2) continue;
+    int d[16], e[16];
+    d[0] = v - p[3 * TP];       d[1] = v - p[3 * TP + 1];  d[2] = v - p[2 * TP + 2];  d[3] = v - p[TP + 3];
+    d[4] = v - p[3];            d[5] = v - p[-TP + 3];     d[6] = v - p[-2 * TP + 2]; d[7] = v - p[-3 * TP + 1];
+    d[8] = v - p[-3 * TP];      d[9] = v - p[-3 * TP - 1]; d[10] = v - p[-2 * TP - 2]; d[11] = v - p[-TP - 3];
+    d[12] = v - p[-3];          d[13] = v - p[TP - 3];     d[14] = v - p[2 * TP - 2]; d[15] = v - p[3 * TP - 1];
+#pragma unroll
+    for (int k = 0; k < 16; k++) e[k] = -d[k];
+    int best = max(arc9_maxmin(d), arc9_maxmin(e));   // corner at t  <=>  best > t ; score = best - 1
+    if (best > minTh) score[(iy + 3) * TP + ix + 3] = (uint8_t)(best - 1);
+  }
+  __syncthreads();
+  // ---- 3x3 non-max suppression inside the cell (frame pixels score 0) -----------------------
+  int my20 = 0;
+  for (int i = tid; i < npx; i += 256) {
+    int iy = i / iw, ix = i - iy * iw;
+    const uint8_t* s = score + (iy + 3) * TP + ix + 3;
+    int v = s[0];
+    if (v == 0) continue;
+    bool keep = v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] && v > s[-1] && v > s[1] && v > s[TP - 1] &&
+                v > s[TP] && v > s[TP + 1];
+    if (keep) {
+      int is20 = v >= iniTh;
+      flag[(iy + 3) * TP + ix + 3] = (uint8_t)(1 + is20);
+      my20 += is20;
+    }
+  }
+  if (my20) atomicAdd(&s_n20, my20);
+  __syncthreads();
+  // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816) -----------------
+  const int want_min = (s_n20 > 0) ? 2 : 1;
+  uint32_t* out = cell_kps + ((long long)f * G.ncells_total + ci) * G.cell_cap;
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int base_i = 0; base_i < npx; base_i += 256) {
+    int i = base_i + tid;
+    bool emit = false;
+    int iy = 0, ix = 0;
+    if (i < npx) {
+      iy = i / iw; ix = i - iy * iw;
+      emit = flag[(iy + 3) * TP + ix + 3] >= want_min;
+    }
+    unsigned long long bal = __ballot(emit);
+    if (lane == 0) s_wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { int cnum = s_wcnt[k]; if (k < wv) woff += cnum; tot += cnum; }
+    int base = s_base;
+    if (emit) {
+      int pos = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+      if (pos < G.cell_cap) {
+        uint32_t x = (uint32_t)(ix + 3 + c.offx), y = (uint32_t)(iy + 3 + c.offy);
+        out[pos] = x | (y << 12) | ((uint32_t)score[(iy + 3) * TP + ix + 3] << 24);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_base = base + tot;
+    __syncthreads();
+  }
+  if (tid == 0) cell_cnt[(long long)f * G.ncells_total + ci] = s_base;
+}
+
+// ---------------------------------------------------------------------------- k_octree
+// exclusive scan of a[0..n) in place by a 256-thread block; returns the total.
+__device__ int block_excl_scan(int* a, int n, int* s_tmp) {
+  const int tid = threadIdx.x;
+  const int items = (n + 255) >> 8;
+  const int beg = min(tid * items, n), end = min(beg + items, n);
+  int sum = 0;
+  for (int i = beg; i < end; i++) sum += a[i];
+  const int lane = tid & 63, w = tid >> 6;
+  int v = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v += t; }
+  if (lane == 63) s_tmp[w] = v;
+  __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { int t = s_tmp[i]; if (i < w) woff += t; total += t; }
+  int run = woff + v - sum;
+  for (int i = beg; i < end; i++) { int t = a[i]; a[i] = run; run += t; }
+  __syncthreads();
+  return total;
+}
+
+struct __attribute__((aligned(8))) Rect16 { short ulx, uly, urx, bry; };
+
+__device__ __forceinline__ int quad_of(const Rect16& r, int x, int y, int& mx, int& my) {
+  mx = r.ulx + ((r.urx - r.ulx + 1) >> 1);     // UL.x + ceil((UR.x-UL.x)/2)   (src/ORBextractor.cc:483-484)
+  my = r.uly + ((r.bry - r.uly + 1) >> 1);
+  return (x < mx ? 0 : 1) + (y < my ? 0 : 2);  // n1=UL n2=UR n3=BL n4=BR        (:515-525)
+}
+
+__global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
+                                                const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
+                                                unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
+                                                int* __restrict__ sel_cnt, int* __restrict__ nkeys_out,
+                                                int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const LevelDev& Lv = G.lv[level];
+  const int NC = G.node_cap, N = Lv.quota;
+  // ---- LDS carve (all offsets multiples of 8) -------------------------------------------------
+  Rect16* rect[2];
+  rect[0] = (Rect16*)smem;
+  rect[1] = rect[0] + NC;
+  uint2* cc = (uint2*)(rect[1] + NC);                 // 4 x u16 child counts (packed)
+  uint2* childpos = cc + NC;                          // 4 x u16 new positions (or .x = shifted position)
+  int* sA = (int*)(childpos + NC);
+  int* sB = sA + NC;
+  int* s_pref = sB + NC;                              // [max_cells_level + 1]
+  unsigned short* cnt[2];
+  cnt[0] = (unsigned short*)(s_pref + G.max_cells_level + 8);
+  cnt[1] = cnt[0] + NC;
+  unsigned short* order = cnt[1] + NC;
+  unsigned short* candl = order + NC;
+  short* rankOf = (short*)(candl + NC);
+  __shared__ int s_tmp[8], s_m, s_nexp, s_L;
+
+  uint32_t* K = keys + (long long)f * G.keys_per_frame + Lv.key_off;
+  unsigned short* KN = knode + (long long)f * G.keys_per_frame + Lv.key_off;
+  const int* ccnt = cell_cnt + (long long)f * G.ncells_total + Lv.cell_begin;
+  const uint32_t* ckps = cell_kps + ((long long)f * G.ncells_total + Lv.cell_begin) * G.cell_cap;
+  uint32_t* SEL = sel + ((long long)f * G.nlevels + level) * G.sel_cap;
+
+  // ---- 0. gather the level's candidates in reference order (cells row-major, pixels row-major) --
+  const int ncell = Lv.ncells;
+  for (int c = tid; c < ncell; c += 256) s_pref[c] = ccnt[c];
+  __syncthreads();
+  const int n = block_excl_scan(s_pref, ncell, s_tmp);
+  if (tid == 0) { s_pref[ncell] = n; nkeys_out[f * G.nlevels + level] = n; }
+  if (n > Lv.kcap) {
+    if (tid == 0) { sel_cnt[f * G.nlevels + level] = 0; atomicOr(&status[f], 1); }
+    return;
+  }
+  __syncthreads();
+  const int nIni = Lv.nIni;
+  for (int i = tid; i < NC; i += 256) { cnt[0][i] = 0; cnt[1][i] = 0; }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    int lo = 0, hi = ncell;                       // largest c with pref[c] <= k
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_pref[mid] <= k) lo = mid; else hi = mid; }
+    uint32_t key = ckps[(long long)lo * G.cell_cap + (k - s_pref[lo])];
+    K[k] = key;
+    int x = key & 0xFFF;
+    int idx = (int)__fdiv_rn((float)x, Lv.hX);     // vpIniNodes[kp.pt.x/hX]   (src/ORBextractor.cc:569)
+    idx = min(idx, nIni - 1);
+    KN[k] = (unsigned short)idx;
+  }
+  // initial node histogram (nIni <= 64): LDS int atomics on sB
+  for (int i = tid; i < MAX_INI; i += 256) sB[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) atomicAdd(&sB[KN[k]], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int L0 = 0;
+    for (int i = 0; i < nIni; i++) {
+      int c = sB[i];
+      sA[i] = L0;                                  // remap (valid where c > 0)
+      if (c > 0) {
+        Rect16 r; r.ulx = (short)Lv.ini_x[i]; r.uly = 0; r.urx = (short)Lv.ini_x[i + 1]; r.bry = (short)Lv.winH;
+        rect[0][L0] = r; cnt[0][L0] = (unsigned short)c; L0++;
+      }
+    }
+    s_L = L0;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) KN[k] = (unsigned short)sA[KN[k]];
+  __syncthreads();
+
+  int cur = 0;
+  int L = s_L;
+  bool final_phase = false;
+  while (true) {
+    const int prev = L;
+    const Rect16* R = rect[cur];
+    const unsigned short* C = cnt[cur];
+    // ---- A: candidates = nodes holding > 1 key, in list order ---------------------------------
+    for (int p = tid; p < L; p += 256) { sA[p] = C[p] > 1; cc[p] = make_uint2(0, 0); rankOf[p] = -1; }
+    if (tid == 0) { s_m = -1; s_nexp = 0; }
+    __syncthreads();
+    const int ncand = block_excl_scan(sA, L, s_tmp);
+    if (ncand == 0) break;                         // no split possible: |L| == prevSize  (:669)
+    for (int p = tid; p < L; p += 256) if (C[p] > 1) candl[sA[p]] = (unsigned short)p;
+    // ---- B: child occupancy of every candidate -------------------------------------------------
+    for (int k = tid; k < n; k += 256) {
+      int p = KN[k];
+      if (C[p] > 1) {
+        uint32_t key = K[k];
+        int mx, my;
+        int q = quad_of(R[p], key & 0xFFF, (key >> 12) & 0xFFF, mx, my);
+        atomicAdd((q & 2) ? &cc[p].y : &cc[p].x, (q & 1) ? 0x10000u : 1u);
+      }
+    }
+    __syncthreads();
+    // ---- C: processing order and how many candidates get split ---------------------------------
+    int m = ncand;
+    if (!final_phase) {
+      for (int r = tid; r < ncand; r += 256) order[r] = candl[r];
+    } else {
+      // sort by (count desc, list position asc): list position asc == creation desc (canonical F9)
+      for (int i = tid; i < ncand; i += 256) {
+        int p = candl[i], cp = C[p], r = 0;
+        for (int j = 0; j < ncand; j++) { int pj = candl[j], cj = C[pj]; r += (cj > cp) || (cj == cp && pj < p); }
+        order[r] = (unsigned short)p;
+      }
+      __syncthreads();
+      for (int r = tid; r < ncand; r += 256) {
+        uint2 v = cc[order[r]];
+        sA[r] = ((v.x & 0xFFFF) != 0) + ((v.x >> 16) != 0) + ((v.y & 0xFFFF) != 0) + ((v.y >> 16) != 0) - 1;
+        sB[r] = sA[r];
+      }
+      __syncthreads();
+      block_excl_scan(sA, ncand, s_tmp);
+      for (int r = tid; r < ncand; r += 256) {
+        int before = L + sA[r], after = before + sB[r];
+        if (after >= N && before < N) s_m = r + 1;       // first split that reaches |L| >= N  (:730-731)
+      }
+      __syncthreads();
+      if (s_m >= 0) m = s_m;
+    }
+    __syncthreads();
+    // ---- D/E/F: ranks, creation bases (rank order), split prefix (list order) -------------------
+    for (int r = tid; r < m; r += 256) {
+      int p = order[r];
+      rankOf[p] = (short)r;
+      uint2 v = cc[p];
+      sA[r] = ((v.x & 0xFFFF) != 0) + ((v.x >> 16) != 0) + ((v.y & 0xFFFF) != 0) + ((v.y >> 16) != 0);
+    }
+    __syncthreads();
+    const int TC = block_excl_scan(sA, m, s_tmp);          // sA[r] = creation index of r's first child
+    for (int p = tid; p < L; p += 256) sB[p] = rankOf[p] >= 0;
+    __syncthreads();
+    block_excl_scan(sB, L, s_tmp);                         // sB[p] = #split nodes before p
+    // ---- G: new list = reverse(children in creation order) ++ (old list minus split nodes) -------
+    Rect16* Rn = rect[cur ^ 1];
+    unsigned short* Cn = cnt[cur ^ 1];
+    int nexp = 0;
+    for (int p = tid; p < L; p += 256) {
+      int r = rankOf[p];
+      if (r >= 0) {
+        Rect16 rc = R[p];
+        int mx, my; quad_of(rc, 0, 0, mx, my);
+        uint2 v = cc[p];
+        int c4[4] = {(int)(v.x & 0xFFFF), (int)(v.x >> 16), (int)(v.y & 0xFFFF), (int)(v.y >> 16)};
+        int e = sA[r];
+        unsigned short pos4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (c4[q] > 0) {
+            int pos = TC - 1 - e; e++;
+            Rect16 ch;
+            ch.ulx = (q & 1) ? (short)mx : rc.ulx; ch.urx = (q & 1) ? rc.urx : (short)mx;
+            ch.uly = (q & 2) ? (short)my : rc.uly; ch.bry = (q & 2) ? rc.bry : (short)my;
+            Rn[pos] = ch; Cn[pos] = (unsigned short)c4[q];
+            pos4[q] = (unsigned short)pos;
+            nexp += c4[q] > 1;
+          }
+        }
+        childpos[p] = make_uint2(pos4[0] | ((uint32_t)pos4[1] << 16), pos4[2] | ((uint32_t)pos4[3] << 16));
+      } else {
+        int pos = TC + p - sB[p];
+        Rn[pos] = R[p]; Cn[pos] = C[p];
+        childpos[p] = make_uint2((uint32_t)pos, 0);
+      }
+    }
+    if (nexp) atomicAdd(&s_nexp, nexp);
+    __syncthreads();
+    // ---- H: move the keys -----------------------------------------------------------------------
+    for (int k = tid; k < n; k += 256) {
+      int p = KN[k];
+      uint2 cp = childpos[p];
+      if (rankOf[p] >= 0) {
+        uint32_t key = K[k];
+        int mx, my;
+        int q = quad_of(R[p], key & 0xFFF, (key >> 12) & 0xFFF, mx, my);
+        uint32_t wv = (q & 2) ? cp.y : cp.x;
+        KN[k] = (unsigned short)((q & 1) ? (wv >> 16) : (wv & 0xFFFF));
+      } else {
+        KN[k] = (unsigned short)cp.x;
+      }
+    }
+    L = TC + L - m;
+    const int nToExpand = s_nexp;
+    cur ^= 1;
+    __syncthreads();
+    if (L >= N || L == prev) break;                              // (:669-672, :734-735)
+    if (!final_phase && L + 3 * nToExpand > N) final_phase = true;   // (:673)
+  }
+  __syncthreads();
+  // ---- best key of every node: max response, earliest candidate on ties (:741-760) ---------------
+  unsigned int* best = (unsigned int*)sA;
+  for (int p = tid; p < L; p += 256) best[p] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) atomicMax(&best[KN[k]], ((K[k] >> 24) << 24) | (0xFFFFFFu - (unsigned)k));
+  __syncthreads();
+  for (int p = tid; p < L; p += 256) {
+    if (p < G.sel_cap) SEL[p] = K[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
+  }
+  if (tid == 0) {
+    sel_cnt[f * G.nlevels + level] = L;
+    if (L > G.sel_cap) atomicOr(&status[f], 2);
+  }
+}
+
+// ---------------------------------------------------------------------------- k_blur7
+#define BLUR_TW 128
+#define BLUR_TH 16
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
+  return i;
+}
+__global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __restrict__ tiles,
+                                               const uint8_t* __restrict__ img0, long long img_frame_bytes,
+                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+  __shared__ uint8_t s_src[BLUR_TH + 6][BLUR_TW + 8];
+  __shared__ unsigned short s_mid[BLUR_TH + 6][BLUR_TW];
+  const BlurTile t = tiles[blockIdx.x];
+  const int f = blockIdx.y, tid = threadIdx.x;
+  const LevelDev& L = G.lv[t.level];
+  const uint8_t* src = level_ptr(G, t.level, f, img0, img_frame_bytes, pyr);
+  uint8_t* dst = blur + (long long)f * G.blur_frame_bytes + L.blur_off;
+  const int x0 = t.tx * BLUR_TW, y0 = t.ty * BLUR_TH;
+  for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
+    int yy = i / (BLUR_TW + 6), xx = i - yy * (BLUR_TW + 6);
+    int sy = reflect101(y0 + yy - 3, L.h), sx = reflect101(x0 + xx - 3, L.w);
+    s_src[yy][xx] = src[(long long)sy * L.pitch + sx];
+  }
+  __syncthreads();
+  // taps cvRound(g*256) = {18,34,49,55,49,34,18}; row pass fits 16 bits (255*257)
+  for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
+    int yy = i / BLUR_TW, xx = i - yy * BLUR_TW;
+    const uint8_t* p = &s_src[yy][xx];
+    int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+    s_mid[yy][xx] = (unsigned short)s;
+  }
+  __syncthreads();
+  for (int i = tid; i < BLUR_TH * (BLUR_TW / 4); i += 256) {
+    int yy = i / (BLUR_TW / 4), x4 = (i - yy * (BLUR_TW / 4)) * 4;
+    int y = y0 + yy;
+    if (y >= L.h || x0 + x4 >= L.w) continue;
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int xx = x4 + j;
+      int s = 18 * (s_mid[yy][xx] + s_mid[yy + 6][xx]) + 34 * (s_mid[yy + 1][xx] + s_mid[yy + 5][xx]) +
+              49 * (s_mid[yy + 2][xx] + s_mid[yy + 4][xx]) + 55 * s_mid[yy + 3][xx];
+      int v = (s + (1 << 15)) >> 16;
+      v = v > 255 ? 255 : v;
+      out |= (uint32_t)v << (8 * j);
+    }
+    *(uint32_t*)(dst + (long long)y * L.bpitch + x0 + x4) = out;     // bpitch is a multiple of 4 >= w
+  }
+}
+
+// ---------------------------------------------------------------------------- k_describe
+__constant__ signed char c_pattern[1024];
+__constant__ int c_umax[16];
+
+// cv::fastAtan2 (degrees), scalar OpenCV 2.4/3.x form, un-contracted
+__device__ __forceinline__ float fast_atan2_deg(float y, float x, float p1, float p3, float p5, float p7) {
+  const float eps = 2.2204460492503131e-16f;
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  } else {
+    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+  }
+  if (x < 0) a = __fsub_rn(180.f, a);
+  if (y < 0) a = __fsub_rn(360.f, a);
+  return a;
+}
+
+// canonical deterministic sin/cos in double (identical operation order to oracle det_sincos)
+__device__ __forceinline__ void det_sincos(double x, double* s_out, double* c_out) {
+  const double TWO_OVER_PI = 6.36619772367581382433e-01;
+  const double PIO2_HI = 1.57079632673412561417e+00;
+  const double PIO2_LO = 6.07710050650619224932e-11;
+  double kd = rint(__dmul_rn(x, TWO_OVER_PI));
+  int k = (int)kd;
+  double r = __dsub_rn(__dsub_rn(x, __dmul_rn(kd, PIO2_HI)), __dmul_rn(kd, PIO2_LO));
+  double z = __dmul_rn(r, r);
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double ps = __dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(S6, z), S5), z), S4), z), S3), z), S2), z), S1);
+  double sn = __dadd_rn(r, __dmul_rn(__dmul_rn(r, z), ps));
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double pc = __dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(C6, z), C5), z), C4), z), C3), z), C2), z), C1);
+  double cs = __dadd_rn(__dsub_rn(1.0, __dmul_rn(0.5, z)), __dmul_rn(__dmul_rn(z, z), pc));
+  switch (k & 3) {
+    case 0: *s_out = sn; *c_out = cs; break;
+    case 1: *s_out = cs; *c_out = -sn; break;
+    case 2: *s_out = -sn; *c_out = -cs; break;
+    default: *s_out = -cs; *c_out = sn; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_describe(GeomDev G, const uint32_t* __restrict__ sel,
+                                                  const int* __restrict__ sel_cnt, const int* __restrict__ status,
+                                                  const uint8_t* __restrict__ img0, long long img_frame_bytes,
+                                                  const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                  orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                  int cap, int* __restrict__ counts, float p1, float p3, float p5,
+                                                  float p7, float factorPI) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);      // keypoint index inside the frame
+  // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104)
+  int total = 0, level = -1, pos = 0;
+  for (int l = 0; l < G.nlevels; l++) {
+    int c = min(sel_cnt[f * G.nlevels + l], G.sel_cap);
+    if (level < 0 && i < total + c) { level = l; pos = i - total; }
+    total += c;
+  }
+  const bool bad = status[f] != 0 || total > cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[f] = bad ? (status[f] != 0 ? -1 : -2) : total;
+  if (bad || level < 0) return;
+  const LevelDev& L = G.lv[level];
+  const uint32_t key = sel[((long long)f * G.nlevels + level) * G.sel_cap + pos];
+  const int cx = (int)(key & 0xFFF) + L.minBX, cy = (int)((key >> 12) & 0xFFF) + L.minBY;
+  const int resp = (int)(key >> 24);
+  // ---- IC_Angle on the un-blurred level (src/ORBextractor.cc:77-104) ---------------------------
+  const uint8_t* img = level_ptr(G, level, f, img0, img_frame_bytes, pyr);
+  int m10 = 0, m01 = 0;
+  if (lane < 31) {
+    int v = lane - 15;
+    int d = c_umax[v < 0 ? -v : v];
+    const uint8_t* row = img + (long long)(cy + v) * L.pitch + cx;
+    int rs = 0;
+    for (int u = -d; u <= d; u++) { int val = row[u]; rs += val; m10 += u * val; }
+    m01 = v * rs;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+  const float angle = fast_atan2_deg((float)m01, (float)m10, p1, p3, p5, p7);
+  // ---- rotated BRIEF-256 on the blurred level (src/ORBextractor.cc:107-147) ---------------------
+  const float ang_rad = __fmul_rn(angle, factorPI);
+  double sd, cd;
+  det_sincos((double)ang_rad, &sd, &cd);
+  const float a = (float)cd, b = (float)sd;
+  const uint8_t* bimg = blur + (long long)f * G.blur_frame_bytes + L.blur_off + (long long)cy * L.bpitch + cx;
+  uint32_t nib = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int pr = lane * 4 + j;                          // pair index 0..255: bit (pr & 7) of byte (pr >> 3)
+    int t[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      float px = (float)c_pattern[4 * pr + 2 * s], py = (float)c_pattern[4 * pr + 2 * s + 1];
+      float fy = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
+      float fx = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
+      int iy = __float2int_rn(fy), ix = __float2int_rn(fx);
+      t[s] = bimg[(long long)iy * L.bpitch + ix];
+    }
+    nib |= (uint32_t)(t[0] < t[1]) << j;
+  }
+  // lane 2k holds the low nibble, lane 2k+1 the high nibble of byte k
+  uint32_t byte = nib | (__shfl_down(nib, 1) << 4);            // valid on even lanes
+  uint32_t half = byte | (__shfl_down(byte, 2) << 8);          // lanes = 0 mod 4
+  uint32_t word = half | (__shfl_down(half, 4) << 16);         // lanes = 0 mod 8: bytes (lane/2 .. lane/2+3)
+  if ((lane & 7) == 0) *(uint32_t*)(desc + ((long long)f * cap + i) * 32 + (lane >> 1)) = word;
+  if (lane == 0) {
+    orbx_keypoint kp;
+    kp.x = (float)cx; kp.y = (float)cy;
+    if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }   // (:1095-1101)
+    kp.size = L.patch; kp.angle = angle; kp.response = (float)resp; kp.octave = level; kp.class_id = -1;
+    kps[(long long)f * cap + i] = kp;
+  }
+}
+
+// ============================================================================ host side
+inline int cv_round(double v) { return (int)std::nearbyint(v); }
+
+}  // namespace orbhip
+
+using namespace orbhip;
+
+struct orbx_ctx {
+  int nfeatures, nlevels, iniTh, minTh, device;
+  double scaleFactor;
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> quota, umax;
+  float atan_p[4], factorPI;
+  // shape-dependent state
+  int w = 0, h = 0, stride = 0, nframes = 0;
+  GeomDev G;
+  std::vector<CellDesc> cells;
+  std::vector<BlurTile> btiles;
+  DevBuf d_cells, d_btiles, d_tab;      // tables
+  std::vector<size_t> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // byte offsets into d_tab per level
+  DevBuf d_pyr, d_blur, d_cellcnt, d_cellkps, d_keys, d_knode, d_sel, d_selcnt, d_nkeys, d_status;
+  DevBuf d_img, d_kps, d_desc, d_counts;   // host-API staging
+  size_t fast_lds = 0, octree_lds = 0;
+  // last call (for introspection)
+  const uint8_t* last_img0 = nullptr; long long last_img_frame_bytes = 0; int last_nframes = 0;
+  bool const_uploaded = false;
+};
+
+static int build_tables(orbx_ctx* c) {
+  const int nl = c->nlevels;
+  c->scale.resize(nl); c->sigma2.resize(nl); c->inv_scale.resize(nl); c->inv_sigma2.resize(nl);
+  c->scale[0] = 1.0f; c->sigma2[0] = 1.0f;
+  for (int i = 1; i < nl; i++) {
+    c->scale[i] = (float)(c->scale[i - 1] * c->scaleFactor);        // src/ORBextractor.cc:421
+    c->sigma2[i] = c->scale[i] * c->scale[i];
+  }
+  for (int i = 0; i < nl; i++) { c->inv_scale[i] = 1.0f / c->scale[i]; c->inv_sigma2[i] = 1.0f / c->sigma2[i]; }
+  c->quota.resize(nl);
+  float factor = (float)(1.0f / c->scaleFactor);
+  float nDesired = c->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; l++) { c->quota[l] = cv_round(nDesired); sum += c->quota[l]; nDesired *= factor; }
+  c->quota[nl - 1] = std::max(c->nfeatures - sum, 0);
+  c->umax.assign(HALF_PATCH + 1, 0);
+  int v, v0, vmax = (int)std::floor(HALF_PATCH * std::sqrt(2.f) / 2 + 1);
+  int vmin = (int)std::ceil(HALF_PATCH * std::sqrt(2.f) / 2);
+  const double hp2 = HALF_PATCH * HALF_PATCH;
+  for (v = 0; v <= vmax; ++v) c->umax[v] = cv_round(std::sqrt(hp2 - v * v));
+  for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+    while (c->umax[v0] == c->umax[v0 + 1]) ++v0;
+    c->umax[v] = v0;
+    ++v0;
+  }
+  const float k = (float)(180.0 / 3.14159265358979323846);
+  c->atan_p[0] = 0.9997878412794807f * k; c->atan_p[1] = -0.3258083974640975f * k;
+  c->atan_p[2] = 0.1555786518463281f * k; c->atan_p[3] = -0.04432655554792128f * k;
+  c->factorPI = (float)(3.14159265358979323846 / 180.f);
+  return 0;
+}
+
+// (re)build geometry + workspace for a batch of nframes images of w x h (row stride `stride`)
+static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
+  const bool same_shape = (c->w == w && c->h == h && c->stride == stride);
+  if (same_shape && nframes <= c->nframes) return 0;
+  ORBHIP_REQUIRE(w >= 2 * EDGE_THRESHOLD + 8 && h >= 2 * EDGE_THRESHOLD + 8, ORBHIP_EINVAL, "image too small");
+  ORBHIP_REQUIRE(w <= 4095 && h <= 4095, ORBHIP_EINVAL, "image larger than 4095 px per side");
+  const int nl = c->nlevels;
+  GeomDev& G = c->G;
+  if (!same_shape) {
+    std::memset(&G, 0, sizeof(G));
+    G.nlevels = nl;
+    c->cells.clear(); c->btiles.clear();
+    long long pyr_off = 0, blur_off = 0;
+    int key_off = 0, tile_w = 8, tile_h = 8, cell_cap = 1, max_cells = 1, node_cap = MAX_INI + 8, sel_cap = 8;
+    std::vector<uint8_t> tab;
+    c->tab_xofs.assign(nl, 0); c->tab_ialpha.assign(nl, 0); c->tab_yofs.assign(nl, 0); c->tab_ibeta.assign(nl, 0);
+    for (int l = 0; l < nl; l++) {
+      LevelDev& L = G.lv[l];
+      float s = c->inv_scale[l];
+      L.w = cv_round((float)w * s); L.h = cv_round((float)h * s);      // src/ORBextractor.cc:1112
+      ORBHIP_REQUIRE(L.w >= 1 && L.h >= 1, ORBHIP_EINVAL, "image too small for the requested number of pyramid levels");
+      L.pitch = (l == 0) ? stride : round_up(L.w, 64);
+      L.bpitch = round_up(L.w, 64);
+      L.pyr_off = pyr_off; if (l > 0) pyr_off += (long long)L.pitch * L.h;
+      L.blur_off = blur_off; blur_off += (long long)L.bpitch * L.h;
+      L.scale = c->scale[l];
+      L.patch = (float)(int)(PATCH_SIZE * c->scale[l]);                 // :837
+      L.quota = c->quota[l];
+      // detection window and cell grid (:773-787)
+      const int minBX = EDGE_THRESHOLD - 3, minBY = minBX;
+      const int maxBX = L.w - EDGE_THRESHOLD + 3, maxBY = L.h - EDGE_THRESHOLD + 3;
+      L.minBX = minBX; L.minBY = minBY; L.winW = maxBX - minBX; L.winH = maxBY - minBY;
+      const float W = 30;
+      const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+      const int nCols = (int)(width / W), nRows = (int)(height / W);
+      L.cell_begin = (int)c->cells.size();
+      if (nCols >= 1 && nRows >= 1) {
+        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+        for (int i = 0; i < nRows; i++) {
+          const float iniY = (float)(minBY + i * hCell);
+          float maxY = iniY + hCell + 6;
+          if (iniY >= maxBY - 3) continue;
+          if (maxY > maxBY) maxY = (float)maxBY;
+          for (int j = 0; j < nCols; j++) {
+            const float iniX = (float)(minBX + j * wCell);
+            float maxX = iniX + wCell + 6;
+            if (iniX >= maxBX - 6) continue;
+            if (maxX > maxBX) maxX = (float)maxBX;
+            CellDesc cd;
+            cd.level = (short)l; cd.x0 = (short)iniX; cd.y0 = (short)iniY; cd.x1 = (short)maxX; cd.y1 = (short)maxY;
+            cd.offx = (short)(j * wCell); cd.offy = (short)(i * hCell); cd.pad = 0;
+            c->cells.push_back(cd);
+            int tw = cd.x1 - cd.x0, th = cd.y1 - cd.y0;
+            tile_w = std::max(tile_w, tw); tile_h = std::max(tile_h, th);
+            int iw = std::max(tw - 6, 0), ih = std::max(th - 6, 0);
+            cell_cap = std::max(cell_cap, ((iw + 1) / 2) * ((ih + 1) / 2));
+          }
+        }
+      }
+      L.ncells = (int)c->cells.size() - L.cell_begin;
+      max_cells = std::max(max_cells, L.ncells);
+      // octree initial nodes (:543-563)
+      // (levels too small to hold a cell produce no candidates; the reference divides by zero there)
+      int nIni = (L.ncells > 0) ? (int)std::round(static_cast<float>(L.winW) / L.winH) : 1;
+      if (nIni < 1) nIni = 1;
+      ORBHIP_REQUIRE(nIni <= MAX_INI, ORBHIP_EINVAL, "aspect ratio too extreme (more than 64 initial octree nodes)");
+      L.nIni = nIni;
+      L.hX = (L.ncells > 0) ? static_cast<float>(L.winW) / nIni : 1.0f;
+      for (int i = 0; i <= nIni; i++) L.ini_x[i] = (int)(L.hX * static_cast<float>(i));
+      node_cap = std::max(node_cap, std::max(L.quota + 8, 4 * nIni + 8));
+      sel_cap = std::max(sel_cap, L.quota + 4);
+      long long theo = (long long)L.ncells * cell_cap;
+      L.kcap = (int)std::min<long long>(std::max<long long>(theo, 64), KEYCAP_MAX);
+      L.key_off = key_off; key_off += round_up(L.kcap, 4);
+      // resize tables: level l from level l-1
+      if (l > 0) {
+        const int sw = G.lv[l - 1].w, sh = G.lv[l - 1].h, dw = L.w, dh = L.h;
+        double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+        double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+        std::vector<int> xofs(dw), yofs(dh);
+        std::vector<short> ia(2 * dw), ib(2 * dh);
+        auto sat = [](int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); };
+        for (int dx = 0; dx < dw; dx++) {
+          float fx = (float)((dx + 0.5) * scale_x - 0.5);
+          int sx = (int)std::floor(fx);
+          fx -= sx;
+          if (sx < 0) { fx = 0; sx = 0; }
+          if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+          xofs[dx] = sx;
+          ia[2 * dx] = sat(cv_round((1.f - fx) * 2048)); ia[2 * dx + 1] = sat(cv_round(fx * 2048));
+        }
+        for (int dy = 0; dy < dh; dy++) {
+          float fy = (float)((dy + 0.5) * scale_y - 0.5);
+          int sy = (int)std::floor(fy);
+          fy -= sy;
+          yofs[dy] = sy;
+          ib[2 * dy] = sat(cv_round((1.f - fy) * 2048)); ib[2 * dy + 1] = sat(cv_round(fy * 2048));
+        }
+        auto push = [&](const void* p, size_t bytes) {
+          size_t off = (tab.size() + 15) / 16 * 16;
+          tab.resize(off + bytes);
+          std::memcpy(tab.data() + off, p, bytes);
+          return off;
+        };
+        c->tab_xofs[l] = push(xofs.data(), xofs.size() * 4);
+        c->tab_ialpha[l] = push(ia.data(), ia.size() * 2);
+        c->tab_yofs[l] = push(yofs.data(), yofs.size() * 4);
+        c->tab_ibeta[l] = push(ib.data(), ib.size() * 2);
+      }
+      // blur tiles
+      for (int ty = 0; ty < (L.h + BLUR_TH - 1) / BLUR_TH; ty++)
+        for (int tx = 0; tx < (L.w + BLUR_TW - 1) / BLUR_TW; tx++) {
+          BlurTile bt; bt.level = (short)l; bt.tx = (short)tx; bt.ty = (short)ty; bt.pad = 0;
+          c->btiles.push_back(bt);
+        }
+    }
+    G.ncells_total = (int)c->cells.size();
+    G.cell_cap = cell_cap; G.sel_cap = sel_cap; G.keys_per_frame = key_off;
+    G.tile_w = tile_w; G.tile_h = tile_h; G.tile_pitch = round_up(tile_w, 4) + 4;
+    G.node_cap = round_up(node_cap, 8); G.max_cells_level = round_up(max_cells, 8);
+    G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
+    G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
+    c->fast_lds = (size_t)3 * G.tile_h * G.tile_pitch;
+    c->octree_lds = (size_t)G.node_cap * (8 * 2 + 8 + 8 + 4 + 4 + 2 * 2 + 2 + 2 + 2) + (size_t)(G.max_cells_level + 8) * 4 + 64;
+    ORBHIP_REQUIRE(c->octree_lds <= 160 * 1024, ORBHIP_EINVAL, "nfeatures too large for the LDS octree");
+    if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
+    if (int rc = c->d_btiles.ensure(c->btiles.size() * sizeof(BlurTile))) return rc;
+    if (int rc = c->d_tab.ensure(std::max<size_t>(tab.size(), 16))) return rc;
+    if (!c->cells.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_cells.p, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    ORBHIP_CHECK_HIP(hipMemcpy(c->d_btiles.p, c->btiles.data(), c->btiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
+    if (!tab.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    if (c->octree_lds > 64 * 1024)
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds));
+    c->w = w; c->h = h; c->stride = stride; c->nframes = 0;
+  }
+  if (!c->const_uploaded) {
+    ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORB_BIT_PATTERN_31, 1024));
+    ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), c->umax.data(), 16 * sizeof(int)));
+    c->const_uploaded = true;
+  }
+  const size_t B = (size_t)nframes;
+  if (int rc = c->d_pyr.ensure(std::max<size_t>(B * G.pyr_frame_bytes, 256))) return rc;
+  if (int rc = c->d_blur.ensure(B * G.blur_frame_bytes)) return rc;
+  if (int rc = c->d_cellcnt.ensure(std::max<size_t>(B * G.ncells_total * 4, 16))) return rc;
+  if (int rc = c->d_cellkps.ensure(std::max<size_t>(B * G.ncells_total * (size_t)G.cell_cap * 4, 16))) return rc;
+  if (int rc = c->d_keys.ensure(B * G.keys_per_frame * 4)) return rc;
+  if (int rc = c->d_knode.ensure(B * G.keys_per_frame * 2)) return rc;
+  if (int rc = c->d_sel.ensure(B * nl * G.sel_cap * 4)) return rc;
+  if (int rc = c->d_selcnt.ensure(B * nl * 4)) return rc;
+  if (int rc = c->d_nkeys.ensure(B * nl * 4)) return rc;
+  if (int rc = c->d_status.ensure(B * 4)) return rc;
+  c->nframes = nframes;
+  return 0;
+}
+
+static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int stride, size_t frame_stride,
+                     int nframes, orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts,
+                     hipStream_t st) {
+  ORBHIP_CHECK_HIP(hipSetDevice(c->device));
+  if (int rc = prepare(c, w, h, stride, nframes)) return rc;
+  const GeomDev& G = c->G;
+  const int nl = c->nlevels;
+  uint8_t* pyr = c->d_pyr.as<uint8_t>();
+  ORBHIP_CHECK_HIP(hipMemsetAsync(c->d_status.p, 0, (size_t)nframes * 4, st));
+  // pyramid chain
+  for (int l = 1; l < nl; l++) {
+    const LevelDev& S = G.lv[l - 1];
+    const LevelDev& D = G.lv[l];
+    const uint8_t* src = (l == 1) ? d_imgs : pyr + S.pyr_off;
+    long long sframe = (l == 1) ? (long long)frame_stride : G.pyr_frame_bytes;
+    dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes), block(64, 4);
+    const uint8_t* T = c->d_tab.as<uint8_t>();
+    hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, S.pitch, sframe, S.w, S.h, pyr + D.pyr_off, D.pitch,
+                       G.pyr_frame_bytes, D.w, D.h, (const int*)(T + c->tab_xofs[l]),
+                       (const short*)(T + c->tab_ialpha[l]), (const int*)(T + c->tab_yofs[l]),
+                       (const short*)(T + c->tab_ibeta[l]));
+  }
+  if (G.ncells_total > 0)
+    hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, nframes), dim3(256), c->fast_lds, st, G,
+                       c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
+                       c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh);
+  hipLaunchKernelGGL(k_octree, dim3(nl, nframes), dim3(256), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
+                     c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
+                     c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
+  hipLaunchKernelGGL(k_blur7, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, st, G,
+                     c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
+  const int maxkp = std::min(cap, nl * G.sel_cap);
+  hipLaunchKernelGGL(k_describe, dim3((maxkp + 3) / 4, nframes), dim3(256), 0, st, G, c->d_sel.as<uint32_t>(),
+                     c->d_selcnt.as<int>(), c->d_status.as<int>(), d_imgs, (long long)frame_stride, pyr,
+                     c->d_blur.as<uint8_t>(), d_kps, d_desc, cap, d_counts, c->atan_p[0], c->atan_p[1],
+                     c->atan_p[2], c->atan_p[3], c->factorPI);
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  c->last_img0 = d_imgs; c->last_img_frame_bytes = (long long)frame_stride; c->last_nframes = nframes;
+  return 0;
+}
+
+extern "C" {
+
+int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
+                orbx_ctx** out) {
+  ORBHIP_REQUIRE(out != nullptr, ORBHIP_EINVAL, "out is NULL");
+  ORBHIP_REQUIRE(nfeatures > 0 && nlevels >= 1 && nlevels <= MAX_LEVELS && scale_factor > 1.0f, ORBHIP_EINVAL,
+                 "bad extractor parameters");
+  ORBHIP_REQUIRE(min_th_fast >= 1 && ini_th_fast >= min_th_fast && ini_th_fast <= 254, ORBHIP_EINVAL,
+                 "FAST thresholds must satisfy 1 <= min <= ini <= 254");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+  ORBHIP_REQUIRE(device >= 0 && device < ndev, ORBHIP_EINVAL, "device ordinal out of range");
+  orbx_ctx* c = new (std::nothrow) orbx_ctx();
+  ORBHIP_REQUIRE(c != nullptr, ORBHIP_ENOMEM, "out of host memory");
+  c->nfeatures = nfeatures; c->scaleFactor = scale_factor; c->nlevels = nlevels;
+  c->iniTh = ini_th_fast; c->minTh = min_th_fast; c->device = device;
+  build_tables(c);
+  *out = c;
+  return 0;
+}
+
+int orbx_destroy(orbx_ctx* c) {
+  if (!c) return 0;
+  DevBuf* bufs[] = {&c->d_cells, &c->d_btiles, &c->d_tab, &c->d_pyr, &c->d_blur, &c->d_cellcnt, &c->d_cellkps,
+                    &c->d_keys, &c->d_knode, &c->d_sel, &c->d_selcnt, &c->d_nkeys, &c->d_status, &c->d_img,
+                    &c->d_kps, &c->d_desc, &c->d_counts};
+  for (DevBuf* b : bufs) b->release();
+  delete c;
+  return 0;
+}
+
+int orbx_get_levels(const orbx_ctx* c) { return c ? c->nlevels : ORBHIP_EINVAL; }
+
+int orbx_get_tables(const orbx_ctx* c, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* fpl) {
+  ORBHIP_REQUIRE(c != nullptr, ORBHIP_EINVAL, "ctx is NULL");
+  for (int i = 0; i < c->nlevels; i++) {
+    if (scale) scale[i] = c->scale[i];
+    if (inv_scale) inv_scale[i] = c->inv_scale[i];
+    if (sigma2) sigma2[i] = c->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = c->inv_sigma2[i];
+    if (fpl) fpl[i] = c->quota[i];
+  }
+  return 0;
+}
+
+int orbx_max_keypoints(const orbx_ctx* c) {
+  if (!c) return ORBHIP_EINVAL;
+  int s = 0;
+  for (int q : c->quota) s += q + 3;
+  return s;
+}
+
+int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int stride, size_t frame_stride,
+                              int nframes, orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts,
+                              void* stream) {
+  ORBHIP_REQUIRE(c && d_imgs && d_kps && d_desc && d_counts, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(w > 0 && h > 0 && stride >= w && nframes > 0 && cap > 0, ORBHIP_EINVAL, "bad dimensions");
+  ORBHIP_REQUIRE(nframes <= 65535, ORBHIP_EINVAL, "at most 65535 frames per batch");
+  return run_batch(c, d_imgs, w, h, stride, frame_stride, nframes, d_kps, d_desc, cap, d_counts, (hipStream_t)stream);
+}
+
+int orbx_extract(orbx_ctx* c, const uint8_t* img, int w, int h, int stride, orbx_keypoint* kps, uint8_t* desc32,
+                 int cap, int* n) {
+  ORBHIP_REQUIRE(c != nullptr, ORBHIP_EINVAL, "ctx is NULL");
+  if (!img || w <= 0 || h <= 0) return 0;                       // empty image: silent return (:1046)
+  ORBHIP_REQUIRE(kps && desc32 && n && cap > 0 && stride >= w, ORBHIP_EINVAL, "bad argument");
+  ORBHIP_CHECK_HIP(hipSetDevice(c->device));
+  const int pitch = round_up(w, 64);
+  const int icap = orbx_max_keypoints(c);
+  if (int rc = c->d_img.ensure((size_t)pitch * h)) return rc;
+  if (int rc = c->d_kps.ensure((size_t)icap * sizeof(orbx_keypoint))) return rc;
+  if (int rc = c->d_desc.ensure((size_t)icap * 32)) return rc;
+  if (int rc = c->d_counts.ensure(16)) return rc;
+  ORBHIP_CHECK_HIP(hipMemcpy2D(c->d_img.p, pitch, img, stride, w, h, hipMemcpyHostToDevice));
+  if (int rc = run_batch(c, c->d_img.as<uint8_t>(), w, h, pitch, (size_t)pitch * h, 1, c->d_kps.as<orbx_keypoint>(),
+                         c->d_desc.as<uint8_t>(), icap, c->d_counts.as<int32_t>(), 0))
+    return rc;
+  int32_t cnt = 0;
+  ORBHIP_CHECK_HIP(hipMemcpy(&cnt, c->d_counts.p, 4, hipMemcpyDeviceToHost));
+  if (cnt == -1) { set_error("candidate capacity exceeded (more than %d FAST corners in one pyramid level)", KEYCAP_MAX); return ORBHIP_EOVERFLOW; }
+  ORBHIP_REQUIRE(cnt >= 0, ORBHIP_EOVERFLOW, "internal keypoint capacity exceeded");
+  ORBHIP_REQUIRE(cnt <= cap, ORBHIP_ECAP, "output capacity too small");
+  if (cnt > 0) {
+    ORBHIP_CHECK_HIP(hipMemcpy(kps, c->d_kps.p, (size_t)cnt * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+    ORBHIP_CHECK_HIP(hipMemcpy(desc32, c->d_desc.p, (size_t)cnt * 32, hipMemcpyDeviceToHost));
+  }
+  *n = cnt;
+  return 0;
+}
+
+int orbx_get_level_image(orbx_ctx* c, int frame, int level, int blurred, uint8_t* out, int* w, int* h) {
+  ORBHIP_REQUIRE(c && c->last_nframes > 0, ORBHIP_EINVAL, "no extract call yet");
+  ORBHIP_REQUIRE(frame >= 0 && frame < c->last_nframes && level >= 0 && level < c->nlevels, ORBHIP_EINVAL, "bad index");
+  const LevelDev& L = c->G.lv[level];
+  if (w) *w = L.w;
+  if (h) *h = L.h;
+  if (!out) return 0;
+  ORBHIP_CHECK_HIP(hipSetDevice(c->device));
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  const uint8_t* src; int pitch;
+  if (blurred) { src = c->d_blur.as<uint8_t>() + (long long)frame * c->G.blur_frame_bytes + L.blur_off; pitch = L.bpitch; }
+  else if (level == 0) { src = c->last_img0 + (long long)frame * c->last_img_frame_bytes; pitch = L.pitch; }
+  else { src = c->d_pyr.as<uint8_t>() + (long long)frame * c->G.pyr_frame_bytes + L.pyr_off; pitch = L.pitch; }
+  ORBHIP_CHECK_HIP(hipMemcpy2D(out, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static void unpack_keys(const std::vector<uint32_t>& k, int32_t* out, int cap) {
+  for (size_t i = 0; i < k.size() && (int)i < cap; i++) {
+    out[3 * i] = (int32_t)(k[i] & 0xFFF); out[3 * i + 1] = (int32_t)((k[i] >> 12) & 0xFFF); out[3 * i + 2] = (int32_t)(k[i] >> 24);
+  }
+}
+
+int orbx_get_level_candidates(orbx_ctx* c, int frame, int level, int32_t* out, int cap, int* n) {
+  ORBHIP_REQUIRE(c && c->last_nframes > 0 && n, ORBHIP_EINVAL, "no extract call yet");
+  ORBHIP_REQUIRE(frame >= 0 && frame < c->last_nframes && level >= 0 && level < c->nlevels, ORBHIP_EINVAL, "bad index");
+  ORBHIP_CHECK_HIP(hipSetDevice(c->device));
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  int nk = 0;
+  ORBHIP_CHECK_HIP(hipMemcpy(&nk, c->d_nkeys.as<int>() + frame * c->nlevels + level, 4, hipMemcpyDeviceToHost));
+  *n = nk;
+  if (!out || nk <= 0) return 0;
+  ORBHIP_REQUIRE(nk <= c->G.lv[level].kcap, ORBHIP_EOVERFLOW, "candidate capacity exceeded");
+  std::vector<uint32_t> k(nk);
+  ORBHIP_CHECK_HIP(hipMemcpy(k.data(), c->d_keys.as<uint32_t>() + (long long)frame * c->G.keys_per_frame + c->G.lv[level].key_off,
+                             (size_t)nk * 4, hipMemcpyDeviceToHost));
+  unpack_keys(k, out, cap);
+  return 0;
+}
+
+int orbx_get_level_selected(orbx_ctx* c, int frame, int level, int32_t* out, int cap, int* n) {
+  ORBHIP_REQUIRE(c && c->last_nframes > 0 && n, ORBHIP_EINVAL, "no extract call yet");
+  ORBHIP_REQUIRE(frame >= 0 && frame < c->last_nframes && level >= 0 && level < c->nlevels, ORBHIP_EINVAL, "bad index");
+  ORBHIP_CHECK_HIP(hipSetDevice(c->device));
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  int nk = 0;
+  ORBHIP_CHECK_HIP(hipMemcpy(&nk, c->d_selcnt.as<int>() + frame * c->nlevels + level, 4, hipMemcpyDeviceToHost));
+  *n = nk;
+  if (!out || nk <= 0) return 0;
+  nk = std::min(nk, c->G.sel_cap);
+  std::vector<uint32_t> k(nk);
+  ORBHIP_CHECK_HIP(hipMemcpy(k.data(), c->d_sel.as<uint32_t>() + ((long long)frame * c->nlevels + level) * c->G.sel_cap,
+                             (size_t)nk * 4, hipMemcpyDeviceToHost));
+  unpack_keys(k, out, cap);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+"""Host mirror of the flattened ORB_SLAM2::ORBmatcher entry points (reference include/ORBmatcher.h,
+src/ORBmatcher.cc) over the HIP C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30          # src/ORBmatcher.cc:35-37
+
+    def __init__(self, nnratio=0.6, checkOri=True):       # include/ORBmatcher.h:38
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self._L = _lib.load()
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """src/ORBmatcher.cc:1422-1437"""
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        assert a.size == 32 and b.size == 32
+        return _lib.load().orbm_descriptor_distance(_lib.ptr(a), _lib.ptr(b))
+
+    def hamming_best2(self, q, t, cand_offsets=None, cand_idx=None):
+        """best/second-best distance of each query over its candidate list (host arrays)."""
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq, nt = len(q), len(t)
+        bi = np.full(nq, -1, np.int32); bd = np.full(nq, 256, np.int32); sd = np.full(nq, 256, np.int32)
+        co = None if cand_offsets is None else np.ascontiguousarray(cand_offsets, np.uint32)
+        ci = None if cand_idx is None else np.ascontiguousarray(cand_idx, np.uint32)
+        if ci is not None and ci.size == 0:
+            ci = np.zeros(1, np.uint32)
+        _lib.check(self._L.orbm_hamming_best2(_lib.ptr(q), nq, _lib.ptr(t), nt, _lib.ptr(co), _lib.ptr(ci),
+                                              _lib.ptr(bi), _lib.ptr(bd), _lib.ptr(sd)), "orbm_hamming_best2")
+        return bi, bd, sd
+
+    def hamming_best2_device(self, d_q, d_t, d_off=None, d_idx=None, stream=None):
+        import torch
+        nq, nt = d_q.shape[0], d_t.shape[0]
+        out = torch.empty((3, max(nq, 1)), dtype=torch.int32, device=d_q.device)
+        st = torch.cuda.current_stream(d_q.device).cuda_stream if stream is None else stream
+        _lib.check(self._L.orbm_hamming_best2_device(_lib.ptr(d_q), nq, _lib.ptr(d_t), nt, _lib.ptr(d_off),
+                                                     _lib.ptr(d_idx), _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                                     _lib.ptr(out[2]), C.c_void_p(st)), "orbm_hamming_best2_device")
+        return out[0, :nq], out[1, :nq], out[2, :nq]
+
+    def match_frames_batch(self, kps, desc, counts, pair_a, pair_b, th=None, stream=None, out=None):
+        """Brute-force frame-to-frame matching of extract_batch outputs (device tensors):
+        ratio test (mfNNratio), threshold (default TH_LOW) and rotation consistency (mbCheckOrientation)."""
+        import torch
+        cap = kps.shape[1]
+        npairs = pair_a.shape[0]
+        if out is None:
+            m = torch.empty((npairs, cap), dtype=torch.int32, device=kps.device)
+            nm = torch.empty((npairs,), dtype=torch.int32, device=kps.device)
+        else:
+            m, nm = out
+        st = torch.cuda.current_stream(kps.device).cuda_stream if stream is None else stream
+        _lib.check(self._L.orbm_match_frames_batch_device(_lib.ptr(kps), _lib.ptr(desc), _lib.ptr(counts), cap,
+                                                          _lib.ptr(pair_a), _lib.ptr(pair_b), npairs, self.mfNNratio,
+                                                          self.TH_LOW if th is None else int(th),
+                                                          int(self.mbCheckOrientation), _lib.ptr(m), _lib.ptr(nm),
+                                                          C.c_void_p(st)), "orbm_match_frames_batch_device")
+        return m, nm
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds2, vbPrevMatched, windowSize=10):
+        """src/ORBmatcher.cc:363-468 on flattened frames.  kps = (n,4) float32 [x,y,octave,angle];
+        vbPrevMatched (n1,2) float32 is updated in place.  Returns (nmatches, vnMatches12)."""
+        kps1 = np.ascontiguousarray(kps1, np.float32); kps2 = np.ascontiguousarray(kps2, np.float32)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        b = np.ascontiguousarray(bounds2, np.float32)
+        assert vbPrevMatched.dtype == np.float32 and vbPrevMatched.flags.c_contiguous
+        m = np.full(len(kps1), -1, np.int32)
+        n = C.c_int(0)
+        _lib.check(self._L.orbm_search_for_initialization(_lib.ptr(kps1), _lib.ptr(desc1), len(kps1), _lib.ptr(kps2),
+                                                          _lib.ptr(desc2), len(kps2), _lib.ptr(b),
+                                                          _lib.ptr(vbPrevMatched), int(windowSize), self.mfNNratio,
+                                                          int(self.mbCheckOrientation), _lib.ptr(m), C.byref(n)),
+                   "orbm_search_for_initialization")
+        return n.value, m

@@ -1,0 +1,195 @@
+/* ============================================================================
+ * orbslam_hip.h -- C ABI of the MI355X (gfx950) ORB front-end and bundle-adjustment
+ * back-end.  This is the drop-in boundary: the reference has no plugin/FFI layer,
+ * its hot path is three C++ classes called directly, so each entry point below
+ * names the reference member it replaces (file:line relative to the reference
+ * tree).  C++ shims with the reference's own class names and signatures live in
+ * ceres_mono_orb_slam2_amd/csrc/compat/ and call nothing but these functions.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ORBHIP_E* code on error;
+ *     orbhip_last_error() gives a message for the calling thread's last failure;
+ *   - the caller owns every buffer; handles are not thread-safe, distinct handles
+ *     are; `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - "_device" entry points take device pointers and only ENQUEUE work on
+ *     `stream` (no host synchronisation); the others take host pointers and return
+ *     after the result is in host memory;
+ *   - there is no CPU fallback: without a HIP device every compute entry point
+ *     fails with ORBHIP_ENODEV.
+ * ========================================================================== */
+#ifndef ORBSLAM_HIP_H
+#define ORBSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBHIP_OK 0
+#define ORBHIP_EINVAL (-1)    /* bad argument */
+#define ORBHIP_ENODEV (-2)    /* no HIP device / HIP runtime error */
+#define ORBHIP_ENOMEM (-3)
+#define ORBHIP_ECAP (-4)      /* caller's output capacity too small */
+#define ORBHIP_EOVERFLOW (-5) /* internal candidate capacity exceeded (see orbx_create_ex) */
+#define ORBHIP_ENUMERIC (-6)  /* linear solve failed */
+
+const char* orbhip_last_error(void);
+int orbhip_device_count(void);
+/* library version / build tag */
+const char* orbhip_version(void);
+
+/* ---------------------------------------------------------------- extractor --
+ * Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-111,
+ * src/ORBextractor.cc:410-470 ctor, :1043-1105 operator()).                     */
+typedef struct orbx_ctx orbx_ctx;
+
+/* cv::KeyPoint's seven fields, 28 bytes (pt.x, pt.y, size, angle, response, octave, class_id) */
+typedef struct orbx_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orbx_keypoint;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (src/ORBextractor.cc:410-470); `device` = HIP device ordinal.                  */
+int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
+                orbx_ctx** out);
+int orbx_destroy(orbx_ctx* ctx);
+
+/* GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:63-83) plus the per-level quotas
+ * mnFeaturesPerLevel (:435-446).  Any pointer may be NULL.                        */
+int orbx_get_levels(const orbx_ctx* ctx);
+int orbx_get_tables(const orbx_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* features_per_level);
+/* upper bound on keypoints per frame (nfeatures + 3 per level): size outputs with this */
+int orbx_max_keypoints(const orbx_ctx* ctx);
+
+/* operator()(image, mask, keypoints, descriptors) for ONE host image (src/ORBextractor.cc:1043-1105).
+ * img: CV_8UC1 rows of `stride` bytes.  Empty image (w<=0 or h<=0 or img==NULL) -> *n untouched,
+ * returns 0 (":1046").  kps[cap], desc32[cap*32].                                */
+int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int w, int h, int stride, orbx_keypoint* kps,
+                 uint8_t* desc32, int cap, int* n);
+
+/* Batched, device-resident form: nframes images of the same size, frame f at
+ * d_imgs + f*frame_stride_bytes.  Outputs (device): d_kps[nframes*cap], d_desc[nframes*cap*32],
+ * d_counts[nframes] (keypoints per frame; -1 = that frame hit ORBHIP_EOVERFLOW).
+ * Only enqueues on `stream`.                                                      */
+int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_imgs, int w, int h, int stride,
+                              size_t frame_stride_bytes, int nframes, orbx_keypoint* d_kps, uint8_t* d_desc,
+                              int cap, int32_t* d_counts, void* stream);
+
+/* mvImagePyramid (include/ORBextractor.h:85) of the last extract call: copies level `level` of frame
+ * `frame` to host (dense, w*h bytes).  blurred=1 returns the 7x7 Gaussian-blurred level that BRIEF
+ * sampled (src/ORBextractor.cc:1085-1086).  out may be NULL to query the size.   */
+int orbx_get_level_image(orbx_ctx* ctx, int frame, int level, int blurred, uint8_t* out, int* w, int* h);
+/* introspection of the last call, for stage-by-stage parity tests: per-level FAST candidates in
+ * candidate order as int32 triples (x, y, score) in detection-window coordinates
+ * (src/ORBextractor.cc:789-829) and per-level selected keypoints (after DistributeOctTree, :834) as
+ * int32 triples in the same coordinates.  out may be NULL; *n returns the count. */
+int orbx_get_level_candidates(orbx_ctx* ctx, int frame, int level, int32_t* out, int cap, int* n);
+int orbx_get_level_selected(orbx_ctx* ctx, int frame, int level, int32_t* out, int cap, int* n);
+
+/* ------------------------------------------------------------------ matcher --
+ * Replaces the distance core of ORB_SLAM2::ORBmatcher (src/ORBmatcher.cc).        */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1422-1437); host pointers, 32 bytes each. */
+int orbm_descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+/* best / second-best Hamming distance of every query against its candidate list, first minimum
+ * wins (the inner loop of every Search* method, e.g. src/ORBmatcher.cc:192-208).
+ * cand_offsets (nq+1) / cand_idx = CSR candidate lists; both NULL = brute force over all nt targets.
+ * Outputs per query: best_idx (-1 = no candidate), best_d, second_d (256 = none). Device pointers. */
+int orbm_hamming_best2_device(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                              const uint32_t* d_cand_offsets, const uint32_t* d_cand_idx, int32_t* d_best_idx,
+                              int32_t* d_best_d, int32_t* d_second_d, void* stream);
+/* same with host pointers (synchronous) */
+int orbm_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint32_t* cand_offsets,
+                       const uint32_t* cand_idx, int32_t* best_idx, int32_t* best_d, int32_t* second_d);
+
+/* Brute-force frame-to-frame matching, batched: pair p matches the keypoints of frame a[p] against
+ * frame b[p] of one extract batch: best/second-best over ALL keypoints of b, accept iff
+ * best <= th && best < ratio*second (src/ORBmatcher.cc:210-212), then the rotation-consistency
+ * histogram filter (ComputeThreeMaxima, :1386-1418; idiom :217-252) when check_ori != 0.
+ * d_kps/d_desc/d_counts are orbx_extract_batch_device's outputs (cap = per-frame capacity).
+ * d_match12[npairs*cap]: index into frame b or -1.  d_nmatch[npairs].              */
+int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_counts,
+                                   int cap, const int32_t* d_pair_a, const int32_t* d_pair_b, int npairs,
+                                   float ratio, int th, int check_ori, int32_t* d_match12, int32_t* d_nmatch,
+                                   void* stream);
+
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:363-468) on flattened frames (host pointers).
+ * kps = n x 4 floats (x, y, octave, angle) of the undistorted keypoints; bounds2 = {min_x,max_x,min_y,max_y}
+ * of frame 2 (Frame::ComputeImageBounds); prev_matched (n1 x 2) is updated in place; matches12[n1].
+ * Distances are computed on the GPU (candidate-list kernel); the order-dependent greedy pass
+ * (":408", ":421-427") runs on the host in reference loop order.  Returns the match count in *nmatches. */
+int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int n1, const float* kps2,
+                                   const uint8_t* desc2, int n2, const float* bounds2, float* prev_matched,
+                                   int window, float nnratio, int check_ori, int32_t* matches12, int* nmatches);
+
+/* ------------------------------------------------------------ bundle adjust --
+ * Replaces CeresOptimizer::{PoseOptimization, BundleAdjustment/GlobalBundleAdjustemnt,
+ * LocalBundleAdjustment, CheckOutlier(s)} (src/CeresOptimizer.cc:49-599) and the Ceres solve
+ * underneath (trust-region LM, Huber loss, quaternion manifold, Jacobi scaling; exact Schur
+ * solve).  All arithmetic is fp64.  Poses are 7-vectors [tx,ty,tz,qx,qy,qz,qw]
+ * (src/MatEigenConverter.cc:66-85); K4 = {fx,fy,cx,cy}.                              */
+typedef struct ba_options {
+  int32_t max_iterations;      /* options.max_num_iterations */
+  double huber_delta;          /* sqrt(5.991) in the reference; applied where obs_robust != 0 */
+  int32_t fix_points;          /* 1 = points are constants (PoseOptimization) */
+  const volatile uint8_t* stop_flag; /* StopFlagCallback (include/CeresOptimizer.h:332-349); may be NULL */
+} ba_options;
+
+typedef struct ba_summary {
+  double initial_cost, final_cost;
+  int32_t iterations;          /* LM iterations attempted */
+  int32_t successful_steps;
+  int32_t termination;         /* 0 max-iters 1 gradient 2 parameter 3 function tol 4 user stop 5 failure 6 min-radius */
+  double final_radius;
+} ba_summary;
+
+/* CeresOptimizer::PoseOptimization(Frame*) (src/CeresOptimizer.cc:275-342) for ONE frame, host pointers.
+ * inv_sigma2[i] = frame->inv_level_sigma2s_[octave_i] (used un-square-rooted as in the reference, F7).
+ * On return pose7 holds t and the NORMALISED quaternion (":336"), outlier[i] = CheckOutliers flag;
+ * *n_inliers = n - n_bad, or 0 with the pose untouched when n < 3 (":330").          */
+int ba_pose_optimization(const double* K4, double* pose7, const double* Xw, const double* uv,
+                         const float* inv_sigma2, int n, uint8_t* outlier, int* n_inliers, ba_summary* summary);
+
+/* batched, device-resident PoseOptimization: problem p uses observations [offsets[p], offsets[p+1]).
+ * d_pose7[np*7] in/out, d_outlier[total], d_n_inliers[np], d_summary[np] (may be NULL). Enqueue only. */
+int ba_pose_optimization_batch_device(const double* d_K4 /*np*4*/, double* d_pose7, const double* d_Xw,
+                                      const double* d_uv, const float* d_inv_sigma2, const int32_t* d_offsets,
+                                      int nproblems, uint8_t* d_outlier, int32_t* d_n_inliers,
+                                      ba_summary* d_summary, void* stream);
+
+/* CeresOptimizer::BundleAdjustment (src/CeresOptimizer.cc:59-225) on flattened arrays, host pointers:
+ * cameras with cam_fixed != 0 are constant (KF id 0, fixed KFs); obs_weight multiplies the pixel
+ * residual (= invSigma2, F7); obs_robust selects the Huber loss per observation.  poses7 / pts3 are
+ * updated in place with the last accepted iterate (quaternions NOT re-normalised here).             */
+int ba_solve(const double* K4_per_cam, double* poses7, const uint8_t* cam_fixed, int ncam, double* pts3,
+             int npts, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv,
+             const double* obs_weight, const uint8_t* obs_robust, int nobs, const ba_options* opts,
+             ba_summary* summary);
+
+/* CeresOptimizer::CheckOutlier (src/CeresOptimizer.cc:227-241); host, scalar. depth may be NULL. */
+int ba_check_outlier(const double* K4, const double* pose7, const double* Xw, const double* uv,
+                     double inv_sigma2, double thres, double* depth);
+
+/* Optimisation core of CeresOptimizer::LocalBundleAdjustment (src/CeresOptimizer.cc:408-598): pass 1
+ * Huber / <=5 iterations, outlier classification (chi2 > 5.991 or depth <= 0, local keyframes only),
+ * pass 2 with the not-erased observations re-added loss-free ON TOP of pass 1's blocks when
+ * duplicate_blocks != 0 (the reference's behaviour) / <=10 iterations, classification again.
+ * obs_erase[i] = final to_erase membership.  *aborted = 1 if *stop_flag was set before a solve
+ * (nothing written back, ":509-512").  Quaternions are normalised on write-back (":589").         */
+int ba_local_bundle_adjustment(const double* K4_per_cam, double* poses7, const uint8_t* cam_fixed,
+                               const uint8_t* cam_local, int ncam, double* pts3, int npts,
+                               const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv,
+                               const float* obs_inv_sigma2, int nobs, const volatile uint8_t* stop_flag,
+                               int duplicate_blocks, uint8_t* obs_erase, int* aborted, ba_summary* pass1,
+                               ba_summary* pass2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBSLAM_HIP_H */

@@ -341,6 +341,7 @@ void divide_node(const Node& n, Node& n1, Node& n2, Node& n3, Node& n4) {
 
 std::vector<KeyPoint> distribute_octree(const std::vector<KeyPoint>& in, int minX, int maxX, int minY,
                                         int maxY, int N) {
+  if (in.empty()) return {};   // (also covers degenerate windows of tiny pyramid levels)
   int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
   if (nIni < 1) nIni = 1;   // reference would index an empty vector here (portrait windows); guarded
   const float hX = static_cast<float>(maxX - minX) / nIni;

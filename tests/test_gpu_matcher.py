@@ -1,0 +1,122 @@
+"""GPU parity: Hamming matching through the C ABI vs the CPU oracle (bit-exact integer work)."""
+import os
+
+import numpy as np
+import pytest
+
+from ceres_mono_orb_slam2_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _m(r=0.9, ori=True):
+    from ceres_mono_orb_slam2_amd import ORBmatcher
+    return ORBmatcher(r, ori)
+
+
+def test_descriptor_distance_identities():
+    from ceres_mono_orb_slam2_amd import ORBmatcher
+    rng = np.random.default_rng(0)
+    z = np.zeros(32, np.uint8)
+    assert ORBmatcher.DescriptorDistance(z, ~z) == 256
+    for _ in range(50):
+        a = rng.integers(0, 256, 32, dtype=np.uint8); b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert ORBmatcher.DescriptorDistance(a, a) == 0
+        assert ORBmatcher.DescriptorDistance(a, b) == int(np.unpackbits(a ^ b).sum())
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (50, 70), (257, 1025), (2000, 2000), (3, 0)])
+def test_best2_brute_force(oracle, nq, nt):
+    rng = np.random.default_rng(nq * 7 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if nt > 30:
+        t[10] = q[0]; t[20] = q[0]                        # exact tie -> first index wins
+    bi, bd, sd = _m().hamming_best2(q, t)
+    obi, obd, osd = oracle.hamming_best2(q, t)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+
+
+def test_best2_csr_ragged(oracle):
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (400, 32), dtype=np.uint8)
+    lens = rng.integers(0, 40, 300); lens[:5] = 0
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    idx = rng.integers(0, 400, int(off[-1])).astype(np.uint32)
+    bi, bd, sd = _m().hamming_best2(q, t, off, idx)
+    obi, obd, osd = oracle.hamming_best2(q, t, off, idx)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+    assert (bi[:5] == -1).all() and (bd[:5] == 256).all()
+    # all-empty candidate lists
+    off0 = np.zeros(301, np.uint32)
+    bi, bd, sd = _m().hamming_best2(q, t, off0, np.zeros(0, np.uint32))
+    assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
+
+
+def test_golden_match_fixture():
+    import torch
+    g = np.load(os.path.join(GOLD, "match_320x240.npz"))
+    bi, bd, sd = _m().hamming_best2(g["d1"], g["d2"])
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_d"]) and np.array_equal(sd, g["second_d"])
+    m, n = _match_pair(g["d1"], g["a1"], g["d2"], g["a2"], 0.9, True)
+    assert n == int(g["nmatch"]) and np.array_equal(m, g["match12"])
+
+
+def _match_pair(d1, a1, d2, a2, ratio, ori, th=None):
+    import torch
+    cap = max(len(d1), len(d2)) + 5
+    kps = torch.zeros((2, cap, 7), dtype=torch.float32)
+    kps[0, :len(a1), 3] = torch.from_numpy(np.asarray(a1, np.float32)); kps[1, :len(a2), 3] = torch.from_numpy(np.asarray(a2, np.float32))
+    desc = torch.zeros((2, cap, 32), dtype=torch.uint8)
+    desc[0, :len(d1)] = torch.from_numpy(d1); desc[1, :len(d2)] = torch.from_numpy(d2)
+    counts = torch.tensor([len(d1), len(d2)], dtype=torch.int32)
+    pa = torch.tensor([0], dtype=torch.int32).cuda(); pb = torch.tensor([1], dtype=torch.int32).cuda()
+    m, nm = _m(ratio, ori).match_frames_batch(kps.cuda(), desc.cuda(), counts.cuda(), pa, pb, th=th)
+    torch.cuda.synchronize()
+    return m[0, :len(d1)].cpu().numpy(), int(nm[0])
+
+
+@pytest.mark.parametrize("ratio,ori", [(0.9, True), (0.7, True), (0.9, False)])
+def test_match_frames_vs_oracle(oracle, ratio, ori):
+    E = oracle.OracleExtractor(1000)
+    seq, _ = synth.make_sequence(21, 640, 480, 2, "blocks", max_shift=8)
+    k1, d1 = E.extract(seq[0]); k2, d2 = E.extract(seq[1])
+    m, n = _match_pair(d1, k1["angle"], d2, k2["angle"], ratio, ori)
+    om, on = oracle.match_frames(d1, k1["angle"], d2, k2["angle"], ratio, 50, ori)
+    assert n == on and np.array_equal(m, om)
+    assert n > 100
+
+
+def test_match_frames_empty_frames():
+    d = np.zeros((0, 32), np.uint8); a = np.zeros(0, np.float32)
+    rng = np.random.default_rng(1)
+    d2 = rng.integers(0, 256, (10, 32), dtype=np.uint8); a2 = np.zeros(10, np.float32)
+    m, n = _match_pair(d2, a2, d, a, 0.9, True)
+    assert n == 0 and (m == -1).all()
+
+
+def test_search_for_initialization_vs_oracle(oracle):
+    E = oracle.OracleExtractor(1000)
+    seq, _ = synth.make_sequence(31, 640, 480, 2, "blocks", max_shift=6)
+    k1, d1 = E.extract(seq[0]); k2, d2 = E.extract(seq[1])
+    f = lambda k: np.stack([k["x"], k["y"], k["octave"].astype(np.float32), k["angle"]], 1).astype(np.float32)
+    bounds = np.array([0, 640, 0, 480], np.float32)
+    for window, ratio in [(100, 0.9), (10, 0.9), (30, 0.6)]:
+        prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32)
+        om, on, opm = oracle.search_for_initialization(f(k1), d1, f(k2), d2, bounds, prev, window, ratio, True)
+        pm = prev.copy()
+        n, m = _m(ratio, True).SearchForInitialization(f(k1), d1, f(k2), d2, bounds, pm, window)
+        assert n == on and np.array_equal(m, om) and np.array_equal(pm, opm)
+
+
+def test_full_size_match_properties():
+    """2000x2000 brute force at BASELINE size: symmetric-input and shuffle-invariance properties."""
+    rng = np.random.default_rng(9)
+    d = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+    bi, bd, sd = _m().hamming_best2(d, d)
+    assert np.array_equal(bi, np.arange(2000)) and (bd == 0).all() and (sd > 0).all()
+    perm = rng.permutation(2000)
+    bi2, bd2, sd2 = _m().hamming_best2(d, d[perm])
+    assert np.array_equal(perm[bi2], np.arange(2000)) and np.array_equal(sd2, sd)
