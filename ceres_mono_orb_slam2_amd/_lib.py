@@ -48,6 +48,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OrbHipError("HIP library %s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % LIB_PATH)
+    # PyTorch (device memory / streams / torch.distributed plumbing) bundles its own libamdhip64.so.7;
+    # load it FIRST so this library binds to the same HIP runtime instead of a second copy from
+    # /opt/rocm (two runtimes in one process cannot both own the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
     L.orbhip_last_error.restype = C.c_char_p
