@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liborbslam_hip.so")
 SYMBOLS = [
     "orbhip_last_error", "orbhip_device_count", "orbhip_version",
     "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_tables", "orbx_max_keypoints", "orbx_extract",
-    "orbx_extract_batch_device", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
+    "orbx_extract_batch_device", "orbx_set_profiling", "orbx_get_stage_ms", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
     "orbm_search_for_initialization",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
@@ -66,6 +66,8 @@ def load():
     L.orbx_max_keypoints.argtypes = [vp]
     L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
     L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, i32, vp, vp, i32, vp, vp]
+    L.orbx_set_profiling.argtypes = [vp, i32]
+    L.orbx_get_stage_ms.argtypes = [vp, vp, C.POINTER(i32)]
     L.orbx_get_level_image.argtypes = [vp, i32, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_get_level_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
     L.orbx_get_level_selected.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]

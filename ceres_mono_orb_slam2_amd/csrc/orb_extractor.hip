@@ -658,6 +658,9 @@ struct orbx_ctx {
   // last call (for introspection)
   const uint8_t* last_img0 = nullptr; long long last_img_frame_bytes = 0; int last_nframes = 0;
   bool const_uploaded = false;
+  // optional per-stage HIP-event timing (bench.py roofline): 6 events per batch call
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;
 };
 
 static int build_tables(orbx_ctx* c) {
@@ -855,7 +858,9 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   const GeomDev& G = c->G;
   const int nl = c->nlevels;
   uint8_t* pyr = c->d_pyr.as<uint8_t>();
+  auto mark = [&]() { if (c->profiling) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_events.push_back(e); } } };
   ORBHIP_CHECK_HIP(hipMemsetAsync(c->d_status.p, 0, (size_t)nframes * 4, st));
+  mark();
   // pyramid chain
   for (int l = 1; l < nl; l++) {
     const LevelDev& S = G.lv[l - 1];
@@ -869,20 +874,25 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
                        (const short*)(T + c->tab_ialpha[l]), (const int*)(T + c->tab_yofs[l]),
                        (const short*)(T + c->tab_ibeta[l]));
   }
+  mark();
   if (G.ncells_total > 0)
     hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, nframes), dim3(256), c->fast_lds, st, G,
                        c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
                        c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh);
+  mark();
   hipLaunchKernelGGL(k_octree, dim3(nl, nframes), dim3(256), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
                      c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
                      c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
+  mark();
   hipLaunchKernelGGL(k_blur7, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, st, G,
                      c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
+  mark();
   const int maxkp = std::min(cap, nl * G.sel_cap);
   hipLaunchKernelGGL(k_describe, dim3((maxkp + 3) / 4, nframes), dim3(256), 0, st, G, c->d_sel.as<uint32_t>(),
                      c->d_selcnt.as<int>(), c->d_status.as<int>(), d_imgs, (long long)frame_stride, pyr,
                      c->d_blur.as<uint8_t>(), d_kps, d_desc, cap, d_counts, c->atan_p[0], c->atan_p[1],
                      c->atan_p[2], c->atan_p[3], c->factorPI);
+  mark();
   ORBHIP_CHECK_HIP(hipGetLastError());
   c->last_img0 = d_imgs; c->last_img_frame_bytes = (long long)frame_stride; c->last_nframes = nframes;
   return 0;
@@ -916,6 +926,32 @@ int orbx_destroy(orbx_ctx* c) {
                     &c->d_kps, &c->d_desc, &c->d_counts};
   for (DevBuf* b : bufs) b->release();
   delete c;
+  return 0;
+}
+
+int orbx_set_profiling(orbx_ctx* c, int enable) {
+  ORBHIP_REQUIRE(c != nullptr, ORBHIP_EINVAL, "ctx is NULL");
+  for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+  c->prof_events.clear();
+  c->profiling = enable != 0;
+  return 0;
+}
+
+int orbx_get_stage_ms(orbx_ctx* c, float* ms, int* ncalls) {
+  ORBHIP_REQUIRE(c && ms && ncalls, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_CHECK_HIP(hipSetDevice(c->device));
+  for (int s = 0; s < 5; s++) ms[s] = 0.f;
+  const size_t n = c->prof_events.size() / 6;
+  if (n) ORBHIP_CHECK_HIP(hipEventSynchronize(c->prof_events.back()));
+  for (size_t k = 0; k < n; k++)
+    for (int s = 0; s < 5; s++) {
+      float t = 0.f;
+      ORBHIP_CHECK_HIP(hipEventElapsedTime(&t, c->prof_events[6 * k + s], c->prof_events[6 * k + s + 1]));
+      ms[s] += t;
+    }
+  *ncalls = (int)n;
+  for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+  c->prof_events.clear();
   return 0;
 }
 

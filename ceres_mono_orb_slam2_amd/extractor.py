@@ -99,6 +99,16 @@ class ORBextractor:
                                                      _lib.ptr(counts), C.c_void_p(st)), "orbx_extract_batch_device")
         return kps, desc, counts
 
+    STAGES = ("pyramid", "fast_cells", "octree", "blur", "describe")
+
+    def set_profiling(self, enable=True):
+        _lib.check(self._L.orbx_set_profiling(self._h, int(enable)))
+
+    def stage_ms(self):
+        ms = np.zeros(5, np.float32); n = C.c_int()
+        _lib.check(self._L.orbx_get_stage_ms(self._h, _lib.ptr(ms), C.byref(n)))
+        return dict(zip(self.STAGES, ms.tolist())), n.value
+
     # ---- mvImagePyramid (include/ORBextractor.h:85) and stage introspection --------------------------
     def level_image(self, level, frame=0, blurred=False):
         w, h = C.c_int(), C.c_int()

@@ -91,6 +91,14 @@ int orbx_get_level_image(orbx_ctx* ctx, int frame, int level, int blurred, uint8
 int orbx_get_level_candidates(orbx_ctx* ctx, int frame, int level, int32_t* out, int cap, int* n);
 int orbx_get_level_selected(orbx_ctx* ctx, int frame, int level, int32_t* out, int cap, int* n);
 
+/* Measurement hook (no reference counterpart): when enabled, every batch call records HIP events on
+ * its stream around its five stages {pyramid, FAST cells, octree, blur, orientation+BRIEF};
+ * orbx_get_stage_ms synchronises on the last event, returns the per-stage sums (ms) over the calls
+ * made since enabling and the number of calls, then resets.                           */
+#define ORBX_NSTAGES 5
+int orbx_set_profiling(orbx_ctx* ctx, int enable);
+int orbx_get_stage_ms(orbx_ctx* ctx, float* ms /*[ORBX_NSTAGES]*/, int* ncalls);
+
 /* ------------------------------------------------------------------ matcher --
  * Replaces the distance core of ORB_SLAM2::ORBmatcher (src/ORBmatcher.cc).        */
 
