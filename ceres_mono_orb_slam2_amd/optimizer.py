@@ -1,0 +1,106 @@
+"""Host mirror of CeresOptimizer's flattened entry points (reference include/CeresOptimizer.h:351-376,
+src/CeresOptimizer.cc:49-599) over the HIP C ABI.  All arithmetic fp64; poses are 7-vectors
+[tx,ty,tz,qx,qy,qz,qw] (src/MatEigenConverter.cc:66-85)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+HUBER_DELTA = float(np.sqrt(5.991))      # ceres::HuberLoss(sqrt(5.991)), src/CeresOptimizer.cc:81,296,421
+CHI2_THRESHOLD = 5.991                   # :257, :553
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def pose_optimization(K4, pose7, Xw, uv, inv_sigma2):
+    """CeresOptimizer::PoseOptimization (src/CeresOptimizer.cc:275-342).
+    Returns (n_inliers, pose7, outlier_flags, summary)."""
+    L = _lib.load()
+    K4 = _f64(K4); pose = _f64(pose7).copy(); Xw = _f64(Xw).reshape(-1, 3); uv = _f64(uv).reshape(-1, 2)
+    isg = np.ascontiguousarray(inv_sigma2, np.float32)
+    n = len(Xw)
+    out = np.zeros(max(n, 1), np.uint8)
+    ninl = C.c_int(0); s = _lib.BaSummary()
+    _lib.check(L.ba_pose_optimization(_lib.ptr(K4), _lib.ptr(pose), _lib.ptr(Xw), _lib.ptr(uv), _lib.ptr(isg), n,
+                                      _lib.ptr(out), C.byref(ninl), C.byref(s)), "ba_pose_optimization")
+    return ninl.value, pose, out[:n], s.as_dict()
+
+
+def pose_optimization_batch(d_K4, d_pose7, d_Xw, d_uv, d_inv_sigma2, d_offsets, stream=None):
+    """Batched device-resident PoseOptimization (torch CUDA tensors); d_pose7 is updated in place.
+    Returns (outlier[total] uint8, n_inliers[np] int32, summaries[np, 6] float64-packed bytes)."""
+    import torch
+    L = _lib.load()
+    npb = d_pose7.shape[0]
+    total = d_Xw.shape[0]
+    outl = torch.empty((max(total, 1),), dtype=torch.uint8, device=d_pose7.device)
+    ninl = torch.empty((npb,), dtype=torch.int32, device=d_pose7.device)
+    summ = torch.empty((npb, C.sizeof(_lib.BaSummary)), dtype=torch.uint8, device=d_pose7.device)
+    st = torch.cuda.current_stream(d_pose7.device).cuda_stream if stream is None else stream
+    _lib.check(L.ba_pose_optimization_batch_device(_lib.ptr(d_K4), _lib.ptr(d_pose7), _lib.ptr(d_Xw), _lib.ptr(d_uv),
+                                                   _lib.ptr(d_inv_sigma2), _lib.ptr(d_offsets), npb, _lib.ptr(outl),
+                                                   _lib.ptr(ninl), _lib.ptr(summ), C.c_void_p(st)),
+               "ba_pose_optimization_batch_device")
+    return outl[:total], ninl, summ
+
+
+def bundle_adjustment(K4, poses7, cam_fixed, pts3, obs_cam, obs_pt, obs_uv, obs_weight, obs_robust, n_iterations=200,
+                      huber_delta=HUBER_DELTA, fix_points=False, stop_flag=None):
+    """CeresOptimizer::BundleAdjustment (src/CeresOptimizer.cc:59-225) on flattened arrays.
+    stop_flag: optional 1-element uint8 numpy array polled between iterations.
+    Returns (poses7, pts3, summary)."""
+    L = _lib.load()
+    K4 = _f64(K4).reshape(-1, 4); poses = _f64(poses7).copy(); pts = _f64(pts3).reshape(-1, 3).copy()
+    cf = np.ascontiguousarray(cam_fixed, np.uint8)
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+    uv = _f64(obs_uv).reshape(-1, 2); w = _f64(obs_weight); rb = np.ascontiguousarray(obs_robust, np.uint8)
+    o = _lib.BaOptions(int(n_iterations), float(huber_delta), int(fix_points),
+                       _lib.ptr(stop_flag) if stop_flag is not None else None)
+    s = _lib.BaSummary()
+    _lib.check(L.ba_solve(_lib.ptr(K4), _lib.ptr(poses), _lib.ptr(cf), len(cf), _lib.ptr(pts), len(pts), _lib.ptr(oc),
+                          _lib.ptr(op), _lib.ptr(uv), _lib.ptr(w), _lib.ptr(rb), len(oc), C.byref(o), C.byref(s)),
+               "ba_solve")
+    return poses, pts, s.as_dict()
+
+
+def global_bundle_adjustment(K4, poses7, cam_fixed, pts3, obs_cam, obs_pt, obs_uv, obs_inv_sigma2, n_iterations=200,
+                             stop_flag=None, is_robust=True):
+    """CeresOptimizer::GlobalBundleAdjustemnt (src/CeresOptimizer.cc:49-57): every observation weighted by
+    invSigma2 (F7), Huber iff is_robust.  Returns (poses7 with NORMALISED quaternions, pts3, summary)."""
+    n = len(obs_cam)
+    poses, pts, s = bundle_adjustment(K4, poses7, cam_fixed, pts3, obs_cam, obs_pt, obs_uv,
+                                      np.asarray(obs_inv_sigma2, np.float32).astype(np.float64),
+                                      np.full(n, 1 if is_robust else 0, np.uint8), n_iterations, stop_flag=stop_flag)
+    poses[:, 3:] /= np.linalg.norm(poses[:, 3:], axis=1, keepdims=True)      # Matrix_7_1_ToMatrix4d (:198)
+    return poses, pts, s
+
+
+def check_outlier(K4, pose7, Xw, uv, inv_sigma2, thres=CHI2_THRESHOLD):
+    """CeresOptimizer::CheckOutlier (src/CeresOptimizer.cc:227-241). Returns (is_outlier, depth)."""
+    L = _lib.load()
+    d = C.c_double()
+    r = L.ba_check_outlier(_lib.ptr(_f64(K4)), _lib.ptr(_f64(pose7)), _lib.ptr(_f64(Xw)), _lib.ptr(_f64(uv)),
+                           float(inv_sigma2), float(thres), C.byref(d))
+    return bool(r), d.value
+
+
+def local_bundle_adjustment(K4, poses7, cam_fixed, cam_local, pts3, obs_cam, obs_pt, obs_uv, obs_inv_sigma2,
+                            stop_flag=None, duplicate_blocks=True):
+    """Optimisation core of CeresOptimizer::LocalBundleAdjustment (src/CeresOptimizer.cc:408-598).
+    Returns (aborted, poses7, pts3, obs_erase, summary_pass1, summary_pass2)."""
+    L = _lib.load()
+    K4 = _f64(K4).reshape(-1, 4); poses = _f64(poses7).copy(); pts = _f64(pts3).reshape(-1, 3).copy()
+    cf = np.ascontiguousarray(cam_fixed, np.uint8); cl = np.ascontiguousarray(cam_local, np.uint8)
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+    uv = _f64(obs_uv).reshape(-1, 2); isg = np.ascontiguousarray(obs_inv_sigma2, np.float32)
+    er = np.zeros(max(len(oc), 1), np.uint8)
+    ab = C.c_int(0); s1 = _lib.BaSummary(); s2 = _lib.BaSummary()
+    _lib.check(L.ba_local_bundle_adjustment(_lib.ptr(K4), _lib.ptr(poses), _lib.ptr(cf), _lib.ptr(cl), len(cf),
+                                            _lib.ptr(pts), len(pts), _lib.ptr(oc), _lib.ptr(op), _lib.ptr(uv),
+                                            _lib.ptr(isg), len(oc), _lib.ptr(stop_flag) if stop_flag is not None else None,
+                                            int(duplicate_blocks), _lib.ptr(er), C.byref(ab), C.byref(s1), C.byref(s2)),
+               "ba_local_bundle_adjustment")
+    return ab.value, poses, pts, er[:len(oc)], s1.as_dict(), s2.as_dict()
