@@ -1,0 +1,61 @@
+"""LocalBA / PoseOptimization throughput legs of bench.py (BASELINE.json configs[2], configs[3])."""
+import time
+
+import numpy as np
+
+from . import optimizer, synth
+
+
+def run(dev, cpu=True, n_localba=6, n_pose_batch=256):
+    import torch
+    out = {}
+    # ---- C4: LocalBundleAdjustment, 100 KF x 10k pts x 50k obs, reference two-pass schedule (5 + 10 iterations)
+    g = synth.make_ba_graph(0, ncam=100, npts=10000, nobs=50000, n_fixed=2)
+    local = np.ones(100, np.uint8)
+    args = (g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+    optimizer.local_bundle_adjustment(*args)                       # warm-up (module load, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_localba):
+        ab, poses, pts, er, s1, s2 = optimizer.local_bundle_adjustment(*args)
+    dt = time.perf_counter() - t0
+    out["localba_solves_per_s"] = n_localba / dt
+    out["localba_ms_per_solve"] = dt / n_localba * 1e3
+    out["localba_note"] = ("100 KF x 10000 pts x 50000 obs, two-pass schedule (5 Huber + 10 iterations with duplicated "
+                           "blocks), host-pointer C ABI end to end: includes H2D/D2H copies and host structure setup")
+    out["localba_lm_iterations"] = int(s1["iterations"] + s2["iterations"])
+    out["localba_final_cost"] = float(s2["final_cost"])
+    # ---- C3: PoseOptimization, 1 camera x 2000 observations, batched device-resident
+    probs = [synth.make_pose_problem(100 + i, n=2000) for i in range(8)]
+    reps = n_pose_batch // len(probs)
+    offs = np.arange(0, 2000 * n_pose_batch + 1, 2000, dtype=np.int32)
+    K4 = torch.from_numpy(np.stack([p["K4"] for p in probs] * reps)).to(dev)
+    pose0 = torch.from_numpy(np.stack([p["pose0"] for p in probs] * reps)).to(dev)
+    Xw = torch.from_numpy(np.concatenate([p["Xw"] for p in probs] * reps)).to(dev)
+    uv = torch.from_numpy(np.concatenate([p["uv"] for p in probs] * reps)).to(dev)
+    isg = torch.from_numpy(np.concatenate([p["inv_sigma2"] for p in probs] * reps)).to(dev)
+    d_off = torch.from_numpy(offs).to(dev)
+    poses = pose0.clone()
+    optimizer.pose_optimization_batch(K4, poses, Xw, uv, isg, d_off)
+    torch.cuda.synchronize()
+    nrep = 10
+    t0 = time.perf_counter()
+    for _ in range(nrep):
+        poses.copy_(pose0)
+        optimizer.pose_optimization_batch(K4, poses, Xw, uv, isg, d_off)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["poseopt_solves_per_s"] = nrep * n_pose_batch / dt
+    out["poseopt_note"] = "1 camera x 2000 observations per problem, %d problems per launch, device-resident" % n_pose_batch
+    if cpu:
+        from oracle import pyoracle as po
+        t0 = time.perf_counter()
+        po.local_ba(*args)
+        dt = time.perf_counter() - t0
+        out["cpu_localba_solves_per_s"] = 1.0 / dt
+        t0 = time.perf_counter()
+        for p in probs:
+            po.pose_optimization(p["K4"], p["pose0"], p["Xw"], p["uv"], p["inv_sigma2"])
+        out["cpu_poseopt_solves_per_s"] = len(probs) / (time.perf_counter() - t0)
+        out["cpu_note"] = "oracle (CPU port), 1 thread: 1 LocalBA solve, %d PoseOptimization solves" % len(probs)
+    return out
