@@ -33,6 +33,8 @@
 #include <vector>
 #include <algorithm>
 #include <numeric>
+#include <chrono>
+#include <cstdlib>
 
 #include "common.h"
 #include "ba_math.h"
@@ -265,8 +267,9 @@ struct BaDev {            // device pointers of one problem
   double* B; double* gc; double* C; double* gp;       // unscaled blocks: B[nfc][21], gc[nfc][6], C[npts][6], gp[npts][3]
   double* scale_c; double* scale_p;  // Jacobi scaling [nfc][6], [npts][3]
   double* Cinv; double* gps; double* E; double* EC;   // Cinv[npts][6], gps[npts][3], E[18][nobs], EC[18][nobs]
-  double* S; double* rhs;            // reduced system S[npad][npad] (lower), rhs/yc [npad]
-  double* yp;                        // [npts][3] (scaled step of points, positive y)
+  double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
+  double* Dinv;                      // inverse of every 32x32 diagonal Cholesky block [npad/32][32][32]
+  const int* blk_a; const int* blk_b; const int* blk_off; const int* pair_i; const int* pair_j; int nblk;   // Schur block pair lists
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
   double huber;
@@ -432,9 +435,7 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(BaDev D) {
   if (st->done || !st->valid || D.fix_points) return;
   const int p = blockIdx.x * BA_TPB + threadIdx.x;
   if (p >= D.npts) return;
-  const int lo = D.pt_off[p], hi = D.pt_off[p + 1];
-  if (lo == hi) return;
-  const size_t n = D.nobs;
+  if (D.pt_off[p] == D.pt_off[p + 1]) return;
   const double* sp = D.scale_p + 3 * (size_t)p;
   const double* Cu = D.C + 6 * (size_t)p;
   double Cs[6] = {Cu[0] * sp[0] * sp[0], Cu[1] * sp[0] * sp[1], Cu[2] * sp[0] * sp[2], Cu[3] * sp[1] * sp[1], Cu[4] * sp[1] * sp[2], Cu[5] * sp[2] * sp[2]};
@@ -446,117 +447,179 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(BaDev D) {
   if (!inv3_sym6(Cs, Ci)) { st->chol_fail = 1; for (int k = 0; k < 6; k++) Ci[k] = 0.0; }
   for (int k = 0; k < 6; k++) D.Cinv[6 * (size_t)p + k] = Ci[k];
   for (int k = 0; k < 3; k++) D.gps[3 * (size_t)p + k] = D.gp[3 * (size_t)p + k] * sp[k];
-  for (int i = lo; i < hi; i++) {
-    const int cc = D.cam_col[D.obs_cam[i]];
-    if (cc < 0) continue;
-    const double* sc = D.scale_c + 6 * (size_t)cc;
-    double jp[6];
-    for (int k = 0; k < 6; k++) jp[k] = D.Jp[k * n + i] * sp[k % 3];
-    for (int u = 0; u < 6; u++) {
-      const double j0 = D.Jc[u * n + i] * sc[u], j1 = D.Jc[(6 + u) * n + i] * sc[u];
-      const double e0 = j0 * jp[0] + j1 * jp[3], e1 = j0 * jp[1] + j1 * jp[4], e2 = j0 * jp[2] + j1 * jp[5];
-      D.E[(3 * u) * n + i] = e0; D.E[(3 * u + 1) * n + i] = e1; D.E[(3 * u + 2) * n + i] = e2;
-      D.EC[(3 * u) * n + i] = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
-      D.EC[(3 * u + 1) * n + i] = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
-      D.EC[(3 * u + 2) * n + i] = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
-    }
+}
+
+// per observation: E = (Jc S_c)^T (Jp S_p) (6x3) and E (C_s+D)^-1, stored AoS (18 doubles each)
+__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(BaDev D) {
+  const BaState* st = D.st;
+  if (st->done || !st->valid || D.fix_points) return;
+  const int i = blockIdx.x * BA_TPB + threadIdx.x;
+  if (i >= D.nobs) return;
+  const int cc = D.cam_col[D.obs_cam[i]];
+  if (cc < 0) return;
+  const int p = D.obs_pt[i];
+  const size_t n = D.nobs;
+  const double* sc = D.scale_c + 6 * (size_t)cc;
+  const double* sp = D.scale_p + 3 * (size_t)p;
+  const double* Ci = D.Cinv + 6 * (size_t)p;
+  double jp[6];
+  for (int k = 0; k < 6; k++) jp[k] = D.Jp[k * n + i] * sp[k % 3];
+  double* Eo = D.E + 18 * (size_t)i;
+  double* ECo = D.EC + 18 * (size_t)i;
+  for (int u = 0; u < 6; u++) {
+    const double j0 = D.Jc[u * n + i] * sc[u], j1 = D.Jc[(6 + u) * n + i] * sc[u];
+    const double e0 = j0 * jp[0] + j1 * jp[3], e1 = j0 * jp[1] + j1 * jp[4], e2 = j0 * jp[2] + j1 * jp[5];
+    Eo[3 * u] = e0; Eo[3 * u + 1] = e1; Eo[3 * u + 2] = e2;
+    ECo[3 * u] = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
+    ECo[3 * u + 1] = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
+    ECo[3 * u + 2] = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
   }
 }
 
-// ---- reduced camera system: one wave per (ca <= cb) block pair --------------------------------------
+// ---- reduced camera system S = B_s + D - sum E (C_s+D)^-1 E^T: one wave per non-empty block pair
+// (a <= b).  Lane (u,v) of the first 36 lanes owns one element and walks the block's pair list in its
+// fixed (host-built) order, so the sum is deterministic; lanes 36..41 of a diagonal block build rhs.
 __global__ __launch_bounds__(256) void k_ba_schur(BaDev D, const int* __restrict__ free_cams) {
   const BaState* st = D.st;
   if (st->done || !st->valid) return;
-  const int lane = threadIdx.x & 63;
-  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long npairs = (long long)D.nfc * (D.nfc + 1) / 2;
-  if (wid >= npairs) return;
-  // unrank wid -> (a, b) with a <= b, row-major over the upper triangle
-  int a = (int)((2.0 * D.nfc + 1.0 - sqrt((2.0 * D.nfc + 1.0) * (2.0 * D.nfc + 1.0) - 8.0 * (double)wid)) * 0.5);
-  while ((long long)a * D.nfc - (long long)a * (a - 1) / 2 > wid) a--;
-  while ((long long)(a + 1) * D.nfc - (long long)(a + 1) * a / 2 <= wid) a++;
-  const int b = a + (int)(wid - ((long long)a * D.nfc - (long long)a * (a - 1) / 2));
-  const int ca = free_cams[a], cb = free_cams[b];
-  const size_t n = D.nobs;
-  double acc[36], racc[6];
-#pragma unroll
-  for (int k = 0; k < 36; k++) acc[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; k++) racc[k] = 0.0;
-  if (!D.fix_points) {
-    const int alo = D.cam_off[ca], ahi = D.cam_off[ca + 1], blo = D.cam_off[cb], bhi = D.cam_off[cb + 1];
-    for (int ea = alo + lane; ea < ahi; ea += 64) {
-      const int ia = D.cam_obs[ea], p = D.cam_obs_pt[ea];
-      // first entry of cb's list with point >= p
-      int lo = blo, hi = bhi;
-      while (lo < hi) { int mid = (lo + hi) >> 1; if (D.cam_obs_pt[mid] < p) lo = mid + 1; else hi = mid; }
-      double ec[18];
-      bool have = false;
-      for (int eb = lo; eb < bhi && D.cam_obs_pt[eb] == p; eb++) {
-        if (!have) { for (int k = 0; k < 18; k++) ec[k] = D.EC[k * n + ia]; have = true; }
-        const int ib = D.cam_obs[eb];
-        double eb3[18];
-        for (int k = 0; k < 18; k++) eb3[k] = D.E[k * n + ib];
-#pragma unroll
-        for (int u = 0; u < 6; u++)
-#pragma unroll
-          for (int v = 0; v < 6; v++) acc[u * 6 + v] += ec[3 * u] * eb3[3 * v] + ec[3 * u + 1] * eb3[3 * v + 1] + ec[3 * u + 2] * eb3[3 * v + 2];
+  __shared__ double s_part[7][36];
+  const int tid = threadIdx.x;
+  const int blk = blockIdx.x;
+  const int a = D.blk_a[blk], b = D.blk_b[blk];
+  const int np = D.npad;
+  const int grp = tid / 36, el = tid - 36 * grp;          // 7 groups x 36 elements (threads 252..255: rhs helpers)
+  if (grp < 7) {
+    const int u = el / 6, v = el - 6 * u;
+    double acc0 = 0.0, acc1 = 0.0;
+    const int lo = D.blk_off[blk], hi = D.blk_off[blk + 1];
+    int e = lo + grp;
+    for (; e + 7 < hi; e += 14) {                           // two independent pairs in flight
+      const double* ec0 = D.EC + 18 * (size_t)D.pair_i[e] + 3 * u;
+      const double* eb0 = D.E + 18 * (size_t)D.pair_j[e] + 3 * v;
+      const double* ec1 = D.EC + 18 * (size_t)D.pair_i[e + 7] + 3 * u;
+      const double* eb1 = D.E + 18 * (size_t)D.pair_j[e + 7] + 3 * v;
+      acc0 += ec0[0] * eb0[0] + ec0[1] * eb0[1] + ec0[2] * eb0[2];
+      acc1 += ec1[0] * eb1[0] + ec1[1] * eb1[1] + ec1[2] * eb1[2];
+    }
+    if (e < hi) {
+      const double* ec0 = D.EC + 18 * (size_t)D.pair_i[e] + 3 * u;
+      const double* eb0 = D.E + 18 * (size_t)D.pair_j[e] + 3 * v;
+      acc0 += ec0[0] * eb0[0] + ec0[1] * eb0[1] + ec0[2] * eb0[2];
+    }
+    s_part[grp][el] = acc0 + acc1;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int u = tid / 6, v = tid - 6 * u;
+    const double acc = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + ((s_part[4][tid] + s_part[5][tid]) + s_part[6][tid]);
+    if (a == b) {
+      if (v <= u) {
+        const double* sc = D.scale_c + 6 * (size_t)a;
+        double bs = D.B[21 * (size_t)a + sym6(u, v)] * sc[u] * sc[v];
+        if (u == v) bs += fmin(fmax(bs, 1e-6), 1e32) / st->radius;
+        D.S[(size_t)(6 * a + u) * np + 6 * a + v] = bs - acc;
       }
-      if (a == b) {
-        if (!have) for (int k = 0; k < 18; k++) ec[k] = D.EC[k * n + ia];
-        const double* g = D.gps + 3 * (size_t)p;
+    } else {
+      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -acc;           // lower triangle: block (b, a) = -(acc)^T
+    }
+  }
+  if (a == b) {
+    // rhs_a = g_s - sum over the camera's observations of EC_i * g_p: all threads, fixed tree
+    __shared__ double s_r[4 * 6], s_ro[6];
+    const int ca = free_cams[a];
+    double racc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (!D.fix_points)
+      for (int e = D.cam_off[ca] + tid; e < D.cam_off[ca + 1]; e += 256) {
+        const double* ec = D.EC + 18 * (size_t)D.cam_obs[e];
+        const double* g = D.gps + 3 * (size_t)D.cam_obs_pt[e];
 #pragma unroll
         for (int u = 0; u < 6; u++) racc[u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
       }
-    }
-#pragma unroll
-    for (int k = 0; k < 36; k++) { double v = acc[k]; for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o); acc[k] = v; }
-    if (a == b) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) { double v = racc[k]; for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o); racc[k] = v; }
-    }
-  }
-  if (lane == 0) {
-    const int np = D.npad;
-    if (a == b) {
-      const double* Bu = D.B + 21 * (size_t)a;
-      const double* sc = D.scale_c + 6 * (size_t)a;
-      const double radius = st->radius;
-      for (int u = 0; u < 6; u++) {
-        for (int v = 0; v <= u; v++) {
-          double bs = Bu[sym6(u, v)] * sc[u] * sc[v];
-          if (u == v) bs += fmin(fmax(bs, 1e-6), 1e32) / radius;
-          D.S[(size_t)(6 * a + u) * np + 6 * a + v] = bs - acc[u * 6 + v];
-        }
-        D.rhs[6 * a + u] = D.gc[6 * (size_t)a + u] * sc[u] - racc[u];
-      }
-    } else {
-      // lower triangle: block (b, a) = -(acc)^T
-      for (int u = 0; u < 6; u++)
-        for (int v = 0; v < 6; v++) D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -acc[u * 6 + v];
+    block_reduce<6>(racc, s_r, s_ro);
+    if (tid < 6) {
+      const double rv = D.gc[6 * (size_t)a + tid] * D.scale_c[6 * (size_t)a + tid] - s_ro[tid];
+      D.rhs[6 * a + tid] = rv;
+      D.S[(size_t)np * np + 6 * a + tid] = rv;                      // augmented row: forward substitution rides the factorisation
     }
   }
 }
 
-// padding rows/cols of S: identity (so the blocked factorisation runs on a multiple of 32)
-__global__ void k_ba_pad(BaDev D) {
+// zero the lower triangle rows of the real block (the factorisation overwrote S in place)
+__global__ __launch_bounds__(256) void k_ba_zero_S(BaDev D) {
   const BaState* st = D.st;
   if (st->done || !st->valid) return;
+  const size_t tot = (size_t)D.n6 * D.npad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) D.S[i] = 0.0;
+}
+
+// padding rows of S (identity): written once per solve - the factorisation maps them to themselves
+__global__ void k_ba_pad(BaDev D) {
   const int np = D.npad, n6 = D.n6;
-  for (int i = n6 + blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
-    for (int j = 0; j < np; j++) D.S[(size_t)i * np + j] = (i == j) ? 1.0 : 0.0;
-    D.rhs[i] = 0.0;
-  }
+  const int i = n6 + blockIdx.x;
+  if (i >= np) return;
+  for (int j = threadIdx.x; j < np; j += blockDim.x) D.S[(size_t)i * np + j] = (i == j) ? 1.0 : 0.0;
+  if (threadIdx.x == 0) { D.rhs[i] = 0.0; D.S[(size_t)np * np + i] = 0.0; }
 }
 
 // ---- dense blocked Cholesky (lower, in place), NB = 32 ---------------------------------------------------
 #define NB 32
-// panel: every workgroup factors the diagonal block redundantly (one wave, in LDS); workgroup 0 stores it;
-// then each workgroup solves its 256 rows of the panel:  L21 = A21 * L11^-T
+// panel: every workgroup factors the 32x32 diagonal block redundantly in ONE wave (left-looking, the block
+// lives in LDS, lane = row), inverts it (lane = column), workgroup 0 stores L11 and L11^-1; then every wave
+// forms 16 rows of L21 = A21 * L11^-T on the FP64 matrix cores (2 column tiles x 8 k-steps of
+// v_mfma_f64_16x16x4_f64).  Rows run to npad INCLUSIVE: row npad is the augmented rhs row.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double bcast_lane(double v, int lane) {      // lane is a compile-time constant after unrolling
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+// 32x32 Cholesky of the block in s_L (lower) by one wave: lane r keeps row r in registers; the pivot and the
+// pivot column are broadcast with v_readlane.  Returns 1 on a non-positive pivot.
+__device__ __noinline__ int diag_factor_wave(double (*s_L)[NB + 1]) {
+  const int r = threadIdx.x & 31;
+  double row[NB];
+#pragma unroll
+  for (int c = 0; c < NB; c++) row[c] = s_L[r][c];
+  int fail = 0;
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    double piv = bcast_lane(row[j], j);
+    if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
+    const double dinv = 1.0 / sqrt(piv);
+    row[j] = (r == j) ? sqrt(piv) : row[j] * dinv;
+#pragma unroll
+    for (int c = j + 1; c < NB; c++) {
+      const double lcj = bcast_lane(row[j], c);
+      row[c] -= (c <= r) ? row[j] * lcj : 0.0;
+    }
+  }
+  if (threadIdx.x < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; c++) s_L[r][c] = (c <= r) ? row[c] : 0.0;
+  }
+  return fail;
+}
+// inverse of the lower-triangular block in s_L into s_X: lane c solves L x = e_c with x in registers
+__device__ __noinline__ void diag_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1]) {
+  const int c = threadIdx.x & 31;
+  double x[NB];
+#pragma unroll
+  for (int rr = 0; rr < NB; rr++) {
+    double sum = (rr == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < rr; m++) sum -= s_L[rr][m] * x[m];
+    x[rr] = sum / s_L[rr][rr];
+  }
+  if (threadIdx.x < NB) {
+#pragma unroll
+    for (int rr = 0; rr < NB; rr++) s_X[rr][c] = x[rr];
+  }
+}
 __global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k) {
   BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_L[NB][NB + 1];
+  __shared__ double s_X[NB][NB + 1];
   __shared__ int s_fail;
   const int np = D.npad, tid = threadIdx.x;
   double* S = D.S;
@@ -564,55 +627,71 @@ __global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k) {
   if (tid == 0) s_fail = 0;
   __syncthreads();
   if (tid < 64) {
-    const int lane = tid;
-    for (int j = 0; j < NB; j++) {
-      double d = s_L[j][j];
-      if (!(d > 0.0) || !isfinite(d)) { if (lane == 0) s_fail = 1; d = 1.0; }
-      d = sqrt(d);
-      // scale column j (rows j..31) and rank-1 update of the trailing lower triangle
-      if (lane == 0) s_L[j][j] = d;
-      if (lane > j && lane < NB) s_L[lane][j] /= d;
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
-      const int rem = NB - 1 - j;                 // trailing rows j+1..31
-      for (int e = lane; e < rem * rem; e += 64) {
-        int r = j + 1 + e / rem, c = j + 1 + e % rem;
-        if (c <= r) s_L[r][c] -= s_L[r][j] * s_L[c][j];
-      }
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
-    }
+    const int fail = diag_factor_wave(s_L);
+    if (fail && tid == 0) s_fail = 1;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    diag_invert_wave(s_L, s_X);
   }
   __syncthreads();
   if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
-  if (blockIdx.x == 0)
-    for (int i = tid; i < NB * NB; i += 256) { int r = i / NB, c = i % NB; if (c <= r) S[(size_t)(k + r) * np + k + c] = s_L[r][c]; }
-  const int row = k + NB + blockIdx.x * 256 + tid;
-  if (row < np) {
-    double x[NB];
-    double* Arow = S + (size_t)row * np + k;
-#pragma unroll
-    for (int c = 0; c < NB; c++) x[c] = Arow[c];
-#pragma unroll
-    for (int c = 0; c < NB; c++) {
-      double s = x[c];
-#pragma unroll
-      for (int m = 0; m < c; m++) s -= x[m] * s_L[c][m];
-      x[c] = s / s_L[c][c];
+  if (blockIdx.x == 0) {
+    double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
+    for (int i = tid; i < NB * NB; i += 256) {
+      int r = i / NB, c = i % NB;
+      if (c <= r) S[(size_t)(k + r) * np + k + c] = s_L[r][c];
+      Di[i] = s_X[r][c];
     }
+  }
+  // ---- L21 rows: X = A * Linv^T on the matrix cores --------------------------------------------------
+  const int w = tid >> 6, lane = tid & 63;
+  const int row0 = k + NB + (blockIdx.x * 4 + w) * 16;
+  if (row0 > np) return;
+  const int li = lane & 15, lk = lane >> 4;
+  const int arow = row0 + li;
+  const bool rvalid = arow <= np;
+  double a[8];
 #pragma unroll
-    for (int c = 0; c < NB; c++) Arow[c] = x[c];
+  for (int ks = 0; ks < 8; ks++) a[ks] = rvalid ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
+  double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) {
+    const double b0 = s_X[li][4 * ks + lk], b1 = s_X[16 + li][4 * ks + lk];     // B[k][j] = Linv[j][k]
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b1, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    const int orow = row0 + (lane >> 4) + 4 * rg;
+    if (orow <= np) {
+      S[(size_t)orow * np + k + (lane & 15)] = acc0[rg];
+      S[(size_t)orow * np + k + 16 + (lane & 15)] = acc1[rg];
+    }
   }
 }
 
 // trailing update A22 -= L21 L21^T on the FP64 matrix cores; one 64x64 lower tile per workgroup,
 // each of the 4 waves owns a 32x32 quadrant as 2x2 v_mfma_f64_16x16x4_f64 tiles.
-typedef double double4_t __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int k) {
+__global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int k, int ntiles) {
   const BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_A[64][NB + 1], s_B[64][NB + 1];
   const int np = D.npad, tid = threadIdx.x;
+  if ((int)blockIdx.x >= ntiles) {           // extra workgroups: trailing update of the augmented rhs row (row npad)
+    double* zrow = D.S + (size_t)np * np;
+    double* s_z = &s_A[0][0];
+    if (tid < NB) s_z[tid] = zrow[k + tid];
+    __syncthreads();
+    const int c = k + NB + ((int)blockIdx.x - ntiles) * 256 + tid;
+    if (c < np) {
+      const double* L = D.S + (size_t)c * np + k;
+      double sum = 0.0;
+#pragma unroll
+      for (int m = 0; m < NB; m++) sum += L[m] * s_z[m];
+      zrow[c] -= sum;
+    }
+    return;
+  }
   // unrank blockIdx.x -> (ti >= tj)
   int ti = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
   while (ti * (ti + 1) / 2 > (int)blockIdx.x) ti--;
@@ -660,53 +739,55 @@ __global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int k) {
       }
 }
 
-// forward + backward substitution with the factor (single workgroup, blocked right-looking)
+// augmented rhs row: z_row[c] -= sum_k z_row[k-block] * L[c][k-block]  (the trailing update of row npad)
+__global__ __launch_bounds__(256) void k_chol_syrk_rhs(BaDev D, int k) {
+  const BaState* st = D.st;
+  if (st->done || !st->valid || st->chol_fail) return;
+  __shared__ double s_z[NB];
+  const int np = D.npad;
+  double* zrow = D.S + (size_t)np * np;
+  if (threadIdx.x < NB) s_z[threadIdx.x] = zrow[k + threadIdx.x];
+  __syncthreads();
+  const int c = k + NB + blockIdx.x * 256 + threadIdx.x;
+  if (c < np) {
+    const double* L = D.S + (size_t)c * np + k;
+    double sum = 0.0;
+#pragma unroll
+    for (int m = 0; m < NB; m++) sum += L[m] * s_z[m];
+    zrow[c] -= sum;
+  }
+}
+
+// backward substitution L^T x = z (z = augmented row, produced by the factorisation itself); single
+// workgroup, blocked right-looking; the diagonal solves are mat-vecs with the stored L11^-1 blocks.
 __global__ __launch_bounds__(256) void k_chol_solve(BaDev D) {
   const BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
-  __shared__ double s_y[NB];
+  extern __shared__ __attribute__((aligned(16))) double s_y[];       // [npad] running vector
+  __shared__ double s_x[NB];
   const int np = D.npad, tid = threadIdx.x;
   const double* S = D.S;
-  double* y = D.rhs;
-  for (int k = 0; k < np; k += NB) {          // L z = rhs
-    if (tid < 64) {
-      double v = (tid < NB) ? y[k + tid] : 0.0;
-      for (int j = 0; j < NB; j++) {
-        double yj = __shfl(v, j) / S[(size_t)(k + j) * np + k + j];
-        if (tid == j) v = yj;
-        if (tid > j && tid < NB) v -= S[(size_t)(k + tid) * np + k + j] * yj;
-      }
-      if (tid < NB) { s_y[tid] = v; y[k + tid] = v; }
+  const double* zrow = D.S + (size_t)np * np;
+  for (int i = tid; i < np; i += 256) s_y[i] = zrow[i];
+  __syncthreads();
+  for (int k = np - NB; k >= 0; k -= NB) {
+    if (tid < NB) {                                   // x = Linv^T z : x[c] = sum_{r >= c} Linv[r][c] z[r]
+      const double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
+      double sum = 0.0;
+      for (int r = tid; r < NB; r++) sum += Di[r * NB + tid] * s_y[k + r];
+      s_x[tid] = sum;
     }
     __syncthreads();
-    for (int r = k + NB + tid; r < np; r += 256) {
-      const double* L = S + (size_t)r * np + k;
-      double s = 0;
-#pragma unroll
-      for (int c = 0; c < NB; c++) s += L[c] * s_y[c];
-      y[r] -= s;
-    }
-    __syncthreads();
-  }
-  for (int k = np - NB; k >= 0; k -= NB) {    // L^T x = z
-    if (tid < 64) {
-      double v = (tid < NB) ? y[k + tid] : 0.0;
-      for (int j = NB - 1; j >= 0; j--) {
-        double xj = __shfl(v, j) / S[(size_t)(k + j) * np + k + j];
-        if (tid == j) v = xj;
-        if (tid < j) v -= S[(size_t)(k + j) * np + k + tid] * xj;
-      }
-      if (tid < NB) { s_y[tid] = v; y[k + tid] = v; }
-    }
-    __syncthreads();
+    if (tid < NB) s_y[k + tid] = s_x[tid];
     for (int c = tid; c < k; c += 256) {
-      double s = 0;
+      double sum = 0;
 #pragma unroll
-      for (int r = 0; r < NB; r++) s += S[(size_t)(k + r) * np + c] * s_y[r];
-      y[c] -= s;
+      for (int r = 0; r < NB; r++) sum += S[(size_t)(k + r) * np + c] * s_x[r];
+      s_y[c] -= sum;
     }
     __syncthreads();
   }
+  for (int i = tid; i < np; i += 256) D.rhs[i] = s_y[i];
 }
 
 // ---- candidate cameras: x+ = Plus(x, -y * scale); partial |dx|^2 -------------------------------------------
@@ -753,7 +834,7 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_backsub(BaDev D, int part_off) {
         const double* y = D.rhs + 6 * cc;
         for (int v = 0; v < 3; v++) {
           double s = 0;
-          for (int u = 0; u < 6; u++) s += D.E[(3 * u + v) * n + i] * y[u];
+          for (int u = 0; u < 6; u++) s += D.E[18 * (size_t)i + 3 * u + v] * y[u];
           t[v] -= s;
         }
       }
@@ -846,19 +927,53 @@ using namespace orbhip;
 // ============================================================================ host driver
 namespace {
 
-struct HostBA {
-  std::vector<DevBuf*> bufs;
-  ~HostBA() { for (DevBuf* b : bufs) { b->release(); delete b; } }
-  template <typename T> T* alloc(size_t count, int* rc) {
-    DevBuf* b = new DevBuf();
-    bufs.push_back(b);
-    int r = b->ensure(std::max<size_t>(count * sizeof(T), 16));
-    if (r && !*rc) *rc = r;
-    return b->as<T>();
+// growable device workspace, reused across calls on the same host thread (slot order = allocation order)
+struct PinnedBuf {
+  void* p = nullptr; size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return 0;
+    if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    size_t want = need + need / 4;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; set_error("hipHostMalloc(%zu) failed", want); return ORBHIP_ENOMEM; }
+    bytes = want;
+    return 0;
   }
-  template <typename T> T* upload(const T* src, size_t count, int* rc) {
+};
+struct BaWorkspace {
+  std::vector<DevBuf> slots;
+  std::vector<PinnedBuf> hslots;
+  // no destructor: freeing device memory from a thread_local destructor can run after the HIP runtime has
+  // shut down (observed as a hang at process exit under rocprofv3); the process teardown reclaims it.
+};
+static thread_local BaWorkspace g_ws;
+// one non-blocking stream per host thread: independent solves issued from different threads overlap on the GPU
+static thread_local hipStream_t g_stream = nullptr;
+static hipStream_t thread_stream() {
+  if (!g_stream) { if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr; }
+  return g_stream;
+}
+
+struct HostBA {
+  size_t next = 0, hnext = 0;
+  // pinned host staging (reused across calls): structure arrays are built straight into it so that the
+  // H2D copies are true async DMA and never touch freshly mmap'ed pageable pages
+  template <typename T> T* pinned(size_t count, int* rc) {
+    if (hnext >= g_ws.hslots.size()) g_ws.hslots.resize(hnext + 1);
+    PinnedBuf& b = g_ws.hslots[hnext++];
+    int r = b.ensure(std::max<size_t>(count * sizeof(T), 16));
+    if (r && !*rc) *rc = r;
+    return (T*)b.p;
+  }
+  template <typename T> T* alloc(size_t count, int* rc) {
+    if (next >= g_ws.slots.size()) g_ws.slots.resize(next + 1);
+    DevBuf& b = g_ws.slots[next++];
+    int r = b.ensure(std::max<size_t>(count * sizeof(T), 16));
+    if (r && !*rc) *rc = r;
+    return b.as<T>();
+  }
+  template <typename T> T* upload(const T* src, size_t count, int* rc, hipStream_t st = 0) {
     T* d = alloc<T>(count, rc);
-    if (!*rc && count) { if (hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy H2D failed"); *rc = ORBHIP_ENODEV; } }
+    if (!*rc && count) { if (hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); *rc = ORBHIP_ENODEV; } }
     return d;
   }
 };
@@ -873,22 +988,31 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
   for (int i = 0; i < nobs; i++)
     ORBHIP_REQUIRE(obs_cam_in[i] >= 0 && obs_cam_in[i] < ncam && obs_pt_in[i] >= 0 && obs_pt_in[i] < npts, ORBHIP_EINVAL, "observation index out of range");
+  const bool timing = std::getenv("ORBHIP_BA_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = tnow();
   // ---- structure (host, O(nobs)): group observations by point (stable), per-camera lists ---------
-  std::vector<int> pt_off(npts + 1, 0);
+  HostBA H; int rc = 0;
+  int* pt_off = H.pinned<int>(npts + 1, &rc);
+  int* oc = H.pinned<int>(nobs, &rc); int* op = H.pinned<int>(nobs, &rc);
+  double* ouv = H.pinned<double>(2 * (size_t)nobs, &rc); double* ow = H.pinned<double>(nobs, &rc);
+  uint8_t* orb = H.pinned<uint8_t>(nobs, &rc);
+  int* cam_off = H.pinned<int>(ncam + 1, &rc); int* cam_obs = H.pinned<int>(nobs, &rc); int* cam_obs_pt = H.pinned<int>(nobs, &rc);
+  if (rc) return rc;
+  for (int p = 0; p <= npts; p++) pt_off[p] = 0;
   for (int i = 0; i < nobs; i++) pt_off[obs_pt_in[i] + 1]++;
   for (int p = 0; p < npts; p++) pt_off[p + 1] += pt_off[p];
-  std::vector<int> perm(nobs), fill(pt_off.begin(), pt_off.end() - 1);
+  std::vector<int> perm(nobs), fill(pt_off, pt_off + npts);
   for (int i = 0; i < nobs; i++) perm[fill[obs_pt_in[i]]++] = i;
-  std::vector<int> oc(nobs), op(nobs); std::vector<double> ouv(2 * (size_t)nobs), ow(nobs); std::vector<uint8_t> orb(nobs);
   for (int j = 0; j < nobs; j++) {
     const int i = perm[j];
     oc[j] = obs_cam_in[i]; op[j] = obs_pt_in[i]; ouv[2 * (size_t)j] = obs_uv_in[2 * (size_t)i]; ouv[2 * (size_t)j + 1] = obs_uv_in[2 * (size_t)i + 1];
     ow[j] = obs_w_in[i]; orb[j] = obs_robust_in[i];
   }
-  std::vector<int> cam_off(ncam + 1, 0);
+  for (int c = 0; c <= ncam; c++) cam_off[c] = 0;
   for (int j = 0; j < nobs; j++) cam_off[oc[j] + 1]++;
   for (int c = 0; c < ncam; c++) cam_off[c + 1] += cam_off[c];
-  std::vector<int> cam_obs(nobs), cam_obs_pt(nobs), cfill(cam_off.begin(), cam_off.end() - 1);
+  std::vector<int> cfill(cam_off, cam_off + ncam);
   for (int j = 0; j < nobs; j++) { int e = cfill[oc[j]]++; cam_obs[e] = j; cam_obs_pt[e] = op[j]; }
   std::vector<int> cam_col(ncam, -1), free_cams;
   for (int c = 0; c < ncam; c++) if (!cam_fixed[c] && cam_off[c + 1] > cam_off[c]) { cam_col[c] = (int)free_cams.size(); free_cams.push_back(c); }
@@ -896,36 +1020,78 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
   const int n6 = 6 * nfc, npad = std::max(round_up(n6, NB), NB);
   const int nb_obs = std::max((nobs + BA_TPB - 1) / BA_TPB, 1), nb_cam = (ncam + BA_TPB - 1) / BA_TPB, nb_pt = std::max((npts + BA_TPB - 1) / BA_TPB, 1);
   const int nparts = std::max(nb_obs, std::max(nb_cam, nb_pt));
+  // Schur block pair lists: for every point, all ordered observation pairs (i, j) with col_i <= col_j,
+  // grouped by block (col_i, col_j) with a counting sort (stable: point order, then list order).
+  std::vector<int> blk_a, blk_b, blk_off;
+  int* pair_i = nullptr; int* pair_j = nullptr; size_t npairs_all = 0;
+  if (!opts->fix_points && nfc > 0) {
+    std::vector<int> cnt((size_t)nfc * nfc + 1, 0);
+    for (int p = 0; p < npts; p++)
+      for (int i = pt_off[p]; i < pt_off[p + 1]; i++) {
+        const int ci = cam_col[oc[i]];
+        if (ci < 0) continue;
+        for (int j = pt_off[p]; j < pt_off[p + 1]; j++) { const int cj = cam_col[oc[j]]; if (cj >= ci) cnt[(size_t)ci * nfc + cj + 1]++; }
+      }
+    for (size_t k = 0; k < (size_t)nfc * nfc; k++) cnt[k + 1] += cnt[k];
+    const int npairs_tot = cnt[(size_t)nfc * nfc];
+    npairs_all = (size_t)npairs_tot;
+    pair_i = H.pinned<int>(npairs_all, &rc); pair_j = H.pinned<int>(npairs_all, &rc);
+    if (rc) return rc;
+    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    for (int p = 0; p < npts; p++)
+      for (int i = pt_off[p]; i < pt_off[p + 1]; i++) {
+        const int ci = cam_col[oc[i]];
+        if (ci < 0) continue;
+        for (int j = pt_off[p]; j < pt_off[p + 1]; j++) {
+          const int cj = cam_col[oc[j]];
+          if (cj >= ci) { const int e = pos[(size_t)ci * nfc + cj]++; pair_i[e] = i; pair_j[e] = j; }
+        }
+      }
+    blk_off.push_back(0);
+    for (int a = 0; a < nfc; a++)
+      for (int b2 = a; b2 < nfc; b2++) {
+        const size_t k = (size_t)a * nfc + b2;
+        if (cnt[k + 1] > cnt[k] || a == b2) { blk_a.push_back(a); blk_b.push_back(b2); blk_off.push_back(cnt[k + 1]); }
+      }
+  } else {
+    blk_off.push_back(0);
+    for (int a = 0; a < nfc; a++) { blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(0); }
+  }
+  const int nblk = (int)blk_a.size();
+  const double t_struct = tnow();
 
-  HostBA H; int rc = 0;
+  hipStream_t s = thread_stream();
   BaDev D; std::memset(&D, 0, sizeof(D));
-  D.ncam = ncam; D.npts = npts; D.nobs = nobs; D.nfc = nfc; D.n6 = n6; D.npad = npad; D.nparts = nparts;
+  D.ncam = ncam; D.npts = npts; D.nobs = nobs; D.nfc = nfc; D.n6 = n6; D.npad = npad; D.nparts = nparts; D.nblk = nblk;
   D.fix_points = opts->fix_points ? 1 : 0; D.huber = opts->huber_delta;
-  D.K4 = H.upload(K4, 4 * (size_t)ncam, &rc); D.cam_fixed = H.upload(cam_fixed, ncam, &rc); D.cam_col = H.upload(cam_col.data(), ncam, &rc);
-  D.poses = H.upload(poses7, 7 * (size_t)ncam, &rc); D.pts = H.upload(pts3, 3 * (size_t)npts, &rc);
+  D.K4 = H.upload(K4, 4 * (size_t)ncam, &rc, s); D.cam_fixed = H.upload(cam_fixed, ncam, &rc, s); D.cam_col = H.upload(cam_col.data(), ncam, &rc, s);
+  D.poses = H.upload(poses7, 7 * (size_t)ncam, &rc, s); D.pts = H.upload(pts3, 3 * (size_t)npts, &rc, s);
   D.cand_poses = H.alloc<double>(7 * (size_t)ncam, &rc); D.cand_pts = H.alloc<double>(3 * (size_t)npts, &rc);
-  D.obs_cam = H.upload(oc.data(), nobs, &rc); D.obs_pt = H.upload(op.data(), nobs, &rc); D.obs_uv = H.upload(ouv.data(), 2 * (size_t)nobs, &rc);
-  D.obs_w = H.upload(ow.data(), nobs, &rc); D.obs_robust = H.upload(orb.data(), nobs, &rc);
-  D.pt_off = H.upload(pt_off.data(), npts + 1, &rc); D.cam_off = H.upload(cam_off.data(), ncam + 1, &rc);
-  D.cam_obs = H.upload(cam_obs.data(), nobs, &rc); D.cam_obs_pt = H.upload(cam_obs_pt.data(), nobs, &rc);
-  const int* d_free = H.upload(free_cams.data(), nfc, &rc);
+  D.obs_cam = H.upload(oc, nobs, &rc, s); D.obs_pt = H.upload(op, nobs, &rc, s); D.obs_uv = H.upload(ouv, 2 * (size_t)nobs, &rc, s);
+  D.obs_w = H.upload(ow, nobs, &rc, s); D.obs_robust = H.upload(orb, nobs, &rc, s);
+  D.pt_off = H.upload(pt_off, npts + 1, &rc, s); D.cam_off = H.upload(cam_off, ncam + 1, &rc, s);
+  D.cam_obs = H.upload(cam_obs, nobs, &rc, s); D.cam_obs_pt = H.upload(cam_obs_pt, nobs, &rc, s);
+  const int* d_free = H.upload(free_cams.data(), nfc, &rc, s);
+  D.blk_a = H.upload(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload(blk_off.data(), nblk + 1, &rc, s);
+  D.pair_i = H.upload(pair_i, npairs_all, &rc, s); D.pair_j = H.upload(pair_j, npairs_all, &rc, s);
   D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jc = H.alloc<double>(12 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
   D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
   D.C = H.alloc<double>(6 * (size_t)npts, &rc); D.gp = H.alloc<double>(3 * (size_t)npts, &rc);
   D.scale_c = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc); D.scale_p = H.alloc<double>(3 * (size_t)npts, &rc);
   D.Cinv = H.alloc<double>(6 * (size_t)npts, &rc); D.gps = H.alloc<double>(3 * (size_t)npts, &rc);
   D.E = H.alloc<double>(18 * (size_t)nobs, &rc); D.EC = H.alloc<double>(18 * (size_t)nobs, &rc);
-  D.S = H.alloc<double>((size_t)npad * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
+  D.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
+  D.Dinv = H.alloc<double>((size_t)npad * NB, &rc);
   D.part = H.alloc<double>(5 * (size_t)nparts, &rc);
   D.st = H.alloc<BaState>(1, &rc);
   if (rc) return rc;
   BaState st0; std::memset(&st0, 0, sizeof(st0));
   st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = opts->max_iterations;
-  ORBHIP_CHECK_HIP(hipMemcpy(D.st, &st0, sizeof(st0), hipMemcpyHostToDevice));
-  ORBHIP_CHECK_HIP(hipMemset(D.S, 0, (size_t)npad * npad * sizeof(double)));
-  ORBHIP_CHECK_HIP(hipMemset(D.rhs, 0, (size_t)npad * sizeof(double)));
-  ORBHIP_CHECK_HIP(hipMemset(D.part, 0, 5 * (size_t)nparts * sizeof(double)));
-  hipStream_t s = 0;
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
+  ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)npad * sizeof(double), s));
+  ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)nparts * sizeof(double), s));
+  if (npad > n6) hipLaunchKernelGGL(k_ba_pad, dim3(npad - n6), dim3(64), 0, s, D);
+  const double t_upload = tnow();
   auto enqueue_eval = [&]() {
     hipLaunchKernelGGL(k_ba_eval, dim3(nb_obs), dim3(BA_TPB), 0, s, D, 0);
     if (ncam > 0) hipLaunchKernelGGL(k_ba_cam_blocks, dim3(ncam), dim3(BA_TPB), 0, s, D);
@@ -935,21 +1101,21 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
   const volatile uint8_t* stop = opts->stop_flag;
   enqueue_eval();                                             // iteration 0
   bool user_stop = stop && *stop;                             // StopFlagCallback after iteration 0
-  const long long npairs = (long long)nfc * (nfc + 1) / 2;
   for (int it = 0; it < opts->max_iterations + 1 && !user_stop; it++) {
     hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1), 0, s, D);
     hipLaunchKernelGGL(k_ba_schur_prep, dim3(nb_pt), dim3(BA_TPB), 0, s, D);
-    if (npairs > 0) hipLaunchKernelGGL(k_ba_schur, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, s, D, d_free);
-    if (npad > n6) hipLaunchKernelGGL(k_ba_pad, dim3(1), dim3(64), 0, s, D);
+    hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(nb_obs), dim3(BA_TPB), 0, s, D);
+    if (n6 > 0) hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)(((size_t)n6 * npad + 255) / 256))), dim3(256), 0, s, D);
+    if (nblk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, s, D, d_free);
     for (int k = 0; k < npad; k += NB) {
       const int rows_below = npad - k - NB;
-      hipLaunchKernelGGL(k_chol_panel, dim3(std::max((rows_below + 255) / 256, 1)), dim3(256), 0, s, D, k);
+      hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 1 + 63) / 64), dim3(256), 0, s, D, k);   // +1: augmented rhs row
       if (rows_below > 0) {
         const int T = (rows_below + 63) / 64;
-        hipLaunchKernelGGL(k_chol_syrk, dim3(T * (T + 1) / 2), dim3(256), 0, s, D, k);
+        hipLaunchKernelGGL(k_chol_syrk, dim3(T * (T + 1) / 2 + (rows_below + 255) / 256), dim3(256), 0, s, D, k, T * (T + 1) / 2);
       }
     }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), 0, s, D);
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), (size_t)npad * sizeof(double), s, D);
     hipLaunchKernelGGL(k_ba_cam_update, dim3(std::max(nb_cam, 1)), dim3(BA_TPB), 0, s, D);
     hipLaunchKernelGGL(k_ba_backsub, dim3(nb_pt), dim3(BA_TPB), 0, s, D, 0);
     hipLaunchKernelGGL(k_ba_eval, dim3(nb_obs), dim3(BA_TPB), 0, s, D, 1);
@@ -957,18 +1123,22 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
     hipLaunchKernelGGL(k_ba_apply, dim3((std::max(7 * ncam, 3 * npts) + BA_TPB - 1) / BA_TPB), dim3(BA_TPB), 0, s, D);
     enqueue_eval();
     if (stop && *stop) user_stop = true;
-    if ((it & 3) == 3) {                                      // converged early? (cheap poll every 4 iterations)
+    if ((it & 7) == 7 && it + 8 < opts->max_iterations) {     // converged early? (poll every 8 iterations of long solves)
       BaState cur;
-      ORBHIP_CHECK_HIP(hipMemcpy(&cur, D.st, sizeof(cur), hipMemcpyDeviceToHost));
+      ORBHIP_CHECK_HIP(hipMemcpyAsync(&cur, D.st, sizeof(cur), hipMemcpyDeviceToHost, s));
+      ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
       if (cur.done) break;
     }
   }
+  const double t_enq = tnow();
   if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1), dim3(1), 0, s, D);
   ORBHIP_CHECK_HIP(hipGetLastError());
   BaState fin;
-  ORBHIP_CHECK_HIP(hipMemcpy(&fin, D.st, sizeof(fin), hipMemcpyDeviceToHost));
-  ORBHIP_CHECK_HIP(hipMemcpy(poses7, D.poses, 7 * (size_t)ncam * sizeof(double), hipMemcpyDeviceToHost));
-  if (npts) ORBHIP_CHECK_HIP(hipMemcpy(pts3, D.pts, 3 * (size_t)npts * sizeof(double), hipMemcpyDeviceToHost));
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(&fin, D.st, sizeof(fin), hipMemcpyDeviceToHost, s));
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(poses7, D.poses, 7 * (size_t)ncam * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (npts) ORBHIP_CHECK_HIP(hipMemcpyAsync(pts3, D.pts, 3 * (size_t)npts * sizeof(double), hipMemcpyDeviceToHost, s));
+  ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+  if (timing) fprintf(stderr, "[ba_solve] nobs=%d pairs=%zu blocks=%d | structure %.2f ms, upload %.2f ms, enqueue %.2f ms, drain+download %.2f ms\n", nobs, npairs_all, nblk, t_struct - t_start, t_upload - t_struct, t_enq - t_upload, tnow() - t_enq);
   if (summary) {
     summary->initial_cost = fin.initial_cost; summary->final_cost = fin.x_cost; summary->iterations = fin.iteration;
     summary->successful_steps = fin.successful_steps; summary->termination = fin.termination; summary->final_radius = fin.radius;

@@ -1,5 +1,5 @@
-import numpy as np, sys
-sys.path.insert(0,'.')
+import numpy as np, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ceres_mono_orb_slam2_amd import synth, optimizer
 from oracle import pyoracle as po
 g = synth.make_ba_graph(3, ncam=25, npts=1500, nobs=7000, n_fixed=2)
