@@ -126,10 +126,8 @@ def main():
     stage_ms, ncalls = ex.stage_ms()
     ex.set_profiling(False)
     match_ms = sum(a.elapsed_time(b) for a, b in ev)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from ceres_mono_orb_slam2_amd import sharding
+    dt = sharding.max_over_ranks(dt, device=dev)
 
     # sanity of the timed work (not timed): every frame produced keypoints and matches
     c = counts.cpu().numpy(); nm = nmatch.cpu().numpy()

@@ -1,0 +1,52 @@
+"""Multi-GPU sharding of the hot path.
+
+Frames (front-end) and independent BA sub-problems shard embarrassingly: one process per GPU, no
+data-path collective.  The only exchange step is the merge of landmark (and pose) updates after a
+batched GlobalBA so that every rank holds the whole map: ONE all-gather (RCCL over xGMI on GPUs,
+gloo in the CPU tests).  Payload at C5 size is 8 x ~50k points x 24 B = 9.6 MB: latency-bound."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous sub-sequence [lo, hi) of rank `rank` (consecutive frames stay co-resident so that the
+    frame t / t+1 match never crosses ranks)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def max_over_ranks(seconds, device=None):
+    """bench.py contract: the step time is the MAX over ranks."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allgather_landmarks(local_pts, local_ids=None):
+    """Merge the landmark updates of every rank's sub-map with a single all-gather.
+    local_pts: (n_local, 3) float64 tensor (n_local may differ per rank); local_ids: optional (n_local,) int64
+    global landmark ids.  Returns (pts_all (sum n, 3), ids_all or None, counts per rank)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return local_pts, local_ids, [local_pts.shape[0]]
+    dev = local_pts.device
+    n = torch.tensor([local_pts.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)                       # 8-byte size exchange (needed because sub-maps are ragged)
+    counts = [int(c.item()) for c in counts]
+    cap = max(counts)
+    width = 4 if local_ids is not None else 3        # ids ride in the same payload (bit-cast to float64)
+    buf = torch.zeros((cap, width), dtype=torch.float64, device=dev)
+    buf[:local_pts.shape[0], :3] = local_pts
+    if local_ids is not None:
+        buf[:local_pts.shape[0], 3] = local_ids.to(torch.int64).view(torch.float64)
+    out = torch.empty((world, cap, width), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out.view(-1), buf.view(-1))      # THE collective (ncclAllGather over xGMI)
+    pts = torch.cat([out[r, :counts[r], :3] for r in range(world)])
+    ids = None
+    if local_ids is not None:
+        ids = torch.cat([out[r, :counts[r], 3].contiguous().view(torch.int64) for r in range(world)])
+    return pts, ids, counts

