@@ -103,19 +103,22 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 }
 
 // ---------------------------------------------------------------------------- k_fast_cells
-// max over the sixteen 9-arcs of min over the arc of d[k]  (sliding-window min by doubling)
-__device__ __forceinline__ int arc9_maxmin(const int d[16]) {
-  int m2[16], m4[16], m8[16];
+// FAST-9 "best" of one pixel for BOTH polarities at once with packed 16-bit min/max (v_pk_min_i16):
+// lane .x carries d[k] = p - ring[k] (ring darker), lane .y carries -d[k] (ring brighter).  For each
+// polarity: max over the sixteen 9-arcs of the min over the arc (sliding-window min by doubling).
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int arc9_best_packed(const short2_t d[16]) {
+  short2_t m2[16], m4[16], m8[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
+  for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
 #pragma unroll
-  for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+  for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
 #pragma unroll
-  for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
-  int best = -1000;
+  for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+  short2_t best = {-1000, -1000};
 #pragma unroll
-  for (int k = 0; k < 16; k++) best = max(best, min(m8[k], d[(k + 8) & 15]));
-  return best;
+  for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
+  return max((int)best.x, (int)best.y);
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(GeomDev G, const CellDesc* __restrict__ cells,
@@ -123,98 +126,114 @@ __global__ __launch_bounds__(256) void k_fast_cells(GeomDev G, const CellDesc* _
                                                     const uint8_t* __restrict__ pyr, int* __restrict__ cell_cnt,
                                                     uint32_t* __restrict__ cell_kps, int iniTh, int minTh) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int TP = G.tile_pitch;
+  const int TP = G.tile_pitch;                        // multiple of 4
+  const int plane = G.tile_h * TP;                    // multiple of 4
   uint8_t* tile = smem;                               // [tile_h][TP]
-  uint8_t* score = smem + (size_t)G.tile_h * TP;      // [tile_h][TP]
-  uint8_t* flag = score + (size_t)G.tile_h * TP;      // [tile_h][TP]
-  __shared__ int s_n20, s_wcnt[4], s_base;
-  const int tid = threadIdx.x;
+  uint8_t* score = smem + plane;                      // [tile_h][TP]
+  uint8_t* flag = score + plane;                      // [tile_h][TP]
+  unsigned short* queue = (unsigned short*)(flag + plane);   // [tile_h*TP] pixels that passed the pre-test
+  __shared__ int s_n20, s_qn, s_rowoff[65];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ci = blockIdx.x, f = blockIdx.y;
   const CellDesc c = cells[ci];
   const LevelDev& L = G.lv[c.level];
   const uint8_t* src = level_ptr(G, c.level, f, img0, img_frame_bytes, pyr);
   const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
-  if (tid == 0) { s_n20 = 0; s_base = 0; }
-  // ---- stage the cell (incl. its 3-px apron) in LDS ----------------------------------------
-  for (int i = tid; i < tw * th; i += 256) {
-    int y = i / tw, x = i - y * tw;
-    tile[y * TP + x] = src[(long long)(c.y0 + y) * L.pitch + c.x0 + x];
-    score[y * TP + x] = 0;
-    flag[y * TP + x] = 0;
-  }
+  if (tid == 0) { s_n20 = 0; s_qn = 0; }
+  // ---- stage the cell (incl. its 3-px apron) in LDS; 64 lanes across x, 4 rows per pass --------
+  for (int i = tid; i < (2 * plane) >> 2; i += 256) ((uint32_t*)score)[i] = 0u;     // score + flag planes
+  if (lane < tw)
+    for (int y = wv; y < th; y += 4) tile[y * TP + lane] = src[(long long)(c.y0 + y) * L.pitch + c.x0 + lane];
   __syncthreads();
   const int iw = tw - 6, ih = th - 6;
-  const int npx = (iw > 0 && ih > 0) ? iw * ih : 0;
-  // ---- FAST-9 score at the LOW threshold; one map serves both thresholds --------
-  for (int i = tid; i < npx; i += 256) {
-    int iy = i / iw, ix = i - iy * iw;
+  // ---- pass A: compass pre-test (any 9-arc contains >= 2 adjacent compass points); survivors are
+  //      queued so that the expensive score runs on dense lanes (no divergence waste) -----------------
+  for (int iy = tid >> 5; iy < ih; iy += 8)
+    for (int ix0 = 0; ix0 < iw; ix0 += 32) {
+      const int ix = ix0 + (tid & 31);
+      bool pass = false;
+      if (ix < iw) {
+        const uint8_t* p = tile + (iy + 3) * TP + ix + 3;
+        const int v = p[0];
+        const int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
+        const int hi = v + minTh, lo = v - minTh;
+        const int nb = (c0 > hi) + (c4 > hi) + (c8 > hi) + (c12 > hi);
+        const int nd = (c0 < lo) + (c4 < lo) + (c8 < lo) + (c12 < lo);
+        pass = (nb >= 2) || (nd >= 2);
+      }
+      const unsigned long long bal = __ballot(pass);
+      int base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&s_qn, __popcll(bal));
+      base = __shfl(base, 0);
+      if (pass) queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((iy << 8) | ix);
+    }
+  __syncthreads();
+  // ---- pass B: FAST-9 score at the LOW threshold; one map serves both thresholds --------
+  const int qn = s_qn;
+  for (int k = tid; k < qn; k += 256) {
+    const int q = queue[k], iy = q >> 8, ix = q & 255;
     const uint8_t* p = tile + (iy + 3) * TP + ix + 3;
     const int v = p[0];
-    // compass pre-test: any 9-arc contains >= 2 adjacent compass points
-    int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
-    int hi = v + minTh, lo = v - minTh;
-    int nb = (c0 > hi) + (c4 > hi) + (c8 > hi) + (c12 > hi);
-    int nd = (c0 < lo) + (c4 < lo) + (c8 < lo) + (c12 < lo);
-    if (nb < 2 && nd < 2) continue;
-    int d[16], e[16];
-    d[0] = v - p[3 * TP];       d[1] = v - p[3 * TP + 1];  d[2] = v - p[2 * TP + 2];  d[3] = v - p[TP + 3];
-    d[4] = v - p[3];            d[5] = v - p[-TP + 3];     d[6] = v - p[-2 * TP + 2]; d[7] = v - p[-3 * TP + 1];
-    d[8] = v - p[-3 * TP];      d[9] = v - p[-3 * TP - 1]; d[10] = v - p[-2 * TP - 2]; d[11] = v - p[-TP - 3];
-    d[12] = v - p[-3];          d[13] = v - p[TP - 3];     d[14] = v - p[2 * TP - 2]; d[15] = v - p[3 * TP - 1];
-#pragma unroll
-    for (int k = 0; k < 16; k++) e[k] = -d[k];
-    int best = max(arc9_maxmin(d), arc9_maxmin(e));   // corner at t  <=>  best > t ; score = best - 1
+    short2_t d[16];
+    auto mk = [&](int r) { const short dd = (short)(v - r); short2_t t = {dd, (short)(-dd)}; return t; };
+    d[0] = mk(p[3 * TP]);         d[1] = mk(p[3 * TP + 1]);   d[2] = mk(p[2 * TP + 2]);   d[3] = mk(p[TP + 3]);
+    d[4] = mk(p[3]);              d[5] = mk(p[-TP + 3]);      d[6] = mk(p[-2 * TP + 2]);  d[7] = mk(p[-3 * TP + 1]);
+    d[8] = mk(p[-3 * TP]);        d[9] = mk(p[-3 * TP - 1]);  d[10] = mk(p[-2 * TP - 2]); d[11] = mk(p[-TP - 3]);
+    d[12] = mk(p[-3]);            d[13] = mk(p[TP - 3]);      d[14] = mk(p[2 * TP - 2]);  d[15] = mk(p[3 * TP - 1]);
+    const int best = arc9_best_packed(d);             // corner at t  <=>  best > t ; score = best - 1
     if (best > minTh) score[(iy + 3) * TP + ix + 3] = (uint8_t)(best - 1);
   }
   __syncthreads();
-  // ---- 3x3 non-max suppression inside the cell (frame pixels score 0) -----------------------
+  // ---- 3x3 non-max suppression inside the cell (frame pixels score 0), again only on queued pixels ----
   int my20 = 0;
-  for (int i = tid; i < npx; i += 256) {
-    int iy = i / iw, ix = i - iy * iw;
-    const uint8_t* s = score + (iy + 3) * TP + ix + 3;
-    int v = s[0];
+  for (int k = tid; k < qn; k += 256) {
+    const int q = queue[k], iy = q >> 8, ix = q & 255;
+    const uint8_t* sp = score + (iy + 3) * TP + ix + 3;
+    const int v = sp[0];
     if (v == 0) continue;
-    bool keep = v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] && v > s[-1] && v > s[1] && v > s[TP - 1] &&
-                v > s[TP] && v > s[TP + 1];
+    const bool keep = v > sp[-TP - 1] && v > sp[-TP] && v > sp[-TP + 1] && v > sp[-1] && v > sp[1] && v > sp[TP - 1] &&
+                      v > sp[TP] && v > sp[TP + 1];
     if (keep) {
-      int is20 = v >= iniTh;
+      const int is20 = v >= iniTh;
       flag[(iy + 3) * TP + ix + 3] = (uint8_t)(1 + is20);
       my20 += is20;
     }
   }
   if (my20) atomicAdd(&s_n20, my20);
   __syncthreads();
-  // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816) -----------------
+  // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816); one wave per row ----
   const int want_min = (s_n20 > 0) ? 2 : 1;
   uint32_t* out = cell_kps + ((long long)f * G.ncells_total + ci) * G.cell_cap;
-  const int lane = tid & 63, wv = tid >> 6;
-  for (int base_i = 0; base_i < npx; base_i += 256) {
-    int i = base_i + tid;
-    bool emit = false;
-    int iy = 0, ix = 0;
-    if (i < npx) {
-      iy = i / iw; ix = i - iy * iw;
-      emit = flag[(iy + 3) * TP + ix + 3] >= want_min;
-    }
-    unsigned long long bal = __ballot(emit);
-    if (lane == 0) s_wcnt[wv] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, tot = 0;
+  unsigned long long bal[16];                           // rows wv, wv+4, ...  (ih <= 58 -> at most 15 rows per wave)
 #pragma unroll
-    for (int k = 0; k < 4; k++) { int cnum = s_wcnt[k]; if (k < wv) woff += cnum; tot += cnum; }
-    int base = s_base;
-    if (emit) {
-      int pos = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+  for (int k = 0; k < 16; k++) {
+    const int iy = wv + 4 * k;
+    bool emit = false;
+    if (iy < ih && lane < iw) emit = flag[(iy + 3) * TP + lane + 3] >= want_min;
+    bal[k] = __ballot(emit);
+    if (lane == 0 && iy < ih) s_rowoff[iy + 1] = __popcll(bal[k]);
+  }
+  __syncthreads();
+  if (tid < 64) {                                       // exclusive prefix over <= 58 row counts (one wave)
+    int v = (tid >= 1 && tid <= ih) ? s_rowoff[tid] : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (tid >= o) v += t; }
+    s_rowoff[tid] = v;                                  // s_rowoff[r] = #emitted in rows < r ; s_rowoff[ih] = total
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int iy = wv + 4 * k;
+    if (iy >= ih) break;
+    if ((bal[k] >> lane) & 1ull) {
+      const int pos = s_rowoff[iy] + __popcll(bal[k] & ((1ull << lane) - 1ull));
       if (pos < G.cell_cap) {
-        uint32_t x = (uint32_t)(ix + 3 + c.offx), y = (uint32_t)(iy + 3 + c.offy);
-        out[pos] = x | (y << 12) | ((uint32_t)score[(iy + 3) * TP + ix + 3] << 24);
+        const uint32_t x = (uint32_t)(lane + 3 + c.offx), y = (uint32_t)(iy + 3 + c.offy);
+        out[pos] = x | (y << 12) | ((uint32_t)score[(iy + 3) * TP + lane + 3] << 24);
       }
     }
-    __syncthreads();
-    if (tid == 0) s_base = base + tot;
-    __syncthreads();
   }
-  if (tid == 0) cell_cnt[(long long)f * G.ncells_total + ci] = s_base;
+  if (tid == 0) cell_cnt[(long long)f * G.ncells_total + ci] = (ih > 0 && iw > 0) ? s_rowoff[ih] : 0;
 }
 
 // ---------------------------------------------------------------------------- k_octree
@@ -462,52 +481,71 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
 
 // ---------------------------------------------------------------------------- k_blur7
 #define BLUR_TW 128
-#define BLUR_TH 16
+#define BLUR_TH 32
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (n == 1) return 0;
   while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
   return i;
 }
+// 128 x 32 output tile per workgroup.  Row pass straight from global memory (each thread: 4 outputs
+// from 10 source bytes = 3 aligned dwords when the row pitch allows) into a u16 LDS plane
+// (255*257 fits 16 bits); column pass reads 7 x ds_read_b64 per 4 outputs and stores one dword.
 __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __restrict__ tiles,
                                                const uint8_t* __restrict__ img0, long long img_frame_bytes,
                                                const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-  __shared__ uint8_t s_src[BLUR_TH + 6][BLUR_TW + 8];
-  __shared__ unsigned short s_mid[BLUR_TH + 6][BLUR_TW];
+  __shared__ __attribute__((aligned(16))) unsigned short s_mid[BLUR_TH + 6][BLUR_TW];
   const BlurTile t = tiles[blockIdx.x];
   const int f = blockIdx.y, tid = threadIdx.x;
   const LevelDev& L = G.lv[t.level];
   const uint8_t* src = level_ptr(G, t.level, f, img0, img_frame_bytes, pyr);
   uint8_t* dst = blur + (long long)f * G.blur_frame_bytes + L.blur_off;
   const int x0 = t.tx * BLUR_TW, y0 = t.ty * BLUR_TH;
-  for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
-    int yy = i / (BLUR_TW + 6), xx = i - yy * (BLUR_TW + 6);
-    int sy = reflect101(y0 + yy - 3, L.h), sx = reflect101(x0 + xx - 3, L.w);
-    s_src[yy][xx] = src[(long long)sy * L.pitch + sx];
+  const int cg = tid & 31, rr = tid >> 5;            // column group (4 px) / row within a pass of 8 rows
+  const int xo = x0 + 4 * cg;                        // first output column of this thread
+  const bool aligned = ((L.pitch & 3) == 0) && (((size_t)src & 3) == 0);
+  const bool inner = (xo >= 4) && (xo + 8 <= L.w);   // bytes xo-4 .. xo+7 all inside the row
+  for (int yy = rr; yy < BLUR_TH + 6; yy += 8) {
+    const int sy = reflect101(y0 + yy - 3, L.h);
+    const uint8_t* row = src + (long long)sy * L.pitch;
+    int b[10];                                         // source bytes xo-3 .. xo+6
+    if (xo < L.w) {
+      if (inner && aligned) {
+        const uint32_t w0 = *(const uint32_t*)(row + xo - 4), w1 = *(const uint32_t*)(row + xo), w2 = *(const uint32_t*)(row + xo + 4);
+        b[0] = (w0 >> 8) & 255; b[1] = (w0 >> 16) & 255; b[2] = w0 >> 24;
+        b[3] = w1 & 255; b[4] = (w1 >> 8) & 255; b[5] = (w1 >> 16) & 255; b[6] = w1 >> 24;
+        b[7] = w2 & 255; b[8] = (w2 >> 8) & 255; b[9] = (w2 >> 16) & 255;
+      } else if (inner) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) b[k] = row[xo - 3 + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 10; k++) b[k] = row[reflect101(xo - 3 + k, L.w)];
+      }
+      // taps cvRound(g*256) = {18,34,49,55,49,34,18}
+      unsigned short o[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        o[j] = (unsigned short)(18 * (b[j] + b[j + 6]) + 34 * (b[j + 1] + b[j + 5]) + 49 * (b[j + 2] + b[j + 4]) + 55 * b[j + 3]);
+      *(uint2*)&s_mid[yy][4 * cg] = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+    }
   }
   __syncthreads();
-  // taps cvRound(g*256) = {18,34,49,55,49,34,18}; row pass fits 16 bits (255*257)
-  for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
-    int yy = i / BLUR_TW, xx = i - yy * BLUR_TW;
-    const uint8_t* p = &s_src[yy][xx];
-    int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-    s_mid[yy][xx] = (unsigned short)s;
-  }
-  __syncthreads();
-  for (int i = tid; i < BLUR_TH * (BLUR_TW / 4); i += 256) {
-    int yy = i / (BLUR_TW / 4), x4 = (i - yy * (BLUR_TW / 4)) * 4;
-    int y = y0 + yy;
-    if (y >= L.h || x0 + x4 >= L.w) continue;
+  if (xo >= L.w) return;
+  for (int yy = rr; yy < BLUR_TH; yy += 8) {
+    const int y = y0 + yy;
+    if (y >= L.h) break;
+    int acc[4] = {0, 0, 0, 0};
+    const int taps[7] = {18, 34, 49, 55, 49, 34, 18};
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const uint2 m = *(const uint2*)&s_mid[yy + k][4 * cg];
+      acc[0] += taps[k] * (int)(m.x & 0xFFFF); acc[1] += taps[k] * (int)(m.x >> 16);
+      acc[2] += taps[k] * (int)(m.y & 0xFFFF); acc[3] += taps[k] * (int)(m.y >> 16);
+    }
     uint32_t out = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      int xx = x4 + j;
-      int s = 18 * (s_mid[yy][xx] + s_mid[yy + 6][xx]) + 34 * (s_mid[yy + 1][xx] + s_mid[yy + 5][xx]) +
-              49 * (s_mid[yy + 2][xx] + s_mid[yy + 4][xx]) + 55 * s_mid[yy + 3][xx];
-      int v = (s + (1 << 15)) >> 16;
-      v = v > 255 ? 255 : v;
-      out |= (uint32_t)v << (8 * j);
-    }
-    *(uint32_t*)(dst + (long long)y * L.bpitch + x0 + x4) = out;     // bpitch is a multiple of 4 >= w
+    for (int j = 0; j < 4; j++) { int v = (acc[j] + (1 << 15)) >> 16; v = v > 255 ? 255 : v; out |= (uint32_t)v << (8 * j); }
+    *(uint32_t*)(dst + (long long)y * L.bpitch + xo) = out;      // bpitch is a multiple of 64 >= w
   }
 }
 
@@ -813,11 +851,12 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     }
     G.ncells_total = (int)c->cells.size();
     G.cell_cap = cell_cap; G.sel_cap = sel_cap; G.keys_per_frame = key_off;
+    ORBHIP_REQUIRE(tile_w <= 64 && tile_h <= 64, ORBHIP_EINVAL, "FAST cell larger than 64 px (unsupported image geometry)");
     G.tile_w = tile_w; G.tile_h = tile_h; G.tile_pitch = round_up(tile_w, 4) + 4;
     G.node_cap = round_up(node_cap, 8); G.max_cells_level = round_up(max_cells, 8);
     G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
     G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
-    c->fast_lds = (size_t)3 * G.tile_h * G.tile_pitch;
+    c->fast_lds = (size_t)5 * G.tile_h * G.tile_pitch;     // tile + score + flag (u8) + queue (u16)
     c->octree_lds = (size_t)G.node_cap * (8 * 2 + 8 + 8 + 4 + 4 + 2 * 2 + 2 + 2 + 2) + (size_t)(G.max_cells_level + 8) * 4 + 64;
     ORBHIP_REQUIRE(c->octree_lds <= 160 * 1024, ORBHIP_EINVAL, "nfeatures too large for the LDS octree");
     if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
