@@ -71,32 +71,58 @@ __device__ __forceinline__ const uint8_t* level_ptr(const GeomDev& G, int l, int
 }
 
 // ---------------------------------------------------------------------------- k_resize
+// xtab[dx] = {sx | a0 << 16, a1}: source column and the two fixed-point weights of output column dx.
+// Each thread produces 4 output pixels; their <= 7 distinct source columns per row come from three
+// aligned dwords when the source pitch allows (every level >= 1, and level 0 when stride % 4 == 0).
+__device__ __forceinline__ int byte_of(uint32_t w0, uint32_t w1, uint32_t w2, int k) {   // byte k of the 12-byte window
+  const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : w2);
+  return (w >> (8 * (k & 3))) & 255;
+}
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int spitch, long long sframe,
                                                 int sw, int sh, uint8_t* __restrict__ dst, int dpitch,
-                                                long long dframe, int dw, int dh, const int* __restrict__ xofs,
-                                                const short* __restrict__ ialpha, const int* __restrict__ yofs,
-                                                const short* __restrict__ ibeta) {
+                                                long long dframe, int dw, int dh, const uint2* __restrict__ xtab,
+                                                const int* __restrict__ yofs, const short* __restrict__ ibeta) {
   const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
   const int y = blockIdx.y * 4 + threadIdx.y;
   const int f = blockIdx.z;
   if (x4 >= dw || y >= dh) return;
-  int sy = yofs[y];
-  int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+  const int sy = yofs[y];
+  const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
   const uint8_t* S0 = src + (long long)f * sframe + (long long)sy0 * spitch;
   const uint8_t* S1 = src + (long long)f * sframe + (long long)sy1 * spitch;
   const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
-  uint32_t out = 0;
+  int sx[4], a0[4], a1[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    int dx = x4 + j;
-    if (dx < dw) {
-      int sx = xofs[dx];
-      int sx1 = min(sx + 1, sw - 1);
-      int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
-      int H0 = S0[sx] * a0 + S0[sx1] * a1;
-      int H1 = S1[sx] * a0 + S1[sx1] * a1;
-      int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
-      out |= (uint32_t)(v & 255) << (8 * j);
+    const uint2 t = xtab[min(x4 + j, dw - 1)];
+    sx[j] = t.x & 0xFFFF; a0[j] = (int)(short)(t.x >> 16); a1[j] = (int)(short)t.y;
+  }
+  const int base = sx[0] & ~3;
+  const bool fast = ((spitch & 3) == 0) && ((((size_t)S0) & 3) == 0) && (base + 12 <= spitch) && (sx[3] + 1 - base < 12);
+  uint32_t out = 0;
+  if (fast) {
+    const uint32_t p0 = *(const uint32_t*)(S0 + base), p1 = *(const uint32_t*)(S0 + base + 4), p2 = *(const uint32_t*)(S0 + base + 8);
+    const uint32_t q0 = *(const uint32_t*)(S1 + base), q1 = *(const uint32_t*)(S1 + base + 4), q2 = *(const uint32_t*)(S1 + base + 8);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (x4 + j < dw) {
+        const int k0 = sx[j] - base, k1 = min(sx[j] + 1, sw - 1) - base;
+        const int H0 = byte_of(p0, p1, p2, k0) * a0[j] + byte_of(p0, p1, p2, k1) * a1[j];
+        const int H1 = byte_of(q0, q1, q2, k0) * a0[j] + byte_of(q0, q1, q2, k1) * a1[j];
+        const int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v & 255) << (8 * j);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (x4 + j < dw) {
+        const int s0 = sx[j], s1 = min(sx[j] + 1, sw - 1);
+        const int H0 = S0[s0] * a0[j] + S0[s1] * a1[j];
+        const int H1 = S1[s0] * a0[j] + S1[s1] * a1[j];
+        const int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v & 255) << (8 * j);
+      }
     }
   }
   *(uint32_t*)(dst + (long long)f * dframe + (long long)y * dpitch + x4) = out;
@@ -550,7 +576,7 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
 }
 
 // ---------------------------------------------------------------------------- k_describe
-__constant__ signed char c_pattern[1024];
+__constant__ __attribute__((aligned(16))) signed char c_pattern[1024];
 __constant__ int c_umax[16];
 
 // cv::fastAtan2 (degrees), scalar OpenCV 2.4/3.x form, un-contracted
@@ -604,15 +630,22 @@ __global__ __launch_bounds__(256) void k_describe(GeomDev G, const uint32_t* __r
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   int cap, int* __restrict__ counts, float p1, float p3, float p5,
                                                   float p7, float factorPI) {
+  __shared__ uint32_t s_pat[256];                           // pattern pair k = bytes (x0, y0, x1, y1)
+  s_pat[threadIdx.x] = ((const uint32_t*)c_pattern)[threadIdx.x];
+  __syncthreads();
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);      // keypoint index inside the frame
-  // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104)
+  // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104): one lane per level + ballot
   int total = 0, level = -1, pos = 0;
-  for (int l = 0; l < G.nlevels; l++) {
-    int c = min(sel_cnt[f * G.nlevels + l], G.sel_cap);
-    if (level < 0 && i < total + c) { level = l; pos = i - total; }
-    total += c;
+  {
+    int cl = (lane < G.nlevels) ? min(sel_cnt[f * G.nlevels + lane], G.sel_cap) : 0;
+    int incl = cl;
+#pragma unroll
+    for (int o = 1; o < MAX_LEVELS; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    total = __shfl(incl, G.nlevels - 1);
+    const unsigned long long m = __ballot(lane < G.nlevels && i < incl);     // first level whose inclusive prefix exceeds i
+    if (m) { level = __ffsll((long long)m) - 1; pos = i - (__shfl(incl, level) - __shfl(cl, level)); }
   }
   const bool bad = status[f] != 0 || total > cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[f] = bad ? (status[f] != 0 ? -1 : -2) : total;
@@ -645,10 +678,11 @@ __global__ __launch_bounds__(256) void k_describe(GeomDev G, const uint32_t* __r
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int pr = lane * 4 + j;                          // pair index 0..255: bit (pr & 7) of byte (pr >> 3)
+    const uint32_t pw = s_pat[pr];
     int t[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-      float px = (float)c_pattern[4 * pr + 2 * s], py = (float)c_pattern[4 * pr + 2 * s + 1];
+      float px = (float)(signed char)(pw >> (16 * s)), py = (float)(signed char)(pw >> (16 * s + 8));
       float fy = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
       float fx = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
       int iy = __float2int_rn(fy), ix = __float2int_rn(fx);
@@ -837,8 +871,13 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
           std::memcpy(tab.data() + off, p, bytes);
           return off;
         };
-        c->tab_xofs[l] = push(xofs.data(), xofs.size() * 4);
-        c->tab_ialpha[l] = push(ia.data(), ia.size() * 2);
+        std::vector<uint32_t> xt(2 * (size_t)dw);
+        for (int dx = 0; dx < dw; dx++) {
+          xt[2 * dx] = (uint32_t)(xofs[dx] & 0xFFFF) | ((uint32_t)(uint16_t)ia[2 * dx] << 16);
+          xt[2 * dx + 1] = (uint32_t)(uint16_t)ia[2 * dx + 1];
+        }
+        c->tab_xofs[l] = push(xt.data(), xt.size() * 4);
+        c->tab_ialpha[l] = 0;
         c->tab_yofs[l] = push(yofs.data(), yofs.size() * 4);
         c->tab_ibeta[l] = push(ib.data(), ib.size() * 2);
       }
@@ -909,8 +948,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
     dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes), block(64, 4);
     const uint8_t* T = c->d_tab.as<uint8_t>();
     hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, S.pitch, sframe, S.w, S.h, pyr + D.pyr_off, D.pitch,
-                       G.pyr_frame_bytes, D.w, D.h, (const int*)(T + c->tab_xofs[l]),
-                       (const short*)(T + c->tab_ialpha[l]), (const int*)(T + c->tab_yofs[l]),
+                       G.pyr_frame_bytes, D.w, D.h, (const uint2*)(T + c->tab_xofs[l]), (const int*)(T + c->tab_yofs[l]),
                        (const short*)(T + c->tab_ibeta[l]));
   }
   mark();

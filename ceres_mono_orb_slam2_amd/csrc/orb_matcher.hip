@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_dist_csr(const uint8_t* __restrict__ q,
 // ---- fused frame-pair matcher: brute force + acceptance + rotation consistency ------------------
 // one 1024-thread workgroup per pair; targets (<= MP_MAXT) live in LDS.
 #define MP_THREADS 1024
+#define MP_Q 2
 __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint* __restrict__ kps,
                                                             const uint8_t* __restrict__ desc,
                                                             const int* __restrict__ counts, int cap,
@@ -113,31 +114,46 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
   for (int k = tid; k < 2 * n2; k += MP_THREADS) s_t[k] = T[k];
   __syncthreads();
   const float factor = 1.0f / HISTO_LENGTH;
-  for (int i0 = 0; i0 < cap; i0 += MP_THREADS) {
-    const int i = i0 + tid;
-    int res = -1;
-    if (i < n1) {
-      const uint4 q0 = Q[2 * i], q1 = Q[2 * i + 1];
-      int b1 = 256, b2 = 256, bi = -1;
+  // each thread keeps MP_Q queries in registers and walks the LDS-resident targets ONCE (every
+  // broadcast ds_read_b128 of a target is reused MP_Q times)
+  for (int i0 = 0; i0 < cap; i0 += MP_THREADS * MP_Q) {
+    uint4 q0[MP_Q], q1[MP_Q];
+    int b1[MP_Q], b2[MP_Q], bi[MP_Q];
+#pragma unroll
+    for (int s = 0; s < MP_Q; s++) {
+      const int i = i0 + s * MP_THREADS + tid;
+      b1[s] = 256; b2[s] = 256; bi[s] = -1;
+      if (i < n1) { q0[s] = Q[2 * i]; q1[s] = Q[2 * i + 1]; } else { q0[s] = make_uint4(0, 0, 0, 0); q1[s] = q0[s]; }
+    }
+    if (i0 + (tid & ~63) < n1) {                         // whole wave beyond n1: nothing to do
       for (int j = 0; j < n2; j++) {
-        int d = hamming256(q0, q1, s_t[2 * j], s_t[2 * j + 1]);
-        if (d < b1) { b2 = b1; b1 = d; bi = j; }
-        else if (d < b2) { b2 = d; }
+        const uint4 t0 = s_t[2 * j], t1 = s_t[2 * j + 1];
+#pragma unroll
+        for (int s = 0; s < MP_Q; s++) {
+          const int d = hamming256(q0[s], q1[s], t0, t1);
+          if (d < b1[s]) { b2[s] = b1[s]; b1[s] = d; bi[s] = j; }
+          else if (d < b2[s]) { b2[s] = d; }
+        }
       }
-      if (bi >= 0 && b1 <= th && (float)b1 < __fmul_rn(ratio, (float)b2)) {
-        res = bi;
+    }
+#pragma unroll
+    for (int s = 0; s < MP_Q; s++) {
+      const int i = i0 + s * MP_THREADS + tid;
+      int res = -1;
+      if (i < n1 && bi[s] >= 0 && b1[s] <= th && (float)b1[s] < __fmul_rn(ratio, (float)b2[s])) {
+        res = bi[s];
         int bin = 0;
         if (check_ori) {
-          float rot = __fsub_rn(KA[i].angle, KB[bi].angle);
+          float rot = __fsub_rn(KA[i].angle, KB[bi[s]].angle);
           if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
           bin = (int)roundf(__fmul_rn(rot, factor));
           if (bin == HISTO_LENGTH) bin = 0;
           atomicAdd(&s_hist[bin], 1);
         }
-        res |= bin << 24;                                     // stash the bin (indices < 2^24)
+        res |= bin << 24;                                   // stash the bin (indices < 2^24)
       }
+      if (i < cap) M[i] = res;
     }
-    if (i < cap) M[i] = res;
   }
   __syncthreads();
   if (tid == 0) {
