@@ -147,56 +147,95 @@ __device__ __forceinline__ int arc9_best_packed(const short2_t d[16]) {
   return max((int)best.x, (int)best.y);
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(GeomDev G, const CellDesc* __restrict__ cells,
-                                                    const uint8_t* __restrict__ img0, long long img_frame_bytes,
-                                                    const uint8_t* __restrict__ pyr, int* __restrict__ cell_cnt,
-                                                    uint32_t* __restrict__ cell_kps, int iniTh, int minTh) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// ONE WAVE per cell (64-thread workgroups): no cross-wave barriers, lanes = columns of the cell, rows are
+// walked sequentially; the ordered (row-major) emit needs only a running wave-uniform offset.
+#define FAST_WPB 1      // waves (= cells) per workgroup
+__global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const CellDesc* __restrict__ cells,
+                                                   const uint8_t* __restrict__ img0, long long img_frame_bytes,
+                                                   const uint8_t* __restrict__ pyr, int* __restrict__ cell_cnt,
+                                                   uint32_t* __restrict__ cell_kps, int iniTh, int minTh, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
   const int TP = G.tile_pitch;                        // multiple of 4
   const int plane = G.tile_h * TP;                    // multiple of 4
+  const int lane = threadIdx.x & 63;
+  const int ci = blockIdx.x * FAST_WPB + (threadIdx.x >> 6), f = blockIdx.y;
+  if (ci >= G.ncells_total) return;                   // (no workgroup-wide barrier below: waves are independent)
+  uint8_t* smem = smem_all + (size_t)(threadIdx.x >> 6) * lds_per_wave;
   uint8_t* tile = smem;                               // [tile_h][TP]
   uint8_t* score = smem + plane;                      // [tile_h][TP]
-  uint8_t* flag = score + plane;                      // [tile_h][TP]
-  unsigned short* queue = (unsigned short*)(flag + plane);   // [tile_h*TP] pixels that passed the pre-test
-  __shared__ int s_n20, s_qn, s_rowoff[65];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ci = blockIdx.x, f = blockIdx.y;
+  unsigned long long* keep = (unsigned long long*)(score + plane);    // [64] NMS survivors per interior row (bit = ix)
+  unsigned long long* k20 = keep + 64;                                 // [64] survivors with score >= iniTh
+  unsigned short* queue = (unsigned short*)(k20 + 64);                 // pixels that passed the pre-test
   const CellDesc c = cells[ci];
   const LevelDev& L = G.lv[c.level];
   const uint8_t* src = level_ptr(G, c.level, f, img0, img_frame_bytes, pyr);
   const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
-  if (tid == 0) { s_n20 = 0; s_qn = 0; }
-  // ---- stage the cell (incl. its 3-px apron) in LDS; 64 lanes across x, 4 rows per pass --------
-  for (int i = tid; i < (2 * plane) >> 2; i += 256) ((uint32_t*)score)[i] = 0u;     // score + flag planes
-  if (lane < tw)
-    for (int y = wv; y < th; y += 4) tile[y * TP + lane] = src[(long long)(c.y0 + y) * L.pitch + c.x0 + lane];
-  __syncthreads();
   const int iw = tw - 6, ih = th - 6;
-  // ---- pass A: compass pre-test (any 9-arc contains >= 2 adjacent compass points); survivors are
-  //      queued so that the expensive score runs on dense lanes (no divergence waste) -----------------
-  for (int iy = tid >> 5; iy < ih; iy += 8)
-    for (int ix0 = 0; ix0 < iw; ix0 += 32) {
-      const int ix = ix0 + (tid & 31);
-      bool pass = false;
-      if (ix < iw) {
-        const uint8_t* p = tile + (iy + 3) * TP + ix + 3;
-        const int v = p[0];
-        const int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
-        const int hi = v + minTh, lo = v - minTh;
-        const int nb = (c0 > hi) + (c4 > hi) + (c8 > hi) + (c12 > hi);
-        const int nd = (c0 < lo) + (c4 < lo) + (c8 < lo) + (c12 < lo);
-        pass = (nb >= 2) || (nd >= 2);
+  // ---- stage the cell (incl. its 3-px apron) in LDS -------------------------------------------------
+  for (int i = lane; i < plane >> 2; i += 64) ((uint32_t*)score)[i] = 0u;
+  keep[lane] = 0ull; k20[lane] = 0ull;
+  {
+    // All global loads of the tile are issued before the first LDS store (a load->store loop serialises on
+    // the ~1 us global latency per row).  Each lane fetches, for 4 rows per step, the two aligned dwords
+    // that cover its 4 tile bytes and realigns them with v_alignbyte; the detection window keeps a 16-px
+    // margin to the image border, so the <= 7 trailing bytes are always inside the frame.
+    const uint8_t* base = src + (long long)c.y0 * L.pitch + c.x0;
+    const int col = lane & 15, r0 = lane >> 4;
+    uint32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int y = r0 + 4 * k;
+      v[k] = 0u;
+      if (y < th && 4 * col < tw) {
+        const uint8_t* a = base + (long long)y * L.pitch + 4 * col;
+        const uint32_t sh = (uint32_t)((size_t)a & 3);
+        const uint32_t* aa = (const uint32_t*)(a - sh);
+        const uint32_t lo = aa[0];
+        const uint32_t hi = sh ? aa[1] : 0u;
+        v[k] = __builtin_amdgcn_alignbyte(hi, lo, sh);
       }
-      const unsigned long long bal = __ballot(pass);
-      int base = 0;
-      if (lane == 0 && bal) base = atomicAdd(&s_qn, __popcll(bal));
-      base = __shfl(base, 0);
-      if (pass) queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((iy << 8) | ix);
     }
-  __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int y = r0 + 4 * k;
+      if (y < th && 4 * col < tw) *(uint32_t*)(tile + y * TP + 4 * col) = v[k];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  // ---- pass A: compass pre-test (any 9-arc contains >= 2 adjacent compass points); survivors are
+  //      queued so that the expensive score runs on dense lanes ---------------------------------------
+  int qn = 0;
+  {
+    // lanes = (row parity, column) when the interior is <= 32 px wide (every KITTI / VGA level), else lanes = columns
+    const bool two = iw <= 32;
+    const int lx = two ? (lane & 31) : lane, ly = two ? (lane >> 5) : 0, rstep = two ? 2 : 1;
+    for (int iy0 = 0; iy0 < ih; iy0 += 4 * rstep) {
+      bool pass[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int iy = iy0 + r * rstep + ly;
+        pass[r] = false;
+        if (lx < iw && iy < ih) {
+          const uint8_t* p = tile + (iy + 3) * TP + lx + 3;
+          const int v = p[0];
+          const int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
+          const int hi = v + minTh, lo = v - minTh;
+          const int nb = (c0 > hi) + (c4 > hi) + (c8 > hi) + (c12 > hi);
+          const int nd = (c0 < lo) + (c4 < lo) + (c8 < lo) + (c12 < lo);
+          pass[r] = (nb >= 2) || (nd >= 2);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const unsigned long long bal = __ballot(pass[r]);
+        if (pass[r]) queue[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(((iy0 + r * rstep + ly) << 8) | lx);
+        qn += __popcll(bal);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   // ---- pass B: FAST-9 score at the LOW threshold; one map serves both thresholds --------
-  const int qn = s_qn;
-  for (int k = tid; k < qn; k += 256) {
+  for (int k = lane; k < qn; k += 64) {
     const int q = queue[k], iy = q >> 8, ix = q & 255;
     const uint8_t* p = tile + (iy + 3) * TP + ix + 3;
     const int v = p[0];
@@ -209,57 +248,48 @@ __global__ __launch_bounds__(256) void k_fast_cells(GeomDev G, const CellDesc* _
     const int best = arc9_best_packed(d);             // corner at t  <=>  best > t ; score = best - 1
     if (best > minTh) score[(iy + 3) * TP + ix + 3] = (uint8_t)(best - 1);
   }
-  __syncthreads();
-  // ---- 3x3 non-max suppression inside the cell (frame pixels score 0), again only on queued pixels ----
-  int my20 = 0;
-  for (int k = tid; k < qn; k += 256) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  // ---- 3x3 non-max suppression inside the cell (frame pixels score 0), only on queued pixels --------
+  int any20 = 0;
+  for (int k = lane; k < qn; k += 64) {
     const int q = queue[k], iy = q >> 8, ix = q & 255;
     const uint8_t* sp = score + (iy + 3) * TP + ix + 3;
     const int v = sp[0];
     if (v == 0) continue;
-    const bool keep = v > sp[-TP - 1] && v > sp[-TP] && v > sp[-TP + 1] && v > sp[-1] && v > sp[1] && v > sp[TP - 1] &&
-                      v > sp[TP] && v > sp[TP + 1];
-    if (keep) {
-      const int is20 = v >= iniTh;
-      flag[(iy + 3) * TP + ix + 3] = (uint8_t)(1 + is20);
-      my20 += is20;
+    const bool kp = v > sp[-TP - 1] && v > sp[-TP] && v > sp[-TP + 1] && v > sp[-1] && v > sp[1] && v > sp[TP - 1] &&
+                    v > sp[TP] && v > sp[TP + 1];
+    if (kp) {
+      atomicOr(&keep[iy], 1ull << ix);
+      if (v >= iniTh) { atomicOr(&k20[iy], 1ull << ix); any20 = 1; }
     }
   }
-  if (my20) atomicAdd(&s_n20, my20);
-  __syncthreads();
-  // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816); one wave per row ----
-  const int want_min = (s_n20 > 0) ? 2 : 1;
+  any20 = __any(any20);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816), row by row -----------
+  const unsigned long long* mask = any20 ? k20 : keep;
   uint32_t* out = cell_kps + ((long long)f * G.ncells_total + ci) * G.cell_cap;
-  unsigned long long bal[16];                           // rows wv, wv+4, ...  (ih <= 58 -> at most 15 rows per wave)
+  // lane r holds row r's mask; exclusive wave scan of the row populations gives every row's base offset
+  const unsigned long long mrow = (lane < ih) ? mask[lane] : 0ull;
+  const int cnt = __popcll(mrow);
+  int incl = cnt;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int iy = wv + 4 * k;
-    bool emit = false;
-    if (iy < ih && lane < iw) emit = flag[(iy + 3) * TP + lane + 3] >= want_min;
-    bal[k] = __ballot(emit);
-    if (lane == 0 && iy < ih) s_rowoff[iy + 1] = __popcll(bal[k]);
-  }
-  __syncthreads();
-  if (tid < 64) {                                       // exclusive prefix over <= 58 row counts (one wave)
-    int v = (tid >= 1 && tid <= ih) ? s_rowoff[tid] : 0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (tid >= o) v += t; }
-    s_rowoff[tid] = v;                                  // s_rowoff[r] = #emitted in rows < r ; s_rowoff[ih] = total
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int iy = wv + 4 * k;
-    if (iy >= ih) break;
-    if ((bal[k] >> lane) & 1ull) {
-      const int pos = s_rowoff[iy] + __popcll(bal[k] & ((1ull << lane) - 1ull));
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int base = __shfl(incl, 63);
+  unsigned long long rows = __ballot(cnt > 0);
+  while (rows) {
+    const int iy = __ffsll((long long)rows) - 1;
+    rows &= rows - 1;
+    const unsigned long long m = __shfl(mrow, iy);
+    const int rbase = __shfl(incl, iy) - __shfl(cnt, iy);
+    if ((m >> lane) & 1ull) {
+      const int pos = rbase + __popcll(m & ((1ull << lane) - 1ull));
       if (pos < G.cell_cap) {
         const uint32_t x = (uint32_t)(lane + 3 + c.offx), y = (uint32_t)(iy + 3 + c.offy);
         out[pos] = x | (y << 12) | ((uint32_t)score[(iy + 3) * TP + lane + 3] << 24);
       }
     }
   }
-  if (tid == 0) cell_cnt[(long long)f * G.ncells_total + ci] = (ih > 0 && iw > 0) ? s_rowoff[ih] : 0;
+  if (lane == 0) cell_cnt[(long long)f * G.ncells_total + ci] = (ih > 0 && iw > 0) ? base : 0;
 }
 
 // ---------------------------------------------------------------------------- k_octree
@@ -658,11 +688,15 @@ __global__ __launch_bounds__(256) void k_describe(GeomDev G, const uint32_t* __r
   const uint8_t* img = level_ptr(G, level, f, img0, img_frame_bytes, pyr);
   int m10 = 0, m01 = 0;
   if (lane < 31) {
-    int v = lane - 15;
-    int d = c_umax[v < 0 ? -v : v];
+    const int v = lane - 15;
+    const int d = c_umax[v < 0 ? -v : v];
     const uint8_t* row = img + (long long)(cy + v) * L.pitch + cx;
+    int val[31];
+#pragma unroll
+    for (int k = 0; k < 31; k++) val[k] = (int)row[k - 15];            // unconditional (the patch is inside the image): all loads in flight
     int rs = 0;
-    for (int u = -d; u <= d; u++) { int val = row[u]; rs += val; m10 += u * val; }
+#pragma unroll
+    for (int k = 0; k < 31; k++) { const int u = k - 15; const int vv = (u >= -d && u <= d) ? val[k] : 0; rs += vv; m10 += u * vv; }
     m01 = v * rs;
   }
 #pragma unroll
@@ -895,7 +929,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     G.node_cap = round_up(node_cap, 8); G.max_cells_level = round_up(max_cells, 8);
     G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
     G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
-    c->fast_lds = (size_t)5 * G.tile_h * G.tile_pitch;     // tile + score + flag (u8) + queue (u16)
+    c->fast_lds = (size_t)round_up((int)((size_t)2 * G.tile_h * G.tile_pitch + 2 * 64 * 8 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue (u16)
     c->octree_lds = (size_t)G.node_cap * (8 * 2 + 8 + 8 + 4 + 4 + 2 * 2 + 2 + 2 + 2) + (size_t)(G.max_cells_level + 8) * 4 + 64;
     ORBHIP_REQUIRE(c->octree_lds <= 160 * 1024, ORBHIP_EINVAL, "nfeatures too large for the LDS octree");
     if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
@@ -953,9 +987,9 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   }
   mark();
   if (G.ncells_total > 0)
-    hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, nframes), dim3(256), c->fast_lds, st, G,
+    hipLaunchKernelGGL(k_fast_cells, dim3((G.ncells_total + FAST_WPB - 1) / FAST_WPB, nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
                        c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
-                       c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh);
+                       c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds);
   mark();
   hipLaunchKernelGGL(k_octree, dim3(nl, nframes), dim3(256), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
                      c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
