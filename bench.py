@@ -143,8 +143,18 @@ def main():
         hbm_stages = {k: per_call[k] for k in ("pyramid", "fast_cells", "blur", "describe")}
         dom = max(hbm_stages, key=hbm_stages.get)
         ach = BYTES[dom] * B / (per_call[dom] * 1e-3) / 1e9
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs;
+        # profiles/r01_pmc_traffic.json) scaled to this batch; None if the summary is absent
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            kname = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur7", "describe": "k_describe"}[dom]
+            traffic = pmc["kernels"][kname]["hbm_bytes_per_frame"] * B
+        except Exception:
+            pass
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None}
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": BYTES[dom] * B}
         pairs_per_s = B / (per_call["match"] * 1e-3)
         lane_ops = mean_kp * mean_kp * MATCH_LANE_OPS_PER_PAIR
         kernels = {k: {"ms_per_launch_batch": v} for k, v in per_call.items()}

@@ -158,7 +158,11 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   const int TP = G.tile_pitch;                        // multiple of 4
   const int plane = G.tile_h * TP;                    // multiple of 4
   const int lane = threadIdx.x & 63;
-  const int ci = blockIdx.x * FAST_WPB + (threadIdx.x >> 6), f = blockIdx.y;
+  // Cell order = plain grid order.  (Measured on MI355X: an XCD-contiguous remap ci = (b%8)*chunk + b/8 cuts
+  // this kernel's FETCH_SIZE 4.9x - neighbouring cells then share one L2 - but makes it 40 % SLOWER; it is
+  // latency/issue-bound, not HBM-bound, so the faster mapping is kept.  DESIGN.md section 4.)
+  const int f = blockIdx.y;
+  const int ci = blockIdx.x * FAST_WPB + (threadIdx.x >> 6);
   if (ci >= G.ncells_total) return;                   // (no workgroup-wide barrier below: waves are independent)
   uint8_t* smem = smem_all + (size_t)(threadIdx.x >> 6) * lds_per_wave;
   uint8_t* tile = smem;                               // [tile_h][TP]
