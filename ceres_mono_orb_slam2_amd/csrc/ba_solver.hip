@@ -575,7 +575,15 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {      // lane 
 }
 // 32x32 Cholesky of the block in s_L (lower) by one wave: lane r keeps row r in registers; the pivot and the
 // pivot column are broadcast with v_readlane.  Returns 1 on a non-positive pivot.
-__device__ __noinline__ int diag_factor_wave(double (*s_L)[NB + 1]) {
+// 1/sqrt(x) in fp64: hardware v_rsq_f64 estimate + two Newton steps (~1 ulp); avoids the long fp64 sqrt + divide
+// sequences on the 32-step critical path of the diagonal factorisation.
+__device__ __forceinline__ double rsqrt_f64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ __noinline__ int diag_factor_wave(double (*s_L)[NB + 1], double* s_dinv) {
   const int r = threadIdx.x & 31;
   double row[NB];
 #pragma unroll
@@ -585,12 +593,15 @@ __device__ __noinline__ int diag_factor_wave(double (*s_L)[NB + 1]) {
   for (int j = 0; j < NB; j++) {
     double piv = bcast_lane(row[j], j);
     if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
-    const double dinv = 1.0 / sqrt(piv);
-    row[j] = (r == j) ? sqrt(piv) : row[j] * dinv;
+    const double dinv = rsqrt_f64(piv);
+    if (threadIdx.x == j) s_dinv[j] = dinv;
+    row[j] = (r == j) ? piv * dinv : row[j] * dinv;
+    // rank-1 update; lanes r < c write don't-care values above the diagonal (never read back into the factor)
 #pragma unroll
     for (int c = j + 1; c < NB; c++) {
       const double lcj = bcast_lane(row[j], c);
-      row[c] -= (c <= r) ? row[j] * lcj : 0.0;
+      row[c] = fma(-row[j], lcj, row[c]);
+      if (((c - j) & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // keep the v_readlane results short-lived (SGPR pressure)
     }
   }
   if (threadIdx.x < NB) {
@@ -600,15 +611,15 @@ __device__ __noinline__ int diag_factor_wave(double (*s_L)[NB + 1]) {
   return fail;
 }
 // inverse of the lower-triangular block in s_L into s_X: lane c solves L x = e_c with x in registers
-__device__ __noinline__ void diag_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1]) {
+__device__ __noinline__ void diag_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1], const double* s_dinv) {
   const int c = threadIdx.x & 31;
   double x[NB];
 #pragma unroll
   for (int rr = 0; rr < NB; rr++) {
     double sum = (rr == c) ? 1.0 : 0.0;
 #pragma unroll
-    for (int m = 0; m < rr; m++) sum -= s_L[rr][m] * x[m];
-    x[rr] = sum / s_L[rr][rr];
+    for (int m = 0; m < rr; m++) sum = fma(-s_L[rr][m], x[m], sum);
+    x[rr] = sum * s_dinv[rr];
   }
   if (threadIdx.x < NB) {
 #pragma unroll
@@ -620,6 +631,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k) {
   if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_L[NB][NB + 1];
   __shared__ double s_X[NB][NB + 1];
+  __shared__ double s_dinv[NB];
   __shared__ int s_fail;
   const int np = D.npad, tid = threadIdx.x;
   double* S = D.S;
@@ -627,11 +639,11 @@ __global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k) {
   if (tid == 0) s_fail = 0;
   __syncthreads();
   if (tid < 64) {
-    const int fail = diag_factor_wave(s_L);
+    const int fail = diag_factor_wave(s_L, s_dinv);
     if (fail && tid == 0) s_fail = 1;
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    diag_invert_wave(s_L, s_X);
+    diag_invert_wave(s_L, s_X, s_dinv);
   }
   __syncthreads();
   if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
@@ -758,36 +770,61 @@ __global__ __launch_bounds__(256) void k_chol_syrk_rhs(BaDev D, int k) {
   }
 }
 
-// backward substitution L^T x = z (z = augmented row, produced by the factorisation itself); single
-// workgroup, blocked right-looking; the diagonal solves are mat-vecs with the stored L11^-1 blocks.
-__global__ __launch_bounds__(256) void k_chol_solve(BaDev D) {
+// backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
+// of 256 rows processed from the bottom: k_chol_bsolve_diag solves one super-block with a single
+// workgroup (its <= 8 diagonal 32x32 solves are mat-vecs with the stored L11^-1 blocks), then
+// k_chol_bsolve_update subtracts its contribution from every earlier entry with many workgroups
+// (64 columns x 4 row groups each, fixed-order LDS reduction -> deterministic).
+#define SBLK 256
+__global__ __launch_bounds__(256) void k_chol_bsolve_diag(BaDev D, int kb, int ke, int first) {
   const BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
-  extern __shared__ __attribute__((aligned(16))) double s_y[];       // [npad] running vector
-  __shared__ double s_x[NB];
+  __shared__ double s_y[SBLK], s_x[NB];
   const int np = D.npad, tid = threadIdx.x;
   const double* S = D.S;
-  const double* zrow = D.S + (size_t)np * np;
-  for (int i = tid; i < np; i += 256) s_y[i] = zrow[i];
+  const double* src = first ? (D.S + (size_t)np * np) : D.rhs;      // the first (bottom) super-block starts from z
+  if (first) for (int i = tid; i < kb; i += 256) D.rhs[i] = src[i];  // seed the running vector for the rows above
+  if (kb + tid < ke) s_y[tid] = src[kb + tid];
   __syncthreads();
-  for (int k = np - NB; k >= 0; k -= NB) {
-    if (tid < NB) {                                   // x = Linv^T z : x[c] = sum_{r >= c} Linv[r][c] z[r]
+  for (int k = ke - NB; k >= kb; k -= NB) {
+    if (tid < NB) {                                   // x = Linv^T y_k : x[c] = sum_{r >= c} Linv[r][c] y[r]
       const double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
       double sum = 0.0;
-      for (int r = tid; r < NB; r++) sum += Di[r * NB + tid] * s_y[k + r];
+      for (int r = tid; r < NB; r++) sum += Di[r * NB + tid] * s_y[k - kb + r];
       s_x[tid] = sum;
     }
     __syncthreads();
-    if (tid < NB) s_y[k + tid] = s_x[tid];
-    for (int c = tid; c < k; c += 256) {
+    if (tid < NB) s_y[k - kb + tid] = s_x[tid];
+    const int c = kb + tid;                           // rows of this super-block above block k
+    if (c < k) {
       double sum = 0;
 #pragma unroll
       for (int r = 0; r < NB; r++) sum += S[(size_t)(k + r) * np + c] * s_x[r];
-      s_y[c] -= sum;
+      s_y[tid] -= sum;
     }
     __syncthreads();
   }
-  for (int i = tid; i < np; i += 256) D.rhs[i] = s_y[i];
+  if (kb + tid < ke) D.rhs[kb + tid] = s_y[tid];
+}
+
+__global__ __launch_bounds__(256) void k_chol_bsolve_update(BaDev D, int kb, int ke) {
+  const BaState* st = D.st;
+  if (st->done || !st->valid || st->chol_fail) return;
+  __shared__ double s_x[SBLK], s_p[4][64];
+  const int np = D.npad, tid = threadIdx.x;
+  const int nr = ke - kb;
+  if (tid < nr) s_x[tid] = D.rhs[kb + tid];
+  __syncthreads();
+  const int cl = tid & 63, rg = tid >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double sum = 0.0;
+  if (c < kb) {
+    const double* L = D.S + (size_t)kb * np + c;
+    for (int r = rg; r < nr; r += 4) sum += L[(size_t)r * np] * s_x[r];
+  }
+  s_p[rg][cl] = sum;
+  __syncthreads();
+  if (tid < 64 && c < kb) D.rhs[c] -= (s_p[0][tid] + s_p[1][tid]) + (s_p[2][tid] + s_p[3][tid]);
 }
 
 // ---- candidate cameras: x+ = Plus(x, -y * scale); partial |dx|^2 -------------------------------------------
@@ -1115,7 +1152,11 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
         hipLaunchKernelGGL(k_chol_syrk, dim3(T * (T + 1) / 2 + (rows_below + 255) / 256), dim3(256), 0, s, D, k, T * (T + 1) / 2);
       }
     }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(256), (size_t)npad * sizeof(double), s, D);
+    for (int kb = ((npad - 1) / SBLK) * SBLK, first = 1; kb >= 0; kb -= SBLK, first = 0) {
+      const int ke = std::min(kb + SBLK, npad);
+      hipLaunchKernelGGL(k_chol_bsolve_diag, dim3(1), dim3(256), 0, s, D, kb, ke, first);
+      if (kb > 0) hipLaunchKernelGGL(k_chol_bsolve_update, dim3((kb + 63) / 64), dim3(256), 0, s, D, kb, ke);
+    }
     hipLaunchKernelGGL(k_ba_cam_update, dim3(std::max(nb_cam, 1)), dim3(BA_TPB), 0, s, D);
     hipLaunchKernelGGL(k_ba_backsub, dim3(nb_pt), dim3(BA_TPB), 0, s, D, 0);
     hipLaunchKernelGGL(k_ba_eval, dim3(nb_obs), dim3(BA_TPB), 0, s, D, 1);

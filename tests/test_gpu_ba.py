@@ -177,3 +177,18 @@ def test_localba_full_size_properties():
     assert np.allclose(poses[:2], g["poses0"][:2], atol=1e-15)
     assert 0.01 * len(er) < er.sum() < 0.2 * len(er)
     assert np.allclose(np.linalg.norm(poses[:, 3:], axis=1), 1.0, atol=1e-14)
+
+
+def test_ba_solve_multi_superblock_vs_oracle(oracle):
+    """Reduced system larger than one 256-row super-block of the backward substitution (119 free cameras ->
+    714 x 714), against the oracle's dense Cholesky."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    g = synth.make_ba_graph(11, ncam=121, npts=3000, nobs=15000, n_fixed=2)
+    n = len(g["obs_cam"])
+    w = g["obs_inv_sigma2"].astype(np.float64); rb = np.ones(n, np.uint8)
+    poses, pts, s = optimizer.bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"],
+                                                g["obs_uv"], w, rb, 8)
+    oposes, opts, os_ = oracle.ba_solve(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, rb, 8)
+    assert s["iterations"] == os_["iterations"] and s["successful_steps"] == os_["successful_steps"]
+    assert abs(s["final_cost"] - os_["final_cost"]) <= RTOL_COST * os_["final_cost"]
+    assert _close(poses, oposes, RTOL_X) and _close_pts(pts, opts)
