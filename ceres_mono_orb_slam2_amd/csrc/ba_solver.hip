@@ -682,62 +682,68 @@ __global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k) {
   }
 }
 
-// trailing update A22 -= L21 L21^T on the FP64 matrix cores; one 64x64 lower tile per workgroup,
-// each of the 4 waves owns a 32x32 quadrant as 2x2 v_mfma_f64_16x16x4_f64 tiles.
-__global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int k, int ntiles) {
+// trailing update C -= L[:, kcol:kcol+K] * L[:, kcol:kcol+K]^T on the FP64 matrix cores for the rows >= r_lo and the
+// columns [c_lo, c_hi) of the lower triangle; one 64x64 tile per workgroup, each of the 4 waves owns a 32x32 quadrant
+// as 2x2 v_mfma_f64_16x16x4_f64 tiles, K (32..128) is walked in 32-wide LDS stages.  Two-level blocking: the four
+// 32-wide panels of a 128-wide outer block only update the rest of that block ("thin" launches, K=32); everything to
+// the right of the outer block is updated ONCE with K=128 (4x the flops per byte of C moved).  Workgroups with
+// blockIdx.x >= ntiles update the augmented rhs row (row npad) over the same column range.
+__global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int kcol, int K, int r_lo, int c_lo, int c_hi, int tiles_c, int ntiles) {
   const BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_A[64][NB + 1], s_B[64][NB + 1];
   const int np = D.npad, tid = threadIdx.x;
-  if ((int)blockIdx.x >= ntiles) {           // extra workgroups: trailing update of the augmented rhs row (row npad)
-    double* zrow = D.S + (size_t)np * np;
+  double* S = D.S;
+  if ((int)blockIdx.x >= ntiles) {           // augmented rhs row
+    double* zrow = S + (size_t)np * np;
     double* s_z = &s_A[0][0];
-    if (tid < NB) s_z[tid] = zrow[k + tid];
+    for (int i = tid; i < K; i += 256) s_z[i] = zrow[kcol + i];
     __syncthreads();
-    const int c = k + NB + ((int)blockIdx.x - ntiles) * 256 + tid;
-    if (c < np) {
-      const double* L = D.S + (size_t)c * np + k;
+    const int c = c_lo + ((int)blockIdx.x - ntiles) * 256 + tid;
+    if (c < c_hi) {
+      const double* L = S + (size_t)c * np + kcol;
       double sum = 0.0;
-#pragma unroll
-      for (int m = 0; m < NB; m++) sum += L[m] * s_z[m];
+      for (int m = 0; m < K; m++) sum += L[m] * s_z[m];
       zrow[c] -= sum;
     }
     return;
   }
-  // unrank blockIdx.x -> (ti >= tj)
-  int ti = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-  while (ti * (ti + 1) / 2 > (int)blockIdx.x) ti--;
-  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
-  const int tj = blockIdx.x - ti * (ti + 1) / 2;
-  const int r0 = k + NB + ti * 64, c0 = k + NB + tj * 64;
-  double* S = D.S;
-  for (int i = tid; i < 64 * NB; i += 256) {
-    int r = i / NB, c = i % NB;
-    s_A[r][c] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + k + c] : 0.0;
-    s_B[r][c] = (c0 + r < np) ? S[(size_t)(c0 + r) * np + k + c] : 0.0;
-  }
-  __syncthreads();
+  const int ti = blockIdx.x / tiles_c, tj = blockIdx.x - ti * tiles_c;
+  const int r0 = r_lo + ti * 64, c0 = c_lo + tj * 64;
+  if (r0 + 63 < c0) return;                                   // tile entirely above the diagonal
   const int w = tid >> 6, lane = tid & 63;
   const int qr = (w >> 1) * 32, qc = (w & 1) * 32;            // quadrant origin inside the 64x64 tile
-  if (ti == tj && qc > qr) return;                            // strictly-upper quadrant of a diagonal tile
+  const bool qskip = (r0 + qr + 31 < c0 + qc);                // quadrant entirely above the diagonal
   double4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const int li = lane & 15, lk = lane >> 4;                   // A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15]
+  for (int k0 = 0; k0 < K; k0 += NB) {
+    __syncthreads();
+    for (int i = tid; i < 64 * NB; i += 256) {
+      const int r = i / NB, c = i % NB;
+      s_A[r][c] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + k0 + c] : 0.0;
+      s_B[r][c] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (!qskip) {
 #pragma unroll
-  for (int kk = 0; kk < NB; kk += 4) {
-    double a[2], b[2];
+      for (int kk = 0; kk < NB; kk += 4) {
+        double a[2], b[2];
 #pragma unroll
-    for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
+        for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
 #pragma unroll
-    for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
+        for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
   }
+  if (qskip) return;
   // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -747,28 +753,12 @@ __global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int k, int ntiles) {
       for (int rg = 0; rg < 4; rg++) {
         const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
         const int col = c0 + qc + 16 * j + (lane & 15);
-        if (row < np && col <= row) S[(size_t)row * np + col] -= acc[i][j][rg];
+        if (row < np && col < c_hi && col <= row) S[(size_t)row * np + col] -= acc[i][j][rg];
       }
 }
 
-// augmented rhs row: z_row[c] -= sum_k z_row[k-block] * L[c][k-block]  (the trailing update of row npad)
-__global__ __launch_bounds__(256) void k_chol_syrk_rhs(BaDev D, int k) {
-  const BaState* st = D.st;
-  if (st->done || !st->valid || st->chol_fail) return;
-  __shared__ double s_z[NB];
-  const int np = D.npad;
-  double* zrow = D.S + (size_t)np * np;
-  if (threadIdx.x < NB) s_z[threadIdx.x] = zrow[k + threadIdx.x];
-  __syncthreads();
-  const int c = k + NB + blockIdx.x * 256 + threadIdx.x;
-  if (c < np) {
-    const double* L = D.S + (size_t)c * np + k;
-    double sum = 0.0;
-#pragma unroll
-    for (int m = 0; m < NB; m++) sum += L[m] * s_z[m];
-    zrow[c] -= sum;
-  }
-}
+// (legacy name kept for the profile history)
+__global__ __launch_bounds__(256) void k_chol_syrk_rhs(BaDev D, int k) {}
 
 // backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
 // of 256 rows processed from the bottom: k_chol_bsolve_diag solves one super-block with a single
@@ -1144,13 +1134,22 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
     hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(nb_obs), dim3(BA_TPB), 0, s, D);
     if (n6 > 0) hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)(((size_t)n6 * npad + 255) / 256))), dim3(256), 0, s, D);
     if (nblk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, s, D, d_free);
-    for (int k = 0; k < npad; k += NB) {
-      const int rows_below = npad - k - NB;
-      hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 1 + 63) / 64), dim3(256), 0, s, D, k);   // +1: augmented rhs row
-      if (rows_below > 0) {
-        const int T = (rows_below + 63) / 64;
-        hipLaunchKernelGGL(k_chol_syrk, dim3(T * (T + 1) / 2 + (rows_below + 255) / 256), dim3(256), 0, s, D, k, T * (T + 1) / 2);
+    auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi) {
+      if (c_hi <= c_lo || r_lo >= npad + 1) return;
+      const int tiles_r = (npad - r_lo + 63) / 64, tiles_c = (c_hi - c_lo + 63) / 64;
+      const int ntiles = std::max(tiles_r, 0) * tiles_c;
+      const int nrhs = (c_hi - c_lo + 255) / 256;
+      hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs), dim3(256), 0, s, D, kcol, K, r_lo, c_lo, c_hi, tiles_c, ntiles);
+    };
+    const int OB = 128;                                       // outer block: 4 panels of NB = 32
+    for (int k0 = 0; k0 < npad; k0 += OB) {
+      const int kend = std::min(k0 + OB, npad);
+      for (int k = k0; k < kend; k += NB) {
+        const int rows_below = npad - k - NB;
+        hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 1 + 63) / 64), dim3(256), 0, s, D, k);   // +1: augmented rhs row
+        if (k + NB < kend) launch_update(k, NB, k + NB, k + NB, kend);          // thin update inside the outer block
       }
+      if (kend < npad) launch_update(k0, kend - k0, kend, kend, npad);          // one wide update for everything to the right
     }
     for (int kb = ((npad - 1) / SBLK) * SBLK, first = 1; kb >= 0; kb -= SBLK, first = 0) {
       const int ke = std::min(kb + SBLK, npad);

@@ -312,6 +312,179 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
   return 0;
 }
 
+// ---- shared helper: all (query, candidate) distances of a CSR list on the GPU (host pointers in/out) -----------
+static int csr_distances_gpu(const uint8_t* q, int nq, const uint8_t* t, int nt, const std::vector<uint32_t>& off,
+                             const std::vector<uint32_t>& idx, std::vector<int>& dist) {
+  const uint32_t total = off[nq];
+  dist.resize(total);
+  if (total == 0) return 0;
+  DevBuf dq, dt, doff, didx, dd;
+  auto cleanup = [&]() { dq.release(); dt.release(); doff.release(); didx.release(); dd.release(); };
+  int rc = 0;
+  if ((rc = dq.ensure((size_t)nq * 32)) || (rc = dt.ensure((size_t)nt * 32)) || (rc = doff.ensure((size_t)(nq + 1) * 4)) ||
+      (rc = didx.ensure((size_t)total * 4)) || (rc = dd.ensure((size_t)total * 4))) { cleanup(); return rc; }
+  MCHK(hipMemcpy(dq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice));
+  MCHK(hipMemcpy(dt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice));
+  MCHK(hipMemcpy(doff.p, off.data(), (size_t)(nq + 1) * 4, hipMemcpyHostToDevice));
+  MCHK(hipMemcpy(didx.p, idx.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_dist_csr, dim3((total + 255) / 256), dim3(256), 0, 0, dq.as<uint8_t>(), nq, dt.as<uint8_t>(),
+                     doff.as<uint32_t>(), didx.as<uint32_t>(), total, dd.as<int>());
+  MCHK(hipGetLastError());
+  MCHK(hipMemcpy(dist.data(), dd.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+  cleanup();
+  return 0;
+}
+
+static void three_maxima_host(const int* cnt, int& i1, int& i2, int& i3) {          // src/ORBmatcher.cc:1386-1418
+  int max1 = 0, max2 = 0, max3 = 0; i1 = i2 = i3 = -1;
+  for (int b = 0; b < HISTO_LENGTH; b++) {
+    const int s = cnt[b];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = b; }
+    else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = b; }
+    else if (s > max3) { max3 = s; i3 = b; }
+  }
+  if (max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { i3 = -1; }
+}
+static inline int rot_bin_host(float a1, float a2) {
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, const float* bounds, const float* q_uv,
+                              const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                              const int32_t* q_pred_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                              const float* q_angle, int nq, const float* inv_level_sigma2, float chi2_gate,
+                              uint8_t* taken, int mode_best2, float ratio, int th, int check_ori, int32_t* q_match,
+                              int32_t* q_best_dist, int* nmatches) {
+  ORBHIP_REQUIRE(n >= 0 && nq >= 0 && nmatches && q_match, ORBHIP_EINVAL, "bad size");
+  *nmatches = 0;
+  for (int i = 0; i < nq; i++) { q_match[i] = -1; if (q_best_dist) q_best_dist[i] = 256; }
+  if (nq == 0 || n == 0) return 0;
+  ORBHIP_REQUIRE(kps4 && desc && bounds && q_uv && q_radius && q_desc, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(!check_ori || q_angle, ORBHIP_EINVAL, "rotation check needs q_angle");
+  ORBHIP_REQUIRE(chi2_gate <= 0.f || inv_level_sigma2, ORBHIP_EINVAL, "chi2 gate needs inv_level_sigma2");
+  FrameGrid* G = new FrameGrid();
+  G->build(kps4, n, bounds);
+  std::vector<uint32_t> off(nq + 1, 0), idx;
+  for (int i = 0; i < nq; i++) {
+    off[i] = (uint32_t)idx.size();
+    if (q_valid && !q_valid[i]) continue;
+    G->query(q_uv[2 * i], q_uv[2 * i + 1], q_radius[i], q_min_level ? q_min_level[i] : -1, q_max_level ? q_max_level[i] : -1, idx);
+  }
+  off[nq] = (uint32_t)idx.size();
+  delete G;
+  std::vector<int> dist;
+  if (int rc = csr_distances_gpu(q_desc, nq, desc, n, off, idx, dist)) return rc;
+  // ---- greedy pass in query order (reference loop order) ---------------------------------------
+  int nm = 0;
+  std::vector<int> hist_bin(nq, -1);
+  int cnt[HISTO_LENGTH] = {0};
+  for (int i = 0; i < nq; i++) {
+    int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
+    for (uint32_t c = off[i]; c < off[i + 1]; c++) {
+      const int t = (int)idx[c];
+      if (taken && taken[t]) continue;
+      const int lvl = (int)kps4[4 * t + 2];
+      if (q_pred_level && q_pred_level[i] >= 0 && (lvl < q_pred_level[i] - 1 || lvl > q_pred_level[i])) continue;
+      if (chi2_gate > 0.f) {
+        const float ex = q_uv[2 * i] - kps4[4 * t], ey = q_uv[2 * i + 1] - kps4[4 * t + 1];
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * inv_level_sigma2[lvl] > chi2_gate) continue;
+      }
+      const int d = dist[c];
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = lvl; bestIdx = t; }
+      else if (mode_best2 && d < bestDist2) { bestLevel2 = lvl; bestDist2 = d; }
+    }
+    if (q_best_dist) q_best_dist[i] = bestDist;
+    if (bestIdx >= 0 && bestDist <= th) {
+      if (mode_best2 && bestLevel == bestLevel2 && bestDist > ratio * bestDist2) continue;
+      q_match[i] = bestIdx;
+      if (taken) taken[bestIdx] = 1;
+      nm++;
+      if (check_ori) { hist_bin[i] = rot_bin_host(q_angle[i], kps4[4 * bestIdx + 3]); cnt[hist_bin[i]]++; }
+    }
+  }
+  if (check_ori) {
+    int i1, i2, i3;
+    three_maxima_host(cnt, i1, i2, i3);
+    for (int i = 0; i < nq; i++)
+      if (q_match[i] >= 0 && hist_bin[i] != i1 && hist_bin[i] != i2 && hist_bin[i] != i3) {
+        if (taken) taken[q_match[i]] = 0;
+        q_match[i] = -1; nm--;
+      }
+  }
+  *nmatches = nm;
+  return 0;
+}
+
+int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, const float* angle1, const uint8_t* desc2, int n2,
+                       const uint8_t* valid2, const float* angle2, const uint32_t* fv1_node, const uint32_t* fv1_off,
+                       const uint32_t* fv1_idx, int fv1_n, const uint32_t* fv2_node, const uint32_t* fv2_off,
+                       const uint32_t* fv2_idx, int fv2_n, float ratio, int th, int strict, int check_ori,
+                       int32_t* match12, int* nmatches) {
+  ORBHIP_REQUIRE(n1 >= 0 && n2 >= 0 && fv1_n >= 0 && fv2_n >= 0 && nmatches && (n1 == 0 || match12), ORBHIP_EINVAL, "bad size");
+  *nmatches = 0;
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  if (n1 == 0 || n2 == 0 || fv1_n == 0 || fv2_n == 0) return 0;
+  ORBHIP_REQUIRE(desc1 && desc2 && fv1_node && fv1_off && fv1_idx && fv2_node && fv2_off && fv2_idx, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(!check_ori || (angle1 && angle2), ORBHIP_EINVAL, "rotation check needs angles");
+  // merge-walk of the two feature vectors (std::map order = ascending node id): queries in (node, list) order
+  std::vector<int> qidx;                       // query -> idx1
+  std::vector<uint32_t> off(1, 0), idx;
+  int a = 0, b = 0;
+  while (a < fv1_n && b < fv2_n) {
+    if (fv1_node[a] == fv2_node[b]) {
+      for (uint32_t e1 = fv1_off[a]; e1 < fv1_off[a + 1]; e1++) {
+        const int i1 = (int)fv1_idx[e1];
+        if (valid1 && !valid1[i1]) continue;
+        qidx.push_back(i1);
+        for (uint32_t e2 = fv2_off[b]; e2 < fv2_off[b + 1]; e2++) idx.push_back(fv2_idx[e2]);
+        off.push_back((uint32_t)idx.size());
+      }
+      a++; b++;
+    } else if (fv1_node[a] < fv2_node[b]) a++;
+    else b++;
+  }
+  const int nq = (int)qidx.size();
+  if (nq == 0) return 0;
+  std::vector<uint8_t> qd((size_t)nq * 32);
+  for (int i = 0; i < nq; i++) std::memcpy(&qd[(size_t)32 * i], desc1 + (size_t)32 * qidx[i], 32);
+  std::vector<int> dist;
+  if (int rc = csr_distances_gpu(qd.data(), nq, desc2, n2, off, idx, dist)) return rc;
+  std::vector<uint8_t> matched2(n2, 0);
+  std::vector<int> bins(n1, -1);
+  int cnt[HISTO_LENGTH] = {0}, nm = 0;
+  for (int i = 0; i < nq; i++) {
+    const int i1 = qidx[i];
+    int bestDist1 = 256, bestDist2 = 256, bestIdx2 = -1;
+    for (uint32_t c = off[i]; c < off[i + 1]; c++) {
+      const int i2 = (int)idx[c];
+      if (matched2[i2] || (valid2 && !valid2[i2])) continue;
+      const int d = dist[c];
+      if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = i2; }
+      else if (d < bestDist2) { bestDist2 = d; }
+    }
+    const bool under = strict ? (bestDist1 < th) : (bestDist1 <= th);
+    if (under && static_cast<float>(bestDist1) < ratio * static_cast<float>(bestDist2)) {
+      match12[i1] = bestIdx2; matched2[bestIdx2] = 1; nm++;
+      if (check_ori) { bins[i1] = rot_bin_host(angle1[i1], angle2[bestIdx2]); cnt[bins[i1]]++; }
+    }
+  }
+  if (check_ori) {
+    int i1, i2, i3;
+    three_maxima_host(cnt, i1, i2, i3);
+    for (int i = 0; i < n1; i++)
+      if (match12[i] >= 0 && bins[i] != i1 && bins[i] != i2 && bins[i] != i3) { match12[i] = -1; nm--; }
+  }
+  *nmatches = nm;
+  return 0;
+}
+
 int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int n1, const float* kps2,
                                    const uint8_t* desc2, int n2, const float* bounds2, float* prev_matched, int window,
                                    float nnratio, int check_ori, int32_t* matches12, int* nmatches) {

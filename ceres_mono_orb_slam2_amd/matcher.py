@@ -79,3 +79,42 @@ class ORBmatcher:
                                                           int(self.mbCheckOrientation), _lib.ptr(m), C.byref(n)),
                    "orbm_search_for_initialization")
         return n.value, m
+
+    # ---- guided searches on flattened data (see include/orbslam_hip.h for the reference entry points covered) ----
+    def search_by_projection(self, kps4, desc, bounds, q_uv, q_radius, q_desc, q_min_level=None, q_max_level=None,
+                             q_pred_level=None, q_valid=None, q_angle=None, inv_level_sigma2=None, chi2_gate=0.0,
+                             taken=None, mode_best2=False, th=None):
+        """Returns (nmatches, q_match[nq], q_best_dist[nq], taken_out or None).  ratio = mfNNratio, rotation check =
+        mbCheckOrientation (needs q_angle); th defaults to TH_HIGH."""
+        f32, u8, i32 = np.float32, np.uint8, np.int32
+        opt = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        kps4 = np.ascontiguousarray(kps4, f32); desc = np.ascontiguousarray(desc, u8); b = np.ascontiguousarray(bounds, f32)
+        q_uv = np.ascontiguousarray(q_uv, f32); q_radius = np.ascontiguousarray(q_radius, f32); q_desc = np.ascontiguousarray(q_desc, u8)
+        nq = len(q_radius)
+        mn, mx, pl = opt(q_min_level, i32), opt(q_max_level, i32), opt(q_pred_level, i32)
+        qv, qa, isg = opt(q_valid, u8), opt(q_angle, f32), opt(inv_level_sigma2, f32)
+        tk = None if taken is None else np.ascontiguousarray(taken, u8).copy()
+        m = np.full(max(nq, 1), -1, i32); bd = np.full(max(nq, 1), 256, i32); n = C.c_int(0)
+        check_ori = int(self.mbCheckOrientation and qa is not None)
+        _lib.check(self._L.orbm_search_by_projection(_lib.ptr(kps4), _lib.ptr(desc), len(kps4), _lib.ptr(b), _lib.ptr(q_uv),
+                                                     _lib.ptr(q_radius), _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(pl), _lib.ptr(q_desc),
+                                                     _lib.ptr(qv), _lib.ptr(qa), nq, _lib.ptr(isg), float(chi2_gate), _lib.ptr(tk),
+                                                     int(mode_best2), self.mfNNratio, self.TH_HIGH if th is None else int(th),
+                                                     check_ori, _lib.ptr(m), _lib.ptr(bd), C.byref(n)), "orbm_search_by_projection")
+        return n.value, m[:nq], bd[:nq], tk
+
+    def SearchByBoW(self, desc1, valid1, angle1, desc2, valid2, angle2, fv1, fv2, strict=False, th=None):
+        """src/ORBmatcher.cc:151-256 (strict=False) / :470-580 (strict=True) on flattened data.
+        fv = (ascending node ids, CSR offsets, keypoint indices).  Returns (nmatches, match12[n1])."""
+        u8, f32, u32 = np.uint8, np.float32, np.uint32
+        opt = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        d1 = np.ascontiguousarray(desc1, u8); d2 = np.ascontiguousarray(desc2, u8)
+        v1, v2, a1, a2 = opt(valid1, u8), opt(valid2, u8), opt(angle1, f32), opt(angle2, f32)
+        f1 = [np.ascontiguousarray(x, u32) for x in fv1]; f2 = [np.ascontiguousarray(x, u32) for x in fv2]
+        m = np.full(max(len(d1), 1), -1, np.int32); n = C.c_int(0)
+        _lib.check(self._L.orbm_search_by_bow(_lib.ptr(d1), len(d1), _lib.ptr(v1), _lib.ptr(a1), _lib.ptr(d2), len(d2), _lib.ptr(v2),
+                                              _lib.ptr(a2), _lib.ptr(f1[0]), _lib.ptr(f1[1]), _lib.ptr(f1[2]), len(f1[0]),
+                                              _lib.ptr(f2[0]), _lib.ptr(f2[1]), _lib.ptr(f2[2]), len(f2[0]), self.mfNNratio,
+                                              self.TH_LOW if th is None else int(th), int(strict), int(self.mbCheckOrientation),
+                                              _lib.ptr(m), C.byref(n)), "orbm_search_by_bow")
+        return n.value, m[:len(d1)]

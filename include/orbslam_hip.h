@@ -136,6 +136,38 @@ int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int 
                                    const uint8_t* desc2, int n2, const float* bounds2, float* prev_matched,
                                    int window, float nnratio, int check_ori, int32_t* matches12, int* nmatches);
 
+/* Projection-guided searches on flattened data (host pointers).  One engine covers
+ *   SearchByProjection(Frame&, vector<MapPoint*>&, th)            src/ORBmatcher.cc:42-119   (mode_best2 = 1, th = TH_HIGH)
+ *   SearchByProjection(Frame& cur, const Frame& last, th)         :1161-1271  (best only, TH_HIGH, rotation check)
+ *   SearchByProjection(Frame&, KeyFrame*, set&, th, ORBdist)      :1273-1384  (best only, th = ORBdist, rotation check)
+ *   SearchByProjection(KeyFrame*, Scw, points, matched, th)       :258-361    (q_pred_level post-filter, TH_LOW)
+ *   the candidate selection of Fuse (:724-954; chi2_gate = 5.99) and of SearchBySim3 (:956-1159, called twice).
+ * The caller keeps the reference's own geometry (projection, frustum / distance / viewing-angle gates,
+ * PredictScale) and passes per query: projected position, window radius, the GetFeaturesInArea level
+ * range (-1,-1 = none), an optional predicted level for the [pred-1, pred] post-filter, the descriptor,
+ * q_valid (0 = query skipped).  Targets: kps4 = n x {x, y, octave, angle} of the undistorted keypoints,
+ * bounds = {min_x, max_x, min_y, max_y}.  Candidates come from the 64x48 grid (Frame::GetFeaturesInArea,
+ * src/Frame.cc:243-307), distances from the GPU, and the order-dependent greedy pass runs in query order:
+ * `taken` (nullable, n bytes, in/out) marks targets that already hold a map point (skipped; set on
+ * assignment, cleared again if the rotation histogram rejects the match).  Outputs: q_match[nq] = target
+ * index or -1, q_best_dist[nq] (nullable), *nmatches.                                        */
+int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, const float* bounds, const float* q_uv,
+                              const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                              const int32_t* q_pred_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                              const float* q_angle, int nq, const float* inv_level_sigma2, float chi2_gate,
+                              uint8_t* taken, int mode_best2, float ratio, int th, int check_ori, int32_t* q_match,
+                              int32_t* q_best_dist, int* nmatches);
+
+/* SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:151-256; strict = 0) and SearchByBoW(KeyFrame*,
+ * KeyFrame*, ...) (:470-580; strict = 1: best < th) on flattened data (host pointers).  The DBoW2 feature
+ * vectors are passed as ascending node ids with CSR keypoint-index lists; valid1/valid2 (nullable) mark
+ * keypoints that hold a usable map point.  match12[n1] = index in set 2 or -1.               */
+int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, const float* angle1, const uint8_t* desc2,
+                       int n2, const uint8_t* valid2, const float* angle2, const uint32_t* fv1_node,
+                       const uint32_t* fv1_off, const uint32_t* fv1_idx, int fv1_n, const uint32_t* fv2_node,
+                       const uint32_t* fv2_off, const uint32_t* fv2_idx, int fv2_n, float ratio, int th, int strict,
+                       int check_ori, int32_t* match12, int* nmatches);
+
 /* ------------------------------------------------------------ bundle adjust --
  * Replaces CeresOptimizer::{PoseOptimization, BundleAdjustment/GlobalBundleAdjustemnt,
  * LocalBundleAdjustment, CheckOutlier(s)} (src/CeresOptimizer.cc:49-599) and the Ceres solve

@@ -224,6 +224,115 @@ int orc_search_for_initialization(const float* kps1, const uint8_t* d1, int n1, 
   return nmatches;
 }
 
+// Projection-guided searches on flattened data (restates the common body of src/ORBmatcher.cc:42-119,
+// :258-361, :1161-1271, :1273-1384 and the candidate selection of Fuse :724-954): per query the caller
+// supplies the projected position, window radius, GetFeaturesInArea level range, optional predicted level
+// ([pred-1, pred] post-filter) and descriptor; `taken` carries the "keypoint already holds a map point" state.
+int orc_search_by_projection(const float* kps4, const uint8_t* desc, int n, const float* bounds, const float* q_uv,
+                             const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
+                             const int32_t* q_pred_level, const uint8_t* q_desc, const uint8_t* q_valid,
+                             const float* q_angle, int nq, const float* inv_level_sigma2, float chi2_gate,
+                             uint8_t* taken, int mode_best2, float ratio, int th, int check_ori, int32_t* q_match,
+                             int32_t* q_best_dist) {
+  Grid* G = new Grid();
+  G->build(kps4, n, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> cand;
+  int nmatches = 0;
+  for (int i = 0; i < nq; i++) {
+    q_match[i] = -1;
+    if (q_best_dist) q_best_dist[i] = 256;
+    if (q_valid && !q_valid[i]) continue;
+    G->features_in_area(q_uv[2 * i], q_uv[2 * i + 1], q_radius[i], q_min_level ? q_min_level[i] : -1,
+                        q_max_level ? q_max_level[i] : -1, cand);
+    if (cand.empty()) continue;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int idx : cand) {
+      if (taken && taken[idx]) continue;
+      const int kpLevel = (int)kps4[4 * idx + 2];
+      if (q_pred_level && q_pred_level[i] >= 0)
+        if (kpLevel < q_pred_level[i] - 1 || kpLevel > q_pred_level[i]) continue;
+      if (chi2_gate > 0) {
+        const float ex = q_uv[2 * i] - kps4[4 * idx], ey = q_uv[2 * i + 1] - kps4[4 * idx + 1];
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * inv_level_sigma2[kpLevel] > chi2_gate) continue;
+      }
+      const int dist = descriptor_distance(q_desc + 32 * (size_t)i, desc + 32 * (size_t)idx);
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kpLevel; bestIdx = idx; }
+      else if (mode_best2 && dist < bestDist2) { bestLevel2 = kpLevel; bestDist2 = dist; }
+    }
+    if (q_best_dist) q_best_dist[i] = bestDist;
+    if (bestIdx >= 0 && bestDist <= th) {
+      if (mode_best2 && bestLevel == bestLevel2 && bestDist > ratio * bestDist2) continue;
+      q_match[i] = bestIdx;
+      if (taken) taken[bestIdx] = 1;
+      nmatches++;
+      if (check_ori) rotHist[rot_bin(q_angle[i], kps4[4 * bestIdx + 3])].push_back(i);
+    }
+  }
+  if (check_ori) {
+    int cnt[HISTO_LENGTH], i1, i2, i3;
+    for (int b = 0; b < HISTO_LENGTH; b++) cnt[b] = (int)rotHist[b].size();
+    three_maxima(cnt, HISTO_LENGTH, i1, i2, i3);
+    for (int b = 0; b < HISTO_LENGTH; b++) {
+      if (b == i1 || b == i2 || b == i3) continue;
+      for (int qi : rotHist[b]) { if (taken) taken[q_match[qi]] = 0; q_match[qi] = -1; nmatches--; }
+    }
+  }
+  delete G;
+  return nmatches;
+}
+
+// SearchByBoW (src/ORBmatcher.cc:151-256 with strict = 0, :470-580 with strict = 1) on flattened data.
+int orc_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, const float* angle1, const uint8_t* desc2, int n2,
+                      const uint8_t* valid2, const float* angle2, const uint32_t* fv1_node, const uint32_t* fv1_off,
+                      const uint32_t* fv1_idx, int fv1_n, const uint32_t* fv2_node, const uint32_t* fv2_off,
+                      const uint32_t* fv2_idx, int fv2_n, float ratio, int th, int strict, int check_ori, int32_t* match12) {
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  std::vector<bool> matched2(n2, false);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0, a = 0, b = 0;
+  while (a < fv1_n && b < fv2_n) {
+    if (fv1_node[a] == fv2_node[b]) {
+      for (uint32_t e1 = fv1_off[a]; e1 < fv1_off[a + 1]; e1++) {
+        const int idx1 = (int)fv1_idx[e1];
+        if (valid1 && !valid1[idx1]) continue;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (uint32_t e2 = fv2_off[b]; e2 < fv2_off[b + 1]; e2++) {
+          const int idx2 = (int)fv2_idx[e2];
+          if (matched2[idx2] || (valid2 && !valid2[idx2])) continue;
+          const int dist = descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+          else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        const bool under = strict ? (bestDist1 < th) : (bestDist1 <= th);
+        if (under) {
+          if (static_cast<float>(bestDist1) < ratio * static_cast<float>(bestDist2)) {
+            match12[idx1] = bestIdx2; matched2[bestIdx2] = true;
+            if (check_ori) rotHist[rot_bin(angle1[idx1], angle2[bestIdx2])].push_back(idx1);
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (fv1_node[a] < fv2_node[b]) {
+      while (a < fv1_n && fv1_node[a] < fv2_node[b]) a++;          // lower_bound
+    } else {
+      while (b < fv2_n && fv2_node[b] < fv1_node[a]) b++;
+    }
+  }
+  if (check_ori) {
+    int cnt[HISTO_LENGTH], i1, i2, i3;
+    for (int k = 0; k < HISTO_LENGTH; k++) cnt[k] = (int)rotHist[k].size();
+    three_maxima(cnt, HISTO_LENGTH, i1, i2, i3);
+    for (int k = 0; k < HISTO_LENGTH; k++) {
+      if (k == i1 || k == i2 || k == i3) continue;
+      for (int idx1 : rotHist[k]) { match12[idx1] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 int orc_th_low() { return TH_LOW; }
 int orc_th_high() { return TH_HIGH; }
 int orc_histo_length() { return HISTO_LENGTH; }

@@ -76,6 +76,10 @@ def lib():
         L.orc_search_for_initialization.restype = C.c_int
         L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                     C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_projection.restype = C.c_int
+        L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_search_by_bow.restype = C.c_int
+        L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
         # BA
         L.orc_ba_solve.restype = C.c_int
         L.orc_ba_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
@@ -284,6 +288,39 @@ def search_for_initialization(kps1, d1, kps2, d2, bounds2, prev_matched, window=
     n = lib().orc_search_for_initialization(_p(kps1), _p(d1), len(kps1), _p(kps2), _p(d2), len(kps2), _p(b), _p(pm),
                                             window, nnratio, int(check_ori), _p(m))
     return m, n, pm
+
+
+def _opt(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dt)
+
+
+def search_by_projection(kps4, desc, bounds, q_uv, q_radius, q_desc, q_min_level=None, q_max_level=None, q_pred_level=None,
+                         q_valid=None, q_angle=None, inv_level_sigma2=None, chi2_gate=0.0, taken=None, mode_best2=False,
+                         ratio=0.8, th=100, check_ori=False):
+    kps4 = np.ascontiguousarray(kps4, np.float32); desc = np.ascontiguousarray(desc, np.uint8)
+    b = np.ascontiguousarray(bounds, np.float32); q_uv = np.ascontiguousarray(q_uv, np.float32)
+    q_radius = np.ascontiguousarray(q_radius, np.float32); q_desc = np.ascontiguousarray(q_desc, np.uint8)
+    nq = len(q_radius)
+    mn = _opt(q_min_level, np.int32); mx = _opt(q_max_level, np.int32); pl = _opt(q_pred_level, np.int32)
+    qv = _opt(q_valid, np.uint8); qa = _opt(q_angle, np.float32); isg = _opt(inv_level_sigma2, np.float32)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8).copy()
+    m = np.zeros(nq, np.int32); bd = np.zeros(nq, np.int32)
+    n = lib().orc_search_by_projection(_p(kps4), _p(desc), len(kps4), _p(b), _p(q_uv), _p(q_radius), _p(mn), _p(mx), _p(pl),
+                                       _p(q_desc), _p(qv), _p(qa), nq, _p(isg), float(chi2_gate), _p(tk), int(mode_best2),
+                                       float(ratio), int(th), int(check_ori), _p(m), _p(bd))
+    return n, m, bd, tk
+
+
+def search_by_bow(desc1, valid1, angle1, desc2, valid2, angle2, fv1, fv2, ratio=0.7, th=50, strict=False, check_ori=True):
+    """fv = (node ids ascending uint32, offsets uint32 [nnodes+1], indices uint32)"""
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    v1 = _opt(valid1, np.uint8); v2 = _opt(valid2, np.uint8); a1 = _opt(angle1, np.float32); a2 = _opt(angle2, np.float32)
+    f1 = [np.ascontiguousarray(x, np.uint32) for x in fv1]; f2 = [np.ascontiguousarray(x, np.uint32) for x in fv2]
+    m = np.zeros(len(d1), np.int32)
+    n = lib().orc_search_by_bow(_p(d1), len(d1), _p(v1), _p(a1), _p(d2), len(d2), _p(v2), _p(a2), _p(f1[0]), _p(f1[1]), _p(f1[2]),
+                                len(f1[0]), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]), float(ratio), int(th), int(strict),
+                                int(check_ori), _p(m))
+    return n, m
 
 
 # --------------------------------- BA ----------------------------------------

@@ -120,3 +120,84 @@ def test_full_size_match_properties():
     perm = rng.permutation(2000)
     bi2, bd2, sd2 = _m().hamming_best2(d, d[perm])
     assert np.array_equal(perm[bi2], np.arange(2000)) and np.array_equal(sd2, sd)
+
+
+# ---------------------------------------------------------------- guided searches (M4-M7, M9-M12 families)
+def _two_frames(oracle, seed=41):
+    E = oracle.OracleExtractor(1000)
+    seq, offs = synth.make_sequence(seed, 640, 480, 2, "blocks", max_shift=6)
+    k1, d1 = E.extract(seq[0]); k2, d2 = E.extract(seq[1])
+    f = lambda k: np.stack([k["x"], k["y"], k["octave"].astype(np.float32), k["angle"]], 1).astype(np.float32)
+    return f(k1), d1, f(k2), d2, (offs[1] - offs[0]).astype(np.float32), E
+
+
+@pytest.mark.parametrize("case", ["mappoints_best2", "lastframe_ori", "reloc_kf", "sim3_pred", "fuse_chi2"])
+def test_search_by_projection_families_vs_oracle(oracle, case):
+    K1, D1, K2, D2, shift, E = _two_frames(oracle)
+    rng = np.random.default_rng(5)
+    bounds = np.array([0, 640, 0, 480], np.float32)
+    nq = len(K1)
+    # "map points" = frame-1 keypoints projected into frame 2 by the known shift (+ a little noise)
+    q_uv = (K1[:, :2] - shift + rng.normal(0, 0.7, (nq, 2))).astype(np.float32)
+    lvl = K1[:, 2].astype(np.int32)
+    scale = E.scale[lvl]
+    valid = (rng.random(nq) > 0.1).astype(np.uint8)
+    taken0 = (rng.random(len(K2)) < 0.15).astype(np.uint8)
+    kw = dict(q_valid=valid)
+    if case == "mappoints_best2":      # src/ORBmatcher.cc:42-119
+        kw.update(q_radius=4.0 * scale, q_min_level=lvl - 1, q_max_level=lvl, taken=taken0, mode_best2=True, th=100)
+        ratio, ori = 0.8, False
+    elif case == "lastframe_ori":      # :1161-1271
+        kw.update(q_radius=15 * scale, q_min_level=lvl - 1, q_max_level=lvl + 1, taken=taken0, th=100, q_angle=K1[:, 3])
+        ratio, ori = 0.9, True
+    elif case == "reloc_kf":           # :1273-1384
+        kw.update(q_radius=10 * scale, q_min_level=lvl - 1, q_max_level=lvl + 1, taken=taken0, th=64, q_angle=K1[:, 3])
+        ratio, ori = 0.75, True
+    elif case == "sim3_pred":          # :258-361
+        kw.update(q_radius=10 * scale, q_pred_level=np.minimum(lvl + rng.integers(0, 2, nq), 7), taken=taken0, th=50)
+        ratio, ori = 0.75, False
+    else:                              # Fuse candidate selection, :724-842
+        kw.update(q_radius=3 * scale, q_pred_level=np.minimum(lvl + rng.integers(0, 2, nq), 7), th=50,
+                  inv_level_sigma2=E.inv_sigma2, chi2_gate=5.99)
+        ratio, ori = 0.6, False
+    n, m, bd, tk = _m(ratio, ori).search_by_projection(K2, D2, bounds, q_uv, kw.pop("q_radius"), D1, **kw)
+    okw = dict(kw); okw.pop("th")
+    on, om, obd, otk = oracle.search_by_projection(K2, D2, bounds, q_uv, (4.0 * scale if case == "mappoints_best2" else
+                                                   15 * scale if case == "lastframe_ori" else 10 * scale if case in ("reloc_kf", "sim3_pred") else 3 * scale),
+                                                   D1, ratio=ratio, th=kw["th"], check_ori=ori, **okw)
+    assert n == on and np.array_equal(m, om) and np.array_equal(bd, obd)
+    if tk is not None:
+        assert np.array_equal(tk, otk)
+    assert n > 50
+    hit = m >= 0
+    assert len(set(m[hit].tolist())) == hit.sum() or case == "fuse_chi2"      # one map point per keypoint when `taken` is tracked
+
+
+def _fake_feature_vector(rng, n, nnodes=40):
+    node_of = rng.integers(0, nnodes, n)
+    nodes = np.unique(node_of)
+    off = [0]; idx = []
+    for nd in nodes:
+        ii = np.nonzero(node_of == nd)[0]
+        idx.extend(ii.tolist()); off.append(len(idx))
+    return (nodes.astype(np.uint32) * 7 + 3, np.array(off, np.uint32), np.array(idx, np.uint32)), node_of
+
+
+@pytest.mark.parametrize("strict,ratio", [(False, 0.7), (True, 0.75)])
+def test_search_by_bow_vs_oracle(oracle, strict, ratio):
+    K1, D1, K2, D2, shift, E = _two_frames(oracle, seed=43)
+    rng = np.random.default_rng(6)
+    # a synthetic vocabulary level: true correspondences mostly share a node (the vocabulary blob is absent)
+    fv2, node2 = _fake_feature_vector(rng, len(K2))
+    bi, _, _ = oracle.hamming_best2(D1, D2)
+    node1 = np.where(rng.random(len(K1)) < 0.8, node2[bi], rng.integers(0, 40, len(K1)))
+    nodes = np.unique(node1); off = [0]; idx = []
+    for nd in nodes:
+        ii = np.nonzero(node1 == nd)[0]; idx.extend(ii.tolist()); off.append(len(idx))
+    fv1 = (nodes.astype(np.uint32) * 7 + 3, np.array(off, np.uint32), np.array(idx, np.uint32))
+    valid1 = (rng.random(len(K1)) > 0.2).astype(np.uint8)
+    valid2 = (rng.random(len(K2)) > 0.1).astype(np.uint8) if strict else None
+    n, m = _m(ratio, True).SearchByBoW(D1, valid1, K1[:, 3], D2, valid2, K2[:, 3], fv1, fv2, strict=strict)
+    on, om = oracle.search_by_bow(D1, valid1, K1[:, 3], D2, valid2, K2[:, 3], fv1, fv2, ratio=ratio, th=50, strict=strict, check_ori=True)
+    assert n == on and np.array_equal(m, om) and n > 30
+    assert (m[valid1 == 0] == -1).all()
