@@ -14,7 +14,7 @@ SYMBOLS = [
     "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_tables", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_set_profiling", "orbx_get_stage_ms", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
-    "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_bow",
+    "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_bow", "orbm_search_for_triangulation",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
     "ba_local_bundle_adjustment",
 ]
@@ -80,6 +80,8 @@ def load():
                                             vp, vp, C.POINTER(i32)]
     L.orbm_search_by_bow.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32, i32, i32, vp,
                                      C.POINTER(i32)]
+    L.orbm_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, f32, f32, vp, vp,
+                                                i32, vp, C.POINTER(i32)]
     if hasattr(L, "ba_solve"):
         L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
         L.ba_pose_optimization_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]

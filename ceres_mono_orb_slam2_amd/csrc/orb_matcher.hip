@@ -485,6 +485,79 @@ int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, cons
   return 0;
 }
 
+int orbm_search_for_triangulation(const float* kps1, const uint8_t* desc1, const uint8_t* unmapped1, int n1, const float* kps2,
+                                   const uint8_t* desc2, const uint8_t* unmapped2, int n2, const uint32_t* fv1_node,
+                                   const uint32_t* fv1_off, const uint32_t* fv1_idx, int fv1_n, const uint32_t* fv2_node,
+                                   const uint32_t* fv2_off, const uint32_t* fv2_idx, int fv2_n, const double* F12, float ex, float ey,
+                                   const float* scale_factors, const float* level_sigma2, int check_ori, int32_t* match12,
+                                   int* nmatches) {
+  ORBHIP_REQUIRE(n1 >= 0 && n2 >= 0 && fv1_n >= 0 && fv2_n >= 0 && nmatches && (n1 == 0 || match12), ORBHIP_EINVAL, "bad size");
+  *nmatches = 0;
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  if (n1 == 0 || n2 == 0 || fv1_n == 0 || fv2_n == 0) return 0;
+  ORBHIP_REQUIRE(kps1 && kps2 && desc1 && desc2 && F12 && scale_factors && level_sigma2 && fv1_node && fv2_node, ORBHIP_EINVAL, "NULL argument");
+  std::vector<int> qidx;
+  std::vector<uint32_t> off(1, 0), idx;
+  int a = 0, b = 0;
+  while (a < fv1_n && b < fv2_n) {
+    if (fv1_node[a] == fv2_node[b]) {
+      for (uint32_t e1 = fv1_off[a]; e1 < fv1_off[a + 1]; e1++) {
+        const int i1 = (int)fv1_idx[e1];
+        if (unmapped1 && !unmapped1[i1]) continue;                  // already holds a MapPoint (:620-623)
+        qidx.push_back(i1);
+        for (uint32_t e2 = fv2_off[b]; e2 < fv2_off[b + 1]; e2++) idx.push_back(fv2_idx[e2]);
+        off.push_back((uint32_t)idx.size());
+      }
+      a++; b++;
+    } else if (fv1_node[a] < fv2_node[b]) a++;
+    else b++;
+  }
+  const int nq = (int)qidx.size();
+  if (nq == 0) return 0;
+  std::vector<uint8_t> qd((size_t)nq * 32);
+  for (int i = 0; i < nq; i++) std::memcpy(&qd[(size_t)32 * i], desc1 + (size_t)32 * qidx[i], 32);
+  std::vector<int> dist;
+  if (int rc = csr_distances_gpu(qd.data(), nq, desc2, n2, off, idx, dist)) return rc;
+  std::vector<int> bins(n1, -1);
+  int cnt[HISTO_LENGTH] = {0}, nm = 0;
+  for (int i = 0; i < nq; i++) {
+    const int i1 = qidx[i];
+    const float x1 = kps1[4 * i1], y1 = kps1[4 * i1 + 1];
+    // epipolar line in image 2: l = x1' F12 (CheckDistEpipolarLine, :128-149)
+    const float la = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float lb = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float lc = x1 * F12[2] + y1 * F12[5] + F12[8];
+    int bestDist = TH_LOW, bestIdx2 = -1;
+    for (uint32_t c = off[i]; c < off[i + 1]; c++) {
+      const int i2 = (int)idx[c];
+      if (unmapped2 && !unmapped2[i2]) continue;                     // (vbMatched2 is never set in this fork)
+      const int d = dist[c];
+      if (d > TH_LOW || d > bestDist) continue;
+      const float x2 = kps2[4 * i2], y2 = kps2[4 * i2 + 1];
+      const int oct2 = (int)kps2[4 * i2 + 2];
+      const float distex = ex - x2, distey = ey - y2;
+      if (distex * distex + distey * distey < 100 * scale_factors[oct2]) continue;
+      const float num = la * x2 + lb * y2 + lc;
+      const float den = la * la + lb * lb;
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (dsqr < 3.84 * level_sigma2[oct2]) { bestIdx2 = i2; bestDist = d; }
+    }
+    if (bestIdx2 >= 0) {
+      match12[i1] = bestIdx2; nm++;
+      if (check_ori) { bins[i1] = rot_bin_host(kps1[4 * i1 + 3], kps2[4 * bestIdx2 + 3]); cnt[bins[i1]]++; }
+    }
+  }
+  if (check_ori) {
+    int i1, i2, i3;
+    three_maxima_host(cnt, i1, i2, i3);
+    for (int i = 0; i < n1; i++)
+      if (match12[i] >= 0 && bins[i] != i1 && bins[i] != i2 && bins[i] != i3) { match12[i] = -1; nm--; }
+  }
+  *nmatches = nm;
+  return 0;
+}
+
 int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int n1, const float* kps2,
                                    const uint8_t* desc2, int n2, const float* bounds2, float* prev_matched, int window,
                                    float nnratio, int check_ori, int32_t* matches12, int* nmatches) {

@@ -118,3 +118,23 @@ class ORBmatcher:
                                               self.TH_LOW if th is None else int(th), int(strict), int(self.mbCheckOrientation),
                                               _lib.ptr(m), C.byref(n)), "orbm_search_by_bow")
         return n.value, m[:len(d1)]
+
+    def SearchForTriangulation(self, kps1, desc1, unmapped1, kps2, desc2, unmapped2, fv1, fv2, F12, epipole, scale_factors,
+                               level_sigma2):
+        """src/ORBmatcher.cc:582-722 (mono) on flattened data.  Returns (nmatches, match12[n1])."""
+        f32, u8, u32 = np.float32, np.uint8, np.uint32
+        opt = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        k1 = np.ascontiguousarray(kps1, f32); k2 = np.ascontiguousarray(kps2, f32)
+        d1 = np.ascontiguousarray(desc1, u8); d2 = np.ascontiguousarray(desc2, u8)
+        u1, u2 = opt(unmapped1, u8), opt(unmapped2, u8)
+        f1 = [np.ascontiguousarray(x, u32) for x in fv1]; f2 = [np.ascontiguousarray(x, u32) for x in fv2]
+        F = np.ascontiguousarray(F12, np.float64).reshape(9); sf = np.ascontiguousarray(scale_factors, f32)
+        ls = np.ascontiguousarray(level_sigma2, f32)
+        m = np.full(max(len(k1), 1), -1, np.int32); n = C.c_int(0)
+        _lib.check(self._L.orbm_search_for_triangulation(_lib.ptr(k1), _lib.ptr(d1), _lib.ptr(u1), len(k1), _lib.ptr(k2), _lib.ptr(d2),
+                                                         _lib.ptr(u2), len(k2), _lib.ptr(f1[0]), _lib.ptr(f1[1]), _lib.ptr(f1[2]),
+                                                         len(f1[0]), _lib.ptr(f2[0]), _lib.ptr(f2[1]), _lib.ptr(f2[2]), len(f2[0]),
+                                                         _lib.ptr(F), float(epipole[0]), float(epipole[1]), _lib.ptr(sf), _lib.ptr(ls),
+                                                         int(self.mbCheckOrientation), _lib.ptr(m), C.byref(n)),
+                   "orbm_search_for_triangulation")
+        return n.value, m[:len(k1)]

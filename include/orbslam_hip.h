@@ -168,6 +168,18 @@ int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, cons
                        const uint32_t* fv2_off, const uint32_t* fv2_idx, int fv2_n, float ratio, int th, int strict,
                        int check_ori, int32_t* match12, int* nmatches);
 
+/* SearchForTriangulation (src/ORBmatcher.cc:582-722, mono) on flattened data (host pointers): BoW-node brute force
+ * between keypoints WITHOUT a map point (unmapped1/2 flags), dist <= TH_LOW with later ties replacing earlier ones
+ * (":654"), rejection near the epipole (ex, ey; ":658-664") and the epipolar-line gate CheckDistEpipolarLine
+ * (":128-149") with F12 row-major (3x3 doubles), scale_factors / level_sigma2 of keyframe 2.  Queries are
+ * independent (vbMatched2 is never set in this fork).  match12[n1] = index in keyframe 2 or -1.          */
+int orbm_search_for_triangulation(const float* kps1, const uint8_t* desc1, const uint8_t* unmapped1, int n1,
+                                  const float* kps2, const uint8_t* desc2, const uint8_t* unmapped2, int n2,
+                                  const uint32_t* fv1_node, const uint32_t* fv1_off, const uint32_t* fv1_idx, int fv1_n,
+                                  const uint32_t* fv2_node, const uint32_t* fv2_off, const uint32_t* fv2_idx, int fv2_n,
+                                  const double* F12, float ex, float ey, const float* scale_factors,
+                                  const float* level_sigma2, int check_ori, int32_t* match12, int* nmatches);
+
 /* ------------------------------------------------------------ bundle adjust --
  * Replaces CeresOptimizer::{PoseOptimization, BundleAdjustment/GlobalBundleAdjustemnt,
  * LocalBundleAdjustment, CheckOutlier(s)} (src/CeresOptimizer.cc:49-599) and the Ceres solve

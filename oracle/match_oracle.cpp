@@ -333,6 +333,62 @@ int orc_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, const
   return nmatches;
 }
 
+// SearchForTriangulation (src/ORBmatcher.cc:582-722, mono: no stereo keypoints) + CheckDistEpipolarLine (:128-149)
+int orc_search_for_triangulation(const float* kps1, const uint8_t* desc1, const uint8_t* unmapped1, int n1, const float* kps2,
+                                 const uint8_t* desc2, const uint8_t* unmapped2, int n2, const uint32_t* fv1_node,
+                                 const uint32_t* fv1_off, const uint32_t* fv1_idx, int fv1_n, const uint32_t* fv2_node,
+                                 const uint32_t* fv2_off, const uint32_t* fv2_idx, int fv2_n, const double* F12, float ex, float ey,
+                                 const float* scale_factors, const float* level_sigma2, int check_ori, int32_t* match12) {
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0, a = 0, b = 0;
+  while (a < fv1_n && b < fv2_n) {
+    if (fv1_node[a] == fv2_node[b]) {
+      for (uint32_t e1 = fv1_off[a]; e1 < fv1_off[a + 1]; e1++) {
+        const int idx1 = (int)fv1_idx[e1];
+        if (unmapped1 && !unmapped1[idx1]) continue;
+        const float k1x = kps1[4 * idx1], k1y = kps1[4 * idx1 + 1];
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (uint32_t e2 = fv2_off[b]; e2 < fv2_off[b + 1]; e2++) {
+          const int idx2 = (int)fv2_idx[e2];
+          if (unmapped2 && !unmapped2[idx2]) continue;
+          const int dist = descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+          if (dist > TH_LOW || dist > bestDist) continue;
+          const float k2x = kps2[4 * idx2], k2y = kps2[4 * idx2 + 1];
+          const int oct2 = (int)kps2[4 * idx2 + 2];
+          const float distex = ex - k2x, distey = ey - k2y;
+          if (distex * distex + distey * distey < 100 * scale_factors[oct2]) continue;
+          // CheckDistEpipolarLine
+          const float la = k1x * F12[0] + k1y * F12[3] + F12[6];
+          const float lb = k1x * F12[1] + k1y * F12[4] + F12[7];
+          const float lc = k1x * F12[2] + k1y * F12[5] + F12[8];
+          const float num = la * k2x + lb * k2y + lc;
+          const float den = la * la + lb * lb;
+          if (den == 0) continue;
+          const float dsqr = num * num / den;
+          if (dsqr < 3.84 * level_sigma2[oct2]) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+          match12[idx1] = bestIdx2; nmatches++;
+          if (check_ori) rotHist[rot_bin(kps1[4 * idx1 + 3], kps2[4 * bestIdx2 + 3])].push_back(idx1);
+        }
+      }
+      a++; b++;
+    } else if (fv1_node[a] < fv2_node[b]) a++;
+    else b++;
+  }
+  if (check_ori) {
+    int cnt[HISTO_LENGTH], i1, i2, i3;
+    for (int k = 0; k < HISTO_LENGTH; k++) cnt[k] = (int)rotHist[k].size();
+    three_maxima(cnt, HISTO_LENGTH, i1, i2, i3);
+    for (int k = 0; k < HISTO_LENGTH; k++) {
+      if (k == i1 || k == i2 || k == i3) continue;
+      for (int idx1 : rotHist[k]) { match12[idx1] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 int orc_th_low() { return TH_LOW; }
 int orc_th_high() { return TH_HIGH; }
 int orc_histo_length() { return HISTO_LENGTH; }

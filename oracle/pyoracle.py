@@ -80,6 +80,8 @@ def lib():
         L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_search_by_bow.restype = C.c_int
         L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_search_for_triangulation.restype = C.c_int
+        L.orc_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         # BA
         L.orc_ba_solve.restype = C.c_int
         L.orc_ba_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
@@ -320,6 +322,21 @@ def search_by_bow(desc1, valid1, angle1, desc2, valid2, angle2, fv1, fv2, ratio=
     n = lib().orc_search_by_bow(_p(d1), len(d1), _p(v1), _p(a1), _p(d2), len(d2), _p(v2), _p(a2), _p(f1[0]), _p(f1[1]), _p(f1[2]),
                                 len(f1[0]), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]), float(ratio), int(th), int(strict),
                                 int(check_ori), _p(m))
+    return n, m
+
+
+def search_for_triangulation(kps1, desc1, unmapped1, kps2, desc2, unmapped2, fv1, fv2, F12, epipole, scale_factors, level_sigma2,
+                             check_ori=False):
+    k1 = np.ascontiguousarray(kps1, np.float32); k2 = np.ascontiguousarray(kps2, np.float32)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    u1 = _opt(unmapped1, np.uint8); u2 = _opt(unmapped2, np.uint8)
+    f1 = [np.ascontiguousarray(x, np.uint32) for x in fv1]; f2 = [np.ascontiguousarray(x, np.uint32) for x in fv2]
+    F = np.ascontiguousarray(F12, np.float64).reshape(9); sf = np.ascontiguousarray(scale_factors, np.float32)
+    ls = np.ascontiguousarray(level_sigma2, np.float32)
+    m = np.zeros(len(k1), np.int32)
+    n = lib().orc_search_for_triangulation(_p(k1), _p(d1), _p(u1), len(k1), _p(k2), _p(d2), _p(u2), len(k2), _p(f1[0]), _p(f1[1]),
+                                           _p(f1[2]), len(f1[0]), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]), _p(F),
+                                           float(epipole[0]), float(epipole[1]), _p(sf), _p(ls), int(check_ori), _p(m))
     return n, m
 
 

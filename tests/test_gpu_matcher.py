@@ -201,3 +201,26 @@ def test_search_by_bow_vs_oracle(oracle, strict, ratio):
     on, om = oracle.search_by_bow(D1, valid1, K1[:, 3], D2, valid2, K2[:, 3], fv1, fv2, ratio=ratio, th=50, strict=strict, check_ori=True)
     assert n == on and np.array_equal(m, om) and n > 30
     assert (m[valid1 == 0] == -1).all()
+
+
+def test_search_for_triangulation_vs_oracle(oracle):
+    K1, D1, K2, D2, shift, E = _two_frames(oracle, seed=47)
+    rng = np.random.default_rng(8)
+    fv2, node2 = _fake_feature_vector(rng, len(K2), nnodes=25)
+    bi, _, _ = oracle.hamming_best2(D1, D2)
+    node1 = np.where(rng.random(len(K1)) < 0.8, node2[bi], rng.integers(0, 25, len(K1)))
+    nodes = np.unique(node1); off = [0]; idx = []
+    for nd in nodes:
+        ii = np.nonzero(node1 == nd)[0]; idx.extend(ii.tolist()); off.append(len(idx))
+    fv1 = (nodes.astype(np.uint32) * 7 + 3, np.array(off, np.uint32), np.array(idx, np.uint32))
+    um1 = (rng.random(len(K1)) > 0.3).astype(np.uint8); um2 = (rng.random(len(K2)) > 0.3).astype(np.uint8)
+    # pure-translation fundamental matrix F12 = [t]x (up to scale) for the known image shift: epipolar lines are
+    # parallel to the shift, so true correspondences pass the 3.84 sigma^2 gate; epipole far outside the image
+    t = np.array([shift[0], shift[1], 0.0]); t = t / (np.linalg.norm(t) + 1e-12)
+    F12 = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]], np.float64)
+    for ori in (False, True):
+        n, m = _m(0.6, ori).SearchForTriangulation(K1, D1, um1, K2, D2, um2, fv1, fv2, F12, (-5000.0, 240.0), E.scale, E.sigma2)
+        on, om = oracle.search_for_triangulation(K1, D1, um1, K2, D2, um2, fv1, fv2, F12, (-5000.0, 240.0), E.scale, E.sigma2,
+                                                 check_ori=ori)
+        assert n == on and np.array_equal(m, om) and n > 20
+        assert (m[um1 == 0] == -1).all() and (um2[m[m >= 0]] == 1).all()
