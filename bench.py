@@ -86,7 +86,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher
+    from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher, _lib
+    _lib.check(_lib.load().orbhip_set_default_device(local_rank), "orbhip_set_default_device")
     B = args.batch
     frames = make_frames(B, seed=rank)                 # each rank: its own frames (frame sharding)
     d_frames = torch.from_numpy(frames).to(dev)
@@ -134,6 +135,31 @@ def main():
     assert (c > 0).all(), "extractor produced an empty/overflowed frame"
     mean_kp, mean_match = float(c.mean()), float(nm.mean())
 
+    # ---- LocalBA / PoseOptimization legs: every rank solves its own independent problems (sub-map sharding, no
+    #      collective in the solve); for N > 1 the landmark updates are merged with ONE all-gather.
+    localba = None
+    if not args.no_ba:
+        ok = 1
+        try:
+            from ceres_mono_orb_slam2_amd import ba_bench
+            localba = ba_bench.run(dev, cpu=(not args.no_cpu) and world == 1)
+        except Exception as e:                       # never lose the headline line to the secondary leg
+            localba, ok = {"error": repr(e)}, 0
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # collectives below only if EVERY rank's leg succeeded
+            if int(flag.item()) == 1:
+                t = torch.tensor([localba["localba_solves_per_s"], localba["poseopt_solves_per_s"]], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                localba["localba_solves_per_s"], localba["poseopt_solves_per_s"] = float(t[0]), float(t[1])
+                pts = torch.from_numpy(localba["_final_points"]).to(dev)
+                torch.cuda.synchronize(); tg = time.perf_counter()
+                allp, _, counts = sharding.allgather_landmarks(pts)
+                torch.cuda.synchronize()
+                localba["landmark_allgather_ms"] = (time.perf_counter() - tg) * 1e3
+                localba["landmark_allgather_points"] = int(allp.shape[0])
+        if isinstance(localba, dict):
+            localba.pop("_final_points", None)
     if rank == 0:
         K = args.steps
         fps = B * world * K / dt
@@ -174,14 +200,10 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, args.cpu_sample)
-        if not args.no_ba:
-            try:
-                from ceres_mono_orb_slam2_amd import ba_bench
-                out["localba"] = ba_bench.run(dev, cpu=not args.no_cpu)
-            except ImportError:
-                out["localba"] = None
+        if localba is not None:
+            out["localba"] = localba
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -49,6 +49,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256):
                            "included); %d independent problems in flight from %d host threads" % (nthreads, nthreads))
     out["localba_lm_iterations"] = int(s1["iterations"] + s2["iterations"])
     out["localba_final_cost"] = float(s2["final_cost"])
+    out["_final_points"] = np.ascontiguousarray(pts)          # for the N > 1 landmark all-gather in bench.py
     # ---- C3: PoseOptimization, 1 camera x 2000 observations, batched device-resident
     probs = [synth.make_pose_problem(100 + i, n=2000) for i in range(8)]
     reps = n_pose_batch // len(probs)

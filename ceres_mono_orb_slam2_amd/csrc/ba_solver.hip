@@ -975,8 +975,14 @@ struct BaWorkspace {
 static thread_local BaWorkspace g_ws;
 // one non-blocking stream per host thread: independent solves issued from different threads overlap on the GPU
 static thread_local hipStream_t g_stream = nullptr;
+static thread_local int g_stream_device = -1;
 static hipStream_t thread_stream() {
-  if (!g_stream) { if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr; }
+  const int dev = g_default_device.load();
+  if (g_stream && g_stream_device != dev) {            // the default device changed: drop the old stream and workspace
+    (void)hipStreamDestroy(g_stream); g_stream = nullptr;
+    g_ws.slots.clear(); g_ws.hslots.clear();           // (buffers of the previous device are intentionally leaked)
+  }
+  if (!g_stream) { if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr; g_stream_device = dev; }
   return g_stream;
 }
 
@@ -1013,6 +1019,7 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
   ORBHIP_REQUIRE(nobs == 0 || (obs_cam_in && obs_pt_in && obs_uv_in && obs_w_in && obs_robust_in), ORBHIP_EINVAL, "NULL observation arrays");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+  if (int rcd = use_default_device()) return rcd;
   for (int i = 0; i < nobs; i++)
     ORBHIP_REQUIRE(obs_cam_in[i] >= 0 && obs_cam_in[i] < ncam && obs_pt_in[i] >= 0 && obs_pt_in[i] < npts, ORBHIP_EINVAL, "observation index out of range");
   const bool timing = std::getenv("ORBHIP_BA_TIMING") != nullptr;
@@ -1221,6 +1228,7 @@ int ba_pose_optimization(const double* K4, double* pose7, const double* Xw, cons
   ORBHIP_REQUIRE(Xw && uv && inv_sigma2 && outlier, ORBHIP_EINVAL, "NULL argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+  if (int rcd = use_default_device()) return rcd;
   HostBA H; int rc = 0;
   int offs[2] = {0, n};
   double* dK = H.upload(K4, 4, &rc); double* dP = H.upload(pose7, 7, &rc); double* dX = H.upload(Xw, 3 * (size_t)n, &rc);

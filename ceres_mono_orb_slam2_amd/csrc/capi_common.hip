@@ -1,7 +1,9 @@
 // Error plumbing and library-level entry points of the C ABI (include/orbslam_hip.h).
 #include "common.h"
 
+#include <atomic>
 namespace orbhip {
+std::atomic<int> g_default_device{0};
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -19,4 +21,11 @@ int orbhip_device_count(void) {
   return n;
 }
 const char* orbhip_version(void) { return "orbslam_hip 0.1 (gfx950)"; }
+int orbhip_set_default_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { orbhip::set_error("device ordinal %d out of range", device); return ORBHIP_EINVAL; }
+  orbhip::g_default_device.store(device);
+  return 0;
+}
+int orbhip_get_default_device(void) { return orbhip::g_default_device.load(); }
 }

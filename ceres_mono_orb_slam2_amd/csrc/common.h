@@ -11,6 +11,15 @@
 namespace orbhip {
 
 void set_error(const char* fmt, ...);
+}  // namespace orbhip
+#include <atomic>
+namespace orbhip {
+extern std::atomic<int> g_default_device;   // device used by the handle-less (matcher / BA) entry points
+inline int use_default_device() {
+  hipError_t e = hipSetDevice(g_default_device.load());
+  if (e != hipSuccess) { set_error("hipSetDevice(%d) failed: %s", g_default_device.load(), hipGetErrorString(e)); return ORBHIP_ENODEV; }
+  return 0;
+}
 
 #define ORBHIP_CHECK_HIP(expr)                                                                   \
   do {                                                                                           \

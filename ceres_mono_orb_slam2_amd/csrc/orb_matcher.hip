@@ -265,6 +265,7 @@ int orbm_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, const
   if (nq == 0) return 0;
   ORBHIP_REQUIRE(q && best_idx && best_d && second_d && (nt == 0 || t), ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE((off == nullptr) == (idx == nullptr), ORBHIP_EINVAL, "cand_offsets/cand_idx must both be given or both be NULL");
+  if (int rcd = use_default_device()) return rcd;
   DevBuf dq, dt, doff, didx, dout;
   const size_t total = off ? off[nq] : 0;
   int rc = 0;
@@ -318,6 +319,7 @@ static int csr_distances_gpu(const uint8_t* q, int nq, const uint8_t* t, int nt,
   const uint32_t total = off[nq];
   dist.resize(total);
   if (total == 0) return 0;
+  if (int rcd = use_default_device()) return rcd;
   DevBuf dq, dt, doff, didx, dd;
   auto cleanup = [&]() { dq.release(); dt.release(); doff.release(); didx.release(); dd.release(); };
   int rc = 0;
@@ -583,6 +585,7 @@ int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int 
   // ---- all candidate distances on the GPU -----------------------------------------------------
   std::vector<int> dist(total);
   {
+    if (int rcd = use_default_device()) return rcd;
     DevBuf dq, dt, doff, didx, dd;
     auto cleanup = [&]() { dq.release(); dt.release(); doff.release(); didx.release(); dd.release(); };
     int rc = 0;

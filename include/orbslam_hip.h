@@ -39,6 +39,10 @@ const char* orbhip_last_error(void);
 int orbhip_device_count(void);
 /* library version / build tag */
 const char* orbhip_version(void);
+/* HIP device used by the entry points that take no handle (matcher host-pointer calls, all ba_* calls);
+ * default 0.  hipSetDevice is per host thread, so every such call re-selects this device itself. */
+int orbhip_set_default_device(int device);
+int orbhip_get_default_device(void);
 
 /* ---------------------------------------------------------------- extractor --
  * Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-111,
