@@ -757,9 +757,6 @@ __global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int kcol, int K, int
       }
 }
 
-// (legacy name kept for the profile history)
-__global__ __launch_bounds__(256) void k_chol_syrk_rhs(BaDev D, int k) {}
-
 // backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
 // of 256 rows processed from the bottom: k_chol_bsolve_diag solves one super-block with a single
 // workgroup (its <= 8 diagonal 32x32 solves are mat-vecs with the stored L11^-1 blocks), then
