@@ -142,7 +142,7 @@ def main():
         ok = 1
         try:
             from ceres_mono_orb_slam2_amd import ba_bench
-            localba = ba_bench.run(dev, cpu=(not args.no_cpu) and world == 1)
+            localba = ba_bench.run(dev, cpu=(not args.no_cpu) and world == 1, rank=rank)
         except Exception as e:                       # never lose the headline line to the secondary leg
             localba, ok = {"error": repr(e)}, 0
         if world > 1:

@@ -6,7 +6,7 @@ import numpy as np
 from . import optimizer, synth
 
 
-def run(dev, cpu=True, n_localba=6, n_pose_batch=256):
+def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     import torch
     out = {}
     # ---- C4: LocalBundleAdjustment, 100 KF x 10k pts x 50k obs, reference two-pass schedule (5 + 10 iterations)
@@ -49,7 +49,6 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256):
                            "included); %d independent problems in flight from %d host threads" % (nthreads, nthreads))
     out["localba_lm_iterations"] = int(s1["iterations"] + s2["iterations"])
     out["localba_final_cost"] = float(s2["final_cost"])
-    out["_final_points"] = np.ascontiguousarray(pts)          # for the N > 1 landmark all-gather in bench.py
     # ---- C3: PoseOptimization, 1 camera x 2000 observations, batched device-resident
     probs = [synth.make_pose_problem(100 + i, n=2000) for i in range(8)]
     reps = n_pose_batch // len(probs)
@@ -72,6 +71,19 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256):
     dt = time.perf_counter() - t0
     out["poseopt_solves_per_s"] = nrep * n_pose_batch / dt
     out["poseopt_note"] = "1 camera x 2000 observations per problem, %d problems per launch, device-resident" % n_pose_batch
+    # ---- C5: GlobalBundleAdjustemnt of one 500-KF sub-map per GPU (~50 k pts, 250 k obs, 2994 x 2994 reduced system),
+    #      loop-closure setting: 50 iterations, Huber (src/LoopClosing.cc:656); each rank solves ITS OWN sub-map
+    gg = synth.make_ba_graph(1000 + rank, ncam=500, npts=50000, nobs=250000, n_fixed=1)
+    gargs = (gg["K4"], gg["poses0"], gg["cam_fixed"], gg["pts0"], gg["obs_cam"], gg["obs_pt"], gg["obs_uv"], gg["obs_inv_sigma2"])
+    optimizer.global_bundle_adjustment(*gargs, n_iterations=2)     # warm-up
+    t0 = time.perf_counter()
+    gposes, gpts, gs = optimizer.global_bundle_adjustment(*gargs, n_iterations=50)
+    dt = time.perf_counter() - t0
+    out["globalba_500kf_ms"] = dt * 1e3
+    out["globalba_500kf_iterations"] = int(gs["iterations"])
+    out["globalba_500kf_ms_per_iteration"] = dt * 1e3 / max(int(gs["iterations"]), 1)
+    out["globalba_note"] = "500 KF x 50000 pts x 250000 obs, <= 50 LM iterations, host-pointer C ABI end to end, one sub-map per GPU"
+    out["_final_points"] = np.ascontiguousarray(gpts)            # merged across ranks with ONE all-gather (bench.py, N > 1)
     if cpu:
         from oracle import pyoracle as po
         t0 = time.perf_counter()
