@@ -24,7 +24,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     out["localba_ms_per_solve_latency"] = dt / n_localba * 1e3
     # throughput: independent LocalBA problems in flight from `nthreads` host threads (one HIP stream and one
     # device workspace per thread) - the sub-problem sharding of SURVEY 8(e) inside one GPU
-    nthreads, n_each = 8, 6
+    nthreads, n_each = 12, 4
     bar = threading.Barrier(nthreads + 1)
 
     def work():
