@@ -881,7 +881,9 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
       node_cap = std::max(node_cap, std::max(L.quota + 8, 4 * nIni + 8));
       sel_cap = std::max(sel_cap, L.quota + 4);
       long long theo = (long long)L.ncells * cell_cap;
-      L.kcap = (int)std::min<long long>(std::max<long long>(theo, 64), KEYCAP_MAX);
+      int keycap_max = KEYCAP_MAX;
+      if (const char* e = std::getenv("ORBHIP_KEYCAP")) keycap_max = std::max(64, std::min(KEYCAP_MAX, atoi(e)));   // test hook for the overflow path
+      L.kcap = (int)std::min<long long>(std::max<long long>(theo, 64), keycap_max);
       L.key_off = key_off; key_off += round_up(L.kcap, 4);
       // resize tables: level l from level l-1
       if (l > 0) {
