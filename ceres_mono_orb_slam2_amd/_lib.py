@@ -16,7 +16,7 @@ SYMBOLS = [
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
     "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_bow", "orbm_search_for_triangulation",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
-    "ba_local_bundle_adjustment",
+    "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log",
 ]
 
 
@@ -90,6 +90,10 @@ def load():
         L.ba_check_outlier.argtypes = [vp, vp, vp, vp, f64, f64, vp]
         L.ba_local_bundle_adjustment.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp,
                                                  C.POINTER(i32), C.POINTER(BaSummary), C.POINTER(BaSummary)]
+        L.ba_optimize_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
+        L.ba_optimize_sim3_batch_device.argtypes = [vp] * 11 + [i32, vp, vp, vp, vp]
+        L.ba_sim3_exp.argtypes = [vp, vp]
+        L.ba_sim3_log.argtypes = [vp, vp]
     _lib = L
     return L
 

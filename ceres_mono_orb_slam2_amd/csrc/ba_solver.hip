@@ -38,6 +38,7 @@
 
 #include "common.h"
 #include "ba_math.h"
+#include "sim3_math.h"
 
 namespace orbhip {
 
@@ -241,6 +242,202 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
     for (int k = 0; k < 3; k++) pose[k] = s_x[k];
     for (int k = 0; k < 4; k++) pose[3 + k] = q[k] / nq;
     n_inliers[p] = n - s_nbad;
+    if (summaries) {
+      ba_summary s;
+      s.initial_cost = s_init; s.final_cost = s_xcost; s.iterations = s_iter; s.successful_steps = s_succ;
+      s.termination = s_term; s.final_radius = s_radius;
+      summaries[p] = s;
+    }
+  }
+}
+
+
+// ============================================================================ OptimizeSim3
+// The WHOLE solve of one keyframe pair inside one workgroup, as k_pose_lm: 2n Sim3ErrorTerm residual blocks on a single
+// 7-parameter block (tangent of S12), HuberLoss(sqrt(th2)), Sim3Parameterization::Plus, <= 100 iterations
+// (src/CeresOptimizer.cc:601-735).  One workgroup per problem; offsets[] delimits the correspondences.
+__device__ __forceinline__ int sym7(int a, int b) { return a <= b ? a * 7 - a * (a - 1) / 2 + (b - a) : b * 7 - b * (b - 1) / 2 + (a - b); }
+
+__device__ bool chol7_solve(double* A, double* b) {
+  const int n = 7;
+  for (int j = 0; j < n; j++) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0.0) || !isfinite(d)) return false;
+    d = sqrt(d);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i * n + k] * b[k]; b[i] = s / A[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= A[k * n + i] * b[k]; b[i] = s / A[i * n + i]; }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_sim3_lm(const double* __restrict__ K1s, const double* __restrict__ K2s, double* __restrict__ s12s,
+                                                 const double* __restrict__ P3D2c, const double* __restrict__ obs1,
+                                                 const float* __restrict__ w1, const double* __restrict__ P3D1c,
+                                                 const double* __restrict__ obs2, const float* __restrict__ w2,
+                                                 const int* __restrict__ offsets, const double* __restrict__ th2s,
+                                                 uint8_t* __restrict__ outlier, int* __restrict__ n_inliers,
+                                                 ba_summary* __restrict__ summaries, int max_iters) {
+  __shared__ double s_red[4 * 36], s_sum[36];
+  __shared__ double s_x[7], s_cand[7], s_S[7], s_Si[7], s_scale[7], s_H[28], s_g[7];
+  __shared__ double s_radius, s_dec, s_xcost, s_xnorm, s_mcc, s_stepnorm, s_init;
+  __shared__ int s_iter, s_term, s_done, s_valid, s_accept, s_invalid, s_succ, s_nbad;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int lo = offsets[p], n = offsets[p + 1] - lo;
+  const double* K1 = K1s + 4 * p;
+  const double* K2 = K2s + 4 * p;
+  const double huber = sqrt(th2s[p]);                         // :619
+  if (tid == 0) {
+    s3_log(s12s + 7 * p, s_x);                                // :605
+    s3_exp(s_x, s_S); s3_inverse(s_S, s_Si);
+    s_radius = 1e4; s_dec = 2.0; s_iter = 0; s_term = 0; s_done = (n == 0); s_invalid = 0; s_succ = 0; s_nbad = 0;
+    s_xcost = 0.0; s_init = 0.0;
+  }
+  __syncthreads();
+
+  auto evaluate = [&](bool first) {          // expects s_S / s_Si = exp(s_x) and its inverse
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+    for (int i = tid; i < 2 * n; i += 256) {
+      const int g = lo + (i >> 1), inv = i & 1;              // residual-block order: forward then inverse term per match
+      double r[2], J[14];
+      const double rho = inv ? s3_term_eval(K2, s_Si, P3D1c + 3 * (size_t)g, obs2[2 * (size_t)g], obs2[2 * (size_t)g + 1], (double)w2[g], huber, r, J)
+                             : s3_term_eval(K1, s_S, P3D2c + 3 * (size_t)g, obs1[2 * (size_t)g], obs1[2 * (size_t)g + 1], (double)w1[g], huber, r, J);
+      acc[0] += 0.5 * rho;
+#pragma unroll
+      for (int a = 0; a < 7; a++) {
+        acc[1 + a] += J[a] * r[0] + J[7 + a] * r[1];
+#pragma unroll
+        for (int b = a; b < 7; b++) acc[8 + sym7(a, b)] += J[a] * J[b] + J[7 + a] * J[7 + b];
+      }
+    }
+    block_reduce<36>(acc, s_red, s_sum);
+    if (tid == 0) {
+      s_xcost = s_sum[0];
+      for (int a = 0; a < 7; a++) s_g[a] = s_sum[1 + a];
+      for (int k = 0; k < 28; k++) s_H[k] = s_sum[8 + k];
+      if (first) {
+        for (int a = 0; a < 7; a++) s_scale[a] = 1.0 / (1.0 + sqrt(s_H[sym7(a, a)]));
+        s_init = s_xcost;
+      }
+      double xn = 0;
+      for (int k = 0; k < 7; k++) xn += s_x[k] * s_x[k];
+      s_xnorm = sqrt(xn);
+      double mg[7], xp[7], gmax = 0;                          // gradient max norm = || x - Plus(x, -g) ||_inf
+      for (int k = 0; k < 7; k++) mg[k] = -s_g[k];
+      s3_plus(s_x, mg, xp);
+      for (int k = 0; k < 7; k++) gmax = fmax(gmax, fabs(s_x[k] - xp[k]));
+      if (gmax <= 1e-10) { s_term = 1; s_done = 1; }
+    }
+    __syncthreads();
+  };
+
+  int done = s_done;
+  if (!done) { evaluate(true); done = s_done; }
+  while (!done) {
+    __syncthreads();
+    if (tid == 0) {
+      s_valid = 0; s_accept = 0;
+      if (s_iter >= max_iters) { s_term = 0; s_done = 1; }
+      else if (s_radius <= 1e-32) { s_term = 6; s_done = 1; }
+      else {
+        s_iter++;
+        double A[49], y[7], Hs[49], gs[7];
+        for (int a = 0; a < 7; a++) {
+          gs[a] = s_g[a] * s_scale[a];
+          for (int b = 0; b < 7; b++) Hs[a * 7 + b] = s_H[sym7(a, b)] * s_scale[a] * s_scale[b];
+        }
+        for (int k = 0; k < 49; k++) A[k] = Hs[k];
+        for (int a = 0; a < 7; a++) A[a * 8] += fmin(fmax(Hs[a * 8], 1e-6), 1e32) / s_radius;
+        for (int a = 0; a < 7; a++) y[a] = gs[a];
+        bool ok = chol7_solve(A, y);
+        double mcc = 0;
+        if (ok) {
+          for (int a = 0; a < 7; a++) {
+            double hs = 0;
+            for (int b = 0; b < 7; b++) hs += Hs[a * 7 + b] * (-y[b]);
+            mcc -= (-y[a]) * (gs[a] + 0.5 * hs);
+          }
+        }
+        if (!ok || !(mcc > 0.0)) {
+          if (++s_invalid >= 5) { s_term = 5; s_done = 1; }
+          s_radius /= s_dec; s_dec *= 2;
+        } else {
+          s_invalid = 0; s_valid = 1; s_mcc = mcc;
+          double d[7];
+          for (int k = 0; k < 7; k++) d[k] = (-y[k]) * s_scale[k];
+          s3_plus(s_x, d, s_cand);
+          double sn = 0;
+          for (int k = 0; k < 7; k++) { double e = s_x[k] - s_cand[k]; sn += e * e; }
+          s_stepnorm = sqrt(sn);
+          s3_exp(s_cand, s_S); s3_inverse(s_S, s_Si);        // candidate transform for the cost pass
+        }
+      }
+    }
+    __syncthreads();
+    done = s_done;
+    const int valid = s_valid;
+    if (done) break;
+    if (!valid) continue;
+    double acc[1] = {0.0};
+    for (int i = tid; i < 2 * n; i += 256) {
+      const int g = lo + (i >> 1), inv = i & 1;
+      double r[2];
+      acc[0] += 0.5 * (inv ? s3_term_eval(K2, s_Si, P3D1c + 3 * (size_t)g, obs2[2 * (size_t)g], obs2[2 * (size_t)g + 1], (double)w2[g], huber, r, nullptr)
+                           : s3_term_eval(K1, s_S, P3D2c + 3 * (size_t)g, obs1[2 * (size_t)g], obs1[2 * (size_t)g + 1], (double)w1[g], huber, r, nullptr));
+    }
+    block_reduce<1>(acc, s_red, s_sum);
+    if (tid == 0) {
+      double cand_cost = s_sum[0];
+      if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
+      if (s_stepnorm <= 1e-8 * (s_xnorm + 1e-8)) { s_term = 2; s_done = 1; }
+      else {
+        const double cost_change = s_xcost - cand_cost;
+        if (fabs(cost_change) <= 1e-6 * s_xcost) { s_term = 3; s_done = 1; }
+        else {
+          const double rel = cost_change / s_mcc;
+          if (rel > 1e-3) {
+            s_accept = 1; s_succ++;
+            for (int k = 0; k < 7; k++) s_x[k] = s_cand[k];   // s_S / s_Si already hold exp(cand)
+            s_radius = fmin(1e16, s_radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3)));
+            s_dec = 2.0;
+          } else {
+            s_radius /= s_dec; s_dec *= 2.0;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    done = s_done;
+    const int accept = s_accept;
+    if (done) break;
+    if (accept) { evaluate(false); done = s_done; }
+  }
+  __syncthreads();
+  if (tid == 0) { s3_exp(s_x, s_S); s3_inverse(s_S, s_Si); }  // S12 = exp(sim12) (:691), S21 (:703)
+  __syncthreads();
+  const double thres = huber * huber;                         // deltaHuber * deltaHuber (:701)
+  int bad = 0;
+  for (int i = tid; i < n; i += 256) {
+    const int g = lo + i;
+    const int o12 = s3_check_outlier(K1, s_S, P3D2c + 3 * (size_t)g, obs1[2 * (size_t)g], obs1[2 * (size_t)g + 1], w1[g], thres);
+    const int o21 = s3_check_outlier(K2, s_Si, P3D1c + 3 * (size_t)g, obs2[2 * (size_t)g], obs2[2 * (size_t)g + 1], w2[g], thres);
+    if (outlier) outlier[g] = (uint8_t)(o12 | o21);
+    bad += (o12 | o21);
+  }
+  if (bad) atomicAdd(&s_nbad, bad);
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 0; k < 7; k++) s12s[7 * p + k] = s_S[k];
+    const int good = n - s_nbad;
+    n_inliers[p] = good < 10 ? 0 : good;                      // :731
     if (summaries) {
       ba_summary s;
       s.initial_cost = s_init; s.final_cost = s_xcost; s.iterations = s_iter; s.successful_steps = s_succ;
@@ -1240,6 +1437,50 @@ int ba_pose_optimization(const double* K4, double* pose7, const double* Xw, cons
   if (summary) ORBHIP_CHECK_HIP(hipMemcpy(summary, dSum, sizeof(ba_summary), hipMemcpyDeviceToHost));
   return 0;
 }
+
+int ba_optimize_sim3_batch_device(const double* d_K1, const double* d_K2, double* d_s12, const double* d_P3D2c, const double* d_obs1,
+                                  const float* d_inv_sigma2_1, const double* d_P3D1c, const double* d_obs2,
+                                  const float* d_inv_sigma2_2, const int32_t* d_offsets, const double* d_th2, int nproblems,
+                                  uint8_t* d_outlier, int32_t* d_n_inliers, ba_summary* d_summary, void* stream) {
+  ORBHIP_REQUIRE(nproblems >= 0, ORBHIP_EINVAL, "bad size");
+  if (nproblems == 0) return 0;
+  ORBHIP_REQUIRE(d_K1 && d_K2 && d_s12 && d_offsets && d_th2 && d_n_inliers, ORBHIP_EINVAL, "NULL argument");
+  hipLaunchKernelGGL(k_sim3_lm, dim3(nproblems), dim3(256), 0, (hipStream_t)stream, d_K1, d_K2, d_s12, d_P3D2c, d_obs1, d_inv_sigma2_1,
+                     d_P3D1c, d_obs2, d_inv_sigma2_2, d_offsets, d_th2, d_outlier, d_n_inliers, d_summary, 100);   // :625
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int ba_optimize_sim3(const double* K1, const double* K2, double* s12, const double* P3D2c, const double* obs1,
+                     const float* inv_sigma2_1, const double* P3D1c, const double* obs2, const float* inv_sigma2_2, int n,
+                     double th2, int fix_scale, uint8_t* outlier, int* n_inliers, ba_summary* summary) {
+  (void)fix_scale;                                             // the reference never reads bFixScale (:604)
+  ORBHIP_REQUIRE(K1 && K2 && s12 && n_inliers && n >= 0 && th2 > 0.0, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(n == 0 || (P3D2c && obs1 && inv_sigma2_1 && P3D1c && obs2 && inv_sigma2_2), ORBHIP_EINVAL, "NULL correspondence arrays");
+  *n_inliers = 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+  if (int rcd = use_default_device()) return rcd;
+  HostBA H; int rc = 0;
+  int offs[2] = {0, n};
+  double* dK1 = H.upload(K1, 4, &rc); double* dK2 = H.upload(K2, 4, &rc); double* dS = H.upload(s12, 7, &rc);
+  double* dP2 = H.upload(P3D2c, 3 * (size_t)n, &rc); double* dO1 = H.upload(obs1, 2 * (size_t)n, &rc); float* dW1 = H.upload(inv_sigma2_1, n, &rc);
+  double* dP1 = H.upload(P3D1c, 3 * (size_t)n, &rc); double* dO2 = H.upload(obs2, 2 * (size_t)n, &rc); float* dW2 = H.upload(inv_sigma2_2, n, &rc);
+  int* dOff = H.upload(offs, 2, &rc); double* dTh = H.upload(&th2, 1, &rc);
+  uint8_t* dOut = H.alloc<uint8_t>(n, &rc); int* dN = H.alloc<int>(1, &rc); ba_summary* dSum = H.alloc<ba_summary>(1, &rc);
+  if (rc) return rc;
+  rc = ba_optimize_sim3_batch_device(dK1, dK2, dS, dP2, dO1, dW1, dP1, dO2, dW2, dOff, dTh, 1, dOut, dN, dSum, nullptr);
+  if (rc) return rc;
+  ORBHIP_CHECK_HIP(hipMemcpy(s12, dS, 7 * sizeof(double), hipMemcpyDeviceToHost));
+  if (outlier && n) ORBHIP_CHECK_HIP(hipMemcpy(outlier, dOut, n, hipMemcpyDeviceToHost));
+  ORBHIP_CHECK_HIP(hipMemcpy(n_inliers, dN, sizeof(int), hipMemcpyDeviceToHost));
+  if (summary) ORBHIP_CHECK_HIP(hipMemcpy(summary, dSum, sizeof(ba_summary), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Sim(3) helpers a host binding needs to cross the Sophus boundary without Sophus (host arithmetic, no device work).
+int ba_sim3_exp(const double* tangent7, double* s12_out) { ORBHIP_REQUIRE(tangent7 && s12_out, ORBHIP_EINVAL, "NULL argument"); s3_exp(tangent7, s12_out); return 0; }
+int ba_sim3_log(const double* s12, double* tangent7_out) { ORBHIP_REQUIRE(s12 && tangent7_out, ORBHIP_EINVAL, "NULL argument"); s3_log(s12, tangent7_out); return 0; }
 
 int ba_local_bundle_adjustment(const double* K4, double* poses7, const uint8_t* cam_fixed, const uint8_t* cam_local, int ncam,
                                double* pts3, int npts, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv,

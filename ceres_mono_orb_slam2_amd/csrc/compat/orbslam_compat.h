@@ -215,9 +215,26 @@ struct BAProblem {            // what BundleAdjustment / LocalBundleAdjustment r
   std::vector<float> obs_inv_sigma2;
   std::vector<uint8_t> obs_erase;         // out (LocalBundleAdjustment: to_erase membership)
 };
+struct Sim3Problem {          // what OptimizeSim3 reads from the two keyframes and matches12 (src/CeresOptimizer.cc:601-692)
+  double K1[4], K2[4];
+  std::vector<double> P3D2c, obs1, P3D1c, obs2;   // 3 / 2 doubles per accepted correspondence, reference loop order
+  std::vector<float> inv_sigma2_1, inv_sigma2_2;
+  std::vector<uint8_t> is_outliers_;              // out: is_outlier_12 || is_outlier_21 (:694-726)
+};
 
 class CeresOptimizer {
  public:
+  // int OptimizeSim3(KeyFrame*, KeyFrame*, vector<MapPoint*>& matches12, Sophus::Sim3d& S12, const float th2,
+  //                  const bool bFixScale) (:601-735).  S12 = Sophus::Sim3d::data() (7 doubles: scaled q_xyzw, t).
+  int static OptimizeSim3(Sim3Problem* p, double* S12, const float th2, const bool bFixScale) {
+    const int n = (int)p->inv_sigma2_1.size();
+    p->is_outliers_.assign(n, 0);
+    int inl = 0;
+    orbcompat_check(ba_optimize_sim3(p->K1, p->K2, S12, p->P3D2c.data(), p->obs1.data(), p->inv_sigma2_1.data(), p->P3D1c.data(),
+                                     p->obs2.data(), p->inv_sigma2_2.data(), n, (double)th2, bFixScale ? 1 : 0,
+                                     p->is_outliers_.data(), &inl, nullptr), "ba_optimize_sim3");
+    return inl;
+  }
   // int PoseOptimization(Frame*) (src/CeresOptimizer.cc:275-342): returns n_initial - n_bad
   int static PoseOptimization(PoseProblem* f) {
     const int n = (int)f->inv_sigma2.size();

@@ -104,3 +104,56 @@ def local_bundle_adjustment(K4, poses7, cam_fixed, cam_local, pts3, obs_cam, obs
                                             int(duplicate_blocks), _lib.ptr(er), C.byref(ab), C.byref(s1), C.byref(s2)),
                "ba_local_bundle_adjustment")
     return ab.value, poses, pts, er[:len(oc)], s1.as_dict(), s2.as_dict()
+
+
+def optimize_sim3(K1, K2, s12, P3D2c, obs1, inv_sigma2_1, P3D1c, obs2, inv_sigma2_2, th2=10.0, fix_scale=False):
+    """CeresOptimizer::OptimizeSim3 (src/CeresOptimizer.cc:601-735) on flattened correspondences.
+    s12 = Sophus::Sim3d::data() layout [qx,qy,qz,qw (|q|^2 = scale), tx,ty,tz]; th2 = 10 at the only call site
+    (src/LoopClosing.cc:324).  fix_scale is ignored exactly as the reference ignores bFixScale.
+    Returns (n_inliers, s12, outlier_flags, summary)."""
+    L = _lib.load()
+    K1 = _f64(K1); K2 = _f64(K2); S = _f64(s12).copy()
+    P2 = _f64(P3D2c).reshape(-1, 3); o1 = _f64(obs1).reshape(-1, 2); w1 = np.ascontiguousarray(inv_sigma2_1, np.float32)
+    P1 = _f64(P3D1c).reshape(-1, 3); o2 = _f64(obs2).reshape(-1, 2); w2 = np.ascontiguousarray(inv_sigma2_2, np.float32)
+    n = len(P2)
+    assert len(P1) == n and len(o1) == n and len(o2) == n and len(w1) == n and len(w2) == n
+    out = np.zeros(max(n, 1), np.uint8)
+    ninl = C.c_int(0); s = _lib.BaSummary()
+    _lib.check(L.ba_optimize_sim3(_lib.ptr(K1), _lib.ptr(K2), _lib.ptr(S), _lib.ptr(P2), _lib.ptr(o1), _lib.ptr(w1), _lib.ptr(P1),
+                                  _lib.ptr(o2), _lib.ptr(w2), n, float(th2), int(bool(fix_scale)), _lib.ptr(out), C.byref(ninl),
+                                  C.byref(s)), "ba_optimize_sim3")
+    return ninl.value, S, out[:n], s.as_dict()
+
+
+def optimize_sim3_batch(d_K1, d_K2, d_s12, d_P3D2c, d_obs1, d_w1, d_P3D1c, d_obs2, d_w2, d_offsets, d_th2, stream=None):
+    """Batched device-resident OptimizeSim3 (torch CUDA tensors, one loop candidate per problem); d_s12 is updated in
+    place.  Returns (outlier[total] uint8, n_inliers[np] int32, summaries[np, sizeof(ba_summary)] bytes)."""
+    import torch
+    L = _lib.load()
+    npb = d_s12.shape[0]
+    total = d_P3D2c.shape[0]
+    dev = d_s12.device
+    outl = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
+    ninl = torch.empty((npb,), dtype=torch.int32, device=dev)
+    summ = torch.empty((npb, C.sizeof(_lib.BaSummary)), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    _lib.check(L.ba_optimize_sim3_batch_device(_lib.ptr(d_K1), _lib.ptr(d_K2), _lib.ptr(d_s12), _lib.ptr(d_P3D2c), _lib.ptr(d_obs1),
+                                               _lib.ptr(d_w1), _lib.ptr(d_P3D1c), _lib.ptr(d_obs2), _lib.ptr(d_w2), _lib.ptr(d_offsets),
+                                               _lib.ptr(d_th2), npb, _lib.ptr(outl), _lib.ptr(ninl), _lib.ptr(summ), C.c_void_p(st)),
+               "ba_optimize_sim3_batch_device")
+    return outl[:total], ninl, summ
+
+
+def sim3_exp(tangent7):
+    """Sophus::Sim3d::exp in the qt7 layout (host arithmetic of the library)."""
+    L = _lib.load()
+    a = _f64(tangent7); out = np.zeros(7)
+    _lib.check(L.ba_sim3_exp(_lib.ptr(a), _lib.ptr(out)), "ba_sim3_exp")
+    return out
+
+
+def sim3_log(s12):
+    L = _lib.load()
+    a = _f64(s12); out = np.zeros(7)
+    _lib.check(L.ba_sim3_log(_lib.ptr(a), _lib.ptr(out)), "ba_sim3_log")
+    return out

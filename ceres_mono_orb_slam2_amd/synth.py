@@ -160,6 +160,36 @@ def make_pose_problem(seed, n=2000, outlier_frac=0.05, w=1241, h=376):
     return dict(K4=K4, pose0=pose0, pose_gt=pose_gt, Xw=Xw, uv=obs, inv_sigma2=inv_sigma2, octave=octv)
 
 
+def make_sim3_problem(seed, n=120, outlier_frac=0.1, scale=1.15, noise=1.0, perturb=(0.02, 0.1, 0.03), w=1241, h=376):
+    """Loop-closure pair for OptimizeSim3: n matched map points seen by keyframe 1 and keyframe 2 whose maps differ by
+    the similarity S12 (P1c = S12 * P2c, scale drift `scale`).  Returns the flattened correspondences of
+    include/orbslam_hip.h::ba_optimize_sim3, the ground truth and a perturbed start, s12 in [qx,qy,qz,qw(|q|^2=s),t]."""
+    rng = np.random.default_rng(seed)
+    K1 = KITTI_K4.copy(); K2 = KITTI_K4.copy()
+    uv1 = np.stack([rng.uniform(100, w - 100, n), rng.uniform(60, h - 60, n)], 1)
+    z = rng.uniform(5, 40, n)
+    P1c = np.stack([(uv1[:, 0] - K1[2]) / K1[0] * z, (uv1[:, 1] - K1[3]) / K1[1] * z, z], 1)
+    q = quat_from_rotvec(rng.normal(0, 0.04, 3)); t = rng.normal(0, 0.4, 3)
+    R = quat_to_R(q)
+    P2c = ((P1c - t) @ R) / scale                       # P2c = S12^-1 P1c
+    uv2 = np.stack([K2[0] * P2c[:, 0] / P2c[:, 2] + K2[2], K2[1] * P2c[:, 1] / P2c[:, 2] + K2[3]], 1)
+    _, sc1, w1 = _octave_inv_sigma2(rng, n)
+    _, sc2, w2 = _octave_inv_sigma2(rng, n)
+    obs1 = uv1 + rng.normal(0, noise, (n, 2)) * sc1[:, None]
+    obs2 = uv2 + rng.normal(0, noise, (n, 2)) * sc2[:, None]
+    nout = int(round(outlier_frac * n))
+    if nout:
+        idx = rng.choice(n, nout, replace=False)
+        obs1[idx] += rng.choice([-1, 1], (nout, 2)) * rng.uniform(15, 40, (nout, 2))
+    s12_gt = np.concatenate([np.sqrt(scale) * q, t])
+    dr, dt, ds = perturb
+    q0 = quat_mul(quat_from_rotvec(rng.normal(0, dr, 3)), q)
+    s0 = scale * float(np.exp(rng.normal(0, ds)))
+    s12_0 = np.concatenate([np.sqrt(s0) * q0, t + rng.normal(0, dt, 3)])
+    return dict(K1=K1, K2=K2, s12_0=s12_0, s12_gt=s12_gt, P3D2c=P2c, obs1=obs1, inv_sigma2_1=w1, P3D1c=P1c, obs2=obs2,
+                inv_sigma2_2=w2)
+
+
 def make_ba_graph(seed, ncam=100, npts=10000, nobs=50000, outlier_frac=0.05, noise=1.0, perturb=True,
                   n_fixed=1, w=1241, h=376):
     """C4/C5-style graph: forward-moving KITTI cameras, points in the frusta, each point seen by a

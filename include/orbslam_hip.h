@@ -219,6 +219,34 @@ int ba_pose_optimization_batch_device(const double* d_K4 /*np*4*/, double* d_pos
                                       int nproblems, uint8_t* d_outlier, int32_t* d_n_inliers,
                                       ba_summary* d_summary, void* stream);
 
+/* CeresOptimizer::OptimizeSim3(KeyFrame*, KeyFrame*, vector<MapPoint*>& matches12, Sophus::Sim3d& S12, float th2,
+ * bool bFixScale) (src/CeresOptimizer.cc:601-735; cost functor include/CeresOptimizer.h:168-236, parameterisation
+ * src/CeresOptimizer.cc:24-47) for ONE keyframe pair, host pointers.  Correspondence i (the reference's accepted
+ * (map_point_1, map_point_2) pairs, in loop order) carries
+ *   P3D2c[i] = R2cw * P3D2w + t2cw, obs1[i] = keyframe_1 keypoint, inv_sigma2_1[i] = kf1->inv_level_sigma2s_[octave]  (:649-664)
+ *   P3D1c[i] = R1cw * P3D1w + t1cw, obs2[i] = keyframe_2 keypoint, inv_sigma2_2[i] likewise                         (:666-683)
+ * s12[7] in/out = Sophus::Sim3d::data() = [qx,qy,qz,qw (|q|^2 = scale), tx,ty,tz].  th2 -> HuberLoss(sqrt(th2)) and the
+ * outlier threshold.  fix_scale is accepted and ignored, as the reference ignores bFixScale.  outlier[n] (may be NULL) =
+ * is_outlier_12 || is_outlier_21 (:694-726).  *n_inliers = n - n_bad, or 0 when that is < 10 (:731).                     */
+int ba_optimize_sim3(const double* K1 /*fx,fy,cx,cy*/, const double* K2, double* s12, const double* P3D2c,
+                     const double* obs1, const float* inv_sigma2_1, const double* P3D1c, const double* obs2,
+                     const float* inv_sigma2_2, int n, double th2, int fix_scale, uint8_t* outlier, int* n_inliers,
+                     ba_summary* summary);
+
+/* batched, device-resident OptimizeSim3 (one loop candidate per problem): problem p uses correspondences
+ * [offsets[p], offsets[p+1]); d_K1/d_K2 [np*4], d_s12 [np*7] in/out, d_th2 [np], d_outlier [total] (may be NULL),
+ * d_n_inliers [np], d_summary [np] (may be NULL).  Enqueue only.                                                         */
+int ba_optimize_sim3_batch_device(const double* d_K1, const double* d_K2, double* d_s12, const double* d_P3D2c,
+                                  const double* d_obs1, const float* d_inv_sigma2_1, const double* d_P3D1c,
+                                  const double* d_obs2, const float* d_inv_sigma2_2, const int32_t* d_offsets,
+                                  const double* d_th2, int nproblems, uint8_t* d_outlier, int32_t* d_n_inliers,
+                                  ba_summary* d_summary, void* stream);
+
+/* Sophus::Sim3d::exp / log in the layout above (tangent = [upsilon, omega, sigma]); host arithmetic, for bindings that
+ * cross the Sophus boundary (LoopClosing builds gScm from (s, R, t): src/LoopClosing.cc:322).                           */
+int ba_sim3_exp(const double* tangent7, double* s12_out);
+int ba_sim3_log(const double* s12, double* tangent7_out);
+
 /* CeresOptimizer::BundleAdjustment (src/CeresOptimizer.cc:59-225) on flattened arrays, host pointers:
  * cameras with cam_fixed != 0 are constant (KF id 0, fixed KFs); obs_weight multiplies the pixel
  * residual (= invSigma2, F7); obs_robust selects the Huber loss per observation.  poses7 / pts3 are

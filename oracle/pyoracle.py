@@ -17,7 +17,7 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp",
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp", "sim3_oracle.cpp",
                                              "orb_pattern_data.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -99,6 +99,14 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_quat_plus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_quat_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        # Sim3
+        for f in ("orc_sim3_exp", "orc_sim3_log", "orc_sim3_inverse"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_sim3_plus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_sim3_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_sim3_eval_term.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_optimize_sim3.restype = C.c_int
+        L.orc_optimize_sim3.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -399,3 +407,47 @@ def quat_rotate(q, v):
     q = np.ascontiguousarray(q, np.float64); v = np.ascontiguousarray(v, np.float64); o = np.zeros(3)
     lib().orc_quat_rotate(_p(q), _p(v), _p(o))
     return o
+
+
+# --------------------------------- Sim3 ---------------------------------------
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def sim3_exp(a):
+    a = _f64(a); o = np.zeros(7); lib().orc_sim3_exp(_p(a), _p(o)); return o
+
+
+def sim3_log(S):
+    S = _f64(S); o = np.zeros(7); lib().orc_sim3_log(_p(S), _p(o)); return o
+
+
+def sim3_inverse(S):
+    S = _f64(S); o = np.zeros(7); lib().orc_sim3_inverse(_p(S), _p(o)); return o
+
+
+def sim3_plus(x, d):
+    x = _f64(x); d = _f64(d); o = np.zeros(7); lib().orc_sim3_plus(_p(x), _p(d), _p(o)); return o
+
+
+def sim3_act(S, p):
+    S = _f64(S); p = _f64(p); o = np.zeros(3); lib().orc_sim3_act(_p(S), _p(p), _p(o)); return o
+
+
+def sim3_eval_term(K4, lie7, P, uv, w, inverse):
+    K4 = _f64(K4); lie7 = _f64(lie7); P = _f64(P); uv = _f64(uv)
+    r = np.zeros(2); J = np.zeros((2, 7))
+    lib().orc_sim3_eval_term(_p(K4), _p(lie7), _p(P), _p(uv), float(w), int(inverse), _p(r), _p(J))
+    return r, J
+
+
+def optimize_sim3(K1, K2, s12, P3D2c, obs1, inv_sigma2_1, P3D1c, obs2, inv_sigma2_2, th2=10.0, fix_scale=False):
+    K1 = _f64(K1); K2 = _f64(K2); S = _f64(s12).copy()
+    P2 = _f64(P3D2c).reshape(-1, 3); o1 = _f64(obs1).reshape(-1, 2); w1 = np.ascontiguousarray(inv_sigma2_1, np.float32)
+    P1 = _f64(P3D1c).reshape(-1, 3); o2 = _f64(obs2).reshape(-1, 2); w2 = np.ascontiguousarray(inv_sigma2_2, np.float32)
+    n = len(P2)
+    out = np.zeros(max(n, 1), np.uint8)
+    s = BaSummary()
+    ninl = lib().orc_optimize_sim3(_p(K1), _p(K2), _p(S), _p(P2), _p(o1), _p(w1), _p(P1), _p(o2), _p(w2), n, float(th2),
+                                   int(bool(fix_scale)), _p(out), C.byref(s))
+    return ninl, S, out[:n], s.as_dict()

@@ -1,9 +1,10 @@
 // Exercises the reference-named C++ shims (csrc/compat/orbslam_compat.h) end to end on a GPU:
 // reads a raw test vector written by the Python test, runs ORBextractor::operator(),
-// ORBmatcher::{DescriptorDistance,HammingBest2} and CeresOptimizer::PoseOptimization, and writes the
+// ORBmatcher::{DescriptorDistance,HammingBest2} and CeresOptimizer::{PoseOptimization,OptimizeSim3}, and writes the
 // results back for the Python side to compare with the oracle.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../ceres_mono_orb_slam2_amd/csrc/compat/orbslam_compat.h"
@@ -43,6 +44,31 @@ int main(int argc, char** argv) {
     MatT r0(1, 32, desc.ptr(0), 32), r1(1, 32, desc.ptr(n > 1 ? 1 : 0), 32);
     int d01 = ORBmatcher::DescriptorDistance(r0, r1);
     fwrite(&d01, 4, 1, f);
+    if (argc >= 8) {
+      // optimizer shims: problems written by the Python test as raw little-endian arrays
+      std::vector<uint8_t> pb = slurp(argv[6]);
+      const uint8_t* c = pb.data();
+      auto take = [&](void* dst, size_t bytes) { memcpy(dst, c, bytes); c += bytes; };
+      int np_ = 0; take(&np_, 4);
+      PoseProblem P;
+      take(P.K4, 32); take(P.pose7, 56);
+      P.Xw.resize(3 * np_); P.uv.resize(2 * np_); P.inv_sigma2.resize(np_);
+      take(P.Xw.data(), 24 * np_); take(P.uv.data(), 16 * np_); take(P.inv_sigma2.data(), 4 * np_);
+      int inl = CeresOptimizer::PoseOptimization(&P);
+      fwrite(&inl, 4, 1, f); fwrite(P.pose7, 8, 7, f); fwrite(P.is_outliers_.data(), 1, np_, f);
+      std::vector<uint8_t> sb = slurp(argv[7]);
+      c = sb.data();
+      int ns = 0; take(&ns, 4);
+      Sim3Problem Q; double S12[7];
+      take(Q.K1, 32); take(Q.K2, 32); take(S12, 56);
+      Q.P3D2c.resize(3 * ns); Q.obs1.resize(2 * ns); Q.P3D1c.resize(3 * ns); Q.obs2.resize(2 * ns);
+      Q.inv_sigma2_1.resize(ns); Q.inv_sigma2_2.resize(ns);
+      take(Q.P3D2c.data(), 24 * ns); take(Q.obs1.data(), 16 * ns); take(Q.P3D1c.data(), 24 * ns); take(Q.obs2.data(), 16 * ns);
+      take(Q.inv_sigma2_1.data(), 4 * ns); take(Q.inv_sigma2_2.data(), 4 * ns);
+      int sinl = CeresOptimizer::OptimizeSim3(&Q, S12, 10.f, false);
+      fwrite(&sinl, 4, 1, f); fwrite(S12, 8, 7, f); fwrite(Q.is_outliers_.data(), 1, ns, f);
+      printf("test_compat: pose inliers %d, sim3 inliers %d\n", inl, sinl);
+    }
     fclose(f);
     printf("test_compat: %d keypoints, d(0,1)=%d\n", n, d01);
   } catch (const std::exception& e) {

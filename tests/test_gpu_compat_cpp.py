@@ -20,7 +20,21 @@ def test_cpp_shims_vs_oracle(oracle, tmp_path):
     img = synth.make_frame(77, 640, 480, "blocks")
     raw = tmp_path / "img.raw"; out = tmp_path / "out.bin"
     img.tofile(raw)
-    subprocess.check_call([str(exe), str(raw), "640", "480", "1000", str(out)])
+    pp = synth.make_pose_problem(5, n=400)
+    posef = tmp_path / "pose.bin"
+    with open(posef, "wb") as f:
+        f.write(np.int32(400).tobytes())
+        for k, dt in (("K4", np.float64), ("pose0", np.float64), ("Xw", np.float64), ("uv", np.float64), ("inv_sigma2", np.float32)):
+            f.write(np.ascontiguousarray(pp[k], dt).tobytes())
+    sp = synth.make_sim3_problem(6, n=150, scale=1.0)
+    sim3f = tmp_path / "sim3.bin"
+    SK = (("K1", np.float64), ("K2", np.float64), ("s12_0", np.float64), ("P3D2c", np.float64), ("obs1", np.float64), ("P3D1c", np.float64),
+          ("obs2", np.float64), ("inv_sigma2_1", np.float32), ("inv_sigma2_2", np.float32))
+    with open(sim3f, "wb") as f:
+        f.write(np.int32(150).tobytes())
+        for k, dt in SK:
+            f.write(np.ascontiguousarray(sp[k], dt).tobytes())
+    subprocess.check_call([str(exe), str(raw), "640", "480", "1000", str(out), str(posef), str(sim3f)])
     buf = open(out, "rb").read()
     n = int(np.frombuffer(buf, np.int32, 1)[0])
     off = 4
@@ -29,7 +43,18 @@ def test_cpp_shims_vs_oracle(oracle, tmp_path):
     bi = np.frombuffer(buf, np.int32, n, off); off += 4 * n
     bd = np.frombuffer(buf, np.int32, n, off); off += 4 * n
     sd = np.frombuffer(buf, np.int32, n, off); off += 4 * n
-    d01 = int(np.frombuffer(buf, np.int32, 1, off)[0])
+    d01 = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+    inl = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+    pose = np.frombuffer(buf, np.float64, 7, off); off += 56
+    pout = np.frombuffer(buf, np.uint8, 400, off); off += 400
+    sinl = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+    s12 = np.frombuffer(buf, np.float64, 7, off); off += 56
+    sout = np.frombuffer(buf, np.uint8, 150, off); off += 150
+    oinl, opose, oout, _ = oracle.pose_optimization(pp["K4"], pp["pose0"], pp["Xw"], pp["uv"], pp["inv_sigma2"])
+    assert inl == oinl and np.array_equal(pout, oout) and np.abs(pose - opose).max() < 1e-7
+    on, oS, oo, _ = oracle.optimize_sim3(sp["K1"], sp["K2"], sp["s12_0"], sp["P3D2c"], sp["obs1"], sp["inv_sigma2_1"], sp["P3D1c"], sp["obs2"],
+                                         sp["inv_sigma2_2"])
+    assert sinl == on and np.array_equal(sout, oo) and np.abs(s12 - oS).max() < 1e-6
     okps, odesc = oracle.OracleExtractor(1000).extract(img)
     assert n == len(okps)
     assert np.array_equal(kps, okps.view(np.uint8).reshape(n, 28)) and np.array_equal(desc, odesc)
