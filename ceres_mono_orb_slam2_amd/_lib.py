@@ -17,7 +17,21 @@ SYMBOLS = [
     "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_bow", "orbm_search_for_triangulation",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log",
+    "ba_solve_batch", "ba_local_bundle_adjustment_batch",
 ]
+
+
+class BaProblem(C.Structure):                 # ba_problem
+    _fields_ = [("K4", C.c_void_p), ("poses7", C.c_void_p), ("cam_fixed", C.c_void_p), ("ncam", C.c_int32),
+                ("pts3", C.c_void_p), ("npts", C.c_int32), ("obs_cam", C.c_void_p), ("obs_pt", C.c_void_p),
+                ("obs_uv", C.c_void_p), ("obs_weight", C.c_void_p), ("obs_robust", C.c_void_p), ("nobs", C.c_int32)]
+
+
+class BaLocalProblem(C.Structure):            # ba_local_problem
+    _fields_ = [("K4", C.c_void_p), ("poses7", C.c_void_p), ("cam_fixed", C.c_void_p), ("cam_local", C.c_void_p),
+                ("ncam", C.c_int32), ("pts3", C.c_void_p), ("npts", C.c_int32), ("obs_cam", C.c_void_p),
+                ("obs_pt", C.c_void_p), ("obs_uv", C.c_void_p), ("obs_inv_sigma2", C.c_void_p), ("nobs", C.c_int32),
+                ("obs_erase", C.c_void_p)]
 
 
 class OrbHipError(RuntimeError):
@@ -94,6 +108,8 @@ def load():
         L.ba_optimize_sim3_batch_device.argtypes = [vp] * 11 + [i32, vp, vp, vp, vp]
         L.ba_sim3_exp.argtypes = [vp, vp]
         L.ba_sim3_log.argtypes = [vp, vp]
+        L.ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaOptions), vp]
+        L.ba_local_bundle_adjustment_batch.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, vp]
     _lib = L
     return L
 

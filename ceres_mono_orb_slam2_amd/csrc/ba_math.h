@@ -46,7 +46,7 @@ BA_HD void quat_plus(const double* q, const double* d, double* out) {
 }
 
 // r = sqrt(rho') * w * (uv - pi(K (q X + t))); returns rho (cost = rho/2).
-// Jc (2x6, [t | half-angle delta]) and Jp (2x3) may be NULL.  robust selects Huber(delta).
+// Jc (2x6, [t | half-angle delta]) and Jp (2x3) may be NULL.  robust: 0 = no loss, 1 = Huber(delta), 2 = Huber block + its loss-free twin.
 BA_HD double reproj_eval(const double* K4, const double* pose7, const double* X, double u_obs, double v_obs,
                          double w, int robust, double huber, double* r, double* Jc, double* Jp) {
   const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
@@ -68,6 +68,11 @@ BA_HD double reproj_eval(const double* K4, const double* pose7, const double* X,
       rho1 = fmax(DBL_MIN, huber / rr);
     }
   }
+  // robust == 2: the observation is present TWICE, once under the loss and once without (LocalBundleAdjustment's second
+  // pass re-adds every kept block on the same problem).  Both blocks share the raw residual r0 and Jacobian J0
+  // and differ only by the corrector scale (sqrt(rho') vs 1), so their joint contribution to J^T J, J^T r and the cost is
+  // exactly that of ONE block scaled by sqrt(rho' + 1) with cost (rho + s) / 2: half the blocks, a quarter of the Schur pairs.
+  if (robust == 2) { rho0 += s; rho1 += 1.0; }
   const double sq = sqrt(rho1);
   if (Jc || Jp) {
     const double iz = 1.0 / p2;

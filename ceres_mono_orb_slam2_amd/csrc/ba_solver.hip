@@ -35,6 +35,7 @@
 #include <numeric>
 #include <chrono>
 #include <cstdlib>
+#include <climits>
 
 #include "common.h"
 #include "ba_math.h"
@@ -467,6 +468,7 @@ struct BaDev {            // device pointers of one problem
   double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
   double* Dinv;                      // inverse of every 32x32 diagonal Cholesky block [npad/32][32][32]
   const int* blk_a; const int* blk_b; const int* blk_off; const int* pair_i; const int* pair_j; int nblk;   // Schur block pair lists
+  const int* free_cams;              // [nfc] reduced column -> camera index
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
   double huber;
@@ -476,12 +478,14 @@ struct BaDev {            // device pointers of one problem
 #define BA_TPB 256
 
 // ---- residuals + Jacobians at x (mode 0) or cost only at the candidate (mode 1) -------------------
-__global__ __launch_bounds__(BA_TPB) void k_ba_eval(BaDev D, int mode) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv, int mode) {
+  const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4], s_out[1];
   const BaState* st = D.st;
   if (st->done) return;
   if (mode == 0 && !st->need_eval) return;
   if (mode == 1 && !st->valid) return;
+  if ((int)blockIdx.x * BA_TPB >= max(D.nobs, 1)) return;               // batched launch: grid.x is the maximum over the problems
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
   double acc[1] = {0.0};
   if (i < D.nobs) {
@@ -505,11 +509,13 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(BaDev D, int mode) {
 }
 
 // ---- 6x6 pose blocks: B_c = sum Jc^T Jc, g_c = sum Jc^T r over the camera's observations ----------
-__global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(BaDev D) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4 * 27], s_out[27];
   const BaState* st = D.st;
   if (st->done || !st->need_eval) return;
   const int c = blockIdx.x;
+  if (c >= D.ncam) return;
   const int cc = D.cam_col[c];
   if (cc < 0) return;
   const size_t n = D.nobs;
@@ -535,7 +541,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(BaDev D) {
 }
 
 // ---- 3x3 landmark blocks ------------------------------------------------------------------------------
-__global__ __launch_bounds__(BA_TPB) void k_ba_pt_blocks(BaDev D) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_pt_blocks(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   if (st->done || !st->need_eval || D.fix_points) return;
   const int p = blockIdx.x * BA_TPB + threadIdx.x;
@@ -556,7 +563,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_pt_blocks(BaDev D) {
 }
 
 // ---- start of an evaluation: x_cost, Jacobi scaling (first time), gradient max-norm, |x| ----------
-__global__ __launch_bounds__(BA_TPB) void k_ba_after_eval(BaDev D) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_after_eval(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4 * 3], s_out[3];
   BaState* st = D.st;
   if (st->done || !st->need_eval) return;
@@ -606,7 +614,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_after_eval(BaDev D) {
 }
 
 // ---- iteration begin: iteration cap / minimum radius ------------------------------------------------
-__global__ void k_ba_iter_begin(BaDev D) {
+__global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
   if (st->done) return;
   st->valid = 0; st->accepted = 0; st->chol_fail = 0;
@@ -627,7 +636,8 @@ __device__ __forceinline__ bool inv3_sym6(const double* C, double* Ci) {   // C 
   return true;
 }
 
-__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(BaDev D) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
   if (st->done || !st->valid || D.fix_points) return;
   const int p = blockIdx.x * BA_TPB + threadIdx.x;
@@ -647,7 +657,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(BaDev D) {
 }
 
 // per observation: E = (Jc S_c)^T (Jp S_p) (6x3) and E (C_s+D)^-1, stored AoS (18 doubles each)
-__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(BaDev D) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   if (st->done || !st->valid || D.fix_points) return;
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
@@ -676,12 +687,15 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(BaDev D) {
 // ---- reduced camera system S = B_s + D - sum E (C_s+D)^-1 E^T: one wave per non-empty block pair
 // (a <= b).  Lane (u,v) of the first 36 lanes owns one element and walks the block's pair list in its
 // fixed (host-built) order, so the sum is deterministic; lanes 36..41 of a diagonal block build rhs.
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev D, const int* __restrict__ free_cams) {
+__global__ __launch_bounds__(256) void k_ba_schur(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
+  const int* __restrict__ free_cams = D.free_cams;
   const BaState* st = D.st;
   if (st->done || !st->valid) return;
   __shared__ double s_part[7][36];
   const int tid = threadIdx.x;
   const int blk = blockIdx.x;
+  if (blk >= D.nblk) return;
   const int a = D.blk_a[blk], b = D.blk_b[blk];
   const int np = D.npad;
   const int grp = tid / 36, el = tid - 36 * grp;          // 7 groups x 36 elements (threads 252..255: rhs helpers)
@@ -742,7 +756,8 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D, const int* __restrict
 }
 
 // zero the lower triangle rows of the real block (the factorisation overwrote S in place)
-__global__ __launch_bounds__(256) void k_ba_zero_S(BaDev D) {
+__global__ __launch_bounds__(256) void k_ba_zero_S(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   if (st->done || !st->valid) return;
   const size_t tot = (size_t)D.n6 * D.npad;
@@ -750,7 +765,8 @@ __global__ __launch_bounds__(256) void k_ba_zero_S(BaDev D) {
 }
 
 // padding rows of S (identity): written once per solve - the factorisation maps them to themselves
-__global__ void k_ba_pad(BaDev D) {
+__global__ void k_ba_pad(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   const int np = D.npad, n6 = D.n6;
   const int i = n6 + blockIdx.x;
   if (i >= np) return;
@@ -823,7 +839,8 @@ __device__ __noinline__ void diag_invert_wave(double (*s_L)[NB + 1], double (*s_
     for (int rr = 0; rr < NB; rr++) s_X[rr][c] = x[rr];
   }
 }
-__global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k) {
+__global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv, int k) {
+  const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_L[NB][NB + 1];
@@ -831,6 +848,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k) {
   __shared__ double s_dinv[NB];
   __shared__ int s_fail;
   const int np = D.npad, tid = threadIdx.x;
+  if (k >= np || k + NB + (int)blockIdx.x * 64 > np) return;     // beyond this problem's matrix (batched launch)
   double* S = D.S;
   for (int i = tid; i < NB * NB; i += 256) { int r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0; }
   if (tid == 0) s_fail = 0;
@@ -885,11 +903,16 @@ __global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k) {
 // 32-wide panels of a 128-wide outer block only update the rest of that block ("thin" launches, K=32); everything to
 // the right of the outer block is updated ONCE with K=128 (4x the flops per byte of C moved).  Workgroups with
 // blockIdx.x >= ntiles update the augmented rhs row (row npad) over the same column range.
-__global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int kcol, int K, int r_lo, int c_lo, int c_hi, int tiles_c, int ntiles) {
+__global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles) {
+  const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_A[64][NB + 1], s_B[64][NB + 1];
   const int np = D.npad, tid = threadIdx.x;
+  // batched launch: the grid and (kcol, K, r_lo, c_lo, c_hi_cap) are laid out for the LARGEST reduced system of the batch;
+  // this problem clips the column range to its own size and drops the steps / tiles that fall outside
+  const int c_hi = min(c_hi_cap, np);
+  if (kcol + K > np || c_hi <= c_lo) return;
   double* S = D.S;
   if ((int)blockIdx.x >= ntiles) {           // augmented rhs row
     double* zrow = S + (size_t)np * np;
@@ -907,7 +930,7 @@ __global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int kcol, int K, int
   }
   const int ti = blockIdx.x / tiles_c, tj = blockIdx.x - ti * tiles_c;
   const int r0 = r_lo + ti * 64, c0 = c_lo + tj * 64;
-  if (r0 + 63 < c0) return;                                   // tile entirely above the diagonal
+  if (r0 + 63 < c0 || r0 >= np || c0 >= c_hi) return;         // tile entirely above the diagonal / outside this problem
   const int w = tid >> 6, lane = tid & 63;
   const int qr = (w >> 1) * 32, qc = (w & 1) * 32;            // quadrant origin inside the 64x64 tile
   const bool qskip = (r0 + qr + 31 < c0 + qc);                // quadrant entirely above the diagonal
@@ -960,11 +983,14 @@ __global__ __launch_bounds__(256) void k_chol_syrk(BaDev D, int kcol, int K, int
 // k_chol_bsolve_update subtracts its contribution from every earlier entry with many workgroups
 // (64 columns x 4 row groups each, fixed-order LDS reduction -> deterministic).
 #define SBLK 256
-__global__ __launch_bounds__(256) void k_chol_bsolve_diag(BaDev D, int kb, int ke, int first) {
+__global__ __launch_bounds__(256) void k_chol_bsolve_diag(const BaDev* __restrict__ Dv, int kb) {
+  const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_y[SBLK], s_x[NB];
   const int np = D.npad, tid = threadIdx.x;
+  if (kb >= np) return;                                             // batched launch: super-block beyond this problem
+  const int ke = min(kb + SBLK, np), first = (kb + SBLK >= np);
   const double* S = D.S;
   const double* src = first ? (D.S + (size_t)np * np) : D.rhs;      // the first (bottom) super-block starts from z
   if (first) for (int i = tid; i < kb; i += 256) D.rhs[i] = src[i];  // seed the running vector for the rows above
@@ -991,11 +1017,14 @@ __global__ __launch_bounds__(256) void k_chol_bsolve_diag(BaDev D, int kb, int k
   if (kb + tid < ke) D.rhs[kb + tid] = s_y[tid];
 }
 
-__global__ __launch_bounds__(256) void k_chol_bsolve_update(BaDev D, int kb, int ke) {
+__global__ __launch_bounds__(256) void k_chol_bsolve_update(const BaDev* __restrict__ Dv, int kb) {
+  const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_x[SBLK], s_p[4][64];
   const int np = D.npad, tid = threadIdx.x;
+  if (kb >= np || (int)blockIdx.x * 64 >= kb) return;
+  const int ke = min(kb + SBLK, np);
   const int nr = ke - kb;
   if (tid < nr) s_x[tid] = D.rhs[kb + tid];
   __syncthreads();
@@ -1012,10 +1041,12 @@ __global__ __launch_bounds__(256) void k_chol_bsolve_update(BaDev D, int kb, int
 }
 
 // ---- candidate cameras: x+ = Plus(x, -y * scale); partial |dx|^2 -------------------------------------------
-__global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(BaDev D) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4], s_out[1];
   const BaState* st = D.st;
   if (st->done || !st->valid) return;
+  if ((int)blockIdx.x * BA_TPB >= D.ncam) return;
   const int c = blockIdx.x * BA_TPB + threadIdx.x;
   double acc[1] = {0.0};
   if (c < D.ncam) {
@@ -1037,10 +1068,12 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(BaDev D) {
 }
 
 // ---- landmark back-substitution, candidate points, model cost change and |dx|^2 partials ---------------------
-__global__ __launch_bounds__(BA_TPB) void k_ba_backsub(BaDev D, int part_off) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_backsub(const BaDev* __restrict__ Dv, int part_off) {
+  const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4 * 2], s_out[2];
   const BaState* st = D.st;
   if (st->done || !st->valid) return;
+  if ((int)blockIdx.x * BA_TPB >= max(D.npts, 1)) return;
   const int p = blockIdx.x * BA_TPB + threadIdx.x;
   const size_t n = D.nobs;
   double acc[2] = {0.0, 0.0};              // model cost change, |dx|^2
@@ -1093,7 +1126,9 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_backsub(BaDev D, int part_off) {
 }
 
 // ---- iteration end: Ceres' step evaluation ------------------------------------------------------
-__global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(BaDev D, int nb_obs, int nb_cam, int nb_pt) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
+  const int nb_obs = max((D.nobs + BA_TPB - 1) / BA_TPB, 1), nb_cam = (D.ncam + BA_TPB - 1) / BA_TPB, nb_pt = max((D.npts + BA_TPB - 1) / BA_TPB, 1);
   __shared__ double s_red[4 * 3], s_out[3];
   BaState* st = D.st;
   if (st->done || !st->valid) return;
@@ -1128,7 +1163,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(BaDev D, int nb_obs, int
   }
 }
 
-__global__ __launch_bounds__(BA_TPB) void k_ba_apply(BaDev D) {
+__global__ __launch_bounds__(BA_TPB) void k_ba_apply(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   if (st->done || !st->accepted) return;
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
@@ -1136,7 +1172,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_apply(BaDev D) {
   if (i < 3 * D.npts) D.pts[i] = D.cand_pts[i];
 }
 
-__global__ void k_ba_user_stop(BaDev D) {
+__global__ void k_ba_user_stop(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
   if (!st->done) { st->termination = 4; st->done = 1; }
 }
@@ -1170,11 +1207,15 @@ static thread_local BaWorkspace g_ws;
 // one non-blocking stream per host thread: independent solves issued from different threads overlap on the GPU
 static thread_local hipStream_t g_stream = nullptr;
 static thread_local int g_stream_device = -1;
+struct GraphCacheEntry { std::vector<BaDev> D; const BaDev* Dv = nullptr; hipGraphExec_t exec = nullptr; unsigned long long stamp = 0; };
+static thread_local std::vector<GraphCacheEntry> g_graphs;      // instantiated per-iteration graphs of this thread (<= 4, LRU)
+static thread_local unsigned long long g_graph_clock = 0;
 static hipStream_t thread_stream() {
   const int dev = g_default_device.load();
   if (g_stream && g_stream_device != dev) {            // the default device changed: drop the old stream and workspace
     (void)hipStreamDestroy(g_stream); g_stream = nullptr;
     g_ws.slots.clear(); g_ws.hslots.clear();           // (buffers of the previous device are intentionally leaked)
+    g_graphs.clear();
   }
   if (!g_stream) { if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr; g_stream_device = dev; }
   return g_stream;
@@ -1205,22 +1246,25 @@ struct HostBA {
   }
 };
 
-int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, int ncam, double* pts3, int npts,
-                  const int32_t* obs_cam_in, const int32_t* obs_pt_in, const double* obs_uv_in, const double* obs_w_in,
-                  const uint8_t* obs_robust_in, int nobs, const ba_options* opts, ba_summary* summary) {
-  ORBHIP_REQUIRE(ncam > 0 && npts >= 0 && nobs >= 0 && opts, ORBHIP_EINVAL, "bad sizes");
-  ORBHIP_REQUIRE(K4 && poses7 && cam_fixed && (npts == 0 || pts3), ORBHIP_EINVAL, "NULL argument");
-  ORBHIP_REQUIRE(nobs == 0 || (obs_cam_in && obs_pt_in && obs_uv_in && obs_w_in && obs_robust_in), ORBHIP_EINVAL, "NULL observation arrays");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
-  if (int rcd = use_default_device()) return rcd;
+// ---- one problem: validation, structure (host, O(nobs)), uploads, device workspace -----------------------------------
+struct BaInputs {
+  const double* K4; double* poses7; const uint8_t* cam_fixed; int ncam; double* pts3; int npts;
+  const int32_t* obs_cam; const int32_t* obs_pt; const double* obs_uv; const double* obs_w; const uint8_t* obs_robust; int nobs;
+};
+struct BaPrepared { BaDev D; int nb_obs, nb_cam, nb_pt; size_t npairs; double t_struct_ms; };
+
+static double ba_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_options* opts, BaPrepared* out) {
+  const int ncam = in.ncam, npts = in.npts, nobs = in.nobs;
+  ORBHIP_REQUIRE(ncam > 0 && npts >= 0 && nobs >= 0, ORBHIP_EINVAL, "bad sizes");
+  ORBHIP_REQUIRE(in.K4 && in.poses7 && in.cam_fixed && (npts == 0 || in.pts3), ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(nobs == 0 || (in.obs_cam && in.obs_pt && in.obs_uv && in.obs_w && in.obs_robust), ORBHIP_EINVAL, "NULL observation arrays");
   for (int i = 0; i < nobs; i++)
-    ORBHIP_REQUIRE(obs_cam_in[i] >= 0 && obs_cam_in[i] < ncam && obs_pt_in[i] >= 0 && obs_pt_in[i] < npts, ORBHIP_EINVAL, "observation index out of range");
-  const bool timing = std::getenv("ORBHIP_BA_TIMING") != nullptr;
-  auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t_start = tnow();
-  // ---- structure (host, O(nobs)): group observations by point (stable), per-camera lists ---------
-  HostBA H; int rc = 0;
+    ORBHIP_REQUIRE(in.obs_cam[i] >= 0 && in.obs_cam[i] < ncam && in.obs_pt[i] >= 0 && in.obs_pt[i] < npts, ORBHIP_EINVAL, "observation index out of range");
+  const double t_start = ba_now_ms();
+  // group observations by point (stable), per-camera lists
+  int rc = 0;
   int* pt_off = H.pinned<int>(npts + 1, &rc);
   int* oc = H.pinned<int>(nobs, &rc); int* op = H.pinned<int>(nobs, &rc);
   double* ouv = H.pinned<double>(2 * (size_t)nobs, &rc); double* ow = H.pinned<double>(nobs, &rc);
@@ -1228,14 +1272,14 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
   int* cam_off = H.pinned<int>(ncam + 1, &rc); int* cam_obs = H.pinned<int>(nobs, &rc); int* cam_obs_pt = H.pinned<int>(nobs, &rc);
   if (rc) return rc;
   for (int p = 0; p <= npts; p++) pt_off[p] = 0;
-  for (int i = 0; i < nobs; i++) pt_off[obs_pt_in[i] + 1]++;
+  for (int i = 0; i < nobs; i++) pt_off[in.obs_pt[i] + 1]++;
   for (int p = 0; p < npts; p++) pt_off[p + 1] += pt_off[p];
   std::vector<int> perm(nobs), fill(pt_off, pt_off + npts);
-  for (int i = 0; i < nobs; i++) perm[fill[obs_pt_in[i]]++] = i;
+  for (int i = 0; i < nobs; i++) perm[fill[in.obs_pt[i]]++] = i;
   for (int j = 0; j < nobs; j++) {
     const int i = perm[j];
-    oc[j] = obs_cam_in[i]; op[j] = obs_pt_in[i]; ouv[2 * (size_t)j] = obs_uv_in[2 * (size_t)i]; ouv[2 * (size_t)j + 1] = obs_uv_in[2 * (size_t)i + 1];
-    ow[j] = obs_w_in[i]; orb[j] = obs_robust_in[i];
+    oc[j] = in.obs_cam[i]; op[j] = in.obs_pt[i]; ouv[2 * (size_t)j] = in.obs_uv[2 * (size_t)i]; ouv[2 * (size_t)j + 1] = in.obs_uv[2 * (size_t)i + 1];
+    ow[j] = in.obs_w[i]; orb[j] = in.obs_robust[i];
   }
   for (int c = 0; c <= ncam; c++) cam_off[c] = 0;
   for (int j = 0; j < nobs; j++) cam_off[oc[j] + 1]++;
@@ -1243,7 +1287,7 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
   std::vector<int> cfill(cam_off, cam_off + ncam);
   for (int j = 0; j < nobs; j++) { int e = cfill[oc[j]]++; cam_obs[e] = j; cam_obs_pt[e] = op[j]; }
   std::vector<int> cam_col(ncam, -1), free_cams;
-  for (int c = 0; c < ncam; c++) if (!cam_fixed[c] && cam_off[c + 1] > cam_off[c]) { cam_col[c] = (int)free_cams.size(); free_cams.push_back(c); }
+  for (int c = 0; c < ncam; c++) if (!in.cam_fixed[c] && cam_off[c + 1] > cam_off[c]) { cam_col[c] = (int)free_cams.size(); free_cams.push_back(c); }
   const int nfc = (int)free_cams.size();
   const int n6 = 6 * nfc, npad = std::max(round_up(n6, NB), NB);
   const int nb_obs = std::max((nobs + BA_TPB - 1) / BA_TPB, 1), nb_cam = (ncam + BA_TPB - 1) / BA_TPB, nb_pt = std::max((npts + BA_TPB - 1) / BA_TPB, 1);
@@ -1261,8 +1305,7 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
         for (int j = pt_off[p]; j < pt_off[p + 1]; j++) { const int cj = cam_col[oc[j]]; if (cj >= ci) cnt[(size_t)ci * nfc + cj + 1]++; }
       }
     for (size_t k = 0; k < (size_t)nfc * nfc; k++) cnt[k + 1] += cnt[k];
-    const int npairs_tot = cnt[(size_t)nfc * nfc];
-    npairs_all = (size_t)npairs_tot;
+    npairs_all = (size_t)cnt[(size_t)nfc * nfc];
     pair_i = H.pinned<int>(npairs_all, &rc); pair_j = H.pinned<int>(npairs_all, &rc);
     if (rc) return rc;
     std::vector<int> pos(cnt.begin(), cnt.end() - 1);
@@ -1286,20 +1329,19 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
     for (int a = 0; a < nfc; a++) { blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(0); }
   }
   const int nblk = (int)blk_a.size();
-  const double t_struct = tnow();
+  out->t_struct_ms = ba_now_ms() - t_start;
 
-  hipStream_t s = thread_stream();
   BaDev D; std::memset(&D, 0, sizeof(D));
   D.ncam = ncam; D.npts = npts; D.nobs = nobs; D.nfc = nfc; D.n6 = n6; D.npad = npad; D.nparts = nparts; D.nblk = nblk;
   D.fix_points = opts->fix_points ? 1 : 0; D.huber = opts->huber_delta;
-  D.K4 = H.upload(K4, 4 * (size_t)ncam, &rc, s); D.cam_fixed = H.upload(cam_fixed, ncam, &rc, s); D.cam_col = H.upload(cam_col.data(), ncam, &rc, s);
-  D.poses = H.upload(poses7, 7 * (size_t)ncam, &rc, s); D.pts = H.upload(pts3, 3 * (size_t)npts, &rc, s);
+  D.K4 = H.upload(in.K4, 4 * (size_t)ncam, &rc, s); D.cam_fixed = H.upload(in.cam_fixed, ncam, &rc, s); D.cam_col = H.upload(cam_col.data(), ncam, &rc, s);
+  D.poses = H.upload(in.poses7, 7 * (size_t)ncam, &rc, s); D.pts = H.upload(in.pts3, 3 * (size_t)npts, &rc, s);
   D.cand_poses = H.alloc<double>(7 * (size_t)ncam, &rc); D.cand_pts = H.alloc<double>(3 * (size_t)npts, &rc);
   D.obs_cam = H.upload(oc, nobs, &rc, s); D.obs_pt = H.upload(op, nobs, &rc, s); D.obs_uv = H.upload(ouv, 2 * (size_t)nobs, &rc, s);
   D.obs_w = H.upload(ow, nobs, &rc, s); D.obs_robust = H.upload(orb, nobs, &rc, s);
   D.pt_off = H.upload(pt_off, npts + 1, &rc, s); D.cam_off = H.upload(cam_off, ncam + 1, &rc, s);
   D.cam_obs = H.upload(cam_obs, nobs, &rc, s); D.cam_obs_pt = H.upload(cam_obs_pt, nobs, &rc, s);
-  const int* d_free = H.upload(free_cams.data(), nfc, &rc, s);
+  D.free_cams = H.upload(free_cams.data(), nfc, &rc, s);
   D.blk_a = H.upload(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload(blk_off.data(), nblk + 1, &rc, s);
   D.pair_i = H.upload(pair_i, npairs_all, &rc, s); D.pair_j = H.upload(pair_j, npairs_all, &rc, s);
   D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jc = H.alloc<double>(12 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
@@ -1318,73 +1360,150 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
   ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
   ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)npad * sizeof(double), s));
   ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)nparts * sizeof(double), s));
-  if (npad > n6) hipLaunchKernelGGL(k_ba_pad, dim3(npad - n6), dim3(64), 0, s, D);
-  const double t_upload = tnow();
+  out->D = D; out->nb_obs = nb_obs; out->nb_cam = nb_cam; out->nb_pt = nb_pt; out->npairs = npairs_all;
+  return 0;
+}
+
+// ---- a batch of independent problems solved in lockstep: every launch covers all of them (grid.y = problem) --------------
+// The LM control flow of each problem lives in its own device-side BaState, so finished problems simply fall through.
+// One LM iteration is a fixed sequence of ~60 launches: it is captured once into a hipGraph and replayed (one graph
+// launch per iteration); instantiated graphs are cached per host thread, keyed by the full kernel-argument blocks
+// (sizes and workspace pointers), so repeated solves of the same shape skip the capture too.  ORBHIP_BA_GRAPH=0 = direct.
+static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* opts, ba_summary* summaries) {
+  ORBHIP_REQUIRE(in && opts && nprob > 0, ORBHIP_EINVAL, "NULL argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+  if (int rcd = use_default_device()) return rcd;
+  const bool timing = std::getenv("ORBHIP_BA_TIMING") != nullptr;
+  const double t_start = ba_now_ms();
+  hipStream_t s = thread_stream();
+  HostBA H; int rc = 0;
+  std::vector<BaPrepared> P(nprob);
+  std::vector<BaDev> Dh(nprob);
+  int g_obs = 1, g_cam = 1, g_pt = 1, g_blk = 0, g_npad = NB, g_pad = 0, g_n6 = 0, g_camcount = 1, g_apply = 1;
+  size_t g_zero = 0;
+  for (int p = 0; p < nprob; p++) {
+    if (int r = ba_prepare(H, s, in[p], opts, &P[p])) return r;
+    const BaDev& D = P[p].D;
+    Dh[p] = D;
+    g_obs = std::max(g_obs, P[p].nb_obs); g_cam = std::max(g_cam, P[p].nb_cam); g_pt = std::max(g_pt, P[p].nb_pt);
+    g_blk = std::max(g_blk, D.nblk); g_npad = std::max(g_npad, D.npad); g_pad = std::max(g_pad, D.npad - D.n6); g_n6 = std::max(g_n6, D.n6);
+    g_camcount = std::max(g_camcount, D.ncam); g_apply = std::max(g_apply, std::max(7 * D.ncam, 3 * D.npts));
+    g_zero = std::max(g_zero, (size_t)D.n6 * D.npad);
+  }
+  const BaDev* Dv = H.upload(Dh.data(), nprob, &rc, s);
+  if (rc) return rc;
+  const double t_upload = ba_now_ms();
+  const unsigned ny = (unsigned)nprob;
+  const int npad = g_npad;
+  if (g_pad > 0) hipLaunchKernelGGL(k_ba_pad, dim3(g_pad, ny), dim3(64), 0, s, Dv);
   auto enqueue_eval = [&]() {
-    hipLaunchKernelGGL(k_ba_eval, dim3(nb_obs), dim3(BA_TPB), 0, s, D, 0);
-    if (ncam > 0) hipLaunchKernelGGL(k_ba_cam_blocks, dim3(ncam), dim3(BA_TPB), 0, s, D);
-    hipLaunchKernelGGL(k_ba_pt_blocks, dim3(nb_pt), dim3(BA_TPB), 0, s, D);
-    hipLaunchKernelGGL(k_ba_after_eval, dim3(1), dim3(BA_TPB), 0, s, D);
+    hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 0);
+    hipLaunchKernelGGL(k_ba_cam_blocks, dim3(g_camcount, ny), dim3(BA_TPB), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_pt_blocks, dim3(g_pt, ny), dim3(BA_TPB), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_after_eval, dim3(1, ny), dim3(BA_TPB), 0, s, Dv);
   };
-  const volatile uint8_t* stop = opts->stop_flag;
-  enqueue_eval();                                             // iteration 0
-  bool user_stop = stop && *stop;                             // StopFlagCallback after iteration 0
-  for (int it = 0; it < opts->max_iterations + 1 && !user_stop; it++) {
-    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1), 0, s, D);
-    hipLaunchKernelGGL(k_ba_schur_prep, dim3(nb_pt), dim3(BA_TPB), 0, s, D);
-    hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(nb_obs), dim3(BA_TPB), 0, s, D);
-    if (n6 > 0) hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)(((size_t)n6 * npad + 255) / 256))), dim3(256), 0, s, D);
-    if (nblk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, s, D, d_free);
-    auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi) {
+  auto enqueue_iteration = [&]() {
+    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(1), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_schur_prep, dim3(g_pt, ny), dim3(BA_TPB), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
+    if (g_n6 > 0) hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)((g_zero + 255) / 256)), ny), dim3(256), 0, s, Dv);
+    if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(256), 0, s, Dv);
+    auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
       if (c_hi <= c_lo || r_lo >= npad + 1) return;
       const int tiles_r = (npad - r_lo + 63) / 64, tiles_c = (c_hi - c_lo + 63) / 64;
       const int ntiles = std::max(tiles_r, 0) * tiles_c;
       const int nrhs = (c_hi - c_lo + 255) / 256;
-      hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs), dim3(256), 0, s, D, kcol, K, r_lo, c_lo, c_hi, tiles_c, ntiles);
+      hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs, ny), dim3(256), 0, s, Dv, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles);
     };
     const int OB = 128;                                       // outer block: 4 panels of NB = 32
     for (int k0 = 0; k0 < npad; k0 += OB) {
       const int kend = std::min(k0 + OB, npad);
       for (int k = k0; k < kend; k += NB) {
         const int rows_below = npad - k - NB;
-        hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 1 + 63) / 64), dim3(256), 0, s, D, k);   // +1: augmented rhs row
-        if (k + NB < kend) launch_update(k, NB, k + NB, k + NB, kend);          // thin update inside the outer block
+        hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 1 + 63) / 64, ny), dim3(256), 0, s, Dv, k);   // +1: augmented rhs row
+        if (k + NB < kend) launch_update(k, NB, k + NB, k + NB, kend, k0 + OB);      // thin update inside the outer block
       }
-      if (kend < npad) launch_update(k0, kend - k0, kend, kend, npad);          // one wide update for everything to the right
+      if (kend < npad) launch_update(k0, kend - k0, kend, kend, npad, INT_MAX);      // one wide update for everything to the right
     }
-    for (int kb = ((npad - 1) / SBLK) * SBLK, first = 1; kb >= 0; kb -= SBLK, first = 0) {
-      const int ke = std::min(kb + SBLK, npad);
-      hipLaunchKernelGGL(k_chol_bsolve_diag, dim3(1), dim3(256), 0, s, D, kb, ke, first);
-      if (kb > 0) hipLaunchKernelGGL(k_chol_bsolve_update, dim3((kb + 63) / 64), dim3(256), 0, s, D, kb, ke);
+    for (int kb = ((npad - 1) / SBLK) * SBLK; kb >= 0; kb -= SBLK) {
+      hipLaunchKernelGGL(k_chol_bsolve_diag, dim3(1, ny), dim3(256), 0, s, Dv, kb);
+      if (kb > 0) hipLaunchKernelGGL(k_chol_bsolve_update, dim3((kb + 63) / 64, ny), dim3(256), 0, s, Dv, kb);
     }
-    hipLaunchKernelGGL(k_ba_cam_update, dim3(std::max(nb_cam, 1)), dim3(BA_TPB), 0, s, D);
-    hipLaunchKernelGGL(k_ba_backsub, dim3(nb_pt), dim3(BA_TPB), 0, s, D, 0);
-    hipLaunchKernelGGL(k_ba_eval, dim3(nb_obs), dim3(BA_TPB), 0, s, D, 1);
-    hipLaunchKernelGGL(k_ba_iter_end, dim3(1), dim3(BA_TPB), 0, s, D, nb_obs, nb_cam, nb_pt);
-    hipLaunchKernelGGL(k_ba_apply, dim3((std::max(7 * ncam, 3 * npts) + BA_TPB - 1) / BA_TPB), dim3(BA_TPB), 0, s, D);
+    hipLaunchKernelGGL(k_ba_cam_update, dim3(g_cam, ny), dim3(BA_TPB), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_backsub, dim3(g_pt, ny), dim3(BA_TPB), 0, s, Dv, 0);
+    hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 1);
+    hipLaunchKernelGGL(k_ba_iter_end, dim3(1, ny), dim3(BA_TPB), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_apply, dim3((g_apply + BA_TPB - 1) / BA_TPB, ny), dim3(BA_TPB), 0, s, Dv);
     enqueue_eval();
-    if (stop && *stop) user_stop = true;
-    if ((it & 7) == 7 && it + 8 < opts->max_iterations) {     // converged early? (poll every 8 iterations of long solves)
-      BaState cur;
-      ORBHIP_CHECK_HIP(hipMemcpyAsync(&cur, D.st, sizeof(cur), hipMemcpyDeviceToHost, s));
-      ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
-      if (cur.done) break;
+  };
+  const volatile uint8_t* stop = opts->stop_flag;
+  enqueue_eval();                                             // iteration 0
+  bool user_stop = stop && *stop;                             // StopFlagCallback after iteration 0
+  hipGraphExec_t gexec = nullptr;
+  static const bool use_graph = []() { const char* e = std::getenv("ORBHIP_BA_GRAPH"); return !(e && e[0] == '0'); }();
+  if (use_graph && opts->max_iterations >= 3 && !user_stop) {
+    for (auto& e : g_graphs)
+      if (e.exec && e.Dv == Dv && e.D.size() == Dh.size() && std::memcmp(e.D.data(), Dh.data(), Dh.size() * sizeof(BaDev)) == 0) { gexec = e.exec; e.stamp = ++g_graph_clock; break; }
+    if (!gexec) {
+      hipGraph_t graph = nullptr;
+      ORBHIP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      enqueue_iteration();
+      ORBHIP_CHECK_HIP(hipStreamEndCapture(s, &graph));
+      hipError_t ge = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ge != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ge)); return ORBHIP_ENODEV; }
+      GraphCacheEntry* slot = nullptr;
+      if (g_graphs.size() < 4) { g_graphs.emplace_back(); slot = &g_graphs.back(); }
+      else { slot = &g_graphs[0]; for (auto& e : g_graphs) if (e.stamp < slot->stamp) slot = &e; }
+      if (slot->exec) { ORBHIP_CHECK_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(slot->exec); }
+      slot->D = Dh; slot->Dv = Dv; slot->exec = gexec; slot->stamp = ++g_graph_clock;
     }
   }
-  const double t_enq = tnow();
-  if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1), dim3(1), 0, s, D);
-  ORBHIP_CHECK_HIP(hipGetLastError());
-  BaState fin;
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(&fin, D.st, sizeof(fin), hipMemcpyDeviceToHost, s));
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(poses7, D.poses, 7 * (size_t)ncam * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (npts) ORBHIP_CHECK_HIP(hipMemcpyAsync(pts3, D.pts, 3 * (size_t)npts * sizeof(double), hipMemcpyDeviceToHost, s));
-  ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
-  if (timing) fprintf(stderr, "[ba_solve] nobs=%d pairs=%zu blocks=%d | structure %.2f ms, upload %.2f ms, enqueue %.2f ms, drain+download %.2f ms\n", nobs, npairs_all, nblk, t_struct - t_start, t_upload - t_struct, t_enq - t_upload, tnow() - t_enq);
-  if (summary) {
-    summary->initial_cost = fin.initial_cost; summary->final_cost = fin.x_cost; summary->iterations = fin.iteration;
-    summary->successful_steps = fin.successful_steps; summary->termination = fin.termination; summary->final_radius = fin.radius;
+  for (int it = 0; it < opts->max_iterations + 1 && !user_stop; it++) {
+    if (gexec) ORBHIP_CHECK_HIP(hipGraphLaunch(gexec, s));
+    else enqueue_iteration();
+    if (stop && *stop) user_stop = true;
+    if ((it & 7) == 7 && it + 8 < opts->max_iterations) {     // all converged early? (poll every 8 iterations of long solves)
+      std::vector<BaState> cur(nprob);
+      for (int p = 0; p < nprob; p++) ORBHIP_CHECK_HIP(hipMemcpyAsync(&cur[p], Dh[p].st, sizeof(BaState), hipMemcpyDeviceToHost, s));
+      ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+      bool all = true;
+      for (int p = 0; p < nprob; p++) all = all && cur[p].done;
+      if (all) break;
+    }
   }
+  const double t_enq = ba_now_ms();
+  if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1, ny), dim3(1), 0, s, Dv);
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  std::vector<BaState> fin(nprob);
+  for (int p = 0; p < nprob; p++) {
+    ORBHIP_CHECK_HIP(hipMemcpyAsync(&fin[p], Dh[p].st, sizeof(BaState), hipMemcpyDeviceToHost, s));
+    ORBHIP_CHECK_HIP(hipMemcpyAsync(in[p].poses7, Dh[p].poses, 7 * (size_t)in[p].ncam * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (in[p].npts) ORBHIP_CHECK_HIP(hipMemcpyAsync(in[p].pts3, Dh[p].pts, 3 * (size_t)in[p].npts * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+  if (timing) {
+    double ts = 0; size_t pairs = 0; long nobs = 0;
+    for (int p = 0; p < nprob; p++) { ts += P[p].t_struct_ms; pairs += P[p].npairs; nobs += in[p].nobs; }
+    fprintf(stderr, "[ba_solve] problems=%d nobs=%ld pairs=%zu | structure %.2f ms, prepare+upload %.2f ms, enqueue %.2f ms, drain+download %.2f ms\n",
+            nprob, nobs, pairs, ts, t_upload - t_start, t_enq - t_upload, ba_now_ms() - t_enq);
+  }
+  if (summaries)
+    for (int p = 0; p < nprob; p++) {
+      ba_summary& o = summaries[p];
+      o.initial_cost = fin[p].initial_cost; o.final_cost = fin[p].x_cost; o.iterations = fin[p].iteration;
+      o.successful_steps = fin[p].successful_steps; o.termination = fin[p].termination; o.final_radius = fin[p].radius;
+    }
   return 0;
+}
+
+int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, int ncam, double* pts3, int npts,
+                  const int32_t* obs_cam_in, const int32_t* obs_pt_in, const double* obs_uv_in, const double* obs_w_in,
+                  const uint8_t* obs_robust_in, int nobs, const ba_options* opts, ba_summary* summary) {
+  ORBHIP_REQUIRE(opts, ORBHIP_EINVAL, "NULL options");
+  BaInputs in{K4, poses7, cam_fixed, ncam, pts3, npts, obs_cam_in, obs_pt_in, obs_uv_in, obs_w_in, obs_robust_in, nobs};
+  return ba_solve_batch_impl(&in, 1, opts, summary);
 }
 
 }  // namespace
@@ -1482,53 +1601,108 @@ int ba_optimize_sim3(const double* K1, const double* K2, double* s12, const doub
 int ba_sim3_exp(const double* tangent7, double* s12_out) { ORBHIP_REQUIRE(tangent7 && s12_out, ORBHIP_EINVAL, "NULL argument"); s3_exp(tangent7, s12_out); return 0; }
 int ba_sim3_log(const double* s12, double* tangent7_out) { ORBHIP_REQUIRE(s12 && tangent7_out, ORBHIP_EINVAL, "NULL argument"); s3_log(s12, tangent7_out); return 0; }
 
+// LocalBundleAdjustment's optimisation core for a batch of independent local maps: pass 1 of every problem in one
+// lockstep batch, host-side classification, pass 2 likewise (src/CeresOptimizer.cc:408-598 per problem).
+int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nproblems, const volatile uint8_t* stop_flag,
+                                     int duplicate_blocks, int* aborted, ba_summary* pass1, ba_summary* pass2) {
+  ORBHIP_REQUIRE(problems && aborted && nproblems > 0, ORBHIP_EINVAL, "NULL argument");
+  *aborted = 0;
+  struct Work {
+    std::vector<double> P0, X0, uv, w; std::vector<int32_t> oc, op; std::vector<uint8_t> rob, erase;
+  };
+  std::vector<Work> W(nproblems);
+  std::vector<BaInputs> in(nproblems);
+  for (int q = 0; q < nproblems; q++) {
+    const ba_local_problem& L = problems[q];
+    ORBHIP_REQUIRE(L.K4 && L.poses7 && L.cam_fixed && L.cam_local && L.obs_erase && L.ncam > 0 && L.nobs >= 0 && L.npts >= 0, ORBHIP_EINVAL, "NULL argument");
+    ORBHIP_REQUIRE(L.nobs == 0 || (L.obs_cam && L.obs_pt && L.obs_uv && L.obs_inv_sigma2), ORBHIP_EINVAL, "NULL observation arrays");
+    ORBHIP_REQUIRE(L.npts == 0 || L.pts3, ORBHIP_EINVAL, "NULL argument");
+    Work& w = W[q];
+    w.P0.assign(L.poses7, L.poses7 + 7 * (size_t)L.ncam); w.X0.assign(L.pts3, L.pts3 + 3 * (size_t)L.npts);
+    w.oc.assign(L.obs_cam, L.obs_cam + L.nobs); w.op.assign(L.obs_pt, L.obs_pt + L.nobs);
+    w.uv.assign(L.obs_uv, L.obs_uv + 2 * (size_t)L.nobs); w.w.resize(L.nobs);
+    for (int i = 0; i < L.nobs; i++) {
+      ORBHIP_REQUIRE(L.obs_cam[i] >= 0 && L.obs_cam[i] < L.ncam && L.obs_pt[i] >= 0 && L.obs_pt[i] < L.npts, ORBHIP_EINVAL, "observation index out of range");
+      w.w[i] = (double)L.obs_inv_sigma2[i];                                // F7: weight = invSigma2
+    }
+    w.rob.assign(L.nobs, 1); w.erase.assign(L.nobs, 0);
+  }
+  auto classify = [&](int q) {                                              // :529-567
+    const ba_local_problem& L = problems[q]; Work& w = W[q];
+    for (int i = 0; i < L.nobs; i++) {
+      w.erase[i] = 0;
+      const int c = L.obs_cam[i];
+      if (!L.cam_local[c]) continue;
+      double depth;
+      int out = check_outlier(L.K4 + 4 * c, w.P0.data() + 7 * c, w.X0.data() + 3 * (size_t)L.obs_pt[i], L.obs_uv[2 * (size_t)i], L.obs_uv[2 * (size_t)i + 1],
+                              (double)L.obs_inv_sigma2[i], 5.991, &depth);
+      if (out || depth <= 0) w.erase[i] = 1;
+    }
+  };
+  auto bind = [&]() {
+    for (int q = 0; q < nproblems; q++) {
+      const ba_local_problem& L = problems[q]; Work& w = W[q];
+      in[q] = BaInputs{L.K4, w.P0.data(), L.cam_fixed, L.ncam, w.X0.data(), L.npts, w.oc.data(), w.op.data(), w.uv.data(), w.w.data(), w.rob.data(), (int)w.oc.size()};
+    }
+  };
+  if (stop_flag && *stop_flag) { *aborted = 1; return 0; }                  // :509-512
+  ba_options o1; o1.max_iterations = 5; o1.huber_delta = sqrt(5.991); o1.fix_points = 0; o1.stop_flag = stop_flag;
+  bind();
+  int rc = ba_solve_batch_impl(in.data(), nproblems, &o1, pass1);
+  if (rc) return rc;
+  for (int q = 0; q < nproblems; q++) {
+    const ba_local_problem& L = problems[q]; Work& w = W[q];
+    classify(q);
+    if (duplicate_blocks) {
+      // F6: the reference adds every kept observation AGAIN without loss on the same problem; a kept observation and its
+      // twin are folded into one block (obs_robust = 2, see reproj_eval) instead of being listed twice
+      for (int i = 0; i < L.nobs; i++) w.rob[i] = w.erase[i] ? 1 : 2;
+    } else {
+      w.oc.clear(); w.op.clear(); w.uv.clear(); w.w.clear(); w.rob.clear();
+      for (int i = 0; i < L.nobs; i++) {
+        if (w.erase[i]) continue;
+        w.oc.push_back(L.obs_cam[i]); w.op.push_back(L.obs_pt[i]); w.uv.push_back(L.obs_uv[2 * (size_t)i]); w.uv.push_back(L.obs_uv[2 * (size_t)i + 1]);
+        w.w.push_back((double)L.obs_inv_sigma2[i]); w.rob.push_back(0);
+      }
+    }
+  }
+  if (stop_flag && *stop_flag) { *aborted = 1; return 0; }
+  ba_options o2 = o1; o2.max_iterations = 10;
+  bind();
+  rc = ba_solve_batch_impl(in.data(), nproblems, &o2, pass2);
+  if (rc) return rc;
+  for (int q = 0; q < nproblems; q++) {
+    const ba_local_problem& L = problems[q]; Work& w = W[q];
+    classify(q);
+    if (L.nobs) std::memcpy(L.obs_erase, w.erase.data(), L.nobs);
+    for (int c = 0; c < L.ncam; c++) {                                      // Matrix_7_1_ToMatrix4d normalises (:80-81)
+      double* qd = w.P0.data() + 7 * c + 3;
+      const double nq = std::sqrt(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
+      for (int k = 0; k < 4; k++) qd[k] /= nq;
+    }
+    std::memcpy(L.poses7, w.P0.data(), sizeof(double) * 7 * L.ncam);
+    if (L.npts) std::memcpy(L.pts3, w.X0.data(), sizeof(double) * 3 * L.npts);
+  }
+  return 0;
+}
+
 int ba_local_bundle_adjustment(const double* K4, double* poses7, const uint8_t* cam_fixed, const uint8_t* cam_local, int ncam,
                                double* pts3, int npts, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv,
                                const float* obs_inv_sigma2, int nobs, const volatile uint8_t* stop_flag, int duplicate_blocks,
                                uint8_t* obs_erase, int* aborted, ba_summary* pass1, ba_summary* pass2) {
   ORBHIP_REQUIRE(K4 && poses7 && cam_fixed && cam_local && obs_erase && aborted && ncam > 0 && nobs >= 0, ORBHIP_EINVAL, "NULL argument");
-  *aborted = 0;
-  std::vector<double> P0(poses7, poses7 + 7 * (size_t)ncam), X0(pts3, pts3 + 3 * (size_t)npts);
-  std::vector<int32_t> oc(obs_cam, obs_cam + nobs), op(obs_pt, obs_pt + nobs);
-  std::vector<double> uv(obs_uv, obs_uv + 2 * (size_t)nobs), w(nobs);
-  for (int i = 0; i < nobs; i++) w[i] = (double)obs_inv_sigma2[i];        // F7: weight = invSigma2
-  std::vector<uint8_t> rob(nobs, 1), erase(nobs, 0);
-  auto classify = [&]() {                                                 // :529-567
-    for (int i = 0; i < nobs; i++) {
-      erase[i] = 0;
-      const int c = obs_cam[i];
-      if (!cam_local[c]) continue;
-      double depth;
-      int out = check_outlier(K4 + 4 * c, P0.data() + 7 * c, X0.data() + 3 * (size_t)obs_pt[i], obs_uv[2 * (size_t)i], obs_uv[2 * (size_t)i + 1],
-                              (double)obs_inv_sigma2[i], 5.991, &depth);
-      if (out || depth <= 0) erase[i] = 1;
-    }
-  };
-  if (stop_flag && *stop_flag) { *aborted = 1; return 0; }                // :509-512
-  ba_options o1; o1.max_iterations = 5; o1.huber_delta = sqrt(5.991); o1.fix_points = 0; o1.stop_flag = stop_flag;
-  int rc = ba_solve_impl(K4, P0.data(), cam_fixed, ncam, X0.data(), npts, oc.data(), op.data(), uv.data(), w.data(), rob.data(), nobs, &o1, pass1);
-  if (rc) return rc;
-  classify();
-  if (!duplicate_blocks) { oc.clear(); op.clear(); uv.clear(); w.clear(); rob.clear(); }
-  for (int i = 0; i < nobs; i++) {
-    if (erase[i]) continue;
-    oc.push_back(obs_cam[i]); op.push_back(obs_pt[i]); uv.push_back(obs_uv[2 * (size_t)i]); uv.push_back(obs_uv[2 * (size_t)i + 1]);
-    w.push_back((double)obs_inv_sigma2[i]); rob.push_back(0);
+  ba_local_problem L{K4, poses7, cam_fixed, cam_local, ncam, pts3, npts, obs_cam, obs_pt, obs_uv, obs_inv_sigma2, nobs, obs_erase};
+  return ba_local_bundle_adjustment_batch(&L, 1, stop_flag, duplicate_blocks, aborted, pass1, pass2);
+}
+
+int ba_solve_batch(const ba_problem* problems, int nproblems, const ba_options* opts, ba_summary* summaries) {
+  ORBHIP_REQUIRE(problems && opts && nproblems > 0, ORBHIP_EINVAL, "NULL argument");
+  std::vector<BaInputs> in(nproblems);
+  for (int q = 0; q < nproblems; q++) {
+    const ba_problem& B = problems[q];
+    in[q] = BaInputs{B.K4, B.poses7, B.cam_fixed, B.ncam, B.pts3, B.npts, B.obs_cam, B.obs_pt, B.obs_uv, B.obs_weight, B.obs_robust, B.nobs};
   }
-  if (stop_flag && *stop_flag) { *aborted = 1; return 0; }
-  ba_options o2 = o1; o2.max_iterations = 10;
-  rc = ba_solve_impl(K4, P0.data(), cam_fixed, ncam, X0.data(), npts, oc.data(), op.data(), uv.data(), w.data(), rob.data(), (int)oc.size(), &o2, pass2);
-  if (rc) return rc;
-  classify();
-  std::memcpy(obs_erase, erase.data(), nobs);
-  for (int c = 0; c < ncam; c++) {                                        // Matrix_7_1_ToMatrix4d normalises (:80-81)
-    double* q = P0.data() + 7 * c + 3;
-    const double nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int k = 0; k < 4; k++) q[k] /= nq;
-  }
-  std::memcpy(poses7, P0.data(), sizeof(double) * 7 * ncam);
-  if (npts) std::memcpy(pts3, X0.data(), sizeof(double) * 3 * npts);
-  return 0;
+  return ba_solve_batch_impl(in.data(), nproblems, opts, summaries);
 }
 
 }  // extern "C"

@@ -157,3 +157,50 @@ def sim3_log(s12):
     a = _f64(s12); out = np.zeros(7)
     _lib.check(L.ba_sim3_log(_lib.ptr(a), _lib.ptr(out)), "ba_sim3_log")
     return out
+
+
+def _addr(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+def bundle_adjustment_batch(problems, n_iterations=200, huber_delta=HUBER_DELTA, fix_points=False, stop_flag=None):
+    """ba_solve_batch: independent problems solved in lockstep (one grid row per problem).  `problems` is a list of
+    tuples (K4, poses7, cam_fixed, pts3, obs_cam, obs_pt, obs_uv, obs_weight, obs_robust), as bundle_adjustment takes them.
+    Returns a list of (poses7, pts3, summary)."""
+    L = _lib.load()
+    keep, arr = [], (_lib.BaProblem * len(problems))()
+    for q, (K4, poses7, cam_fixed, pts3, obs_cam, obs_pt, obs_uv, obs_weight, obs_robust) in enumerate(problems):
+        K4 = _f64(K4).reshape(-1, 4); poses = _f64(poses7).copy(); pts = _f64(pts3).reshape(-1, 3).copy()
+        cf = np.ascontiguousarray(cam_fixed, np.uint8)
+        oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+        uv = _f64(obs_uv).reshape(-1, 2); w = _f64(obs_weight); rb = np.ascontiguousarray(obs_robust, np.uint8)
+        keep.append((K4, poses, cf, pts, oc, op, uv, w, rb))
+        arr[q] = _lib.BaProblem(_addr(K4), _addr(poses), _addr(cf), len(cf), _addr(pts), len(pts), _addr(oc), _addr(op), _addr(uv),
+                                _addr(w), _addr(rb), len(oc))
+    o = _lib.BaOptions(int(n_iterations), float(huber_delta), int(fix_points), _addr(stop_flag) if stop_flag is not None else None)
+    summ = (_lib.BaSummary * len(problems))()
+    _lib.check(L.ba_solve_batch(C.cast(arr, C.c_void_p), len(problems), C.byref(o), C.cast(summ, C.c_void_p)), "ba_solve_batch")
+    return [(k[1], k[3], summ[q].as_dict()) for q, k in enumerate(keep)]
+
+
+def local_bundle_adjustment_batch(problems, stop_flag=None, duplicate_blocks=True):
+    """ba_local_bundle_adjustment_batch: `problems` is a list of tuples (K4, poses7, cam_fixed, cam_local, pts3, obs_cam,
+    obs_pt, obs_uv, obs_inv_sigma2), as local_bundle_adjustment takes them.
+    Returns (aborted, [(poses7, pts3, obs_erase, summary_pass1, summary_pass2), ...])."""
+    L = _lib.load()
+    keep, arr = [], (_lib.BaLocalProblem * len(problems))()
+    for q, (K4, poses7, cam_fixed, cam_local, pts3, obs_cam, obs_pt, obs_uv, obs_inv_sigma2) in enumerate(problems):
+        K4 = _f64(K4).reshape(-1, 4); poses = _f64(poses7).copy(); pts = _f64(pts3).reshape(-1, 3).copy()
+        cf = np.ascontiguousarray(cam_fixed, np.uint8); cl = np.ascontiguousarray(cam_local, np.uint8)
+        oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+        uv = _f64(obs_uv).reshape(-1, 2); isg = np.ascontiguousarray(obs_inv_sigma2, np.float32)
+        er = np.zeros(max(len(oc), 1), np.uint8)
+        keep.append((K4, poses, cf, cl, pts, oc, op, uv, isg, er))
+        arr[q] = _lib.BaLocalProblem(_addr(K4), _addr(poses), _addr(cf), _addr(cl), len(cf), _addr(pts), len(pts), _addr(oc), _addr(op),
+                                     _addr(uv), _addr(isg), len(oc), er.ctypes.data)
+    ab = C.c_int(0)
+    s1 = (_lib.BaSummary * len(problems))(); s2 = (_lib.BaSummary * len(problems))()
+    _lib.check(L.ba_local_bundle_adjustment_batch(C.cast(arr, C.c_void_p), len(problems), _lib.ptr(stop_flag) if stop_flag is not None else None,
+                                                  int(duplicate_blocks), C.byref(ab), C.cast(s1, C.c_void_p), C.cast(s2, C.c_void_p)),
+               "ba_local_bundle_adjustment_batch")
+    return ab.value, [(k[1], k[4], k[9][:len(k[5])], s1[q].as_dict(), s2[q].as_dict()) for q, k in enumerate(keep)]

@@ -219,6 +219,27 @@ int ba_pose_optimization_batch_device(const double* d_K4 /*np*4*/, double* d_pos
                                       int nproblems, uint8_t* d_outlier, int32_t* d_n_inliers,
                                       ba_summary* d_summary, void* stream);
 
+/* Batches of INDEPENDENT problems (sub-maps) solved in lockstep: every kernel launch covers all problems of
+ * the batch (one grid row per problem), each with its own device-side LM state, so small problems fill the 256 CUs together
+ * instead of one at a time.  Results are identical to calling the single-problem entry points one by one.               */
+typedef struct ba_problem {                 /* arguments of ba_solve */
+  const double* K4; double* poses7; const uint8_t* cam_fixed; int32_t ncam;
+  double* pts3; int32_t npts;
+  const int32_t* obs_cam; const int32_t* obs_pt; const double* obs_uv; const double* obs_weight; const uint8_t* obs_robust;
+  int32_t nobs;
+} ba_problem;
+int ba_solve_batch(const ba_problem* problems, int nproblems, const ba_options* opts, ba_summary* summaries /*[nproblems], may be NULL*/);
+
+typedef struct ba_local_problem {           /* arguments of ba_local_bundle_adjustment */
+  const double* K4; double* poses7; const uint8_t* cam_fixed; const uint8_t* cam_local; int32_t ncam;
+  double* pts3; int32_t npts;
+  const int32_t* obs_cam; const int32_t* obs_pt; const double* obs_uv; const float* obs_inv_sigma2; int32_t nobs;
+  uint8_t* obs_erase;                       /* out [nobs] */
+} ba_local_problem;
+int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nproblems, const volatile uint8_t* stop_flag,
+                                     int duplicate_blocks, int* aborted, ba_summary* pass1 /*[nproblems] or NULL*/,
+                                     ba_summary* pass2 /*[nproblems] or NULL*/);
+
 /* CeresOptimizer::OptimizeSim3(KeyFrame*, KeyFrame*, vector<MapPoint*>& matches12, Sophus::Sim3d& S12, float th2,
  * bool bFixScale) (src/CeresOptimizer.cc:601-735; cost functor include/CeresOptimizer.h:168-236, parameterisation
  * src/CeresOptimizer.cc:24-47) for ONE keyframe pair, host pointers.  Correspondence i (the reference's accepted
@@ -249,7 +270,8 @@ int ba_sim3_log(const double* s12, double* tangent7_out);
 
 /* CeresOptimizer::BundleAdjustment (src/CeresOptimizer.cc:59-225) on flattened arrays, host pointers:
  * cameras with cam_fixed != 0 are constant (KF id 0, fixed KFs); obs_weight multiplies the pixel
- * residual (= invSigma2, F7); obs_robust selects the Huber loss per observation.  poses7 / pts3 are
+ * residual (= invSigma2, F7); obs_robust selects the loss per observation: 0 = none, 1 = Huber, 2 = the observation
+ * is present twice, under Huber AND without loss (LocalBA pass 2, F6), folded into one block.  poses7 / pts3 are
  * updated in place with the last accepted iterate (quaternions NOT re-normalised here).             */
 int ba_solve(const double* K4_per_cam, double* poses7, const uint8_t* cam_fixed, int ncam, double* pts3,
              int npts, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv,

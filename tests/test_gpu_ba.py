@@ -192,3 +192,47 @@ def test_ba_solve_multi_superblock_vs_oracle(oracle):
     assert s["iterations"] == os_["iterations"] and s["successful_steps"] == os_["successful_steps"]
     assert abs(s["final_cost"] - os_["final_cost"]) <= RTOL_COST * os_["final_cost"]
     assert _close(poses, oposes, RTOL_X) and _close_pts(pts, opts)
+
+
+def test_batched_solves_equal_single_solves():
+    """ba_solve_batch / ba_local_bundle_adjustment_batch: heterogeneous problems (different camera counts -> different
+    reduced-system sizes, panel counts and super-block counts) in one lockstep batch give exactly the single-call results."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    shapes = [(10, 300, 1400, 2), (23, 500, 2600, 1), (6, 120, 500, 2), (48, 900, 4500, 1), (100, 2000, 9000, 2), (3, 60, 200, 1)]
+    gs = [synth.make_ba_graph(30 + i, ncam=c, npts=p, nobs=o, n_fixed=f) for i, (c, p, o, f) in enumerate(shapes)]
+    probs = [(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"].astype(np.float64),
+              np.ones(len(g["obs_cam"]), np.uint8)) for g in gs]
+    res = optimizer.bundle_adjustment_batch(probs, n_iterations=12)
+    for pr, (poses, pts, s) in zip(probs, res):
+        p1, x1, s1 = optimizer.bundle_adjustment(*pr, n_iterations=12)
+        assert s == s1 and np.array_equal(poses, p1) and np.array_equal(pts, x1)
+    lprobs = [(g["K4"], g["poses0"], g["cam_fixed"], np.ones(len(g["cam_fixed"]), np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"],
+               g["obs_inv_sigma2"]) for g in gs]
+    ab, lres = optimizer.local_bundle_adjustment_batch(lprobs)
+    assert ab == 0
+    for pr, (poses, pts, er, s1, s2) in zip(lprobs, lres):
+        ab1, p1, x1, e1, t1, t2 = optimizer.local_bundle_adjustment(*pr)
+        assert (s1, s2) == (t1, t2) and np.array_equal(er, e1) and np.array_equal(poses, p1) and np.array_equal(pts, x1)
+    stop = np.array([1], np.uint8)
+    ab, lres = optimizer.local_bundle_adjustment_batch(lprobs[:2], stop_flag=stop)
+    assert ab == 1 and np.array_equal(lres[0][0], gs[0]["poses0"])
+
+
+def test_folded_twin_blocks_equal_literal_duplicates(oracle):
+    """obs_robust = 2 (a Huber block + its loss-free twin folded into one block, the form LocalBA's second pass uses for
+    the reference's re-added blocks, F6) against the oracle solving the LITERAL duplicated list."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    g = synth.make_ba_graph(12, ncam=14, npts=500, nobs=2600, n_fixed=2)
+    n = len(g["obs_cam"])
+    w = g["obs_inv_sigma2"].astype(np.float64)
+    twin = np.random.default_rng(1).random(n) < 0.8                       # 80 % of the observations have a twin
+    rb = np.where(twin, 2, 1).astype(np.uint8)
+    poses, pts, s = optimizer.bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, rb, 12)
+    cat = lambda a: np.concatenate([a, a[twin]])
+    orb = np.concatenate([np.ones(n, np.uint8), np.zeros(int(twin.sum()), np.uint8)])
+    oposes, opts, os_ = oracle.ba_solve(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], cat(g["obs_cam"]), cat(g["obs_pt"]), cat(g["obs_uv"]),
+                                        cat(w), orb, 12)
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"])
+    assert abs(s["initial_cost"] - os_["initial_cost"]) <= RTOL_COST * os_["initial_cost"]
+    assert abs(s["final_cost"] - os_["final_cost"]) <= RTOL_COST * os_["final_cost"]
+    assert _close(poses, oposes, RTOL_X) and _close_pts(pts, opts)

@@ -1,0 +1,23 @@
+"""LocalBA (C4 size) throughput: batch size B per call x T host threads.  usage: ba_batch_thr.py B:T [B:T ...]"""
+import numpy as np, sys, time, os, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ceres_mono_orb_slam2_amd import synth, optimizer
+gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=2) for s in range(4)]
+local = np.ones(100, np.uint8)
+def prob(g): return (g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+for spec in sys.argv[1:]:
+    B, T = [int(x) for x in spec.split(":")]
+    probs = [prob(gs[i % 4]) for i in range(B)]
+    n_each = max(2, 48 // (B * T))
+    bar = threading.Barrier(T + 1)
+    def work():
+        for _ in range(2): optimizer.local_bundle_adjustment_batch(probs)
+        bar.wait()
+        for _ in range(n_each): optimizer.local_bundle_adjustment_batch(probs)
+    ths = [threading.Thread(target=work) for _ in range(T)]
+    for t in ths: t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    for t in ths: t.join()
+    dt = time.perf_counter() - t0
+    print('batch', B, 'threads', T, 'solves/s %.1f' % (B * T * n_each / dt), 'ms/batch %.1f' % (dt / n_each * 1e3), flush=True)
