@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=48)
+    ap.add_argument("--cpu-sample", type=int, default=160)   # ~13 s of single-thread oracle work
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     args = ap.parse_args()
