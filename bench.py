@@ -26,7 +26,8 @@ W_IMG, H_IMG, NFEAT = 1241, 376, 2000
 PX_TOTAL = 1444097
 BYTES = {"pyramid": 1407767 + 977481, "fast_cells": 1444097, "blur": 2 * 1444097, "describe": 2000 * (32 + 28)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_TOPS = 78.6          # 256 CU x 128 lanes x 2.4 GHz integer lane-ops/s (match kernel, not an HBM kernel)
+VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer VALU instruction issues over 4 cycles;
+                               # measured 35-39 T lane-instr/s for xor/bcnt/pk_*16/dot4/dot2/sad/alignbyte (tools/ubench/valu_rate.hip)
 MATCH_LANE_OPS_PER_PAIR = 19   # 8 xor + 8 bcnt-accumulate + ~3 compare/select per descriptor pair
 
 
