@@ -182,6 +182,14 @@ def main():
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": BYTES[dom] * B}
+        # the kernel is an HBM kernel by bytes but binds on the integer VALU issue rate: report that fraction too, from the
+        # committed PMC pass (profiles/r01_pmc_valu.json: SQ_INSTS_VALU x 4 cycles / SIMD-cycles of the launch)
+        try:
+            vp = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu.json")))["kernels"][kname]
+            roof["valu_issue_frac"] = vp["valu_busy_frac"]
+            roof["valu_insts_per_wave"] = vp["valu_insts_per_wave"]
+        except Exception:
+            pass
         pairs_per_s = B / (per_call["match"] * 1e-3)
         lane_ops = mean_kp * mean_kp * MATCH_LANE_OPS_PER_PAIR
         kernels = {k: {"ms_per_launch_batch": v} for k, v in per_call.items()}
