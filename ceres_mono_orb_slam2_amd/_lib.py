@@ -15,6 +15,7 @@ SYMBOLS = [
     "orbx_extract_batch_device", "orbx_set_profiling", "orbx_get_stage_ms", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
     "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_bow", "orbm_search_for_triangulation",
+    "orbm_undistort_keypoints", "orbm_assign_features_to_grid", "orbm_features_in_area", "orbm_is_in_frustum",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log",
     "ba_solve_batch", "ba_local_bundle_adjustment_batch",
@@ -96,6 +97,10 @@ def load():
                                      C.POINTER(i32)]
     L.orbm_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, f32, f32, vp, vp,
                                                 i32, vp, C.POINTER(i32)]
+    L.orbm_undistort_keypoints.argtypes = [vp, i32, vp, vp, vp]
+    L.orbm_assign_features_to_grid.argtypes = [vp, i32, vp, vp, vp, C.POINTER(i32)]
+    L.orbm_features_in_area.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.POINTER(i32)]
+    L.orbm_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, vp, vp, vp]
     if hasattr(L, "ba_solve"):
         L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
         L.ba_pose_optimization_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]

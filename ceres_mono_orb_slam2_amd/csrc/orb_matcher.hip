@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "orb_frame.h"
 
 namespace orbhip {
 
@@ -370,18 +371,44 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
   ORBHIP_REQUIRE(kps4 && desc && bounds && q_uv && q_radius && q_desc, ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE(!check_ori || q_angle, ORBHIP_EINVAL, "rotation check needs q_angle");
   ORBHIP_REQUIRE(chi2_gate <= 0.f || inv_level_sigma2, ORBHIP_EINVAL, "chi2 gate needs inv_level_sigma2");
-  FrameGrid* G = new FrameGrid();
-  G->build(kps4, n, bounds);
+  // ---- grid, window candidates and every (query, candidate) distance on the device: the host only keeps the
+  //      order-dependent greedy pass below, fed with the CSR lists in the reference's candidate order
   std::vector<uint32_t> off(nq + 1, 0), idx;
-  for (int i = 0; i < nq; i++) {
-    off[i] = (uint32_t)idx.size();
-    if (q_valid && !q_valid[i]) continue;
-    G->query(q_uv[2 * i], q_uv[2 * i + 1], q_radius[i], q_min_level ? q_min_level[i] : -1, q_max_level ? q_max_level[i] : -1, idx);
-  }
-  off[nq] = (uint32_t)idx.size();
-  delete G;
   std::vector<int> dist;
-  if (int rc = csr_distances_gpu(q_desc, nq, desc, n, off, idx, dist)) return rc;
+  {
+    if (int rcd = use_default_device()) return rcd;
+    FrameGridDev G; DevBuf dk, dd, dq, dr, dmn, dmx, dv, dqd, dcnt, doff, didx, ddist;
+    DevBuf* all[] = {&dk, &dd, &dq, &dr, &dmn, &dmx, &dv, &dqd, &dcnt, &doff, &didx, &ddist};
+    auto cleanup = [&]() { G.release(); for (DevBuf* b : all) b->release(); };
+    int rc = 0;
+    if ((rc = dk.ensure((size_t)n * 16)) || (rc = dd.ensure((size_t)n * 32)) || (rc = dq.ensure((size_t)nq * 8)) || (rc = dr.ensure((size_t)nq * 4)) ||
+        (rc = dqd.ensure((size_t)nq * 32)) || (q_min_level && (rc = dmn.ensure((size_t)nq * 4))) || (q_max_level && (rc = dmx.ensure((size_t)nq * 4))) ||
+        (q_valid && (rc = dv.ensure((size_t)nq)))) { cleanup(); return rc; }
+#define SBP_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return ORBHIP_ENODEV; } } while (0)
+    SBP_CHK(hipMemcpy(dk.p, kps4, (size_t)n * 16, hipMemcpyHostToDevice)); SBP_CHK(hipMemcpy(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    SBP_CHK(hipMemcpy(dq.p, q_uv, (size_t)nq * 8, hipMemcpyHostToDevice)); SBP_CHK(hipMemcpy(dr.p, q_radius, (size_t)nq * 4, hipMemcpyHostToDevice));
+    SBP_CHK(hipMemcpy(dqd.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
+    if (q_min_level) SBP_CHK(hipMemcpy(dmn.p, q_min_level, (size_t)nq * 4, hipMemcpyHostToDevice));
+    if (q_max_level) SBP_CHK(hipMemcpy(dmx.p, q_max_level, (size_t)nq * 4, hipMemcpyHostToDevice));
+    if (q_valid) SBP_CHK(hipMemcpy(dv.p, q_valid, (size_t)nq, hipMemcpyHostToDevice));
+    const float gb[4] = {bounds[0], bounds[1], bounds[2], bounds[3]};
+    if ((rc = frame_grid_build(G, dk.as<float>(), n, gb, nullptr))) { cleanup(); return rc; }
+    uint32_t total = 0;
+    if ((rc = frame_area_candidates(G, dk.as<float>(), dq.as<float>(), dr.as<float>(), q_min_level ? dmn.as<int>() : nullptr,
+                                    q_max_level ? dmx.as<int>() : nullptr, q_valid ? dv.as<uint8_t>() : nullptr, nq, dcnt, doff, didx, &total, nullptr))) { cleanup(); return rc; }
+    SBP_CHK(hipMemcpy(off.data(), doff.p, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost));
+    idx.resize(total); dist.resize(total);
+    if (total) {
+      if ((rc = ddist.ensure((size_t)total * 4))) { cleanup(); return rc; }
+      hipLaunchKernelGGL(k_dist_csr, dim3((total + 255) / 256), dim3(256), 0, 0, dqd.as<uint8_t>(), nq, dd.as<uint8_t>(), doff.as<uint32_t>(),
+                         didx.as<uint32_t>(), total, ddist.as<int>());
+      SBP_CHK(hipGetLastError());
+      SBP_CHK(hipMemcpy(idx.data(), didx.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+      SBP_CHK(hipMemcpy(dist.data(), ddist.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    }
+#undef SBP_CHK
+    cleanup();
+  }
   // ---- greedy pass in query order (reference loop order) ---------------------------------------
   int nm = 0;
   std::vector<int> hist_bin(nq, -1);

@@ -172,6 +172,36 @@ int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, cons
                        const uint32_t* fv2_off, const uint32_t* fv2_idx, int fv2_n, float ratio, int th, int strict,
                        int check_ori, int32_t* match12, int* nmatches);
 
+/* ---- the steps either side of extract -> match: undistortion, the 64 x 48 frame grid, window candidates,
+ * frustum test.  kps4 = n x {x, y, octave, angle} floats of the UNDISTORTED keypoints; bounds = {min_x, max_x, min_y, max_y}
+ * (Frame::ComputeImageBounds, src/Frame.cc:357-385).  Host pointers; the arithmetic runs on the device.                  */
+
+/* Frame::UndistortKeyPoints (src/Frame.cc:329-355): cv::undistortPoints(mat, mat, K, dist, Mat(), K) on n points,
+ * dist5 = {k1, k2, p1, p2, k3}; k1 == 0 copies the input, as the reference does.                                        */
+int orbm_undistort_keypoints(const float* xy, int n, const float* K4 /*fx,fy,cx,cy*/, const float* dist5, float* xy_out);
+
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:158-173, PosInGrid :309-320): cell c = x * 48 + y holds keypoint indices
+ * cell_idx[cell_offsets[c] .. cell_offsets[c+1]) in push_back order; keypoints outside the grid are skipped.            */
+int orbm_assign_features_to_grid(const float* kps4, int n, const float* bounds, uint32_t* cell_offsets /*[64*48+1]*/,
+                                 uint32_t* cell_idx /*[n]*/, int* n_assigned);
+
+/* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:243-307) for nq queries -> CSR lists in the
+ * reference's order (cells ix-major then iy, entries in keypoint-index order).  q_min_level / q_max_level NULL = -1 / -1,
+ * which is also KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:575-622).  cand_idx may be NULL to size: *total is always set;
+ * ORBHIP_ECAP if cap < *total with cand_idx given.                                                                       */
+int orbm_features_in_area(const float* kps4, int n, const float* bounds, const float* q_xy, const float* q_radius,
+                          const int32_t* q_min_level, const int32_t* q_max_level, int nq, uint32_t* cand_offsets /*[nq+1]*/,
+                          uint32_t* cand_idx, int cap, int* total);
+
+/* Frame::isInFrustum (src/Frame.cc:191-241) + MapPoint::PredictScale (src/MapPoint.cc:406-420) for n map points:
+ * Rcw (row-major 3x3), tcw of the frame; P = world position, Pn = mean viewing direction, min_dist / max_dist = the map
+ * point's raw min_distance_ / max_distance_ (the 0.8 / 1.2 invariance factors are applied here).  Outputs per point:
+ * in_view (is_track_in_view_), uv (track_proj_x_, track_proj_y_), level (track_scale_level_), view_cos (track_view_cos_);
+ * uv / level / view_cos are written for every point, meaningful where in_view is set.                                    */
+int orbm_is_in_frustum(const double* Rcw, const double* tcw, const float* K4, const float* bounds, const double* P,
+                       const double* Pn, const float* min_dist, const float* max_dist, int n, float viewing_cos_limit,
+                       float log_scale_factor, int n_levels, uint8_t* in_view, float* uv, int32_t* level, float* view_cos);
+
 /* SearchForTriangulation (src/ORBmatcher.cc:582-722, mono) on flattened data (host pointers): BoW-node brute force
  * between keypoints WITHOUT a map point (unmapped1/2 flags), dist <= TH_LOW with later ties replacing earlier ones
  * (":654"), rejection near the epipole (ex, ey; ":658-664") and the epipolar-line gate CheckDistEpipolarLine

@@ -394,3 +394,77 @@ int orc_th_high() { return TH_HIGH; }
 int orc_histo_length() { return HISTO_LENGTH; }
 
 }  // extern "C"
+
+// ============================================================================ SURVEY N2: the steps either side of extract -> match
+extern "C" {
+
+// Frame::AssignFeaturesToGrid (src/Frame.cc:158-173): CSR form of grid_[x][y], cell = x * 48 + y
+int orc_assign_features_to_grid(const float* kps, int n, const float* bounds /*minx,maxx,miny,maxy*/, uint32_t* cell_off, uint32_t* cell_idx) {
+  Grid* G = new Grid();
+  G->build(kps, n, bounds[0], bounds[1], bounds[2], bounds[3]);
+  uint32_t tot = 0;
+  for (int x = 0; x < Grid::COLS; x++)
+    for (int y = 0; y < Grid::ROWS; y++) {
+      cell_off[x * Grid::ROWS + y] = tot;
+      for (int j : G->cell[x][y]) cell_idx[tot++] = (uint32_t)j;
+    }
+  cell_off[Grid::COLS * Grid::ROWS] = tot;
+  delete G;
+  return (int)tot;
+}
+
+// Frame::UndistortKeyPoints (src/Frame.cc:329-355) = cv::undistortPoints(src, dst, K, dist, noArray(), K): OpenCV 2.4 / 3.2,
+// five fixed-point iterations in double, (k1, k2, p1, p2, k3), destination CV_32F.
+void orc_undistort_keypoints(const float* xy, int n, const float* K4, const float* dist5, float* out) {
+  if (dist5[0] == 0.0f) { for (int i = 0; i < 2 * n; i++) out[i] = xy[i]; return; }
+  const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+  const double k1 = dist5[0], k2 = dist5[1], p1 = dist5[2], p2 = dist5[3], k3 = dist5[4];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  for (int i = 0; i < n; i++) {
+    double x = ((double)xy[2 * i] - cx) * ifx, y = ((double)xy[2 * i + 1] - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    out[2 * i] = (float)(fx * x + cx);
+    out[2 * i + 1] = (float)(fy * y + cy);
+  }
+}
+
+// Frame::isInFrustum (src/Frame.cc:191-241) + MapPoint::PredictScale (src/MapPoint.cc:406-420).  Canonical choice where the
+// reference is ambiguous: log / ceil of the float ratio use the float overloads.
+void orc_is_in_frustum(const double* R, const double* t, const float* K4, const float* bounds, const double* P, const double* Pn,
+                       const float* min_dist, const float* max_dist, int n, float cos_limit, float log_scale, int nlevels,
+                       uint8_t* in_view, float* uv, int* level, float* view_cos) {
+  double Ow[3];
+  for (int k = 0; k < 3; k++) Ow[k] = -(R[k] * t[0] + R[3 + k] * t[1] + R[6 + k] * t[2]);
+  for (int i = 0; i < n; i++) {
+    const double X = P[3 * i], Y = P[3 * i + 1], Z = P[3 * i + 2];
+    const float PcX = (float)(R[0] * X + R[1] * Y + R[2] * Z + t[0]);
+    const float PcY = (float)(R[3] * X + R[4] * Y + R[5] * Z + t[1]);
+    const float PcZ = (float)(R[6] * X + R[7] * Y + R[8] * Z + t[2]);
+    bool ok = !(PcZ < 0.0f);
+    const float invz = 1.0f / PcZ;
+    const float u = K4[0] * PcX * invz + K4[2];
+    const float v = K4[1] * PcY * invz + K4[3];
+    if (u < bounds[0] || u > bounds[1]) ok = false;
+    if (v < bounds[2] || v > bounds[3]) ok = false;
+    const float maxD = 1.2f * max_dist[i], minD = 0.8f * min_dist[i];
+    const double POx = X - Ow[0], POy = Y - Ow[1], POz = Z - Ow[2];
+    const float dist = (float)std::sqrt(POx * POx + POy * POy + POz * POz);
+    if (dist < minD || dist > maxD) ok = false;
+    const float vc = (float)((POx * Pn[3 * i] + POy * Pn[3 * i + 1] + POz * Pn[3 * i + 2]) / (double)dist);
+    if (vc < cos_limit) ok = false;
+    const float ratio = max_dist[i] / dist;
+    int nScale = (int)std::ceil(std::log(ratio) / log_scale);       // float overloads
+    if (nScale < 0) nScale = 0; else if (nScale >= nlevels) nScale = nlevels - 1;
+    in_view[i] = ok ? 1 : 0; uv[2 * i] = u; uv[2 * i + 1] = v; level[i] = nScale; view_cos[i] = vc;
+  }
+}
+
+}  // extern "C"

@@ -451,3 +451,34 @@ def optimize_sim3(K1, K2, s12, P3D2c, obs1, inv_sigma2_1, P3D1c, obs2, inv_sigma
     ninl = lib().orc_optimize_sim3(_p(K1), _p(K2), _p(S), _p(P2), _p(o1), _p(w1), _p(P1), _p(o2), _p(w2), n, float(th2),
                                    int(bool(fix_scale)), _p(out), C.byref(s))
     return ninl, S, out[:n], s.as_dict()
+
+
+# --------------------------------- frame grid / frustum / undistort ----------------
+def assign_features_to_grid(kps4, bounds):
+    k = np.ascontiguousarray(kps4, np.float32).reshape(-1, 4); b = np.ascontiguousarray(bounds, np.float32)
+    off = np.zeros(64 * 48 + 1, np.uint32); idx = np.zeros(max(len(k), 1), np.uint32)
+    L = lib(); L.orc_assign_features_to_grid.restype = C.c_int
+    L.orc_assign_features_to_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = L.orc_assign_features_to_grid(_p(k), len(k), _p(b), _p(off), _p(idx))
+    return off, idx[:n]
+
+
+def undistort_keypoints(xy, K4, dist5):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2); out = np.zeros_like(xy)
+    K4 = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist5, np.float32)
+    L = lib(); L.orc_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_undistort_keypoints(_p(xy), len(xy), _p(K4), _p(d), _p(out))
+    return out
+
+
+def is_in_frustum(Rcw, tcw, K4, bounds, P, Pn, min_dist, max_dist, cos_limit, log_scale, nlevels):
+    R = _f64(Rcw).reshape(9); t = _f64(tcw); K4 = np.ascontiguousarray(K4, np.float32); b = np.ascontiguousarray(bounds, np.float32)
+    P = _f64(P).reshape(-1, 3); Pn = _f64(Pn).reshape(-1, 3)
+    mn = np.ascontiguousarray(min_dist, np.float32); mx = np.ascontiguousarray(max_dist, np.float32)
+    n = len(P)
+    iv = np.zeros(n, np.uint8); uv = np.zeros((n, 2), np.float32); lv = np.zeros(n, np.int32); vc = np.zeros(n, np.float32)
+    L = lib()
+    L.orc_is_in_frustum.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 4
+    L.orc_is_in_frustum(_p(R), _p(t), _p(K4), _p(b), _p(P), _p(Pn), _p(mn), _p(mx), n, float(cos_limit), float(log_scale), int(nlevels),
+                        _p(iv), _p(uv), _p(lv), _p(vc))
+    return iv, uv, lv, vc
