@@ -254,3 +254,40 @@ def make_ba_graph(seed, ncam=100, npts=10000, nobs=50000, outlier_frac=0.05, noi
     cam_fixed = np.zeros(ncam, np.uint8); cam_fixed[:n_fixed] = 1
     return dict(K4=np.tile(K4, (ncam, 1)), poses0=poses0, poses_gt=poses_gt, cam_fixed=cam_fixed, pts0=pts0,
                 pts_gt=pts, obs_cam=oc, obs_pt=op, obs_uv=obs, obs_inv_sigma2=inv_sigma2, octave=octv)
+
+
+
+def make_vocabulary(seed, k=10, L=4, flip=40, ragged=0.0, stop_frac=0.02):
+    """Synthetic ORB vocabulary tree in the flattened form of include/orbslam_hip.h::orbv_create (stands in for the
+    un-shipped ORBvoc.txt, k = 10, L = 6): children descriptors are their parent's with up to `flip` random bits toggled
+    (a clustering-like hierarchy), leaves carry consecutive word ids and idf-like weights (a fraction stop_frac are 0 =
+    stopped words); `ragged` randomly drops children so that nodes have fewer than k.  Nodes are numbered level by level."""
+    rng = np.random.default_rng(seed)
+    descs = [rng.integers(0, 256, (1, 32), dtype=np.uint8)]
+    counts = []                                      # children count of every node, level by level
+    for lev in range(L):
+        par = descs[-1]
+        m = len(par)
+        nk = np.full(m, k, np.int64) if ragged == 0.0 else np.maximum(2, k - rng.binomial(k - 2, ragged, m))
+        counts.append(nk)
+        rep = np.repeat(np.arange(m), nk)
+        out = np.empty((len(rep), 32), np.uint8)
+        for c0 in range(0, len(rep), 1 << 16):       # chunked: the bit masks are 256 bytes per child
+            r = rep[c0:c0 + (1 << 16)]
+            mask = np.zeros((len(r), 256), np.uint8)
+            mask[np.arange(len(r))[:, None], rng.integers(0, 256, (len(r), flip))] = 1
+            out[c0:c0 + len(r)] = par[r] ^ np.packbits(mask, axis=1)
+        descs.append(out)
+        flip = max(4, int(flip * 0.7))
+    counts.append(np.zeros(len(descs[-1]), np.int64))
+    node_desc = np.concatenate(descs)
+    nk_all = np.concatenate(counts)
+    n = len(node_desc)
+    child_off = np.zeros(n + 1, np.uint32); child_off[1:] = np.cumsum(nk_all)
+    children = np.arange(1, n, dtype=np.uint32)      # level-by-level numbering: the children of all nodes are consecutive
+    word_id = np.full(n, -1, np.int32); weight = np.zeros(n, np.float64)
+    leaves = np.nonzero(nk_all == 0)[0]
+    word_id[leaves] = np.arange(len(leaves))
+    wts = rng.uniform(0.5, 9.0, len(leaves)); wts[rng.random(len(leaves)) < stop_frac] = 0.0
+    weight[leaves] = wts
+    return dict(node_desc=node_desc, child_off=child_off, children=children, word_id=word_id, weight=weight, L=L, k=k)

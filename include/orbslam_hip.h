@@ -172,6 +172,27 @@ int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, cons
                        const uint32_t* fv2_off, const uint32_t* fv2_idx, int fv2_n, float ratio, int th, int strict,
                        int check_ori, int32_t* match12, int* nmatches);
 
+/* ---- Frame::ComputeBoW: DBoW2 TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+ * (lib/DBoW2/DBoW2/TemplatedVocabulary.h:1124-1260), TF_IDF weighting + L1 norm as ORBVocabulary uses.  The tree is given
+ * flattened, node 0 = root: node_desc[n_nodes][32], children of node i = children[child_off[i] .. child_off[i+1]) in their
+ * stored order (a leaf has none), word_id / weight of the leaves (word id of an inner node is ignored), L = depth.        */
+typedef struct orbv_ctx orbv_ctx;
+int orbv_create(const uint8_t* node_desc, const uint32_t* child_off /*[n_nodes+1]*/, const uint32_t* children,
+                const int32_t* word_id, const double* weight, int n_nodes, int L, int device, orbv_ctx** out);
+int orbv_destroy(orbv_ctx* ctx);
+/* desc[n][32] -> BowVector as ascending (bow_word[k], bow_value[k]), k < *n_words <= n, and FeatureVector as CSR:
+ * node ids fv_node[m] ascending, features fv_idx[fv_off[m] .. fv_off[m+1]) ascending, m < *n_fv_nodes <= n (fv_off has n+1
+ * entries) - the layout orbm_search_by_bow / orbm_search_for_triangulation take.  src/Frame.cc:322-327 uses levelsup = 4.
+ * The node of a feature whose leaf lies above level L - levelsup is 0 (the reference leaves it uninitialised there).     */
+int orbv_transform(orbv_ctx* ctx, const uint8_t* desc, int n, int levelsup, uint32_t* bow_word, double* bow_value,
+                   int* n_words, uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes);
+/* the tree descent only, device-resident and batchable over frames: per feature its word id, idf weight and node id.
+ * Enqueue only.                                                                                                          */
+int orbv_descend_device(orbv_ctx* ctx, const uint8_t* d_desc, int n, int levelsup, int32_t* d_word, double* d_weight,
+                        uint32_t* d_node, void* stream);
+/* L1Scoring::score (lib/DBoW2/DBoW2/ScoringObject.cpp:23-68) between two BowVectors in the layout above (host arithmetic). */
+double orbv_score_l1(const uint32_t* w1, const double* v1, int n1, const uint32_t* w2, const double* v2, int n2);
+
 /* ---- the steps either side of extract -> match: undistortion, the 64 x 48 frame grid, window candidates,
  * frustum test.  kps4 = n x {x, y, octave, angle} floats of the UNDISTORTED keypoints; bounds = {min_x, max_x, min_y, max_y}
  * (Frame::ComputeImageBounds, src/Frame.cc:357-385).  Host pointers; the arithmetic runs on the device.                  */

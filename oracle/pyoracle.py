@@ -17,7 +17,7 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp", "sim3_oracle.cpp",
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp", "sim3_oracle.cpp", "bow_oracle.cpp",
                                              "orb_pattern_data.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -482,3 +482,24 @@ def is_in_frustum(Rcw, tcw, K4, bounds, P, Pn, min_dist, max_dist, cos_limit, lo
     L.orc_is_in_frustum(_p(R), _p(t), _p(K4), _p(b), _p(P), _p(Pn), _p(mn), _p(mx), n, float(cos_limit), float(log_scale), int(nlevels),
                         _p(iv), _p(uv), _p(lv), _p(vc))
     return iv, uv, lv, vc
+
+
+# --------------------------------- BoW ---------------------------------------------
+def bow_transform(voc, desc, levelsup=4):
+    """voc = dict(node_desc, child_off, children, word_id, weight, L).  Returns (bow_word, bow_value, fv_node, fv_off, fv_idx)."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); n = len(d)
+    bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64); nw = C.c_int(0)
+    fn = np.zeros(max(n, 1), np.uint32); fo = np.zeros(n + 2, np.uint32); fi = np.zeros(max(n, 1), np.uint32); nf = C.c_int(0)
+    L = lib()
+    L.orc_bow_transform.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+    L.orc_bow_transform(_p(voc["node_desc"]), _p(voc["child_off"]), _p(voc["children"]), _p(voc["word_id"]), _p(voc["weight"]),
+                        len(voc["word_id"]), int(voc["L"]), int(levelsup), _p(d), n, _p(bw), _p(bv), C.byref(nw), _p(fn), _p(fo), _p(fi),
+                        C.byref(nf))
+    return bw[:nw.value], bv[:nw.value], fn[:nf.value], fo[:nf.value + 1], fi[:fo[nf.value]]
+
+
+def bow_score_l1(w1, v1, w2, v2):
+    L = lib(); L.orc_bow_score_l1.restype = C.c_double
+    L.orc_bow_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    w1 = np.ascontiguousarray(w1, np.uint32); w2 = np.ascontiguousarray(w2, np.uint32); v1 = _f64(v1); v2 = _f64(v2)
+    return L.orc_bow_score_l1(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2))

@@ -1,0 +1,66 @@
+"""GPU parity (bit-exact) for Frame::ComputeBoW = DBoW2 TemplatedVocabulary::transform vs the CPU oracle:
+BowVector words and L1-normalised tf-idf values (as bit patterns), FeatureVector CSR, on synthetic k-ary trees."""
+import numpy as np
+import pytest
+
+from ceres_mono_orb_slam2_amd import synth
+
+pytestmark = pytest.mark.gpu
+KEYS = ("node_desc", "child_off", "children", "word_id", "weight", "L")
+
+
+def _features(voc, seed, n, noise=25):
+    """descriptors near random leaves (so the descent is meaningful) plus some pure-random ones"""
+    rng = np.random.default_rng(seed)
+    leaves = np.nonzero(voc["word_id"] >= 0)[0]
+    d = voc["node_desc"][rng.choice(leaves, n)].copy()
+    bits = np.unpackbits(d, axis=1)
+    for i in range(n):
+        bits[i, rng.choice(256, noise, replace=False)] ^= 1
+    d = np.packbits(bits, axis=1)
+    d[: n // 10] = rng.integers(0, 256, (n // 10, 32), dtype=np.uint8)
+    return d
+
+
+@pytest.mark.parametrize("seed,k,L,ragged,n,levelsup", [(0, 10, 4, 0.0, 2000, 2), (1, 10, 3, 0.3, 500, 1), (2, 4, 6, 0.0, 1000, 4), (3, 16, 3, 0.2, 777, 2),
+                                                          (4, 10, 4, 0.0, 1, 4), (5, 10, 5, 0.0, 3000, 4)])
+def test_transform_vs_oracle(oracle, seed, k, L, ragged, n, levelsup):
+    from ceres_mono_orb_slam2_amd.vocabulary import ORBVocabulary
+    voc = synth.make_vocabulary(seed, k=k, L=L, ragged=ragged)
+    V = ORBVocabulary(*[voc[x] for x in KEYS])
+    d = _features(voc, 10 + seed, n)
+    bw, bv, (fn, fo, fi) = V.transform(d, levelsup)
+    obw, obv, ofn, ofo, ofi = oracle.bow_transform(voc, d, levelsup)
+    assert np.array_equal(bw, obw) and np.array_equal(bv.view(np.uint64), obv.view(np.uint64))     # values bit-exact
+    assert np.array_equal(fn, ofn) and np.array_equal(fo, ofo) and np.array_equal(fi, ofi)
+    assert abs(bv.sum() - 1.0) < 1e-12 and len(fi) <= n
+    if levelsup >= L:
+        assert len(fn) == 1 and fn[0] == 0                             # nid_level <= 0: everything under the root (:1226)
+
+
+def test_empty_and_scores(oracle):
+    from ceres_mono_orb_slam2_amd.vocabulary import ORBVocabulary
+    voc = synth.make_vocabulary(7, k=10, L=4)
+    V = ORBVocabulary(*[voc[x] for x in KEYS])
+    bw, bv, (fn, fo, fi) = V.transform(np.zeros((0, 32), np.uint8))
+    assert len(bw) == 0 and len(fn) == 0 and list(fo) == [0]
+    a = V.transform(_features(voc, 1, 1500)); b = V.transform(_features(voc, 2, 1500))
+    assert abs(V.score(a, a) - 1.0) < 1e-12
+    s = V.score(a, b)
+    assert s == oracle.bow_score_l1(a[0], a[1], b[0], b[1]) and 0.0 <= s < 0.2
+
+
+def test_descend_device_batch(oracle):
+    import torch
+    from ceres_mono_orb_slam2_amd.vocabulary import ORBVocabulary
+    voc = synth.make_vocabulary(8, k=10, L=4)
+    V = ORBVocabulary(*[voc[x] for x in KEYS])
+    d = _features(voc, 3, 40000)                                        # e.g. 20 frames x 2000 descriptors in one launch
+    word, wt, node = V.descend_device(torch.from_numpy(d).cuda(), 2)
+    torch.cuda.synchronize()
+    word = word.cpu().numpy(); wt = wt.cpu().numpy(); node = node.cpu().numpy().view(np.uint32)
+    for f0 in (0, 2000, 38000):
+        obw, obv, ofn, ofo, ofi = oracle.bow_transform(voc, d[f0:f0 + 2000], 2)
+        live = wt[f0:f0 + 2000] > 0
+        assert np.array_equal(np.unique(word[f0:f0 + 2000][live]), obw.astype(np.int64))
+        assert np.array_equal(np.unique(node[f0:f0 + 2000][live]), ofn)
