@@ -17,6 +17,7 @@ SYMBOLS = [
     "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_bow", "orbm_search_for_triangulation",
     "orbv_create", "orbv_destroy", "orbv_transform", "orbv_descend_device", "orbv_score_l1",
     "orbm_undistort_keypoints", "orbm_assign_features_to_grid", "orbm_features_in_area", "orbm_is_in_frustum",
+    "orbm_triangulate_matches",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log",
     "ba_solve_batch", "ba_local_bundle_adjustment_batch",
@@ -107,6 +108,7 @@ def load():
     L.orbm_undistort_keypoints.argtypes = [vp, i32, vp, vp, vp]
     L.orbm_assign_features_to_grid.argtypes = [vp, i32, vp, vp, vp, C.POINTER(i32)]
     L.orbm_features_in_area.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.POINTER(i32)]
+    L.orbm_triangulate_matches.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, vp]
     L.orbm_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, vp, vp, vp]
     if hasattr(L, "ba_solve"):
         L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]

@@ -60,3 +60,17 @@ def isInFrustum(Rcw, tcw, K4, bounds, P, Pn, min_dist, max_dist, viewing_cos_lim
                                     float(viewing_cos_limit), float(log_scale_factor), int(n_levels), _lib.ptr(iv), _lib.ptr(uv), _lib.ptr(lv),
                                     _lib.ptr(vc)), "orbm_is_in_frustum")
     return iv[:n], uv[:n], lv[:n], vc[:n]
+
+
+def TriangulateMatches(Tcw1, Tcw2, K1, K2, kp1, kp2, level_sigma2, scale_factors, ratio_factor):
+    """Per-match body of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:267-378).  kp = n x (x, y, octave).
+    Returns (x3D [n, 3] float64, ok [n] uint8)."""
+    L = _lib.load()
+    T1 = np.ascontiguousarray(Tcw1, np.float64).reshape(12); T2 = np.ascontiguousarray(Tcw2, np.float64).reshape(12)
+    K1 = np.ascontiguousarray(K1, np.float32); K2 = np.ascontiguousarray(K2, np.float32)
+    k1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 3); k2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 3)
+    ls = np.ascontiguousarray(level_sigma2, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    n = len(k1); X = np.zeros((max(n, 1), 3)); ok = np.zeros(max(n, 1), np.uint8)
+    _lib.check(L.orbm_triangulate_matches(_lib.ptr(T1), _lib.ptr(T2), _lib.ptr(K1), _lib.ptr(K2), _lib.ptr(k1), _lib.ptr(k2), n, _lib.ptr(ls),
+                                          _lib.ptr(sf), len(sf), float(ratio_factor), _lib.ptr(X), _lib.ptr(ok)), "orbm_triangulate_matches")
+    return X[:n], ok[:n]

@@ -172,6 +172,15 @@ int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, cons
                        const uint32_t* fv2_off, const uint32_t* fv2_idx, int fv2_n, float ratio, int th, int strict,
                        int check_ori, int32_t* match12, int* nmatches);
 
+/* ---- LocalMapping::CreateNewMapPoints, per-match body (src/LocalMapping.cc:267-378, monocular): ray-parallax
+ * test, linear triangulation (null vector of the 4x4 system; the reference uses Eigen::JacobiSVD<Matrix4d>), positive depth in
+ * both keyframes, chi-square reprojection gates (5.991 * level_sigma2), scale consistency.  Tcw = [Rcw | tcw] row-major 3x4 of
+ * the current (1) and the neighbour (2) keyframe; kp1 / kp2 = n x {x, y, octave} floats of the matched undistorted keypoints
+ * (matched_indices_ already applied); ratio_factor = 1.5f * scale_factor_.  ok[i] = 1 and x3D[i] valid for accepted matches. */
+int orbm_triangulate_matches(const double* Tcw1, const double* Tcw2, const float* K1, const float* K2, const float* kp1,
+                             const float* kp2, int n, const float* level_sigma2, const float* scale_factors, int n_levels,
+                             float ratio_factor, double* x3D, uint8_t* ok);
+
 /* ---- Frame::ComputeBoW: DBoW2 TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
  * (lib/DBoW2/DBoW2/TemplatedVocabulary.h:1124-1260), TF_IDF weighting + L1 norm as ORBVocabulary uses.  The tree is given
  * flattened, node 0 = root: node_desc[n_nodes][32], children of node i = children[child_off[i] .. child_off[i+1]) in their

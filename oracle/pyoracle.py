@@ -17,7 +17,7 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp", "sim3_oracle.cpp", "bow_oracle.cpp",
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp", "sim3_oracle.cpp", "bow_oracle.cpp", "tri_oracle.cpp",
                                              "orb_pattern_data.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -503,3 +503,22 @@ def bow_score_l1(w1, v1, w2, v2):
     L.orc_bow_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     w1 = np.ascontiguousarray(w1, np.uint32); w2 = np.ascontiguousarray(w2, np.uint32); v1 = _f64(v1); v2 = _f64(v2)
     return L.orc_bow_score_l1(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2))
+
+
+# --------------------------------- triangulation -----------------------------------
+def null_vector4(A):
+    A = _f64(A).reshape(16); x = np.zeros(4)
+    L = lib(); L.orc_null_vector4.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_null_vector4(_p(A), _p(x))
+    return x
+
+
+def triangulate_matches(T1, T2, K1, K2, kp1, kp2, level_sigma2, scale_factors, ratio_factor):
+    T1 = _f64(T1).reshape(12); T2 = _f64(T2).reshape(12)
+    K1 = np.ascontiguousarray(K1, np.float32); K2 = np.ascontiguousarray(K2, np.float32)
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 3); kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 3)
+    ls = np.ascontiguousarray(level_sigma2, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    n = len(kp1); X = np.zeros((n, 3)); ok = np.zeros(n, np.uint8)
+    L = lib(); L.orc_triangulate_matches.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_triangulate_matches(_p(T1), _p(T2), _p(K1), _p(K2), _p(kp1), _p(kp2), n, _p(ls), _p(sf), float(ratio_factor), _p(X), _p(ok))
+    return X, ok
