@@ -81,11 +81,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    # ORBHIP_BENCH_SHARED_GPU=1: dry run of the N > 1 code path on a box with ONE GPU (every rank uses device 0, gloo carries
+    # the collectives on host tensors); the real multi-GPU run is one rank per GPU over RCCL
+    shared = os.environ.get("ORBHIP_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if shared else dev          # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher, _lib
     _lib.check(_lib.load().orbhip_set_default_device(local_rank), "orbhip_set_default_device")
@@ -129,7 +138,7 @@ def main():
     ex.set_profiling(False)
     match_ms = sum(a.elapsed_time(b) for a, b in ev)
     from ceres_mono_orb_slam2_amd import sharding
-    dt = sharding.max_over_ranks(dt, device=dev)
+    dt = sharding.max_over_ranks(dt, device=cdev)
 
     # sanity of the timed work (not timed): every frame produced keypoints and matches
     c = counts.cpu().numpy(); nm = nmatch.cpu().numpy()
@@ -147,13 +156,13 @@ def main():
         except Exception as e:                       # never lose the headline line to the secondary leg
             localba, ok = {"error": repr(e)}, 0
         if world > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # collectives below only if EVERY rank's leg succeeded
             if int(flag.item()) == 1:
-                t = torch.tensor([localba["localba_solves_per_s"], localba["poseopt_solves_per_s"]], dtype=torch.float64, device=dev)
+                t = torch.tensor([localba["localba_solves_per_s"], localba["poseopt_solves_per_s"]], dtype=torch.float64, device=cdev)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 localba["localba_solves_per_s"], localba["poseopt_solves_per_s"] = float(t[0]), float(t[1])
-                pts = torch.from_numpy(localba["_final_points"]).to(dev)
+                pts = torch.from_numpy(localba["_final_points"]).to(cdev)
                 torch.cuda.synchronize(); tg = time.perf_counter()
                 allp, _, counts = sharding.allgather_landmarks(pts)
                 torch.cuda.synchronize()
