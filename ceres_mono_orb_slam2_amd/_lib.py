@@ -20,7 +20,7 @@ SYMBOLS = [
     "orbm_triangulate_matches",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log",
-    "ba_solve_batch", "ba_local_bundle_adjustment_batch",
+    "ba_solve_batch", "ba_local_bundle_adjustment_batch", "ba_optimize_essential_graph", "ba_essential_graph_correct",
 ]
 
 
@@ -122,6 +122,8 @@ def load():
         L.ba_optimize_sim3_batch_device.argtypes = [vp] * 11 + [i32, vp, vp, vp, vp]
         L.ba_sim3_exp.argtypes = [vp, vp]
         L.ba_sim3_log.argtypes = [vp, vp]
+        L.ba_optimize_essential_graph.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, vp, C.POINTER(BaSummary)]
+        L.ba_essential_graph_correct.argtypes = [vp, vp, i32, vp, vp, vp, i32]
         L.ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaOptions), vp]
         L.ba_local_bundle_adjustment_batch.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, vp]
     _lib = L

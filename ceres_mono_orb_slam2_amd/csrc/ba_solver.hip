@@ -1178,6 +1178,248 @@ __global__ void k_ba_user_stop(const BaDev* __restrict__ Dv) {
   if (!st->done) { st->termination = 4; st->done = 1; }
 }
 
+
+// ============================================================================ OptimizeEssentialGraph (pose graph over Sim(3))
+// CeresOptimizer::OptimizeEssentialGraph (src/CeresOptimizer.cc:737-957): vertices = Sim(3) tangents under
+// Sim3Parameterization, edges = EssentialGraphErrorTerm (include/CeresOptimizer.h:266-330).  The LM controller, the dense
+// Cholesky (k_chol_*) and the step logic (k_ba_iter_begin / k_ba_iter_end) are the bundle-adjustment ones, driven through a
+// BaDev "view" that only carries S / rhs / Dinv / npad / part / state; the kernels below are the graph-specific parts.
+struct PgDev {
+  int n, nf, n7, npad, ne, nblk, nparts;
+  double* x; double* cand; const int* col;                 // [n][7] tangents, reduced column of every vertex (-1 = constant)
+  const int* ej; const int* ei; const double* Sji;          // edges: vertex j, vertex i, measurement (qt7)
+  double* r; double* J;                                     // [ne][7], [ne][49] (J_i; J_j = -J_i)
+  double* g; double* scale;                                 // [n7] gradient (unscaled), Jacobi scaling
+  const int* v_off; const int* v_edge; const signed char* v_sign;   // per vertex: incident edges in insertion order, +1 = it is i, -1 = it is j
+  const int* blk_a; const int* blk_b; const int* blk_off; const int* blk_edge;    // off-diagonal blocks (col_a > col_b) and their edges
+  double* vpart;                                            // per vertex: |x|^2, gmax
+  double* S; double* rhs; double* part; BaState* st;
+};
+
+// residuals (+ Jacobians) of every edge: mode 0 at x, mode 1 cost only at the candidate
+__global__ __launch_bounds__(128) void k_pg_eval(PgDev P, int mode) {
+  __shared__ double s_red[4], s_out[1];
+  const BaState* st = P.st;
+  if (st->done) return;
+  if (mode == 0 && !st->need_eval) return;
+  if (mode == 1 && !st->valid) return;
+  const int e = blockIdx.x * 128 + threadIdx.x;
+  double acc = 0.0;
+  if (e < P.ne) {
+    const double* X = mode ? P.cand : P.x;
+    double r[7];
+    s3_graph_edge(X + 7 * (size_t)P.ej[e], X + 7 * (size_t)P.ei[e], P.Sji + 7 * (size_t)e, r, mode == 0 ? P.J + 49 * (size_t)e : nullptr);
+#pragma unroll
+    for (int k = 0; k < 7; k++) acc += 0.5 * r[k] * r[k];
+    if (mode == 0)
+#pragma unroll
+      for (int k = 0; k < 7; k++) P.r[7 * (size_t)e + k] = r[k];
+  }
+  // 128-thread block sum (2 waves)
+  double v = acc;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { s_out[0] = s_red[0] + s_red[1]; P.part[(mode ? 1 : 0) * P.nparts + blockIdx.x] = s_out[0]; }
+}
+
+// per free vertex (thread): gradient, (first time) Jacobi scale, |x|^2 and its gradient-max-norm term
+__global__ __launch_bounds__(128) void k_pg_vertex(PgDev P) {
+  const BaState* st = P.st;
+  if (st->done || !st->need_eval) return;
+  const int v = blockIdx.x * 128 + threadIdx.x;
+  if (v >= P.n) return;
+  const int c = P.col[v];
+  if (c < 0) { P.vpart[2 * v] = 0.0; P.vpart[2 * v + 1] = 0.0; return; }
+  double g[7] = {0, 0, 0, 0, 0, 0, 0}, n2[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int q = P.v_off[v]; q < P.v_off[v + 1]; q++) {
+    const int e = P.v_edge[q];
+    const double sgn = (double)P.v_sign[q];
+    const double* J = P.J + 49 * (size_t)e; const double* r = P.r + 7 * (size_t)e;
+    for (int a = 0; a < 7; a++) {
+      double s = 0, m = 0;
+      for (int k = 0; k < 7; k++) { s += J[k * 7 + a] * r[k]; m += J[k * 7 + a] * J[k * 7 + a]; }
+      g[a] += sgn * s; n2[a] += m;
+    }
+  }
+  double xn = 0, mg[7], xp[7], gmax = 0;
+  for (int a = 0; a < 7; a++) {
+    P.g[7 * c + a] = g[a];
+    if (st->first) P.scale[7 * c + a] = 1.0 / (1.0 + sqrt(n2[a]));
+    const double xv = P.x[7 * (size_t)v + a];
+    xn += xv * xv; mg[a] = -g[a];
+  }
+  s3_plus(P.x + 7 * (size_t)v, mg, xp);
+  for (int a = 0; a < 7; a++) gmax = fmax(gmax, fabs(P.x[7 * (size_t)v + a] - xp[a]));
+  P.vpart[2 * v] = xn; P.vpart[2 * v + 1] = gmax;
+}
+
+__global__ __launch_bounds__(256) void k_pg_after_eval(PgDev P) {
+  __shared__ double s_red[4 * 2], s_out[2], s_max[4];
+  BaState* st = P.st;
+  if (st->done || !st->need_eval) return;
+  const int tid = threadIdx.x;
+  double acc[2] = {0.0, 0.0};
+  double m = 0.0;
+  for (int b = tid; b < P.nparts; b += 256) acc[0] += P.part[b];
+  for (int v = tid; v < P.n; v += 256) { acc[1] += P.vpart[2 * v]; m = fmax(m, P.vpart[2 * v + 1]); }
+  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) s_max[tid >> 6] = m;
+  block_reduce<2>(acc, s_red, s_out);
+  if (tid == 0) {
+    st->x_cost = s_out[0]; st->x_norm = sqrt(s_out[1]);
+    st->gmax = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+    if (st->first) st->initial_cost = s_out[0];
+    st->first = 0; st->need_eval = 0;
+    if (st->gmax <= 1e-10) { st->termination = 1; st->done = 1; }
+  }
+}
+
+// scaled normal equations into the dense lower triangle: one 64-thread workgroup per diagonal block (free vertex) and per
+// off-diagonal block; every block sums its edges in list order (deterministic), element (u, v) per lane
+__global__ __launch_bounds__(64) void k_pg_build(PgDev P) {
+  const BaState* st = P.st;
+  if (st->done || !st->valid) return;
+  const int np = P.npad, tid = threadIdx.x;
+  const int u = tid / 7, w = tid - 7 * u;
+  if ((int)blockIdx.x < P.n) {                         // diagonal block + rhs of vertex v
+    const int v = blockIdx.x, c = P.col[v];
+    if (c < 0) return;
+    if (tid < 49) {
+      double acc = 0.0;
+      for (int q = P.v_off[v]; q < P.v_off[v + 1]; q++) {
+        const double* J = P.J + 49 * (size_t)P.v_edge[q];
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += J[k * 7 + u] * J[k * 7 + w];
+        acc += s;
+      }
+      double hs = acc * P.scale[7 * c + u] * P.scale[7 * c + w];
+      if (u == w) hs += fmin(fmax(hs, 1e-6), 1e32) / st->radius;
+      if (w <= u) P.S[(size_t)(7 * c + u) * np + 7 * c + w] = hs;
+    }
+    if (tid < 7) {
+      const double gs = P.g[7 * c + tid] * P.scale[7 * c + tid];
+      P.rhs[7 * c + tid] = gs;
+      P.S[(size_t)np * np + 7 * c + tid] = gs;           // augmented row: forward substitution rides the factorisation
+    }
+  } else {                                              // off-diagonal block (a, b), col_a > col_b:  - sum_e J_e^T J_e
+    const int blk = blockIdx.x - P.n;
+    if (blk >= P.nblk || tid >= 49) return;
+    const int ca = P.blk_a[blk], cb = P.blk_b[blk];
+    double acc = 0.0;
+    for (int q = P.blk_off[blk]; q < P.blk_off[blk + 1]; q++) {
+      const double* J = P.J + 49 * (size_t)P.blk_edge[q];
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) s += J[k * 7 + u] * J[k * 7 + w];
+      acc += s;
+    }
+    P.S[(size_t)(7 * ca + u) * np + 7 * cb + w] = -acc * P.scale[7 * ca + u] * P.scale[7 * cb + w];
+  }
+}
+
+// padding rows (identity) of the reduced system, written once per solve
+__global__ void k_pg_pad(PgDev P) {
+  const int np = P.npad, i = P.n7 + blockIdx.x;
+  if (i >= np) return;
+  for (int j = threadIdx.x; j < np; j += blockDim.x) P.S[(size_t)i * np + j] = (i == j) ? 1.0 : 0.0;
+  if (threadIdx.x == 0) { P.rhs[i] = 0.0; P.S[(size_t)np * np + i] = 0.0; }
+}
+
+// candidate x+ = Plus(x, -y * scale) per vertex, partial |dx|^2 -> part[2 * nparts + block]
+__global__ __launch_bounds__(128) void k_pg_step(PgDev P) {
+  __shared__ double s_red[2];
+  const BaState* st = P.st;
+  if (st->done || !st->valid) return;
+  const int v = blockIdx.x * 128 + threadIdx.x;
+  double acc = 0.0;
+  if (v < P.n) {
+    const int c = P.col[v];
+    const double* x = P.x + 7 * (size_t)v; double* xc = P.cand + 7 * (size_t)v;
+    if (c < 0 || st->chol_fail) { for (int k = 0; k < 7; k++) xc[k] = x[k]; }
+    else {
+      double d[7];
+      for (int k = 0; k < 7; k++) d[k] = (-P.rhs[7 * c + k]) * P.scale[7 * c + k];
+      s3_plus(x, d, xc);
+      for (int k = 0; k < 7; k++) { const double e = x[k] - xc[k]; acc += e * e; }
+    }
+  }
+  double vv = acc;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) vv += __shfl_xor(vv, o);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = vv;
+  __syncthreads();
+  if (threadIdx.x == 0) P.part[2 * P.nparts + blockIdx.x] = s_red[0] + s_red[1];
+}
+
+// model cost change -(J s).(r + J s / 2) per edge -> part[3 * nparts + block]; part[4 * nparts + block] = 0
+__global__ __launch_bounds__(128) void k_pg_mcc(PgDev P) {
+  __shared__ double s_red[2];
+  const BaState* st = P.st;
+  if (st->done || !st->valid) return;
+  const int e = blockIdx.x * 128 + threadIdx.x;
+  double acc = 0.0;
+  if (e < P.ne && !st->chol_fail) {
+    const int ci = P.col[P.ei[e]], cj = P.col[P.ej[e]];
+    double d[7];
+    for (int a = 0; a < 7; a++) {
+      double di = 0, dj = 0;
+      if (ci >= 0) di = (-P.rhs[7 * ci + a]) * P.scale[7 * ci + a];
+      if (cj >= 0) dj = (-P.rhs[7 * cj + a]) * P.scale[7 * cj + a];
+      d[a] = di - dj;
+    }
+    const double* J = P.J + 49 * (size_t)e; const double* r = P.r + 7 * (size_t)e;
+    for (int k = 0; k < 7; k++) {
+      double m = 0;
+      for (int a = 0; a < 7; a++) m += J[k * 7 + a] * d[a];
+      acc -= m * (r[k] + m / 2);
+    }
+  }
+  double vv = acc;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) vv += __shfl_xor(vv, o);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = vv;
+  __syncthreads();
+  if (threadIdx.x == 0) { P.part[3 * P.nparts + blockIdx.x] = s_red[0] + s_red[1]; P.part[4 * P.nparts + blockIdx.x] = 0.0; }
+}
+
+__global__ __launch_bounds__(256) void k_pg_apply(PgDev P) {
+  const BaState* st = P.st;
+  if (st->done || !st->accepted) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 7 * P.n) P.x[i] = P.cand[i];
+}
+
+// write-back arithmetic (src/CeresOptimizer.cc:916-956): Tiw = [R | t / s] per keyframe; P' = Swr_corrected * (Srw_original * P)
+__global__ __launch_bounds__(128) void k_pg_poses(const double* __restrict__ lie_opt, int n, double* __restrict__ Tiw) {
+  const int v = blockIdx.x * 128 + threadIdx.x;
+  if (v >= n) return;
+  double S[7];
+  s3_exp(lie_opt + 7 * (size_t)v, S);
+  const double s = S[0] * S[0] + S[1] * S[1] + S[2] * S[2] + S[3] * S[3];
+  const double inv = 1.0 / sqrt(s);
+  const double q[4] = {S[0] * inv, S[1] * inv, S[2] * inv, S[3] * inv};
+  double R[9];
+  quat_to_R(q, R);
+  const double inv_s = 1. / s;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tiw[12 * (size_t)v + 4 * i + j] = R[3 * i + j]; Tiw[12 * (size_t)v + 4 * i + 3] = inv_s * S[4 + i]; }
+}
+__global__ __launch_bounds__(256) void k_pg_points(const double* __restrict__ lie_orig, const double* __restrict__ lie_opt,
+                                                   const int* __restrict__ pt_ref, double* __restrict__ pts, int npts) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= npts) return;
+  const int rk = pt_ref[p];
+  double S0[7], S1[7], S1i[7], Pc[3], Pw[3];
+  s3_exp(lie_orig + 7 * (size_t)rk, S0);
+  s3_exp(lie_opt + 7 * (size_t)rk, S1);
+  s3_inverse(S1, S1i);
+  s3_act(S0, pts + 3 * (size_t)p, Pc);
+  s3_act(S1i, Pc, Pw);
+  pts[3 * (size_t)p] = Pw[0]; pts[3 * (size_t)p + 1] = Pw[1]; pts[3 * (size_t)p + 2] = Pw[2];
+}
+
 }  // namespace orbhip
 
 using namespace orbhip;
@@ -1508,6 +1750,140 @@ int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, in
 
 }  // namespace
 
+namespace {
+
+int pg_solve_impl(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* edge_j, const int32_t* edge_i, const double* edge_Sji, int ne,
+                  int max_iterations, const volatile uint8_t* stop, ba_summary* summary) {
+  ORBHIP_REQUIRE(lie7 && kf_fixed && n > 0 && ne >= 0 && max_iterations >= 0, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(ne == 0 || (edge_j && edge_i && edge_Sji), ORBHIP_EINVAL, "NULL edge arrays");
+  for (int e = 0; e < ne; e++)
+    ORBHIP_REQUIRE(edge_j[e] >= 0 && edge_j[e] < n && edge_i[e] >= 0 && edge_i[e] < n && edge_i[e] != edge_j[e], ORBHIP_EINVAL, "edge vertex out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+  if (int rcd = use_default_device()) return rcd;
+  std::vector<int> col(n, -1);
+  int nf = 0;
+  for (int v = 0; v < n; v++) if (!kf_fixed[v]) col[v] = nf++;
+  const int n7 = 7 * nf, npad = std::max(round_up(std::max(n7, 1), NB), NB);
+  if (npad > 16384) { set_error("essential graph with %d free keyframes exceeds the dense solver's capacity (2340)", nf); return ORBHIP_ECAP; }
+  // incident edge lists (insertion order) and off-diagonal block lists
+  std::vector<int> v_off(n + 1, 0), v_edge(2 * (size_t)ne); std::vector<signed char> v_sign(2 * (size_t)ne);
+  for (int e = 0; e < ne; e++) { v_off[edge_i[e] + 1]++; v_off[edge_j[e] + 1]++; }
+  for (int v = 0; v < n; v++) v_off[v + 1] += v_off[v];
+  { std::vector<int> fill(v_off.begin(), v_off.end() - 1);
+    for (int e = 0; e < ne; e++) { int q = fill[edge_i[e]]++; v_edge[q] = e; v_sign[q] = 1; q = fill[edge_j[e]]++; v_edge[q] = e; v_sign[q] = -1; } }
+  std::vector<std::pair<long long, int>> keyed;
+  for (int e = 0; e < ne; e++) {
+    const int ci = col[edge_i[e]], cj = col[edge_j[e]];
+    if (ci < 0 || cj < 0) continue;
+    const int a = std::max(ci, cj), b = std::min(ci, cj);
+    keyed.push_back({(long long)a * nf + b, e});
+  }
+  std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<long long, int>& x, const std::pair<long long, int>& y) { return x.first < y.first; });
+  std::vector<int> blk_a, blk_b, blk_off(1, 0), blk_edge;
+  for (size_t k = 0; k < keyed.size(); k++) {
+    if (k == 0 || keyed[k].first != keyed[k - 1].first) {
+      if (k) blk_off.push_back((int)blk_edge.size());
+      blk_a.push_back((int)(keyed[k].first / nf)); blk_b.push_back((int)(keyed[k].first % nf));
+    }
+    blk_edge.push_back(keyed[k].second);
+  }
+  if (!keyed.empty()) blk_off.push_back((int)blk_edge.size());
+  const int nblk = (int)blk_a.size();
+  const int nb_e = std::max((ne + 127) / 128, 1), nb_v = (n + 127) / 128;
+  const int nparts = std::max(std::max(nb_e, nb_v), std::max((ne + BA_TPB - 1) / BA_TPB, (n + BA_TPB - 1) / BA_TPB));
+
+  hipStream_t s = thread_stream();
+  HostBA H; int rc = 0;
+  PgDev P; std::memset(&P, 0, sizeof(P));
+  P.n = n; P.nf = nf; P.n7 = n7; P.npad = npad; P.ne = ne; P.nblk = nblk; P.nparts = nparts;
+  P.x = H.upload(lie7, 7 * (size_t)n, &rc, s); P.cand = H.alloc<double>(7 * (size_t)n, &rc); P.col = H.upload(col.data(), n, &rc, s);
+  P.ej = H.upload(edge_j, ne, &rc, s); P.ei = H.upload(edge_i, ne, &rc, s); P.Sji = H.upload(edge_Sji, 7 * (size_t)ne, &rc, s);
+  P.r = H.alloc<double>(7 * (size_t)std::max(ne, 1), &rc); P.J = H.alloc<double>(49 * (size_t)std::max(ne, 1), &rc);
+  P.g = H.alloc<double>(std::max(n7, 1), &rc); P.scale = H.alloc<double>(std::max(n7, 1), &rc);
+  P.v_off = H.upload(v_off.data(), n + 1, &rc, s); P.v_edge = H.upload(v_edge.data(), v_edge.size(), &rc, s); P.v_sign = H.upload(v_sign.data(), v_sign.size(), &rc, s);
+  P.blk_a = H.upload(blk_a.data(), nblk, &rc, s); P.blk_b = H.upload(blk_b.data(), nblk, &rc, s); P.blk_off = H.upload(blk_off.data(), blk_off.size(), &rc, s);
+  P.blk_edge = H.upload(blk_edge.data(), blk_edge.size(), &rc, s);
+  P.vpart = H.alloc<double>(2 * (size_t)n, &rc);
+  P.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); P.rhs = H.alloc<double>(npad, &rc);
+  double* Dinv = H.alloc<double>((size_t)npad * NB, &rc);
+  P.part = H.alloc<double>(5 * (size_t)nparts, &rc);
+  P.st = H.alloc<BaState>(1, &rc);
+  if (rc) return rc;
+  // the view through which the shared Cholesky / controller kernels see this problem (sizes chosen so that k_ba_iter_end
+  // sums exactly the partial slots written above: candidate cost and model change per 256 edges ... see nparts)
+  BaDev F; std::memset(&F, 0, sizeof(F));
+  F.npad = npad; F.n6 = n7; F.nparts = nparts; F.S = P.S; F.rhs = P.rhs; F.Dinv = Dinv; F.part = P.part; F.st = P.st;
+  F.nobs = nb_e * BA_TPB; F.npts = nb_e * BA_TPB; F.ncam = nb_v * BA_TPB;     // -> nb_obs = nb_pt = nb_e blocks, nb_cam = nb_v blocks
+  const BaDev* Fv = H.upload(&F, 1, &rc, s);
+  if (rc) return rc;
+  BaState st0; std::memset(&st0, 0, sizeof(st0));
+  st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = max_iterations;
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(P.st, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
+  ORBHIP_CHECK_HIP(hipMemsetAsync(P.rhs, 0, (size_t)npad * sizeof(double), s));
+  ORBHIP_CHECK_HIP(hipMemsetAsync(P.part, 0, 5 * (size_t)nparts * sizeof(double), s));
+  if (npad > n7) hipLaunchKernelGGL(k_pg_pad, dim3(npad - n7), dim3(64), 0, s, P);
+  auto enqueue_eval = [&]() {
+    hipLaunchKernelGGL(k_pg_eval, dim3(nb_e), dim3(128), 0, s, P, 0);
+    hipLaunchKernelGGL(k_pg_vertex, dim3(nb_v), dim3(128), 0, s, P);
+    hipLaunchKernelGGL(k_pg_after_eval, dim3(1), dim3(256), 0, s, P);
+  };
+  enqueue_eval();
+  bool user_stop = stop && *stop;
+  for (int it = 0; it < max_iterations + 1 && !user_stop && n7 > 0; it++) {
+    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, 1), dim3(1), 0, s, Fv);
+    hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)(((size_t)n7 * npad + 255) / 256)), 1), dim3(256), 0, s, Fv);
+    hipLaunchKernelGGL(k_pg_build, dim3(n + nblk), dim3(64), 0, s, P);
+    auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
+      if (c_hi <= c_lo || r_lo >= npad + 1) return;
+      const int tiles_r = (npad - r_lo + 63) / 64, tiles_c = (c_hi - c_lo + 63) / 64;
+      const int ntiles = std::max(tiles_r, 0) * tiles_c;
+      const int nrhs = (c_hi - c_lo + 255) / 256;
+      hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs, 1), dim3(256), 0, s, Fv, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles);
+    };
+    const int OB = 128;
+    for (int k0 = 0; k0 < npad; k0 += OB) {
+      const int kend = std::min(k0 + OB, npad);
+      for (int k = k0; k < kend; k += NB) {
+        const int rows_below = npad - k - NB;
+        hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 1 + 63) / 64, 1), dim3(256), 0, s, Fv, k);
+        if (k + NB < kend) launch_update(k, NB, k + NB, k + NB, kend, k0 + OB);
+      }
+      if (kend < npad) launch_update(k0, kend - k0, kend, kend, npad, INT_MAX);
+    }
+    for (int kb = ((npad - 1) / SBLK) * SBLK; kb >= 0; kb -= SBLK) {
+      hipLaunchKernelGGL(k_chol_bsolve_diag, dim3(1, 1), dim3(256), 0, s, Fv, kb);
+      if (kb > 0) hipLaunchKernelGGL(k_chol_bsolve_update, dim3((kb + 63) / 64, 1), dim3(256), 0, s, Fv, kb);
+    }
+    hipLaunchKernelGGL(k_pg_step, dim3(nb_v), dim3(128), 0, s, P);
+    hipLaunchKernelGGL(k_pg_mcc, dim3(nb_e), dim3(128), 0, s, P);
+    hipLaunchKernelGGL(k_pg_eval, dim3(nb_e), dim3(128), 0, s, P, 1);
+    hipLaunchKernelGGL(k_ba_iter_end, dim3(1, 1), dim3(BA_TPB), 0, s, Fv);
+    hipLaunchKernelGGL(k_pg_apply, dim3((7 * n + 255) / 256), dim3(256), 0, s, P);
+    enqueue_eval();
+    if (stop && *stop) user_stop = true;
+    if ((it & 3) == 3) {                                       // converged early? (pose graphs usually need ~10 of the 100 iterations)
+      BaState cur;
+      ORBHIP_CHECK_HIP(hipMemcpyAsync(&cur, P.st, sizeof(cur), hipMemcpyDeviceToHost, s));
+      ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+      if (cur.done) break;
+    }
+  }
+  if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1, 1), dim3(1), 0, s, Fv);
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  BaState fin;
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(&fin, P.st, sizeof(fin), hipMemcpyDeviceToHost, s));
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(lie7, P.x, 7 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+  if (summary) {
+    summary->initial_cost = fin.initial_cost; summary->final_cost = fin.x_cost; summary->iterations = fin.iteration;
+    summary->successful_steps = fin.successful_steps; summary->termination = fin.termination; summary->final_radius = fin.radius;
+  }
+  return 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int ba_check_outlier(const double* K4, const double* pose7, const double* Xw, const double* uv, double inv_sigma2,
@@ -1693,6 +2069,32 @@ int ba_local_bundle_adjustment(const double* K4, double* poses7, const uint8_t* 
   ORBHIP_REQUIRE(K4 && poses7 && cam_fixed && cam_local && obs_erase && aborted && ncam > 0 && nobs >= 0, ORBHIP_EINVAL, "NULL argument");
   ba_local_problem L{K4, poses7, cam_fixed, cam_local, ncam, pts3, npts, obs_cam, obs_pt, obs_uv, obs_inv_sigma2, nobs, obs_erase};
   return ba_local_bundle_adjustment_batch(&L, 1, stop_flag, duplicate_blocks, aborted, pass1, pass2);
+}
+
+int ba_optimize_essential_graph(double* lie7, const uint8_t* kf_fixed, int n_kf, const int32_t* edge_j, const int32_t* edge_i,
+                                const double* edge_Sji, int n_edges, int max_iterations, const volatile uint8_t* stop_flag, ba_summary* summary) {
+  return pg_solve_impl(lie7, kf_fixed, n_kf, edge_j, edge_i, edge_Sji, n_edges, max_iterations, stop_flag, summary);
+}
+
+int ba_essential_graph_correct(const double* lie7_orig, const double* lie7_opt, int n_kf, double* Tiw, const int32_t* pt_ref_kf, double* pts3, int npts) {
+  ORBHIP_REQUIRE(lie7_orig && lie7_opt && n_kf > 0 && Tiw && npts >= 0 && (npts == 0 || (pt_ref_kf && pts3)), ORBHIP_EINVAL, "NULL argument");
+  for (int p = 0; p < npts; p++) ORBHIP_REQUIRE(pt_ref_kf[p] >= 0 && pt_ref_kf[p] < n_kf, ORBHIP_EINVAL, "reference keyframe out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+  if (int rcd = use_default_device()) return rcd;
+  hipStream_t s = thread_stream();
+  HostBA H; int rc = 0;
+  const double* d0 = H.upload(lie7_orig, 7 * (size_t)n_kf, &rc, s); const double* d1 = H.upload(lie7_opt, 7 * (size_t)n_kf, &rc, s);
+  double* dT = H.alloc<double>(12 * (size_t)n_kf, &rc);
+  const int* dref = H.upload(pt_ref_kf, npts, &rc, s); double* dp = H.upload(pts3, 3 * (size_t)npts, &rc, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pg_poses, dim3((n_kf + 127) / 128), dim3(128), 0, s, d1, n_kf, dT);
+  if (npts) hipLaunchKernelGGL(k_pg_points, dim3((npts + 255) / 256), dim3(256), 0, s, d0, d1, dref, dp, npts);
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(Tiw, dT, 12 * (size_t)n_kf * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (npts) ORBHIP_CHECK_HIP(hipMemcpyAsync(pts3, dp, 3 * (size_t)npts * sizeof(double), hipMemcpyDeviceToHost, s));
+  ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
 }
 
 int ba_solve_batch(const ba_problem* problems, int nproblems, const ba_options* opts, ba_summary* summaries) {

@@ -219,4 +219,64 @@ S3_HD int s3_check_outlier(const double* K4, const double* S, const double* P, d
   return ((eu * eu + ev * ev) * (double)inv_sigma > thres) ? 1 : 0;
 }
 
+
+// ---- pieces of the essential-graph error term (include/CeresOptimizer.h:266-330) --------------------------------------
+// Sophus::Sim3d::Adj(): [[s R, [t]x R, -t], [0, R, 0], [0, 0, 1]]  (7x7 row-major)
+S3_HD void s3_adj(const double* S, double* A) {
+  const double scale = S[0] * S[0] + S[1] * S[1] + S[2] * S[2] + S[3] * S[3];
+  const double inv = 1.0 / sqrt(scale);
+  const double x = S[0] * inv, y = S[1] * inv, z = S[2] * inv, w = S[3] * inv;
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x,
+               txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+  const double T[3][3] = {{0, -S[6], S[5]}, {S[6], 0, -S[4]}, {-S[5], S[4], 0}};
+#pragma unroll
+  for (int k = 0; k < 49; k++) A[k] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      A[i * 7 + j] = scale * R[i][j];
+      A[i * 7 + 3 + j] = T[i][0] * R[0][j] + T[i][1] * R[1][j] + T[i][2] * R[2][j];
+      A[(3 + i) * 7 + 3 + j] = R[i][j];
+    }
+  A[6] = -S[4]; A[13] = -S[5]; A[20] = -S[6];
+  A[48] = 1.0;
+}
+
+// residual r = log(Sji * exp(lie_i) * exp(lie_j)^-1) and, if Ji != NULL, J_i = (I + ad/2 + ad^2/12) * Adj(exp(lie_j)); J_j = -J_i
+S3_HD void s3_graph_edge(const double* lie_j, const double* lie_i, const double* Sji, double* r, double* Ji) {
+  double Si[7], Sj[7], Sjinv[7], T1[7], E[7];
+  s3_exp(lie_i, Si); s3_exp(lie_j, Sj);
+  s3_inverse(Sj, Sjinv);
+  s3_mul(Sji, Si, T1);
+  s3_mul(T1, Sjinv, E);
+  s3_log(E, r);
+  if (!Ji) return;
+  double ad[49];
+#pragma unroll
+  for (int k = 0; k < 49; k++) ad[k] = 0.0;
+  const double ux = r[0], uy = r[1], uz = r[2], wx = r[3], wy = r[4], wz = r[5], sg = r[6];
+  const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}}, U[3][3] = {{0, -uz, uy}, {uz, 0, -ux}, {-uy, ux, 0}};
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { ad[i * 7 + j] = W[i][j] + (i == j ? sg : 0.0); ad[i * 7 + 3 + j] = U[i][j]; ad[(3 + i) * 7 + 3 + j] = W[i][j]; }
+  ad[6] = -ux; ad[13] = -uy; ad[20] = -uz;
+  double Jr[49], Adj[49];
+  for (int i = 0; i < 7; i++)
+    for (int j = 0; j < 7; j++) {
+      double s2 = 0;
+      for (int k = 0; k < 7; k++) s2 += ad[i * 7 + k] * ad[k * 7 + j];
+      Jr[i * 7 + j] = (i == j ? 1.0 : 0.0) + 0.5 * ad[i * 7 + j] + 1.0 / 12. * s2;
+    }
+  s3_adj(Sj, Adj);
+  for (int i = 0; i < 7; i++)
+    for (int j = 0; j < 7; j++) {
+      double s2 = 0;
+      for (int k = 0; k < 7; k++) s2 += Jr[i * 7 + k] * Adj[k * 7 + j];
+      Ji[i * 7 + j] = s2;
+    }
+}
+
 }  // namespace orbhip

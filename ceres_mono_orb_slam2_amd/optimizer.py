@@ -204,3 +204,26 @@ def local_bundle_adjustment_batch(problems, stop_flag=None, duplicate_blocks=Tru
                                                   int(duplicate_blocks), C.byref(ab), C.cast(s1, C.c_void_p), C.cast(s2, C.c_void_p)),
                "ba_local_bundle_adjustment_batch")
     return ab.value, [(k[1], k[4], k[9][:len(k[5])], s1[q].as_dict(), s2[q].as_dict()) for q, k in enumerate(keep)]
+
+
+def optimize_essential_graph(lie7, kf_fixed, edge_j, edge_i, edge_Sji, max_iterations=100, stop_flag=None):
+    """CeresOptimizer::OptimizeEssentialGraph, the solve (src/CeresOptimizer.cc:737-914) on flattened vertices / edges.
+    lie7 = Scw.log() per keyframe; edges (j, i, Sji qt7) in the reference's insertion order.  Returns (lie7, summary)."""
+    L = _lib.load()
+    x = _f64(lie7).reshape(-1, 7).copy(); fx = np.ascontiguousarray(kf_fixed, np.uint8)
+    ej = np.ascontiguousarray(edge_j, np.int32); ei = np.ascontiguousarray(edge_i, np.int32); S = _f64(edge_Sji).reshape(-1, 7)
+    s = _lib.BaSummary()
+    _lib.check(L.ba_optimize_essential_graph(_lib.ptr(x), _lib.ptr(fx), len(x), _lib.ptr(ej), _lib.ptr(ei), _lib.ptr(S), len(ej),
+                                             int(max_iterations), _lib.ptr(stop_flag) if stop_flag is not None else None, C.byref(s)),
+               "ba_optimize_essential_graph")
+    return x, s.as_dict()
+
+
+def essential_graph_correct(lie7_orig, lie7_opt, pt_ref_kf, pts3):
+    """Write-back arithmetic of OptimizeEssentialGraph (:916-956).  Returns (Tiw [n, 3, 4], corrected points)."""
+    L = _lib.load()
+    a = _f64(lie7_orig).reshape(-1, 7); b = _f64(lie7_opt).reshape(-1, 7); n = len(a)
+    T = np.zeros((n, 12)); pr = np.ascontiguousarray(pt_ref_kf, np.int32); P = _f64(pts3).reshape(-1, 3).copy()
+    _lib.check(L.ba_essential_graph_correct(_lib.ptr(a), _lib.ptr(b), n, _lib.ptr(T), _lib.ptr(pr), _lib.ptr(P), len(P)),
+               "ba_essential_graph_correct")
+    return T.reshape(n, 3, 4), P

@@ -291,3 +291,39 @@ def make_vocabulary(seed, k=10, L=4, flip=40, ragged=0.0, stop_frac=0.02):
     wts = rng.uniform(0.5, 9.0, len(leaves)); wts[rng.random(len(leaves)) < stop_frac] = 0.0
     weight[leaves] = wts
     return dict(node_desc=node_desc, child_off=child_off, children=children, word_id=word_id, weight=weight, L=L, k=k)
+
+
+def _sim3_qt(s, q, t):
+    return np.concatenate([np.sqrt(s) * np.asarray(q, np.float64), np.asarray(t, np.float64)])
+
+
+def make_essential_graph(seed, n=200, drift=0.002, n_corrected=6, extra_every=5):
+    """Loop-closure pose graph for OptimizeEssentialGraph: n keyframes on a closed loop; the estimated Scw drift in scale and
+    position along the trajectory; the last n_corrected keyframes (the current keyframe and its neighbours) start from their
+    loop-corrected Sim(3) as LoopClosing::CorrectLoop leaves them; vertex 0 (the loop keyframe) is constant.  Edges in the
+    reference's insertion order: the loop connection first, then per keyframe its spanning-tree parent and a few older
+    covisibility neighbours, each with Sji = Sjw * Swi from the NON-corrected estimates (src/CeresOptimizer.cc:821-905).
+    Returns tangents (via the caller's sim3_log), qt7 arrays and the edge lists."""
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    true = []; est = []
+    scale = 1.0; pos_drift = np.zeros(3)
+    for k in range(n):
+        q = quat_from_rotvec([0, -ang[k], 0]); R = quat_to_R(q)
+        Cw = np.array([30 * np.cos(ang[k]), 0.2 * np.sin(3 * ang[k]), 30 * np.sin(ang[k])])
+        t = -R @ Cw
+        true.append((1.0, q, t))
+        scale *= 1.0 + drift * (1 + 0.3 * rng.normal()); pos_drift = pos_drift + rng.normal(0, 0.01, 3)
+        qe = quat_mul(quat_from_rotvec(rng.normal(0, 0.002, 3)), q)
+        est.append((1.0 / scale, qe, (t + pos_drift) / scale))     # a map whose scale shrinks along the way
+    est[0] = true[0]
+    S_true = np.stack([_sim3_qt(*x) for x in true]); S_est = np.stack([_sim3_qt(*x) for x in est])
+    init = S_est.copy()
+    init[n - n_corrected:] = S_true[n - n_corrected:]              # corrected Sim3 of the current keyframe's neighbourhood
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    edges = [(0, n - 1, "corr")]                                    # (j, i): the loop connection, from the corrected values
+    for i in range(1, n):
+        edges.append((i - 1, i, "est"))
+        if i % extra_every == 0 and i >= 3:
+            edges.append((i - 3, i, "est"))
+    return dict(S_true=S_true, S_est=S_est, S_init=init, fixed=fixed, edges=edges)

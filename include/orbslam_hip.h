@@ -323,6 +323,21 @@ int ba_optimize_sim3_batch_device(const double* d_K1, const double* d_K2, double
                                   const double* d_th2, int nproblems, uint8_t* d_outlier, int32_t* d_n_inliers,
                                   ba_summary* d_summary, void* stream);
 
+/* CeresOptimizer::OptimizeEssentialGraph (src/CeresOptimizer.cc:737-957), the solve: n_kf Sim(3) vertices given as tangent
+ * 7-vectors (Scw.log(), in/out), kf_fixed[v] != 0 for the constant loop keyframe, n_edges EssentialGraphErrorTerm blocks
+ * (include/CeresOptimizer.h:266-330) as (vertex j, vertex i, Sji in the qt7 layout) in the reference's insertion order
+ * (loop connections :797-821, then per keyframe its parent :839-852, loop edges :855-874 and covisibility edges :877-905;
+ * the caller forms Sji = Sjw * Swi from the corrected / non-corrected Sim3 exactly as there).  Identity information, no
+ * loss, Sim3Parameterization, <= max_iterations (100 in the reference) LM iterations; the normal equations are solved with
+ * the dense FP64-MFMA Cholesky (up to 2340 free keyframes, ORBHIP_ECAP beyond).                                              */
+int ba_optimize_essential_graph(double* lie7, const uint8_t* kf_fixed, int n_kf, const int32_t* edge_j, const int32_t* edge_i,
+                                const double* edge_Sji, int n_edges, int max_iterations, const volatile uint8_t* stop_flag,
+                                ba_summary* summary);
+/* its write-back arithmetic (:916-956): Tiw[v] = [R | t / s] (row-major 3x4) of exp(lie7_opt[v]); every map point
+ * P <- corrected_Swr * (Srw_original * P) with r = pt_ref_kf[p].                                                            */
+int ba_essential_graph_correct(const double* lie7_orig, const double* lie7_opt, int n_kf, double* Tiw /*[n_kf*12]*/,
+                               const int32_t* pt_ref_kf, double* pts3, int npts);
+
 /* Sophus::Sim3d::exp / log in the layout above (tangent = [upsilon, omega, sigma]); host arithmetic, for bindings that
  * cross the Sophus boundary (LoopClosing builds gScm from (s, R, t): src/LoopClosing.cc:322).                           */
 int ba_sim3_exp(const double* tangent7, double* s12_out);

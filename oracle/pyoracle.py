@@ -522,3 +522,37 @@ def triangulate_matches(T1, T2, K1, K2, kp1, kp2, level_sigma2, scale_factors, r
     L = lib(); L.orc_triangulate_matches.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     L.orc_triangulate_matches(_p(T1), _p(T2), _p(K1), _p(K2), _p(kp1), _p(kp2), n, _p(ls), _p(sf), float(ratio_factor), _p(X), _p(ok))
     return X, ok
+
+
+# --------------------------------- essential graph ---------------------------------
+def sim3_adj(S):
+    S = _f64(S); A = np.zeros((7, 7)); L = lib(); L.orc_sim3_adj.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_sim3_adj(_p(S), _p(A)); return A
+
+
+def sim3_mul(a, b):
+    a = _f64(a); b = _f64(b); o = np.zeros(7); L = lib(); L.orc_sim3_mul.argtypes = [C.c_void_p] * 3
+    L.orc_sim3_mul(_p(a), _p(b), _p(o)); return o
+
+
+def eg_eval_edge(lie_j, lie_i, Sji):
+    lj = _f64(lie_j); li = _f64(lie_i); S = _f64(Sji); r = np.zeros(7); J = np.zeros((7, 7))
+    L = lib(); L.orc_eg_eval_edge.argtypes = [C.c_void_p] * 5
+    L.orc_eg_eval_edge(_p(lj), _p(li), _p(S), _p(r), _p(J)); return r, J
+
+
+def optimize_essential_graph(lie7, kf_fixed, edge_j, edge_i, edge_Sji, max_iters=100):
+    x = _f64(lie7).reshape(-1, 7).copy(); fx = np.ascontiguousarray(kf_fixed, np.uint8)
+    ej = np.ascontiguousarray(edge_j, np.int32); ei = np.ascontiguousarray(edge_i, np.int32); S = _f64(edge_Sji).reshape(-1, 7)
+    s = BaSummary(); L = lib()
+    L.orc_optimize_essential_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.orc_optimize_essential_graph(_p(x), _p(fx), len(x), _p(ej), _p(ei), _p(S), len(ej), int(max_iters), C.byref(s))
+    return x, s.as_dict()
+
+
+def essential_graph_correct(lie_orig, lie_opt, pt_ref, pts):
+    a = _f64(lie_orig).reshape(-1, 7); b = _f64(lie_opt).reshape(-1, 7); n = len(a)
+    T = np.zeros((n, 12)); pr = np.ascontiguousarray(pt_ref, np.int32); P = _f64(pts).reshape(-1, 3).copy()
+    L = lib(); L.orc_essential_graph_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_essential_graph_correct(_p(a), _p(b), n, _p(T), _p(pr), _p(P), len(P))
+    return T, P

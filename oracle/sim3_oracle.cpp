@@ -441,3 +441,252 @@ int orc_optimize_sim3(const double* K1, const double* K2, double* s12, const dou
 }
 
 }  // extern "C"
+
+// ============================================================================ OptimizeEssentialGraph (second half)
+// CeresOptimizer::OptimizeEssentialGraph, the solve and the write-back arithmetic (src/CeresOptimizer.cc:737-957) with
+// EssentialGraphErrorTerm (include/CeresOptimizer.h:266-330): vertices = Sim(3) tangent 7-vectors (Scw.log()) under
+// Sim3Parameterization::Plus, the loop keyframe constant; every edge (j, i, Sji) contributes the 7-vector residual
+// log(Sji * Si * Sj^-1) (identity information, no loss) with Jacobians J_i = Jr * Adj(Sj), J_j = -J_i where
+// Jr = I + ad/2 + ad^2/12 of the residual.  Ceres 1.14 LM with default options; the normal equations are solved densely
+// (SPARSE_NORMAL_CHOLESKY is the same solve up to rounding).  Sophus::Sim3d::Adj() restated: [[sR, [t]x R, -t], [0, R, 0],
+// [0, 0, 1]] - pinned against expm in tests/test_oracle_essential_graph.py.
+#include <vector>
+namespace {
+
+void sim3_adj(const Sim3& S, double A[49]) {
+  const double scale = qn2(S.q);
+  const M3 R = rot_matrix(S.q);
+  const M3 T = hat(S.t);
+  const M3 TR = matmul(T, R);
+  for (int k = 0; k < 49; k++) A[k] = 0.0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { A[i * 7 + j] = scale * R.m[i][j]; A[i * 7 + 3 + j] = TR.m[i][j]; A[(3 + i) * 7 + 3 + j] = R.m[i][j]; }
+  A[0 * 7 + 6] = -S.t.x; A[1 * 7 + 6] = -S.t.y; A[2 * 7 + 6] = -S.t.z;
+  A[48] = 1.0;
+}
+
+// residual (7) and J_i (7x7 row-major); J_j = -J_i
+void eg_eval_edge(const double* lie_j, const double* lie_i, const Sim3& Sji, double* r, double* Ji) {
+  const Sim3 Si = sim3_exp(lie_i), Sj = sim3_exp(lie_j);
+  const Sim3 E = sim3_mul(sim3_mul(Sji, Si), sim3_inv(Sj));
+  sim3_log(E, r);
+  if (!Ji) return;
+  double ad[49];
+  for (int k = 0; k < 49; k++) ad[k] = 0.0;
+  const double ux = r[0], uy = r[1], uz = r[2], wx = r[3], wy = r[4], wz = r[5], sg = r[6];
+  // block(0,0) = hat(omega) + sigma I ; block(0,3) = hat(upsilon) ; block(0,6) = -upsilon ; block(3,3) = hat(omega)
+  const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}}, U[3][3] = {{0, -uz, uy}, {uz, 0, -ux}, {-uy, ux, 0}};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { ad[i * 7 + j] = W[i][j] + (i == j ? sg : 0.0); ad[i * 7 + 3 + j] = U[i][j]; ad[(3 + i) * 7 + 3 + j] = W[i][j]; }
+  ad[0 * 7 + 6] = -ux; ad[1 * 7 + 6] = -uy; ad[2 * 7 + 6] = -uz;
+  double ad2[49], Jr[49], Adj[49];
+  for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) { double s = 0; for (int k = 0; k < 7; k++) s += ad[i * 7 + k] * ad[k * 7 + j]; ad2[i * 7 + j] = s; }
+  for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) Jr[i * 7 + j] = (i == j ? 1.0 : 0.0) + 0.5 * ad[i * 7 + j] + 1.0 / 12. * ad2[i * 7 + j];
+  sim3_adj(Sj, Adj);
+  for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) { double s = 0; for (int k = 0; k < 7; k++) s += Jr[i * 7 + k] * Adj[k * 7 + j]; Ji[i * 7 + j] = s; }
+}
+
+bool dense_chol(std::vector<double>& A, int n) {
+  for (int j = 0; j < n; j++) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    d = std::sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = s / d;
+    }
+  }
+  return true;
+}
+void dense_chol_solve(const std::vector<double>& L, int n, std::vector<double>& b) {
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[(size_t)i * n + k] * b[k]; b[i] = s / L[(size_t)i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= L[(size_t)k * n + i] * b[k]; b[i] = s / L[(size_t)i * n + i]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_sim3_adj(const double* qt7, double* A49) {
+  Sim3 S{{qt7[0], qt7[1], qt7[2], qt7[3]}, {qt7[4], qt7[5], qt7[6]}};
+  sim3_adj(S, A49);
+}
+void orc_sim3_mul(const double* a, const double* b, double* out) {
+  Sim3 A{{a[0], a[1], a[2], a[3]}, {a[4], a[5], a[6]}}, B{{b[0], b[1], b[2], b[3]}, {b[4], b[5], b[6]}};
+  Sim3 C = sim3_mul(A, B);
+  out[0] = C.q.x; out[1] = C.q.y; out[2] = C.q.z; out[3] = C.q.w; out[4] = C.t.x; out[5] = C.t.y; out[6] = C.t.z;
+}
+void orc_eg_eval_edge(const double* lie_j, const double* lie_i, const double* Sji_qt7, double* r, double* Ji) {
+  Sim3 S{{Sji_qt7[0], Sji_qt7[1], Sji_qt7[2], Sji_qt7[3]}, {Sji_qt7[4], Sji_qt7[5], Sji_qt7[6]}};
+  eg_eval_edge(lie_j, lie_i, S, r, Ji);
+}
+
+// the solve: lie7 [n*7] in/out; kf_fixed[n]; edges (edge_j[e], edge_i[e], Sji qt7) in insertion order
+int orc_optimize_essential_graph(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* edge_j, const int32_t* edge_i,
+                                 const double* edge_Sji, int ne, int max_iters, orc_sim3_summary* sum) {
+  std::vector<int> col(n, -1);
+  int nf = 0;
+  for (int v = 0; v < n; v++) if (!kf_fixed[v]) col[v] = nf++;
+  const int nc = 7 * nf;
+  std::vector<Sim3> Sji(ne);
+  for (int e = 0; e < ne; e++) Sji[e] = Sim3{{edge_Sji[7 * e], edge_Sji[7 * e + 1], edge_Sji[7 * e + 2], edge_Sji[7 * e + 3]}, {edge_Sji[7 * e + 4], edge_Sji[7 * e + 5], edge_Sji[7 * e + 6]}};
+  std::vector<double> r(7 * (size_t)ne), J(49 * (size_t)ne), g(nc), scale(nc, 1.0), H, step(nc), cand(lie7, lie7 + 7 * (size_t)n);
+  orc_sim3_summary S{};
+  double radius = 1e4, dec = 2.0, x_cost = 0, x_norm = 0;
+  int iteration = 0, invalid = 0;
+  auto cost_at = [&](const double* x) {
+    double c = 0, rr[7];
+    for (int e = 0; e < ne; e++) { eg_eval_edge(x + 7 * edge_j[e], x + 7 * edge_i[e], Sji[e], rr, nullptr); for (int k = 0; k < 7; k++) c += 0.5 * rr[k] * rr[k]; }
+    return c;
+  };
+  auto evaluate = [&](bool first) -> double {
+    x_cost = 0;
+    std::fill(g.begin(), g.end(), 0.0);
+    for (int e = 0; e < ne; e++) {
+      double* re = &r[7 * (size_t)e]; double* Je = &J[49 * (size_t)e];
+      eg_eval_edge(lie7 + 7 * edge_j[e], lie7 + 7 * edge_i[e], Sji[e], re, Je);
+      for (int k = 0; k < 7; k++) x_cost += 0.5 * re[k] * re[k];
+      const int ci = col[edge_i[e]], cj = col[edge_j[e]];
+      for (int a = 0; a < 7; a++) {
+        double s = 0;
+        for (int k = 0; k < 7; k++) s += Je[k * 7 + a] * re[k];
+        if (ci >= 0) g[7 * ci + a] += s;
+        if (cj >= 0) g[7 * cj + a] -= s;
+      }
+    }
+    if (first) {
+      std::vector<double> n2(nc, 0.0);
+      for (int e = 0; e < ne; e++) {
+        const double* Je = &J[49 * (size_t)e];
+        const int ci = col[edge_i[e]], cj = col[edge_j[e]];
+        for (int a = 0; a < 7; a++) {
+          double s = 0;
+          for (int k = 0; k < 7; k++) s += Je[k * 7 + a] * Je[k * 7 + a];
+          if (ci >= 0) n2[7 * ci + a] += s;
+          if (cj >= 0) n2[7 * cj + a] += s;
+        }
+      }
+      for (int c = 0; c < nc; c++) scale[c] = 1.0 / (1.0 + std::sqrt(n2[c]));
+    }
+    double xn = 0, gmax = 0;
+    for (int v = 0; v < n; v++) {
+      if (col[v] < 0) continue;
+      double mg[7], xp[7];
+      for (int k = 0; k < 7; k++) { xn += lie7[7 * v + k] * lie7[7 * v + k]; mg[k] = -g[7 * col[v] + k]; }
+      sim3_plus(lie7 + 7 * v, mg, xp);
+      for (int k = 0; k < 7; k++) gmax = std::max(gmax, std::fabs(lie7[7 * v + k] - xp[k]));
+    }
+    x_norm = std::sqrt(xn);
+    return gmax;
+  };
+  bool done = false;
+  double gmax = evaluate(true);
+  S.initial_cost = x_cost;
+  if (gmax <= 1e-10) { S.termination = 1; done = true; }
+  while (!done && nc > 0) {
+    if (iteration >= max_iters) { S.termination = 0; break; }
+    if (radius <= 1e-32) { S.termination = 6; break; }
+    iteration++;
+    // scaled normal equations
+    H.assign((size_t)nc * nc, 0.0);
+    std::vector<double> gs(nc);
+    for (int c = 0; c < nc; c++) gs[c] = g[c] * scale[c];
+    for (int e = 0; e < ne; e++) {
+      const double* Je = &J[49 * (size_t)e];
+      const int ci = col[edge_i[e]], cj = col[edge_j[e]];
+      for (int a = 0; a < 7; a++)
+        for (int b = 0; b < 7; b++) {
+          double s = 0;
+          for (int k = 0; k < 7; k++) s += Je[k * 7 + a] * Je[k * 7 + b];
+          if (ci >= 0) H[(size_t)(7 * ci + a) * nc + 7 * ci + b] += s * scale[7 * ci + a] * scale[7 * ci + b];
+          if (cj >= 0) H[(size_t)(7 * cj + a) * nc + 7 * cj + b] += s * scale[7 * cj + a] * scale[7 * cj + b];
+          if (ci >= 0 && cj >= 0) {
+            H[(size_t)(7 * ci + a) * nc + 7 * cj + b] -= s * scale[7 * ci + a] * scale[7 * cj + b];
+            H[(size_t)(7 * cj + a) * nc + 7 * ci + b] -= s * scale[7 * cj + a] * scale[7 * ci + b];
+          }
+        }
+    }
+    std::vector<double> Hs(H);
+    for (int c = 0; c < nc; c++) H[(size_t)c * nc + c] += std::min(std::max(Hs[(size_t)c * nc + c], 1e-6), 1e32) / radius;
+    std::vector<double> y(gs);
+    bool ok = dense_chol(H, nc);
+    double mcc = 0;
+    if (ok) {
+      dense_chol_solve(H, nc, y);
+      for (int c = 0; c < nc; c++) step[c] = -y[c];
+      // model cost change = -(J s).(r + J s / 2) over the residual blocks (scaled J, scaled step)
+      for (int e = 0; e < ne; e++) {
+        const double* Je = &J[49 * (size_t)e]; const double* re = &r[7 * (size_t)e];
+        const int ci = col[edge_i[e]], cj = col[edge_j[e]];
+        for (int k = 0; k < 7; k++) {
+          double m = 0;
+          for (int a = 0; a < 7; a++) {
+            if (ci >= 0) m += Je[k * 7 + a] * scale[7 * ci + a] * step[7 * ci + a];
+            if (cj >= 0) m -= Je[k * 7 + a] * scale[7 * cj + a] * step[7 * cj + a];
+          }
+          mcc -= m * (re[k] + m / 2);
+        }
+      }
+    }
+    if (!ok || !(mcc > 0.0)) {
+      if (++invalid >= 5) { S.termination = 5; break; }
+      radius /= dec; dec *= 2;
+      continue;
+    }
+    invalid = 0;
+    double sn = 0;
+    for (int v = 0; v < n; v++) {
+      for (int k = 0; k < 7; k++) cand[7 * v + k] = lie7[7 * v + k];
+      if (col[v] < 0) continue;
+      double d[7];
+      for (int k = 0; k < 7; k++) d[k] = step[7 * col[v] + k] * scale[7 * col[v] + k];
+      sim3_plus(lie7 + 7 * v, d, &cand[7 * v]);
+      for (int k = 0; k < 7; k++) { const double e2 = lie7[7 * v + k] - cand[7 * v + k]; sn += e2 * e2; }
+    }
+    double cand_cost = cost_at(cand.data());
+    if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    if (std::sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) { S.termination = 2; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (std::fabs(cost_change) <= 1e-6 * x_cost) { S.termination = 3; break; }
+    const double rel = cost_change / mcc;
+    if (rel > 1e-3) {
+      std::memcpy(lie7, cand.data(), sizeof(double) * 7 * n);
+      gmax = evaluate(false);
+      S.successful_steps++;
+      radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
+      dec = 2.0;
+      if (gmax <= 1e-10) { S.termination = 1; break; }
+    } else {
+      radius /= dec; dec *= 2.0;
+    }
+  }
+  S.final_cost = x_cost; S.iterations = iteration; S.final_radius = radius;
+  if (sum) *sum = S;
+  return 0;
+}
+
+// the write-back arithmetic (src/CeresOptimizer.cc:916-956): Tiw = [R | t / s] per keyframe (row-major 3x4); every map point
+// P' = corrected_Swr * (Srw * P) with r = pt_ref[p] (reference keyframe index), Srw from the ORIGINAL tangents
+void orc_essential_graph_correct(const double* lie_orig, const double* lie_opt, int n, double* Tiw, const int32_t* pt_ref, double* pts, int npts) {
+  std::vector<Sim3> Swc(n), Scw0(n);
+  for (int v = 0; v < n; v++) {
+    const Sim3 S = sim3_exp(lie_opt + 7 * v);
+    Swc[v] = sim3_inv(S); Scw0[v] = sim3_exp(lie_orig + 7 * v);
+    const M3 R = rot_matrix(S.q);
+    const double s = qn2(S.q);
+    const double inv_s = 1. / s;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Tiw[12 * v + 4 * i + j] = R.m[i][j];
+    Tiw[12 * v + 3] = inv_s * S.t.x; Tiw[12 * v + 7] = inv_s * S.t.y; Tiw[12 * v + 11] = inv_s * S.t.z;
+  }
+  for (int p = 0; p < npts; p++) {
+    const int rk = pt_ref[p];
+    const V3 Pc = sim3_act(Scw0[rk], {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]});
+    const V3 Pw = sim3_act(Swc[rk], Pc);
+    pts[3 * p] = Pw.x; pts[3 * p + 1] = Pw.y; pts[3 * p + 2] = Pw.z;
+  }
+}
+
+}  // extern "C"

@@ -42,4 +42,19 @@ qq = (k[:, :2] + rng.normal(0, 5, (2000, 2))).astype(np.float32); r = rng.unifor
 frame.GetFeaturesInArea(k, b, qq, r); t0 = time.perf_counter(); off, idx = frame.GetFeaturesInArea(k, b, qq, r); out["area_queries_per_s_host_api"] = 2000 / (time.perf_counter() - t0)
 out["area_candidates_per_query"] = float(off[-1]) / 2000
 m1 = np.full(2000, -1, np.int32); t0 = time.perf_counter(); po.features_in_area(k, b, qq, r, m1, m1); out["cpu_area_queries_per_s"] = 2000 / (time.perf_counter() - t0)
+# essential graph (N4): 500 keyframes, ~700 edges
+from ceres_mono_orb_slam2_amd import optimizer
+from tests.test_oracle_essential_graph import build_problem
+g = synth.make_essential_graph(11, n=500, drift=0.001, n_corrected=8)
+x0, ej, ei, Sji = build_problem(g)
+optimizer.optimize_essential_graph(x0, g["fixed"], ej, ei, Sji)
+t0 = time.perf_counter(); x, s = optimizer.optimize_essential_graph(x0, g["fixed"], ej, ei, Sji); dt = time.perf_counter() - t0
+out["essential_graph_500kf_ms"] = dt * 1e3; out["essential_graph_500kf_iterations"] = s["iterations"]
+t0 = time.perf_counter(); ox, os_ = po.optimize_essential_graph(x0, g["fixed"], ej, ei, Sji); out["cpu_essential_graph_500kf_ms"] = (time.perf_counter() - t0) * 1e3
+# triangulation (N4)
+from tests.test_oracle_tri import make_tri_problem
+p = make_tri_problem(5, n=200000)
+a = (p["T1"], p["T2"], p["K1"], p["K2"], p["kp1"], p["kp2"], p["ls"], p["sf"], p["ratio"])
+frame.TriangulateMatches(*a); t0 = time.perf_counter(); frame.TriangulateMatches(*a); out["triangulate_matches_per_s_host_api"] = 200000 / (time.perf_counter() - t0)
+t0 = time.perf_counter(); po.triangulate_matches(*a); out["cpu_triangulate_matches_per_s"] = 200000 / (time.perf_counter() - t0)
 print(json.dumps(out))
