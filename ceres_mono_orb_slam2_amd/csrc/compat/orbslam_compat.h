@@ -19,6 +19,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../../include/orbslam_hip.h"
@@ -156,6 +157,76 @@ struct FrameView {
   float min_x_ = 0, max_x_ = 0, min_y_ = 0, max_y_ = 0;     // Frame::ComputeImageBounds
 };
 
+// Frame-side steps (reference src/Frame.cc:158-173, 191-241, 243-355) on a FrameView: the batched forms the device wants
+struct FrameOps {
+  static std::vector<float> kps4(const FrameView& F) {
+    std::vector<float> k(4 * F.undistort_keypoints_.size());
+    for (size_t i = 0; i < F.undistort_keypoints_.size(); i++) {
+      const KeyPointT& p = F.undistort_keypoints_[i];
+      k[4 * i] = p.pt.x; k[4 * i + 1] = p.pt.y; k[4 * i + 2] = (float)p.octave; k[4 * i + 3] = p.angle;
+    }
+    return k;
+  }
+  // Frame::UndistortKeyPoints: keypoints -> undistort_keypoints_ (dist5 = k1, k2, p1, p2, k3)
+  static void UndistortKeyPoints(const std::vector<KeyPointT>& keypoints, const float K4[4], const float dist5[5], FrameView& F) {
+    const int n = (int)keypoints.size();
+    std::vector<float> xy(2 * (size_t)n), out(2 * (size_t)n);
+    for (int i = 0; i < n; i++) { xy[2 * i] = keypoints[i].pt.x; xy[2 * i + 1] = keypoints[i].pt.y; }
+    orbcompat_check(orbm_undistort_keypoints(xy.data(), n, K4, dist5, out.data()), "orbm_undistort_keypoints");
+    F.undistort_keypoints_ = keypoints;
+    for (int i = 0; i < n; i++) { F.undistort_keypoints_[i].pt.x = out[2 * i]; F.undistort_keypoints_[i].pt.y = out[2 * i + 1]; }
+  }
+  // Frame::GetFeaturesInArea for a list of queries (x, y, r, minLevel, maxLevel): indices[q] in the reference's order
+  static void GetFeaturesInArea(const FrameView& F, const std::vector<float>& q_xy, const std::vector<float>& q_r, const std::vector<int>& q_min_level,
+                                const std::vector<int>& q_max_level, std::vector<std::vector<size_t>>& indices) {
+    const int nq = (int)q_r.size(), n = (int)F.undistort_keypoints_.size();
+    const std::vector<float> k = kps4(F);
+    const float bounds[4] = {F.min_x_, F.max_x_, F.min_y_, F.max_y_};
+    std::vector<uint32_t> off(nq + 1, 0), idx;
+    int total = 0;
+    orbcompat_check(orbm_features_in_area(k.data(), n, bounds, q_xy.data(), q_r.data(), q_min_level.empty() ? nullptr : q_min_level.data(),
+                                          q_max_level.empty() ? nullptr : q_max_level.data(), nq, off.data(), nullptr, 0, &total), "orbm_features_in_area");
+    idx.resize((size_t)std::max(total, 1));
+    orbcompat_check(orbm_features_in_area(k.data(), n, bounds, q_xy.data(), q_r.data(), q_min_level.empty() ? nullptr : q_min_level.data(),
+                                          q_max_level.empty() ? nullptr : q_max_level.data(), nq, off.data(), idx.data(), (int)idx.size(), &total), "orbm_features_in_area");
+    indices.assign(nq, std::vector<size_t>());
+    for (int q = 0; q < nq; q++) indices[q].assign(idx.begin() + off[q], idx.begin() + off[q + 1]);
+  }
+};
+
+// ORBVocabulary::transform as Frame::ComputeBoW calls it (src/Frame.cc:322-327); BowVector / FeatureVector keep DBoW2's map types
+typedef std::map<unsigned int, double> BowVector;
+typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;
+class ORBVocabulary {
+ public:
+  // flattened tree (what loadFromTextFile builds in m_nodes), see include/orbslam_hip.h::orbv_create
+  ORBVocabulary(const uint8_t* node_desc, const uint32_t* child_off, const uint32_t* children, const int32_t* word_id, const double* weight,
+                int n_nodes, int L, int device = 0) {
+    orbcompat_check(orbv_create(node_desc, child_off, children, word_id, weight, n_nodes, L, device, &ctx_), "orbv_create");
+  }
+  ~ORBVocabulary() { orbv_destroy(ctx_); }
+  ORBVocabulary(const ORBVocabulary&) = delete;
+  ORBVocabulary& operator=(const ORBVocabulary&) = delete;
+  void transform(const MatT& descriptors, BowVector& v, FeatureVector& fv, int levelsup) const {
+    const int n = descriptors.rows;
+    std::vector<uint32_t> bw(std::max(n, 1)), fn(std::max(n, 1)), fo(n + 2), fi(std::max(n, 1));
+    std::vector<double> bv(std::max(n, 1));
+    int nw = 0, nf = 0;
+    orbcompat_check(orbv_transform(ctx_, descriptors.data, n, levelsup, bw.data(), bv.data(), &nw, fn.data(), fo.data(), fi.data(), &nf), "orbv_transform");
+    v.clear(); fv.clear();
+    for (int k = 0; k < nw; k++) v[bw[k]] = bv[k];
+    for (int m = 0; m < nf; m++) fv[fn[m]].assign(fi.begin() + fo[m], fi.begin() + fo[m + 1]);
+  }
+  double score(const BowVector& a, const BowVector& b) const {
+    std::vector<uint32_t> wa, wb; std::vector<double> va, vb;
+    for (auto& kv : a) { wa.push_back(kv.first); va.push_back(kv.second); }
+    for (auto& kv : b) { wb.push_back(kv.first); vb.push_back(kv.second); }
+    return orbv_score_l1(wa.data(), va.data(), (int)wa.size(), wb.data(), vb.data(), (int)wb.size());
+  }
+ private:
+  orbv_ctx* ctx_ = nullptr;
+};
+
 class ORBmatcher {
  public:
   static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;      // src/ORBmatcher.cc:35-37
@@ -222,8 +293,20 @@ struct Sim3Problem {          // what OptimizeSim3 reads from the two keyframes 
   std::vector<uint8_t> is_outliers_;              // out: is_outlier_12 || is_outlier_21 (:694-726)
 };
 
+struct EssentialGraphProblem { // what OptimizeEssentialGraph builds from the map (src/CeresOptimizer.cc:765-905)
+  std::vector<double> Scw_datas;            // n x 7 tangents (Scw.log()), in/out
+  std::vector<uint8_t> kf_fixed;            // 1 for loop_keyframe
+  std::vector<int32_t> edge_j, edge_i;      // AddResidualBlock(cost, nullptr, Scw_datas[id_j], Scw_datas[id_i])
+  std::vector<double> edge_Sji;             // ne x 7, Sophus::Sim3d::data() of Sji
+};
+
 class CeresOptimizer {
  public:
+  // the solve of OptimizeEssentialGraph(Map*, KeyFrame* loop, KeyFrame* current, ...) (:737-914)
+  void static OptimizeEssentialGraph(EssentialGraphProblem* p) {
+    orbcompat_check(ba_optimize_essential_graph(p->Scw_datas.data(), p->kf_fixed.data(), (int)p->kf_fixed.size(), p->edge_j.data(), p->edge_i.data(),
+                                                p->edge_Sji.data(), (int)p->edge_j.size(), 100, nullptr, nullptr), "ba_optimize_essential_graph");
+  }
   // int OptimizeSim3(KeyFrame*, KeyFrame*, vector<MapPoint*>& matches12, Sophus::Sim3d& S12, const float th2,
   //                  const bool bFixScale) (:601-735).  S12 = Sophus::Sim3d::data() (7 doubles: scaled q_xyzw, t).
   int static OptimizeSim3(Sim3Problem* p, double* S12, const float th2, const bool bFixScale) {

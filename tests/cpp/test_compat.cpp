@@ -69,6 +69,39 @@ int main(int argc, char** argv) {
       fwrite(&sinl, 4, 1, f); fwrite(S12, 8, 7, f); fwrite(Q.is_outliers_.data(), 1, ns, f);
       printf("test_compat: pose inliers %d, sim3 inliers %d\n", inl, sinl);
     }
+    if (argc >= 9) {
+      // widened rows: window candidates, ORBVocabulary::transform, OptimizeEssentialGraph (inputs written by the Python test)
+      std::vector<uint8_t> ab = slurp(argv[8]);
+      const uint8_t* c = ab.data();
+      auto take = [&](void* dst, size_t bytes) { memcpy(dst, c, bytes); c += bytes; };
+      FrameView F;
+      F.undistort_keypoints_ = kps; F.descriptors_ = desc; F.min_x_ = 0; F.max_x_ = (float)w; F.min_y_ = 0; F.max_y_ = (float)h;
+      int nq = 0; take(&nq, 4);
+      std::vector<float> qxy(2 * nq), qr(nq); std::vector<int> qmn(nq), qmx(nq);
+      take(qxy.data(), 8 * nq); take(qr.data(), 4 * nq); take(qmn.data(), 4 * nq); take(qmx.data(), 4 * nq);
+      std::vector<std::vector<size_t>> ind;
+      FrameOps::GetFeaturesInArea(F, qxy, qr, qmn, qmx, ind);
+      for (int q = 0; q < nq; q++) { int m = (int)ind[q].size(); fwrite(&m, 4, 1, f); for (size_t v : ind[q]) { int vi = (int)v; fwrite(&vi, 4, 1, f); } }
+      int nn = 0, L = 0, nch = 0; take(&nn, 4); take(&L, 4); take(&nch, 4);
+      std::vector<uint8_t> nd(32 * (size_t)nn); std::vector<uint32_t> co(nn + 1), ch(nch); std::vector<int32_t> wi(nn); std::vector<double> wt(nn);
+      take(nd.data(), nd.size()); take(co.data(), 4 * (nn + 1)); take(ch.data(), 4 * (size_t)nch); take(wi.data(), 4 * (size_t)nn); take(wt.data(), 8 * (size_t)nn);
+      ORBVocabulary voc(nd.data(), co.data(), ch.data(), wi.data(), wt.data(), nn, L);
+      BowVector bv; FeatureVector fv;
+      voc.transform(desc, bv, fv, 2);
+      int nw = (int)bv.size(); fwrite(&nw, 4, 1, f);
+      for (auto& kv : bv) { fwrite(&kv.first, 4, 1, f); fwrite(&kv.second, 8, 1, f); }
+      int nfv = (int)fv.size(); fwrite(&nfv, 4, 1, f);
+      for (auto& kv : fv) { int m = (int)kv.second.size(); fwrite(&kv.first, 4, 1, f); fwrite(&m, 4, 1, f); fwrite(kv.second.data(), 4, m, f); }
+      double self = voc.score(bv, bv); fwrite(&self, 8, 1, f);
+      EssentialGraphProblem G;
+      int nv = 0, ne = 0; take(&nv, 4); take(&ne, 4);
+      G.Scw_datas.resize(7 * (size_t)nv); G.kf_fixed.resize(nv); G.edge_j.resize(ne); G.edge_i.resize(ne); G.edge_Sji.resize(7 * (size_t)ne);
+      take(G.Scw_datas.data(), 56 * (size_t)nv); take(G.kf_fixed.data(), nv); take(G.edge_j.data(), 4 * (size_t)ne); take(G.edge_i.data(), 4 * (size_t)ne);
+      take(G.edge_Sji.data(), 56 * (size_t)ne);
+      CeresOptimizer::OptimizeEssentialGraph(&G);
+      fwrite(G.Scw_datas.data(), 8, 7 * (size_t)nv, f);
+      printf("test_compat: %d bow words, %d fv nodes, essential graph of %d keyframes\n", nw, nfv, nv);
+    }
     fclose(f);
     printf("test_compat: %d keypoints, d(0,1)=%d\n", n, d01);
   } catch (const std::exception& e) {

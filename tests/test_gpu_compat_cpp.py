@@ -34,7 +34,23 @@ def test_cpp_shims_vs_oracle(oracle, tmp_path):
         f.write(np.int32(150).tobytes())
         for k, dt in SK:
             f.write(np.ascontiguousarray(sp[k], dt).tobytes())
-    subprocess.check_call([str(exe), str(raw), "640", "480", "1000", str(out), str(posef), str(sim3f)])
+    from tests.test_oracle_essential_graph import build_problem
+    rng = np.random.default_rng(3)
+    nq = 64
+    qxy = np.stack([rng.uniform(0, 640, nq), rng.uniform(0, 480, nq)], 1).astype(np.float32); qr = rng.uniform(5, 40, nq).astype(np.float32)
+    qmn = rng.integers(-1, 3, nq).astype(np.int32); qmx = (qmn + rng.integers(0, 4, nq)).astype(np.int32)
+    voc = synth.make_vocabulary(5, k=6, L=3)
+    eg = synth.make_essential_graph(9, n=25)
+    x0, ej, ei, Sji = build_problem(eg)
+    auxf = tmp_path / "aux.bin"
+    with open(auxf, "wb") as f:
+        f.write(np.int32(nq).tobytes()); f.write(qxy.tobytes()); f.write(qr.tobytes()); f.write(qmn.tobytes()); f.write(qmx.tobytes())
+        f.write(np.array([len(voc["word_id"]), voc["L"], len(voc["children"])], np.int32).tobytes())
+        for k in ("node_desc", "child_off", "children", "word_id", "weight"):
+            f.write(np.ascontiguousarray(voc[k]).tobytes())
+        f.write(np.array([len(x0), len(ej)], np.int32).tobytes())
+        f.write(x0.tobytes()); f.write(eg["fixed"].tobytes()); f.write(ej.tobytes()); f.write(ei.tobytes()); f.write(Sji.tobytes())
+    subprocess.check_call([str(exe), str(raw), "640", "480", "1000", str(out), str(posef), str(sim3f), str(auxf)])
     buf = open(out, "rb").read()
     n = int(np.frombuffer(buf, np.int32, 1)[0])
     off = 4
@@ -55,6 +71,29 @@ def test_cpp_shims_vs_oracle(oracle, tmp_path):
     on, oS, oo, _ = oracle.optimize_sim3(sp["K1"], sp["K2"], sp["s12_0"], sp["P3D2c"], sp["obs1"], sp["inv_sigma2_1"], sp["P3D1c"], sp["obs2"],
                                          sp["inv_sigma2_2"])
     assert sinl == on and np.array_equal(sout, oo) and np.abs(s12 - oS).max() < 1e-6
+    # widened rows through the C++ shims
+    kk = np.ascontiguousarray(kps).view(oracle.KP_DTYPE).reshape(-1)          # (checked bit-exact against the oracle below)
+    kps4 = np.stack([kk["x"], kk["y"], kk["octave"].astype(np.float32), kk["angle"]], 1).astype(np.float32)
+    ooff, oidx = oracle.features_in_area(kps4, np.array([0, 640, 0, 480], np.float32), qxy, qr, qmn, qmx)
+    for q in range(nq):
+        m = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+        got = np.frombuffer(buf, np.int32, m, off); off += 4 * m
+        assert np.array_equal(got, oidx[ooff[q]:ooff[q + 1]].astype(np.int32))
+    obw, obv, ofn, ofo, ofi = oracle.bow_transform(voc, desc, 2)
+    nw = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+    rec = np.frombuffer(buf, np.dtype([("w", "<u4"), ("v", "<f8")]), nw, off); off += 12 * nw
+    assert np.array_equal(rec["w"], obw) and np.array_equal(rec["v"], obv)
+    nfv = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+    assert nfv == len(ofn)
+    for mI in range(nfv):
+        node, cnt = np.frombuffer(buf, np.uint32, 2, off); off += 8
+        feats = np.frombuffer(buf, np.uint32, int(cnt), off); off += 4 * int(cnt)
+        assert node == ofn[mI] and np.array_equal(feats, ofi[ofo[mI]:ofo[mI + 1]])
+    self_score = np.frombuffer(buf, np.float64, 1, off)[0]; off += 8
+    assert abs(self_score - 1.0) < 1e-12
+    gx = np.frombuffer(buf, np.float64, 7 * len(x0), off).reshape(-1, 7); off += 56 * len(x0)
+    ogx, _ = oracle.optimize_essential_graph(x0, eg["fixed"], ej, ei, Sji)
+    assert np.abs(gx - ogx).max() < 1e-7 and off == len(buf)
     okps, odesc = oracle.OracleExtractor(1000).extract(img)
     assert n == len(okps)
     assert np.array_equal(kps, okps.view(np.uint8).reshape(n, 28)) and np.array_equal(desc, odesc)
