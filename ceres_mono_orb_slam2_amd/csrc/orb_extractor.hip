@@ -35,7 +35,7 @@ namespace orbhip {
 static const int PATCH_SIZE = 31, HALF_PATCH = 15, EDGE_THRESHOLD = 19;
 static const int MAX_LEVELS = 16;
 static const int MAX_INI = 64;            // initial octree nodes per level (round(W/H))
-static const int KEYCAP_MAX = 32768;      // dense candidate capacity per (frame, level)
+static const int KEYCAP_MAX = 131072;     // dense candidate capacity per (frame, level); beyond it the frame reports ORBHIP_EOVERFLOW
 
 struct LevelDev {
   int w, h;
@@ -881,7 +881,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
       L.hX = (L.ncells > 0) ? static_cast<float>(L.winW) / nIni : 1.0f;
       for (int i = 0; i <= nIni; i++) L.ini_x[i] = (int)(L.hX * static_cast<float>(i));
       node_cap = std::max(node_cap, std::max(L.quota + 8, 4 * nIni + 8));
-      sel_cap = std::max(sel_cap, L.quota + 4);
+      sel_cap = std::max(sel_cap, std::max(L.quota + 4, 4 * nIni + 4));   // the first octree sweep can return 4 * nIni > N nodes
       long long theo = (long long)L.ncells * cell_cap;
       int keycap_max = KEYCAP_MAX;
       if (const char* e = std::getenv("ORBHIP_KEYCAP")) keycap_max = std::max(64, std::min(KEYCAP_MAX, atoi(e)));   // test hook for the overflow path
@@ -1124,8 +1124,11 @@ int orbx_get_tables(const orbx_ctx* c, float* scale, float* inv_scale, float* si
 
 int orbx_max_keypoints(const orbx_ctx* c) {
   if (!c) return ORBHIP_EINVAL;
+  // DistributeOctTree returns at most N + 3 keypoints per level once it is past its first sweep, but that first sweep splits
+  // all nIni initial nodes unconditionally (src/ORBextractor.cc:589-660): a wide, short level with few features can come
+  // back with up to 4 * nIni > N keypoints.  nIni depends on the image aspect ratio (<= MAX_INI), so the bound is taken over it.
   int s = 0;
-  for (int q : c->quota) s += q + 3;
+  for (int q : c->quota) s += std::max(q + 3, 4 * MAX_INI);
   return s;
 }
 

@@ -32,7 +32,7 @@ extern "C" {
 #define ORBHIP_ENODEV (-2)    /* no HIP device / HIP runtime error */
 #define ORBHIP_ENOMEM (-3)
 #define ORBHIP_ECAP (-4)      /* caller's output capacity too small */
-#define ORBHIP_EOVERFLOW (-5) /* internal candidate capacity exceeded (see orbx_create_ex) */
+#define ORBHIP_EOVERFLOW (-5) /* internal candidate capacity exceeded: > 131072 FAST corners in one pyramid level of one frame */
 #define ORBHIP_ENUMERIC (-6)  /* linear solve failed */
 
 const char* orbhip_last_error(void);
@@ -56,7 +56,10 @@ typedef struct orbx_keypoint {
 } orbx_keypoint;
 
 /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
- * (src/ORBextractor.cc:410-470); `device` = HIP device ordinal.                  */
+ * (src/ORBextractor.cc:410-470); `device` = HIP device ordinal.  Capacities (errors, never silent): the largest
+ * per-level quota must fit the LDS octree (about 3200 keypoints in one level, i.e. any nfeatures the reference's 8-level
+ * configurations use; ORBHIP_EINVAL from the first extract call otherwise), and a level may hold at most 131072 FAST
+ * corners (ORBHIP_EOVERFLOW for that frame).                                                                              */
 int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
                 orbx_ctx** out);
 int orbx_destroy(orbx_ctx* ctx);
