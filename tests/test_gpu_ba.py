@@ -236,3 +236,36 @@ def test_folded_twin_blocks_equal_literal_duplicates(oracle):
     assert abs(s["initial_cost"] - os_["initial_cost"]) <= RTOL_COST * os_["initial_cost"]
     assert abs(s["final_cost"] - os_["final_cost"]) <= RTOL_COST * os_["final_cost"]
     assert _close(poses, oposes, RTOL_X) and _close_pts(pts, opts)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ba_random_shapes_vs_oracle(oracle, seed):
+    """Random graph shapes: 2-40 cameras, random fixed sets (incl. cameras nobody observes and every camera but one fixed),
+    points seen once only (rank-deficient landmark blocks), mixed loss flags (0 / 1 / 2), random iteration caps."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    rng = np.random.default_rng(900 + seed)
+    ncam = int(rng.integers(2, 41)); npts = int(rng.integers(8, 900)); nobs = int(npts * rng.uniform(2.0, 5.0))
+    g = synth.make_ba_graph(100 + seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=1, outlier_frac=float(rng.choice([0.0, 0.05, 0.2])))
+    n = len(g["obs_cam"])
+    fixed = g["cam_fixed"].copy()
+    mode = seed % 3
+    if mode == 1:
+        fixed[:] = 1; fixed[int(rng.integers(0, ncam))] = 0               # a single free camera
+    elif mode == 2:
+        fixed[rng.random(ncam) < 0.4] = 1; fixed[0] = 1
+    keep = np.ones(n, bool)
+    lonely = rng.choice(npts, max(1, npts // 10), replace=False)           # points left with exactly one observation
+    for p in lonely:
+        idx = np.nonzero(g["obs_pt"] == p)[0]
+        keep[idx[1:]] = False
+    oc, op, uv = g["obs_cam"][keep], g["obs_pt"][keep], g["obs_uv"][keep]
+    w = g["obs_inv_sigma2"][keep].astype(np.float64)
+    rb = rng.integers(0, 2, keep.sum()).astype(np.uint8)
+    iters = int(rng.choice([1, 3, 8, 25]))
+    poses, pts, s = optimizer.bundle_adjustment(g["K4"], g["poses0"], fixed, g["pts0"], oc, op, uv, w, rb, iters)
+    oposes, opts, os_ = oracle.ba_solve(g["K4"], g["poses0"], fixed, g["pts0"], oc, op, uv, w, rb, iters)
+    assert (s["iterations"], s["successful_steps"], s["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"])
+    assert abs(s["initial_cost"] - os_["initial_cost"]) <= RTOL_COST * os_["initial_cost"]
+    assert abs(s["final_cost"] - os_["final_cost"]) <= RTOL_COST * max(os_["final_cost"], 1e-9 * os_["initial_cost"])   # (a cost of ~1e-15 is zero)
+    assert _close(poses, oposes, RTOL_X) and _close_pts(pts, opts)
+    assert np.array_equal(poses[fixed != 0], g["poses0"][fixed != 0])

@@ -224,3 +224,28 @@ def test_search_for_triangulation_vs_oracle(oracle):
                                                  check_ori=ori)
         assert n == on and np.array_equal(m, om) and n > 20
         assert (m[um1 == 0] == -1).all() and (um2[m[m >= 0]] == 1).all()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_match_frames_random_sizes_and_ties(oracle, seed):
+    """Random frame sizes (1 .. 4100 keypoints, more targets than the LDS tile holds at once included) with descriptors drawn
+    from a small pool so that equal distances are everywhere: the first-minimum / second-distance bookkeeping and the
+    rotation histogram must follow the reference's scan order exactly."""
+    rng = np.random.default_rng(500 + seed)
+    n1 = int(rng.choice([1, 2, 63, 64, 65, 500, 1999, 2048, 4100])); n2 = int(rng.choice([1, 3, 64, 127, 1000, 2049, 4100]))
+    pool = rng.integers(0, 256, (int(rng.choice([4, 40, 400])), 32), dtype=np.uint8)
+    def draw(n):
+        d = pool[rng.integers(0, len(pool), n)].copy()
+        flip = rng.random(n) < 0.5                                      # half of them one or two bits away -> distances 0, 1, 2 tie a lot
+        d[flip, rng.integers(0, 32, flip.sum())] ^= (1 << rng.integers(0, 8, flip.sum())).astype(np.uint8)
+        return d
+    d1, d2 = draw(n1), draw(n2)
+    a1 = rng.choice([0.0, 12.0, 90.0, 359.5], n1).astype(np.float32) + rng.uniform(0, 0.4, n1).astype(np.float32)
+    a2 = rng.choice([0.0, 12.0, 90.0, 359.5], n2).astype(np.float32) + rng.uniform(0, 0.4, n2).astype(np.float32)
+    ratio = float(rng.choice([0.6, 0.9, 1.0])); ori = bool(rng.integers(0, 2)); th = int(rng.choice([50, 100, 3]))
+    m, n = _match_pair(d1, a1, d2, a2, ratio, ori, th)
+    om, on = oracle.match_frames(d1, a1, d2, a2, ratio, th, ori)
+    assert n == on and np.array_equal(m, om)
+    bi, bd, sd = _m().hamming_best2(d1, d2)
+    obi, obd, osd = oracle.hamming_best2(d1, d2)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
