@@ -656,31 +656,55 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restric
   for (int k = 0; k < 3; k++) D.gps[3 * (size_t)p + k] = D.gp[3 * (size_t)p + k] * sp[k];
 }
 
-// per observation: E = (Jc S_c)^T (Jp S_p) (6x3) and E (C_s+D)^-1, stored AoS (18 doubles each)
+// per observation: E = (Jc S_c)^T (Jp S_p) (6x3) and E (C_s+D)^-1, stored AoS (18 doubles each).  Every wave transposes its
+// 64 x 18 results through LDS so that the AoS arrays are written as contiguous 512-byte runs (thread-strided 8-byte stores
+// of a 144-byte record cost 8x their bytes in write sectors - the kernel was the second most expensive of a batched solve).
 __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   if (st->done || !st->valid || D.fix_points) return;
+  if ((int)blockIdx.x * BA_TPB >= D.nobs) return;
+  __shared__ double s_t[BA_TPB / 64][64][19];          // + 1 pad
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
-  if (i >= D.nobs) return;
-  const int cc = D.cam_col[D.obs_cam[i]];
-  if (cc < 0) return;
-  const int p = D.obs_pt[i];
-  const size_t n = D.nobs;
-  const double* sc = D.scale_c + 6 * (size_t)cc;
-  const double* sp = D.scale_p + 3 * (size_t)p;
-  const double* Ci = D.Cinv + 6 * (size_t)p;
-  double jp[6];
-  for (int k = 0; k < 6; k++) jp[k] = D.Jp[k * n + i] * sp[k % 3];
-  double* Eo = D.E + 18 * (size_t)i;
-  double* ECo = D.EC + 18 * (size_t)i;
-  for (int u = 0; u < 6; u++) {
-    const double j0 = D.Jc[u * n + i] * sc[u], j1 = D.Jc[(6 + u) * n + i] * sc[u];
-    const double e0 = j0 * jp[0] + j1 * jp[3], e1 = j0 * jp[1] + j1 * jp[4], e2 = j0 * jp[2] + j1 * jp[5];
-    Eo[3 * u] = e0; Eo[3 * u + 1] = e1; Eo[3 * u + 2] = e2;
-    ECo[3 * u] = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
-    ECo[3 * u + 1] = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
-    ECo[3 * u + 2] = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i0 = blockIdx.x * BA_TPB + 64 * w;         // first observation of this wave
+  const int cc = (i < D.nobs) ? D.cam_col[D.obs_cam[i]] : -1;
+  const bool act = cc >= 0;
+  const unsigned long long amask = __ballot(act);
+  double e[18], ec[18];
+  if (act) {
+    const int p = D.obs_pt[i];
+    const size_t n = D.nobs;
+    const double* sc = D.scale_c + 6 * (size_t)cc;
+    const double* sp = D.scale_p + 3 * (size_t)p;
+    const double* Ci = D.Cinv + 6 * (size_t)p;
+    double jp[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) jp[k] = D.Jp[k * n + i] * sp[k % 3];
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+      const double j0 = D.Jc[u * n + i] * sc[u], j1 = D.Jc[(6 + u) * n + i] * sc[u];
+      const double e0 = j0 * jp[0] + j1 * jp[3], e1 = j0 * jp[1] + j1 * jp[4], e2 = j0 * jp[2] + j1 * jp[5];
+      e[3 * u] = e0; e[3 * u + 1] = e1; e[3 * u + 2] = e2;
+      ec[3 * u] = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
+      ec[3 * u + 1] = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
+      ec[3 * u + 2] = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < 18; k++) s_t[w][lane][k] = pass ? ec[k] : e[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    double* dst = (pass ? D.EC : D.E) + 18 * (size_t)i0;
+    const int rows = min(64, D.nobs - i0);
+    for (int idx = lane; idx < 18 * rows; idx += 64) {
+      const int r = idx / 18, k = idx - 18 * r;
+      if ((amask >> r) & 1ull) dst[idx] = s_t[w][r][k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   }
 }
 
