@@ -461,6 +461,8 @@ struct BaDev {            // device pointers of one problem
   const int* obs_cam; const int* obs_pt; const double* obs_uv; const double* obs_w; const unsigned char* obs_robust;
   const int* pt_off;                 // [npts+1] observations grouped by point
   const int* cam_off; const int* cam_obs; const int* cam_obs_pt;   // per-camera lists (sorted by point)
+  const int* cam_pos;                // [nobs] position of an observation inside its camera's list (inverse of cam_obs)
+  double* JcR;                       // [nobs][14] per-camera-ordered records {Jc (12), r (2)}: k_ba_cam_blocks streams them
   double* r; double* Jc; double* Jp; // SoA: r[2][nobs], Jc[12][nobs], Jp[6][nobs]
   double* B; double* gc; double* C; double* gp;       // unscaled blocks: B[nfc][21], gc[nfc][6], C[npts][6], gp[npts][3]
   double* scale_c; double* scale_p;  // Jacobi scaling [nfc][6], [npts][3]
@@ -500,7 +502,12 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
     if (mode == 0) {
       const size_t n = D.nobs;
       D.r[i] = r[0]; D.r[n + i] = r[1];
-      if (wantc) for (int k = 0; k < 12; k++) D.Jc[k * n + i] = Jc[k];
+      if (wantc) {
+        for (int k = 0; k < 12; k++) D.Jc[k * n + i] = Jc[k];
+        double* rec = D.JcR + 14 * (size_t)D.cam_pos[i];            // the same values, grouped by camera (contiguous 112-byte records)
+        for (int k = 0; k < 12; k++) rec[k] = Jc[k];
+        rec[12] = r[0]; rec[13] = r[1];
+      }
       if (wantp) for (int k = 0; k < 6; k++) D.Jp[k * n + i] = Jp[k];
     }
   }
@@ -518,16 +525,15 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
   if (c >= D.ncam) return;
   const int cc = D.cam_col[c];
   if (cc < 0) return;
-  const size_t n = D.nobs;
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
   for (int e = D.cam_off[c] + threadIdx.x; e < D.cam_off[c + 1]; e += BA_TPB) {
-    const int i = D.cam_obs[e];
+    const double* rec = D.JcR + 14 * (size_t)e;           // streamed: the list order is the record order
     double J[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) J[k] = D.Jc[k * n + i];
-    const double r0 = D.r[i], r1 = D.r[n + i];
+    for (int k = 0; k < 12; k++) J[k] = rec[k];
+    const double r0 = rec[12], r1 = rec[13];
 #pragma unroll
     for (int a = 0; a < 6; a++) {
       acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
@@ -1551,7 +1557,9 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   for (int j = 0; j < nobs; j++) cam_off[oc[j] + 1]++;
   for (int c = 0; c < ncam; c++) cam_off[c + 1] += cam_off[c];
   std::vector<int> cfill(cam_off, cam_off + ncam);
-  for (int j = 0; j < nobs; j++) { int e = cfill[oc[j]]++; cam_obs[e] = j; cam_obs_pt[e] = op[j]; }
+  int* cam_pos = H.pinned<int>(nobs, &rc);
+  if (rc) return rc;
+  for (int j = 0; j < nobs; j++) { int e = cfill[oc[j]]++; cam_obs[e] = j; cam_obs_pt[e] = op[j]; cam_pos[j] = e; }
   std::vector<int> cam_col(ncam, -1), free_cams;
   for (int c = 0; c < ncam; c++) if (!in.cam_fixed[c] && cam_off[c + 1] > cam_off[c]) { cam_col[c] = (int)free_cams.size(); free_cams.push_back(c); }
   const int nfc = (int)free_cams.size();
@@ -1607,6 +1615,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.obs_w = H.upload(ow, nobs, &rc, s); D.obs_robust = H.upload(orb, nobs, &rc, s);
   D.pt_off = H.upload(pt_off, npts + 1, &rc, s); D.cam_off = H.upload(cam_off, ncam + 1, &rc, s);
   D.cam_obs = H.upload(cam_obs, nobs, &rc, s); D.cam_obs_pt = H.upload(cam_obs_pt, nobs, &rc, s);
+  D.cam_pos = H.upload(cam_pos, nobs, &rc, s); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
   D.free_cams = H.upload(free_cams.data(), nfc, &rc, s);
   D.blk_a = H.upload(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload(blk_off.data(), nblk + 1, &rc, s);
   D.pair_i = H.upload(pair_i, npairs_all, &rc, s); D.pair_j = H.upload(pair_j, npairs_all, &rc, s);
