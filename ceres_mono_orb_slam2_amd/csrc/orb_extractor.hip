@@ -765,7 +765,8 @@ struct orbx_ctx {
   DevBuf d_cells, d_btiles, d_tab;      // tables
   std::vector<size_t> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // byte offsets into d_tab per level
   DevBuf d_pyr, d_blur, d_cellcnt, d_cellkps, d_keys, d_knode, d_sel, d_selcnt, d_nkeys, d_status;
-  DevBuf d_img, d_kps, d_desc, d_counts;   // host-API staging
+  DevBuf d_img, d_out;                     // host-API staging: image; {counts | keypoints | descriptors} in one block
+  void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
   size_t fast_lds = 0, octree_lds = 0;
   // last call (for introspection)
   const uint8_t* last_img0 = nullptr; long long last_img_frame_bytes = 0; int last_nframes = 0;
@@ -1065,8 +1066,9 @@ int orbx_destroy(orbx_ctx* c) {
   if (!c) return 0;
   DevBuf* bufs[] = {&c->d_cells, &c->d_btiles, &c->d_tab, &c->d_pyr, &c->d_blur, &c->d_cellcnt, &c->d_cellkps,
                     &c->d_keys, &c->d_knode, &c->d_sel, &c->d_selcnt, &c->d_nkeys, &c->d_status, &c->d_img,
-                    &c->d_kps, &c->d_desc, &c->d_counts};
+                    &c->d_out};
   for (DevBuf* b : bufs) b->release();
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1141,30 +1143,43 @@ int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, 
   return run_batch(c, d_imgs, w, h, stride, frame_stride, nframes, d_kps, d_desc, cap, d_counts, (hipStream_t)stream);
 }
 
+// Single-frame host path (what Frame::ExtractORB -> operator() is in the reference): latency matters more than bandwidth
+// here.  The image goes up with ONE 1-D copy through a pinned staging buffer (a 2-D pageable copy of a 1241-byte-stride
+// image cost 2.5 ms on its own) and is used with the caller's stride; counts, keypoints and descriptors live in ONE
+// device block and come back with ONE copy into pinned memory.
 int orbx_extract(orbx_ctx* c, const uint8_t* img, int w, int h, int stride, orbx_keypoint* kps, uint8_t* desc32,
                  int cap, int* n) {
   ORBHIP_REQUIRE(c != nullptr, ORBHIP_EINVAL, "ctx is NULL");
   if (!img || w <= 0 || h <= 0) return 0;                       // empty image: silent return (:1046)
   ORBHIP_REQUIRE(kps && desc32 && n && cap > 0 && stride >= w, ORBHIP_EINVAL, "bad argument");
   ORBHIP_CHECK_HIP(hipSetDevice(c->device));
-  const int pitch = round_up(w, 64);
   const int icap = orbx_max_keypoints(c);
-  if (int rc = c->d_img.ensure((size_t)pitch * h)) return rc;
-  if (int rc = c->d_kps.ensure((size_t)icap * sizeof(orbx_keypoint))) return rc;
-  if (int rc = c->d_desc.ensure((size_t)icap * 32)) return rc;
-  if (int rc = c->d_counts.ensure(16)) return rc;
-  ORBHIP_CHECK_HIP(hipMemcpy2D(c->d_img.p, pitch, img, stride, w, h, hipMemcpyHostToDevice));
-  if (int rc = run_batch(c, c->d_img.as<uint8_t>(), w, h, pitch, (size_t)pitch * h, 1, c->d_kps.as<orbx_keypoint>(),
-                         c->d_desc.as<uint8_t>(), icap, c->d_counts.as<int32_t>(), 0))
+  const size_t img_bytes = (size_t)stride * (h - 1) + w;        // the caller owns exactly this span
+  const size_t off_kps = 64, off_desc = off_kps + (size_t)icap * sizeof(orbx_keypoint), out_bytes = off_desc + (size_t)icap * 32;
+  if (int rc = c->d_img.ensure((size_t)stride * h + 64)) return rc;
+  if (int rc = c->d_out.ensure(out_bytes)) return rc;
+  if (c->h_bytes < std::max(img_bytes, out_bytes)) {
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    c->h_pin = nullptr; c->h_bytes = 0;
+    const size_t want = std::max(img_bytes, out_bytes) * 5 / 4 + 4096;
+    ORBHIP_CHECK_HIP(hipHostMalloc(&c->h_pin, want, hipHostMallocDefault));
+    c->h_bytes = want;
+  }
+  std::memcpy(c->h_pin, img, img_bytes);
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(c->d_img.p, c->h_pin, img_bytes, hipMemcpyHostToDevice, 0));
+  uint8_t* dout = c->d_out.as<uint8_t>();
+  if (int rc = run_batch(c, c->d_img.as<uint8_t>(), w, h, stride, (size_t)stride * h, 1, (orbx_keypoint*)(dout + off_kps), dout + off_desc, icap,
+                         (int32_t*)dout, 0))
     return rc;
-  int32_t cnt = 0;
-  ORBHIP_CHECK_HIP(hipMemcpy(&cnt, c->d_counts.p, 4, hipMemcpyDeviceToHost));
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(c->h_pin, dout, out_bytes, hipMemcpyDeviceToHost, 0));
+  ORBHIP_CHECK_HIP(hipStreamSynchronize(0));
+  const int32_t cnt = *(const int32_t*)c->h_pin;
   if (cnt == -1) { set_error("candidate capacity exceeded (more than %d FAST corners in one pyramid level)", KEYCAP_MAX); return ORBHIP_EOVERFLOW; }
   ORBHIP_REQUIRE(cnt >= 0, ORBHIP_EOVERFLOW, "internal keypoint capacity exceeded");
   ORBHIP_REQUIRE(cnt <= cap, ORBHIP_ECAP, "output capacity too small");
   if (cnt > 0) {
-    ORBHIP_CHECK_HIP(hipMemcpy(kps, c->d_kps.p, (size_t)cnt * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
-    ORBHIP_CHECK_HIP(hipMemcpy(desc32, c->d_desc.p, (size_t)cnt * 32, hipMemcpyDeviceToHost));
+    std::memcpy(kps, (const uint8_t*)c->h_pin + off_kps, (size_t)cnt * sizeof(orbx_keypoint));
+    std::memcpy(desc32, (const uint8_t*)c->h_pin + off_desc, (size_t)cnt * 32);
   }
   *n = cnt;
   return 0;
