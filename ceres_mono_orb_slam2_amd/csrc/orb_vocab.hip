@@ -86,12 +86,12 @@ int orbv_create(const uint8_t* node_desc, const uint32_t* child_off, const uint3
                 const double* weight, int n_nodes, int L, int device, orbv_ctx** out) {
   ORBHIP_REQUIRE(node_desc && child_off && children && word_id && weight && out && n_nodes > 1 && L > 0, ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE(child_off[0] == 0 && child_off[1] > 0, ORBHIP_EINVAL, "the root (node 0) must have children");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
-  ORBHIP_REQUIRE(device >= 0 && device < ndev, ORBHIP_EINVAL, "bad device index");
   const uint32_t nchild = child_off[n_nodes];
   for (int i = 0; i < n_nodes; i++) ORBHIP_REQUIRE(child_off[i + 1] >= child_off[i] && child_off[i + 1] - child_off[i] <= 255, ORBHIP_EINVAL, "bad children table");
   for (uint32_t e = 0; e < nchild; e++) ORBHIP_REQUIRE(children[e] > 0 && children[e] < (uint32_t)n_nodes, ORBHIP_EINVAL, "child index out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+  ORBHIP_REQUIRE(device >= 0 && device < ndev, ORBHIP_EINVAL, "bad device index");
   VCHK(hipSetDevice(device));
   orbv_ctx* c = new orbv_ctx();
   c->device = device; c->n_nodes = n_nodes; c->L = L;

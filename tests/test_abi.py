@@ -81,3 +81,44 @@ def test_compat_shims_compile_and_link(lib, tmp_path):
            lib.LIB_PATH, "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     assert exe.exists()
+
+
+def test_new_entry_points_fail_loudly_without_gpu_and_validate_arguments(lib):
+    """The widened rows (Sim3, frame-side steps, vocabulary, triangulation, essential graph, batched BA) obey the same
+    contract: argument errors are ORBHIP_EINVAL before any device work, valid calls without a device are ORBHIP_ENODEV."""
+    import numpy as np
+    from ceres_mono_orb_slam2_amd import frame, optimizer, synth
+    from ceres_mono_orb_slam2_amd._lib import OrbHipError
+    from ceres_mono_orb_slam2_amd.vocabulary import ORBVocabulary
+    b = np.array([0, 640, 0, 480], np.float32)
+    k = np.zeros((10, 4), np.float32)
+    with pytest.raises(OrbHipError, match="no HIP device"):
+        frame.AssignFeaturesToGrid(k, b)
+    with pytest.raises(OrbHipError, match="no HIP device"):
+        frame.GetFeaturesInArea(k, b, np.zeros((3, 2), np.float32), np.ones(3, np.float32))
+    with pytest.raises(OrbHipError, match="no HIP device"):
+        frame.UndistortKeyPoints(np.zeros((4, 2), np.float32), [500, 500, 320, 240], [0.1, 0, 0, 0, 0])
+    assert np.array_equal(frame.UndistortKeyPoints(np.ones((4, 2), np.float32), [500, 500, 320, 240], [0, 0, 0, 0, 0]), np.ones((4, 2)))   # k1 == 0: host copy
+    voc = synth.make_vocabulary(0, k=3, L=2)
+    with pytest.raises(OrbHipError, match="no HIP device"):
+        ORBVocabulary(*[voc[x] for x in ("node_desc", "child_off", "children", "word_id", "weight", "L")])
+    bad = voc["children"].copy(); bad[0] = 10 ** 6
+    with pytest.raises(OrbHipError, match="child index out of range"):
+        ORBVocabulary(voc["node_desc"], voc["child_off"], bad, voc["word_id"], voc["weight"], voc["L"])
+    x0 = np.zeros((3, 7)); S = np.tile([0, 0, 0, 1, 0, 0, 0.0], (2, 1))
+    with pytest.raises(OrbHipError, match="edge vertex out of range"):
+        optimizer.optimize_essential_graph(x0, [1, 0, 0], [0, 5], [1, 2], S)
+    with pytest.raises(OrbHipError, match="no HIP device"):
+        optimizer.optimize_essential_graph(x0, [1, 0, 0], [0, 1], [1, 2], S)
+    p = synth.make_sim3_problem(0, n=20)
+    with pytest.raises(OrbHipError, match="no HIP device"):
+        optimizer.optimize_sim3(p["K1"], p["K2"], p["s12_0"], p["P3D2c"], p["obs1"], p["inv_sigma2_1"], p["P3D1c"], p["obs2"], p["inv_sigma2_2"])
+    g = synth.make_ba_graph(1, ncam=3, npts=20, nobs=60, n_fixed=1)
+    prob = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(3, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+    with pytest.raises(OrbHipError, match="no HIP device"):
+        optimizer.local_bundle_adjustment_batch([prob, prob])
+    badp = list(prob); badp[5] = g["obs_cam"].copy(); badp[5][0] = 99
+    with pytest.raises(OrbHipError, match="observation index out of range"):
+        optimizer.local_bundle_adjustment_batch([prob, tuple(badp)])
+    with pytest.raises(OrbHipError, match="octave out of range"):
+        frame.TriangulateMatches(np.eye(3, 4), np.eye(3, 4), [500, 500, 320, 240], [500, 500, 320, 240], [[1, 1, 9]], [[1, 1, 0]], np.ones(8), np.ones(8), 1.8)
