@@ -149,7 +149,9 @@ class OracleExtractor:
     def extract(self, img):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        cap = self.nfeatures + 4 * self.nlevels + 64
+        # per level at most max(quota + 3, 4 * nIni) keypoints (the first DistributeOctTree sweep splits all nIni = round(W/H)
+        # initial nodes unconditionally), so size for the aspect ratio as well
+        cap = self.nfeatures + (4 * max(1, int(round(w / max(h, 1)))) + 8) * self.nlevels + 64
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = self.L.orc_extract(self.h, _p(img), w, h, w, _p(kps), _p(desc), cap)
