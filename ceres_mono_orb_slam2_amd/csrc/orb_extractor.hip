@@ -98,11 +98,25 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     sx[j] = t.x & 0xFFFF; a0[j] = (int)(short)(t.x >> 16); a1[j] = (int)(short)t.y;
   }
   const int base = sx[0] & ~3;
-  const bool fast = ((spitch & 3) == 0) && ((((size_t)S0) & 3) == 0) && (base + 12 <= spitch) && (sx[3] + 1 - base < 12);
+  const bool window = (sx[3] + 1 - base < 12);
+  const bool fast = ((spitch & 3) == 0) && ((((size_t)S0) & 3) == 0) && (base + 12 <= spitch) && window;
+  // rows of any alignment (level 1 reads the caller's frames, e.g. a 1241-byte stride): four ALIGNED dwords re-cut with
+  // v_alignbyte give the same 12-byte window; base + 16 <= sw keeps every byte read inside the source row
+  const bool fast_unaligned = !fast && window && (base + 16 <= sw) && (base >= 4 || sy0 > 0 || f > 0);   // (the <= 3 bytes read before S0 + base stay inside the buffer)
   uint32_t out = 0;
-  if (fast) {
-    const uint32_t p0 = *(const uint32_t*)(S0 + base), p1 = *(const uint32_t*)(S0 + base + 4), p2 = *(const uint32_t*)(S0 + base + 8);
-    const uint32_t q0 = *(const uint32_t*)(S1 + base), q1 = *(const uint32_t*)(S1 + base + 4), q2 = *(const uint32_t*)(S1 + base + 8);
+  if (fast || fast_unaligned) {
+    uint32_t p0, p1, p2, q0, q1, q2;
+    if (fast) {
+      p0 = *(const uint32_t*)(S0 + base); p1 = *(const uint32_t*)(S0 + base + 4); p2 = *(const uint32_t*)(S0 + base + 8);
+      q0 = *(const uint32_t*)(S1 + base); q1 = *(const uint32_t*)(S1 + base + 4); q2 = *(const uint32_t*)(S1 + base + 8);
+    } else {
+      const uint8_t* a = S0 + base; const uint8_t* b = S1 + base;
+      const uint32_t sa = (uint32_t)((size_t)a & 3), sb = (uint32_t)((size_t)b & 3);
+      const uint32_t* pa = (const uint32_t*)(a - sa); const uint32_t* pb = (const uint32_t*)(b - sb);
+      const uint32_t a0d = pa[0], a1d = pa[1], a2d = pa[2], a3d = pa[3], b0d = pb[0], b1d = pb[1], b2d = pb[2], b3d = pb[3];
+      p0 = __builtin_amdgcn_alignbyte(a1d, a0d, sa); p1 = __builtin_amdgcn_alignbyte(a2d, a1d, sa); p2 = __builtin_amdgcn_alignbyte(a3d, a2d, sa);
+      q0 = __builtin_amdgcn_alignbyte(b1d, b0d, sb); q1 = __builtin_amdgcn_alignbyte(b2d, b1d, sb); q2 = __builtin_amdgcn_alignbyte(b3d, b2d, sb);
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (x4 + j < dw) {
