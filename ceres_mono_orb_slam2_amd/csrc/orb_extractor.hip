@@ -71,9 +71,10 @@ __device__ __forceinline__ const uint8_t* level_ptr(const GeomDev& G, int l, int
 }
 
 // ---------------------------------------------------------------------------- k_resize
-// xtab[dx] = {sx | a0 << 16, a1}: source column and the two fixed-point weights of output column dx.
+// xtab[dx] = {sx | a0 << 16, a0 | a1 << 16}: source column and the two fixed-point weights (0..2048) of output column dx.
 // Each thread produces 4 output pixels; their <= 7 distinct source columns per row come from three
 // aligned dwords when the source pitch allows (every level >= 1, and level 0 when stride % 4 == 0).
+typedef unsigned short ushort2_rs __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int byte_of(uint32_t w0, uint32_t w1, uint32_t w2, int k) {   // byte k of the 12-byte window
   const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : w2);
   return (w >> (8 * (k & 3))) & 255;
@@ -92,10 +93,11 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   const uint8_t* S1 = src + (long long)f * sframe + (long long)sy1 * spitch;
   const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
   int sx[4], a0[4], a1[4];
+  uint32_t wp[4];                                   // a0 | a1 << 16
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const uint2 t = xtab[min(x4 + j, dw - 1)];
-    sx[j] = t.x & 0xFFFF; a0[j] = (int)(short)(t.x >> 16); a1[j] = (int)(short)t.y;
+    sx[j] = t.x & 0xFFFF; a0[j] = (int)(t.y & 0xFFFF); a1[j] = (int)(t.y >> 16); wp[j] = t.y;
   }
   const int base = sx[0] & ~3;
   const bool window = (sx[3] + 1 - base < 12);
@@ -120,9 +122,15 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (x4 + j < dw) {
-        const int k0 = sx[j] - base, k1 = min(sx[j] + 1, sw - 1) - base;
-        const int H0 = byte_of(p0, p1, p2, k0) * a0[j] + byte_of(p0, p1, p2, k1) * a1[j];
-        const int H1 = byte_of(q0, q1, q2, k0) * a0[j] + byte_of(q0, q1, q2, k1) * a1[j];
+        // bytes k0, k0 + 1 of the 12-byte window as one u16 pair, times (a0, a1) with ONE v_dot2_u32_u16 per row.  At the right
+        // border the reference clamps the second column and its weight a1 is 0, so the byte after the row never matters.
+        const int k0 = sx[j] - base;
+        const bool hi = k0 >= 4, hi2 = k0 >= 8;
+        const uint32_t lo0 = hi2 ? p2 : (hi ? p1 : p0), up0 = hi2 ? 0u : (hi ? p2 : p1);
+        const uint32_t lo1 = hi2 ? q2 : (hi ? q1 : q0), up1 = hi2 ? 0u : (hi ? q2 : q1);
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(up0, lo0, (uint32_t)(k0 & 3)), w1 = __builtin_amdgcn_alignbyte(up1, lo1, (uint32_t)(k0 & 3));
+        const int H0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_rs, __builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), __builtin_bit_cast(ushort2_rs, wp[j]), 0u, false);
+        const int H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_rs, __builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), __builtin_bit_cast(ushort2_rs, wp[j]), 0u, false);
         const int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
         out |= (uint32_t)(v & 255) << (8 * j);
       }
@@ -935,7 +943,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
         std::vector<uint32_t> xt(2 * (size_t)dw);
         for (int dx = 0; dx < dw; dx++) {
           xt[2 * dx] = (uint32_t)(xofs[dx] & 0xFFFF) | ((uint32_t)(uint16_t)ia[2 * dx] << 16);
-          xt[2 * dx + 1] = (uint32_t)(uint16_t)ia[2 * dx + 1];
+          xt[2 * dx + 1] = (uint32_t)(uint16_t)ia[2 * dx] | ((uint32_t)(uint16_t)ia[2 * dx + 1] << 16);   // both weights, v_dot2 operand order
         }
         c->tab_xofs[l] = push(xt.data(), xt.size() * 4);
         c->tab_ialpha[l] = 0;
