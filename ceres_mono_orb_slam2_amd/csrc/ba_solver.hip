@@ -816,79 +816,126 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {      // lane 
   lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
   return __hiloint2double(hi, lo);
 }
-// 32x32 Cholesky of the block in s_L (lower) by one wave: lane r keeps row r in registers; the pivot and the
-// pivot column are broadcast with v_readlane.  Returns 1 on a non-positive pivot.
+// 32x32 Cholesky of the block in s_L (lower) by one wave: lane r keeps row r in registers.  Column j, once scaled, is
+// written to LDS (s_T[j][r]) and comes back to every lane as b128 BROADCAST reads for the rank-1 update; only the two
+// values on the critical path - the pivot and the pivot row's own entry l(j+1, j) - travel by v_readlane, so the
+// rsqrt chain of column j+1 overlaps the LDS round trip of column j.  (The first version broadcast every l(c, j) with
+// v_readlane: 1552 readlanes + 496 SGPR spills, 10.2 us; this one 5.3 us, tools/ubench/chol_panel.hip.)
+// A non-positive / non-finite pivot poisons the rest of the block (NaN) and is reported; the caller discards the step.
 // 1/sqrt(x) in fp64: hardware v_rsq_f64 estimate + two Newton steps (~1 ulp); avoids the long fp64 sqrt + divide
 // sequences on the 32-step critical path of the diagonal factorisation.
 __device__ __forceinline__ double rsqrt_f64(double x) {
+  // y += y * (0.5 - (x/2) y^2) with explicit fmas: 3 dependent operations per step (the file is built with
+  // -ffp-contract=off, so the textbook y * (1.5 - 0.5 x y y) would be 5 dependent multiplies / subtracts)
+  const double hx = 0.5 * x;
   double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
+  double r = fma(-(hx * y), y, 0.5);
+  y = fma(y, r, y);
+  r = fma(-(hx * y), y, 0.5);
+  y = fma(y, r, y);
   return y;
 }
-__device__ __noinline__ int diag_factor_wave(double (*s_L)[NB + 1], double* s_dinv) {
+__device__ __forceinline__ int diag_factor_wave(double (*s_L)[NB + 1], double (*s_T)[NB], double* s_dinv) {
   const int r = threadIdx.x & 31;
   double row[NB];
 #pragma unroll
   for (int c = 0; c < NB; c++) row[c] = s_L[r][c];
-  int fail = 0;
+  int bad = 0;
 #pragma unroll
   for (int j = 0; j < NB; j++) {
-    double piv = bcast_lane(row[j], j);
-    if (!(piv > 0.0) || !isfinite(piv)) { fail = 1; piv = 1.0; }
+    const double piv = bcast_lane(row[j], j);
+    bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
     const double dinv = rsqrt_f64(piv);
     if (threadIdx.x == j) s_dinv[j] = dinv;
-    row[j] = (r == j) ? piv * dinv : row[j] * dinv;
-    // rank-1 update; lanes r < c write don't-care values above the diagonal (never read back into the factor)
+    row[j] = row[j] * dinv;                               // lane j: piv * dinv = sqrt(piv)
+    s_T[j][r] = row[j];
+    if (j + 1 < NB) { const double l = bcast_lane(row[j], j + 1); row[j + 1] = fma(-row[j], l, row[j + 1]); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int c = j + 2;
+    if (c < NB && (c & 1)) { const double l = s_T[j][c]; row[c] = fma(-row[j], l, row[c]); c++; }
 #pragma unroll
-    for (int c = j + 1; c < NB; c++) {
-      const double lcj = bcast_lane(row[j], c);
-      row[c] = fma(-row[j], lcj, row[c]);
-      if (((c - j) & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // keep the v_readlane results short-lived (SGPR pressure)
+    for (; c + 1 < NB; c += 2) {
+      const double2 l = *(const double2*)&s_T[j][c];
+      row[c] = fma(-row[j], l.x, row[c]);
+      row[c + 1] = fma(-row[j], l.y, row[c + 1]);
     }
   }
   if (threadIdx.x < NB) {
 #pragma unroll
     for (int c = 0; c < NB; c++) s_L[r][c] = (c <= r) ? row[c] : 0.0;
   }
-  return fail;
+  return bad;
 }
-// inverse of the lower-triangular block in s_L into s_X: lane c solves L x = e_c with x in registers
-__device__ __noinline__ void diag_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1], const double* s_dinv) {
-  const int c = threadIdx.x & 31;
-  double x[NB];
+// X = L^-1 in 16x16 blocks: the diagonal blocks X11 = L11^-1 and X22 = L22^-1 by lanes (lane = one column of one block,
+// a 120-term substitution instead of 496), then X21 = -X22 (L21 X11) as two 16x16x16 products on the FP64 matrix cores
+// (5.9 -> 2.3 us).
+__device__ __forceinline__ void diag_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1], double (*s_T)[NB], const double* s_dinv) {
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 15, b = lane & 16;
+  {
+    double x[16];
 #pragma unroll
-  for (int rr = 0; rr < NB; rr++) {
-    double sum = (rr == c) ? 1.0 : 0.0;
+    for (int rr = 0; rr < 16; rr++) {
+      double sum = (rr == c) ? 1.0 : 0.0;
 #pragma unroll
-    for (int m = 0; m < rr; m++) sum = fma(-s_L[rr][m], x[m], sum);
-    x[rr] = sum * s_dinv[rr];
+      for (int m = 0; m < rr; m++) sum = fma(-s_L[b + rr][b + m], x[m], sum);
+      x[rr] = sum * s_dinv[b + rr];
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) { s_X[b + rr][b + c] = x[rr]; if (b == 0) s_X[rr][16 + c] = 0.0; }
+    }
   }
-  if (threadIdx.x < NB) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  const int li = lane & 15, lk = lane >> 4;                 // MFMA operands: A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15]
+  double4_t t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int rr = 0; rr < NB; rr++) s_X[rr][c] = x[rr];
-  }
+  for (int ks = 0; ks < 4; ks++) t = __builtin_amdgcn_mfma_f64_16x16x4f64(s_L[16 + li][4 * ks + lk], s_X[4 * ks + lk][li], t, 0, 0, 0);
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) s_T[lk + 4 * rg][li] = t[rg];     // C layout: row = (lane >> 4) + 4 * reg, col = lane & 15
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  double4_t u = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) u = __builtin_amdgcn_mfma_f64_16x16x4f64(s_X[16 + li][16 + 4 * ks + lk], s_T[4 * ks + lk][li], u, 0, 0, 0);
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) s_X[16 + lk + 4 * rg][li] = -u[rg];
 }
 __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv, int k) {
   const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
-  if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_L[NB][NB + 1];
   __shared__ double s_X[NB][NB + 1];
   __shared__ double s_dinv[NB];
+  __shared__ __attribute__((aligned(16))) double s_T[NB][NB];   // factor: column broadcast buffer; inverse: L21 X11
   __shared__ int s_fail;
   const int np = D.npad, tid = threadIdx.x;
   if (k >= np || k + NB + (int)blockIdx.x * 64 > np) return;     // beyond this problem's matrix (batched launch)
   double* S = D.S;
-  for (int i = tid; i < NB * NB; i += 256) { int r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0; }
+  // this wave's 16 rows of A21 do not depend on the diagonal factor: their loads are issued first and land while wave 0 factors
+  const int w = tid >> 6, lane = tid & 63;
+  const int row0 = k + NB + (blockIdx.x * 4 + w) * 16;
+  const int li = lane & 15, lk = lane >> 4;
+  const int arow = row0 + li;
+  const bool rvalid = arow <= np;
+  double a[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) a[ks] = rvalid ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
+  double d4[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; d4[u] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0; }
+  // (the state flags are read AFTER the matrix loads are in flight: one dependent global round trip less per launch;
+  // S is a valid allocation for finished problems too)
+  if (st->done || !st->valid || st->chol_fail) return;
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; s_L[i / NB][i % NB] = d4[u]; }
   if (tid == 0) s_fail = 0;
   __syncthreads();
   if (tid < 64) {
-    const int fail = diag_factor_wave(s_L, s_dinv);
+    const int fail = diag_factor_wave(s_L, s_T, s_dinv);
     if (fail && tid == 0) s_fail = 1;
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    diag_invert_wave(s_L, s_X, s_dinv);
+    diag_invert_wave(s_L, s_X, s_T, s_dinv);
   }
   __syncthreads();
   if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
@@ -901,15 +948,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
     }
   }
   // ---- L21 rows: X = A * Linv^T on the matrix cores --------------------------------------------------
-  const int w = tid >> 6, lane = tid & 63;
-  const int row0 = k + NB + (blockIdx.x * 4 + w) * 16;
   if (row0 > np) return;
-  const int li = lane & 15, lk = lane >> 4;
-  const int arow = row0 + li;
-  const bool rvalid = arow <= np;
-  double a[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ks++) a[ks] = rvalid ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
   double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int ks = 0; ks < 8; ks++) {
@@ -936,7 +975,6 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
 __global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
-  if (st->done || !st->valid || st->chol_fail) return;
   __shared__ double s_A[64][NB + 1], s_B[64][NB + 1];
   const int np = D.npad, tid = threadIdx.x;
   // batched launch: the grid and (kcol, K, r_lo, c_lo, c_hi_cap) are laid out for the LARGEST reduced system of the batch;
@@ -945,6 +983,7 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv,
   if (kcol + K > np || c_hi <= c_lo) return;
   double* S = D.S;
   if ((int)blockIdx.x >= ntiles) {           // augmented rhs row
+    if (st->done || !st->valid || st->chol_fail) return;
     double* zrow = S + (size_t)np * np;
     double* s_z = &s_A[0][0];
     for (int i = tid; i < K; i += 256) s_z[i] = zrow[kcol + i];
@@ -970,13 +1009,38 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv,
 #pragma unroll
     for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const int li = lane & 15, lk = lane >> 4;                   // A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15]
+  // the first K stage and this lane's C entries are requested before the state flags are looked at (one dependent
+  // global round trip less per launch), and C no longer waits for the matrix-core loop to finish
+  double va[8], vb[8], cpre[2][2][4];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int i = tid + 256 * u, r = i / NB, c = i % NB;
+    va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + c] : 0.0;
+    vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol + c] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
+        const int col = c0 + qc + 16 * j + (lane & 15);
+        cpre[i][j][rg] = (!qskip && row < np && col < c_hi && col <= row) ? S[(size_t)row * np + col] : 0.0;
+      }
+  if (st->done || !st->valid || st->chol_fail) return;
   for (int k0 = 0; k0 < K; k0 += NB) {
     __syncthreads();
-    for (int i = tid; i < 64 * NB; i += 256) {
-      const int r = i / NB, c = i % NB;
-      s_A[r][c] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + k0 + c] : 0.0;
-      s_B[r][c] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol + k0 + c] : 0.0;
+    if (k0 > 0) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = tid + 256 * u, r = i / NB, c = i % NB;
+        va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + k0 + c] : 0.0;
+        vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol + k0 + c] : 0.0;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
     __syncthreads();
     if (!qskip) {
 #pragma unroll
@@ -1003,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv,
       for (int rg = 0; rg < 4; rg++) {
         const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
         const int col = c0 + qc + 16 * j + (lane & 15);
-        if (row < np && col < c_hi && col <= row) S[(size_t)row * np + col] -= acc[i][j][rg];
+        if (row < np && col < c_hi && col <= row) S[(size_t)row * np + col] = cpre[i][j][rg] - acc[i][j][rg];
       }
 }
 
