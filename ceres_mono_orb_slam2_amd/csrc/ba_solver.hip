@@ -734,30 +734,53 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(const BaDev* __res
   }
 }
 
-// ---- reduced camera system S = B_s + D - sum E (C_s+D)^-1 E^T: one wave per non-empty block pair
-// (a <= b).  Lane (u,v) of the first 36 lanes owns one element and walks the block's pair list in its
-// fixed (host-built) order, so the sum is deterministic; lanes 36..41 of a diagonal block build rhs.
+// ---- reduced camera system S = B_s + D - sum E (C_s+D)^-1 E^T over the non-empty block pairs (a <= b) ----------------
+// One workgroup per block; the pair lists are long (C4 graph: 100 diagonal blocks of 90..600 pairs, 903 off-diagonal blocks,
+// mean 127, max 493 pairs), so the work is laid out one PAIR per thread: the 36 (diagonal: 21 lower-triangle) products
+// accumulate in registers and one fixed-order block reduction finishes the block - two dependent loads (index -> record)
+// per thread instead of a serial walk.  Workgroups 0..nfc-1 own the diagonal blocks and also build the rhs.
+// Tried: element-per-lane walks of the list (7 groups x 36 lanes: 52 us; one wave per block, 8 pairs in flight: 68 us).
 __global__ __launch_bounds__(256) void k_ba_schur(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const int* __restrict__ free_cams = D.free_cams;
   const BaState* st = D.st;
   if (st->done || !st->valid) return;
-  __shared__ double s_part[7][36];
   const int tid = threadIdx.x;
-  const int blk = blockIdx.x;
-  if (blk >= D.nblk) return;
-  const int a = D.blk_a[blk], b = D.blk_b[blk];
   const int np = D.npad;
-  const int grp = tid / 36, el = tid - 36 * grp;          // 7 groups x 36 elements (threads 252..255: rhs helpers)
-  if (a == b) {
-    // diagonal block: its pair list is (at least) every observation of the camera - hundreds of pairs.  One pair per thread
-    // with the 21 lower-triangle products in registers and ONE block reduction; the 7-group walk below would chain
-    // ~70 dependent index -> record loads per group (it bounded the whole launch: 52 us at C4 size).
+  if ((int)blockIdx.x >= D.nblk) return;
+  if ((int)blockIdx.x >= D.nfc) {
+    // off-diagonal block (a, b): one pair per thread, all 36 products in registers, one block reduction
+    __shared__ double s_o[4 * 36], s_oo[36];
+    const int blk = blockIdx.x;
+    const int a = D.blk_a[blk], b = D.blk_b[blk];
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+    for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += 256) {
+      const double* ec = D.EC + 18 * (size_t)D.pair_i[e];
+      const double* eb = D.E + 18 * (size_t)D.pair_j[e];
+      double x[18], y[18];
+#pragma unroll
+      for (int k = 0; k < 18; k++) { x[k] = ec[k]; y[k] = eb[k]; }
+#pragma unroll
+      for (int u = 0; u < 6; u++)
+#pragma unroll
+        for (int v = 0; v < 6; v++) acc[6 * u + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
+    }
+    block_reduce<36>(acc, s_o, s_oo);
+    if (tid < 36) {
+      const int u = tid / 6, v = tid - 6 * u;
+      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -s_oo[tid];                 // lower triangle: block (b, a) = -(acc)^T
+    }
+    return;
+  }
+  const int blk = blockIdx.x, a = blk;                     // diagonal block (a, a)
+  {
     __shared__ double s_d[4 * 21], s_do[21];
     double acc[21];
 #pragma unroll
     for (int k = 0; k < 21; k++) acc[k] = 0.0;
-    for (int e = D.blk_off[blk] + tid; e < D.blk_off[blk + 1]; e += 256) {
+    for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += 256) {
       const double* ec = D.EC + 18 * (size_t)D.pair_i[e];
       const double* eb = D.E + 18 * (size_t)D.pair_j[e];
       double x[18], y[18];
@@ -778,33 +801,8 @@ __global__ __launch_bounds__(256) void k_ba_schur(const BaDev* __restrict__ Dv) 
       if (u == v) bs += fmin(fmax(bs, 1e-6), 1e32) / st->radius;
       D.S[(size_t)(6 * a + u) * np + 6 * a + v] = bs - s_do[tid];
     }
-  } else if (grp < 7) {
-    const int u = el / 6, v = el - 6 * u;
-    double acc0 = 0.0, acc1 = 0.0;
-    const int lo = D.blk_off[blk], hi = D.blk_off[blk + 1];
-    int e = lo + grp;
-    for (; e + 7 < hi; e += 14) {                           // two independent pairs in flight
-      const double* ec0 = D.EC + 18 * (size_t)D.pair_i[e] + 3 * u;
-      const double* eb0 = D.E + 18 * (size_t)D.pair_j[e] + 3 * v;
-      const double* ec1 = D.EC + 18 * (size_t)D.pair_i[e + 7] + 3 * u;
-      const double* eb1 = D.E + 18 * (size_t)D.pair_j[e + 7] + 3 * v;
-      acc0 += ec0[0] * eb0[0] + ec0[1] * eb0[1] + ec0[2] * eb0[2];
-      acc1 += ec1[0] * eb1[0] + ec1[1] * eb1[1] + ec1[2] * eb1[2];
-    }
-    if (e < hi) {
-      const double* ec0 = D.EC + 18 * (size_t)D.pair_i[e] + 3 * u;
-      const double* eb0 = D.E + 18 * (size_t)D.pair_j[e] + 3 * v;
-      acc0 += ec0[0] * eb0[0] + ec0[1] * eb0[1] + ec0[2] * eb0[2];
-    }
-    s_part[grp][el] = acc0 + acc1;
   }
-  __syncthreads();
-  if (a != b && tid < 36) {
-    const int u = tid / 6, v = tid - 6 * u;
-    const double acc = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + ((s_part[4][tid] + s_part[5][tid]) + s_part[6][tid]);
-    D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -acc;             // lower triangle: block (b, a) = -(acc)^T
-  }
-  if (a == b) {
+  {
     // rhs_a = g_s - sum over the camera's observations of EC_i * g_p: all threads, fixed tree
     __shared__ double s_r[4 * 6], s_ro[6];
     const int ca = free_cams[a];
@@ -1765,15 +1763,19 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
           if (cj >= ci) { const int e = pos[(size_t)ci * nfc + cj]++; pair_i[e] = i; pair_j[e] = j; }
         }
       }
-    blk_off.push_back(0);
+    // block list: the nfc diagonal blocks first (one workgroup each), then the non-empty off-diagonal blocks in (a, b) order
+    // (one wave each); blk_off holds {lo, hi} of every block's run in the pair arrays
+    for (int a = 0; a < nfc; a++) {
+      const size_t k = (size_t)a * nfc + a;
+      blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(cnt[k]); blk_off.push_back(cnt[k + 1]);
+    }
     for (int a = 0; a < nfc; a++)
-      for (int b2 = a; b2 < nfc; b2++) {
+      for (int b2 = a + 1; b2 < nfc; b2++) {
         const size_t k = (size_t)a * nfc + b2;
-        if (cnt[k + 1] > cnt[k] || a == b2) { blk_a.push_back(a); blk_b.push_back(b2); blk_off.push_back(cnt[k + 1]); }
+        if (cnt[k + 1] > cnt[k]) { blk_a.push_back(a); blk_b.push_back(b2); blk_off.push_back(cnt[k]); blk_off.push_back(cnt[k + 1]); }
       }
   } else {
-    blk_off.push_back(0);
-    for (int a = 0; a < nfc; a++) { blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(0); }
+    for (int a = 0; a < nfc; a++) { blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(0); blk_off.push_back(0); }
   }
   const int nblk = (int)blk_a.size();
   out->t_struct_ms = ba_now_ms() - t_start;
@@ -1790,7 +1792,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.cam_obs = H.upload(cam_obs, nobs, &rc, s); D.cam_obs_pt = H.upload(cam_obs_pt, nobs, &rc, s);
   D.cam_pos = H.upload(cam_pos, nobs, &rc, s); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
   D.free_cams = H.upload(free_cams.data(), nfc, &rc, s);
-  D.blk_a = H.upload(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload(blk_off.data(), nblk + 1, &rc, s);
+  D.blk_a = H.upload(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload(blk_off.data(), 2 * (size_t)nblk, &rc, s);
   D.pair_i = H.upload(pair_i, npairs_all, &rc, s); D.pair_j = H.upload(pair_j, npairs_all, &rc, s);
   D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jc = H.alloc<double>(12 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
   D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
