@@ -75,6 +75,38 @@ __device__ __forceinline__ void block_reduce_wide(double (&acc)[V], double* s_re
   __syncthreads();
 }
 
+// Wave sum on the VALU only (DPP row permutations + row broadcasts, no LDS crossbar): 6 steps x (2 v_mov_dpp + v_add_f64).
+// The __shfl_xor tree costs 12 ds_bpermute per value; with 36 values per thread the LDS pipe, not the loads, bounded
+// k_ba_schur.  Fixed order: quads, 8, 16 inside each row of 16 lanes, then rows (0+1), (2+3), ((2+3)+(0+1)); the total is
+// valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_take<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xF>(v);     // row_half_mirror
+  v += dpp_take<0x140, 0xF>(v);     // row_mirror: every lane of a row holds the row total
+  v += dpp_take<0x142, 0xA>(v);     // row_bcast15 into rows 1 and 3
+  v += dpp_take<0x143, 0xC>(v);     // row_bcast31 into rows 2 and 3
+  return v;
+}
+template <int V>
+__device__ __forceinline__ void block_reduce_dpp(double (&acc)[V], double* s_red /*[(blockDim.x/64)*V]*/, double* s_out /*[V]*/) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const double t = wave_sum_dpp(acc[k]);
+    if (lane == 63) s_red[w * V + k] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < V) { double t = 0.0; for (int i = 0; i < nw; i++) t += s_red[i * V + threadIdx.x]; s_out[threadIdx.x] = t; }
+  __syncthreads();
+}
+
 // in-place Cholesky + solve of a tiny SPD system (n <= 6), row-major; returns false if not PD
 __device__ bool small_chol_solve(double* A, double* b, int n) {
   for (int j = 0; j < n; j++) {
@@ -740,23 +772,24 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(const BaDev* __res
 // accumulate in registers and one fixed-order block reduction finishes the block - two dependent loads (index -> record)
 // per thread instead of a serial walk.  Workgroups 0..nfc-1 own the diagonal blocks and also build the rhs.
 // Tried: element-per-lane walks of the list (7 groups x 36 lanes: 52 us; one wave per block, 8 pairs in flight: 68 us).
-__global__ __launch_bounds__(256) void k_ba_schur(const BaDev* __restrict__ Dv) {
+#define SC_TPB 256
+__global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const int* __restrict__ free_cams = D.free_cams;
   const BaState* st = D.st;
   if (st->done || !st->valid) return;
   const int tid = threadIdx.x;
   const int np = D.npad;
+  __shared__ double s_red[16 * 36], s_out[36];
   if ((int)blockIdx.x >= D.nblk) return;
   if ((int)blockIdx.x >= D.nfc) {
     // off-diagonal block (a, b): one pair per thread, all 36 products in registers, one block reduction
-    __shared__ double s_o[4 * 36], s_oo[36];
     const int blk = blockIdx.x;
     const int a = D.blk_a[blk], b = D.blk_b[blk];
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += 256) {
+    for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += SC_TPB) {
       const double* ec = D.EC + 18 * (size_t)D.pair_i[e];
       const double* eb = D.E + 18 * (size_t)D.pair_j[e];
       double x[18], y[18];
@@ -767,59 +800,54 @@ __global__ __launch_bounds__(256) void k_ba_schur(const BaDev* __restrict__ Dv) 
 #pragma unroll
         for (int v = 0; v < 6; v++) acc[6 * u + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
     }
-    block_reduce<36>(acc, s_o, s_oo);
+    block_reduce_dpp<36>(acc, s_red, s_out);
     if (tid < 36) {
       const int u = tid / 6, v = tid - 6 * u;
-      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -s_oo[tid];                 // lower triangle: block (b, a) = -(acc)^T
+      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -s_out[tid];                 // lower triangle: block (b, a) = -(acc)^T
     }
     return;
   }
-  const int blk = blockIdx.x, a = blk;                     // diagonal block (a, a)
-  {
-    __shared__ double s_d[4 * 21], s_do[21];
-    double acc[21];
+  // diagonal block (a, a): 21 lower-triangle products per pair, and the rhs of camera a
+  //   rhs_a = g_s - sum over the camera's observations of EC_i * g_p
+  // both sums are accumulated first and share ONE block reduction (27 values)
+  const int blk = blockIdx.x, a = blk;
+  double acc[27];
 #pragma unroll
-    for (int k = 0; k < 21; k++) acc[k] = 0.0;
-    for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += 256) {
-      const double* ec = D.EC + 18 * (size_t)D.pair_i[e];
-      const double* eb = D.E + 18 * (size_t)D.pair_j[e];
-      double x[18], y[18];
+  for (int k = 0; k < 27; k++) acc[k] = 0.0;
+  for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += SC_TPB) {
+    const double* ec = D.EC + 18 * (size_t)D.pair_i[e];
+    const double* eb = D.E + 18 * (size_t)D.pair_j[e];
+    double x[18], y[18];
 #pragma unroll
-      for (int k = 0; k < 18; k++) { x[k] = ec[k]; y[k] = eb[k]; }
+    for (int k = 0; k < 18; k++) { x[k] = ec[k]; y[k] = eb[k]; }
 #pragma unroll
-      for (int u = 0; u < 6; u++)
+    for (int u = 0; u < 6; u++)
 #pragma unroll
-        for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
-    }
-    block_reduce<21>(acc, s_d, s_do);
-    if (tid < 21) {
-      int u = 0;
-      while ((u + 1) * (u + 2) / 2 <= tid) u++;
-      const int v = tid - u * (u + 1) / 2;
-      const double* sc = D.scale_c + 6 * (size_t)a;
-      double bs = D.B[21 * (size_t)a + sym6(u, v)] * sc[u] * sc[v];
-      if (u == v) bs += fmin(fmax(bs, 1e-6), 1e32) / st->radius;
-      D.S[(size_t)(6 * a + u) * np + 6 * a + v] = bs - s_do[tid];
+      for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
+  }
+  if (!D.fix_points) {
+    const int ca = free_cams[a];
+    for (int e = D.cam_off[ca] + tid; e < D.cam_off[ca + 1]; e += SC_TPB) {
+      const double* ec = D.EC + 18 * (size_t)D.cam_obs[e];
+      const double* g = D.gps + 3 * (size_t)D.cam_obs_pt[e];
+#pragma unroll
+      for (int u = 0; u < 6; u++) acc[21 + u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
     }
   }
-  {
-    // rhs_a = g_s - sum over the camera's observations of EC_i * g_p: all threads, fixed tree
-    __shared__ double s_r[4 * 6], s_ro[6];
-    const int ca = free_cams[a];
-    double racc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (!D.fix_points)
-      for (int e = D.cam_off[ca] + tid; e < D.cam_off[ca + 1]; e += 256) {
-        const double* ec = D.EC + 18 * (size_t)D.cam_obs[e];
-        const double* g = D.gps + 3 * (size_t)D.cam_obs_pt[e];
-#pragma unroll
-        for (int u = 0; u < 6; u++) racc[u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
-      }
-    block_reduce<6>(racc, s_r, s_ro);
-    if (tid < 6) {
-      const double rv = D.gc[6 * (size_t)a + tid] * D.scale_c[6 * (size_t)a + tid] - s_ro[tid];
-      D.rhs[6 * a + tid] = rv;
-      D.S[(size_t)np * np + 6 * a + tid] = rv;                      // augmented row: forward substitution rides the factorisation
-    }
+  block_reduce_dpp<27>(acc, s_red, s_out);
+  if (tid < 21) {
+    int u = 0;
+    while ((u + 1) * (u + 2) / 2 <= tid) u++;
+    const int v = tid - u * (u + 1) / 2;
+    const double* sc = D.scale_c + 6 * (size_t)a;
+    double bs = D.B[21 * (size_t)a + sym6(u, v)] * sc[u] * sc[v];
+    if (u == v) bs += fmin(fmax(bs, 1e-6), 1e32) / st->radius;
+    D.S[(size_t)(6 * a + u) * np + 6 * a + v] = bs - s_out[tid];
+  } else if (tid < 27) {
+    const int u = tid - 21;
+    const double rv = D.gc[6 * (size_t)a + u] * D.scale_c[6 * (size_t)a + u] - s_out[tid];
+    D.rhs[6 * a + u] = rv;
+    D.S[(size_t)np * np + 6 * a + u] = rv;                          // augmented row: forward substitution rides the factorisation
   }
 }
 
@@ -1859,7 +1887,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     hipLaunchKernelGGL(k_ba_schur_prep, dim3(g_pt, ny), dim3(BA_TPB), 0, s, Dv);
     hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
     if (g_n6 > 0) hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)((g_zero + 255) / 256)), ny), dim3(256), 0, s, Dv);
-    if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(256), 0, s, Dv);
+    if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), 0, s, Dv);
     auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
       if (c_hi <= c_lo || r_lo >= npad + 1) return;
       const int tiles_r = (npad - r_lo + 63) / 64, tiles_c = (c_hi - c_lo + 63) / 64;
