@@ -1692,7 +1692,12 @@ static hipStream_t thread_stream() {
   return g_stream;
 }
 
+// the workspace of this thread still holds the complete prepared batch of the last ba_solve_batch_impl call (structure
+// arrays, block lists, workspace, final poses / points): LocalBA's second pass solves the SAME observation set and
+// reuses it.  Every new walk over the workspace slots (any HostBA) invalidates it.
+static thread_local bool g_batch_valid = false;
 struct HostBA {
+  HostBA() { g_batch_valid = false; }
   size_t next = 0, hnext = 0;
   // pinned host staging (reused across calls): structure arrays are built straight into it so that the
   // H2D copies are true async DMA and never touch freshly mmap'ed pageable pages
@@ -1722,7 +1727,12 @@ struct BaInputs {
   const double* K4; double* poses7; const uint8_t* cam_fixed; int ncam; double* pts3; int npts;
   const int32_t* obs_cam; const int32_t* obs_pt; const double* obs_uv; const double* obs_w; const uint8_t* obs_robust; int nobs;
 };
-struct BaPrepared { BaDev D; int nb_obs, nb_cam, nb_pt; size_t npairs; double t_struct_ms; };
+struct BaPrepared { BaDev D; int nb_obs, nb_cam, nb_pt; size_t npairs; double t_struct_ms; std::vector<int> perm; uint8_t* h_rob; };
+struct BaBatch {
+  std::vector<BaPrepared> P; std::vector<BaDev> Dh; const BaDev* Dv = nullptr;
+  int g_obs, g_cam, g_pt, g_blk, g_npad, g_pad, g_n6, g_camcount, g_apply; size_t g_zero;
+};
+static thread_local BaBatch g_batch;
 
 static double ba_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -1840,6 +1850,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)npad * sizeof(double), s));
   ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)nparts * sizeof(double), s));
   out->D = D; out->nb_obs = nb_obs; out->nb_cam = nb_cam; out->nb_pt = nb_pt; out->npairs = npairs_all;
+  out->perm.swap(perm); out->h_rob = orb;
   return 0;
 }
 
@@ -1848,7 +1859,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
 // One LM iteration is a fixed sequence of ~60 launches: it is captured once into a hipGraph and replayed (one graph
 // launch per iteration); instantiated graphs are cached per host thread, keyed by the full kernel-argument blocks
 // (sizes and workspace pointers), so repeated solves of the same shape skip the capture too.  ORBHIP_BA_GRAPH=0 = direct.
-static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* opts, ba_summary* summaries) {
+static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* opts, ba_summary* summaries, bool reuse_structure = false) {
   ORBHIP_REQUIRE(in && opts && nprob > 0, ORBHIP_EINVAL, "NULL argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
@@ -1856,22 +1867,52 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   const bool timing = std::getenv("ORBHIP_BA_TIMING") != nullptr;
   const double t_start = ba_now_ms();
   hipStream_t s = thread_stream();
-  HostBA H; int rc = 0;
-  std::vector<BaPrepared> P(nprob);
-  std::vector<BaDev> Dh(nprob);
-  int g_obs = 1, g_cam = 1, g_pt = 1, g_blk = 0, g_npad = NB, g_pad = 0, g_n6 = 0, g_camcount = 1, g_apply = 1;
-  size_t g_zero = 0;
-  for (int p = 0; p < nprob; p++) {
-    if (int r = ba_prepare(H, s, in[p], opts, &P[p])) return r;
-    const BaDev& D = P[p].D;
-    Dh[p] = D;
-    g_obs = std::max(g_obs, P[p].nb_obs); g_cam = std::max(g_cam, P[p].nb_cam); g_pt = std::max(g_pt, P[p].nb_pt);
-    g_blk = std::max(g_blk, D.nblk); g_npad = std::max(g_npad, D.npad); g_pad = std::max(g_pad, D.npad - D.n6); g_n6 = std::max(g_n6, D.n6);
-    g_camcount = std::max(g_camcount, D.ncam); g_apply = std::max(g_apply, std::max(7 * D.ncam, 3 * D.npts));
-    g_zero = std::max(g_zero, (size_t)D.n6 * D.npad);
+  int rc = 0;
+  BaBatch& B = g_batch;
+  bool reused = false;
+  if (reuse_structure && g_batch_valid && (int)B.P.size() == nprob) {
+    // same cameras, points and observation lists as the batch still resident in this thread's workspace (the caller
+    // guarantees it; sizes are re-checked): only the loss flags and the iteration cap change, the solve starts from the
+    // poses / points the previous solve left on the device.  No structure pass, no pair lists, no uploads but the flags.
+    reused = true;
+    for (int p = 0; p < nprob; p++)
+      reused = reused && B.Dh[p].ncam == in[p].ncam && B.Dh[p].npts == in[p].npts && B.Dh[p].nobs == in[p].nobs && B.Dh[p].fix_points == (opts->fix_points ? 1 : 0);
   }
-  const BaDev* Dv = H.upload(Dh.data(), nprob, &rc, s);
-  if (rc) return rc;
+  if (reused) {
+    for (int p = 0; p < nprob; p++) {
+      const BaDev& D = B.Dh[p];
+      BaPrepared& Pp = B.P[p];
+      for (int j = 0; j < D.nobs; j++) Pp.h_rob[j] = in[p].obs_robust[Pp.perm[j]];
+      if (D.nobs) ORBHIP_CHECK_HIP(hipMemcpyAsync(const_cast<unsigned char*>(D.obs_robust), Pp.h_rob, D.nobs, hipMemcpyHostToDevice, s));
+      BaState st0; std::memset(&st0, 0, sizeof(st0));
+      st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = opts->max_iterations;
+      ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
+      ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)D.npad * sizeof(double), s));
+      ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)D.nparts * sizeof(double), s));
+      Pp.t_struct_ms = 0.0;
+    }
+  } else {
+    HostBA H;                                             // (invalidates the resident batch)
+    B.P.assign(nprob, BaPrepared()); B.Dh.assign(nprob, BaDev());
+    B.g_obs = 1; B.g_cam = 1; B.g_pt = 1; B.g_blk = 0; B.g_npad = NB; B.g_pad = 0; B.g_n6 = 0; B.g_camcount = 1; B.g_apply = 1; B.g_zero = 0;
+    for (int p = 0; p < nprob; p++) {
+      if (int r = ba_prepare(H, s, in[p], opts, &B.P[p])) return r;
+      const BaDev& D = B.P[p].D;
+      B.Dh[p] = D;
+      B.g_obs = std::max(B.g_obs, B.P[p].nb_obs); B.g_cam = std::max(B.g_cam, B.P[p].nb_cam); B.g_pt = std::max(B.g_pt, B.P[p].nb_pt);
+      B.g_blk = std::max(B.g_blk, D.nblk); B.g_npad = std::max(B.g_npad, D.npad); B.g_pad = std::max(B.g_pad, D.npad - D.n6); B.g_n6 = std::max(B.g_n6, D.n6);
+      B.g_camcount = std::max(B.g_camcount, D.ncam); B.g_apply = std::max(B.g_apply, std::max(7 * D.ncam, 3 * D.npts));
+      B.g_zero = std::max(B.g_zero, (size_t)D.n6 * D.npad);
+    }
+    B.Dv = H.upload(B.Dh.data(), nprob, &rc, s);
+    if (rc) return rc;
+    g_batch_valid = true;
+  }
+  std::vector<BaPrepared>& P = B.P;
+  std::vector<BaDev>& Dh = B.Dh;
+  const BaDev* Dv = B.Dv;
+  const int g_obs = B.g_obs, g_cam = B.g_cam, g_pt = B.g_pt, g_blk = B.g_blk, g_npad = B.g_npad, g_pad = B.g_pad, g_n6 = B.g_n6, g_camcount = B.g_camcount, g_apply = B.g_apply;
+  const size_t g_zero = B.g_zero;
   const double t_upload = ba_now_ms();
   const unsigned ny = (unsigned)nprob;
   const int npad = g_npad;
@@ -2282,7 +2323,7 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
   if (stop_flag && *stop_flag) { *aborted = 1; return 0; }
   ba_options o2 = o1; o2.max_iterations = 10;
   bind();
-  rc = ba_solve_batch_impl(in.data(), nproblems, &o2, pass2);
+  rc = ba_solve_batch_impl(in.data(), nproblems, &o2, pass2, duplicate_blocks != 0);      // same observation set: structure reused
   if (rc) return rc;
   for (int q = 0; q < nproblems; q++) {
     const ba_local_problem& L = problems[q]; Work& w = W[q];
