@@ -228,8 +228,11 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-  // ---- pass A: compass pre-test (any 9-arc contains >= 2 adjacent compass points); survivors are
-  //      queued so that the expensive score runs on dense lanes ---------------------------------------
+  // ---- pass A: compass pre-test; survivors are queued so that the expensive score runs on dense lanes ---------
+  // A 9-arc of the 16-ring always contains two ADJACENT compass points (ring 0/4/8/12), i.e. one of {0, 8} and one of
+  // {4, 12}.  Necessary for a brighter corner: max(c0, c8) > v + t and max(c4, c12) > v + t, i.e.
+  // min(max(c0, c8), max(c4, c12)) - v > t; darker likewise with min / max swapped.  6 min/max + 2 sub + max + 1 compare
+  // per pixel, and tighter than ">= 2 of the 4 compass points" (which also admits the opposite pairs).
   int qn = 0;
   {
     // lanes = (row parity, column) when the interior is <= 32 px wide (every KITTI / VGA level), else lanes = columns
@@ -245,18 +248,15 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
           const uint8_t* p = tile + (iy + 3) * TP + lx + 3;
           const int v = p[0];
           const int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
-          // ">= 2 of the 4 compass points brighter than v + t" <=> their SECOND LARGEST is; likewise the second smallest
-          // for darker: 8 min/max + 2 compares instead of 8 compares + 8 accumulates (the kernel is VALU-bound)
-          const int m1 = max(c0, c4), n1 = min(c0, c4), m2 = max(c8, c12), n2 = min(c8, c12);
-          const int lo_of_hi = min(m1, m2), hi_of_lo = max(n1, n2);       // the two middle values, in some order
-          const int second_largest = max(lo_of_hi, hi_of_lo), second_smallest = min(lo_of_hi, hi_of_lo);
-          pass[r] = (second_largest > v + minTh) || (second_smallest < v - minTh);
+          const int hi = min(max(c0, c8), max(c4, c12)), lo = max(min(c0, c8), min(c4, c12));
+          pass[r] = max(hi - v, v - lo) > minTh;
         }
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const unsigned long long bal = __ballot(pass[r]);
-        if (pass[r]) queue[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(((iy0 + r * rstep + ly) << 8) | lx);
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (pass[r]) queue[qn + below] = (unsigned short)(((iy0 + r * rstep + ly) << 8) | lx);
         qn += __popcll(bal);
       }
     }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     const unsigned long long m = __shfl(mrow, iy);
     const int rbase = __shfl(incl, iy) - __shfl(cnt, iy);
     if ((m >> lane) & 1ull) {
-      const int pos = rbase + __popcll(m & ((1ull << lane) - 1ull));
+      const int pos = rbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       if (pos < G.cell_cap) {
         const uint32_t x = (uint32_t)(lane + 3 + c.offx), y = (uint32_t)(iy + 3 + c.offy);
         out[pos] = x | (y << 12) | ((uint32_t)score[(iy + 3) * TP + lane + 3] << 24);
