@@ -1995,7 +1995,10 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     }
   }
   for (int it = 0; it < opts->max_iterations + 1 && !user_stop; it++) {
-    if (gexec) ORBHIP_CHECK_HIP(hipGraphLaunch(gexec, s));
+    // the pass after the last iteration only has to record "iteration cap reached": its first kernel does that, the other
+    // ~60 launches of the graph would all fall through (0.2 ms per solve at C4 size)
+    if (it == opts->max_iterations) hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(1), 0, s, Dv);
+    else if (gexec) ORBHIP_CHECK_HIP(hipGraphLaunch(gexec, s));
     else enqueue_iteration();
     if (stop && *stop) user_stop = true;
     if ((it & 7) == 7 && it + 8 < opts->max_iterations) {     // all converged early? (poll every 8 iterations of long solves)
@@ -2124,6 +2127,7 @@ int pg_solve_impl(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* e
   bool user_stop = stop && *stop;
   for (int it = 0; it < max_iterations + 1 && !user_stop && n7 > 0; it++) {
     hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, 1), dim3(1), 0, s, Fv);
+    if (it == max_iterations) break;                          // (only records "iteration cap reached")
     hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)(((size_t)n7 * npad + 255) / 256)), 1), dim3(256), 0, s, Fv);
     hipLaunchKernelGGL(k_pg_build, dim3(n + nblk), dim3(64), 0, s, P);
     auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
