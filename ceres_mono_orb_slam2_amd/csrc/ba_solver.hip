@@ -522,6 +522,7 @@ struct BaDev {            // device pointers of one problem
   const int* free_cams;              // [nfc] reduced column -> camera index
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
+  int chol_la;                       // 1: this problem's reduced system is factored by the look-ahead kernel (npad <= 1024), 0: two-level blocking
   double huber;
   BaState* st;
 };
@@ -973,6 +974,7 @@ __device__ __forceinline__ void diag_invert_wave(double (*s_L)[NB + 1], double (
 template <int G>
 __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv, int k) {
   const BaDev D = Dv[blockIdx.y];
+  if (D.chol_la) return;                                      // factored by k_chol_la
   BaState* st = D.st;
   __shared__ double s_L[NB][NB + 1];
   __shared__ double s_X[NB][NB + 1];
@@ -1051,23 +1053,21 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
 // 32-wide panels of a 128-wide outer block only update the rest of that block ("thin" launches, K=32); everything to
 // the right of the outer block is updated ONCE with K=128 (4x the flops per byte of C moved).  Workgroups with
 // blockIdx.x >= ntiles update the augmented rhs row (row npad) over the same column range.
-__global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles) {
-  const BaDev D = Dv[blockIdx.y];
-  const BaState* st = D.st;
-  __shared__ double s_A[64][NB + 1], s_B[64][NB + 1];
+__device__ __forceinline__ void chol_syrk_body(const BaDev& D, const BaState* st, const int bx, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles,
+                                               double (*s_A)[NB + 1], double (*s_B)[NB + 1]) {
   const int np = D.npad, tid = threadIdx.x;
   // batched launch: the grid and (kcol, K, r_lo, c_lo, c_hi_cap) are laid out for the LARGEST reduced system of the batch;
   // this problem clips the column range to its own size and drops the steps / tiles that fall outside
   const int c_hi = min(c_hi_cap, np);
   if (kcol + K > np || c_hi <= c_lo) return;
   double* S = D.S;
-  if ((int)blockIdx.x >= ntiles) {           // augmented rhs row
+  if (bx >= ntiles) {           // augmented rhs row
     if (st->done || !st->valid || st->chol_fail) return;
     double* zrow = S + (size_t)np * np;
     double* s_z = &s_A[0][0];
     for (int i = tid; i < K; i += 256) s_z[i] = zrow[kcol + i];
     __syncthreads();
-    const int c = c_lo + ((int)blockIdx.x - ntiles) * 256 + tid;
+    const int c = c_lo + (bx - ntiles) * 256 + tid;
     if (c < c_hi) {
       const double* L = S + (size_t)c * np + kcol;
       double sum = 0.0;
@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv,
     }
     return;
   }
-  const int ti = blockIdx.x / tiles_c, tj = blockIdx.x - ti * tiles_c;
+  const int ti = bx / tiles_c, tj = bx - ti * tiles_c;
   const int r0 = r_lo + ti * 64, c0 = c_lo + tj * 64;
   if (r0 + 63 < c0 || r0 >= np || c0 >= c_hi) return;         // tile entirely above the diagonal / outside this problem
   const int w = tid >> 6, lane = tid & 63;
@@ -1148,6 +1148,146 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv,
         const int col = c0 + qc + 16 * j + (lane & 15);
         if (row < np && col < c_hi && col <= row) S[(size_t)row * np + col] = cpre[i][j][rg] - acc[i][j][rg];
       }
+}
+
+__global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles) {
+  const BaDev D = Dv[blockIdx.y];
+  if (D.chol_la) return;                                      // factored by k_chol_la
+  __shared__ double s_A[64][NB + 1], s_B[64][NB + 1];
+  chol_syrk_body(D, D.st, (int)blockIdx.x, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles, s_A, s_B);
+}
+
+// ---- look-ahead Cholesky step for reduced systems up to 1024 unknowns (LocalBA: 600) -----------------------------------
+// The two-level scheme above is a chain of panel -> update -> panel ... launches; at n = 600 every launch is latency-bound
+// (9.8 + 6.1 us per step).  Here ONE launch per 32-column step carries both roles:
+//   role A (first nA workgroups): panel k.  The rank-32 update of the PREVIOUS step is applied to this column block inside
+//     the kernel: the diagonal block as D -= P P^T before it is factored (P = the previous panel's rows of the diagonal
+//     block), and the rows below algebraically, L21 = A21 X^T - Lprev (X P)^T with X = L11^-1 - both operand sets are
+//     loaded straight into the MFMA layout before the factor starts, M = X P costs 8 MFMAs per wave after the inverse;
+//   role B (remaining workgroups): the previous step's update of everything to the RIGHT of this column block (and of the
+//     augmented rhs row) - the old k_chol_syrk body, now off the critical path because it runs beside the factor.
+// Same launch count as panels alone; deterministic (fixed MFMA order).
+template <int G>
+__global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, int k, int nA, int tiles_c, int ntiles) {
+  const BaDev D = Dv[blockIdx.y];
+  if (!D.chol_la) return;
+  BaState* st = D.st;
+  __shared__ __attribute__((aligned(16))) double s_raw[5 * NB * (NB + 1) + NB];
+  const int np = D.npad, tid = threadIdx.x;
+  if ((int)blockIdx.x >= nA) {
+    double (*s_A)[NB + 1] = (double (*)[NB + 1])s_raw;
+    double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_raw + 64 * (NB + 1));
+    chol_syrk_body(D, st, (int)blockIdx.x - nA, k - NB, NB, k + NB, k + NB, INT_MAX, tiles_c, ntiles, s_A, s_B);
+    return;
+  }
+  double (*s_L)[NB + 1] = (double (*)[NB + 1])s_raw;
+  double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_raw + NB * (NB + 1));
+  double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_raw + 2 * NB * (NB + 1));
+  double (*s_M)[NB + 1] = (double (*)[NB + 1])(s_raw + 3 * NB * (NB + 1));
+  double (*s_T)[NB] = (double (*)[NB])(s_raw + 4 * NB * (NB + 1));          // 16-byte aligned: 4 * 32 * 33 * 8 bytes
+  double* s_dinv = s_raw + 4 * NB * (NB + 1) + NB * NB;
+  __shared__ int s_fail;
+  if (k >= np || k + NB + (int)blockIdx.x * (64 * G) > np) return;     // beyond this problem's matrix (batched launch)
+  double* S = D.S;
+  const bool upd = k > 0;
+  const int kp = k - NB;
+  const int w = tid >> 6, lane = tid & 63;
+  const int row0 = k + NB + (blockIdx.x * 4 + w) * (16 * G);
+  const int li = lane & 15, lk = lane >> 4;
+  double a[G][8], ap[G][8];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const int arow = row0 + 16 * g + li;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      a[g][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
+      ap[g][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;      // negated: L21 = A21 X^T + (-Lprev) M^T
+    }
+  }
+  double d4[4], p4[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = tid + 256 * u, r = i / NB, c = i % NB;
+    d4[u] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0;
+    p4[u] = upd ? S[(size_t)(k + r) * np + kp + c] : 0.0;
+  }
+  if (st->done || !st->valid || st->chol_fail) return;
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; s_L[i / NB][i % NB] = d4[u]; s_P[i / NB][i % NB] = p4[u]; }
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  const int ti = w >> 1, tj = w & 1;                         // this wave's 16x16 tile of the 32x32 products
+  if (upd) {
+    if (tj <= ti) {                                           // D -= P P^T on the lower tiles
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * ti + li][4 * ks + lk], s_P[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
+        if (c <= r) s_L[r][c] -= acc[rg];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < 64) {
+    const int fail = diag_factor_wave(s_L, s_T, s_dinv);
+    if (fail && tid == 0) s_fail = 1;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    diag_invert_wave(s_L, s_X, s_T, s_dinv);
+  }
+  __syncthreads();
+  if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
+  if (blockIdx.x == 0) {
+    double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
+    for (int i = tid; i < NB * NB; i += 256) {
+      int r = i / NB, c = i % NB;
+      if (c <= r) S[(size_t)(k + r) * np + k + c] = s_L[r][c];
+      Di[i] = s_X[r][c];
+    }
+  }
+  if (upd) {                                                  // M = X P, one 16x16 tile per wave
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_X[16 * ti + li][4 * ks + lk], s_P[4 * ks + lk][16 * tj + li], acc, 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) s_M[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
+    __syncthreads();
+  }
+  // ---- L21 rows on the matrix cores: [A21 | -Lprev] [X | M]^T ---------------------------------------------------------
+  double b0[8], b1[8], m0[8], m1[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) {
+    b0[ks] = s_X[li][4 * ks + lk]; b1[ks] = s_X[16 + li][4 * ks + lk];     // B[k][j] = X[j][k]
+    m0[ks] = upd ? s_M[li][4 * ks + lk] : 0.0; m1[ks] = upd ? s_M[16 + li][4 * ks + lk] : 0.0;
+  }
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const int rg0 = row0 + 16 * g;
+    if (rg0 > np) break;
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][ks], b0[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][ks], b1[ks], acc1, 0, 0, 0);
+    }
+    if (upd) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g][ks], m0[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g][ks], m1[ks], acc1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int orow = rg0 + (lane >> 4) + 4 * rg;
+      if (orow <= np) {
+        S[(size_t)orow * np + k + (lane & 15)] = acc0[rg];
+        S[(size_t)orow * np + k + 16 + (lane & 15)] = acc1[rg];
+      }
+    }
+  }
 }
 
 // backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
@@ -1744,6 +1884,7 @@ struct BaPrepared { BaDev D; int nb_obs, nb_cam, nb_pt; size_t npairs; double t_
 struct BaBatch {
   std::vector<BaPrepared> P; std::vector<BaDev> Dh; const BaDev* Dv = nullptr;
   int g_obs, g_cam, g_pt, g_blk, g_npad, g_pad, g_n6, g_camcount, g_apply; size_t g_zero;
+  int g_npad_la, g_npad_2l;         // largest reduced system factored by the look-ahead kernel / by the two-level scheme (0: none)
 };
 static thread_local BaBatch g_batch;
 
@@ -1834,6 +1975,8 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   BaDev D; std::memset(&D, 0, sizeof(D));
   D.ncam = ncam; D.npts = npts; D.nobs = nobs; D.nfc = nfc; D.n6 = n6; D.npad = npad; D.nparts = nparts; D.nblk = nblk;
   D.fix_points = opts->fix_points ? 1 : 0; D.huber = opts->huber_delta;
+  static const bool use_la = []() { const char* e = std::getenv("ORBHIP_BA_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+  D.chol_la = (use_la && npad <= 1024) ? 1 : 0;
   D.K4 = H.upload(in.K4, 4 * (size_t)ncam, &rc, s); D.cam_fixed = H.upload(in.cam_fixed, ncam, &rc, s); D.cam_col = H.upload(cam_col.data(), ncam, &rc, s);
   D.poses = H.upload(in.poses7, 7 * (size_t)ncam, &rc, s); D.pts = H.upload(in.pts3, 3 * (size_t)npts, &rc, s);
   D.cand_poses = H.alloc<double>(7 * (size_t)ncam, &rc); D.cand_pts = H.alloc<double>(3 * (size_t)npts, &rc);
@@ -1907,6 +2050,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   } else {
     HostBA H;                                             // (invalidates the resident batch)
     B.P.assign(nprob, BaPrepared()); B.Dh.assign(nprob, BaDev());
+    B.g_npad_la = 0; B.g_npad_2l = 0;
     B.g_obs = 1; B.g_cam = 1; B.g_pt = 1; B.g_blk = 0; B.g_npad = NB; B.g_pad = 0; B.g_n6 = 0; B.g_camcount = 1; B.g_apply = 1; B.g_zero = 0;
     for (int p = 0; p < nprob; p++) {
       if (int r = ba_prepare(H, s, in[p], opts, &B.P[p])) return r;
@@ -1916,6 +2060,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       B.g_blk = std::max(B.g_blk, D.nblk); B.g_npad = std::max(B.g_npad, D.npad); B.g_pad = std::max(B.g_pad, D.npad - D.n6); B.g_n6 = std::max(B.g_n6, D.n6);
       B.g_camcount = std::max(B.g_camcount, D.ncam); B.g_apply = std::max(B.g_apply, std::max(7 * D.ncam, 3 * D.npts));
       B.g_zero = std::max(B.g_zero, (size_t)D.n6 * D.npad);
+      if (D.chol_la) B.g_npad_la = std::max(B.g_npad_la, D.npad); else B.g_npad_2l = std::max(B.g_npad_2l, D.npad);
     }
     B.Dv = H.upload(B.Dh.data(), nprob, &rc, s);
     if (rc) return rc;
@@ -1928,7 +2073,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   const size_t g_zero = B.g_zero;
   const double t_upload = ba_now_ms();
   const unsigned ny = (unsigned)nprob;
-  const int npad = g_npad;
+  const int npad_all = g_npad;
   if (g_pad > 0) hipLaunchKernelGGL(k_ba_pad, dim3(g_pad, ny), dim3(64), 0, s, Dv);
   auto enqueue_eval = [&]() {
     hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 0);
@@ -1942,6 +2087,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
     if (g_n6 > 0) hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)((g_zero + 255) / 256)), ny), dim3(256), 0, s, Dv);
     if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), 0, s, Dv);
+    const int npad = B.g_npad_2l;                             // (0 when every problem of the batch takes the look-ahead scheme)
     auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
       if (c_hi <= c_lo || r_lo >= npad + 1) return;
       const int tiles_r = (npad - r_lo + 63) / 64, tiles_c = (c_hi - c_lo + 63) / 64;
@@ -1949,7 +2095,16 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       const int nrhs = (c_hi - c_lo + 255) / 256;
       hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs, ny), dim3(256), 0, s, Dv, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles);
     };
-    const int OB = 128;                                       // outer block: 4 panels of NB = 32
+    // look-ahead scheme (reduced systems <= 1024): one launch per 32-column step, panel + the previous step's update
+    for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) {
+      const int rows_below = npl - k - NB;
+      const int r_lo = k + NB;
+      int tiles_c = 1, ntiles = 0, nrhs = 0;
+      if (k > 0 && r_lo < npl) { tiles_c = (npl - r_lo + 63) / 64; ntiles = tiles_c * tiles_c; nrhs = (npl - r_lo + 255) / 256; }
+      if (ny >= 4) { const int nA = (rows_below + 1 + 255) / 256; hipLaunchKernelGGL(k_chol_la<4>, dim3(nA + ntiles + nrhs, ny), dim3(256), 0, s, Dv, k, nA, tiles_c, ntiles); }
+      else { const int nA = (rows_below + 1 + 63) / 64; hipLaunchKernelGGL(k_chol_la<1>, dim3(nA + ntiles + nrhs, ny), dim3(256), 0, s, Dv, k, nA, tiles_c, ntiles); }
+    }
+    const int OB = 128;                                       // two-level scheme: outer block = 4 panels of NB = 32
     for (int k0 = 0; k0 < npad; k0 += OB) {
       const int kend = std::min(k0 + OB, npad);
       for (int k = k0; k < kend; k += NB) {
@@ -1960,7 +2115,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       }
       if (kend < npad) launch_update(k0, kend - k0, kend, kend, npad, INT_MAX);      // one wide update for everything to the right
     }
-    for (int kb = ((npad - 1) / SBLK) * SBLK; kb >= 0; kb -= SBLK) {
+    for (int kb = ((npad_all - 1) / SBLK) * SBLK; kb >= 0; kb -= SBLK) {
       hipLaunchKernelGGL(k_chol_bsolve_diag, dim3(1, ny), dim3(1024), 0, s, Dv, kb);
       if (kb > 0) hipLaunchKernelGGL(k_chol_bsolve_update, dim3((kb + 63) / 64, ny), dim3(1024), 0, s, Dv, kb);
     }
