@@ -1194,6 +1194,14 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   const int w = tid >> 6, lane = tid & 63;
   const int row0 = k + NB + (blockIdx.x * 4 + w) * (16 * G);
   const int li = lane & 15, lk = lane >> 4;
+  // request order = need order: the two 32x32 blocks the factor waits for first, the L21 operands behind them
+  double d4[4], p4[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = tid + 256 * u, r = i / NB, c = i % NB;
+    d4[u] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0;
+    p4[u] = upd ? S[(size_t)(k + r) * np + kp + c] : 0.0;
+  }
   double a[G][8], ap[G][8];
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -1203,13 +1211,6 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
       a[g][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
       ap[g][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;      // negated: L21 = A21 X^T + (-Lprev) M^T
     }
-  }
-  double d4[4], p4[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int i = tid + 256 * u, r = i / NB, c = i % NB;
-    d4[u] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0;
-    p4[u] = upd ? S[(size_t)(k + r) * np + kp + c] : 0.0;
   }
   if (st->done || !st->valid || st->chol_fail) return;
 #pragma unroll
@@ -1239,14 +1240,6 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   }
   __syncthreads();
   if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
-  if (blockIdx.x == 0) {
-    double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
-    for (int i = tid; i < NB * NB; i += 256) {
-      int r = i / NB, c = i % NB;
-      if (c <= r) S[(size_t)(k + r) * np + k + c] = s_L[r][c];
-      Di[i] = s_X[r][c];
-    }
-  }
   if (upd) {                                                  // M = X P, one 16x16 tile per wave
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1286,6 +1279,14 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
         S[(size_t)orow * np + k + (lane & 15)] = acc0[rg];
         S[(size_t)orow * np + k + 16 + (lane & 15)] = acc1[rg];
       }
+    }
+  }
+  if (blockIdx.x == 0) {                                      // L11 and L11^-1 leave last: nothing in this launch waits for them
+    double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
+    for (int i = tid; i < NB * NB; i += 256) {
+      int r = i / NB, c = i % NB;
+      if (c <= r) S[(size_t)(k + r) * np + k + c] = s_L[r][c];
+      Di[i] = s_X[r][c];
     }
   }
 }
