@@ -1829,6 +1829,10 @@ struct BaWorkspace {
   // shut down (observed as a hang at process exit under rocprofv3); the process teardown reclaims it.
 };
 static thread_local BaWorkspace g_ws;
+// the workspace of this thread still holds the complete prepared batch of the last ba_solve_batch_impl call (structure
+// arrays, block lists, workspace, final poses / points): LocalBA's second pass solves the SAME observation set and
+// reuses it.  Every new walk over the workspace slots (any HostBA) invalidates it.
+static thread_local bool g_batch_valid = false;
 // one non-blocking stream per host thread: independent solves issued from different threads overlap on the GPU
 static thread_local hipStream_t g_stream = nullptr;
 static thread_local int g_stream_device = -1;
@@ -1841,15 +1845,12 @@ static hipStream_t thread_stream() {
     (void)hipStreamDestroy(g_stream); g_stream = nullptr;
     g_ws.slots.clear(); g_ws.hslots.clear();           // (buffers of the previous device are intentionally leaked)
     g_graphs.clear();
+    g_batch_valid = false;
   }
   if (!g_stream) { if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr; g_stream_device = dev; }
   return g_stream;
 }
 
-// the workspace of this thread still holds the complete prepared batch of the last ba_solve_batch_impl call (structure
-// arrays, block lists, workspace, final poses / points): LocalBA's second pass solves the SAME observation set and
-// reuses it.  Every new walk over the workspace slots (any HostBA) invalidates it.
-static thread_local bool g_batch_valid = false;
 struct HostBA {
   HostBA() { g_batch_valid = false; }
   size_t next = 0, hnext = 0;

@@ -272,3 +272,41 @@ def test_ba_random_shapes_vs_oracle(oracle, seed):
     assert abs(s["final_cost"] - os_["final_cost"]) <= RTOL_COST * max(os_["final_cost"], 1e-9 * os_["initial_cost"])   # (a cost of ~1e-15 is zero)
     assert _close(poses, oposes, RTOL_X) and _close_pts(pts, opts)
     assert np.array_equal(poses[fixed != 0], g["poses0"][fixed != 0])
+
+
+_TWO_LEVEL_SCRIPT = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+from ceres_mono_orb_slam2_amd import synth, optimizer
+out = []
+for seed, ncam, npts, nobs in ((5, 30, 600, 3000), (6, 100, 2000, 9000)):
+    g = synth.make_ba_graph(seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=2)
+    n = len(g["obs_cam"]); w = g["obs_inv_sigma2"].astype(np.float64); rb = np.ones(n, np.uint8)
+    poses, pts, s = optimizer.bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, rb, 6)
+    out.append({"poses": poses.tolist(), "summary": s})
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_two_level_and_lookahead_factorisations_agree(oracle):
+    """Reduced systems up to 1024 unknowns are factored by the look-ahead kernel (k_chol_la), larger ones by the two-level
+    blocked scheme.  ORBHIP_BA_LOOKAHEAD=0 (read once per process, hence the subprocess) forces the two-level scheme on the
+    same problems: both must reproduce the oracle (iterations / termination identical, cost 1e-9, poses RTOL_X)."""
+    import json, subprocess, sys
+    from ceres_mono_orb_slam2_amd import optimizer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORBHIP_BA_LOOKAHEAD="0")
+    r = subprocess.run([sys.executable, "-c", _TWO_LEVEL_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    two_level = json.loads(line[len("RESULT "):])
+    for res, (seed, ncam, npts, nobs) in zip(two_level, ((5, 30, 600, 3000), (6, 100, 2000, 9000))):
+        g = synth.make_ba_graph(seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=2)
+        n = len(g["obs_cam"]); w = g["obs_inv_sigma2"].astype(np.float64); rb = np.ones(n, np.uint8)
+        a = (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, rb, 6)
+        poses, pts, s = optimizer.bundle_adjustment(*a)                      # look-ahead (default)
+        oposes, opts, os_ = oracle.ba_solve(*a)
+        for name, pp, ss in (("look-ahead", poses, s), ("two-level", np.array(res["poses"]), res["summary"])):
+            assert (ss["iterations"], ss["successful_steps"], ss["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"]), name
+            assert abs(ss["final_cost"] - os_["final_cost"]) <= RTOL_COST * os_["final_cost"], name
+            assert _close(pp, oposes, RTOL_X), name
