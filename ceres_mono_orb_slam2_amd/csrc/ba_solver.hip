@@ -1978,7 +1978,8 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.ncam = ncam; D.npts = npts; D.nobs = nobs; D.nfc = nfc; D.n6 = n6; D.npad = npad; D.nparts = nparts; D.nblk = nblk;
   D.fix_points = opts->fix_points ? 1 : 0; D.huber = opts->huber_delta;
   static const bool use_la = []() { const char* e = std::getenv("ORBHIP_BA_LOOKAHEAD"); return !(e && e[0] == '0'); }();
-  D.chol_la = (use_la && npad <= 1024) ? 1 : 0;
+  static const int la_max = []() { const char* e = std::getenv("ORBHIP_BA_LA_MAX"); return e ? atoi(e) : 1024; }();
+  D.chol_la = (use_la && npad <= la_max) ? 1 : 0;
   D.K4 = H.upload(in.K4, 4 * (size_t)ncam, &rc, s); D.cam_fixed = H.upload(in.cam_fixed, ncam, &rc, s); D.cam_col = H.upload(cam_col.data(), ncam, &rc, s);
   D.poses = H.upload(in.poses7, 7 * (size_t)ncam, &rc, s); D.pts = H.upload(in.pts3, 3 * (size_t)npts, &rc, s);
   D.cand_poses = H.alloc<double>(7 * (size_t)ncam, &rc); D.cand_pts = H.alloc<double>(3 * (size_t)npts, &rc);
