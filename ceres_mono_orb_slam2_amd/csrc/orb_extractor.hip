@@ -79,19 +79,15 @@ __device__ __forceinline__ int byte_of(uint32_t w0, uint32_t w1, uint32_t w2, in
   const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : w2);
   return (w >> (8 * (k & 3))) & 255;
 }
+#define RS_ROWS 4      // output rows per thread: the x tables are read once per thread and 4 rows of source loads are in flight together
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int spitch, long long sframe,
                                                 int sw, int sh, uint8_t* __restrict__ dst, int dpitch,
                                                 long long dframe, int dw, int dh, const uint2* __restrict__ xtab,
                                                 const int* __restrict__ yofs, const short* __restrict__ ibeta) {
   const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int y0 = (blockIdx.y * 4 + threadIdx.y) * RS_ROWS;
   const int f = blockIdx.z;
-  if (x4 >= dw || y >= dh) return;
-  const int sy = yofs[y];
-  const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
-  const uint8_t* S0 = src + (long long)f * sframe + (long long)sy0 * spitch;
-  const uint8_t* S1 = src + (long long)f * sframe + (long long)sy1 * spitch;
-  const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+  if (x4 >= dw || y0 >= dh) return;
   int sx[4], a0[4], a1[4];
   uint32_t wp[4];                                   // a0 | a1 << 16
 #pragma unroll
@@ -101,53 +97,82 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   }
   const int base = sx[0] & ~3;
   const bool window = (sx[3] + 1 - base < 12);
-  const bool fast = ((spitch & 3) == 0) && ((((size_t)S0) & 3) == 0) && (base + 12 <= spitch) && window;
-  // rows of any alignment (level 1 reads the caller's frames, e.g. a 1241-byte stride): four ALIGNED dwords re-cut with
-  // v_alignbyte give the same 12-byte window; base + 16 <= sw keeps every byte read inside the source row
-  const bool fast_unaligned = !fast && window && (base + 16 <= sw) && (base >= 4 || sy0 > 0 || f > 0);   // (the <= 3 bytes read before S0 + base stay inside the buffer)
-  uint32_t out = 0;
-  if (fast || fast_unaligned) {
-    uint32_t p0, p1, p2, q0, q1, q2;
-    if (fast) {
-      p0 = *(const uint32_t*)(S0 + base); p1 = *(const uint32_t*)(S0 + base + 4); p2 = *(const uint32_t*)(S0 + base + 8);
-      q0 = *(const uint32_t*)(S1 + base); q1 = *(const uint32_t*)(S1 + base + 4); q2 = *(const uint32_t*)(S1 + base + 8);
-    } else {
-      const uint8_t* a = S0 + base; const uint8_t* b = S1 + base;
-      const uint32_t sa = (uint32_t)((size_t)a & 3), sb = (uint32_t)((size_t)b & 3);
-      const uint32_t* pa = (const uint32_t*)(a - sa); const uint32_t* pb = (const uint32_t*)(b - sb);
-      const uint32_t a0d = pa[0], a1d = pa[1], a2d = pa[2], a3d = pa[3], b0d = pb[0], b1d = pb[1], b2d = pb[2], b3d = pb[3];
-      p0 = __builtin_amdgcn_alignbyte(a1d, a0d, sa); p1 = __builtin_amdgcn_alignbyte(a2d, a1d, sa); p2 = __builtin_amdgcn_alignbyte(a3d, a2d, sa);
-      q0 = __builtin_amdgcn_alignbyte(b1d, b0d, sb); q1 = __builtin_amdgcn_alignbyte(b2d, b1d, sb); q2 = __builtin_amdgcn_alignbyte(b3d, b2d, sb);
-    }
+  // ---- phase 1: every row's source dwords are requested before any arithmetic (one thread used to do one row: two
+  // dependent global round trips around ~100 VALU instructions; PMC: 49 % VALU-busy at 3.8 waves per SIMD) ----
+  uint32_t P[RS_ROWS][3], Q[RS_ROWS][3];
+  int bb0[RS_ROWS], bb1[RS_ROWS], mode[RS_ROWS];      // mode 0: row outside, 1: dword window in P / Q, 2: byte path
+  const uint8_t* R0[RS_ROWS]; const uint8_t* R1[RS_ROWS];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (x4 + j < dw) {
-        // bytes k0, k0 + 1 of the 12-byte window as one u16 pair, times (a0, a1) with ONE v_dot2_u32_u16 per row.  At the right
-        // border the reference clamps the second column and its weight a1 is 0, so the byte after the row never matters.
-        const int k0 = sx[j] - base;
-        const bool hi = k0 >= 4, hi2 = k0 >= 8;
-        const uint32_t lo0 = hi2 ? p2 : (hi ? p1 : p0), up0 = hi2 ? 0u : (hi ? p2 : p1);
-        const uint32_t lo1 = hi2 ? q2 : (hi ? q1 : q0), up1 = hi2 ? 0u : (hi ? q2 : q1);
-        const uint32_t w0 = __builtin_amdgcn_alignbyte(up0, lo0, (uint32_t)(k0 & 3)), w1 = __builtin_amdgcn_alignbyte(up1, lo1, (uint32_t)(k0 & 3));
-        const int H0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_rs, __builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), __builtin_bit_cast(ushort2_rs, wp[j]), 0u, false);
-        const int H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_rs, __builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), __builtin_bit_cast(ushort2_rs, wp[j]), 0u, false);
-        const int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
-        out |= (uint32_t)(v & 255) << (8 * j);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (x4 + j < dw) {
-        const int s0 = sx[j], s1 = min(sx[j] + 1, sw - 1);
-        const int H0 = S0[s0] * a0[j] + S0[s1] * a1[j];
-        const int H1 = S1[s0] * a0[j] + S1[s1] * a1[j];
-        const int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
-        out |= (uint32_t)(v & 255) << (8 * j);
+  for (int r = 0; r < RS_ROWS; r++) {
+    const int y = y0 + r;
+    mode[r] = 0;
+    if (y < dh) {
+      const int sy = yofs[y];
+      const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+      const uint8_t* S0 = src + (long long)f * sframe + (long long)sy0 * spitch;
+      const uint8_t* S1 = src + (long long)f * sframe + (long long)sy1 * spitch;
+      R0[r] = S0; R1[r] = S1;
+      bb0[r] = ibeta[2 * y]; bb1[r] = ibeta[2 * y + 1];
+      const bool fast = ((spitch & 3) == 0) && ((((size_t)S0) & 3) == 0) && (base + 12 <= spitch) && window;
+      // rows of any alignment (level 1 reads the caller's frames, e.g. a 1241-byte stride): four ALIGNED dwords re-cut with
+      // v_alignbyte give the same 12-byte window; base + 16 <= sw keeps every byte read inside the source row
+      const bool fast_unaligned = !fast && window && (base + 16 <= sw) && (base >= 4 || sy0 > 0 || f > 0);   // (the <= 3 bytes read before S0 + base stay inside the buffer)
+      if (fast) {
+        P[r][0] = *(const uint32_t*)(S0 + base); P[r][1] = *(const uint32_t*)(S0 + base + 4); P[r][2] = *(const uint32_t*)(S0 + base + 8);
+        Q[r][0] = *(const uint32_t*)(S1 + base); Q[r][1] = *(const uint32_t*)(S1 + base + 4); Q[r][2] = *(const uint32_t*)(S1 + base + 8);
+        mode[r] = 1;
+      } else if (fast_unaligned) {
+        const uint8_t* a = S0 + base; const uint8_t* b = S1 + base;
+        const uint32_t sa = (uint32_t)((size_t)a & 3), sb = (uint32_t)((size_t)b & 3);
+        const uint32_t* pa = (const uint32_t*)(a - sa); const uint32_t* pb = (const uint32_t*)(b - sb);
+        const uint32_t a0d = pa[0], a1d = pa[1], a2d = pa[2], a3d = pa[3], b0d = pb[0], b1d = pb[1], b2d = pb[2], b3d = pb[3];
+        P[r][0] = __builtin_amdgcn_alignbyte(a1d, a0d, sa); P[r][1] = __builtin_amdgcn_alignbyte(a2d, a1d, sa); P[r][2] = __builtin_amdgcn_alignbyte(a3d, a2d, sa);
+        Q[r][0] = __builtin_amdgcn_alignbyte(b1d, b0d, sb); Q[r][1] = __builtin_amdgcn_alignbyte(b2d, b1d, sb); Q[r][2] = __builtin_amdgcn_alignbyte(b3d, b2d, sb);
+        mode[r] = 1;
+      } else {
+        mode[r] = 2;
       }
     }
   }
-  *(uint32_t*)(dst + (long long)f * dframe + (long long)y * dpitch + x4) = out;
+  // ---- phase 2: interpolate and store ----
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; r++) {
+    if (mode[r] == 0) continue;
+    const int b0 = bb0[r], b1 = bb1[r];
+    uint32_t out = 0;
+    if (mode[r] == 1) {
+      const uint32_t p0 = P[r][0], p1 = P[r][1], p2 = P[r][2], q0 = Q[r][0], q1 = Q[r][1], q2 = Q[r][2];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (x4 + j < dw) {
+          // bytes k0, k0 + 1 of the 12-byte window as one u16 pair, times (a0, a1) with ONE v_dot2_u32_u16 per row.  At the right
+          // border the reference clamps the second column and its weight a1 is 0, so the byte after the row never matters.
+          const int k0 = sx[j] - base;
+          const bool hi = k0 >= 4, hi2 = k0 >= 8;
+          const uint32_t lo0 = hi2 ? p2 : (hi ? p1 : p0), up0 = hi2 ? 0u : (hi ? p2 : p1);
+          const uint32_t lo1 = hi2 ? q2 : (hi ? q1 : q0), up1 = hi2 ? 0u : (hi ? q2 : q1);
+          const uint32_t w0 = __builtin_amdgcn_alignbyte(up0, lo0, (uint32_t)(k0 & 3)), w1 = __builtin_amdgcn_alignbyte(up1, lo1, (uint32_t)(k0 & 3));
+          const int H0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_rs, __builtin_amdgcn_perm(0u, w0, 0x0c010c00u)), __builtin_bit_cast(ushort2_rs, wp[j]), 0u, false);
+          const int H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_rs, __builtin_amdgcn_perm(0u, w1, 0x0c010c00u)), __builtin_bit_cast(ushort2_rs, wp[j]), 0u, false);
+          const int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+          out |= (uint32_t)(v & 255) << (8 * j);
+        }
+      }
+    } else {
+      const uint8_t* S0 = R0[r]; const uint8_t* S1 = R1[r];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (x4 + j < dw) {
+          const int s0 = sx[j], s1 = min(sx[j] + 1, sw - 1);
+          const int H0 = S0[s0] * a0[j] + S0[s1] * a1[j];
+          const int H1 = S1[s0] * a0[j] + S1[s1] * a1[j];
+          const int v = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+          out |= (uint32_t)(v & 255) << (8 * j);
+        }
+      }
+    }
+    *(uint32_t*)(dst + (long long)f * dframe + (long long)(y0 + r) * dpitch + x4) = out;
+  }
 }
 
 // ---------------------------------------------------------------------------- k_fast_cells
@@ -1014,7 +1039,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
     const LevelDev& D = G.lv[l];
     const uint8_t* src = (l == 1) ? d_imgs : pyr + S.pyr_off;
     long long sframe = (l == 1) ? (long long)frame_stride : G.pyr_frame_bytes;
-    dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes), block(64, 4);
+    dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nframes), block(64, 4);
     const uint8_t* T = c->d_tab.as<uint8_t>();
     hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, S.pitch, sframe, S.w, S.h, pyr + D.pyr_off, D.pitch,
                        G.pyr_frame_bytes, D.w, D.h, (const uint2*)(T + c->tab_xofs[l]), (const int*)(T + c->tab_yofs[l]),
