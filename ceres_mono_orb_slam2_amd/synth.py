@@ -327,3 +327,39 @@ def make_essential_graph(seed, n=200, drift=0.002, n_corrected=6, extra_every=5)
         if i % extra_every == 0 and i >= 3:
             edges.append((i - 3, i, "est"))
     return dict(S_true=S_true, S_est=S_est, S_init=init, fixed=fixed, edges=edges)
+
+
+def make_degenerate_ba(seed):
+    """Small BA graphs with one structural degeneracy each (kind = seed % 6): a camera with a single observation,
+    duplicated (camera, point) observations, zero-weight observations, every point seen once, gross errors, points seen
+    only by fixed cameras; random loss flags 0 / 1 / 2 (2 = Huber block folded with its loss-free twin) and 2 / 6 / 15
+    iterations.  Returns a dict; 'oracle_obs' expands the folded twins into the literal duplicated list the oracle solves."""
+    rng = np.random.default_rng(4000 + seed)
+    ncam = int(rng.integers(2, 12)); npts = int(rng.integers(4, 120)); nobs = int(npts * rng.uniform(1.5, 4))
+    g = make_ba_graph(300 + seed, ncam=ncam, npts=npts, nobs=max(nobs, 2 * npts), n_fixed=1, outlier_frac=0.1)
+    oc, op, uv = g["obs_cam"].copy(), g["obs_pt"].copy(), g["obs_uv"].copy()
+    w = g["obs_inv_sigma2"].astype(np.float64)
+    n = len(oc)
+    kind = seed % 6
+    fixed = g["cam_fixed"].copy()
+    if kind == 0:      # a camera with a single observation
+        keep = np.ones(n, bool); idx = np.nonzero(oc == ncam - 1)[0]; keep[idx[1:]] = False
+        oc, op, uv, w = oc[keep], op[keep], uv[keep], w[keep]
+    elif kind == 1:    # duplicated (camera, point) observations
+        d = rng.choice(n, n // 5, replace=False); oc = np.concatenate([oc, oc[d]]); op = np.concatenate([op, op[d]]); uv = np.concatenate([uv, uv[d] + 0.3]); w = np.concatenate([w, w[d]])
+    elif kind == 2:    # zero-weight observations
+        w[rng.random(len(w)) < 0.3] = 0.0
+    elif kind == 3:    # every point seen once
+        _, first = np.unique(op, return_index=True); oc, op, uv, w = oc[first], op[first], uv[first], w[first]
+    elif kind == 4:    # gross errors
+        uv[rng.random(len(uv)) < 0.3] += 400
+    elif kind == 5:    # points seen only by fixed cameras
+        fixed[: max(1, ncam // 2)] = 1
+    rb = rng.integers(0, 3, len(oc)).astype(np.uint8)
+    iters = int(rng.choice([2, 6, 15]))
+    twin = rb == 2
+    oracle_obs = (np.concatenate([oc, oc[twin]]), np.concatenate([op, op[twin]]), np.concatenate([uv, uv[twin]]), np.concatenate([w, w[twin]]),
+                  np.concatenate([np.where(rb >= 1, 1, 0), np.zeros(int(twin.sum()))]).astype(np.uint8))
+    return dict(kind=kind, K4=g["K4"], poses0=g["poses0"], cam_fixed=fixed, pts0=g["pts0"], obs_cam=oc, obs_pt=op, obs_uv=uv, obs_w=w,
+                obs_robust=rb, iterations=iters, oracle_obs=oracle_obs)
+

@@ -1,4 +1,4 @@
-"""One-off fuzz of ba_solve / ba_local_bundle_adjustment against the oracle over degenerate graph structures."""
+"""Fuzz of ba_solve against the oracle over degenerate graph structures (synth.make_degenerate_ba).  usage: fuzz_ba.py [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,44 +7,18 @@ from oracle import pyoracle as po
 bad = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 for seed in range(N):
-    rng = np.random.default_rng(4000 + seed)
-    ncam = int(rng.integers(2, 12)); npts = int(rng.integers(4, 120)); nobs = int(npts * rng.uniform(1.5, 4))
-    g = synth.make_ba_graph(300 + seed, ncam=ncam, npts=npts, nobs=max(nobs, 2 * npts), n_fixed=1, outlier_frac=0.1)
-    oc, op, uv = g["obs_cam"].copy(), g["obs_pt"].copy(), g["obs_uv"].copy()
-    w = g["obs_inv_sigma2"].astype(np.float64)
-    n = len(oc)
-    kind = seed % 6
-    fixed = g["cam_fixed"].copy()
-    if kind == 0:      # a camera with a single observation
-        keep = np.ones(n, bool); idx = np.nonzero(oc == ncam - 1)[0]; keep[idx[1:]] = False
-        oc, op, uv, w = oc[keep], op[keep], uv[keep], w[keep]
-    elif kind == 1:    # duplicated (camera, point) observations
-        d = rng.choice(n, n // 5, replace=False); oc = np.concatenate([oc, oc[d]]); op = np.concatenate([op, op[d]]); uv = np.concatenate([uv, uv[d] + 0.3]); w = np.concatenate([w, w[d]])
-    elif kind == 2:    # zero-weight observations
-        w[rng.random(len(w)) < 0.3] = 0.0
-    elif kind == 3:    # every point seen once
-        _, first = np.unique(op, return_index=True); oc, op, uv, w = oc[first], op[first], uv[first], w[first]
-    elif kind == 4:    # gross errors
-        uv[rng.random(len(uv)) < 0.3] += 400
-    elif kind == 5:    # points seen only by fixed cameras
-        fixed[: max(1, ncam // 2)] = 1
-    rb = rng.integers(0, 3, len(oc)).astype(np.uint8)
-    rb_or = rb.copy()
-    iters = int(rng.choice([2, 6, 15]))
-    # obs_robust = 2 has no single-list oracle equivalent: expand for the oracle
-    twin = rb == 2
-    ooc = np.concatenate([oc, oc[twin]]); oop = np.concatenate([op, op[twin]]); ouv = np.concatenate([uv, uv[twin]]); ow = np.concatenate([w, w[twin]])
-    orb = np.concatenate([np.where(rb >= 1, 1, 0), np.zeros(int(twin.sum()))]).astype(np.uint8)
+    d = synth.make_degenerate_ba(seed)
     try:
-        poses, pts, s = optimizer.bundle_adjustment(g["K4"], g["poses0"], fixed, g["pts0"], oc, op, uv, w, rb, iters)
+        poses, pts, s = optimizer.bundle_adjustment(d["K4"], d["poses0"], d["cam_fixed"], d["pts0"], d["obs_cam"], d["obs_pt"], d["obs_uv"], d["obs_w"], d["obs_robust"], d["iterations"])
     except Exception as e:
-        print("GPU raised", seed, kind, e); bad += 1; continue
-    oposes, opts, os_ = po.ba_solve(g["K4"], g["poses0"], fixed, g["pts0"], ooc, oop, ouv, ow, orb, iters)
+        print("GPU raised", seed, d["kind"], e); bad += 1; continue
+    ooc, oop, ouv, ow, orb = d["oracle_obs"]
+    oposes, opts, os_ = po.ba_solve(d["K4"], d["poses0"], d["cam_fixed"], d["pts0"], ooc, oop, ouv, ow, orb, d["iterations"])
     same = (s["iterations"], s["successful_steps"], s["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"])
     dc = abs(s["final_cost"] - os_["final_cost"]) / max(os_["final_cost"], 1e-9 * max(os_["initial_cost"], 1e-30), 1e-300)
     dx = np.abs(poses - oposes).max()
     # rank-deficient graphs amplify the summation order of the reduced system: 1e-8 .. 3e-8 on the cost has been seen
     # (two iterations, final cost 1e-9 of the initial one); discrete outputs must always be identical
     if not same or dc > 5e-8 or dx > 1e-6:
-        bad += 1; print("DIFF seed", seed, "kind", kind, s, os_, "dcost", dc, "dx", dx)
+        bad += 1; print("DIFF seed", seed, "kind", d["kind"], s, os_, "dcost", dc, "dx", dx)
 print("fuzz_ba: %d problems, %d differences" % (N, bad))
