@@ -329,3 +329,24 @@ def test_degenerate_graphs_vs_oracle(oracle, seed):
     assert abs(s["final_cost"] - os_["final_cost"]) <= 5e-8 * floor
     assert np.abs(poses - oposes).max() <= 1e-6
 
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_local_ba_on_degenerate_graphs_vs_oracle(oracle, seed):
+    """LocalBundleAdjustment (both passes, outlier classification in between; with and without the re-added blocks) on the
+    degenerate graphs: erase flags and iteration counts identical to the oracle, final cost within 5e-8, poses within 1e-6.
+    With duplicate_blocks the second pass reuses the structure of the first on the device - same results as a rebuild."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    d = synth.make_degenerate_ba(seed)
+    ncam = len(d["cam_fixed"])
+    local = np.ones(ncam, np.uint8); local[-1] = 0
+    args = (d["K4"], d["poses0"], d["cam_fixed"], local, d["pts0"], d["obs_cam"], d["obs_pt"], d["obs_uv"], d["obs_w"].astype(np.float32))
+    for dup in (True, False):
+        ab, poses, pts, er, s1, s2 = optimizer.local_bundle_adjustment(*args, duplicate_blocks=dup)
+        rc, oposes, opts, oer, os1, os2 = oracle.local_ba(*args, duplicate_blocks=dup)
+        assert ab == 0 and rc == 0
+        assert (s1["iterations"], s1["termination"], s2["iterations"], s2["termination"]) == (os1["iterations"], os1["termination"], os2["iterations"], os2["termination"])
+        assert np.array_equal(er, oer)
+        floor = max(os2["final_cost"], 1e-9 * max(os1["initial_cost"], 1e-30), 1e-300)
+        assert abs(s2["final_cost"] - os2["final_cost"]) <= 5e-8 * floor
+        assert np.abs(poses - oposes).max() <= 1e-6
