@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
 
 // ---------------------------------------------------------------------------- k_blur7
 #define BLUR_TW 128
-#define BLUR_TH 32
+#define BLUR_TH 64
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (n == 1) return 0;
   while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
