@@ -706,7 +706,8 @@ __device__ __forceinline__ void det_sincos(double x, double* s_out, double* c_ou
   }
 }
 
-__global__ __launch_bounds__(256) void k_describe(GeomDev G, const uint32_t* __restrict__ sel,
+#define DESC_WPB 4      // keypoints (= waves) per workgroup (1 / 2 / 4 / 8 / 16: 0.575 / 0.548 / 0.530 / 0.551 / 0.587 ms)
+__global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uint32_t* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, const int* __restrict__ status,
                                                   const uint8_t* __restrict__ img0, long long img_frame_bytes,
                                                   const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
@@ -714,11 +715,11 @@ __global__ __launch_bounds__(256) void k_describe(GeomDev G, const uint32_t* __r
                                                   int cap, int* __restrict__ counts, float p1, float p3, float p5,
                                                   float p7, float factorPI) {
   __shared__ uint32_t s_pat[256];                           // pattern pair k = bytes (x0, y0, x1, y1)
-  s_pat[threadIdx.x] = ((const uint32_t*)c_pattern)[threadIdx.x];
+  for (int q = threadIdx.x; q < 256; q += 64 * DESC_WPB) s_pat[q] = ((const uint32_t*)c_pattern)[q];
   __syncthreads();
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);      // keypoint index inside the frame
+  const int i = blockIdx.x * DESC_WPB + (threadIdx.x >> 6);      // keypoint index inside the frame
   // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104): one lane per level + ballot
   int total = 0, level = -1, pos = 0;
   {
@@ -1071,7 +1072,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   else ORBHIP_CHECK_HIP(hipStreamWaitEvent(st, c->ev_join, 0));       // join: describe needs the blurred levels
   mark();
   const int maxkp = std::min(cap, nl * G.sel_cap);
-  hipLaunchKernelGGL(k_describe, dim3((maxkp + 3) / 4, nframes), dim3(256), 0, st, G, c->d_sel.as<uint32_t>(),
+  hipLaunchKernelGGL(k_describe, dim3((maxkp + DESC_WPB - 1) / DESC_WPB, nframes), dim3(64 * DESC_WPB), 0, st, G, c->d_sel.as<uint32_t>(),
                      c->d_selcnt.as<int>(), c->d_status.as<int>(), d_imgs, (long long)frame_stride, pyr,
                      c->d_blur.as<uint8_t>(), d_kps, d_desc, cap, d_counts, c->atan_p[0], c->atan_p[1],
                      c->atan_p[2], c->atan_p[3], c->factorPI);
