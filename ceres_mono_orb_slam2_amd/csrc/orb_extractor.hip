@@ -376,6 +376,7 @@ __device__ __forceinline__ int quad_of(const Rect16& r, int x, int y, int& mx, i
   return (x < mx ? 0 : 1) + (y < my ? 0 : 2);  // n1=UL n2=UR n3=BL n4=BR        (:515-525)
 }
 
+#define OCT_U 8        // key entries per thread requested together in the sweep loops
 __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
                                                 const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
                                                 unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
@@ -435,7 +436,13 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
   // initial node histogram (nIni <= 64): LDS int atomics on sB
   for (int i = tid; i < MAX_INI; i += 256) sB[i] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) atomicAdd(&sB[KN[k]], 1);
+  for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+    int pv[OCT_U];
+#pragma unroll
+    for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; pv[u] = k < n ? (int)KN[k] : -1; }
+#pragma unroll
+    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) atomicAdd(&sB[pv[u]], 1);
+  }
   __syncthreads();
   if (tid == 0) {
     int L0 = 0;
@@ -450,7 +457,13 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     s_L = L0;
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) KN[k] = (unsigned short)sA[KN[k]];
+  for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+    int pv[OCT_U];
+#pragma unroll
+    for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; pv[u] = k < n ? (int)KN[k] : -1; }
+#pragma unroll
+    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) KN[k0 + 256 * u] = (unsigned short)sA[pv[u]];
+  }
   __syncthreads();
 
   int cur = 0;
@@ -468,13 +481,21 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     if (ncand == 0) break;                         // no split possible: |L| == prevSize  (:669)
     for (int p = tid; p < L; p += 256) if (C[p] > 1) candl[sA[p]] = (unsigned short)p;
     // ---- B: child occupancy of every candidate -------------------------------------------------
-    for (int k = tid; k < n; k += 256) {
-      int p = KN[k];
-      if (C[p] > 1) {
-        uint32_t key = K[k];
-        int mx, my;
-        int q = quad_of(R[p], key & 0xFFF, (key >> 12) & 0xFFF, mx, my);
-        atomicAdd((q & 2) ? &cc[p].y : &cc[p].x, (q & 1) ? 0x10000u : 1u);
+    // (the key loops read K / KN from global memory: OCT_U entries per thread are requested together - a one-entry loop
+    // pays the global latency ~20 times per sweep phase at level 0, which bounded this kernel at ~0.2 ms)
+    for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+      uint32_t keyv[OCT_U]; int pv[OCT_U];
+#pragma unroll
+      for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
+#pragma unroll
+      for (int u = 0; u < OCT_U; u++) {
+        const int p = pv[u];
+        if (p >= 0 && C[p] > 1) {
+          const uint32_t key = keyv[u];
+          int mx, my;
+          int q = quad_of(R[p], key & 0xFFF, (key >> 12) & 0xFFF, mx, my);
+          atomicAdd((q & 2) ? &cc[p].y : &cc[p].x, (q & 1) ? 0x10000u : 1u);
+        }
       }
     }
     __syncthreads();
@@ -552,17 +573,25 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     if (nexp) atomicAdd(&s_nexp, nexp);
     __syncthreads();
     // ---- H: move the keys -----------------------------------------------------------------------
-    for (int k = tid; k < n; k += 256) {
-      int p = KN[k];
-      uint2 cp = childpos[p];
-      if (rankOf[p] >= 0) {
-        uint32_t key = K[k];
-        int mx, my;
-        int q = quad_of(R[p], key & 0xFFF, (key >> 12) & 0xFFF, mx, my);
-        uint32_t wv = (q & 2) ? cp.y : cp.x;
-        KN[k] = (unsigned short)((q & 1) ? (wv >> 16) : (wv & 0xFFFF));
-      } else {
-        KN[k] = (unsigned short)cp.x;
+    for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+      uint32_t keyv[OCT_U]; int pv[OCT_U];
+#pragma unroll
+      for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
+#pragma unroll
+      for (int u = 0; u < OCT_U; u++) {
+        const int p = pv[u];
+        if (p < 0) continue;
+        const int k = k0 + 256 * u;
+        uint2 cp = childpos[p];
+        if (rankOf[p] >= 0) {
+          const uint32_t key = keyv[u];
+          int mx, my;
+          int q = quad_of(R[p], key & 0xFFF, (key >> 12) & 0xFFF, mx, my);
+          uint32_t wv = (q & 2) ? cp.y : cp.x;
+          KN[k] = (unsigned short)((q & 1) ? (wv >> 16) : (wv & 0xFFFF));
+        } else {
+          KN[k] = (unsigned short)cp.x;
+        }
       }
     }
     L = TC + L - m;
@@ -577,7 +606,13 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
   unsigned int* best = (unsigned int*)sA;
   for (int p = tid; p < L; p += 256) best[p] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) atomicMax(&best[KN[k]], ((K[k] >> 24) << 24) | (0xFFFFFFu - (unsigned)k));
+  for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+    uint32_t keyv[OCT_U]; int pv[OCT_U];
+#pragma unroll
+    for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
+#pragma unroll
+    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) atomicMax(&best[pv[u]], ((keyv[u] >> 24) << 24) | (0xFFFFFFu - (unsigned)(k0 + 256 * u)));
+  }
   __syncthreads();
   for (int p = tid; p < L; p += 256) {
     if (p < G.sel_cap) SEL[p] = K[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
@@ -825,7 +860,7 @@ struct orbx_ctx {
   // the blur pass only depends on the pyramid: it runs on a side stream concurrently with FAST + octree
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool overlap_blur = false;   // measured on MI355X: +0.8 % only (FAST is issue-bound, no idle capacity); opt in with ORBHIP_OVERLAP_BLUR=1
+  int overlap_blur = 0;        // 0: one stream; 1: k_blur7 on the side stream beside FAST + octree (+0.8 % only: FAST is issue-bound); 2: beside the octree only
 };
 
 static int build_tables(orbx_ctx* c) {
@@ -1046,9 +1081,32 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
                        G.pyr_frame_bytes, D.w, D.h, (const uint2*)(T + c->tab_xofs[l]), (const int*)(T + c->tab_yofs[l]),
                        (const short*)(T + c->tab_ibeta[l]));
   }
-  const bool use_side = c->overlap_blur && c->side;
-  if (use_side) {
+  const int side_mode = c->side ? c->overlap_blur : 0;
+  auto launch_blur_side = [&]() -> int {
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
+    ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    hipEvent_t sb = nullptr, se = nullptr;
+    if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, c->side); }
+    hipLaunchKernelGGL(k_blur7, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, c->side, G,
+                       c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
+    if (c->profiling) { (void)hipEventRecord(se, c->side); c->side_events.push_back(sb); c->side_events.push_back(se); }
+    ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, c->side));
+    return 0;
+  };
+  if (side_mode == 1) { if (int rc = launch_blur_side()) return rc; }
+  mark();
+  if (G.ncells_total > 0)
+    hipLaunchKernelGGL(k_fast_cells, dim3((G.ncells_total + FAST_WPB - 1) / FAST_WPB, nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
+                       c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
+                       c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds);
+  mark();
+  // mode 2: the octree is one latency-bound workgroup per (frame, level) - 6 % VALU-busy, 0.6 waves per SIMD - so the
+  // VALU-bound blur runs BESIDE it: the fork is taken after FAST, the octree is submitted first and keeps its slots
+  if (side_mode == 2) ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
+  hipLaunchKernelGGL(k_octree, dim3(nl, nframes), dim3(256), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
+                     c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
+                     c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
+  if (side_mode == 2) {
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
     if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, c->side); }
@@ -1058,17 +1116,8 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, c->side));
   }
   mark();
-  if (G.ncells_total > 0)
-    hipLaunchKernelGGL(k_fast_cells, dim3((G.ncells_total + FAST_WPB - 1) / FAST_WPB, nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
-                       c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
-                       c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds);
-  mark();
-  hipLaunchKernelGGL(k_octree, dim3(nl, nframes), dim3(256), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
-                     c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
-                     c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
-  mark();
-  if (!use_side) hipLaunchKernelGGL(k_blur7, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, st, G,
-                                     c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
+  if (side_mode == 0) hipLaunchKernelGGL(k_blur7, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, st, G,
+                                         c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
   else ORBHIP_CHECK_HIP(hipStreamWaitEvent(st, c->ev_join, 0));       // join: describe needs the blurred levels
   mark();
   const int maxkp = std::min(cap, nl * G.sel_cap);
@@ -1105,7 +1154,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
     if (c->side) (void)hipStreamDestroy(c->side);
     c->side = nullptr;
   }
-  if (std::getenv("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = true;
+  if (const char* e = std::getenv("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = atoi(e);
   *out = c;
   return 0;
 }
