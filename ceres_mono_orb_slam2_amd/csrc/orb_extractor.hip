@@ -423,15 +423,30 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
   const int nIni = Lv.nIni;
   for (int i = tid; i < NC; i += 256) { cnt[0][i] = 0; cnt[1][i] = 0; }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
-    int lo = 0, hi = ncell;                       // largest c with pref[c] <= k
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_pref[mid] <= k) lo = mid; else hi = mid; }
-    uint32_t key = ckps[(long long)lo * G.cell_cap + (k - s_pref[lo])];
-    K[k] = key;
-    int x = key & 0xFFF;
-    int idx = (int)__fdiv_rn((float)x, Lv.hX);     // vpIniNodes[kp.pt.x/hX]   (src/ORBextractor.cc:569)
-    idx = min(idx, nIni - 1);
-    KN[k] = (unsigned short)idx;
+  for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+    uint32_t keyv[OCT_U];
+#pragma unroll
+    for (int u = 0; u < OCT_U; u++) {             // all OCT_U cell-list reads of this thread in flight together
+      const int k = k0 + 256 * u;
+      keyv[u] = 0u;
+      if (k < n) {
+        int lo = 0, hi = ncell;                   // largest c with pref[c] <= k
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_pref[mid] <= k) lo = mid; else hi = mid; }
+        keyv[u] = ckps[(long long)lo * G.cell_cap + (k - s_pref[lo])];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < OCT_U; u++) {
+      const int k = k0 + 256 * u;
+      if (k < n) {
+        const uint32_t key = keyv[u];
+        K[k] = key;
+        int x = key & 0xFFF;
+        int idx = (int)__fdiv_rn((float)x, Lv.hX);     // vpIniNodes[kp.pt.x/hX]   (src/ORBextractor.cc:569)
+        idx = min(idx, nIni - 1);
+        KN[k] = (unsigned short)idx;
+      }
+    }
   }
   // initial node histogram (nIni <= 64): LDS int atomics on sB
   for (int i = tid; i < MAX_INI; i += 256) sB[i] = 0;
