@@ -522,6 +522,7 @@ struct BaDev {            // device pointers of one problem
   const int* free_cams;              // [nfc] reduced column -> camera index
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
+  const unsigned char* cam_local; unsigned char* erase;   // LocalBA classification (k_ba_classify): local flags [ncam], result [nobs] (device order)
   int chol_la;                       // 1: this problem's reduced system is factored by the look-ahead kernel (npad <= 1024), 0: two-level blocking
   double huber;
   BaState* st;
@@ -1555,6 +1556,24 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_apply(const BaDev* __restrict__ D
   if (i < 3 * D.npts) D.pts[i] = D.cand_pts[i];
 }
 
+// ---- LocalBA outlier classification on the final poses / points (src/CeresOptimizer.cc:529-567): chi2 > 5.991 or
+// non-positive depth, only for observations of local keyframes.  Same check_outlier() as the host path (no contraction:
+// bit-identical decisions); flags are written in device (point-grouped) order.
+__global__ __launch_bounds__(BA_TPB) void k_ba_classify(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
+  const int i = blockIdx.x * BA_TPB + threadIdx.x;
+  if (i >= D.nobs || !D.erase) return;
+  const int c = D.obs_cam[i];
+  unsigned char e = 0;
+  if (D.cam_local[c]) {
+    double depth;
+    const int out = check_outlier(D.K4 + 4 * c, D.poses + 7 * c, D.pts + 3 * (size_t)D.obs_pt[i], D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
+                                  D.obs_w[i], 5.991, &depth);
+    e = (out || depth <= 0) ? 1 : 0;
+  }
+  D.erase[i] = e;
+}
+
 __global__ void k_ba_user_stop(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
@@ -1881,6 +1900,7 @@ struct HostBA {
 struct BaInputs {
   const double* K4; double* poses7; const uint8_t* cam_fixed; int ncam; double* pts3; int npts;
   const int32_t* obs_cam; const int32_t* obs_pt; const double* obs_uv; const double* obs_w; const uint8_t* obs_robust; int nobs;
+  const uint8_t* cam_local = nullptr;   // LocalBA only: cameras whose observations are classified after the solve
 };
 struct BaPrepared { BaDev D; int nb_obs, nb_cam, nb_pt; size_t npairs; double t_struct_ms; std::vector<int> perm; uint8_t* h_rob; };
 struct BaBatch {
@@ -1998,6 +2018,8 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.Cinv = H.alloc<double>(6 * (size_t)npts, &rc); D.gps = H.alloc<double>(3 * (size_t)npts, &rc);
   D.E = H.alloc<double>(18 * (size_t)nobs, &rc); D.EC = H.alloc<double>(18 * (size_t)nobs, &rc);
   D.t3 = H.alloc<double>(3 * (size_t)std::max(nobs, 1), &rc);
+  D.cam_local = in.cam_local ? H.upload(in.cam_local, ncam, &rc, s) : nullptr;
+  D.erase = in.cam_local ? H.alloc<unsigned char>(std::max(nobs, 1), &rc) : nullptr;
   D.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
   D.Dinv = H.alloc<double>((size_t)npad * NB, &rc);
   D.part = H.alloc<double>(5 * (size_t)nparts, &rc);
@@ -2018,7 +2040,8 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
 // One LM iteration is a fixed sequence of ~60 launches: it is captured once into a hipGraph and replayed (one graph
 // launch per iteration); instantiated graphs are cached per host thread, keyed by the full kernel-argument blocks
 // (sizes and workspace pointers), so repeated solves of the same shape skip the capture too.  ORBHIP_BA_GRAPH=0 = direct.
-static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* opts, ba_summary* summaries, bool reuse_structure = false) {
+static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* opts, ba_summary* summaries, bool reuse_structure = false,
+                               uint8_t* const* erase_out = nullptr) {
   ORBHIP_REQUIRE(in && opts && nprob > 0, ORBHIP_EINVAL, "NULL argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
@@ -2172,7 +2195,10 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1, ny), dim3(1), 0, s, Dv);
   ORBHIP_CHECK_HIP(hipGetLastError());
   std::vector<BaState> fin(nprob);
+  const bool classify = erase_out != nullptr && Dh[0].erase != nullptr;
+  if (classify) hipLaunchKernelGGL(k_ba_classify, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
   for (int p = 0; p < nprob; p++) {
+    if (classify && in[p].nobs) ORBHIP_CHECK_HIP(hipMemcpyAsync(P[p].h_rob, Dh[p].erase, in[p].nobs, hipMemcpyDeviceToHost, s));   // (the pinned flag buffer is free again)
     ORBHIP_CHECK_HIP(hipMemcpyAsync(&fin[p], Dh[p].st, sizeof(BaState), hipMemcpyDeviceToHost, s));
     ORBHIP_CHECK_HIP(hipMemcpyAsync(in[p].poses7, Dh[p].poses, 7 * (size_t)in[p].ncam * sizeof(double), hipMemcpyDeviceToHost, s));
     if (in[p].npts) ORBHIP_CHECK_HIP(hipMemcpyAsync(in[p].pts3, Dh[p].pts, 3 * (size_t)in[p].npts * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2184,6 +2210,9 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     fprintf(stderr, "[ba_solve] problems=%d nobs=%ld pairs=%zu | structure %.2f ms, prepare+upload %.2f ms, enqueue %.2f ms, drain+download %.2f ms\n",
             nprob, nobs, pairs, ts, t_upload - t_start, t_enq - t_upload, ba_now_ms() - t_enq);
   }
+  if (classify)
+    for (int p = 0; p < nprob; p++)
+      for (int j = 0; j < in[p].nobs; j++) erase_out[p][P[p].perm[j]] = P[p].h_rob[j];
   if (summaries)
     for (int p = 0; p < nprob; p++) {
       ba_summary& o = summaries[p];
@@ -2473,16 +2502,20 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
     for (int q = 0; q < nproblems; q++) {
       const ba_local_problem& L = problems[q]; Work& w = W[q];
       in[q] = BaInputs{L.K4, w.P0.data(), L.cam_fixed, L.ncam, w.X0.data(), L.npts, w.oc.data(), w.op.data(), w.uv.data(), w.w.data(), w.rob.data(), (int)w.oc.size()};
+      if (duplicate_blocks) in[q].cam_local = L.cam_local;     // both passes see every observation: the outlier test runs on the device
     }
   };
+  std::vector<uint8_t*> erase_ptrs(nproblems);
+  for (int q = 0; q < nproblems; q++) erase_ptrs[q] = W[q].erase.data();
+  uint8_t* const* erase_dev = duplicate_blocks ? erase_ptrs.data() : nullptr;
   if (stop_flag && *stop_flag) { *aborted = 1; return 0; }                  // :509-512
   ba_options o1; o1.max_iterations = 5; o1.huber_delta = sqrt(5.991); o1.fix_points = 0; o1.stop_flag = stop_flag;
   bind();
-  int rc = ba_solve_batch_impl(in.data(), nproblems, &o1, pass1);
+  int rc = ba_solve_batch_impl(in.data(), nproblems, &o1, pass1, false, erase_dev);
   if (rc) return rc;
   for (int q = 0; q < nproblems; q++) {
     const ba_local_problem& L = problems[q]; Work& w = W[q];
-    classify(q);
+    if (!duplicate_blocks) classify(q);
     if (duplicate_blocks) {
       // F6: the reference adds every kept observation AGAIN without loss on the same problem; a kept observation and its
       // twin are folded into one block (obs_robust = 2, see reproj_eval) instead of being listed twice
@@ -2499,11 +2532,11 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
   if (stop_flag && *stop_flag) { *aborted = 1; return 0; }
   ba_options o2 = o1; o2.max_iterations = 10;
   bind();
-  rc = ba_solve_batch_impl(in.data(), nproblems, &o2, pass2, duplicate_blocks != 0);      // same observation set: structure reused
+  rc = ba_solve_batch_impl(in.data(), nproblems, &o2, pass2, duplicate_blocks != 0, erase_dev);      // same observation set: structure reused
   if (rc) return rc;
   for (int q = 0; q < nproblems; q++) {
     const ba_local_problem& L = problems[q]; Work& w = W[q];
-    classify(q);
+    if (!duplicate_blocks) classify(q);
     if (L.nobs) std::memcpy(L.obs_erase, w.erase.data(), L.nobs);
     for (int c = 0; c < L.ncam; c++) {                                      // Matrix_7_1_ToMatrix4d normalises (:80-81)
       double* qd = w.P0.data() + 7 * c + 3;
