@@ -2478,8 +2478,11 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
     ORBHIP_REQUIRE(L.npts == 0 || L.pts3, ORBHIP_EINVAL, "NULL argument");
     Work& w = W[q];
     w.P0.assign(L.poses7, L.poses7 + 7 * (size_t)L.ncam); w.X0.assign(L.pts3, L.pts3 + 3 * (size_t)L.npts);
-    w.oc.assign(L.obs_cam, L.obs_cam + L.nobs); w.op.assign(L.obs_pt, L.obs_pt + L.nobs);
-    w.uv.assign(L.obs_uv, L.obs_uv + 2 * (size_t)L.nobs); w.w.resize(L.nobs);
+    if (!duplicate_blocks) {                                                // (pass 2 filters these lists; with the re-added blocks the caller's arrays are used as they are)
+      w.oc.assign(L.obs_cam, L.obs_cam + L.nobs); w.op.assign(L.obs_pt, L.obs_pt + L.nobs);
+      w.uv.assign(L.obs_uv, L.obs_uv + 2 * (size_t)L.nobs);
+    }
+    w.w.resize(L.nobs);
     for (int i = 0; i < L.nobs; i++) {
       ORBHIP_REQUIRE(L.obs_cam[i] >= 0 && L.obs_cam[i] < L.ncam && L.obs_pt[i] >= 0 && L.obs_pt[i] < L.npts, ORBHIP_EINVAL, "observation index out of range");
       w.w[i] = (double)L.obs_inv_sigma2[i];                                // F7: weight = invSigma2
@@ -2501,8 +2504,12 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
   auto bind = [&]() {
     for (int q = 0; q < nproblems; q++) {
       const ba_local_problem& L = problems[q]; Work& w = W[q];
-      in[q] = BaInputs{L.K4, w.P0.data(), L.cam_fixed, L.ncam, w.X0.data(), L.npts, w.oc.data(), w.op.data(), w.uv.data(), w.w.data(), w.rob.data(), (int)w.oc.size()};
-      if (duplicate_blocks) in[q].cam_local = L.cam_local;     // both passes see every observation: the outlier test runs on the device
+      if (duplicate_blocks) {
+        in[q] = BaInputs{L.K4, w.P0.data(), L.cam_fixed, L.ncam, w.X0.data(), L.npts, L.obs_cam, L.obs_pt, L.obs_uv, w.w.data(), w.rob.data(), L.nobs};
+        in[q].cam_local = L.cam_local;                         // both passes see every observation: the outlier test runs on the device
+      } else {
+        in[q] = BaInputs{L.K4, w.P0.data(), L.cam_fixed, L.ncam, w.X0.data(), L.npts, w.oc.data(), w.op.data(), w.uv.data(), w.w.data(), w.rob.data(), (int)w.oc.size()};
+      }
     }
   };
   std::vector<uint8_t*> erase_ptrs(nproblems);
