@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
         for (int b = a; b < 6; b++) acc[7 + sym6(a, b)] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
       }
     }
-    block_reduce<28>(acc, s_red, s_sum);
+    block_reduce_dpp<28>(acc, s_red, s_sum);
     if (tid == 0) {
       s_xcost = s_sum[0];
       for (int a = 0; a < 6; a++) s_g[a] = s_sum[1 + a];
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
       for (int b = a; b < 6; b++) acc[sym6(a, b)] += J[a] * J[b] + J[6 + a] * J[6 + b];
     }
   }
-  block_reduce<27>(acc, s_red, s_out);
+  block_reduce_dpp<27>(acc, s_red, s_out);
   if (threadIdx.x < 21) D.B[21 * (size_t)cc + threadIdx.x] = s_out[threadIdx.x];
   if (threadIdx.x < 6) D.gc[6 * (size_t)cc + threadIdx.x] = s_out[21 + threadIdx.x];
 }
