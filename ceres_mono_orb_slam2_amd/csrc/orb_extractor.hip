@@ -70,6 +70,29 @@ __device__ __forceinline__ const uint8_t* level_ptr(const GeomDev& G, int l, int
                 : pyr + (long long)f * G.pyr_frame_bytes + G.lv[l].pyr_off;
 }
 
+// ---- wave-level integer sum / inclusive scan on DPP row operations (VALU only; __shfl goes through the LDS crossbar, ~100
+// cycles of dependent latency per step) -------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true); }
+__device__ __forceinline__ int wave_sum_i32(int v) {              // total in every lane (readlane of lane 63)
+  v += dpp_i32<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+  v += dpp_i32<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+  v += dpp_i32<0x141, 0xF>(v);      // row_half_mirror
+  v += dpp_i32<0x140, 0xF>(v);      // row_mirror
+  v += dpp_i32<0x142, 0xA>(v);      // row_bcast15 -> rows 1, 3
+  v += dpp_i32<0x143, 0xC>(v);      // row_bcast31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {        // Hillis-Steele inside each row of 16, then the row totals
+  v += dpp_i32<0x111, 0xF>(v);      // row_shr:1
+  v += dpp_i32<0x112, 0xF>(v);      // row_shr:2
+  v += dpp_i32<0x114, 0xF>(v);      // row_shr:4
+  v += dpp_i32<0x118, 0xF>(v);      // row_shr:8
+  v += dpp_i32<0x142, 0xA>(v);      // row_bcast15 -> rows 1, 3
+  v += dpp_i32<0x143, 0xC>(v);      // row_bcast31 -> rows 2, 3
+  return v;
+}
+
 // ---------------------------------------------------------------------------- k_resize
 // xtab[dx] = {sx | a0 << 16, a0 | a1 << 16}: source column and the two fixed-point weights (0..2048) of output column dx.
 // Each thread produces 4 output pixels; their <= 7 distinct source columns per row come from three
@@ -324,10 +347,8 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   // lane r holds row r's mask; exclusive wave scan of the row populations gives every row's base offset
   const unsigned long long mrow = (lane < ih) ? mask[lane] : 0ull;
   const int cnt = __popcll(mrow);
-  int incl = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-  const int base = __shfl(incl, 63);
+  const int incl = wave_incl_scan_i32(cnt);
+  const int base = __builtin_amdgcn_readlane(incl, 63);
   unsigned long long rows = __ballot(cnt > 0);
   while (rows) {
     const int iy = __ffsll((long long)rows) - 1;
@@ -803,8 +824,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
     for (int k = 0; k < 31; k++) { const int u = k - 15; const int vv = (u >= -d && u <= d) ? val[k] : 0; rs += vv; m10 += u * vv; }
     m01 = v * rs;
   }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+  m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10, p1, p3, p5, p7);
   // ---- rotated BRIEF-256 on the blurred level (src/ORBextractor.cc:107-147) ---------------------
   const float ang_rad = __fmul_rn(angle, factorPI);
