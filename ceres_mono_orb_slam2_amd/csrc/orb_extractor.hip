@@ -353,8 +353,10 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   while (rows) {
     const int iy = __ffsll((long long)rows) - 1;
     rows &= rows - 1;
-    const unsigned long long m = __shfl(mrow, iy);
-    const int rbase = __shfl(incl, iy) - __shfl(cnt, iy);
+    // (iy comes from a wave ballot: uniform - v_readlane instead of three trips through the LDS crossbar)
+    const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mrow, iy) |
+                                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mrow >> 32), iy) << 32);
+    const int rbase = __builtin_amdgcn_readlane(incl, iy) - __builtin_amdgcn_readlane(cnt, iy);
     if ((m >> lane) & 1ull) {
       const int pos = rbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       if (pos < G.cell_cap) {
@@ -375,9 +377,7 @@ __device__ int block_excl_scan(int* a, int n, int* s_tmp) {
   int sum = 0;
   for (int i = beg; i < end; i++) sum += a[i];
   const int lane = tid & 63, w = tid >> 6;
-  int v = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v += t; }
+  int v = wave_incl_scan_i32(sum);
   if (lane == 63) s_tmp[w] = v;
   __syncthreads();
   int woff = 0, total = 0;
@@ -795,12 +795,10 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   int total = 0, level = -1, pos = 0;
   {
     int cl = (lane < G.nlevels) ? min(sel_cnt[f * G.nlevels + lane], G.sel_cap) : 0;
-    int incl = cl;
-#pragma unroll
-    for (int o = 1; o < MAX_LEVELS; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    total = __shfl(incl, G.nlevels - 1);
+    const int incl = wave_incl_scan_i32(cl);
+    total = __builtin_amdgcn_readlane(incl, 63);                             // (lanes >= nlevels hold 0)
     const unsigned long long m = __ballot(lane < G.nlevels && i < incl);     // first level whose inclusive prefix exceeds i
-    if (m) { level = __ffsll((long long)m) - 1; pos = i - (__shfl(incl, level) - __shfl(cl, level)); }
+    if (m) { level = __ffsll((long long)m) - 1; pos = i - (__builtin_amdgcn_readlane(incl, level) - __builtin_amdgcn_readlane(cl, level)); }
   }
   const bool bad = status[f] != 0 || total > cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[f] = bad ? (status[f] != 0 ? -1 : -2) : total;
@@ -849,9 +847,9 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
     nib |= (uint32_t)(t[0] < t[1]) << j;
   }
   // lane 2k holds the low nibble, lane 2k+1 the high nibble of byte k
-  uint32_t byte = nib | (__shfl_down(nib, 1) << 4);            // valid on even lanes
-  uint32_t half = byte | (__shfl_down(byte, 2) << 8);          // lanes = 0 mod 4
-  uint32_t word = half | (__shfl_down(half, 4) << 16);         // lanes = 0 mod 8: bytes (lane/2 .. lane/2+3)
+  uint32_t byte = nib | ((uint32_t)dpp_i32<0x101, 0xF>((int)nib) << 4);     // row_shl:1 = lane + 1; valid on even lanes
+  uint32_t half = byte | ((uint32_t)dpp_i32<0x102, 0xF>((int)byte) << 8);    // lanes = 0 mod 4
+  uint32_t word = half | ((uint32_t)dpp_i32<0x104, 0xF>((int)half) << 16);   // lanes = 0 mod 8: bytes (lane/2 .. lane/2+3)
   if ((lane & 7) == 0) *(uint32_t*)(desc + ((long long)f * cap + i) * 32 + (lane >> 1)) = word;
   if (lane == 0) {
     orbx_keypoint kp;
