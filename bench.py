@@ -28,7 +28,7 @@ BYTES = {"pyramid": 1407767 + 977481, "fast_cells": 1444097, "blur": 2 * 1444097
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer VALU instruction issues over 4 cycles;
                                # measured 35-39 T lane-instr/s for xor/bcnt/pk_*16/dot4/dot2/sad/alignbyte (tools/ubench/valu_rate.hip)
-MATCH_LANE_OPS_PER_PAIR = 19   # 8 xor + 8 bcnt-accumulate + ~3 compare/select per descriptor pair
+MATCH_LANE_OPS_PER_PAIR = 19.5   # VALU instructions per Hamming distance in k_match_pairs (ISA-checked: 8 xor + 8 v_bcnt + v_lshl_or + v_max + v_min + half a v_min3)
 
 
 def make_frames(batch, seed):
