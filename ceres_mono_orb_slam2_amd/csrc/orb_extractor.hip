@@ -60,8 +60,8 @@ struct GeomDev {
   LevelDev lv[MAX_LEVELS];
 };
 
-struct CellDesc { short level, x0, y0, x1, y1, offx, offy, pad; };
-struct BlurTile { short level, tx, ty, pad; };
+struct alignas(16) CellDesc { short level, x0, y0, x1, y1, offx, offy, pad; };   // 16-byte aligned: read with one scalar load
+struct alignas(8) BlurTile { short level, tx, ty, pad; };
 
 // ---------------------------------------------------------------------------- device helpers
 __device__ __forceinline__ const uint8_t* level_ptr(const GeomDev& G, int l, int f, const uint8_t* img0,
@@ -232,9 +232,10 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   // this kernel's FETCH_SIZE 4.9x - neighbouring cells then share one L2 - but makes it 40 % SLOWER; it is
   // latency/issue-bound, not HBM-bound, so the faster mapping is kept.  DESIGN.md section 4.)
   const int f = blockIdx.y;
-  const int ci = blockIdx.x * FAST_WPB + (threadIdx.x >> 6);
+  const int wv = FAST_WPB == 1 ? 0 : (int)(threadIdx.x >> 6);       // (one wave per workgroup: the cell index is visibly uniform, its descriptor comes by scalar loads)
+  const int ci = blockIdx.x * FAST_WPB + wv;
   if (ci >= G.ncells_total) return;                   // (no workgroup-wide barrier below: waves are independent)
-  uint8_t* smem = smem_all + (size_t)(threadIdx.x >> 6) * lds_per_wave;
+  uint8_t* smem = smem_all + (size_t)wv * lds_per_wave;
   uint8_t* tile = smem;                               // [tile_h][TP]
   uint8_t* score = smem + plane;                      // [tile_h][TP]
   unsigned long long* keep = (unsigned long long*)(score + plane);    // [64] NMS survivors per interior row (bit = ix)
@@ -253,21 +254,27 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     // the ~1 us global latency per row).  Each lane fetches, for 4 rows per step, the two aligned dwords
     // that cover its 4 tile bytes and realigns them with v_alignbyte; the detection window keeps a 16-px
     // margin to the image border, so the <= 7 trailing bytes are always inside the frame.
+    // wave-uniform aligned base + a 32-bit per-lane byte offset: the loads take the scalar-base form and the row walk is one
+    // v_add per row (per-lane 64-bit pointers cost ~100 VALU per cell here, a sixth of them quarter-rate 64-bit multiply-adds)
     const uint8_t* base = src + (long long)c.y0 * L.pitch + c.x0;
+    const uint32_t bsh = (uint32_t)((size_t)base & 3);
+    const uint8_t* base_al = base - bsh;
     const int col = lane & 15, r0 = lane >> 4;
+    int off = r0 * L.pitch + 4 * col + (int)bsh;
+    const int step = 4 * L.pitch;
     uint32_t v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int y = r0 + 4 * k;
       v[k] = 0u;
       if (y < th && 4 * col < tw) {
-        const uint8_t* a = base + (long long)y * L.pitch + 4 * col;
-        const uint32_t sh = (uint32_t)((size_t)a & 3);
-        const uint32_t* aa = (const uint32_t*)(a - sh);
+        const uint32_t sh = (uint32_t)off & 3u;
+        const uint32_t* aa = (const uint32_t*)(base_al + (off & ~3));
         const uint32_t lo = aa[0];
         const uint32_t hi = sh ? aa[1] : 0u;
         v[k] = __builtin_amdgcn_alignbyte(hi, lo, sh);
       }
+      off += step;
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
