@@ -260,26 +260,24 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     const uint32_t bsh = (uint32_t)((size_t)base & 3);
     const uint8_t* base_al = base - bsh;
     const int col = lane & 15, r0 = lane >> 4;
-    int off = r0 * L.pitch + 4 * col + (int)bsh;
-    const int step = 4 * L.pitch;
-    uint32_t v[16];
+    // BRANCH-FREE requests: rows / column groups outside the tile are clamped onto valid ones (their data is simply not
+    // stored) and the second dword is always read (the 16-px border margin keeps it inside the frame).  With the loads under
+    // `if (row inside) { lo = ..; hi = sh ? .. : 0; align }` the compiler kept every row's wait inside its branch: sixteen
+    // SERIAL global round trips per cell, most of a wave's lifetime.
+    const int colc = (4 * col < tw) ? 4 * col : 0;
+    uint32_t lo[16], hi[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const int y = r0 + 4 * k;
-      v[k] = 0u;
-      if (y < th && 4 * col < tw) {
-        const uint32_t sh = (uint32_t)off & 3u;
-        const uint32_t* aa = (const uint32_t*)(base_al + (off & ~3));
-        const uint32_t lo = aa[0];
-        const uint32_t hi = sh ? aa[1] : 0u;
-        v[k] = __builtin_amdgcn_alignbyte(hi, lo, sh);
-      }
-      off += step;
+      const int y = min(r0 + 4 * k, th - 1);
+      const int off = y * L.pitch + colc + (int)bsh;
+      const uint32_t* aa = (const uint32_t*)(base_al + (off & ~3));
+      lo[k] = aa[0]; hi[k] = aa[1];
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int y = r0 + 4 * k;
-      if (y < th && 4 * col < tw) *(uint32_t*)(tile + y * TP + 4 * col) = v[k];
+      const uint32_t sh = (uint32_t)(min(y, th - 1) * L.pitch + colc + (int)bsh) & 3u;
+      if (y < th && 4 * col < tw) *(uint32_t*)(tile + y * TP + 4 * col) = __builtin_amdgcn_alignbyte(hi[k], lo[k], sh);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
