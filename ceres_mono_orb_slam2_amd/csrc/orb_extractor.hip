@@ -798,6 +798,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   const int i = blockIdx.x * DESC_WPB + (threadIdx.x >> 6);      // keypoint index inside the frame
   // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104): one lane per level + ballot
   int total = 0, level = -1, pos = 0;
+  const int st_f = status[f];                               // (requested together with the level counts: one dependent round trip less)
   {
     int cl = (lane < G.nlevels) ? min(sel_cnt[f * G.nlevels + lane], G.sel_cap) : 0;
     const int incl = wave_incl_scan_i32(cl);
@@ -805,8 +806,8 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
     const unsigned long long m = __ballot(lane < G.nlevels && i < incl);     // first level whose inclusive prefix exceeds i
     if (m) { level = __ffsll((long long)m) - 1; pos = i - (__builtin_amdgcn_readlane(incl, level) - __builtin_amdgcn_readlane(cl, level)); }
   }
-  const bool bad = status[f] != 0 || total > cap;
-  if (blockIdx.x == 0 && threadIdx.x == 0) counts[f] = bad ? (status[f] != 0 ? -1 : -2) : total;
+  const bool bad = st_f != 0 || total > cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[f] = bad ? (st_f != 0 ? -1 : -2) : total;
   if (bad || level < 0) return;
   const LevelDev& L = G.lv[level];
   const uint32_t key = sel[((long long)f * G.nlevels + level) * G.sel_cap + pos];
