@@ -130,6 +130,7 @@ __device__ bool small_chol_solve(double* A, double* b, int n) {
 // upper-triangle index of a symmetric 6x6 stored as 21 values
 __device__ __forceinline__ int sym6(int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); }
 
+#define POSE_R 8
 __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s, double* __restrict__ poses,
                                                  const double* __restrict__ Xw, const double* __restrict__ uv,
                                                  const float* __restrict__ inv_sigma2, const int* __restrict__ offsets,
@@ -152,16 +153,44 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
   }
   if (tid < 7) s_x[tid] = pose[tid];
   if (tid == 0) { s_radius = 1e4; s_dec = 2.0; s_iter = 0; s_term = 0; s_done = 0; s_invalid = 0; s_succ = 0; s_nbad = 0; }
+  // The observations never change during the solve: up to POSE_R per thread (frames of up to 2048 map points) are read
+  // ONCE into registers; every evaluation of the LM loop - two passes over the observations per iteration - then runs
+  // without a global load.  (One workgroup per frame = one wave per SIMD: the per-iteration loads were pure exposed latency.)
+  const bool in_regs = n <= 256 * POSE_R;
+  double oX[POSE_R][3], oU[POSE_R][2], oW[POSE_R];
+  if (in_regs) {
+#pragma unroll
+    for (int u = 0; u < POSE_R; u++) {
+      const int i = tid + 256 * u;
+      const size_t g = (size_t)lo + (size_t)min(i, n - 1);
+      oX[u][0] = Xw[3 * g]; oX[u][1] = Xw[3 * g + 1]; oX[u][2] = Xw[3 * g + 2];
+      oU[u][0] = uv[2 * g]; oU[u][1] = uv[2 * g + 1];
+      oW[u] = (double)inv_sigma2[g];
+    }
+  }
+  const double k4r[4] = {K4[0], K4[1], K4[2], K4[3]};
+  // f(i, X, u, v, w) over this thread's observations
+  auto for_obs = [&](auto f) {
+    if (in_regs) {
+#pragma unroll
+      for (int u = 0; u < POSE_R; u++) { const int i = tid + 256 * u; if (i < n) f(i, oX[u], oU[u][0], oU[u][1], oW[u]); }
+    } else {
+      for (int i = tid; i < n; i += 256) {
+        const size_t g = (size_t)lo + i;
+        const double X[3] = {Xw[3 * g], Xw[3 * g + 1], Xw[3 * g + 2]};
+        f(i, X, uv[2 * g], uv[2 * g + 1], (double)inv_sigma2[g]);
+      }
+    }
+  };
   __syncthreads();
 
   auto evaluate = [&](bool first) {
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
-    for (int i = tid; i < n; i += 256) {
+    for_obs([&](int, const double* X, double u0, double v0, double w) {
       double r[2], Jc[12];
-      const int g = lo + i;
-      double rho = reproj_eval(K4, s_x, Xw + 3 * (size_t)g, uv[2 * (size_t)g], uv[2 * (size_t)g + 1], (double)inv_sigma2[g], 1, huber, r, Jc, nullptr);
+      double rho = reproj_eval(k4r, s_x, X, u0, v0, w, 1, huber, r, Jc, nullptr);
       acc[0] += 0.5 * rho;
 #pragma unroll
       for (int a = 0; a < 6; a++) {
@@ -169,7 +198,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
 #pragma unroll
         for (int b = a; b < 6; b++) acc[7 + sym6(a, b)] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
       }
-    }
+    });
     block_reduce_dpp<28>(acc, s_red, s_sum);
     if (tid == 0) {
       s_xcost = s_sum[0];
@@ -242,11 +271,10 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
     if (!valid) continue;
     // candidate cost
     double acc[1] = {0.0};
-    for (int i = tid; i < n; i += 256) {
+    for_obs([&](int, const double* X, double u0, double v0, double w) {
       double r[2];
-      const int g = lo + i;
-      acc[0] += 0.5 * reproj_eval(K4, s_cand, Xw + 3 * (size_t)g, uv[2 * (size_t)g], uv[2 * (size_t)g + 1], (double)inv_sigma2[g], 1, huber, r, nullptr, nullptr);
-    }
+      acc[0] += 0.5 * reproj_eval(k4r, s_cand, X, u0, v0, w, 1, huber, r, nullptr, nullptr);
+    });
     block_reduce<1>(acc, s_red, s_sum);
     if (tid == 0) {
       double cand_cost = s_sum[0];
@@ -277,12 +305,11 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
   __syncthreads();
   // CheckOutliers with the un-normalised quaternion (:333), then normalise for SetPose (:336)
   int bad = 0;
-  for (int i = tid; i < n; i += 256) {
-    const int g = lo + i;
-    int o = check_outlier(K4, s_x, Xw + 3 * (size_t)g, uv[2 * (size_t)g], uv[2 * (size_t)g + 1], (double)inv_sigma2[g], 5.991, nullptr);
-    outlier[g] = (uint8_t)o;
+  for_obs([&](int i, const double* X, double u0, double v0, double w) {
+    int o = check_outlier(k4r, s_x, X, u0, v0, w, 5.991, nullptr);
+    outlier[lo + i] = (uint8_t)o;
     bad += o;
-  }
+  });
   if (bad) atomicAdd(&s_nbad, bad);
   __syncthreads();
   if (tid == 0) {
