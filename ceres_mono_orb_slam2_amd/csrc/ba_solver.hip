@@ -555,6 +555,15 @@ struct BaDev {            // device pointers of one problem
   BaState* st;
 };
 
+// The early-exit flags of a problem, read with UNCONDITIONAL loads: `if (st->done || !st->valid || st->chol_fail) return;` makes
+// the compiler fetch and wait for each flag in turn (short-circuit semantics) - two or three serial round trips at the top of
+// every one of the ~45 kernels of an LM iteration.
+struct StFlags { int done, need_eval, valid, chol_fail, accepted; };
+__device__ __forceinline__ StFlags ld_flags(const BaState* st) {
+  StFlags f; f.done = st->done; f.need_eval = st->need_eval; f.valid = st->valid; f.chol_fail = st->chol_fail; f.accepted = st->accepted;
+  return f;
+}
+
 #define BA_TPB 256
 
 // ---- residuals + Jacobians at x (mode 0) or cost only at the candidate (mode 1) -------------------
@@ -562,9 +571,10 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4], s_out[1];
   const BaState* st = D.st;
-  if (st->done) return;
-  if (mode == 0 && !st->need_eval) return;
-  if (mode == 1 && !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done) return;
+  if (mode == 0 && !F.need_eval) return;
+  if (mode == 1 && !F.valid) return;
   if ((int)blockIdx.x * BA_TPB >= max(D.nobs, 1)) return;               // batched launch: grid.x is the maximum over the problems
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
   double acc[1] = {0.0};
@@ -598,7 +608,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4 * 27], s_out[27];
   const BaState* st = D.st;
-  if (st->done || !st->need_eval) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.need_eval) return;
   const int c = blockIdx.x;
   if (c >= D.ncam) return;
   const int cc = D.cam_col[c];
@@ -628,7 +639,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
 __global__ __launch_bounds__(BA_TPB) void k_ba_pt_blocks(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
-  if (st->done || !st->need_eval || D.fix_points) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.need_eval || D.fix_points) return;
   const int p = blockIdx.x * BA_TPB + threadIdx.x;
   if (p >= D.npts) return;
   const size_t n = D.nobs;
@@ -652,7 +664,8 @@ __global__ __launch_bounds__(AE_TPB) void k_ba_after_eval(const BaDev* __restric
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[16 * 3], s_out[3];
   BaState* st = D.st;
-  if (st->done || !st->need_eval) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.need_eval) return;
   const int tid = threadIdx.x;
   if (st->first) {
     for (int j = tid; j < 6 * D.nfc; j += AE_TPB) D.scale_c[j] = 1.0 / (1.0 + sqrt(D.B[21 * (size_t)(j / 6) + sym6(j % 6, j % 6)]));
@@ -704,11 +717,14 @@ __global__ __launch_bounds__(AE_TPB) void k_ba_after_eval(const BaDev* __restric
 __global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
-  if (st->done) return;
+  const StFlags F = ld_flags(st);
+  const int iteration = st->iteration, max_iters = st->max_iters;      // (all reads first: one round trip)
+  const double radius = st->radius;
+  if (F.done) return;
   st->valid = 0; st->accepted = 0; st->chol_fail = 0;
-  if (st->iteration >= st->max_iters) { st->termination = 0; st->done = 1; return; }
-  if (st->radius <= 1e-32) { st->termination = 6; st->done = 1; return; }
-  st->iteration++;
+  if (iteration >= max_iters) { st->termination = 0; st->done = 1; return; }
+  if (radius <= 1e-32) { st->termination = 6; st->done = 1; return; }
+  st->iteration = iteration + 1;
   st->valid = 1;          // provisional; cleared by a failed factorisation / non-positive model change
 }
 
@@ -726,7 +742,8 @@ __device__ __forceinline__ bool inv3_sym6(const double* C, double* Ci) {   // C 
 __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
-  if (st->done || !st->valid || D.fix_points) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid || D.fix_points) return;
   const int p = blockIdx.x * BA_TPB + threadIdx.x;
   if (p >= D.npts) return;
   if (D.pt_off[p] == D.pt_off[p + 1]) return;
@@ -749,7 +766,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restric
 __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
-  if (st->done || !st->valid || D.fix_points) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid || D.fix_points) return;
   if ((int)blockIdx.x * BA_TPB >= D.nobs) return;
   __shared__ double s_t[BA_TPB / 64][64][19];          // + 1 pad
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
@@ -806,7 +824,8 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
   const BaDev D = Dv[blockIdx.y];
   const int* __restrict__ free_cams = D.free_cams;
   const BaState* st = D.st;
-  if (st->done || !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid) return;
   const int tid = threadIdx.x;
   const int np = D.npad;
   __shared__ double s_red[16 * 36], s_out[36];
@@ -884,7 +903,8 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
 __global__ __launch_bounds__(256) void k_ba_zero_S(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
-  if (st->done || !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid) return;
   const size_t tot = (size_t)D.n6 * D.npad;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) D.S[i] = 0.0;
 }
@@ -1004,6 +1024,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
   const BaDev D = Dv[blockIdx.y];
   if (D.chol_la) return;                                      // factored by k_chol_la
   BaState* st = D.st;
+  const StFlags F = ld_flags(st);
   __shared__ double s_L[NB][NB + 1];
   __shared__ double s_X[NB][NB + 1];
   __shared__ double s_dinv[NB];
@@ -1028,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
   for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; d4[u] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0; }
   // (the state flags are read AFTER the matrix loads are in flight: one dependent global round trip less per launch;
   // S is a valid allocation for finished problems too)
-  if (st->done || !st->valid || st->chol_fail) return;
+  if (F.done || !F.valid || F.chol_fail) return;
 #pragma unroll
   for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; s_L[i / NB][i % NB] = d4[u]; }
   if (tid == 0) s_fail = 0;
@@ -1083,6 +1104,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
 // blockIdx.x >= ntiles update the augmented rhs row (row npad) over the same column range.
 __device__ __forceinline__ void chol_syrk_body(const BaDev& D, const BaState* st, const int bx, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles,
                                                double (*s_A)[NB + 1], double (*s_B)[NB + 1]) {
+  const StFlags F = ld_flags(st);
   const int np = D.npad, tid = threadIdx.x;
   // batched launch: the grid and (kcol, K, r_lo, c_lo, c_hi_cap) are laid out for the LARGEST reduced system of the batch;
   // this problem clips the column range to its own size and drops the steps / tiles that fall outside
@@ -1090,7 +1112,7 @@ __device__ __forceinline__ void chol_syrk_body(const BaDev& D, const BaState* st
   if (kcol + K > np || c_hi <= c_lo) return;
   double* S = D.S;
   if (bx >= ntiles) {           // augmented rhs row
-    if (st->done || !st->valid || st->chol_fail) return;
+    if (F.done || !F.valid || F.chol_fail) return;
     double* zrow = S + (size_t)np * np;
     double* s_z = &s_A[0][0];
     for (int i = tid; i < K; i += 256) s_z[i] = zrow[kcol + i];
@@ -1135,7 +1157,7 @@ __device__ __forceinline__ void chol_syrk_body(const BaDev& D, const BaState* st
         const int col = c0 + qc + 16 * j + (lane & 15);
         cpre[i][j][rg] = (!qskip && row < np && col < c_hi && col <= row) ? S[(size_t)row * np + col] : 0.0;
       }
-  if (st->done || !st->valid || st->chol_fail) return;
+  if (F.done || !F.valid || F.chol_fail) return;
   for (int k0 = 0; k0 < K; k0 += NB) {
     __syncthreads();
     if (k0 > 0) {
@@ -1200,6 +1222,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   const BaDev D = Dv[blockIdx.y];
   if (!D.chol_la) return;
   BaState* st = D.st;
+  const StFlags F = ld_flags(st);
   __shared__ __attribute__((aligned(16))) double s_raw[5 * NB * (NB + 1) + NB];
   const int np = D.npad, tid = threadIdx.x;
   if ((int)blockIdx.x >= nA) {
@@ -1240,7 +1263,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
       ap[g][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;      // negated: L21 = A21 X^T + (-Lprev) M^T
     }
   }
-  if (st->done || !st->valid || st->chol_fail) return;
+  if (F.done || !F.valid || F.chol_fail) return;
 #pragma unroll
   for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; s_L[i / NB][i % NB] = d4[u]; s_P[i / NB][i % NB] = p4[u]; }
   if (tid == 0) s_fail = 0;
@@ -1332,6 +1355,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
 __global__ __launch_bounds__(1024) void k_chol_bsolve_diag(const BaDev* __restrict__ Dv, int kb) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
+  const StFlags F = ld_flags(st);
   __shared__ double s_y[SBLK], s_x[NB];
   __shared__ double s_p[NB][SBLK - NB];                             // partial products, [row of the block][column above the block]
   const int np = D.npad, tid = threadIdx.x;
@@ -1349,7 +1373,7 @@ __global__ __launch_bounds__(1024) void k_chol_bsolve_diag(const BaDev* __restri
 #pragma unroll
     for (int cb = 0; cb < bb; cb++)
       sv[bb * (bb - 1) / 2 + cb] = (bb < nblk) ? S[(size_t)(kb + NB * bb + r) * np + kb + NB * cb + c] : 0.0;
-  if (st->done || !st->valid || st->chol_fail) return;
+  if (F.done || !F.valid || F.chol_fail) return;
   const double* src = first ? (D.S + (size_t)np * np) : D.rhs;      // the first (bottom) super-block starts from z
   if (first) for (int i = tid; i < kb; i += 1024) D.rhs[i] = src[i];  // seed the running vector for the rows above
   if (tid < ke - kb) s_y[tid] = src[kb + tid];
@@ -1390,6 +1414,7 @@ __global__ __launch_bounds__(1024) void k_chol_bsolve_diag(const BaDev* __restri
 __global__ __launch_bounds__(1024) void k_chol_bsolve_update(const BaDev* __restrict__ Dv, int kb) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
+  const StFlags F = ld_flags(st);
   __shared__ double s_x[SBLK], s_p[16][64];
   const int np = D.npad, tid = threadIdx.x;
   if (kb >= np || (int)blockIdx.x * 64 >= kb) return;
@@ -1403,7 +1428,7 @@ __global__ __launch_bounds__(1024) void k_chol_bsolve_update(const BaDev* __rest
     const int rr = rg + 16 * u;
     lv[u] = (c < kb && rr < nr) ? D.S[(size_t)(kb + rr) * np + c] : 0.0;
   }
-  if (st->done || !st->valid || st->chol_fail) return;
+  if (F.done || !F.valid || F.chol_fail) return;
   if (tid < nr) s_x[tid] = D.rhs[kb + tid];
   __syncthreads();
   double sum = 0.0;
@@ -1424,7 +1449,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restric
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4], s_out[1];
   const BaState* st = D.st;
-  if (st->done || !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid) return;
   if ((int)blockIdx.x * BA_TPB >= D.ncam) return;
   const int c = blockIdx.x * BA_TPB + threadIdx.x;
   double acc[1] = {0.0};
@@ -1459,7 +1485,8 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
   __shared__ double s_red[16 * 2], s_out[2];
   __shared__ double s_step[BS_PTS][3];
   const BaState* st = D.st;
-  if (st->done || !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid) return;
   if ((int)blockIdx.x * BS_PTS >= max(D.npts, 1)) return;
   const int tid = threadIdx.x;
   const int p0 = blockIdx.x * BS_PTS, p1 = min(p0 + BS_PTS, D.npts);
@@ -1542,7 +1569,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(const BaDev* __restrict_
   const int nb_obs = max((D.nobs + BA_TPB - 1) / BA_TPB, 1), nb_cam = (D.ncam + BA_TPB - 1) / BA_TPB, nb_pt = max((D.npts + BA_TPB - 1) / BA_TPB, 1);
   __shared__ double s_red[4 * 3], s_out[3];
   BaState* st = D.st;
-  if (st->done || !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid) return;
   const int tid = threadIdx.x;
   double acc[3] = {0.0, 0.0, 0.0};           // candidate cost, model cost change, |dx|^2
   for (int b = tid; b < nb_obs; b += BA_TPB) acc[0] += D.part[D.nparts + b];
@@ -1577,7 +1605,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(const BaDev* __restrict_
 __global__ __launch_bounds__(BA_TPB) void k_ba_apply(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
-  if (st->done || !st->accepted) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.accepted) return;
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
   if (i < 7 * D.ncam) D.poses[i] = D.cand_poses[i];
   if (i < 3 * D.npts) D.pts[i] = D.cand_pts[i];
@@ -1629,9 +1658,10 @@ struct PgDev {
 __global__ __launch_bounds__(128) void k_pg_eval(PgDev P, int mode) {
   __shared__ double s_red[4], s_out[1];
   const BaState* st = P.st;
-  if (st->done) return;
-  if (mode == 0 && !st->need_eval) return;
-  if (mode == 1 && !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done) return;
+  if (mode == 0 && !F.need_eval) return;
+  if (mode == 1 && !F.valid) return;
   const int e = blockIdx.x * 128 + threadIdx.x;
   double acc = 0.0;
   if (e < P.ne) {
@@ -1656,7 +1686,8 @@ __global__ __launch_bounds__(128) void k_pg_eval(PgDev P, int mode) {
 // per free vertex (thread): gradient, (first time) Jacobi scale, |x|^2 and its gradient-max-norm term
 __global__ __launch_bounds__(128) void k_pg_vertex(PgDev P) {
   const BaState* st = P.st;
-  if (st->done || !st->need_eval) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.need_eval) return;
   const int v = blockIdx.x * 128 + threadIdx.x;
   if (v >= P.n) return;
   const int c = P.col[v];
@@ -1687,7 +1718,8 @@ __global__ __launch_bounds__(128) void k_pg_vertex(PgDev P) {
 __global__ __launch_bounds__(256) void k_pg_after_eval(PgDev P) {
   __shared__ double s_red[4 * 2], s_out[2], s_max[4];
   BaState* st = P.st;
-  if (st->done || !st->need_eval) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.need_eval) return;
   const int tid = threadIdx.x;
   double acc[2] = {0.0, 0.0};
   double m = 0.0;
@@ -1709,7 +1741,8 @@ __global__ __launch_bounds__(256) void k_pg_after_eval(PgDev P) {
 // off-diagonal block; every block sums its edges in list order (deterministic), element (u, v) per lane
 __global__ __launch_bounds__(64) void k_pg_build(PgDev P) {
   const BaState* st = P.st;
-  if (st->done || !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid) return;
   const int np = P.npad, tid = threadIdx.x;
   const int u = tid / 7, w = tid - 7 * u;
   if ((int)blockIdx.x < P.n) {                         // diagonal block + rhs of vertex v
@@ -1761,7 +1794,8 @@ __global__ void k_pg_pad(PgDev P) {
 __global__ __launch_bounds__(128) void k_pg_step(PgDev P) {
   __shared__ double s_red[2];
   const BaState* st = P.st;
-  if (st->done || !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid) return;
   const int v = blockIdx.x * 128 + threadIdx.x;
   double acc = 0.0;
   if (v < P.n) {
@@ -1787,7 +1821,8 @@ __global__ __launch_bounds__(128) void k_pg_step(PgDev P) {
 __global__ __launch_bounds__(128) void k_pg_mcc(PgDev P) {
   __shared__ double s_red[2];
   const BaState* st = P.st;
-  if (st->done || !st->valid) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid) return;
   const int e = blockIdx.x * 128 + threadIdx.x;
   double acc = 0.0;
   if (e < P.ne && !st->chol_fail) {
@@ -1816,7 +1851,8 @@ __global__ __launch_bounds__(128) void k_pg_mcc(PgDev P) {
 
 __global__ __launch_bounds__(256) void k_pg_apply(PgDev P) {
   const BaState* st = P.st;
-  if (st->done || !st->accepted) return;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.accepted) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 7 * P.n) P.x[i] = P.cand[i];
 }
