@@ -264,20 +264,19 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     // stored) and the second dword is always read (the 16-px border margin keeps it inside the frame).  With the loads under
     // `if (row inside) { lo = ..; hi = sh ? .. : 0; align }` the compiler kept every row's wait inside its branch: sixteen
     // SERIAL global round trips per cell, most of a wave's lifetime.
-    const int colc = (4 * col < tw) ? 4 * col : 0;
-    uint32_t lo[16], hi[16];
+    const bool colv = 4 * col < tw;
+    const int c0 = (colv ? 4 * col : 0) + (int)bsh;
+    uint32_t lo[16], hi[16]; int offk[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const int y = min(r0 + 4 * k, th - 1);
-      const int off = y * L.pitch + colc + (int)bsh;
-      const uint32_t* aa = (const uint32_t*)(base_al + (off & ~3));
+      offk[k] = min(r0 + 4 * k, th - 1) * L.pitch + c0;
+      const uint32_t* aa = (const uint32_t*)(base_al + (offk[k] & ~3));
       lo[k] = aa[0]; hi[k] = aa[1];
     }
+    uint8_t* trow = tile + r0 * TP + 4 * col;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const int y = r0 + 4 * k;
-      const uint32_t sh = (uint32_t)(min(y, th - 1) * L.pitch + colc + (int)bsh) & 3u;
-      if (y < th && 4 * col < tw) *(uint32_t*)(tile + y * TP + 4 * col) = __builtin_amdgcn_alignbyte(hi[k], lo[k], sh);
+      if (colv && r0 + 4 * k < th) *(uint32_t*)(trow + 4 * k * TP) = __builtin_amdgcn_alignbyte(hi[k], lo[k], (uint32_t)offk[k] & 3u);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
