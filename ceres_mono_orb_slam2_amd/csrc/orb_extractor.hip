@@ -290,19 +290,25 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     // lanes = (row parity, column) when the interior is <= 32 px wide (every KITTI / VGA level), else lanes = columns
     const bool two = iw <= 32;
     const int lx = two ? (lane & 31) : lane, ly = two ? (lane >> 5) : 0, rstep = two ? 2 : 1;
+    // BRANCH-FREE reads (same lesson as the tile requests): lanes / rows outside the interior read a clamped pixel and are
+    // masked afterwards, so the 20 LDS reads of the four rounds are in flight together instead of one exec-masked block
+    // - with its own wait - per round
+    const int lxc = min(lx, iw - 1);
+    const bool lxv = lx < iw;
+    const uint8_t* pcol = tile + 3 * TP + lxc + 3;
     for (int iy0 = 0; iy0 < ih; iy0 += 4 * rstep) {
+      int v[4], c0[4], c4[4], c8[4], c12[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int iy = min(iy0 + r * rstep + ly, ih - 1);
+        const uint8_t* p = pcol + iy * TP;
+        v[r] = p[0]; c0[r] = p[3 * TP]; c4[r] = p[3]; c8[r] = p[-3 * TP]; c12[r] = p[-3];
+      }
       bool pass[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int iy = iy0 + r * rstep + ly;
-        pass[r] = false;
-        if (lx < iw && iy < ih) {
-          const uint8_t* p = tile + (iy + 3) * TP + lx + 3;
-          const int v = p[0];
-          const int c0 = p[3 * TP], c4 = p[3], c8 = p[-3 * TP], c12 = p[-3];
-          const int hi = min(max(c0, c8), max(c4, c12)), lo = max(min(c0, c8), min(c4, c12));
-          pass[r] = max(hi - v, v - lo) > minTh;
-        }
+        const int hi = min(max(c0[r], c8[r]), max(c4[r], c12[r])), lo = max(min(c0[r], c8[r]), min(c4[r], c12[r]));
+        pass[r] = lxv && (iy0 + r * rstep + ly < ih) && (max(hi - v[r], v[r] - lo) > minTh);
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
