@@ -341,9 +341,10 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     const int q = queue[k], iy = q >> 8, ix = q & 255;
     const uint8_t* sp = score + (iy + 3) * TP + ix + 3;
     const int v = sp[0];
-    if (v == 0) continue;
-    const bool kp = v > sp[-TP - 1] && v > sp[-TP] && v > sp[-TP + 1] && v > sp[-1] && v > sp[1] && v > sp[TP - 1] &&
-                    v > sp[TP] && v > sp[TP + 1];
+    // (all nine reads unconditional and the comparison without short-circuit: one LDS round trip per queued pixel)
+    const int n0 = sp[-TP - 1], n1 = sp[-TP], n2 = sp[-TP + 1], n3 = sp[-1], n4 = sp[1], n5 = sp[TP - 1], n6 = sp[TP], n7 = sp[TP + 1];
+    const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+    const bool kp = v != 0 && v > nmax;
     if (kp) {
       atomicOr(&keep[iy], 1ull << ix);
       if (v >= iniTh) { atomicOr(&k20[iy], 1ull << ix); any20 = 1; }
