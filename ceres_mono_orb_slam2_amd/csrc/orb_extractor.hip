@@ -360,20 +360,18 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   const int cnt = __popcll(mrow);
   const int incl = wave_incl_scan_i32(cnt);
   const int base = __builtin_amdgcn_readlane(incl, 63);
-  unsigned long long rows = __ballot(cnt > 0);
-  while (rows) {
-    const int iy = __ffsll((long long)rows) - 1;
-    rows &= rows - 1;
-    // (iy comes from a wave ballot: uniform - v_readlane instead of three trips through the LDS crossbar)
-    const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mrow, iy) |
-                                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mrow >> 32), iy) << 32);
-    const int rbase = __builtin_amdgcn_readlane(incl, iy) - __builtin_amdgcn_readlane(cnt, iy);
-    if ((m >> lane) & 1ull) {
-      const int pos = rbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (pos < G.cell_cap) {
-        const uint32_t x = (uint32_t)(lane + 3 + c.offx), y = (uint32_t)(iy + 3 + c.offy);
-        out[pos] = x | (y << 12) | ((uint32_t)score[(iy + 3) * TP + lane + 3] << 24);
-      }
+  // lane r writes row r's survivors itself, left to right, starting at the row's base offset: the loop runs for the
+  // LARGEST row population of the cell (a handful) instead of once per non-empty row, without cross-lane traffic
+  {
+    unsigned long long m = mrow;
+    int pos = incl - cnt;
+    const uint32_t yv = (uint32_t)(lane + 3 + c.offy) << 12;
+    const uint8_t* srow = score + (lane + 3) * TP + 3;
+    while (m) {
+      const int ix = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (pos < G.cell_cap) out[pos] = (uint32_t)(ix + 3 + c.offx) | yv | ((uint32_t)srow[ix] << 24);
+      pos++;
     }
   }
   if (lane == 0) cell_cnt[(long long)f * G.ncells_total + ci] = (ih > 0 && iw > 0) ? base : 0;
