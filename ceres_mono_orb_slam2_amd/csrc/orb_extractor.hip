@@ -50,10 +50,11 @@ struct LevelDev {
   int ini_x[MAX_INI + 1];
   float scale; float patch;
   int kcap; int key_off;          // dense key capacity / offset (in keys) inside one frame's key block
+  int dblk_begin, dblk_count;     // k_describe: first workgroup of this level / number of workgroups (level capacity / DESC_WPB)
 };
 
 struct GeomDev {
-  int nlevels, ncells_total, cell_cap, sel_cap, keys_per_frame;
+  int nlevels, ncells_total, cell_cap, sel_cap, keys_per_frame, desc_blocks;
   int tile_w, tile_h, tile_pitch;       // FAST LDS tile (max cell incl. apron)
   int node_cap, max_cells_level;
   long long pyr_frame_bytes, blur_frame_bytes;
@@ -799,22 +800,25 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   __syncthreads();
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * DESC_WPB + (threadIdx.x >> 6);      // keypoint index inside the frame
-  // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104): one lane per level + ballot
-  int total = 0, level = -1, pos = 0;
-  const int st_f = status[f];                               // (requested together with the level counts: one dependent round trip less)
-  {
-    int cl = (lane < G.nlevels) ? min(sel_cnt[f * G.nlevels + lane], G.sel_cap) : 0;
-    const int incl = wave_incl_scan_i32(cl);
-    total = __builtin_amdgcn_readlane(incl, 63);                             // (lanes >= nlevels hold 0)
-    const unsigned long long m = __ballot(lane < G.nlevels && i < incl);     // first level whose inclusive prefix exceeds i
-    if (m) { level = __ffsll((long long)m) - 1; pos = i - (__builtin_amdgcn_readlane(incl, level) - __builtin_amdgcn_readlane(cl, level)); }
-  }
+  // The grid is laid out per LEVEL (every level gets capacity / DESC_WPB workgroups): level and position inside the level
+  // come from the block index, so the keypoint's key is requested together with the level counts and the frame status -
+  // one dependent global round trip less than "find the level of keypoint i from the counts, then fetch its key".
+  int level = 0;
+#pragma unroll
+  for (int l = 1; l < MAX_LEVELS; l++) if (l < G.nlevels && (int)blockIdx.x >= G.lv[l].dblk_begin) level = l;
+  const LevelDev& L = G.lv[level];
+  const int pos = ((int)blockIdx.x - L.dblk_begin) * DESC_WPB + (threadIdx.x >> 6);
+  const uint32_t key = sel[((long long)f * G.nlevels + level) * G.sel_cap + min(pos, G.sel_cap - 1)];
+  const int st_f = status[f];
+  // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104): one lane per level
+  const int cl = (lane < G.nlevels) ? min(sel_cnt[f * G.nlevels + lane], G.sel_cap) : 0;
+  const int incl = wave_incl_scan_i32(cl);
+  const int total = __builtin_amdgcn_readlane(incl, 63);                     // (lanes >= nlevels hold 0)
+  const int cl_level = __builtin_amdgcn_readlane(cl, level);
+  const int i = __builtin_amdgcn_readlane(incl, level) - cl_level + pos;     // keypoint index inside the frame
   const bool bad = st_f != 0 || total > cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[f] = bad ? (st_f != 0 ? -1 : -2) : total;
-  if (bad || level < 0) return;
-  const LevelDev& L = G.lv[level];
-  const uint32_t key = sel[((long long)f * G.nlevels + level) * G.sel_cap + pos];
+  if (bad || pos >= cl_level) return;
   const int cx = (int)(key & 0xFFF) + L.minBX, cy = (int)((key >> 12) & 0xFFF) + L.minBY;
   const int resp = (int)(key >> 24);
   // ---- IC_Angle on the un-blurred level (src/ORBextractor.cc:77-104) ---------------------------
@@ -951,7 +955,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     G.nlevels = nl;
     c->cells.clear(); c->btiles.clear();
     long long pyr_off = 0, blur_off = 0;
-    int key_off = 0, tile_w = 8, tile_h = 8, cell_cap = 1, max_cells = 1, node_cap = MAX_INI + 8, sel_cap = 8;
+    int key_off = 0, tile_w = 8, tile_h = 8, cell_cap = 1, max_cells = 1, node_cap = MAX_INI + 8, sel_cap = 8, desc_blocks = 0;
     std::vector<uint8_t> tab;
     c->tab_xofs.assign(nl, 0); c->tab_ialpha.assign(nl, 0); c->tab_yofs.assign(nl, 0); c->tab_ibeta.assign(nl, 0);
     for (int l = 0; l < nl; l++) {
@@ -1009,6 +1013,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
       for (int i = 0; i <= nIni; i++) L.ini_x[i] = (int)(L.hX * static_cast<float>(i));
       node_cap = std::max(node_cap, std::max(L.quota + 8, 4 * nIni + 8));
       sel_cap = std::max(sel_cap, std::max(L.quota + 4, 4 * nIni + 4));   // the first octree sweep can return 4 * nIni > N nodes
+      L.dblk_begin = desc_blocks; L.dblk_count = (std::max(L.quota + 4, 4 * nIni + 4) + DESC_WPB - 1) / DESC_WPB; desc_blocks += L.dblk_count;
       long long theo = (long long)L.ncells * cell_cap;
       int keycap_max = KEYCAP_MAX;
       if (const char* e = std::getenv("ORBHIP_KEYCAP")) keycap_max = std::max(64, std::min(KEYCAP_MAX, atoi(e)));   // test hook for the overflow path
@@ -1062,7 +1067,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
         }
     }
     G.ncells_total = (int)c->cells.size();
-    G.cell_cap = cell_cap; G.sel_cap = sel_cap; G.keys_per_frame = key_off;
+    G.cell_cap = cell_cap; G.sel_cap = sel_cap; G.keys_per_frame = key_off; G.desc_blocks = desc_blocks;
     ORBHIP_REQUIRE(tile_w <= 64 && tile_h <= 64, ORBHIP_EINVAL, "FAST cell larger than 64 px (unsupported image geometry)");
     G.tile_w = tile_w; G.tile_h = tile_h; G.tile_pitch = round_up(tile_w, 4) + 4;
     G.node_cap = round_up(node_cap, 8); G.max_cells_level = round_up(max_cells, 8);
@@ -1163,8 +1168,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
                                          c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
   else ORBHIP_CHECK_HIP(hipStreamWaitEvent(st, c->ev_join, 0));       // join: describe needs the blurred levels
   mark();
-  const int maxkp = std::min(cap, nl * G.sel_cap);
-  hipLaunchKernelGGL(k_describe, dim3((maxkp + DESC_WPB - 1) / DESC_WPB, nframes), dim3(64 * DESC_WPB), 0, st, G, c->d_sel.as<uint32_t>(),
+  hipLaunchKernelGGL(k_describe, dim3(G.desc_blocks, nframes), dim3(64 * DESC_WPB), 0, st, G, c->d_sel.as<uint32_t>(),
                      c->d_selcnt.as<int>(), c->d_status.as<int>(), d_imgs, (long long)frame_stride, pyr,
                      c->d_blur.as<uint8_t>(), d_kps, d_desc, cap, d_counts, c->atan_p[0], c->atan_p[1],
                      c->atan_p[2], c->atan_p[3], c->factorPI);
