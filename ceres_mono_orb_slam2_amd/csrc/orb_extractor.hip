@@ -800,32 +800,39 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   __syncthreads();
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  // The grid is laid out per LEVEL (every level gets capacity / DESC_WPB workgroups): level and position inside the level
-  // come from the block index, so the keypoint's key is requested together with the level counts and the frame status -
-  // one dependent global round trip less than "find the level of keypoint i from the counts, then fetch its key".
+  const int half = lane >> 5, hl = lane & 31;
+  // The grid is laid out per LEVEL (every level gets capacity / (2 DESC_WPB) workgroups): level and position inside the level
+  // come from the block index, so the keys are requested together with the level counts and the frame status.
+  // TWO keypoints per wave, one per 32-lane half: the intensity-centroid sums need 31 lanes per keypoint, the 256 BRIEF tests
+  // are 8 per lane, and every lane computes the orientation of its own half - the per-wave instruction stream barely grows
+  // while the global requests in flight per wave double (the kernel is bound by its chain of dependent global round trips:
+  // 67 % VALU-busy at 6.3 waves per SIMD with one keypoint per wave).
   int level = 0;
 #pragma unroll
   for (int l = 1; l < MAX_LEVELS; l++) if (l < G.nlevels && (int)blockIdx.x >= G.lv[l].dblk_begin) level = l;
   const LevelDev& L = G.lv[level];
-  const int pos = ((int)blockIdx.x - L.dblk_begin) * DESC_WPB + (threadIdx.x >> 6);
-  const uint32_t key = sel[((long long)f * G.nlevels + level) * G.sel_cap + min(pos, G.sel_cap - 1)];
+  const int pos = (((int)blockIdx.x - L.dblk_begin) * DESC_WPB + (threadIdx.x >> 6)) * 2 + half;
   const int st_f = status[f];
   // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104): one lane per level
   const int cl = (lane < G.nlevels) ? min(sel_cnt[f * G.nlevels + lane], G.sel_cap) : 0;
+  const uint32_t key_any = sel[((long long)f * G.nlevels + level) * G.sel_cap + min(pos, G.sel_cap - 1)];   // (speculative: position may be past the level's count)
   const int incl = wave_incl_scan_i32(cl);
   const int total = __builtin_amdgcn_readlane(incl, 63);                     // (lanes >= nlevels hold 0)
   const int cl_level = __builtin_amdgcn_readlane(cl, level);
   const int i = __builtin_amdgcn_readlane(incl, level) - cl_level + pos;     // keypoint index inside the frame
   const bool bad = st_f != 0 || total > cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[f] = bad ? (st_f != 0 ? -1 : -2) : total;
-  if (bad || pos >= cl_level) return;
+  const bool valid = pos < cl_level;
+  if (bad || !__any(valid)) return;
+  // an empty half repeats the other half's keypoint (its loads stay inside the image, nothing is stored)
+  const uint32_t key = valid ? key_any : (uint32_t)__builtin_amdgcn_readlane((int)key_any, 0);
   const int cx = (int)(key & 0xFFF) + L.minBX, cy = (int)((key >> 12) & 0xFFF) + L.minBY;
   const int resp = (int)(key >> 24);
-  // ---- IC_Angle on the un-blurred level (src/ORBextractor.cc:77-104) ---------------------------
+  // ---- IC_Angle on the un-blurred level (src/ORBextractor.cc:77-104): lanes 0..30 of each half = rows -15..15 ------
   const uint8_t* img = level_ptr(G, level, f, img0, img_frame_bytes, pyr);
   int m10 = 0, m01 = 0;
-  if (lane < 31) {
-    const int v = lane - 15;
+  if (hl < 31) {
+    const int v = hl - 15;
     const int d = c_umax[v < 0 ? -v : v];
     const uint8_t* row = img + (long long)(cy + v) * L.pitch + cx;
     int val[31];
@@ -836,7 +843,17 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
     for (int k = 0; k < 31; k++) { const int u = k - 15; const int vv = (u >= -d && u <= d) ? val[k] : 0; rs += vv; m10 += u * vv; }
     m01 = v * rs;
   }
-  m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
+  // sums over each half: rows of 16 lanes, then row 0 -> 1 and row 2 -> 3; lane 31 / 63 hold the half totals
+  m10 += dpp_i32<0xB1, 0xF>(m10); m01 += dpp_i32<0xB1, 0xF>(m01);
+  m10 += dpp_i32<0x4E, 0xF>(m10); m01 += dpp_i32<0x4E, 0xF>(m01);
+  m10 += dpp_i32<0x141, 0xF>(m10); m01 += dpp_i32<0x141, 0xF>(m01);
+  m10 += dpp_i32<0x140, 0xF>(m10); m01 += dpp_i32<0x140, 0xF>(m01);
+  m10 += dpp_i32<0x142, 0xA>(m10); m01 += dpp_i32<0x142, 0xA>(m01);
+  {
+    const int a10 = __builtin_amdgcn_readlane(m10, 31), b10 = __builtin_amdgcn_readlane(m10, 63);
+    const int a01 = __builtin_amdgcn_readlane(m01, 31), b01 = __builtin_amdgcn_readlane(m01, 63);
+    m10 = half ? b10 : a10; m01 = half ? b01 : a01;
+  }
   const float angle = fast_atan2_deg((float)m01, (float)m10, p1, p3, p5, p7);
   // ---- rotated BRIEF-256 on the blurred level (src/ORBextractor.cc:107-147) ---------------------
   const float ang_rad = __fmul_rn(angle, factorPI);
@@ -844,11 +861,12 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   det_sincos((double)ang_rad, &sd, &cd);
   const float a = (float)cd, b = (float)sd;
   const uint8_t* bimg = blur + (long long)f * G.blur_frame_bytes + L.blur_off + (long long)cy * L.bpitch + cx;
-  uint32_t nib = 0;
+  // pair index pr = 32 j + hl: consecutive lanes read consecutive pattern words, and the wave ballot of test j holds descriptor
+  // dword j of the first keypoint in its low half and of the second keypoint in its high half (bit pr & 7 of byte pr >> 3)
+  uint32_t mydw = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int pr = lane * 4 + j;                          // pair index 0..255: bit (pr & 7) of byte (pr >> 3)
-    const uint32_t pw = s_pat[pr];
+  for (int j = 0; j < 8; j++) {
+    const uint32_t pw = s_pat[32 * j + hl];
     int t[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -858,14 +876,12 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
       int iy = __float2int_rn(fy), ix = __float2int_rn(fx);
       t[s] = bimg[(long long)iy * L.bpitch + ix];
     }
-    nib |= (uint32_t)(t[0] < t[1]) << j;
+    const unsigned long long bal = __ballot(t[0] < t[1]);
+    const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+    if (hl == j) mydw = mine;
   }
-  // lane 2k holds the low nibble, lane 2k+1 the high nibble of byte k
-  uint32_t byte = nib | ((uint32_t)dpp_i32<0x101, 0xF>((int)nib) << 4);     // row_shl:1 = lane + 1; valid on even lanes
-  uint32_t half = byte | ((uint32_t)dpp_i32<0x102, 0xF>((int)byte) << 8);    // lanes = 0 mod 4
-  uint32_t word = half | ((uint32_t)dpp_i32<0x104, 0xF>((int)half) << 16);   // lanes = 0 mod 8: bytes (lane/2 .. lane/2+3)
-  if ((lane & 7) == 0) *(uint32_t*)(desc + ((long long)f * cap + i) * 32 + (lane >> 1)) = word;
-  if (lane == 0) {
+  if (valid && hl < 8) *(uint32_t*)(desc + ((long long)f * cap + i) * 32 + 4 * hl) = mydw;
+  if (valid && hl == 0) {
     orbx_keypoint kp;
     kp.x = (float)cx; kp.y = (float)cy;
     if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }   // (:1095-1101)
@@ -1013,7 +1029,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
       for (int i = 0; i <= nIni; i++) L.ini_x[i] = (int)(L.hX * static_cast<float>(i));
       node_cap = std::max(node_cap, std::max(L.quota + 8, 4 * nIni + 8));
       sel_cap = std::max(sel_cap, std::max(L.quota + 4, 4 * nIni + 4));   // the first octree sweep can return 4 * nIni > N nodes
-      L.dblk_begin = desc_blocks; L.dblk_count = (std::max(L.quota + 4, 4 * nIni + 4) + DESC_WPB - 1) / DESC_WPB; desc_blocks += L.dblk_count;
+      L.dblk_begin = desc_blocks; L.dblk_count = (std::max(L.quota + 4, 4 * nIni + 4) + 2 * DESC_WPB - 1) / (2 * DESC_WPB); desc_blocks += L.dblk_count;
       long long theo = (long long)L.ncells * cell_cap;
       int keycap_max = KEYCAP_MAX;
       if (const char* e = std::getenv("ORBHIP_KEYCAP")) keycap_max = std::max(64, std::min(KEYCAP_MAX, atoi(e)));   // test hook for the overflow path
