@@ -796,7 +796,21 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
                                                   int cap, int* __restrict__ counts, float p1, float p3, float p5,
                                                   float p7, float factorPI) {
   __shared__ uint32_t s_pat[256];                           // pattern pair k = bytes (x0, y0, x1, y1)
-  for (int q = threadIdx.x; q < 256; q += 64 * DESC_WPB) s_pat[q] = ((const uint32_t*)c_pattern)[q];
+  // intensity-centroid weights as byte vectors: for patch row |v| and source dword i (bytes k = 4i .. 4i+3 of the 31-byte row,
+  // u = k - 15), s_icm holds [|u| <= umax[|v|]] and s_ick holds k * [..] - the row sums become v_dot4_u32_u8 on whole dwords
+  __shared__ __attribute__((aligned(16))) uint32_t s_icm[16][8], s_ick[16][8];
+  for (int q = threadIdx.x; q < 256; q += 64 * DESC_WPB) {
+    s_pat[q] = ((const uint32_t*)c_pattern)[q];
+    const int which = q >> 7, rv = (q >> 3) & 15, i4 = q & 7, d = c_umax[rv];
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = 4 * i4 + j, u = k - 15;
+      const bool in = k < 31 && u >= -d && u <= d;
+      w |= (uint32_t)(in ? (which ? k : 1) : 0) << (8 * j);
+    }
+    if (which) s_ick[rv][i4] = w; else s_icm[rv][i4] = w;
+  }
   __syncthreads();
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
@@ -832,16 +846,28 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   const uint8_t* img = level_ptr(G, level, f, img0, img_frame_bytes, pyr);
   int m10 = 0, m01 = 0;
   if (hl < 31) {
-    const int v = hl - 15;
-    const int d = c_umax[v < 0 ? -v : v];
-    const uint8_t* row = img + (long long)(cy + v) * L.pitch + cx;
-    int val[31];
+    // the row's 31 bytes as NINE aligned dwords re-cut with v_alignbyte (the 19-px border keeps the <= 3 bytes before and
+    // the <= 5 after inside the image row) and two v_dot4_u32_u8 per dword against the weight vectors: 9 requests and ~30
+    // VALU per row instead of 31 byte requests and 155 VALU - the kernel is bound by the request rate of its gathers
+    const int v = hl - 15, rv = v < 0 ? -v : v;
+    const uint8_t* rp = img + (long long)(cy + v) * L.pitch + (cx - 15);
+    const uint32_t sh = (uint32_t)((size_t)rp & 3);
+    const uint32_t* ap = (const uint32_t*)(rp - sh);
+    uint32_t dw[9];
 #pragma unroll
-    for (int k = 0; k < 31; k++) val[k] = (int)row[k - 15];            // unconditional (the patch is inside the image): all loads in flight
-    int rs = 0;
+    for (int q = 0; q < 9; q++) dw[q] = ap[q];
+    const uint4 mA = *(const uint4*)&s_icm[rv][0], mB = *(const uint4*)&s_icm[rv][4];
+    const uint4 kA = *(const uint4*)&s_ick[rv][0], kB = *(const uint4*)&s_ick[rv][4];
+    const uint32_t mw[8] = {mA.x, mA.y, mA.z, mA.w, mB.x, mB.y, mB.z, mB.w}, kw[8] = {kA.x, kA.y, kA.z, kA.w, kB.x, kB.y, kB.z, kB.w};
+    uint32_t rs = 0, ks = 0;
 #pragma unroll
-    for (int k = 0; k < 31; k++) { const int u = k - 15; const int vv = (u >= -d && u <= d) ? val[k] : 0; rs += vv; m10 += u * vv; }
-    m01 = v * rs;
+    for (int q = 0; q < 8; q++) {
+      const uint32_t w = __builtin_amdgcn_alignbyte(dw[q + 1], dw[q], sh);       // source bytes k = 4q .. 4q+3
+      rs = __builtin_amdgcn_udot4(w, mw[q], rs, false);
+      ks = __builtin_amdgcn_udot4(w, kw[q], ks, false);
+    }
+    m10 = (int)ks - 15 * (int)rs;                                                // sum of (k - 15) * I over the circle's row
+    m01 = v * (int)rs;
   }
   // sums over each half: rows of 16 lanes, then row 0 -> 1 and row 2 -> 3; lane 31 / 63 hold the half totals
   m10 += dpp_i32<0xB1, 0xF>(m10); m01 += dpp_i32<0xB1, 0xF>(m01);
