@@ -114,10 +114,12 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   if (x4 >= dw || y0 >= dh) return;
   int sx[4], a0[4], a1[4];
   uint32_t wp[4];                                   // a0 | a1 << 16
+  {
+    // (the table is padded to a multiple of 4 columns with copies of the last one: two 16-byte requests instead of four clamped 8-byte ones)
+    const uint4 t01 = ((const uint4*)xtab)[x4 >> 1], t23 = ((const uint4*)xtab)[(x4 >> 1) + 1];
+    const uint32_t tx[4] = {t01.x, t01.z, t23.x, t23.z}, ty[4] = {t01.y, t01.w, t23.y, t23.w};
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint2 t = xtab[min(x4 + j, dw - 1)];
-    sx[j] = t.x & 0xFFFF; a0[j] = (int)(t.y & 0xFFFF); a1[j] = (int)(t.y >> 16); wp[j] = t.y;
+    for (int j = 0; j < 4; j++) { sx[j] = tx[j] & 0xFFFF; a0[j] = (int)(ty[j] & 0xFFFF); a1[j] = (int)(ty[j] >> 16); wp[j] = ty[j]; }
   }
   const int base = sx[0] & ~3;
   const bool window = (sx[3] + 1 - base < 12);
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   const uint8_t* R0[RS_ROWS]; const uint8_t* R1[RS_ROWS];
 #pragma unroll
   for (int r = 0; r < RS_ROWS; r++) {
-    const int y = y0 + r;
+    const int y = __builtin_amdgcn_readfirstlane(y0 + r);   // a wave is one row group (blockDim.x = 64): the row tables come by scalar loads
     mode[r] = 0;
     if (y < dh) {
       const int sy = yofs[y];
@@ -1091,10 +1093,12 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
           std::memcpy(tab.data() + off, p, bytes);
           return off;
         };
-        std::vector<uint32_t> xt(2 * (size_t)dw);
-        for (int dx = 0; dx < dw; dx++) {
-          xt[2 * dx] = (uint32_t)(xofs[dx] & 0xFFFF) | ((uint32_t)(uint16_t)ia[2 * dx] << 16);
-          xt[2 * dx + 1] = (uint32_t)(uint16_t)ia[2 * dx] | ((uint32_t)(uint16_t)ia[2 * dx + 1] << 16);   // both weights, v_dot2 operand order
+        const int dw4 = round_up(dw, 4);                      // padded with copies of the last column: a thread reads its 4 entries as two 16-byte loads
+        std::vector<uint32_t> xt(2 * (size_t)dw4);
+        for (int dx4 = 0; dx4 < dw4; dx4++) {
+          const int dx = std::min(dx4, dw - 1);
+          xt[2 * dx4] = (uint32_t)(xofs[dx] & 0xFFFF) | ((uint32_t)(uint16_t)ia[2 * dx] << 16);
+          xt[2 * dx4 + 1] = (uint32_t)(uint16_t)ia[2 * dx] | ((uint32_t)(uint16_t)ia[2 * dx + 1] << 16);   // both weights, v_dot2 operand order
         }
         c->tab_xofs[l] = push(xt.data(), xt.size() * 4);
         c->tab_ialpha[l] = 0;
