@@ -269,17 +269,17 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     // SERIAL global round trips per cell, most of a wave's lifetime.
     const bool colv = 4 * col < tw;
     const int c0 = (colv ? 4 * col : 0) + (int)bsh;
-    uint32_t lo[16], hi[16]; int offk[16];
+    uint32_t lo[16], hi[16], offk[16];                     // (unsigned offsets: the scalar-base + 32-bit-offset load form needs them zero-extended)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      offk[k] = min(r0 + 4 * k, th - 1) * L.pitch + c0;
-      const uint32_t* aa = (const uint32_t*)(base_al + (offk[k] & ~3));
+      offk[k] = (uint32_t)(min(r0 + 4 * k, th - 1) * L.pitch + c0);
+      const uint32_t* aa = (const uint32_t*)(base_al + (offk[k] & ~3u));
       lo[k] = aa[0]; hi[k] = aa[1];
     }
     uint8_t* trow = tile + r0 * TP + 4 * col;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      if (colv && r0 + 4 * k < th) *(uint32_t*)(trow + 4 * k * TP) = __builtin_amdgcn_alignbyte(hi[k], lo[k], (uint32_t)offk[k] & 3u);
+      if (colv && r0 + 4 * k < th) *(uint32_t*)(trow + 4 * k * TP) = __builtin_amdgcn_alignbyte(hi[k], lo[k], offk[k] & 3u);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
