@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
   const bool inner = (xo >= 4) && (xo + 8 <= L.w);   // bytes xo-4 .. xo+7 all inside the row
   for (int yy = rr; yy < BLUR_TH + 6; yy += 8) {
     const int sy = reflect101(y0 + yy - 3, L.h);
-    const uint8_t* row = src + (long long)sy * L.pitch;
+    const uint8_t* row = src + (uint32_t)sy * (uint32_t)L.pitch;      // (32-bit unsigned row offset on the wave-uniform level base: no per-lane 64-bit multiply)
     int b[10];                                         // source bytes xo-3 .. xo+6
     if (xo < L.w) {
       if (inner && aligned) {
@@ -723,7 +723,9 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
   }
   __syncthreads();
   if (xo >= L.w) return;
-  for (int yy = rr; yy < BLUR_TH; yy += 8) {
+  uint8_t* drow = dst + (uint32_t)(y0 + rr) * (uint32_t)L.bpitch + (uint32_t)xo;
+  const uint32_t dstep = 8u * (uint32_t)L.bpitch;
+  for (int yy = rr; yy < BLUR_TH; yy += 8, drow += dstep) {
     const int y = y0 + yy;
     if (y >= L.h) break;
     int acc[4] = {0, 0, 0, 0};
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
     uint32_t out = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) { int v = (acc[j] + (1 << 15)) >> 16; v = v > 255 ? 255 : v; out |= (uint32_t)v << (8 * j); }
-    *(uint32_t*)(dst + (long long)y * L.bpitch + xo) = out;      // bpitch is a multiple of 64 >= w
+    *(uint32_t*)drow = out;                                      // bpitch is a multiple of 64 >= w
   }
 }
 
