@@ -5,13 +5,13 @@
 //
 // Pipeline for a batch of B same-sized frames, everything resident in HBM:
 //   k_resize        x (L-1)  level l from level l-1, fixed-point bilinear          (E2, :1107-1132)
-//   k_fast_cells    x 1      one workgroup per ~30x30 cell: FAST-9 score map in LDS,
+//   k_fast_cells    x 1      one wave per ~30x30 cell: FAST-9 score map in LDS,
 //                            3x3 NMS inside the cell, 20 -> 7 threshold fallback,
 //                            ordered (row-major) compaction into the cell's slot   (E3, :789-829)
 //   k_octree        x 1      one workgroup per (frame, level): DistributeOctTree in
 //                            its level-synchronous array form (tests/octree_twin.py) (E4, :539-763)
 //   k_blur7         x 1      separable 7x7 Gaussian, fixed-point taps, reflect-101  (E7, :1085-1086)
-//   k_describe      x 1      one wave per keypoint: intensity-centroid angle on the
+//   k_describe      x 1      one 32-lane half-wave per keypoint: intensity-centroid angle on the
 //                            un-blurred level, rotated BRIEF-256 on the blurred one,
 //                            cv::KeyPoint record                                     (E5,E6,E8,E9)
 // All integer stages are bit-exact by construction; the two float stages
