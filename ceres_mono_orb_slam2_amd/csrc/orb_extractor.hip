@@ -381,10 +381,11 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
 }
 
 // ---------------------------------------------------------------------------- k_octree
-// exclusive scan of a[0..n) in place by a 256-thread block; returns the total.
+#define OCT_TPB 256     // threads per (frame, level) workgroup: 64 / 128 / 256 / 512 / 1024 -> 0.390 / 0.234 / 0.158 / 0.198 / 0.393 ms
+// exclusive scan of a[0..n) in place by an OCT_TPB-thread block; returns the total.
 __device__ int block_excl_scan(int* a, int n, int* s_tmp) {
   const int tid = threadIdx.x;
-  const int items = (n + 255) >> 8;
+  const int items = (n + OCT_TPB - 1) / OCT_TPB;
   const int beg = min(tid * items, n), end = min(beg + items, n);
   int sum = 0;
   for (int i = beg; i < end; i++) sum += a[i];
@@ -394,7 +395,7 @@ __device__ int block_excl_scan(int* a, int n, int* s_tmp) {
   __syncthreads();
   int woff = 0, total = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { int t = s_tmp[i]; if (i < w) woff += t; total += t; }
+  for (int i = 0; i < OCT_TPB / 64; i++) { int t = s_tmp[i]; if (i < w) woff += t; total += t; }
   int run = woff + v - sum;
   for (int i = beg; i < end; i++) { int t = a[i]; a[i] = run; run += t; }
   __syncthreads();
@@ -410,7 +411,7 @@ __device__ __forceinline__ int quad_of(const Rect16& r, int x, int y, int& mx, i
 }
 
 #define OCT_U 8        // key entries per thread requested together in the sweep loops
-__global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
+__global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
                                                 const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
                                                 unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
                                                 int* __restrict__ sel_cnt, int* __restrict__ nkeys_out,
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
   unsigned short* order = cnt[1] + NC;
   unsigned short* candl = order + NC;
   short* rankOf = (short*)(candl + NC);
-  __shared__ int s_tmp[8], s_m, s_nexp, s_L;
+  __shared__ int s_tmp[16], s_m, s_nexp, s_L;
 
   uint32_t* K = keys + (long long)f * G.keys_per_frame + Lv.key_off;
   unsigned short* KN = knode + (long long)f * G.keys_per_frame + Lv.key_off;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
 
   // ---- 0. gather the level's candidates in reference order (cells row-major, pixels row-major) --
   const int ncell = Lv.ncells;
-  for (int c = tid; c < ncell; c += 256) s_pref[c] = ccnt[c];
+  for (int c = tid; c < ncell; c += OCT_TPB) s_pref[c] = ccnt[c];
   __syncthreads();
   const int n = block_excl_scan(s_pref, ncell, s_tmp);
   if (tid == 0) { s_pref[ncell] = n; nkeys_out[f * G.nlevels + level] = n; }
@@ -454,13 +455,13 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
   }
   __syncthreads();
   const int nIni = Lv.nIni;
-  for (int i = tid; i < NC; i += 256) { cnt[0][i] = 0; cnt[1][i] = 0; }
+  for (int i = tid; i < NC; i += OCT_TPB) { cnt[0][i] = 0; cnt[1][i] = 0; }
   __syncthreads();
-  for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+  for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
     uint32_t keyv[OCT_U];
 #pragma unroll
     for (int u = 0; u < OCT_U; u++) {             // all OCT_U cell-list reads of this thread in flight together
-      const int k = k0 + 256 * u;
+      const int k = k0 + OCT_TPB * u;
       keyv[u] = 0u;
       if (k < n) {
         int lo = 0, hi = ncell;                   // largest c with pref[c] <= k
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     }
 #pragma unroll
     for (int u = 0; u < OCT_U; u++) {
-      const int k = k0 + 256 * u;
+      const int k = k0 + OCT_TPB * u;
       if (k < n) {
         const uint32_t key = keyv[u];
         K[k] = key;
@@ -482,12 +483,12 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     }
   }
   // initial node histogram (nIni <= 64): LDS int atomics on sB
-  for (int i = tid; i < MAX_INI; i += 256) sB[i] = 0;
+  for (int i = tid; i < MAX_INI; i += OCT_TPB) sB[i] = 0;
   __syncthreads();
-  for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+  for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
     int pv[OCT_U];
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; pv[u] = k < n ? (int)KN[k] : -1; }
+    for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; pv[u] = k < n ? (int)KN[k] : -1; }
 #pragma unroll
     for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) atomicAdd(&sB[pv[u]], 1);
   }
@@ -505,12 +506,12 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     s_L = L0;
   }
   __syncthreads();
-  for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+  for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
     int pv[OCT_U];
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; pv[u] = k < n ? (int)KN[k] : -1; }
+    for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; pv[u] = k < n ? (int)KN[k] : -1; }
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) KN[k0 + 256 * u] = (unsigned short)sA[pv[u]];
+    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) KN[k0 + OCT_TPB * u] = (unsigned short)sA[pv[u]];
   }
   __syncthreads();
 
@@ -522,19 +523,19 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     const Rect16* R = rect[cur];
     const unsigned short* C = cnt[cur];
     // ---- A: candidates = nodes holding > 1 key, in list order ---------------------------------
-    for (int p = tid; p < L; p += 256) { sA[p] = C[p] > 1; cc[p] = make_uint2(0, 0); rankOf[p] = -1; }
+    for (int p = tid; p < L; p += OCT_TPB) { sA[p] = C[p] > 1; cc[p] = make_uint2(0, 0); rankOf[p] = -1; }
     if (tid == 0) { s_m = -1; s_nexp = 0; }
     __syncthreads();
     const int ncand = block_excl_scan(sA, L, s_tmp);
     if (ncand == 0) break;                         // no split possible: |L| == prevSize  (:669)
-    for (int p = tid; p < L; p += 256) if (C[p] > 1) candl[sA[p]] = (unsigned short)p;
+    for (int p = tid; p < L; p += OCT_TPB) if (C[p] > 1) candl[sA[p]] = (unsigned short)p;
     // ---- B: child occupancy of every candidate -------------------------------------------------
     // (the key loops read K / KN from global memory: OCT_U entries per thread are requested together - a one-entry loop
     // pays the global latency ~20 times per sweep phase at level 0, which bounded this kernel at ~0.2 ms)
-    for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+    for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
       uint32_t keyv[OCT_U]; int pv[OCT_U];
 #pragma unroll
-      for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
+      for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
 #pragma unroll
       for (int u = 0; u < OCT_U; u++) {
         const int p = pv[u];
@@ -550,23 +551,23 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     // ---- C: processing order and how many candidates get split ---------------------------------
     int m = ncand;
     if (!final_phase) {
-      for (int r = tid; r < ncand; r += 256) order[r] = candl[r];
+      for (int r = tid; r < ncand; r += OCT_TPB) order[r] = candl[r];
     } else {
       // sort by (count desc, list position asc): list position asc == creation desc (canonical F9)
-      for (int i = tid; i < ncand; i += 256) {
+      for (int i = tid; i < ncand; i += OCT_TPB) {
         int p = candl[i], cp = C[p], r = 0;
         for (int j = 0; j < ncand; j++) { int pj = candl[j], cj = C[pj]; r += (cj > cp) || (cj == cp && pj < p); }
         order[r] = (unsigned short)p;
       }
       __syncthreads();
-      for (int r = tid; r < ncand; r += 256) {
+      for (int r = tid; r < ncand; r += OCT_TPB) {
         uint2 v = cc[order[r]];
         sA[r] = ((v.x & 0xFFFF) != 0) + ((v.x >> 16) != 0) + ((v.y & 0xFFFF) != 0) + ((v.y >> 16) != 0) - 1;
         sB[r] = sA[r];
       }
       __syncthreads();
       block_excl_scan(sA, ncand, s_tmp);
-      for (int r = tid; r < ncand; r += 256) {
+      for (int r = tid; r < ncand; r += OCT_TPB) {
         int before = L + sA[r], after = before + sB[r];
         if (after >= N && before < N) s_m = r + 1;       // first split that reaches |L| >= N  (:730-731)
       }
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     }
     __syncthreads();
     // ---- D/E/F: ranks, creation bases (rank order), split prefix (list order) -------------------
-    for (int r = tid; r < m; r += 256) {
+    for (int r = tid; r < m; r += OCT_TPB) {
       int p = order[r];
       rankOf[p] = (short)r;
       uint2 v = cc[p];
@@ -583,14 +584,14 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     }
     __syncthreads();
     const int TC = block_excl_scan(sA, m, s_tmp);          // sA[r] = creation index of r's first child
-    for (int p = tid; p < L; p += 256) sB[p] = rankOf[p] >= 0;
+    for (int p = tid; p < L; p += OCT_TPB) sB[p] = rankOf[p] >= 0;
     __syncthreads();
     block_excl_scan(sB, L, s_tmp);                         // sB[p] = #split nodes before p
     // ---- G: new list = reverse(children in creation order) ++ (old list minus split nodes) -------
     Rect16* Rn = rect[cur ^ 1];
     unsigned short* Cn = cnt[cur ^ 1];
     int nexp = 0;
-    for (int p = tid; p < L; p += 256) {
+    for (int p = tid; p < L; p += OCT_TPB) {
       int r = rankOf[p];
       if (r >= 0) {
         Rect16 rc = R[p];
@@ -621,15 +622,15 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
     if (nexp) atomicAdd(&s_nexp, nexp);
     __syncthreads();
     // ---- H: move the keys -----------------------------------------------------------------------
-    for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+    for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
       uint32_t keyv[OCT_U]; int pv[OCT_U];
 #pragma unroll
-      for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
+      for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
 #pragma unroll
       for (int u = 0; u < OCT_U; u++) {
         const int p = pv[u];
         if (p < 0) continue;
-        const int k = k0 + 256 * u;
+        const int k = k0 + OCT_TPB * u;
         uint2 cp = childpos[p];
         if (rankOf[p] >= 0) {
           const uint32_t key = keyv[u];
@@ -652,17 +653,17 @@ __global__ __launch_bounds__(256) void k_octree(GeomDev G, const int* __restrict
   __syncthreads();
   // ---- best key of every node: max response, earliest candidate on ties (:741-760) ---------------
   unsigned int* best = (unsigned int*)sA;
-  for (int p = tid; p < L; p += 256) best[p] = 0;
+  for (int p = tid; p < L; p += OCT_TPB) best[p] = 0;
   __syncthreads();
-  for (int k0 = tid; k0 < n; k0 += 256 * OCT_U) {
+  for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
     uint32_t keyv[OCT_U]; int pv[OCT_U];
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) { const int k = k0 + 256 * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
+    for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) atomicMax(&best[pv[u]], ((keyv[u] >> 24) << 24) | (0xFFFFFFu - (unsigned)(k0 + 256 * u)));
+    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) atomicMax(&best[pv[u]], ((keyv[u] >> 24) << 24) | (0xFFFFFFu - (unsigned)(k0 + OCT_TPB * u)));
   }
   __syncthreads();
-  for (int p = tid; p < L; p += 256) {
+  for (int p = tid; p < L; p += OCT_TPB) {
     if (p < G.sel_cap) SEL[p] = K[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
   }
   if (tid == 0) {
@@ -1199,7 +1200,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   // mode 2: the octree is one latency-bound workgroup per (frame, level) - 6 % VALU-busy, 0.6 waves per SIMD - so the
   // VALU-bound blur runs BESIDE it: the fork is taken after FAST, the octree is submitted first and keeps its slots
   if (side_mode == 2) ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
-  hipLaunchKernelGGL(k_octree, dim3(nl, nframes), dim3(256), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
+  hipLaunchKernelGGL(k_octree, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
                      c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
                      c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
   if (side_mode == 2) {
