@@ -4,16 +4,27 @@
 Metric (BASELINE.json): "frames/sec ORB extract+match @1241x376 + LocalBA solves/sec; 1/2/4/8 GPU".
 `value` = whole-job frames/s of ORB extract (2000 features, 8 levels) + brute-force Hamming match
 of every frame against its predecessor, on synthetic 1241x376 frames already resident in HBM
-(BASELINE.json configs[1]).  LocalBA solves/s (configs[3]) is reported in `localba`.
+(BASELINE.json configs[1]).  LocalBA solves/s (configs[3]), PoseOptimization (configs[2]) and the
+500-KF GlobalBA sub-map per GPU + landmark all-gather (configs[4]) are reported in `localba`.
 
-A "step" = one pass of the hot path over one batch of `--batch` frames per GPU.  Frames shard
-across ranks with no data-path collective (weak scaling): value = frames all ranks processed / max
-rank time.  One JSON line is printed by rank 0.
+A "step" = one pass of the hot path over `--batches-per-step` batches of `--batch` frames per GPU
+(32 x 256 = 8192 distinct resident frames by default, so that 20 steps are > 1 s of GPU time).
+Frames shard across ranks with no data-path collective (weak scaling): value = frames all ranks
+processed / max rank time.  One JSON line is printed by rank 0.
+
+Launching: `python bench.py --gpus N` spawns its own N ranks (one process per GPU, RCCL) when it
+is not already running under torchrun (WORLD_SIZE unset); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
+Either way the rank count must equal --gpus.  ORBHIP_BENCH_SHARED_GPU=1 = dry run of the N > 1
+path on a box with fewer GPUs (every rank on device 0, gloo on host tensors).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -25,10 +36,13 @@ W_IMG, H_IMG, NFEAT = 1241, 376, 2000
 # algorithmic bytes per 1241x376 frame (DESIGN.md "Kernels")
 PX_TOTAL = 1444097
 BYTES = {"pyramid": 1407767 + 977481, "fast_cells": 1444097, "blur": 2 * 1444097, "describe": 2000 * (32 + 28)}
+KERNEL_OF = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur7", "describe": "k_describe"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer VALU instruction issues over 4 cycles;
                                # measured 35-39 T lane-instr/s for xor/bcnt/pk_*16/dot4/dot2/sad/alignbyte (tools/ubench/valu_rate.hip)
 MATCH_LANE_OPS_PER_PAIR = 19.5   # VALU instructions per Hamming distance in k_match_pairs (ISA-checked: 8 xor + 8 v_bcnt + v_lshl_or + v_max + v_min + half a v_min3)
+PMC_TRAFFIC = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 PMC summaries, newest first
+PMC_VALU = ("r02_pmc_valu.json", "r01_pmc_valu.json")
 
 
 def make_frames(batch, seed):
@@ -44,63 +58,170 @@ def make_frames(batch, seed):
     return np.concatenate(out)[:batch]
 
 
-def cpu_baseline(frames, n_sample):
-    """Oracle (CPU port of the reference algorithm), single thread, on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------ CPU baseline
+def _ncores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def _cpu_frames_worker(frames, lo, n, out, k):
     from oracle import pyoracle as po
     E = po.OracleExtractor(NFEAT)
-    n = min(n_sample, len(frames))
-    t0 = time.perf_counter()
     prev = None
-    for i in range(n):
-        k, d = E.extract(frames[i])
-        if prev is not None:
-            po.match_frames(d, k["angle"], prev[1], prev[0]["angle"], 0.9, 50, True)
-        else:
-            po.match_frames(d, k["angle"], d, k["angle"], 0.9, 50, True)
-        prev = (k, d)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+    for i in range(lo, lo + n):
+        kp, d = E.extract(frames[i % len(frames)])
+        ref = prev if prev is not None else (kp, d)
+        po.match_frames(d, kp["angle"], ref[1], ref[0]["angle"], 0.9, 50, True)
+        prev = (kp, d)
+    out[k] = n
+
+
+def cpu_baseline(frames, n_sample, n_all):
+    """Oracle (CPU port of the reference algorithm) on a bounded sample of the same workload: one thread (the reference's
+    own threading for extract / match) and all host cores running independent frame sub-sequences (throughput-fair)."""
+    from oracle import pyoracle as po
+    po.lib()
+    n = min(n_sample, len(frames))
+    res = [0]
+    t0 = time.perf_counter()
+    _cpu_frames_worker(frames, 0, n, res, 0)
+    dt1 = time.perf_counter() - t0
+    cores = _ncores()
+    per = max(24, n_all // cores)
+    res = [0] * cores
+    ths = [threading.Thread(target=_cpu_frames_worker, args=(frames, c * per, per, res, c)) for c in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dta = time.perf_counter() - t0
+    return {"value": n / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d of the bench's 1241x376 frames: oracle extract (2000 features) + 1 brute-force match each, "
-                      "single thread, %.1f s" % (n, dt)}
+                      "single thread (the reference's threading for this path), %.1f s" % (n, dt1),
+            "all_cores": {"value": sum(res) / dta, "unit": "frames/s", "cores": cores,
+                          "sample": "%d frames as %d independent sub-sequences, one oracle instance per core, %.1f s"
+                                    % (sum(res), cores, dta)},
+            "host_cores": cores}
 
 
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def worker_envs(n, port, base=None):
+    """Environment of each of the N ranks the launcher starts (one process per GPU; LOCAL_RANK selects the device)."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ORBHIP_BENCH_WORKER": "1"})
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        envs.append(e)
+    return envs
+
+
+def launch(argv, n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script, pass rank 0's stdout through."""
+    envs = worker_envs(n, _free_port())
+    procs = []
+    for r, e in enumerate(envs):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def launch_check(rank, world):
+    """--launch-check: rendezvous only (gloo, CPU): proves the launcher built `world` ranks.  No GPU needed."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank], dtype=torch.int64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        ranks = [int(g.item()) for g in got]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks = [0]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": ranks,
+                          "local_rank_env": os.environ.get("LOCAL_RANK", "0")}))
+
+
+# ------------------------------------------------------------------------------------------ the benchmark
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=160)   # ~13 s of single-thread oracle work
+    ap.add_argument("--batch", type=int, default=256, help="frames per extract/match launch sequence")
+    ap.add_argument("--batches-per-step", type=int, default=32, help="batches per step (distinct resident frames)")
+    ap.add_argument("--cpu-sample", type=int, default=96)    # ~8 s of single-thread oracle work
+    ap.add_argument("--cpu-all-sample", type=int, default=96 * 8)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous of the N ranks only (CPU, gloo)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but %d ranks were launched (WORLD_SIZE)" % (args.gpus, world)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.launch_check:
+        return launch_check(rank, world)
+
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    # ORBHIP_BENCH_SHARED_GPU=1: dry run of the N > 1 code path on a box with ONE GPU (every rank uses device 0, gloo carries
-    # the collectives on host tensors); the real multi-GPU run is one rank per GPU over RCCL
+    # ORBHIP_BENCH_SHARED_GPU=1: dry run of the N > 1 code path on a box with fewer GPUs than ranks (every rank uses
+    # device 0, gloo carries the collectives on host tensors); the real multi-GPU run is one rank per GPU over RCCL
     shared = os.environ.get("ORBHIP_BENCH_SHARED_GPU") == "1"
+    ndev = torch.cuda.device_count()
     if shared:
         local_rank = 0
+    assert local_rank < ndev, ("rank %d needs GPU %d but only %d visible (ORBHIP_BENCH_SHARED_GPU=1 runs the N > 1 path "
+                               "on one GPU as a dry run)" % (rank, local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if shared else dev          # where collective payloads live
+    backend = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if shared else "nccl"
         if shared:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
-    from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher, _lib
+    from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher, _lib, sharding
     _lib.check(_lib.load().orbhip_set_default_device(local_rank), "orbhip_set_default_device")
-    B = args.batch
-    frames = make_frames(B, seed=rank)                 # each rank: its own frames (frame sharding)
-    d_frames = torch.from_numpy(frames).to(dev)
+    B, M = args.batch, args.batches_per_step
+    # M distinct batches resident in HBM: two synthetic base batches per rank (its own frames: frame sharding) and their
+    # translations (a whole batch rolled by (3v, 2v) px keeps the <=8 px frame-to-frame chains and moves every corner
+    # relative to the cell grid, so no two batches repeat work)
+    nbase = min(2, M)
+    base = [torch.from_numpy(make_frames(B, seed=rank * 16 + b)).to(dev) for b in range(nbase)]
+    batches = []
+    for m in range(M):
+        v = m // nbase
+        batches.append(base[m % nbase] if v == 0 else torch.roll(base[m % nbase], shifts=(2 * v, 3 * v), dims=(1, 2)).contiguous())
+    frames_host = base[0].cpu().numpy()
     ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
     mt = ORBmatcher(0.9, True)
     cap = ex.max_keypoints
@@ -111,10 +232,19 @@ def main():
     nmatch = torch.empty((B,), dtype=torch.int32, device=dev)
     pair_a = torch.arange(B, dtype=torch.int32, device=dev)
     pair_b = (pair_a + B - 1) % B                      # frame i against its predecessor
+    kp_sum = torch.zeros((), dtype=torch.int64, device=dev)
+    nm_sum = torch.zeros((), dtype=torch.int64, device=dev)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
 
-    def step():
-        ex.extract_batch(d_frames, out=(kps, desc, counts))
-        mt.match_frames_batch(kps, desc, counts, pair_a, pair_b, out=(match12, nmatch))
+    def step(events=None):
+        for m in range(M):
+            ex.extract_batch(batches[m], out=(kps, desc, counts))
+            if events is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            mt.match_frames_batch(kps, desc, counts, pair_a, pair_b, out=(match12, nmatch))
+            if events is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                events.append((e0, e1))
 
     def barrier():
         if world > 1:
@@ -125,29 +255,29 @@ def main():
         step()
     barrier()
     ex.set_profiling(True)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ex.extract_batch(d_frames, out=(kps, desc, counts))
-        ev[k][0].record()
-        mt.match_frames_batch(kps, desc, counts, pair_a, pair_b, out=(match12, nmatch))
-        ev[k][1].record()
+        step(ev)
     barrier()
     dt = time.perf_counter() - t0
     stage_ms, ncalls = ex.stage_ms()
     ex.set_profiling(False)
     match_ms = sum(a.elapsed_time(b) for a, b in ev)
-    from ceres_mono_orb_slam2_amd import sharding
     dt = sharding.max_over_ranks(dt, device=cdev)
 
-    # sanity of the timed work (not timed): every frame produced keypoints and matches
-    c = counts.cpu().numpy(); nm = nmatch.cpu().numpy()
-    assert (c > 0).all(), "extractor produced an empty/overflowed frame"
-    mean_kp, mean_match = float(c.mean()), float(nm.mean())
+    # sanity of the timed work (not timed): one more pass, every frame of every batch produced keypoints and matches
+    for m in range(M):
+        ex.extract_batch(batches[m], out=(kps, desc, counts))
+        mt.match_frames_batch(kps, desc, counts, pair_a, pair_b, out=(match12, nmatch))
+        kp_sum += counts.sum(); nm_sum += nmatch.sum(); bad += (counts <= 0).sum()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, "extractor produced an empty/overflowed frame"
+    mean_kp, mean_match = float(kp_sum.item()) / (B * M), float(nm_sum.item()) / (B * M)
 
-    # ---- LocalBA / PoseOptimization legs: every rank solves its own independent problems (sub-map sharding, no
-    #      collective in the solve); for N > 1 the landmark updates are merged with ONE all-gather.
-    localba = None
+    # ---- LocalBA / PoseOptimization / GlobalBA legs: every rank solves its own independent problems (sub-map sharding,
+    #      no collective in the solve); for N > 1 the landmark updates are merged with ONE all-gather.
+    localba, collective = None, None
     if not args.no_ba:
         ok = 1
         try:
@@ -159,46 +289,61 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # collectives below only if EVERY rank's leg succeeded
             if int(flag.item()) == 1:
-                t = torch.tensor([localba["localba_solves_per_s"], localba["poseopt_solves_per_s"]], dtype=torch.float64, device=cdev)
+                keys = ["localba_solves_per_s", "localba_single_stream_solves_per_s", "poseopt_solves_per_s"]
+                t = torch.tensor([localba[k] for k in keys], dtype=torch.float64, device=cdev)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                localba["localba_solves_per_s"], localba["poseopt_solves_per_s"] = float(t[0]), float(t[1])
+                for k, v in zip(keys, t.tolist()):
+                    localba[k] = v
                 pts = torch.from_numpy(localba["_final_points"]).to(cdev)
-                torch.cuda.synchronize(); tg = time.perf_counter()
-                allp, _, counts = sharding.allgather_landmarks(pts)
+                allp, _, cnts = sharding.allgather_landmarks(pts)          # warm-up (communicator setup)
+                barrier(); tg = time.perf_counter()
+                allp, _, cnts = sharding.allgather_landmarks(pts)
                 torch.cuda.synchronize()
-                localba["landmark_allgather_ms"] = (time.perf_counter() - tg) * 1e3
-                localba["landmark_allgather_points"] = int(allp.shape[0])
+                collective = {"backend": backend + (" (RCCL)" if backend == "nccl" else " (shared-GPU dry run)"),
+                              "world_size": dist.get_world_size(), "op": "all_gather of every rank's GlobalBA landmarks",
+                              "landmark_allgather_ms": (time.perf_counter() - tg) * 1e3,
+                              "points_per_rank": cnts, "merged_points": int(allp.shape[0]),
+                              "payload_bytes": int(allp.shape[0]) * 24}
         if isinstance(localba, dict):
             localba.pop("_final_points", None)
     if rank == 0:
         K = args.steps
-        fps = B * world * K / dt
+        fps = B * M * world * K / dt
         per_call = {k: v / max(ncalls, 1) for k, v in stage_ms.items()}
-        per_call["match"] = match_ms / K
+        per_call["match"] = match_ms / max(len(ev), 1)
         # HBM roofline of the dominant streaming kernel of the extract path
         hbm_stages = {k: per_call[k] for k in ("pyramid", "fast_cells", "blur", "describe")}
         dom = max(hbm_stages, key=hbm_stages.get)
+        kname = KERNEL_OF[dom]
         ach = BYTES[dom] * B / (per_call[dom] * 1e-3) / 1e9
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs;
-        # profiles/r01_pmc_traffic.json) scaled to this batch; None if the summary is absent
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            kname = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur7", "describe": "k_describe"}[dom]
-            traffic = pmc["kernels"][kname]["hbm_bytes_per_frame"] * B
-        except Exception:
-            pass
-        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # HBM traffic per launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs),
+        # scaled to this batch -- not measured in this run (counters need rocprofv3); None if the summary is absent
+        traffic, traffic_src = None, None
+        for f in PMC_TRAFFIC:
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", f)))
+                traffic, traffic_src = pmc["kernels"][kname]["hbm_bytes_per_frame"] * B, "profiles/" + f
+                break
+            except Exception:
+                continue
+        roof = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": BYTES[dom] * B}
-        # the kernel is an HBM kernel by bytes but binds on the integer VALU issue rate: report that fraction too, from the
-        # committed PMC pass (profiles/r01_pmc_valu.json: SQ_INSTS_VALU x 4 cycles / SIMD-cycles of the launch)
-        try:
-            vp = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu.json")))["kernels"][kname]
-            roof["valu_issue_frac"] = vp["valu_busy_frac"]
-            roof["valu_insts_per_wave"] = vp["valu_insts_per_wave"]
-        except Exception:
-            pass
+                "traffic_source": (traffic_src + " (committed PMC pass of this kernel, scaled to the batch; not collected in this run)") if traffic_src else None,
+                "algorithmic_bytes_per_launch": BYTES[dom] * B,
+                "ms_per_launch": per_call[dom], "launches_timed": ncalls,
+                "timing": "HIP events on the launch stream inside the timed region (orbx_set_profiling)"}
+        # the kernel streams bytes but BINDS on the integer VALU issue rate: report that fraction too, from the
+        # committed PMC pass (SQ_INSTS_VALU x 4 cycles / SIMD-cycles of the launch)
+        for f in PMC_VALU:
+            try:
+                vp = json.load(open(os.path.join(ROOT, "profiles", f)))["kernels"][kname]
+                roof["limiter"] = "valu_issue"
+                roof["valu_issue_frac"] = vp["valu_busy_frac"]
+                roof["valu_insts_per_wave"] = vp["valu_insts_per_wave"]
+                roof["valu_source"] = "profiles/" + f
+                break
+            except Exception:
+                continue
         pairs_per_s = B / (per_call["match"] * 1e-3)
         lane_ops = mean_kp * mean_kp * MATCH_LANE_OPS_PER_PAIR
         kernels = {k: {"ms_per_launch_batch": v} for k, v in per_call.items()}
@@ -213,13 +358,16 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "KITTI 1241x376, 2000 features/frame, 8 levels, ORB extract + brute-force Hamming "
                                    "match vs previous frame (ratio 0.9, TH_LOW 50, rotation histogram)",
-                       "frames_per_gpu_per_step": B, "sharding": "frames across ranks, no collective",
+                       "frames_per_gpu_per_step": B * M, "frames_per_launch": B, "batches_per_step": M,
+                       "sharding": "frames across ranks, no collective in the data path",
                        "mean_keypoints": mean_kp, "mean_matches": mean_match},
             "roofline": roof,
             "kernels": kernels,
         }
+        if collective is not None:
+            out["collective"] = collective
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(frames_host, args.cpu_sample, args.cpu_all_sample)
         if localba is not None:
             out["localba"] = localba
         print(json.dumps(out))

@@ -21,6 +21,7 @@ SYMBOLS = [
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log",
     "ba_solve_batch", "ba_local_bundle_adjustment_batch", "ba_optimize_essential_graph", "ba_essential_graph_correct",
+    "ba_matrix4d_to_pose7", "ba_pose7_to_matrix4d", "ba_set_profiling", "ba_get_profile",
 ]
 
 
@@ -124,6 +125,10 @@ def load():
         L.ba_sim3_log.argtypes = [vp, vp]
         L.ba_optimize_essential_graph.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, vp, C.POINTER(BaSummary)]
         L.ba_essential_graph_correct.argtypes = [vp, vp, i32, vp, vp, vp, i32]
+        L.ba_matrix4d_to_pose7.argtypes = [vp, vp]
+        L.ba_pose7_to_matrix4d.argtypes = [vp, vp]
+        L.ba_set_profiling.argtypes = [i32]
+        L.ba_get_profile.argtypes = [C.POINTER(f64), C.POINTER(i32), C.POINTER(i32)]
         L.ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaOptions), vp]
         L.ba_local_bundle_adjustment_batch.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, vp]
     _lib = L

@@ -34,6 +34,8 @@
 #include <algorithm>
 #include <numeric>
 #include <chrono>
+#include <thread>
+#include <atomic>
 #include <cstdlib>
 #include <climits>
 
@@ -552,6 +554,7 @@ struct BaDev {            // device pointers of one problem
   const unsigned char* cam_local; unsigned char* erase;   // LocalBA classification (k_ba_classify): local flags [ncam], result [nobs] (device order)
   int chol_la;                       // 1: this problem's reduced system is factored by the look-ahead kernel (npad <= 1024), 0: two-level blocking
   double huber;
+  const volatile unsigned char* stop_dev;   // device-visible mirror of the caller's stop flag (pinned host byte of the calling thread)
   BaState* st;
 };
 
@@ -722,6 +725,9 @@ __global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
   const double radius = st->radius;
   if (F.done) return;
   st->valid = 0; st->accepted = 0; st->chol_fail = 0;
+  // StopFlagCallback (include/CeresOptimizer.h:332-349) runs after every iteration, before the iteration-cap test: the
+  // host keeps copying the caller's flag into this pinned byte while the enqueued iterations drain
+  if (D.stop_dev && __atomic_load_n(D.stop_dev, __ATOMIC_RELAXED)) { st->termination = 4; st->done = 1; return; }
   if (iteration >= max_iters) { st->termination = 0; st->done = 1; return; }
   if (radius <= 1e-32) { st->termination = 6; st->done = 1; return; }
   st->iteration = iteration + 1;
@@ -1921,6 +1927,37 @@ static thread_local int g_stream_device = -1;
 struct GraphCacheEntry { std::vector<BaDev> D; const BaDev* Dv = nullptr; hipGraphExec_t exec = nullptr; unsigned long long stamp = 0; };
 static thread_local std::vector<GraphCacheEntry> g_graphs;      // instantiated per-iteration graphs of this thread (<= 4, LRU)
 static thread_local unsigned long long g_graph_clock = 0;
+// pinned, device-mapped byte through which the kernels see the caller's stop flag (a plain bool somewhere in host memory):
+// the host copies *stop_flag into it while it waits for the stream, k_ba_iter_begin reads it before every iteration
+static thread_local unsigned char* g_stop_host = nullptr;
+static thread_local unsigned char* g_stop_dev = nullptr;
+static int stop_mirror(unsigned char** host, const volatile unsigned char** dev) {
+  if (!g_stop_host) {
+    void* h = nullptr; void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      set_error("hipHostMalloc(stop flag mirror) failed"); return ORBHIP_ENOMEM;
+    }
+    g_stop_host = (unsigned char*)h; g_stop_dev = (unsigned char*)d;
+  }
+  *host = g_stop_host; *dev = g_stop_dev;
+  return 0;
+}
+// wait for the stream; while waiting, forward the caller's stop flag to the device mirror
+static hipError_t wait_stream_forwarding_stop(hipStream_t s, const volatile uint8_t* stop, unsigned char* mirror) {
+  if (!stop || !mirror) return hipStreamSynchronize(s);
+  for (;;) {
+    if (*stop) __atomic_store_n(mirror, (unsigned char)1, __ATOMIC_RELEASE);
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return hipSuccess;
+    if (q != hipErrorNotReady) return q;
+    std::this_thread::yield();
+  }
+}
+// measurement hook (ba_set_profiling / ba_get_profile): device time of the solves of this host thread, HIP events on its stream
+static std::atomic<int> g_ba_profiling{0};
+static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
+static thread_local double g_prof_ms = 0.0;
+static thread_local int g_prof_solves = 0, g_prof_iters = 0;
 static hipStream_t thread_stream() {
   const int dev = g_default_device.load();
   if (g_stream && g_stream_device != dev) {            // the default device changed: drop the old stream and workspace
@@ -2113,6 +2150,9 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   const double t_start = ba_now_ms();
   hipStream_t s = thread_stream();
   int rc = 0;
+  unsigned char* stop_host = nullptr; const volatile unsigned char* stop_devp = nullptr;
+  if (int r = stop_mirror(&stop_host, &stop_devp)) return r;
+  *stop_host = 0;                                         // (no solve of this thread is in flight: every call drains its stream)
   BaBatch& B = g_batch;
   bool reused = false;
   if (reuse_structure && g_batch_valid && (int)B.P.size() == nprob) {
@@ -2143,6 +2183,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     B.g_obs = 1; B.g_cam = 1; B.g_pt = 1; B.g_blk = 0; B.g_npad = NB; B.g_pad = 0; B.g_n6 = 0; B.g_camcount = 1; B.g_apply = 1; B.g_zero = 0;
     for (int p = 0; p < nprob; p++) {
       if (int r = ba_prepare(H, s, in[p], opts, &B.P[p])) return r;
+      B.P[p].D.stop_dev = stop_devp;
       const BaDev& D = B.P[p].D;
       B.Dh[p] = D;
       B.g_obs = std::max(B.g_obs, B.P[p].nb_obs); B.g_cam = std::max(B.g_cam, B.P[p].nb_cam); B.g_pt = std::max(B.g_pt, B.P[p].nb_pt);
@@ -2161,6 +2202,11 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   const int g_obs = B.g_obs, g_cam = B.g_cam, g_pt = B.g_pt, g_blk = B.g_blk, g_npad = B.g_npad, g_pad = B.g_pad, g_n6 = B.g_n6, g_camcount = B.g_camcount, g_apply = B.g_apply;
   const size_t g_zero = B.g_zero;
   const double t_upload = ba_now_ms();
+  const bool prof = g_ba_profiling.load() != 0;
+  if (prof) {
+    for (int k = 0; k < 2; k++) if (!g_prof_ev[k]) ORBHIP_CHECK_HIP(hipEventCreate(&g_prof_ev[k]));
+    ORBHIP_CHECK_HIP(hipEventRecord(g_prof_ev[0], s));
+  }
   const unsigned ny = (unsigned)nprob;
   const int npad_all = g_npad;
   if (g_pad > 0) hipLaunchKernelGGL(k_ba_pad, dim3(g_pad, ny), dim3(64), 0, s, Dv);
@@ -2244,11 +2290,11 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     if (it == opts->max_iterations) hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(1), 0, s, Dv);
     else if (gexec) ORBHIP_CHECK_HIP(hipGraphLaunch(gexec, s));
     else enqueue_iteration();
-    if (stop && *stop) user_stop = true;
+    if (stop && *stop) { __atomic_store_n(stop_host, (unsigned char)1, __ATOMIC_RELEASE); user_stop = true; }   // the device stops at its next iteration boundary
     if ((it & 7) == 7 && it + 8 < opts->max_iterations) {     // all converged early? (poll every 8 iterations of long solves)
       std::vector<BaState> cur(nprob);
       for (int p = 0; p < nprob; p++) ORBHIP_CHECK_HIP(hipMemcpyAsync(&cur[p], Dh[p].st, sizeof(BaState), hipMemcpyDeviceToHost, s));
-      ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+      ORBHIP_CHECK_HIP(wait_stream_forwarding_stop(s, stop, stop_host));
       bool all = true;
       for (int p = 0; p < nprob; p++) all = all && cur[p].done;
       if (all) break;
@@ -2257,6 +2303,10 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   const double t_enq = ba_now_ms();
   if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1, ny), dim3(1), 0, s, Dv);
   ORBHIP_CHECK_HIP(hipGetLastError());
+  if (prof) ORBHIP_CHECK_HIP(hipEventRecord(g_prof_ev[1], s));
+  // the iterations are all enqueued: a flag raised from now on reaches the device through the mirror (StopFlagCallback is
+  // polled after EVERY iteration, include/CeresOptimizer.h:332-349), the iterations behind it fall through
+  if (stop) ORBHIP_CHECK_HIP(wait_stream_forwarding_stop(s, stop, stop_host));
   std::vector<BaState> fin(nprob);
   const bool classify = erase_out != nullptr && Dh[0].erase != nullptr;
   if (classify) hipLaunchKernelGGL(k_ba_classify, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
@@ -2267,6 +2317,12 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     if (in[p].npts) ORBHIP_CHECK_HIP(hipMemcpyAsync(in[p].pts3, Dh[p].pts, 3 * (size_t)in[p].npts * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+  if (prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof_ev[0], g_prof_ev[1]) == hipSuccess) g_prof_ms += ms;
+    g_prof_solves += nprob;
+    for (int p = 0; p < nprob; p++) g_prof_iters += fin[p].iteration;
+  }
   if (timing) {
     double ts = 0; size_t pairs = 0; long nobs = 0;
     for (int p = 0; p < nprob; p++) { ts += P[p].t_struct_ms; pairs += P[p].npairs; nobs += in[p].nobs; }
@@ -2360,6 +2416,9 @@ int pg_solve_impl(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* e
   BaDev F; std::memset(&F, 0, sizeof(F));
   F.npad = npad; F.n6 = n7; F.nparts = nparts; F.S = P.S; F.rhs = P.rhs; F.Dinv = Dinv; F.part = P.part; F.st = P.st;
   F.nobs = nb_e * BA_TPB; F.npts = nb_e * BA_TPB; F.ncam = nb_v * BA_TPB;     // -> nb_obs = nb_pt = nb_e blocks, nb_cam = nb_v blocks
+  unsigned char* stop_host = nullptr;
+  if (int r = stop_mirror(&stop_host, &F.stop_dev)) return r;
+  *stop_host = 0;
   const BaDev* Fv = H.upload(&F, 1, &rc, s);
   if (rc) return rc;
   BaState st0; std::memset(&st0, 0, sizeof(st0));
@@ -2407,16 +2466,17 @@ int pg_solve_impl(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* e
     hipLaunchKernelGGL(k_ba_iter_end, dim3(1, 1), dim3(BA_TPB), 0, s, Fv);
     hipLaunchKernelGGL(k_pg_apply, dim3((7 * n + 255) / 256), dim3(256), 0, s, P);
     enqueue_eval();
-    if (stop && *stop) user_stop = true;
+    if (stop && *stop) { __atomic_store_n(stop_host, (unsigned char)1, __ATOMIC_RELEASE); user_stop = true; }
     if ((it & 3) == 3) {                                       // converged early? (pose graphs usually need ~10 of the 100 iterations)
       BaState cur;
       ORBHIP_CHECK_HIP(hipMemcpyAsync(&cur, P.st, sizeof(cur), hipMemcpyDeviceToHost, s));
-      ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+      ORBHIP_CHECK_HIP(wait_stream_forwarding_stop(s, stop, stop_host));
       if (cur.done) break;
     }
   }
   if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1, 1), dim3(1), 0, s, Fv);
   ORBHIP_CHECK_HIP(hipGetLastError());
+  if (stop) ORBHIP_CHECK_HIP(wait_stream_forwarding_stop(s, stop, stop_host));
   BaState fin;
   ORBHIP_CHECK_HIP(hipMemcpyAsync(&fin, P.st, sizeof(fin), hipMemcpyDeviceToHost, s));
   ORBHIP_CHECK_HIP(hipMemcpyAsync(lie7, P.x, 7 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2651,6 +2711,57 @@ int ba_essential_graph_correct(const double* lie7_orig, const double* lie7_opt, 
   ORBHIP_CHECK_HIP(hipMemcpyAsync(Tiw, dT, 12 * (size_t)n_kf * sizeof(double), hipMemcpyDeviceToHost, s));
   if (npts) ORBHIP_CHECK_HIP(hipMemcpyAsync(pts3, dp, 3 * (size_t)npts * sizeof(double), hipMemcpyDeviceToHost, s));
   ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---- measurement hook: device time of this host thread's ba_solve / ba_local_bundle_adjustment calls ---------------------
+int ba_set_profiling(int enable) { g_ba_profiling.store(enable ? 1 : 0); return 0; }
+int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations) {
+  if (device_ms) *device_ms = g_prof_ms;
+  if (nsolves) *nsolves = g_prof_solves;
+  if (lm_iterations) *lm_iterations = g_prof_iters;
+  g_prof_ms = 0.0; g_prof_solves = 0; g_prof_iters = 0;
+  return 0;
+}
+
+// ---- 7-vector pose codec (src/MatEigenConverter.cc:66-85); T = row-major 4x4 ------------------------------------------
+// Matrix4dToMatrix_7_1: [t, Eigen::Quaterniond(R).coeffs()] -- Eigen's matrix -> quaternion conversion branches on the
+// trace and, when it is not positive, on the largest diagonal element (no normalisation, no sign convention on w).
+int ba_matrix4d_to_pose7(const double* T, double* pose7) {
+  ORBHIP_REQUIRE(T && pose7, ORBHIP_EINVAL, "NULL argument");
+  const double m[3][3] = {{T[0], T[1], T[2]}, {T[4], T[5], T[6]}, {T[8], T[9], T[10]}};
+  double q[4];                                                  // x y z w
+  double t = m[0][0] + m[1][1] + m[2][2];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[2][1] - m[1][2]) * t; q[1] = (m[0][2] - m[2][0]) * t; q[2] = (m[1][0] - m[0][1]) * t;
+  } else {
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m[k][j] - m[j][k]) * t; q[j] = (m[j][i] + m[i][j]) * t; q[k] = (m[k][i] + m[i][k]) * t;
+  }
+  pose7[0] = T[3]; pose7[1] = T[7]; pose7[2] = T[11];
+  pose7[3] = q[0]; pose7[4] = q[1]; pose7[5] = q[2]; pose7[6] = q[3];
+  return 0;
+}
+// Matrix_7_1_ToMatrix4d: q.normalized().toRotationMatrix() (coefficients divided by the norm, then Eigen's product form)
+int ba_pose7_to_matrix4d(const double* pose7, double* T) {
+  ORBHIP_REQUIRE(T && pose7, ORBHIP_EINVAL, "NULL argument");
+  const double n = std::sqrt(pose7[3] * pose7[3] + pose7[4] * pose7[4] + pose7[5] * pose7[5] + pose7[6] * pose7[6]);
+  const double x = pose7[3] / n, y = pose7[4] / n, z = pose7[5] / n, w = pose7[6] / n;
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x,
+               tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  T[0] = 1 - (tyy + tzz); T[1] = txy - twz; T[2] = txz + twy; T[3] = pose7[0];
+  T[4] = txy + twz; T[5] = 1 - (txx + tzz); T[6] = tyz - twx; T[7] = pose7[1];
+  T[8] = txz - twy; T[9] = tyz + twx; T[10] = 1 - (txx + tyy); T[11] = pose7[2];
+  T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
   return 0;
 }
 

@@ -411,6 +411,27 @@ __device__ __forceinline__ int quad_of(const Rect16& r, int x, int y, int& mx, i
 }
 
 #define OCT_U 8        // key entries per thread requested together in the sweep loops
+// Per-node key counts and the four child counts of a candidate node: 16-bit fields when no level of the geometry can hold
+// more than 65535 candidates, 32-bit otherwise (a node of a nearly square or noisy level can own > 65535 keys in the first
+// sweeps; 16-bit fields would wrap and carry into their neighbours).
+template <bool WIDE> struct OctT;
+template <> struct OctT<false> {
+  typedef unsigned short cnt_t; typedef uint2 cc_t;
+  static __device__ __forceinline__ cc_t zero() { return make_uint2(0, 0); }
+  static __device__ __forceinline__ void add(cc_t* cc, int p, int q) { atomicAdd((q & 2) ? &cc[p].y : &cc[p].x, (q & 1) ? 0x10000u : 1u); }
+  static __device__ __forceinline__ void get(const cc_t& v, int c4[4]) { c4[0] = (int)(v.x & 0xFFFF); c4[1] = (int)(v.x >> 16); c4[2] = (int)(v.y & 0xFFFF); c4[3] = (int)(v.y >> 16); }
+};
+template <> struct OctT<true> {
+  typedef unsigned int cnt_t; typedef uint4 cc_t;
+  static __device__ __forceinline__ cc_t zero() { return make_uint4(0, 0, 0, 0); }
+  static __device__ __forceinline__ void add(cc_t* cc, int p, int q) { atomicAdd(&cc[p].x + q, 1u); }
+  static __device__ __forceinline__ void get(const cc_t& v, int c4[4]) { c4[0] = (int)v.x; c4[1] = (int)v.y; c4[2] = (int)v.z; c4[3] = (int)v.w; }
+};
+static size_t octree_lds_bytes(int node_cap, int max_cells_level, bool wide) {
+  const size_t per_node = 8 * 2 + (wide ? 16 : 8) + 8 + 4 + 4 + (wide ? 4 : 2) * 2 + 2 + 2 + 2;
+  return (size_t)node_cap * per_node + (size_t)(max_cells_level + 8) * 4 + 64;
+}
+template <bool WIDE>
 __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
                                                 const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
                                                 unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
@@ -424,15 +445,17 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
   Rect16* rect[2];
   rect[0] = (Rect16*)smem;
   rect[1] = rect[0] + NC;
-  uint2* cc = (uint2*)(rect[1] + NC);                 // 4 x u16 child counts (packed)
-  uint2* childpos = cc + NC;                          // 4 x u16 new positions (or .x = shifted position)
+  typedef typename OctT<WIDE>::cnt_t cnt_t;
+  typedef typename OctT<WIDE>::cc_t cc_t;
+  cc_t* cc = (cc_t*)(rect[1] + NC);                   // 4 child counts of a candidate node
+  uint2* childpos = (uint2*)(cc + NC);                // 4 x u16 new positions (or .x = shifted position)
   int* sA = (int*)(childpos + NC);
   int* sB = sA + NC;
   int* s_pref = sB + NC;                              // [max_cells_level + 1]
-  unsigned short* cnt[2];
-  cnt[0] = (unsigned short*)(s_pref + G.max_cells_level + 8);
+  cnt_t* cnt[2];
+  cnt[0] = (cnt_t*)(s_pref + G.max_cells_level + 8);
   cnt[1] = cnt[0] + NC;
-  unsigned short* order = cnt[1] + NC;
+  unsigned short* order = (unsigned short*)(cnt[1] + NC);
   unsigned short* candl = order + NC;
   short* rankOf = (short*)(candl + NC);
   __shared__ int s_tmp[16], s_m, s_nexp, s_L;
@@ -500,7 +523,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
       sA[i] = L0;                                  // remap (valid where c > 0)
       if (c > 0) {
         Rect16 r; r.ulx = (short)Lv.ini_x[i]; r.uly = 0; r.urx = (short)Lv.ini_x[i + 1]; r.bry = (short)Lv.winH;
-        rect[0][L0] = r; cnt[0][L0] = (unsigned short)c; L0++;
+        rect[0][L0] = r; cnt[0][L0] = (cnt_t)c; L0++;
       }
     }
     s_L = L0;
@@ -521,9 +544,9 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
   while (true) {
     const int prev = L;
     const Rect16* R = rect[cur];
-    const unsigned short* C = cnt[cur];
+    const cnt_t* C = cnt[cur];
     // ---- A: candidates = nodes holding > 1 key, in list order ---------------------------------
-    for (int p = tid; p < L; p += OCT_TPB) { sA[p] = C[p] > 1; cc[p] = make_uint2(0, 0); rankOf[p] = -1; }
+    for (int p = tid; p < L; p += OCT_TPB) { sA[p] = C[p] > 1; cc[p] = OctT<WIDE>::zero(); rankOf[p] = -1; }
     if (tid == 0) { s_m = -1; s_nexp = 0; }
     __syncthreads();
     const int ncand = block_excl_scan(sA, L, s_tmp);
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
           const uint32_t key = keyv[u];
           int mx, my;
           int q = quad_of(R[p], key & 0xFFF, (key >> 12) & 0xFFF, mx, my);
-          atomicAdd((q & 2) ? &cc[p].y : &cc[p].x, (q & 1) ? 0x10000u : 1u);
+          OctT<WIDE>::add(cc, p, q);
         }
       }
     }
@@ -555,14 +578,14 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     } else {
       // sort by (count desc, list position asc): list position asc == creation desc (canonical F9)
       for (int i = tid; i < ncand; i += OCT_TPB) {
-        int p = candl[i], cp = C[p], r = 0;
-        for (int j = 0; j < ncand; j++) { int pj = candl[j], cj = C[pj]; r += (cj > cp) || (cj == cp && pj < p); }
+        int p = candl[i], cp = (int)C[p], r = 0;
+        for (int j = 0; j < ncand; j++) { int pj = candl[j], cj = (int)C[pj]; r += (cj > cp) || (cj == cp && pj < p); }
         order[r] = (unsigned short)p;
       }
       __syncthreads();
       for (int r = tid; r < ncand; r += OCT_TPB) {
-        uint2 v = cc[order[r]];
-        sA[r] = ((v.x & 0xFFFF) != 0) + ((v.x >> 16) != 0) + ((v.y & 0xFFFF) != 0) + ((v.y >> 16) != 0) - 1;
+        int c4[4]; OctT<WIDE>::get(cc[order[r]], c4);
+        sA[r] = (c4[0] != 0) + (c4[1] != 0) + (c4[2] != 0) + (c4[3] != 0) - 1;
         sB[r] = sA[r];
       }
       __syncthreads();
@@ -579,8 +602,8 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     for (int r = tid; r < m; r += OCT_TPB) {
       int p = order[r];
       rankOf[p] = (short)r;
-      uint2 v = cc[p];
-      sA[r] = ((v.x & 0xFFFF) != 0) + ((v.x >> 16) != 0) + ((v.y & 0xFFFF) != 0) + ((v.y >> 16) != 0);
+      int c4[4]; OctT<WIDE>::get(cc[p], c4);
+      sA[r] = (c4[0] != 0) + (c4[1] != 0) + (c4[2] != 0) + (c4[3] != 0);
     }
     __syncthreads();
     const int TC = block_excl_scan(sA, m, s_tmp);          // sA[r] = creation index of r's first child
@@ -589,15 +612,14 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     block_excl_scan(sB, L, s_tmp);                         // sB[p] = #split nodes before p
     // ---- G: new list = reverse(children in creation order) ++ (old list minus split nodes) -------
     Rect16* Rn = rect[cur ^ 1];
-    unsigned short* Cn = cnt[cur ^ 1];
+    cnt_t* Cn = cnt[cur ^ 1];
     int nexp = 0;
     for (int p = tid; p < L; p += OCT_TPB) {
       int r = rankOf[p];
       if (r >= 0) {
         Rect16 rc = R[p];
         int mx, my; quad_of(rc, 0, 0, mx, my);
-        uint2 v = cc[p];
-        int c4[4] = {(int)(v.x & 0xFFFF), (int)(v.x >> 16), (int)(v.y & 0xFFFF), (int)(v.y >> 16)};
+        int c4[4]; OctT<WIDE>::get(cc[p], c4);
         int e = sA[r];
         unsigned short pos4[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -607,7 +629,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
             Rect16 ch;
             ch.ulx = (q & 1) ? (short)mx : rc.ulx; ch.urx = (q & 1) ? rc.urx : (short)mx;
             ch.uly = (q & 2) ? (short)my : rc.uly; ch.bry = (q & 2) ? rc.bry : (short)my;
-            Rn[pos] = ch; Cn[pos] = (unsigned short)c4[q];
+            Rn[pos] = ch; Cn[pos] = (cnt_t)c4[q];
             pos4[q] = (unsigned short)pos;
             nexp += c4[q] > 1;
           }
@@ -945,6 +967,7 @@ struct orbx_ctx {
   DevBuf d_img, d_out;                     // host-API staging: image; {counts | keypoints | descriptors} in one block
   void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
   size_t fast_lds = 0, octree_lds = 0;
+  bool octree_wide = false;           // some level can hold > 65535 candidates: 32-bit node counters (k_octree<true>)
   // last call (for introspection)
   const uint8_t* last_img0 = nullptr; long long last_img_frame_bytes = 0; int last_nframes = 0;
   bool const_uploaded = false;
@@ -1123,7 +1146,9 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
     G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
     c->fast_lds = (size_t)round_up((int)((size_t)2 * G.tile_h * G.tile_pitch + 2 * 64 * 8 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue (u16)
-    c->octree_lds = (size_t)G.node_cap * (8 * 2 + 8 + 8 + 4 + 4 + 2 * 2 + 2 + 2 + 2) + (size_t)(G.max_cells_level + 8) * 4 + 64;
+    c->octree_wide = false;
+    for (int l = 0; l < c->nlevels; l++) c->octree_wide = c->octree_wide || G.lv[l].kcap > 65535;
+    c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, c->octree_wide);
     ORBHIP_REQUIRE(c->octree_lds <= 160 * 1024, ORBHIP_EINVAL, "nfeatures too large for the LDS octree");
     if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
     if (int rc = c->d_btiles.ensure(c->btiles.size() * sizeof(BlurTile))) return rc;
@@ -1132,7 +1157,8 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     ORBHIP_CHECK_HIP(hipMemcpy(c->d_btiles.p, c->btiles.data(), c->btiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
     if (!tab.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
     if (c->octree_lds > 64 * 1024)
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds));
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute(c->octree_wide ? (const void*)k_octree<true> : (const void*)k_octree<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds));
     c->w = w; c->h = h; c->stride = stride; c->nframes = 0;
   }
   if (!c->const_uploaded) {
@@ -1200,9 +1226,14 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   // mode 2: the octree is one latency-bound workgroup per (frame, level) - 6 % VALU-busy, 0.6 waves per SIMD - so the
   // VALU-bound blur runs BESIDE it: the fork is taken after FAST, the octree is submitted first and keeps its slots
   if (side_mode == 2) ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
-  hipLaunchKernelGGL(k_octree, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
-                     c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
-                     c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
+  if (c->octree_wide)
+    hipLaunchKernelGGL(k_octree<true>, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
+                       c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
+                       c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
+  else
+    hipLaunchKernelGGL(k_octree<false>, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
+                       c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
+                       c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
   if (side_mode == 2) {
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
@@ -1343,7 +1374,7 @@ int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, 
 int orbx_extract(orbx_ctx* c, const uint8_t* img, int w, int h, int stride, orbx_keypoint* kps, uint8_t* desc32,
                  int cap, int* n) {
   ORBHIP_REQUIRE(c != nullptr, ORBHIP_EINVAL, "ctx is NULL");
-  if (!img || w <= 0 || h <= 0) return 0;                       // empty image: silent return (:1046)
+  if (!img || w <= 0 || h <= 0) { if (n) *n = 0; return 0; }    // empty image: silent return (:1046), nothing written
   ORBHIP_REQUIRE(kps && desc32 && n && cap > 0 && stride >= w, ORBHIP_EINVAL, "bad argument");
   ORBHIP_CHECK_HIP(hipSetDevice(c->device));
   const int icap = orbx_max_keypoints(c);

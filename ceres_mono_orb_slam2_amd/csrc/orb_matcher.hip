@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <vector>
+#include <mutex>
 #include <algorithm>
 
 #include "common.h"
@@ -323,10 +324,15 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
   const size_t lds = (size_t)cap * 32;
   ORBHIP_REQUIRE(lds <= 150 * 1024, ORBHIP_EINVAL, "per-frame capacity too large for the LDS-resident matcher (cap <= 4800)");
   ORBHIP_REQUIRE(cap < (1 << 24), ORBHIP_EINVAL, "cap too large");
-  static size_t attr_set = 0;
-  if (lds > 64 * 1024 && lds > attr_set) {
-    ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_match_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = lds;
+  if (lds > 64 * 1024) {                                   // the dynamic-LDS opt-in is per device: cache it per device, under a lock
+    static std::mutex mu; static size_t attr_set[64] = {0};
+    int dev = 0;
+    ORBHIP_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(mu);
+    if (dev < 0 || dev >= 64 || lds > attr_set[dev]) {
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_match_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (dev >= 0 && dev < 64) attr_set[dev] = lds;
+    }
   }
   hipLaunchKernelGGL(k_match_pairs, dim3(npairs), dim3(MP_THREADS), lds, (hipStream_t)stream, d_kps, d_desc, d_counts,
                      cap, d_pair_a, d_pair_b, ratio, th, check_ori, d_match12, d_nmatch, cap);

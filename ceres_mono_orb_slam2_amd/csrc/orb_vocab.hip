@@ -82,6 +82,7 @@ using namespace orbhip;
 
 extern "C" {
 
+int orbv_destroy(orbv_ctx* c);
 int orbv_create(const uint8_t* node_desc, const uint32_t* child_off, const uint32_t* children, const int32_t* word_id,
                 const double* weight, int n_nodes, int L, int device, orbv_ctx** out) {
   ORBHIP_REQUIRE(node_desc && child_off && children && word_id && weight && out && n_nodes > 1 && L > 0, ORBHIP_EINVAL, "NULL argument");
@@ -97,12 +98,13 @@ int orbv_create(const uint8_t* node_desc, const uint32_t* child_off, const uint3
   c->device = device; c->n_nodes = n_nodes; c->L = L;
   int rc = 0;
   if ((rc = c->desc.ensure((size_t)n_nodes * 32)) || (rc = c->child_off.ensure((size_t)(n_nodes + 1) * 4)) || (rc = c->children.ensure((size_t)std::max<uint32_t>(nchild, 1) * 4)) ||
-      (rc = c->word_id.ensure((size_t)n_nodes * 4)) || (rc = c->weight.ensure((size_t)n_nodes * 8))) { delete c; return rc; }
-  VCHK(hipMemcpy(c->desc.p, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice));
-  VCHK(hipMemcpy(c->child_off.p, child_off, (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice));
-  VCHK(hipMemcpy(c->children.p, children, (size_t)nchild * 4, hipMemcpyHostToDevice));
-  VCHK(hipMemcpy(c->word_id.p, word_id, (size_t)n_nodes * 4, hipMemcpyHostToDevice));
-  VCHK(hipMemcpy(c->weight.p, weight, (size_t)n_nodes * 8, hipMemcpyHostToDevice));
+      (rc = c->word_id.ensure((size_t)n_nodes * 4)) || (rc = c->weight.ensure((size_t)n_nodes * 8))) { orbv_destroy(c); return rc; }
+  hipError_t e = hipMemcpy(c->desc.p, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->child_off.p, child_off, (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && nchild) e = hipMemcpy(c->children.p, children, (size_t)nchild * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->word_id.p, word_id, (size_t)n_nodes * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->weight.p, weight, (size_t)n_nodes * 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("orbv_create: upload failed: %s", hipGetErrorString(e)); orbv_destroy(c); return ORBHIP_ENODEV; }
   *out = c;
   return 0;
 }

@@ -159,6 +159,33 @@ def sim3_log(s12):
     return out
 
 
+def matrix4d_to_pose7(T):
+    """MatEigenConverter::Matrix4dToMatrix_7_1 (src/MatEigenConverter.cc:66-75): 4x4 [R t; 0 1] -> [t, qx,qy,qz,qw]."""
+    L = _lib.load()
+    a = _f64(T).reshape(4, 4); out = np.zeros(7)
+    _lib.check(L.ba_matrix4d_to_pose7(_lib.ptr(a), _lib.ptr(out)), "ba_matrix4d_to_pose7")
+    return out
+
+
+def pose7_to_matrix4d(pose7):
+    """MatEigenConverter::Matrix_7_1_ToMatrix4d (src/MatEigenConverter.cc:77-85): normalises the quaternion."""
+    L = _lib.load()
+    a = _f64(pose7); out = np.zeros((4, 4))
+    _lib.check(L.ba_pose7_to_matrix4d(_lib.ptr(a), _lib.ptr(out)), "ba_pose7_to_matrix4d")
+    return out
+
+
+def set_profiling(enable=True):
+    _lib.check(_lib.load().ba_set_profiling(int(enable)))
+
+
+def get_profile():
+    """(device ms, problems solved, LM iterations) of THIS host thread's solves since the last call."""
+    ms, n, it = C.c_double(), C.c_int(), C.c_int()
+    _lib.check(_lib.load().ba_get_profile(C.byref(ms), C.byref(n), C.byref(it)))
+    return ms.value, n.value, it.value
+
+
 def _addr(a):
     return a.ctypes.data if a is not None and a.size else None
 

@@ -74,8 +74,9 @@ int orbx_get_tables(const orbx_ctx* ctx, float* scale, float* inv_scale, float* 
 int orbx_max_keypoints(const orbx_ctx* ctx);
 
 /* operator()(image, mask, keypoints, descriptors) for ONE host image (src/ORBextractor.cc:1043-1105).
- * img: CV_8UC1 rows of `stride` bytes.  Empty image (w<=0 or h<=0 or img==NULL) -> *n untouched,
- * returns 0 (":1046").  kps[cap], desc32[cap*32].                                */
+ * img: CV_8UC1 rows of `stride` bytes.  Empty image (w<=0 or h<=0 or img==NULL) -> returns 0 with *n = 0 and
+ * kps / desc32 untouched (":1046": the reference returns without touching its outputs; the C++ shim keeps the caller's
+ * vector as it is in that case).  kps[cap], desc32[cap*32].                                */
 int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int w, int h, int stride, orbx_keypoint* kps,
                  uint8_t* desc32, int cap, int* n);
 
@@ -257,8 +258,17 @@ typedef struct ba_options {
   int32_t max_iterations;      /* options.max_num_iterations */
   double huber_delta;          /* sqrt(5.991) in the reference; applied where obs_robust != 0 */
   int32_t fix_points;          /* 1 = points are constants (PoseOptimization) */
-  const volatile uint8_t* stop_flag; /* StopFlagCallback (include/CeresOptimizer.h:332-349); may be NULL */
+  const volatile uint8_t* stop_flag; /* StopFlagCallback (include/CeresOptimizer.h:332-349); may be NULL.  Any host byte: it is
+                                        polled before every enqueue and forwarded to the device while the solve drains, so a flag
+                                        raised mid-solve ends it at the next LM iteration boundary with termination 4 and the last
+                                        accepted iterate written back */
 } ba_options;
+
+/* MatEigenConverter::Matrix4dToMatrix_7_1 / Matrix_7_1_ToMatrix4d (src/MatEigenConverter.cc:66-85): T = row-major 4x4
+ * [R t; 0 1] <-> [tx,ty,tz,qx,qy,qz,qw].  Encoding is Eigen::Quaterniond(R).coeffs() (trace / largest-diagonal branches, not
+ * normalised); decoding normalises the quaternion first.  Host arithmetic.                                             */
+int ba_matrix4d_to_pose7(const double* T, double* pose7);
+int ba_pose7_to_matrix4d(const double* pose7, double* T);
 
 typedef struct ba_summary {
   double initial_cost, final_cost;
@@ -345,6 +355,13 @@ int ba_essential_graph_correct(const double* lie7_orig, const double* lie7_opt, 
  * cross the Sophus boundary (LoopClosing builds gScm from (s, R, t): src/LoopClosing.cc:322).                           */
 int ba_sim3_exp(const double* tangent7, double* s12_out);
 int ba_sim3_log(const double* s12, double* tangent7_out);
+
+/* Measurement hook (no reference counterpart): while enabled, every ba_solve / ba_solve_batch / ba_local_bundle_adjustment(_batch)
+ * / call brackets its device work (first kernel .. last LM iteration, copies excluded) with HIP events on the calling thread's
+ * stream; ba_get_profile returns the sums of THIS host thread since its last call (device ms, problems solved, LM iterations)
+ * and resets them.                                                                                                       */
+int ba_set_profiling(int enable);
+int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations);
 
 /* CeresOptimizer::BundleAdjustment (src/CeresOptimizer.cc:59-225) on flattened arrays, host pointers:
  * cameras with cam_fixed != 0 are constant (KF id 0, fixed KFs); obs_weight multiplies the pixel

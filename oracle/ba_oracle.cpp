@@ -26,8 +26,23 @@
 #include <vector>
 #include <algorithm>
 #include <limits>
+#include <thread>
+#include <functional>
 
 namespace {
+
+// Worker threads for the per-observation evaluation and the Schur elimination (the reference runs LocalBA with
+// options.num_threads = 4, src/CeresOptimizer.cc:516).  Every sum keeps its single-thread order (a thread owns whole
+// rows of the reduced system; costs and gradients are accumulated sequentially from per-observation values), so results
+// are bit-identical for any thread count.
+int g_ba_threads = 1;
+void parallel_for(int n, const std::function<void(int, int, int)>& body) {   // body(lo, hi, tid)
+  int T = std::max(1, std::min(g_ba_threads, n / 64 + 1));
+  if (T == 1) { body(0, n, 0); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) th.emplace_back(body, (int)((int64_t)n * t / T), (int)((int64_t)n * (t + 1) / T), t);
+  for (auto& x : th) x.join();
+}
 
 struct Opts {
   int max_iters;          // options.max_num_iterations
@@ -155,11 +170,15 @@ inline double eval_obs(const Problem& P, int i, const double* pose7, const doubl
 }
 
 double total_cost(const Problem& P, const double* poses, const double* pts) {
+  std::vector<double> rho(P.nobs);
+  parallel_for(P.nobs, [&](int lo, int hi, int) {
+    for (int i = lo; i < hi; i++) {
+      double r[2];
+      rho[i] = eval_obs(P, i, poses + 7 * P.obs_cam[i], pts + 3 * P.obs_pt[i], r, nullptr, nullptr);
+    }
+  });
   double c = 0;
-  for (int i = 0; i < P.nobs; i++) {
-    double r[2];
-    c += 0.5 * eval_obs(P, i, poses + 7 * P.obs_cam[i], pts + 3 * P.obs_pt[i], r, nullptr, nullptr);
-  }
+  for (int i = 0; i < P.nobs; i++) c += 0.5 * rho[i];
   return c;
 }
 
@@ -217,7 +236,7 @@ int lm_solve(Problem& P, double* poses, double* pts, Summary* sum) {
   if (!P.opt.fix_points) for (int p = 0; p < P.npts; p++) if (pt_used[p]) P.pt_col[p] = P.nfp++;
   const int nc6 = 6 * P.nfc, np3 = 3 * P.nfp, ncols = nc6 + np3;
 
-  std::vector<double> r(2 * (size_t)nobs), Jc(12 * (size_t)nobs), Jp(6 * (size_t)nobs);
+  std::vector<double> r(2 * (size_t)nobs), Jc(12 * (size_t)nobs), Jp(6 * (size_t)nobs), rho_obs(nobs);
   std::vector<double> scale(ncols, 1.0), grad(ncols), diag(ncols), step(ncols);
   std::vector<double> cand_poses(poses, poses + 7 * (size_t)P.ncam), cand_pts(pts, pts + 3 * (size_t)P.npts);
   double radius = 1e4, decrease_factor = 2.0;
@@ -235,11 +254,16 @@ int lm_solve(Problem& P, double* poses, double* pts, Summary* sum) {
   auto evaluate_at_x = [&](bool first) -> double {
     x_cost = 0;
     std::fill(grad.begin(), grad.end(), 0.0);
+    parallel_for(nobs, [&](int lo, int hi, int) {
+      for (int i = lo; i < hi; i++) {
+        int c = P.obs_cam[i], p = P.obs_pt[i];
+        rho_obs[i] = eval_obs(P, i, poses + 7 * c, pts + 3 * p, &r[2 * i], P.cam_col[c] >= 0 ? &Jc[12 * (size_t)i] : nullptr,
+                              P.pt_col[p] >= 0 ? &Jp[6 * (size_t)i] : nullptr);
+      }
+    });
     for (int i = 0; i < nobs; i++) {
-      int c = P.obs_cam[i], p = P.obs_pt[i];
-      int cc = P.cam_col[c], pc = P.pt_col[p];
-      x_cost += 0.5 * eval_obs(P, i, poses + 7 * c, pts + 3 * p, &r[2 * i], cc >= 0 ? &Jc[12 * (size_t)i] : nullptr,
-                               pc >= 0 ? &Jp[6 * (size_t)i] : nullptr);
+      int cc = P.cam_col[P.obs_cam[i]], pc = P.pt_col[P.obs_pt[i]];
+      x_cost += 0.5 * rho_obs[i];
       if (cc >= 0) for (int k = 0; k < 6; k++) grad[6 * cc + k] += Jc[12 * (size_t)i + k] * r[2 * i] + Jc[12 * (size_t)i + 6 + k] * r[2 * i + 1];
       if (pc >= 0) for (int k = 0; k < 3; k++) grad[nc6 + 3 * pc + k] += Jp[6 * (size_t)i + k] * r[2 * i] + Jp[6 * (size_t)i + 3 + k] * r[2 * i + 1];
     }
@@ -324,43 +348,60 @@ int lm_solve(Problem& P, double* poses, double* pts, Summary* sum) {
     // observations grouped by point
     std::vector<std::vector<int>> by_pt(P.nfp);
     if (P.nfp) for (int i = 0; i < nobs; i++) { int pc = P.pt_col[P.obs_pt[i]]; if (pc >= 0) by_pt[pc].push_back(i); }
-    std::vector<double> EC;   // per obs: E_i * Cinv (6x3)
-    for (int p = 0; p < P.nfp && ok; p++) {
-      const double* Ci = &Cinv[9 * (size_t)p];
-      const std::vector<int>& L = by_pt[p];
-      EC.assign(18 * L.size(), 0.0);
-      std::vector<double> E(18 * L.size(), 0.0);
-      for (size_t a = 0; a < L.size(); a++) {
-        int i = L[a];
-        int cc = P.cam_col[P.obs_cam[i]];
-        if (cc < 0) continue;
-        const double* jc = &Jc[12 * (size_t)i]; const double* jp = &Jp[6 * (size_t)i];
-        for (int u = 0; u < 6; u++) for (int v = 0; v < 3; v++) E[18 * a + 3 * u + v] = jc[u] * jp[v] + jc[6 + u] * jp[3 + v];
-        for (int u = 0; u < 6; u++) for (int v = 0; v < 3; v++) {
-          double acc = 0;
-          for (int k = 0; k < 3; k++) acc += E[18 * a + 3 * u + k] * Ci[3 * k + v];
-          EC[18 * a + 3 * u + v] = acc;
-        }
-      }
-      const double* gp = &gs[nc6 + 3 * p];
-      for (size_t a = 0; a < L.size(); a++) {
-        int ca = P.cam_col[P.obs_cam[L[a]]];
-        if (ca < 0) continue;
-        for (int u = 0; u < 6; u++) {
-          double acc = 0;
-          for (int k = 0; k < 3; k++) acc += EC[18 * a + 3 * u + k] * gp[k];
-          rhs[6 * ca + u] -= acc;
-        }
-        for (size_t b = 0; b < L.size(); b++) {
-          int cb = P.cam_col[P.obs_cam[L[b]]];
-          if (cb < 0) continue;
-          for (int u = 0; u < 6; u++) for (int v = 0; v < 6; v++) {
+    // per observation: E_i = Jc^T Jp (6x3) and E_i * Cinv (6x3), at the observation's position in its point's list
+    std::vector<size_t> pt_base(P.nfp + 1, 0);
+    for (int p = 0; p < P.nfp; p++) pt_base[p + 1] = pt_base[p] + by_pt[p].size();
+    std::vector<double> E(18 * pt_base[P.nfp], 0.0), EC(18 * pt_base[P.nfp], 0.0);
+    if (ok) parallel_for(P.nfp, [&](int plo, int phi, int) {
+      for (int p = plo; p < phi; p++) {
+        const double* Ci = &Cinv[9 * (size_t)p];
+        const std::vector<int>& L = by_pt[p];
+        double* Ep = &E[18 * pt_base[p]]; double* ECp = &EC[18 * pt_base[p]];
+        for (size_t a = 0; a < L.size(); a++) {
+          int i = L[a];
+          int cc = P.cam_col[P.obs_cam[i]];
+          if (cc < 0) continue;
+          const double* jc = &Jc[12 * (size_t)i]; const double* jp = &Jp[6 * (size_t)i];
+          for (int u = 0; u < 6; u++) for (int v = 0; v < 3; v++) Ep[18 * a + 3 * u + v] = jc[u] * jp[v] + jc[6 + u] * jp[3 + v];
+          for (int u = 0; u < 6; u++) for (int v = 0; v < 3; v++) {
             double acc = 0;
-            for (int k = 0; k < 3; k++) acc += EC[18 * a + 3 * u + k] * E[18 * b + 3 * v + k];
-            S[(size_t)(6 * ca + u) * nc6 + 6 * cb + v] -= acc;
+            for (int k = 0; k < 3; k++) acc += Ep[18 * a + 3 * u + k] * Ci[3 * k + v];
+            ECp[18 * a + 3 * u + v] = acc;
           }
         }
       }
+    });
+    // S -= sum_p E Cinv E^T, rhs -= sum_p E Cinv g_p: a thread owns the camera rows ca with ca % T == tid and walks the
+    // points in ascending order, so every entry is summed in the single-thread order
+    const int T = std::max(1, g_ba_threads);
+    auto schur_rows = [&](int tid) {
+      for (int p = 0; p < P.nfp; p++) {
+        const std::vector<int>& L = by_pt[p];
+        const double* Ep = &E[18 * pt_base[p]]; const double* ECp = &EC[18 * pt_base[p]];
+        const double* gp = &gs[nc6 + 3 * p];
+        for (size_t a = 0; a < L.size(); a++) {
+          int ca = P.cam_col[P.obs_cam[L[a]]];
+          if (ca < 0 || ca % T != tid) continue;
+          for (int u = 0; u < 6; u++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += ECp[18 * a + 3 * u + k] * gp[k];
+            rhs[6 * ca + u] -= acc;
+          }
+          for (size_t b = 0; b < L.size(); b++) {
+            int cb = P.cam_col[P.obs_cam[L[b]]];
+            if (cb < 0) continue;
+            for (int u = 0; u < 6; u++) for (int v = 0; v < 6; v++) {
+              double acc = 0;
+              for (int k = 0; k < 3; k++) acc += ECp[18 * a + 3 * u + k] * Ep[18 * b + 3 * v + k];
+              S[(size_t)(6 * ca + u) * nc6 + 6 * cb + v] -= acc;
+            }
+          }
+        }
+      }
+    };
+    if (ok) {
+      if (T == 1) schur_rows(0);
+      else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(schur_rows, t); for (auto& x : th) x.join(); }
     }
     if (ok && nc6) ok = cholesky(S, nc6);
     double model_cost_change = 0;
@@ -575,6 +616,49 @@ void orc_ba_eval_obs(const double* K4, const double* pose7, const double* X, con
   P.K4 = K4; P.obs_cam = &z; P.obs_pt = &z; P.obs_uv = uv; P.obs_w = &w; P.obs_robust = &rb; P.opt.huber_delta = huber_delta;
   *rho = eval_obs(P, 0, pose7, X, r2, Jc12, Jp6);
 }
+// MatEigenConverter::Matrix4dToMatrix_7_1 (src/MatEigenConverter.cc:66-75): Tcw_7_1 = [pose.block<3,1>(0,3),
+// Eigen::Quaterniond(R).coeffs()], coeffs = [x,y,z,w].  Eigen's matrix -> quaternion assignment
+// (Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl<Other,3,3>): trace > 0 -> w from the trace; otherwise the
+// largest diagonal element selects the component computed from a square root.  T row-major 4x4.
+void orc_matrix4d_to_pose7(const double* T, double* out) {
+  auto M = [&](int r, int c) { return T[4 * r + c]; };
+  double q[4];
+  double t = M(0, 0) + M(1, 1) + M(2, 2);
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (M(2, 1) - M(1, 2)) * t;
+    q[1] = (M(0, 2) - M(2, 0)) * t;
+    q[2] = (M(1, 0) - M(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (M(1, 1) > M(0, 0)) i = 1;
+    if (M(2, 2) > M(i, i)) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (M(k, j) - M(j, k)) * t;
+    q[j] = (M(j, i) + M(i, j)) * t;
+    q[k] = (M(k, i) + M(i, k)) * t;
+  }
+  out[0] = M(0, 3); out[1] = M(1, 3); out[2] = M(2, 3);
+  out[3] = q[0]; out[4] = q[1]; out[5] = q[2]; out[6] = q[3];
+}
+// MatEigenConverter::Matrix_7_1_ToMatrix4d (src/MatEigenConverter.cc:77-85): Quaterniond(w,x,y,z).normalized()
+// .toRotationMatrix() into an identity 4x4, translation copied.
+void orc_pose7_to_matrix4d(const double* p, double* T) {
+  const double n = std::sqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+  const double q[4] = {p[3] / n, p[4] / n, p[5] / n, p[6] / n};
+  double R[9];
+  quat_to_R(q, R);
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[4 * r + c] = R[3 * r + c]; T[4 * r + 3] = p[r]; }
+  T[12] = T[13] = T[14] = 0.0; T[15] = 1.0;
+}
+
+// worker threads of the evaluation / Schur elimination (results do not depend on it); returns the previous value
+int orc_set_ba_threads(int n) { int o = g_ba_threads; g_ba_threads = n < 1 ? 1 : n; return o; }
 void orc_quat_plus(const double* q, const double* d, double* out) { quat_plus(q, d, out); }
 void orc_quat_rotate(const double* q, const double* v, double* out) { quat_rotate(q, v, out); }
 

@@ -97,6 +97,8 @@ def lib():
                                    C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ba_eval_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_matrix4d_to_pose7.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pose7_to_matrix4d.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_quat_plus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_quat_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         # Sim3
@@ -388,6 +390,24 @@ def local_ba(K4, poses7, cam_fixed, cam_local, pts3, obs_cam, obs_pt, obs_uv, ob
                             _p(isg), len(oc), _p(stop) if stop is not None else None, int(duplicate_blocks), _p(er),
                             C.byref(s1), C.byref(s2))
     return rc, poses, pts, er, s1.as_dict(), s2.as_dict()
+
+
+def matrix4d_to_pose7(T):
+    a = np.ascontiguousarray(T, np.float64).reshape(4, 4); o = np.zeros(7)
+    lib().orc_matrix4d_to_pose7(_p(a), _p(o))
+    return o
+
+
+def pose7_to_matrix4d(p7):
+    a = np.ascontiguousarray(p7, np.float64); o = np.zeros((4, 4))
+    lib().orc_pose7_to_matrix4d(_p(a), _p(o))
+    return o
+
+
+def set_ba_threads(n):
+    """Worker threads of the BA oracle's evaluation / Schur elimination (the reference's LocalBA uses 4,
+    src/CeresOptimizer.cc:516).  Results are bit-identical for any count.  Returns the previous value."""
+    return lib().orc_set_ba_threads(int(n))
 
 
 def ba_eval_obs(K4, pose7, X, uv, w, robust=False, huber_delta=np.sqrt(5.991)):

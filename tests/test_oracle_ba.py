@@ -145,3 +145,21 @@ def test_local_ba_two_pass_and_stop_flag(oracle):
     rc, poses_nd, _, _, _, s2nd = oracle.local_ba(g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"],
                                                   g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"], duplicate_blocks=False)
     assert s2nd["initial_cost"] < s2["initial_cost"]
+
+
+def test_thread_count_does_not_change_results(oracle):
+    po = oracle
+    """The 4-thread leg of the CPU baseline (reference: options.num_threads = 4, src/CeresOptimizer.cc:516) must be the
+    same computation: bit-identical poses / points / flags for 1, 3 and 4 worker threads."""
+    from ceres_mono_orb_slam2_amd import synth
+    g = synth.make_ba_graph(5, ncam=12, npts=600, nobs=3000, n_fixed=1)
+    a = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(12, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+    ref = po.local_ba(*a)
+    try:
+        for t in (3, 4):
+            po.set_ba_threads(t)
+            out = po.local_ba(*a)
+            assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]) and np.array_equal(out[3], ref[3])
+            assert out[4] == ref[4] and out[5] == ref[5]
+    finally:
+        po.set_ba_threads(1)
