@@ -45,15 +45,16 @@ PMC_TRAFFIC = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed r
 PMC_VALU = ("r02_pmc_valu.json", "r01_pmc_valu.json")
 
 
-def make_frames(batch, seed):
-    """`batch` frames cut from a few synthetic canvases as chains of <=8 px translations."""
+def make_frames(batch, seed, pad_w=0, pad_h=0):
+    """`batch` frames cut from a few synthetic canvases as chains of <=8 px translations; pad_w / pad_h make
+    them larger so that several distinct 1241x376 crops can be taken from every frame."""
     from ceres_mono_orb_slam2_amd import synth
     fams = ["blocks", "checker", "blocks", "checker", "blocks", "flat", "blocks", "checker"]
     ncanvas = min(len(fams), max(1, batch // 8))
     per = (batch + ncanvas - 1) // ncanvas
     out = []
     for c in range(ncanvas):
-        fr, _ = synth.make_sequence(seed * 100 + c, W_IMG, H_IMG, per, fams[c], max_shift=8)
+        fr, _ = synth.make_sequence(seed * 100 + c, W_IMG + pad_w, H_IMG + pad_h, per, fams[c], max_shift=8)
         out.append(fr)
     return np.concatenate(out)[:batch]
 
@@ -66,21 +67,27 @@ def _ncores():
         return os.cpu_count() or 1
 
 
-def _cpu_frames_worker(frames, lo, n, out, k):
+def _cpu_frames_worker(frames, lo, n, out, k, deadline=None):
     from oracle import pyoracle as po
     E = po.OracleExtractor(NFEAT)
     prev = None
+    done = 0
     for i in range(lo, lo + n):
+        if deadline is not None and time.perf_counter() >= deadline:
+            break
         kp, d = E.extract(frames[i % len(frames)])
         ref = prev if prev is not None else (kp, d)
         po.match_frames(d, kp["angle"], ref[1], ref[0]["angle"], 0.9, 50, True)
         prev = (kp, d)
-    out[k] = n
+        done += 1
+    out[k] = done
 
 
-def cpu_baseline(frames, n_sample, n_all):
+def cpu_baseline(frames, n_sample, all_seconds):
     """Oracle (CPU port of the reference algorithm) on a bounded sample of the same workload: one thread (the reference's
-    own threading for extract / match) and all host cores running independent frame sub-sequences (throughput-fair)."""
+    own threading for extract / match) and all host cores running independent frame sub-sequences for `all_seconds`
+    (throughput-fair).  `cores` of the all-core leg = CPU seconds consumed / wall seconds (a container may be allowed
+    fewer cores than its affinity mask shows)."""
     from oracle import pyoracle as po
     po.lib()
     n = min(n_sample, len(frames))
@@ -88,23 +95,24 @@ def cpu_baseline(frames, n_sample, n_all):
     t0 = time.perf_counter()
     _cpu_frames_worker(frames, 0, n, res, 0)
     dt1 = time.perf_counter() - t0
-    cores = _ncores()
-    per = max(24, n_all // cores)
-    res = [0] * cores
-    ths = [threading.Thread(target=_cpu_frames_worker, args=(frames, c * per, per, res, c)) for c in range(cores)]
-    t0 = time.perf_counter()
+    nthr = min(_ncores(), 64)
+    res = [0] * nthr
+    deadline = time.perf_counter() + all_seconds
+    ths = [threading.Thread(target=_cpu_frames_worker, args=(frames, c * 16, 1 << 30, res, c, deadline)) for c in range(nthr)]
+    c0, t0 = time.process_time(), time.perf_counter()
     for t in ths:
         t.start()
     for t in ths:
         t.join()
     dta = time.perf_counter() - t0
+    used = (time.process_time() - c0) / dta
     return {"value": n / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d of the bench's 1241x376 frames: oracle extract (2000 features) + 1 brute-force match each, "
                       "single thread (the reference's threading for this path), %.1f s" % (n, dt1),
-            "all_cores": {"value": sum(res) / dta, "unit": "frames/s", "cores": cores,
-                          "sample": "%d frames as %d independent sub-sequences, one oracle instance per core, %.1f s"
-                                    % (sum(res), cores, dta)},
-            "host_cores": cores}
+            "all_cores": {"value": sum(res) / dta, "unit": "frames/s", "cores": max(1, int(round(used))), "threads": nthr,
+                          "sample": "%d frames as %d independent sub-sequences (one oracle instance per thread) in %.1f s; "
+                                    "cores = CPU seconds / wall seconds" % (sum(res), nthr, dta)},
+            "host_cores": _ncores()}
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -169,7 +177,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per extract/match launch sequence")
     ap.add_argument("--batches-per-step", type=int, default=32, help="batches per step (distinct resident frames)")
     ap.add_argument("--cpu-sample", type=int, default=96)    # ~8 s of single-thread oracle work
-    ap.add_argument("--cpu-all-sample", type=int, default=96 * 8)
+    ap.add_argument("--cpu-all-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous of the N ranks only (CPU, gloo)")
@@ -212,16 +220,18 @@ def main():
     from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher, _lib, sharding
     _lib.check(_lib.load().orbhip_set_default_device(local_rank), "orbhip_set_default_device")
     B, M = args.batch, args.batches_per_step
-    # M distinct batches resident in HBM: two synthetic base batches per rank (its own frames: frame sharding) and their
-    # translations (a whole batch rolled by (3v, 2v) px keeps the <=8 px frame-to-frame chains and moves every corner
-    # relative to the cell grid, so no two batches repeat work)
+    # M distinct batches resident in HBM: two synthetic base batches per rank (its own frames: frame sharding), generated
+    # a little larger than 1241x376, and crops of them at offsets (3v, 2v) px: a crop keeps the <=8 px frame-to-frame
+    # chains and moves every corner relative to the cell grid, so no two batches repeat work
     nbase = min(2, M)
-    base = [torch.from_numpy(make_frames(B, seed=rank * 16 + b)).to(dev) for b in range(nbase)]
+    nvar = (M + nbase - 1) // nbase
+    base = [torch.from_numpy(make_frames(B, seed=rank * 16 + b, pad_w=3 * (nvar - 1), pad_h=2 * (nvar - 1))).to(dev) for b in range(nbase)]
     batches = []
     for m in range(M):
         v = m // nbase
-        batches.append(base[m % nbase] if v == 0 else torch.roll(base[m % nbase], shifts=(2 * v, 3 * v), dims=(1, 2)).contiguous())
-    frames_host = base[0].cpu().numpy()
+        batches.append(base[m % nbase][:, 2 * v:2 * v + H_IMG, 3 * v:3 * v + W_IMG].contiguous())
+    frames_host = batches[0].cpu().numpy()
+    del base
     ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
     mt = ORBmatcher(0.9, True)
     cap = ex.max_keypoints
@@ -367,7 +377,7 @@ def main():
         if collective is not None:
             out["collective"] = collective
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames_host, args.cpu_sample, args.cpu_all_sample)
+            out["cpu_baseline"] = cpu_baseline(frames_host, args.cpu_sample, args.cpu_all_seconds)
         if localba is not None:
             out["localba"] = localba
         print(json.dumps(out))

@@ -1,44 +1,85 @@
 """LocalBA / PoseOptimization throughput legs of bench.py (BASELINE.json configs[2], configs[3])."""
+import os
+import threading
 import time
 
 import numpy as np
 
 from . import optimizer, synth
 
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD datasheet; the in-container guide does not state it)
+
+
+def reduced_solve_flops(g):
+    """flops of the Schur-complement GEMMs + the dense Cholesky of one LM iteration.
+    Schur: per point seen by k free cameras k^2 * 216 + k * 108; Cholesky: n^3 / 3 with n = 6 * free cameras."""
+    free = g["cam_fixed"] == 0
+    used = np.zeros(len(free), bool); used[np.unique(g["obs_cam"])] = True
+    k = np.bincount(g["obs_pt"][free[g["obs_cam"]]], minlength=len(g["pts0"])).astype(np.float64)
+    n = 6.0 * int((free & used).sum())
+    return float((k * k * 216 + k * 108).sum()), n ** 3 / 3.0
+
+
+def _roof(flops, seconds, what, **extra):
+    ach = flops / seconds / 1e12
+    d = {"achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "ms": seconds * 1e3, "what": what}
+    d.update(extra)
+    return d
+
+
+def _ncores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
 
 def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     import torch
     out = {}
-    # ---- C4: LocalBundleAdjustment, 100 KF x 10k pts x 50k obs, reference two-pass schedule (5 + 10 iterations)
-    g = synth.make_ba_graph(0, ncam=100, npts=10000, nobs=50000, n_fixed=2)
+    roof = {"bound": "mfma", "kernel": "reduced camera system: Schur complement (k_ba_schur) + dense FP64-MFMA Cholesky (k_chol_*)",
+            "definition": "(Schur GEMM flops + n^3/3) x LM iterations / solve time / FP64 matrix peak (SURVEY 8(d))",
+            "peak_source": "AMD MI355X datasheet, FP64 matrix 78.6 TFLOP/s", "cases": {}}
+    # ---- C4: LocalBundleAdjustment, 100 KF x 10k pts x 50k obs (all free except the gauge keyframe 0), reference two-pass
+    #      schedule (5 + 10 iterations)
+    g = synth.make_ba_graph(0, ncam=100, npts=10000, nobs=50000, n_fixed=1)
     local = np.ones(100, np.uint8)
     args = (g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
-    import threading
+    f_schur, f_chol = reduced_solve_flops(g)
     optimizer.local_bundle_adjustment(*args)                       # warm-up (module load, allocator)
     torch.cuda.synchronize()
+    optimizer.set_profiling(True); optimizer.get_profile()
     t0 = time.perf_counter()
     for _ in range(n_localba):
         ab, poses, pts, er, s1, s2 = optimizer.local_bundle_adjustment(*args)
     dt = time.perf_counter() - t0
+    dev_ms, nsolv, nit = optimizer.get_profile()                   # HIP events on the solver's stream, both passes of every solve
     out["localba_single_stream_solves_per_s"] = n_localba / dt
     out["localba_ms_per_solve_latency"] = dt / n_localba * 1e3
+    out["localba_ms_per_solve_device"] = dev_ms / n_localba
+    roof["cases"]["c4_single"] = _roof((f_schur + f_chol) * nit, dev_ms * 1e-3,
+                                       "one LocalBA at a time; device time of the %d LM iterations of %d solves (HIP events on the solve stream)" % (nit, n_localba),
+                                       flops_per_iteration=f_schur + f_chol, cholesky_n=600 - 6)
     # throughput: independent LocalBA problems (the sub-map sharding of SURVEY 8(e) inside one GPU): `nbatch` problems
     # per call solved in lockstep (ba_local_bundle_adjustment_batch: one grid row per problem), `nthreads` such calls
     # in flight from host threads (one HIP stream + device workspace per thread)
     nbatch, nthreads, n_each = 16, 8, 3
-    gs = [g] + [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=2) for s in (1, 2, 3)]
-    probs = [(q["K4"], q["poses0"], q["cam_fixed"], local, q["pts0"], q["obs_cam"], q["obs_pt"], q["obs_uv"], q["obs_inv_sigma2"])
-             for q in (gs[i % 4] for i in range(nbatch))]
+    gs = [g] + [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(1, nbatch)]   # 16 distinct local maps
+    probs = [(q["K4"], q["poses0"], q["cam_fixed"], local, q["pts0"], q["obs_cam"], q["obs_pt"], q["obs_uv"], q["obs_inv_sigma2"]) for q in gs]
+    fl_batch = sum(sum(reduced_solve_flops(q)) for q in gs)
     bar = threading.Barrier(nthreads + 1)
+    iters = [0] * nthreads
 
-    def work():
+    def work(k):
         for _ in range(2):
             optimizer.local_bundle_adjustment_batch(probs)
+        optimizer.get_profile()
         bar.wait()
         for _ in range(n_each):
             optimizer.local_bundle_adjustment_batch(probs)
+        iters[k] = optimizer.get_profile()[2]
 
-    ths = [threading.Thread(target=work) for _ in range(nthreads)]
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(nthreads)]
     for t in ths:
         t.start()
     bar.wait()
@@ -48,13 +89,19 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     dt = time.perf_counter() - t0
     out["localba_solves_per_s"] = nbatch * nthreads * n_each / dt
     out["localba_concurrency"] = nbatch * nthreads
+    mean_it = sum(iters) / float(nbatch * nthreads * n_each)
+    roof["cases"]["c4_batched"] = _roof(fl_batch / nbatch * mean_it * nbatch * nthreads * n_each, dt,
+                                        "%d distinct local maps per lockstep batch x %d host threads; wall time of %d solves (copies and host structure setup included)"
+                                        % (nbatch, nthreads, nbatch * nthreads * n_each), lm_iterations_per_solve=mean_it)
     out["localba_note"] = ("100 KF x 10000 pts x 50000 obs, reference two-pass schedule (5 Huber + 10 iterations with the "
                            "re-added blocks), host-pointer C ABI end to end (H2D/D2H copies and host structure setup "
-                           "included); %d independent problems per lockstep batch x %d host threads" % (nbatch, nthreads))
+                           "included); %d distinct problems per lockstep batch x %d host threads; all keyframes free except "
+                           "the gauge keyframe 0" % (nbatch, nthreads))
     out["localba_lm_iterations"] = int(s1["iterations"] + s2["iterations"])
     out["localba_final_cost"] = float(s2["final_cost"])
     # ---- C3: PoseOptimization, 1 camera x 2000 observations, batched device-resident
-    probs = [synth.make_pose_problem(100 + i, n=2000) for i in range(8)]
+    pprobs = [synth.make_pose_problem(100 + i, n=2000) for i in range(8)]
+    probs = pprobs
     reps = n_pose_batch // len(probs)
     offs = np.arange(0, 2000 * n_pose_batch + 1, 2000, dtype=np.int32)
     K4 = torch.from_numpy(np.stack([p["K4"] for p in probs] * reps)).to(dev)
@@ -80,23 +127,57 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     gg = synth.make_ba_graph(1000 + rank, ncam=500, npts=50000, nobs=250000, n_fixed=1)
     gargs = (gg["K4"], gg["poses0"], gg["cam_fixed"], gg["pts0"], gg["obs_cam"], gg["obs_pt"], gg["obs_uv"], gg["obs_inv_sigma2"])
     optimizer.global_bundle_adjustment(*gargs, n_iterations=2)     # warm-up
+    optimizer.get_profile()
     t0 = time.perf_counter()
-    gposes, gpts, gs = optimizer.global_bundle_adjustment(*gargs, n_iterations=50)
+    gposes, gpts, gsum = optimizer.global_bundle_adjustment(*gargs, n_iterations=50)
     dt = time.perf_counter() - t0
+    dev_ms, _, nit = optimizer.get_profile()
+    optimizer.set_profiling(False)
+    f5_schur, f5_chol = reduced_solve_flops(gg)
+    roof["cases"]["c5"] = _roof((f5_schur + f5_chol) * nit, dev_ms * 1e-3,
+                                "one 500-KF GlobalBA; device time of its %d LM iterations (HIP events on the solve stream)" % nit,
+                                flops_per_iteration=f5_schur + f5_chol, cholesky_n=6 * 499)
+    out["roofline"] = roof
     out["globalba_500kf_ms"] = dt * 1e3
-    out["globalba_500kf_iterations"] = int(gs["iterations"])
-    out["globalba_500kf_ms_per_iteration"] = dt * 1e3 / max(int(gs["iterations"]), 1)
+    out["globalba_500kf_iterations"] = int(gsum["iterations"])
+    out["globalba_500kf_ms_per_iteration"] = dt * 1e3 / max(int(gsum["iterations"]), 1)
     out["globalba_note"] = "500 KF x 50000 pts x 250000 obs, <= 50 LM iterations, host-pointer C ABI end to end, one sub-map per GPU"
     out["_final_points"] = np.ascontiguousarray(gpts)            # merged across ranks with ONE all-gather (bench.py, N > 1)
     if cpu:
         from oracle import pyoracle as po
+        cores = _ncores()
         t0 = time.perf_counter()
         po.local_ba(*args)
-        dt = time.perf_counter() - t0
-        out["cpu_localba_solves_per_s"] = 1.0 / dt
+        dt1 = time.perf_counter() - t0
+        po.set_ba_threads(4)                                       # options.num_threads = 4 (src/CeresOptimizer.cc:516)
         t0 = time.perf_counter()
-        for p in probs:
+        po.local_ba(*args)
+        dt4 = time.perf_counter() - t0
+        po.set_ba_threads(1)
+        lprobs = [(q["K4"], q["poses0"], q["cam_fixed"], local, q["pts0"], q["obs_cam"], q["obs_pt"], q["obs_uv"], q["obs_inv_sigma2"]) for q in gs]
+        nthr = min(cores, 32)
+        ths = [threading.Thread(target=po.local_ba, args=lprobs[c % len(lprobs)]) for c in range(nthr)]
+        c0, t0 = time.process_time(), time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dta = time.perf_counter() - t0
+        used = max(1, int(round((time.process_time() - c0) / dta)))
+        t0 = time.perf_counter()
+        for p in pprobs:
             po.pose_optimization(p["K4"], p["pose0"], p["Xw"], p["uv"], p["inv_sigma2"])
-        out["cpu_poseopt_solves_per_s"] = len(probs) / (time.perf_counter() - t0)
-        out["cpu_note"] = "oracle (CPU port), 1 thread: 1 LocalBA solve, %d PoseOptimization solves" % len(probs)
+        dtp = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "kind": "port", "host_cores": cores,
+            "localba_1_thread": {"value": 1.0 / dt1, "unit": "solves/s", "cores": 1, "sample": "1 LocalBA solve at C4 size, %.2f s" % dt1},
+            "localba_4_threads": {"value": 1.0 / dt4, "unit": "solves/s", "cores": 4,
+                                  "sample": "the same solve with 4 worker threads in the evaluation and the Schur elimination (the reference's "
+                                            "num_threads = 4), %.2f s" % dt4},
+            "localba_all_cores": {"value": nthr / dta, "unit": "solves/s", "cores": used, "threads": nthr,
+                                  "sample": "%d independent LocalBA solves, one single-thread oracle each, %.2f s; cores = CPU seconds / wall seconds" % (nthr, dta)},
+            "poseopt_1_thread": {"value": len(pprobs) / dtp, "unit": "solves/s", "cores": 1, "sample": "%d PoseOptimization solves" % len(pprobs)},
+        }
+        out["cpu_localba_solves_per_s"] = 1.0 / dt1
+        out["cpu_poseopt_solves_per_s"] = len(pprobs) / dtp
     return out

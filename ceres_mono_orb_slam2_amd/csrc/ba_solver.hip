@@ -1073,7 +1073,8 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
     double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
     for (int i = tid; i < NB * NB; i += 256) {
       int r = i / NB, c = i % NB;
-      if (c <= r) S[(size_t)(k + r) * np + k + c] = s_L[r][c];
+      // (L11 itself is NOT written back: nothing downstream reads it - the substitutions use L11^-1 - and the other
+      // workgroups of this launch, which factor the same block redundantly, may still be reading the unfactored one)
       Di[i] = s_X[r][c];
     }
   }
@@ -1342,7 +1343,8 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
     double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
     for (int i = tid; i < NB * NB; i += 256) {
       int r = i / NB, c = i % NB;
-      if (c <= r) S[(size_t)(k + r) * np + k + c] = s_L[r][c];
+      // (L11 itself is NOT written back: nothing downstream reads it - the substitutions use L11^-1 - and the other
+      // workgroups of this launch, which factor the same block redundantly, may still be reading the unfactored one)
       Di[i] = s_X[r][c];
     }
   }
@@ -1994,6 +1996,15 @@ struct HostBA {
     if (!*rc && count) { if (hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); *rc = ORBHIP_ENODEV; } }
     return d;
   }
+  // for host data that does NOT outlive the enqueue (function-local vectors, stack structs): an asynchronous copy from
+  // pageable memory may read its source after the call returned, so the data is first copied into this thread's pinned
+  // staging, which stays valid until the solve has drained
+  template <typename T> T* upload_staged(const T* src, size_t count, int* rc, hipStream_t st) {
+    T* h = pinned<T>(count, rc);
+    if (*rc) return nullptr;
+    if (count) std::memcpy(h, src, count * sizeof(T));
+    return upload(h, count, rc, st);
+  }
 };
 
 // ---- one problem: validation, structure (host, O(nobs)), uploads, device workspace -----------------------------------
@@ -2002,7 +2013,7 @@ struct BaInputs {
   const int32_t* obs_cam; const int32_t* obs_pt; const double* obs_uv; const double* obs_w; const uint8_t* obs_robust; int nobs;
   const uint8_t* cam_local = nullptr;   // LocalBA only: cameras whose observations are classified after the solve
 };
-struct BaPrepared { BaDev D; int nb_obs, nb_cam, nb_pt; size_t npairs; double t_struct_ms; std::vector<int> perm; uint8_t* h_rob; };
+struct BaPrepared { BaDev D; int nb_obs, nb_cam, nb_pt; size_t npairs; double t_struct_ms; std::vector<int> perm; uint8_t* h_rob; BaState* h_st; };
 struct BaBatch {
   std::vector<BaPrepared> P; std::vector<BaDev> Dh; const BaDev* Dv = nullptr;
   int g_obs, g_cam, g_pt, g_blk, g_npad, g_pad, g_n6, g_camcount, g_apply; size_t g_zero;
@@ -2100,7 +2111,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   static const bool use_la = []() { const char* e = std::getenv("ORBHIP_BA_LOOKAHEAD"); return !(e && e[0] == '0'); }();
   static const int la_max = []() { const char* e = std::getenv("ORBHIP_BA_LA_MAX"); return e ? atoi(e) : 1024; }();
   D.chol_la = (use_la && npad <= la_max) ? 1 : 0;
-  D.K4 = H.upload(in.K4, 4 * (size_t)ncam, &rc, s); D.cam_fixed = H.upload(in.cam_fixed, ncam, &rc, s); D.cam_col = H.upload(cam_col.data(), ncam, &rc, s);
+  D.K4 = H.upload(in.K4, 4 * (size_t)ncam, &rc, s); D.cam_fixed = H.upload(in.cam_fixed, ncam, &rc, s); D.cam_col = H.upload_staged(cam_col.data(), ncam, &rc, s);
   D.poses = H.upload(in.poses7, 7 * (size_t)ncam, &rc, s); D.pts = H.upload(in.pts3, 3 * (size_t)npts, &rc, s);
   D.cand_poses = H.alloc<double>(7 * (size_t)ncam, &rc); D.cand_pts = H.alloc<double>(3 * (size_t)npts, &rc);
   D.obs_cam = H.upload(oc, nobs, &rc, s); D.obs_pt = H.upload(op, nobs, &rc, s); D.obs_uv = H.upload(ouv, 2 * (size_t)nobs, &rc, s);
@@ -2108,8 +2119,8 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.pt_off = H.upload(pt_off, npts + 1, &rc, s); D.cam_off = H.upload(cam_off, ncam + 1, &rc, s);
   D.cam_obs = H.upload(cam_obs, nobs, &rc, s); D.cam_obs_pt = H.upload(cam_obs_pt, nobs, &rc, s);
   D.cam_pos = H.upload(cam_pos, nobs, &rc, s); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
-  D.free_cams = H.upload(free_cams.data(), nfc, &rc, s);
-  D.blk_a = H.upload(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload(blk_off.data(), 2 * (size_t)nblk, &rc, s);
+  D.free_cams = H.upload_staged(free_cams.data(), nfc, &rc, s);
+  D.blk_a = H.upload_staged(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload_staged(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload_staged(blk_off.data(), 2 * (size_t)nblk, &rc, s);
   D.pair_i = H.upload(pair_i, npairs_all, &rc, s); D.pair_j = H.upload(pair_j, npairs_all, &rc, s);
   D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jc = H.alloc<double>(12 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
   D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
@@ -2127,7 +2138,11 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   if (rc) return rc;
   BaState st0; std::memset(&st0, 0, sizeof(st0));
   st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = opts->max_iterations;
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
+  BaState* h_st = H.pinned<BaState>(1, &rc);                  // (pinned: the copy may run after this function has returned)
+  if (rc) return rc;
+  *h_st = st0;
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, h_st, sizeof(st0), hipMemcpyHostToDevice, s));
+  out->h_st = h_st;
   ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)npad * sizeof(double), s));
   ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)nparts * sizeof(double), s));
   out->D = D; out->nb_obs = nb_obs; out->nb_cam = nb_cam; out->nb_pt = nb_pt; out->npairs = npairs_all;
@@ -2171,7 +2186,8 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       if (D.nobs) ORBHIP_CHECK_HIP(hipMemcpyAsync(const_cast<unsigned char*>(D.obs_robust), Pp.h_rob, D.nobs, hipMemcpyHostToDevice, s));
       BaState st0; std::memset(&st0, 0, sizeof(st0));
       st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = opts->max_iterations;
-      ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
+      *Pp.h_st = st0;                                       // (the pinned state block of pass 1: that solve has drained)
+      ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, Pp.h_st, sizeof(st0), hipMemcpyHostToDevice, s));
       ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)D.npad * sizeof(double), s));
       ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)D.nparts * sizeof(double), s));
       Pp.t_struct_ms = 0.0;

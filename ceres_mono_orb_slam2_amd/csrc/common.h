@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/orbslam_hip.h"
@@ -51,6 +52,10 @@ struct DevBuf {
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return ORBHIP_ENOMEM; }
     bytes = want;
+    // debugging aid: ORBHIP_POISON=ff (or 00) fills every new device buffer with that byte, so that a kernel reading
+    // memory nobody wrote shows up as NaNs (ff) instead of depending on what the allocator handed out
+    static const int poison = []() { const char* v = std::getenv("ORBHIP_POISON"); return v ? (int)std::strtol(v, nullptr, 16) : -1; }();
+    if (poison >= 0) { (void)hipMemset(p, poison, want); (void)hipDeviceSynchronize(); }
     return 0;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }

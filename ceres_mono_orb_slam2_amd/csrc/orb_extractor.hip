@@ -35,7 +35,9 @@ namespace orbhip {
 static const int PATCH_SIZE = 31, HALF_PATCH = 15, EDGE_THRESHOLD = 19;
 static const int MAX_LEVELS = 16;
 static const int MAX_INI = 64;            // initial octree nodes per level (round(W/H))
-static const int KEYCAP_MAX = 131072;     // dense candidate capacity per (frame, level); beyond it the frame reports ORBHIP_EOVERFLOW
+static const int KEYCAP_MAX = 1 << 23;     // the dense candidate array of a (frame, level) is sized for its theoretical worst case (cells x
+                                           // in-cell NMS density 1/4); this bound only keeps the 24-bit candidate index of the octree's
+                                           // best-key word valid (a 4095 x 4095 level has at most 4.2 M).  ORBHIP_KEYCAP lowers it (test hook)
 
 struct LevelDev {
   int w, h;
@@ -472,6 +474,10 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
   __syncthreads();
   const int n = block_excl_scan(s_pref, ncell, s_tmp);
   if (tid == 0) { s_pref[ncell] = n; nkeys_out[f * G.nlevels + level] = n; }
+  // Two instantiations share the work: the 16-bit one (always launched) takes every level with <= 65535 candidates and
+  // reports overflow; the 32-bit one is launched behind it only when the geometry allows more than 65535 candidates in a
+  // level, and takes exactly those (its other workgroups leave here).
+  if (WIDE ? (n <= 65535 || n > Lv.kcap) : (n > 65535 && n <= Lv.kcap)) return;
   if (n > Lv.kcap) {
     if (tid == 0) { sel_cnt[f * G.nlevels + level] = 0; atomicOr(&status[f], 1); }
     return;
@@ -966,7 +972,7 @@ struct orbx_ctx {
   DevBuf d_pyr, d_blur, d_cellcnt, d_cellkps, d_keys, d_knode, d_sel, d_selcnt, d_nkeys, d_status;
   DevBuf d_img, d_out;                     // host-API staging: image; {counts | keypoints | descriptors} in one block
   void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
-  size_t fast_lds = 0, octree_lds = 0;
+  size_t fast_lds = 0, octree_lds = 0, octree_lds_wide = 0;
   bool octree_wide = false;           // some level can hold > 65535 candidates: 32-bit node counters (k_octree<true>)
   // last call (for introspection)
   const uint8_t* last_img0 = nullptr; long long last_img_frame_bytes = 0; int last_nframes = 0;
@@ -1148,8 +1154,9 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     c->fast_lds = (size_t)round_up((int)((size_t)2 * G.tile_h * G.tile_pitch + 2 * 64 * 8 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue (u16)
     c->octree_wide = false;
     for (int l = 0; l < c->nlevels; l++) c->octree_wide = c->octree_wide || G.lv[l].kcap > 65535;
-    c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, c->octree_wide);
-    ORBHIP_REQUIRE(c->octree_lds <= 160 * 1024, ORBHIP_EINVAL, "nfeatures too large for the LDS octree");
+    c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, false);
+    c->octree_lds_wide = octree_lds_bytes(G.node_cap, G.max_cells_level, true);
+    ORBHIP_REQUIRE((c->octree_wide ? c->octree_lds_wide : c->octree_lds) <= 160 * 1024, ORBHIP_EINVAL, "nfeatures too large for the LDS octree");
     if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
     if (int rc = c->d_btiles.ensure(c->btiles.size() * sizeof(BlurTile))) return rc;
     if (int rc = c->d_tab.ensure(std::max<size_t>(tab.size(), 16))) return rc;
@@ -1157,8 +1164,9 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     ORBHIP_CHECK_HIP(hipMemcpy(c->d_btiles.p, c->btiles.data(), c->btiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
     if (!tab.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
     if (c->octree_lds > 64 * 1024)
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute(c->octree_wide ? (const void*)k_octree<true> : (const void*)k_octree<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds));
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds));
+    if (c->octree_wide && c->octree_lds_wide > 64 * 1024)
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds_wide));
     c->w = w; c->h = h; c->stride = stride; c->nframes = 0;
   }
   if (!c->const_uploaded) {
@@ -1226,12 +1234,11 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   // mode 2: the octree is one latency-bound workgroup per (frame, level) - 6 % VALU-busy, 0.6 waves per SIMD - so the
   // VALU-bound blur runs BESIDE it: the fork is taken after FAST, the octree is submitted first and keeps its slots
   if (side_mode == 2) ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
-  if (c->octree_wide)
-    hipLaunchKernelGGL(k_octree<true>, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
-                       c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
-                       c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
-  else
-    hipLaunchKernelGGL(k_octree<false>, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
+  hipLaunchKernelGGL(k_octree<false>, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
+                     c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
+                     c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
+  if (c->octree_wide)        // levels with more than 65535 candidates (32-bit node counters); every other workgroup leaves at once
+    hipLaunchKernelGGL(k_octree<true>, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds_wide, st, G, c->d_cellcnt.as<int>(),
                        c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
                        c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
   if (side_mode == 2) {
@@ -1398,7 +1405,7 @@ int orbx_extract(orbx_ctx* c, const uint8_t* img, int w, int h, int stride, orbx
   ORBHIP_CHECK_HIP(hipMemcpyAsync(c->h_pin, dout, out_bytes, hipMemcpyDeviceToHost, 0));
   ORBHIP_CHECK_HIP(hipStreamSynchronize(0));
   const int32_t cnt = *(const int32_t*)c->h_pin;
-  if (cnt == -1) { set_error("candidate capacity exceeded (more than %d FAST corners in one pyramid level)", KEYCAP_MAX); return ORBHIP_EOVERFLOW; }
+  if (cnt == -1) { set_error("candidate capacity exceeded (ORBHIP_KEYCAP test hook, or more than %d FAST corners in one pyramid level)", KEYCAP_MAX); return ORBHIP_EOVERFLOW; }
   ORBHIP_REQUIRE(cnt >= 0, ORBHIP_EOVERFLOW, "internal keypoint capacity exceeded");
   ORBHIP_REQUIRE(cnt <= cap, ORBHIP_ECAP, "output capacity too small");
   if (cnt > 0) {

@@ -191,9 +191,12 @@ def make_sim3_problem(seed, n=120, outlier_frac=0.1, scale=1.15, noise=1.0, pert
 
 
 def make_ba_graph(seed, ncam=100, npts=10000, nobs=50000, outlier_frac=0.05, noise=1.0, perturb=True,
-                  n_fixed=1, w=1241, h=376):
+                  n_fixed=1, w=1241, h=376, max_depth=60.0, min_len=2):
     """C4/C5-style graph: forward-moving KITTI cameras, points in the frusta, each point seen by a
-    run of consecutive cameras (mean track length nobs/npts).  Camera 0..n_fixed-1 are fixed (gauge)."""
+    run of consecutive cameras (mean track length nobs/npts).  Camera 0..n_fixed-1 are fixed (gauge).
+    The defaults are SURVEY 8(d)'s workload (depth 4-60 m, tracks of >= 2 views 0.8 m apart: many points have a parallax
+    below 1 degree, so the problem is ill-conditioned by construction); max_depth / min_len make a well-conditioned
+    variant of the same shape for the parity tests that need one."""
     rng = np.random.default_rng(seed)
     K4 = KITTI_K4.copy()
     step = 0.8
@@ -208,14 +211,14 @@ def make_ba_graph(seed, ncam=100, npts=10000, nobs=50000, outlier_frac=0.05, noi
     mean_len = nobs / npts
     pts = np.zeros((npts, 3))
     oc, op = [], []
-    lens = np.clip(rng.poisson(max(mean_len - 2, 0.0), npts) + 2, 2, ncam)
+    lens = np.clip(rng.poisson(max(mean_len - min_len, 0.0), npts) + min_len, min_len, ncam)
     # adjust total to nobs exactly
     diff = int(lens.sum() - nobs)
     order = rng.permutation(npts)
     i = 0
     while diff != 0 and i < 50 * npts:
         p = order[i % npts]
-        if diff > 0 and lens[p] > 2:
+        if diff > 0 and lens[p] > min_len:
             lens[p] -= 1; diff -= 1
         elif diff < 0 and lens[p] < ncam:
             lens[p] += 1; diff += 1
@@ -226,7 +229,7 @@ def make_ba_graph(seed, ncam=100, npts=10000, nobs=50000, outlier_frac=0.05, noi
         cm = c0 + L // 2
         # place the point in the frustum of the middle camera, far enough to be seen by the run
         u = rng.uniform(100, w - 100); v = rng.uniform(40, h - 40)
-        z = rng.uniform(4 + step * L, 60)
+        z = rng.uniform(min(4 + step * L, max_depth - 1.0), max_depth)
         pc = np.array([(u - K4[2]) / K4[0] * z, (v - K4[3]) / K4[1] * z, z])
         R = quat_to_R(poses_gt[cm, 3:])
         pts[p] = R.T @ (pc - poses_gt[cm, :3])

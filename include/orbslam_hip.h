@@ -32,7 +32,8 @@ extern "C" {
 #define ORBHIP_ENODEV (-2)    /* no HIP device / HIP runtime error */
 #define ORBHIP_ENOMEM (-3)
 #define ORBHIP_ECAP (-4)      /* caller's output capacity too small */
-#define ORBHIP_EOVERFLOW (-5) /* internal candidate capacity exceeded: > 131072 FAST corners in one pyramid level of one frame */
+#define ORBHIP_EOVERFLOW (-5) /* internal candidate capacity exceeded (cannot happen for images up to 4095 x 4095: the candidate arrays
+                                 are sized for the worst case; only the ORBHIP_KEYCAP test hook lowers them) */
 #define ORBHIP_ENUMERIC (-6)  /* linear solve failed */
 
 const char* orbhip_last_error(void);
@@ -56,10 +57,10 @@ typedef struct orbx_keypoint {
 } orbx_keypoint;
 
 /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
- * (src/ORBextractor.cc:410-470); `device` = HIP device ordinal.  Capacities (errors, never silent): the largest
+ * (src/ORBextractor.cc:410-470); `device` = HIP device ordinal.  Capacity (an error, never silent): the largest
  * per-level quota must fit the LDS octree (about 3200 keypoints in one level, i.e. any nfeatures the reference's 8-level
- * configurations use; ORBHIP_EINVAL from the first extract call otherwise), and a level may hold at most 131072 FAST
- * corners (ORBHIP_EOVERFLOW for that frame).                                                                              */
+ * configurations use; ORBHIP_EINVAL from the first extract call otherwise).  The number of FAST corners per level is not
+ * limited (candidate arrays are sized for the worst case of the image geometry).                                         */
 int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
                 orbx_ctx** out);
 int orbx_destroy(orbx_ctx* ctx);

@@ -28,6 +28,7 @@
 #include <limits>
 #include <thread>
 #include <functional>
+#include <atomic>
 
 namespace {
 
@@ -182,23 +183,40 @@ double total_cost(const Problem& P, const double* poses, const double* pts) {
   return c;
 }
 
-// dense in-place Cholesky (lower) of n x n row-major A; returns false if not PD
+// dense in-place Cholesky (lower) of n x n row-major A; returns false if not PD.  With worker threads (g_ba_threads > 1)
+// the rows below the diagonal of a column are shared out among a team that meets at a barrier after every column; each
+// entry is still one sequential dot product over k, so the factor is bit-identical for any thread count.
 bool cholesky(std::vector<double>& A, int n) {
-  for (int j = 0; j < n; j++) {
-    double d = A[(size_t)j * n + j];
-    for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(d > 0.0) || !std::isfinite(d)) return false;
-    d = std::sqrt(d);
-    A[(size_t)j * n + j] = d;
-    for (int i = j + 1; i < n; i++) {
-      double s = A[(size_t)i * n + j];
-      const double* ai = &A[(size_t)i * n];
+  const int T = (n >= 256) ? std::max(1, g_ba_threads) : 1;
+  std::atomic<int> arrived{0}, phase{0};
+  std::atomic<bool> failed{false};
+  auto barrier = [&](int& local_phase) {
+    if (T == 1) return;
+    local_phase ^= 1;
+    if (arrived.fetch_add(1) == T - 1) { arrived.store(0); phase.store(local_phase); }
+    else while (phase.load() != local_phase) std::this_thread::yield();
+  };
+  auto team = [&](int tid) {
+    int local_phase = 0;
+    for (int j = 0; j < n; j++) {
+      double d = A[(size_t)j * n + j];
+      for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+      if (!(d > 0.0) || !std::isfinite(d)) { failed.store(true); return; }     // (every member sees the same d)
+      d = std::sqrt(d);
       const double* aj = &A[(size_t)j * n];
-      for (int k = 0; k < j; k++) s -= ai[k] * aj[k];
-      A[(size_t)i * n + j] = s / d;
+      for (int i = j + 1 + tid; i < n; i += T) {
+        double s = A[(size_t)i * n + j];
+        const double* ai = &A[(size_t)i * n];
+        for (int k = 0; k < j; k++) s -= ai[k] * aj[k];
+        A[(size_t)i * n + j] = s / d;
+      }
+      barrier(local_phase);                       // column j complete (the diagonal is written after everyone has used it)
+      if (tid == 0) A[(size_t)j * n + j] = d;
     }
-  }
-  return true;
+  };
+  if (T == 1) team(0);
+  else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(team, t); for (auto& x : th) x.join(); }
+  return !failed.load();
 }
 void chol_solve(const std::vector<double>& L, int n, std::vector<double>& b) {
   for (int i = 0; i < n; i++) {

@@ -1,0 +1,87 @@
+"""B6: StopFlagCallback (reference include/CeresOptimizer.h:332-349, src/CeresOptimizer.cc:509-514) raised MID-SOLVE.
+
+The reference polls the flag after every LM iteration; when it is set Ceres terminates with USER_SUCCESS and the last accepted
+iterate is what gets written back.  The HIP path enqueues all iterations ahead of time, so the flag is forwarded to a pinned
+byte that k_ba_iter_begin reads before every iteration.  Checks: termination == 4 (user stop), fewer iterations than the cap,
+and the returned state is EXACTLY the state an uninterrupted solve capped at that iteration count returns (bit-identical:
+same kernels, same order) -- i.e. the accepted iterate was written back, not a half-applied candidate."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from ceres_mono_orb_slam2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _raise_after(flag, seconds):
+    def run():
+        time.sleep(seconds)
+        flag[0] = 1
+    t = threading.Thread(target=run)
+    t.start()
+    return t
+
+
+def test_globalba_flag_raised_mid_solve_stops_at_an_iteration_boundary():
+    from ceres_mono_orb_slam2_amd import optimizer
+    g = synth.make_ba_graph(21, ncam=500, npts=50000, nobs=250000, n_fixed=2)
+    a = (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+    optimizer.global_bundle_adjustment(*a, n_iterations=2)                       # warm-up: graph capture, allocations
+    t0 = time.perf_counter()
+    _, _, full = optimizer.global_bundle_adjustment(*a, n_iterations=50)
+    t_full = time.perf_counter() - t0
+    assert full["iterations"] >= 20, full
+    flag = np.zeros(1, np.uint8)
+    th = _raise_after(flag, 0.25 * t_full)
+    poses, pts, s = optimizer.global_bundle_adjustment(*a, n_iterations=50, stop_flag=flag)
+    th.join()
+    assert s["termination"] == 4, s                                               # SOLVER_TERMINATE_SUCCESSFULLY
+    assert 1 <= s["iterations"] < full["iterations"], (s, full)
+    # the state is the accepted iterate after exactly s["iterations"] iterations
+    rposes, rpts, r = optimizer.global_bundle_adjustment(*a, n_iterations=s["iterations"])
+    assert r["iterations"] == s["iterations"] and r["successful_steps"] == s["successful_steps"]
+    assert r["final_cost"] == s["final_cost"]
+    assert np.array_equal(rposes, poses) and np.array_equal(rpts, pts)
+
+
+def test_localba_flag_raised_mid_solve():
+    """Raised during pass 1 or pass 2 of LocalBundleAdjustment: the running solve ends at its next iteration boundary; if
+    that was pass 1 the reference returns before pass 2 without writing anything back (src/CeresOptimizer.cc:509-512 after
+    `goto reoptimize`), if it was pass 2 the accepted iterate is written back."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    g = synth.make_ba_graph(22, ncam=100, npts=10000, nobs=50000, n_fixed=1)
+    a = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(100, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+    optimizer.local_bundle_adjustment(*a)
+    t0 = time.perf_counter()
+    ab0, poses0, pts0, er0, f1, f2 = optimizer.local_bundle_adjustment(*a)
+    t_full = time.perf_counter() - t0
+    assert ab0 == 0 and f1["iterations"] == 5 and f2["iterations"] >= 5
+    seen = set()
+    for frac in (0.15, 0.3, 0.5, 0.65, 0.8):
+        flag = np.zeros(1, np.uint8)
+        th = _raise_after(flag, frac * t_full)
+        ab, poses, pts, er, s1, s2 = optimizer.local_bundle_adjustment(*a, stop_flag=flag)
+        th.join()
+        if ab:                                                                    # stopped in pass 1 (or between the passes)
+            assert np.array_equal(poses, g["poses0"]) and np.array_equal(pts, g["pts0"])    # nothing written back
+            seen.add("pass1")
+        elif s2["termination"] == 4:
+            assert s2["iterations"] < f2["iterations"] and s1["iterations"] == 5
+            assert np.isfinite(poses).all() and s2["final_cost"] <= s2["initial_cost"]
+            seen.add("pass2")
+        else:
+            seen.add("late")                                                      # the flag came after the last iteration
+    assert seen & {"pass1", "pass2"}, seen
+
+
+def test_flag_set_before_the_call():
+    from ceres_mono_orb_slam2_amd import optimizer
+    g = synth.make_ba_graph(23, ncam=20, npts=800, nobs=4000, n_fixed=1)
+    flag = np.ones(1, np.uint8)
+    poses, pts, s = optimizer.global_bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"],
+                                                       g["obs_inv_sigma2"], n_iterations=20, stop_flag=flag)
+    assert s["termination"] == 4 and s["iterations"] == 0                        # callback after iteration 0
+    assert np.array_equal(pts, g["pts0"])
