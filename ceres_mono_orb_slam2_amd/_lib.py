@@ -14,7 +14,7 @@ SYMBOLS = [
     "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_tables", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_set_profiling", "orbx_get_stage_ms", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
-    "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_bow", "orbm_search_for_triangulation",
+    "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_sim3", "orbm_search_by_bow", "orbm_search_for_triangulation",
     "orbv_create", "orbv_destroy", "orbv_transform", "orbv_descend_device", "orbv_score_l1",
     "orbm_undistort_keypoints", "orbm_assign_features_to_grid", "orbm_features_in_area", "orbm_is_in_frustum",
     "orbm_triangulate_matches",
@@ -96,6 +96,7 @@ def load():
     L.orbm_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, i32, vp, C.POINTER(i32)]
     L.orbm_search_by_projection.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, vp, i32, f32, i32, i32,
                                             vp, vp, C.POINTER(i32)]
+    L.orbm_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.orbm_search_by_bow.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32, i32, i32, vp,
                                      C.POINTER(i32)]
     L.orbm_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, f32, f32, vp, vp,

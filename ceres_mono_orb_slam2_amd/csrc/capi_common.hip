@@ -11,6 +11,7 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+ThreadWs& thread_ws() { static thread_local ThreadWs ws; return ws; }
 }  // namespace orbhip
 
 extern "C" {

@@ -6,12 +6,15 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <vector>
+#include <algorithm>
 
 #include "../../include/orbslam_hip.h"
 
 namespace orbhip {
 
 void set_error(const char* fmt, ...);
+
 }  // namespace orbhip
 #include <atomic>
 namespace orbhip {
@@ -61,5 +64,95 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
   template <typename T> T* as() const { return (T*)p; }
 };
+
+// growable pinned host buffer
+struct PinnedHost {
+  void* p = nullptr; size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return 0;
+    if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    size_t want = need + need / 4;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; set_error("hipHostMalloc(%zu) failed", want); return ORBHIP_ENOMEM; }
+    bytes = want;
+    return 0;
+  }
+};
+
+// Per-host-thread workspace of the host-pointer entry points (matcher / frame calls): ONE non-blocking stream, device
+// buffers and pinned staging that grow and are reused across calls (slot order = request order inside a call), so a call
+// costs no hipMalloc / hipFree and its copies are true asynchronous DMA; every call ends with a single stream synchronise.
+// No destructor: freeing from a thread_local destructor can run after the HIP runtime has shut down.
+struct ThreadWs {
+  hipStream_t s = nullptr; int device = -1;
+  std::vector<DevBuf> dev; std::vector<PinnedHost> pin;
+  size_t dnext = 0, pnext = 0;
+  int begin() {                                              // select the default device, (re)create the stream, rewind the slots
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
+    if (int rc = use_default_device()) return rc;
+    const int d = g_default_device.load();
+    if (s && device != d) { (void)hipStreamDestroy(s); s = nullptr; dev.clear(); pin.clear(); }   // (buffers of the old device are leaked on purpose)
+    if (!s) { if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; set_error("hipStreamCreate failed"); return ORBHIP_ENODEV; } device = d; }
+    dnext = pnext = 0;
+    return 0;
+  }
+  template <typename T> T* d(size_t count, int* rc) {
+    if (dnext >= dev.size()) dev.resize(dnext + 1);
+    DevBuf& b = dev[dnext++];
+    int r = b.ensure(std::max<size_t>(count * sizeof(T), 16));
+    if (r && !*rc) *rc = r;
+    return b.as<T>();
+  }
+  template <typename T> T* h(size_t count, int* rc) {
+    if (pnext >= pin.size()) pin.resize(pnext + 1);
+    PinnedHost& b = pin[pnext++];
+    int r = b.ensure(std::max<size_t>(count * sizeof(T), 16));
+    if (r && !*rc) *rc = r;
+    return (T*)b.p;
+  }
+  template <typename T> T* up(const T* src, size_t count, int* rc) {          // host (any memory) -> pinned -> device, asynchronous
+    T* hp = h<T>(count, rc); T* dp = d<T>(count, rc);
+    if (*rc) return dp;
+    if (count) {
+      std::memcpy(hp, src, count * sizeof(T));
+      if (hipMemcpyAsync(dp, hp, count * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) { set_error("hipMemcpyAsync H2D failed"); *rc = ORBHIP_ENODEV; }
+    }
+    return dp;
+  }
+  template <typename T> T* down(const T* dp, size_t count, int* rc) {        // device -> pinned (valid after sync())
+    T* hp = h<T>(count, rc);
+    if (*rc) return hp;
+    if (count && hipMemcpyAsync(hp, dp, count * sizeof(T), hipMemcpyDeviceToHost, s) != hipSuccess) { set_error("hipMemcpyAsync D2H failed"); *rc = ORBHIP_ENODEV; }
+    return hp;
+  }
+  // several host arrays in ONE pinned block and ONE asynchronous copy (a copy costs microseconds of fixed overhead, the
+  // per-frame calls move a few hundred kilobytes in ten pieces): add() the pieces, commit(), then dev<T>(piece)
+  struct Pack {
+    struct Piece { const void* src; size_t bytes, off; };
+    std::vector<Piece> pieces; size_t total = 0; uint8_t* dbase = nullptr;
+    int add(const void* src, size_t bytes) {
+      const size_t off = total;
+      pieces.push_back({src, bytes, off});
+      total = (off + bytes + 255) & ~(size_t)255;
+      return (int)pieces.size() - 1;
+    }
+    template <typename T> T* dev(int piece) const { return piece < 0 ? nullptr : (T*)(dbase + pieces[piece].off); }
+  };
+  int commit(Pack& P) {
+    int rc = 0;
+    uint8_t* hp = h<uint8_t>(P.total, &rc); P.dbase = d<uint8_t>(P.total, &rc);
+    if (rc) return rc;
+    for (const Pack::Piece& q : P.pieces) if (q.bytes) std::memcpy(hp + q.off, q.src, q.bytes);
+    if (P.total && hipMemcpyAsync(P.dbase, hp, P.total, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("hipMemcpyAsync H2D failed"); return ORBHIP_ENODEV; }
+    return 0;
+  }
+  int sync() {
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { set_error("stream synchronise failed: %s", hipGetErrorString(e)); return ORBHIP_ENODEV; }
+    return 0;
+  }
+};
+ThreadWs& thread_ws();          // (capi_common.hip)
 
 }  // namespace orbhip

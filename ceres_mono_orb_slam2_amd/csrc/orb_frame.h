@@ -25,4 +25,11 @@ int frame_area_candidates(const FrameGridDev& g, const float* d_kps4, const floa
                           const int* d_q_maxl, const uint8_t* d_q_valid, int nq, DevBuf& cnt, DevBuf& cand_off, DevBuf& cand_idx,
                           uint32_t* total_out, hipStream_t s);
 
+// the same without a host round trip: the lists are written into a buffer of `cap` entries the caller sized beforehand
+// (entries beyond cap are dropped); the true total is cand_off[nq] on the device - the caller reads it with its own
+// downloads, and re-runs with a larger buffer if it exceeds cap.  Entry k of the lists is written at d_cand_idx[k * idx_stride]
+// (2 = interleaved with another per-candidate value).  Enqueue only.
+int frame_area_candidates_enqueue(const FrameGridDev& g, const float* d_kps4, const float* d_q_xy, const float* d_q_r, const int* d_q_minl,
+                                  const int* d_q_maxl, const uint8_t* d_q_valid, int nq, int* d_cnt, uint32_t* d_cand_off /*[nq+1]*/,
+                                  uint32_t* d_cand_idx, uint32_t cap, int idx_stride, hipStream_t s);
 }  // namespace orbhip

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_area(const float* __restrict__ kps4, co
                                               const float* __restrict__ q_xy, const float* __restrict__ q_r,
                                               const int* __restrict__ q_minl, const int* __restrict__ q_maxl,
                                               const uint8_t* __restrict__ q_valid, int nq, int* __restrict__ q_cnt,
-                                              const uint32_t* __restrict__ cand_off, uint32_t* __restrict__ cand_idx) {
+                                              const uint32_t* __restrict__ cand_off, uint32_t* __restrict__ cand_idx, uint32_t cap, int stride) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (q >= nq) return;
   int total = 0;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_area(const float* __restrict__ kps4, co
         for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         if (FILL) {
           uint32_t pos = obase + (uint32_t)(total + incl - mine);
-          for (uint32_t e = lo; e < hi; e++) { const uint32_t j = cell_idx[e]; if (hit(j)) cand_idx[pos++] = j; }
+          for (uint32_t e = lo; e < hi; e++) { const uint32_t j = cell_idx[e]; if (hit(j)) { if (pos < cap) cand_idx[(size_t)pos * stride] = j; pos++; } }
         }
         total += __shfl(incl, 63);
       }
@@ -225,7 +225,7 @@ int frame_area_candidates(const FrameGridDev& g, const float* d_kps4, const floa
   int rc = 0;
   if ((rc = cnt.ensure((size_t)nq * 4)) || (rc = cand_off.ensure((size_t)(nq + 1) * 4))) return rc;
   hipLaunchKernelGGL(k_area<false>, dim3((nq + 3) / 4), dim3(256), 0, s, d_kps4, g.off.as<uint32_t>(), g.idx.as<uint32_t>(), g.min_x, g.min_y,
-                     g.winv, g.hinv, d_q_xy, d_q_r, d_q_minl, d_q_maxl, d_q_valid, nq, cnt.as<int>(), (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                     g.winv, g.hinv, d_q_xy, d_q_r, d_q_minl, d_q_maxl, d_q_valid, nq, cnt.as<int>(), (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 1);
   hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, s, cnt.as<int>(), nq, cand_off.as<uint32_t>());
   uint32_t total = 0;
   ORBHIP_CHECK_HIP(hipMemcpyAsync(&total, cand_off.as<uint32_t>() + nq, 4, hipMemcpyDeviceToHost, s));
@@ -234,7 +234,20 @@ int frame_area_candidates(const FrameGridDev& g, const float* d_kps4, const floa
   if (total == 0) return 0;
   if ((rc = cand_idx.ensure((size_t)total * 4))) return rc;
   hipLaunchKernelGGL(k_area<true>, dim3((nq + 3) / 4), dim3(256), 0, s, d_kps4, g.off.as<uint32_t>(), g.idx.as<uint32_t>(), g.min_x, g.min_y,
-                     g.winv, g.hinv, d_q_xy, d_q_r, d_q_minl, d_q_maxl, d_q_valid, nq, (int*)nullptr, cand_off.as<uint32_t>(), cand_idx.as<uint32_t>());
+                     g.winv, g.hinv, d_q_xy, d_q_r, d_q_minl, d_q_maxl, d_q_valid, nq, (int*)nullptr, cand_off.as<uint32_t>(), cand_idx.as<uint32_t>(), total, 1);
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int frame_area_candidates_enqueue(const FrameGridDev& g, const float* d_kps4, const float* d_q_xy, const float* d_q_r, const int* d_q_minl,
+                                  const int* d_q_maxl, const uint8_t* d_q_valid, int nq, int* d_cnt, uint32_t* d_cand_off, uint32_t* d_cand_idx,
+                                  uint32_t cap, int idx_stride, hipStream_t s) {
+  if (nq <= 0) return 0;
+  hipLaunchKernelGGL(k_area<false>, dim3((nq + 3) / 4), dim3(256), 0, s, d_kps4, g.off.as<uint32_t>(), g.idx.as<uint32_t>(), g.min_x, g.min_y,
+                     g.winv, g.hinv, d_q_xy, d_q_r, d_q_minl, d_q_maxl, d_q_valid, nq, d_cnt, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 1);
+  hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, s, d_cnt, nq, d_cand_off);
+  hipLaunchKernelGGL(k_area<true>, dim3((nq + 3) / 4), dim3(256), 0, s, d_kps4, g.off.as<uint32_t>(), g.idx.as<uint32_t>(), g.min_x, g.min_y,
+                     g.winv, g.hinv, d_q_xy, d_q_r, d_q_minl, d_q_maxl, d_q_valid, nq, (int*)nullptr, d_cand_off, d_cand_idx, cap, idx_stride);
   ORBHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -18,6 +18,7 @@
 #include <vector>
 #include <mutex>
 #include <algorithm>
+#include <cstring>
 
 #include "common.h"
 #include "orb_frame.h"
@@ -209,44 +210,160 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
   if (tid == 0) nmatch[p] = s_n;
 }
 
-// ---- host mirror of Frame's 64x48 grid (reference src/Frame.cc:158-173, :243-320) -----------------
-struct FrameGrid {
-  static const int COLS = 64, ROWS = 48;
-  float min_x, min_y, winv, hinv;
-  std::vector<int> cell[COLS][ROWS];
-  const float* kps; int n;
-  void build(const float* k, int n_, const float* b) {
-    kps = k; n = n_; min_x = b[0]; min_y = b[2];
-    winv = static_cast<float>(COLS) / (b[1] - b[0]);
-    hinv = static_cast<float>(ROWS) / (b[3] - b[2]);
-    for (int i = 0; i < n; i++) {
-      int px = (int)std::round((k[4 * i] - min_x) * winv), py = (int)std::round((k[4 * i + 1] - min_y) * hinv);
-      if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
-      cell[px][py].push_back(i);
-    }
+// ---- brute force for ONE query set, split so that a single 2000 x 2000 match fills the chip ------------------------
+// 64 queries per workgroup (lane = query, descriptor in 8 VGPRs), its 16 waves take the targets j = w, w + 16, ... : the
+// target index is wave-uniform, so the descriptors arrive through the scalar unit (s_load, no LDS staging), and every wave
+// keeps (best, second best) as packed keys (distance << 16 | index) - "first minimum wins" is the minimum key, whatever
+// order the slices are merged in.  The 16 partial pairs are merged through LDS: k1 = min(k1a, k1b),
+// k2 = min(k2a, k2b, max(k1a, k1b)).  2000 queries -> 32 workgroups x 16 waves instead of 8 x 4.
+#define BS_WAVES 16
+__global__ __launch_bounds__(64 * BS_WAVES) void k_best2_split(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                                               int* __restrict__ best_idx, int* __restrict__ best_d, int* __restrict__ second_d) {
+  __shared__ uint32_t s_k1[BS_WAVES][64], s_k2[BS_WAVES][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+  if (i < nq) { q0 = ((const uint4*)q)[2 * (size_t)i]; q1 = ((const uint4*)q)[2 * (size_t)i + 1]; }
+  uint32_t k1 = (256u << 16) | 0xFFFFu, k2 = k1;
+  const uint4* T = (const uint4*)t;
+  for (int j = w; j < nt; j += BS_WAVES) {
+    const uint4 t0 = T[2 * (size_t)j], t1 = T[2 * (size_t)j + 1];
+    const uint32_t k = ((uint32_t)hamming256(q0, q1, t0, t1) << 16) | (uint32_t)j;
+    k2 = min(k2, max(k1, k));
+    k1 = min(k1, k);
   }
-  void query(float x, float y, float r, int minLevel, int maxLevel, std::vector<uint32_t>& out) const {
-    const int min_cx = std::max(0, (int)std::floor((x - min_x - r) * winv));
-    if (min_cx >= COLS) return;
-    const int max_cx = std::min(COLS - 1, (int)std::ceil((x - min_x + r) * winv));
-    if (max_cx < 0) return;
-    const int min_cy = std::max(0, (int)std::floor((y - min_y - r) * hinv));
-    if (min_cy >= ROWS) return;
-    const int max_cy = std::min(ROWS - 1, (int)std::ceil((y - min_y + r) * hinv));
-    if (max_cy < 0) return;
-    const bool check = (minLevel > 0) || (maxLevel >= 0);
-    for (int ix = min_cx; ix <= max_cx; ix++)
-      for (int iy = min_cy; iy <= max_cy; iy++)
-        for (int j : cell[ix][iy]) {
-          int oct = (int)kps[4 * j + 2];
-          if (check) {
-            if (oct < minLevel) continue;
-            if (maxLevel >= 0 && oct > maxLevel) continue;
-          }
-          if (std::fabs(kps[4 * j] - x) < r && std::fabs(kps[4 * j + 1] - y) < r) out.push_back((uint32_t)j);
-        }
+  s_k1[w][lane] = k1; s_k2[w][lane] = k2;
+  __syncthreads();
+  if (w == 0 && i < nq) {
+#pragma unroll
+    for (int u = 1; u < BS_WAVES; u++) {
+      const uint32_t a1 = s_k1[u][lane], a2 = s_k2[u][lane];
+      k2 = min(min(k2, a2), max(k1, a1));
+      k1 = min(k1, a1);
+    }
+    const int b1 = (int)(k1 >> 16);
+    best_idx[i] = (k1 & 0xFFFFu) == 0xFFFFu ? -1 : (int)(k1 & 0xFFFFu);
+    best_d[i] = b1 > 256 ? 256 : b1;
+    second_d[i] = min((int)(k2 >> 16), 256);
+  }
+}
+
+// every (query, candidate) distance of a CSR list whose total is only known on the device (off[nq]); grid sized for `cap`
+// (the lists are {candidate index, distance} pairs: pair[c].x is given, pair[c].y is written here)
+__global__ __launch_bounds__(256) void k_dist_csr_dev(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t,
+                                                      const uint32_t* __restrict__ off, uint2* __restrict__ pair, uint32_t cap) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t total = min(off[nq], cap);
+  if (c >= total) return;
+  int lo = 0, hi = nq;                 // largest i with off[i] <= c
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (off[mid] <= c) lo = mid; else hi = mid; }
+  const uint32_t j = pair[c].x;
+  pair[c].y = (uint32_t)hamming256(((const uint4*)q)[2 * (size_t)lo], ((const uint4*)q)[2 * (size_t)lo + 1],
+                       ((const uint4*)t)[2 * (size_t)j], ((const uint4*)t)[2 * (size_t)j + 1]);
+}
+
+// ---- rotation-consistency bookkeeping of the guided searches (host; tiny) ----------------------------------------------
+// Bin of a match: rot = a1 - a2 (+360 if negative), bin = round(rot / 30), 30 -> 0 (e.g. src/ORBmatcher.cc:431-437).
+static inline int rotation_bin(float a1, float a2) {
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+  return bin == HISTO_LENGTH ? 0 : bin;
+}
+// ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1386-1418) on bin populations: which bins survive.
+struct RotationFilter {
+  int cnt[HISTO_LENGTH];
+  RotationFilter() { for (int& c : cnt) c = 0; }
+  void add(int bin) { cnt[bin]++; }
+  // keep[b] = bin b is one of the (up to) three most populated ones after the 10 % rule
+  void kept(bool keep[HISTO_LENGTH]) const {
+    int top[3] = {-1, -1, -1}, pop[3] = {0, 0, 0};
+    for (int b = 0; b < HISTO_LENGTH; b++) {                 // strict '>' : the earlier bin wins ties, as the reference's scan
+      int r = 3;
+      while (r > 0 && cnt[b] > pop[r - 1]) r--;
+      if (r == 3) continue;
+      for (int m = 2; m > r; m--) { top[m] = top[m - 1]; pop[m] = pop[m - 1]; }
+      top[r] = b; pop[r] = cnt[b];
+    }
+    if ((float)pop[1] < 0.1f * (float)pop[0]) { top[1] = -1; top[2] = -1; }
+    else if ((float)pop[2] < 0.1f * (float)pop[0]) { top[2] = -1; }
+    for (int b = 0; b < HISTO_LENGTH; b++) keep[b] = (b == top[0] || b == top[1] || b == top[2]);
   }
 };
+
+// ---- window candidates + all their distances, device-side, one synchronisation -----------------------------------------
+// Frame grid (Frame::AssignFeaturesToGrid), Frame::GetFeaturesInArea lists in the reference's order and the Hamming
+// distance of every (query, candidate) pair.  Results land in pinned host memory owned by the thread workspace:
+// off[nq + 1], idx[total], dist[total].
+struct Candidate { uint32_t idx; int32_t dist; };
+struct WindowLists { const uint32_t* off = nullptr; const Candidate* cand = nullptr; uint32_t total = 0; };
+static thread_local FrameGridDev g_grid;                       // device grid of the calling thread (buffers grow, are reused)
+static thread_local uint32_t g_cand_cap = 0;                   // candidate capacity that was enough so far
+
+static int window_lists(ThreadWs& W, const float* kps4, const uint8_t* desc, int n, const float* bounds, const float* q_uv, const float* q_radius,
+                        const int32_t* q_minl, const int32_t* q_maxl, const uint8_t* q_valid, const uint8_t* q_desc, int nq, WindowLists* out) {
+  for (int attempt = 0; attempt < 2; attempt++) {
+    int rc = W.begin();
+    if (rc) return rc;
+    const uint32_t cap = std::max<uint32_t>(g_cand_cap, (uint32_t)nq * 64u);
+    ThreadWs::Pack in;                                           // every input in one pinned block, one H2D copy
+    const int pk = in.add(kps4, 16 * (size_t)n), pd = in.add(desc, 32 * (size_t)n), pq = in.add(q_uv, 8 * (size_t)nq), pr = in.add(q_radius, 4 * (size_t)nq),
+              pqd = in.add(q_desc, 32 * (size_t)nq), pmn = q_minl ? in.add(q_minl, 4 * (size_t)nq) : -1, pmx = q_maxl ? in.add(q_maxl, 4 * (size_t)nq) : -1,
+              pv = q_valid ? in.add(q_valid, (size_t)nq) : -1;
+    if ((rc = W.commit(in))) return rc;
+    // outputs in one device block [off (nq + 1) | {idx, dist} pairs (cap)]: its used prefix comes back with one D2H copy
+    const size_t off_words = ((size_t)nq + 1 + 1) & ~(size_t)1;  // (pairs 8-byte aligned)
+    int* dcnt = W.d<int>(nq, &rc);
+    uint32_t* dout = W.d<uint32_t>(off_words + 2 * (size_t)cap, &rc);
+    if (rc) return rc;
+    uint32_t* doff = dout; uint2* dpair = (uint2*)(dout + off_words);
+    const float* dk = in.dev<float>(pk);
+    const float gb[4] = {bounds[0], bounds[1], bounds[2], bounds[3]};
+    if ((rc = frame_grid_build(g_grid, dk, n, gb, W.s))) return rc;
+    if ((rc = frame_area_candidates_enqueue(g_grid, dk, in.dev<float>(pq), in.dev<float>(pr), in.dev<int>(pmn), in.dev<int>(pmx), in.dev<uint8_t>(pv), nq,
+                                            dcnt, doff, (uint32_t*)dpair, cap, 2, W.s))) return rc;
+    hipLaunchKernelGGL(k_dist_csr_dev, dim3((cap + 255) / 256), dim3(256), 0, W.s, in.dev<uint8_t>(pqd), nq, in.dev<uint8_t>(pd), doff, dpair, cap);
+    // the lists are usually far shorter than the capacity: download what the previous call needed (+ slack), the rest only if used
+    const uint32_t guess = std::min<uint32_t>(cap, std::max<uint32_t>(g_cand_cap, (uint32_t)nq * 16u));
+    uint32_t* hout = W.h<uint32_t>(off_words + 2 * (size_t)cap, &rc);
+    if (rc) return rc;
+    ORBHIP_CHECK_HIP(hipMemcpyAsync(hout, dout, (off_words + 2 * (size_t)guess) * 4, hipMemcpyDeviceToHost, W.s));
+    if ((rc = W.sync())) return rc;
+    const uint32_t total = hout[nq];
+    if (total > cap) { g_cand_cap = total + total / 4; continue; }          // (rare) lists longer than the buffer: once more, larger
+    if (total > guess) {
+      ORBHIP_CHECK_HIP(hipMemcpyAsync(hout + off_words + 2 * (size_t)guess, dout + off_words + 2 * (size_t)guess, 2 * (size_t)(total - guess) * 4, hipMemcpyDeviceToHost, W.s));
+      if ((rc = W.sync())) return rc;
+    }
+    g_cand_cap = std::max<uint32_t>(g_cand_cap, total + total / 8);
+    out->off = hout; out->cand = (const Candidate*)(hout + off_words); out->total = total;
+    return 0;
+  }
+  set_error("window candidate lists did not fit after regrowing");
+  return ORBHIP_ENOMEM;
+}
+
+// all distances of host-built CSR lists (BoW family): uploads, one kernel, one download, one synchronisation
+static int csr_distances(ThreadWs& W, const uint8_t* q, int nq, const uint8_t* t, int nt, const std::vector<uint32_t>& off,
+                         const std::vector<uint32_t>& idx, const int** dist_out) {
+  const uint32_t total = off[nq];
+  *dist_out = nullptr;
+  if (total == 0) return 0;
+  int rc = W.begin();
+  if (rc) return rc;
+  ThreadWs::Pack in;
+  const int pq = in.add(q, 32 * (size_t)nq), pt = in.add(t, 32 * (size_t)nt), po = in.add(off.data(), 4 * ((size_t)nq + 1)), pi = in.add(idx.data(), 4 * (size_t)total);
+  if ((rc = W.commit(in))) return rc;
+  int* dd = W.d<int>(total, &rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_dist_csr, dim3((total + 255) / 256), dim3(256), 0, W.s, in.dev<uint8_t>(pq), nq, in.dev<uint8_t>(pt), in.dev<uint32_t>(po),
+                     in.dev<uint32_t>(pi), total, dd);
+  const int* h = W.down(dd, total, &rc);
+  if (rc) return rc;
+  if ((rc = W.sync())) return rc;
+  *dist_out = h;
+  return 0;
+}
 
 }  // namespace orbhip
 
@@ -275,6 +392,8 @@ int orbm_hamming_best2_device(const uint8_t* d_q, int nq, const uint8_t* d_t, in
   hipStream_t st = (hipStream_t)stream;
   if (d_off)
     hipLaunchKernelGGL(k_best2_csr, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, nq, d_t, d_off, d_idx, d_best_idx, d_best_d, d_second_d);
+  else if (nt < 65535)          // (packed 16-bit target index)
+    hipLaunchKernelGGL(k_best2_split, dim3((nq + 63) / 64), dim3(64 * BS_WAVES), 0, st, d_q, nq, d_t, nt, d_best_idx, d_best_d, d_second_d);
   else
     hipLaunchKernelGGL(k_best2_brute, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, nq, d_t, nt, d_best_idx, d_best_d, d_second_d);
   ORBHIP_CHECK_HIP(hipGetLastError());
@@ -287,31 +406,21 @@ int orbm_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, const
   if (nq == 0) return 0;
   ORBHIP_REQUIRE(q && best_idx && best_d && second_d && (nt == 0 || t), ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE((off == nullptr) == (idx == nullptr), ORBHIP_EINVAL, "cand_offsets/cand_idx must both be given or both be NULL");
-  if (int rcd = use_default_device()) return rcd;
-  DevBuf dq, dt, doff, didx, dout;
+  ThreadWs& W = thread_ws();
+  int rc = W.begin();
+  if (rc) return rc;
   const size_t total = off ? off[nq] : 0;
-  int rc = 0;
-  if ((rc = dq.ensure((size_t)nq * 32)) || (rc = dt.ensure(std::max<size_t>((size_t)nt * 32, 32))) ||
-      (rc = dout.ensure((size_t)nq * 12)) || (off && ((rc = doff.ensure((size_t)(nq + 1) * 4)) || (rc = didx.ensure(std::max<size_t>(total * 4, 4)))))) {
-    dq.release(); dt.release(); doff.release(); didx.release(); dout.release();
-    return rc;
-  }
-  auto cleanup = [&]() { dq.release(); dt.release(); doff.release(); didx.release(); dout.release(); };
-#define MCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s: %s", #e, hipGetErrorString(_e)); cleanup(); return ORBHIP_ENODEV; } } while (0)
-  MCHK(hipMemcpy(dq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice));
-  if (nt) MCHK(hipMemcpy(dt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice));
-  if (off) {
-    MCHK(hipMemcpy(doff.p, off, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice));
-    if (total) MCHK(hipMemcpy(didx.p, idx, total * 4, hipMemcpyHostToDevice));
-  }
-  int32_t* o = dout.as<int32_t>();
-  rc = orbm_hamming_best2_device(dq.as<uint8_t>(), nq, dt.as<uint8_t>(), nt, off ? doff.as<uint32_t>() : nullptr,
-                                 off ? didx.as<uint32_t>() : nullptr, o, o + nq, o + 2 * (size_t)nq, nullptr);
-  if (rc) { cleanup(); return rc; }
-  MCHK(hipMemcpy(best_idx, o, (size_t)nq * 4, hipMemcpyDeviceToHost));
-  MCHK(hipMemcpy(best_d, o + nq, (size_t)nq * 4, hipMemcpyDeviceToHost));
-  MCHK(hipMemcpy(second_d, o + 2 * (size_t)nq, (size_t)nq * 4, hipMemcpyDeviceToHost));
-  cleanup();
+  ThreadWs::Pack in;
+  const int pq = in.add(q, 32 * (size_t)nq), pt = in.add(t, 32 * (size_t)nt), po = off ? in.add(off, 4 * ((size_t)nq + 1)) : -1, pi = off ? in.add(idx, 4 * total) : -1;
+  if ((rc = W.commit(in))) return rc;
+  int32_t* dout = W.d<int32_t>(3 * (size_t)nq, &rc);
+  if (rc) return rc;
+  if ((rc = orbm_hamming_best2_device(in.dev<uint8_t>(pq), nq, in.dev<uint8_t>(pt), nt, in.dev<uint32_t>(po), in.dev<uint32_t>(pi), dout, dout + nq,
+                                      dout + 2 * (size_t)nq, W.s))) return rc;
+  const int32_t* h = W.down(dout, 3 * (size_t)nq, &rc);
+  if (rc) return rc;
+  if ((rc = W.sync())) return rc;
+  std::memcpy(best_idx, h, (size_t)nq * 4); std::memcpy(best_d, h + nq, (size_t)nq * 4); std::memcpy(second_d, h + 2 * (size_t)nq, (size_t)nq * 4);
   return 0;
 }
 
@@ -340,50 +449,9 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
   return 0;
 }
 
-// ---- shared helper: all (query, candidate) distances of a CSR list on the GPU (host pointers in/out) -----------
-static int csr_distances_gpu(const uint8_t* q, int nq, const uint8_t* t, int nt, const std::vector<uint32_t>& off,
-                             const std::vector<uint32_t>& idx, std::vector<int>& dist) {
-  const uint32_t total = off[nq];
-  dist.resize(total);
-  if (total == 0) return 0;
-  if (int rcd = use_default_device()) return rcd;
-  DevBuf dq, dt, doff, didx, dd;
-  auto cleanup = [&]() { dq.release(); dt.release(); doff.release(); didx.release(); dd.release(); };
-  int rc = 0;
-  if ((rc = dq.ensure((size_t)nq * 32)) || (rc = dt.ensure((size_t)nt * 32)) || (rc = doff.ensure((size_t)(nq + 1) * 4)) ||
-      (rc = didx.ensure((size_t)total * 4)) || (rc = dd.ensure((size_t)total * 4))) { cleanup(); return rc; }
-  MCHK(hipMemcpy(dq.p, q, (size_t)nq * 32, hipMemcpyHostToDevice));
-  MCHK(hipMemcpy(dt.p, t, (size_t)nt * 32, hipMemcpyHostToDevice));
-  MCHK(hipMemcpy(doff.p, off.data(), (size_t)(nq + 1) * 4, hipMemcpyHostToDevice));
-  MCHK(hipMemcpy(didx.p, idx.data(), (size_t)total * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_dist_csr, dim3((total + 255) / 256), dim3(256), 0, 0, dq.as<uint8_t>(), nq, dt.as<uint8_t>(),
-                     doff.as<uint32_t>(), didx.as<uint32_t>(), total, dd.as<int>());
-  MCHK(hipGetLastError());
-  MCHK(hipMemcpy(dist.data(), dd.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-  cleanup();
-  return 0;
-}
-
-static void three_maxima_host(const int* cnt, int& i1, int& i2, int& i3) {          // src/ORBmatcher.cc:1386-1418
-  int max1 = 0, max2 = 0, max3 = 0; i1 = i2 = i3 = -1;
-  for (int b = 0; b < HISTO_LENGTH; b++) {
-    const int s = cnt[b];
-    if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = b; }
-    else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = b; }
-    else if (s > max3) { max3 = s; i3 = b; }
-  }
-  if (max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
-  else if (max3 < 0.1f * (float)max1) { i3 = -1; }
-}
-static inline int rot_bin_host(float a1, float a2) {
-  const float factor = 1.0f / HISTO_LENGTH;
-  float rot = a1 - a2;
-  if (rot < 0.0) rot += 360.0f;
-  int bin = (int)std::round(rot * factor);
-  if (bin == HISTO_LENGTH) bin = 0;
-  return bin;
-}
-
+// The projection family.  Device: grid, window lists, distances.  Host: the order-dependent pass, in query order - a target
+// that received a map point is closed for later queries (`taken`), best / second best with the level rule of :109-113,
+// Fuse's chi-square gate, and the rotation-consistency filter which re-opens the targets it rejects.
 int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, const float* bounds, const float* q_uv,
                               const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
                               const int32_t* q_pred_level, const uint8_t* q_desc, const uint8_t* q_valid,
@@ -397,85 +465,107 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
   ORBHIP_REQUIRE(kps4 && desc && bounds && q_uv && q_radius && q_desc, ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE(!check_ori || q_angle, ORBHIP_EINVAL, "rotation check needs q_angle");
   ORBHIP_REQUIRE(chi2_gate <= 0.f || inv_level_sigma2, ORBHIP_EINVAL, "chi2 gate needs inv_level_sigma2");
-  // ---- grid, window candidates and every (query, candidate) distance on the device: the host only keeps the
-  //      order-dependent greedy pass below, fed with the CSR lists in the reference's candidate order
-  std::vector<uint32_t> off(nq + 1, 0), idx;
-  std::vector<int> dist;
-  {
-    if (int rcd = use_default_device()) return rcd;
-    FrameGridDev G; DevBuf dk, dd, dq, dr, dmn, dmx, dv, dqd, dcnt, doff, didx, ddist;
-    DevBuf* all[] = {&dk, &dd, &dq, &dr, &dmn, &dmx, &dv, &dqd, &dcnt, &doff, &didx, &ddist};
-    auto cleanup = [&]() { G.release(); for (DevBuf* b : all) b->release(); };
-    int rc = 0;
-    if ((rc = dk.ensure((size_t)n * 16)) || (rc = dd.ensure((size_t)n * 32)) || (rc = dq.ensure((size_t)nq * 8)) || (rc = dr.ensure((size_t)nq * 4)) ||
-        (rc = dqd.ensure((size_t)nq * 32)) || (q_min_level && (rc = dmn.ensure((size_t)nq * 4))) || (q_max_level && (rc = dmx.ensure((size_t)nq * 4))) ||
-        (q_valid && (rc = dv.ensure((size_t)nq)))) { cleanup(); return rc; }
-#define SBP_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return ORBHIP_ENODEV; } } while (0)
-    SBP_CHK(hipMemcpy(dk.p, kps4, (size_t)n * 16, hipMemcpyHostToDevice)); SBP_CHK(hipMemcpy(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
-    SBP_CHK(hipMemcpy(dq.p, q_uv, (size_t)nq * 8, hipMemcpyHostToDevice)); SBP_CHK(hipMemcpy(dr.p, q_radius, (size_t)nq * 4, hipMemcpyHostToDevice));
-    SBP_CHK(hipMemcpy(dqd.p, q_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
-    if (q_min_level) SBP_CHK(hipMemcpy(dmn.p, q_min_level, (size_t)nq * 4, hipMemcpyHostToDevice));
-    if (q_max_level) SBP_CHK(hipMemcpy(dmx.p, q_max_level, (size_t)nq * 4, hipMemcpyHostToDevice));
-    if (q_valid) SBP_CHK(hipMemcpy(dv.p, q_valid, (size_t)nq, hipMemcpyHostToDevice));
-    const float gb[4] = {bounds[0], bounds[1], bounds[2], bounds[3]};
-    if ((rc = frame_grid_build(G, dk.as<float>(), n, gb, nullptr))) { cleanup(); return rc; }
-    uint32_t total = 0;
-    if ((rc = frame_area_candidates(G, dk.as<float>(), dq.as<float>(), dr.as<float>(), q_min_level ? dmn.as<int>() : nullptr,
-                                    q_max_level ? dmx.as<int>() : nullptr, q_valid ? dv.as<uint8_t>() : nullptr, nq, dcnt, doff, didx, &total, nullptr))) { cleanup(); return rc; }
-    SBP_CHK(hipMemcpy(off.data(), doff.p, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost));
-    idx.resize(total); dist.resize(total);
-    if (total) {
-      if ((rc = ddist.ensure((size_t)total * 4))) { cleanup(); return rc; }
-      hipLaunchKernelGGL(k_dist_csr, dim3((total + 255) / 256), dim3(256), 0, 0, dqd.as<uint8_t>(), nq, dd.as<uint8_t>(), doff.as<uint32_t>(),
-                         didx.as<uint32_t>(), total, ddist.as<int>());
-      SBP_CHK(hipGetLastError());
-      SBP_CHK(hipMemcpy(idx.data(), didx.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-      SBP_CHK(hipMemcpy(dist.data(), ddist.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-    }
-#undef SBP_CHK
-    cleanup();
-  }
-  // ---- greedy pass in query order (reference loop order) ---------------------------------------
-  int nm = 0;
-  std::vector<int> hist_bin(nq, -1);
-  int cnt[HISTO_LENGTH] = {0};
-  for (int i = 0; i < nq; i++) {
-    int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
-    for (uint32_t c = off[i]; c < off[i + 1]; c++) {
-      const int t = (int)idx[c];
+  WindowLists L;
+  if (int rc = window_lists(thread_ws(), kps4, desc, n, bounds, q_uv, q_radius, q_min_level, q_max_level, q_valid, q_desc, nq, &L)) return rc;
+  struct Level2 { int d = 256, lvl = -1; };                     // (distance, octave) of a candidate
+  RotationFilter rot;
+  std::vector<signed char> bin_of(nq, -1);
+  int found = 0;
+  for (int qi = 0; qi < nq; qi++) {
+    Level2 first, second; int target = -1;
+    const bool level_gate = q_pred_level && q_pred_level[qi] >= 0;
+    for (uint32_t c = L.off[qi]; c < L.off[qi + 1]; c++) {
+      const int t = (int)L.cand[c].idx;
       if (taken && taken[t]) continue;
       const int lvl = (int)kps4[4 * t + 2];
-      if (q_pred_level && q_pred_level[i] >= 0 && (lvl < q_pred_level[i] - 1 || lvl > q_pred_level[i])) continue;
+      if (level_gate && (lvl < q_pred_level[qi] - 1 || lvl > q_pred_level[qi])) continue;
       if (chi2_gate > 0.f) {
-        const float ex = q_uv[2 * i] - kps4[4 * t], ey = q_uv[2 * i + 1] - kps4[4 * t + 1];
+        const float ex = q_uv[2 * qi] - kps4[4 * t], ey = q_uv[2 * qi + 1] - kps4[4 * t + 1];
         const float e2 = ex * ex + ey * ey;
         if (e2 * inv_level_sigma2[lvl] > chi2_gate) continue;
       }
-      const int d = dist[c];
-      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = lvl; bestIdx = t; }
-      else if (mode_best2 && d < bestDist2) { bestLevel2 = lvl; bestDist2 = d; }
+      const int d = L.cand[c].dist;
+      if (d < first.d) { second = first; first.d = d; first.lvl = lvl; target = t; }
+      else if (mode_best2 && d < second.d) { second.d = d; second.lvl = lvl; }
     }
-    if (q_best_dist) q_best_dist[i] = bestDist;
-    if (bestIdx >= 0 && bestDist <= th) {
-      if (mode_best2 && bestLevel == bestLevel2 && bestDist > ratio * bestDist2) continue;
-      q_match[i] = bestIdx;
-      if (taken) taken[bestIdx] = 1;
-      nm++;
-      if (check_ori) { hist_bin[i] = rot_bin_host(q_angle[i], kps4[4 * bestIdx + 3]); cnt[hist_bin[i]]++; }
-    }
+    if (q_best_dist) q_best_dist[qi] = first.d;
+    if (target < 0 || first.d > th) continue;
+    if (mode_best2 && first.lvl == second.lvl && first.d > ratio * second.d) continue;
+    q_match[qi] = target;
+    if (taken) taken[target] = 1;
+    found++;
+    if (check_ori) { bin_of[qi] = (signed char)rotation_bin(q_angle[qi], kps4[4 * target + 3]); rot.add(bin_of[qi]); }
   }
   if (check_ori) {
-    int i1, i2, i3;
-    three_maxima_host(cnt, i1, i2, i3);
-    for (int i = 0; i < nq; i++)
-      if (q_match[i] >= 0 && hist_bin[i] != i1 && hist_bin[i] != i2 && hist_bin[i] != i3) {
-        if (taken) taken[q_match[i]] = 0;
-        q_match[i] = -1; nm--;
-      }
+    bool keep[HISTO_LENGTH];
+    rot.kept(keep);
+    for (int qi = 0; qi < nq; qi++)
+      if (q_match[qi] >= 0 && !keep[bin_of[qi]]) { if (taken) taken[q_match[qi]] = 0; q_match[qi] = -1; found--; }
   }
-  *nmatches = nm;
+  *nmatches = found;
   return 0;
 }
+
+// ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:956-1159) from the two window searches on: every valid keyframe-1 feature
+// looks for its map point in keyframe 2 (q12_*: projected position, radius th * scale[predicted level], predicted level;
+// descriptor = desc1 row, the caller passes the map point's representative descriptor there) and vice versa; best <=
+// TH_HIGH each way with the [pred - 1, pred] level gate, no `taken` state; a pair survives iff both directions agree
+// (:1145-1157).  match12[n1] = index in keyframe 2 or -1.
+int orbm_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
+                        const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred, const uint8_t* q12_valid,
+                        const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid, int32_t* match12,
+                        int* nfound) {
+  ORBHIP_REQUIRE(n1 >= 0 && n2 >= 0 && nfound && (n1 == 0 || match12), ORBHIP_EINVAL, "bad size");
+  *nfound = 0;
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  if (n1 == 0 || n2 == 0) return 0;
+  ORBHIP_REQUIRE(kps1 && kps2 && desc1 && desc2 && bounds && q12_uv && q12_radius && q12_pred && q21_uv && q21_radius && q21_pred, ORBHIP_EINVAL, "NULL argument");
+  std::vector<int32_t> m1(n1), m2(n2);
+  int k = 0;
+  const int TH_HIGH = 100;
+  if (int rc = orbm_search_by_projection(kps2, desc2, n2, bounds, q12_uv, q12_radius, nullptr, nullptr, q12_pred, desc1, q12_valid, nullptr, n1,
+                                         nullptr, 0.f, nullptr, 0, 1.f, TH_HIGH, 0, m1.data(), nullptr, &k)) return rc;
+  if (int rc = orbm_search_by_projection(kps1, desc1, n1, bounds, q21_uv, q21_radius, nullptr, nullptr, q21_pred, desc2, q21_valid, nullptr, n2,
+                                         nullptr, 0.f, nullptr, 0, 1.f, TH_HIGH, 0, m2.data(), nullptr, &k)) return rc;
+  int found = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    const int i2 = m1[i1];
+    if (i2 >= 0 && m2[i2] == i1) { match12[i1] = i2; found++; }
+  }
+  *nfound = found;
+  return 0;
+}
+
+}  // extern "C"
+
+// ---- the BoW family: queries = features of set 1 in (node, list) order of the merge-walk over the two feature vectors ----
+namespace {
+struct NodeQueries { std::vector<int> q_feature; std::vector<uint32_t> off{0}, idx; };
+// DBoW2::FeatureVector is a std::map: both inputs are ascending node ids; equal ids pair their lists (:170-176, :496-500)
+void pair_node_lists(const uint32_t* n1, const uint32_t* o1, const uint32_t* x1, int c1, const uint32_t* n2, const uint32_t* o2, const uint32_t* x2, int c2,
+                     const uint8_t* usable1, NodeQueries* Q) {
+  int a = 0, b = 0;
+  while (a < c1 && b < c2) {
+    if (n1[a] < n2[b]) { a++; continue; }
+    if (n2[b] < n1[a]) { b++; continue; }
+    for (uint32_t e1 = o1[a]; e1 < o1[a + 1]; e1++) {
+      const int f = (int)x1[e1];
+      if (usable1 && !usable1[f]) continue;
+      Q->q_feature.push_back(f);
+      Q->idx.insert(Q->idx.end(), x2 + o2[b], x2 + o2[b + 1]);
+      Q->off.push_back((uint32_t)Q->idx.size());
+    }
+    a++; b++;
+  }
+}
+std::vector<uint8_t> gather_descriptors(const uint8_t* desc, const std::vector<int>& rows) {
+  std::vector<uint8_t> out(rows.size() * 32);
+  for (size_t i = 0; i < rows.size(); i++) std::memcpy(&out[32 * i], desc + 32 * (size_t)rows[i], 32);
+  return out;
+}
+}  // namespace
+
+extern "C" {
 
 int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, const float* angle1, const uint8_t* desc2, int n2,
                        const uint8_t* valid2, const float* angle2, const uint32_t* fv1_node, const uint32_t* fv1_off,
@@ -488,55 +578,39 @@ int orbm_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, cons
   if (n1 == 0 || n2 == 0 || fv1_n == 0 || fv2_n == 0) return 0;
   ORBHIP_REQUIRE(desc1 && desc2 && fv1_node && fv1_off && fv1_idx && fv2_node && fv2_off && fv2_idx, ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE(!check_ori || (angle1 && angle2), ORBHIP_EINVAL, "rotation check needs angles");
-  // merge-walk of the two feature vectors (std::map order = ascending node id): queries in (node, list) order
-  std::vector<int> qidx;                       // query -> idx1
-  std::vector<uint32_t> off(1, 0), idx;
-  int a = 0, b = 0;
-  while (a < fv1_n && b < fv2_n) {
-    if (fv1_node[a] == fv2_node[b]) {
-      for (uint32_t e1 = fv1_off[a]; e1 < fv1_off[a + 1]; e1++) {
-        const int i1 = (int)fv1_idx[e1];
-        if (valid1 && !valid1[i1]) continue;
-        qidx.push_back(i1);
-        for (uint32_t e2 = fv2_off[b]; e2 < fv2_off[b + 1]; e2++) idx.push_back(fv2_idx[e2]);
-        off.push_back((uint32_t)idx.size());
-      }
-      a++; b++;
-    } else if (fv1_node[a] < fv2_node[b]) a++;
-    else b++;
-  }
-  const int nq = (int)qidx.size();
+  NodeQueries Q;
+  pair_node_lists(fv1_node, fv1_off, fv1_idx, fv1_n, fv2_node, fv2_off, fv2_idx, fv2_n, valid1, &Q);
+  const int nq = (int)Q.q_feature.size();
   if (nq == 0) return 0;
-  std::vector<uint8_t> qd((size_t)nq * 32);
-  for (int i = 0; i < nq; i++) std::memcpy(&qd[(size_t)32 * i], desc1 + (size_t)32 * qidx[i], 32);
-  std::vector<int> dist;
-  if (int rc = csr_distances_gpu(qd.data(), nq, desc2, n2, off, idx, dist)) return rc;
-  std::vector<uint8_t> matched2(n2, 0);
-  std::vector<int> bins(n1, -1);
-  int cnt[HISTO_LENGTH] = {0}, nm = 0;
-  for (int i = 0; i < nq; i++) {
-    const int i1 = qidx[i];
-    int bestDist1 = 256, bestDist2 = 256, bestIdx2 = -1;
-    for (uint32_t c = off[i]; c < off[i + 1]; c++) {
-      const int i2 = (int)idx[c];
-      if (matched2[i2] || (valid2 && !valid2[i2])) continue;
+  const std::vector<uint8_t> qd = gather_descriptors(desc1, Q.q_feature);
+  const int* dist = nullptr;
+  if (int rc = csr_distances(thread_ws(), qd.data(), nq, desc2, n2, Q.off, Q.idx, &dist)) return rc;
+  std::vector<uint8_t> used2(n2, 0);                            // vpMapPointMatches[realIdxF] / vbMatched2
+  std::vector<signed char> bin_of(n1, -1);
+  RotationFilter rot;
+  int found = 0;
+  for (int k = 0; k < nq; k++) {
+    const int f1 = Q.q_feature[k];
+    int d1 = 256, d2 = 256, f2 = -1;
+    for (uint32_t c = Q.off[k]; c < Q.off[k + 1]; c++) {
+      const int cand = (int)Q.idx[c];
+      if (used2[cand] || (valid2 && !valid2[cand])) continue;
       const int d = dist[c];
-      if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = i2; }
-      else if (d < bestDist2) { bestDist2 = d; }
+      if (d < d1) { d2 = d1; d1 = d; f2 = cand; }
+      else if (d < d2) d2 = d;
     }
-    const bool under = strict ? (bestDist1 < th) : (bestDist1 <= th);
-    if (under && static_cast<float>(bestDist1) < ratio * static_cast<float>(bestDist2)) {
-      match12[i1] = bestIdx2; matched2[bestIdx2] = 1; nm++;
-      if (check_ori) { bins[i1] = rot_bin_host(angle1[i1], angle2[bestIdx2]); cnt[bins[i1]]++; }
-    }
+    const bool close_enough = strict ? d1 < th : d1 <= th;     // (:535 '<' between keyframes, :210 '<=' keyframe-frame)
+    if (!close_enough || !(static_cast<float>(d1) < ratio * static_cast<float>(d2))) continue;
+    match12[f1] = f2; used2[f2] = 1; found++;
+    if (check_ori) { bin_of[f1] = (signed char)rotation_bin(angle1[f1], angle2[f2]); rot.add(bin_of[f1]); }
   }
   if (check_ori) {
-    int i1, i2, i3;
-    three_maxima_host(cnt, i1, i2, i3);
-    for (int i = 0; i < n1; i++)
-      if (match12[i] >= 0 && bins[i] != i1 && bins[i] != i2 && bins[i] != i3) { match12[i] = -1; nm--; }
+    bool keep[HISTO_LENGTH];
+    rot.kept(keep);
+    for (int f1 = 0; f1 < n1; f1++)
+      if (match12[f1] >= 0 && !keep[bin_of[f1]]) { match12[f1] = -1; found--; }
   }
-  *nmatches = nm;
+  *nmatches = found;
   return 0;
 }
 
@@ -551,68 +625,56 @@ int orbm_search_for_triangulation(const float* kps1, const uint8_t* desc1, const
   for (int i = 0; i < n1; i++) match12[i] = -1;
   if (n1 == 0 || n2 == 0 || fv1_n == 0 || fv2_n == 0) return 0;
   ORBHIP_REQUIRE(kps1 && kps2 && desc1 && desc2 && F12 && scale_factors && level_sigma2 && fv1_node && fv2_node, ORBHIP_EINVAL, "NULL argument");
-  std::vector<int> qidx;
-  std::vector<uint32_t> off(1, 0), idx;
-  int a = 0, b = 0;
-  while (a < fv1_n && b < fv2_n) {
-    if (fv1_node[a] == fv2_node[b]) {
-      for (uint32_t e1 = fv1_off[a]; e1 < fv1_off[a + 1]; e1++) {
-        const int i1 = (int)fv1_idx[e1];
-        if (unmapped1 && !unmapped1[i1]) continue;                  // already holds a MapPoint (:620-623)
-        qidx.push_back(i1);
-        for (uint32_t e2 = fv2_off[b]; e2 < fv2_off[b + 1]; e2++) idx.push_back(fv2_idx[e2]);
-        off.push_back((uint32_t)idx.size());
-      }
-      a++; b++;
-    } else if (fv1_node[a] < fv2_node[b]) a++;
-    else b++;
-  }
-  const int nq = (int)qidx.size();
+  NodeQueries Q;
+  pair_node_lists(fv1_node, fv1_off, fv1_idx, fv1_n, fv2_node, fv2_off, fv2_idx, fv2_n, unmapped1, &Q);     // features that already hold a MapPoint are skipped (:620-623)
+  const int nq = (int)Q.q_feature.size();
   if (nq == 0) return 0;
-  std::vector<uint8_t> qd((size_t)nq * 32);
-  for (int i = 0; i < nq; i++) std::memcpy(&qd[(size_t)32 * i], desc1 + (size_t)32 * qidx[i], 32);
-  std::vector<int> dist;
-  if (int rc = csr_distances_gpu(qd.data(), nq, desc2, n2, off, idx, dist)) return rc;
-  std::vector<int> bins(n1, -1);
-  int cnt[HISTO_LENGTH] = {0}, nm = 0;
-  for (int i = 0; i < nq; i++) {
-    const int i1 = qidx[i];
-    const float x1 = kps1[4 * i1], y1 = kps1[4 * i1 + 1];
-    // epipolar line in image 2: l = x1' F12 (CheckDistEpipolarLine, :128-149)
+  const std::vector<uint8_t> qd = gather_descriptors(desc1, Q.q_feature);
+  const int* dist = nullptr;
+  if (int rc = csr_distances(thread_ws(), qd.data(), nq, desc2, n2, Q.off, Q.idx, &dist)) return rc;
+  std::vector<signed char> bin_of(n1, -1);
+  RotationFilter rot;
+  int found = 0;
+  for (int k = 0; k < nq; k++) {
+    const int f1 = Q.q_feature[k];
+    const float x1 = kps1[4 * f1], y1 = kps1[4 * f1 + 1];
+    // CheckDistEpipolarLine (:128-149): l = x1' F12, double products narrowed to float
     const float la = x1 * F12[0] + y1 * F12[3] + F12[6];
     const float lb = x1 * F12[1] + y1 * F12[4] + F12[7];
     const float lc = x1 * F12[2] + y1 * F12[5] + F12[8];
-    int bestDist = TH_LOW, bestIdx2 = -1;
-    for (uint32_t c = off[i]; c < off[i + 1]; c++) {
-      const int i2 = (int)idx[c];
-      if (unmapped2 && !unmapped2[i2]) continue;                     // (vbMatched2 is never set in this fork)
+    const float den = la * la + lb * lb;
+    int limit = TH_LOW, f2 = -1;                                // a later candidate at the SAME distance replaces the earlier one (:654)
+    for (uint32_t c = Q.off[k]; c < Q.off[k + 1]; c++) {
+      const int cand = (int)Q.idx[c];
+      if (unmapped2 && !unmapped2[cand]) continue;               // (vbMatched2 is never set in this fork)
       const int d = dist[c];
-      if (d > TH_LOW || d > bestDist) continue;
-      const float x2 = kps2[4 * i2], y2 = kps2[4 * i2 + 1];
-      const int oct2 = (int)kps2[4 * i2 + 2];
-      const float distex = ex - x2, distey = ey - y2;
-      if (distex * distex + distey * distey < 100 * scale_factors[oct2]) continue;
-      const float num = la * x2 + lb * y2 + lc;
-      const float den = la * la + lb * lb;
+      if (d > TH_LOW || d > limit) continue;
+      const float x2 = kps2[4 * cand], y2 = kps2[4 * cand + 1];
+      const int oct2 = (int)kps2[4 * cand + 2];
+      const float dex = ex - x2, dey = ey - y2;
+      if (dex * dex + dey * dey < 100 * scale_factors[oct2]) continue;      // too close to the epipole (:658-664)
       if (den == 0) continue;
-      const float dsqr = num * num / den;
-      if (dsqr < 3.84 * level_sigma2[oct2]) { bestIdx2 = i2; bestDist = d; }
+      const float num = la * x2 + lb * y2 + lc;
+      if (num * num / den < 3.84 * level_sigma2[oct2]) { f2 = cand; limit = d; }
     }
-    if (bestIdx2 >= 0) {
-      match12[i1] = bestIdx2; nm++;
-      if (check_ori) { bins[i1] = rot_bin_host(kps1[4 * i1 + 3], kps2[4 * bestIdx2 + 3]); cnt[bins[i1]]++; }
-    }
+    if (f2 < 0) continue;
+    match12[f1] = f2; found++;
+    if (check_ori) { bin_of[f1] = (signed char)rotation_bin(kps1[4 * f1 + 3], kps2[4 * f2 + 3]); rot.add(bin_of[f1]); }
   }
   if (check_ori) {
-    int i1, i2, i3;
-    three_maxima_host(cnt, i1, i2, i3);
-    for (int i = 0; i < n1; i++)
-      if (match12[i] >= 0 && bins[i] != i1 && bins[i] != i2 && bins[i] != i3) { match12[i] = -1; nm--; }
+    bool keep[HISTO_LENGTH];
+    rot.kept(keep);
+    for (int f1 = 0; f1 < n1; f1++)
+      if (match12[f1] >= 0 && !keep[bin_of[f1]]) { match12[f1] = -1; found--; }
   }
-  *nmatches = nm;
+  *nmatches = found;
   return 0;
 }
 
+// SearchForInitialization: the window lists come from the same device grid as every other guided search (queries = the
+// level-0 features of frame 1 at their previously matched positions, window radius, level range [0, 0]); the host keeps the
+// pass whose outcome depends on the order of frame 1: a frame-2 feature remembers the distance it was won with, a later
+// query only takes it with a strictly smaller one and then displaces the earlier owner (:408, :421-427).
 int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int n1, const float* kps2,
                                    const uint8_t* desc2, int n2, const float* bounds2, float* prev_matched, int window,
                                    float nnratio, int check_ori, int32_t* matches12, int* nmatches) {
@@ -620,87 +682,43 @@ int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int 
   *nmatches = 0;
   if (n1 == 0) return 0;
   ORBHIP_REQUIRE(kps1 && desc1 && prev_matched && matches12 && bounds2 && (n2 == 0 || (kps2 && desc2)), ORBHIP_EINVAL, "NULL argument");
-  // ---- candidate generation on the host: Frame::GetFeaturesInArea (src/Frame.cc:243-307) ------
-  FrameGrid* G = new FrameGrid();
-  G->build(kps2, n2, bounds2);
-  std::vector<uint32_t> off(n1 + 1, 0), idx;
-  for (int i1 = 0; i1 < n1; i1++) {
-    off[i1] = (uint32_t)idx.size();
-    int level1 = (int)kps1[4 * i1 + 2];
-    if (level1 > 0) continue;                                    // (:383-385)
-    G->query(prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window, level1, level1, idx);
-  }
-  off[n1] = (uint32_t)idx.size();
-  delete G;
-  const uint32_t total = off[n1];
   for (int i = 0; i < n1; i++) matches12[i] = -1;
-  if (total == 0) return 0;
-  // ---- all candidate distances on the GPU -----------------------------------------------------
-  std::vector<int> dist(total);
-  {
-    if (int rcd = use_default_device()) return rcd;
-    DevBuf dq, dt, doff, didx, dd;
-    auto cleanup = [&]() { dq.release(); dt.release(); doff.release(); didx.release(); dd.release(); };
-    int rc = 0;
-    if ((rc = dq.ensure((size_t)n1 * 32)) || (rc = dt.ensure((size_t)n2 * 32)) || (rc = doff.ensure((size_t)(n1 + 1) * 4)) ||
-        (rc = didx.ensure((size_t)total * 4)) || (rc = dd.ensure((size_t)total * 4))) { cleanup(); return rc; }
-    MCHK(hipMemcpy(dq.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    MCHK(hipMemcpy(dt.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
-    MCHK(hipMemcpy(doff.p, off.data(), (size_t)(n1 + 1) * 4, hipMemcpyHostToDevice));
-    MCHK(hipMemcpy(didx.p, idx.data(), (size_t)total * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_dist_csr, dim3((total + 255) / 256), dim3(256), 0, 0, dq.as<uint8_t>(), n1, dt.as<uint8_t>(),
-                       doff.as<uint32_t>(), didx.as<uint32_t>(), total, dd.as<int>());
-    MCHK(hipGetLastError());
-    MCHK(hipMemcpy(dist.data(), dd.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-    cleanup();
-  }
-  // ---- order-dependent greedy pass in reference loop order (src/ORBmatcher.cc:379-441) -----------
-  int nm = 0;
-  std::vector<int> rotHist[HISTO_LENGTH];
-  std::vector<int> matchedDist(n2, INT_MAX), matches21(n2, -1);
-  const float factor = 1.0f / HISTO_LENGTH;
+  if (n2 == 0) return 0;
+  std::vector<float> radius(n1, (float)window);
+  std::vector<int32_t> level(n1);
+  std::vector<uint8_t> level0(n1);
+  for (int i = 0; i < n1; i++) { level[i] = (int32_t)kps1[4 * i + 2]; level0[i] = level[i] > 0 ? 0 : 1; }      // (:383-385)
+  WindowLists L;
+  if (int rc = window_lists(thread_ws(), kps2, desc2, n2, bounds2, prev_matched, radius.data(), level.data(), level.data(), level0.data(), desc1, n1, &L)) return rc;
+  std::vector<int> owner(n2, -1), won_with(n2, INT_MAX);
+  std::vector<signed char> bin_of(n1, -1);
+  int found = 0;
   for (int i1 = 0; i1 < n1; i1++) {
-    if (off[i1] == off[i1 + 1]) continue;
-    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
-    for (uint32_t c = off[i1]; c < off[i1 + 1]; c++) {
-      const int i2 = (int)idx[c], d = dist[c];
-      if (matchedDist[i2] <= d) continue;                        // (:408)
-      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
-      else if (d < bestDist2) { bestDist2 = d; }
+    int d1 = INT_MAX, d2 = INT_MAX, f2 = -1;
+    for (uint32_t c = L.off[i1]; c < L.off[i1 + 1]; c++) {
+      const int cand = (int)L.cand[c].idx, d = L.cand[c].dist;
+      if (won_with[cand] <= d) continue;
+      if (d < d1) { d2 = d1; d1 = d; f2 = cand; }
+      else if (d < d2) d2 = d;
     }
-    if (bestDist <= TH_LOW) {
-      if (bestDist < (float)bestDist2 * nnratio) {
-        if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nm--; }   // (:421-424)
-        matches12[i1] = bestIdx2; matches21[bestIdx2] = i1; matchedDist[bestIdx2] = bestDist;
-        nm++;
-        if (check_ori) {
-          float rot = kps1[4 * i1 + 3] - kps2[4 * bestIdx2 + 3];
-          if (rot < 0.0) rot += 360.0f;
-          int bin = (int)std::round(rot * factor);
-          if (bin == HISTO_LENGTH) bin = 0;
-          rotHist[bin].push_back(i1);
-        }
-      }
-    }
+    if (f2 < 0 || d1 > TH_LOW || !(d1 < (float)d2 * nnratio)) continue;
+    if (owner[f2] >= 0) { matches12[owner[f2]] = -1; found--; }
+    matches12[i1] = f2; owner[f2] = i1; won_with[f2] = d1; found++;
+    if (check_ori) bin_of[i1] = (signed char)rotation_bin(kps1[4 * i1 + 3], kps2[4 * f2 + 3]);
   }
   if (check_ori) {
-    int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
-    for (int b = 0; b < HISTO_LENGTH; b++) {
-      const int s = (int)rotHist[b].size();
-      if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = b; }
-      else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = b; }
-      else if (s > max3) { max3 = s; i3 = b; }
-    }
-    if (max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
-    else if (max3 < 0.1f * (float)max1) { i3 = -1; }
-    for (int b = 0; b < HISTO_LENGTH; b++) {
-      if (b == i1 || b == i2 || b == i3) continue;
-      for (int idx1 : rotHist[b]) if (matches12[idx1] >= 0) { matches12[idx1] = -1; nm--; }
-    }
+    // the reference's histogram holds EVERY accepted i1, displaced ones included (they stay in rotHist, :433-437): the
+    // populations below count them, the removal only touches matches that still exist
+    RotationFilter rot;
+    for (int i1 = 0; i1 < n1; i1++) if (bin_of[i1] >= 0) rot.add(bin_of[i1]);
+    bool keep[HISTO_LENGTH];
+    rot.kept(keep);
+    for (int i1 = 0; i1 < n1; i1++)
+      if (bin_of[i1] >= 0 && !keep[bin_of[i1]] && matches12[i1] >= 0) { matches12[i1] = -1; found--; }
   }
   for (int i1 = 0; i1 < n1; i1++)
     if (matches12[i1] >= 0) { prev_matched[2 * i1] = kps2[4 * matches12[i1]]; prev_matched[2 * i1 + 1] = kps2[4 * matches12[i1] + 1]; }
-  *nmatches = nm;
+  *nmatches = found;
   return 0;
 }
 

@@ -139,8 +139,8 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:363-468) on flattened frames (host pointers).
  * kps = n x 4 floats (x, y, octave, angle) of the undistorted keypoints; bounds2 = {min_x,max_x,min_y,max_y}
  * of frame 2 (Frame::ComputeImageBounds); prev_matched (n1 x 2) is updated in place; matches12[n1].
- * Distances are computed on the GPU (candidate-list kernel); the order-dependent greedy pass
- * (":408", ":421-427") runs on the host in reference loop order.  Returns the match count in *nmatches. */
+ * The frame grid, the window lists and every candidate distance are computed on the GPU; the order-dependent pass
+ * (":408", ":421-427") runs on the host in frame-1 order.  Returns the match count in *nmatches. */
 int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int n1, const float* kps2,
                                    const uint8_t* desc2, int n2, const float* bounds2, float* prev_matched,
                                    int window, float nnratio, int check_ori, int32_t* matches12, int* nmatches);
@@ -166,6 +166,18 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
                               const float* q_angle, int nq, const float* inv_level_sigma2, float chi2_gate,
                               uint8_t* taken, int mode_best2, float ratio, int th, int check_ori, int32_t* q_match,
                               int32_t* q_best_dist, int* nmatches);
+
+/* ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:956-1159) on flattened data (host pointers), whole entry point from the two
+ * window searches on.  The caller keeps the reference's geometry (transform with sR21 / sR12, depth / image / distance gates,
+ * PredictScale) and passes, per feature of keyframe 1 that holds a usable, not yet matched map point (q12_valid), its
+ * projection into keyframe 2, the radius th * scale_factors_[predicted level] and the predicted level - and the same for
+ * keyframe 2 into keyframe 1 (q21_*).  desc1 / desc2 rows = the map point's descriptor for that feature.  Each direction takes
+ * the best candidate of KeyFrame::GetFeaturesInArea with level in [pred - 1, pred] and distance <= TH_HIGH; a pair is kept iff
+ * the two directions agree (:1145-1157).  match12[n1] = index in keyframe 2 or -1; *nfound = the return value.            */
+int orbm_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
+                        const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred,
+                        const uint8_t* q12_valid, const float* q21_uv, const float* q21_radius, const int32_t* q21_pred,
+                        const uint8_t* q21_valid, int32_t* match12, int* nfound);
 
 /* SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:151-256; strict = 0) and SearchByBoW(KeyFrame*,
  * KeyFrame*, ...) (:470-580; strict = 1: best < th) on flattened data (host pointers).  The DBoW2 feature

@@ -370,6 +370,7 @@ int lm_solve(Problem& P, double* poses, double* pts, Summary* sum) {
     std::vector<size_t> pt_base(P.nfp + 1, 0);
     for (int p = 0; p < P.nfp; p++) pt_base[p + 1] = pt_base[p] + by_pt[p].size();
     std::vector<double> E(18 * pt_base[P.nfp], 0.0), EC(18 * pt_base[P.nfp], 0.0);
+    std::vector<int> ca_flat(pt_base[P.nfp], -1);            // reduced camera column of every observation, point-major
     if (ok) parallel_for(P.nfp, [&](int plo, int phi, int) {
       for (int p = plo; p < phi; p++) {
         const double* Ci = &Cinv[9 * (size_t)p];
@@ -378,6 +379,7 @@ int lm_solve(Problem& P, double* poses, double* pts, Summary* sum) {
         for (size_t a = 0; a < L.size(); a++) {
           int i = L[a];
           int cc = P.cam_col[P.obs_cam[i]];
+          ca_flat[pt_base[p] + a] = cc;
           if (cc < 0) continue;
           const double* jc = &Jc[12 * (size_t)i]; const double* jp = &Jp[6 * (size_t)i];
           for (int u = 0; u < 6; u++) for (int v = 0; v < 3; v++) Ep[18 * a + 3 * u + v] = jc[u] * jp[v] + jc[6 + u] * jp[3 + v];
@@ -389,24 +391,27 @@ int lm_solve(Problem& P, double* poses, double* pts, Summary* sum) {
         }
       }
     });
-    // S -= sum_p E Cinv E^T, rhs -= sum_p E Cinv g_p: a thread owns the camera rows ca with ca % T == tid and walks the
-    // points in ascending order, so every entry is summed in the single-thread order
+    // S -= sum_p E Cinv E^T, rhs -= sum_p E Cinv g_p: a thread owns a contiguous range of camera rows (tracks are runs of
+    // consecutive keyframes, so it mostly meets its own points) and walks the points in ascending order: every entry is
+    // summed in the single-thread order
     const int T = std::max(1, g_ba_threads);
     auto schur_rows = [&](int tid) {
+      const int nfc1 = std::max(P.nfc, 1);
       for (int p = 0; p < P.nfp; p++) {
-        const std::vector<int>& L = by_pt[p];
-        const double* Ep = &E[18 * pt_base[p]]; const double* ECp = &EC[18 * pt_base[p]];
+        const size_t base = pt_base[p], len = pt_base[p + 1] - base;
+        const int* cap = &ca_flat[base];
+        const double* Ep = &E[18 * base]; const double* ECp = &EC[18 * base];
         const double* gp = &gs[nc6 + 3 * p];
-        for (size_t a = 0; a < L.size(); a++) {
-          int ca = P.cam_col[P.obs_cam[L[a]]];
-          if (ca < 0 || ca % T != tid) continue;
+        for (size_t a = 0; a < len; a++) {
+          const int ca = cap[a];
+          if (ca < 0 || (int)((int64_t)ca * T / nfc1) != tid) continue;
           for (int u = 0; u < 6; u++) {
             double acc = 0;
             for (int k = 0; k < 3; k++) acc += ECp[18 * a + 3 * u + k] * gp[k];
             rhs[6 * ca + u] -= acc;
           }
-          for (size_t b = 0; b < L.size(); b++) {
-            int cb = P.cam_col[P.obs_cam[L[b]]];
+          for (size_t b = 0; b < len; b++) {
+            const int cb = cap[b];
             if (cb < 0) continue;
             for (int u = 0; u < 6; u++) for (int v = 0; v < 6; v++) {
               double acc = 0;

@@ -283,6 +283,62 @@ int orc_search_by_projection(const float* kps4, const uint8_t* desc, int n, cons
   return nmatches;
 }
 
+// SearchBySim3 (src/ORBmatcher.cc:956-1159) on flattened data, from the two GetFeaturesInArea calls on.  The geometry in front
+// of them (sR21 / sR12 transforms, depth, IsInImage, distance-invariance gates, PredictScale) stays with the caller, which
+// passes per feature: q_valid (the feature holds a usable, not already matched map point and passed the gates), the projected
+// position, radius = th * scale_factors_[nPredictedLevel] and nPredictedLevel.  desc1 / desc2 rows = pMP->GetDescriptor().
+int orc_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
+                       const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred, const uint8_t* q12_valid,
+                       const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid, int32_t* match12) {
+  const int TH_HIGH = 100;
+  Grid* G1 = new Grid(); Grid* G2 = new Grid();
+  G1->build(kps1, n1, bounds[0], bounds[1], bounds[2], bounds[3]);
+  G2->build(kps2, n2, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<int> vnMatch1(n1, -1), vnMatch2(n2, -1), vIndices;
+  // Transform from KF1 to KF2 and search (:995-1064)
+  for (int i1 = 0; i1 < n1; i1++) {
+    if (q12_valid && !q12_valid[i1]) continue;
+    const int nPredictedLevel = q12_pred[i1];
+    G2->features_in_area(q12_uv[2 * i1], q12_uv[2 * i1 + 1], q12_radius[i1], -1, -1, vIndices);       // KeyFrame::GetFeaturesInArea
+    if (vIndices.empty()) continue;
+    int bestDist = INT_MAX, bestIdx = -1;
+    for (int idx : vIndices) {
+      const int octave = (int)kps2[4 * idx + 2];
+      if (octave < nPredictedLevel - 1 || octave > nPredictedLevel) continue;
+      const int dist = descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= TH_HIGH) vnMatch1[i1] = bestIdx;
+  }
+  // Transform from KF2 to KF1 and search (:1066-1140)
+  for (int i2 = 0; i2 < n2; i2++) {
+    if (q21_valid && !q21_valid[i2]) continue;
+    const int nPredictedLevel = q21_pred[i2];
+    G1->features_in_area(q21_uv[2 * i2], q21_uv[2 * i2 + 1], q21_radius[i2], -1, -1, vIndices);
+    if (vIndices.empty()) continue;
+    int bestDist = INT_MAX, bestIdx = -1;
+    for (int idx : vIndices) {
+      const int octave = (int)kps1[4 * idx + 2];
+      if (octave < nPredictedLevel - 1 || octave > nPredictedLevel) continue;
+      const int dist = descriptor_distance(desc2 + 32 * (size_t)i2, desc1 + 32 * (size_t)idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= TH_HIGH) vnMatch2[i2] = bestIdx;
+  }
+  // Check agreement (:1142-1157)
+  int nFound = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    match12[i1] = -1;
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0) {
+      const int idx1 = vnMatch2[idx2];
+      if (idx1 == i1) { match12[i1] = idx2; nFound++; }
+    }
+  }
+  delete G1; delete G2;
+  return nFound;
+}
+
 // SearchByBoW (src/ORBmatcher.cc:151-256 with strict = 0, :470-580 with strict = 1) on flattened data.
 int orc_search_by_bow(const uint8_t* desc1, int n1, const uint8_t* valid1, const float* angle1, const uint8_t* desc2, int n2,
                       const uint8_t* valid2, const float* angle2, const uint32_t* fv1_node, const uint32_t* fv1_off,

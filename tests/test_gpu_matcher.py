@@ -173,6 +173,19 @@ def test_search_by_projection_families_vs_oracle(oracle, case):
     assert len(set(m[hit].tolist())) == hit.sum() or case == "fuse_chi2"      # one map point per keypoint when `taken` is tracked
 
 
+def test_search_by_sim3_vs_oracle(oracle):
+    """M11: ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:956-1159) end to end: both window searches on the device grid, the
+    mutual-agreement pass (:1145-1157) on the host; same generator as the CPU test against the numpy restatement."""
+    from tests.test_oracle_matcher_npref import sim3_queries, BOUNDS
+    fr = _two_frames(oracle)
+    K1, D1, K2, D2, shift, E = fr
+    for seed in (9, 10):
+        q = sim3_queries(fr, seed)
+        n, m = _m().SearchBySim3(K1, D1, K2, D2, BOUNDS, *q)
+        on, om = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q)
+        assert n == on and np.array_equal(m, om) and n > 50
+
+
 def _fake_feature_vector(rng, n, nnodes=40):
     node_of = rng.integers(0, nnodes, n)
     nodes = np.unique(node_of)
