@@ -1,0 +1,792 @@
+// ============================================================================
+// orbslam_dropin.h -- ORB_SLAM2::ORBmatcher and ORB_SLAM2::CeresOptimizer with the REFERENCE's member-function
+// signatures (reference include/ORBmatcher.h:36-97, include/CeresOptimizer.h:351-376), implemented over the C ABI of
+// include/orbslam_hip.h.  The call sites in Tracking / LocalMapping / LoopClosing compile unchanged:
+//
+//     ORBmatcher matcher(0.9, true);
+//     int nmatches = matcher.SearchByProjection(current_frame_, last_frame_, th);       // src/Tracking.cc:632
+//     CeresOptimizer::PoseOptimization(&current_frame_);                                // src/Tracking.cc:646
+//     CeresOptimizer::LocalBundleAdjustment(current_keyframe_, &is_abort_BA_, map_);    // src/LocalMapping.cc:89
+//
+// The classes are templates over a `Types` bundle naming the reference's own data model (Frame, KeyFrame, MapPoint, Map,
+// the Eigen fixed-size types, cv::Mat / cv::KeyPoint / cv::Point2f).  Inside the reference tree
+//     #define ORBSLAM_DROPIN_REFERENCE_TYPES       (before including this header; needs Frame.h, KeyFrame.h, MapPoint.h, Map.h)
+// instantiates them as ORB_SLAM2::ORBmatcher / ORB_SLAM2::CeresOptimizer; tests/cpp/ instantiates them over mock structs
+// that copy the member names of include/Frame.h, KeyFrame.h, MapPoint.h, Map.h.
+//
+// What runs where: every method walks the pointer graph exactly as the reference does (which map points, validity tests,
+// projection geometry with the reference's float / double mix, the mutations Replace / AddObservation / SetPose /
+// EraseObservation under the reference's lock scopes) and hands the data-parallel part - frame grid, window candidates,
+// Hamming distances; residuals, Jacobians, Schur complement, MFMA Cholesky - to the HIP library in ONE call per method.
+// Only element access is used on the math types (M(i, j), v[i]); nothing here needs Eigen to compile.
+// ============================================================================
+#pragma once
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../../include/orbslam_hip.h"
+
+namespace ORB_SLAM2 {
+namespace dropin {
+
+inline void check(int rc, const char* what) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + orbhip_last_error());
+}
+
+struct P3 { double x, y, z; };
+template <class V> inline P3 p3(const V& v) { return {v[0], v[1], v[2]}; }
+// R (3x3 block of any matrix type, row r0 / col c0) * p + t, plain left-to-right double arithmetic
+template <class M> inline P3 rot(const M& R, const P3& p) {
+  return {R(0, 0) * p.x + R(0, 1) * p.y + R(0, 2) * p.z, R(1, 0) * p.x + R(1, 1) * p.y + R(1, 2) * p.z, R(2, 0) * p.x + R(2, 1) * p.y + R(2, 2) * p.z};
+}
+inline P3 add(const P3& a, const P3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline P3 sub(const P3& a, const P3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline double dot(const P3& a, const P3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline double norm(const P3& a) { return std::sqrt(dot(a, a)); }
+struct R33 { double m[3][3]; double operator()(int r, int c) const { return m[r][c]; } };
+template <class M> inline R33 block33(const M& T) { R33 R; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R.m[r][c] = T(r, c); return R; }
+template <class M> inline P3 col3(const M& T) { return {T(0, 3), T(1, 3), T(2, 3)}; }
+inline P3 rot_t(const R33& R, const P3& p) {   // R^T p
+  return {R.m[0][0] * p.x + R.m[1][0] * p.y + R.m[2][0] * p.z, R.m[0][1] * p.x + R.m[1][1] * p.y + R.m[2][1] * p.z, R.m[0][2] * p.x + R.m[1][2] * p.y + R.m[2][2] * p.z};
+}
+
+// flattened view of one frame / keyframe: what the C ABI takes
+struct Flat {
+  std::vector<float> kps4; const uint8_t* desc = nullptr; int n = 0; float bounds[4] = {0, 0, 0, 0};
+  std::vector<uint8_t> desc_store;
+};
+template <class F> inline void flatten(const F& f, Flat* o) {          // Frame& or KeyFrame&
+  o->n = (int)f.undistort_keypoints_.size();
+  o->kps4.resize(4 * (size_t)o->n);
+  for (int i = 0; i < o->n; i++) {
+    const auto& kp = f.undistort_keypoints_[i];
+    o->kps4[4 * i] = kp.pt.x; o->kps4[4 * i + 1] = kp.pt.y; o->kps4[4 * i + 2] = (float)kp.octave; o->kps4[4 * i + 3] = kp.angle;
+  }
+  o->desc_store.resize(32 * (size_t)o->n);                               // (cv::Mat rows may be padded: copy row by row)
+  for (int i = 0; i < o->n; i++) std::memcpy(&o->desc_store[32 * (size_t)i], f.descriptors_.ptr(i), 32);
+  o->desc = o->desc_store.data();
+  o->bounds[0] = (float)f.min_x_; o->bounds[1] = (float)f.max_x_; o->bounds[2] = (float)f.min_y_; o->bounds[3] = (float)f.max_y_;
+}
+// DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) -> ascending node ids + CSR lists
+struct FlatFV { std::vector<uint32_t> node, off{0}, idx; };
+template <class FV> inline void flatten_fv(const FV& fv, FlatFV* o) {
+  for (auto it = fv.begin(); it != fv.end(); ++it) {
+    o->node.push_back((uint32_t)it->first);
+    for (auto v : it->second) o->idx.push_back((uint32_t)v);
+    o->off.push_back((uint32_t)o->idx.size());
+  }
+}
+// per-query arrays of the projection engine
+struct Queries {
+  std::vector<float> uv, radius, angle; std::vector<int32_t> lo, hi, pred; std::vector<uint8_t> valid, desc;
+  explicit Queries(size_t n) : uv(2 * n, 0.f), radius(n, 0.f), angle(n, 0.f), lo(n, -1), hi(n, -1), pred(n, -1), valid(n, 0), desc(32 * n, 0) {}
+  template <class MatT> void set_desc(size_t q, const MatT& d) { std::memcpy(&desc[32 * q], d.ptr(0), 32); }
+};
+
+}  // namespace dropin
+
+// ============================================================================================== ORBmatcher
+template <class Types>
+class ORBmatcherT {
+ public:
+  typedef typename Types::Frame Frame;
+  typedef typename Types::KeyFrame KeyFrame;
+  typedef typename Types::MapPoint MapPoint;
+  typedef typename Types::Matrix3d Matrix3d;
+  typedef typename Types::Matrix4d Matrix4d;
+  typedef typename Types::Vector3d Vector3d;
+  typedef typename Types::Mat Mat;
+  typedef typename Types::Point2f Point2f;
+
+  static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;        // src/ORBmatcher.cc:35-37
+
+  ORBmatcherT(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+  // src/ORBmatcher.cc:1422-1437
+  static int DescriptorDistance(const Mat& a, const Mat& b) { return orbm_descriptor_distance(a.ptr(0), b.ptr(0)); }
+
+  // ---- Tracking::SearchLocalPoints (src/Tracking.cc:834), src/ORBmatcher.cc:42-119 -------------------------------------
+  int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3) {
+    using namespace dropin;
+    const bool bFactor = th != 1.0;
+    const size_t nq = vpMapPoints.size();
+    Queries Q(nq);
+    for (size_t iMP = 0; iMP < nq; iMP++) {
+      MapPoint* pMP = vpMapPoints[iMP];
+      if (!pMP->is_track_in_view_) continue;
+      if (pMP->isBad()) continue;
+      const int nPredictedLevel = pMP->track_scale_level_;
+      float r = RadiusByViewingCos(pMP->track_view_cos_);
+      if (bFactor) r *= th;
+      Q.valid[iMP] = 1;
+      Q.uv[2 * iMP] = pMP->track_proj_x_; Q.uv[2 * iMP + 1] = pMP->track_proj_y_;
+      Q.radius[iMP] = r * F.scale_factors_[nPredictedLevel];
+      Q.lo[iMP] = nPredictedLevel - 1; Q.hi[iMP] = nPredictedLevel;
+      Q.set_desc(iMP, pMP->GetDescriptor());
+    }
+    Flat T; flatten(F, &T);
+    std::vector<uint8_t> taken(T.n, 0);                       // F.map_points_[idx] holds a point with observations (":83-84")
+    for (int i = 0; i < T.n; i++) taken[i] = (F.map_points_[i] && F.map_points_[i]->Observations() > 0) ? 1 : 0;
+    std::vector<int32_t> match(nq ? nq : 1, -1);
+    int nmatches = 0;
+    check(orbm_search_by_projection(T.kps4.data(), T.desc, T.n, T.bounds, Q.uv.data(), Q.radius.data(), Q.lo.data(), Q.hi.data(), nullptr, Q.desc.data(),
+                                    Q.valid.data(), nullptr, (int)nq, nullptr, 0.f, taken.data(), 1, mfNNratio, TH_HIGH, 0, match.data(), nullptr, &nmatches),
+          "orbm_search_by_projection");
+    for (size_t iMP = 0; iMP < nq; iMP++) if (match[iMP] >= 0) F.map_points_[match[iMP]] = vpMapPoints[iMP];
+    return nmatches;
+  }
+
+  // ---- Tracking::TrackWithMotionModel (src/Tracking.cc:632,638), src/ORBmatcher.cc:1161-1271 ---------------------------
+  int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th) {
+    using namespace dropin;
+    const R33 Rcw = block33(CurrentFrame.Tcw_); const P3 tcw = col3(CurrentFrame.Tcw_);
+    const size_t nq = (size_t)LastFrame.N_;
+    Queries Q(nq);
+    for (size_t i = 0; i < nq; i++) {
+      MapPoint* map_point = LastFrame.map_points_[i];
+      if (!map_point || LastFrame.is_outliers_[i]) continue;
+      const P3 x3Dc = add(rot(Rcw, p3(map_point->GetWorldPos())), tcw);
+      const float xc = x3Dc.x, yc = x3Dc.y;
+      const float invzc = 1.0 / x3Dc.z;
+      if (invzc < 0) continue;
+      const float u = CurrentFrame.fx_ * xc * invzc + CurrentFrame.cx_;
+      const float v = CurrentFrame.fy_ * yc * invzc + CurrentFrame.cy_;
+      if (u < CurrentFrame.min_x_ || u > CurrentFrame.max_x_) continue;
+      if (v < CurrentFrame.min_y_ || v > CurrentFrame.max_y_) continue;
+      const int nLastOctave = LastFrame.keypoints_[i].octave;
+      Q.valid[i] = 1; Q.uv[2 * i] = u; Q.uv[2 * i + 1] = v;
+      Q.radius[i] = th * CurrentFrame.scale_factors_[nLastOctave];
+      Q.lo[i] = nLastOctave - 1; Q.hi[i] = nLastOctave + 1;
+      Q.angle[i] = LastFrame.undistort_keypoints_[i].angle;
+      Q.set_desc(i, map_point->GetDescriptor());
+    }
+    Flat T; flatten(CurrentFrame, &T);
+    std::vector<uint8_t> taken(T.n, 0);
+    for (int i = 0; i < T.n; i++) taken[i] = (CurrentFrame.map_points_[i] && CurrentFrame.map_points_[i]->Observations() > 0) ? 1 : 0;
+    std::vector<int32_t> match(nq ? nq : 1, -1);
+    int nmatches = 0;
+    check(orbm_search_by_projection(T.kps4.data(), T.desc, T.n, T.bounds, Q.uv.data(), Q.radius.data(), Q.lo.data(), Q.hi.data(), nullptr, Q.desc.data(),
+                                    Q.valid.data(), Q.angle.data(), (int)nq, nullptr, 0.f, taken.data(), 0, mfNNratio, TH_HIGH, mbCheckOrientation ? 1 : 0,
+                                    match.data(), nullptr, &nmatches), "orbm_search_by_projection");
+    // (a match the rotation histogram rejects was assigned and reset to nullptr by the reference: net effect none)
+    for (size_t i = 0; i < nq; i++) if (match[i] >= 0) CurrentFrame.map_points_[match[i]] = LastFrame.map_points_[i];
+    return nmatches;
+  }
+
+  // ---- Tracking::Relocalization (src/Tracking.cc:1085,1101), src/ORBmatcher.cc:1273-1384 -------------------------------
+  int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) {
+    using namespace dropin;
+    const R33 Rcw = block33(CurrentFrame.Tcw_); const P3 tcw = col3(CurrentFrame.Tcw_);
+    const P3 Rt = rot_t(Rcw, tcw); const P3 Ow = {-Rt.x, -Rt.y, -Rt.z};
+    const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+    const size_t nq = vpMPs.size();
+    Queries Q(nq);
+    for (size_t i = 0; i < nq; i++) {
+      MapPoint* pMP = vpMPs[i];
+      if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+      const P3 x3Dw = p3(pMP->GetWorldPos());
+      const P3 x3Dc = add(rot(Rcw, x3Dw), tcw);
+      const float xc = x3Dc.x, yc = x3Dc.y;
+      const float invzc = 1.0 / x3Dc.z;
+      const float u = CurrentFrame.fx_ * xc * invzc + CurrentFrame.cx_;
+      const float v = CurrentFrame.fy_ * yc * invzc + CurrentFrame.cy_;
+      if (u < CurrentFrame.min_x_ || u > CurrentFrame.max_x_) continue;
+      if (v < CurrentFrame.min_y_ || v > CurrentFrame.max_y_) continue;
+      float dist3D = norm(sub(x3Dw, Ow));
+      const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+      if (dist3D < minDistance || dist3D > maxDistance) continue;
+      const int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+      Q.valid[i] = 1; Q.uv[2 * i] = u; Q.uv[2 * i + 1] = v;
+      Q.radius[i] = th * CurrentFrame.scale_factors_[nPredictedLevel];
+      Q.lo[i] = nPredictedLevel - 1; Q.hi[i] = nPredictedLevel + 1;
+      Q.angle[i] = pKF->undistort_keypoints_[i].angle;
+      Q.set_desc(i, pMP->GetDescriptor());
+    }
+    Flat T; flatten(CurrentFrame, &T);
+    std::vector<uint8_t> taken(T.n, 0);
+    for (int i = 0; i < T.n; i++) taken[i] = CurrentFrame.map_points_[i] ? 1 : 0;          // (":1336": any map point closes the feature)
+    std::vector<int32_t> match(nq ? nq : 1, -1);
+    int nmatches = 0;
+    check(orbm_search_by_projection(T.kps4.data(), T.desc, T.n, T.bounds, Q.uv.data(), Q.radius.data(), Q.lo.data(), Q.hi.data(), nullptr, Q.desc.data(),
+                                    Q.valid.data(), Q.angle.data(), (int)nq, nullptr, 0.f, taken.data(), 0, mfNNratio, ORBdist, mbCheckOrientation ? 1 : 0,
+                                    match.data(), nullptr, &nmatches), "orbm_search_by_projection");
+    for (size_t i = 0; i < nq; i++) if (match[i] >= 0) CurrentFrame.map_points_[match[i]] = vpMPs[i];
+    return nmatches;
+  }
+
+  // ---- LoopClosing::ComputeSim3 (src/LoopClosing.cc:374), src/ORBmatcher.cc:258-361 ------------------------------------
+  int SearchByProjection(KeyFrame* pKF, const Matrix4d& Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th) {
+    using namespace dropin;
+    Sim3Cam C = decompose(Scw);
+    std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint*>(nullptr));
+    const size_t nq = vpPoints.size();
+    Queries Q(nq);
+    for (size_t iMP = 0; iMP < nq; iMP++) {
+      MapPoint* pMP = vpPoints[iMP];
+      if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+      float u, v, dist; int level;
+      if (!project_with_gates(pKF, C, pMP, 0.0, true, &u, &v, &dist, &level)) continue;
+      Q.valid[iMP] = 1; Q.uv[2 * iMP] = u; Q.uv[2 * iMP + 1] = v;
+      Q.radius[iMP] = th * pKF->scale_factors_[level];
+      Q.pred[iMP] = level;
+      Q.set_desc(iMP, pMP->GetDescriptor());
+    }
+    Flat T; flatten(*pKF, &T);
+    std::vector<uint8_t> taken(T.n, 0);
+    for (int i = 0; i < T.n && i < (int)vpMatched.size(); i++) taken[i] = vpMatched[i] ? 1 : 0;
+    std::vector<int32_t> match(nq ? nq : 1, -1);
+    int nmatches = 0;
+    check(orbm_search_by_projection(T.kps4.data(), T.desc, T.n, T.bounds, Q.uv.data(), Q.radius.data(), nullptr, nullptr, Q.pred.data(), Q.desc.data(),
+                                    Q.valid.data(), nullptr, (int)nq, nullptr, 0.f, taken.data(), 0, mfNNratio, TH_LOW, 0, match.data(), nullptr, &nmatches),
+          "orbm_search_by_projection");
+    for (size_t iMP = 0; iMP < nq; iMP++) if (match[iMP] >= 0) vpMatched[match[iMP]] = vpPoints[iMP];
+    return nmatches;
+  }
+
+  // ---- Tracking::TrackReferenceKeyFrame / Relocalization (src/Tracking.cc:576,1019), src/ORBmatcher.cc:151-256 ----------
+  int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+    using namespace dropin;
+    const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPoint*>(F.N_, static_cast<MapPoint*>(nullptr));
+    Flat A, B; flatten(*pKF, &A); flatten(F, &B);
+    std::vector<uint8_t> valid1(A.n, 0);
+    std::vector<float> a1(A.n), a2(B.n);
+    for (int i = 0; i < A.n; i++) { MapPoint* p = i < (int)vpMapPointsKF.size() ? vpMapPointsKF[i] : nullptr; valid1[i] = (p && !p->isBad()) ? 1 : 0; a1[i] = pKF->undistort_keypoints_[i].angle; }
+    for (int i = 0; i < B.n; i++) a2[i] = F.keypoints_[i].angle;                         // (":221": the frame's raw keypoint angle)
+    FlatFV f1, f2; flatten_fv(pKF->feature_vector_, &f1); flatten_fv(F.feature_vector_, &f2);
+    std::vector<int32_t> m12(A.n ? A.n : 1, -1);
+    int nmatches = 0;
+    check(orbm_search_by_bow(A.desc, A.n, valid1.data(), a1.data(), B.desc, B.n, nullptr, a2.data(), f1.node.data(), f1.off.data(), f1.idx.data(), (int)f1.node.size(),
+                             f2.node.data(), f2.off.data(), f2.idx.data(), (int)f2.node.size(), mfNNratio, TH_LOW, 0, mbCheckOrientation ? 1 : 0, m12.data(), &nmatches),
+          "orbm_search_by_bow");
+    for (int i = 0; i < A.n; i++) if (m12[i] >= 0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
+    return nmatches;
+  }
+
+  // ---- LoopClosing::ComputeSim3 (src/LoopClosing.cc:262), src/ORBmatcher.cc:470-580 ------------------------------------
+  int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
+    using namespace dropin;
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(nullptr));
+    Flat A, B; flatten(*pKF1, &A); flatten(*pKF2, &B);
+    std::vector<uint8_t> valid1(A.n, 0), valid2(B.n, 0);
+    std::vector<float> a1(A.n), a2(B.n);
+    for (int i = 0; i < A.n; i++) { MapPoint* p = i < (int)vpMapPoints1.size() ? vpMapPoints1[i] : nullptr; valid1[i] = (p && !p->isBad()) ? 1 : 0; a1[i] = pKF1->undistort_keypoints_[i].angle; }
+    for (int i = 0; i < B.n; i++) { MapPoint* p = i < (int)vpMapPoints2.size() ? vpMapPoints2[i] : nullptr; valid2[i] = (p && !p->isBad()) ? 1 : 0; a2[i] = pKF2->undistort_keypoints_[i].angle; }
+    FlatFV f1, f2; flatten_fv(pKF1->feature_vector_, &f1); flatten_fv(pKF2->feature_vector_, &f2);
+    std::vector<int32_t> m12(A.n ? A.n : 1, -1);
+    int nmatches = 0;
+    check(orbm_search_by_bow(A.desc, A.n, valid1.data(), a1.data(), B.desc, B.n, valid2.data(), a2.data(), f1.node.data(), f1.off.data(), f1.idx.data(),
+                             (int)f1.node.size(), f2.node.data(), f2.off.data(), f2.idx.data(), (int)f2.node.size(), mfNNratio, TH_LOW, 1,
+                             mbCheckOrientation ? 1 : 0, m12.data(), &nmatches), "orbm_search_by_bow");
+    for (int i = 0; i < A.n && i < (int)vpMatches12.size(); i++) if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];
+    return nmatches;
+  }
+
+  // ---- Tracking::MonocularInitialization (src/Tracking.cc:416), src/ORBmatcher.cc:363-468 ------------------------------
+  int SearchForInitialization(Frame& F1, Frame& F2, std::vector<Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10) {
+    using namespace dropin;
+    Flat A, B; flatten(F1, &A); flatten(F2, &B);
+    std::vector<float> pm(2 * (size_t)A.n);
+    for (int i = 0; i < A.n; i++) { pm[2 * i] = vbPrevMatched[i].x; pm[2 * i + 1] = vbPrevMatched[i].y; }
+    vnMatches12 = std::vector<int>(A.n, -1);
+    std::vector<int32_t> m(A.n ? A.n : 1, -1);
+    int nmatches = 0;
+    check(orbm_search_for_initialization(A.kps4.data(), A.desc, A.n, B.kps4.data(), B.desc, B.n, B.bounds, pm.data(), windowSize, mfNNratio,
+                                         mbCheckOrientation ? 1 : 0, m.data(), &nmatches), "orbm_search_for_initialization");
+    for (int i = 0; i < A.n; i++) { vnMatches12[i] = m[i]; vbPrevMatched[i].x = pm[2 * i]; vbPrevMatched[i].y = pm[2 * i + 1]; }
+    return nmatches;
+  }
+
+  // ---- LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:250), src/ORBmatcher.cc:582-722 (monocular) ---------------
+  int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, const Matrix3d& F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs, const bool bOnlyStereo) {
+    using namespace dropin;
+    vMatchedPairs.clear();
+    if (bOnlyStereo) return 0;                                   // no feature of a monocular keyframe has a right coordinate (":626-629")
+    // epipole in the second image (":589-596")
+    const P3 Cw = p3(pKF1->GetCameraCenter());
+    const Matrix3d R2w = pKF2->GetRotation();
+    const P3 C2 = add(rot(R2w, Cw), p3(pKF2->GetTranslation()));
+    const float invz = 1.0f / C2.z;
+    const float ex = pKF2->fx_ * C2.x * invz + pKF2->cx_;
+    const float ey = pKF2->fy_ * C2.y * invz + pKF2->cy_;
+    Flat A, B; flatten(*pKF1, &A); flatten(*pKF2, &B);
+    std::vector<uint8_t> um1(A.n), um2(B.n);
+    for (int i = 0; i < A.n; i++) um1[i] = pKF1->GetMapPoint(i) ? 0 : 1;
+    for (int i = 0; i < B.n; i++) um2[i] = pKF2->GetMapPoint(i) ? 0 : 1;
+    FlatFV f1, f2; flatten_fv(pKF1->feature_vector_, &f1); flatten_fv(pKF2->feature_vector_, &f2);
+    double F[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F[3 * r + c] = F12(r, c);
+    std::vector<int32_t> m12(A.n ? A.n : 1, -1);
+    int nmatches = 0;
+    check(orbm_search_for_triangulation(A.kps4.data(), A.desc, um1.data(), A.n, B.kps4.data(), B.desc, um2.data(), B.n, f1.node.data(), f1.off.data(), f1.idx.data(),
+                                        (int)f1.node.size(), f2.node.data(), f2.off.data(), f2.idx.data(), (int)f2.node.size(), F, ex, ey,
+                                        pKF2->scale_factors_.data(), pKF2->level_sigma2s_.data(), mbCheckOrientation ? 1 : 0, m12.data(), &nmatches),
+          "orbm_search_for_triangulation");
+    vMatchedPairs.reserve(nmatches);
+    for (int i = 0; i < A.n; i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+    return nmatches;
+  }
+
+  // ---- LoopClosing::ComputeSim3 (src/LoopClosing.cc:319), src/ORBmatcher.cc:956-1159 -----------------------------------
+  int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const Matrix3d& R12, const Vector3d& t12, const float th) {
+    using namespace dropin;
+    const Matrix3d R1w = pKF1->GetRotation(), R2w = pKF2->GetRotation();
+    const P3 t1w = p3(pKF1->GetTranslation()), t2w = p3(pKF2->GetTranslation());
+    R33 sR12, sR21;                                              // sR12 = s12 * R12, sR21 = (1 / s12) * R12^T  (":973-975")
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { sR12.m[r][c] = s12 * R12(r, c); sR21.m[r][c] = (1.0 / s12) * R12(c, r); }
+    const P3 t12p = p3(t12);
+    const P3 t21r = rot(sR21, t12p); const P3 t21 = {-t21r.x, -t21r.y, -t21r.z};
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {
+      MapPoint* pMP = vpMatches12[i];
+      if (pMP) {
+        vbAlreadyMatched1[i] = true;
+        const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+        if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+      }
+    }
+    Flat A, B; flatten(*pKF1, &A); flatten(*pKF2, &B);
+    Queries Q12(N1), Q21(N2);
+    auto one_way = [&](const std::vector<MapPoint*>& pts, const std::vector<bool>& already, const Matrix3d& Raw, const P3& taw, const R33& sRba, const P3& tba,
+                       KeyFrame* target, Queries& Q) {
+      for (size_t i = 0; i < pts.size(); i++) {
+        MapPoint* pMP = pts[i];
+        if (!pMP || already[i]) continue;
+        if (pMP->isBad()) continue;
+        const P3 p3Dca = add(rot(Raw, p3(pMP->GetWorldPos())), taw);
+        const P3 p3Dcb = add(rot(sRba, p3Dca), tba);
+        if (p3Dcb.z < 0.0) continue;
+        const float invz = 1.0 / p3Dcb.z;
+        const float x = p3Dcb.x * invz, y = p3Dcb.y * invz;
+        const float u = pKF1->fx_ * x + pKF1->cx_, v = pKF1->fy_ * y + pKF1->cy_;          // (both directions use keyframe 1's intrinsics, ":958-961")
+        if (!target->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+        const float dist3D = norm(p3Dcb);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, target);
+        Q.valid[i] = 1; Q.uv[2 * i] = u; Q.uv[2 * i + 1] = v;
+        Q.radius[i] = th * target->scale_factors_[nPredictedLevel];
+        Q.pred[i] = nPredictedLevel;
+        Q.set_desc(i, pMP->GetDescriptor());
+      }
+    };
+    one_way(vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, Q12);
+    one_way(vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12p, pKF1, Q21);
+    // the descriptor rows the C ABI searches with are the MAP POINTS' descriptors (":1036", ":1112"), not the keyframes' own
+    std::vector<int32_t> m12(N1 ? N1 : 1, -1);
+    int nFound = 0;
+    check(orbm_search_by_sim3(A.kps4.data(), A.desc, N1, B.kps4.data(), B.desc, N2, A.bounds, Q12.uv.data(), Q12.radius.data(), Q12.pred.data(),
+                              Q12.valid.data(), Q12.desc.data(), Q21.uv.data(), Q21.radius.data(), Q21.pred.data(), Q21.valid.data(), Q21.desc.data(),
+                              m12.data(), &nFound), "orbm_search_by_sim3");
+    for (int i1 = 0; i1 < N1; i1++) if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];
+    return nFound;
+  }
+
+  // ---- LocalMapping::SearchInNeighbors (src/LocalMapping.cc:441,472), src/ORBmatcher.cc:724-842 --------------------------
+  int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0) {
+    using namespace dropin;
+    Sim3Cam C;
+    C.R = block33(pKF->GetRotation()); C.t = p3(pKF->GetTranslation()); C.Ow = p3(pKF->GetCameraCenter());
+    const size_t nq = vpMapPoints.size();
+    Queries Q(nq);
+    // candidate selection does not depend on the map mutations below (no `taken` state, ":775-811"): it is computed for
+    // every non-null point first; validity (isBad / IsInKeyFrame) is evaluated in the sequential pass, where it can change
+    for (size_t i = 0; i < nq; i++) {
+      MapPoint* pMP = vpMapPoints[i];
+      if (!pMP) continue;
+      float u, v, dist; int level;
+      if (!project_with_gates(pKF, C, pMP, 0.0f, true, &u, &v, &dist, &level)) continue;
+      Q.valid[i] = 1; Q.uv[2 * i] = u; Q.uv[2 * i + 1] = v;
+      Q.radius[i] = th * pKF->scale_factors_[level];
+      Q.pred[i] = level;
+      Q.set_desc(i, pMP->GetDescriptor());
+    }
+    Flat T; flatten(*pKF, &T);
+    std::vector<int32_t> match(nq ? nq : 1, -1);
+    int n = 0;
+    check(orbm_search_by_projection(T.kps4.data(), T.desc, T.n, T.bounds, Q.uv.data(), Q.radius.data(), nullptr, nullptr, Q.pred.data(), Q.desc.data(),
+                                    Q.valid.data(), nullptr, (int)nq, pKF->inv_level_sigma2s_.data(), 5.99f, nullptr, 0, mfNNratio, TH_LOW, 0, match.data(), nullptr, &n),
+          "orbm_search_by_projection");
+    int nFused = 0;
+    for (size_t i = 0; i < nq; i++) {
+      MapPoint* pMP = vpMapPoints[i];
+      if (!pMP) continue;
+      if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+      if (match[i] < 0) continue;
+      const int bestIdx = match[i];
+      MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) {
+          if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+          else pMPinKF->Replace(pMP);
+        }
+      } else {
+        pMP->AddObservation(pKF, bestIdx);
+        pKF->AddMapPoint(pMP, bestIdx);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
+  // ---- LoopClosing::SearchAndFuse (src/LoopClosing.cc:611), src/ORBmatcher.cc:844-954 ------------------------------------
+  int Fuse(KeyFrame* pKF, Matrix4d Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) {
+    using namespace dropin;
+    Sim3Cam C = decompose(Scw);
+    const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+    const size_t nq = vpPoints.size();
+    Queries Q(nq);
+    for (size_t iMP = 0; iMP < nq; iMP++) {
+      MapPoint* pMP = vpPoints[iMP];
+      if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+      float u, v, dist; int level;
+      if (!project_with_gates(pKF, C, pMP, 0.0f, true, &u, &v, &dist, &level)) continue;
+      Q.valid[iMP] = 1; Q.uv[2 * iMP] = u; Q.uv[2 * iMP + 1] = v;
+      Q.radius[iMP] = th * pKF->scale_factors_[level];
+      Q.pred[iMP] = level;
+      Q.set_desc(iMP, pMP->GetDescriptor());
+    }
+    Flat T; flatten(*pKF, &T);
+    std::vector<int32_t> match(nq ? nq : 1, -1);
+    int n = 0;
+    check(orbm_search_by_projection(T.kps4.data(), T.desc, T.n, T.bounds, Q.uv.data(), Q.radius.data(), nullptr, nullptr, Q.pred.data(), Q.desc.data(),
+                                    Q.valid.data(), nullptr, (int)nq, nullptr, 0.f, nullptr, 0, mfNNratio, TH_LOW, 0, match.data(), nullptr, &n),
+          "orbm_search_by_projection");
+    int nFused = 0;
+    for (size_t iMP = 0; iMP < nq; iMP++) {
+      if (match[iMP] < 0) continue;
+      MapPoint* pMP = vpPoints[iMP];
+      MapPoint* pMPinKF = pKF->GetMapPoint(match[iMP]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+      } else {
+        pMP->AddObservation(pKF, match[iMP]);
+        pKF->AddMapPoint(pMP, match[iMP]);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
+ protected:
+  float RadiusByViewingCos(const float& viewCos) { return viewCos > 0.998 ? 2.5 : 4.0; }        // src/ORBmatcher.cc:121-126
+
+  struct Sim3Cam { dropin::R33 R; dropin::P3 t, Ow; };
+  // "Decompose Scw" (":269-274", ":854-859"): scw from the first row, Rcw = sRcw / scw, tcw = Scw.t / scw, Ow = -Rcw^T tcw
+  static Sim3Cam decompose(const Matrix4d& Scw) {
+    using namespace dropin;
+    Sim3Cam C;
+    const R33 sR = block33(Scw);
+    const float scw = std::sqrt(sR.m[0][0] * sR.m[0][0] + sR.m[0][1] * sR.m[0][1] + sR.m[0][2] * sR.m[0][2]);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) C.R.m[r][c] = sR.m[r][c] / scw;
+    const P3 st = col3(Scw);
+    C.t = {st.x / scw, st.y / scw, st.z / scw};
+    const P3 Rt = rot_t(C.R, C.t);
+    C.Ow = {-Rt.x, -Rt.y, -Rt.z};
+    return C;
+  }
+  // the gates shared by SearchByProjection(KeyFrame*, Scw, ...) and both Fuse overloads (":286-322", ":746-777", ":873-906"):
+  // positive depth, inside the image, distance inside the scale-invariance region, viewing angle below 60 degrees
+  static bool project_with_gates(KeyFrame* pKF, const Sim3Cam& C, MapPoint* pMP, double, bool viewing_gate, float* u_out, float* v_out, float* dist_out, int* level_out) {
+    using namespace dropin;
+    const P3 p3Dw = p3(pMP->GetWorldPos());
+    const P3 p3Dc = add(rot(C.R, p3Dw), C.t);
+    if (p3Dc.z < 0.0) return false;
+    const float invz = 1 / p3Dc.z;
+    const float x = p3Dc.x * invz, y = p3Dc.y * invz;
+    const float u = pKF->fx_ * x + pKF->cx_, v = pKF->fy_ * y + pKF->cy_;
+    if (!pKF->IsInImage(u, v)) return false;
+    const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+    const P3 PO = sub(p3Dw, C.Ow);
+    const float dist = norm(PO);
+    if (dist < minDistance || dist > maxDistance) return false;
+    if (viewing_gate && dot(PO, p3(pMP->GetNormal())) < 0.5 * dist) return false;
+    *u_out = u; *v_out = v; *dist_out = dist;
+    *level_out = pMP->PredictScale(dist, pKF);
+    return true;
+  }
+
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
+
+// ============================================================================================== CeresOptimizer
+template <class Types>
+class CeresOptimizerT {
+ public:
+  typedef typename Types::Frame Frame;
+  typedef typename Types::KeyFrame KeyFrame;
+  typedef typename Types::MapPoint MapPoint;
+  typedef typename Types::Map Map;
+  typedef typename Types::Matrix3d Matrix3d;
+  typedef typename Types::Matrix4d Matrix4d;
+  typedef typename Types::Vector2d Vector2d;
+  typedef typename Types::Vector3d Vector3d;
+  typedef typename Types::Quaterniond Quaterniond;
+
+  // MatEigenConverter::Matrix4dToMatrix_7_1 / Matrix_7_1_ToMatrix4d (src/MatEigenConverter.cc:66-85)
+  static void Matrix4dToMatrix_7_1(const Matrix4d& pose, double out7[7]) {
+    double T[16];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[4 * r + c] = pose(r, c);
+    dropin::check(ba_matrix4d_to_pose7(T, out7), "ba_matrix4d_to_pose7");
+  }
+  static Matrix4d Matrix_7_1_ToMatrix4d(const double in7[7]) {
+    double T[16];
+    dropin::check(ba_pose7_to_matrix4d(in7, T), "ba_pose7_to_matrix4d");
+    Matrix4d pose;
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose(r, c) = T[4 * r + c];
+    return pose;
+  }
+
+  // src/CeresOptimizer.cc:227-241
+  bool static CheckOutlier(Matrix3d K, Vector2d& observation, float inv_sigma, Vector3d& world_pose, Vector3d& tcw, Quaterniond& qcw, double thres) {
+    const double K4[4] = {K(0, 0), K(1, 1), K(0, 2), K(1, 2)};
+    const double pose7[7] = {tcw[0], tcw[1], tcw[2], qcw.x(), qcw.y(), qcw.z(), qcw.w()};
+    const double X[3] = {world_pose[0], world_pose[1], world_pose[2]}, uv[2] = {observation[0], observation[1]};
+    return ba_check_outlier(K4, pose7, X, uv, (double)inv_sigma, thres, nullptr) != 0;
+  }
+
+  // src/CeresOptimizer.cc:243-269
+  int static CheckOutliers(Frame* frame, Vector3d& tcw, Quaterniond& qcw) {
+    int n_bad = 0;
+    const double K4[4] = {frame->fx_, frame->fy_, frame->cx_, frame->cy_};
+    const double pose7[7] = {tcw[0], tcw[1], tcw[2], qcw.x(), qcw.y(), qcw.z(), qcw.w()};
+    for (int i = 0; i < frame->N_; i++) {
+      MapPoint* map_point = frame->map_points_[i];
+      if (!map_point) continue;
+      const Vector3d wp = map_point->GetWorldPos();
+      const double X[3] = {wp[0], wp[1], wp[2]};
+      const auto& kp = frame->undistort_keypoints_[i];
+      const double uv[2] = {kp.pt.x, kp.pt.y};
+      const float inv_sigma = frame->inv_level_sigma2s_[kp.octave];
+      if (ba_check_outlier(K4, pose7, X, uv, (double)inv_sigma, 5.991, nullptr) != 0) { frame->is_outliers_[i] = true; n_bad++; }
+      else frame->is_outliers_[i] = false;
+    }
+    return n_bad;
+  }
+
+  // ---- src/CeresOptimizer.cc:275-342 (Tracking.cc:587,646,684,1074,...) --------------------------------------------------
+  int static PoseOptimization(Frame* frame) {
+    const int N = frame->N_;
+    double pose7[7];
+    std::vector<double> Xw, uv; std::vector<float> isg; std::vector<int> slot;
+    std::vector<uint8_t> outlier;
+    int n_inliers = 0;
+    {
+      std::unique_lock<std::mutex> lock(MapPoint::global_mutex_);               // (":284")
+      Matrix4dToMatrix_7_1(frame->Tcw_, pose7);                                 // frame_tcw, Eigen::Quaterniond(frame_R)
+      const double K4[4] = {frame->fx_, frame->fy_, frame->cx_, frame->cy_};
+      for (int i = 0; i < N; i++) {
+        MapPoint* map_point = frame->map_points_[i];
+        if (!map_point) continue;
+        frame->is_outliers_[i] = false;
+        const Vector3d p = map_point->GetWorldPos();
+        const auto& kp = frame->undistort_keypoints_[i];
+        Xw.push_back(p[0]); Xw.push_back(p[1]); Xw.push_back(p[2]);
+        uv.push_back(kp.pt.x); uv.push_back(kp.pt.y);
+        isg.push_back(frame->inv_level_sigma2s_[kp.octave]);
+        slot.push_back(i);
+      }
+      const int n = (int)slot.size();
+      if (n < 3) return 0;                                                      // (":330": pose untouched)
+      outlier.assign(n, 0);
+      dropin::check(ba_pose_optimization(K4, pose7, Xw.data(), uv.data(), isg.data(), n, outlier.data(), &n_inliers, nullptr), "ba_pose_optimization");
+      for (int k = 0; k < n; k++) frame->is_outliers_[slot[k]] = outlier[k] != 0;       // CheckOutliers (":333")
+    }
+    frame->SetPose(Matrix_7_1_ToMatrix4d(pose7));                               // normalized q -> R (":336-340")
+    return n_inliers;
+  }
+
+  // ---- src/CeresOptimizer.cc:49-57 (Tracking.cc:502, LoopClosing.cc:656) -------------------------------------------------
+  void static GlobalBundleAdjustemnt(Map* map, int n_iterations = 200, bool* stop_flag = nullptr, const unsigned long n_loop_keyframe = 0,
+                                     const bool is_robust = true) {
+    std::vector<KeyFrame*> keyframes = map->GetAllKeyFrames();
+    std::vector<MapPoint*> map_points = map->GetAllMapPoints();
+    BundleAdjustment(keyframes, map_points, n_iterations, stop_flag, n_loop_keyframe, is_robust);
+  }
+
+  // ---- src/CeresOptimizer.cc:59-225 ---------------------------------------------------------------------------------------
+  void static BundleAdjustment(const std::vector<KeyFrame*>& keyframes, const std::vector<MapPoint*>& map_points, int n_iterations = 200,
+                               bool* stop_flag = nullptr, const unsigned long n_loop_keyframe = 0, const bool is_robust = true) {
+    if (keyframes.empty()) return;
+    unsigned long max_keyframe_id = 0;
+    std::map<KeyFrame*, int> cam_of;                               // ided_keyframe_pose: non-bad keyframes
+    std::vector<KeyFrame*> cams;
+    std::vector<double> K4, poses7; std::vector<uint8_t> cam_fixed;
+    for (size_t i = 0; i < keyframes.size(); i++) {
+      KeyFrame* keyframe = keyframes[i];
+      if (keyframe->isBad()) continue;
+      if (cam_of.count(keyframe)) continue;
+      double p7[7];
+      Matrix4dToMatrix_7_1(keyframe->GetPose(), p7);
+      cam_of[keyframe] = (int)cams.size(); cams.push_back(keyframe);
+      poses7.insert(poses7.end(), p7, p7 + 7);
+      const double k4[4] = {keyframe->fx_, keyframe->fy_, keyframe->cx_, keyframe->cy_};
+      K4.insert(K4.end(), k4, k4 + 4);
+      cam_fixed.push_back(keyframe->id_ == 0 ? 1 : 0);            // (":115-120")
+      if (keyframe->id_ > max_keyframe_id) max_keyframe_id = keyframe->id_;
+    }
+    std::vector<int> pt_of(map_points.size(), -1);                 // -1: bad, or no edge (is_not_optimized_map_point)
+    std::vector<double> pts3, obs_uv, obs_w; std::vector<int32_t> obs_cam, obs_pt; std::vector<uint8_t> obs_rob;
+    for (size_t i = 0; i < map_points.size(); i++) {
+      MapPoint* map_point = map_points[i];
+      if (map_point->isBad()) continue;
+      const Vector3d X = map_point->GetWorldPos();
+      const std::map<KeyFrame*, size_t> observations = map_point->GetObservations();
+      int n_edges = 0;
+      const int pid = (int)(pts3.size() / 3);
+      for (auto it = observations.begin(); it != observations.end(); ++it) {
+        KeyFrame* keyframe = it->first;
+        if (keyframe->isBad() || keyframe->id_ > max_keyframe_id) continue;
+        auto c = cam_of.find(keyframe);
+        if (c == cam_of.end()) continue;                           // (a keyframe outside `keyframes`: the reference would insert a zero pose here)
+        n_edges++;
+        const auto& kp = keyframe->undistort_keypoints_[it->second];
+        obs_cam.push_back(c->second); obs_pt.push_back(pid);
+        obs_uv.push_back(kp.pt.x); obs_uv.push_back(kp.pt.y);
+        obs_w.push_back((double)keyframe->inv_level_sigma2s_[kp.octave]);        // sqrt_information = I * invSigma2 (F7)
+        obs_rob.push_back(is_robust ? 1 : 0);
+      }
+      if (n_edges == 0) continue;                                  // (":170-172": RemoveParameterBlock of a never-added block; skipped)
+      pt_of[i] = pid;
+      pts3.push_back(X[0]); pts3.push_back(X[1]); pts3.push_back(X[2]);
+    }
+    ba_options o; o.max_iterations = n_iterations; o.huber_delta = std::sqrt(5.991); o.fix_points = 0;
+    o.stop_flag = reinterpret_cast<const volatile uint8_t*>(stop_flag);
+    dropin::check(ba_solve(K4.data(), poses7.data(), cam_fixed.data(), (int)cams.size(), pts3.data(), (int)(pts3.size() / 3), obs_cam.data(), obs_pt.data(),
+                           obs_uv.data(), obs_w.data(), obs_rob.data(), (int)obs_cam.size(), &o, nullptr), "ba_solve");
+    for (size_t c = 0; c < cams.size(); c++) {                     // (":194-209")
+      KeyFrame* keyframe = cams[c];
+      if (keyframe->isBad()) continue;
+      const Matrix4d pose = Matrix_7_1_ToMatrix4d(&poses7[7 * c]);
+      if (n_loop_keyframe == 0) keyframe->SetPose(pose);
+      else { keyframe->global_BA_Tcw_ = pose; keyframe->n_BA_global_for_keyframe_ = n_loop_keyframe; }
+    }
+    for (size_t i = 0; i < map_points.size(); i++) {               // (":211-224")
+      if (pt_of[i] < 0) continue;
+      MapPoint* map_point = map_points[i];
+      if (map_point->isBad()) continue;
+      Vector3d X;
+      for (int k = 0; k < 3; k++) X[k] = pts3[3 * (size_t)pt_of[i] + k];
+      if (n_loop_keyframe == 0) { map_point->SetWorldPos(X); map_point->UpdateNormalAndDepth(); }
+      else { map_point->global_BA_pose_ = X; map_point->n_BA_global_for_keyframe_ = n_loop_keyframe; }
+    }
+  }
+
+  // ---- src/CeresOptimizer.cc:344-599 (LocalMapping.cc:89) -----------------------------------------------------------------
+  void static LocalBundleAdjustment(KeyFrame* keyframe, bool* stop_flag, Map* map) {
+    // local keyframes: the current one and its covisibles (":348-363")
+    std::vector<KeyFrame*> local_kfs; std::map<KeyFrame*, int> cam_of;
+    auto add_cam = [&](KeyFrame* kf, std::vector<KeyFrame*>& list) { if (!cam_of.count(kf)) { cam_of[kf] = -1; list.push_back(kf); } };
+    add_cam(keyframe, local_kfs);
+    keyframe->n_BA_local_for_keyframe_ = keyframe->id_;
+    const std::vector<KeyFrame*> neighbor_keyframes = keyframe->GetVectorCovisibleKeyFrames();
+    for (size_t i = 0; i < neighbor_keyframes.size(); i++) {
+      KeyFrame* nb = neighbor_keyframes[i];
+      nb->n_BA_local_for_keyframe_ = keyframe->id_;
+      if (!nb->isBad()) add_cam(nb, local_kfs);
+    }
+    // local map points seen in local keyframes (":366-384"); std::map = the reference's container (and its iteration order)
+    std::map<MapPoint*, int> pt_of;
+    for (KeyFrame* kf : local_kfs) {
+      const std::vector<MapPoint*> mps = kf->GetMapPointMatches();
+      for (MapPoint* mp : mps)
+        if (mp && !mp->isBad() && mp->n_BA_local_for_keyframe_ != keyframe->id_) { pt_of[mp] = -1; mp->n_BA_local_for_keyframe_ = keyframe->id_; }
+    }
+    // fixed keyframes: see local points, are not local (":388-406")
+    std::map<KeyFrame*, int> fixed_set;
+    for (auto it = pt_of.begin(); it != pt_of.end(); ++it) {
+      const std::map<KeyFrame*, size_t> observations = it->first->GetObservations();
+      for (auto ob = observations.begin(); ob != observations.end(); ++ob) {
+        KeyFrame* kf = ob->first;
+        if (kf->n_BA_local_for_keyframe_ != keyframe->id_ && kf->n_BA_fixed_for_keyframe_ != keyframe->id_) {
+          kf->n_BA_fixed_for_keyframe_ = keyframe->id_;
+          if (!kf->isBad()) fixed_set[kf] = -1;
+        }
+      }
+    }
+    // flatten: cameras = local (free unless id 0) then fixed; points in map order; one observation per (point, non-bad keyframe)
+    std::vector<KeyFrame*> cams;
+    std::vector<double> K4, poses7; std::vector<uint8_t> cam_fixed, cam_local;
+    auto push_cam = [&](KeyFrame* kf, bool local) {
+      double p7[7];
+      Matrix4dToMatrix_7_1(kf->GetPose(), p7);
+      cam_of[kf] = (int)cams.size(); cams.push_back(kf);
+      poses7.insert(poses7.end(), p7, p7 + 7);
+      const double k4[4] = {kf->fx_, kf->fy_, kf->cx_, kf->cy_};
+      K4.insert(K4.end(), k4, k4 + 4);
+      cam_local.push_back(local ? 1 : 0);
+      cam_fixed.push_back((!local || kf->id_ == 0) ? 1 : 0);      // (":476-481", ":499-502")
+    };
+    for (KeyFrame* kf : local_kfs) push_cam(kf, true);
+    for (auto it = fixed_set.begin(); it != fixed_set.end(); ++it) push_cam(it->first, false);
+    std::vector<MapPoint*> pts; std::vector<double> pts3, obs_uv; std::vector<float> obs_isg; std::vector<int32_t> obs_cam, obs_pt;
+    std::vector<std::pair<KeyFrame*, MapPoint*>> obs_edge;
+    for (auto it = pt_of.begin(); it != pt_of.end(); ++it) {
+      MapPoint* mp = it->first;
+      const Vector3d X = mp->GetWorldPos();
+      it->second = (int)pts.size(); pts.push_back(mp);
+      pts3.push_back(X[0]); pts3.push_back(X[1]); pts3.push_back(X[2]);
+      const std::map<KeyFrame*, size_t> observations = mp->GetObservations();
+      for (auto ob = observations.begin(); ob != observations.end(); ++ob) {
+        KeyFrame* kf = ob->first;
+        if (kf->isBad()) continue;
+        auto c = cam_of.find(kf);
+        if (c == cam_of.end() || c->second < 0) continue;          // neither local nor fixed (":465,:483": no residual is added)
+        const auto& kp = kf->undistort_keypoints_[ob->second];
+        obs_cam.push_back(c->second); obs_pt.push_back(it->second);
+        obs_uv.push_back(kp.pt.x); obs_uv.push_back(kp.pt.y);
+        obs_isg.push_back(kf->inv_level_sigma2s_[kp.octave]);
+        obs_edge.push_back(std::make_pair(kf, mp));
+      }
+    }
+    if (stop_flag && *stop_flag) return;                           // (":509-512")
+    std::vector<uint8_t> erase(obs_cam.size() ? obs_cam.size() : 1, 0);
+    int aborted = 0;
+    dropin::check(ba_local_bundle_adjustment(K4.data(), poses7.data(), cam_fixed.data(), cam_local.data(), (int)cams.size(), pts3.data(), (int)pts.size(),
+                                             obs_cam.data(), obs_pt.data(), obs_uv.data(), obs_isg.data(), (int)obs_cam.size(),
+                                             reinterpret_cast<const volatile uint8_t*>(stop_flag), 1, erase.data(), &aborted, nullptr, nullptr),
+                  "ba_local_bundle_adjustment");
+    if (aborted) return;                                           // stop raised before pass 2: the reference returns without writing back
+    std::unique_lock<std::mutex> lock(map->mutex_map_update_);     // (":573")
+    for (size_t i = 0; i < obs_edge.size(); i++)
+      if (erase[i]) { obs_edge[i].first->EraseMapPointMatch(obs_edge[i].second); obs_edge[i].second->EraseObservation(obs_edge[i].first); }
+    for (size_t c = 0; c < local_kfs.size(); c++) local_kfs[c]->SetPose(Matrix_7_1_ToMatrix4d(&poses7[7 * c]));          // (":584-590")
+    for (size_t p = 0; p < pts.size(); p++) {                      // (":592-598")
+      Vector3d X;
+      for (int k = 0; k < 3; k++) X[k] = pts3[3 * p + k];
+      pts[p]->SetWorldPos(X);
+      pts[p]->UpdateNormalAndDepth();
+    }
+  }
+};
+
+}  // namespace ORB_SLAM2
+
+#ifdef ORBSLAM_DROPIN_REFERENCE_TYPES
+// Inside the reference tree (Frame.h, KeyFrame.h, MapPoint.h, Map.h, Eigen and OpenCV already included): the classes the
+// call sites name.  src/ORBmatcher.cc and the three CeresOptimizer methods above drop out of the build.
+namespace ORB_SLAM2 {
+struct ReferenceTypes {
+  typedef ORB_SLAM2::Frame Frame; typedef ORB_SLAM2::KeyFrame KeyFrame; typedef ORB_SLAM2::MapPoint MapPoint; typedef ORB_SLAM2::Map Map;
+  typedef Eigen::Matrix3d Matrix3d; typedef Eigen::Matrix4d Matrix4d; typedef Eigen::Vector2d Vector2d; typedef Eigen::Vector3d Vector3d;
+  typedef Eigen::Quaterniond Quaterniond; typedef cv::Mat Mat; typedef cv::Point2f Point2f;
+};
+typedef ORBmatcherT<ReferenceTypes> ORBmatcher;
+typedef CeresOptimizerT<ReferenceTypes> CeresOptimizerHip;      // PoseOptimization / LocalBundleAdjustment / GlobalBundleAdjustemnt / BundleAdjustment
+}  // namespace ORB_SLAM2
+#endif

@@ -508,13 +508,13 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
 
 // ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:956-1159) from the two window searches on: every valid keyframe-1 feature
 // looks for its map point in keyframe 2 (q12_*: projected position, radius th * scale[predicted level], predicted level;
-// descriptor = desc1 row, the caller passes the map point's representative descriptor there) and vice versa; best <=
+// descriptor = q12_desc row = the map point's representative descriptor) and vice versa; best <=
 // TH_HIGH each way with the [pred - 1, pred] level gate, no `taken` state; a pair survives iff both directions agree
 // (:1145-1157).  match12[n1] = index in keyframe 2 or -1.
 int orbm_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
                         const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred, const uint8_t* q12_valid,
-                        const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid, int32_t* match12,
-                        int* nfound) {
+                        const uint8_t* q12_desc, const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid,
+                        const uint8_t* q21_desc, int32_t* match12, int* nfound) {
   ORBHIP_REQUIRE(n1 >= 0 && n2 >= 0 && nfound && (n1 == 0 || match12), ORBHIP_EINVAL, "bad size");
   *nfound = 0;
   for (int i = 0; i < n1; i++) match12[i] = -1;
@@ -523,9 +523,9 @@ int orbm_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const f
   std::vector<int32_t> m1(n1), m2(n2);
   int k = 0;
   const int TH_HIGH = 100;
-  if (int rc = orbm_search_by_projection(kps2, desc2, n2, bounds, q12_uv, q12_radius, nullptr, nullptr, q12_pred, desc1, q12_valid, nullptr, n1,
+  if (int rc = orbm_search_by_projection(kps2, desc2, n2, bounds, q12_uv, q12_radius, nullptr, nullptr, q12_pred, q12_desc ? q12_desc : desc1, q12_valid, nullptr, n1,
                                          nullptr, 0.f, nullptr, 0, 1.f, TH_HIGH, 0, m1.data(), nullptr, &k)) return rc;
-  if (int rc = orbm_search_by_projection(kps1, desc1, n1, bounds, q21_uv, q21_radius, nullptr, nullptr, q21_pred, desc2, q21_valid, nullptr, n2,
+  if (int rc = orbm_search_by_projection(kps1, desc1, n1, bounds, q21_uv, q21_radius, nullptr, nullptr, q21_pred, q21_desc ? q21_desc : desc2, q21_valid, nullptr, n2,
                                          nullptr, 0.f, nullptr, 0, 1.f, TH_HIGH, 0, m2.data(), nullptr, &k)) return rc;
   int found = 0;
   for (int i1 = 0; i1 < n1; i1++) {

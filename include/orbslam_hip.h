@@ -171,13 +171,14 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
  * window searches on.  The caller keeps the reference's geometry (transform with sR21 / sR12, depth / image / distance gates,
  * PredictScale) and passes, per feature of keyframe 1 that holds a usable, not yet matched map point (q12_valid), its
  * projection into keyframe 2, the radius th * scale_factors_[predicted level] and the predicted level - and the same for
- * keyframe 2 into keyframe 1 (q21_*).  desc1 / desc2 rows = the map point's descriptor for that feature.  Each direction takes
- * the best candidate of KeyFrame::GetFeaturesInArea with level in [pred - 1, pred] and distance <= TH_HIGH; a pair is kept iff
- * the two directions agree (:1145-1157).  match12[n1] = index in keyframe 2 or -1; *nfound = the return value.            */
+ * keyframe 2 into keyframe 1 (q21_*).  desc1 / desc2 = the keyframes' own descriptors (the search targets); q12_desc[n1][32] /
+ * q21_desc[n2][32] = pMP->GetDescriptor() of the feature's map point (":1036", ":1112"; NULL = the keyframe's own row).  Each
+ * direction takes the best candidate of KeyFrame::GetFeaturesInArea with level in [pred - 1, pred] and distance <= TH_HIGH; a
+ * pair is kept iff the two directions agree (:1145-1157).  match12[n1] = index in keyframe 2 or -1; *nfound = the return value. */
 int orbm_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
                         const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred,
-                        const uint8_t* q12_valid, const float* q21_uv, const float* q21_radius, const int32_t* q21_pred,
-                        const uint8_t* q21_valid, int32_t* match12, int* nfound);
+                        const uint8_t* q12_valid, const uint8_t* q12_desc, const float* q21_uv, const float* q21_radius,
+                        const int32_t* q21_pred, const uint8_t* q21_valid, const uint8_t* q21_desc, int32_t* match12, int* nfound);
 
 /* SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:151-256; strict = 0) and SearchByBoW(KeyFrame*,
  * KeyFrame*, ...) (:470-580; strict = 1: best < th) on flattened data (host pointers).  The DBoW2 feature

@@ -286,10 +286,13 @@ int orc_search_by_projection(const float* kps4, const uint8_t* desc, int n, cons
 // SearchBySim3 (src/ORBmatcher.cc:956-1159) on flattened data, from the two GetFeaturesInArea calls on.  The geometry in front
 // of them (sR21 / sR12 transforms, depth, IsInImage, distance-invariance gates, PredictScale) stays with the caller, which
 // passes per feature: q_valid (the feature holds a usable, not already matched map point and passed the gates), the projected
-// position, radius = th * scale_factors_[nPredictedLevel] and nPredictedLevel.  desc1 / desc2 rows = pMP->GetDescriptor().
+// position, radius = th * scale_factors_[nPredictedLevel] and nPredictedLevel; q12_desc / q21_desc rows = pMP->GetDescriptor().
 int orc_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
                        const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred, const uint8_t* q12_valid,
-                       const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid, int32_t* match12) {
+                       const uint8_t* q12_desc, const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid,
+                       const uint8_t* q21_desc, int32_t* match12) {
+  if (!q12_desc) q12_desc = desc1;             // dMP = pMP->GetDescriptor() (:1036, :1112); default: the keyframe's own row
+  if (!q21_desc) q21_desc = desc2;
   const int TH_HIGH = 100;
   Grid* G1 = new Grid(); Grid* G2 = new Grid();
   G1->build(kps1, n1, bounds[0], bounds[1], bounds[2], bounds[3]);
@@ -305,7 +308,7 @@ int orc_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const fl
     for (int idx : vIndices) {
       const int octave = (int)kps2[4 * idx + 2];
       if (octave < nPredictedLevel - 1 || octave > nPredictedLevel) continue;
-      const int dist = descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)idx);
+      const int dist = descriptor_distance(q12_desc + 32 * (size_t)i1, desc2 + 32 * (size_t)idx);
       if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
     }
     if (bestDist <= TH_HIGH) vnMatch1[i1] = bestIdx;
@@ -320,7 +323,7 @@ int orc_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const fl
     for (int idx : vIndices) {
       const int octave = (int)kps1[4 * idx + 2];
       if (octave < nPredictedLevel - 1 || octave > nPredictedLevel) continue;
-      const int dist = descriptor_distance(desc2 + 32 * (size_t)i2, desc1 + 32 * (size_t)idx);
+      const int dist = descriptor_distance(q21_desc + 32 * (size_t)i2, desc1 + 32 * (size_t)idx);
       if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
     }
     if (bestDist <= TH_HIGH) vnMatch2[i2] = bestIdx;

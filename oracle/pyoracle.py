@@ -325,15 +325,17 @@ def search_by_projection(kps4, desc, bounds, q_uv, q_radius, q_desc, q_min_level
     return n, m, bd, tk
 
 
-def search_by_sim3(kps1, desc1, kps2, desc2, bounds, q12_uv, q12_radius, q12_pred, q12_valid, q21_uv, q21_radius, q21_pred, q21_valid):
+def search_by_sim3(kps1, desc1, kps2, desc2, bounds, q12_uv, q12_radius, q12_pred, q12_valid, q21_uv, q21_radius, q21_pred, q21_valid,
+                   q12_desc=None, q21_desc=None):
     c = np.ascontiguousarray
     k1, k2, d1, d2, b = c(kps1, np.float32), c(kps2, np.float32), c(desc1, np.uint8), c(desc2, np.uint8), c(bounds, np.float32)
-    a = [c(q12_uv, np.float32), c(q12_radius, np.float32), c(q12_pred, np.int32), c(q12_valid, np.uint8),
-         c(q21_uv, np.float32), c(q21_radius, np.float32), c(q21_pred, np.int32), c(q21_valid, np.uint8)]
+    od = lambda d: None if d is None else c(d, np.uint8)
+    a = [c(q12_uv, np.float32), c(q12_radius, np.float32), c(q12_pred, np.int32), c(q12_valid, np.uint8), od(q12_desc),
+         c(q21_uv, np.float32), c(q21_radius, np.float32), c(q21_pred, np.int32), c(q21_valid, np.uint8), od(q21_desc)]
     m = np.zeros(len(k1), np.int32)
     L = lib()
     L.orc_search_by_sim3.restype = C.c_int
-    L.orc_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10
+    L.orc_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 12
     n = L.orc_search_by_sim3(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(b), *[_p(x) for x in a], _p(m))
     return n, m
 

@@ -411,7 +411,8 @@ def search_for_triangulation(k1, d1, unmapped1, k2, d2, unmapped2, fv1, fv2, F12
 
 
 # ------------------------------------------------------------------------------------------------ M11
-def search_by_sim3(K1, D1, K2, D2, bounds, q12_uv, q12_radius, q12_pred, q12_valid, q21_uv, q21_radius, q21_pred, q21_valid):
+def search_by_sim3(K1, D1, K2, D2, bounds, q12_uv, q12_radius, q12_pred, q12_valid, q21_uv, q21_radius, q21_pred, q21_valid,
+                   q12_desc=None, q21_desc=None):
     """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:956-1159) from the two GetFeaturesInArea calls on: direction 1->2 searches
     keyframe 2 for the map point of every keyframe-1 feature (descriptor = that feature's, i.e. the map point's
     representative descriptor passed by the caller), direction 2->1 likewise; best <= TH_HIGH each way, no `taken` state;
@@ -433,8 +434,8 @@ def search_by_sim3(K1, D1, K2, D2, bounds, q12_uv, q12_radius, q12_pred, q12_val
             if best <= TH_HIGH:
                 out[q] = bidx
         return out
-    m1 = one_way(K2, D2, q12_uv, q12_radius, q12_pred, q12_valid, D1)
-    m2 = one_way(K1, D1, q21_uv, q21_radius, q21_pred, q21_valid, D2)
+    m1 = one_way(K2, D2, q12_uv, q12_radius, q12_pred, q12_valid, D1 if q12_desc is None else q12_desc)
+    m2 = one_way(K1, D1, q21_uv, q21_radius, q21_pred, q21_valid, D2 if q21_desc is None else q21_desc)
     m12 = [-1] * len(K1)
     found = 0
     for i1 in range(len(K1)):

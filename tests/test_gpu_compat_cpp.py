@@ -100,3 +100,23 @@ def test_cpp_shims_vs_oracle(oracle, tmp_path):
     obi, obd, osd = oracle.hamming_best2(odesc, odesc)
     assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
     assert d01 == oracle.descriptor_distance(odesc[0], odesc[1])
+
+
+def test_reference_signature_dropin_classes(oracle, tmp_path):
+    """(b) boundary: csrc/compat/orbslam_dropin.h - ORBmatcher's twelve methods (include/ORBmatcher.h:43-97) and
+    CeresOptimizer::{PoseOptimization, GlobalBundleAdjustemnt / BundleAdjustment, LocalBundleAdjustment}
+    (include/CeresOptimizer.h:351-376) with the reference's own signatures, instantiated over mock structs that copy the member
+    names of Frame.h / KeyFrame.h / MapPoint.h / Map.h.  tests/cpp/test_dropin.cpp writes every call as the reference's call
+    site writes it, runs it through the HIP library and compares the resulting map state with a literal CPU restatement of the
+    same entry point (tests/cpp/reference_literal.h, CPU oracle underneath)."""
+    from ceres_mono_orb_slam2_amd import _lib
+    from oracle import pyoracle
+    exe = tmp_path / "test_dropin"
+    oso = pyoracle.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", str(exe), _lib.LIB_PATH, oso, "-lpthread",
+                           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath," + os.path.dirname(oso), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-4000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " 0 failed" in r.stdout

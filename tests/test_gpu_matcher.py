@@ -184,6 +184,13 @@ def test_search_by_sim3_vs_oracle(oracle):
         n, m = _m().SearchBySim3(K1, D1, K2, D2, BOUNDS, *q)
         on, om = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q)
         assert n == on and np.array_equal(m, om) and n > 50
+        rng = np.random.default_rng(seed)
+        M1 = D1.copy(); M2 = D2.copy()                                   # map-point descriptors != the keyframes' own rows
+        for M in (M1, M2):
+            M[np.arange(len(M)), rng.integers(0, 32, len(M))] ^= (1 << rng.integers(0, 8, len(M))).astype(np.uint8)
+        n, m = _m().SearchBySim3(K1, D1, K2, D2, BOUNDS, *q, q12_desc=M1, q21_desc=M2)
+        on, om = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, q12_desc=M1, q21_desc=M2)
+        assert n == on and np.array_equal(m, om) and n > 50
 
 
 def _fake_feature_vector(rng, n, nnodes=40):

@@ -173,6 +173,15 @@ def test_search_by_sim3(oracle, frames):                                  # M11 
     on, om = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q)
     n, m = NP.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q)
     assert n == on and np.array_equal(m, om) and n > 50
+    # map-point descriptors that are NOT the keyframes' own rows (a map point's representative descriptor comes from any of
+    # its observations): a few bits flipped
+    rng = np.random.default_rng(3)
+    M1 = D1.copy(); M2 = D2.copy()
+    for M in (M1, M2):
+        M[np.arange(len(M)), rng.integers(0, 32, len(M))] ^= (1 << rng.integers(0, 8, len(M))).astype(np.uint8)
+    on2, om2 = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, q12_desc=M1, q21_desc=M2)
+    n2, m2 = NP.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, q12_desc=M1, q21_desc=M2)
+    assert n2 == on2 and np.array_equal(m2, om2) and n2 > 50
     # agreement really filters: one-directional matches outnumber the mutual ones
     n12, m12, _, _ = oracle.search_by_projection(K2, D2, BOUNDS, q[0], q[1], D1, q_pred_level=q[2], q_valid=q[3], th=100, ratio=1.0)
     assert n12 > on
