@@ -222,6 +222,36 @@ __device__ __forceinline__ int arc9_best_packed(const short2_t d[16]) {
   return max((int)best.x, (int)best.y);
 }
 
+// Phase timing of k_fast_cells (tools/fast_phase_prof.py builds a separate library with -DORBHIP_FAST_PROF): every wave
+// adds the 100 MHz s_memrealtime ticks it spent in each phase to g_fast_prof[phase]; off in the product build.
+#ifdef ORBHIP_FAST_PROF
+#define FAST_PROF_WAVES (1 << 19)
+__device__ unsigned int g_fast_prof[FAST_PROF_WAVES][8];        // per wave (no contention): ticks of phases 0..4, [7] = 1 when written
+#define FAST_STAMP(k) do { const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); t_ph[k] = (unsigned int)(_t - t_prev); t_prev = _t; } while (0)
+#define FAST_STAMP_INIT unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(); unsigned int t_ph[5] = {0, 0, 0, 0, 0}
+#else
+#define FAST_STAMP(k) do { } while (0)
+#define FAST_STAMP_INIT do { } while (0)
+#endif
+
+#define FAST_TILE_LOADS 17   // global_load_lds instructions per tile, 64 dwords each: a 64 x 64 tile (pitch 68) has 1088 dwords
+// instruction JJ of the direct-to-LDS tile load (compile-time recursion: one straight-line instruction per 64 dwords)
+template <int JJ>
+__device__ __forceinline__ void fast_tile_load(const uint8_t* base, uint8_t* tile, int lane, int ndw, int W4, uint32_t inv, uint32_t pitch) {
+  if constexpr (JJ < FAST_TILE_LOADS) {
+    if (64 * JJ >= ndw) return;                                // (wave-uniform)
+    const uint32_t k = (uint32_t)lane + 64u * JJ;
+    const uint32_t row = (k * inv) >> 16;
+    const uint32_t goff = row * pitch + 4u * (k - row * (uint32_t)W4);
+    if ((int)k < ndw)
+      // (the instruction's immediate offset would be added to BOTH the global and the LDS address: the LDS position goes
+      // through M0 instead - tools/ubench/lds_direct.hip)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + goff),
+                                       (void __attribute__((address_space(3)))*)(tile + 256 * JJ), 4, 0, 0);
+    fast_tile_load<JJ + 1>(base, tile, lane, ndw, W4, inv, pitch);
+  }
+}
+
 // ONE WAVE per cell (64-thread workgroups): no cross-wave barriers, lanes = columns of the cell, rows are
 // walked sequentially; the ordered (row-major) emit needs only a running wave-uniform offset.
 #define FAST_WPB 1      // waves (= cells) per workgroup
@@ -246,45 +276,36 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   unsigned long long* keep = (unsigned long long*)(score + plane);    // [64] NMS survivors per interior row (bit = ix)
   unsigned long long* k20 = keep + 64;                                 // [64] survivors with score >= iniTh
   unsigned short* queue = (unsigned short*)(k20 + 64);                 // pixels that passed the pre-test
+  FAST_STAMP_INIT;
   const CellDesc c = cells[ci];
   const LevelDev& L = G.lv[c.level];
   const uint8_t* src = level_ptr(G, c.level, f, img0, img_frame_bytes, pyr);
   const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
   const int iw = tw - 6, ih = th - 6;
   // ---- stage the cell (incl. its 3-px apron) in LDS -------------------------------------------------
+  // LDS-direct loads move ALIGNED dwords: the tile is fetched from the 4-byte boundary at or before its first pixel, so tile
+  // byte (row, x) lives at LDS byte row * TP + x + bsh (TP = round_up(tw, 4) + 4 leaves room for the <= 3 extra bytes)
+  const uint8_t* cell_base = src + (long long)c.y0 * L.pitch + c.x0;
+  const uint32_t bsh = (uint32_t)((size_t)cell_base & 3);
+  const uint8_t* base_al = cell_base - bsh;
+  const uint8_t* tileb = tile + bsh;
   for (int i = lane; i < plane >> 2; i += 64) ((uint32_t*)score)[i] = 0u;
   keep[lane] = 0ull; k20[lane] = 0ull;
   {
-    // All global loads of the tile are issued before the first LDS store (a load->store loop serialises on
-    // the ~1 us global latency per row).  Each lane fetches, for 4 rows per step, the two aligned dwords
-    // that cover its 4 tile bytes and realigns them with v_alignbyte; the detection window keeps a 16-px
-    // margin to the image border, so the <= 7 trailing bytes are always inside the frame.
-    // wave-uniform aligned base + a 32-bit per-lane byte offset: the loads take the scalar-base form and the row walk is one
-    // v_add per row (per-lane 64-bit pointers cost ~100 VALU per cell here, a sixth of them quarter-rate 64-bit multiply-adds)
-    const uint8_t* base = src + (long long)c.y0 * L.pitch + c.x0;
-    const uint32_t bsh = (uint32_t)((size_t)base & 3);
-    const uint8_t* base_al = base - bsh;
-    const int col = lane & 15, r0 = lane >> 4;
-    // BRANCH-FREE requests: rows / column groups outside the tile are clamped onto valid ones (their data is simply not
-    // stored) and the second dword is always read (the 16-px border margin keeps it inside the frame).  With the loads under
-    // `if (row inside) { lo = ..; hi = sh ? .. : 0; align }` the compiler kept every row's wait inside its branch: sixteen
-    // SERIAL global round trips per cell, most of a wave's lifetime.
-    const bool colv = 4 * col < tw;
-    const int c0 = (colv ? 4 * col : 0) + (int)bsh;
-    uint32_t lo[16], hi[16], offk[16];                     // (unsigned offsets: the scalar-base + 32-bit-offset load form needs them zero-extended)
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      offk[k] = (uint32_t)(min(r0 + 4 * k, th - 1) * L.pitch + c0);
-      const uint32_t* aa = (const uint32_t*)(base_al + (offk[k] & ~3u));
-      lo[k] = aa[0]; hi[k] = aa[1];
-    }
-    uint8_t* trow = tile + r0 * TP + 4 * col;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (colv && r0 + 4 * k < th) *(uint32_t*)(trow + 4 * k * TP) = __builtin_amdgcn_alignbyte(hi[k], lo[k], offk[k] & 3u);
-    }
+    // The tile goes from global memory STRAIGHT into LDS (global_load_lds_dword: no VGPR staging, no re-alignment, no LDS
+    // store instructions): a wave instruction writes 64 consecutive LDS dwords, so lane l of instruction j owns tile dword
+    // k = l + 64 j = (row k / W4, column word k % W4) and reads it from row * pitch + 4 * (k % W4) - an unaligned dword when
+    // the cell does not start on a 4-byte boundary, which the memory system handles.  All <= 9 instructions are in flight
+    // together.  The detection window keeps a 16-px margin to the image border, so the <= 7 bytes read past the right edge of
+    // a tile row are inside the frame.  (The first version staged the rows through registers: 32 loads + 16 v_alignbyte +
+    // 16 LDS stores and ~170 VALU per cell; this one needs ~50.)
+    const int W4 = TP >> 2, ndw = th * W4;
+    const uint32_t inv = (65536u + (uint32_t)W4 - 1u) / (uint32_t)W4;          // k / W4 = (k * inv) >> 16 for k < 4096, W4 <= 17
+    fast_tile_load<0>(base_al, tile, lane, ndw, W4, inv, (uint32_t)L.pitch);
+    __builtin_amdgcn_s_waitcnt(0);                            // vmcnt(0): the tile has landed in LDS
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  FAST_STAMP(0);       // tile staged
   // ---- pass A: compass pre-test; survivors are queued so that the expensive score runs on dense lanes ---------
   // A 9-arc of the 16-ring always contains two ADJACENT compass points (ring 0/4/8/12), i.e. one of {0, 8} and one of
   // {4, 12}.  Necessary for a brighter corner: max(c0, c8) > v + t and max(c4, c12) > v + t, i.e.
@@ -292,43 +313,70 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   // per pixel, and tighter than ">= 2 of the 4 compass points" (which also admits the opposite pairs).
   int qn = 0;
   {
-    // lanes = (row parity, column) when the interior is <= 32 px wide (every KITTI / VGA level), else lanes = columns
-    const bool two = iw <= 32;
-    const int lx = two ? (lane & 31) : lane, ly = two ? (lane >> 5) : 0, rstep = two ? 2 : 1;
-    // BRANCH-FREE reads (same lesson as the tile requests): lanes / rows outside the interior read a clamped pixel and are
-    // masked afterwards, so the 20 LDS reads of the four rounds are in flight together instead of one exec-masked block
-    // - with its own wait - per round
-    const int lxc = min(lx, iw - 1);
-    const bool lxv = lx < iw;
-    const uint8_t* pcol = tile + 3 * TP + lxc + 3;
-    for (int iy0 = 0; iy0 < ih; iy0 += 4 * rstep) {
-      int v[4], c0[4], c4[4], c8[4], c12[4];
+    // FOUR horizontally adjacent pixels per lane, from dword LDS reads: lanes = (row, column group of 4); 8 groups x 8 rows
+    // when the interior is <= 32 px wide (every KITTI / VGA level), else 16 groups x 4 rows.  With D[k] = the aligned dword at
+    // tile columns 4k .. 4k+3, the interior pixels 4g .. 4g+3 (tile columns 4g+3 .. 4g+6) need
+    //   v, c0, c8 : bytes 3.. of {D[g], D[g+1]} of the rows 0, +3, -3      (v_alignbyte)
+    //   c12       : D[g] itself,   c4 : bytes 2.. of {D[g+1], D[g+2]}
+    // - seven dword reads instead of twenty byte reads per four pixels.  The bytes are split into even / odd pixels as u16
+    // pairs and the min / max network runs on v_pk_{min,max,sub}_*16: ~10 VALU per pixel instead of ~18, and one prefix sum
+    // + enqueue per FOUR pixels (most lanes have nothing to enqueue: 8 % of the pixels pass).
+    const bool narrow = iw <= 32;
+    const int CG = narrow ? 8 : 16, RW = narrow ? 8 : 4;
+    const int g = narrow ? (lane & 7) : (lane & 15), lr = narrow ? (lane >> 3) : (lane >> 4);
+    const int ix4 = 4 * g;
+    // validity of this lane's four columns (bit k = column ix4 + k is inside the interior)
+    const uint32_t colmask = ix4 + 3 < iw ? 15u : (ix4 < iw ? ((1u << (iw - ix4)) - 1u) : 0u);
+    (void)CG;
+    const uint32_t T1 = (uint32_t)(minTh + 1) * 0x00010001u;
+    const int qv = (int)((3u + bsh) >> 2), q4 = 1 + (int)((2u + bsh) >> 2);       // (wave-uniform dword offsets / byte shifts)
+    const uint32_t sv = (3u + bsh) & 3u, s4 = (2u + bsh) & 3u;
+    for (int iy0 = 0; iy0 < ih; iy0 += RW) {
+      const int iyl = iy0 + lr;
+      const int iy = min(iyl, ih - 1);                          // (clamped: rows outside are masked, their reads stay inside the tile)
+      // byte offsets of the three quads inside the (shifted) LDS row: c12 at 4g + bsh, v / c0 / c8 at 4g + 3 + bsh, c4 at 4g + 6 + bsh
+      const uint32_t* rc = (const uint32_t*)(tile + (iy + 3) * TP) + g;
+      const uint32_t* ru = (const uint32_t*)(tile + iy * TP) + g + qv;         // ring point 8 (row - 3)
+      const uint32_t* rd = (const uint32_t*)(tile + (iy + 6) * TP) + g + qv;   // ring point 0 (row + 3)
+      const uint32_t e0 = rc[0], e1 = rc[1], v0 = rc[qv], v1 = rc[qv + 1], f0 = rc[q4], f1 = rc[q4 + 1], u0 = ru[0], u1 = ru[1], b0 = rd[0], b1 = rd[1];
+      const uint32_t vq = __builtin_amdgcn_alignbyte(v1, v0, sv), c8q = __builtin_amdgcn_alignbyte(u1, u0, sv), c0q = __builtin_amdgcn_alignbyte(b1, b0, sv);
+      const uint32_t c12q = __builtin_amdgcn_alignbyte(e1, e0, bsh), c4q = __builtin_amdgcn_alignbyte(f1, f0, s4);
+      uint32_t pm = 0;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int iy = min(iy0 + r * rstep + ly, ih - 1);
-        const uint8_t* p = pcol + iy * TP;
-        v[r] = p[0]; c0[r] = p[3 * TP]; c4[r] = p[3]; c8[r] = p[-3 * TP]; c12[r] = p[-3];
+      for (int par = 0; par < 2; par++) {                       // even pixels (bytes 0, 2), odd pixels (bytes 1, 3) as u16 pairs
+        auto split = [&](uint32_t q) { return par ? ((q >> 8) & 0x00FF00FFu) : (q & 0x00FF00FFu); };
+        typedef unsigned short ushort2_v __attribute__((ext_vector_type(2)));
+        auto U = [](uint32_t x) { return __builtin_bit_cast(ushort2_v, x); };
+        auto S = [](uint32_t x) { return __builtin_bit_cast(short2_t, x); };
+        const ushort2_v v2 = U(split(vq)), a0 = U(split(c0q)), a8 = U(split(c8q)), a4 = U(split(c4q)), a12 = U(split(c12q));
+        const ushort2_v hi = __builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12));
+        const ushort2_v lo = __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12));
+        const short2_t up = S(__builtin_bit_cast(uint32_t, hi)) - S(__builtin_bit_cast(uint32_t, v2));     // (values 0..255: no overflow in 16 bits)
+        const short2_t dn = S(__builtin_bit_cast(uint32_t, v2)) - S(__builtin_bit_cast(uint32_t, lo));
+        const short2_t m = __builtin_elementwise_max(up, dn) - S(T1);                                       // >= 0  <=>  max(..) > minTh
+        const uint32_t neg = ~__builtin_bit_cast(uint32_t, m) & 0x80008000u;                                // bit 15 / 31 set where the pixel passes
+        // pixel order inside the lane: byte k = pixel k; even parity holds pixels 0, 2, odd parity pixels 1, 3
+        pm |= par ? (((neg >> 14) & 2u) | ((neg >> 28) & 8u)) : (((neg >> 15) & 1u) | ((neg >> 29) & 4u));
       }
-      bool pass[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int hi = min(max(c0[r], c8[r]), max(c4[r], c12[r])), lo = max(min(c0[r], c8[r]), min(c4[r], c12[r]));
-        pass[r] = lxv && (iy0 + r * rstep + ly < ih) && (max(hi - v[r], v[r] - lo) > minTh);
+      pm &= (iyl < ih) ? colmask : 0u;
+      const int cnt = __popc(pm);
+      const int incl = wave_incl_scan_i32(cnt);
+      int pos = qn + incl - cnt;
+      const uint32_t rowbits = (uint32_t)iyl << 8;
+      while (pm) {
+        const int k = __ffs((int)pm) - 1;
+        pm &= pm - 1;
+        queue[pos++] = (unsigned short)(rowbits | (uint32_t)(ix4 + k));
       }
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const unsigned long long bal = __ballot(pass[r]);
-        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (pass[r]) queue[qn + below] = (unsigned short)(((iy0 + r * rstep + ly) << 8) | lx);
-        qn += __popcll(bal);
-      }
+      qn += __builtin_amdgcn_readlane(incl, 63);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  FAST_STAMP(1);       // pre-test + queue
   // ---- pass B: FAST-9 score at the LOW threshold; one map serves both thresholds --------
   for (int k = lane; k < qn; k += 64) {
     const int q = queue[k], iy = q >> 8, ix = q & 255;
-    const uint8_t* p = tile + (iy + 3) * TP + ix + 3;
+    const uint8_t* p = tileb + (iy + 3) * TP + ix + 3;
     const int v = p[0];
     short2_t d[16];
     auto mk = [&](int r) { const short dd = (short)(v - r); short2_t t = {dd, (short)(-dd)}; return t; };
@@ -340,6 +388,7 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     if (best > minTh) score[(iy + 3) * TP + ix + 3] = (uint8_t)(best - 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  FAST_STAMP(2);       // 9-arc score
   // ---- 3x3 non-max suppression inside the cell (frame pixels score 0), only on queued pixels --------
   int any20 = 0;
   for (int k = lane; k < qn; k += 64) {
@@ -357,6 +406,7 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   }
   any20 = __any(any20);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  FAST_STAMP(3);       // NMS
   // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816), row by row -----------
   const unsigned long long* mask = any20 ? k20 : keep;
   uint32_t* out = cell_kps + ((long long)f * G.ncells_total + ci) * G.cell_cap;
@@ -380,6 +430,11 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     }
   }
   if (lane == 0) cell_cnt[(long long)f * G.ncells_total + ci] = (ih > 0 && iw > 0) ? base : 0;
+  FAST_STAMP(4);       // ordered emit
+#ifdef ORBHIP_FAST_PROF
+  { const long long wid = (long long)f * G.ncells_total + ci;
+    if (lane == 0 && wid < FAST_PROF_WAVES) { for (int k = 0; k < 5; k++) g_fast_prof[wid][k] = t_ph[k]; g_fast_prof[wid][7] = 1u; } }
+#endif
 }
 
 // ---------------------------------------------------------------------------- k_octree
@@ -1306,6 +1361,17 @@ int orbx_destroy(orbx_ctx* c) {
   delete c;
   return 0;
 }
+
+#ifdef ORBHIP_FAST_PROF
+int orbx_debug_fast_prof(unsigned long long* out8) {          // sums over the waves of the LAST launch: ticks per phase, [7] = waves
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  std::vector<unsigned int> h((size_t)FAST_PROF_WAVES * 8);
+  ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_fast_prof), h.size() * 4));
+  for (int k = 0; k < 8; k++) out8[k] = 0;
+  for (size_t w = 0; w < FAST_PROF_WAVES; w++) if (h[8 * w + 7]) { for (int k = 0; k < 5; k++) out8[k] += h[8 * w + k]; out8[7]++; }
+  return 0;
+}
+#endif
 
 int orbx_set_profiling(orbx_ctx* c, int enable) {
   ORBHIP_REQUIRE(c != nullptr, ORBHIP_EINVAL, "ctx is NULL");
