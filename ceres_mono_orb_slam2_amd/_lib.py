@@ -15,7 +15,7 @@ SYMBOLS = [
     "orbx_extract_batch_device", "orbx_set_profiling", "orbx_get_stage_ms", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
     "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_sim3", "orbm_search_by_bow", "orbm_search_for_triangulation",
-    "orbv_create", "orbv_destroy", "orbv_transform", "orbv_descend_device", "orbv_score_l1",
+    "orbv_create", "orbv_destroy", "orbv_load_text", "orbv_parse_text", "orbv_free_parsed", "orbv_transform", "orbv_descend_device", "orbv_score_l1",
     "orbm_undistort_keypoints", "orbm_assign_features_to_grid", "orbm_features_in_area", "orbm_is_in_frustum",
     "orbm_triangulate_matches",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
@@ -103,6 +103,10 @@ def load():
                                                 i32, vp, C.POINTER(i32)]
     L.orbv_create.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(vp)]
     L.orbv_destroy.argtypes = [vp]
+    L.orbv_load_text.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.orbv_parse_text.argtypes = [C.c_char_p] + [C.POINTER(i32)] * 6 + [C.POINTER(vp)] * 5
+    L.orbv_free_parsed.argtypes = [vp]
+    L.orbv_free_parsed.restype = None
     L.orbv_transform.argtypes = [vp, vp, i32, i32, vp, vp, C.POINTER(i32), vp, vp, vp, C.POINTER(i32)]
     L.orbv_descend_device.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     L.orbv_score_l1.argtypes = [vp, vp, i32, vp, vp, i32]

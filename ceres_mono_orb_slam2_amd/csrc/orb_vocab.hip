@@ -17,6 +17,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -83,6 +85,72 @@ using namespace orbhip;
 extern "C" {
 
 int orbv_destroy(orbv_ctx* c);
+
+// ---- ORBvoc.txt: TemplatedVocabulary::loadFromTextFile (lib/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1423) ------------------
+// "k L scoring weighting" then one line per node (ids 1, 2, ... in file order; node 0 = root): "parent is_leaf d0 .. d31 weight".
+// Children keep the file order (m_nodes[pid].children.push_back), words are numbered in file order.  Host only (no device).
+// The reference's `while (!f.eof())` loop turns the empty line after the last '\n' into one more node (parent 0, descriptor
+// uninitialised memory): that accident is not reproduced - blank lines are skipped.
+int orbv_parse_text(const char* path, int32_t* k_out, int32_t* L_out, int32_t* scoring, int32_t* weighting, int32_t* n_nodes, int32_t* n_children,
+                    uint8_t** node_desc, uint32_t** child_off, uint32_t** children, int32_t** word_id, double** weight) {
+  ORBHIP_REQUIRE(path && n_nodes && n_children && node_desc && child_off && children && word_id && weight, ORBHIP_EINVAL, "NULL argument");
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { set_error("cannot open vocabulary file %s", path); return ORBHIP_EINVAL; }
+  std::fseek(f, 0, SEEK_END); const long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+  std::vector<char> buf((size_t)sz + 1);
+  const size_t got = std::fread(buf.data(), 1, (size_t)sz, f); std::fclose(f);
+  buf[got] = 0;
+  char* p = buf.data(); char* end = p + got;
+  auto next_line = [&](char*& a, char*& b) -> bool {              // [a, b) = next non-blank line
+    while (p < end) {
+      a = p; while (p < end && *p != '\n') p++;
+      b = p; if (p < end) p++;
+      for (char* q = a; q < b; q++) if (*q != ' ' && *q != '\r' && *q != '\t') return true;
+    }
+    return false;
+  };
+  char *a, *b;
+  if (!next_line(a, b)) { set_error("empty vocabulary file"); return ORBHIP_EINVAL; }
+  char* q = a;
+  const long k = std::strtol(q, &q, 10), L = std::strtol(q, &q, 10), n1 = std::strtol(q, &q, 10), n2 = std::strtol(q, &q, 10);
+  if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) { set_error("not a DBoW2 text vocabulary (header %ld %ld %ld %ld)", k, L, n1, n2); return ORBHIP_EINVAL; }
+  std::vector<int32_t> parent(1, -1), wid(1, -1); std::vector<uint8_t> desc(32, 0); std::vector<double> wt(1, 0.0);
+  int nwords = 0;
+  while (next_line(a, b)) {
+    q = a;
+    const long pid = std::strtol(q, &q, 10), leaf = std::strtol(q, &q, 10);
+    const size_t nid = parent.size();
+    if (pid < 0 || (size_t)pid >= nid) { set_error("vocabulary node %zu names parent %ld", nid, pid); return ORBHIP_EINVAL; }
+    parent.push_back((int32_t)pid);
+    for (int i = 0; i < 32; i++) desc.push_back((uint8_t)std::strtol(q, &q, 10));
+    wt.push_back(std::strtod(q, &q));
+    wid.push_back(leaf > 0 ? nwords++ : -1);
+  }
+  const size_t n = parent.size();
+  std::vector<uint32_t> off(n + 1, 0);
+  for (size_t i = 1; i < n; i++) off[parent[i] + 1]++;
+  for (size_t i = 0; i < n; i++) off[i + 1] += off[i];
+  std::vector<uint32_t> ch(n > 1 ? n - 1 : 1), fill(off.begin(), off.end() - 1);
+  for (size_t i = 1; i < n; i++) ch[fill[parent[i]]++] = (uint32_t)i;         // ascending node id = file order = push_back order
+  auto dup = [](const void* src, size_t bytes) { void* d = std::malloc(bytes ? bytes : 1); if (d && bytes) std::memcpy(d, src, bytes); return d; };
+  *node_desc = (uint8_t*)dup(desc.data(), desc.size()); *child_off = (uint32_t*)dup(off.data(), off.size() * 4); *children = (uint32_t*)dup(ch.data(), (n - 1) * 4);
+  *word_id = (int32_t*)dup(wid.data(), n * 4); *weight = (double*)dup(wt.data(), n * 8);
+  if (k_out) *k_out = (int32_t)k; if (L_out) *L_out = (int32_t)L; if (scoring) *scoring = (int32_t)n1; if (weighting) *weighting = (int32_t)n2;
+  *n_nodes = (int32_t)n; *n_children = (int32_t)(n - 1);
+  return 0;
+}
+void orbv_free_parsed(void* p) { std::free(p); }
+
+int orbv_create(const uint8_t* node_desc, const uint32_t* child_off, const uint32_t* children, const int32_t* word_id, const double* weight, int n_nodes, int L,
+                int device, orbv_ctx** out);
+int orbv_load_text(const char* path, int device, orbv_ctx** out) {
+  int32_t k = 0, L = 0, n = 0, nc = 0; uint8_t* nd = nullptr; uint32_t *co = nullptr, *ch = nullptr; int32_t* wi = nullptr; double* wt = nullptr;
+  if (int rc = orbv_parse_text(path, &k, &L, nullptr, nullptr, &n, &nc, &nd, &co, &ch, &wi, &wt)) return rc;
+  const int rc = orbv_create(nd, co, ch, wi, wt, n, L, device, out);
+  std::free(nd); std::free(co); std::free(ch); std::free(wi); std::free(wt);
+  return rc;
+}
+
 int orbv_create(const uint8_t* node_desc, const uint32_t* child_off, const uint32_t* children, const int32_t* word_id,
                 const double* weight, int n_nodes, int L, int device, orbv_ctx** out) {
   ORBHIP_REQUIRE(node_desc && child_off && children && word_id && weight && out && n_nodes > 1 && L > 0, ORBHIP_EINVAL, "NULL argument");

@@ -18,6 +18,16 @@ class ORBVocabulary:
         _lib.check(self._L.orbv_create(_lib.ptr(nd), _lib.ptr(co), _lib.ptr(ch), _lib.ptr(wi), _lib.ptr(wt), len(wi), int(L), int(device),
                                        C.byref(self._h)), "orbv_create")
 
+    @classmethod
+    def loadFromTextFile(cls, path, device=0):
+        """ORBVocabulary::loadFromTextFile (lib/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1423): ORBvoc.txt -> device-resident tree."""
+        self = cls.__new__(cls)
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._L.orbv_load_text(str(path).encode(), int(device), C.byref(self._h)), "orbv_load_text")
+        self.depth = None
+        return self
+
     def __del__(self):
         if getattr(self, "_h", None):
             self._L.orbv_destroy(self._h); self._h = None
@@ -47,3 +57,19 @@ class ORBVocabulary:
         w1 = np.ascontiguousarray(bow1[0], np.uint32); v1 = np.ascontiguousarray(bow1[1], np.float64)
         w2 = np.ascontiguousarray(bow2[0], np.uint32); v2 = np.ascontiguousarray(bow2[1], np.float64)
         return float(self._L.orbv_score_l1(_lib.ptr(w1), _lib.ptr(v1), len(w1), _lib.ptr(w2), _lib.ptr(v2), len(w2)))
+
+
+def parse_text(path):
+    """Host half of loadFromTextFile: the flattened arrays orbv_create takes.  No device needed."""
+    L = _lib.load()
+    ints = [C.c_int32() for _ in range(6)]
+    ptrs = [C.c_void_p() for _ in range(5)]
+    _lib.check(L.orbv_parse_text(str(path).encode(), *[C.byref(x) for x in ints], *[C.byref(x) for x in ptrs]), "orbv_parse_text")
+    k, depth, scoring, weighting, n, nc = [x.value for x in ints]
+    def take(ptr, dt, count):
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(max(count, 1),))[:count].copy()
+        L.orbv_free_parsed(ptr)
+        return a
+    return dict(k=k, L=depth, scoring=scoring, weighting=weighting, node_desc=take(ptrs[0], np.uint8, 32 * n).reshape(n, 32),
+                child_off=take(ptrs[1], np.uint32, n + 1), children=take(ptrs[2], np.uint32, nc), word_id=take(ptrs[3], np.int32, n),
+                weight=take(ptrs[4], np.float64, n))

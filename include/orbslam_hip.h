@@ -207,6 +207,15 @@ typedef struct orbv_ctx orbv_ctx;
 int orbv_create(const uint8_t* node_desc, const uint32_t* child_off /*[n_nodes+1]*/, const uint32_t* children,
                 const int32_t* word_id, const double* weight, int n_nodes, int L, int device, orbv_ctx** out);
 int orbv_destroy(orbv_ctx* ctx);
+/* ORBVocabulary::loadFromTextFile (lib/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1423) - ORBvoc.txt straight into the device-resident
+ * flattened tree: header "k L scoring weighting", then one node per line "parent is_leaf d0 .. d31 weight" (node ids in file
+ * order from 1, children in file order, word ids in file order).  orbv_parse_text is the host half alone (arrays allocated with
+ * malloc, release each with orbv_free_parsed); blank lines are skipped (the reference's eof loop turns the trailing one into a
+ * spurious child of the root with an uninitialised descriptor - not reproduced).                                              */
+int orbv_load_text(const char* path, int device, orbv_ctx** out);
+int orbv_parse_text(const char* path, int32_t* k, int32_t* L, int32_t* scoring, int32_t* weighting, int32_t* n_nodes, int32_t* n_children,
+                    uint8_t** node_desc, uint32_t** child_off, uint32_t** children, int32_t** word_id, double** weight);
+void orbv_free_parsed(void* p);
 /* desc[n][32] -> BowVector as ascending (bow_word[k], bow_value[k]), k < *n_words <= n, and FeatureVector as CSR:
  * node ids fv_node[m] ascending, features fv_idx[fv_off[m] .. fv_off[m+1]) ascending, m < *n_fv_nodes <= n (fv_off has n+1
  * entries) - the layout orbm_search_by_bow / orbm_search_for_triangulation take.  src/Frame.cc:322-327 uses levelsup = 4.
