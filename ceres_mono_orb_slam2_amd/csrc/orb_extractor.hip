@@ -875,6 +875,27 @@ __device__ __forceinline__ void det_sincos(double x, double* s_out, double* c_ou
   }
 }
 
+// The blurred 37 x 37 reach of a keypoint's rotated BRIEF pattern (|x|, |y| <= 13 -> radius 18) goes straight into LDS as 37
+// rows of 10 aligned dwords (LDS-direct loads, 64 dwords per instruction), requested as soon as the keypoint is known - i.e.
+// together with the orientation's own loads - so that the 512 byte gathers of the descriptor become LDS reads instead of a
+// second dependent global round trip.
+#define DESC_PATCH_R 18
+#define DESC_PATCH_W4 10
+#define DESC_PATCH_DW (37 * DESC_PATCH_W4)      // 370 dwords, 6 instructions
+#define DESC_PATCH_LDS 384
+template <int JJ>
+__device__ __forceinline__ void desc_patch_load(const uint8_t* base_al, uint32_t* lds, int lane, uint32_t pitch) {
+  if constexpr (JJ < 6) {
+    const uint32_t k = (uint32_t)lane + 64u * JJ;
+    const uint32_t row = (k * 6554u) >> 16;                    // k / 10 for k < 16384
+    const uint32_t goff = row * pitch + 4u * (k - row * (uint32_t)DESC_PATCH_W4);
+    if (k < (uint32_t)DESC_PATCH_DW)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base_al + goff),
+                                       (void __attribute__((address_space(3)))*)(lds + 64 * JJ), 4, 0, 0);
+    desc_patch_load<JJ + 1>(base_al, lds, lane, pitch);
+  }
+}
+
 #define DESC_WPB 4      // keypoints (= waves) per workgroup (1 / 2 / 4 / 8 / 16: 0.575 / 0.548 / 0.530 / 0.551 / 0.587 ms)
 __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uint32_t* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, const int* __restrict__ status,
@@ -887,6 +908,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   // intensity-centroid weights as byte vectors: for patch row |v| and source dword i (bytes k = 4i .. 4i+3 of the 31-byte row,
   // u = k - 15), s_icm holds [|u| <= umax[|v|]] and s_ick holds k * [..] - the row sums become v_dot4_u32_u8 on whole dwords
   __shared__ __attribute__((aligned(16))) uint32_t s_icm[16][8], s_ick[16][8];
+  __shared__ __attribute__((aligned(16))) uint32_t s_patch[DESC_WPB][2][DESC_PATCH_LDS];
   for (int q = threadIdx.x; q < 256; q += 64 * DESC_WPB) {
     s_pat[q] = ((const uint32_t*)c_pattern)[q];
     const int which = q >> 7, rv = (q >> 3) & 15, i4 = q & 7, d = c_umax[rv];
@@ -930,6 +952,20 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   const uint32_t key = valid ? key_any : (uint32_t)__builtin_amdgcn_readlane((int)key_any, 0);
   const int cx = (int)(key & 0xFFF) + L.minBX, cy = (int)((key >> 12) & 0xFFF) + L.minBY;
   const int resp = (int)(key >> 24);
+  // ---- the blurred patches of both keypoints of the wave are requested first (they are needed last) ----
+  const uint8_t* bimg = blur + (long long)f * G.blur_frame_bytes + L.blur_off + (long long)cy * L.bpitch + cx;
+  uint32_t bsh;                                               // byte offset of this half's patch inside its first LDS dword
+  {
+    const int wv = (int)(threadIdx.x >> 6);
+    const int cx0 = __builtin_amdgcn_readlane(cx, 0), cy0 = __builtin_amdgcn_readlane(cy, 0), cx1 = __builtin_amdgcn_readlane(cx, 32), cy1 = __builtin_amdgcn_readlane(cy, 32);
+    const uint8_t* lev = blur + (long long)f * G.blur_frame_bytes + L.blur_off;
+    const uint8_t* p0 = lev + (long long)(cy0 - DESC_PATCH_R) * L.bpitch + (cx0 - DESC_PATCH_R);
+    const uint8_t* p1 = lev + (long long)(cy1 - DESC_PATCH_R) * L.bpitch + (cx1 - DESC_PATCH_R);
+    const uint32_t s0 = (uint32_t)((size_t)p0 & 3), s1 = (uint32_t)((size_t)p1 & 3);
+    desc_patch_load<0>(p0 - s0, &s_patch[wv][0][0], lane, (uint32_t)L.bpitch);
+    desc_patch_load<0>(p1 - s1, &s_patch[wv][1][0], lane, (uint32_t)L.bpitch);
+    bsh = half ? s1 : s0;
+  }
   // ---- IC_Angle on the un-blurred level (src/ORBextractor.cc:77-104): lanes 0..30 of each half = rows -15..15 ------
   const uint8_t* img = level_ptr(G, level, f, img0, img_frame_bytes, pyr);
   int m10 = 0, m01 = 0;
@@ -974,7 +1010,10 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   double sd, cd;
   det_sincos((double)ang_rad, &sd, &cd);
   const float a = (float)cd, b = (float)sd;
-  const uint8_t* bimg = blur + (long long)f * G.blur_frame_bytes + L.blur_off + (long long)cy * L.bpitch + cx;
+  (void)bimg;
+  __builtin_amdgcn_s_waitcnt(0);                              // the patches have landed (their requests precede the orientation's loads)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  const uint8_t* lpatch = (const uint8_t*)&s_patch[threadIdx.x >> 6][half][0] + bsh + DESC_PATCH_R * (4 * DESC_PATCH_W4) + DESC_PATCH_R;   // pattern origin
   // pair index pr = 32 j + hl: consecutive lanes read consecutive pattern words, and the wave ballot of test j holds descriptor
   // dword j of the first keypoint in its low half and of the second keypoint in its high half (bit pr & 7 of byte pr >> 3)
   uint32_t mydw = 0;
@@ -988,7 +1027,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
       float fy = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
       float fx = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
       int iy = __float2int_rn(fy), ix = __float2int_rn(fx);
-      t[s] = bimg[(long long)iy * L.bpitch + ix];
+      t[s] = lpatch[iy * (4 * DESC_PATCH_W4) + ix];
     }
     const unsigned long long bal = __ballot(t[0] < t[1]);
     const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 #include "common.h"
 #include "orb_frame.h"
@@ -100,20 +101,24 @@ __global__ __launch_bounds__(256) void k_dist_csr(const uint8_t* __restrict__ q,
 }
 
 // ---- fused frame-pair matcher: brute force + acceptance + rotation consistency ------------------
-// one 1024-thread workgroup per pair; targets (<= MP_MAXT) live in LDS.
+// `nsplit` 1024-thread workgroups per pair; targets (<= max_targets) live in LDS of every one of them, the queries are dealt
+// out in 64-wide chunks (chunk g belongs to workgroup g % nsplit), so that two workgroups of one pair share a CU (2 x 76 kB of
+// LDS, 8 waves per SIMD) and few pairs still fill the chip.  With nsplit > 1 the rotation histogram is merged through global
+// memory: every workgroup adds its 30 bins to the pair's scratch row, and the LAST one to arrive (atomic ticket after a
+// device-scope fence) runs ComputeThreeMaxima and the filter pass over the whole pair, then clears the scratch for the next call.
 #define MP_THREADS 1024
-#define MP_Q 2
+template <int MP_Q>       // queries per thread: 2 when a pair is one workgroup (16 waves x 2 chunks = 2048 query slots), 1 when it is split
 __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint* __restrict__ kps,
                                                             const uint8_t* __restrict__ desc,
                                                             const int* __restrict__ counts, int cap,
                                                             const int* __restrict__ pair_a, const int* __restrict__ pair_b,
                                                             float ratio, int th, int check_ori,
                                                             int* __restrict__ match12, int* __restrict__ nmatch,
-                                                            int max_targets) {
+                                                            int max_targets, int nsplit, int* __restrict__ scratch /*[npairs][32]*/) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint4* s_t = (uint4*)smem;                                  // [max_targets * 2]
-  __shared__ int s_hist[HISTO_LENGTH], s_keep[3], s_n;
-  const int p = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_hist[HISTO_LENGTH], s_keep[3], s_n, s_last;
+  const int p = (int)blockIdx.x / nsplit, sp = (int)blockIdx.x % nsplit, tid = threadIdx.x;
   const int fa = pair_a[p], fb = pair_b[p];
   int n1 = counts[fa], n2 = counts[fb];
   n1 = n1 < 0 ? 0 : min(n1, cap);
@@ -128,21 +133,28 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
   for (int k = tid; k < 2 * n2; k += MP_THREADS) s_t[k] = T[k];
   __syncthreads();
   const float factor = 1.0f / HISTO_LENGTH;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int nchunk = (cap + 63) >> 6;                         // 64-wide query chunks of the pair
   // each thread keeps MP_Q queries in registers and walks the LDS-resident targets ONCE (every
   // broadcast ds_read_b128 of a target is reused MP_Q times)
-  for (int i0 = 0; i0 < cap; i0 += MP_THREADS * MP_Q) {
+  for (int c0 = 0; (c0 * nsplit + sp) < nchunk; c0 += (MP_THREADS / 64) * MP_Q) {
     uint4 q0[MP_Q], q1[MP_Q];
+    int qi[MP_Q];
     // best / second best as packed keys (distance << 16 | target index): "first minimum wins" is the lexicographic minimum
     // of (d, j), and the reference's second-best update (d < second, ties of the best included) is min(k2, max(k1, k)) -
     // one shift-or, two minima and one maximum per distance instead of two compares and four selects
     uint32_t k1[MP_Q], k2[MP_Q];
+    bool any_q = false;
 #pragma unroll
     for (int s = 0; s < MP_Q; s++) {
-      const int i = i0 + s * MP_THREADS + tid;
+      const int g = (c0 + wv * MP_Q + s) * nsplit + sp;                    // this wave's chunk (wave-uniform)
+      const int i = g * 64 + lane;
+      qi[s] = i;
       k1[s] = (256u << 16) | 0xFFFFu; k2[s] = (256u << 16) | 0xFFFFu;
       if (i < n1) { q0[s] = Q[2 * i]; q1[s] = Q[2 * i + 1]; } else { q0[s] = make_uint4(0, 0, 0, 0); q1[s] = q0[s]; }
+      any_q = any_q || (g * 64 < n1);
     }
-    if (i0 + (tid & ~63) < n1) {                         // whole wave beyond n1: nothing to do
+    if (any_q) {                                          // (whole wave beyond n1: nothing to do)
       for (int j = 0; j < n2; j++) {
         const uint4 t0 = s_t[2 * j], t1 = s_t[2 * j + 1];
 #pragma unroll
@@ -153,21 +165,17 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
         }
       }
     }
-    int b1[MP_Q], b2[MP_Q], bi[MP_Q];
 #pragma unroll
     for (int s = 0; s < MP_Q; s++) {
-      b1[s] = (int)(k1[s] >> 16); b2[s] = (int)(k2[s] >> 16);
-      bi[s] = (k1[s] & 0xFFFFu) == 0xFFFFu ? -1 : (int)(k1[s] & 0xFFFFu);       // (no target, or only targets at distance 256: rejected by the threshold either way)
-    }
-#pragma unroll
-    for (int s = 0; s < MP_Q; s++) {
-      const int i = i0 + s * MP_THREADS + tid;
+      const int i = qi[s];
+      const int b1 = (int)(k1[s] >> 16), b2 = (int)(k2[s] >> 16);
+      const int bi = (k1[s] & 0xFFFFu) == 0xFFFFu ? -1 : (int)(k1[s] & 0xFFFFu);       // (no target, or only targets at distance 256: rejected by the threshold either way)
       int res = -1;
-      if (i < n1 && bi[s] >= 0 && b1[s] <= th && (float)b1[s] < __fmul_rn(ratio, (float)b2[s])) {
-        res = bi[s];
+      if (i < n1 && bi >= 0 && b1 <= th && (float)b1 < __fmul_rn(ratio, (float)b2)) {
+        res = bi;
         int bin = 0;
         if (check_ori) {
-          float rot = __fsub_rn(KA[i].angle, KB[bi[s]].angle);
+          float rot = __fsub_rn(KA[i].angle, KB[bi].angle);
           if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
           bin = (int)roundf(__fmul_rn(rot, factor));
           if (bin == HISTO_LENGTH) bin = 0;
@@ -179,6 +187,20 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
     }
   }
   __syncthreads();
+  if (nsplit > 1) {
+    // merge: partial bins -> the pair's scratch row; the last workgroup of the pair to arrive finishes it
+    int* sc = scratch + (size_t)p * 32;
+    if (tid < HISTO_LENGTH && s_hist[tid]) atomicAdd(&sc[tid], s_hist[tid]);
+    __threadfence();                                        // (this workgroup's M entries and bins are visible device-wide)
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&sc[31], 1) == nsplit - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid < HISTO_LENGTH) { s_hist[tid] = __atomic_load_n(&sc[tid], __ATOMIC_RELAXED); sc[tid] = 0; }
+    if (tid == 31) sc[31] = 0;
+    __syncthreads();
+  }
   if (tid == 0) {
     int i1 = -1, i2 = -1, i3 = -1;
     if (check_ori) {                                          // ComputeThreeMaxima (:1386-1418)
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
   __syncthreads();
   int mine = 0;
   for (int i = tid; i < cap; i += MP_THREADS) {
-    int r = M[i];
+    int r = nsplit > 1 ? __atomic_load_n(&M[i], __ATOMIC_RELAXED) : M[i];       // (other workgroups wrote part of M)
     if (r >= 0) {
       int bin = r >> 24, j = r & 0xFFFFFF;
       if (check_ori && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) j = -1;
@@ -439,12 +461,41 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
     ORBHIP_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mu);
     if (dev < 0 || dev >= 64 || lds > attr_set[dev]) {
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_match_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_match_pairs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_match_pairs<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (dev >= 0 && dev < 64) attr_set[dev] = lds;
     }
   }
-  hipLaunchKernelGGL(k_match_pairs, dim3(npairs), dim3(MP_THREADS), lds, (hipStream_t)stream, d_kps, d_desc, d_counts,
-                     cap, d_pair_a, d_pair_b, ratio, th, check_ori, d_match12, d_nmatch, cap);
+  // workgroups per pair: one workgroup saturates a CU's issue slots (two per CU gain nothing: 256 pairs take 0.64 ms as 256
+  // workgroups, 0.67 ms as 512), so a launch is split until it has about one workgroup per CU - 64 pairs: 0.63 ms unsplit,
+  // 0.38 / 0.28 / 0.35 ms with 2 / 4 / 8 workgroups per pair.  ORBHIP_MATCH_SPLIT forces a value.
+  static const int force_split = []() { const char* e = std::getenv("ORBHIP_MATCH_SPLIT"); return e ? atoi(e) : 0; }();
+  const int nsplit = force_split > 0 ? force_split : std::min(8, std::max(1, 256 / npairs));
+  int* scratch = nullptr;
+  if (nsplit > 1) {
+    // per-device scratch rows {30 bins, -, ticket}, zero when allocated and left zero by every launch (the last workgroup of a
+    // pair clears its row); grown under a lock, only ever used by launches on the caller's stream
+    static std::mutex mu; static DevBuf buf[64]; static int rows[64] = {0};
+    int dev = 0;
+    ORBHIP_CHECK_HIP(hipGetDevice(&dev));
+    ORBHIP_REQUIRE(dev >= 0 && dev < 64, ORBHIP_EINVAL, "device ordinal out of range");
+    std::lock_guard<std::mutex> g(mu);
+    if (npairs > rows[dev]) {
+      ORBHIP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+      const int want = std::max(npairs, 1024);
+      if (int rc = buf[dev].ensure((size_t)want * 32 * sizeof(int))) return rc;
+      ORBHIP_CHECK_HIP(hipMemset(buf[dev].p, 0, (size_t)want * 32 * sizeof(int)));
+      ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+      rows[dev] = want;
+    }
+    scratch = buf[dev].as<int>();
+  }
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_match_pairs<1>, dim3(npairs * nsplit), dim3(MP_THREADS), lds, (hipStream_t)stream, d_kps, d_desc, d_counts,
+                       cap, d_pair_a, d_pair_b, ratio, th, check_ori, d_match12, d_nmatch, cap, nsplit, scratch);
+  else
+    hipLaunchKernelGGL(k_match_pairs<2>, dim3(npairs), dim3(MP_THREADS), lds, (hipStream_t)stream, d_kps, d_desc, d_counts,
+                       cap, d_pair_a, d_pair_b, ratio, th, check_ori, d_match12, d_nmatch, cap, 1, scratch);
   ORBHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
