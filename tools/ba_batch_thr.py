@@ -2,12 +2,12 @@
 import numpy as np, sys, time, os, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ceres_mono_orb_slam2_amd import synth, optimizer
-gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=2) for s in range(4)]
+gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(16)]      # as bench.py: gauge keyframe only, 16 distinct local maps
 local = np.ones(100, np.uint8)
 def prob(g): return (g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
 for spec in sys.argv[1:]:
     B, T = [int(x) for x in spec.split(":")]
-    probs = [prob(gs[i % 4]) for i in range(B)]
+    probs = [prob(gs[i % 16]) for i in range(B)]
     n_each = max(2, 48 // (B * T))
     bar = threading.Barrier(T + 1)
     def work():
