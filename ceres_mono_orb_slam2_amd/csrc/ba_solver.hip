@@ -927,8 +927,20 @@ __global__ void k_ba_pad(const BaDev* __restrict__ Dv) {
 
 // ---- dense blocked Cholesky (lower, in place), NB = 32 ---------------------------------------------------
 #define NB 32
-// panel: every workgroup factors the 32x32 diagonal block redundantly in ONE wave (left-looking, the block
-// lives in LDS, lane = row), inverts it (lane = column), workgroup 0 stores L11 and L11^-1; then every wave
+// Phase timing of the factorisation step kernels (tools/chol_phase_prof.py builds a scratch library with -DORBHIP_CHOL_PROF):
+// wave 0 of workgroup 0 of problem 0 stamps s_memrealtime (100 MHz) at the phase boundaries; sums per step index.
+#ifdef ORBHIP_CHOL_PROF
+__device__ unsigned long long g_chol_prof[128][10];
+#define CHOL_STAMP(i) do { if (prof_on) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+                              if (threadIdx.x == 0) g_chol_prof[prof_step][i] += t_ - prof_t; prof_t = t_; } } while (0)
+#define CHOL_PROF_BEGIN(step) const bool prof_on = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64; const int prof_step = (step) & 127; \
+                              unsigned long long prof_t = __builtin_amdgcn_s_memrealtime(); if (prof_on && threadIdx.x == 0) g_chol_prof[prof_step][9] += 1
+#else
+#define CHOL_STAMP(i) do { } while (0)
+#define CHOL_PROF_BEGIN(step) do { } while (0)
+#endif
+// panel: every workgroup factors and inverts the 32x32 diagonal block redundantly in ONE wave
+// (diag_factor_invert_wave below), workgroup 0 stores L11^-1; then every wave
 // forms 16 rows of L21 = A21 * L11^-T on the FP64 matrix cores (2 column tiles x 8 k-steps of
 // v_mfma_f64_16x16x4_f64).  Rows run to npad INCLUSIVE: row npad is the augmented rhs row.
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -937,12 +949,6 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {      // lane 
   lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
   return __hiloint2double(hi, lo);
 }
-// 32x32 Cholesky of the block in s_L (lower) by one wave: lane r keeps row r in registers.  Column j, once scaled, is
-// written to LDS (s_T[j][r]) and comes back to every lane as b128 BROADCAST reads for the rank-1 update; only the two
-// values on the critical path - the pivot and the pivot row's own entry l(j+1, j) - travel by v_readlane, so the
-// rsqrt chain of column j+1 overlaps the LDS round trip of column j.  (The first version broadcast every l(c, j) with
-// v_readlane: 1552 readlanes + 496 SGPR spills, 10.2 us; this one 5.3 us, tools/ubench/chol_panel.hip.)
-// A non-positive / non-finite pivot poisons the rest of the block (NaN) and is reported; the caller discards the step.
 // 1/sqrt(x) in fp64: hardware v_rsq_f64 estimate + two Newton steps (~1 ulp); avoids the long fp64 sqrt + divide
 // sequences on the 32-step critical path of the diagonal factorisation.
 __device__ __forceinline__ double rsqrt_f64(double x) {
@@ -956,70 +962,107 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
   y = fma(y, r, y);
   return y;
 }
-__device__ __forceinline__ int diag_factor_wave(double (*s_L)[NB + 1], double (*s_T)[NB], double* s_dinv) {
-  const int r = threadIdx.x & 31;
-  double row[NB];
+// ---- 32x32 diagonal block: Cholesky factor AND its inverse by ONE wave in ONE pass -----------------------------------
+// Right-looking factor, lane r (< 32) keeps row r of the block in registers: per column j, scale entry j by 1/sqrt(pivot j)
+// and subtract l(c, j) times it from every entry c > j.  Forward substitution of L x = e_c' does EXACTLY the same to the
+// entries of a column of the identity (x_j = sum_j / l(j, j), sum_c -= l(c, j) x_j), so lanes 32..63 - idle in the factor -
+// each carry one column of I through the same instructions and end up holding L^-1: there is no inverse phase (round 2:
+// factor 4.8 us + blocked inverse 1.8 us per step of k_chol_la; this: see DESIGN.md section 4).
+// One wave alone on its SIMD issues one instruction per ~4.5 cycles whatever it is (tools/ubench/f64_latency.hip), and it
+// stalls in order, so the body is arranged around that:
+//   * the loop-carried chain never touches a lane: the next pivot is formed from two uniform values read ahead of time
+//     (sa = a(j+1, j), sb = a(j+1, j+1) by v_readlane while the previous rsqrt chain runs), pivot' = sb - (sa y)^2 - bit for
+//     bit what lane j+1 computes for itself;
+//   * column j, once scaled, goes to LDS (s_T[j][lane]) and comes back to every lane as b128 broadcast reads - a 105-cycle
+//     round trip, so the reads are consumed ONE BODY LATER (entries j+1 and j+2, which the next two pivots need, get column
+//     j's update through v_readlane instead);
+//   * those deferred updates are placed between the Newton steps of the next pivot's rsqrt (sched_barriers pin the machine
+//     scheduler; PIN - an empty volatile asm with the value as in/out operand - keeps the IR from moving a pure operation
+//     across them; no conditional store inside the loop: it would split the basic block and the code sinker then collects
+//     every update behind the whole chain).
+// A non-positive / non-finite pivot poisons the rest of the block (NaN) and is reported; the caller discards the step.
+#define CHOL_SB() __builtin_amdgcn_sched_barrier(0)
+#define CHOL_PIN(x) asm volatile("" : "+v"(x))
+template <int J, int C0, int N>
+__device__ __forceinline__ void diag_prev_update(double (&acc)[NB], const double (&lp)[NB], const double mp) {     // column J-1 applied to entries C0 .. C0+N-1
+  if constexpr (J > 0) {
 #pragma unroll
-  for (int c = 0; c < NB; c++) row[c] = s_L[r][c];
-  int bad = 0;
-#pragma unroll
-  for (int j = 0; j < NB; j++) {
-    const double piv = bcast_lane(row[j], j);
-    bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
-    const double dinv = rsqrt_f64(piv);
-    if (threadIdx.x == j) s_dinv[j] = dinv;
-    row[j] = row[j] * dinv;                               // lane j: piv * dinv = sqrt(piv)
-    s_T[j][r] = row[j];
-    if (j + 1 < NB) { const double l = bcast_lane(row[j], j + 1); row[j + 1] = fma(-row[j], l, row[j + 1]); }
+    for (int q = 0; q < N; q++) if (C0 + q < NB) acc[C0 + q] = fma(-mp, lp[C0 + q], acc[C0 + q]);
+  }
+}
+// body J: y = 1/sqrt(pivot J); sa, sb as above; lp[c] = l(c, J-1) for c >= J+2 (requested one body earlier), mp = this
+// lane's scaled entry J-1
+template <int J>
+struct DiagCol {
+  static constexpr int U = 4;                                  // deferred updates per Newton operation
+  static __device__ __forceinline__ void run(double (&acc)[NB], const double (&lp)[NB], const double mp, const double y, const double sa, const double sb,
+                                             int& bad, double (*s_T)[64], const int lane) {
+    double l = 0.0, pivn = 1.0, hxn = 0.0, yn = 0.0;
+    if constexpr (J + 1 < NB) {
+      l = sa * y;
+      pivn = fma(-l, l, sb);
+      hxn = 0.5 * pivn;
+      yn = __builtin_amdgcn_rsq(pivn);
+      CHOL_PIN(yn); CHOL_PIN(hxn);
+      bad |= (!(pivn > 0.0) || !isfinite(pivn)) ? 1 : 0;
+    }
+    CHOL_SB();
+    acc[J] = acc[J] * y;                                       // lane J: pivot * y = sqrt(pivot); lane 32 + c': x_J of column c'
+    s_T[J][lane] = acc[J];                                     // (lanes 32..63 write the half of the row nobody reads)
+    if constexpr (J + 1 < NB) acc[J + 1] = fma(-acc[J], l, acc[J + 1]);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    int c = j + 2;
-    if (c < NB && (c & 1)) { const double l = s_T[j][c]; row[c] = fma(-row[j], l, row[c]); c++; }
+    double san = 0.0, sbn = 0.0;
+    if constexpr (J + 2 < NB) {
+      diag_prev_update<J, J + 2, 1>(acc, lp, mp);
+      const double l2 = bcast_lane(acc[J], J + 2);
+      acc[J + 2] = fma(-acc[J], l2, acc[J + 2]);
+      san = bcast_lane(acc[J + 1], J + 2);
+      sbn = bcast_lane(acc[J + 2], J + 2);
+    }
+    double lpn[NB];
+    if constexpr (J + 3 < NB) {
+      constexpr int ce = (J + 3) + ((J + 3) & 1);              // first even (16-byte aligned) entry
+      if constexpr (((J + 3) & 1) != 0) lpn[J + 3] = s_T[J][J + 3];
 #pragma unroll
-    for (; c + 1 < NB; c += 2) {
-      const double2 l = *(const double2*)&s_T[j][c];
-      row[c] = fma(-row[j], l.x, row[c]);
-      row[c + 1] = fma(-row[j], l.y, row[c + 1]);
+      for (int c = ce; c + 1 < NB; c += 2) { const double2 v = *(const double2*)&s_T[J][c]; lpn[c] = v.x; lpn[c + 1] = v.y; }
+    }
+    if constexpr (J + 1 < NB) {
+      constexpr int c0 = J + 3;
+      CHOL_SB(); double t = hxn * yn;
+      CHOL_SB(); diag_prev_update<J, c0, U>(acc, lp, mp);
+      CHOL_SB(); double e = fma(-t, yn, 0.5);
+      CHOL_SB(); diag_prev_update<J, c0 + U, U>(acc, lp, mp);
+      CHOL_SB(); yn = fma(yn, e, yn);
+      CHOL_SB(); diag_prev_update<J, c0 + 2 * U, U>(acc, lp, mp);
+      CHOL_SB(); t = hxn * yn;
+      CHOL_SB(); diag_prev_update<J, c0 + 3 * U, U>(acc, lp, mp);
+      CHOL_SB(); e = fma(-t, yn, 0.5);
+      CHOL_SB(); diag_prev_update<J, c0 + 4 * U, U>(acc, lp, mp);
+      CHOL_SB(); yn = fma(yn, e, yn); CHOL_PIN(yn);
+      CHOL_SB(); diag_prev_update<J, c0 + 5 * U, NB>(acc, lp, mp);
+      CHOL_SB();
+      DiagCol<J + 1>::run(acc, lpn, acc[J], yn, san, sbn, bad, s_T, lane);
     }
   }
-  if (threadIdx.x < NB) {
+};
+// in: s_L = the block (lower triangle, zeros above); out: s_X = L^-1 (full 32x32, zeros above the diagonal).  L itself stays
+// in registers and is dropped: nothing downstream reads it (the L21 rows and the substitutions use L^-1).  One wave (64 lanes).
+__device__ __forceinline__ int diag_factor_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1], double (*s_T)[64]) {
+  const int lane = threadIdx.x & 63, r = lane & 31;
+  double acc[NB], lp0[NB];
 #pragma unroll
-    for (int c = 0; c < NB; c++) s_L[r][c] = (c <= r) ? row[c] : 0.0;
+  for (int c = 0; c < NB; c++) { acc[c] = (lane < 32) ? s_L[r][c] : ((c == r) ? 1.0 : 0.0); lp0[c] = 0.0; }
+  int bad = 0;
+  const double piv = bcast_lane(acc[0], 0);
+  bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
+  const double y0 = rsqrt_f64(piv);
+  const double sa = bcast_lane(acc[0], 1), sb = bcast_lane(acc[1], 1);
+  DiagCol<0>::run(acc, lp0, 0.0, y0, sa, sb, bad, s_T, lane);
+  if (lane >= 32) {
+#pragma unroll
+    for (int rr = 0; rr < NB; rr++) s_X[rr][r] = acc[rr];      // column r of L^-1 (the zeros above the diagonal come out by themselves)
   }
   return bad;
-}
-// X = L^-1 in 16x16 blocks: the diagonal blocks X11 = L11^-1 and X22 = L22^-1 by lanes (lane = one column of one block,
-// a 120-term substitution instead of 496), then X21 = -X22 (L21 X11) as two 16x16x16 products on the FP64 matrix cores
-// (5.9 -> 2.3 us).
-__device__ __forceinline__ void diag_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1], double (*s_T)[NB], const double* s_dinv) {
-  const int lane = threadIdx.x & 63;
-  const int c = lane & 15, b = lane & 16;
-  {
-    double x[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; rr++) {
-      double sum = (rr == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int m = 0; m < rr; m++) sum = fma(-s_L[b + rr][b + m], x[m], sum);
-      x[rr] = sum * s_dinv[b + rr];
-    }
-    if (lane < 32) {
-#pragma unroll
-      for (int rr = 0; rr < 16; rr++) { s_X[b + rr][b + c] = x[rr]; if (b == 0) s_X[rr][16 + c] = 0.0; }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-  const int li = lane & 15, lk = lane >> 4;                 // MFMA operands: A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15]
-  double4_t t = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) t = __builtin_amdgcn_mfma_f64_16x16x4f64(s_L[16 + li][4 * ks + lk], s_X[4 * ks + lk][li], t, 0, 0, 0);
-#pragma unroll
-  for (int rg = 0; rg < 4; rg++) s_T[lk + 4 * rg][li] = t[rg];     // C layout: row = (lane >> 4) + 4 * reg, col = lane & 15
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-  double4_t u = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) u = __builtin_amdgcn_mfma_f64_16x16x4f64(s_X[16 + li][16 + 4 * ks + lk], s_T[4 * ks + lk][li], u, 0, 0, 0);
-#pragma unroll
-  for (int rg = 0; rg < 4; rg++) s_X[16 + lk + 4 * rg][li] = -u[rg];
 }
 // G = groups of 16 L21 rows per wave.  Every workgroup repeats the diagonal factor, so a lockstep batch (throughput-bound)
 // runs G = 4 (256 rows per workgroup: 3.3x fewer repeated factors at n = 600, +8 % solves/s), while a single problem
@@ -1033,8 +1076,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
   const StFlags F = ld_flags(st);
   __shared__ double s_L[NB][NB + 1];
   __shared__ double s_X[NB][NB + 1];
-  __shared__ double s_dinv[NB];
-  __shared__ __attribute__((aligned(16))) double s_T[NB][NB];   // factor: column broadcast buffer; inverse: L21 X11
+  __shared__ __attribute__((aligned(16))) double s_T[NB][64];   // column broadcast buffer of the factor
   __shared__ int s_fail;
   const int np = D.npad, tid = threadIdx.x;
   if (k >= np || k + NB + (int)blockIdx.x * (64 * G) > np) return;     // beyond this problem's matrix (batched launch)
@@ -1061,11 +1103,8 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
   if (tid == 0) s_fail = 0;
   __syncthreads();
   if (tid < 64) {
-    const int fail = diag_factor_wave(s_L, s_T, s_dinv);
+    const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
     if (fail && tid == 0) s_fail = 1;
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
-    diag_invert_wave(s_L, s_X, s_T, s_dinv);
   }
   __syncthreads();
   if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
@@ -1230,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   if (!D.chol_la) return;
   BaState* st = D.st;
   const StFlags F = ld_flags(st);
-  __shared__ __attribute__((aligned(16))) double s_raw[5 * NB * (NB + 1) + NB];
+  __shared__ __attribute__((aligned(16))) double s_raw[4 * NB * (NB + 1) + NB * 64];
   const int np = D.npad, tid = threadIdx.x;
   if ((int)blockIdx.x >= nA) {
     double (*s_A)[NB + 1] = (double (*)[NB + 1])s_raw;
@@ -1242,10 +1281,10 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_raw + NB * (NB + 1));
   double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_raw + 2 * NB * (NB + 1));
   double (*s_M)[NB + 1] = (double (*)[NB + 1])(s_raw + 3 * NB * (NB + 1));
-  double (*s_T)[NB] = (double (*)[NB])(s_raw + 4 * NB * (NB + 1));          // 16-byte aligned: 4 * 32 * 33 * 8 bytes
-  double* s_dinv = s_raw + 4 * NB * (NB + 1) + NB * NB;
+  double (*s_T)[64] = (double (*)[64])(s_raw + 4 * NB * (NB + 1));          // 16-byte aligned: 4 * 32 * 33 * 8 bytes
   __shared__ int s_fail;
   if (k >= np || k + NB + (int)blockIdx.x * (64 * G) > np) return;     // beyond this problem's matrix (batched launch)
+  CHOL_PROF_BEGIN(k / NB);
   double* S = D.S;
   const bool upd = k > 0;
   const int kp = k - NB;
@@ -1275,6 +1314,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; s_L[i / NB][i % NB] = d4[u]; s_P[i / NB][i % NB] = p4[u]; }
   if (tid == 0) s_fail = 0;
   __syncthreads();
+  CHOL_STAMP(0);                                              // loads landed
   const int ti = w >> 1, tj = w & 1;                         // this wave's 16x16 tile of the 32x32 products
   if (upd) {
     if (tj <= ti) {                                           // D -= P P^T on the lower tiles
@@ -1289,14 +1329,14 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
     }
     __syncthreads();
   }
+  CHOL_STAMP(1);                                              // D -= P P^T
   if (tid < 64) {
-    const int fail = diag_factor_wave(s_L, s_T, s_dinv);
+    const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
     if (fail && tid == 0) s_fail = 1;
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
-    diag_invert_wave(s_L, s_X, s_T, s_dinv);
+    CHOL_STAMP(2);                                            // factor + inverse
   }
   __syncthreads();
+  CHOL_STAMP(3);
   if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
   if (upd) {                                                  // M = X P, one 16x16 tile per wave
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -1313,6 +1353,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
     b0[ks] = s_X[li][4 * ks + lk]; b1[ks] = s_X[16 + li][4 * ks + lk];     // B[k][j] = X[j][k]
     m0[ks] = upd ? s_M[li][4 * ks + lk] : 0.0; m1[ks] = upd ? s_M[16 + li][4 * ks + lk] : 0.0;
   }
+  CHOL_STAMP(4);                                              // M = X P + operand reads
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const int rg0 = row0 + 16 * g;
@@ -1339,6 +1380,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
       }
     }
   }
+  CHOL_STAMP(5);                                              // L21 on the matrix cores + stores
   if (blockIdx.x == 0) {                                      // L11 and L11^-1 leave last: nothing in this launch waits for them
     double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
     for (int i = tid; i < NB * NB; i += 256) {
@@ -1348,6 +1390,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
       Di[i] = s_X[r][c];
     }
   }
+  CHOL_STAMP(6);                                              // L11^-1 store
 }
 
 // backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
@@ -2739,6 +2782,15 @@ int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations) {
   g_prof_ms = 0.0; g_prof_solves = 0; g_prof_iters = 0;
   return 0;
 }
+
+#ifdef ORBHIP_CHOL_PROF
+int ba_debug_chol_prof(unsigned long long* out, int reset) {     // [128][10]: ticks per phase summed over launches, [9] = launches
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  if (out) ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_prof), sizeof(unsigned long long) * 128 * 10));
+  if (reset) { static unsigned long long z[128 * 10]; ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_chol_prof), z, sizeof(z))); }
+  return 0;
+}
+#endif
 
 // ---- 7-vector pose codec (src/MatEigenConverter.cc:66-85); T = row-major 4x4 ------------------------------------------
 // Matrix4dToMatrix_7_1: [t, Eigen::Quaterniond(R).coeffs()] -- Eigen's matrix -> quaternion conversion branches on the
