@@ -1263,10 +1263,18 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv,
 //   role B (remaining workgroups): the previous step's update of everything to the RIGHT of this column block (and of the
 //     augmented rhs row) - the old k_chol_syrk body, now off the critical path because it runs beside the factor.
 // Same launch count as panels alone; deterministic (fixed MFMA order).
+// Larger systems (hybrid = 1: the problems with chol_la == 0) run the same kernel INSIDE each 128-column outer block of the
+// two-level scheme: k0 = first column of the outer block (its first step has no pending update: everything older was applied
+// by the K = 128 updates), c_cap = its end (role B stops there; the rest of the matrix gets the four panels at once).
+//   role C (workgroups behind role B): a share of the PREVIOUS outer block's K = 128 update of everything to the right of
+//     this outer block.  That update is needed only after this block's steps, so it is taken off the serial chain and dealt
+//     out over this block's launches (tile t goes to step t mod nq), beside the latency-bound panel work.  (A second stream
+//     joined by events inside the captured graph was tried first: ~40 us per fork / join, slower than no overlap at all.)
+struct CholWide { int kcol, K, lo, tiles_c, total, nrhs, q, nq; };     // total = tiles of the whole update; nq = 0: no role C
 template <int G>
-__global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, int k, int nA, int tiles_c, int ntiles) {
+__global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, int k, int k0, int c_cap, int nA, int tiles_c, int ntiles, int nB, int hybrid, CholWide wd) {
   const BaDev D = Dv[blockIdx.y];
-  if (!D.chol_la) return;
+  if ((D.chol_la != 0) == (hybrid != 0)) return;
   BaState* st = D.st;
   const StFlags F = ld_flags(st);
   __shared__ __attribute__((aligned(16))) double s_raw[4 * NB * (NB + 1) + NB * 64];
@@ -1274,7 +1282,13 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   if ((int)blockIdx.x >= nA) {
     double (*s_A)[NB + 1] = (double (*)[NB + 1])s_raw;
     double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_raw + 64 * (NB + 1));
-    chol_syrk_body(D, st, (int)blockIdx.x - nA, k - NB, NB, k + NB, k + NB, INT_MAX, tiles_c, ntiles, s_A, s_B);
+    const int bb = (int)blockIdx.x - nA;
+    if (bb < nB) chol_syrk_body(D, st, bb, k - NB, NB, k + NB, k + NB, c_cap, tiles_c, ntiles, s_A, s_B);
+    else {
+      const int wi = bb - nB, cnt = (wd.total - wd.q + wd.nq - 1) / wd.nq;          // this step's tiles: q, q + nq, q + 2 nq, ...
+      const int bx = wi < cnt ? wd.q + wi * wd.nq : wd.total + (wi - cnt);           // behind them (step 0 only): the rhs-row workgroups
+      chol_syrk_body(D, st, bx, wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B);
+    }
     return;
   }
   double (*s_L)[NB + 1] = (double (*)[NB + 1])s_raw;
@@ -1286,7 +1300,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   if (k >= np || k + NB + (int)blockIdx.x * (64 * G) > np) return;     // beyond this problem's matrix (batched launch)
   CHOL_PROF_BEGIN(k / NB);
   double* S = D.S;
-  const bool upd = k > 0;
+  const bool upd = k > k0;
   const int kp = k - NB;
   const int w = tid >> 6, lane = tid & 63;
   const int row0 = k + NB + (blockIdx.x * 4 + w) * (16 * G);
@@ -2282,32 +2296,61 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     if (g_n6 > 0) hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)((g_zero + 255) / 256)), ny), dim3(256), 0, s, Dv);
     if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), 0, s, Dv);
     const int npad = B.g_npad_2l;                             // (0 when every problem of the batch takes the look-ahead scheme)
-    auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
+    auto launch_update = [&](hipStream_t st_, int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
       if (c_hi <= c_lo || r_lo >= npad + 1) return;
       const int tiles_r = (npad - r_lo + 63) / 64, tiles_c = (c_hi - c_lo + 63) / 64;
       const int ntiles = std::max(tiles_r, 0) * tiles_c;
       const int nrhs = (c_hi - c_lo + 255) / 256;
-      hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs, ny), dim3(256), 0, s, Dv, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles);
+      hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs, ny), dim3(256), 0, st_, Dv, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles);
     };
-    // look-ahead scheme (reduced systems <= 1024): one launch per 32-column step, panel + the previous step's update
-    for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) {
-      const int rows_below = npl - k - NB;
-      const int r_lo = k + NB;
+    // one look-ahead step: panel k + the previous step's update of the columns [k + 32, c_end) (c_end = min(cap, n))
+    // + (hybrid) this step's share of the previous outer block's wide update
+    auto launch_la = [&](int np_, int k, int k0, int c_cap, int hybrid, CholWide w) {
+      const int rows_below = np_ - k - NB;
+      const int r_lo = k + NB, c_end = std::min(c_cap, np_);
       int tiles_c = 1, ntiles = 0, nrhs = 0;
-      if (k > 0 && r_lo < npl) { tiles_c = (npl - r_lo + 63) / 64; ntiles = tiles_c * tiles_c; nrhs = (npl - r_lo + 255) / 256; }
-      if (ny >= 4) { const int nA = (rows_below + 1 + 255) / 256; hipLaunchKernelGGL(k_chol_la<4>, dim3(nA + ntiles + nrhs, ny), dim3(256), 0, s, Dv, k, nA, tiles_c, ntiles); }
-      else { const int nA = (rows_below + 1 + 63) / 64; hipLaunchKernelGGL(k_chol_la<1>, dim3(nA + ntiles + nrhs, ny), dim3(256), 0, s, Dv, k, nA, tiles_c, ntiles); }
-    }
-    const int OB = 128;                                       // two-level scheme: outer block = 4 panels of NB = 32
-    for (int k0 = 0; k0 < npad; k0 += OB) {
-      const int kend = std::min(k0 + OB, npad);
-      for (int k = k0; k < kend; k += NB) {
-        const int rows_below = npad - k - NB;
-        if (ny >= 4 && npad <= 1024) hipLaunchKernelGGL(k_chol_panel<4>, dim3((rows_below + 1 + 255) / 256, ny), dim3(256), 0, s, Dv, k);
-        else hipLaunchKernelGGL(k_chol_panel<1>, dim3((rows_below + 1 + 63) / 64, ny), dim3(256), 0, s, Dv, k);   // +1: augmented rhs row
-        if (k + NB < kend) launch_update(k, NB, k + NB, k + NB, kend, k0 + OB);      // thin update inside the outer block
+      if (k > k0 && r_lo < c_end) { tiles_c = (c_end - r_lo + 63) / 64; ntiles = ((np_ - r_lo + 63) / 64) * tiles_c; nrhs = (c_end - r_lo + 255) / 256; }
+      const int nC = w.nq > 0 ? (w.total - w.q + w.nq - 1) / w.nq + (w.q == 0 ? w.nrhs : 0) : 0;
+      if (ny >= 4 && np_ <= 1024) { const int nA = (rows_below + 1 + 255) / 256; hipLaunchKernelGGL(k_chol_la<4>, dim3(nA + ntiles + nrhs + nC, ny), dim3(256), 0, s, Dv, k, k0, c_cap, nA, tiles_c, ntiles, ntiles + nrhs, hybrid, w); }
+      else { const int nA = (rows_below + 1 + 63) / 64; hipLaunchKernelGGL(k_chol_la<1>, dim3(nA + ntiles + nrhs + nC, ny), dim3(256), 0, s, Dv, k, k0, c_cap, nA, tiles_c, ntiles, ntiles + nrhs, hybrid, w); }
+    };
+    const CholWide no_wide = {0, 0, 0, 1, 0, 0, 0, 0};
+    // look-ahead scheme (reduced systems <= 1024): one launch per 32-column step, panel + the previous step's update
+    for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) launch_la(npl, k, 0, INT_MAX, 0, no_wide);
+    // two-level scheme (outer block = 4 panels of NB = 32) for the larger systems.
+    const int OB = 128;
+    static const bool classic = []() { const char* e = std::getenv("ORBHIP_BA_2L_CLASSIC"); return e && e[0] == '1'; }();
+    if (classic) {
+      // round-1 form: panel -> thin update -> panel ... -> one wide update
+      for (int k0 = 0; k0 < npad; k0 += OB) {
+        const int kend = std::min(k0 + OB, npad);
+        for (int k = k0; k < kend; k += NB) {
+          const int rows_below = npad - k - NB;
+          if (ny >= 4 && npad <= 1024) hipLaunchKernelGGL(k_chol_panel<4>, dim3((rows_below + 1 + 255) / 256, ny), dim3(256), 0, s, Dv, k);
+          else hipLaunchKernelGGL(k_chol_panel<1>, dim3((rows_below + 1 + 63) / 64, ny), dim3(256), 0, s, Dv, k);   // +1: augmented rhs row
+          if (k + NB < kend) launch_update(s, k, NB, k + NB, k + NB, kend, k0 + OB);      // thin update inside the outer block
+        }
+        if (kend < npad) launch_update(s, k0, kend - k0, kend, kend, npad, INT_MAX);      // one wide update for everything to the right
       }
-      if (kend < npad) launch_update(k0, kend - k0, kend, kend, npad, INT_MAX);      // one wide update for everything to the right
+    } else if (npad > 0) {
+      // hybrid: the steps of an outer block are look-ahead launches confined to the block (the thin updates leave the serial
+      // chain); of its K = 128 update only the NEXT outer block's 128 columns are a launch of their own (the chain needs
+      // them), everything further right rides along with the next block's steps (role C).  One stream: every entry still
+      // receives its updates in one fixed order.
+      CholWide w = no_wide;
+      for (int k0 = 0; k0 < npad; k0 += OB) {
+        const int kend = std::min(k0 + OB, npad);
+        w.nq = w.total > 0 ? (kend - k0) / NB : 0;
+        for (int k = k0, q = 0; k < kend; k += NB, q++) { w.q = q; launch_la(npad, k, k0, k0 + OB, 1, w); }
+        w = no_wide;
+        if (kend >= npad) break;
+        const int nend = std::min(kend + OB, npad);
+        launch_update(s, k0, kend - k0, kend, kend, nend, kend + OB);
+        if (nend < npad) {
+          const int t = (npad - nend + 63) / 64;
+          w.kcol = k0; w.K = kend - k0; w.lo = nend; w.tiles_c = t; w.total = t * t; w.nrhs = (npad - nend + 255) / 256;
+        }
+      }
     }
     for (int kb = ((npad_all - 1) / SBLK) * SBLK; kb >= 0; kb -= SBLK) {
       hipLaunchKernelGGL(k_chol_bsolve_diag, dim3(1, ny), dim3(1024), 0, s, Dv, kb);
