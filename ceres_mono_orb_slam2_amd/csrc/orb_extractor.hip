@@ -204,22 +204,30 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 }
 
 // ---------------------------------------------------------------------------- k_fast_cells
-// FAST-9 "best" of one pixel for BOTH polarities at once with packed 16-bit min/max (v_pk_min_i16):
-// lane .x carries d[k] = p - ring[k] (ring darker), lane .y carries -d[k] (ring brighter).  For each
-// polarity: max over the sixteen 9-arcs of the min over the arc (sliding-window min by doubling).
+// FAST-9 "best" of one pixel for BOTH polarities at once with packed 16-bit min/max (v_pk_min_i16), on the RAW ring values:
+// P[k] = (ring[k], -ring[k]) as two i16 (ONE v_mul_i32_i24 by -65535: r * (1 - 2^16) = r + ((-r) << 16)).  A window minimum then
+// holds (min ring, -max ring), the maximum over the sixteen 9-arcs (max_arcs min_arc ring, -min_arcs max_arc ring) = (B, -A), and
+//   best = max over arcs of min over the arc of |v - ring| with one sign = max(B - v, v - A) = halves of (B, -A) - (v, -v).
+// The sixteen arcs share their 8-windows pairwise (the structure of OpenCV's cornerScore<16>): with m8[j] = min P[j .. j+7] for the
+// eight ODD j, the arcs starting at j-1 and at j are min(P[j-1], m8[j]) and min(m8[j], P[j+8]), whose maximum is
+// min(m8[j], max(P[j-1], P[j+8])) - 8 + 8 + 8 window minima, 8 max, 8 min, 7 max = 47 packed operations per pixel (the first
+// version differenced and negated every ring value and ran the doubling on all sixteen positions: 48 + 80).
 typedef short short2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int arc9_best_packed(const short2_t d[16]) {
-  short2_t m2[16], m4[16], m8[16];
+__device__ __forceinline__ short2_t ring_pair(int r) { return __builtin_bit_cast(short2_t, __mul24(r, -65535)); }
+__device__ __forceinline__ int arc9_best_packed(const short2_t P[16], int v) {
+  short2_t m2[8], m4[8], m8[8];
 #pragma unroll
-  for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+  for (int i = 0; i < 8; i++) m2[i] = __builtin_elementwise_min(P[2 * i + 1], P[(2 * i + 2) & 15]);     // min P[j .. j+1], j = 2i + 1
 #pragma unroll
-  for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+  for (int i = 0; i < 8; i++) m4[i] = __builtin_elementwise_min(m2[i], m2[(i + 1) & 7]);                // min P[j .. j+3]
 #pragma unroll
-  for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-  short2_t best = {-1000, -1000};
+  for (int i = 0; i < 8; i++) m8[i] = __builtin_elementwise_min(m4[i], m4[(i + 2) & 7]);                // min P[j .. j+7]
+  short2_t best = __builtin_elementwise_min(m8[0], __builtin_elementwise_max(P[0], P[9]));
 #pragma unroll
-  for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
-  return max((int)best.x, (int)best.y);
+  for (int i = 1; i < 8; i++)
+    best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[i], __builtin_elementwise_max(P[2 * i], P[(2 * i + 9) & 15])));
+  const short2_t e = best - ring_pair(v);                   // (B - v, v - A): both within +-255
+  return max((int)e.x, (int)e.y);
 }
 
 // Phase timing of k_fast_cells (tools/fast_phase_prof.py builds a separate library with -DORBHIP_FAST_PROF): every wave
@@ -241,8 +249,8 @@ __device__ __forceinline__ void fast_tile_load(const uint8_t* base, uint8_t* til
   if constexpr (JJ < FAST_TILE_LOADS) {
     if (64 * JJ >= ndw) return;                                // (wave-uniform)
     const uint32_t k = (uint32_t)lane + 64u * JJ;
-    const uint32_t row = (k * inv) >> 16;
-    const uint32_t goff = row * pitch + 4u * (k - row * (uint32_t)W4);
+    const uint32_t row = __umul24(k, inv) >> 16;                // (all factors < 2^24: full-rate v_mul_u32_u24 instead of quarter-rate v_mul_lo_u32)
+    const uint32_t goff = __umul24(row, pitch) + 4u * (k - __umul24(row, (uint32_t)W4));
     if ((int)k < ndw)
       // (the instruction's immediate offset would be added to BOTH the global and the LDS address: the LDS position goes
       // through M0 instead - tools/ubench/lds_direct.hip)
@@ -335,9 +343,10 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
       const int iyl = iy0 + lr;
       const int iy = min(iyl, ih - 1);                          // (clamped: rows outside are masked, their reads stay inside the tile)
       // byte offsets of the three quads inside the (shifted) LDS row: c12 at 4g + bsh, v / c0 / c8 at 4g + 3 + bsh, c4 at 4g + 6 + bsh
-      const uint32_t* rc = (const uint32_t*)(tile + (iy + 3) * TP) + g;
-      const uint32_t* ru = (const uint32_t*)(tile + iy * TP) + g + qv;         // ring point 8 (row - 3)
-      const uint32_t* rd = (const uint32_t*)(tile + (iy + 6) * TP) + g + qv;   // ring point 0 (row + 3)
+      const int rowoff = __mul24(iy, TP);
+      const uint32_t* rc = (const uint32_t*)(tile + rowoff + 3 * TP) + g;
+      const uint32_t* ru = (const uint32_t*)(tile + rowoff) + g + qv;            // ring point 8 (row - 3)
+      const uint32_t* rd = (const uint32_t*)(tile + rowoff + 6 * TP) + g + qv;   // ring point 0 (row + 3)
       const uint32_t e0 = rc[0], e1 = rc[1], v0 = rc[qv], v1 = rc[qv + 1], f0 = rc[q4], f1 = rc[q4 + 1], u0 = ru[0], u1 = ru[1], b0 = rd[0], b1 = rd[1];
       const uint32_t vq = __builtin_amdgcn_alignbyte(v1, v0, sv), c8q = __builtin_amdgcn_alignbyte(u1, u0, sv), c0q = __builtin_amdgcn_alignbyte(b1, b0, sv);
       const uint32_t c12q = __builtin_amdgcn_alignbyte(e1, e0, bsh), c4q = __builtin_amdgcn_alignbyte(f1, f0, s4);
@@ -376,16 +385,16 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   // ---- pass B: FAST-9 score at the LOW threshold; one map serves both thresholds --------
   for (int k = lane; k < qn; k += 64) {
     const int q = queue[k], iy = q >> 8, ix = q & 255;
-    const uint8_t* p = tileb + (iy + 3) * TP + ix + 3;
+    const uint8_t* p = tileb + __mul24(iy + 3, TP) + ix + 3;
     const int v = p[0];
     short2_t d[16];
-    auto mk = [&](int r) { const short dd = (short)(v - r); short2_t t = {dd, (short)(-dd)}; return t; };
+    auto mk = [&](int r) { return ring_pair(r); };
     d[0] = mk(p[3 * TP]);         d[1] = mk(p[3 * TP + 1]);   d[2] = mk(p[2 * TP + 2]);   d[3] = mk(p[TP + 3]);
     d[4] = mk(p[3]);              d[5] = mk(p[-TP + 3]);      d[6] = mk(p[-2 * TP + 2]);  d[7] = mk(p[-3 * TP + 1]);
     d[8] = mk(p[-3 * TP]);        d[9] = mk(p[-3 * TP - 1]);  d[10] = mk(p[-2 * TP - 2]); d[11] = mk(p[-TP - 3]);
     d[12] = mk(p[-3]);            d[13] = mk(p[TP - 3]);      d[14] = mk(p[2 * TP - 2]);  d[15] = mk(p[3 * TP - 1]);
-    const int best = arc9_best_packed(d);             // corner at t  <=>  best > t ; score = best - 1
-    if (best > minTh) score[(iy + 3) * TP + ix + 3] = (uint8_t)(best - 1);
+    const int best = arc9_best_packed(d, v);             // corner at t  <=>  best > t ; score = best - 1
+    if (best > minTh) score[__mul24(iy + 3, TP) + ix + 3] = (uint8_t)(best - 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   FAST_STAMP(2);       // 9-arc score
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   int any20 = 0;
   for (int k = lane; k < qn; k += 64) {
     const int q = queue[k], iy = q >> 8, ix = q & 255;
-    const uint8_t* sp = score + (iy + 3) * TP + ix + 3;
+    const uint8_t* sp = score + __mul24(iy + 3, TP) + ix + 3;
     const int v = sp[0];
     // (all nine reads unconditional and the comparison without short-circuit: one LDS round trip per queued pixel)
     const int n0 = sp[-TP - 1], n1 = sp[-TP], n2 = sp[-TP + 1], n3 = sp[-1], n4 = sp[1], n5 = sp[TP - 1], n6 = sp[TP], n7 = sp[TP + 1];
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     unsigned long long m = mrow;
     int pos = incl - cnt;
     const uint32_t yv = (uint32_t)(lane + 3 + c.offy) << 12;
-    const uint8_t* srow = score + (lane + 3) * TP + 3;
+    const uint8_t* srow = score + __mul24(lane + 3, TP) + 3;
     while (m) {
       const int ix = __ffsll((long long)m) - 1;
       m &= m - 1;
