@@ -6,8 +6,11 @@
 //
 // TEST INFRASTRUCTURE ONLY (see oracle/orb_oracle.cpp header for the rule).
 //
-// PARITY STATUS: "parity unpinned" -- DBoW2 is vendored in the reference tree but its FORB descriptor type is a cv::Mat
-// (OpenCV absent), so it cannot be compiled here, and the vocabulary blob (Vocabulary/ORBvoc.txt) is not shipped.  The
+// PARITY STATUS: the MERGE half (orc_bow_merge: BowVector::addWeight / normalize, FeatureVector::addFeature) is PINNED against
+// the reference's own BowVector.cpp / FeatureVector.cpp, compiled from /root/reference into oracle/_ref/libdbow2_ref.so
+// (`make -C oracle ref`; tests/test_oracle_bow_ref.py + tests/golden/bow_merge_ref.npz).  The DESCENT half stays "parity
+// unpinned": TemplatedVocabulary.h and FORB.cpp need OpenCV (FORB's descriptor type is a cv::Mat; absent, no stand-ins), and
+// the vocabulary blob (Vocabulary/ORBvoc.txt) is not shipped.  The
 // tree is taken in flattened form (what loadFromTextFile builds in m_nodes): per node a 256-bit descriptor, its children
 // in order, a word id (leaves) and an idf weight.  Pinned in tests/test_oracle_bow.py by a numpy brute-force descent.
 // ============================================================================
@@ -58,21 +61,19 @@ void orc_bow_descend(const uint8_t* node_desc, const uint32_t* child_off, const 
   *w = weight[final_id];
 }
 
-// batch transform, TF_IDF weighting + L1 normalisation (:1124-1200).  Outputs: BowVector as ascending (word, value) pairs,
-// FeatureVector as CSR over ascending node ids with the feature indices of each node in ascending order.
-void orc_bow_transform(const uint8_t* node_desc, const uint32_t* child_off, const uint32_t* children, const int32_t* word_id,
-                       const double* weight, int n_nodes, int L, int levelsup, const uint8_t* desc, int n, uint32_t* bow_word,
-                       double* bow_value, int* n_words, uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes) {
-  (void)n_nodes;
+// the merge half of the batch transform (:1166-1200 with BowVector::addWeight / normalize(L1) and FeatureVector::addFeature written
+// out on std::map): per-feature (word, weight, node) triples -> BowVector as ascending (word, value) pairs, FeatureVector as
+// CSR over ascending node ids with the feature indices of each node in ascending order.  PINNED against the reference's own
+// BowVector.cpp / FeatureVector.cpp compiled into oracle/_ref/libdbow2_ref.so (tests/test_oracle_bow_ref.py).
+void orc_bow_merge(int n, const int32_t* wid, const double* w, const uint32_t* nid, uint32_t* bow_word, double* bow_value,
+                   int* n_words, uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes) {
   std::map<uint32_t, double> v;
   std::map<uint32_t, std::vector<uint32_t>> fv;
   for (int i = 0; i < n; i++) {
-    int32_t id; double w; uint32_t nid;
-    orc_bow_descend(node_desc, child_off, children, word_id, weight, L, levelsup, desc + 32 * (size_t)i, &id, &w, &nid);
-    if (w > 0) {                                      // not stopped
-      auto it = v.lower_bound((uint32_t)id);
-      if (it != v.end() && it->first == (uint32_t)id) it->second += w; else v.insert(it, {(uint32_t)id, w});
-      fv[nid].push_back((uint32_t)i);
+    if (w[i] > 0) {                                   // not stopped
+      auto it = v.lower_bound((uint32_t)wid[i]);
+      if (it != v.end() && it->first == (uint32_t)wid[i]) it->second += w[i]; else v.insert(it, {(uint32_t)wid[i], w[i]});
+      fv[nid[i]].push_back((uint32_t)i);
     }
   }
   double norm = 0.0;                                  // BowVector::normalize(L1)
@@ -89,6 +90,17 @@ void orc_bow_transform(const uint8_t* node_desc, const uint32_t* child_off, cons
   }
   fv_off[m] = pos;
   *n_fv_nodes = m;
+}
+
+// batch transform, TF_IDF weighting + L1 normalisation (:1124-1200): descent per feature, then the merge above.
+void orc_bow_transform(const uint8_t* node_desc, const uint32_t* child_off, const uint32_t* children, const int32_t* word_id,
+                       const double* weight, int n_nodes, int L, int levelsup, const uint8_t* desc, int n, uint32_t* bow_word,
+                       double* bow_value, int* n_words, uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes) {
+  (void)n_nodes;
+  std::vector<int32_t> wid(n > 0 ? n : 1); std::vector<double> w(n > 0 ? n : 1); std::vector<uint32_t> nid(n > 0 ? n : 1);
+  for (int i = 0; i < n; i++)
+    orc_bow_descend(node_desc, child_off, children, word_id, weight, L, levelsup, desc + 32 * (size_t)i, &wid[i], &w[i], &nid[i]);
+  orc_bow_merge(n, wid.data(), w.data(), nid.data(), bow_word, bow_value, n_words, fv_node, fv_off, fv_idx, n_fv_nodes);
 }
 
 // L1 score between two BowVectors (L1Scoring::score, lib/DBoW2/DBoW2/ScoringObject.cpp): 1 - 0.5 * sum |v1 - v2| over

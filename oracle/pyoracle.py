@@ -535,6 +535,74 @@ def bow_transform(voc, desc, levelsup=4):
     return bw[:nw.value], bv[:nw.value], fn[:nf.value], fo[:nf.value + 1], fi[:fo[nf.value]]
 
 
+def bow_descend(voc, desc, levelsup=4):
+    """Per-feature descent only: (word id, idf weight, node id at level L - levelsup) of every descriptor."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); n = len(d)
+    wid = np.zeros(n, np.int32); w = np.zeros(n, np.float64); nid = np.zeros(n, np.uint32)
+    L = lib()
+    L.orc_bow_descend.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int] + [C.c_void_p] * 4
+    for i in range(n):
+        L.orc_bow_descend(_p(voc["node_desc"]), _p(voc["child_off"]), _p(voc["children"]), _p(voc["word_id"]), _p(voc["weight"]),
+                          int(voc["L"]), int(levelsup), d[i].ctypes.data, wid[i:].ctypes.data, w[i:].ctypes.data, nid[i:].ctypes.data)
+    return wid, w, nid
+
+
+def _merge_call(fn, wid, w, nid, *extra):
+    wid = np.ascontiguousarray(wid, np.int32); w = np.ascontiguousarray(w, np.float64); nid = np.ascontiguousarray(nid, np.uint32)
+    n = len(wid)
+    bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64)
+    fn_ = np.zeros(max(n, 1), np.uint32); fo = np.zeros(n + 2, np.uint32); fi = np.zeros(max(n, 1), np.uint32); nf = C.c_int(0)
+    return n, wid, w, nid, bw, bv, fn_, fo, fi, nf
+
+
+def bow_merge(wid, w, nid):
+    """The oracle's merge of per-feature triples (restatement of BowVector / FeatureVector); same outputs as bow_transform."""
+    n, wid, w, nid, bw, bv, fn_, fo, fi, nf = _merge_call(None, wid, w, nid)
+    nw = C.c_int(0)
+    L = lib()
+    L.orc_bow_merge.argtypes = [C.c_int] + [C.c_void_p] * 10
+    L.orc_bow_merge(n, _p(wid), _p(w), _p(nid), _p(bw), _p(bv), C.byref(nw), _p(fn_), _p(fo), _p(fi), C.byref(nf))
+    return bw[:nw.value], bv[:nw.value], fn_[:nf.value], fo[:nf.value + 1], fi[:fo[nf.value]]
+
+
+# --------------------------------- oracle/_ref: the REFERENCE's own DBoW2 classes ------------------------------------
+_REF_SO = os.path.join(_HERE, "_ref", "libdbow2_ref.so")
+_REFERENCE_ROOT = os.environ.get("ORB_REFERENCE_ROOT", "/root/reference")
+
+
+def build_ref(force=False):
+    """Compile the reference's BowVector.cpp / FeatureVector.cpp (where they lie) + oracle/ref_dbow2_shim.cpp into
+    oracle/_ref/libdbow2_ref.so.  Returns the path, or None when the reference tree is absent (GPU box: the prebuilt file travels)."""
+    src = os.path.join(_REFERENCE_ROOT, "lib", "DBoW2", "DBoW2", "BowVector.cpp")
+    if not os.path.exists(src):
+        return _REF_SO if os.path.exists(_REF_SO) else None
+    if force or not os.path.exists(_REF_SO) or os.path.getmtime(os.path.join(_HERE, "ref_dbow2_shim.cpp")) > os.path.getmtime(_REF_SO):
+        subprocess.check_call(["make", "-C", _HERE, "ref", "REF=" + _REFERENCE_ROOT] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return _REF_SO
+
+
+_ref = None
+
+
+def ref_lib():
+    """The built oracle/_ref library, or None if it was never built (no reference tree and no prebuilt file)."""
+    global _ref
+    if _ref is None and os.path.exists(_REF_SO):
+        _ref = C.CDLL(_REF_SO)
+        _ref.ref_bow_merge.restype = C.c_int
+        _ref.ref_bow_merge.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        _ref.ref_bow_merge_if_not_exist.restype = C.c_int
+        _ref.ref_bow_merge_if_not_exist.argtypes = [C.c_int] + [C.c_void_p] * 4
+    return _ref
+
+
+def ref_bow_merge(wid, w, nid, norm=0):
+    """The same merge done by the reference's BowVector::addWeight / normalize and FeatureVector::addFeature."""
+    n, wid, w, nid, bw, bv, fn_, fo, fi, nf = _merge_call(None, wid, w, nid)
+    k = ref_lib().ref_bow_merge(n, _p(wid), _p(w), _p(nid), int(norm), _p(bw), _p(bv), _p(fn_), _p(fo), _p(fi), C.byref(nf))
+    return bw[:k], bv[:k], fn_[:nf.value], fo[:nf.value + 1], fi[:fo[nf.value]]
+
+
 def bow_score_l1(w1, v1, w2, v2):
     L = lib(); L.orc_bow_score_l1.restype = C.c_double
     L.orc_bow_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]

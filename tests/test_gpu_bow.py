@@ -64,3 +64,15 @@ def test_descend_device_batch(oracle):
         live = wt[f0:f0 + 2000] > 0
         assert np.array_equal(np.unique(word[f0:f0 + 2000][live]), obw.astype(np.int64))
         assert np.array_equal(np.unique(node[f0:f0 + 2000][live]), ofn)
+
+
+def test_transform_vs_reference_built_golden():
+    """Product vs tests/golden/bow_merge_ref.npz: the expected BowVector / FeatureVector were produced by the REFERENCE's own
+    BowVector.cpp / FeatureVector.cpp (oracle/_ref, tests/golden/make_golden_bow_ref.py) from the descents of the fixture."""
+    import os
+    from ceres_mono_orb_slam2_amd.vocabulary import ORBVocabulary
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bow_merge_ref.npz"))
+    V = ORBVocabulary(*([g["voc_" + k] for k in KEYS[:-1]] + [int(g["voc_L"])]))
+    bw, bv, (fn, fo, fi) = V.transform(g["voc_desc"], int(g["voc_levelsup"]))
+    assert np.array_equal(bw, g["voc_bow_word"]) and np.array_equal(bv.view(np.uint64), g["voc_bow_value"].view(np.uint64))
+    assert np.array_equal(fn, g["voc_fv_node"]) and np.array_equal(fo, g["voc_fv_off"]) and np.array_equal(fi, g["voc_fv_idx"])
