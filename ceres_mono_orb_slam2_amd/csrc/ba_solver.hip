@@ -2468,7 +2468,15 @@ int pg_solve_impl(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* e
   int nf = 0;
   for (int v = 0; v < n; v++) if (!kf_fixed[v]) col[v] = nf++;
   const int n7 = 7 * nf, npad = std::max(round_up(std::max(n7, 1), NB), NB);
-  if (npad > 16384) { set_error("essential graph with %d free keyframes exceeds the dense solver's capacity (2340)", nf); return ORBHIP_ECAP; }
+  // The reduced system is dense: (npad + 1) * npad doubles.  Round 1 refused more than 2340 free keyframes (npad > 16384); the
+  // factorisation itself has no size limit (all offsets are 64-bit), so the only bound is device memory: 4700 keyframes need
+  // 8.7 GB, 10000 keyframes 39 GB of the 288 GB.  (The reference's sparse Cholesky has no limit either.)
+  { size_t free_b = 0, total_b = 0;
+    const size_t need = ((size_t)(npad + 1) * npad + (size_t)npad * NB) * sizeof(double);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b) {
+      set_error("essential graph with %d free keyframes needs %.1f GB for the dense reduced system, %.1f GB free on the device", nf, need / 1e9, free_b / 1e9);
+      return ORBHIP_ECAP;
+    } }
   // incident edge lists (insertion order) and off-diagonal block lists
   std::vector<int> v_off(n + 1, 0), v_edge(2 * (size_t)ne); std::vector<signed char> v_sign(2 * (size_t)ne);
   for (int e = 0; e < ne; e++) { v_off[edge_i[e] + 1]++; v_off[edge_j[e] + 1]++; }
