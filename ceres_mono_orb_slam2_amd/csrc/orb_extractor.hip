@@ -497,16 +497,21 @@ static size_t octree_lds_bytes(int node_cap, int max_cells_level, bool wide) {
   const size_t per_node = 8 * 2 + (wide ? 16 : 8) + 8 + 4 + 4 + (wide ? 4 : 2) * 2 + 2 + 2 + 2;
   return (size_t)node_cap * per_node + (size_t)(max_cells_level + 8) * 4 + 64;
 }
-template <bool WIDE>
+// GMEM: the node arrays live in a global scratch row of the (frame, level) workgroup instead of LDS - the fallback for per-level
+// quotas whose node arrays exceed the 160 kB of LDS (about 3200 keypoints in one level, i.e. nfeatures beyond ~15000; the
+// reference has no such limit).  Same code, same order of operations, slower memory.
+template <bool WIDE, bool GMEM>
 __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
                                                 const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
                                                 unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
                                                 int* __restrict__ sel_cnt, int* __restrict__ nkeys_out,
-                                                int* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+                                                int* __restrict__ status, uint8_t* __restrict__ gnodes, size_t gnodes_stride) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_lds[];
   const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   const LevelDev& Lv = G.lv[level];
   const int NC = G.node_cap, N = Lv.quota;
+  uint8_t* smem;
+  if constexpr (GMEM) smem = gnodes + ((size_t)f * G.nlevels + level) * gnodes_stride; else smem = smem_lds;
   // ---- LDS carve (all offsets multiples of 8) -------------------------------------------------
   Rect16* rect[2];
   rect[0] = (Rect16*)smem;
@@ -1072,11 +1077,13 @@ struct orbx_ctx {
   std::vector<BlurTile> btiles;
   DevBuf d_cells, d_btiles, d_tab;      // tables
   std::vector<size_t> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // byte offsets into d_tab per level
-  DevBuf d_pyr, d_blur, d_cellcnt, d_cellkps, d_keys, d_knode, d_sel, d_selcnt, d_nkeys, d_status;
+  DevBuf d_pyr, d_blur, d_cellcnt, d_cellkps, d_keys, d_knode, d_sel, d_selcnt, d_nkeys, d_status, d_octnodes;
   DevBuf d_img, d_out;                     // host-API staging: image; {counts | keypoints | descriptors} in one block
   void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
   size_t fast_lds = 0, octree_lds = 0, octree_lds_wide = 0;
-  bool octree_wide = false;           // some level can hold > 65535 candidates: 32-bit node counters (k_octree<true>)
+  bool octree_wide = false;           // some level can hold > 65535 candidates: 32-bit node counters (k_octree<true, .>)
+  bool octree_gmem = false;           // node arrays larger than the LDS: global scratch rows (k_octree<., true>)
+  size_t octree_row = 0;
   // last call (for introspection)
   const uint8_t* last_img0 = nullptr; long long last_img_frame_bytes = 0; int last_nframes = 0;
   bool const_uploaded = false;
@@ -1259,17 +1266,20 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     for (int l = 0; l < c->nlevels; l++) c->octree_wide = c->octree_wide || G.lv[l].kcap > 65535;
     c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, false);
     c->octree_lds_wide = octree_lds_bytes(G.node_cap, G.max_cells_level, true);
-    ORBHIP_REQUIRE((c->octree_wide ? c->octree_lds_wide : c->octree_lds) <= 160 * 1024, ORBHIP_EINVAL, "nfeatures too large for the LDS octree");
+    // node arrays beyond the LDS: both instantiations keep them in a global scratch row per (frame, level) instead (k_octree<.., true>)
+    c->octree_gmem = (c->octree_wide ? c->octree_lds_wide : c->octree_lds) > 160 * 1024;
+    c->octree_row = (size_t)round_up((int)c->octree_lds_wide, 256);
+    ORBHIP_REQUIRE(G.node_cap <= 32760, ORBHIP_EINVAL, "nfeatures too large: more than 32752 keypoints in one level (16-bit node indices)");
     if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
     if (int rc = c->d_btiles.ensure(c->btiles.size() * sizeof(BlurTile))) return rc;
     if (int rc = c->d_tab.ensure(std::max<size_t>(tab.size(), 16))) return rc;
     if (!c->cells.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_cells.p, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
     ORBHIP_CHECK_HIP(hipMemcpy(c->d_btiles.p, c->btiles.data(), c->btiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
     if (!tab.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
-    if (c->octree_lds > 64 * 1024)
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds));
-    if (c->octree_wide && c->octree_lds_wide > 64 * 1024)
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds_wide));
+    if (!c->octree_gmem && c->octree_lds > 64 * 1024)
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds));
+    if (!c->octree_gmem && c->octree_wide && c->octree_lds_wide > 64 * 1024)
+      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds_wide));
     c->w = w; c->h = h; c->stride = stride; c->nframes = 0;
   }
   if (!c->const_uploaded) {
@@ -1285,6 +1295,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
   if (int rc = c->d_keys.ensure(B * G.keys_per_frame * 4)) return rc;
   if (int rc = c->d_knode.ensure(B * G.keys_per_frame * 2)) return rc;
   if (int rc = c->d_sel.ensure(B * nl * G.sel_cap * 4)) return rc;
+  if (c->octree_gmem) { if (int rc = c->d_octnodes.ensure(B * nl * c->octree_row)) return rc; }
   if (int rc = c->d_selcnt.ensure(B * nl * 4)) return rc;
   if (int rc = c->d_nkeys.ensure(B * nl * 4)) return rc;
   if (int rc = c->d_status.ensure(B * 4)) return rc;
@@ -1337,13 +1348,23 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   // mode 2: the octree is one latency-bound workgroup per (frame, level) - 6 % VALU-busy, 0.6 waves per SIMD - so the
   // VALU-bound blur runs BESIDE it: the fork is taken after FAST, the octree is submitted first and keeps its slots
   if (side_mode == 2) ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
-  hipLaunchKernelGGL(k_octree<false>, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
-                     c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
-                     c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
-  if (c->octree_wide)        // levels with more than 65535 candidates (32-bit node counters); every other workgroup leaves at once
-    hipLaunchKernelGGL(k_octree<true>, dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds_wide, st, G, c->d_cellcnt.as<int>(),
+  if (!c->octree_gmem) {
+    hipLaunchKernelGGL((k_octree<false, false>), dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
                        c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
-                       c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
+                       c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>(), (uint8_t*)nullptr, (size_t)0);
+    if (c->octree_wide)        // levels with more than 65535 candidates (32-bit node counters); every other workgroup leaves at once
+      hipLaunchKernelGGL((k_octree<true, false>), dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds_wide, st, G, c->d_cellcnt.as<int>(),
+                         c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
+                         c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>(), (uint8_t*)nullptr, (size_t)0);
+  } else {                     // per-level quota beyond the LDS: node arrays in a global scratch row per (frame, level)
+    hipLaunchKernelGGL((k_octree<false, true>), dim3(nl, nframes), dim3(OCT_TPB), 0, st, G, c->d_cellcnt.as<int>(),
+                       c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
+                       c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>(), c->d_octnodes.as<uint8_t>(), c->octree_row);
+    if (c->octree_wide)
+      hipLaunchKernelGGL((k_octree<true, true>), dim3(nl, nframes), dim3(OCT_TPB), 0, st, G, c->d_cellcnt.as<int>(),
+                         c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
+                         c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>(), c->d_octnodes.as<uint8_t>(), c->octree_row);
+  }
   if (side_mode == 2) {
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
@@ -1400,7 +1421,7 @@ int orbx_destroy(orbx_ctx* c) {
   if (!c) return 0;
   DevBuf* bufs[] = {&c->d_cells, &c->d_btiles, &c->d_tab, &c->d_pyr, &c->d_blur, &c->d_cellcnt, &c->d_cellkps,
                     &c->d_keys, &c->d_knode, &c->d_sel, &c->d_selcnt, &c->d_nkeys, &c->d_status, &c->d_img,
-                    &c->d_out};
+                    &c->d_out, &c->d_octnodes};
   for (DevBuf* b : bufs) b->release();
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }

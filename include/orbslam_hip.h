@@ -57,10 +57,11 @@ typedef struct orbx_keypoint {
 } orbx_keypoint;
 
 /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
- * (src/ORBextractor.cc:410-470); `device` = HIP device ordinal.  Capacity (an error, never silent): the largest
- * per-level quota must fit the LDS octree (about 3200 keypoints in one level, i.e. any nfeatures the reference's 8-level
- * configurations use; ORBHIP_EINVAL from the first extract call otherwise).  The number of FAST corners per level is not
- * limited (candidate arrays are sized for the worst case of the image geometry).                                         */
+ * (src/ORBextractor.cc:410-470); `device` = HIP device ordinal.  Capacity: per-level quotas up to about 3200 keypoints keep
+ * the octree's node arrays in LDS; larger ones (nfeatures beyond ~15000) run the same kernel on a global scratch row per
+ * (frame, level), up to 32752 keypoints in one level (16-bit node indices; ORBHIP_EINVAL from the first extract call beyond
+ * that - an error, never silent).  The number of FAST corners per level is not limited (candidate arrays are sized for the
+ * worst case of the image geometry).                                                                                      */
 int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
                 orbx_ctx** out);
 int orbx_destroy(orbx_ctx* ctx);
