@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
                                                   const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   int cap, int* __restrict__ counts, float p1, float p3, float p5,
-                                                  float p7, float factorPI) {
+                                                  float p7, float factorPI, int xcd_map) {
   __shared__ uint32_t s_pat[256];                           // pattern pair k = bytes (x0, y0, x1, y1)
   // intensity-centroid weights as byte vectors: for patch row |v| and source dword i (bytes k = 4i .. 4i+3 of the 31-byte row,
   // u = k - 15), s_icm holds [|u| <= umax[|v|]] and s_ick holds k * [..] - the row sums become v_dot4_u32_u8 on whole dwords
@@ -936,7 +936,16 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
     if (which) s_ick[rv][i4] = w; else s_icm[rv][i4] = w;
   }
   __syncthreads();
-  const int f = blockIdx.y;
+  // XCD-aware frame placement: workgroups are dealt round-robin to the 8 XCDs by their LINEAR id, and every XCD has its own
+  // L2.  With the plain (block, frame) order the ~900 workgroups of one frame are spread over all eight L2s and every patch row
+  // is fetched from the fabric up to 8 times (PMC: 4.65 MB per frame for 2.9 MB of level data).  xcd_map puts frame f on XCD
+  // f % 8: linear id L -> XCD x = L % 8, position i = L / 8 inside the XCD's queue -> frame x + 8 (i / blocks), block i % blocks.
+  int f = blockIdx.y, bx = blockIdx.x;
+  if (xcd_map) {                                              // (host: only when the frame count is a multiple of 8)
+    const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, x = lin & 7u, i = lin >> 3;
+    const uint32_t q = i / gridDim.x;
+    f = (int)(x + 8u * q); bx = (int)(i - q * gridDim.x);
+  }
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, hl = lane & 31;
   // The grid is laid out per LEVEL (every level gets capacity / (2 DESC_WPB) workgroups): level and position inside the level
@@ -947,9 +956,9 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   // 67 % VALU-busy at 6.3 waves per SIMD with one keypoint per wave).
   int level = 0;
 #pragma unroll
-  for (int l = 1; l < MAX_LEVELS; l++) if (l < G.nlevels && (int)blockIdx.x >= G.lv[l].dblk_begin) level = l;
+  for (int l = 1; l < MAX_LEVELS; l++) if (l < G.nlevels && bx >= G.lv[l].dblk_begin) level = l;
   const LevelDev& L = G.lv[level];
-  const int pos = (((int)blockIdx.x - L.dblk_begin) * DESC_WPB + (threadIdx.x >> 6)) * 2 + half;
+  const int pos = ((bx - L.dblk_begin) * DESC_WPB + (threadIdx.x >> 6)) * 2 + half;
   const int st_f = status[f];
   // level offsets (levels concatenated 0..L-1, src/ORBextractor.cc:1075-1104): one lane per level
   const int cl = (lane < G.nlevels) ? min(sel_cnt[f * G.nlevels + lane], G.sel_cap) : 0;
@@ -959,7 +968,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   const int cl_level = __builtin_amdgcn_readlane(cl, level);
   const int i = __builtin_amdgcn_readlane(incl, level) - cl_level + pos;     // keypoint index inside the frame
   const bool bad = st_f != 0 || total > cap;
-  if (blockIdx.x == 0 && threadIdx.x == 0) counts[f] = bad ? (st_f != 0 ? -1 : -2) : total;
+  if (bx == 0 && threadIdx.x == 0) counts[f] = bad ? (st_f != 0 ? -1 : -2) : total;
   const bool valid = pos < cl_level;
   if (bad || !__any(valid)) return;
   // an empty half repeats the other half's keypoint (its loads stay inside the image, nothing is stored)
@@ -1082,6 +1091,7 @@ struct orbx_ctx {
   void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
   size_t fast_lds = 0, octree_lds = 0, octree_lds_wide = 0;
   bool octree_wide = false;           // some level can hold > 65535 candidates: 32-bit node counters (k_octree<true, .>)
+  int desc_xcd = 1;                   // k_describe: frame f on XCD f % 8 (ORBHIP_DESC_XCD=0 restores the plain order)
   bool octree_gmem = false;           // node arrays larger than the LDS: global scratch rows (k_octree<., true>)
   size_t octree_row = 0;
   // last call (for introspection)
@@ -1382,7 +1392,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   hipLaunchKernelGGL(k_describe, dim3(G.desc_blocks, nframes), dim3(64 * DESC_WPB), 0, st, G, c->d_sel.as<uint32_t>(),
                      c->d_selcnt.as<int>(), c->d_status.as<int>(), d_imgs, (long long)frame_stride, pyr,
                      c->d_blur.as<uint8_t>(), d_kps, d_desc, cap, d_counts, c->atan_p[0], c->atan_p[1],
-                     c->atan_p[2], c->atan_p[3], c->factorPI);
+                     c->atan_p[2], c->atan_p[3], c->factorPI, (c->desc_xcd && nframes % 8 == 0) ? 1 : 0);
   mark();
   ORBHIP_CHECK_HIP(hipGetLastError());
   c->last_img0 = d_imgs; c->last_img_frame_bytes = (long long)frame_stride; c->last_nframes = nframes;
@@ -1413,6 +1423,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
     c->side = nullptr;
   }
   if (const char* e = std::getenv("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = atoi(e);
+  if (const char* e = std::getenv("ORBHIP_DESC_XCD")) c->desc_xcd = atoi(e);
   *out = c;
   return 0;
 }

@@ -46,6 +46,14 @@ __device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, cons
 
 // ---- brute force: every query against every target, first minimum wins -----------------------
 #define BF_CHUNK 1024
+// median of three unsigned keys in ONE instruction.  With k1 <= k2 (best and second-best key) the second-best update of the
+// reference, min(k2, max(k1, k)), is exactly med3(k1, k2, k): k <= k1 -> k1, k1 < k < k2 -> k, k >= k2 -> k2.
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 __global__ __launch_bounds__(256) void k_best2_brute(const uint8_t* __restrict__ q, int nq,
                                                      const uint8_t* __restrict__ t, int nt,
                                                      int* __restrict__ best_idx, int* __restrict__ best_d,
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
 #pragma unroll
         for (int s = 0; s < MP_Q; s++) {
           const uint32_t k = ((uint32_t)hamming256(q0[s], q1[s], t0, t1) << 16) | (uint32_t)j;
-          k2[s] = min(k2[s], max(k1[s], k));
+          k2[s] = med3_u32(k1[s], k2[s], k);              // = min(k2, max(k1, k)) because k1 <= k2: the median of the three
           k1[s] = min(k1[s], k);
         }
       }
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(64 * BS_WAVES) void k_best2_split(const uint8_t* __
   for (int j = w; j < nt; j += BS_WAVES) {
     const uint4 t0 = T[2 * (size_t)j], t1 = T[2 * (size_t)j + 1];
     const uint32_t k = ((uint32_t)hamming256(q0, q1, t0, t1) << 16) | (uint32_t)j;
-    k2 = min(k2, max(k1, k));
+    k2 = med3_u32(k1, k2, k);
     k1 = min(k1, k);
   }
   s_k1[w][lane] = k1; s_k2[w][lane] = k2;

@@ -1,0 +1,37 @@
+"""Quick per-stage timing of the front-end on ONE 256-frame batch (no CPU legs, no BA): the A/B loop for kernel work.
+usage: python tools/frontend_ab.py [reps=20] [B=256]      (prints one JSON line: ms per launch per stage + frames/s)"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+dev = torch.device("cuda:0")
+frames = torch.from_numpy(bench.make_frames(B, seed=0)).to(dev)
+ex = ORBextractor(bench.NFEAT, 1.2, 8, 20, 7)
+mt = ORBmatcher(0.9, True)
+cap = ex.max_keypoints
+kps = torch.empty((B, cap, 7), dtype=torch.float32, device=dev); desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
+counts = torch.empty((B,), dtype=torch.int32, device=dev); match12 = torch.empty((B, cap), dtype=torch.int32, device=dev)
+nmatch = torch.empty((B,), dtype=torch.int32, device=dev)
+pa = torch.arange(B, dtype=torch.int32, device=dev); pb = (pa + B - 1) % B
+for _ in range(3):
+    ex.extract_batch(frames, out=(kps, desc, counts)); mt.match_frames_batch(kps, desc, counts, pa, pb, out=(match12, nmatch))
+torch.cuda.synchronize()
+ex.set_profiling(True)
+ev = []
+t0 = time.perf_counter()
+for _ in range(reps):
+    ex.extract_batch(frames, out=(kps, desc, counts))
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    mt.match_frames_batch(kps, desc, counts, pa, pb, out=(match12, nmatch))
+    e1 = torch.cuda.Event(enable_timing=True); e1.record(); ev.append((e0, e1))
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+st, n = ex.stage_ms()
+out = {k: round(v / max(n, 1), 4) for k, v in st.items()}
+out["match"] = round(sum(a.elapsed_time(b) for a, b in ev) / reps, 4)
+out["frames_per_s"] = round(B * reps / dt, 1)
+out["checksum"] = [int(counts.sum().item()), int(nmatch.sum().item()), int(desc.to(torch.int64).sum().item()), int(match12.to(torch.int64).sum().item())]
+print(json.dumps(out))
