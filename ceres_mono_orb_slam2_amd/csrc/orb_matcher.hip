@@ -163,14 +163,33 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
       any_q = any_q || (g * 64 < n1);
     }
     if (any_q) {                                          // (whole wave beyond n1: nothing to do)
-      for (int j = 0; j < n2; j++) {
-        const uint4 t0 = s_t[2 * j], t1 = s_t[2 * j + 1];
+      // Software pipeline over the LDS-resident targets, two per trip on alternating register sets: the NEXT target's two
+      // broadcast reads are requested before the current one's 2 x 19 VALU instructions (the plain loop waited for its own reads
+      // at the top of every iteration: one exposed LDS round trip per target and wave).  sched_barrier keeps the reads where
+      // they are written (the scheduler sinks them to the middle of the body otherwise), the empty asm pins the values to this
+      // trip (the compiler otherwise re-issues the reads at the top of the next one, in front of their first use).
+      auto score = [&](const uint4& t0, const uint4& t1, int j) {
 #pragma unroll
         for (int s = 0; s < MP_Q; s++) {
           const uint32_t k = ((uint32_t)hamming256(q0[s], q1[s], t0, t1) << 16) | (uint32_t)j;
           k2[s] = med3_u32(k1[s], k2[s], k);              // = min(k2, max(k1, k)) because k1 <= k2: the median of the three
           k1[s] = min(k1[s], k);
         }
+      };
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));            // (one 128-bit register tuple per asm operand)
+      const u32x4* s_v = (const u32x4*)s_t;
+      auto U4 = [](const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); };
+      u32x4 a0 = s_v[0], a1 = s_v[1];
+      for (int j = 0; j < n2; j += 2) {
+        const int jb = min(j + 1, n2 - 1), ja = min(j + 2, n2 - 1);
+        u32x4 b0 = s_v[2 * jb], b1 = s_v[2 * jb + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        score(U4(a0), U4(a1), j);
+        asm volatile("" : "+v"(b0), "+v"(b1));
+        a0 = s_v[2 * ja]; a1 = s_v[2 * ja + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < n2) score(U4(b0), U4(b1), j + 1);
+        asm volatile("" : "+v"(a0), "+v"(a1));
       }
     }
 #pragma unroll
