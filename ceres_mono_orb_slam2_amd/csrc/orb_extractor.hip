@@ -263,14 +263,29 @@ __device__ __forceinline__ void fast_tile_load(const uint8_t* base, uint8_t* til
 // ONE WAVE per cell (64-thread workgroups): no cross-wave barriers, lanes = columns of the cell, rows are
 // walked sequentially; the ordered (row-major) emit needs only a running wave-uniform offset.
 #define FAST_WPB 1      // waves (= cells) per workgroup
+// NARROW: every cell interior of the geometry is <= 32 px wide (all KITTI / VGA levels: 30-px cells): the per-row survivor masks
+// are 32-bit (one v_ffbl / v_bcnt / ds_or_b32 instead of pairs) and the pre-test's lane layout is a constant.
+template <bool NARROW> struct FastMask;
+template <> struct FastMask<true> {
+  typedef uint32_t type;
+  static __device__ __forceinline__ int popc(uint32_t m) { return __popc(m); }
+  static __device__ __forceinline__ int ffs0(uint32_t m) { return __ffs((int)m) - 1; }
+};
+template <> struct FastMask<false> {
+  typedef unsigned long long type;
+  static __device__ __forceinline__ int popc(unsigned long long m) { return __popcll(m); }
+  static __device__ __forceinline__ int ffs0(unsigned long long m) { return __ffsll((long long)m) - 1; }
+};
+template <bool NARROW>
 __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const CellDesc* __restrict__ cells,
                                                    const uint8_t* __restrict__ img0, long long img_frame_bytes,
                                                    const uint8_t* __restrict__ pyr, int* __restrict__ cell_cnt,
                                                    uint32_t* __restrict__ cell_kps, int iniTh, int minTh, int lds_per_wave) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
   const int TP = G.tile_pitch;                        // multiple of 4
-  const int plane = G.tile_h * TP;                    // multiple of 4
+  const int plane = (G.tile_h * TP + 15) & ~15;       // multiple of 16 (the score plane is cleared with 16-byte stores)
   const int lane = threadIdx.x & 63;
+  typedef typename FastMask<NARROW>::type mask_t;
   // Cell order = plain grid order.  (Measured on MI355X: an XCD-contiguous remap ci = (b%8)*chunk + b/8 cuts
   // this kernel's FETCH_SIZE 4.9x - neighbouring cells then share one L2 - but makes it 40 % SLOWER; it is
   // latency/issue-bound, not HBM-bound, so the faster mapping is kept.  DESIGN.md section 4.)
@@ -281,9 +296,10 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   uint8_t* smem = smem_all + (size_t)wv * lds_per_wave;
   uint8_t* tile = smem;                               // [tile_h][TP]
   uint8_t* score = smem + plane;                      // [tile_h][TP]
-  unsigned long long* keep = (unsigned long long*)(score + plane);    // [64] NMS survivors per interior row (bit = ix)
-  unsigned long long* k20 = keep + 64;                                 // [64] survivors with score >= iniTh
-  unsigned short* queue = (unsigned short*)(k20 + 64);                 // pixels that passed the pre-test
+  mask_t* keep = (mask_t*)(score + plane);            // [64] NMS survivors per interior row (bit = ix)
+  mask_t* k20 = keep + 64;                            // [64] survivors with score >= iniTh
+  int* qcnt = (int*)(k20 + 64);                       // queue length (LDS atomic counter; 16 bytes reserved)
+  unsigned short* queue = (unsigned short*)(qcnt + 4);                 // pixels that passed the pre-test
   FAST_STAMP_INIT;
   const CellDesc c = cells[ci];
   const LevelDev& L = G.lv[c.level];
@@ -297,8 +313,9 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   const uint32_t bsh = (uint32_t)((size_t)cell_base & 3);
   const uint8_t* base_al = cell_base - bsh;
   const uint8_t* tileb = tile + bsh;
-  for (int i = lane; i < plane >> 2; i += 64) ((uint32_t*)score)[i] = 0u;
-  keep[lane] = 0ull; k20[lane] = 0ull;
+  for (int i = lane; i < plane >> 4; i += 64) ((uint4*)score)[i] = make_uint4(0u, 0u, 0u, 0u);
+  keep[lane] = 0; k20[lane] = 0;
+  if (lane == 0) *qcnt = 0;
   {
     // The tile goes from global memory STRAIGHT into LDS (global_load_lds_dword: no VGPR staging, no re-alignment, no LDS
     // store instructions): a wave instruction writes 64 consecutive LDS dwords, so lane l of instruction j owns tile dword
@@ -329,14 +346,14 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     // - seven dword reads instead of twenty byte reads per four pixels.  The bytes are split into even / odd pixels as u16
     // pairs and the min / max network runs on v_pk_{min,max,sub}_*16: ~10 VALU per pixel instead of ~18, and one prefix sum
     // + enqueue per FOUR pixels (most lanes have nothing to enqueue: 8 % of the pixels pass).
-    const bool narrow = iw <= 32;
-    const int CG = narrow ? 8 : 16, RW = narrow ? 8 : 4;
+    const bool narrow = NARROW || iw <= 32;
+    const int RW = narrow ? 8 : 4;
     const int g = narrow ? (lane & 7) : (lane & 15), lr = narrow ? (lane >> 3) : (lane >> 4);
     const int ix4 = 4 * g;
     // validity of this lane's four columns (bit k = column ix4 + k is inside the interior)
     const uint32_t colmask = ix4 + 3 < iw ? 15u : (ix4 < iw ? ((1u << (iw - ix4)) - 1u) : 0u);
-    (void)CG;
-    const uint32_t T1 = (uint32_t)(minTh + 1) * 0x00010001u;
+    const uint32_t T0 = (uint32_t)minTh * 0x00010001u;
+    const uint32_t qaddr = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)qcnt;      // LDS byte address of the queue counter
     const int qv = (int)((3u + bsh) >> 2), q4 = 1 + (int)((2u + bsh) >> 2);       // (wave-uniform dword offsets / byte shifts)
     const uint32_t sv = (3u + bsh) & 3u, s4 = (2u + bsh) & 3u;
     for (int iy0 = 0; iy0 < ih; iy0 += RW) {
@@ -350,10 +367,12 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
       const uint32_t e0 = rc[0], e1 = rc[1], v0 = rc[qv], v1 = rc[qv + 1], f0 = rc[q4], f1 = rc[q4 + 1], u0 = ru[0], u1 = ru[1], b0 = rd[0], b1 = rd[1];
       const uint32_t vq = __builtin_amdgcn_alignbyte(v1, v0, sv), c8q = __builtin_amdgcn_alignbyte(u1, u0, sv), c0q = __builtin_amdgcn_alignbyte(b1, b0, sv);
       const uint32_t c12q = __builtin_amdgcn_alignbyte(e1, e0, bsh), c4q = __builtin_amdgcn_alignbyte(f1, f0, s4);
-      uint32_t pm = 0;
+      uint32_t sg[2];                                           // per parity: bit 15 / 31 set where the pixel passes
 #pragma unroll
       for (int par = 0; par < 2; par++) {                       // even pixels (bytes 0, 2), odd pixels (bytes 1, 3) as u16 pairs
-        auto split = [&](uint32_t q) { return par ? ((q >> 8) & 0x00FF00FFu) : (q & 0x00FF00FFu); };
+        // ONE instruction per quad and parity: v_and for the even bytes, v_perm (bytes 1 and 3 to the low halves, 0x0c = constant
+        // zero) for the odd ones
+        auto split = [&](uint32_t q) { return par ? __builtin_amdgcn_perm(0u, q, 0x0c030c01u) : (q & 0x00FF00FFu); };
         typedef unsigned short ushort2_v __attribute__((ext_vector_type(2)));
         auto U = [](uint32_t x) { return __builtin_bit_cast(ushort2_v, x); };
         auto S = [](uint32_t x) { return __builtin_bit_cast(short2_t, x); };
@@ -362,24 +381,32 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
         const ushort2_v lo = __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12));
         const short2_t up = S(__builtin_bit_cast(uint32_t, hi)) - S(__builtin_bit_cast(uint32_t, v2));     // (values 0..255: no overflow in 16 bits)
         const short2_t dn = S(__builtin_bit_cast(uint32_t, v2)) - S(__builtin_bit_cast(uint32_t, lo));
-        const short2_t m = __builtin_elementwise_max(up, dn) - S(T1);                                       // >= 0  <=>  max(..) > minTh
-        const uint32_t neg = ~__builtin_bit_cast(uint32_t, m) & 0x80008000u;                                // bit 15 / 31 set where the pixel passes
-        // pixel order inside the lane: byte k = pixel k; even parity holds pixels 0, 2, odd parity pixels 1, 3
-        pm |= par ? (((neg >> 14) & 2u) | ((neg >> 28) & 8u)) : (((neg >> 15) & 1u) | ((neg >> 29) & 4u));
+        const short2_t m = S(T0) - __builtin_elementwise_max(up, dn);                                       // < 0  <=>  max(..) > minTh
+        sg[par] = __builtin_bit_cast(uint32_t, m);
       }
+      // pixel k of the lane = byte k: pixels 0 / 2 are the sign bits 15 / 31 of the even parity, pixels 1 / 3 those of the odd one;
+      // t carries them at bits 14, 15, 30, 31 (one shift + one bit-field insert), two field extracts bring them to bits 0..3
+      const uint32_t t = (sg[1] & 0x80008000u) | ((sg[0] >> 1) & ~0x80008000u);
+      uint32_t pm = ((t >> 14) & 3u) | ((t >> 28) & 0xCu);
       pm &= (iyl < ih) ? colmask : 0u;
-      const int cnt = __popc(pm);
-      const int incl = wave_incl_scan_i32(cnt);
-      int pos = qn + incl - cnt;
-      const uint32_t rowbits = (uint32_t)iyl << 8;
-      while (pm) {
-        const int k = __ffs((int)pm) - 1;
-        pm &= pm - 1;
-        queue[pos++] = (unsigned short)(rowbits | (uint32_t)(ix4 + k));
+      if (pm) {
+        // queue slots from an LDS counter (the order of the queue is irrelevant: scores go to their pixel, survivors to row
+        // masks): one ds_add_rtn by the lanes that have something, instead of a 6-step DPP prefix sum by all of them
+        // (inline asm: written as atomicAdd, the compiler's atomic optimizer serialises the active lanes with a readlane /
+        // writelane loop to issue ONE atomic per wave - ~8 scalar steps per lane, far more than the LDS unit's own conflict handling)
+        int pos;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(qaddr), "v"(__popc(pm)) : "memory");
+        const uint32_t rowbits = ((uint32_t)iyl << 8) | (uint32_t)ix4;
+        do {
+          const int k = __ffs((int)pm) - 1;
+          pm &= pm - 1;
+          queue[pos++] = (unsigned short)(rowbits + (uint32_t)k);
+        } while (pm);
       }
-      qn += __builtin_amdgcn_readlane(incl, 63);
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  qn = __builtin_amdgcn_readfirstlane(*qcnt);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   FAST_STAMP(1);       // pre-test + queue
   // ---- pass B: FAST-9 score at the LOW threshold; one map serves both thresholds --------
@@ -409,30 +436,30 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
     const bool kp = v != 0 && v > nmax;
     if (kp) {
-      atomicOr(&keep[iy], 1ull << ix);
-      if (v >= iniTh) { atomicOr(&k20[iy], 1ull << ix); any20 = 1; }
+      atomicOr(&keep[iy], (mask_t)1 << ix);
+      if (v >= iniTh) { atomicOr(&k20[iy], (mask_t)1 << ix); any20 = 1; }
     }
   }
   any20 = __any(any20);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   FAST_STAMP(3);       // NMS
   // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816), row by row -----------
-  const unsigned long long* mask = any20 ? k20 : keep;
+  const mask_t* mask = any20 ? k20 : keep;
   uint32_t* out = cell_kps + ((long long)f * G.ncells_total + ci) * G.cell_cap;
   // lane r holds row r's mask; exclusive wave scan of the row populations gives every row's base offset
-  const unsigned long long mrow = (lane < ih) ? mask[lane] : 0ull;
-  const int cnt = __popcll(mrow);
+  const mask_t mrow = (lane < ih) ? mask[lane] : (mask_t)0;
+  const int cnt = FastMask<NARROW>::popc(mrow);
   const int incl = wave_incl_scan_i32(cnt);
   const int base = __builtin_amdgcn_readlane(incl, 63);
   // lane r writes row r's survivors itself, left to right, starting at the row's base offset: the loop runs for the
   // LARGEST row population of the cell (a handful) instead of once per non-empty row, without cross-lane traffic
   {
-    unsigned long long m = mrow;
+    mask_t m = mrow;
     int pos = incl - cnt;
     const uint32_t yv = (uint32_t)(lane + 3 + c.offy) << 12;
     const uint8_t* srow = score + __mul24(lane + 3, TP) + 3;
     while (m) {
-      const int ix = __ffsll((long long)m) - 1;
+      const int ix = FastMask<NARROW>::ffs0(m);
       m &= m - 1;
       if (pos < G.cell_cap) out[pos] = (uint32_t)(ix + 3 + c.offx) | yv | ((uint32_t)srow[ix] << 24);
       pos++;
@@ -1094,6 +1121,7 @@ struct orbx_ctx {
   void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
   size_t fast_lds = 0, octree_lds = 0, octree_lds_wide = 0;
   bool octree_wide = false;           // some level can hold > 65535 candidates: 32-bit node counters (k_octree<true, .>)
+  bool fast_narrow = false;           // k_fast_cells<true>: all cell interiors <= 32 px wide
   int desc_xcd = 1;                   // k_describe: frame f on XCD f % 8 (ORBHIP_DESC_XCD=0 restores the plain order)
   bool octree_gmem = false;           // node arrays larger than the LDS: global scratch rows (k_octree<., true>)
   size_t octree_row = 0;
@@ -1274,7 +1302,8 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     G.node_cap = round_up(node_cap, 8); G.max_cells_level = round_up(max_cells, 8);
     G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
     G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
-    c->fast_lds = (size_t)round_up((int)((size_t)2 * G.tile_h * G.tile_pitch + 2 * 64 * 8 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue (u16)
+    c->fast_narrow = tile_w - 6 <= 32;                      // every cell interior <= 32 px wide: k_fast_cells<true> (32-bit row masks)
+    c->fast_lds = (size_t)round_up((int)((size_t)2 * round_up(G.tile_h * G.tile_pitch, 16) + 2 * 64 * 8 + 16 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue counter + queue (u16)
     c->octree_wide = false;
     for (int l = 0; l < c->nlevels; l++) c->octree_wide = c->octree_wide || G.lv[l].kcap > 65535;
     c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, false);
@@ -1353,10 +1382,16 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   };
   if (side_mode == 1) { if (int rc = launch_blur_side()) return rc; }
   mark();
-  if (G.ncells_total > 0)
-    hipLaunchKernelGGL(k_fast_cells, dim3((G.ncells_total + FAST_WPB - 1) / FAST_WPB, nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
-                       c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
-                       c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds);
+  if (G.ncells_total > 0) {
+    if (c->fast_narrow)
+      hipLaunchKernelGGL(k_fast_cells<true>, dim3((G.ncells_total + FAST_WPB - 1) / FAST_WPB, nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
+                         c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
+                         c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds);
+    else
+      hipLaunchKernelGGL(k_fast_cells<false>, dim3((G.ncells_total + FAST_WPB - 1) / FAST_WPB, nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
+                         c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
+                         c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds);
+  }
   mark();
   // mode 2: the octree is one latency-bound workgroup per (frame, level) - 6 % VALU-busy, 0.6 waves per SIMD - so the
   // VALU-bound blur runs BESIDE it: the fork is taken after FAST, the octree is submitted first and keeps its slots

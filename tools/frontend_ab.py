@@ -35,3 +35,20 @@ out["match"] = round(sum(a.elapsed_time(b) for a, b in ev) / reps, 4)
 out["frames_per_s"] = round(B * reps / dt, 1)
 out["checksum"] = [int(counts.sum().item()), int(nmatch.sum().item()), int(desc.to(torch.int64).sum().item()), int(match12.to(torch.int64).sum().item())]
 print(json.dumps(out))
+# ---- two-stream pipeline (opt-in in production): batch m on stream m % 2 with its own extractor context and outputs, so that
+#      the latency-bound octree of one batch runs beside the VALU-bound kernels of the other
+if len(sys.argv) > 3:
+    S = int(sys.argv[3])
+    exs = [ex] + [ORBextractor(bench.NFEAT, 1.2, 8, 20, 7) for _ in range(S - 1)]
+    outs = [(kps, desc, counts, match12, nmatch)] + [tuple(torch.empty_like(t) for t in (kps, desc, counts, match12, nmatch)) for _ in range(S - 1)]
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    ex.set_profiling(False)
+    def run(n):
+        for m in range(n):
+            k = m % S
+            with torch.cuda.stream(streams[k]):
+                exs[k].extract_batch(frames, out=outs[k][:3])
+                mt.match_frames_batch(outs[k][0], outs[k][1], outs[k][2], pa, pb, out=outs[k][3:])
+    run(2 * S); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(reps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"streams": S, "frames_per_s": round(B * reps / dt, 1), "nmatch": [int(o[4].sum().item()) for o in outs]}))
