@@ -262,7 +262,10 @@ __device__ __forceinline__ void fast_tile_load(const uint8_t* base, uint8_t* til
 
 // ONE WAVE per cell (64-thread workgroups): no cross-wave barriers, lanes = columns of the cell, rows are
 // walked sequentially; the ordered (row-major) emit needs only a running wave-uniform offset.
-#define FAST_WPB 1      // waves (= cells) per workgroup
+#define FAST_WPB 1      // waves per workgroup
+#ifndef FAST_CPW
+#define FAST_CPW 1      // cells per wave, processed one after the other (2: 0.4858 vs 0.4827 ms - workgroup dispatch is not the limiter)
+#endif
 // NARROW: every cell interior of the geometry is <= 32 px wide (all KITTI / VGA levels: 30-px cells): the per-row survivor masks
 // are 32-bit (one v_ffbl / v_bcnt / ds_or_b32 instead of pairs) and the pre-test's lane layout is a constant.
 template <bool NARROW> struct FastMask;
@@ -280,7 +283,7 @@ template <bool NARROW>
 __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const CellDesc* __restrict__ cells,
                                                    const uint8_t* __restrict__ img0, long long img_frame_bytes,
                                                    const uint8_t* __restrict__ pyr, int* __restrict__ cell_cnt,
-                                                   uint32_t* __restrict__ cell_kps, int iniTh, int minTh, int lds_per_wave) {
+                                                   uint32_t* __restrict__ cell_kps, int iniTh, int minTh, int lds_per_wave, int xcd_map) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
   const int TP = G.tile_pitch;                        // multiple of 4
   const int plane = (G.tile_h * TP + 15) & ~15;       // multiple of 16 (the score plane is cleared with 16-byte stores)
@@ -289,11 +292,19 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   // Cell order = plain grid order.  (Measured on MI355X: an XCD-contiguous remap ci = (b%8)*chunk + b/8 cuts
   // this kernel's FETCH_SIZE 4.9x - neighbouring cells then share one L2 - but makes it 40 % SLOWER; it is
   // latency/issue-bound, not HBM-bound, so the faster mapping is kept.  DESIGN.md section 4.)
-  const int f = blockIdx.y;
+  int f = blockIdx.y, bxi = blockIdx.x;
+  if (xcd_map) {                                              // frame f on XCD f % 8 (as k_describe; host: frame count multiple of 8)
+    const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, x = lin & 7u, i = lin >> 3;
+    const uint32_t q = i / gridDim.x;
+    f = (int)(x + 8u * q); bxi = (int)(i - q * gridDim.x);
+  }
   const int wv = FAST_WPB == 1 ? 0 : (int)(threadIdx.x >> 6);       // (one wave per workgroup: the cell index is visibly uniform, its descriptor comes by scalar loads)
-  const int ci = blockIdx.x * FAST_WPB + wv;
-  if (ci >= G.ncells_total) return;                   // (no workgroup-wide barrier below: waves are independent)
   uint8_t* smem = smem_all + (size_t)wv * lds_per_wave;
+  // FAST_CPW cells per wave, one after the other on the same LDS (a wave's LDS operations execute in order, so the next cell's
+  // clears cannot overtake this cell's emit reads)
+  for (int rep = 0; rep < FAST_CPW; rep++) {
+  const int ci = (bxi * FAST_WPB + wv) * FAST_CPW + rep;
+  if (ci >= G.ncells_total) return;                   // (no workgroup-wide barrier below: waves are independent)
   uint8_t* tile = smem;                               // [tile_h][TP]
   uint8_t* score = smem + plane;                      // [tile_h][TP]
   mask_t* keep = (mask_t*)(score + plane);            // [64] NMS survivors per interior row (bit = ix)
@@ -471,6 +482,8 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   { const long long wid = (long long)f * G.ncells_total + ci;
     if (lane == 0 && wid < FAST_PROF_WAVES) { for (int k = 0; k < 5; k++) g_fast_prof[wid][k] = t_ph[k]; g_fast_prof[wid][7] = 1u; } }
 #endif
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  }   // cells of this wave
 }
 
 // ---------------------------------------------------------------------------- k_octree
@@ -1121,6 +1134,7 @@ struct orbx_ctx {
   void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
   size_t fast_lds = 0, octree_lds = 0, octree_lds_wide = 0;
   bool octree_wide = false;           // some level can hold > 65535 candidates: 32-bit node counters (k_octree<true, .>)
+  int fast_xcd = 0;                   // ORBHIP_FAST_XCD=1: k_fast_cells with frame f on XCD f % 8 (experiment)
   bool fast_narrow = false;           // k_fast_cells<true>: all cell interiors <= 32 px wide
   int desc_xcd = 1;                   // k_describe: frame f on XCD f % 8 (ORBHIP_DESC_XCD=0 restores the plain order)
   bool octree_gmem = false;           // node arrays larger than the LDS: global scratch rows (k_octree<., true>)
@@ -1303,7 +1317,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
     G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
     c->fast_narrow = tile_w - 6 <= 32;                      // every cell interior <= 32 px wide: k_fast_cells<true> (32-bit row masks)
-    c->fast_lds = (size_t)round_up((int)((size_t)2 * round_up(G.tile_h * G.tile_pitch, 16) + 2 * 64 * 8 + 16 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue counter + queue (u16)
+    c->fast_lds = (size_t)round_up((int)((size_t)2 * round_up(G.tile_h * G.tile_pitch, 16) + 2 * 64 * (c->fast_narrow ? 4 : 8) + 16 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue counter + queue (u16)
     c->octree_wide = false;
     for (int l = 0; l < c->nlevels; l++) c->octree_wide = c->octree_wide || G.lv[l].kcap > 65535;
     c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, false);
@@ -1384,13 +1398,13 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   mark();
   if (G.ncells_total > 0) {
     if (c->fast_narrow)
-      hipLaunchKernelGGL(k_fast_cells<true>, dim3((G.ncells_total + FAST_WPB - 1) / FAST_WPB, nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
+      hipLaunchKernelGGL(k_fast_cells<true>, dim3((G.ncells_total + FAST_WPB * FAST_CPW - 1) / (FAST_WPB * FAST_CPW), nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
                          c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
-                         c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds);
+                         c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds, (c->fast_xcd && nframes % 8 == 0) ? 1 : 0);
     else
-      hipLaunchKernelGGL(k_fast_cells<false>, dim3((G.ncells_total + FAST_WPB - 1) / FAST_WPB, nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
+      hipLaunchKernelGGL(k_fast_cells<false>, dim3((G.ncells_total + FAST_WPB * FAST_CPW - 1) / (FAST_WPB * FAST_CPW), nframes), dim3(64 * FAST_WPB), c->fast_lds * FAST_WPB, st, G,
                          c->d_cells.as<CellDesc>(), d_imgs, (long long)frame_stride, pyr, c->d_cellcnt.as<int>(),
-                         c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds);
+                         c->d_cellkps.as<uint32_t>(), c->iniTh, c->minTh, (int)c->fast_lds, (c->fast_xcd && nframes % 8 == 0) ? 1 : 0);
   }
   mark();
   // mode 2: the octree is one latency-bound workgroup per (frame, level) - 6 % VALU-busy, 0.6 waves per SIMD - so the
@@ -1462,6 +1476,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
   }
   if (const char* e = std::getenv("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = atoi(e);
   if (const char* e = std::getenv("ORBHIP_DESC_XCD")) c->desc_xcd = atoi(e);
+  if (const char* e = std::getenv("ORBHIP_FAST_XCD")) c->fast_xcd = atoi(e);
   *out = c;
   return 0;
 }
