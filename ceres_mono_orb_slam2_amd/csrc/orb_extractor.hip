@@ -59,6 +59,9 @@ struct GeomDev {
   int nlevels, ncells_total, cell_cap, sel_cap, keys_per_frame, desc_blocks;
   int tile_w, tile_h, tile_pitch;       // FAST LDS tile (max cell incl. apron)
   int node_cap, max_cells_level;
+#ifdef ORBHIP_OCT_LEVEL_EXPERIMENT
+  int oct_level_mask;
+#endif
   long long pyr_frame_bytes, blur_frame_bytes;
   LevelDev lv[MAX_LEVELS];
 };
@@ -487,6 +490,18 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
 }
 
 // ---------------------------------------------------------------------------- k_octree
+// Phase timing of k_octree (tools/octree_phase_prof.py builds a scratch library with -DORBHIP_OCT_PROF): thread 0 of every
+// workgroup adds the 100 MHz ticks between its stamps to g_oct_prof[level][phase]; [level][15] counts workgroups, [14] sweeps.
+#ifdef ORBHIP_OCT_PROF
+__device__ unsigned long long g_oct_prof[MAX_LEVELS][16];
+#define OCT_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_oct_prof[blockIdx.x][k], _t - t_prev); t_prev = _t; } } while (0)
+#define OCT_STAMP_INIT unsigned long long t_prev = __builtin_amdgcn_s_memrealtime()
+#define OCT_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_oct_prof[blockIdx.x][k], 1ull); } while (0)
+#else
+#define OCT_STAMP(k) do { } while (0)
+#define OCT_STAMP_INIT do { } while (0)
+#define OCT_COUNT(k) do { } while (0)
+#endif
 #define OCT_TPB 256     // threads per (frame, level) workgroup: 64 / 128 / 256 / 512 / 1024 -> 0.390 / 0.234 / 0.158 / 0.198 / 0.393 ms
 // exclusive scan of a[0..n) in place by an OCT_TPB-thread block; returns the total.
 __device__ int block_excl_scan(int* a, int n, int* s_tmp) {
@@ -551,6 +566,9 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
   // 0.190 ms; the 256 long workgroups then compete with each other for the same CUs' LDS pipes instead of being interleaved
   // with short ones.)
   const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+#ifdef ORBHIP_OCT_LEVEL_EXPERIMENT
+  if (!((G.oct_level_mask >> level) & 1)) return;
+#endif
   const LevelDev& Lv = G.lv[level];
   const int NC = G.node_cap, N = Lv.quota;
   uint8_t* smem;
@@ -580,6 +598,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
   const uint32_t* ckps = cell_kps + ((long long)f * G.ncells_total + Lv.cell_begin) * G.cell_cap;
   uint32_t* SEL = sel + ((long long)f * G.nlevels + level) * G.sel_cap;
 
+  OCT_STAMP_INIT;
   // ---- 0. gather the level's candidates in reference order (cells row-major, pixels row-major) --
   const int ncell = Lv.ncells;
   for (int c = tid; c < ncell; c += OCT_TPB) s_pref[c] = ccnt[c];
@@ -659,7 +678,10 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
   int cur = 0;
   int L = s_L;
   bool final_phase = false;
+  OCT_STAMP(0);        // gather + initial nodes
+  OCT_COUNT(15);
   while (true) {
+    OCT_COUNT(14);
     const int prev = L;
     const Rect16* R = rect[cur];
     const cnt_t* C = cnt[cur];
@@ -670,6 +692,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     const int ncand = block_excl_scan(sA, L, s_tmp);
     if (ncand == 0) break;                         // no split possible: |L| == prevSize  (:669)
     for (int p = tid; p < L; p += OCT_TPB) if (C[p] > 1) candl[sA[p]] = (unsigned short)p;
+    OCT_STAMP(1);      // A
     // ---- B: child occupancy of every candidate -------------------------------------------------
     // (the key loops read K / KN from global memory: OCT_U entries per thread are requested together - a one-entry loop
     // pays the global latency ~20 times per sweep phase at level 0, which bounded this kernel at ~0.2 ms)
@@ -689,6 +712,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
       }
     }
     __syncthreads();
+    OCT_STAMP(2);      // B (key loop)
     // ---- C: processing order and how many candidates get split ---------------------------------
     int m = ncand;
     if (!final_phase) {
@@ -716,6 +740,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
       if (s_m >= 0) m = s_m;
     }
     __syncthreads();
+    OCT_STAMP(final_phase ? 4 : 3);      // C (plain / final-phase sort)
     // ---- D/E/F: ranks, creation bases (rank order), split prefix (list order) -------------------
     for (int r = tid; r < m; r += OCT_TPB) {
       int p = order[r];
@@ -761,6 +786,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     }
     if (nexp) atomicAdd(&s_nexp, nexp);
     __syncthreads();
+    OCT_STAMP(5);      // D-G
     // ---- H: move the keys -----------------------------------------------------------------------
     for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
       uint32_t keyv[OCT_U]; int pv[OCT_U];
@@ -787,6 +813,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     const int nToExpand = s_nexp;
     cur ^= 1;
     __syncthreads();
+    OCT_STAMP(6);      // H (key loop)
     if (L >= N || L == prev) break;                              // (:669-672, :734-735)
     if (!final_phase && L + 3 * nToExpand > N) final_phase = true;   // (:673)
   }
@@ -810,6 +837,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     sel_cnt[f * G.nlevels + level] = L;
     if (L > G.sel_cap) atomicOr(&status[f], 2);
   }
+  OCT_STAMP(7);        // best key per node + output
 }
 
 // ---------------------------------------------------------------------------- k_blur7
@@ -1314,6 +1342,9 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     ORBHIP_REQUIRE(tile_w <= 64 && tile_h <= 64, ORBHIP_EINVAL, "FAST cell larger than 64 px (unsupported image geometry)");
     G.tile_w = tile_w; G.tile_h = tile_h; G.tile_pitch = round_up(tile_w, 4) + 4;
     G.node_cap = round_up(node_cap, 8); G.max_cells_level = round_up(max_cells, 8);
+#ifdef ORBHIP_OCT_LEVEL_EXPERIMENT
+    G.oct_level_mask = std::getenv("ORBHIP_OCT_LEVELS") ? (int)strtol(std::getenv("ORBHIP_OCT_LEVELS"), nullptr, 0) : 0xFFFF;
+#endif
     G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
     G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
     c->fast_narrow = tile_w - 6 <= 32;                      // every cell interior <= 32 px wide: k_fast_cells<true> (32-bit row masks)
@@ -1494,6 +1525,15 @@ int orbx_destroy(orbx_ctx* c) {
   delete c;
   return 0;
 }
+
+#ifdef ORBHIP_OCT_PROF
+int orbx_debug_oct_prof(unsigned long long* out /*[MAX_LEVELS][16]*/, int reset) {
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_prof), sizeof(unsigned long long) * MAX_LEVELS * 16));
+  if (reset) { std::vector<unsigned long long> z((size_t)MAX_LEVELS * 16, 0ull); ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_oct_prof), z.data(), z.size() * 8)); }
+  return 0;
+}
+#endif
 
 #ifdef ORBHIP_FAST_PROF
 int orbx_debug_fast_prof(unsigned long long* out8) {          // sums over the waves of the LAST launch: ticks per phase, [7] = waves
