@@ -719,10 +719,37 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
       for (int r = tid; r < ncand; r += OCT_TPB) order[r] = candl[r];
     } else {
       // sort by (count desc, list position asc): list position asc == creation desc (canonical F9)
-      for (int i = tid; i < ncand; i += OCT_TPB) {
-        int p = candl[i], cp = (int)C[p], r = 0;
-        for (int j = 0; j < ncand; j++) { int pj = candl[j], cj = (int)C[pj]; r += (cj > cp) || (cj == cp && pj < p); }
-        order[r] = (unsigned short)p;
+      if constexpr (!WIDE) {
+        // rank = number of candidates with a larger packed key (count << 16 | 0xFFFF - position; keys are distinct).  The keys
+        // live in the childpos rows (dead until phase G) and are read back as 16-byte broadcasts, two own keys per thread and
+        // trip: ~ncand / 4 LDS reads per thread instead of 2 ncand dependent ones (the pair loop took 20 us of a level-0
+        // workgroup's 83, tools/octree_phase_prof.py).
+        uint32_t* skeys = (uint32_t*)childpos;
+        const int npad4 = (ncand + 3) & ~3;
+        for (int i = tid; i < npad4; i += OCT_TPB) {
+          uint32_t kv = 0u;                                  // padding: smaller than every real key (counts are >= 2)
+          if (i < ncand) { const int p = candl[i]; kv = ((uint32_t)C[p] << 16) | (0xFFFFu - (uint32_t)p); }
+          skeys[i] = kv;
+        }
+        __syncthreads();
+        for (int i0 = tid; i0 < ncand; i0 += 2 * OCT_TPB) {
+          const int i1 = i0 + OCT_TPB;
+          const uint32_t my0 = skeys[i0], my1 = i1 < ncand ? skeys[i1] : 0xFFFFFFFFu;
+          int r0 = 0, r1 = 0;
+          for (int j = 0; j < npad4; j += 4) {
+            const uint4 k4 = *(const uint4*)(skeys + j);
+            r0 += (int)(k4.x > my0) + (int)(k4.y > my0) + (int)(k4.z > my0) + (int)(k4.w > my0);
+            r1 += (int)(k4.x > my1) + (int)(k4.y > my1) + (int)(k4.z > my1) + (int)(k4.w > my1);
+          }
+          order[r0] = (unsigned short)(0xFFFFu - (my0 & 0xFFFFu));
+          if (i1 < ncand) order[r1] = (unsigned short)(0xFFFFu - (my1 & 0xFFFFu));
+        }
+      } else {
+        for (int i = tid; i < ncand; i += OCT_TPB) {
+          int p = candl[i], cp = (int)C[p], r = 0;
+          for (int j = 0; j < ncand; j++) { int pj = candl[j], cj = (int)C[pj]; r += (cj > cp) || (cj == cp && pj < p); }
+          order[r] = (unsigned short)p;
+        }
       }
       __syncthreads();
       for (int r = tid; r < ncand; r += OCT_TPB) {
