@@ -26,6 +26,7 @@
 #include <vector>
 #include <algorithm>
 #include <new>
+#include <type_traits>
 
 #include "common.h"
 #include "orb_pattern_data.h"
@@ -495,21 +496,24 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
 #ifdef ORBHIP_OCT_PROF
 __device__ unsigned long long g_oct_prof[MAX_LEVELS][16];
 #define OCT_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_oct_prof[blockIdx.x][k], _t - t_prev); t_prev = _t; } } while (0)
-#define OCT_STAMP_INIT unsigned long long t_prev = __builtin_amdgcn_s_memrealtime()
+#define OCT_STAMP_INIT unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(); const unsigned long long t_begin = t_prev
+#define OCT_STAMP_END do { if (threadIdx.x == 0) { atomicMax(&g_oct_prof[blockIdx.x][13], t_prev - t_begin); atomicMax(&g_oct_prof[blockIdx.x][12], (unsigned long long)n); } } while (0)
 #define OCT_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_oct_prof[blockIdx.x][k], 1ull); } while (0)
 #else
 #define OCT_STAMP(k) do { } while (0)
 #define OCT_STAMP_INIT do { } while (0)
+#define OCT_STAMP_END do { } while (0)
 #define OCT_COUNT(k) do { } while (0)
 #endif
 #define OCT_TPB 256     // threads per (frame, level) workgroup: 64 / 128 / 256 / 512 / 1024 -> 0.390 / 0.234 / 0.158 / 0.198 / 0.393 ms
 // exclusive scan of a[0..n) in place by an OCT_TPB-thread block; returns the total.
-__device__ int block_excl_scan(int* a, int n, int* s_tmp) {
+template <typename T>
+__device__ int block_excl_scan(T* a, int n, int* s_tmp) {
   const int tid = threadIdx.x;
   const int items = (n + OCT_TPB - 1) / OCT_TPB;
   const int beg = min(tid * items, n), end = min(beg + items, n);
   int sum = 0;
-  for (int i = beg; i < end; i++) sum += a[i];
+  for (int i = beg; i < end; i++) sum += (int)a[i];
   const int lane = tid & 63, w = tid >> 6;
   int v = wave_incl_scan_i32(sum);
   if (lane == 63) s_tmp[w] = v;
@@ -518,7 +522,7 @@ __device__ int block_excl_scan(int* a, int n, int* s_tmp) {
 #pragma unroll
   for (int i = 0; i < OCT_TPB / 64; i++) { int t = s_tmp[i]; if (i < w) woff += t; total += t; }
   int run = woff + v - sum;
-  for (int i = beg; i < end; i++) { int t = a[i]; a[i] = run; run += t; }
+  for (int i = beg; i < end; i++) { int t = (int)a[i]; a[i] = (T)run; run += t; }
   __syncthreads();
   return total;
 }
@@ -548,15 +552,23 @@ template <> struct OctT<true> {
   static __device__ __forceinline__ void add(cc_t* cc, int p, int q) { atomicAdd(&cc[p].x + q, 1u); }
   static __device__ __forceinline__ void get(const cc_t& v, int c4[4]) { c4[0] = (int)v.x; c4[1] = (int)v.y; c4[2] = (int)v.z; c4[3] = (int)v.w; }
 };
-static size_t octree_lds_bytes(int node_cap, int max_cells_level, bool wide) {
-  const size_t per_node = 8 * 2 + (wide ? 16 : 8) + 8 + 4 + 4 + (wide ? 4 : 2) * 2 + 2 + 2 + 2;
-  return (size_t)node_cap * per_node + (size_t)(max_cells_level + 8) * 4 + 64;
+// Node arrays of one (frame, level) workgroup.  LDS instantiation with 16-bit counters: 44 bytes per node, so that the 442 nodes of
+// nfeatures = 2000 take 19.3 kB and EIGHT workgroups share a CU's 160 kB - all 2048 workgroups of a 256-frame batch are resident at
+// once (at 50 bytes per node plus a separate cell-prefix array only six fitted and the kernel ran in two rounds).  The scan
+// arrays are 16-bit there (values <= 4 node_cap), the cell-prefix array of the gather phase lies over everything behind rect[0]
+// (nothing else is live yet), the final-phase sort keys and the processing order share the childpos rows (dead until phase G),
+// the best-key array the child-count rows (dead after the last sweep).
+static size_t octree_lds_bytes(int node_cap, int max_cells_level, bool wide, bool gmem) {
+  const size_t scan_b = (wide || gmem) ? 4 : 2;
+  const size_t per_node = 8 * 2 + (wide ? 16 : 8) + 8 + 2 * scan_b + (wide ? 4 : 2) * 2 + 2 + 2;
+  const size_t nodes = (size_t)node_cap * per_node, pref = (size_t)node_cap * 8 + (size_t)(max_cells_level + 8) * 4;
+  return std::max(nodes, pref) + 16;
 }
 // GMEM: the node arrays live in a global scratch row of the (frame, level) workgroup instead of LDS - the fallback for per-level
 // quotas whose node arrays exceed the 160 kB of LDS (about 3200 keypoints in one level, i.e. nfeatures beyond ~15000; the
 // reference has no such limit).  Same code, same order of operations, slower memory.
 template <bool WIDE, bool GMEM>
-__global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
+__global__ __launch_bounds__(OCT_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
                                                 const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
                                                 unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
                                                 int* __restrict__ sel_cnt, int* __restrict__ nkeys_out,
@@ -581,16 +593,17 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
   typedef typename OctT<WIDE>::cc_t cc_t;
   cc_t* cc = (cc_t*)(rect[1] + NC);                   // 4 child counts of a candidate node
   uint2* childpos = (uint2*)(cc + NC);                // 4 x u16 new positions (or .x = shifted position)
-  int* sA = (int*)(childpos + NC);
-  int* sB = sA + NC;
-  int* s_pref = sB + NC;                              // [max_cells_level + 1]
+  typedef typename std::conditional<(WIDE || GMEM), int, unsigned short>::type scan_t;      // scan values are <= 4 NC
+  scan_t* sA = (scan_t*)(childpos + NC);
+  scan_t* sB = sA + NC;
   cnt_t* cnt[2];
-  cnt[0] = (cnt_t*)(s_pref + G.max_cells_level + 8);
+  cnt[0] = (cnt_t*)(sB + NC);
   cnt[1] = cnt[0] + NC;
-  unsigned short* order = (unsigned short*)(cnt[1] + NC);
-  unsigned short* candl = order + NC;
+  unsigned short* candl = (unsigned short*)(cnt[1] + NC);
   short* rankOf = (short*)(candl + NC);
-  __shared__ int s_tmp[16], s_m, s_nexp, s_L;
+  unsigned short* order = (unsigned short*)((uint8_t*)childpos + 4 * (size_t)NC);   // second half of the childpos rows (first half: sort keys)
+  int* s_pref = (int*)rect[1];                        // [max_cells_level + 1], gather phase only: lies over everything behind rect[0]
+  __shared__ int s_tmp[16], s_m, s_nexp, s_L, s_hist[MAX_INI], s_remap[MAX_INI], s_need_remap;
 
   uint32_t* K = keys + (long long)f * G.keys_per_frame + Lv.key_off;
   unsigned short* KN = knode + (long long)f * G.keys_per_frame + Lv.key_off;
@@ -613,10 +626,10 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     if (tid == 0) { sel_cnt[f * G.nlevels + level] = 0; atomicOr(&status[f], 1); }
     return;
   }
-  __syncthreads();
   const int nIni = Lv.nIni;
-  for (int i = tid; i < NC; i += OCT_TPB) { cnt[0][i] = 0; cnt[1][i] = 0; }
+  for (int i = tid; i < MAX_INI; i += OCT_TPB) s_hist[i] = 0;
   __syncthreads();
+  // ONE pass over the keys: fetch from the cell lists, store, initial node index and its histogram (LDS int atomics, nIni <= 64)
   for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
     uint32_t keyv[OCT_U];
 #pragma unroll
@@ -639,41 +652,37 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
         int idx = (int)__fdiv_rn((float)x, Lv.hX);     // vpIniNodes[kp.pt.x/hX]   (src/ORBextractor.cc:569)
         idx = min(idx, nIni - 1);
         KN[k] = (unsigned short)idx;
+        atomicAdd(&s_hist[idx], 1);
       }
     }
   }
-  // initial node histogram (nIni <= 64): LDS int atomics on sB
-  for (int i = tid; i < MAX_INI; i += OCT_TPB) sB[i] = 0;
-  __syncthreads();
-  for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
-    int pv[OCT_U];
-#pragma unroll
-    for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; pv[u] = k < n ? (int)KN[k] : -1; }
-#pragma unroll
-    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) atomicAdd(&sB[pv[u]], 1);
-  }
+  __syncthreads();                                  // (the cell-prefix array is dead from here: the node arrays it lay over come alive)
+  for (int i = tid; i < NC; i += OCT_TPB) { cnt[0][i] = 0; cnt[1][i] = 0; }
   __syncthreads();
   if (tid == 0) {
     int L0 = 0;
     for (int i = 0; i < nIni; i++) {
-      int c = sB[i];
-      sA[i] = L0;                                  // remap (valid where c > 0)
+      int c = s_hist[i];
+      s_remap[i] = L0;                             // (valid where c > 0)
       if (c > 0) {
         Rect16 r; r.ulx = (short)Lv.ini_x[i]; r.uly = 0; r.urx = (short)Lv.ini_x[i + 1]; r.bry = (short)Lv.winH;
         rect[0][L0] = r; cnt[0][L0] = (cnt_t)c; L0++;
       }
     }
     s_L = L0;
+    s_need_remap = L0 != nIni;                     // an empty initial node is dropped (:575-590): the later ones move up
   }
   __syncthreads();
-  for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
-    int pv[OCT_U];
+  if (s_need_remap) {
+    for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
+      int pv[OCT_U];
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; pv[u] = k < n ? (int)KN[k] : -1; }
+      for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; pv[u] = k < n ? (int)KN[k] : -1; }
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) KN[k0 + OCT_TPB * u] = (unsigned short)sA[pv[u]];
+      for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) KN[k0 + OCT_TPB * u] = (unsigned short)s_remap[pv[u]];
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   int cur = 0;
   int L = s_L;
@@ -846,7 +855,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
   }
   __syncthreads();
   // ---- best key of every node: max response, earliest candidate on ties (:741-760) ---------------
-  unsigned int* best = (unsigned int*)sA;
+  unsigned int* best = (unsigned int*)cc;                  // (the child-count rows are dead after the last sweep)
   for (int p = tid; p < L; p += OCT_TPB) best[p] = 0;
   __syncthreads();
   for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
@@ -865,6 +874,7 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree(GeomDev G, const int* __rest
     if (L > G.sel_cap) atomicOr(&status[f], 2);
   }
   OCT_STAMP(7);        // best key per node + output
+  OCT_STAMP_END;
 }
 
 // ---------------------------------------------------------------------------- k_blur7
@@ -1378,11 +1388,11 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     c->fast_lds = (size_t)round_up((int)((size_t)2 * round_up(G.tile_h * G.tile_pitch, 16) + 2 * 64 * (c->fast_narrow ? 4 : 8) + 16 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue counter + queue (u16)
     c->octree_wide = false;
     for (int l = 0; l < c->nlevels; l++) c->octree_wide = c->octree_wide || G.lv[l].kcap > 65535;
-    c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, false);
-    c->octree_lds_wide = octree_lds_bytes(G.node_cap, G.max_cells_level, true);
+    c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, false, false);
+    c->octree_lds_wide = octree_lds_bytes(G.node_cap, G.max_cells_level, true, false);
     // node arrays beyond the LDS: both instantiations keep them in a global scratch row per (frame, level) instead (k_octree<.., true>)
     c->octree_gmem = (c->octree_wide ? c->octree_lds_wide : c->octree_lds) > 160 * 1024;
-    c->octree_row = (size_t)round_up((int)c->octree_lds_wide, 256);
+    c->octree_row = (size_t)round_up((int)octree_lds_bytes(G.node_cap, G.max_cells_level, true, true), 256);
     ORBHIP_REQUIRE(G.node_cap <= 32760, ORBHIP_EINVAL, "nfeatures too large: more than 32752 keypoints in one level (16-bit node indices)");
     if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
     if (int rc = c->d_btiles.ensure(c->btiles.size() * sizeof(BlurTile))) return rc;

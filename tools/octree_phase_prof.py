@@ -35,5 +35,6 @@ for l in range(8):
     n = max(row[15], 1)
     d = {names[k]: round(row[k] / n * 0.01, 2) for k in range(8)}      # us per workgroup
     d["sweeps"] = round(row[14] / n, 2); d["total_us"] = round(sum(row[:8]) / n * 0.01, 1)
+    d["slowest_workgroup_us"] = round(row[13] * 0.01, 1); d["max_keys"] = int(row[12])
     res["level %d" % l] = d
 print(json.dumps(res, indent=1))
