@@ -880,6 +880,9 @@ __global__ __launch_bounds__(OCT_TPB) __attribute__((amdgpu_waves_per_eu(8, 8)))
 // ---------------------------------------------------------------------------- k_blur7
 #define BLUR_TW 128
 #define BLUR_TH 64
+#ifndef BLUR_COL_SLIDE
+#define BLUR_COL_SLIDE 0      // 1: a thread owns eight CONSECUTIVE output rows (14 LDS reads + 56 unpacks per thread instead of 56 + 224, bit-exact) - 0.407 ms against 0.392
+#endif
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (n == 1) return 0;
   while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
@@ -902,6 +905,9 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
   const int xo = x0 + 4 * cg;                        // first output column of this thread
   const bool aligned = ((L.pitch & 3) == 0) && (((size_t)src & 3) == 0);
   const bool inner = (xo >= 4) && (xo + 8 <= L.w);   // bytes xo-4 .. xo+7 all inside the row
+  // Row pass.  (Tried again in round 2, with the kernel 100 % VALU-busy: two v_dot4_u32_u8 per output on v_alignbyte windows of
+  // the 12-byte block - 14 instructions per four outputs instead of ~40, bit-exact - runs 0.450 ms against 0.392: the dot
+  // instructions cost more issue time than the SDWA byte-select multiply-adds they replace.)
   for (int yy = rr; yy < BLUR_TH + 6; yy += 8) {
     const int sy = reflect101(y0 + yy - 3, L.h);
     const uint8_t* row = src + (uint32_t)sy * (uint32_t)L.pitch;      // (32-bit unsigned row offset on the wave-uniform level base: no per-lane 64-bit multiply)
@@ -929,24 +935,61 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
   }
   __syncthreads();
   if (xo >= L.w) return;
-  uint8_t* drow = dst + (uint32_t)(y0 + rr) * (uint32_t)L.bpitch + (uint32_t)xo;
-  const uint32_t dstep = 8u * (uint32_t)L.bpitch;
-  for (int yy = rr; yy < BLUR_TH; yy += 8, drow += dstep) {
-    const int y = y0 + yy;
-    if (y >= L.h) break;
-    int acc[4] = {0, 0, 0, 0};
-    const int taps[7] = {18, 34, 49, 55, 49, 34, 18};
+#if BLUR_COL_SLIDE == 0
+  {
+    uint8_t* drow = dst + (uint32_t)(y0 + rr) * (uint32_t)L.bpitch + (uint32_t)xo;
+    const uint32_t dstep = 8u * (uint32_t)L.bpitch;
+    for (int yy = rr; yy < BLUR_TH; yy += 8, drow += dstep) {
+      const int y = y0 + yy;
+      if (y >= L.h) break;
+      int acc[4] = {0, 0, 0, 0};
+      const int taps[7] = {18, 34, 49, 55, 49, 34, 18};
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-      const uint2 m = *(const uint2*)&s_mid[yy + k][4 * cg];
-      acc[0] += taps[k] * (int)(m.x & 0xFFFF); acc[1] += taps[k] * (int)(m.x >> 16);
-      acc[2] += taps[k] * (int)(m.y & 0xFFFF); acc[3] += taps[k] * (int)(m.y >> 16);
+      for (int k = 0; k < 7; k++) {
+        const uint2 m = *(const uint2*)&s_mid[yy + k][4 * cg];
+        acc[0] += taps[k] * (int)(m.x & 0xFFFF); acc[1] += taps[k] * (int)(m.x >> 16);
+        acc[2] += taps[k] * (int)(m.y & 0xFFFF); acc[3] += taps[k] * (int)(m.y >> 16);
+      }
+      uint32_t out = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { int v = (acc[j] + (1 << 15)) >> 16; v = v > 255 ? 255 : v; out |= (uint32_t)v << (8 * j); }
+      *(uint32_t*)drow = out;                                      // bpitch is a multiple of 64 >= w
     }
-    uint32_t out = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) { int v = (acc[j] + (1 << 15)) >> 16; v = v > 255 ? 255 : v; out |= (uint32_t)v << (8 * j); }
-    *(uint32_t*)drow = out;                                      // bpitch is a multiple of 64 >= w
   }
+#else
+  // Column pass: a thread owns EIGHT CONSECUTIVE output rows of its four columns, so every intermediate row is read and unpacked
+  // once and feeds up to seven accumulators (the strided assignment read and unpacked seven rows per output row: 56 LDS reads
+  // and 224 unpacks per thread instead of 14 and 56).
+  {
+    const int rb = 8 * rr;                               // first output row of this thread inside the tile
+    const int taps[7] = {18, 34, 49, 55, 49, 34, 18};
+    int acc[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { acc[j][0] = 0; acc[j][1] = 0; acc[j][2] = 0; acc[j][3] = 0; }
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+      const uint2 m = *(const uint2*)&s_mid[rb + k][4 * cg];
+      const int v0 = (int)(m.x & 0xFFFF), v1 = (int)(m.x >> 16), v2 = (int)(m.y & 0xFFFF), v3 = (int)(m.y >> 16);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (k - j >= 0 && k - j <= 6) {
+          const int t = taps[k - j];
+          acc[j][0] += t * v0; acc[j][1] += t * v1; acc[j][2] += t * v2; acc[j][3] += t * v3;
+        }
+      }
+    }
+    uint8_t* drow = dst + (uint32_t)(y0 + rb) * (uint32_t)L.bpitch + (uint32_t)xo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (y0 + rb + j < L.h) {
+        uint32_t out = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { int v = (acc[j][c] + (1 << 15)) >> 16; v = v > 255 ? 255 : v; out |= (uint32_t)v << (8 * c); }
+        *(uint32_t*)(drow + (uint32_t)j * (uint32_t)L.bpitch) = out;           // bpitch is a multiple of 64 >= w
+      }
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------- k_describe
