@@ -766,6 +766,18 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restric
   for (int k = 0; k < 3; k++) D.gps[3 * (size_t)p + k] = D.gp[3 * (size_t)p + k] * sp[k];
 }
 
+// Layout of the per-observation 6x3 records E and E (C+D)^-1 (18 doubles = 144 bytes): the first 16 doubles of record i are ONE
+// aligned 128-byte line at base + 16 i, the last two live in a tail array at base + 16 nobs + 2 i.  As plain 144-byte AoS every
+// record straddled two or three 128-byte lines, and k_ba_schur - which gathers two records per pair, 3 GB per launch of a
+// 64-problem batch - moved about twice its useful bytes over the fabric (it ran at 2.85 TB/s of useful bytes).
+__device__ __forceinline__ void ld_rec18(const double* __restrict__ base, size_t nobs, size_t i, double* x) {
+  const double2* m = (const double2*)(base + 16 * i);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const double2 v = m[k]; x[2 * k] = v.x; x[2 * k + 1] = v.y; }
+  const double2 t = *(const double2*)(base + 16 * nobs + 2 * i);
+  x[16] = t.x; x[17] = t.y;
+}
+
 // per observation: E = (Jc S_c)^T (Jp S_p) (6x3) and E (C_s+D)^-1, stored AoS (18 doubles each).  Every wave transposes its
 // 64 x 18 results through LDS so that the AoS arrays are written as contiguous 512-byte runs (thread-strided 8-byte stores
 // of a 144-byte record cost 8x their bytes in write sectors - the kernel was the second most expensive of a batched solve).
@@ -809,11 +821,17 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(const BaDev* __res
       for (int k = 0; k < 18; k++) s_t[w][lane][k] = pass ? ec[k] : e[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-    double* dst = (pass ? D.EC : D.E) + 18 * (size_t)i0;
+    double* base = pass ? D.EC : D.E;
+    double* dst = base + 16 * (size_t)i0;                                   // (record layout: ld_rec18)
+    double* dtail = base + 16 * (size_t)D.nobs + 2 * (size_t)i0;
     const int rows = min(64, D.nobs - i0);
-    for (int idx = lane; idx < 18 * rows; idx += 64) {
-      const int r = idx / 18, k = idx - 18 * r;
+    for (int idx = lane; idx < 16 * rows; idx += 64) {
+      const int r = idx >> 4, k = idx & 15;
       if ((amask >> r) & 1ull) dst[idx] = s_t[w][r][k];
+    }
+    for (int idx = lane; idx < 2 * rows; idx += 64) {
+      const int r = idx >> 1, k = 16 + (idx & 1);
+      if ((amask >> r) & 1ull) dtail[idx] = s_t[w][r][k];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   }
@@ -844,11 +862,9 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
     for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += SC_TPB) {
-      const double* ec = D.EC + 18 * (size_t)D.pair_i[e];
-      const double* eb = D.E + 18 * (size_t)D.pair_j[e];
       double x[18], y[18];
-#pragma unroll
-      for (int k = 0; k < 18; k++) { x[k] = ec[k]; y[k] = eb[k]; }
+      ld_rec18(D.EC, (size_t)D.nobs, (size_t)D.pair_i[e], x);
+      ld_rec18(D.E, (size_t)D.nobs, (size_t)D.pair_j[e], y);
 #pragma unroll
       for (int u = 0; u < 6; u++)
 #pragma unroll
@@ -869,11 +885,9 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
   for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += SC_TPB) {
-    const double* ec = D.EC + 18 * (size_t)D.pair_i[e];
-    const double* eb = D.E + 18 * (size_t)D.pair_j[e];
     double x[18], y[18];
-#pragma unroll
-    for (int k = 0; k < 18; k++) { x[k] = ec[k]; y[k] = eb[k]; }
+    ld_rec18(D.EC, (size_t)D.nobs, (size_t)D.pair_i[e], x);
+    ld_rec18(D.E, (size_t)D.nobs, (size_t)D.pair_j[e], y);
 #pragma unroll
     for (int u = 0; u < 6; u++)
 #pragma unroll
@@ -882,7 +896,8 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
   if (!D.fix_points) {
     const int ca = free_cams[a];
     for (int e = D.cam_off[ca] + tid; e < D.cam_off[ca + 1]; e += SC_TPB) {
-      const double* ec = D.EC + 18 * (size_t)D.cam_obs[e];
+      double ec[18];
+      ld_rec18(D.EC, (size_t)D.nobs, (size_t)D.cam_obs[e], ec);
       const double* g = D.gps + 3 * (size_t)D.cam_obs_pt[e];
 #pragma unroll
       for (int u = 0; u < 6; u++) acc[21 + u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
@@ -1565,7 +1580,8 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
       double t[3] = {0.0, 0.0, 0.0};
       if (cc >= 0) {
         const double* y = D.rhs + 6 * cc;
-        const double* E = D.E + 18 * (size_t)i;
+        double E[18];
+        ld_rec18(D.E, n, (size_t)i, E);
 #pragma unroll
         for (int v = 0; v < 3; v++) {
           double sacc = 0;
