@@ -1328,14 +1328,21 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
     d4[u] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0;
     p4[u] = upd ? S[(size_t)(k + r) * np + kp + c] : 0.0;
   }
-  double a[G][8], ap[G][8];
+  // G = 1 (one problem at a time: latency): the L21 operands of this wave's rows are requested HERE, before the factor, and
+  // wait in registers.  G = 4 (lockstep batches: throughput): they are loaded where they are used instead - 128 registers
+  // less, so that the kernel fits two waves per SIMD (338 -> <= 256 registers; the trailing-update workgroups of the same
+  // launch, which are the majority, were held to one workgroup per CU by the panel role's register count).
+  constexpr bool EARLY = (G == 1);
+  double a[EARLY ? G : 1][8], ap[EARLY ? G : 1][8];
+  if constexpr (EARLY) {
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    const int arow = row0 + 16 * g + li;
+    for (int g = 0; g < G; g++) {
+      const int arow = row0 + 16 * g + li;
 #pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      a[g][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
-      ap[g][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;      // negated: L21 = A21 X^T + (-Lprev) M^T
+      for (int ks = 0; ks < 8; ks++) {
+        a[g][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
+        ap[g][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;      // negated: L21 = A21 X^T + (-Lprev) M^T
+      }
     }
   }
   if (F.done || !F.valid || F.chol_fail) return;
@@ -1388,16 +1395,25 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
     const int rg0 = row0 + 16 * g;
     if (rg0 > np) break;
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const int gi = EARLY ? g : 0;
+    if constexpr (!EARLY) {
+      const int arow = rg0 + li;
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        a[0][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
+        ap[0][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][ks], b0[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][ks], b1[ks], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gi][ks], b0[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gi][ks], b1[ks], acc1, 0, 0, 0);
     }
     if (upd) {
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g][ks], m0[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g][ks], m1[ks], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[gi][ks], m0[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[gi][ks], m1[ks], acc1, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -2069,6 +2085,33 @@ struct HostBA {
     if (!*rc && count) { if (hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); *rc = ORBHIP_ENODEV; } }
     return d;
   }
+  // Upload arena: the arrays of one problem whose sizes are known up front are built (or copied) into ONE pinned block at
+  // 256-byte-aligned offsets and reach the device with ONE copy into a device block of the same layout - a problem used to
+  // issue ~23 small H2D copies (a batched solve spent 10 % of its GPU time in 4-us copy kernels).
+  uint8_t* ar_h = nullptr; uint8_t* ar_d = nullptr; size_t ar_off = 0, ar_cap = 0;
+  int begin_arena(size_t bytes) {
+    int rc = 0;
+    ar_h = pinned<uint8_t>(bytes, &rc); ar_d = alloc<uint8_t>(bytes, &rc);
+    ar_off = 0; ar_cap = bytes;
+    return rc;
+  }
+  static size_t arena_need(size_t count, size_t elem) { return (count * elem + 255) & ~(size_t)255; }
+  template <typename T> T* arena_host(size_t count, int* rc) {
+    const size_t need = arena_need(std::max<size_t>(count, 1), sizeof(T));
+    if (ar_off + need > ar_cap) { if (!*rc) { set_error("internal: upload arena too small"); *rc = ORBHIP_EINVAL; } return nullptr; }
+    T* h = (T*)(ar_h + ar_off); ar_off += need;
+    return h;
+  }
+  template <typename T> T* arena_copy(const T* src, size_t count, int* rc) {       // caller memory -> arena (host side)
+    T* h = arena_host<T>(count, rc);
+    if (h && count) std::memcpy(h, src, count * sizeof(T));
+    return h;
+  }
+  template <typename T> T* arena_dev(const T* host_ptr) const { return host_ptr ? (T*)(ar_d + ((const uint8_t*)host_ptr - ar_h)) : nullptr; }
+  int flush_arena(hipStream_t st) {
+    if (ar_off && hipMemcpyAsync(ar_d, ar_h, ar_off, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); return ORBHIP_ENODEV; }
+    return 0;
+  }
   // for host data that does NOT outlive the enqueue (function-local vectors, stack structs): an asynchronous copy from
   // pageable memory may read its source after the call returned, so the data is first copied into this thread's pinned
   // staging, which stays valid until the solve has drained
@@ -2106,11 +2149,19 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   const double t_start = ba_now_ms();
   // group observations by point (stable), per-camera lists
   int rc = 0;
-  int* pt_off = H.pinned<int>(npts + 1, &rc);
-  int* oc = H.pinned<int>(nobs, &rc); int* op = H.pinned<int>(nobs, &rc);
-  double* ouv = H.pinned<double>(2 * (size_t)nobs, &rc); double* ow = H.pinned<double>(nobs, &rc);
-  uint8_t* orb = H.pinned<uint8_t>(nobs, &rc);
-  int* cam_off = H.pinned<int>(ncam + 1, &rc); int* cam_obs = H.pinned<int>(nobs, &rc); int* cam_obs_pt = H.pinned<int>(nobs, &rc);
+  {
+    typedef HostBA A;
+    const size_t no = (size_t)nobs, nc = (size_t)ncam, npt = (size_t)npts;
+    const size_t bytes = A::arena_need(npt + 1, 4) + 5 * A::arena_need(no, 4) + A::arena_need(2 * no, 8) + A::arena_need(no, 8) + A::arena_need(no, 1) +
+                         A::arena_need(nc + 1, 4) + A::arena_need(4 * nc, 8) + 2 * A::arena_need(nc, 1) + A::arena_need(nc, 4) + A::arena_need(7 * nc, 8) +
+                         A::arena_need(3 * npt, 8) + A::arena_need(1, sizeof(BaState)) + 16 * 256;
+    if (int r = H.begin_arena(bytes)) return r;
+  }
+  int* pt_off = H.arena_host<int>(npts + 1, &rc);
+  int* oc = H.arena_host<int>(nobs, &rc); int* op = H.arena_host<int>(nobs, &rc);
+  double* ouv = H.arena_host<double>(2 * (size_t)nobs, &rc); double* ow = H.arena_host<double>(nobs, &rc);
+  uint8_t* orb = H.arena_host<uint8_t>(nobs, &rc);
+  int* cam_off = H.arena_host<int>(ncam + 1, &rc); int* cam_obs = H.arena_host<int>(nobs, &rc); int* cam_obs_pt = H.arena_host<int>(nobs, &rc);
   if (rc) return rc;
   for (int p = 0; p <= npts; p++) pt_off[p] = 0;
   for (int i = 0; i < nobs; i++) pt_off[in.obs_pt[i] + 1]++;
@@ -2126,7 +2177,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   for (int j = 0; j < nobs; j++) cam_off[oc[j] + 1]++;
   for (int c = 0; c < ncam; c++) cam_off[c + 1] += cam_off[c];
   std::vector<int> cfill(cam_off, cam_off + ncam);
-  int* cam_pos = H.pinned<int>(nobs, &rc);
+  int* cam_pos = H.arena_host<int>(nobs, &rc);
   if (rc) return rc;
   for (int j = 0; j < nobs; j++) { int e = cfill[oc[j]]++; cam_obs[e] = j; cam_obs_pt[e] = op[j]; cam_pos[j] = e; }
   std::vector<int> cam_col(ncam, -1), free_cams;
@@ -2184,14 +2235,16 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   static const bool use_la = []() { const char* e = std::getenv("ORBHIP_BA_LOOKAHEAD"); return !(e && e[0] == '0'); }();
   static const int la_max = []() { const char* e = std::getenv("ORBHIP_BA_LA_MAX"); return e ? atoi(e) : 1024; }();
   D.chol_la = (use_la && npad <= la_max) ? 1 : 0;
-  D.K4 = H.upload(in.K4, 4 * (size_t)ncam, &rc, s); D.cam_fixed = H.upload(in.cam_fixed, ncam, &rc, s); D.cam_col = H.upload_staged(cam_col.data(), ncam, &rc, s);
-  D.poses = H.upload(in.poses7, 7 * (size_t)ncam, &rc, s); D.pts = H.upload(in.pts3, 3 * (size_t)npts, &rc, s);
+  // (arena: host images of these arrays sit in one pinned block; ONE copy below moves them all)
+  D.K4 = H.arena_dev(H.arena_copy(in.K4, 4 * (size_t)ncam, &rc)); D.cam_fixed = H.arena_dev(H.arena_copy(in.cam_fixed, ncam, &rc));
+  D.cam_col = H.arena_dev(H.arena_copy(cam_col.data(), ncam, &rc));
+  D.poses = H.arena_dev(H.arena_copy(in.poses7, 7 * (size_t)ncam, &rc)); D.pts = H.arena_dev(H.arena_copy(in.pts3, 3 * (size_t)npts, &rc));
   D.cand_poses = H.alloc<double>(7 * (size_t)ncam, &rc); D.cand_pts = H.alloc<double>(3 * (size_t)npts, &rc);
-  D.obs_cam = H.upload(oc, nobs, &rc, s); D.obs_pt = H.upload(op, nobs, &rc, s); D.obs_uv = H.upload(ouv, 2 * (size_t)nobs, &rc, s);
-  D.obs_w = H.upload(ow, nobs, &rc, s); D.obs_robust = H.upload(orb, nobs, &rc, s);
-  D.pt_off = H.upload(pt_off, npts + 1, &rc, s); D.cam_off = H.upload(cam_off, ncam + 1, &rc, s);
-  D.cam_obs = H.upload(cam_obs, nobs, &rc, s); D.cam_obs_pt = H.upload(cam_obs_pt, nobs, &rc, s);
-  D.cam_pos = H.upload(cam_pos, nobs, &rc, s); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
+  D.obs_cam = H.arena_dev(oc); D.obs_pt = H.arena_dev(op); D.obs_uv = H.arena_dev(ouv);
+  D.obs_w = H.arena_dev(ow); D.obs_robust = H.arena_dev(orb);
+  D.pt_off = H.arena_dev(pt_off); D.cam_off = H.arena_dev(cam_off);
+  D.cam_obs = H.arena_dev(cam_obs); D.cam_obs_pt = H.arena_dev(cam_obs_pt);
+  D.cam_pos = H.arena_dev(cam_pos); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
   D.free_cams = H.upload_staged(free_cams.data(), nfc, &rc, s);
   D.blk_a = H.upload_staged(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload_staged(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload_staged(blk_off.data(), 2 * (size_t)nblk, &rc, s);
   D.pair_i = H.upload(pair_i, npairs_all, &rc, s); D.pair_j = H.upload(pair_j, npairs_all, &rc, s);
@@ -2202,7 +2255,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.Cinv = H.alloc<double>(6 * (size_t)npts, &rc); D.gps = H.alloc<double>(3 * (size_t)npts, &rc);
   D.E = H.alloc<double>(18 * (size_t)nobs, &rc); D.EC = H.alloc<double>(18 * (size_t)nobs, &rc);
   D.t3 = H.alloc<double>(3 * (size_t)std::max(nobs, 1), &rc);
-  D.cam_local = in.cam_local ? H.upload(in.cam_local, ncam, &rc, s) : nullptr;
+  D.cam_local = in.cam_local ? H.arena_dev(H.arena_copy(in.cam_local, ncam, &rc)) : nullptr;
   D.erase = in.cam_local ? H.alloc<unsigned char>(std::max(nobs, 1), &rc) : nullptr;
   D.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
   D.Dinv = H.alloc<double>((size_t)npad * NB, &rc);
@@ -2216,6 +2269,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   *h_st = st0;
   ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, h_st, sizeof(st0), hipMemcpyHostToDevice, s));
   out->h_st = h_st;
+  if (int r = H.flush_arena(s)) return r;
   ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)npad * sizeof(double), s));
   ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)nparts * sizeof(double), s));
   out->D = D; out->nb_obs = nb_obs; out->nb_cam = nb_cam; out->nb_pt = nb_pt; out->npairs = npairs_all;
