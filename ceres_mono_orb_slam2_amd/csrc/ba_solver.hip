@@ -853,15 +853,19 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
   const int tid = threadIdx.x;
   const int np = D.npad;
   __shared__ double s_red[16 * 36], s_out[36];
-  if ((int)blockIdx.x >= D.nblk) return;
   if ((int)blockIdx.x >= D.nfc) {
-    // off-diagonal block (a, b): one pair per thread, all 36 products in registers, one block reduction
-    const int blk = blockIdx.x;
+    // off-diagonal blocks (a, b): ONE WAVE per block, four blocks per workgroup (mean 127 pairs: two trips of a wave), all 36
+    // products in registers and a wave-level reduction only.  (One 256-thread workgroup per block spent most of its VALU time
+    // in the reduction - 36 values x 18 DPP operations in each of four waves that held one pair per thread or none: 973 -> 774
+    // us per 64-problem launch with one wave per block; the diagonal blocks, 90..600 pairs plus the rhs, keep four waves.)
+    const int w = tid >> 6, lane = tid & 63;
+    const int blk = D.nfc + 4 * ((int)blockIdx.x - D.nfc) + w;
+    if (blk >= D.nblk) return;                                 // (wave-level exit: no workgroup barrier on this path)
     const int a = D.blk_a[blk], b = D.blk_b[blk];
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += SC_TPB) {
+    for (int e = D.blk_off[2 * blk] + lane; e < D.blk_off[2 * blk + 1]; e += 64) {
       double x[18], y[18];
       ld_rec18(D.EC, (size_t)D.nobs, (size_t)D.pair_i[e], x);
       ld_rec18(D.E, (size_t)D.nobs, (size_t)D.pair_j[e], y);
@@ -870,13 +874,19 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
 #pragma unroll
         for (int v = 0; v < 6; v++) acc[6 * u + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
     }
-    block_reduce_dpp<36>(acc, s_red, s_out);
-    if (tid < 36) {
-      const int u = tid / 6, v = tid - 6 * u;
-      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -s_out[tid];                 // lower triangle: block (b, a) = -(acc)^T
+#pragma unroll
+    for (int k = 0; k < 36; k++) {
+      const double t = wave_sum_dpp(acc[k]);                   // (total valid in lane 63)
+      if (lane == 63) s_red[w * 36 + k] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+      const int u = lane / 6, v = lane - 6 * u;
+      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -s_red[w * 36 + lane];       // lower triangle: block (b, a) = -(acc)^T
     }
     return;
   }
+  if ((int)blockIdx.x >= D.nblk) return;
   // diagonal block (a, a): 21 lower-triangle products per pair, and the rhs of camera a
   //   rhs_a = g_s - sum over the camera's observations of EC_i * g_p
   // both sums are accumulated first and share ONE block reduction (27 values)
@@ -2330,7 +2340,8 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       const BaDev& D = B.P[p].D;
       B.Dh[p] = D;
       B.g_obs = std::max(B.g_obs, B.P[p].nb_obs); B.g_cam = std::max(B.g_cam, B.P[p].nb_cam); B.g_pt = std::max(B.g_pt, B.P[p].nb_pt);
-      B.g_blk = std::max(B.g_blk, D.nblk); B.g_npad = std::max(B.g_npad, D.npad); B.g_pad = std::max(B.g_pad, D.npad - D.n6); B.g_n6 = std::max(B.g_n6, D.n6);
+      B.g_blk = std::max(B.g_blk, D.nfc + (D.nblk - D.nfc + 3) / 4);      /* k_ba_schur: a workgroup per diagonal block, a WAVE per off-diagonal block */
+      B.g_npad = std::max(B.g_npad, D.npad); B.g_pad = std::max(B.g_pad, D.npad - D.n6); B.g_n6 = std::max(B.g_n6, D.n6);
       B.g_camcount = std::max(B.g_camcount, D.ncam); B.g_apply = std::max(B.g_apply, std::max(7 * D.ncam, 3 * D.npts));
       B.g_zero = std::max(B.g_zero, (size_t)D.n6 * D.npad);
       if (D.chol_la) B.g_npad_la = std::max(B.g_npad_la, D.npad); else B.g_npad_2l = std::max(B.g_npad_2l, D.npad);
