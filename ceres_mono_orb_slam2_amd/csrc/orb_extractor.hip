@@ -1069,13 +1069,16 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   int cap, int* __restrict__ counts, float p1, float p3, float p5,
                                                   float p7, float factorPI, int xcd_map) {
-  __shared__ uint32_t s_pat[256];                           // pattern pair k = bytes (x0, y0, x1, y1)
+  // pattern pair k as FLOATS (x0, x1, y0, y1): one 16-byte LDS read per pair, and the two x and the two y of a pair sit in
+  // consecutive registers for the packed-f32 rotation below (the byte form cost a sign-extension + conversion per coordinate)
+  __shared__ __attribute__((aligned(16))) float s_patf[256][4];
   // intensity-centroid weights as byte vectors: for patch row |v| and source dword i (bytes k = 4i .. 4i+3 of the 31-byte row,
   // u = k - 15), s_icm holds [|u| <= umax[|v|]] and s_ick holds k * [..] - the row sums become v_dot4_u32_u8 on whole dwords
   __shared__ __attribute__((aligned(16))) uint32_t s_icm[16][8], s_ick[16][8];
   __shared__ __attribute__((aligned(16))) uint32_t s_patch[DESC_WPB][2][DESC_PATCH_LDS];
   for (int q = threadIdx.x; q < 256; q += 64 * DESC_WPB) {
-    s_pat[q] = ((const uint32_t*)c_pattern)[q];
+    { const signed char* pc = c_pattern + 4 * q;
+      s_patf[q][0] = (float)pc[0]; s_patf[q][1] = (float)pc[2]; s_patf[q][2] = (float)pc[1]; s_patf[q][3] = (float)pc[3]; }
     const int which = q >> 7, rv = (q >> 3) & 15, i4 = q & 7, d = c_umax[rv];
     uint32_t w = 0;
 #pragma unroll
@@ -1190,18 +1193,29 @@ __global__ __launch_bounds__(64 * DESC_WPB) void k_describe(GeomDev G, const uin
   const uint8_t* lpatch = (const uint8_t*)&s_patch[threadIdx.x >> 6][half][0] + bsh + DESC_PATCH_R * (4 * DESC_PATCH_W4) + DESC_PATCH_R;   // pattern origin
   // pair index pr = 32 j + hl: consecutive lanes read consecutive pattern words, and the wave ballot of test j holds descriptor
   // dword j of the first keypoint in its low half and of the second keypoint in its high half (bit pr & 7 of byte pr >> 3)
+  // Both points of a pair at once on packed f32 (v_pk_mul_f32 / v_pk_add_f32, the same IEEE operations in the same order as the
+  // scalar form, no contraction): FY = X b + Y a, FX = X a - Y b with X = (x0, x1), Y = (y0, y1).  cvRound = round-half-even is
+  // ONE more packed add of 1.5 * 2^23: the integer then sits in the low mantissa bits (0x4B400000 + i for |i| < 2^22), the
+  // multiply-add of the LDS address uses only the low 24 bits of the row term (0x400000 + iy) and the constant parts go into
+  // the patch base.  8 packed operations per pair instead of 8 conversions + 12 multiplies / adds + 8 roundings.
+  typedef float float2_v __attribute__((ext_vector_type(2)));
+  const float2_v A2 = {a, a}, B2 = {b, b}, MAGIC = {12582912.0f, 12582912.0f};
+  const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) const uint8_t*)lpatch
+                         - (0x400000u * (uint32_t)(4 * DESC_PATCH_W4) + 0x4B400000u);
   uint32_t mydw = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    const uint32_t pw = s_pat[32 * j + hl];
+    const float4 pf = *(const float4*)&s_patf[32 * j + hl][0];
+    const float2_v X = {pf.x, pf.y}, Y = {pf.z, pf.w};
+    const float2_v FY = X * B2 + Y * A2;
+    const float2_v FX = X * A2 - Y * B2;
+    const float2_v RY = FY + MAGIC, RX = FX + MAGIC;
     int t[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-      float px = (float)(signed char)(pw >> (16 * s)), py = (float)(signed char)(pw >> (16 * s + 8));
-      float fy = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
-      float fx = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
-      int iy = __float2int_rn(fy), ix = __float2int_rn(fx);
-      t[s] = lpatch[iy * (4 * DESC_PATCH_W4) + ix];
+      const uint32_t iyb = __builtin_bit_cast(uint32_t, s ? RY.y : RY.x), ixb = __builtin_bit_cast(uint32_t, s ? RX.y : RX.x);
+      const uint32_t addr = __umul24(iyb, (uint32_t)(4 * DESC_PATCH_W4)) + ixb + lbase;
+      t[s] = *(const __attribute__((address_space(3))) uint8_t*)(size_t)addr;
     }
     const unsigned long long bal = __ballot(t[0] < t[1]);
     const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
