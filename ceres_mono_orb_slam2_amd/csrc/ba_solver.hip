@@ -2416,7 +2416,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     // look-ahead scheme (reduced systems <= 1024): one launch per 32-column step, panel + the previous step's update
     for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) launch_la(npl, k, 0, INT_MAX, 0, no_wide);
     // two-level scheme (outer block = 4 panels of NB = 32) for the larger systems.
-    const int OB = 128;
+    static const int OB = []() { const char* e = std::getenv("ORBHIP_BA_OB"); const int v = e ? atoi(e) : 128; return (v >= 64 && v <= 1024 && v % 32 == 0) ? v : 128; }();
     static const bool classic = []() { const char* e = std::getenv("ORBHIP_BA_2L_CLASSIC"); return e && e[0] == '1'; }();
     if (classic) {
       // round-1 form: panel -> thin update -> panel ... -> one wide update
