@@ -607,12 +607,16 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
 }
 
 // ---- 6x6 pose blocks: B_c = sum Jc^T Jc, g_c = sum Jc^T r over the camera's observations ----------
-__global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restrict__ Dv) {
+__device__ __forceinline__ void ba_pt_blocks_body(const BaDev& D, int bx);
+// k_ba_cam_blocks also carries the 3x3 landmark blocks (workgroups behind the `ncam_grid` camera workgroups): the two were
+// separate launches of ~7 us each on a single solve's dependent chain, and neither depends on the other.
+__global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restrict__ Dv, int ncam_grid) {
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4 * 27], s_out[27];
   const BaState* st = D.st;
   const StFlags F = ld_flags(st);
   if (F.done || !F.need_eval) return;
+  if ((int)blockIdx.x >= ncam_grid) { ba_pt_blocks_body(D, (int)blockIdx.x - ncam_grid); return; }
   const int c = blockIdx.x;
   if (c >= D.ncam) return;
   const int cc = D.cam_col[c];
@@ -639,12 +643,9 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
 }
 
 // ---- 3x3 landmark blocks ------------------------------------------------------------------------------
-__global__ __launch_bounds__(BA_TPB) void k_ba_pt_blocks(const BaDev* __restrict__ Dv) {
-  const BaDev D = Dv[blockIdx.y];
-  const BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.need_eval || D.fix_points) return;
-  const int p = blockIdx.x * BA_TPB + threadIdx.x;
+__device__ __forceinline__ void ba_pt_blocks_body(const BaDev& D, int bx) {
+  if (D.fix_points) return;
+  const int p = bx * BA_TPB + threadIdx.x;
   if (p >= D.npts) return;
   const size_t n = D.nobs;
   double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
@@ -745,11 +746,18 @@ __device__ __forceinline__ bool inv3_sym6(const double* C, double* Ci) {   // C 
   return true;
 }
 
-__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restrict__ Dv) {
+// (the workgroups behind the `npt_grid` landmark workgroups zero the reduced system: k_ba_zero_S was a launch of its own)
+__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restrict__ Dv, int npt_grid) {
   const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
   const StFlags F = ld_flags(st);
-  if (F.done || !F.valid || D.fix_points) return;
+  if (F.done || !F.valid) return;
+  if ((int)blockIdx.x >= npt_grid) {
+    const size_t tot = (size_t)D.n6 * D.npad, nz = (size_t)(gridDim.x - npt_grid) * BA_TPB;
+    for (size_t i = (size_t)((int)blockIdx.x - npt_grid) * BA_TPB + threadIdx.x; i < tot; i += nz) D.S[i] = 0.0;
+    return;
+  }
+  if (D.fix_points) return;
   const int p = blockIdx.x * BA_TPB + threadIdx.x;
   if (p >= D.npts) return;
   if (D.pt_off[p] == D.pt_off[p + 1]) return;
@@ -2383,15 +2391,14 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   if (g_pad > 0) hipLaunchKernelGGL(k_ba_pad, dim3(g_pad, ny), dim3(64), 0, s, Dv);
   auto enqueue_eval = [&]() {
     hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 0);
-    hipLaunchKernelGGL(k_ba_cam_blocks, dim3(g_camcount, ny), dim3(BA_TPB), 0, s, Dv);
-    hipLaunchKernelGGL(k_ba_pt_blocks, dim3(g_pt, ny), dim3(BA_TPB), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_cam_blocks, dim3(g_camcount + g_pt, ny), dim3(BA_TPB), 0, s, Dv, g_camcount);      // + the landmark blocks
     hipLaunchKernelGGL(k_ba_after_eval, dim3(1, ny), dim3(AE_TPB), 0, s, Dv);
   };
   auto enqueue_iteration = [&]() {
     hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(1), 0, s, Dv);
-    hipLaunchKernelGGL(k_ba_schur_prep, dim3(g_pt, ny), dim3(BA_TPB), 0, s, Dv);
+    const int g_zs = g_n6 > 0 ? std::min(1024, (int)((g_zero + 255) / 256)) : 0;
+    hipLaunchKernelGGL(k_ba_schur_prep, dim3(g_pt + g_zs, ny), dim3(BA_TPB), 0, s, Dv, g_pt);                    // + zeroing of S
     hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
-    if (g_n6 > 0) hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)((g_zero + 255) / 256)), ny), dim3(256), 0, s, Dv);
     if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), 0, s, Dv);
     const int npad = B.g_npad_2l;                             // (0 when every problem of the batch takes the look-ahead scheme)
     auto launch_update = [&](hipStream_t st_, int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
