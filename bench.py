@@ -41,8 +41,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer VALU instruction issues over 4 cycles;
                                # measured 35-39 T lane-instr/s for xor/bcnt/pk_*16/dot4/dot2/sad/alignbyte (tools/ubench/valu_rate.hip)
 MATCH_LANE_OPS_PER_PAIR = 19.5   # VALU instructions per Hamming distance in k_match_pairs (ISA-checked: 8 xor + 8 v_bcnt + v_lshl_or + v_max + v_min + half a v_min3)
-PMC_TRAFFIC = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 PMC summaries, newest first
-PMC_VALU = ("r02_pmc_valu.json", "r01_pmc_valu.json")
+PMC_TRAFFIC = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 PMC summaries, newest first
+PMC_VALU = ("r03_pmc_valu.json", "r02_pmc_valu.json", "r01_pmc_valu.json")
+MATCH_BYTES_PER_KP = 2 * (32 + 28) + 4      # k_match_pairs per keypoint of a pair: both frames' descriptor + keypoint record read once, match12 written
 
 
 def make_frames(batch, seed, pad_w=0, pad_h=0):
@@ -81,6 +82,40 @@ def _cpu_frames_worker(frames, lo, n, out, k, deadline=None):
         prev = (kp, d)
         done += 1
     out[k] = done
+
+
+def prepare_cpu_oracle(frames):
+    """the CPU legs are timed on a `-O3 -march=native -ffp-contract=off` build of the oracle, compiled on THIS
+    host (oracle/pyoracle.build_native) and used only after it reproduced the canonical (-march=x86-64-v2) build bit for bit
+    on two of the bench's frames (keypoints, descriptors, matches) and on a small LocalBA (poses, points, flags)."""
+    from oracle import pyoracle as po
+    from ceres_mono_orb_slam2_amd import synth
+    info = {"flags": po.CANONICAL_FLAGS, "native": False}
+    po.use_library(None)
+    so = po.build_native()
+    if so is None:
+        info["note"] = "native build failed on this host: canonical build timed"
+        return info
+    g = synth.make_ba_graph(2, ncam=8, npts=200, nobs=900, n_fixed=1)
+    a = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(8, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+
+    def probe():
+        E = po.OracleExtractor(NFEAT)
+        k0, d0 = E.extract(frames[0]); k1, d1 = E.extract(frames[1])
+        m, nm = po.match_frames(d1, k1["angle"], d0, k0["angle"], 0.9, 50, True)
+        rc, poses, pts, erase, _, s2 = po.local_ba(*a)
+        return [k0.tobytes(), d0.tobytes(), k1.tobytes(), d1.tobytes(), m.tobytes(), int(nm),
+                np.asarray(poses).tobytes(), np.asarray(pts).tobytes(), np.asarray(erase).tobytes(), int(s2["iterations"])]
+    ref = probe()
+    po.use_library(so)
+    same = probe() == ref
+    if not same:
+        po.use_library(None)
+        info["note"] = "native build is NOT bit-identical to the canonical one on this host: canonical build timed"
+        return info
+    info.update({"flags": po.NATIVE_FLAGS, "native": True,
+                 "bit_identical_to_canonical": "2 frames (keypoints, descriptors, matches) + 1 small LocalBA (poses, points, erase flags, iterations)"})
+    return info
 
 
 def cpu_baseline(frames, n_sample, all_seconds):
@@ -213,7 +248,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if shared else dev          # where collective payloads live
     backend = None
-    if world > 1:
+    # ORBHIP_BENCH_FORCE_DIST=1: build the process group (RCCL) and run the landmark all-gather even at world size 1 - the
+    # one-GPU box's only way to execute the N > 1 code path on a real RCCL communicator (tests/test_gpu_rccl.py)
+    use_dist = world > 1 or os.environ.get("ORBHIP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if shared else "nccl"
         if shared:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -274,7 +315,7 @@ def main():
                     one(m, m % S, events)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -342,6 +383,12 @@ def main():
     # ---- LocalBA / PoseOptimization / GlobalBA legs: every rank solves its own independent problems (sub-map sharding,
     #      no collective in the solve); for N > 1 the landmark updates are merged with ONE all-gather.
     localba, collective = None, None
+    oracle_build = None
+    if not args.no_cpu and world == 1 and rank == 0:
+        try:
+            oracle_build = prepare_cpu_oracle(frames_host)
+        except Exception as e:
+            oracle_build = {"error": repr(e)}
     if not args.no_ba:
         ok = 1
         try:
@@ -349,7 +396,7 @@ def main():
             localba = ba_bench.run(dev, cpu=(not args.no_cpu) and world == 1, rank=rank)
         except Exception as e:                       # never lose the headline line to the secondary leg
             localba, ok = {"error": repr(e)}, 0
-        if world > 1:
+        if use_dist:
             flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # collectives below only if EVERY rank's leg succeeded
             if int(flag.item()) == 1:
@@ -375,11 +422,15 @@ def main():
         fps = B * M * world * K / dt
         per_call = {k: v / max(ncalls, 1) for k, v in stage_ms.items()}
         per_call["match"] = match_ms / max(len(ev), 1)
-        # HBM roofline of the dominant streaming kernel of the extract path
+        # the dominant kernel = the longest launch of the step, the matcher included (its bytes: both frames' records once)
+        bytes_of = dict(BYTES); bytes_of["match"] = int(round(mean_kp * MATCH_BYTES_PER_KP))
+        kernel_of = dict(KERNEL_OF); kernel_of["match"] = "k_match_pairs"
+        stages = {k: per_call[k] for k in ("pyramid", "fast_cells", "blur", "describe", "match")}
+        dom = max(stages, key=stages.get)
         hbm_stages = {k: per_call[k] for k in ("pyramid", "fast_cells", "blur", "describe")}
-        dom = max(hbm_stages, key=hbm_stages.get)
-        kname = KERNEL_OF[dom]
-        ach = BYTES[dom] * B / (per_call[dom] * 1e-3) / 1e9
+        hdom = max(hbm_stages, key=hbm_stages.get)
+        kname = kernel_of[dom]
+        ach = bytes_of[dom] * B / (per_call[dom] * 1e-3) / 1e9
         # HBM traffic per launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs),
         # scaled to this batch -- not measured in this run (counters need rocprofv3); None if the summary is absent
         traffic, traffic_src = None, None
@@ -393,9 +444,9 @@ def main():
         roof = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": (traffic_src + " (committed PMC pass of this kernel, scaled to the batch; not collected in this run)") if traffic_src else None,
-                "algorithmic_bytes_per_launch": BYTES[dom] * B,
-                "ms_per_launch": per_call[dom], "launches_timed": ncalls,
-                "timing": "HIP events on the launch stream inside the timed region (orbx_set_profiling)"}
+                "algorithmic_bytes_per_launch": bytes_of[dom] * B,
+                "ms_per_launch": per_call[dom], "launches_timed": ncalls if dom != "match" else len(ev),
+                "timing": "HIP events on the launch stream inside the timed region (orbx_set_profiling; the matcher: torch events on the same stream)"}
         # the kernel streams bytes but BINDS on the integer VALU issue rate: report that fraction too, from the
         # committed PMC pass (SQ_INSTS_VALU x 4 cycles / SIMD-cycles of the launch)
         for f in PMC_VALU:
@@ -410,6 +461,53 @@ def main():
                 continue
         pairs_per_s = B / (per_call["match"] * 1e-3)
         lane_ops = mean_kp * mean_kp * MATCH_LANE_OPS_PER_PAIR
+        match_valu = {"achieved": pairs_per_s * lane_ops / 1e12, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
+                      "frac": pairs_per_s * lane_ops / 1e12 / VALU_PEAK_TOPS,
+                      "lane_ops_per_launch": lane_ops * B, "lane_ops_per_distance": MATCH_LANE_OPS_PER_PAIR,
+                      "distances_per_pair": mean_kp * mean_kp}
+        if dom == "match":              # VALU-issue bound: its HBM fraction is tiny by construction
+            roof["limiter"] = "valu_issue"
+            roof["valu_issue"] = match_valu
+            roof["valu_issue_frac"] = match_valu["frac"]
+        # the longest HBM-streaming kernel keeps its own block (the contract's "hbm" roofline), with the PMC traffic
+        hk = KERNEL_OF[hdom]
+        hach = BYTES[hdom] * B / (per_call[hdom] * 1e-3) / 1e9
+        hroof = {"kernel": hk, "bound": "hbm", "achieved": hach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hach / HBM_PEAK_GBS,
+                 "algorithmic_bytes_per_launch": BYTES[hdom] * B, "ms_per_launch": per_call[hdom], "traffic": None}
+        for f in PMC_TRAFFIC:
+            try:
+                hroof["traffic"] = json.load(open(os.path.join(ROOT, "profiles", f)))["kernels"][hk]["hbm_bytes_per_frame"] * B
+                hroof["traffic_source"] = "profiles/" + f
+                break
+            except Exception:
+                continue
+        for f in PMC_VALU:
+            try:
+                vp = json.load(open(os.path.join(ROOT, "profiles", f)))["kernels"][hk]
+                hroof.update({"limiter": "valu_issue", "valu_issue_frac": vp["valu_busy_frac"], "valu_insts_per_wave": vp["valu_insts_per_wave"],
+                              "valu_source": "profiles/" + f})
+                break
+            except Exception:
+                continue
+        roof["hbm_stream_kernel"] = hroof
+        roof["match_kernel_valu_issue"] = match_valu
+        # whole front-end (extract + match of one frame) against both ceilings: algorithmic bytes / frame x frames/s / HBM peak,
+        # and VALU lane-ops / frame (committed PMC pass: SQ_INSTS_VALU x 64 lanes of the five extract kernels, + the matcher's
+        # counted instructions) x frames/s / issue peak
+        fe_bytes = sum(BYTES.values()) + bytes_of["match"]
+        fe = {"algorithmic_bytes_per_frame": fe_bytes, "hbm_GBps": fe_bytes * fps / world / 1e9, "hbm_frac": fe_bytes * fps / world / 1e9 / HBM_PEAK_GBS}
+        for f in PMC_VALU:
+            try:
+                vj = json.load(open(os.path.join(ROOT, "profiles", f)))
+                per_frame = sum(v["valu_insts"] for v in vj["kernels"].values() if "valu_insts" in v and not v.get("is_match")) * 64.0 / vj["frames_per_launch"]
+                mj = vj["kernels"].get("k_match_pairs")
+                m_ops = (mj["valu_insts"] * 64.0 / vj["frames_per_launch"]) if mj and mj.get("is_match") else lane_ops
+                fe.update({"valu_lane_ops_per_frame": per_frame + m_ops, "valu_Tops": (per_frame + m_ops) * fps / world / 1e12,
+                           "valu_frac": (per_frame + m_ops) * fps / world / 1e12 / VALU_PEAK_TOPS, "valu_source": "profiles/" + f})
+                break
+            except Exception:
+                continue
+        roof["front_end"] = fe
         kernels = {k: {"ms_per_launch_batch": v} for k, v in per_call.items()}
         for k in BYTES:
             kernels[k]["algorithmic_GBps"] = BYTES[k] * B / (per_call[k] * 1e-3) / 1e9
@@ -420,8 +518,9 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "KITTI 1241x376, 2000 features/frame, 8 levels, ORB extract + brute-force Hamming "
-                                   "match vs previous frame (ratio 0.9, TH_LOW 50, rotation histogram)",
+            "config": {"workload": "KITTI 1241x376, 2000 features/frame requested (nfeatures = 2000; the octree keeps %.0f on average on these "
+                                   "synthetic frames, so a match is %.0f x %.0f distances), 8 levels, ORB extract + brute-force Hamming "
+                                   "match vs previous frame (ratio 0.9, TH_LOW 50, rotation histogram)" % (mean_kp, mean_kp, mean_kp),
                        "frames_per_gpu_per_step": B * M, "frames_per_launch": B, "batches_per_step": M,
                        "sharding": "frames across ranks, no collective in the data path", "streams": S,
                        "mean_keypoints": mean_kp, "mean_matches": mean_match},
@@ -434,10 +533,13 @@ def main():
             out["collective"] = collective
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_host, args.cpu_sample, args.cpu_all_seconds)
+            out["cpu_baseline"]["build"] = oracle_build
         if localba is not None:
+            if isinstance(localba.get("cpu_baseline"), dict):
+                localba["cpu_baseline"]["build"] = oracle_build
             out["localba"] = localba
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -96,7 +96,7 @@ def load():
     L.orbm_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, i32, vp, C.POINTER(i32)]
     L.orbm_search_by_projection.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, vp, i32, f32, i32, i32,
                                             vp, vp, C.POINTER(i32)]
-    L.orbm_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+    L.orbm_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.orbm_search_by_bow.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32, i32, i32, vp,
                                      C.POINTER(i32)]
     L.orbm_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, f32, f32, vp, vp,

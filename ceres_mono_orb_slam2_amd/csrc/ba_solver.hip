@@ -2043,7 +2043,7 @@ static thread_local unsigned char* g_stop_dev = nullptr;
 static int stop_mirror(unsigned char** host, const volatile unsigned char** dev) {
   if (!g_stop_host) {
     void* h = nullptr; void* d = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
       set_error("hipHostMalloc(stop flag mirror) failed"); return ORBHIP_ENOMEM;
     }
     g_stop_host = (unsigned char*)h; g_stop_dev = (unsigned char*)d;
@@ -2054,12 +2054,22 @@ static int stop_mirror(unsigned char** host, const volatile unsigned char** dev)
 // wait for the stream; while waiting, forward the caller's stop flag to the device mirror
 static hipError_t wait_stream_forwarding_stop(hipStream_t s, const volatile uint8_t* stop, unsigned char* mirror) {
   if (!stop || !mirror) return hipStreamSynchronize(s);
+  // the first 150 us are polled with yield (PoseOptimization-sized solves end inside them), after that the thread sleeps
+  // ~50 us between polls: a LocalBA / GlobalBA no longer burns a host core for its whole duration, and the stop flag still
+  // reaches the device within one LM iteration
+  const auto t0 = std::chrono::steady_clock::now();
+  bool spin = true;
   for (;;) {
     if (*stop) __atomic_store_n(mirror, (unsigned char)1, __ATOMIC_RELEASE);
     const hipError_t q = hipStreamQuery(s);
     if (q == hipSuccess) return hipSuccess;
     if (q != hipErrorNotReady) return q;
-    std::this_thread::yield();
+    if (spin) {
+      std::this_thread::yield();
+      spin = std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(150);
+    } else {
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
   }
 }
 // measurement hook (ba_set_profiling / ba_get_profile): device time of the solves of this host thread, HIP events on its stream
@@ -2074,6 +2084,7 @@ static hipStream_t thread_stream() {
     g_ws.slots.clear(); g_ws.hslots.clear();           // (buffers of the previous device are intentionally leaked)
     g_graphs.clear();
     g_batch_valid = false;
+    g_stop_host = nullptr; g_stop_dev = nullptr;       // the mirror's device pointer belongs to the old device: re-derive it
   }
   if (!g_stream) { if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr; g_stream_device = dev; }
   return g_stream;

@@ -128,7 +128,7 @@ class ORBmatcherT {
       const int nPredictedLevel = pMP->track_scale_level_;
       float r = RadiusByViewingCos(pMP->track_view_cos_);
       if (bFactor) r *= th;
-      Q.valid[iMP] = 1;
+      Q.valid[iMP] = pMP->Observations() > 0 ? 1 : 3;          // (3: once assigned, the feature stays open for later points, ":83-84")
       Q.uv[2 * iMP] = pMP->track_proj_x_; Q.uv[2 * iMP + 1] = pMP->track_proj_y_;
       Q.radius[iMP] = r * F.scale_factors_[nPredictedLevel];
       Q.lo[iMP] = nPredictedLevel - 1; Q.hi[iMP] = nPredictedLevel;
@@ -164,7 +164,8 @@ class ORBmatcherT {
       if (u < CurrentFrame.min_x_ || u > CurrentFrame.max_x_) continue;
       if (v < CurrentFrame.min_y_ || v > CurrentFrame.max_y_) continue;
       const int nLastOctave = LastFrame.keypoints_[i].octave;
-      Q.valid[i] = 1; Q.uv[2 * i] = u; Q.uv[2 * i + 1] = v;
+      Q.valid[i] = map_point->Observations() > 0 ? 1 : 3;      // (":1220-1221" looks at the point assigned earlier in this loop, too)
+      Q.uv[2 * i] = u; Q.uv[2 * i + 1] = v;
       Q.radius[i] = th * CurrentFrame.scale_factors_[nLastOctave];
       Q.lo[i] = nLastOctave - 1; Q.hi[i] = nLastOctave + 1;
       Q.angle[i] = LastFrame.undistort_keypoints_[i].angle;
@@ -178,8 +179,13 @@ class ORBmatcherT {
     check(orbm_search_by_projection(T.kps4.data(), T.desc, T.n, T.bounds, Q.uv.data(), Q.radius.data(), Q.lo.data(), Q.hi.data(), nullptr, Q.desc.data(),
                                     Q.valid.data(), Q.angle.data(), (int)nq, nullptr, 0.f, taken.data(), 0, mfNNratio, TH_HIGH, mbCheckOrientation ? 1 : 0,
                                     match.data(), nullptr, &nmatches), "orbm_search_by_projection");
-    // (a match the rotation histogram rejects was assigned and reset to nullptr by the reference: net effect none)
-    for (size_t i = 0; i < nq; i++) if (match[i] >= 0) CurrentFrame.map_points_[match[i]] = LastFrame.map_points_[i];
+    // the reference assigns in query order (":1232") and then resets the slots of the removed rotation bins (":1260-1264"):
+    // a slot that held a point without observations, or that two queries shared, ends as nullptr when ANY of its matches is removed
+    for (size_t i = 0; i < nq; i++) {
+      if (match[i] >= 0) CurrentFrame.map_points_[match[i]] = LastFrame.map_points_[i];
+      else if (match[i] <= -2) CurrentFrame.map_points_[-2 - match[i]] = LastFrame.map_points_[i];
+    }
+    for (size_t i = 0; i < nq; i++) if (match[i] <= -2) CurrentFrame.map_points_[-2 - match[i]] = static_cast<MapPoint*>(nullptr);
     return nmatches;
   }
 
@@ -220,6 +226,7 @@ class ORBmatcherT {
     check(orbm_search_by_projection(T.kps4.data(), T.desc, T.n, T.bounds, Q.uv.data(), Q.radius.data(), Q.lo.data(), Q.hi.data(), nullptr, Q.desc.data(),
                                     Q.valid.data(), Q.angle.data(), (int)nq, nullptr, 0.f, taken.data(), 0, mfNNratio, ORBdist, mbCheckOrientation ? 1 : 0,
                                     match.data(), nullptr, &nmatches), "orbm_search_by_projection");
+    // (every candidate slot was empty, ":1336", so a removed match leaves nullptr behind: assign only the kept ones)
     for (size_t i = 0; i < nq; i++) if (match[i] >= 0) CurrentFrame.map_points_[match[i]] = vpMPs[i];
     return nmatches;
   }
@@ -389,7 +396,7 @@ class ORBmatcherT {
     // the descriptor rows the C ABI searches with are the MAP POINTS' descriptors (":1036", ":1112"), not the keyframes' own
     std::vector<int32_t> m12(N1 ? N1 : 1, -1);
     int nFound = 0;
-    check(orbm_search_by_sim3(A.kps4.data(), A.desc, N1, B.kps4.data(), B.desc, N2, A.bounds, Q12.uv.data(), Q12.radius.data(), Q12.pred.data(),
+    check(orbm_search_by_sim3(A.kps4.data(), A.desc, N1, B.kps4.data(), B.desc, N2, A.bounds, B.bounds, Q12.uv.data(), Q12.radius.data(), Q12.pred.data(),
                               Q12.valid.data(), Q12.desc.data(), Q21.uv.data(), Q21.radius.data(), Q21.pred.data(), Q21.valid.data(), Q21.desc.data(),
                               m12.data(), &nFound), "orbm_search_by_sim3");
     for (int i1 = 0; i1 < N1; i1++) if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <vector>
+#include <map>
 #include <mutex>
 #include <algorithm>
 #include <cstring>
@@ -348,12 +349,16 @@ struct Candidate { uint32_t idx; int32_t dist; };
 struct WindowLists { const uint32_t* off = nullptr; const Candidate* cand = nullptr; uint32_t total = 0; };
 static thread_local FrameGridDev g_grid;                       // device grid of the calling thread (buffers grow, are reused)
 static thread_local uint32_t g_cand_cap = 0;                   // candidate capacity that was enough so far
+static thread_local int g_grid_device = -1;                    // device g_grid's buffers live on
 
 static int window_lists(ThreadWs& W, const float* kps4, const uint8_t* desc, int n, const float* bounds, const float* q_uv, const float* q_radius,
                         const int32_t* q_minl, const int32_t* q_maxl, const uint8_t* q_valid, const uint8_t* q_desc, int nq, WindowLists* out) {
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = W.begin();
     if (rc) return rc;
+    if (g_grid_device != W.device) {                             // default device changed: like ThreadWs, forget (leak) the old device's buffers
+      g_grid = FrameGridDev(); g_cand_cap = 0; g_grid_device = W.device;
+    }
     const uint32_t cap = std::max<uint32_t>(g_cand_cap, (uint32_t)nq * 64u);
     ThreadWs::Pack in;                                           // every input in one pinned block, one H2D copy
     const int pk = in.add(kps4, 16 * (size_t)n), pd = in.add(desc, 32 * (size_t)n), pq = in.add(q_uv, 8 * (size_t)nq), pr = in.add(q_radius, 4 * (size_t)nq),
@@ -500,22 +505,26 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
   const int nsplit = force_split > 0 ? force_split : std::min(8, std::max(1, 256 / npairs));
   int* scratch = nullptr;
   if (nsplit > 1) {
-    // per-device scratch rows {30 bins, -, ticket}, zero when allocated and left zero by every launch (the last workgroup of a
-    // pair clears its row); grown under a lock, only ever used by launches on the caller's stream
-    static std::mutex mu; static DevBuf buf[64]; static int rows[64] = {0};
+    // scratch rows {30 bins, -, ticket} per (device, stream): zero when allocated and left zero by every launch (the last
+    // workgroup of a pair clears its row).  Launches that share a row set are ordered by their stream, so tickets and bins of
+    // two launches in flight (other streams, other host threads) never mix.  A row set that has to grow is REPLACED, the old
+    // allocation stays alive until process end (a launch enqueued earlier may still use it; growth is geometric, so the
+    // retired memory is bounded by the final size).
+    struct Rows { int* p = nullptr; int rows = 0; };
+    static std::mutex mu; static std::map<std::pair<int, void*>, Rows> pool;
     int dev = 0;
     ORBHIP_CHECK_HIP(hipGetDevice(&dev));
-    ORBHIP_REQUIRE(dev >= 0 && dev < 64, ORBHIP_EINVAL, "device ordinal out of range");
     std::lock_guard<std::mutex> g(mu);
-    if (npairs > rows[dev]) {
-      ORBHIP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-      const int want = std::max(npairs, 1024);
-      if (int rc = buf[dev].ensure((size_t)want * 32 * sizeof(int))) return rc;
-      ORBHIP_CHECK_HIP(hipMemset(buf[dev].p, 0, (size_t)want * 32 * sizeof(int)));
-      ORBHIP_CHECK_HIP(hipDeviceSynchronize());
-      rows[dev] = want;
+    Rows& R = pool[std::make_pair(dev, stream)];
+    if (npairs > R.rows) {
+      const int want = std::max(std::max(npairs, 2 * R.rows), 256);
+      void* q = nullptr;
+      hipError_t e = hipMalloc(&q, (size_t)want * 32 * sizeof(int));
+      if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", (size_t)want * 32 * sizeof(int), hipGetErrorString(e)); return ORBHIP_ENOMEM; }
+      ORBHIP_CHECK_HIP(hipMemsetAsync(q, 0, (size_t)want * 32 * sizeof(int), (hipStream_t)stream));   // ordered before the launch below
+      R.p = (int*)q; R.rows = want;
     }
-    scratch = buf[dev].as<int>();
+    scratch = R.p;
   }
   if (nsplit > 1)
     hipLaunchKernelGGL(k_match_pairs<1>, dim3(npairs * nsplit), dim3(MP_THREADS), lds, (hipStream_t)stream, d_kps, d_desc, d_counts,
@@ -570,7 +579,9 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
     if (target < 0 || first.d > th) continue;
     if (mode_best2 && first.lvl == second.lvl && first.d > ratio * second.d) continue;
     q_match[qi] = target;
-    if (taken) taken[target] = 1;
+    // (q_valid bit 1: the query's map point has no observations - the reference assigns it but the feature stays open for
+    // later queries, ":83-84", ":1220-1221")
+    if (taken && !(q_valid && (q_valid[qi] & 2))) taken[target] = 1;
     found++;
     if (check_ori) { bin_of[qi] = (signed char)rotation_bin(q_angle[qi], kps4[4 * target + 3]); rot.add(bin_of[qi]); }
   }
@@ -578,7 +589,7 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
     bool keep[HISTO_LENGTH];
     rot.kept(keep);
     for (int qi = 0; qi < nq; qi++)
-      if (q_match[qi] >= 0 && !keep[bin_of[qi]]) { if (taken) taken[q_match[qi]] = 0; q_match[qi] = -1; found--; }
+      if (q_match[qi] >= 0 && !keep[bin_of[qi]]) { if (taken) taken[q_match[qi]] = 0; q_match[qi] = -2 - q_match[qi]; found--; }
   }
   *nmatches = found;
   return 0;
@@ -588,22 +599,23 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
 // looks for its map point in keyframe 2 (q12_*: projected position, radius th * scale[predicted level], predicted level;
 // descriptor = q12_desc row = the map point's representative descriptor) and vice versa; best <=
 // TH_HIGH each way with the [pred - 1, pred] level gate, no `taken` state; a pair survives iff both directions agree
-// (:1145-1157).  match12[n1] = index in keyframe 2 or -1.
+// (:1145-1157).  match12[n1] = index in keyframe 2 or -1.  bounds1 / bounds2 = the image bounds of keyframe 1 / keyframe 2
+// (each keyframe has its own grid: KeyFrame::GetFeaturesInArea of pKF2 for the 1->2 search :1022, of pKF1 for 2->1 :1102).
 int orbm_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
-                        const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred, const uint8_t* q12_valid,
-                        const uint8_t* q12_desc, const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid,
+                        const float* bounds1, const float* bounds2, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred,
+                        const uint8_t* q12_valid, const uint8_t* q12_desc, const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid,
                         const uint8_t* q21_desc, int32_t* match12, int* nfound) {
   ORBHIP_REQUIRE(n1 >= 0 && n2 >= 0 && nfound && (n1 == 0 || match12), ORBHIP_EINVAL, "bad size");
   *nfound = 0;
   for (int i = 0; i < n1; i++) match12[i] = -1;
   if (n1 == 0 || n2 == 0) return 0;
-  ORBHIP_REQUIRE(kps1 && kps2 && desc1 && desc2 && bounds && q12_uv && q12_radius && q12_pred && q21_uv && q21_radius && q21_pred, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(kps1 && kps2 && desc1 && desc2 && bounds1 && bounds2 && q12_uv && q12_radius && q12_pred && q21_uv && q21_radius && q21_pred, ORBHIP_EINVAL, "NULL argument");
   std::vector<int32_t> m1(n1), m2(n2);
   int k = 0;
   const int TH_HIGH = 100;
-  if (int rc = orbm_search_by_projection(kps2, desc2, n2, bounds, q12_uv, q12_radius, nullptr, nullptr, q12_pred, q12_desc ? q12_desc : desc1, q12_valid, nullptr, n1,
+  if (int rc = orbm_search_by_projection(kps2, desc2, n2, bounds2, q12_uv, q12_radius, nullptr, nullptr, q12_pred, q12_desc ? q12_desc : desc1, q12_valid, nullptr, n1,
                                          nullptr, 0.f, nullptr, 0, 1.f, TH_HIGH, 0, m1.data(), nullptr, &k)) return rc;
-  if (int rc = orbm_search_by_projection(kps1, desc1, n1, bounds, q21_uv, q21_radius, nullptr, nullptr, q21_pred, q21_desc ? q21_desc : desc2, q21_valid, nullptr, n2,
+  if (int rc = orbm_search_by_projection(kps1, desc1, n1, bounds1, q21_uv, q21_radius, nullptr, nullptr, q21_pred, q21_desc ? q21_desc : desc2, q21_valid, nullptr, n2,
                                          nullptr, 0.f, nullptr, 0, 1.f, TH_HIGH, 0, m2.data(), nullptr, &k)) return rc;
   int found = 0;
   for (int i1 = 0; i1 < n1; i1++) {

@@ -96,9 +96,14 @@ int orbv_parse_text(const char* path, int32_t* k_out, int32_t* L_out, int32_t* s
   ORBHIP_REQUIRE(path && n_nodes && n_children && node_desc && child_off && children && word_id && weight, ORBHIP_EINVAL, "NULL argument");
   FILE* f = std::fopen(path, "rb");
   if (!f) { set_error("cannot open vocabulary file %s", path); return ORBHIP_EINVAL; }
-  std::fseek(f, 0, SEEK_END); const long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+  long sz = -1;
+  if (std::fseek(f, 0, SEEK_END) == 0) sz = std::ftell(f);
+  if (sz < 0 || std::fseek(f, 0, SEEK_SET) != 0) { std::fclose(f); set_error("cannot size vocabulary file %s", path); return ORBHIP_EINVAL; }
   std::vector<char> buf((size_t)sz + 1);
-  const size_t got = std::fread(buf.data(), 1, (size_t)sz, f); std::fclose(f);
+  const size_t got = std::fread(buf.data(), 1, (size_t)sz, f);
+  const bool read_err = std::ferror(f) != 0;
+  std::fclose(f);
+  if (read_err || got != (size_t)sz) { set_error("short read of vocabulary file %s (%zu of %ld bytes)", path, got, sz); return ORBHIP_EINVAL; }
   buf[got] = 0;
   char* p = buf.data(); char* end = p + got;
   auto next_line = [&](char*& a, char*& b) -> bool {              // [a, b) = next non-blank line
@@ -112,21 +117,38 @@ int orbv_parse_text(const char* path, int32_t* k_out, int32_t* L_out, int32_t* s
   char *a, *b;
   if (!next_line(a, b)) { set_error("empty vocabulary file"); return ORBHIP_EINVAL; }
   char* q = a;
-  const long k = std::strtol(q, &q, 10), L = std::strtol(q, &q, 10), n1 = std::strtol(q, &q, 10), n2 = std::strtol(q, &q, 10);
+  // a token = strtol / strtod must ADVANCE (a missing token would otherwise parse as 0) and must stay inside its line
+  bool tok_ok = true;
+  // and must end at white space ("0.5" is not the integer 0 followed by the number .5)
+  auto ends = [](const char* e, const char* lim) { return e == lim || *e == ' ' || *e == '\t' || *e == '\r' || *e == '\n' || *e == 0; };
+  auto tol = [&](char*& c, char* lim) -> long { char* e = c; const long v = std::strtol(c, &e, 10); if (e == c || e > lim || !ends(e, lim)) tok_ok = false; c = e; return v; };
+  auto tod = [&](char*& c, char* lim) -> double { char* e = c; const double v = std::strtod(c, &e); if (e == c || e > lim || !ends(e, lim)) tok_ok = false; c = e; return v; };
+  const long k = tol(q, b), L = tol(q, b), n1 = tol(q, b), n2 = tol(q, b);
+  if (!tok_ok) { set_error("not a DBoW2 text vocabulary (header needs 4 integers)"); return ORBHIP_EINVAL; }
   if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) { set_error("not a DBoW2 text vocabulary (header %ld %ld %ld %ld)", k, L, n1, n2); return ORBHIP_EINVAL; }
   std::vector<int32_t> parent(1, -1), wid(1, -1); std::vector<uint8_t> desc(32, 0); std::vector<double> wt(1, 0.0);
   int nwords = 0;
   while (next_line(a, b)) {
     q = a;
-    const long pid = std::strtol(q, &q, 10), leaf = std::strtol(q, &q, 10);
+    const long pid = tol(q, b), leaf = tol(q, b);
     const size_t nid = parent.size();
     if (pid < 0 || (size_t)pid >= nid) { set_error("vocabulary node %zu names parent %ld", nid, pid); return ORBHIP_EINVAL; }
     parent.push_back((int32_t)pid);
-    for (int i = 0; i < 32; i++) desc.push_back((uint8_t)std::strtol(q, &q, 10));
-    wt.push_back(std::strtod(q, &q));
+    for (int i = 0; i < 32; i++) {
+      const long v = tol(q, b);
+      if (v < 0 || v > 255) tok_ok = false;
+      desc.push_back((uint8_t)v);
+    }
+    wt.push_back(tod(q, b));
+    if (!tok_ok) { set_error("vocabulary node %zu: expected 'parent leaf 32 bytes weight' (35 tokens)", nid); return ORBHIP_EINVAL; }
     wid.push_back(leaf > 0 ? nwords++ : -1);
   }
   const size_t n = parent.size();
+  {                                                              // a k-ary tree of depth L has at most (k^(L+1) - 1) / (k - 1) nodes
+    double lim = 1.0, pw = 1.0;
+    for (long l = 0; l < L; l++) { pw *= (double)std::max<long>(k, 1); lim += pw; }
+    if ((double)n > lim) { set_error("vocabulary has %zu nodes, more than a %ld-ary tree of depth %ld can hold", n, k, L); return ORBHIP_EINVAL; }
+  }
   std::vector<uint32_t> off(n + 1, 0);
   for (size_t i = 1; i < n; i++) off[parent[i] + 1]++;
   for (size_t i = 0; i < n; i++) off[i + 1] += off[i];
@@ -145,7 +167,13 @@ int orbv_create(const uint8_t* node_desc, const uint32_t* child_off, const uint3
                 int device, orbv_ctx** out);
 int orbv_load_text(const char* path, int device, orbv_ctx** out) {
   int32_t k = 0, L = 0, n = 0, nc = 0; uint8_t* nd = nullptr; uint32_t *co = nullptr, *ch = nullptr; int32_t* wi = nullptr; double* wt = nullptr;
-  if (int rc = orbv_parse_text(path, &k, &L, nullptr, nullptr, &n, &nc, &nd, &co, &ch, &wi, &wt)) return rc;
+  int32_t scoring = 0, weighting = 0;
+  if (int rc = orbv_parse_text(path, &k, &L, &scoring, &weighting, &n, &nc, &nd, &co, &ch, &wi, &wt)) return rc;
+  if (scoring != 0 || weighting != 0) {                          // DBoW2 enums: L1_NORM = 0, TF_IDF = 0 - what orbv_transform / orbv_score_l1 implement
+    std::free(nd); std::free(co); std::free(ch); std::free(wi); std::free(wt);
+    set_error("vocabulary %s uses scoring %d / weighting %d; only L1_NORM (0) / TF_IDF (0) - ORBvoc.txt - are implemented", path, scoring, weighting);
+    return ORBHIP_EINVAL;
+  }
   const int rc = orbv_create(nd, co, ch, wi, wt, n, L, device, out);
   std::free(nd); std::free(co); std::free(ch); std::free(wi); std::free(wt);
   return rc;

@@ -140,15 +140,17 @@ class ORBmatcher:
         return n.value, m[:len(k1)]
 
     def SearchBySim3(self, kps1, desc1, kps2, desc2, bounds, q12_uv, q12_radius, q12_pred, q12_valid, q21_uv, q21_radius,
-                     q21_pred, q21_valid, q12_desc=None, q21_desc=None):
-        """src/ORBmatcher.cc:956-1159 from the two window searches on (see orbm_search_by_sim3).  Returns (nFound, match12[n1])."""
+                     q21_pred, q21_valid, q12_desc=None, q21_desc=None, bounds2=None):
+        """src/ORBmatcher.cc:956-1159 from the two window searches on (see orbm_search_by_sim3).  Returns (nFound, match12[n1]).
+        bounds = image bounds of keyframe 1, bounds2 = of keyframe 2 (default: the same camera)."""
         f32, u8, i32 = np.float32, np.uint8, np.int32
         c = np.ascontiguousarray
         k1, k2, d1, d2, b = c(kps1, f32), c(kps2, f32), c(desc1, u8), c(desc2, u8), c(bounds, f32)
+        b2 = b if bounds2 is None else c(bounds2, f32)
         od = lambda d: None if d is None else c(d, u8)
         a = [c(q12_uv, f32), c(q12_radius, f32), c(q12_pred, i32), c(q12_valid, u8), od(q12_desc), c(q21_uv, f32), c(q21_radius, f32),
              c(q21_pred, i32), c(q21_valid, u8), od(q21_desc)]
         m = np.full(max(len(k1), 1), -1, i32); n = C.c_int(0)
-        _lib.check(self._L.orbm_search_by_sim3(_lib.ptr(k1), _lib.ptr(d1), len(k1), _lib.ptr(k2), _lib.ptr(d2), len(k2), _lib.ptr(b),
+        _lib.check(self._L.orbm_search_by_sim3(_lib.ptr(k1), _lib.ptr(d1), len(k1), _lib.ptr(k2), _lib.ptr(d2), len(k2), _lib.ptr(b), _lib.ptr(b2),
                                                *[_lib.ptr(x) for x in a], _lib.ptr(m), C.byref(n)), "orbm_search_by_sim3")
         return n.value, m[:len(k1)]

@@ -18,7 +18,7 @@ def shard_range(n_items, rank, world):
 
 def max_over_ranks(seconds, device=None):
     """bench.py contract: the step time is the MAX over ranks."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -29,9 +29,9 @@ def allgather_landmarks(local_pts, local_ids=None):
     """Merge the landmark updates of every rank's sub-map with a single all-gather.
     local_pts: (n_local, 3) float64 tensor (n_local may differ per rank); local_ids: optional (n_local,) int64
     global landmark ids.  Returns (pts_all (sum n, 3), ids_all or None, counts per rank)."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():                    # no process group: a single process holds the whole map already
         return local_pts, local_ids, [local_pts.shape[0]]
+    world = dist.get_world_size()                    # (a group of ONE rank still runs the collective: the one-GPU RCCL check)
     dev = local_pts.device
     n = torch.tensor([local_pts.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]

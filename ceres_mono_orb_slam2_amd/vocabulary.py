@@ -25,7 +25,8 @@ class ORBVocabulary:
         self._L = _lib.load()
         self._h = C.c_void_p()
         _lib.check(self._L.orbv_load_text(str(path).encode(), int(device), C.byref(self._h)), "orbv_load_text")
-        self.depth = None
+        with open(path, "rb") as f:                     # header line "k L scoring weighting" (orbv_load_text validated it)
+            self.depth = int(f.readline().split()[1])
         return self
 
     def __del__(self):

@@ -161,6 +161,10 @@ int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int 
  * `taken` (nullable, n bytes, in/out) marks targets that already hold a map point (skipped; set on
  * assignment, cleared again if the rotation histogram rejects the match).  Outputs: q_match[nq] = target
  * index or -1, q_best_dist[nq] (nullable), *nmatches.                                        */
+/* q_valid[q] (nullable = all 1): 0 = skip the query; bit 0 = search; bit 1 (value 3) = search, but a match does NOT close the
+ * target for later queries - the reference closes a feature only while its map point has Observations() > 0
+ * (src/ORBmatcher.cc:83-84, :1220-1221).  q_match[q] = target index, -1 = none, or -2 - target for a match the rotation
+ * histogram removed (the reference had assigned that slot and resets it to nullptr, :1260-1264; *nmatches does not count it). */
 int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, const float* bounds, const float* q_uv,
                               const float* q_radius, const int32_t* q_min_level, const int32_t* q_max_level,
                               const int32_t* q_pred_level, const uint8_t* q_desc, const uint8_t* q_valid,
@@ -175,9 +179,11 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
  * keyframe 2 into keyframe 1 (q21_*).  desc1 / desc2 = the keyframes' own descriptors (the search targets); q12_desc[n1][32] /
  * q21_desc[n2][32] = pMP->GetDescriptor() of the feature's map point (":1036", ":1112"; NULL = the keyframe's own row).  Each
  * direction takes the best candidate of KeyFrame::GetFeaturesInArea with level in [pred - 1, pred] and distance <= TH_HIGH; a
- * pair is kept iff the two directions agree (:1145-1157).  match12[n1] = index in keyframe 2 or -1; *nfound = the return value. */
+ * pair is kept iff the two directions agree (:1145-1157).  match12[n1] = index in keyframe 2 or -1; *nfound = the return value.
+ * bounds1[4] / bounds2[4] = {min_x, max_x, min_y, max_y} of keyframe 1 / 2: each window search runs on the TARGET keyframe's own
+ * grid (pKF2->GetFeaturesInArea :1022, pKF1->GetFeaturesInArea :1102). */
 int orbm_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
-                        const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred,
+                        const float* bounds1, const float* bounds2, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred,
                         const uint8_t* q12_valid, const uint8_t* q12_desc, const float* q21_uv, const float* q21_radius,
                         const int32_t* q21_pred, const uint8_t* q21_valid, const uint8_t* q21_desc, int32_t* match12, int* nfound);
 

@@ -265,7 +265,8 @@ int orc_search_by_projection(const float* kps4, const uint8_t* desc, int n, cons
     if (bestIdx >= 0 && bestDist <= th) {
       if (mode_best2 && bestLevel == bestLevel2 && bestDist > ratio * bestDist2) continue;
       q_match[i] = bestIdx;
-      if (taken) taken[bestIdx] = 1;
+      // (:83-84, :1220-1221: a feature whose map point has no observations stays open; q_valid bit 1 marks such a query point)
+      if (taken && !(q_valid && (q_valid[i] & 2))) taken[bestIdx] = 1;
       nmatches++;
       if (check_ori) rotHist[rot_bin(q_angle[i], kps4[4 * bestIdx + 3])].push_back(i);
     }
@@ -276,7 +277,7 @@ int orc_search_by_projection(const float* kps4, const uint8_t* desc, int n, cons
     three_maxima(cnt, HISTO_LENGTH, i1, i2, i3);
     for (int b = 0; b < HISTO_LENGTH; b++) {
       if (b == i1 || b == i2 || b == i3) continue;
-      for (int qi : rotHist[b]) { if (taken) taken[q_match[qi]] = 0; q_match[qi] = -1; nmatches--; }
+      for (int qi : rotHist[b]) { if (taken) taken[q_match[qi]] = 0; q_match[qi] = -2 - q_match[qi]; nmatches--; }   // (:1260-1264: the slot is reset; the value keeps which slot)
     }
   }
   delete G;
@@ -288,15 +289,15 @@ int orc_search_by_projection(const float* kps4, const uint8_t* desc, int n, cons
 // passes per feature: q_valid (the feature holds a usable, not already matched map point and passed the gates), the projected
 // position, radius = th * scale_factors_[nPredictedLevel] and nPredictedLevel; q12_desc / q21_desc rows = pMP->GetDescriptor().
 int orc_search_by_sim3(const float* kps1, const uint8_t* desc1, int n1, const float* kps2, const uint8_t* desc2, int n2,
-                       const float* bounds, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred, const uint8_t* q12_valid,
-                       const uint8_t* q12_desc, const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid,
+                       const float* bounds1, const float* bounds2, const float* q12_uv, const float* q12_radius, const int32_t* q12_pred,
+                       const uint8_t* q12_valid, const uint8_t* q12_desc, const float* q21_uv, const float* q21_radius, const int32_t* q21_pred, const uint8_t* q21_valid,
                        const uint8_t* q21_desc, int32_t* match12) {
   if (!q12_desc) q12_desc = desc1;             // dMP = pMP->GetDescriptor() (:1036, :1112); default: the keyframe's own row
   if (!q21_desc) q21_desc = desc2;
   const int TH_HIGH = 100;
   Grid* G1 = new Grid(); Grid* G2 = new Grid();
-  G1->build(kps1, n1, bounds[0], bounds[1], bounds[2], bounds[3]);
-  G2->build(kps2, n2, bounds[0], bounds[1], bounds[2], bounds[3]);
+  G1->build(kps1, n1, bounds1[0], bounds1[1], bounds1[2], bounds1[3]);     // every keyframe has its own grid bounds
+  G2->build(kps2, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3]);
   std::vector<int> vnMatch1(n1, -1), vnMatch2(n2, -1), vIndices;
   // Transform from KF1 to KF2 and search (:995-1064)
   for (int i1 = 0; i1 < n1; i1++) {

@@ -25,13 +25,51 @@ def build(force=False):
     return _SO
 
 
+CANONICAL_FLAGS = "-O3 -march=x86-64-v2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math"     # (oracle/Makefile; runs on any host)
+NATIVE_FLAGS = "-O3 -march=native -std=c++17 -fPIC -ffp-contract=off -fno-fast-math"            # the CPU-baseline build
+
+
+def build_native():
+    """The timing build of SURVEY 8(d) (`-O3 -march=native -ffp-contract=off`): compiled ON the host that runs it (an
+    -march=native object must not travel between machines), into a directory named after this host's CPU flags.
+    Returns the path, or None when the compiler is missing / fails.  bench.py's cpu_baseline leg times this build after
+    checking that it reproduces the canonical build bit for bit."""
+    import hashlib
+    try:
+        flags = [l for l in open("/proc/cpuinfo") if l.startswith("flags")][0]
+    except Exception:
+        flags = "unknown"
+    d = os.path.join(_HERE, "_build", "native_" + hashlib.sha1(flags.encode()).hexdigest()[:10])
+    so = os.path.join(d, "liborb_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "match_oracle.cpp", "ba_oracle.cpp", "sim3_oracle.cpp", "bow_oracle.cpp", "tri_oracle.cpp")]
+    if os.path.exists(so) and all(os.path.getmtime(s) <= os.path.getmtime(so) for s in srcs):
+        return so
+    try:
+        os.makedirs(d, exist_ok=True)
+        subprocess.check_call(["g++"] + NATIVE_FLAGS.split() + ["-Wall", "-Wno-unused-function", "-pthread", "-shared", "-o", so] + srcs,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return so
+    except Exception:
+        return None
+
+
 _lib = None
+
+
+def use_library(path=None):
+    """Switch every function of this module to another build of the oracle (None = the canonical one).  Objects created
+    before the switch (OracleExtractor) keep working only with the library that made them: create new ones."""
+    global _lib, _SO
+    _SO = path or os.path.join(_HERE, "_build", "liborb_oracle.so")
+    _lib = None
+    return lib()
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if _SO == os.path.join(_HERE, "_build", "liborb_oracle.so"):
+            build()
         L = C.CDLL(_SO)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
@@ -326,17 +364,18 @@ def search_by_projection(kps4, desc, bounds, q_uv, q_radius, q_desc, q_min_level
 
 
 def search_by_sim3(kps1, desc1, kps2, desc2, bounds, q12_uv, q12_radius, q12_pred, q12_valid, q21_uv, q21_radius, q21_pred, q21_valid,
-                   q12_desc=None, q21_desc=None):
+                   q12_desc=None, q21_desc=None, bounds2=None):
     c = np.ascontiguousarray
     k1, k2, d1, d2, b = c(kps1, np.float32), c(kps2, np.float32), c(desc1, np.uint8), c(desc2, np.uint8), c(bounds, np.float32)
+    b2 = b if bounds2 is None else c(bounds2, np.float32)
     od = lambda d: None if d is None else c(d, np.uint8)
     a = [c(q12_uv, np.float32), c(q12_radius, np.float32), c(q12_pred, np.int32), c(q12_valid, np.uint8), od(q12_desc),
          c(q21_uv, np.float32), c(q21_radius, np.float32), c(q21_pred, np.int32), c(q21_valid, np.uint8), od(q21_desc)]
     m = np.zeros(len(k1), np.int32)
     L = lib()
     L.orc_search_by_sim3.restype = C.c_int
-    L.orc_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 12
-    n = L.orc_search_by_sim3(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(b), *[_p(x) for x in a], _p(m))
+    L.orc_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 13
+    n = L.orc_search_by_sim3(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(b), _p(b2), *[_p(x) for x in a], _p(m))
     return n, m
 
 

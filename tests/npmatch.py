@@ -183,7 +183,8 @@ def search_by_projection_mappoints(K, D, bounds, q_uv, q_radius, q_level, q_desc
             if blvl == blvl2 and best > F32(nnratio) * F32(best2):
                 continue
             match[q] = bidx
-            taken[bidx] = 1
+            if not (int(q_valid[q]) & 2):           # Observations() > 0 of the assigned point closes the feature (:83-84)
+                taken[bidx] = 1
             n += 1
     return n, np.array(match, np.int32), np.array(taken, np.uint8)
 
@@ -212,7 +213,8 @@ def search_by_projection_frame(K, D, bounds, q_uv, q_radius, q_level, q_desc, q_
                 best, bidx = dist, i2
         if best <= th:
             match[q] = bidx
-            taken[bidx] = 1
+            if not (int(q_valid[q]) & 2):           # (:1220-1221)
+                taken[bidx] = 1
             n += 1
             if check_ori:
                 hist[rot_bin(q_angle[q], K[bidx, 3])].append((q, bidx))
@@ -220,7 +222,7 @@ def search_by_projection_frame(K, D, bounds, q_uv, q_radius, q_level, q_desc, q_
         for b in _keep_bins(hist):
             for q, i2 in hist[b]:
                 taken[i2] = 0                       # CurrentFrame.map_points_[i2] = nullptr
-                match[q] = -1
+                match[q] = -2 - i2                  # (removed: the value keeps which slot was reset)
                 n -= 1
     return n, np.array(match, np.int32), np.array(taken, np.uint8)
 
@@ -412,13 +414,13 @@ def search_for_triangulation(k1, d1, unmapped1, k2, d2, unmapped2, fv1, fv2, F12
 
 # ------------------------------------------------------------------------------------------------ M11
 def search_by_sim3(K1, D1, K2, D2, bounds, q12_uv, q12_radius, q12_pred, q12_valid, q21_uv, q21_radius, q21_pred, q21_valid,
-                   q12_desc=None, q21_desc=None):
+                   q12_desc=None, q21_desc=None, bounds2=None):
     """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:956-1159) from the two GetFeaturesInArea calls on: direction 1->2 searches
     keyframe 2 for the map point of every keyframe-1 feature (descriptor = that feature's, i.e. the map point's
     representative descriptor passed by the caller), direction 2->1 likewise; best <= TH_HIGH each way, no `taken` state;
     a pair is kept iff vnMatch2[vnMatch1[i1]] == i1 (:1145-1157).  Returns (nFound, match12)."""
-    def one_way(Kt, Dt, q_uv, q_rad, q_pred, q_valid, q_desc):
-        g = Grid(Kt, bounds)
+    def one_way(Kt, Dt, bt, q_uv, q_rad, q_pred, q_valid, q_desc):
+        g = Grid(Kt, bt)                                  # the TARGET keyframe's own grid (:1022, :1102)
         out = [-1] * len(q_uv)
         for q in range(len(q_uv)):
             if not q_valid[q]:
@@ -434,8 +436,8 @@ def search_by_sim3(K1, D1, K2, D2, bounds, q12_uv, q12_radius, q12_pred, q12_val
             if best <= TH_HIGH:
                 out[q] = bidx
         return out
-    m1 = one_way(K2, D2, q12_uv, q12_radius, q12_pred, q12_valid, D1 if q12_desc is None else q12_desc)
-    m2 = one_way(K1, D1, q21_uv, q21_radius, q21_pred, q21_valid, D2 if q21_desc is None else q21_desc)
+    m1 = one_way(K2, D2, bounds if bounds2 is None else bounds2, q12_uv, q12_radius, q12_pred, q12_valid, D1 if q12_desc is None else q12_desc)
+    m2 = one_way(K1, D1, bounds, q21_uv, q21_radius, q21_pred, q21_valid, D2 if q21_desc is None else q21_desc)
     m12 = [-1] * len(K1)
     found = 0
     for i1 in range(len(K1)):

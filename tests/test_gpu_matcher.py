@@ -131,9 +131,14 @@ def _two_frames(oracle, seed=41):
     return f(k1), d1, f(k2), d2, (offs[1] - offs[0]).astype(np.float32), E
 
 
-@pytest.mark.parametrize("case", ["mappoints_best2", "lastframe_ori", "reloc_kf", "sim3_pred", "fuse_chi2"])
+@pytest.mark.parametrize("case", ["mappoints_best2", "lastframe_ori", "reloc_kf", "sim3_pred", "fuse_chi2",
+                                  "mappoints_best2+noclaim", "lastframe_ori+noclaim"])
 def test_search_by_projection_families_vs_oracle(oracle, case):
     K1, D1, K2, D2, shift, E = _two_frames(oracle)
+    noclaim = case.endswith("+noclaim")
+    case = case.split("+")[0]
+    if noclaim:                         # every query twice; see below
+        K1 = np.concatenate([K1, K1]); D1 = np.concatenate([D1, D1])
     rng = np.random.default_rng(5)
     bounds = np.array([0, 640, 0, 480], np.float32)
     nq = len(K1)
@@ -143,6 +148,12 @@ def test_search_by_projection_families_vs_oracle(oracle, case):
     scale = E.scale[lvl]
     valid = (rng.random(nq) > 0.1).astype(np.uint8)
     taken0 = (rng.random(len(K2)) < 0.15).astype(np.uint8)
+    if noclaim:
+        # query points without observations (q_valid = 3, src/ORBmatcher.cc:83-84, :1220-1221) leave the feature they are
+        # assigned to open: the duplicate of the query (same projection, second half) is then assigned to it again
+        h = nq // 2
+        q_uv[h:] = q_uv[:h]; valid[h:] = valid[:h]
+        valid[:h][(rng.random(h) < 0.33) & (valid[:h] > 0)] = 3
     kw = dict(q_valid=valid)
     if case == "mappoints_best2":      # src/ORBmatcher.cc:42-119
         kw.update(q_radius=4.0 * scale, q_min_level=lvl - 1, q_max_level=lvl, taken=taken0, mode_best2=True, th=100)
@@ -168,6 +179,12 @@ def test_search_by_projection_families_vs_oracle(oracle, case):
     assert n == on and np.array_equal(m, om) and np.array_equal(bd, obd)
     if tk is not None:
         assert np.array_equal(tk, otk)
+    if ori:
+        assert (m <= -2).any()          # matches the rotation histogram removed keep their slot: -2 - target
+    if noclaim:
+        slot = np.where(m >= 0, m, np.where(m <= -2, -2 - m, -1)); slot = slot[slot >= 0]
+        assert len(slot) > len(set(slot.tolist()))      # some feature really was assigned twice
+        return
     assert n > 50
     hit = m >= 0
     assert len(set(m[hit].tolist())) == hit.sum() or case == "fuse_chi2"      # one map point per keypoint when `taken` is tracked
@@ -190,6 +207,10 @@ def test_search_by_sim3_vs_oracle(oracle):
             M[np.arange(len(M)), rng.integers(0, 32, len(M))] ^= (1 << rng.integers(0, 8, len(M))).astype(np.uint8)
         n, m = _m().SearchBySim3(K1, D1, K2, D2, BOUNDS, *q, q12_desc=M1, q21_desc=M2)
         on, om = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, q12_desc=M1, q21_desc=M2)
+        assert n == on and np.array_equal(m, om) and n > 50
+        B2 = (BOUNDS[0] - 7.0, BOUNDS[1] + 19.0, BOUNDS[2] - 3.0, BOUNDS[3] + 11.0)      # keyframe 2 from another camera: its own grid
+        n, m = _m().SearchBySim3(K1, D1, K2, D2, BOUNDS, *q, bounds2=B2)
+        on, om = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, bounds2=B2)
         assert n == on and np.array_equal(m, om) and n > 50
 
 

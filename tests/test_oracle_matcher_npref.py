@@ -71,6 +71,16 @@ def _queries(frames, seed=5):
     return q_uv, lvl, E.scale[lvl].astype(np.float32), valid, taken0, pred
 
 
+def _no_claim_variant(valid, q_uv, rad, lvl, desc, seed=11):
+    """Every query twice (second copy right after the first pass), a third of the valid ones marked "no observations"
+    (q_valid = 3): their match leaves the feature open, so the duplicate can be assigned to it again."""
+    rng = np.random.default_rng(seed)
+    v = valid.copy()
+    v[(rng.random(len(v)) < 0.33) & (valid > 0)] = 3
+    two = lambda a: np.concatenate([a, a])
+    return two(v), two(q_uv), two(rad), two(lvl), two(desc)
+
+
 def test_projection_family_map_points(oracle, frames):                     # M4, src/ORBmatcher.cc:42-119
     K1, D1, K2, D2, shift, E = frames
     q_uv, lvl, scale, valid, taken0, pred = _queries(frames)
@@ -79,6 +89,15 @@ def test_projection_family_map_points(oracle, frames):                     # M4,
                                                    taken=taken0, mode_best2=True, ratio=0.8, th=100, check_ori=False)
     n, m, tk = NP.search_by_projection_mappoints(K2, D2, BOUNDS, q_uv, rad, lvl, D1, valid, taken0, 0.8)
     assert n == on and np.array_equal(m, om) and np.array_equal(tk, otk) and n > 50
+    # query points without observations do not close the feature they are assigned to (:83-84): q_valid = 3; with duplicated
+    # queries the second copy then lands on the same feature
+    v3, q2, r2, l2, d2 = _no_claim_variant(valid, q_uv, rad, lvl, D1)
+    on3, om3, _, otk3 = oracle.search_by_projection(K2, D2, BOUNDS, q2, r2, d2, q_min_level=l2 - 1, q_max_level=l2, q_valid=v3,
+                                                    taken=taken0, mode_best2=True, ratio=0.8, th=100, check_ori=False)
+    n3, m3, tk3 = NP.search_by_projection_mappoints(K2, D2, BOUNDS, q2, r2, l2, d2, v3, taken0, 0.8)
+    assert n3 == on3 and np.array_equal(m3, om3) and np.array_equal(tk3, otk3)
+    hit = om3[om3 >= 0]
+    assert len(hit) > len(set(hit.tolist()))                      # some feature really was assigned twice
 
 
 @pytest.mark.parametrize("th,mult", [(100, 15), (64, 10)])
@@ -90,6 +109,13 @@ def test_projection_family_frame(oracle, frames, th, mult):               # M5 :
                                                    taken=taken0, q_angle=K1[:, 3], ratio=0.9, th=th, check_ori=True)
     n, m, tk = NP.search_by_projection_frame(K2, D2, BOUNDS, q_uv, rad, lvl, D1, valid, K1[:, 3], taken0, th, True)
     assert n == on and np.array_equal(m, om) and np.array_equal(tk, otk) and n > 50
+    assert (om <= -2).any()                                       # the rotation histogram removed something: encoded -2 - slot
+    v3, q2, r2, l2, d2 = _no_claim_variant(valid, q_uv, rad, lvl, D1)
+    a2 = np.concatenate([K1[:, 3], K1[:, 3]])
+    on3, om3, _, otk3 = oracle.search_by_projection(K2, D2, BOUNDS, q2, r2, d2, q_min_level=l2 - 1, q_max_level=l2 + 1, q_valid=v3,
+                                                    taken=taken0, q_angle=a2, ratio=0.9, th=th, check_ori=True)
+    n3, m3, tk3 = NP.search_by_projection_frame(K2, D2, BOUNDS, q2, r2, l2, d2, v3, a2, taken0, th, True)
+    assert n3 == on3 and np.array_equal(m3, om3) and np.array_equal(tk3, otk3)
 
 
 def test_projection_family_sim3(oracle, frames):                          # M12 :258-361
@@ -182,6 +208,11 @@ def test_search_by_sim3(oracle, frames):                                  # M11 
     on2, om2 = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, q12_desc=M1, q21_desc=M2)
     n2, m2 = NP.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, q12_desc=M1, q21_desc=M2)
     assert n2 == on2 and np.array_equal(m2, om2) and n2 > 50
+    # keyframes of two cameras: each direction searches the TARGET keyframe's own grid (:1022 pKF2, :1102 pKF1)
+    B2 = (BOUNDS[0] - 7.0, BOUNDS[1] + 19.0, BOUNDS[2] - 3.0, BOUNDS[3] + 11.0)
+    on3, om3 = oracle.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, bounds2=B2)
+    n3, m3 = NP.search_by_sim3(K1, D1, K2, D2, BOUNDS, *q, bounds2=B2)
+    assert n3 == on3 and np.array_equal(m3, om3) and n3 > 50
     # agreement really filters: one-directional matches outnumber the mutual ones
     n12, m12, _, _ = oracle.search_by_projection(K2, D2, BOUNDS, q[0], q[1], D1, q_pred_level=q[2], q_valid=q[3], th=100, ratio=1.0)
     assert n12 > on

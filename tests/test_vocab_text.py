@@ -44,6 +44,34 @@ def test_parse_text_rejects_garbage(tmp_path):
     p.write_text("10 6 0 0\n7 0 " + "1 " * 32 + "0.5\n")                          # parent 7 does not exist yet
     with pytest.raises(_lib.OrbHipError):
         vocabulary.parse_text(p)
+    p.write_text("10 6 0 0\n0 0 " + "1 " * 31 + "0.5\n")                          # 34 tokens: a byte is missing
+    with pytest.raises(_lib.OrbHipError, match="35 tokens"):
+        vocabulary.parse_text(p)
+    p.write_text("10 6 0 0\n0 0 " + "1 " * 32 + "\n")                             # the weight is missing
+    with pytest.raises(_lib.OrbHipError, match="35 tokens"):
+        vocabulary.parse_text(p)
+    p.write_text("10 6 0 0\n0 0 " + "300 " * 32 + "0.5\n")                        # not bytes
+    with pytest.raises(_lib.OrbHipError):
+        vocabulary.parse_text(p)
+    p.write_text("10 6 0\n")                                                       # header too short
+    with pytest.raises(_lib.OrbHipError):
+        vocabulary.parse_text(p)
+    p.write_text("2 1 0 0\n" + ("0 1 " + "1 " * 32 + "0.5\n") * 3)                # 4 nodes in a binary tree of depth 1
+    with pytest.raises(_lib.OrbHipError, match="more than"):
+        vocabulary.parse_text(p)
+
+
+def test_load_text_rejects_other_scoring_before_touching_a_device(tmp_path):
+    """orbv_transform / orbv_score_l1 implement TF-IDF weights with L1 scores (ORBvoc.txt: "10 6 0 0"); a vocabulary saved with
+    another scoring / weighting type must not silently get those semantics."""
+    from ceres_mono_orb_slam2_amd import vocabulary, _lib
+    voc = synth.make_vocabulary(3, k=4, L=2)
+    for sc, wt in ((1, 0), (0, 2)):
+        path = tmp_path / ("voc_%d_%d.txt" % (sc, wt))
+        save_to_text_file(voc, path, scoring=sc, weighting=wt)
+        assert vocabulary.parse_text(path)["scoring"] == sc and vocabulary.parse_text(path)["weighting"] == wt
+        with pytest.raises(_lib.OrbHipError, match="L1_NORM"):
+            vocabulary.ORBVocabulary.loadFromTextFile(path)
 
 
 @pytest.mark.gpu
@@ -54,6 +82,7 @@ def test_loaded_vocabulary_transforms_like_the_array_one(tmp_path):
     save_to_text_file(voc, path)
     A = vocabulary.ORBVocabulary(voc["node_desc"], voc["child_off"], voc["children"], voc["word_id"], voc["weight"], voc["L"])
     B = vocabulary.ORBVocabulary.loadFromTextFile(path)
+    assert B.depth == A.depth == voc["L"]
     desc = np.random.default_rng(1).integers(0, 256, (1500, 32), dtype=np.uint8)
     a, b = A.transform(desc, 2), B.transform(desc, 2)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -1,40 +1,119 @@
-"""Copy the evidence tools/run_profiles.sh left under gpurun_out/ (scratch) into profiles/ (tracked), named per round.
-usage: python tools/collect_profiles.py r02"""
-import csv, json, os, shutil, sqlite3, subprocess, sys, collections
+"""Copy the evidence tools/run_profiles.sh left under gpurun_out/<round>/ (scratch) into profiles/ (tracked), named per round.
+usage: python tools/collect_profiles.py r03
+
+Every input is VALIDATED before anything under profiles/ changes: it must exist, be non-empty and parse (a JSON line, a
+kernel-stats CSV with at least the front-end's kernels, a PMC database with counters).  An input that fails is reported and
+SKIPPED - the tracked file of an earlier, good run is never overwritten by a missing, empty or broken one (round 2 lost its
+headline kernel stats exactly that way).  Files are written to a temporary name and renamed.  Exit code 1 if anything was skipped."""
+import csv, json, os, sqlite3, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = os.path.join(ROOT, "gpurun_out"); O = os.path.join(G, RND); P = os.path.join(ROOT, "profiles")
+skipped = []
+
+
+def put(name, text):
+    tmp = os.path.join(P, name + ".tmp")
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, os.path.join(P, name))
+    print("  profiles/%s (%d bytes)" % (name, len(text)))
+
 
 def first_json_line(path):
+    if not os.path.exists(path) or os.path.getsize(path) == 0:
+        raise ValueError("missing or empty")
     for line in open(path):
         line = line.strip()
         if line.startswith("{"):
             return json.loads(line)
-    raise SystemExit("no JSON line in " + path)
+    raise ValueError("no JSON line")
 
-json.dump(first_json_line(os.path.join(O, "bench.json")), open(os.path.join(P, RND + "_bench.json"), "w"), indent=1)
-json.dump(first_json_line(os.path.join(O, "bench_2rank_shared.json")), open(os.path.join(P, RND + "_bench_2rank_shared_gpu.json"), "w"), indent=1)
-shutil.copy(os.path.join(O, "bench_kernel_stats.csv"), os.path.join(P, RND + "_bench_kernel_stats.csv"))
-shutil.copy(os.path.join(O, "localba_batch16_kernel_stats.csv"), os.path.join(P, RND + "_localba_batch16_kernel_stats.csv"))
-old = json.load(open(os.path.join(P, RND + "_api_latency.json"))) if os.path.exists(os.path.join(P, RND + "_api_latency.json")) else {}
-api = {"note": old.get("note", "wall latency of the per-frame host-pointer entry points on one MI355X (C++ through the C ABI, tools/cpp/api_latency.cpp; Python ctypes mirror, tools/api_latency.py)"),
-       "cpp": first_json_line(os.path.join(O, "api_latency_cpp.json")), "python": first_json_line(os.path.join(O, "api_latency_py.json"))}
-if "round1_python" in old: api["round1_python"] = old["round1_python"]
-json.dump(api, open(os.path.join(P, RND + "_api_latency.json"), "w"), indent=1)
-txt = open(os.path.join(O, "fast_phase_prof.json")).read().strip()
-open(os.path.join(P, RND + "_fast_phase_prof.json"), "w").write(txt + "\n")
+
+def take_json(src, dst, must_have=()):
+    try:
+        j = first_json_line(os.path.join(O, src))
+        for k in must_have:
+            if k not in j:
+                raise ValueError("no key %r" % k)
+        put(dst, json.dumps(j, indent=1) + "\n")
+        return j
+    except Exception as e:
+        skipped.append("%s: %s" % (src, e)); return None
+
+
+def take_kernel_csv(src, dst, must_name=()):
+    path = os.path.join(O, src)
+    try:
+        if not os.path.exists(path) or os.path.getsize(path) == 0:
+            raise ValueError("missing or empty")
+        rows = list(csv.reader(open(path)))
+        if len(rows) < 2 or rows[0][:2] != ["Name", "Calls"]:
+            raise ValueError("not a kernel-stats table")
+        names = " ".join(r[0] for r in rows[1:])
+        for k in must_name:
+            if k not in names:
+                raise ValueError("kernel %s absent" % k)
+        put(dst, open(path).read())
+    except Exception as e:
+        skipped.append("%s: %s" % (src, e))
+
+
+print("collecting %s -> profiles/" % O)
+take_json("bench.json", RND + "_bench.json", ("value", "roofline"))
+take_kernel_csv("bench_kernel_stats.csv", RND + "_bench_kernel_stats.csv", ("k_fast_cells", "k_match_pairs", "k_blur7", "k_resize", "k_describe", "k_octree"))
+take_json("bench_traced.json", RND + "_bench_traced.json", ("value", "kernels"))
+take_kernel_csv("localba_batch16_kernel_stats.csv", RND + "_localba_batch16_kernel_stats.csv", ("k_ba_schur",))
+take_kernel_csv("gba_c5_kernel_stats.csv", RND + "_gba_c5_kernel_stats.csv", ("k_chol",))
+take_json("bench_2rank_shared.json", RND + "_bench_2rank_shared_gpu.json", ("value", "collective"))
+take_json("bench_rccl_ws1.json", RND + "_bench_rccl_ws1.json", ("collective",))
+try:
+    api = {"note": "wall latency of the per-frame host-pointer entry points on one MI355X (C++ through the C ABI, tools/cpp/api_latency.cpp; "
+                   "Python ctypes mirror, tools/api_latency.py)",
+           "cpp": first_json_line(os.path.join(O, "api_latency_cpp.json")), "python": first_json_line(os.path.join(O, "api_latency_py.json"))}
+    put(RND + "_api_latency.json", json.dumps(api, indent=1) + "\n")
+except Exception as e:
+    skipped.append("api_latency: %s" % e)
+for extra in ("fast_phase_prof.json", "chol_phase_prof.json", "octree_phase_prof.json", "gba_c5_mfma.json", "pcie_pipeline.json", "tracking_step.json"):
+    path = os.path.join(O, extra)
+    if os.path.exists(path):
+        try:
+            txt = open(path).read().strip()
+            json.loads(txt if txt.startswith("{") and "\n{" not in txt else txt.splitlines()[-1])
+            put(RND + "_" + extra, txt + "\n")
+        except Exception as e:
+            skipped.append("%s: %s" % (extra, e))
 # raw per-dispatch PMC tables (rows of one dispatch summed over its shader engines) + the two summaries
+pmc_ok = True
+tables = {}
 for tag in ("insts", "active", "fetch", "write"):
     db = os.path.join(G, "pmc_x_" + tag, "run_results.db")
-    c = sqlite3.connect(db)
-    acc = collections.OrderedDict(); names = set()
-    for did, name, cn, val in c.execute("select dispatch_id,kernel_name,counter_name,value from counters_collection order by dispatch_id"):
-        k = name.split("(")[0].replace("orbhip::", "").replace("void ", "")
-        acc.setdefault(did, [k, collections.defaultdict(float)])[1][cn] += val; names.add(cn)
-    names = sorted(names)
-    with open(os.path.join(P, "%s_pmc_%s_counter_collection.csv" % (RND, tag)), "w", newline="") as f:
-        w = csv.writer(f); w.writerow(["dispatch_id", "kernel"] + names)
+    try:
+        if not os.path.exists(db) or os.path.getsize(db) == 0:
+            raise ValueError("missing or empty")
+        c = sqlite3.connect(db)
+        acc = collections.OrderedDict(); names = set()
+        for did, name, cn, val in c.execute("select dispatch_id,kernel_name,counter_name,value from counters_collection order by dispatch_id"):
+            k = name.split("(")[0].replace("orbhip::", "").replace("void ", "")
+            acc.setdefault(did, [k, collections.defaultdict(float)])[1][cn] += val; names.add(cn)
+        if not acc:
+            raise ValueError("no counter rows")
+        tables[tag] = (acc, sorted(names))
+    except Exception as e:
+        skipped.append("pmc_x_%s: %s" % (tag, e)); pmc_ok = False
+if pmc_ok:
+    import io
+    for tag, (acc, names) in tables.items():
+        buf = io.StringIO()
+        w = csv.writer(buf); w.writerow(["dispatch_id", "kernel"] + names)
         for did, (k, d) in acc.items():
             w.writerow([did, k] + [d.get(n, 0.0) for n in names])
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_extract.py"), RND])
+        put("%s_pmc_%s_counter_collection.csv" % (RND, tag), buf.getvalue())
+    if subprocess.call([sys.executable, os.path.join(ROOT, "tools", "pmc_extract.py"), RND]) != 0:
+        skipped.append("pmc_extract failed")
+if skipped:
+    print("SKIPPED (tracked files of earlier runs left untouched):")
+    for s in skipped:
+        print("  " + s)
+    sys.exit(1)
 print("profiles/%s_* refreshed" % RND)

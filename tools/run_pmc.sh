@@ -1,17 +1,20 @@
 #!/bin/bash
-# The four rocprofv3 PMC passes over tools/extract_only.py (separate runs, --pmc only: no trace domains), rocpd databases under
-# gpurun_out/pmc_x_{insts,active,fetch,write}; tools/pmc_extract.py <round> turns them into profiles/<round>_pmc_{valu,traffic}.json.
+# The four rocprofv3 PMC passes over tools/frontend_only.py (separate runs, --pmc only: no trace domains), ALL at the bench's
+# batch of 256 frames; rocpd databases under gpurun_out/pmc_x_{insts,active,fetch,write}; tools/pmc_extract.py <round> turns
+# them into profiles/<round>_pmc_{valu,traffic}.json.
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-run() {  # tag batch counters...
-  tag=$1; B=$2; shift 2
+B=${PMC_BATCH:-256}
+run() {  # tag counters...
+  tag=$1; shift 1
   rm -rf gpurun_out/pmc_x_$tag
-  rocprofv3 --pmc "$@" --output-format rocpd -d gpurun_out/pmc_x_$tag -o run -- python tools/extract_only.py $B > gpurun_out/pmc_x_$tag.log 2>&1 || { tail -5 gpurun_out/pmc_x_$tag.log; exit 1; }
+  rocprofv3 --pmc "$@" --output-format rocpd -d gpurun_out/pmc_x_$tag -o run -- python tools/frontend_only.py $B 3 > gpurun_out/pmc_x_$tag.log 2>&1 || { tail -5 gpurun_out/pmc_x_$tag.log; exit 1; }
   f=$(find gpurun_out/pmc_x_$tag -name "*.db" | head -1); [ -n "$f" ] && [ "$f" != "gpurun_out/pmc_x_$tag/run_results.db" ] && mv "$f" gpurun_out/pmc_x_$tag/run_results.db
   ls -la gpurun_out/pmc_x_$tag | tail -2
 }
-run insts 64 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
-run active 64 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT
-run fetch 256 FETCH_SIZE
-run write 256 WRITE_SIZE
+run insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+run active GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+echo $B > gpurun_out/pmc_x_batch.txt
