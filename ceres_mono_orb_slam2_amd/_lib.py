@@ -16,10 +16,10 @@ SYMBOLS = [
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
     "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_sim3", "orbm_search_by_bow", "orbm_search_for_triangulation",
     "orbv_create", "orbv_destroy", "orbv_load_text", "orbv_parse_text", "orbv_free_parsed", "orbv_transform", "orbv_descend_device", "orbv_score_l1",
-    "orbm_undistort_keypoints", "orbm_assign_features_to_grid", "orbm_features_in_area", "orbm_is_in_frustum",
+    "orbm_undistort_keypoints", "orbm_assign_features_to_grid", "orbm_features_in_area", "orbm_is_in_frustum", "orbm_is_in_frustum_gates",
     "orbm_triangulate_matches",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
-    "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log",
+    "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log", "ba_sim3_mul", "ba_sim3_inverse",
     "ba_solve_batch", "ba_local_bundle_adjustment_batch", "ba_optimize_essential_graph", "ba_essential_graph_correct",
     "ba_matrix4d_to_pose7", "ba_pose7_to_matrix4d", "ba_set_profiling", "ba_get_profile",
 ]
@@ -116,6 +116,7 @@ def load():
     L.orbm_features_in_area.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.POINTER(i32)]
     L.orbm_triangulate_matches.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, vp]
     L.orbm_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, vp, vp, vp]
+    L.orbm_is_in_frustum_gates.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp]
     if hasattr(L, "ba_solve"):
         L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
         L.ba_pose_optimization_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
@@ -128,6 +129,7 @@ def load():
         L.ba_optimize_sim3_batch_device.argtypes = [vp] * 11 + [i32, vp, vp, vp, vp]
         L.ba_sim3_exp.argtypes = [vp, vp]
         L.ba_sim3_log.argtypes = [vp, vp]
+        L.ba_sim3_mul.argtypes = [vp, vp, vp]; L.ba_sim3_inverse.argtypes = [vp, vp]
         L.ba_optimize_essential_graph.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, vp, C.POINTER(BaSummary)]
         L.ba_essential_graph_correct.argtypes = [vp, vp, i32, vp, vp, vp, i32]
         L.ba_matrix4d_to_pose7.argtypes = [vp, vp]

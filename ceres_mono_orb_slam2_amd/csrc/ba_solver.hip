@@ -2808,6 +2808,14 @@ int ba_optimize_sim3(const double* K1, const double* K2, double* s12, const doub
 // Sim(3) helpers a host binding needs to cross the Sophus boundary without Sophus (host arithmetic, no device work).
 int ba_sim3_exp(const double* tangent7, double* s12_out) { ORBHIP_REQUIRE(tangent7 && s12_out, ORBHIP_EINVAL, "NULL argument"); s3_exp(tangent7, s12_out); return 0; }
 int ba_sim3_log(const double* s12, double* tangent7_out) { ORBHIP_REQUIRE(s12 && tangent7_out, ORBHIP_EINVAL, "NULL argument"); s3_log(s12, tangent7_out); return 0; }
+int ba_sim3_mul(const double* a, const double* b, double* out) {
+  ORBHIP_REQUIRE(a && b && out, ORBHIP_EINVAL, "NULL argument");
+  double r[7]; s3_mul(a, b, r); for (int k = 0; k < 7; k++) out[k] = r[k]; return 0;
+}
+int ba_sim3_inverse(const double* a, double* out) {
+  ORBHIP_REQUIRE(a && out, ORBHIP_EINVAL, "NULL argument");
+  double r[7]; s3_inverse(a, r); for (int k = 0; k < 7; k++) out[k] = r[k]; return 0;
+}
 
 // LocalBundleAdjustment's optimisation core for a batch of independent local maps: pass 1 of every problem in one
 // lockstep batch, host-side classification, pass 2 likewise (src/CeresOptimizer.cc:408-598 per problem).

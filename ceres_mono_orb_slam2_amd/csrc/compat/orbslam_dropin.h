@@ -780,6 +780,288 @@ class CeresOptimizerT {
       pts[p]->UpdateNormalAndDepth();
     }
   }
+
+  // ---- src/CeresOptimizer.cc:601-735 (LoopClosing.cc:324) ------------------------------------------------------------------
+  // Sim3 = Sophus::Sim3d (or anything whose data() is its storage [qx, qy, qz, qw with |q|^2 = scale, tx, ty, tz]).
+  typedef typename Types::Sim3 Sim3;
+  typedef typename Types::KeyFrameAndSim3 KeyFrameAndSim3;
+
+  int static OptimizeSim3(KeyFrame* keyframe_1, KeyFrame* keyframe_2, std::vector<MapPoint*>& matches12, Sim3& S12, const float th2, const bool bFixScale) {
+    using namespace dropin;
+    const double K1[4] = {keyframe_1->fx_, keyframe_1->fy_, keyframe_1->cx_, keyframe_1->cy_};      // keyframe->K_ (":607-608")
+    const double K2[4] = {keyframe_2->fx_, keyframe_2->fy_, keyframe_2->cx_, keyframe_2->cy_};
+    const Matrix3d R1cw = keyframe_1->GetRotation(), R2cw = keyframe_2->GetRotation();
+    const P3 t1cw = p3(keyframe_1->GetTranslation()), t2cw = p3(keyframe_2->GetTranslation());
+    const int N = (int)matches12.size();
+    const std::vector<MapPoint*> map_points_1 = keyframe_1->GetMapPointMatches();
+    std::vector<double> P3D2c, obs1, P3D1c, obs2; std::vector<float> w1, w2;
+    for (int i = 0; i < N; i++) {                                      // (":633-692")
+      if (!matches12[i]) continue;
+      MapPoint* map_point_1 = map_points_1[i];
+      MapPoint* map_point_2 = matches12[i];
+      const int i2 = map_point_2->GetIndexInKeyFrame(keyframe_2);
+      if (!map_point_1 || !map_point_2) continue;
+      if (map_point_1->isBad() || map_point_2->isBad() || i2 < 0) continue;
+      const auto& keypoint_1 = keyframe_1->undistort_keypoints_[i];
+      const auto& keypoint_2 = keyframe_2->undistort_keypoints_[i2];
+      const P3 c2 = add(rot(R2cw, p3(map_point_2->GetWorldPos())), t2cw);
+      const P3 c1 = add(rot(R1cw, p3(map_point_1->GetWorldPos())), t1cw);
+      P3D2c.push_back(c2.x); P3D2c.push_back(c2.y); P3D2c.push_back(c2.z); obs1.push_back(keypoint_1.pt.x); obs1.push_back(keypoint_1.pt.y);
+      w1.push_back(keyframe_1->inv_level_sigma2s_[keypoint_1.octave]);
+      P3D1c.push_back(c1.x); P3D1c.push_back(c1.y); P3D1c.push_back(c1.z); obs2.push_back(keypoint_2.pt.x); obs2.push_back(keypoint_2.pt.y);
+      w2.push_back(keyframe_2->inv_level_sigma2s_[keypoint_2.octave]);
+    }
+    int n_inliers = 0;
+    double s12[7];
+    for (int k = 0; k < 7; k++) s12[k] = S12.data()[k];
+    const double dummy[3] = {0, 0, 0}; const float fdummy[1] = {0};
+    const int n = (int)w1.size();
+    check(ba_optimize_sim3(K1, K2, s12, n ? P3D2c.data() : dummy, n ? obs1.data() : dummy, n ? w1.data() : fdummy, n ? P3D1c.data() : dummy, n ? obs2.data() : dummy,
+                           n ? w2.data() : fdummy, n, (double)th2, bFixScale ? 1 : 0, nullptr, &n_inliers, nullptr), "ba_optimize_sim3");
+    for (int k = 0; k < 7; k++) S12.data()[k] = s12[k];                // S12 = Sim3d::exp(sim12) (":696")
+    return n_inliers;                                                  // 0 when fewer than 10 (":731")
+  }
+
+  // ---- src/CeresOptimizer.cc:737-957 (LoopClosing.cc:573) -----------------------------------------------------------------
+  // The reference indexes its parameter blocks by keyframe id in arrays of max id + 1; here the non-bad keyframes of the map
+  // are numbered densely in map order.  An edge to a keyframe without a block (bad, or not in the map: the reference would
+  // read an uninitialised 7-vector there) is not added, and bad keyframes are not written back.
+  void static OptimizeEssentialGraph(Map* map, KeyFrame* loop_keyframe, KeyFrame* current_keyframe, const KeyFrameAndSim3& keyframes_non_corrected_sim3,
+                                     const KeyFrameAndSim3& keyframes_corrected_sim3, const std::map<KeyFrame*, std::set<KeyFrame*> >& loop_connections,
+                                     const bool& is_fixed_scale) {
+    (void)is_fixed_scale;                                              // (never read by the reference either)
+    const int min_weight = 100;
+    const std::vector<KeyFrame*> all_keyframes = map->GetAllKeyFrames();
+    const std::vector<MapPoint*> all_map_points = map->GetAllMapPoints();
+    std::unordered_map<KeyFrame*, int> vtx;
+    std::vector<KeyFrame*> kfs;
+    std::vector<double> lie; std::vector<uint8_t> fixed;
+    for (size_t i = 0; i < all_keyframes.size(); i++) {                // (":769-793")
+      KeyFrame* keyframe = all_keyframes[i];
+      if (keyframe->isBad() || vtx.count(keyframe)) continue;
+      double S[7], x[7];
+      auto it = keyframes_corrected_sim3.find(keyframe);
+      if (it != keyframes_corrected_sim3.end()) { for (int k = 0; k < 7; k++) S[k] = it->second.data()[k]; }
+      else se3_as_sim3(keyframe->GetPose(), S);                        // Sim3d(RxSO3d(1.0, Rcw), tcw)
+      dropin::check(ba_sim3_log(S, x), "ba_sim3_log");
+      vtx[keyframe] = (int)kfs.size(); kfs.push_back(keyframe);
+      lie.insert(lie.end(), x, x + 7);
+      fixed.push_back(keyframe == loop_keyframe ? 1 : 0);
+    }
+    const int n_kf = (int)kfs.size();
+    if (n_kf == 0) return;
+    const std::vector<double> lie_orig = lie;
+    std::vector<int32_t> edge_j, edge_i; std::vector<double> edge_S;
+    auto exp_of = [&](int v, double* S) { dropin::check(ba_sim3_exp(&lie_orig[7 * (size_t)v], S), "ba_sim3_exp"); };
+    auto add_edge = [&](int vj, int vi, const double* Sjw, const double* Swi) {
+      double Sji[7];
+      dropin::check(ba_sim3_mul(Sjw, Swi, Sji), "ba_sim3_mul");
+      edge_j.push_back(vj); edge_i.push_back(vi); edge_S.insert(edge_S.end(), Sji, Sji + 7);
+    };
+    // the pose a keyframe enters "normal" edges with: its non-corrected Sim3 if it has one, else exp of its block (":826-833", ":842-847")
+    auto world_pose = [&](KeyFrame* kf, int v, double* S) {
+      auto it = keyframes_non_corrected_sim3.find(kf);
+      if (it != keyframes_non_corrected_sim3.end()) { for (int k = 0; k < 7; k++) S[k] = it->second.data()[k]; }
+      else exp_of(v, S);
+    };
+    std::set<std::pair<unsigned long, unsigned long> > inserted_edges;
+    for (auto it = loop_connections.begin(); it != loop_connections.end(); ++it) {       // (":797-821")
+      KeyFrame* keyframe = it->first;
+      auto vi = vtx.find(keyframe);
+      if (vi == vtx.end()) continue;
+      const unsigned long id_i = keyframe->id_;
+      double Siw[7], Swi[7];
+      exp_of(vi->second, Siw);
+      dropin::check(ba_sim3_inverse(Siw, Swi), "ba_sim3_inverse");
+      for (auto jt = it->second.begin(); jt != it->second.end(); ++jt) {
+        const unsigned long id_j = (*jt)->id_;
+        if ((id_i != current_keyframe->id_ || id_j != loop_keyframe->id_) && keyframe->GetWeight(*jt) < min_weight) continue;
+        auto vj = vtx.find(*jt);
+        if (vj == vtx.end()) continue;
+        double Sjw[7];
+        exp_of(vj->second, Sjw);
+        add_edge(vj->second, vi->second, Sjw, Swi);
+        inserted_edges.insert(std::make_pair(std::min(id_i, id_j), std::max(id_i, id_j)));
+      }
+    }
+    for (size_t i = 0; i < all_keyframes.size(); i++) {                // (":824-905")
+      KeyFrame* keyframe = all_keyframes[i];
+      auto vi = vtx.find(keyframe);
+      if (vi == vtx.end() || kfs[vi->second] != keyframe) continue;
+      double Siw[7], Swi[7];
+      world_pose(keyframe, vi->second, Siw);
+      dropin::check(ba_sim3_inverse(Siw, Swi), "ba_sim3_inverse");
+      KeyFrame* parent_keyframe = keyframe->GetParent();
+      if (parent_keyframe) {
+        auto vj = vtx.find(parent_keyframe);
+        if (vj != vtx.end()) { double Sjw[7]; world_pose(parent_keyframe, vj->second, Sjw); add_edge(vj->second, vi->second, Sjw, Swi); }
+      }
+      const std::set<KeyFrame*> loop_edges = keyframe->GetLoopEdges();
+      for (auto lt = loop_edges.begin(); lt != loop_edges.end(); ++lt) {
+        KeyFrame* local_loop_keyframe = *lt;
+        if (local_loop_keyframe->id_ < keyframe->id_) {
+          auto vl = vtx.find(local_loop_keyframe);
+          if (vl == vtx.end()) continue;
+          double Slw[7]; world_pose(local_loop_keyframe, vl->second, Slw); add_edge(vl->second, vi->second, Slw, Swi);
+        }
+      }
+      const std::vector<KeyFrame*> connected_keyframes = keyframe->GetCovisiblesByWeight(min_weight);
+      for (auto ct = connected_keyframes.begin(); ct != connected_keyframes.end(); ++ct) {
+        KeyFrame* keyframe_n = *ct;
+        if (keyframe_n && keyframe_n != parent_keyframe && !keyframe->hasChild(keyframe_n) && !loop_edges.count(keyframe_n)) {
+          if (!keyframe_n->isBad() && keyframe_n->id_ < keyframe->id_) {
+            if (inserted_edges.count(std::make_pair(std::min<unsigned long>(keyframe->id_, keyframe_n->id_), std::max<unsigned long>(keyframe->id_, keyframe_n->id_)))) continue;
+            auto vn = vtx.find(keyframe_n);
+            if (vn == vtx.end()) continue;
+            double Snw[7]; world_pose(keyframe_n, vn->second, Snw); add_edge(vn->second, vi->second, Snw, Swi);
+          }
+        }
+      }
+    }
+    const int32_t idummy[1] = {0}; const double ddummy[7] = {0, 0, 0, 1, 0, 0, 0};
+    const int n_edges = (int)edge_j.size();
+    dropin::check(ba_optimize_essential_graph(lie.data(), fixed.data(), n_kf, n_edges ? edge_j.data() : idummy, n_edges ? edge_i.data() : idummy,
+                                              n_edges ? edge_S.data() : ddummy, n_edges, 100, nullptr, nullptr), "ba_optimize_essential_graph");
+    // write-back (":908-956"): SE(3) recovery per keyframe, map points through their reference keyframe
+    std::vector<MapPoint*> pts; std::vector<int32_t> pt_ref; std::vector<double> pts3;
+    for (size_t i = 0; i < all_map_points.size(); i++) {
+      MapPoint* map_point = all_map_points[i];
+      if (map_point->isBad()) continue;
+      KeyFrame* ref = nullptr;
+      if (map_point->corrected_by_keyframe_ == current_keyframe->id_) {
+        for (KeyFrame* k : kfs) if (k->id_ == (unsigned long)map_point->corrected_reference_) { ref = k; break; }
+      } else ref = map_point->GetReferenceKeyFrame();
+      auto vr = ref ? vtx.find(ref) : vtx.end();
+      if (vr == vtx.end()) continue;                                   // (no block for the reference keyframe: left as it is)
+      const Vector3d X = map_point->GetWorldPos();
+      pts.push_back(map_point); pt_ref.push_back(vr->second); pts3.push_back(X[0]); pts3.push_back(X[1]); pts3.push_back(X[2]);
+    }
+    std::vector<double> Tiw(12 * (size_t)n_kf);
+    dropin::check(ba_essential_graph_correct(lie_orig.data(), lie.data(), n_kf, Tiw.data(), pts.empty() ? idummy : pt_ref.data(), pts.empty() ? nullptr : pts3.data(), (int)pts.size()),
+                  "ba_essential_graph_correct");
+    std::unique_lock<std::mutex> lock(map->mutex_map_update_);         // (":911")
+    for (int v = 0; v < n_kf; v++) {
+      Matrix4d T;
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) T(r, c) = Tiw[12 * (size_t)v + 4 * r + c];
+      T(3, 0) = 0; T(3, 1) = 0; T(3, 2) = 0; T(3, 3) = 1;
+      kfs[v]->SetPose(T);
+    }
+    for (size_t p = 0; p < pts.size(); p++) {
+      Vector3d X;
+      for (int k = 0; k < 3; k++) X[k] = pts3[3 * p + k];
+      pts[p]->SetWorldPos(X);
+      pts[p]->UpdateNormalAndDepth();
+    }
+  }
+
+  // Sophus::Sim3d(Sophus::RxSO3d(1.0, R), t) of a rigid pose, as 7 doubles (Eigen's matrix -> quaternion branches through the pose codec)
+  static void se3_as_sim3(const Matrix4d& T, double S[7]) {
+    double p7[7];
+    Matrix4dToMatrix_7_1(T, p7);
+    S[0] = p7[3]; S[1] = p7[4]; S[2] = p7[5]; S[3] = p7[6]; S[4] = p7[0]; S[5] = p7[1]; S[6] = p7[2];
+  }
+};
+
+// ============================================================================================== Frame-side steps
+// The bodies of the reference's member functions on either side of the matcher, over the same Types bundle: a maintainer
+// replaces the body of Frame::ComputeBoW / KeyFrame::ComputeBoW / Frame::isInFrustum / Frame::GetFeaturesInArea /
+// KeyFrame::GetFeaturesInArea by ONE call, and the per-match body of LocalMapping::CreateNewMapPoints by TriangulateMatches.
+template <class Types>
+struct FrameOpsT {
+  typedef typename Types::Frame Frame;
+  typedef typename Types::KeyFrame KeyFrame;
+  typedef typename Types::MapPoint MapPoint;
+  typedef typename Types::Matrix3d Matrix3d;
+  typedef typename Types::Vector3d Vector3d;
+
+  // Frame::ComputeBoW (src/Frame.cc:322-327: only when bow_vector_ is empty) and KeyFrame::ComputeBoW (src/KeyFrame.cc:107-117:
+  // when either container is empty): orb_vocabulary_->transform(descriptors, bow_vector_, feature_vector_, 4)
+  template <class F> static void ComputeBoW(F& f, orbv_ctx* orb_vocabulary, bool also_when_feature_vector_empty = false) {
+    if (!(f.bow_vector_.empty() || (also_when_feature_vector_empty && f.feature_vector_.empty()))) return;
+    const int n = (int)f.undistort_keypoints_.size();
+    std::vector<uint8_t> desc(32 * (size_t)std::max(n, 1));
+    for (int i = 0; i < n; i++) std::memcpy(&desc[32 * (size_t)i], f.descriptors_.ptr(i), 32);
+    std::vector<uint32_t> bw(std::max(n, 1)), fn(std::max(n, 1)), fo(n + 2), fi(std::max(n, 1));
+    std::vector<double> bv(std::max(n, 1));
+    int nw = 0, nf = 0;
+    dropin::check(orbv_transform(orb_vocabulary, desc.data(), n, 4, bw.data(), bv.data(), &nw, fn.data(), fo.data(), fi.data(), &nf), "orbv_transform");
+    f.bow_vector_.clear(); f.feature_vector_.clear();
+    for (int k = 0; k < nw; k++) f.bow_vector_.insert(f.bow_vector_.end(), std::make_pair(bw[k], bv[k]));
+    for (int m = 0; m < nf; m++) {
+      auto it = f.feature_vector_.insert(f.feature_vector_.end(), std::make_pair(fn[m], std::vector<unsigned int>()));
+      it->second.assign(fi.begin() + fo[m], fi.begin() + fo[m + 1]);
+    }
+  }
+
+  // Frame::isInFrustum (src/Frame.cc:191-241) for a LIST of map points - the loop of Tracking::SearchLocalPoints
+  // (src/Tracking.cc:810-826) in one call: sets is_track_in_view_, track_proj_x_, track_proj_y_, track_scale_level_,
+  // track_view_cos_ of every point exactly as the member function does and returns the per-point results.
+  static std::vector<bool> isInFrustum(Frame& F, const std::vector<MapPoint*>& points, float viewingCosLimit) {
+    using namespace dropin;
+    const size_t n = points.size();
+    std::vector<bool> res(n, false);
+    if (!n) return res;
+    double R[9], t[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[3 * r + c] = F.Tcw_(r, c); t[r] = F.Tcw_(r, 3); }
+    const float K4[4] = {F.fx_, F.fy_, F.cx_, F.cy_}, bounds[4] = {(float)F.min_x_, (float)F.max_x_, (float)F.min_y_, (float)F.max_y_};
+    std::vector<double> P(3 * n), Pn(3 * n); std::vector<float> mn(n), mx(n);
+    for (size_t i = 0; i < n; i++) {
+      const Vector3d p = points[i]->GetWorldPos(), nn = points[i]->GetNormal();
+      for (int k = 0; k < 3; k++) { P[3 * i + k] = p[k]; Pn[3 * i + k] = nn[k]; }
+      mn[i] = points[i]->GetMinDistanceInvariance(); mx[i] = points[i]->GetMaxDistanceInvariance();
+    }
+    std::vector<uint8_t> in_view(n); std::vector<float> uv(2 * n), vc(n), dist(n);
+    check(orbm_is_in_frustum_gates(R, t, K4, bounds, P.data(), Pn.data(), mn.data(), mx.data(), (int)n, viewingCosLimit, in_view.data(), uv.data(), vc.data(), dist.data()),
+          "orbm_is_in_frustum_gates");
+    for (size_t i = 0; i < n; i++) {
+      MapPoint* mp = points[i];
+      mp->is_track_in_view_ = false;                                   // (":192")
+      if (!in_view[i]) continue;
+      const int nPredictedLevel = mp->PredictScale(dist[i], &F);      // (":231")
+      mp->is_track_in_view_ = true; mp->track_proj_x_ = uv[2 * i]; mp->track_proj_y_ = uv[2 * i + 1];
+      mp->track_scale_level_ = nPredictedLevel; mp->track_view_cos_ = vc[i];
+      res[i] = true;
+    }
+    return res;
+  }
+  static bool isInFrustum(Frame& F, MapPoint* map_point, float viewingCosLimit) { return isInFrustum(F, std::vector<MapPoint*>(1, map_point), viewingCosLimit)[0]; }
+
+  // Frame::GetFeaturesInArea (src/Frame.cc:243-307) and KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:575-622, levels -1 / -1)
+  template <class F> static std::vector<size_t> GetFeaturesInArea(const F& f, const float& x, const float& y, const float& r, const int minLevel = -1, const int maxLevel = -1) {
+    dropin::Flat T; dropin::flatten(f, &T);
+    const float q[2] = {x, y};
+    const int32_t lo = minLevel, hi = maxLevel;
+    std::vector<uint32_t> off(2, 0), idx((size_t)std::max(T.n, 1));
+    int total = 0;
+    dropin::check(orbm_features_in_area(T.kps4.data(), T.n, T.bounds, q, &r, &lo, &hi, 1, off.data(), idx.data(), (int)idx.size(), &total), "orbm_features_in_area");
+    return std::vector<size_t>(idx.begin(), idx.begin() + total);
+  }
+
+  // LocalMapping::CreateNewMapPoints, the body of "Triangulate each match" (src/LocalMapping.cc:267-378) for all matches of one
+  // neighbour keyframe: x3D[k] / ok[k] for matched_indices[k]; the caller keeps the MapPoint construction (":380-395").
+  static void TriangulateMatches(KeyFrame* current_keyframe, KeyFrame* neighbor_keyframe, const std::vector<std::pair<size_t, size_t> >& matched_indices,
+                                 const float ratioFactor, std::vector<Vector3d>* x3D, std::vector<bool>* ok) {
+    const size_t n = matched_indices.size();
+    x3D->assign(n, Vector3d()); ok->assign(n, false);
+    if (!n) return;
+    double T1[12], T2[12];
+    const Matrix3d R1 = current_keyframe->GetRotation(), R2 = neighbor_keyframe->GetRotation();
+    const Vector3d t1 = current_keyframe->GetTranslation(), t2 = neighbor_keyframe->GetTranslation();
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { T1[4 * r + c] = R1(r, c); T2[4 * r + c] = R2(r, c); } T1[4 * r + 3] = t1[r]; T2[4 * r + 3] = t2[r]; }
+    const float K1[4] = {current_keyframe->fx_, current_keyframe->fy_, current_keyframe->cx_, current_keyframe->cy_};
+    const float K2[4] = {neighbor_keyframe->fx_, neighbor_keyframe->fy_, neighbor_keyframe->cx_, neighbor_keyframe->cy_};
+    std::vector<float> kp1(3 * n), kp2(3 * n);
+    for (size_t k = 0; k < n; k++) {
+      const auto& a = current_keyframe->undistort_keypoints_[matched_indices[k].first];
+      const auto& b = neighbor_keyframe->undistort_keypoints_[matched_indices[k].second];
+      kp1[3 * k] = a.pt.x; kp1[3 * k + 1] = a.pt.y; kp1[3 * k + 2] = (float)a.octave;
+      kp2[3 * k] = b.pt.x; kp2[3 * k + 1] = b.pt.y; kp2[3 * k + 2] = (float)b.octave;
+    }
+    std::vector<double> X(3 * n); std::vector<uint8_t> good(n);
+    dropin::check(orbm_triangulate_matches(T1, T2, K1, K2, kp1.data(), kp2.data(), (int)n, current_keyframe->level_sigma2s_.data(), current_keyframe->scale_factors_.data(),
+                                           (int)current_keyframe->scale_factors_.size(), ratioFactor, X.data(), good.data()), "orbm_triangulate_matches");
+    for (size_t k = 0; k < n; k++) { (*ok)[k] = good[k] != 0; for (int c = 0; c < 3; c++) (*x3D)[k][c] = X[3 * k + c]; }
+  }
 };
 
 }  // namespace ORB_SLAM2
@@ -792,8 +1074,10 @@ struct ReferenceTypes {
   typedef ORB_SLAM2::Frame Frame; typedef ORB_SLAM2::KeyFrame KeyFrame; typedef ORB_SLAM2::MapPoint MapPoint; typedef ORB_SLAM2::Map Map;
   typedef Eigen::Matrix3d Matrix3d; typedef Eigen::Matrix4d Matrix4d; typedef Eigen::Vector2d Vector2d; typedef Eigen::Vector3d Vector3d;
   typedef Eigen::Quaterniond Quaterniond; typedef cv::Mat Mat; typedef cv::Point2f Point2f;
+  typedef Sophus::Sim3d Sim3; typedef LoopClosing::KeyFrameAndSim3 KeyFrameAndSim3;
 };
 typedef ORBmatcherT<ReferenceTypes> ORBmatcher;
-typedef CeresOptimizerT<ReferenceTypes> CeresOptimizerHip;      // PoseOptimization / LocalBundleAdjustment / GlobalBundleAdjustemnt / BundleAdjustment
+typedef CeresOptimizerT<ReferenceTypes> CeresOptimizerHip;      // every static of include/CeresOptimizer.h:351-388
+typedef FrameOpsT<ReferenceTypes> FrameOpsHip;
 }  // namespace ORB_SLAM2
 #endif

@@ -167,7 +167,7 @@ struct FrustumCam { double R[9], t[3], Ow[3]; float fx, fy, cx, cy, min_x, max_x
 __global__ __launch_bounds__(256) void k_frustum(FrustumCam C, const double* __restrict__ P, const double* __restrict__ Pn,
                                                  const float* __restrict__ min_dist, const float* __restrict__ max_dist, int n,
                                                  uint8_t* __restrict__ in_view, float* __restrict__ uv, int* __restrict__ level,
-                                                 float* __restrict__ view_cos) {
+                                                 float* __restrict__ view_cos, int invariance_bounds, float* __restrict__ dist_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const double X = P[3 * i], Y = P[3 * i + 1], Z = P[3 * i + 2];
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void k_frustum(FrustumCam C, const double* __r
   const float v = C.fy * PcY * invz + C.cy;
   if (u < C.min_x || u > C.max_x) ok = false;
   if (v < C.min_y || v > C.max_y) ok = false;
-  const float maxD = 1.2f * max_dist[i], minD = 0.8f * min_dist[i];          // GetMax/MinDistanceInvariance (src/MapPoint.cc:379-387)
+  // GetMax/MinDistanceInvariance (src/MapPoint.cc:379-387): applied here, or by the caller (invariance_bounds)
+  const float maxD = invariance_bounds ? max_dist[i] : 1.2f * max_dist[i], minD = invariance_bounds ? min_dist[i] : 0.8f * min_dist[i];
   const double POx = X - C.Ow[0], POy = Y - C.Ow[1], POz = Z - C.Ow[2];
   const float dist = (float)sqrt(POx * POx + POy * POy + POz * POz);
   if (dist < minD || dist > maxD) ok = false;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256) void k_frustum(FrustumCam C, const double* __r
   uv[2 * i] = u; uv[2 * i + 1] = v;
   level[i] = nScale;
   view_cos[i] = vc;
+  if (dist_out) dist_out[i] = dist;
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -286,9 +288,9 @@ int orbm_undistort_keypoints(const float* xy, int n, const float* K4, const floa
   return 0;
 }
 
-int orbm_is_in_frustum(const double* Rcw, const double* tcw, const float* K4, const float* bounds, const double* P, const double* Pn,
-                       const float* min_dist, const float* max_dist, int n, float viewing_cos_limit, float log_scale_factor,
-                       int n_levels, uint8_t* in_view, float* uv, int32_t* level, float* view_cos) {
+static int is_in_frustum_impl(const double* Rcw, const double* tcw, const float* K4, const float* bounds, const double* P, const double* Pn,
+                              const float* min_dist, const float* max_dist, int n, float viewing_cos_limit, float log_scale_factor,
+                              int n_levels, uint8_t* in_view, float* uv, int32_t* level, float* view_cos, int invariance_bounds, float* dist) {
   ORBHIP_REQUIRE(n >= 0 && Rcw && tcw && K4 && bounds && n_levels > 0, ORBHIP_EINVAL, "NULL argument");
   if (n == 0) return 0;
   ORBHIP_REQUIRE(P && Pn && min_dist && max_dist && in_view && uv && level && view_cos, ORBHIP_EINVAL, "NULL argument");
@@ -300,21 +302,39 @@ int orbm_is_in_frustum(const double* Rcw, const double* tcw, const float* K4, co
   C.fx = K4[0]; C.fy = K4[1]; C.cx = K4[2]; C.cy = K4[3];
   C.min_x = bounds[0]; C.max_x = bounds[1]; C.min_y = bounds[2]; C.max_y = bounds[3];
   C.cos_limit = viewing_cos_limit; C.log_scale = log_scale_factor; C.nlevels = n_levels;
-  DevBuf dP, dN, dmin, dmax, dflag, duv, dlv, dvc;
-  DevBuf* all[] = {&dP, &dN, &dmin, &dmax, &dflag, &duv, &dlv, &dvc};
+  DevBuf dP, dN, dmin, dmax, dflag, duv, dlv, dvc, ddist;
+  DevBuf* all[] = {&dP, &dN, &dmin, &dmax, &dflag, &duv, &dlv, &dvc, &ddist};
   auto cleanup = [&]() { for (DevBuf* b : all) b->release(); };
   int rc = 0;
   if ((rc = dP.ensure((size_t)n * 24)) || (rc = dN.ensure((size_t)n * 24)) || (rc = dmin.ensure((size_t)n * 4)) || (rc = dmax.ensure((size_t)n * 4)) ||
-      (rc = dflag.ensure((size_t)n)) || (rc = duv.ensure((size_t)n * 8)) || (rc = dlv.ensure((size_t)n * 4)) || (rc = dvc.ensure((size_t)n * 4))) { cleanup(); return rc; }
+      (rc = dflag.ensure((size_t)n)) || (rc = duv.ensure((size_t)n * 8)) || (rc = dlv.ensure((size_t)n * 4)) || (rc = dvc.ensure((size_t)n * 4)) ||
+      (dist && (rc = ddist.ensure((size_t)n * 4)))) { cleanup(); return rc; }
   FCHK(hipMemcpy(dP.p, P, (size_t)n * 24, hipMemcpyHostToDevice)); FCHK(hipMemcpy(dN.p, Pn, (size_t)n * 24, hipMemcpyHostToDevice));
   FCHK(hipMemcpy(dmin.p, min_dist, (size_t)n * 4, hipMemcpyHostToDevice)); FCHK(hipMemcpy(dmax.p, max_dist, (size_t)n * 4, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_frustum, dim3((n + 255) / 256), dim3(256), 0, 0, C, dP.as<double>(), dN.as<double>(), dmin.as<float>(), dmax.as<float>(), n,
-                     dflag.as<uint8_t>(), duv.as<float>(), dlv.as<int>(), dvc.as<float>());
+                     dflag.as<uint8_t>(), duv.as<float>(), dlv.as<int>(), dvc.as<float>(), invariance_bounds, dist ? ddist.as<float>() : (float*)nullptr);
   FCHK(hipGetLastError());
+  if (dist) FCHK(hipMemcpy(dist, ddist.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   FCHK(hipMemcpy(in_view, dflag.p, (size_t)n, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(uv, duv.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   FCHK(hipMemcpy(level, dlv.p, (size_t)n * 4, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(view_cos, dvc.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   cleanup();
   return 0;
+}
+
+int orbm_is_in_frustum(const double* Rcw, const double* tcw, const float* K4, const float* bounds, const double* P, const double* Pn,
+                       const float* min_dist, const float* max_dist, int n, float viewing_cos_limit, float log_scale_factor,
+                       int n_levels, uint8_t* in_view, float* uv, int32_t* level, float* view_cos) {
+  return is_in_frustum_impl(Rcw, tcw, K4, bounds, P, Pn, min_dist, max_dist, n, viewing_cos_limit, log_scale_factor, n_levels, in_view, uv, level, view_cos, 0, nullptr);
+}
+
+// the form a caller outside MapPoint can feed: the PUBLIC accessors GetMinDistanceInvariance() / GetMaxDistanceInvariance()
+// (min_distance_ / max_distance_ are protected, include/MapPoint.h:125-151) and the distance back, for MapPoint::PredictScale
+int orbm_is_in_frustum_gates(const double* Rcw, const double* tcw, const float* K4, const float* bounds, const double* P, const double* Pn,
+                             const float* min_dist_invariance, const float* max_dist_invariance, int n, float viewing_cos_limit,
+                             uint8_t* in_view, float* uv, float* view_cos, float* dist) {
+  ORBHIP_REQUIRE(n == 0 || dist, ORBHIP_EINVAL, "NULL argument");
+  std::vector<int32_t> level((size_t)std::max(n, 1));
+  return is_in_frustum_impl(Rcw, tcw, K4, bounds, P, Pn, min_dist_invariance, max_dist_invariance, n, viewing_cos_limit, 1.0f, 1, in_view, uv, level.data(), view_cos, 1, dist);
 }
 
 int orbm_assign_features_to_grid(const float* kps4, int n, const float* bounds, uint32_t* cell_offsets, uint32_t* cell_idx, int* n_assigned) {

@@ -265,6 +265,12 @@ int orbm_features_in_area(const float* kps4, int n, const float* bounds, const f
 int orbm_is_in_frustum(const double* Rcw, const double* tcw, const float* K4, const float* bounds, const double* P,
                        const double* Pn, const float* min_dist, const float* max_dist, int n, float viewing_cos_limit,
                        float log_scale_factor, int n_levels, uint8_t* in_view, float* uv, int32_t* level, float* view_cos);
+/* The same gates fed from MapPoint's PUBLIC accessors: min / max = GetMinDistanceInvariance() / GetMaxDistanceInvariance()
+ * (min_distance_ / max_distance_ are protected, include/MapPoint.h:125-151), and dist = |P - Ow| as float comes back so that
+ * the caller runs MapPoint::PredictScale(dist, frame) itself for the points in view (src/Frame.cc:231).                   */
+int orbm_is_in_frustum_gates(const double* Rcw, const double* tcw, const float* K4, const float* bounds, const double* P,
+                             const double* Pn, const float* min_dist_invariance, const float* max_dist_invariance, int n,
+                             float viewing_cos_limit, uint8_t* in_view, float* uv, float* view_cos, float* dist);
 
 /* SearchForTriangulation (src/ORBmatcher.cc:582-722, mono) on flattened data (host pointers): BoW-node brute force
  * between keypoints WITHOUT a map point (unmapped1/2 flags), dist <= TH_LOW with later ties replacing earlier ones
@@ -386,6 +392,10 @@ int ba_essential_graph_correct(const double* lie7_orig, const double* lie7_opt, 
  * cross the Sophus boundary (LoopClosing builds gScm from (s, R, t): src/LoopClosing.cc:322).                           */
 int ba_sim3_exp(const double* tangent7, double* s12_out);
 int ba_sim3_log(const double* s12, double* tangent7_out);
+/* Sophus::Sim3d::operator* and ::inverse() in the same layout (src/CeresOptimizer.cc:806-813,828-849 form Sji = Sjw * Swi from
+ * them; src/LoopClosing.cc:335,458 likewise); out may alias an input.  Host arithmetic.                                   */
+int ba_sim3_mul(const double* a, const double* b, double* out);
+int ba_sim3_inverse(const double* a, double* out);
 
 /* Measurement hook (no reference counterpart): while enabled, every ba_solve / ba_solve_batch / ba_local_bundle_adjustment(_batch)
  * / call brackets its device work (first kernel .. last LM iteration, copies excluded) with HIP events on the calling thread's

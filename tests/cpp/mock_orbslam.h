@@ -1,7 +1,7 @@
 // Mock data model for the drop-in tests: structs that copy the member names (and the small accessor functions) of the
 // reference's include/Frame.h, include/KeyFrame.h, include/MapPoint.h, include/Map.h, with tiny stand-ins for the Eigen and
-// OpenCV types they use.  TEST INFRASTRUCTURE: the product header csrc/compat/orbslam_dropin.h is instantiated over these, and
-// tests/cpp/reference_literal.h runs the reference's own loops on them.
+// OpenCV types they use.  TEST INFRASTRUCTURE: the product header csrc/compat/orbslam_dropin.h is instantiated over these;
+// tests/cpp/scene_io.h writes their state to disk and tests/dropin_checker.py replays every entry point on it in Python.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -38,6 +38,8 @@ struct Matrix4d {
   double& operator()(int r, int c) { return m[r][c]; } double operator()(int r, int c) const { return m[r][c]; }
 };
 struct Quaterniond { double qx = 0, qy = 0, qz = 0, qw = 1; double x() const { return qx; } double y() const { return qy; } double z() const { return qz; } double w() const { return qw; } };
+// Sophus::Sim3d as far as the boundary needs it: data() = [qx, qy, qz, qw (|q|^2 = scale), tx, ty, tz]
+struct Sim3d { double d[7] = {0, 0, 0, 1, 0, 0, 0}; double* data() { return d; } const double* data() const { return d; } };
 
 struct Point2f { float x = 0, y = 0; };
 struct KeyPoint { Point2f pt; float size = 31, angle = 0, response = 0; int octave = 0, class_id = -1; };
@@ -48,6 +50,7 @@ struct Mat {                       // N x 32 CV_8U
   Mat row(int r) const { Mat o(1); std::memcpy(o.d.data(), ptr(r), 32); return o; }
 };
 typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
+typedef std::map<unsigned int, double> BowVector;
 
 enum { FRAME_GRID_COLS = 64, FRAME_GRID_ROWS = 48 };
 struct KeyFrame; struct Frame; struct Map;
@@ -62,6 +65,8 @@ struct MapPoint {
   float track_proj_x_ = 0, track_proj_y_ = 0, track_proj_x_r_ = 0, track_view_cos_ = 0; bool is_track_in_view_ = false; int track_scale_level_ = 0;
   unsigned long n_BA_local_for_keyframe_ = ~0ul, n_BA_global_for_keyframe_ = 0; Vector3d global_BA_pose_;
   int n_update_normal_calls_ = 0;
+  unsigned long corrected_by_keyframe_ = ~0ul, corrected_reference_ = 0; KeyFrame* reference_keyframe_ = nullptr;     // loop closing (src/LoopClosing.cc:470-472)
+  KeyFrame* GetReferenceKeyFrame() { return reference_keyframe_; }
   static std::mutex global_mutex_;
 
   Vector3d GetWorldPos() { return world_pose_; } void SetWorldPos(const Vector3d& p) { world_pose_ = p; }
@@ -89,7 +94,7 @@ struct GridOwner {                 // the members Frame and KeyFrame share
   std::vector<KeyPoint> keypoints_, undistort_keypoints_; Mat descriptors_;
   std::vector<MapPoint*> map_points_;
   std::vector<MapPoint*> true_owner_;           // (test only) the map point every feature was generated from, nullptr for noise
-  FeatureVector feature_vector_;
+  FeatureVector feature_vector_; BowVector bow_vector_;
   int n_scale_levels_ = 8; float scale_factor_ = 1.2f, log_scale_factor_ = std::log(1.2f);
   std::vector<float> scale_factors_, level_sigma2s_, inv_level_sigma2s_;
   std::vector<size_t> grid_[FRAME_GRID_COLS][FRAME_GRID_ROWS];
@@ -146,7 +151,20 @@ struct KeyFrame : GridOwner {
   float fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0; int min_x_ = 0, min_y_ = 0, max_x_ = 0, max_y_ = 0;
   Matrix4d Tcw_; Vector3d Ow_; bool is_bad_ = false;
   unsigned long n_BA_local_for_keyframe_ = ~0ul, n_BA_fixed_for_keyframe_ = ~0ul, n_BA_global_for_keyframe_ = 0; Matrix4d global_BA_Tcw_;
-  std::vector<KeyFrame*> ordered_connected_keyframes_;
+  std::vector<KeyFrame*> ordered_connected_keyframes_; std::vector<int> ordered_weights_; std::map<KeyFrame*, int> connected_keyframe_weights_;
+  KeyFrame* parent_ = nullptr; std::set<KeyFrame*> children_, loop_edges_;                     // spanning tree and loop edges (include/KeyFrame.h)
+  KeyFrame* GetParent() { return parent_; } bool hasChild(KeyFrame* kf) { return children_.count(kf) != 0; }
+  std::set<KeyFrame*> GetLoopEdges() { return loop_edges_; }
+  int GetWeight(KeyFrame* kf) { auto it = connected_keyframe_weights_.find(kf); return it == connected_keyframe_weights_.end() ? 0 : it->second; }
+  std::vector<KeyFrame*> GetCovisiblesByWeight(const int& w) {                                 // src/KeyFrame.cc:218-235 (weights descending)
+    size_t n = 0; while (n < ordered_weights_.size() && ordered_weights_[n] >= w) n++;
+    if (ordered_connected_keyframes_.empty() || n == ordered_weights_.size()) return std::vector<KeyFrame*>();
+    return std::vector<KeyFrame*>(ordered_connected_keyframes_.begin(), ordered_connected_keyframes_.begin() + n);
+  }
+  std::vector<KeyFrame*> GetBestCovisibilityKeyFrames(const int& N) {
+    if ((int)ordered_connected_keyframes_.size() < N) return ordered_connected_keyframes_;
+    return std::vector<KeyFrame*>(ordered_connected_keyframes_.begin(), ordered_connected_keyframes_.begin() + N);
+  }
   int n_set_pose_calls_ = 0;
   void SetPose(const Matrix4d& T) {
     Tcw_ = T; n_set_pose_calls_++;
@@ -169,6 +187,14 @@ struct KeyFrame : GridOwner {
   bool isBad() { return is_bad_; }
   bool IsInImage(const float& x, const float& y) const { return (x >= min_x_ && x < max_x_ && y >= min_y_ && y < max_y_); }
   std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r) const { return features_in_area(x, y, r, -1, -1); }   // src/KeyFrame.cc:575-622
+  float ComputeSceneMedianDepth(const int q) {                                                  // src/KeyFrame.cc:624-655
+    std::vector<float> depths;
+    const double zc = Tcw_(2, 3);
+    for (int i = 0; i < N_; i++) if (map_points_[i]) { const Vector3d X = map_points_[i]->GetWorldPos(); depths.push_back((float)(Tcw_(2, 0) * X[0] + Tcw_(2, 1) * X[1] + Tcw_(2, 2) * X[2] + zc)); }
+    if (depths.empty()) return -1.0f;
+    std::sort(depths.begin(), depths.end());
+    return depths[(depths.size() - 1) / q];
+  }
 };
 
 inline void MapPoint::Replace(MapPoint* pMP) {                // src/MapPoint.cc:185-222 (visible / found counters omitted)
@@ -187,12 +213,15 @@ struct Map {
   std::vector<KeyFrame*> keyframes_; std::vector<MapPoint*> map_points_;
   std::vector<KeyFrame*> GetAllKeyFrames() { return keyframes_; }
   std::vector<MapPoint*> GetAllMapPoints() { return map_points_; }
+  long unsigned int GetMaxKFid() { long unsigned int m = 0; for (KeyFrame* k : keyframes_) m = std::max<long unsigned int>(m, k->id_); return m; }
+  void AddMapPoint(MapPoint* p) { map_points_.push_back(p); }
 };
 
 struct Types {
   typedef mock::Frame Frame; typedef mock::KeyFrame KeyFrame; typedef mock::MapPoint MapPoint; typedef mock::Map Map;
   typedef mock::Matrix3d Matrix3d; typedef mock::Matrix4d Matrix4d; typedef mock::Vector2d Vector2d; typedef mock::Vector3d Vector3d;
   typedef mock::Quaterniond Quaterniond; typedef mock::Mat Mat; typedef mock::Point2f Point2f;
+  typedef mock::Sim3d Sim3; typedef std::map<mock::KeyFrame*, mock::Sim3d> KeyFrameAndSim3;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- scene
@@ -286,7 +315,21 @@ inline void build_scene(Scene& S, unsigned seed, int n_kf = 6, int n_mp = 1500, 
     fill_owner(kf, kf.Tcw_, 0.75, 250, &kf);
     S.map.keyframes_.push_back(&kf);
   }
-  for (int k = 0; k < n_kf; k++) for (int j = 0; j < n_kf; j++) if (j != k && std::abs(j - k) <= 3) S.kfs[k].ordered_connected_keyframes_.push_back(&S.kfs[j]);
+  // covisibility (KeyFrame::UpdateConnections, src/KeyFrame.cc:293-377): weight = shared map points; the window is kept at
+  // |j - k| <= 3 so that local BA sees fixed keyframes in a six-keyframe scene; neighbours ordered by weight, descending
+  for (int k = 0; k < n_kf; k++) {
+    std::vector<std::pair<int, int> > wj;
+    for (int j = 0; j < n_kf; j++) {
+      if (j == k || std::abs(j - k) > 3) continue;
+      int w = 0;
+      for (MapPoint* p : S.kfs[k].map_points_) if (p && p->IsInKeyFrame(&S.kfs[j])) w++;
+      wj.push_back(std::make_pair(w, j));
+    }
+    std::stable_sort(wj.begin(), wj.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+    for (auto& e : wj) { S.kfs[k].ordered_connected_keyframes_.push_back(&S.kfs[e.second]); S.kfs[k].ordered_weights_.push_back(e.first); S.kfs[k].connected_keyframe_weights_[&S.kfs[e.second]] = e.first; }
+    if (k > 0) { S.kfs[k].parent_ = &S.kfs[k - 1]; S.kfs[k - 1].children_.insert(&S.kfs[k]); }      // spanning tree: a chain
+  }
+  for (MapPoint& mp : S.mps) if (!mp.observations_.empty()) mp.reference_keyframe_ = mp.observations_.begin()->first;
   for (MapPoint& mp : S.mps) if (mp.n_observations_ > 0) S.map.map_points_.push_back(&mp);
   for (int f = 0; f < n_frames; f++) {
     Frame& F = S.frames[f];

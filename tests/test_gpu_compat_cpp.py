@@ -103,20 +103,30 @@ def test_cpp_shims_vs_oracle(oracle, tmp_path):
 
 
 def test_reference_signature_dropin_classes(oracle, tmp_path):
-    """(b) boundary: csrc/compat/orbslam_dropin.h - ORBmatcher's twelve methods (include/ORBmatcher.h:43-97) and
-    CeresOptimizer::{PoseOptimization, GlobalBundleAdjustemnt / BundleAdjustment, LocalBundleAdjustment}
-    (include/CeresOptimizer.h:351-376) with the reference's own signatures, instantiated over mock structs that copy the member
-    names of Frame.h / KeyFrame.h / MapPoint.h / Map.h.  tests/cpp/test_dropin.cpp writes every call as the reference's call
-    site writes it, runs it through the HIP library and compares the resulting map state with a literal CPU restatement of the
-    same entry point (tests/cpp/reference_literal.h, CPU oracle underneath)."""
+    """(b) boundary: csrc/compat/orbslam_dropin.h - ORBmatcher's twelve methods (include/ORBmatcher.h:43-97), every static of
+    CeresOptimizer (include/CeresOptimizer.h:351-388: PoseOptimization, GlobalBundleAdjustemnt / BundleAdjustment,
+    LocalBundleAdjustment, OptimizeSim3, OptimizeEssentialGraph) and the Frame-side member bodies (ComputeBoW, isInFrustum,
+    GetFeaturesInArea, the per-match body of CreateNewMapPoints) with the reference's own signatures, instantiated over mock
+    structs that copy the member names of Frame.h / KeyFrame.h / MapPoint.h / Map.h.  tests/cpp/test_dropin.cpp writes every
+    call as the reference's call site writes it and runs it through the HIP library, dumping the whole map state before and
+    after; tests/dropin_checker.py replays each entry point on the "before" state - an independent Python restatement of the
+    reference's semantics over the CPU oracle's flat solves - and the complete "after" state must agree."""
     from ceres_mono_orb_slam2_amd import _lib
-    from oracle import pyoracle
+    from tests import dropin_checker
     exe = tmp_path / "test_dropin"
-    oso = pyoracle.build()
+    out = tmp_path / "cases"
+    out.mkdir()
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
-                           os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", str(exe), _lib.LIB_PATH, oso, "-lpthread",
-                           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath," + os.path.dirname(oso), "-Wl,-rpath,/opt/rocm/lib"])
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+                           os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", str(exe), _lib.LIB_PATH, "-lpthread",
+                           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe), str(out)], capture_output=True, text=True, timeout=600)
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " 0 failed" in r.stdout
+    cases = sorted(os.listdir(out))
+    assert len(cases) == 23, cases
+    failures = []
+    for c in cases:
+        fails, info = dropin_checker.check_case(str(out / c), oracle)
+        print("%-34s %s%s" % (c[:-4], info, "" if not fails else "   FAIL"))
+        failures += ["%s: %s" % (c[:-4], f) for f in fails]
+    assert not failures, "\n".join(failures[:40])
