@@ -547,6 +547,8 @@ struct BaDev {            // device pointers of one problem
   double* t3;                        // [nobs][3] E_i^T y_cam of the landmark back-substitution
   double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
   double* Dinv;                      // inverse of every 32x32 diagonal Cholesky block [npad/32][32][32]
+  double* Mb;                        // persistent Cholesky: M_k = X_k P_k of every step [npad/32][32][32]
+  int* cflags;                       // persistent Cholesky: hand-off flags of this problem [CP_NFLAGS], zeroed by k_ba_iter_begin
   const int* blk_a; const int* blk_b; const int* blk_off; const int* pair_i; const int* pair_j; int nblk;   // Schur block pair lists
   const int* free_cams;              // [nfc] reduced column -> camera index
   double* part;                      // partial sums: [3][nparts]
@@ -726,6 +728,7 @@ __global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
   const double radius = st->radius;
   if (F.done) return;
   st->valid = 0; st->accepted = 0; st->chol_fail = 0;
+  if (D.cflags) for (int i = 0; i < 256 /* CP_NFLAGS */; i++) D.cflags[i] = 0;
   // StopFlagCallback (include/CeresOptimizer.h:332-349) runs after every iteration, before the iteration-cap test: the
   // host keeps copying the caller's flag into this pinned byte while the enqueued iterations drain
   if (D.stop_dev && __atomic_load_n(D.stop_dev, __ATOMIC_RELAXED)) { st->termination = 4; st->done = 1; return; }
@@ -1454,6 +1457,350 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
     }
   }
   CHOL_STAMP(6);                                              // L11^-1 store
+}
+
+// ---- persistent look-ahead Cholesky: ONE launch for the whole factorisation of a reduced system <= 1024 -------------------
+// k_chol_la is one launch per 32-column step, and a step's kernel spends 2.5 of its 10.8 us waiting for its first loads and
+// ~1 us outside the kernel (profiles/r02_chol_phase_prof_fused.json): the chain of 19 (C4) steps is launch- and
+// load-latency on top of the 5.1 us diagonal factor.  Here the steps are iterations of a loop inside ONE kernel and the
+// dependencies between workgroups are flags in global memory (tools/ubench/flag_hop.hip: a flag + 8 KB hand-off between two
+// workgroups costs 1.1 - 1.4 us with agent-scope (sc1) data accesses, 2.7 - 3.6 us with __threadfence on both sides, so every
+// access to data another workgroup wrote or will read is an agent-scope relaxed atomic and no fence is used):
+//   workgroup 0, the CHAIN: all diagonal blocks and the sub-diagonal tile of every step.  Per step k: wave 0 factors and
+//     inverts D_k; meanwhile waves 1..3 wait for row k+1 to be final and stage its three tiles; then M_k = X_k P_k,
+//     L(k+1,k) = A(k+1,k) X_k^T - L(k+1,k-1) M_k^T, D_(k+1) = A(k+1,k+1) - L(k+1,k) L(k+1,k)^T in LDS - the chain never waits
+//     for a kernel boundary or for its own stores - and X_k, M_k, L(k+1,k) are published (flag XREADY = k + 1);
+//   ROW i (2 <= i < nb), its PRODUCER: for j = 0 .. i - 2: waits for X_j / M_j, L(i,j) = A(i,j) X_j^T - L(i,j-1) M_j^T, flag
+//     LREADY[i] = j + 1; in its last step also the row's diagonal tile, flag FINAL[i];
+//   ROW i, its ceil((i-1)/8) CONSUMERS: update j of their tiles (i, c), c = j + 2 .. i, with L(i,j) and L(c,j) of the rows above:
+//     all flags of the step, then all loads of the step, then the MFMAs; flag PROG[i][share] = j + 1;
+//   the last workgroup, the augmented rhs ROW: the same with one row, to the last block (forward substitution).
+// The ARITHMETIC is k_chol_la's, operation for operation (tile (i,c) receives the updates 0 .. c-2 one by one as cpre - acc of
+// eight MFMA k-steps, the last one algebraically through M; the rhs row's updates are the same sequential mul / add), so the
+// results are bit-identical to the launch-per-step kernels (tests/test_gpu_ba.py::test_persistent_cholesky_is_bit_identical)
+// and batched solves (k_chol_la<4>, throughput-bound) stay bit-identical to single calls.
+// No deadlock: a workgroup only waits for workgroups with a smaller blockIdx.x of its own problem, which are dispatched
+// first; every wait is bounded (CP_SPIN_CAP polls) and a timeout or a failed pivot raises FAIL, which ends every wait.
+#define CP_XREADY 0
+#define CP_FAIL 1
+#define CP_LREADY 2
+#define CP_FINAL 40
+#define CP_PROG 80                 // [CP_PROG + 4 * row + share]: steps this share of the row has completed
+#define CP_NFLAGS 256
+#define CP_CH 8                    // tiles a row workgroup updates per step (their operands wait in registers together)
+#define CP_SPIN_CAP (1 << 21)
+#define CP_LDS_DOUBLES ((1 + CP_CH) * NB * (NB + 1))      /* a consumer: L(i,j) + CP_CH operand tiles; the chain: 6 tiles + the factor's column buffer */
+__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool cp_wait(const int* flags, int which, int v) {
+  for (int it = 0; it < CP_SPIN_CAP; it++) {
+    if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return true;
+    if ((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+__device__ __forceinline__ void cp_set(int* flags, int which, int v) { __hip_atomic_store(flags + which, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.y];
+  if (!D.chol_la) return;
+  BaState* st = D.st;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid || F.chol_fail) return;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const int np = D.npad, nb = np / NB, tid = threadIdx.x, bx = (int)blockIdx.x;
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ti = w >> 1, tj = w & 1;
+  double* S = D.S;
+  double* Dinv = D.Dinv;
+  double* Mb = D.Mb;
+  int* flags = D.cflags;
+  if (bx == 0) {
+    // ------------------------------------------------------------------------------------------------ the chain
+    double (*s_L)[NB + 1] = (double (*)[NB + 1])s_dyn;
+    double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
+    double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
+    double (*s_M)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
+    double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
+    double (*s_Lp)[NB + 1] = (double (*)[NB + 1])(s_dyn + 5 * NB * (NB + 1));
+    double (*s_T)[64] = (double (*)[64])(s_dyn + 6 * NB * (NB + 1));         // 16-byte aligned: 6 * 32 * 33 * 8 bytes
+    __shared__ int s_fail, s_arrive;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(size_t)r * np + c] : 0.0; }
+    if (tid == 0) { s_fail = 0; s_arrive = 0; }
+    // waves 1..3 own the lower 16x16 tiles of the NEXT diagonal block: (0,0), (1,0), (1,1)
+    const int di = (w == 1) ? 0 : 1, dj = (w == 3) ? 1 : 0;
+    __syncthreads();
+    for (int k = 0; k < nb; k++) {
+      const bool upd = k > 0, next = k + 1 < nb;
+      CHOL_PROF_BEGIN(k);
+      double c2[4] = {0.0, 0.0, 0.0, 0.0};
+      if (tid < 64) {
+        const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
+        if (fail && tid == 0) s_fail = 1;
+        CHOL_STAMP(0);                                          // factor + inverse
+      } else if (next) {
+        // stage row k + 1: its tile in column block k (updates 0 .. k-2 applied), L(k+1, k-1), and this wave's entries of its
+        // diagonal tile (updates 0 .. k-1 applied)
+        bool ok = true;
+        if (upd) ok = cp_wait(flags, CP_FINAL + k + 1, 1);
+        if (!ok) s_fail = 2;
+        const size_t rb = (size_t)(k + 1) * NB;
+        for (int i = tid - 64; i < NB * NB; i += 192) {
+          const int r = i / NB, c = i % NB;
+          s_A1[r][c] = ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]);
+          s_Lp[r][c] = upd ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
+          c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
+        }
+      }
+      __syncthreads();
+      CHOL_STAMP(1);                                            // barrier: what the staging waves are late by
+      if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (upd) {                                                // M = X P, one 16x16 tile per wave (k_chol_la's order)
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_X[16 * ti + li][4 * ks + lk], s_P[4 * ks + lk][16 * tj + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
+          s_M[r][c] = acc[rg];
+          st_sc1(&Mb[(size_t)k * NB * NB + r * NB + c], acc[rg]);
+        }
+      }
+      {
+        double* Di = Dinv + (size_t)k * NB * NB;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; st_sc1(&Di[i], s_X[i / NB][i % NB]); }
+      }
+      __syncthreads();
+      CHOL_STAMP(2);                                            // M = X P, stores of X and M
+      if (next) {
+        // L(k+1, k) = [A | -Lprev] [X | M]^T on the matrix cores: the new P
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_A1[16 * ti + li][4 * ks + lk], s_X[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
+        if (upd) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-s_Lp[16 * ti + li][4 * ks + lk], s_M[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
+        }
+        const size_t rb = (size_t)(k + 1) * NB;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
+        // X_k and M_k have left (their stores were issued before the MFMAs above): the last wave to see that publishes them -
+        // the row producers start on step k a microsecond before the chain is through with it
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_XREADY, k + 1);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
+        __syncthreads();
+        CHOL_STAMP(3);                                          // L(k+1, k)
+        if (w >= 1) {                                           // D_(k+1) = A(k+1,k+1) - P P^T on the lower tiles
+          double4_t a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * di + li][4 * ks + lk], s_P[16 * dj + li][4 * ks + lk], a2, 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
+            if (c <= r) s_L[r][c] = c2[rg] - a2[rg];
+          }
+        }
+      }
+      CHOL_STAMP(4);                                            // D update
+      if (!next) {                                              // the last step: X and M are published here
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
+      }
+      __syncthreads();
+      CHOL_STAMP(5);                                            // barrier
+    }
+    return;
+  }
+  // -------------------------------------------------------------------------------------------------- a row
+  // workgroups behind the chain, row by row (i = 2 .. nb - 1, then the rhs row nb): one PRODUCER - L(i, j) for every step - and
+  // W_i = ceil((i - 1) / CP_CH) CONSUMERS - share g applies update j to the tiles (i, c), c % W_i == g, at most CP_CH per step.
+  // Two short pipelines instead of one long step: a row keeps up with the chain when each stage fits a chain step.
+  int irow = -1, share = -1, W = 1;                             // share -1: the producer
+  bool is_rhs = false;
+  {
+    int b = 1;
+    for (int i = 2; i < nb && irow < 0; i++) {
+      const int wi = (i - 1 + CP_CH - 1) / CP_CH;
+      if (bx < b + 1 + wi) { irow = i; share = bx - b - 1; W = wi; }
+      b += 1 + wi;
+    }
+    if (irow < 0) { if (bx == b || bx == b + 1) { irow = nb; is_rhs = true; share = bx - b - 1; } else return; }
+  }
+  const size_t r0 = is_rhs ? (size_t)np : (size_t)irow * NB;
+  double (*s_Lc)[NB + 1] = (double (*)[NB + 1])s_dyn;           // L(i, j) of the current step
+  double (*s_Lq)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));      // L(i, j-1)
+  __shared__ int s_dead;
+  if (tid == 0) s_dead = 0;
+  __syncthreads();
+  if (share < 0) {
+    // ---- producer: L(i, j) = A(i, j) X_j^T - L(i, j-1) M_j^T; in its last step (j = i - 2) also the row's diagonal tile
+    const int jend = is_rhs ? nb : irow - 1;
+    const int arow = 16 * ti + li;                              // this lane's row of the A operand
+    double (*s_A)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
+    double (*s_Xj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
+    double (*s_Mj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
+    for (int j = 0; j < jend; j++) {
+      const bool upd = j > 0, last = !is_rhs && j == jend - 1;
+      bool ok = true;
+      if (j >= 2) ok = cp_wait(flags, CP_PROG + 4 * irow + (j % W), j - 1);                // tile (i, j) has its last update (j - 2): old flags, polled first
+      if (ok && last && j >= 1) ok = cp_wait(flags, CP_PROG + 4 * irow + (irow % W), j);   // the diagonal tile has update j - 1
+      if (ok) ok = cp_wait(flags, CP_XREADY, j + 1);
+      // the three operand tiles arrive as whole rows (256 contiguous bytes per half wave: uncoalesced agent-scope loads in the
+      // MFMA operand layout cost several microseconds per tile) and go through LDS
+      double va[4], vx[4], vm[4], cd[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int idx = tid + 256 * u, r = idx / NB, c = idx % NB;
+        va[u] = (ok && (is_rhs ? r == 0 : true)) ? ld_sc1(&S[(r0 + r) * np + (size_t)j * NB + c]) : 0.0;
+        vx[u] = ok ? ld_sc1(&Dinv[(size_t)j * NB * NB + idx]) : 0.0;
+        vm[u] = (ok && upd) ? ld_sc1(&Mb[(size_t)j * NB * NB + idx]) : 0.0;
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) cd[rg] = (ok && last) ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + r0 + 16 * tj + (lane & 15)]) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u, r = idx / NB, c = idx % NB; s_A[r][c] = va[u]; s_Xj[r][c] = vx[u]; s_Mj[r][c] = vm[u]; }
+      __syncthreads();
+      double a[8], ap[8], b[8], m[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        a[ks] = s_A[arow][4 * ks + lk];
+        b[ks] = s_Xj[16 * tj + li][4 * ks + lk];
+        m[ks] = s_Mj[16 * tj + li][4 * ks + lk];
+        ap[ks] = upd ? -s_Lq[arow][4 * ks + lk] : 0.0;
+      }
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+      if (upd) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[ks], m[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
+        s_Lc[r][c] = acc[rg];
+        if (ok && (is_rhs ? r == 0 : true)) st_sc1(&S[(r0 + r) * np + (size_t)j * NB + c], acc[rg]);
+      }
+      if (!ok) s_dead = 1;
+      if (last) {
+        __syncthreads();
+        double4_t u4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_Lc[16 * ti + li][4 * ks + lk], s_Lc[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = r0 + 16 * tj + (lane & 15);
+          if (ok && col <= row) st_sc1(&S[row * np + col], cd[rg] - u4[rg]);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (tid == 0) { cp_set(flags, CP_LREADY + irow, j + 1); if (last) cp_set(flags, CP_FINAL + irow, 1); }
+      { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
+    }
+    return;
+  }
+  if (!is_rhs) {
+    // ---- consumer: update j of this share's tiles (i, c), c = j + 2 .. i: C = C - L(i,j) L(c,j)^T, one 16x16 tile of every 32x32
+    // tile per wave.  All flags of the step first (one lane per tile), then EVERY load of the step, then the matrix cores.
+    for (int j = 0; j + 3 <= irow; j++) {
+      const int c_first = j + 2 + ((share - (j + 2)) % W + W) % W;         // smallest c >= j + 2 with c % W == share
+      {
+        const int ct = lane < CP_CH ? c_first + lane * W : irow;            // lane CP_CH: this row's own L(i, j)
+        const bool mine = lane <= CP_CH && ct <= irow;
+        bool good = true;
+        for (int it = 0; it < CP_SPIN_CAP; it++) {
+          const bool ready = !mine || __hip_atomic_load(flags + CP_LREADY + ct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= j + 1;
+          if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
+          if (((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) || it == CP_SPIN_CAP - 1) { good = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!good) s_dead = 1;
+      }
+      // operand tiles as whole rows into LDS (see the producer); this lane's C entries directly (64 contiguous bytes per row)
+      double vl[4], vb[CP_CH][4], cpre[CP_CH][4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vl[u] = ld_sc1(&S[(r0 + idx / NB) * np + (size_t)j * NB + idx % NB]); }
+#pragma unroll
+      for (int t = 0; t < CP_CH; t++) {
+        const int c = c_first + t * W;
+        const size_t cb = (size_t)c * NB;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vb[t][u] = (c <= irow) ? ld_sc1(&S[(cb + idx / NB) * np + (size_t)j * NB + idx % NB]) : 0.0; }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) cpre[t][rg] = (c <= irow) ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + cb + 16 * tj + (lane & 15)]) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Lc[idx / NB][idx % NB] = vl[u]; }
+#pragma unroll
+      for (int t = 0; t < CP_CH; t++) {
+        double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + (1 + t) * NB * (NB + 1));
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_B[idx / NB][idx % NB] = vb[t][u]; }
+      }
+      __syncthreads();
+      double la[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) la[ks] = s_Lc[16 * ti + li][4 * ks + lk];
+#pragma unroll
+      for (int t = 0; t < CP_CH; t++) {
+        const int c = c_first + t * W;
+        if (c > irow) break;
+        const size_t cb = (size_t)c * NB;
+        const double (*s_B)[NB + 1] = (const double (*)[NB + 1])(s_dyn + (1 + t) * NB * (NB + 1));
+        double4_t u4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_B[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = cb + 16 * tj + (lane & 15);
+          if (col <= row) st_sc1(&S[row * np + col], cpre[t][rg] - u4[rg]);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (tid == 0) cp_set(flags, CP_PROG + 4 * irow + share, j + 1);
+    }
+    return;
+  }
+  // ---- the rhs row's consumer: z_c -= sum_m L(c, 32 j + m) z_(32 j + m) for the columns from block j + 2 on (sequential mul / add
+  // per column, as k_chol_la's rhs role; the 32 loads of a column are in flight together)
+  double* zrow = S + (size_t)np * np;
+  double* s_z = &s_Lc[0][0];
+  for (int j = 0; j + 2 < nb; j++) {
+    bool ok = cp_wait(flags, CP_LREADY + nb, j + 1);
+    if (tid < NB) s_z[tid] = ok ? ld_sc1(&zrow[(size_t)j * NB + tid]) : 0.0;
+    __syncthreads();
+    for (int cc = (j + 2) * NB + tid; ok && cc < np; cc += 256) {
+      if (!cp_wait(flags, CP_LREADY + cc / NB, j + 1)) { ok = false; break; }
+      const double* L = S + (size_t)cc * np + (size_t)j * NB;
+      double lv[NB];
+#pragma unroll
+      for (int mm = 0; mm < NB; mm++) lv[mm] = ld_sc1(&L[mm]);
+      const double z0 = ld_sc1(&zrow[cc]);
+      double sum = 0.0;
+#pragma unroll
+      for (int mm = 0; mm < NB; mm++) sum += lv[mm] * s_z[mm];
+      st_sc1(&zrow[cc], z0 - sum);
+    }
+    if (!ok) s_dead = 1;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    if (tid == 0) cp_set(flags, CP_PROG + 4 * nb, j + 1);
+  }
 }
 
 // backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
@@ -2305,6 +2652,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.erase = in.cam_local ? H.alloc<unsigned char>(std::max(nobs, 1), &rc) : nullptr;
   D.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
   D.Dinv = H.alloc<double>((size_t)npad * NB, &rc);
+  D.Mb = H.alloc<double>((size_t)npad * NB, &rc); D.cflags = H.alloc<int>(256 /* CP_NFLAGS */, &rc);
   D.part = H.alloc<double>(5 * (size_t)nparts, &rc);
   D.st = H.alloc<BaState>(1, &rc);
   if (rc) return rc;
@@ -2432,6 +2780,16 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     };
     const CholWide no_wide = {0, 0, 0, 1, 0, 0, 0, 0};
     // look-ahead scheme (reduced systems <= 1024): one launch per 32-column step, panel + the previous step's update
+    // (fewer than four problems: the whole factorisation as ONE persistent launch, bit-identical to the steps; ORBHIP_BA_PERSIST=0 disables)
+    static const bool use_persist = []() { const char* e = std::getenv("ORBHIP_BA_PERSIST"); return !(e && e[0] == '0'); }();
+    if (use_persist && ny < 4 && B.g_npad_la > 0 && B.g_npad_la <= 1024) {            // (<= 32 block rows: the flag arrays; ORBHIP_BA_LA_MAX can push larger systems onto the look-ahead steps)
+      const int nbm = B.g_npad_la / NB;
+      static const hipError_t lds_ok = hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
+      (void)lds_ok;
+      int nwg = 3;                                            // the chain, producer + consumers of the rows 2 .. nb - 1, the rhs row's two
+      for (int i = 2; i < nbm; i++) nwg += 1 + (i - 1 + CP_CH - 1) / CP_CH;
+      hipLaunchKernelGGL(k_chol_persist, dim3(nwg, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv);
+    } else
     for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) launch_la(npl, k, 0, INT_MAX, 0, no_wide);
     // two-level scheme (outer block = 4 panels of NB = 32) for the larger systems.
     static const int OB = []() { const char* e = std::getenv("ORBHIP_BA_OB"); const int v = e ? atoi(e) : 128; return (v >= 64 && v <= 1024 && v % 32 == 0) ? v : 128; }();

@@ -312,6 +312,44 @@ def test_two_level_and_lookahead_factorisations_agree(oracle):
             assert _close(pp, oposes, RTOL_X), name
 
 
+_PERSIST_SCRIPT = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+from ceres_mono_orb_slam2_amd import synth, optimizer
+out = []
+for seed, ncam, npts, nobs, fixed in ((5, 30, 600, 3000, 2), (6, 100, 2000, 9000, 2), (7, 12, 150, 700, 1), (8, 171, 1500, 9000, 1), (9, 7, 60, 300, 2)):
+    g = synth.make_ba_graph(seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=fixed)
+    n = len(g["obs_cam"]); w = g["obs_inv_sigma2"].astype(np.float64); rb = np.ones(n, np.uint8)
+    poses, pts, s = optimizer.bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, rb, 6)
+    out.append({"poses": poses.tobytes().hex(), "pts": pts.tobytes().hex(), "summary": s})
+g = synth.make_ba_graph(11, ncam=40, npts=900, nobs=4500, n_fixed=1)
+a = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(40, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+ab, poses, pts, erase, s1, s2 = optimizer.local_bundle_adjustment(*a)
+out.append({"poses": poses.tobytes().hex(), "pts": pts.tobytes().hex(), "summary": s2, "erase": erase.tobytes().hex()})
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_persistent_cholesky_is_bit_identical():
+    """Reduced systems <= 1024 unknowns of fewer than four problems per call are factored by ONE persistent launch
+    (k_chol_persist: chain workgroup + one workgroup per block row, flags in global memory) instead of one k_chol_la launch
+    per 32-column step.  Its arithmetic is the step kernels' operation for operation, so poses, points, summaries and erase
+    flags must be BIT-IDENTICAL between ORBHIP_BA_PERSIST=1 and =0 (read once per process: two subprocesses) - sizes from 1 to
+    32 block rows (42 .. 1020 unknowns), incl. one that is exactly the 1024 limit, and a two-pass LocalBA."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root], env=dict(os.environ, ORBHIP_BA_PERSIST=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
+    assert len(res[0]) == 6
+    for a, b in zip(*res):
+        assert a["summary"] == b["summary"]
+        assert a["summary"]["iterations"] >= 2
+        assert a["poses"] == b["poses"] and a["pts"] == b["pts"] and a.get("erase") == b.get("erase")
+
+
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_degenerate_graphs_vs_oracle(oracle, seed):
     """Structural degeneracies (single-observation cameras, duplicated observations, zero weights, points seen once, gross
