@@ -1,0 +1,431 @@
+// ============================================================================
+// orb_track.hip -- the per-frame Tracking step with the motion model, device-resident from the image to the optimised pose
+// (reference src/Tracking.cc:616-646: Frame construction - ORBextractor::operator(), AssignFeaturesToGrid -, then
+// ORBmatcher::SearchByProjection(current_frame_, last_frame_, th) src/ORBmatcher.cc:1161-1271 and
+// CeresOptimizer::PoseOptimization src/CeresOptimizer.cc:275-342).
+//
+// The separate entry points cost a host round trip each (orbx_extract 0.19 ms, orbm_search_by_projection 0.21 ms,
+// ba_pose_optimization 0.14 ms, profiles/r02_api_latency.json) because every one uploads its inputs, synchronises and downloads.
+// Here the frame's records never leave the device between the stages:
+//   upload   the image, and ONE packed block with the predicted pose and the last frame's map-point arrays
+//   kernels  extractor (orb_extractor.hip, on this call's stream) -> k_trk_prepare: projection of the last frame's points with
+//            the reference's float / double mix, the current frame's {x, y, octave, angle} records and its 64 x 48 grid in the
+//            reference's push_back order (one workgroup, the keypoint COUNT is read on the device) -> window candidates
+//            (orb_frame.hip k_area) -> k_trk_dist -> k_trk_greedy: the reference's sequential, order-dependent pass as a
+//            parallel fixpoint (below), rotation histogram, slot ownership, the observation list of PoseOptimization in feature
+//            order -> k_pose_lm (ba_solver.hip)
+//   download ONE block: keypoints, descriptors, matches, slot owners, outlier flags, pose, counters.
+//
+// The greedy pass on the device.  The reference walks the last frame's features in index order; query q takes the closest
+// candidate that no EARLIER query with an observed map point has claimed (first minimum in candidate order), and claims it
+// unless its own map point has no observations.  That is a serial dictatorship, evaluated here in rounds: every unsettled query
+// proposes its best still-available candidate.  A claimer can be settled with its proposal when it is the first to want it AND
+// no earlier claimer that stays unsettled has that target anywhere on its list (such a one could fall back to it later); the
+// set of claimers that stay unsettled is found from the losers outwards (they sign every target they could still take, a
+// winner whose target carries an earlier signature joins them, until nothing changes).  The earliest unsettled claimer is
+// always settled, so the loop ends; 3 - 6 rounds on dense frames (signing ALL candidates of ALL unsettled claimers instead
+// needed 15 - 25).  Availability is "claimed by a settled query with a SMALLER index": the result is the sequential one exactly.
+// ============================================================================
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/orbslam_hip.h"
+#include "common.h"
+#include "orb_frame.h"
+
+namespace orbhip {
+
+#define TRK_TH_HIGH 100
+#define TRK_HISTO 30
+#define TRK_MAXKP 4096                                       // keypoints per frame the single-workgroup kernels hold in LDS
+#define TRK_NCELL (FRAME_GRID_COLS * FRAME_GRID_ROWS)
+
+struct TrkIn {                                               // the packed constant part of the upload
+  double R[9], t[3];                                         // predicted Tcw (velocity * last pose)
+  double pose7[7];                                           // the same as [t, q] for the pose optimisation
+  float K4[4], bounds[4], th;
+  float scale[16], inv_sigma2[16];
+  int nq, check_ori, nlevels, pad;
+};
+
+// ---- one workgroup: queries, the frame's float records, its grid ------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_trk_prepare(const TrkIn* __restrict__ in, const double* __restrict__ last_Xw,
+                                                      const int32_t* __restrict__ last_octave, const uint8_t* __restrict__ last_valid,
+                                                      const orbx_keypoint* __restrict__ kps, const int32_t* __restrict__ d_count, int cap,
+                                                      float* __restrict__ q_uv, float* __restrict__ q_radius, int32_t* __restrict__ q_lo,
+                                                      int32_t* __restrict__ q_hi, uint8_t* __restrict__ q_valid, float* __restrict__ kps4,
+                                                      uint32_t* __restrict__ cell_off, uint32_t* __restrict__ cell_idx) {
+  __shared__ int s_cnt[TRK_NCELL];
+  __shared__ int s_off[TRK_NCELL + 1];
+  __shared__ unsigned short s_cell[TRK_MAXKP];
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x;
+  const TrkIn I = *in;
+  const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
+  // projection of the last frame's map points (src/ORBmatcher.cc:1185-1212): double camera coordinates, float from there on
+  for (int i = tid; i < I.nq; i += 1024) {
+    uint8_t v = last_valid[i];
+    float u = 0.f, vv = 0.f, rad = 0.f; int oc = 0;
+    if (v) {
+      const double X = last_Xw[3 * i], Y = last_Xw[3 * i + 1], Z = last_Xw[3 * i + 2];
+      const double cx3 = (I.R[0] * X + I.R[1] * Y + I.R[2] * Z) + I.t[0], cy3 = (I.R[3] * X + I.R[4] * Y + I.R[5] * Z) + I.t[1],
+                   cz3 = (I.R[6] * X + I.R[7] * Y + I.R[8] * Z) + I.t[2];
+      const float xc = (float)cx3, yc = (float)cy3;
+      const float invzc = (float)(1.0 / cz3);
+      if (invzc < 0) v = 0;
+      u = I.K4[0] * xc * invzc + I.K4[2];
+      vv = I.K4[1] * yc * invzc + I.K4[3];
+      if (u < I.bounds[0] || u > I.bounds[1] || vv < I.bounds[2] || vv > I.bounds[3]) v = 0;
+      oc = last_octave[i];
+      if (oc < 0 || oc >= I.nlevels) v = 0; else rad = I.th * I.scale[oc];
+    }
+    q_uv[2 * i] = u; q_uv[2 * i + 1] = vv; q_radius[i] = rad; q_lo[i] = oc - 1; q_hi[i] = oc + 1; q_valid[i] = v;
+  }
+  // the frame: {x, y, octave, angle} of the (undistorted == raw: zero distortion) keypoints and their grid cells (src/Frame.cc:158-173, :309-320)
+  const float winv = (float)FRAME_GRID_COLS / (I.bounds[1] - I.bounds[0]), hinv = (float)FRAME_GRID_ROWS / (I.bounds[3] - I.bounds[2]);
+  for (int c = tid; c < TRK_NCELL; c += 1024) s_cnt[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const orbx_keypoint k = kps[i];
+    kps4[4 * i] = k.x; kps4[4 * i + 1] = k.y; kps4[4 * i + 2] = (float)k.octave; kps4[4 * i + 3] = k.angle;
+    const int px = (int)roundf((k.x - I.bounds[0]) * winv), py = (int)roundf((k.y - I.bounds[2]) * hinv);
+    unsigned short id = 0xFFFF;
+    if (!(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS)) { id = (unsigned short)(px * FRAME_GRID_ROWS + py); atomicAdd(&s_cnt[id], 1); }
+    s_cell[i] = id;
+  }
+  __syncthreads();
+  // exclusive scan of the 3072 cell counts: three per thread, wave scan, wave totals through LDS
+  {
+    const int c0 = 3 * tid;
+    const int a0 = s_cnt[c0], a1 = s_cnt[c0 + 1], a2 = s_cnt[c0 + 2], mine = a0 + a1 + a2;
+    int inc = mine;
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; k++) base += s_w[k];
+    const int ex = base + inc - mine;
+    s_off[c0] = ex; s_off[c0 + 1] = ex + a0; s_off[c0 + 2] = ex + a0 + a1;
+    if (tid == 1023) s_off[TRK_NCELL] = ex + mine;
+  }
+  __syncthreads();
+  for (int c = tid; c <= TRK_NCELL; c += 1024) cell_off[c] = (uint32_t)s_off[c];
+  for (int c = tid; c < TRK_NCELL; c += 1024) s_cnt[c] = 0;
+  __syncthreads();
+  // fill: slots by atomics, then every (tiny) list sorted by keypoint index = the reference's push_back order
+  for (int i = tid; i < n; i += 1024) {
+    const unsigned short id = s_cell[i];
+    if (id != 0xFFFF) cell_idx[s_off[id] + atomicAdd(&s_cnt[id], 1)] = (uint32_t)i;
+  }
+  __syncthreads();
+  for (int c = tid; c < TRK_NCELL; c += 1024) {
+    const int b = s_off[c], e = s_off[c + 1];
+    for (int i = b + 1; i < e; i++) {
+      const uint32_t v = cell_idx[i];
+      int j = i - 1;
+      while (j >= b && cell_idx[j] > v) { cell_idx[j + 1] = cell_idx[j]; j--; }
+      cell_idx[j + 1] = v;
+    }
+  }
+}
+
+// ---- distances of the window candidates: pairs[k] = {target index (written by k_area), distance} ------------------------
+__global__ __launch_bounds__(256) void k_trk_dist(const uint8_t* __restrict__ q_desc, int nq, const uint8_t* __restrict__ t_desc,
+                                                  const uint32_t* __restrict__ off, uint2* __restrict__ pairs, uint32_t cap) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t total = min(off[nq], cap);
+  if (k >= total) return;
+  int lo = 0, hi = nq;                                       // the query of candidate k: last q with off[q] <= k
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= k) lo = mid; else hi = mid; }
+  const uint4* a = (const uint4*)(q_desc + 32 * (size_t)lo);
+  const uint4* b = (const uint4*)(t_desc + 32 * (size_t)pairs[k].x);
+  const uint4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+  pairs[k].y = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
+               __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+struct TrkOut { int32_t n_keypoints, nmatches, nobs, rounds, cand_total, n_inliers, pad0, pad1; };
+
+// ---- one workgroup: the order-dependent pass, rotation consistency, slot owners, PoseOptimization's observation list ----
+__global__ __launch_bounds__(1024) void k_trk_greedy(const TrkIn* __restrict__ in, const uint8_t* __restrict__ q_valid, const float* __restrict__ q_angle,
+                                                     const double* __restrict__ last_Xw, const uint32_t* __restrict__ off, const uint2* __restrict__ pairs,
+                                                     uint32_t cand_cap, const float* __restrict__ kps4, const int32_t* __restrict__ d_count, int cap,
+                                                     int32_t* __restrict__ match, int32_t* __restrict__ owner, int32_t* __restrict__ obs_feat,
+                                                     double* __restrict__ obs_Xw, double* __restrict__ obs_uv, float* __restrict__ obs_w,
+                                                     int32_t* __restrict__ obs_off, double* __restrict__ pose7, double* __restrict__ K4d, TrkOut* __restrict__ out) {
+  __shared__ int s_taken[TRK_MAXKP];                          // index of the settled claiming query that holds the target (INT_MAX: free)
+  __shared__ int s_mark[TRK_MAXKP];                           // smallest index of an unsettled claimer that could still take the target
+  __shared__ int s_hist[TRK_HISTO], s_keep[TRK_HISTO];
+  __shared__ int s_left, s_nm, s_w[16];
+  const int tid = threadIdx.x;
+  const TrkIn I = *in;
+  const int nq = I.nq;
+  const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
+  const bool overflow = off[nq] > cand_cap;                   // (the caller re-runs with a larger candidate buffer)
+  for (int t = tid; t < TRK_MAXKP; t += 1024) { s_taken[t] = INT_MAX; s_mark[t] = INT_MAX; }
+  if (tid < TRK_HISTO) s_hist[tid] = 0;
+  if (tid == 0) { s_left = 0; s_nm = 0; }
+  // state of the (<= 3 per thread) queries this thread owns: -3 unsettled, -1 settled without a match, >= 0 the matched target
+  int st[4] = {-1, -1, -1, -1};
+  for (int k = 0; k < 4; k++) { const int q = tid + 1024 * k; if (q < nq && q_valid[q] && !overflow) st[k] = -3; }
+  __syncthreads();
+  int rounds = 0;
+  for (; rounds < 4096; rounds++) {
+    // (1) proposals: the best still-available candidate of every unsettled query; claimers sign their PROPOSAL
+    int prop[4] = {-1, -1, -1, -1};
+    bool nonfinal[4] = {false, false, false, false}, pushed[4] = {false, false, false, false};
+    for (int k = 0; k < 4; k++) {
+      const int q = tid + 1024 * k;
+      if (st[k] != -3) continue;
+      int best = 256, bi = -1;
+      for (uint32_t c = off[q]; c < off[q + 1]; c++) {
+        const int t = (int)pairs[c].x, d = (int)pairs[c].y;
+        if (s_taken[t] < q) continue;                         // (:1220-1221: the feature holds a point with observations)
+        if (d < best) { best = d; bi = t; }
+      }
+      if (bi < 0 || best > TRK_TH_HIGH) { st[k] = -1; continue; }           // can only get worse: settled, nothing matched
+      prop[k] = bi;
+      if (q_valid[q] == 1) atomicMin(&s_mark[bi], q);
+    }
+    __syncthreads();
+    // (2) a claimer that is not the first to want its target cannot be settled in this round
+    for (int k = 0; k < 4; k++) {
+      const int q = tid + 1024 * k;
+      if (st[k] == -3 && q_valid[q] == 1 && s_mark[prop[k]] != q) nonfinal[k] = true;
+    }
+    __syncthreads();
+    for (int t = tid; t < TRK_MAXKP; t += 1024) s_mark[t] = INT_MAX;
+    __syncthreads();
+    // (3) the winners that can still lose their target: some EARLIER claimer that stays unsettled has it on its list.  Greatest
+    // fixpoint, from the losers outwards: the unsettled-for-sure claimers sign every target they could still take.
+    for (int inner = 0; inner < 4096; inner++) {
+      for (int k = 0; k < 4; k++) {
+        const int q = tid + 1024 * k;
+        if (st[k] != -3 || !nonfinal[k] || pushed[k]) continue;
+        pushed[k] = true;
+        for (uint32_t c = off[q]; c < off[q + 1]; c++) {
+          const int t = (int)pairs[c].x;
+          if (s_taken[t] >= q && (int)pairs[c].y <= TRK_TH_HIGH) atomicMin(&s_mark[t], q);
+        }
+      }
+      __syncthreads();
+      int changed = 0;
+      for (int k = 0; k < 4; k++) {
+        const int q = tid + 1024 * k;
+        if (st[k] == -3 && q_valid[q] == 1 && !nonfinal[k] && s_mark[prop[k]] < q) { nonfinal[k] = true; changed = 1; }
+      }
+      if (changed) s_left = 1;
+      __syncthreads();
+      const int any = s_left;
+      __syncthreads();
+      if (tid == 0) s_left = 0;
+      if (!any) break;
+    }
+    __syncthreads();
+    // (4) settle: the final claimers take their targets; a query without observations keeps its proposal when no earlier claimer
+    // took it in this round and none that stays unsettled could
+    for (int k = 0; k < 4; k++) {
+      const int q = tid + 1024 * k;
+      if (st[k] == -3 && q_valid[q] == 1 && !nonfinal[k]) { st[k] = prop[k]; s_taken[prop[k]] = q; }
+    }
+    __syncthreads();
+    int mine_left = 0;
+    for (int k = 0; k < 4; k++) {
+      const int q = tid + 1024 * k;
+      if (st[k] != -3) continue;
+      if (q_valid[q] != 1 && s_mark[prop[k]] > q && s_taken[prop[k]] > q) st[k] = prop[k]; else mine_left++;
+    }
+    __syncthreads();
+    for (int t = tid; t < TRK_MAXKP; t += 1024) s_mark[t] = INT_MAX;
+    if (mine_left) atomicAdd(&s_left, mine_left);
+    __syncthreads();
+    const int left = s_left;
+    __syncthreads();
+    if (tid == 0) s_left = 0;
+    if (left == 0) { rounds++; break; }
+  }
+  // rotation consistency (src/ORBmatcher.cc:1235-1264): histogram of the matches, the three fullest bins survive
+  int bin[4] = {-1, -1, -1, -1};
+  for (int k = 0; k < 4; k++) {
+    const int q = tid + 1024 * k;
+    if (q >= nq || st[k] < 0) continue;
+    atomicAdd(&s_nm, 1);
+    if (I.check_ori) {
+      float rot = q_angle[q] - kps4[4 * st[k] + 3];
+      if (rot < 0.0) rot += 360.0f;
+      int b = (int)roundf(rot * (1.0f / TRK_HISTO));
+      if (b == TRK_HISTO) b = 0;
+      bin[k] = b; atomicAdd(&s_hist[b], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int top[3] = {-1, -1, -1}, pop[3] = {0, 0, 0};
+    for (int b = 0; b < TRK_HISTO; b++) {                    // strict '>': the earlier bin wins ties (ComputeThreeMaxima :1386-1418)
+      int r = 3;
+      while (r > 0 && s_hist[b] > pop[r - 1]) r--;
+      if (r == 3) continue;
+      for (int m = 2; m > r; m--) { top[m] = top[m - 1]; pop[m] = pop[m - 1]; }
+      top[r] = b; pop[r] = s_hist[b];
+    }
+    if ((float)pop[1] < 0.1f * (float)pop[0]) { top[1] = -1; top[2] = -1; }
+    else if ((float)pop[2] < 0.1f * (float)pop[0]) { top[2] = -1; }
+    for (int b = 0; b < TRK_HISTO; b++) s_keep[b] = (b == top[0] || b == top[1] || b == top[2]) ? 1 : 0;
+  }
+  // slot owners: the LAST query assigned to a feature holds it (:1232), a removed match empties the slot whoever else shares it (:1260-1264)
+  int* s_owner = s_taken; int* s_dead = s_mark;
+  __syncthreads();
+  for (int t = tid; t < TRK_MAXKP; t += 1024) { s_owner[t] = -1; s_dead[t] = 0; }
+  __syncthreads();
+  for (int k = 0; k < 4; k++) {
+    const int q = tid + 1024 * k;
+    if (q >= nq) continue;
+    int mres = st[k] >= 0 ? st[k] : -1;
+    if (st[k] >= 0) {
+      atomicMax(&s_owner[st[k]], q);
+      if (I.check_ori && !s_keep[bin[k]]) { s_dead[st[k]] = 1; mres = -2 - st[k]; atomicAdd(&s_nm, -1); }
+    }
+    match[q] = mres;
+  }
+  __syncthreads();
+  // PoseOptimization's observations: the features that hold a point, in feature order (src/CeresOptimizer.cc:297-327)
+  int has[4], cntv = 0;
+  for (int k = 0; k < 4; k++) { const int t = 4 * tid + k; has[k] = (t < n && s_owner[t] >= 0 && !s_dead[t]) ? 1 : 0; cntv += has[k]; }
+  int inc = cntv;
+  {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; k++) base += s_w[k];
+    inc += base;
+  }
+  int pos = inc - cntv;
+  for (int k = 0; k < 4; k++) {
+    const int t = 4 * tid + k;
+    if (t < cap) owner[t] = (t < n && s_owner[t] >= 0 && !s_dead[t]) ? s_owner[t] : -1;
+    if (!has[k]) continue;
+    const int q = s_owner[t];
+    obs_feat[pos] = t;
+    obs_Xw[3 * pos] = last_Xw[3 * q]; obs_Xw[3 * pos + 1] = last_Xw[3 * q + 1]; obs_Xw[3 * pos + 2] = last_Xw[3 * q + 2];
+    obs_uv[2 * pos] = (double)kps4[4 * t]; obs_uv[2 * pos + 1] = (double)kps4[4 * t + 1];
+    const int oc = (int)kps4[4 * t + 2];
+    obs_w[pos] = I.inv_sigma2[oc];
+    pos++;
+  }
+  if (tid == 1023) { obs_off[0] = 0; obs_off[1] = inc; out->nobs = inc; }
+  if (tid < 7) pose7[tid] = I.pose7[tid];
+  if (tid < 4) K4d[tid] = (double)I.K4[tid];
+  if (tid == 0) { out->n_keypoints = *d_count; out->nmatches = overflow ? -1 : s_nm; out->rounds = rounds; out->cand_total = (int32_t)off[nq]; }
+}
+
+}  // namespace orbhip
+
+using namespace orbhip;
+
+extern "C" {
+
+int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h, int stride, const float* K4, const float* bounds,
+                                 const double* Tcw_pred, const double* last_Xw, const uint8_t* last_desc, const int32_t* last_octave,
+                                 const float* last_angle, const uint8_t* last_valid, int n_last, float th, int check_ori,
+                                 orbx_keypoint* kps_out, uint8_t* desc_out, int cap, int32_t* match_out, int32_t* owner_out,
+                                 uint8_t* outlier_out, orbt_result* res) {
+  ORBHIP_REQUIRE(ctx && img && w > 0 && h > 0 && stride >= w && K4 && bounds && Tcw_pred && res && kps_out && desc_out && owner_out && outlier_out,
+                 ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(n_last >= 0 && n_last <= 4096 && (n_last == 0 || (last_Xw && last_desc && last_octave && last_angle && last_valid && match_out)), ORBHIP_EINVAL,
+                 "bad last-frame arrays (at most 4096 features)");
+  const int icap = orbx_max_keypoints(ctx);
+  ORBHIP_REQUIRE(cap >= icap && icap <= TRK_MAXKP, ORBHIP_ECAP, "output capacity below orbx_max_keypoints(ctx) (or more than 4096 features per frame)");
+  const int nlevels = orbx_get_levels(ctx);
+  ORBHIP_REQUIRE(nlevels > 0 && nlevels <= 16, ORBHIP_EINVAL, "bad level count");
+  ThreadWs& W = thread_ws();
+  static thread_local uint32_t cand_cap_tl = 0;
+  static thread_local FrameGridDev grid;                       // (off / idx buffers filled by k_trk_prepare)
+  static thread_local int grid_device = -1;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    int rc = W.begin();
+    if (rc) return rc;
+    if (grid_device != W.device) { grid = FrameGridDev(); grid_device = W.device; cand_cap_tl = 0; }
+    const int nq = n_last;
+    const uint32_t cand_cap = std::max<uint32_t>(cand_cap_tl, (uint32_t)std::max(nq, 1) * 64u);
+    TrkIn I; std::memset(&I, 0, sizeof(I));
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) I.R[3 * r + c] = Tcw_pred[4 * r + c]; I.t[r] = Tcw_pred[4 * r + 3]; }
+    { double T[16]; for (int k = 0; k < 12; k++) T[k] = Tcw_pred[k]; T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1; if (int r2 = ba_matrix4d_to_pose7(T, I.pose7)) return r2; }
+    for (int k = 0; k < 4; k++) { I.K4[k] = K4[k]; I.bounds[k] = bounds[k]; }
+    I.th = th; I.nq = nq; I.check_ori = check_ori ? 1 : 0; I.nlevels = nlevels;
+    if (int r2 = orbx_get_tables(ctx, I.scale, nullptr, nullptr, I.inv_sigma2, nullptr)) return r2;
+    // uploads: the image (straight from the caller's memory through pinned staging) and ONE packed block
+    const size_t img_bytes = (size_t)stride * (h - 1) + w;
+    uint8_t* d_img = W.up<uint8_t>(img, img_bytes, &rc);
+    ThreadWs::Pack in;
+    const int pI = in.add(&I, sizeof(I)), pX = in.add(last_Xw, 24 * (size_t)nq), pD = in.add(last_desc, 32 * (size_t)nq), pO = in.add(last_octave, 4 * (size_t)nq),
+              pA = in.add(last_angle, 4 * (size_t)nq), pV = in.add(last_valid, (size_t)nq);
+    if (rc || (rc = W.commit(in))) return rc;
+    // ONE output block: [TrkOut | pose7 | summary | count | kps | desc | match | owner | obs_feat | outlier]
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+    const size_t oOut = take(sizeof(TrkOut)), oPose = take(56), oSum = take(sizeof(ba_summary)), oCnt = take(4), oNin = take(4), oKps = take((size_t)icap * sizeof(orbx_keypoint)),
+                 oDesc = take((size_t)icap * 32), oMatch = take(4 * (size_t)std::max(nq, 1)), oOwner = take(4 * (size_t)icap), oFeat = take(4 * (size_t)icap),
+                 oOutl = take((size_t)icap);
+    uint8_t* dblk = W.d<uint8_t>(o, &rc);
+    float* d_quv = W.d<float>(2 * (size_t)std::max(nq, 1), &rc); float* d_qr = W.d<float>(std::max(nq, 1), &rc);
+    int32_t* d_qlo = W.d<int32_t>(std::max(nq, 1), &rc); int32_t* d_qhi = W.d<int32_t>(std::max(nq, 1), &rc); uint8_t* d_qv = W.d<uint8_t>(std::max(nq, 1), &rc);
+    float* d_kps4 = W.d<float>(4 * (size_t)icap, &rc);
+    int* d_cnt = W.d<int>(std::max(nq, 1), &rc); uint32_t* d_off = W.d<uint32_t>((size_t)nq + 2, &rc); uint2* d_pairs = W.d<uint2>(cand_cap, &rc);
+    double* d_oX = W.d<double>(3 * (size_t)icap, &rc); double* d_ouv = W.d<double>(2 * (size_t)icap, &rc); float* d_ow = W.d<float>(icap, &rc);
+    int32_t* d_ooff = W.d<int32_t>(2, &rc); double* d_K4 = W.d<double>(4, &rc);
+    if (rc) return rc;
+    if ((rc = grid.off.ensure((size_t)(TRK_NCELL + 1) * 4)) || (rc = grid.idx.ensure((size_t)icap * 4))) return rc;
+    grid.min_x = bounds[0]; grid.min_y = bounds[2];
+    grid.winv = static_cast<float>(FRAME_GRID_COLS) / (bounds[1] - bounds[0]); grid.hinv = static_cast<float>(FRAME_GRID_ROWS) / (bounds[3] - bounds[2]);
+    orbx_keypoint* d_kps = (orbx_keypoint*)(dblk + oKps); uint8_t* d_desc = dblk + oDesc; int32_t* d_count = (int32_t*)(dblk + oCnt);
+    if ((rc = orbx_extract_batch_device(ctx, d_img, w, h, stride, (long long)stride * h, 1, d_kps, d_desc, icap, d_count, (void*)W.s))) return rc;
+    const TrkIn* dI = in.dev<TrkIn>(pI);
+    hipLaunchKernelGGL(k_trk_prepare, dim3(1), dim3(1024), 0, W.s, dI, in.dev<double>(pX), in.dev<int32_t>(pO), in.dev<uint8_t>(pV), d_kps, d_count, icap, d_quv, d_qr,
+                       d_qlo, d_qhi, d_qv, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>());
+    if (nq > 0) {
+      if ((rc = frame_area_candidates_enqueue(grid, d_kps4, d_quv, d_qr, d_qlo, d_qhi, d_qv, nq, d_cnt, d_off, (uint32_t*)d_pairs, cand_cap, 2, W.s))) return rc;
+      hipLaunchKernelGGL(k_trk_dist, dim3((cand_cap + 255) / 256), dim3(256), 0, W.s, in.dev<uint8_t>(pD), nq, d_desc, d_off, d_pairs, cand_cap);
+    } else {
+      ORBHIP_CHECK_HIP(hipMemsetAsync(d_off, 0, 8, W.s));
+    }
+    hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(1024), 0, W.s, dI, d_qv, in.dev<float>(pA), in.dev<double>(pX), d_off, d_pairs, cand_cap, d_kps4, d_count, icap,
+                       (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow, d_ooff, (double*)(dblk + oPose), d_K4,
+                       (TrkOut*)(dblk + oOut));
+    ORBHIP_CHECK_HIP(hipGetLastError());
+    if ((rc = ba_pose_optimization_batch_device(d_K4, (double*)(dblk + oPose), d_oX, d_ouv, d_ow, d_ooff, 1, dblk + oOutl, (int32_t*)(dblk + oNin),
+                                                (ba_summary*)(dblk + oSum), (void*)W.s))) return rc;
+    const uint8_t* hb = W.down(dblk, o, &rc);
+    if (rc || (rc = W.sync())) return rc;
+    const TrkOut* T = (const TrkOut*)(hb + oOut);
+    if (T->n_keypoints < 0) { set_error("extractor capacity exceeded"); return ORBHIP_EOVERFLOW; }
+    if ((uint32_t)T->cand_total > cand_cap) { cand_cap_tl = (uint32_t)T->cand_total + (uint32_t)T->cand_total / 4; continue; }   // (rare) once more, larger lists
+    cand_cap_tl = std::max<uint32_t>(cand_cap_tl, (uint32_t)T->cand_total + (uint32_t)T->cand_total / 8);
+    const int n = std::min(T->n_keypoints, icap);
+    std::memcpy(kps_out, hb + oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hb + oDesc, (size_t)n * 32);
+    if (nq) std::memcpy(match_out, hb + oMatch, 4 * (size_t)nq);
+    std::memcpy(owner_out, hb + oOwner, 4 * (size_t)n);
+    std::memset(outlier_out, 0, (size_t)n);
+    const int32_t* feat = (const int32_t*)(hb + oFeat);
+    for (int k = 0; k < T->nobs; k++) outlier_out[feat[k]] = hb[oOutl + k];
+    res->n_keypoints = n; res->nmatches = T->nmatches; res->n_correspondences = T->nobs; res->greedy_rounds = T->rounds;
+    std::memcpy(res->pose7, hb + oPose, 56);
+    // PoseOptimization returns 0 and leaves the pose alone with fewer than 3 correspondences (src/CeresOptimizer.cc:330)
+    res->n_inliers = T->nobs < 3 ? 0 : *(const int32_t*)(hb + oNin);
+    if (T->nobs < 3) std::memcpy(res->pose7, I.pose7, 56);
+    return 0;
+  }
+  set_error("window candidate lists did not fit after regrowing");
+  return ORBHIP_ENOMEM;
+}
+
+}  // extern "C"

@@ -284,6 +284,34 @@ int orbm_search_for_triangulation(const float* kps1, const uint8_t* desc1, const
                                   const double* F12, float ex, float ey, const float* scale_factors,
                                   const float* level_sigma2, int check_ori, int32_t* match12, int* nmatches);
 
+/* ---- the per-frame Tracking step with the motion model, device-resident (src/Tracking.cc:616-646): Frame construction
+ * (ORBextractor::operator(), AssignFeaturesToGrid; zero distortion: the undistorted keypoints are the raw ones, as for the
+ * KITTI configurations), ORBmatcher::SearchByProjection(current_frame_, last_frame_, th) (src/ORBmatcher.cc:1161-1271,
+ * monocular) and CeresOptimizer::PoseOptimization (src/CeresOptimizer.cc:275-342) in ONE call: the image and one packed block
+ * go up, the kernels of all three stages run back to back on one stream (the greedy, order-dependent pass of the search as a
+ * parallel fixpoint on the device, csrc/orb_track.hip), one block comes down.
+ *   in   img: CV_8UC1 w x h; K4 = {fx, fy, cx, cy}; bounds = {min_x, max_x, min_y, max_y}; Tcw_pred = current_frame_.Tcw_
+ *        after SetPose(velocity_ * last_frame_.Tcw_), row-major 3x4 (or the first 12 of a 4x4); per last-frame feature i
+ *        (n_last <= 4096): last_Xw = map point position, last_desc = its descriptor (MapPoint::GetDescriptor), last_octave =
+ *        LastFrame.keypoints_[i].octave, last_angle = LastFrame.undistort_keypoints_[i].angle, last_valid = 0 (no map point,
+ *        or is_outliers_[i]), 1 (map point with Observations() > 0) or 3 (without: it is matched but does not close the
+ *        feature for later points, :1220-1221); th = 15 (the caller repeats the call with 2 * th when nmatches < 20,
+ *        src/Tracking.cc:635-641); check_ori = mbCheckOrientation.
+ *   out  kps / desc [cap >= orbx_max_keypoints(ctx)]: the frame's keypoints and descriptors; match[n_last]: index of the
+ *        current feature matched to last-frame feature i, -1 none, -2 - index removed by the rotation check; owner[n_kp]:
+ *        which last-frame feature's map point CurrentFrame.map_points_[f] holds, or -1; outlier[n_kp] = is_outliers_ after
+ *        PoseOptimization; res: counts, the optimised pose [tx, ty, tz, qx, qy, qz, qw] (the predicted one when fewer than
+ *        3 correspondences, as the reference leaves the pose alone then).                                                  */
+typedef struct orbt_result {
+  int32_t n_keypoints, nmatches, n_correspondences, n_inliers, greedy_rounds, reserved;
+  double pose7[7];
+} orbt_result;
+int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h, int stride, const float* K4, const float* bounds,
+                                 const double* Tcw_pred, const double* last_Xw, const uint8_t* last_desc, const int32_t* last_octave,
+                                 const float* last_angle, const uint8_t* last_valid, int n_last, float th, int check_ori,
+                                 orbx_keypoint* kps_out, uint8_t* desc_out, int cap, int32_t* match_out, int32_t* owner_out,
+                                 uint8_t* outlier_out, orbt_result* res);
+
 /* ------------------------------------------------------------ bundle adjust --
  * Replaces CeresOptimizer::{PoseOptimization, BundleAdjustment/GlobalBundleAdjustemnt,
  * LocalBundleAdjustment, CheckOutlier(s)} (src/CeresOptimizer.cc:49-599) and the Ceres solve

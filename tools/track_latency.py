@@ -1,0 +1,26 @@
+"""Per-frame latency of the device-resident Tracking step (orbt_track_with_motion_model) on a 1241 x 376 frame pair.
+Under rocprofv3 --kernel-trace --stats the kernel breakdown of the chain is the by-product."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ceres_mono_orb_slam2_amd import ORBextractor, tracking, synth
+K4 = np.array([718.856, 718.856, 607.1928, 185.2157], np.float32)
+B = np.array([0, 1241, 0, 376], np.float32)
+seq, offs = synth.make_sequence(11, 1241, 376, 2, "blocks", max_shift=6)
+ex = ORBextractor(2000, 1.2, 8, 20, 7)
+k0, d0 = ex(seq[0])
+n = len(k0); depth = 18.0
+X = np.stack([(k0["x"] - K4[2]) / K4[0] * depth, (k0["y"] - K4[3]) / K4[1] * depth, np.full(n, depth)], 1).astype(np.float64)
+sh = (offs[1] - offs[0]).astype(np.float64)
+T = np.eye(4); T[0, 3] = -sh[0] * depth / K4[0] + 0.01; T[1, 3] = -sh[1] * depth / K4[1] - 0.01
+a = (ex, seq[1], K4, B, T, X, d0, k0["octave"].astype(np.int32), k0["angle"].astype(np.float32), np.ones(n, np.uint8), 15.0, True)
+for _ in range(10): r = tracking.track_with_motion_model(*a)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+t0 = time.perf_counter()
+for _ in range(N): r = tracking.track_with_motion_model(*a)
+ms = (time.perf_counter() - t0) / N * 1e3
+t0 = time.perf_counter()
+for _ in range(N): ex(seq[1])
+ms_ex = (time.perf_counter() - t0) / N * 1e3
+print(json.dumps({"tracking_step_ms": round(ms, 4), "orbx_extract_alone_ms": round(ms_ex, 4), "keypoints": len(r["kps"]), "matches": r["nmatches"], "inliers": r["n_inliers"],
+                  "greedy_rounds": r["greedy_rounds"]}))
