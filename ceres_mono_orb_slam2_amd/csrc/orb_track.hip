@@ -23,13 +23,16 @@
 // no earlier claimer that stays unsettled has that target anywhere on its list (such a one could fall back to it later); the
 // set of claimers that stay unsettled is found from the losers outwards (they sign every target they could still take, a
 // winner whose target carries an earlier signature joins them, until nothing changes).  The earliest unsettled claimer is
-// always settled, so the loop ends; 3 - 6 rounds on dense frames (signing ALL candidates of ALL unsettled claimers instead
-// needed 15 - 25).  Availability is "claimed by a settled query with a SMALLER index": the result is the sequential one exactly.
+// always settled, so the loop ends; 4 - 11 rounds on dense 2000-feature frames (signing ALL candidates of ALL unsettled claimers
+// instead needed 15 - 25).  Availability is "claimed by a settled query with a SMALLER index": the result is the sequential one exactly.
 // ============================================================================
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -44,6 +47,9 @@ namespace orbhip {
 #define TRK_HISTO 30
 #define TRK_MAXKP 4096                                       // keypoints per frame the single-workgroup kernels hold in LDS
 #define TRK_NCELL (FRAME_GRID_COLS * FRAME_GRID_ROWS)
+#define TRK_LMAX 16                                          // acceptable candidates per query held in registers
+#define TRK_GT 1024                                          // threads of the greedy workgroup
+#define TRK_QPT (TRK_MAXKP / TRK_GT)                         // queries per thread
 
 struct TrkIn {                                               // the packed constant part of the upload
   double R[9], t[3];                                         // predicted Tcw (velocity * last pose)
@@ -136,125 +142,178 @@ __global__ __launch_bounds__(1024) void k_trk_prepare(const TrkIn* __restrict__ 
   }
 }
 
-// ---- distances of the window candidates: pairs[k] = {target index (written by k_area), distance} ------------------------
+// ---- distances of the window candidates, one WAVE per query: pairs[k] = {target index (written by k_area), distance}, and the
+// query's ACCEPTABLE candidates (distance <= TH_HIGH: the only ones that can ever be chosen or block anybody; a window holds
+// few of them - the true match and the odd look-alike, random descriptors are 128 +- 8 bits apart) compacted in list order:
+// acc[q][r] = target | distance << 16 for the first TRK_LMAX of them, acc_n[q] = how many there are
 __global__ __launch_bounds__(256) void k_trk_dist(const uint8_t* __restrict__ q_desc, int nq, const uint8_t* __restrict__ t_desc,
-                                                  const uint32_t* __restrict__ off, uint2* __restrict__ pairs, uint32_t cap) {
-  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t total = min(off[nq], cap);
-  if (k >= total) return;
-  int lo = 0, hi = nq;                                       // the query of candidate k: last q with off[q] <= k
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= k) lo = mid; else hi = mid; }
-  const uint4* a = (const uint4*)(q_desc + 32 * (size_t)lo);
-  const uint4* b = (const uint4*)(t_desc + 32 * (size_t)pairs[k].x);
-  const uint4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
-  pairs[k].y = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
-               __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+                                                  const uint32_t* __restrict__ off, uint2* __restrict__ pairs, uint32_t cap,
+                                                  uint32_t* __restrict__ acc, int32_t* __restrict__ acc_n) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const uint32_t b = min(off[q], cap), e = min(off[q + 1], cap);
+  const uint4* a = (const uint4*)(q_desc + 32 * (size_t)q);
+  const uint4 a0 = a[0], a1 = a[1];
+  int found = 0;
+  for (uint32_t base = b; base < e; base += 64) {
+    const uint32_t k = base + lane;
+    int d = 256; uint32_t t = 0;
+    if (k < e) {
+      t = pairs[k].x;
+      const uint4* tb = (const uint4*)(t_desc + 32 * (size_t)t);
+      const uint4 b0 = tb[0], b1 = tb[1];
+      d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
+          __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+      pairs[k].y = (uint32_t)d;
+    }
+    const bool ok = k < e && d <= TRK_TH_HIGH;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+    const int r = found + __popcll(m & ((1ull << lane) - 1ull));
+    if (ok && r < TRK_LMAX) acc[(size_t)q * TRK_LMAX + r] = t | ((uint32_t)d << 16);
+    found += __popcll(m);
+  }
+  if (lane == 0) acc_n[q] = found;
 }
 
-struct TrkOut { int32_t n_keypoints, nmatches, nobs, rounds, cand_total, n_inliers, pad0, pad1; };
+struct TrkOut { int32_t n_keypoints, nmatches, nobs, rounds, cand_total, n_inliers, pad0, pad1; int32_t ticks[8]; };
 
 // ---- one workgroup: the order-dependent pass, rotation consistency, slot owners, PoseOptimization's observation list ----
-__global__ __launch_bounds__(1024) void k_trk_greedy(const TrkIn* __restrict__ in, const uint8_t* __restrict__ q_valid, const float* __restrict__ q_angle,
+__global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__ in, const uint8_t* __restrict__ q_valid, const float* __restrict__ q_angle,
+                                                     const uint32_t* __restrict__ acc, const int32_t* __restrict__ acc_n,
                                                      const double* __restrict__ last_Xw, const uint32_t* __restrict__ off, const uint2* __restrict__ pairs,
                                                      uint32_t cand_cap, const float* __restrict__ kps4, const int32_t* __restrict__ d_count, int cap,
                                                      int32_t* __restrict__ match, int32_t* __restrict__ owner, int32_t* __restrict__ obs_feat,
                                                      double* __restrict__ obs_Xw, double* __restrict__ obs_uv, float* __restrict__ obs_w,
                                                      int32_t* __restrict__ obs_off, double* __restrict__ pose7, double* __restrict__ K4d, TrkOut* __restrict__ out) {
   __shared__ int s_taken[TRK_MAXKP];                          // index of the settled claiming query that holds the target (INT_MAX: free)
-  __shared__ int s_mark[TRK_MAXKP];                           // smallest index of an unsettled claimer that could still take the target
+  __shared__ int s_mark[TRK_MAXKP];                           // smallest index of a claimer that stays unsettled and could still take the target
+  __shared__ int s_sign[TRK_MAXKP];                           // smallest index of an unsettled claimer that PROPOSES the target
+  __shared__ int s_flag[3];
   __shared__ int s_hist[TRK_HISTO], s_keep[TRK_HISTO];
   __shared__ int s_left, s_nm, s_w[16];
+  const unsigned long long tkb = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x;
   const TrkIn I = *in;
   const int nq = I.nq;
   const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
   const bool overflow = off[nq] > cand_cap;                   // (the caller re-runs with a larger candidate buffer)
-  for (int t = tid; t < TRK_MAXKP; t += 1024) { s_taken[t] = INT_MAX; s_mark[t] = INT_MAX; }
+  for (int t = tid; t < TRK_MAXKP; t += TRK_GT) { s_taken[t] = INT_MAX; s_mark[t] = INT_MAX; s_sign[t] = INT_MAX; }
+  if (tid < 3) s_flag[tid] = 0;
   if (tid < TRK_HISTO) s_hist[tid] = 0;
   if (tid == 0) { s_left = 0; s_nm = 0; }
   // state of the (<= 3 per thread) queries this thread owns: -3 unsettled, -1 settled without a match, >= 0 the matched target
-  int st[4] = {-1, -1, -1, -1};
-  for (int k = 0; k < 4; k++) { const int q = tid + 1024 * k; if (q < nq && q_valid[q] && !overflow) st[k] = -3; }
+  int st[TRK_QPT];
+#pragma unroll
+  for (int k = 0; k < TRK_QPT; k++) st[k] = -1;
+  for (int k = 0; k < TRK_QPT; k++) { const int q = tid + TRK_GT * k; if (q < nq && q_valid[q] && !overflow) st[k] = -3; }
   __syncthreads();
-  int rounds = 0;
+  // Only candidates within TH_HIGH can ever be chosen or block anybody, and a window holds few of those (the true match and
+  // the odd look-alike; random descriptors are 128 +- 8 bits apart): each query's acceptable candidates, in list order, are
+  // read from global memory ONCE into registers of the thread that owns the query (target | distance << 16; a query with more
+  // than TRK_LMAX of them keeps walking its global list).  Every round below then runs on registers and LDS.
+  unsigned lst[TRK_QPT][TRK_LMAX]; int ln[TRK_QPT]; bool big[TRK_QPT];
+#pragma unroll
+  for (int k = 0; k < TRK_QPT; k++) {
+    const int q = tid + TRK_GT * k;
+    ln[k] = 0; big[k] = false;
+#pragma unroll
+    for (int e = 0; e < TRK_LMAX; e++) lst[k][e] = 0u;
+    if (st[k] != -3) continue;
+    const int cnt = acc_n[q];
+#pragma unroll
+    for (int e = 0; e < TRK_LMAX; e++) if (e < cnt) lst[k][e] = acc[(size_t)q * TRK_LMAX + e];
+    ln[k] = min(cnt, TRK_LMAX); big[k] = cnt > TRK_LMAX;
+    if (cnt == 0) st[k] = -1;                                   // nothing acceptable: settled, nothing matched
+  }
+  const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
+  int rounds = 0, inner_total = 0, phase = 0;                  // phase: counter of the rotating "anything changed?" flags
   for (; rounds < 4096; rounds++) {
     // (1) proposals: the best still-available candidate of every unsettled query; claimers sign their PROPOSAL
-    int prop[4] = {-1, -1, -1, -1};
-    bool nonfinal[4] = {false, false, false, false}, pushed[4] = {false, false, false, false};
-    for (int k = 0; k < 4; k++) {
-      const int q = tid + 1024 * k;
+    int prop[TRK_QPT]; bool nonfinal[TRK_QPT];
+#pragma unroll
+    for (int k = 0; k < TRK_QPT; k++) { prop[k] = -1; nonfinal[k] = false; }
+#pragma unroll
+    for (int k = 0; k < TRK_QPT; k++) {
+      const int q = tid + TRK_GT * k;
       if (st[k] != -3) continue;
       int best = 256, bi = -1;
-      for (uint32_t c = off[q]; c < off[q + 1]; c++) {
-        const int t = (int)pairs[c].x, d = (int)pairs[c].y;
-        if (s_taken[t] < q) continue;                         // (:1220-1221: the feature holds a point with observations)
-        if (d < best) { best = d; bi = t; }
-      }
-      if (bi < 0 || best > TRK_TH_HIGH) { st[k] = -1; continue; }           // can only get worse: settled, nothing matched
-      prop[k] = bi;
-      if (q_valid[q] == 1) atomicMin(&s_mark[bi], q);
-    }
-    __syncthreads();
-    // (2) a claimer that is not the first to want its target cannot be settled in this round
-    for (int k = 0; k < 4; k++) {
-      const int q = tid + 1024 * k;
-      if (st[k] == -3 && q_valid[q] == 1 && s_mark[prop[k]] != q) nonfinal[k] = true;
-    }
-    __syncthreads();
-    for (int t = tid; t < TRK_MAXKP; t += 1024) s_mark[t] = INT_MAX;
-    __syncthreads();
-    // (3) the winners that can still lose their target: some EARLIER claimer that stays unsettled has it on its list.  Greatest
-    // fixpoint, from the losers outwards: the unsettled-for-sure claimers sign every target they could still take.
-    for (int inner = 0; inner < 4096; inner++) {
-      for (int k = 0; k < 4; k++) {
-        const int q = tid + 1024 * k;
-        if (st[k] != -3 || !nonfinal[k] || pushed[k]) continue;
-        pushed[k] = true;
+      if (!big[k]) {
+#pragma unroll
+        for (int e = 0; e < TRK_LMAX; e++) {
+          const int t = (int)(lst[k][e] & 0xFFFFu), d = (int)(lst[k][e] >> 16);
+          if (e < ln[k] && s_taken[t] >= q && d < best) { best = d; bi = t; }       // (:1220-1221: a feature that holds an observed point is skipped)
+        }
+      } else {
         for (uint32_t c = off[q]; c < off[q + 1]; c++) {
-          const int t = (int)pairs[c].x;
-          if (s_taken[t] >= q && (int)pairs[c].y <= TRK_TH_HIGH) atomicMin(&s_mark[t], q);
+          const int t = (int)pairs[c].x, d = (int)pairs[c].y;
+          if (d <= TRK_TH_HIGH && s_taken[t] >= q && d < best) { best = d; bi = t; }
         }
       }
-      __syncthreads();
-      int changed = 0;
-      for (int k = 0; k < 4; k++) {
-        const int q = tid + 1024 * k;
-        if (st[k] == -3 && q_valid[q] == 1 && !nonfinal[k] && s_mark[prop[k]] < q) { nonfinal[k] = true; changed = 1; }
-      }
-      if (changed) s_left = 1;
-      __syncthreads();
-      const int any = s_left;
-      __syncthreads();
-      if (tid == 0) s_left = 0;
-      if (!any) break;
+      if (bi < 0) { st[k] = -1; continue; }                    // can only get worse: settled, nothing matched
+      prop[k] = bi;
+      if (q_valid[q] == 1) atomicMin(&s_sign[bi], q);
     }
     __syncthreads();
-    // (4) settle: the final claimers take their targets; a query without observations keeps its proposal when no earlier claimer
-    // took it in this round and none that stays unsettled could
-    for (int k = 0; k < 4; k++) {
-      const int q = tid + 1024 * k;
+    // (2) + (3) the claimers that stay unsettled in this round: the ones that are not the first to want their target, and -
+    // greatest fixpoint, from those losers outwards - every winner whose target an EARLIER unsettled claimer has on its list.
+    // A claimer that joins the set signs, at once, every target it could still take (s_mark); ONE barrier per sweep, the
+    // "anything changed?" flags rotate so that none has to be cleared between two barriers that read it.
+    for (int sweep = 0; sweep < 8192; sweep++) {
+      inner_total++;
+      bool changed = false;
+#pragma unroll
+      for (int k = 0; k < TRK_QPT; k++) {
+        const int q = tid + TRK_GT * k;
+        if (st[k] != -3 || nonfinal[k] || q_valid[q] != 1) continue;
+        if (sweep == 0 ? (s_sign[prop[k]] != q) : (s_mark[prop[k]] < q)) {
+          nonfinal[k] = true; changed = true;
+          if (!big[k]) {
+#pragma unroll
+            for (int e = 0; e < TRK_LMAX; e++) { const int t = (int)(lst[k][e] & 0xFFFFu); if (e < ln[k] && s_taken[t] >= q) atomicMin(&s_mark[t], q); }
+          } else {
+            for (uint32_t c = off[q]; c < off[q + 1]; c++) { const int t = (int)pairs[c].x; if (s_taken[t] >= q && (int)pairs[c].y <= TRK_TH_HIGH) atomicMin(&s_mark[t], q); }
+          }
+        }
+      }
+      if (changed) s_flag[phase % 3] = 1;
+      if (tid == 0) s_flag[(phase + 1) % 3] = 0;
+      __syncthreads();
+      const int any = s_flag[phase % 3];
+      phase++;
+      if (!any) break;
+    }
+    // (4) settle: the final claimers take their targets ...
+#pragma unroll
+    for (int k = 0; k < TRK_QPT; k++) {
+      const int q = tid + TRK_GT * k;
       if (st[k] == -3 && q_valid[q] == 1 && !nonfinal[k]) { st[k] = prop[k]; s_taken[prop[k]] = q; }
     }
     __syncthreads();
+    // ... a query without observations keeps its proposal when no earlier claimer took it in this round and none that stays
+    // unsettled could
     int mine_left = 0;
-    for (int k = 0; k < 4; k++) {
-      const int q = tid + 1024 * k;
+#pragma unroll
+    for (int k = 0; k < TRK_QPT; k++) {
+      const int q = tid + TRK_GT * k;
       if (st[k] != -3) continue;
       if (q_valid[q] != 1 && s_mark[prop[k]] > q && s_taken[prop[k]] > q) st[k] = prop[k]; else mine_left++;
     }
+    if (mine_left) s_flag[phase % 3] = 1;
+    if (tid == 0) s_flag[(phase + 1) % 3] = 0;
     __syncthreads();
-    for (int t = tid; t < TRK_MAXKP; t += 1024) s_mark[t] = INT_MAX;
-    if (mine_left) atomicAdd(&s_left, mine_left);
-    __syncthreads();
-    const int left = s_left;
-    __syncthreads();
-    if (tid == 0) s_left = 0;
+    const int left = s_flag[phase % 3];
+    phase++;
     if (left == 0) { rounds++; break; }
+    for (int t = tid; t < TRK_MAXKP; t += TRK_GT) { s_mark[t] = INT_MAX; s_sign[t] = INT_MAX; }
+    __syncthreads();
   }
+  const unsigned long long tk1 = __builtin_amdgcn_s_memrealtime();
   // rotation consistency (src/ORBmatcher.cc:1235-1264): histogram of the matches, the three fullest bins survive
-  int bin[4] = {-1, -1, -1, -1};
-  for (int k = 0; k < 4; k++) {
-    const int q = tid + 1024 * k;
+  int bin[TRK_QPT];
+#pragma unroll
+  for (int k = 0; k < TRK_QPT; k++) bin[k] = -1;
+  for (int k = 0; k < TRK_QPT; k++) {
+    const int q = tid + TRK_GT * k;
     if (q >= nq || st[k] < 0) continue;
     atomicAdd(&s_nm, 1);
     if (I.check_ori) {
@@ -282,10 +341,10 @@ __global__ __launch_bounds__(1024) void k_trk_greedy(const TrkIn* __restrict__ i
   // slot owners: the LAST query assigned to a feature holds it (:1232), a removed match empties the slot whoever else shares it (:1260-1264)
   int* s_owner = s_taken; int* s_dead = s_mark;
   __syncthreads();
-  for (int t = tid; t < TRK_MAXKP; t += 1024) { s_owner[t] = -1; s_dead[t] = 0; }
+  for (int t = tid; t < TRK_MAXKP; t += TRK_GT) { s_owner[t] = -1; s_dead[t] = 0; }
   __syncthreads();
-  for (int k = 0; k < 4; k++) {
-    const int q = tid + 1024 * k;
+  for (int k = 0; k < TRK_QPT; k++) {
+    const int q = tid + TRK_GT * k;
     if (q >= nq) continue;
     int mres = st[k] >= 0 ? st[k] : -1;
     if (st[k] >= 0) {
@@ -295,9 +354,11 @@ __global__ __launch_bounds__(1024) void k_trk_greedy(const TrkIn* __restrict__ i
     match[q] = mres;
   }
   __syncthreads();
+  const unsigned long long tk2 = __builtin_amdgcn_s_memrealtime();
   // PoseOptimization's observations: the features that hold a point, in feature order (src/CeresOptimizer.cc:297-327)
-  int has[4], cntv = 0;
-  for (int k = 0; k < 4; k++) { const int t = 4 * tid + k; has[k] = (t < n && s_owner[t] >= 0 && !s_dead[t]) ? 1 : 0; cntv += has[k]; }
+  constexpr int FPT = TRK_MAXKP / TRK_GT;                    // features per thread
+  int cntv = 0;
+  for (int k = 0; k < FPT; k++) { const int t = FPT * tid + k; cntv += (t < n && s_owner[t] >= 0 && !s_dead[t]) ? 1 : 0; }
   int inc = cntv;
   {
     const int lane = tid & 63, w = tid >> 6;
@@ -310,10 +371,11 @@ __global__ __launch_bounds__(1024) void k_trk_greedy(const TrkIn* __restrict__ i
     inc += base;
   }
   int pos = inc - cntv;
-  for (int k = 0; k < 4; k++) {
-    const int t = 4 * tid + k;
-    if (t < cap) owner[t] = (t < n && s_owner[t] >= 0 && !s_dead[t]) ? s_owner[t] : -1;
-    if (!has[k]) continue;
+  for (int k = 0; k < FPT; k++) {
+    const int t = FPT * tid + k;
+    const bool has = t < n && s_owner[t] >= 0 && !s_dead[t];
+    if (t < cap) owner[t] = has ? s_owner[t] : -1;
+    if (!has) continue;
     const int q = s_owner[t];
     obs_feat[pos] = t;
     obs_Xw[3 * pos] = last_Xw[3 * q]; obs_Xw[3 * pos + 1] = last_Xw[3 * q + 1]; obs_Xw[3 * pos + 2] = last_Xw[3 * q + 2];
@@ -322,10 +384,11 @@ __global__ __launch_bounds__(1024) void k_trk_greedy(const TrkIn* __restrict__ i
     obs_w[pos] = I.inv_sigma2[oc];
     pos++;
   }
-  if (tid == 1023) { obs_off[0] = 0; obs_off[1] = inc; out->nobs = inc; }
+  if (tid == TRK_GT - 1) { obs_off[0] = 0; obs_off[1] = inc; out->nobs = inc; }
   if (tid < 7) pose7[tid] = I.pose7[tid];
   if (tid < 4) K4d[tid] = (double)I.K4[tid];
-  if (tid == 0) { out->n_keypoints = *d_count; out->nmatches = overflow ? -1 : s_nm; out->rounds = rounds; out->cand_total = (int32_t)off[nq]; }
+  if (tid == 0) { const unsigned long long tk3 = __builtin_amdgcn_s_memrealtime(); out->ticks[0] = (int)(tk0 - tkb); out->ticks[1] = (int)(tk1 - tk0); out->ticks[2] = (int)(tk2 - tk1); out->ticks[3] = (int)(tk3 - tk2); }
+  if (tid == 0) { out->n_keypoints = *d_count; out->nmatches = overflow ? -1 : s_nm; out->rounds = rounds + 1000 * inner_total; out->cand_total = (int32_t)off[nq]; }
 }
 
 }  // namespace orbhip
@@ -348,6 +411,11 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
   const int nlevels = orbx_get_levels(ctx);
   ORBHIP_REQUIRE(nlevels > 0 && nlevels <= 16, ORBHIP_EINVAL, "bad level count");
   ThreadWs& W = thread_ws();
+  // ORBHIP_TRACK_TIMING=1: host wall time of the call's phases (mean over every 100 calls, on stderr)
+  static const bool timing = []() { const char* e = std::getenv("ORBHIP_TRACK_TIMING"); return e && e[0] == '1'; }();
+  static thread_local double t_acc[5] = {0, 0, 0, 0, 0}; static thread_local int t_n = 0;
+  auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = timing ? now_us() : 0.0;
   static thread_local uint32_t cand_cap_tl = 0;
   static thread_local FrameGridDev grid;                       // (off / idx buffers filled by k_trk_prepare)
   static thread_local int grid_device = -1;
@@ -370,6 +438,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     const int pI = in.add(&I, sizeof(I)), pX = in.add(last_Xw, 24 * (size_t)nq), pD = in.add(last_desc, 32 * (size_t)nq), pO = in.add(last_octave, 4 * (size_t)nq),
               pA = in.add(last_angle, 4 * (size_t)nq), pV = in.add(last_valid, (size_t)nq);
     if (rc || (rc = W.commit(in))) return rc;
+    const double t1 = timing ? now_us() : 0.0;
     // ONE output block: [TrkOut | pose7 | summary | count | kps | desc | match | owner | obs_feat | outlier]
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
@@ -383,6 +452,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     int* d_cnt = W.d<int>(std::max(nq, 1), &rc); uint32_t* d_off = W.d<uint32_t>((size_t)nq + 2, &rc); uint2* d_pairs = W.d<uint2>(cand_cap, &rc);
     double* d_oX = W.d<double>(3 * (size_t)icap, &rc); double* d_ouv = W.d<double>(2 * (size_t)icap, &rc); float* d_ow = W.d<float>(icap, &rc);
     int32_t* d_ooff = W.d<int32_t>(2, &rc); double* d_K4 = W.d<double>(4, &rc);
+    uint32_t* d_acc = W.d<uint32_t>((size_t)std::max(nq, 1) * TRK_LMAX, &rc); int32_t* d_accn = W.d<int32_t>(std::max(nq, 1), &rc);
     if (rc) return rc;
     if ((rc = grid.off.ensure((size_t)(TRK_NCELL + 1) * 4)) || (rc = grid.idx.ensure((size_t)icap * 4))) return rc;
     grid.min_x = bounds[0]; grid.min_y = bounds[2];
@@ -394,18 +464,20 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
                        d_qlo, d_qhi, d_qv, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>());
     if (nq > 0) {
       if ((rc = frame_area_candidates_enqueue(grid, d_kps4, d_quv, d_qr, d_qlo, d_qhi, d_qv, nq, d_cnt, d_off, (uint32_t*)d_pairs, cand_cap, 2, W.s))) return rc;
-      hipLaunchKernelGGL(k_trk_dist, dim3((cand_cap + 255) / 256), dim3(256), 0, W.s, in.dev<uint8_t>(pD), nq, d_desc, d_off, d_pairs, cand_cap);
+      hipLaunchKernelGGL(k_trk_dist, dim3((nq + 3) / 4), dim3(256), 0, W.s, in.dev<uint8_t>(pD), nq, d_desc, d_off, d_pairs, cand_cap, d_acc, d_accn);
     } else {
       ORBHIP_CHECK_HIP(hipMemsetAsync(d_off, 0, 8, W.s));
     }
-    hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(1024), 0, W.s, dI, d_qv, in.dev<float>(pA), in.dev<double>(pX), d_off, d_pairs, cand_cap, d_kps4, d_count, icap,
+    hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(TRK_GT), 0, W.s, dI, d_qv, in.dev<float>(pA), d_acc, d_accn, in.dev<double>(pX), d_off, d_pairs, cand_cap, d_kps4, d_count, icap,
                        (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow, d_ooff, (double*)(dblk + oPose), d_K4,
                        (TrkOut*)(dblk + oOut));
     ORBHIP_CHECK_HIP(hipGetLastError());
     if ((rc = ba_pose_optimization_batch_device(d_K4, (double*)(dblk + oPose), d_oX, d_ouv, d_ow, d_ooff, 1, dblk + oOutl, (int32_t*)(dblk + oNin),
                                                 (ba_summary*)(dblk + oSum), (void*)W.s))) return rc;
     const uint8_t* hb = W.down(dblk, o, &rc);
+    const double t2 = timing ? now_us() : 0.0;
     if (rc || (rc = W.sync())) return rc;
+    const double t3 = timing ? now_us() : 0.0;
     const TrkOut* T = (const TrkOut*)(hb + oOut);
     if (T->n_keypoints < 0) { set_error("extractor capacity exceeded"); return ORBHIP_EOVERFLOW; }
     if ((uint32_t)T->cand_total > cand_cap) { cand_cap_tl = (uint32_t)T->cand_total + (uint32_t)T->cand_total / 4; continue; }   // (rare) once more, larger lists
@@ -417,11 +489,21 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     std::memset(outlier_out, 0, (size_t)n);
     const int32_t* feat = (const int32_t*)(hb + oFeat);
     for (int k = 0; k < T->nobs; k++) outlier_out[feat[k]] = hb[oOutl + k];
-    res->n_keypoints = n; res->nmatches = T->nmatches; res->n_correspondences = T->nobs; res->greedy_rounds = T->rounds;
+    res->n_keypoints = n; res->nmatches = T->nmatches; res->n_correspondences = T->nobs; res->greedy_rounds = T->rounds % 1000;
     std::memcpy(res->pose7, hb + oPose, 56);
     // PoseOptimization returns 0 and leaves the pose alone with fewer than 3 correspondences (src/CeresOptimizer.cc:330)
     res->n_inliers = T->nobs < 3 ? 0 : *(const int32_t*)(hb + oNin);
     if (T->nobs < 3) std::memcpy(res->pose7, I.pose7, 56);
+    if (timing) {
+      const double t4 = now_us();
+      t_acc[0] += t1 - t0; t_acc[1] += t2 - t1; t_acc[2] += t3 - t2; t_acc[3] += t4 - t3; t_acc[4] += t4 - t0;
+      if (++t_n == 100) {
+        fprintf(stderr, "k_trk_greedy ticks (10 ns): setup %d rounds %d (%d rounds, %d sweeps) rotation+owners %d observations %d\n", T->ticks[0], T->ticks[1], T->rounds % 1000, T->rounds / 1000, T->ticks[2], T->ticks[3]);
+        fprintf(stderr, "orbt_track_with_motion_model: staging + upload enqueue %.1f us, kernel launches %.1f us, wait %.1f us, unpack %.1f us, total %.1f us\n",
+                t_acc[0] / 100, t_acc[1] / 100, t_acc[2] / 100, t_acc[3] / 100, t_acc[4] / 100);
+        for (double& a : t_acc) a = 0; t_n = 0;
+      }
+    }
     return 0;
   }
   set_error("window candidate lists did not fit after regrowing");
