@@ -32,4 +32,6 @@ int frame_area_candidates(const FrameGridDev& g, const float* d_kps4, const floa
 int frame_area_candidates_enqueue(const FrameGridDev& g, const float* d_kps4, const float* d_q_xy, const float* d_q_r, const int* d_q_minl,
                                   const int* d_q_maxl, const uint8_t* d_q_valid, int nq, int* d_cnt, uint32_t* d_cand_off /*[nq+1]*/,
                                   uint32_t* d_cand_idx, uint32_t cap, int idx_stride, hipStream_t s);
+// exclusive scan of d_cnt[0..n) into d_off[0..n] (one workgroup); enqueue only
+int frame_scan_enqueue(const int* d_cnt, int n, uint32_t* d_off, hipStream_t s);
 }  // namespace orbhip

@@ -241,6 +241,12 @@ int frame_area_candidates(const FrameGridDev& g, const float* d_kps4, const floa
   return 0;
 }
 
+int frame_scan_enqueue(const int* d_cnt, int n, uint32_t* d_off, hipStream_t s) {
+  hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, s, d_cnt, n, d_off);
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int frame_area_candidates_enqueue(const FrameGridDev& g, const float* d_kps4, const float* d_q_xy, const float* d_q_r, const int* d_q_minl,
                                   const int* d_q_maxl, const uint8_t* d_q_valid, int nq, int* d_cnt, uint32_t* d_cand_off, uint32_t* d_cand_idx,
                                   uint32_t cap, int idx_stride, hipStream_t s) {

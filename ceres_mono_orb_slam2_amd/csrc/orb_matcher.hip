@@ -312,6 +312,31 @@ __global__ __launch_bounds__(256) void k_dist_csr_dev(const uint8_t* __restrict_
                        ((const uint4*)t)[2 * (size_t)j], ((const uint4*)t)[2 * (size_t)j + 1]);
 }
 
+// A guided search only ever looks at candidates within a distance bound (the acceptance threshold, divided by the ratio where a
+// second-best test exists: a farther candidate can be neither the best nor a second best that matters), and a window holds few
+// of those - random descriptors are 128 +- 8 bits apart.  One wave per query: count the candidates within `keep`, and (after a
+// scan of the counts) write them densely, in list order, so that the download and the host pass see a few thousand pairs
+// instead of a few hundred thousand (SearchForInitialization, window 100: 600 k pairs, 4.8 MB -> ~50 kB).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_filter_lists(const uint32_t* __restrict__ off, const uint2* __restrict__ pair, uint32_t cap, int nq, uint32_t keep,
+                                                      int* __restrict__ fcnt, const uint32_t* __restrict__ foff, uint2* __restrict__ fpair, uint32_t fcap) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const uint32_t b = min(off[q], cap), e = min(off[q + 1], cap);
+  uint32_t found = 0;
+  const uint32_t base_out = FILL ? foff[q] : 0u;
+  for (uint32_t base = b; base < e; base += 64) {
+    const uint32_t k = base + lane;
+    uint2 v = make_uint2(0u, 0xFFFFFFFFu);
+    if (k < e) v = pair[k];
+    const bool ok = k < e && v.y <= keep;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+    if (FILL) { const uint32_t at = base_out + found + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); if (ok && at < fcap) fpair[at] = v; }
+    found += (uint32_t)__popcll(m);
+  }
+  if (!FILL && lane == 0) fcnt[q] = (int)found;
+}
+
 // ---- rotation-consistency bookkeeping of the guided searches (host; tiny) ----------------------------------------------
 // Bin of a match: rot = a1 - a2 (+360 if negative), bin = round(rot / 30), 30 -> 0 (e.g. src/ORBmatcher.cc:431-437).
 static inline int rotation_bin(float a1, float a2) {
@@ -351,13 +376,15 @@ static thread_local FrameGridDev g_grid;                       // device grid of
 static thread_local uint32_t g_cand_cap = 0;                   // candidate capacity that was enough so far
 static thread_local int g_grid_device = -1;                    // device g_grid's buffers live on
 
+static thread_local uint32_t g_fcand_cap = 0;                  // kept-candidate capacity that was enough so far
+// keep < 0: every candidate comes back; keep >= 0: only the candidates within that distance (dense, list order preserved)
 static int window_lists(ThreadWs& W, const float* kps4, const uint8_t* desc, int n, const float* bounds, const float* q_uv, const float* q_radius,
-                        const int32_t* q_minl, const int32_t* q_maxl, const uint8_t* q_valid, const uint8_t* q_desc, int nq, WindowLists* out) {
+                        const int32_t* q_minl, const int32_t* q_maxl, const uint8_t* q_valid, const uint8_t* q_desc, int nq, WindowLists* out, int keep = -1) {
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = W.begin();
     if (rc) return rc;
     if (g_grid_device != W.device) {                             // default device changed: like ThreadWs, forget (leak) the old device's buffers
-      g_grid = FrameGridDev(); g_cand_cap = 0; g_grid_device = W.device;
+      g_grid = FrameGridDev(); g_cand_cap = 0; g_fcand_cap = 0; g_grid_device = W.device;
     }
     const uint32_t cap = std::max<uint32_t>(g_cand_cap, (uint32_t)nq * 64u);
     ThreadWs::Pack in;                                           // every input in one pinned block, one H2D copy
@@ -377,6 +404,35 @@ static int window_lists(ThreadWs& W, const float* kps4, const uint8_t* desc, int
     if ((rc = frame_area_candidates_enqueue(g_grid, dk, in.dev<float>(pq), in.dev<float>(pr), in.dev<int>(pmn), in.dev<int>(pmx), in.dev<uint8_t>(pv), nq,
                                             dcnt, doff, (uint32_t*)dpair, cap, 2, W.s))) return rc;
     hipLaunchKernelGGL(k_dist_csr_dev, dim3((cap + 255) / 256), dim3(256), 0, W.s, in.dev<uint8_t>(pqd), nq, in.dev<uint8_t>(pd), doff, dpair, cap);
+    if (keep >= 0) {
+      // filtered form: [foff (nq + 1) | kept pairs]; the full lists stay on the device
+      const uint32_t fcap = std::max<uint32_t>(g_fcand_cap, (uint32_t)nq * 8u);
+      int* dfc = W.d<int>(nq, &rc);
+      uint32_t* dfo = W.d<uint32_t>(off_words + 2 * (size_t)fcap + 2, &rc);
+      uint32_t* hf = W.h<uint32_t>(off_words + 2 * (size_t)fcap + 2, &rc);
+      if (rc) return rc;
+      uint2* dfp = (uint2*)(dfo + off_words);
+      hipLaunchKernelGGL(k_filter_lists<false>, dim3((nq + 3) / 4), dim3(256), 0, W.s, doff, dpair, cap, nq, (uint32_t)keep, dfc, (const uint32_t*)nullptr, (uint2*)nullptr, 0u);
+      if ((rc = frame_scan_enqueue(dfc, nq, dfo, W.s))) return rc;
+      hipLaunchKernelGGL(k_filter_lists<true>, dim3((nq + 3) / 4), dim3(256), 0, W.s, doff, dpair, cap, nq, (uint32_t)keep, (int*)nullptr, dfo, dfp, fcap);
+      // the true total of the unfiltered lists travels in the spare word behind the offsets (off_words >= nq + 1 ... nq + 2)
+      ORBHIP_CHECK_HIP(hipMemcpyAsync(dfo + off_words + 2 * (size_t)fcap, doff + nq, 4, hipMemcpyDeviceToDevice, W.s));
+      const uint32_t fguess = std::min<uint32_t>(fcap, std::max<uint32_t>(g_fcand_cap, (uint32_t)nq * 4u));
+      ORBHIP_CHECK_HIP(hipMemcpyAsync(hf, dfo, (off_words + 2 * (size_t)fguess) * 4, hipMemcpyDeviceToHost, W.s));
+      ORBHIP_CHECK_HIP(hipMemcpyAsync(hf + off_words + 2 * (size_t)fcap, dfo + off_words + 2 * (size_t)fcap, 4, hipMemcpyDeviceToHost, W.s));
+      if ((rc = W.sync())) return rc;
+      const uint32_t total_all = hf[off_words + 2 * (size_t)fcap], ftotal = hf[nq];
+      if (total_all > cap) { g_cand_cap = total_all + total_all / 4; continue; }
+      if (ftotal > fcap) { g_fcand_cap = ftotal + ftotal / 4; continue; }
+      if (ftotal > fguess) {
+        ORBHIP_CHECK_HIP(hipMemcpyAsync(hf + off_words + 2 * (size_t)fguess, dfo + off_words + 2 * (size_t)fguess, 2 * (size_t)(ftotal - fguess) * 4, hipMemcpyDeviceToHost, W.s));
+        if ((rc = W.sync())) return rc;
+      }
+      g_cand_cap = std::max<uint32_t>(g_cand_cap, total_all + total_all / 8);
+      g_fcand_cap = std::max<uint32_t>(g_fcand_cap, ftotal + ftotal / 8);
+      out->off = hf; out->cand = (const Candidate*)(hf + off_words); out->total = ftotal;
+      return 0;
+    }
     // the lists are usually far shorter than the capacity: download what the previous call needed (+ slack), the rest only if used
     const uint32_t guess = std::min<uint32_t>(cap, std::max<uint32_t>(g_cand_cap, (uint32_t)nq * 16u));
     uint32_t* hout = W.h<uint32_t>(off_words + 2 * (size_t)cap, &rc);
@@ -553,7 +609,11 @@ int orbm_search_by_projection(const float* kps4, const uint8_t* desc, int n, con
   ORBHIP_REQUIRE(!check_ori || q_angle, ORBHIP_EINVAL, "rotation check needs q_angle");
   ORBHIP_REQUIRE(chi2_gate <= 0.f || inv_level_sigma2, ORBHIP_EINVAL, "chi2 gate needs inv_level_sigma2");
   WindowLists L;
-  if (int rc = window_lists(thread_ws(), kps4, desc, n, bounds, q_uv, q_radius, q_min_level, q_max_level, q_valid, q_desc, nq, &L)) return rc;
+  // (the reported best distance needs every candidate; without it only candidates that can be accepted, or be a second best that
+  // vetoes an acceptance, matter: distance <= th, or <= th / ratio with the second-best rule)
+  int keep = -1;
+  if (!q_best_dist) { keep = th; if (mode_best2 && ratio > 0.f) keep = (int)std::ceil((float)th / ratio) + 1; if (mode_best2 && !(ratio > 0.f)) keep = -1; if (keep > 256) keep = -1; }
+  if (int rc = window_lists(thread_ws(), kps4, desc, n, bounds, q_uv, q_radius, q_min_level, q_max_level, q_valid, q_desc, nq, &L, keep)) return rc;
   struct Level2 { int d = 256, lvl = -1; };                     // (distance, octave) of a candidate
   RotationFilter rot;
   std::vector<signed char> bin_of(nq, -1);
@@ -779,7 +839,10 @@ int orbm_search_for_initialization(const float* kps1, const uint8_t* desc1, int 
   std::vector<uint8_t> level0(n1);
   for (int i = 0; i < n1; i++) { level[i] = (int32_t)kps1[4 * i + 2]; level0[i] = level[i] > 0 ? 0 : 1; }      // (:383-385)
   WindowLists L;
-  if (int rc = window_lists(thread_ws(), kps2, desc2, n2, bounds2, prev_matched, radius.data(), level.data(), level.data(), level0.data(), desc1, n1, &L)) return rc;
+  // (a candidate farther than TH_LOW / nnratio can be neither the best nor a second best that fails the ratio test, :425-427)
+  int keep = nnratio > 0.f ? (int)std::ceil((float)TH_LOW / nnratio) + 1 : -1;
+  if (keep > 256) keep = -1;
+  if (int rc = window_lists(thread_ws(), kps2, desc2, n2, bounds2, prev_matched, radius.data(), level.data(), level.data(), level0.data(), desc1, n1, &L, keep)) return rc;
   std::vector<int> owner(n2, -1), won_with(n2, INT_MAX);
   std::vector<signed char> bin_of(n1, -1);
   int found = 0;
