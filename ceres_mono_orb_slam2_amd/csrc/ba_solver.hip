@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         a[g][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
-        ap[g][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;      // negated: L21 = A21 X^T + (-Lprev) M^T
+        ap[g][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;      // negated: A21 + P (-Lprev)^T
       }
     }
   }
@@ -1373,6 +1373,20 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   __syncthreads();
   CHOL_STAMP(0);                                              // loads landed
   const int ti = w >> 1, tj = w & 1;                         // this wave's 16x16 tile of the 32x32 products
+  // The previous step's rank-32 update of THIS column block's rows below the diagonal, A21 <- A21 - Lprev P^T, on the matrix
+  // cores before the factor starts (round 3: it used to be folded algebraically into the product behind the factor,
+  // L21 = A21 X^T - Lprev (X P)^T, which put M = X P and a barrier on the serial chain).  a[ks] is at once the MFMA A operand
+  // of k-step ks and - the same register - row (lane >> 4) + 4 (ks & 3) of the 16 x 16 C tile ks >> 2 of A21^T, so the update
+  // accumulates INTO it: tile t of A21'^T = A21^T + P (-Lprev)^T with P's rows 16 t .. as the A operand and ap as the B operand.
+  auto apply_prev = [&](double (&av)[8], const double (&apv)[8]) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      double4_t acc = {av[4 * t], av[4 * t + 1], av[4 * t + 2], av[4 * t + 3]};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], apv[ks], acc, 0, 0, 0);
+      av[4 * t] = acc[0]; av[4 * t + 1] = acc[1]; av[4 * t + 2] = acc[2]; av[4 * t + 3] = acc[3];
+    }
+  };
   if (upd) {
     if (tj <= ti) {                                           // D -= P P^T on the lower tiles
       double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -1391,26 +1405,26 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
     const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
     if (fail && tid == 0) s_fail = 1;
     CHOL_STAMP(2);                                            // factor + inverse
+  } else if (upd) {                                           // waves 1..3 bring their rows up to date beside the factor ...
+    if constexpr (EARLY) {
+#pragma unroll
+      for (int g = 0; g < G; g++) apply_prev(a[g], ap[g]);
+    }
   }
   __syncthreads();
   CHOL_STAMP(3);
   if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
-  if (upd) {                                                  // M = X P, one 16x16 tile per wave
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  if (tid < 64 && upd) {                                      // ... wave 0 behind it
+    if constexpr (EARLY) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_X[16 * ti + li][4 * ks + lk], s_P[4 * ks + lk][16 * tj + li], acc, 0, 0, 0);
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) s_M[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
-    __syncthreads();
+      for (int g = 0; g < G; g++) apply_prev(a[g], ap[g]);
+    }
   }
-  // ---- L21 rows on the matrix cores: [A21 | -Lprev] [X | M]^T ---------------------------------------------------------
-  double b0[8], b1[8], m0[8], m1[8];
+  // ---- L21 rows on the matrix cores: A21' X^T ----------------------------------------------------------------------------
+  double b0[8], b1[8];
 #pragma unroll
-  for (int ks = 0; ks < 8; ks++) {
-    b0[ks] = s_X[li][4 * ks + lk]; b1[ks] = s_X[16 + li][4 * ks + lk];     // B[k][j] = X[j][k]
-    m0[ks] = upd ? s_M[li][4 * ks + lk] : 0.0; m1[ks] = upd ? s_M[16 + li][4 * ks + lk] : 0.0;
-  }
-  CHOL_STAMP(4);                                              // M = X P + operand reads
+  for (int ks = 0; ks < 8; ks++) { b0[ks] = s_X[li][4 * ks + lk]; b1[ks] = s_X[16 + li][4 * ks + lk]; }     // B[k][j] = X[j][k]
+  CHOL_STAMP(4);                                              // operand reads
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const int rg0 = row0 + 16 * g;
@@ -1425,17 +1439,11 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
         ap[0][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;
       }
     }
+    if constexpr (!EARLY) { if (upd) apply_prev(a[0], ap[0]); }
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gi][ks], b0[ks], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gi][ks], b1[ks], acc1, 0, 0, 0);
-    }
-    if (upd) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[gi][ks], m0[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[gi][ks], m1[ks], acc1, 0, 0, 0);
-      }
     }
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
@@ -1518,31 +1526,34 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
   int* flags = D.cflags;
   if (bx == 0) {
     // ------------------------------------------------------------------------------------------------ the chain
-    double (*s_L)[NB + 1] = (double (*)[NB + 1])s_dyn;
-    double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
-    double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
-    double (*s_M)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
-    double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
-    double (*s_Lp)[NB + 1] = (double (*)[NB + 1])(s_dyn + 5 * NB * (NB + 1));
-    double (*s_T)[64] = (double (*)[64])(s_dyn + 6 * NB * (NB + 1));         // 16-byte aligned: 6 * 32 * 33 * 8 bytes
-    __shared__ int s_fail, s_arrive;
+    double (*s_L)[NB + 1] = (double (*)[NB + 1])s_dyn;                                  // D_k
+    double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));                // X_k = L_kk^-1
+    double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));            // P_k = L(k, k-1); after the L phase L(k+1, k)
+    double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));           // A(k+1, k), updates 0 .. k-2 applied
+    double (*s_Lp)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));           // L(k+1, k-1)
+    double* s_share = s_dyn + 5 * NB * (NB + 1);                                        // wave 1 -> wave 0: the updated rows 0..15 of A(k+1, k) [lane][8]
+    double (*s_T)[64] = (double (*)[64])(s_dyn + 6 * NB * (NB + 1));                    // 16-byte aligned: 6 * 32 * 33 * 8 bytes
+    __shared__ int s_fail, s_arrive, s_arrive2, s_grp;
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(size_t)r * np + c] : 0.0; }
-    if (tid == 0) { s_fail = 0; s_arrive = 0; }
+    if (tid == 0) { s_fail = 0; s_arrive = 0; s_arrive2 = 0; s_grp = 0; }
     // waves 1..3 own the lower 16x16 tiles of the NEXT diagonal block: (0,0), (1,0), (1,1)
     const int di = (w == 1) ? 0 : 1, dj = (w == 3) ? 1 : 0;
+    const int ai = (w <= 1) ? 0 : 1;                            // the 16 rows of A(k+1, k) this wave multiplies: waves 0, 1 the upper, 2, 3 the lower
+    int n_grp = 0;
     __syncthreads();
     for (int k = 0; k < nb; k++) {
       const bool upd = k > 0, next = k + 1 < nb;
       CHOL_PROF_BEGIN(k);
       double c2[4] = {0.0, 0.0, 0.0, 0.0};
+      double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (tid < 64) {
         const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
         if (fail && tid == 0) s_fail = 1;
         CHOL_STAMP(0);                                          // factor + inverse
       } else if (next) {
         // stage row k + 1: its tile in column block k (updates 0 .. k-2 applied), L(k+1, k-1), and this wave's entries of its
-        // diagonal tile (updates 0 .. k-1 applied)
+        // diagonal tile (updates 0 .. k-1 applied); then the tile's last update, A <- A - L(k+1, k-1) P_k^T, beside the factor
         bool ok = true;
         if (upd) ok = cp_wait(flags, CP_FINAL + k + 1, 1);
         if (!ok) s_fail = 2;
@@ -1557,42 +1568,51 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
           const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
           c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
         }
+        // the three staging waves meet (wave 0 is in the factor: no __syncthreads here)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        n_grp += 3;
+        if (lane == 0) __hip_atomic_fetch_add(&s_grp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int it = 0; it < CP_SPIN_CAP && __hip_atomic_load(&s_grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_grp; it++) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) a[ks] = s_A1[16 * ai + li][4 * ks + lk];
+        if (upd) {
+#pragma unroll
+          for (int t = 0; t < 2; t++) {                         // (k_chol_la's apply_prev: the registers are rows of the C tiles of A^T)
+            double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], -s_Lp[16 * ai + li][4 * ks + lk], acc, 0, 0, 0);
+            a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+          }
+        }
+        if (w == 1) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) s_share[lane * 8 + ks] = a[ks];
+        }
       }
       __syncthreads();
       CHOL_STAMP(1);                                            // barrier: what the staging waves are late by
       if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
-      if (upd) {                                                // M = X P, one 16x16 tile per wave (k_chol_la's order)
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_X[16 * ti + li][4 * ks + lk], s_P[4 * ks + lk][16 * tj + li], acc, 0, 0, 0);
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
-          s_M[r][c] = acc[rg];
-          st_sc1(&Mb[(size_t)k * NB * NB + r * NB + c], acc[rg]);
-        }
-      }
       {
         double* Di = Dinv + (size_t)k * NB * NB;
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; st_sc1(&Di[i], s_X[i / NB][i % NB]); }
       }
-      __syncthreads();
-      CHOL_STAMP(2);                                            // M = X P, stores of X and M
+      CHOL_STAMP(2);                                            // X stores issued
       if (next) {
-        // L(k+1, k) = [A | -Lprev] [X | M]^T on the matrix cores: the new P
+        if (w == 0) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) a[ks] = s_share[lane * 8 + ks];
+        }
+        // L(k+1, k) = A' X^T on the matrix cores: the new P
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_A1[16 * ti + li][4 * ks + lk], s_X[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
-        if (upd) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-s_Lp[16 * ti + li][4 * ks + lk], s_M[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
-        }
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], s_X[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
         const size_t rb = (size_t)(k + 1) * NB;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
-        // X_k and M_k have left (their stores were issued before the MFMAs above): the last wave to see that publishes them -
-        // the row producers start on step k a microsecond before the chain is through with it
+        // X_k has left (its stores were issued before the MFMAs above): the last wave to see that publishes it - the row
+        // producers start on step k a microsecond before the chain is through with it
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_XREADY, k + 1);
 #pragma unroll
@@ -1609,9 +1629,12 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
             if (c <= r) s_L[r][c] = c2[rg] - a2[rg];
           }
         }
+        // L(k+1, k) has left: it is the P the row producers need for their step k + 1
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_LREADY + k + 1, k + 1);
       }
       CHOL_STAMP(4);                                            // D update
-      if (!next) {                                              // the last step: X and M are published here
+      if (!next) {                                              // the last step: X is published here
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
@@ -1651,40 +1674,49 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
     double (*s_Mj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
     for (int j = 0; j < jend; j++) {
       const bool upd = j > 0, last = !is_rhs && j == jend - 1;
+      // before X_j exists: the tile (i, j) with its last update, A' = A - L(i, j-1) P_j^T (P_j = L(j, j-1), the chain's tile of
+      // the previous step); all its inputs are one chain step old
       bool ok = true;
-      if (j >= 2) ok = cp_wait(flags, CP_PROG + 4 * irow + (j % W), j - 1);                // tile (i, j) has its last update (j - 2): old flags, polled first
+      if (j >= 2) ok = cp_wait(flags, CP_PROG + 4 * irow + (j % W), j - 1);                // tile (i, j) has its update j - 2
       if (ok && last && j >= 1) ok = cp_wait(flags, CP_PROG + 4 * irow + (irow % W), j);   // the diagonal tile has update j - 1
-      if (ok) ok = cp_wait(flags, CP_XREADY, j + 1);
-      // the three operand tiles arrive as whole rows (256 contiguous bytes per half wave: uncoalesced agent-scope loads in the
-      // MFMA operand layout cost several microseconds per tile) and go through LDS
-      double va[4], vx[4], vm[4], cd[4];
+      if (ok && upd) ok = cp_wait(flags, CP_LREADY + j, j);                                // P_j is published
+      double va[4], vp[4], cd[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int idx = tid + 256 * u, r = idx / NB, c = idx % NB;
         va[u] = (ok && (is_rhs ? r == 0 : true)) ? ld_sc1(&S[(r0 + r) * np + (size_t)j * NB + c]) : 0.0;
-        vx[u] = ok ? ld_sc1(&Dinv[(size_t)j * NB * NB + idx]) : 0.0;
-        vm[u] = (ok && upd) ? ld_sc1(&Mb[(size_t)j * NB * NB + idx]) : 0.0;
+        vp[u] = (ok && upd) ? ld_sc1(&S[((size_t)j * NB + r) * np + (size_t)(j - 1) * NB + c]) : 0.0;
       }
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) cd[rg] = (ok && last) ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + r0 + 16 * tj + (lane & 15)]) : 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u, r = idx / NB, c = idx % NB; s_A[r][c] = va[u]; s_Xj[r][c] = vx[u]; s_Mj[r][c] = vm[u]; }
+      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u, r = idx / NB, c = idx % NB; s_A[r][c] = va[u]; s_Mj[r][c] = vp[u]; }
       __syncthreads();
-      double a[8], ap[8], b[8], m[8];
+      double a[8], b[8];
 #pragma unroll
-      for (int ks = 0; ks < 8; ks++) {
-        a[ks] = s_A[arow][4 * ks + lk];
-        b[ks] = s_Xj[16 * tj + li][4 * ks + lk];
-        m[ks] = s_Mj[16 * tj + li][4 * ks + lk];
-        ap[ks] = upd ? -s_Lq[arow][4 * ks + lk] : 0.0;
+      for (int ks = 0; ks < 8; ks++) a[ks] = s_A[arow][4 * ks + lk];
+      if (upd) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {                           // (k_chol_la's apply_prev)
+          double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_Mj[16 * t + li][4 * ks + lk], -s_Lq[arow][4 * ks + lk], acc, 0, 0, 0);
+          a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+        }
       }
+      // X_j: the only thing this step waits for on the chain
+      if (ok) ok = cp_wait(flags, CP_XREADY, j + 1);
+      double vx[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) vx[u] = ok ? ld_sc1(&Dinv[(size_t)j * NB * NB + tid + 256 * u]) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vx[u]; }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) b[ks] = s_Xj[16 * tj + li][4 * ks + lk];
       double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-      if (upd) {
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[ks], m[ks], acc, 0, 0, 0);
-      }
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);

@@ -25,7 +25,7 @@ for _ in range(4): optimizer.local_bundle_adjustment(*args)
 buf = (C.c_ulonglong * 1280)()
 L.ba_debug_chol_prof(buf, 0)
 a = np.array(buf, dtype=np.float64).reshape(128, 10)
-names = ["factor + inverse (wave 0)", "barrier (staging waves late)", "M = X P, X / M stores", "L(k+1,k) + publication of X / M", "D update", "barrier"]
+names = ["factor + inverse (wave 0)", "barrier (staging waves late)", "X stores issued", "L(k+1,k) + publication of X", "D update + publication of L(k+1,k)", "barrier"]
 steps = [k for k in range(128) if a[k, 9] > 0]
 res = {"steps": len(steps), "visits_per_step": a[steps[0], 9], "ns_per_phase_mean": {}, "per_step_ns": {}}
 for i, n in enumerate(names):
