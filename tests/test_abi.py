@@ -83,6 +83,29 @@ def test_compat_shims_compile_and_link(lib, tmp_path):
     assert exe.exists()
 
 
+def test_dropin_test_program_and_reference_types_branch_compile(lib, tmp_path):
+    """The drop-in call-site program links against the library (it runs on the GPU box: tests/test_gpu_compat_cpp.py), and the
+    `#ifdef ORBSLAM_DROPIN_REFERENCE_TYPES` branch of orbslam_dropin.h - the one a maintainer of the reference uses - compiles
+    with every member function instantiated (the reference's type NAMES bound to the mock data model: a spelling / type check
+    of our header, not a build of the reference)."""
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall"] + inc + [os.path.join(ROOT, "tests", "cpp", "test_reference_types_branch.cpp")])
+    exe = tmp_path / "test_dropin"
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + inc + [os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", str(exe), lib.LIB_PATH, "-lpthread",
+                           "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    assert exe.exists()
+
+
+def test_tracking_step_validates_arguments_and_fails_loudly_without_gpu(lib):
+    import numpy as np
+    from ceres_mono_orb_slam2_amd._lib import OrbHipError
+    L = lib.load()
+    res = (C.c_double * 16)()
+    z = np.zeros(64, np.uint8)
+    rc = L.orbt_track_with_motion_model(None, lib.ptr(z), 8, 8, 8, None, None, None, None, None, None, None, None, 0, C.c_float(15.0), 1, None, None, 0, None, None, None, res)
+    assert rc != 0 and b"NULL" in L.orbhip_last_error()
+
+
 def test_new_entry_points_fail_loudly_without_gpu_and_validate_arguments(lib):
     """The widened rows (Sim3, frame-side steps, vocabulary, triangulation, essential graph, batched BA) obey the same
     contract: argument errors are ORBHIP_EINVAL before any device work, valid calls without a device are ORBHIP_ENODEV."""
