@@ -184,7 +184,8 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
                                                      uint32_t cand_cap, const float* __restrict__ kps4, const int32_t* __restrict__ d_count, int cap,
                                                      int32_t* __restrict__ match, int32_t* __restrict__ owner, int32_t* __restrict__ obs_feat,
                                                      double* __restrict__ obs_Xw, double* __restrict__ obs_uv, float* __restrict__ obs_w,
-                                                     int32_t* __restrict__ obs_off, double* __restrict__ pose7, double* __restrict__ K4d, TrkOut* __restrict__ out) {
+                                                     int32_t* __restrict__ obs_off, double* __restrict__ pose7, double* __restrict__ K4d, TrkOut* __restrict__ out, int ecap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   __shared__ int s_taken[TRK_MAXKP];                          // index of the settled claiming query that holds the target (INT_MAX: free)
   __shared__ int s_mark[TRK_MAXKP];                           // smallest index of a claimer that stays unsettled and could still take the target
   __shared__ int s_sign[TRK_MAXKP];                           // smallest index of an unsettled claimer that PROPOSES the target
@@ -201,57 +202,88 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
   if (tid < 3) s_flag[tid] = 0;
   if (tid < TRK_HISTO) s_hist[tid] = 0;
   if (tid == 0) { s_left = 0; s_nm = 0; }
-  // state of the (<= 3 per thread) queries this thread owns: -3 unsettled, -1 settled without a match, >= 0 the matched target
-  int st[TRK_QPT];
-#pragma unroll
-  for (int k = 0; k < TRK_QPT; k++) st[k] = -1;
-  for (int k = 0; k < TRK_QPT; k++) { const int q = tid + TRK_GT * k; if (q < nq && q_valid[q] && !overflow) st[k] = -3; }
   __syncthreads();
   // Only candidates within TH_HIGH can ever be chosen or block anybody, and a window holds few of those (the true match and
-  // the odd look-alike; random descriptors are 128 +- 8 bits apart): each query's acceptable candidates, in list order, are
-  // read from global memory ONCE into registers of the thread that owns the query (target | distance << 16; a query with more
-  // than TRK_LMAX of them keeps walking its global list).  Every round below then runs on registers and LDS.
-  unsigned lst[TRK_QPT][TRK_LMAX]; int ln[TRK_QPT]; bool big[TRK_QPT];
-#pragma unroll
-  for (int k = 0; k < TRK_QPT; k++) {
-    const int q = tid + TRK_GT * k;
-    ln[k] = 0; big[k] = false;
-#pragma unroll
-    for (int e = 0; e < TRK_LMAX; e++) lst[k][e] = 0u;
-    if (st[k] != -3) continue;
-    const int cnt = acc_n[q];
-#pragma unroll
-    for (int e = 0; e < TRK_LMAX; e++) if (e < cnt) lst[k][e] = acc[(size_t)q * TRK_LMAX + e];
-    ln[k] = min(cnt, TRK_LMAX); big[k] = cnt > TRK_LMAX;
-    if (cnt == 0) st[k] = -1;                                   // nothing acceptable: settled, nothing matched
-  }
-  const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
-  int rounds = 0, inner_total = 0, phase = 0;                  // phase: counter of the rotating "anything changed?" flags
-  for (; rounds < 4096; rounds++) {
-    // (1) proposals: the best still-available candidate of every unsettled query; claimers sign their PROPOSAL
-    int prop[TRK_QPT]; bool nonfinal[TRK_QPT];
-#pragma unroll
-    for (int k = 0; k < TRK_QPT; k++) { prop[k] = -1; nonfinal[k] = false; }
+  // the odd look-alike; random descriptors are 128 +- 8 bits apart; k_trk_dist compacted them in list order): they go into LDS
+  // as CSR lists (a query whose list does not fit any more reads its <= TRK_LMAX entries from global memory; one with more
+  // than TRK_LMAX acceptable candidates walks its full list), and the rounds below run over a WORK LIST of the unsettled
+  // queries that is compacted after every round - after the first round a few hundred of the ~2000 queries are left, so a
+  // phase is a handful of instructions for a fraction of the threads instead of fully unrolled, predicated per-thread lists
+  // for all of them (160 -> ~45 us on a dense frame).
+  int* s_coff = (int*)s_dyn;                                   // [nq + 1]
+  int* s_st = s_coff + (nq + 1);                               // [nq] -3 unsettled, -1 settled without a match, >= 0 the matched target
+  int* s_prop = s_st + nq;                                     // [nq] proposal | nonfinal << 16
+  unsigned short* s_wl[2];
+  s_wl[0] = (unsigned short*)(s_prop + nq); s_wl[1] = s_wl[0] + ((nq + 1) & ~1);
+  uint32_t* s_ent = (uint32_t*)(s_wl[1] + ((nq + 1) & ~1));    // [ecap]
+  // per-query counts -> offsets (block scan over <= 4 queries per thread), work list of everything that has a candidate
+  {
+    int c4[TRK_QPT], mine = 0;
 #pragma unroll
     for (int k = 0; k < TRK_QPT; k++) {
-      const int q = tid + TRK_GT * k;
-      if (st[k] != -3) continue;
-      int best = 256, bi = -1;
-      if (!big[k]) {
+      const int q = TRK_QPT * tid + k;
+      c4[k] = (q < nq && q_valid[q] && !overflow) ? min(acc_n[q], TRK_LMAX) : 0;
+      mine += c4[k];
+    }
+    int inc = mine;
+    const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
-        for (int e = 0; e < TRK_LMAX; e++) {
-          const int t = (int)(lst[k][e] & 0xFFFFu), d = (int)(lst[k][e] >> 16);
-          if (e < ln[k] && s_taken[t] >= q && d < best) { best = d; bi = t; }       // (:1220-1221: a feature that holds an observed point is skipped)
-        }
-      } else {
-        for (uint32_t c = off[q]; c < off[q + 1]; c++) {
-          const int t = (int)pairs[c].x, d = (int)pairs[c].y;
-          if (d <= TRK_TH_HIGH && s_taken[t] >= q && d < best) { best = d; bi = t; }
-        }
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; k++) base += s_w[k];
+    int at = base + inc - mine;
+#pragma unroll
+    for (int k = 0; k < TRK_QPT; k++) {
+      const int q = TRK_QPT * tid + k;
+      if (q < nq) {
+        // (bit 30: the query has more than TRK_LMAX acceptable candidates; bit 29: its map point has observations, it CLAIMS its
+        // target - everything a phase needs to know about a query then comes from LDS)
+        s_coff[q] = at | ((acc_n[q] > TRK_LMAX) ? (1 << 30) : 0) | ((q_valid[q] == 1) ? (1 << 29) : 0);
+        const bool live = q_valid[q] && !overflow && acc_n[q] > 0;
+        s_st[q] = live ? -3 : -1;
+        if (live) s_wl[0][atomicAdd(&s_left, 1)] = (unsigned short)q;
+        if (at + c4[k] <= ecap) for (int e = 0; e < c4[k]; e++) s_ent[at + e] = acc[(size_t)q * TRK_LMAX + e];
+        at += c4[k];
       }
-      if (bi < 0) { st[k] = -1; continue; }                    // can only get worse: settled, nothing matched
-      prop[k] = bi;
-      if (q_valid[q] == 1) atomicMin(&s_sign[bi], q);
+      if (q == nq - 1) s_coff[nq] = at;                         // (s_coff[q + 1] - s_coff[q], masked, is the list length)
+    }
+    if (nq == 0 && tid == 0) s_coff[0] = 0;
+  }
+  __syncthreads();
+  int U = s_left;
+  __syncthreads();
+  if (tid == 0) s_left = 0;
+  // visit the acceptable, still available candidates of query q in list order: fn(target, distance)
+  constexpr int OFFM = (1 << 29) - 1;
+  auto claims = [&](int q) { return (s_coff[q] >> 29) & 1; };
+  auto for_candidates = [&](int q, auto fn) {
+    const int cq = s_coff[q];
+    if (cq & (1 << 30)) {                                        // (rare) the full window list
+      for (uint32_t c = off[q]; c < off[q + 1]; c++) { const int t = (int)pairs[c].x, d = (int)pairs[c].y; if (d <= TRK_TH_HIGH && s_taken[t] >= q) fn(t, d); }
+      return;
+    }
+    const int b = cq & OFFM, cnt = (s_coff[q + 1] & OFFM) - b;
+    const bool in_lds = b + cnt <= ecap;
+    for (int e = 0; e < cnt; e++) {
+      const uint32_t v = in_lds ? s_ent[b + e] : acc[(size_t)q * TRK_LMAX + e];
+      const int t = (int)(v & 0xFFFFu);
+      if (s_taken[t] >= q) fn(t, (int)(v >> 16));               // (:1220-1221: a feature that holds an observed point is skipped)
+    }
+  };
+  const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
+  int rounds = 0, inner_total = 0, phase = 0, cur = 0;         // phase: counter of the rotating "anything changed?" flags
+  for (; rounds < 4096 && U > 0; rounds++) {
+    const unsigned short* wl = s_wl[cur];
+    // (1) proposals: the best still-available candidate of every unsettled query; claimers sign their PROPOSAL
+    for (int i = tid; i < U; i += TRK_GT) {
+      const int q = wl[i];
+      int best = 256, bi = -1;
+      for_candidates(q, [&](int t, int d) { if (d < best) { best = d; bi = t; } });
+      if (bi < 0) { s_st[q] = -1; continue; }                  // can only get worse: settled, nothing matched
+      s_prop[q] = bi;
+      if (claims(q)) atomicMin(&s_sign[bi], q);
     }
     __syncthreads();
     // (2) + (3) the claimers that stay unsettled in this round: the ones that are not the first to want their target, and -
@@ -261,18 +293,13 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
     for (int sweep = 0; sweep < 8192; sweep++) {
       inner_total++;
       bool changed = false;
-#pragma unroll
-      for (int k = 0; k < TRK_QPT; k++) {
-        const int q = tid + TRK_GT * k;
-        if (st[k] != -3 || nonfinal[k] || q_valid[q] != 1) continue;
-        if (sweep == 0 ? (s_sign[prop[k]] != q) : (s_mark[prop[k]] < q)) {
-          nonfinal[k] = true; changed = true;
-          if (!big[k]) {
-#pragma unroll
-            for (int e = 0; e < TRK_LMAX; e++) { const int t = (int)(lst[k][e] & 0xFFFFu); if (e < ln[k] && s_taken[t] >= q) atomicMin(&s_mark[t], q); }
-          } else {
-            for (uint32_t c = off[q]; c < off[q + 1]; c++) { const int t = (int)pairs[c].x; if (s_taken[t] >= q && (int)pairs[c].y <= TRK_TH_HIGH) atomicMin(&s_mark[t], q); }
-          }
+      for (int i = tid; i < U; i += TRK_GT) {
+        const int q = wl[i];
+        const int pr = s_prop[q];
+        if (s_st[q] != -3 || (pr >> 16) || !claims(q)) continue;
+        if (sweep == 0 ? (s_sign[pr] != q) : (s_mark[pr] < q)) {
+          s_prop[q] = pr | (1 << 16); changed = true;
+          for_candidates(q, [&](int t, int) { atomicMin(&s_mark[t], q); });
         }
       }
       if (changed) s_flag[phase % 3] = 1;
@@ -283,30 +310,33 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
       if (!any) break;
     }
     // (4) settle: the final claimers take their targets ...
-#pragma unroll
-    for (int k = 0; k < TRK_QPT; k++) {
-      const int q = tid + TRK_GT * k;
-      if (st[k] == -3 && q_valid[q] == 1 && !nonfinal[k]) { st[k] = prop[k]; s_taken[prop[k]] = q; }
+    for (int i = tid; i < U; i += TRK_GT) {
+      const int q = wl[i];
+      const int pr = s_prop[q];
+      if (s_st[q] == -3 && claims(q) && !(pr >> 16)) { s_st[q] = pr; s_taken[pr] = q; }
     }
     __syncthreads();
     // ... a query without observations keeps its proposal when no earlier claimer took it in this round and none that stays
-    // unsettled could
-    int mine_left = 0;
-#pragma unroll
-    for (int k = 0; k < TRK_QPT; k++) {
-      const int q = tid + TRK_GT * k;
-      if (st[k] != -3) continue;
-      if (q_valid[q] != 1 && s_mark[prop[k]] > q && s_taken[prop[k]] > q) st[k] = prop[k]; else mine_left++;
+    // unsettled could; what is left goes onto the next work list
+    unsigned short* wn = s_wl[cur ^ 1];
+    for (int i = tid; i < U; i += TRK_GT) {
+      const int q = wl[i];
+      if (s_st[q] != -3) continue;
+      const int pr = s_prop[q] & 0xFFFF;
+      if (!claims(q) && s_mark[pr] > q && s_taken[pr] > q) s_st[q] = pr;
+      else wn[atomicAdd(&s_left, 1)] = (unsigned short)q;
     }
-    if (mine_left) s_flag[phase % 3] = 1;
-    if (tid == 0) s_flag[(phase + 1) % 3] = 0;
     __syncthreads();
-    const int left = s_flag[phase % 3];
-    phase++;
-    if (left == 0) { rounds++; break; }
+    U = s_left; cur ^= 1;
     for (int t = tid; t < TRK_MAXKP; t += TRK_GT) { s_mark[t] = INT_MAX; s_sign[t] = INT_MAX; }
     __syncthreads();
+    if (tid == 0) s_left = 0;
   }
+  __syncthreads();
+  // back to the queries this thread owns for the passes below
+  int st[TRK_QPT];
+#pragma unroll
+  for (int k = 0; k < TRK_QPT; k++) { const int q = tid + TRK_GT * k; st[k] = q < nq ? s_st[q] : -1; }
   const unsigned long long tk1 = __builtin_amdgcn_s_memrealtime();
   // rotation consistency (src/ORBmatcher.cc:1235-1264): histogram of the matches, the three fullest bins survive
   int bin[TRK_QPT];
@@ -468,9 +498,15 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     } else {
       ORBHIP_CHECK_HIP(hipMemsetAsync(d_off, 0, 8, W.s));
     }
-    hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(TRK_GT), 0, W.s, dI, d_qv, in.dev<float>(pA), d_acc, d_accn, in.dev<double>(pX), d_off, d_pairs, cand_cap, d_kps4, d_count, icap,
+    // dynamic LDS of the greedy kernel: offsets, states, proposals (ints per query), two work lists, the candidate entries
+    const size_t lds_fixed = (size_t)(3 * nq + 1) * 4 + 2 * (size_t)((nq + 1) & ~1) * 2;
+    const int ecap = (int)std::min<size_t>((size_t)std::max(nq, 1) * TRK_LMAX, (size_t)(100 * 1024 - lds_fixed) / 4);
+    const size_t lds_greedy = lds_fixed + (size_t)ecap * 4 + 16;
+    static const hipError_t lds_attr = hipFuncSetAttribute((const void*)k_trk_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024 + 64);
+    (void)lds_attr;
+    hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(TRK_GT), lds_greedy, W.s, dI, d_qv, in.dev<float>(pA), d_acc, d_accn, in.dev<double>(pX), d_off, d_pairs, cand_cap, d_kps4, d_count, icap,
                        (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow, d_ooff, (double*)(dblk + oPose), d_K4,
-                       (TrkOut*)(dblk + oOut));
+                       (TrkOut*)(dblk + oOut), ecap);
     ORBHIP_CHECK_HIP(hipGetLastError());
     if ((rc = ba_pose_optimization_batch_device(d_K4, (double*)(dblk + oPose), d_oX, d_ouv, d_ow, d_ooff, 1, dblk + oOutl, (int32_t*)(dblk + oNin),
                                                 (ba_summary*)(dblk + oSum), (void*)W.s))) return rc;
