@@ -728,7 +728,7 @@ __global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
   const double radius = st->radius;
   if (F.done) return;
   st->valid = 0; st->accepted = 0; st->chol_fail = 0;
-  if (D.cflags) for (int i = 0; i < 256 /* CP_NFLAGS */; i++) D.cflags[i] = 0;
+  if (D.cflags) { const int nfl = D.chol_la ? 256 /* CP_NFLAGS */ : 2 * (D.npad / 32 + 2) + 8; for (int i = 0; i < nfl; i++) D.cflags[i] = 0; }
   // StopFlagCallback (include/CeresOptimizer.h:332-349) runs after every iteration, before the iteration-cap test: the
   // host keeps copying the caller's flag into this pinned byte while the enqueued iterations drain
   if (D.stop_dev && __atomic_load_n(D.stop_dev, __ATOMIC_RELAXED)) { st->termination = 4; st->done = 1; return; }
@@ -1835,6 +1835,280 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
   }
 }
 
+// ---- the same for the LARGE reduced systems (two-level scheme, GlobalBA): ONE persistent launch per 128-column outer block --
+// k_chol_la steps an outer block with one launch per 32-column step (panel + thin updates confined to the block + a share of
+// the previous block's K = 128 update); here the <= 4 steps of a block are a loop inside one launch, with the roles of
+// k_chol_persist reduced to what a block needs:
+//   workgroup 0, the CHAIN (as above; the first step of a block has no pending update - everything older came with the K = 128
+//     updates -, and the last one leaves the next diagonal block alone: that is the next launch's first load);
+//   one workgroup per block row below (row jb0 + 2 .. nb - 1, then the rhs row): L(i, j) for the steps of this block, and the
+//     thin updates of its tiles INSIDE the block (at most two per step), in the step kernels' order;
+//   behind them the workgroups of the previous outer block's K = 128 update (role C of k_chol_la: every tile once).
+// Flags carry ABSOLUTE step numbers and are never reset between the launches of a factorisation.  Arithmetic = the step
+// kernels' operation for operation: batched calls (>= 4 problems, k_chol_la) stay bit-identical to single ones.
+#define BP_LREADY 2
+__global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restrict__ Dv, int jb0, int ns, int rolec_base, CholWide wd) {
+  const BaDev D = Dv[blockIdx.y];
+  if (D.chol_la) return;
+  BaState* st = D.st;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid || F.chol_fail) return;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const int np = D.npad, nb = np / NB, tid = threadIdx.x, bx = (int)blockIdx.x;
+  if (jb0 >= nb) return;
+  const int kend = min(jb0 + ns, nb);                           // steps jb0 .. kend - 1; thin updates touch the column blocks < kend
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ti = w >> 1, tj = w & 1;
+  double* S = D.S;
+  double* Dinv = D.Dinv;
+  int* flags = D.cflags;
+  const int R = nb + 2;
+  const int FIN = BP_LREADY + R;                                // FINAL flags behind the LREADY flags
+  if (bx >= rolec_base) {
+    // ---- the previous outer block's K = 128 update of everything right of this block (role C of k_chol_la)
+    if (wd.total + wd.nrhs <= 0) return;
+    double (*s_A)[NB + 1] = (double (*)[NB + 1])s_dyn;
+    double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + 64 * (NB + 1));
+    const int wi = bx - rolec_base;
+    if (wi < wd.total + wd.nrhs) chol_syrk_body(D, st, wi, wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B);
+    return;
+  }
+  if (bx == 0) {
+    // ------------------------------------------------------------------------------------------------ the chain
+    double (*s_L)[NB + 1] = (double (*)[NB + 1])s_dyn;
+    double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
+    double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
+    double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
+    double (*s_Lp)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
+    double* s_share = s_dyn + 5 * NB * (NB + 1);
+    double (*s_T)[64] = (double (*)[64])(s_dyn + 6 * NB * (NB + 1));
+    __shared__ int s_fail, s_arrive, s_arrive2, s_grp;
+    {
+      const size_t d0 = (size_t)jb0 * NB;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(d0 + r) * np + d0 + c] : 0.0; }
+    }
+    if (tid == 0) { s_fail = 0; s_arrive = 0; s_arrive2 = 0; s_grp = 0; }
+    const int di = (w == 1) ? 0 : 1, dj = (w == 3) ? 1 : 0;
+    const int ai = (w <= 1) ? 0 : 1;
+    int n_grp = 0;
+    __syncthreads();
+    for (int k = jb0; k < kend; k++) {
+      const bool upd = k > jb0, next = k + 1 < nb, nextD = next && k + 1 < kend;
+      const int kr = k - jb0;
+      double c2[4] = {0.0, 0.0, 0.0, 0.0};
+      double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (tid < 64) {
+        const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
+        if (fail && tid == 0) s_fail = 1;
+      } else if (next) {
+        bool ok = true;
+        if (upd) ok = cp_wait(flags, FIN + k + 1, 1);
+        if (!ok) s_fail = 2;
+        const size_t rb = (size_t)(k + 1) * NB;
+        for (int i = tid - 64; i < NB * NB; i += 192) {
+          const int r = i / NB, c = i % NB;
+          s_A1[r][c] = ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]);
+          s_Lp[r][c] = upd ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+        }
+        if (nextD) {
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
+            c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        n_grp += 3;
+        if (lane == 0) __hip_atomic_fetch_add(&s_grp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int it = 0; it < CP_SPIN_CAP && __hip_atomic_load(&s_grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_grp; it++) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) a[ks] = s_A1[16 * ai + li][4 * ks + lk];
+        if (upd) {
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], -s_Lp[16 * ai + li][4 * ks + lk], acc, 0, 0, 0);
+            a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+          }
+        }
+        if (w == 1) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) s_share[lane * 8 + ks] = a[ks];
+        }
+      }
+      __syncthreads();
+      if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      {
+        double* Di = Dinv + (size_t)k * NB * NB;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; st_sc1(&Di[i], s_X[i / NB][i % NB]); }
+      }
+      if (next) {
+        if (w == 0) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) a[ks] = s_share[lane * 8 + ks];
+        }
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], s_X[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
+        const size_t rb = (size_t)(k + 1) * NB;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * kr + 3) cp_set(flags, CP_XREADY, k + 1);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
+        __syncthreads();
+        if (w >= 1 && nextD) {
+          double4_t a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * di + li][4 * ks + lk], s_P[16 * dj + li][4 * ks + lk], a2, 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
+            if (c <= r) s_L[r][c] = c2[rg] - a2[rg];
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * kr + 3) cp_set(flags, BP_LREADY + k + 1, k + 1);
+      }
+      if (!next) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // -------------------------------------------------------------------------------------------------- a row
+  const int nrow = max(nb - (jb0 + 2), 0);
+  int irow; bool is_rhs = false;
+  if (bx <= nrow) irow = jb0 + 1 + bx;                          // bx 1 -> row jb0 + 2
+  else if (bx == nrow + 1) { irow = nb; is_rhs = true; }
+  else return;
+  const size_t r0 = is_rhs ? (size_t)np : (size_t)irow * NB;
+  double (*s_Lc)[NB + 1] = (double (*)[NB + 1])s_dyn;
+  double (*s_Lq)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
+  double (*s_A)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
+  double (*s_Xj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
+  double (*s_Pj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
+  __shared__ int s_dead;
+  if (tid == 0) s_dead = 0;
+  __syncthreads();
+  const int arow = 16 * ti + li;
+  const int jend = is_rhs ? kend : min(kend, irow - 1);         // the producer's steps of this block: j <= i - 2 (the chain forms L(i, i-1))
+  for (int j = jb0; j < jend; j++) {
+    const bool upd = j > jb0;
+    bool ok = true;
+    if (upd) ok = cp_wait(flags, BP_LREADY + j, j);             // P_j = L(j, j-1) is published
+    double va[4], vp[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = tid + 256 * u, r = idx / NB, c = idx % NB;
+      va[u] = (ok && (is_rhs ? r == 0 : true)) ? ld_sc1(&S[(r0 + r) * np + (size_t)j * NB + c]) : 0.0;
+      vp[u] = (ok && upd) ? ld_sc1(&S[((size_t)j * NB + r) * np + (size_t)(j - 1) * NB + c]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u, r = idx / NB, c = idx % NB; s_A[r][c] = va[u]; s_Pj[r][c] = vp[u]; }
+    __syncthreads();
+    double a[8], b[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) a[ks] = s_A[arow][4 * ks + lk];
+    if (upd) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_Pj[16 * t + li][4 * ks + lk], -s_Lq[arow][4 * ks + lk], acc, 0, 0, 0);
+        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+      }
+    }
+    if (ok) ok = cp_wait(flags, CP_XREADY, j + 1);
+    double vx[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) vx[u] = ok ? ld_sc1(&Dinv[(size_t)j * NB * NB + tid + 256 * u]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vx[u]; }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) b[ks] = s_Xj[16 * tj + li][4 * ks + lk];
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
+      s_Lc[r][c] = acc[rg];
+      if (ok && (is_rhs ? r == 0 : true)) st_sc1(&S[(r0 + r) * np + (size_t)j * NB + c], acc[rg]);
+    }
+    if (!ok) s_dead = 1;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    if (tid == 0) cp_set(flags, BP_LREADY + irow, j + 1);
+    // update j of this row's tiles inside the block (k_chol_la's role B confined by c_cap): column blocks j + 2 .. kend - 1, not beyond the diagonal
+    if (!is_rhs) {
+      double la[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) la[ks] = s_Lc[16 * ti + li][4 * ks + lk];
+      for (int c = j + 2; c < kend && c <= irow; c++) {
+        const size_t cb = (size_t)c * NB;
+        bool okc = true;
+        if (c < irow) okc = cp_wait(flags, BP_LREADY + c, j + 1);
+        double vb[4], cpre[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vb[u] = (okc && c < irow) ? ld_sc1(&S[(cb + idx / NB) * np + (size_t)j * NB + idx % NB]) : 0.0; }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) cpre[rg] = okc ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + cb + 16 * tj + (lane & 15)]) : 0.0;
+        __syncthreads();                                        // (s_Xj is free again: everybody has its X operands)
+        if (c < irow) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vb[u]; }
+        }
+        __syncthreads();
+        double4_t u4 = {0.0, 0.0, 0.0, 0.0};
+        if (c < irow) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_Xj[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_Lc[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = cb + 16 * tj + (lane & 15);
+          if (okc && col <= row) st_sc1(&S[row * np + col], cpre[rg] - u4[rg]);
+        }
+        if (!okc) s_dead = 1;
+      }
+    } else {
+      double* zrow = S + (size_t)np * np;
+      for (int cc = (j + 2) * NB + tid; cc < kend * NB; cc += 256) {
+        if (!cp_wait(flags, BP_LREADY + cc / NB, j + 1)) { s_dead = 1; break; }
+        const double* L = S + (size_t)cc * np + (size_t)j * NB;
+        double lv[NB];
+#pragma unroll
+        for (int mm = 0; mm < NB; mm++) lv[mm] = ld_sc1(&L[mm]);
+        const double z0 = ld_sc1(&zrow[cc]);
+        double sum = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < NB; mm++) sum += lv[mm] * s_Lc[0][mm];
+        st_sc1(&zrow[cc], z0 - sum);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    // the chain needs this row once it is the next one: L(i, i-2) and the row's tiles in the column blocks i - 1 and i are final
+    if (tid == 0 && !is_rhs && j == irow - 2) cp_set(flags, FIN + irow, 1);
+    { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
+  }
+}
+
 // backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
 // of 256 rows processed from the bottom: k_chol_bsolve_diag solves one super-block with a single 1024-thread
 // workgroup, then k_chol_bsolve_update subtracts its contribution from every earlier entry with many workgroups
@@ -2684,7 +2958,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.erase = in.cam_local ? H.alloc<unsigned char>(std::max(nobs, 1), &rc) : nullptr;
   D.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
   D.Dinv = H.alloc<double>((size_t)npad * NB, &rc);
-  D.Mb = H.alloc<double>((size_t)npad * NB, &rc); D.cflags = H.alloc<int>(256 /* CP_NFLAGS */, &rc);
+  D.Mb = H.alloc<double>((size_t)npad * NB, &rc); D.cflags = H.alloc<int>(std::max(256 /* CP_NFLAGS */, 2 * (npad / NB + 2) + 8), &rc);
   D.part = H.alloc<double>(5 * (size_t)nparts, &rc);
   D.st = H.alloc<BaState>(1, &rc);
   if (rc) return rc;
@@ -2847,6 +3121,15 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       for (int k0 = 0; k0 < npad; k0 += OB) {
         const int kend = std::min(k0 + OB, npad);
         w.nq = w.total > 0 ? (kend - k0) / NB : 0;
+        if (use_persist && ny < 4) {
+          // one persistent launch per outer block: the chain, a workgroup per block row below, the previous block's K = 128 update
+          static const hipError_t lds_ok2 = hipFuncSetAttribute((const void*)k_chol_persist_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
+          (void)lds_ok2;
+          const int nbm = npad / NB, jb0 = k0 / NB;
+          const int rolec_base = std::max(nbm - (jb0 + 2), 0) + 2;
+          const int nC = w.total > 0 ? w.total + w.nrhs : 0;
+          hipLaunchKernelGGL(k_chol_persist_blk, dim3(rolec_base + nC, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, jb0, (kend - k0) / NB, rolec_base, w);
+        } else
         for (int k = k0, q = 0; k < kend; k += NB, q++) { w.q = q; launch_la(npad, k, k0, k0 + OB, 1, w); }
         w = no_wide;
         if (kend >= npad) break;
