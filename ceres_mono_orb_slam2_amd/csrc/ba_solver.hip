@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv
 // the right of the outer block is updated ONCE with K=128 (4x the flops per byte of C moved).  Workgroups with
 // blockIdx.x >= ntiles update the augmented rhs row (row npad) over the same column range.
 __device__ __forceinline__ void chol_syrk_body(const BaDev& D, const BaState* st, const int bx, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles,
-                                               double (*s_A)[NB + 1], double (*s_B)[NB + 1]) {
+                                               double (*s_A)[NB + 1], double (*s_B)[NB + 1], int c_rhs_min = 0) {
   const StFlags F = ld_flags(st);
   const int np = D.npad, tid = threadIdx.x;
   // batched launch: the grid and (kcol, K, r_lo, c_lo, c_hi_cap) are laid out for the LARGEST reduced system of the batch;
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void chol_syrk_body(const BaDev& D, const BaState* st
     for (int i = tid; i < K; i += 256) s_z[i] = zrow[kcol + i];
     __syncthreads();
     const int c = c_lo + (bx - ntiles) * 256 + tid;
-    if (c < c_hi) {
+    if (c < c_hi && c >= c_rhs_min) {
       const double* L = S + (size_t)c * np + kcol;
       double sum = 0.0;
       for (int m = 0; m < K; m++) sum += L[m] * s_z[m];
@@ -1847,7 +1847,138 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
 // Flags carry ABSOLUTE step numbers and are never reset between the launches of a factorisation.  Arithmetic = the step
 // kernels' operation for operation: batched calls (>= 4 problems, k_chol_la) stay bit-identical to single ones.
 #define BP_LREADY 2
-__global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restrict__ Dv, int jb0, int ns, int rolec_base, CholWide wd) {
+struct BlkGeo { int jb0, ns, base, kend, nend, tcn, n_tiles_n, n_rhs_n, n_tiles_c; };     // (blocks of NB; host values = the largest problem of the launch)
+// One 64 x 64 tile of the NEXT outer block's columns: the previous outer block's K = 128 update of it (role C's share, if any),
+// then THIS block's, stage by stage as its panels are published - two chol_syrk_body passes operation for operation (the
+// intermediate tile stays in registers), so that the next launch's chain finds its columns complete when this one ends.
+__device__ __forceinline__ void chol_tile_next(const BaDev& D, const int* flags, int r0, int c0, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns,
+                                               double (*s_A)[NB + 1], double (*s_B)[NB + 1]) {
+  const int np = D.npad, nb = np / NB, tid = threadIdx.x;
+  if (r0 + 63 < c0 || r0 >= np || c0 >= c_hi) return;
+  double* S = D.S;
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int qr = (w >> 1) * 32, qc = (w & 1) * 32;
+  const bool qskip = (r0 + qr + 31 < c0 + qc);
+  double cpre[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
+        const int col = c0 + qc + 16 * j + (lane & 15);
+        cpre[i][j][rg] = (!qskip && row < np && col < c_hi && col <= row) ? S[(size_t)row * np + col] : 0.0;
+      }
+  double4_t acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  };
+  auto stage_mma = [&]() {
+    if (qskip) return;
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
+#pragma unroll
+      for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  double va[8], vb[8];
+  if (has_prev) {
+    zero_acc();
+    for (int k0 = 0; k0 < k_prev; k0 += NB) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = tid + 256 * u, r = i / NB, c = i % NB;
+        va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol_prev + k0 + c] : 0.0;
+        vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol_prev + k0 + c] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
+      __syncthreads();
+      stage_mma();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) cpre[i][j][rg] = cpre[i][j][rg] - acc[i][j][rg];
+  }
+  zero_acc();
+  const int rb0 = r0 / NB, cb0 = c0 / NB;
+  for (int q = 0; q < ns; q++) {
+    const int need = jb0 + q + 1;                               // L(x, jb0 + q) is published
+    bool ok = cp_wait(flags, BP_LREADY + rb0, need) && cp_wait(flags, BP_LREADY + cb0, need);
+    if (ok && rb0 + 1 < nb) ok = cp_wait(flags, BP_LREADY + rb0 + 1, need);
+    if (ok && cb0 + 1 < nb && (c0 + NB) < c_hi) ok = cp_wait(flags, BP_LREADY + cb0 + 1, need);
+    if (__syncthreads_count(!ok)) return;                       // (failed factorisation: the step is rejected, nothing more to do)
+    const size_t kc = (size_t)(jb0 + q) * NB;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = tid + 256 * u, r = i / NB, c = i % NB;
+      va[u] = (r0 + r < np) ? ld_sc1(&S[(size_t)(r0 + r) * np + kc + c]) : 0.0;
+      vb[u] = (c0 + r < c_hi) ? ld_sc1(&S[(size_t)(c0 + r) * np + kc + c]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
+    __syncthreads();
+    stage_mma();
+  }
+  if (qskip) return;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
+        const int col = c0 + qc + 16 * j + (lane & 15);
+        if (row < np && col < c_hi && col <= row) S[(size_t)row * np + col] = cpre[i][j][rg] - acc[i][j][rg];
+      }
+}
+// the augmented rhs row's entries of the next outer block's columns, the same two updates (sequential mul / add per column)
+__device__ __forceinline__ void chol_rhs_next(const BaDev& D, const int* flags, int c, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns, double* s_z) {
+  const int np = D.npad, nb = np / NB, tid = threadIdx.x;
+  double* S = D.S;
+  double* zrow = S + (size_t)np * np;
+  const bool mine = c < c_hi;
+  double zv = mine ? zrow[c] : 0.0;
+  if (has_prev) {
+    for (int i = tid; i < k_prev; i += 256) s_z[i] = zrow[kcol_prev + i];
+    __syncthreads();
+    if (mine) {
+      const double* L = S + (size_t)c * np + kcol_prev;
+      double sum = 0.0;
+      for (int m = 0; m < k_prev; m++) sum += L[m] * s_z[m];
+      zv -= sum;
+    }
+  }
+  const int kend = jb0 + ns, K = ns * NB;
+  bool ok = cp_wait(flags, BP_LREADY + nb, kend);               // the row's own entries of this block
+  if (ok && mine) ok = cp_wait(flags, BP_LREADY + c / NB, kend);
+  if (__syncthreads_count(!ok)) return;
+  for (int i = tid; i < K; i += 256) s_z[i] = ld_sc1(&zrow[(size_t)jb0 * NB + i]);
+  __syncthreads();
+  if (mine) {
+    const double* L = S + (size_t)c * np + (size_t)jb0 * NB;
+    double sum = 0.0;
+    for (int m = 0; m < K; m++) sum += ld_sc1(&L[m]) * s_z[m];
+    zrow[c] = zv - sum;
+  }
+}
+__global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restrict__ Dv, BlkGeo geo, CholWide wd) {
+  const int jb0 = geo.jb0, ns = geo.ns, rolec_base = geo.base;
   const BaDev D = Dv[blockIdx.y];
   if (D.chol_la) return;
   BaState* st = D.st;
@@ -1866,11 +1997,35 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
   const int FIN = BP_LREADY + R;                                // FINAL flags behind the LREADY flags
   if (bx >= rolec_base) {
     // ---- the previous outer block's K = 128 update of everything right of this block (role C of k_chol_la)
-    if (wd.total + wd.nrhs <= 0) return;
     double (*s_A)[NB + 1] = (double (*)[NB + 1])s_dyn;
     double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + 64 * (NB + 1));
-    const int wi = bx - rolec_base;
-    if (wi < wd.total + wd.nrhs) chol_syrk_body(D, st, wi, wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B);
+    int wi = bx - rolec_base;
+    const bool has_prev = wd.total > 0;
+    const int c_hi_n = min(geo.nend * NB, np);
+    if (wi < geo.n_tiles_n) {                                   // the next outer block's columns: the previous block's update, then this one's
+      if (geo.kend != kend) return;                             // (a smaller problem of the launch: this is its last block)
+      const int ti_n = wi / geo.tcn, tj_n = wi - ti_n * geo.tcn;
+      chol_tile_next(D, flags, geo.kend * NB + 64 * ti_n, geo.kend * NB + 64 * tj_n, c_hi_n, has_prev, wd.kcol, wd.K, jb0, ns, s_A, s_B);
+      return;
+    }
+    wi -= geo.n_tiles_n;
+    if (wi < geo.n_rhs_n) {
+      if (geo.kend != kend) return;
+      chol_rhs_next(D, flags, geo.kend * NB + 256 * wi + tid, c_hi_n, has_prev, wd.kcol, wd.K, jb0, ns, &s_A[0][0]);
+      return;
+    }
+    wi -= geo.n_rhs_n;
+    if (!has_prev) return;
+    // the rest of the previous block's update: the columns right of the next outer block
+    const int tcr = wd.tiles_c - geo.tcn;
+    if (wi < geo.n_tiles_c) {
+      if (tcr <= 0) return;
+      const int ti_c = wi / tcr, tj_c = geo.tcn + (wi - ti_c * tcr);
+      chol_syrk_body(D, st, ti_c * wd.tiles_c + tj_c, wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B);
+      return;
+    }
+    wi -= geo.n_tiles_c;
+    if (wi < wd.nrhs) chol_syrk_body(D, st, wd.total + wi, wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B, geo.n_tiles_n > 0 ? geo.nend * NB : 0);
     return;
   }
   if (bx == 0) {
@@ -3125,16 +3280,22 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
           // one persistent launch per outer block: the chain, a workgroup per block row below, the previous block's K = 128 update
           static const hipError_t lds_ok2 = hipFuncSetAttribute((const void*)k_chol_persist_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
           (void)lds_ok2;
-          const int nbm = npad / NB, jb0 = k0 / NB;
-          const int rolec_base = std::max(nbm - (jb0 + 2), 0) + 2;
-          const int nC = w.total > 0 ? w.total + w.nrhs : 0;
-          hipLaunchKernelGGL(k_chol_persist_blk, dim3(rolec_base + nC, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, jb0, (kend - k0) / NB, rolec_base, w);
+          const int nbm = npad / NB, nend_ = std::min(kend + OB, npad);
+          BlkGeo geo;
+          geo.jb0 = k0 / NB; geo.ns = (kend - k0) / NB; geo.base = std::max(nbm - (geo.jb0 + 2), 0) + 2;
+          geo.kend = kend / NB; geo.nend = nend_ / NB;
+          geo.tcn = kend < npad ? (nend_ - kend + 63) / 64 : 0;
+          geo.n_tiles_n = geo.tcn * ((npad - kend + 63) / 64);
+          geo.n_rhs_n = kend < npad ? (nend_ - kend + 255) / 256 : 0;
+          geo.n_tiles_c = w.total > 0 ? w.tiles_c * std::max(w.tiles_c - geo.tcn, 0) : 0;
+          const int nC = w.total > 0 ? geo.n_tiles_c + w.nrhs : 0;
+          hipLaunchKernelGGL(k_chol_persist_blk, dim3(geo.base + geo.n_tiles_n + geo.n_rhs_n + nC, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, geo, w);
         } else
         for (int k = k0, q = 0; k < kend; k += NB, q++) { w.q = q; launch_la(npad, k, k0, k0 + OB, 1, w); }
         w = no_wide;
         if (kend >= npad) break;
         const int nend = std::min(kend + OB, npad);
-        launch_update(s, k0, kend - k0, kend, kend, nend, kend + OB);
+        if (!(use_persist && ny < 4)) launch_update(s, k0, kend - k0, kend, kend, nend, kend + OB);      // (the persistent launch did it itself)
         if (nend < npad) {
           const int t = (npad - nend + 63) / 64;
           w.kcol = k0; w.K = kend - k0; w.lo = nend; w.tiles_c = t; w.total = t * t; w.nrhs = (npad - nend + 255) / 256;
