@@ -548,7 +548,8 @@ struct BaDev {            // device pointers of one problem
   double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
   double* Dinv;                      // inverse of every 32x32 diagonal Cholesky block [npad/32][32][32]
   double* Mb;                        // persistent Cholesky: M_k = X_k P_k of every step [npad/32][32][32]
-  int* cflags;                       // persistent Cholesky: hand-off flags of this problem [CP_NFLAGS], zeroed by k_ba_iter_begin
+  int* cflags;                       // persistent Cholesky: hand-off flags of this problem [ncflags], zeroed by k_ba_iter_begin
+  int ncflags;
   const int* blk_a; const int* blk_b; const int* blk_off; const int* pair_i; const int* pair_j; int nblk;   // Schur block pair lists
   const int* free_cams;              // [nfc] reduced column -> camera index
   double* part;                      // partial sums: [3][nparts]
@@ -727,8 +728,9 @@ __global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
   const int iteration = st->iteration, max_iters = st->max_iters;      // (all reads first: one round trip)
   const double radius = st->radius;
   if (F.done) return;
+  if (D.cflags) for (int i = threadIdx.x; i < D.ncflags; i += blockDim.x) D.cflags[i] = 0;      // (any block size; the rest is thread 0's)
+  if (threadIdx.x != 0) return;
   st->valid = 0; st->accepted = 0; st->chol_fail = 0;
-  if (D.cflags) { const int nfl = D.chol_la ? 256 /* CP_NFLAGS */ : 2 * (D.npad / 32 + 2) + 8; for (int i = 0; i < nfl; i++) D.cflags[i] = 0; }
   // StopFlagCallback (include/CeresOptimizer.h:332-349) runs after every iteration, before the iteration-cap test: the
   // host keeps copying the caller's flag into this pinned byte while the enqueued iterations drain
   if (D.stop_dev && __atomic_load_n(D.stop_dev, __ATOMIC_RELAXED)) { st->termination = 4; st->done = 1; return; }
@@ -966,6 +968,8 @@ __global__ void k_ba_pad(const BaDev* __restrict__ Dv) {
 // Phase timing of the factorisation step kernels (tools/chol_phase_prof.py builds a scratch library with -DORBHIP_CHOL_PROF):
 // wave 0 of workgroup 0 of problem 0 stamps s_memrealtime (100 MHz) at the phase boundaries; sums per step index.
 #ifdef ORBHIP_CHOL_PROF
+__device__ unsigned long long g_p2_prof[8][128];       // k_chol_persist_2l timeline (absolute s_memrealtime): see tools/chol_p2_timeline.py
+#define P2_MARK(row, idx) do { if ((threadIdx.x & 63) == 0) atomicMax(&g_p2_prof[row][(idx) & 127], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
 __device__ unsigned long long g_chol_prof[128][10];
 #define CHOL_STAMP(i) do { if (prof_on) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
                               if (threadIdx.x == 0) g_chol_prof[prof_step][i] += t_ - prof_t; prof_t = t_; } } while (0)
@@ -974,6 +978,7 @@ __device__ unsigned long long g_chol_prof[128][10];
 #else
 #define CHOL_STAMP(i) do { } while (0)
 #define CHOL_PROF_BEGIN(step) do { } while (0)
+#define P2_MARK(row, idx) do { } while (0)
 #endif
 // panel: every workgroup factors and inverts the 32x32 diagonal block redundantly in ONE wave
 // (diag_factor_invert_wave below), workgroup 0 stores L11^-1; then every wave
@@ -1846,13 +1851,181 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
 //   behind them the workgroups of the previous outer block's K = 128 update (role C of k_chol_la: every tile once).
 // Flags carry ABSOLUTE step numbers and are never reset between the launches of a factorisation.  Arithmetic = the step
 // kernels' operation for operation: batched calls (>= 4 problems, k_chol_la) stay bit-identical to single ones.
+// chol_syrk_body's tile part with the next K stage's loads issued BEFORE the matrix-core loop of the current one: the persistent
+// kernels hold one workgroup per CU (the chain role's registers), so no other workgroup hides a stage's load latency.  Same
+// operations in the same order.
+__device__ __forceinline__ void chol_syrk_tile_pf(const BaDev& D, int ti, int tj, int kcol, int K, int lo, double (*s_A)[NB + 1], double (*s_B)[NB + 1]) {
+  const int np = D.npad, tid = threadIdx.x;
+  if (kcol + K > np) return;
+  double* S = D.S;
+  const int r0 = lo + ti * 64, c0 = lo + tj * 64;
+  if (r0 + 63 < c0 || r0 >= np || c0 >= np) return;
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int qr = (w >> 1) * 32, qc = (w & 1) * 32;
+  const bool qskip = (r0 + qr + 31 < c0 + qc);
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double va[8], vb[8], cpre[2][2][4];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int i = tid + 256 * u, r = i / NB, c = i % NB;
+    va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + c] : 0.0;
+    vb[u] = (c0 + r < np) ? S[(size_t)(c0 + r) * np + kcol + c] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
+        const int col = c0 + qc + 16 * j + (lane & 15);
+        cpre[i][j][rg] = (!qskip && row < np && col < np && col <= row) ? S[(size_t)row * np + col] : 0.0;
+      }
+  for (int k0 = 0; k0 < K; k0 += NB) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
+    __syncthreads();
+    if (k0 + NB < K) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = tid + 256 * u, r = i / NB, c = i % NB;
+        va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + k0 + NB + c] : 0.0;
+        vb[u] = (c0 + r < np) ? S[(size_t)(c0 + r) * np + kcol + k0 + NB + c] : 0.0;
+      }
+    }
+    if (!qskip) {
+#pragma unroll
+      for (int kk = 0; kk < NB; kk += 4) {
+        double a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
+#pragma unroll
+        for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (qskip) return;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
+        const int col = c0 + qc + 16 * j + (lane & 15);
+        if (row < np && col < np && col <= row) S[(size_t)row * np + col] = cpre[i][j][rg] - acc[i][j][rg];
+      }
+}
+// ... and TWO vertically adjacent tiles (128 x 64) per item: the column operand of a K stage is loaded once for both, and the
+// fixed cost of an item (first loads, C tile, store) is spread over twice the matrix-core work.
+__device__ __forceinline__ void chol_syrk_tile2_pf(const BaDev& D, int ti2, int tj, int kcol, int K, int lo, double* s_raw) {
+  const int np = D.npad, tid = threadIdx.x;
+  if (kcol + K > np) return;
+  double* S = D.S;
+  const int r0 = lo + ti2 * 128, c0 = lo + tj * 64;
+  if (r0 + 127 < c0 || r0 >= np || c0 >= np) return;
+  double (*s_A0)[NB + 1] = (double (*)[NB + 1])s_raw;
+  double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_raw + 64 * (NB + 1));
+  double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_raw + 128 * (NB + 1));
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int qr = (w >> 1) * 32, qc = (w & 1) * 32;
+  const bool live1 = r0 + 64 < np;                              // the lower tile exists
+  const bool skip0 = (r0 + qr + 31 < c0 + qc), skip1 = !live1 || (r0 + 64 + qr + 31 < c0 + qc);
+  double4_t acc[2][2][2];
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[h][i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double va0[8], va1[8], vb[8], cpre[2][2][2][4];
+  auto load_stage = [&](int kc) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = tid + 256 * u, r = i / NB, c = i % NB;
+      va0[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kc + c] : 0.0;
+      va1[u] = (r0 + 64 + r < np) ? S[(size_t)(r0 + 64 + r) * np + kc + c] : 0.0;
+      vb[u] = (c0 + r < np) ? S[(size_t)(c0 + r) * np + kc + c] : 0.0;
+    }
+  };
+  load_stage(kcol);
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int row = r0 + 64 * h + qr + 16 * i + (lane >> 4) + 4 * rg;
+          const int col = c0 + qc + 16 * j + (lane & 15);
+          cpre[h][i][j][rg] = (!(h ? skip1 : skip0) && row < np && col < np && col <= row) ? S[(size_t)row * np + col] : 0.0;
+        }
+  for (int k0 = 0; k0 < K; k0 += NB) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A0[i / NB][i % NB] = va0[u]; s_A1[i / NB][i % NB] = va1[u]; s_B[i / NB][i % NB] = vb[u]; }
+    __syncthreads();
+    if (k0 + NB < K) load_stage(kcol + k0 + NB);
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      double b[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
+      if (!skip0) {
+        double a[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) a[i] = s_A0[qr + 16 * i + li][kk + lk];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[0][i][j], 0, 0, 0);
+      }
+      if (!skip1) {
+        double a[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) a[i] = s_A1[qr + 16 * i + li][kk + lk];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[1][i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if (h ? skip1 : skip0) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int row = r0 + 64 * h + qr + 16 * i + (lane >> 4) + 4 * rg;
+          const int col = c0 + qc + 16 * j + (lane & 15);
+          if (row < np && col < np && col <= row) S[(size_t)row * np + col] = cpre[h][i][j][rg] - acc[h][i][j][rg];
+        }
+  }
+}
 #define BP_LREADY 2
 struct BlkGeo { int jb0, ns, base, kend, nend, tcn, n_tiles_n, n_rhs_n, n_tiles_c; };     // (blocks of NB; host values = the largest problem of the launch)
 // One 64 x 64 tile of the NEXT outer block's columns: the previous outer block's K = 128 update of it (role C's share, if any),
 // then THIS block's, stage by stage as its panels are published - two chol_syrk_body passes operation for operation (the
 // intermediate tile stays in registers), so that the next launch's chain finds its columns complete when this one ends.
+// While the panels of a stage are not published yet (all but the last stage: that one is the block's critical path) the workgroup
+// takes tiles of the previous block's far update from the launch's queue (steal() processes one and returns false when none is left).
+template <class Steal>
 __device__ __forceinline__ void chol_tile_next(const BaDev& D, const int* flags, int r0, int c0, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns,
-                                               double (*s_A)[NB + 1], double (*s_B)[NB + 1]) {
+                                               double (*s_A)[NB + 1], double (*s_B)[NB + 1], Steal steal) {
   const int np = D.npad, nb = np / NB, tid = threadIdx.x;
   if (r0 + 63 < c0 || r0 >= np || c0 >= c_hi) return;
   double* S = D.S;
@@ -1895,17 +2068,25 @@ __device__ __forceinline__ void chol_tile_next(const BaDev& D, const int* flags,
   double va[8], vb[8];
   if (has_prev) {
     zero_acc();
-    for (int k0 = 0; k0 < k_prev; k0 += NB) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = tid + 256 * u, r = i / NB, c = i % NB;
-        va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol_prev + k0 + c] : 0.0;
-        vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol_prev + k0 + c] : 0.0;
-      }
+    for (int u = 0; u < 8; u++) {
+      const int i = tid + 256 * u, r = i / NB, c = i % NB;
+      va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol_prev + c] : 0.0;
+      vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol_prev + c] : 0.0;
+    }
+    for (int k0 = 0; k0 < k_prev; k0 += NB) {
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
       __syncthreads();
+      if (k0 + NB < k_prev) {                                   // the next stage's loads fly during this stage's matrix-core loop
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = tid + 256 * u, r = i / NB, c = i % NB;
+          va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol_prev + k0 + NB + c] : 0.0;
+          vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol_prev + k0 + NB + c] : 0.0;
+        }
+      }
       stage_mma();
     }
 #pragma unroll
@@ -1919,6 +2100,14 @@ __device__ __forceinline__ void chol_tile_next(const BaDev& D, const int* flags,
   const int rb0 = r0 / NB, cb0 = c0 / NB;
   for (int q = 0; q < ns; q++) {
     const int need = jb0 + q + 1;                               // L(x, jb0 + q) is published
+    while (q + 1 < ns) {
+      bool up = __hip_atomic_load(flags + BP_LREADY + rb0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need &&
+                __hip_atomic_load(flags + BP_LREADY + cb0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+      if (up && rb0 + 1 < nb) up = __hip_atomic_load(flags + BP_LREADY + rb0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+      if (up && cb0 + 1 < nb && (c0 + NB) < c_hi) up = __hip_atomic_load(flags + BP_LREADY + cb0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+      if (__syncthreads_and(up)) break;
+      if (!steal()) break;                                      // (nothing left to take: wait below)
+    }
     bool ok = cp_wait(flags, BP_LREADY + rb0, need) && cp_wait(flags, BP_LREADY + cb0, need);
     if (ok && rb0 + 1 < nb) ok = cp_wait(flags, BP_LREADY + rb0 + 1, need);
     if (ok && cb0 + 1 < nb && (c0 + NB) < c_hi) ok = cp_wait(flags, BP_LREADY + cb0 + 1, need);
@@ -1999,33 +2188,38 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
     // ---- the previous outer block's K = 128 update of everything right of this block (role C of k_chol_la)
     double (*s_A)[NB + 1] = (double (*)[NB + 1])s_dyn;
     double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + 64 * (NB + 1));
-    int wi = bx - rolec_base;
+    // ---- the pool: the owners of the next outer block's tiles, and whoever else fits on the device.  The rest of the previous
+    // block's K = 128 update (the columns right of the next outer block; every tile once, any order) is a QUEUE all of them draw
+    // from - the owners while their panels are not published yet, everybody until it is empty: with one workgroup per CU (the
+    // chain role's registers) a workgroup that only spins is a CU that does nothing.
+    const int wi = bx - rolec_base;
     const bool has_prev = wd.total > 0;
     const int c_hi_n = min(geo.nend * NB, np);
-    if (wi < geo.n_tiles_n) {                                   // the next outer block's columns: the previous block's update, then this one's
-      if (geo.kend != kend) return;                             // (a smaller problem of the launch: this is its last block)
-      const int ti_n = wi / geo.tcn, tj_n = wi - ti_n * geo.tcn;
-      chol_tile_next(D, flags, geo.kend * NB + 64 * ti_n, geo.kend * NB + 64 * tj_n, c_hi_n, has_prev, wd.kcol, wd.K, jb0, ns, s_A, s_B);
-      return;
-    }
-    wi -= geo.n_tiles_n;
-    if (wi < geo.n_rhs_n) {
-      if (geo.kend != kend) return;
-      chol_rhs_next(D, flags, geo.kend * NB + 256 * wi + tid, c_hi_n, has_prev, wd.kcol, wd.K, jb0, ns, &s_A[0][0]);
-      return;
-    }
-    wi -= geo.n_rhs_n;
-    if (!has_prev) return;
-    // the rest of the previous block's update: the columns right of the next outer block
     const int tcr = wd.tiles_c - geo.tcn;
-    if (wi < geo.n_tiles_c) {
-      if (tcr <= 0) return;
-      const int ti_c = wi / tcr, tj_c = geo.tcn + (wi - ti_c * tcr);
-      chol_syrk_body(D, st, ti_c * wd.tiles_c + tj_c, wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B);
-      return;
+    const int n_items = has_prev ? (tcr > 0 ? geo.n_tiles_c : 0) + wd.nrhs : 0, n_tile_items = has_prev && tcr > 0 ? geo.n_tiles_c : 0;
+    int* qctr = flags + BP_LREADY + 2 * R + jb0 / max(ns, 1);    // this launch's queue head (zeroed with the flags; one per outer block)
+    __shared__ int s_item;
+    auto steal = [&]() -> bool {
+      if (n_items <= 0) return false;
+      __syncthreads();
+      if (tid == 0) s_item = __hip_atomic_fetch_add(qctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int it = s_item;
+      if (it >= n_items) return false;
+      if (it < n_tile_items) { const int ti_c = it / tcr, tj_c = geo.tcn + (it - ti_c * tcr); chol_syrk_tile2_pf(D, ti_c, tj_c, wd.kcol, wd.K, wd.lo, s_dyn); }
+      else chol_syrk_body(D, st, wd.total + (it - n_tile_items), wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B, geo.n_tiles_n > 0 ? geo.nend * NB : 0);
+      return true;
+    };
+    if (geo.kend == kend) {                                     // (else a smaller problem of the launch: this is its last block)
+      if (wi < geo.n_tiles_n) {                                 // the next outer block's columns: the previous block's update, then this one's
+        const int ti_n = wi / geo.tcn, tj_n = wi - ti_n * geo.tcn;
+        chol_tile_next(D, flags, geo.kend * NB + 64 * ti_n, geo.kend * NB + 64 * tj_n, c_hi_n, has_prev, wd.kcol, wd.K, jb0, ns, s_A, s_B, steal);
+      } else if (wi < geo.n_tiles_n + geo.n_rhs_n) {
+        __syncthreads();
+        chol_rhs_next(D, flags, geo.kend * NB + 256 * (wi - geo.n_tiles_n) + tid, c_hi_n, has_prev, wd.kcol, wd.K, jb0, ns, &s_A[0][0]);
+      }
     }
-    wi -= geo.n_tiles_c;
-    if (wi < wd.nrhs) chol_syrk_body(D, st, wd.total + wi, wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B, geo.n_tiles_n > 0 ? geo.nend * NB : 0);
+    while (steal()) {}
     return;
   }
   if (bx == 0) {
@@ -2260,6 +2454,486 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
     if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
     // the chain needs this row once it is the next one: L(i, i-2) and the row's tiles in the column blocks i - 1 and i are final
     if (tid == 0 && !is_rhs && j == irow - 2) cp_set(flags, FIN + irow, 1);
+    { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
+  }
+}
+
+// ---- the two-level factorisation as ONE persistent launch (a single large problem, the GPU to itself) -------------------------
+// The block launches above still end 24 times per C5 factorisation: ~9 us per boundary (launch, first loads, the next block's
+// columns) on top of 4 x 9 us of steps.  Here the chain runs through all the steps and the K = 128 updates become dataflow too:
+//   workgroup 0, the CHAIN: as above, through all blocks.  At a block's last step it forms the NEXT block's first diagonal block
+//     itself (the K = 128 update of D(kend,kend): the stages accumulated over the block's steps beside the factor, the last one
+//     from the L(kend,kend-1) it has just computed) - the boundary costs the chain nothing;
+//   one workgroup per block row: L(i,j), the thin updates inside the block, and the K = 128 update of its tiles in the NEXT
+//     block's four column blocks ("near"): one K stage per step accumulated in registers, applied (cpre - acc) at the block's end;
+//   W WORKERS: the K = 128 updates of everything right of the next block ("far"), 64 x 64 tiles with a fixed owner each (tile
+//     index mod W, columns in ascending order: what is needed first comes first), one update per finished outer block; a tile's
+//     count of applied updates is its WPROG flag, which the near update (its last K = 128 update) waits for.  The owner of a
+//     diagonal tile also updates the rhs row's entries of its 64 columns.
+// Every element receives the operations of the step kernels in their order: bit-identical.  Rows wait for workers and workers
+// for rows, so ALL workgroups must be resident: the host launches this only when the kernel's occupancy x CUs covers the grid and
+// no other persistent factorisation is in flight on the device (otherwise the block launches above / the step kernels: same bits).
+__global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict__ Dv, int ns, int nworkers) {
+  const BaDev D = Dv[blockIdx.y];
+  if (D.chol_la) return;
+  BaState* st = D.st;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid || F.chol_fail) return;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const int np = D.npad, nb = np / NB, tid = threadIdx.x, bx = (int)blockIdx.x;
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ti = w >> 1, tj = w & 1;
+  double* S = D.S;
+  double* Dinv = D.Dinv;
+  int* flags = D.cflags;
+  const int R = nb + 2, FIN = BP_LREADY + R, NEAR = BP_LREADY + 2 * R, WP = BP_LREADY + 3 * R;
+  const int nt = (nb + 1) / 2;                                  // 64-row tiles per side
+  if (bx == 0) {
+    // ------------------------------------------------------------------------------------------------ the chain
+    double (*s_L)[NB + 1] = (double (*)[NB + 1])s_dyn;
+    double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
+    double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
+    double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
+    double (*s_Lp)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
+    double* s_share = s_dyn + 5 * NB * (NB + 1);
+    double (*s_T)[64] = (double (*)[64])(s_dyn + 6 * NB * (NB + 1));                  // (2048 doubles: ends inside tile slot 7)
+    double (*s_N)[NB + 1] = (double (*)[NB + 1])(s_dyn + 8 * NB * (NB + 1));
+    __shared__ int s_fail, s_arrive, s_arrive2, s_grp;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(size_t)r * np + c] : 0.0; }
+    if (tid == 0) { s_fail = 0; s_arrive = 0; s_arrive2 = 0; s_grp = 0; }
+    const int di = (w == 1) ? 0 : 1, dj = (w == 3) ? 1 : 0;
+    const int ai = (w <= 1) ? 0 : 1;
+    int n_grp = 0;
+    double4_t accD = {0.0, 0.0, 0.0, 0.0};                      // the next block's first diagonal block: K stages of its update
+    __syncthreads();
+    for (int k = 0; k < nb; k++) {
+      const int b = k / ns, jb0 = b * ns, kend = min(jb0 + ns, nb);
+      const bool upd = k > jb0, next = k + 1 < nb, last = (k == kend - 1);
+      const bool nextD = next && !last, nearD = next && last;
+      const bool has_n = kend < nb;
+      double c2[4] = {0.0, 0.0, 0.0, 0.0};
+      double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (!upd) accD = (double4_t){0.0, 0.0, 0.0, 0.0};
+      if (tid == 0) P2_MARK(0, k);                              // step start
+      if (tid < 64) {
+        const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
+        if (tid == 0) P2_MARK(1, k);                            // factor done
+        if (fail && tid == 0) s_fail = 1;
+      } else if (next) {
+        bool ok = true;
+        if (upd) ok = cp_wait(flags, FIN + k + 1, 1);           // row k + 1 has its thin updates
+        else if (b > 0) ok = cp_wait(flags, NEAR + k + 1, b);   // ... the previous block's K = 128 update
+        const bool extra = has_n && upd && !last;               // a K stage of D(kend,kend) that is not staged anyway: L(kend, k - 1)
+        if (ok && extra) ok = cp_wait(flags, BP_LREADY + kend, k);
+        if (ok && nearD && b > 0) ok = cp_wait(flags, WP + (kend / 2) * nt + kend / 2, b);
+        if (!ok) s_fail = 2;
+        if (tid == 64) P2_MARK(2, k);                           // staging waits satisfied
+        const size_t rb = (size_t)(k + 1) * NB;
+        for (int i = tid - 64; i < NB * NB; i += 192) {
+          const int r = i / NB, c = i % NB;
+          s_A1[r][c] = ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]);
+          s_Lp[r][c] = upd ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+          if (extra) s_N[r][c] = ld_sc1(&S[((size_t)kend * NB + r) * np + (size_t)(k - 1) * NB + c]);
+        }
+        if (nextD || nearD) {
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
+            c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        n_grp += 3;
+        if (lane == 0) __hip_atomic_fetch_add(&s_grp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int it = 0; it < CP_SPIN_CAP && __hip_atomic_load(&s_grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_grp; it++) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) a[ks] = s_A1[16 * ai + li][4 * ks + lk];
+        if (upd) {
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], -s_Lp[16 * ai + li][4 * ks + lk], acc, 0, 0, 0);
+            a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+          }
+        }
+        if (w == 1) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) s_share[lane * 8 + ks] = a[ks];
+        }
+        if (has_n && upd) {                                     // K stage k - 1 - jb0 of D(kend,kend): L(kend, k - 1) (at the last step that IS s_Lp)
+          double (*src)[NB + 1] = last ? s_Lp : s_N;
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(src[16 * di + li][4 * ks + lk], src[16 * dj + li][4 * ks + lk], accD, 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      {
+        double* Di = Dinv + (size_t)k * NB * NB;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; st_sc1(&Di[i], s_X[i / NB][i % NB]); }
+      }
+      if (next) {
+        if (w == 0) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) a[ks] = s_share[lane * 8 + ks];
+        }
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], s_X[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
+        const size_t rb = (size_t)(k + 1) * NB;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_XREADY, k + 1);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
+        __syncthreads();
+        if (w >= 1) {
+          if (nextD) {
+            double4_t a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * di + li][4 * ks + lk], s_P[16 * dj + li][4 * ks + lk], a2, 0, 0, 0);
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+              const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
+              if (c <= r) s_L[r][c] = c2[rg] - a2[rg];
+            }
+          } else if (nearD) {                                   // the block's last K stage, then the whole K = 128 update at once
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * di + li][4 * ks + lk], s_P[16 * dj + li][4 * ks + lk], accD, 0, 0, 0);
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+              const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
+              if (c <= r) s_L[r][c] = c2[rg] - accD[rg];
+            }
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, BP_LREADY + k + 1, k + 1);
+      }
+      if (!next) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  if (bx >= nb) {
+    // ------------------------------------------------------------------------------------------------ a worker
+    const int wk = bx - nb;
+    if (wk >= nworkers) return;
+    double (*s_A)[NB + 1] = (double (*)[NB + 1])s_dyn;
+    double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + 64 * (NB + 1));
+    double* s_z = s_dyn;
+    double* zrow = S + (size_t)np * np;
+    const int qr = (w >> 1) * 32, qc = (w & 1) * 32;
+    const int tpb = ns / 2;                                     // 64-column tiles per outer block
+    for (int b = 0; (b + 1) * ns < nb; b++) {
+      const int kend = (b + 1) * ns, kcol = b * ns * NB, K = ns * NB;
+      for (int C = (b + 2) * tpb; C < nt; C++) {
+        const int off = C * nt - C * (C - 1) / 2;
+        const int Rr = C + (((wk - off) % nworkers) + nworkers) % nworkers;
+        if (Rr >= nt) continue;                                 // (nworkers >= nt: at most one tile of a column is this worker's)
+        const int r0 = 64 * Rr, c0 = 64 * C;
+        bool ok = cp_wait(flags, BP_LREADY + 2 * Rr, kend) && cp_wait(flags, BP_LREADY + 2 * C, kend);
+        if (ok && 2 * Rr + 1 < nb) ok = cp_wait(flags, BP_LREADY + 2 * Rr + 1, kend);
+        if (ok && 2 * C + 1 < nb) ok = cp_wait(flags, BP_LREADY + 2 * C + 1, kend);
+        if (ok && Rr == C) ok = cp_wait(flags, BP_LREADY + nb, kend);
+        if (__syncthreads_count(!ok)) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+        const bool qskip = (r0 + qr + 31 < c0 + qc);
+        double va[8], vb[8], cpre[2][2][4];
+        double4_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = tid + 256 * u, r = i / NB, c = i % NB;
+          va[u] = (r0 + r < np) ? ld_sc1(&S[(size_t)(r0 + r) * np + kcol + c]) : 0.0;
+          vb[u] = (c0 + r < np) ? ld_sc1(&S[(size_t)(c0 + r) * np + kcol + c]) : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+              const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
+              const int col = c0 + qc + 16 * j + (lane & 15);
+              cpre[i][j][rg] = (!qskip && row < np && col < np && col <= row) ? ld_sc1(&S[(size_t)row * np + col]) : 0.0;
+            }
+        for (int k0 = 0; k0 < K; k0 += NB) {
+#pragma unroll
+          for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
+          __syncthreads();
+          if (k0 + NB < K) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int i = tid + 256 * u, r = i / NB, c = i % NB;
+              va[u] = (r0 + r < np) ? ld_sc1(&S[(size_t)(r0 + r) * np + kcol + k0 + NB + c]) : 0.0;
+              vb[u] = (c0 + r < np) ? ld_sc1(&S[(size_t)(c0 + r) * np + kcol + k0 + NB + c]) : 0.0;
+            }
+          }
+          if (!qskip) {
+#pragma unroll
+            for (int kk = 0; kk < NB; kk += 4) {
+              double a[2], bb[2];
+#pragma unroll
+              for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
+#pragma unroll
+              for (int j = 0; j < 2; j++) bb[j] = s_B[qc + 16 * j + li][kk + lk];
+#pragma unroll
+              for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+          }
+          __syncthreads();
+        }
+        if (!qskip) {
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+              for (int rg = 0; rg < 4; rg++) {
+                const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
+                const int col = c0 + qc + 16 * j + (lane & 15);
+                if (row < np && col < np && col <= row) st_sc1(&S[(size_t)row * np + col], cpre[i][j][rg] - acc[i][j][rg]);
+              }
+        }
+        if (Rr == C) {                                          // the rhs row's entries of these 64 columns
+          for (int i = tid; i < K; i += 256) s_z[i] = ld_sc1(&zrow[kcol + i]);
+          __syncthreads();
+          const int c = c0 + tid;
+          if (tid < 64 && c < np) {
+            const double* L = S + (size_t)c * np + kcol;
+            double sum = 0.0;
+            for (int m = 0; m < K; m++) sum += ld_sc1(&L[m]) * s_z[m];
+            st_sc1(&zrow[c], ld_sc1(&zrow[c]) - sum);
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) cp_set(flags, WP + Rr * nt + C, b + 1);
+        if (tid == 0 && C < (b + 3) * tpb) P2_MARK(4, b);       // the tiles the next near update needs
+      }
+      if (tid == 0) P2_MARK(3, b);                              // all far tiles of block b
+    }
+    return;
+  }
+  // -------------------------------------------------------------------------------------------------- a row
+  int irow; bool is_rhs = false;
+  if (bx <= nb - 2) irow = bx + 1;                              // bx 1 -> row 2
+  else { irow = nb; is_rhs = true; }
+  const size_t r0 = is_rhs ? (size_t)np : (size_t)irow * NB;
+  double (*s_Lc)[NB + 1] = (double (*)[NB + 1])s_dyn;
+  double (*s_Lq)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
+  double (*s_A)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
+  double (*s_Xj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
+  double (*s_Pj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
+  double* s_near = s_dyn + 5 * NB * (NB + 1);                   // up to four operand tiles L(c, j) of the next block's rows
+  __shared__ int s_dead;
+  if (tid == 0) s_dead = 0;
+  __syncthreads();
+  const int arow = 16 * ti + li;
+  const int jend = is_rhs ? nb : irow - 1;                      // j <= i - 2 (the chain forms L(i, i-1))
+  double4_t accN[4];
+  double zsum = 0.0;
+#pragma unroll
+  for (int t = 0; t < 4; t++) accN[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double* zrow = S + (size_t)np * np;
+  for (int j = 0; j < jend; j++) {
+    const int b = j / ns, jb0 = b * ns, kend = min(jb0 + ns, nb), nend = min(kend + ns, nb);
+    const bool upd = j > jb0, lastj = (j == kend - 1);
+    const bool near_on = kend < nb && (is_rhs || irow > kend);  // (row kend's only tile of the next block is the diagonal one: the chain's)
+    if (!upd) {
+      zsum = 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) accN[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    bool ok = true;
+    if (upd) ok = cp_wait(flags, BP_LREADY + j, j);             // P_j = L(j, j-1) is published
+    double va[4], vp[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = tid + 256 * u, r = idx / NB, c = idx % NB;
+      va[u] = (ok && (is_rhs ? r == 0 : true)) ? ld_sc1(&S[(r0 + r) * np + (size_t)j * NB + c]) : 0.0;
+      vp[u] = (ok && upd) ? ld_sc1(&S[((size_t)j * NB + r) * np + (size_t)(j - 1) * NB + c]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u, r = idx / NB, c = idx % NB; s_A[r][c] = va[u]; s_Pj[r][c] = vp[u]; }
+    __syncthreads();
+    double a[8], bq[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) a[ks] = s_A[arow][4 * ks + lk];
+    if (upd) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_Pj[16 * t + li][4 * ks + lk], -s_Lq[arow][4 * ks + lk], acc, 0, 0, 0);
+        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
+      }
+    }
+    if (ok) ok = cp_wait(flags, CP_XREADY, j + 1);
+    double vx[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) vx[u] = ok ? ld_sc1(&Dinv[(size_t)j * NB * NB + tid + 256 * u]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vx[u]; }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) bq[ks] = s_Xj[16 * tj + li][4 * ks + lk];
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], bq[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
+      s_Lc[r][c] = acc[rg];
+      if (ok && (is_rhs ? r == 0 : true)) st_sc1(&S[(r0 + r) * np + (size_t)j * NB + c], acc[rg]);
+    }
+    if (!ok) s_dead = 1;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    if (tid == 0) cp_set(flags, BP_LREADY + irow, j + 1);
+    if (tid == 0) P2_MARK(5, j);                                // L(i, j) published (latest row)
+    if (!is_rhs) {
+      double la[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) la[ks] = s_Lc[16 * ti + li][4 * ks + lk];
+      // ---- thin updates inside the block
+      for (int c = j + 2; c < kend && c <= irow; c++) {
+        const size_t cb = (size_t)c * NB;
+        bool okc = true;
+        if (c < irow) okc = cp_wait(flags, BP_LREADY + c, j + 1);
+        double vb[4], cpre[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vb[u] = (okc && c < irow) ? ld_sc1(&S[(cb + idx / NB) * np + (size_t)j * NB + idx % NB]) : 0.0; }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) cpre[rg] = okc ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + cb + 16 * tj + (lane & 15)]) : 0.0;
+        __syncthreads();
+        if (c < irow) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vb[u]; }
+        }
+        __syncthreads();
+        double4_t u4 = {0.0, 0.0, 0.0, 0.0};
+        if (c < irow) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_Xj[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_Lc[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = cb + 16 * tj + (lane & 15);
+          if (okc && col <= row) st_sc1(&S[row * np + col], cpre[rg] - u4[rg]);
+        }
+        if (!okc) s_dead = 1;
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (tid == 0 && j == irow - 2) cp_set(flags, FIN + irow, 1);
+      // ---- K stage j - jb0 of the next block's columns (<= four tiles), accumulated; applied at the block's last step
+      if (near_on) {
+        const int ntile = min(nend, irow + 1) - kend;           // tiles c = kend + t <= irow
+        bool okn = true;
+        double vn[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int c = kend + t;
+          if (t < ntile && c < irow) {
+            if (okn) okn = cp_wait(flags, BP_LREADY + c, j + 1);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vn[t][u] = okn ? ld_sc1(&S[((size_t)c * NB + idx / NB) * np + (size_t)j * NB + idx % NB]) : 0.0; }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (t < ntile && kend + t < irow) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_near[t * NB * (NB + 1) + (idx / NB) * (NB + 1) + idx % NB] = vn[t][u]; }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (t < ntile) {
+            const double* src = (kend + t < irow) ? s_near + t * NB * (NB + 1) : &s_Lc[0][0];
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) accN[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], src[(16 * tj + li) * (NB + 1) + 4 * ks + lk], accN[t], 0, 0, 0);
+          }
+        }
+        if (lastj) {
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            if (t < ntile) {
+              const int c = kend + t;
+              if (okn && b > 0) okn = cp_wait(flags, WP + (irow / 2) * nt + c / 2, b);      // the tile has the far updates of the blocks before
+              const size_t cb = (size_t)c * NB;
+#pragma unroll
+              for (int rg = 0; rg < 4; rg++) {
+                const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = cb + 16 * tj + (lane & 15);
+                if (okn && col <= row) st_sc1(&S[row * np + col], ld_sc1(&S[row * np + col]) - accN[t][rg]);
+              }
+            }
+          }
+        }
+        if (!okn) s_dead = 1;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+        if (lastj && tid == 0) cp_set(flags, NEAR + irow, b + 1);
+        if (tid == 0) P2_MARK(6, j);                            // step j complete incl. near part (latest row)
+        if (tid == 0 && irow == kend + 1) P2_MARK(7, j);        // ... the row the chain needs next
+      }
+    } else {
+      // the rhs row: thin columns, then the K stage of the next block's columns
+      for (int cc = (j + 2) * NB + tid; cc < kend * NB; cc += 256) {
+        if (!cp_wait(flags, BP_LREADY + cc / NB, j + 1)) { s_dead = 1; break; }
+        const double* L = S + (size_t)cc * np + (size_t)j * NB;
+        double lv[NB];
+#pragma unroll
+        for (int mm = 0; mm < NB; mm++) lv[mm] = ld_sc1(&L[mm]);
+        const double z0 = ld_sc1(&zrow[cc]);
+        double sum = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < NB; mm++) sum += lv[mm] * s_Lc[0][mm];
+        st_sc1(&zrow[cc], z0 - sum);
+      }
+      if (near_on) {
+        const int cc = kend * NB + tid;                         // (<= 256 columns per outer block)
+        if (cc < nend * NB) {
+          bool okn = cp_wait(flags, BP_LREADY + cc / NB, j + 1);
+          const double* L = S + (size_t)cc * np + (size_t)j * NB;
+          double lv[NB];
+#pragma unroll
+          for (int mm = 0; mm < NB; mm++) lv[mm] = okn ? ld_sc1(&L[mm]) : 0.0;
+#pragma unroll
+          for (int mm = 0; mm < NB; mm++) zsum += lv[mm] * s_Lc[0][mm];
+          if (lastj) {
+            if (okn && b > 0) okn = cp_wait(flags, WP + (cc / 64) * nt + cc / 64, b);
+            if (okn) st_sc1(&zrow[cc], ld_sc1(&zrow[cc]) - zsum);
+          }
+          if (!okn) s_dead = 1;
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    }
     { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
   }
 }
@@ -2841,7 +3515,22 @@ static thread_local bool g_batch_valid = false;
 // one non-blocking stream per host thread: independent solves issued from different threads overlap on the GPU
 static thread_local hipStream_t g_stream = nullptr;
 static thread_local int g_stream_device = -1;
-struct GraphCacheEntry { std::vector<BaDev> D; const BaDev* Dv = nullptr; hipGraphExec_t exec = nullptr; unsigned long long stamp = 0; };
+struct GraphCacheEntry { std::vector<BaDev> D; const BaDev* Dv = nullptr; hipGraphExec_t exec = nullptr; unsigned long long stamp = 0; int mode = 0; };
+// Persistent factorisations need their waiting workgroups RESIDENT (the chain waits for rows with larger block indices; the
+// one-launch two-level kernel needs its whole grid): the launches in flight on a device are accounted in workgroup slots, and a
+// solve that does not get its slots takes the step kernels instead - the results are the same bits either way.
+static std::atomic<int> g_persist_used[16];
+struct PersistLease {
+  int n = 0, dev = 0;
+  bool take(int device, int need, int cap) {
+    dev = device & 15;
+    int cur = g_persist_used[dev].load();
+    while (cur + need <= cap)
+      if (g_persist_used[dev].compare_exchange_weak(cur, cur + need)) { n = need; return true; }
+    return false;
+  }
+  ~PersistLease() { if (n) g_persist_used[dev].fetch_sub(n); }
+};
 static thread_local std::vector<GraphCacheEntry> g_graphs;      // instantiated per-iteration graphs of this thread (<= 4, LRU)
 static thread_local unsigned long long g_graph_clock = 0;
 // pinned, device-mapped byte through which the kernels see the caller's stop flag (a plain bool somewhere in host memory):
@@ -3113,7 +3802,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.erase = in.cam_local ? H.alloc<unsigned char>(std::max(nobs, 1), &rc) : nullptr;
   D.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
   D.Dinv = H.alloc<double>((size_t)npad * NB, &rc);
-  D.Mb = H.alloc<double>((size_t)npad * NB, &rc); D.cflags = H.alloc<int>(std::max(256 /* CP_NFLAGS */, 2 * (npad / NB + 2) + 8), &rc);
+  D.Mb = H.alloc<double>((size_t)npad * NB, &rc); { const int nbm = npad / NB, ntm = (nbm + 1) / 2; D.ncflags = std::max(256 /* CP_NFLAGS */, 2 + 3 * (nbm + 2) + ntm * ntm + 8); D.cflags = H.alloc<int>(D.ncflags, &rc); }
   D.part = H.alloc<double>(5 * (size_t)nparts, &rc);
   D.st = H.alloc<BaState>(1, &rc);
   if (rc) return rc;
@@ -3208,6 +3897,38 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   }
   const unsigned ny = (unsigned)nprob;
   const int npad_all = g_npad;
+  // ---- which form of the Cholesky this solve takes (0 step kernels, 1 persistent launches, 2 the one-launch two-level kernel)
+  static const int persist_max = []() { const char* e = std::getenv("ORBHIP_BA_PERSIST"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+  static const int OB = []() { const char* e = std::getenv("ORBHIP_BA_OB"); const int v = e ? atoi(e) : 128; return (v >= 64 && v <= 1024 && v % 32 == 0) ? v : 128; }();
+  PersistLease lease;
+  int persist_mode = 0, p2_workers = 0, persist_cus = 0;
+  if (persist_max > 0 && ny < 4 && B.g_npad_la <= 1024) {
+    static thread_local int cus = 0, occ2l = 0, occ1 = 0, cu_dev = -1;
+    if (cu_dev != g_stream_device) {
+      hipDeviceProp_t prop;
+      cus = hipGetDeviceProperties(&prop, g_stream_device) == hipSuccess ? prop.multiProcessorCount : 0;
+      (void)hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
+      (void)hipFuncSetAttribute((const void*)k_chol_persist_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
+      (void)hipFuncSetAttribute((const void*)k_chol_persist_2l, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2l, k_chol_persist_2l, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) occ2l = 0;
+      int oa = 0, ob = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_chol_persist, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) oa = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_chol_persist_blk, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) ob = 0;
+      occ1 = std::min(oa, ob);
+      (void)hipGetLastError();
+      cu_dev = g_stream_device;
+    }
+    persist_cus = cus * std::max(occ1, 1);
+    const int cap = cus * std::min(occ1, 2) * 9 / 10;         // resident workgroups of the persistent kernels the device holds (registers / 76 KB LDS), with a margin
+    int need = 0;
+    if (B.g_npad_la > 0) { const int nbm = B.g_npad_la / NB; int nwg = 3; for (int i = 2; i < nbm; i++) nwg += 1 + (i - 1 + CP_CH - 1) / CP_CH; need += nwg * (int)ny; }
+    if (B.g_npad_2l > 0) need += (B.g_npad_2l / NB + 2) * (int)ny;
+    // the one-launch kernel: a single large problem, outer blocks of 2 or 4 panels, the whole device
+    const int nbm2 = B.g_npad_2l / NB, ntm2 = (nbm2 + 1) / 2, cap2 = occ2l * cus * 9 / 10;
+    if (persist_max >= 2 && ny == 1 && B.g_npad_la == 0 && nbm2 >= 8 && (OB == 64 || OB == 128) && cap2 - nbm2 >= std::max(64, ntm2) && lease.take(g_stream_device, std::max(cap, 1), std::max(cap, 1))) {
+      persist_mode = 2; p2_workers = std::min(384, cap2 - nbm2);
+    } else if (need > 0 && lease.take(g_stream_device, need, cap)) persist_mode = 1;
+  }
   if (g_pad > 0) hipLaunchKernelGGL(k_ba_pad, dim3(g_pad, ny), dim3(64), 0, s, Dv);
   auto enqueue_eval = [&]() {
     hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 0);
@@ -3215,7 +3936,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     hipLaunchKernelGGL(k_ba_after_eval, dim3(1, ny), dim3(AE_TPB), 0, s, Dv);
   };
   auto enqueue_iteration = [&]() {
-    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(1), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(64), 0, s, Dv);
     const int g_zs = g_n6 > 0 ? std::min(1024, (int)((g_zero + 255) / 256)) : 0;
     hipLaunchKernelGGL(k_ba_schur_prep, dim3(g_pt + g_zs, ny), dim3(BA_TPB), 0, s, Dv, g_pt);                    // + zeroing of S
     hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
@@ -3242,18 +3963,15 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     const CholWide no_wide = {0, 0, 0, 1, 0, 0, 0, 0};
     // look-ahead scheme (reduced systems <= 1024): one launch per 32-column step, panel + the previous step's update
     // (fewer than four problems: the whole factorisation as ONE persistent launch, bit-identical to the steps; ORBHIP_BA_PERSIST=0 disables)
-    static const bool use_persist = []() { const char* e = std::getenv("ORBHIP_BA_PERSIST"); return !(e && e[0] == '0'); }();
-    if (use_persist && ny < 4 && B.g_npad_la > 0 && B.g_npad_la <= 1024) {            // (<= 32 block rows: the flag arrays; ORBHIP_BA_LA_MAX can push larger systems onto the look-ahead steps)
+    const bool use_persist = persist_mode > 0;
+    if (use_persist && B.g_npad_la > 0) {                     // (<= 32 block rows: the flag arrays; ORBHIP_BA_LA_MAX can push larger systems onto the look-ahead steps)
       const int nbm = B.g_npad_la / NB;
-      static const hipError_t lds_ok = hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
-      (void)lds_ok;
       int nwg = 3;                                            // the chain, producer + consumers of the rows 2 .. nb - 1, the rhs row's two
       for (int i = 2; i < nbm; i++) nwg += 1 + (i - 1 + CP_CH - 1) / CP_CH;
       hipLaunchKernelGGL(k_chol_persist, dim3(nwg, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv);
     } else
     for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) launch_la(npl, k, 0, INT_MAX, 0, no_wide);
     // two-level scheme (outer block = 4 panels of NB = 32) for the larger systems.
-    static const int OB = []() { const char* e = std::getenv("ORBHIP_BA_OB"); const int v = e ? atoi(e) : 128; return (v >= 64 && v <= 1024 && v % 32 == 0) ? v : 128; }();
     static const bool classic = []() { const char* e = std::getenv("ORBHIP_BA_2L_CLASSIC"); return e && e[0] == '1'; }();
     if (classic) {
       // round-1 form: panel -> thin update -> panel ... -> one wide update
@@ -3267,6 +3985,8 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
         }
         if (kend < npad) launch_update(s, k0, kend - k0, kend, kend, npad, INT_MAX);      // one wide update for everything to the right
       }
+    } else if (npad > 0 && persist_mode == 2) {
+      hipLaunchKernelGGL(k_chol_persist_2l, dim3(npad / NB + p2_workers, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, OB / NB, p2_workers);
     } else if (npad > 0) {
       // hybrid: the steps of an outer block are look-ahead launches confined to the block (the thin updates leave the serial
       // chain); of its K = 128 update only the NEXT outer block's 128 columns are a launch of their own (the chain needs
@@ -3276,10 +3996,8 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       for (int k0 = 0; k0 < npad; k0 += OB) {
         const int kend = std::min(k0 + OB, npad);
         w.nq = w.total > 0 ? (kend - k0) / NB : 0;
-        if (use_persist && ny < 4) {
+        if (use_persist) {
           // one persistent launch per outer block: the chain, a workgroup per block row below, the previous block's K = 128 update
-          static const hipError_t lds_ok2 = hipFuncSetAttribute((const void*)k_chol_persist_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
-          (void)lds_ok2;
           const int nbm = npad / NB, nend_ = std::min(kend + OB, npad);
           BlkGeo geo;
           geo.jb0 = k0 / NB; geo.ns = (kend - k0) / NB; geo.base = std::max(nbm - (geo.jb0 + 2), 0) + 2;
@@ -3287,15 +4005,18 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
           geo.tcn = kend < npad ? (nend_ - kend + 63) / 64 : 0;
           geo.n_tiles_n = geo.tcn * ((npad - kend + 63) / 64);
           geo.n_rhs_n = kend < npad ? (nend_ - kend + 255) / 256 : 0;
-          geo.n_tiles_c = w.total > 0 ? w.tiles_c * std::max(w.tiles_c - geo.tcn, 0) : 0;
-          const int nC = w.total > 0 ? geo.n_tiles_c + w.nrhs : 0;
-          hipLaunchKernelGGL(k_chol_persist_blk, dim3(geo.base + geo.n_tiles_n + geo.n_rhs_n + nC, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, geo, w);
+          geo.n_tiles_c = w.total > 0 ? ((w.tiles_c + 1) / 2) * std::max(w.tiles_c - geo.tcn, 0) : 0;      // items of two vertically adjacent tiles
+          // the pool behind the rows: the owners of the next block's tiles + as many workgroups as the device holds besides (they
+          // all draw from the queue of the previous block's far tiles)
+          const int n_items = w.total > 0 ? geo.n_tiles_c + w.nrhs : 0;
+          const int n_pool = std::max(geo.n_tiles_n + geo.n_rhs_n, std::min(n_items, persist_cus - geo.base));
+          hipLaunchKernelGGL(k_chol_persist_blk, dim3(geo.base + std::max(n_pool, 0), ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, geo, w);
         } else
         for (int k = k0, q = 0; k < kend; k += NB, q++) { w.q = q; launch_la(npad, k, k0, k0 + OB, 1, w); }
         w = no_wide;
         if (kend >= npad) break;
         const int nend = std::min(kend + OB, npad);
-        if (!(use_persist && ny < 4)) launch_update(s, k0, kend - k0, kend, kend, nend, kend + OB);      // (the persistent launch did it itself)
+        if (!use_persist) launch_update(s, k0, kend - k0, kend, kend, nend, kend + OB);      // (the persistent launch did it itself)
         if (nend < npad) {
           const int t = (npad - nend + 63) / 64;
           w.kcol = k0; w.K = kend - k0; w.lo = nend; w.tiles_c = t; w.total = t * t; w.nrhs = (npad - nend + 255) / 256;
@@ -3320,7 +4041,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   static const bool use_graph = []() { const char* e = std::getenv("ORBHIP_BA_GRAPH"); return !(e && e[0] == '0'); }();
   if (use_graph && opts->max_iterations >= 3 && !user_stop) {
     for (auto& e : g_graphs)
-      if (e.exec && e.Dv == Dv && e.D.size() == Dh.size() && std::memcmp(e.D.data(), Dh.data(), Dh.size() * sizeof(BaDev)) == 0) { gexec = e.exec; e.stamp = ++g_graph_clock; break; }
+      if (e.exec && e.Dv == Dv && e.mode == persist_mode && e.D.size() == Dh.size() && std::memcmp(e.D.data(), Dh.data(), Dh.size() * sizeof(BaDev)) == 0) { gexec = e.exec; e.stamp = ++g_graph_clock; break; }
     if (!gexec) {
       hipGraph_t graph = nullptr;
       ORBHIP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -3333,13 +4054,13 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       if (g_graphs.size() < 4) { g_graphs.emplace_back(); slot = &g_graphs.back(); }
       else { slot = &g_graphs[0]; for (auto& e : g_graphs) if (e.stamp < slot->stamp) slot = &e; }
       if (slot->exec) { ORBHIP_CHECK_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(slot->exec); }
-      slot->D = Dh; slot->Dv = Dv; slot->exec = gexec; slot->stamp = ++g_graph_clock;
+      slot->D = Dh; slot->Dv = Dv; slot->mode = persist_mode; slot->exec = gexec; slot->stamp = ++g_graph_clock;
     }
   }
   for (int it = 0; it < opts->max_iterations + 1 && !user_stop; it++) {
     // the pass after the last iteration only has to record "iteration cap reached": its first kernel does that, the other
     // ~60 launches of the graph would all fall through (0.2 ms per solve at C4 size)
-    if (it == opts->max_iterations) hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(1), 0, s, Dv);
+    if (it == opts->max_iterations) hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(64), 0, s, Dv);
     else if (gexec) ORBHIP_CHECK_HIP(hipGraphLaunch(gexec, s));
     else enqueue_iteration();
     if (stop && *stop) { __atomic_store_n(stop_host, (unsigned char)1, __ATOMIC_RELEASE); user_stop = true; }   // the device stops at its next iteration boundary
@@ -3793,6 +4514,12 @@ int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations) {
 }
 
 #ifdef ORBHIP_CHOL_PROF
+int ba_debug_p2_prof(unsigned long long* out, int reset) {       // [8][128] absolute ticks (100 MHz)
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  if (out) ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2_prof), sizeof(unsigned long long) * 8 * 128));
+  if (reset) { static unsigned long long z[8 * 128]; ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2_prof), z, sizeof(z))); }
+  return 0;
+}
 int ba_debug_chol_prof(unsigned long long* out, int reset) {     // [128][10]: ticks per phase summed over launches, [9] = launches
   ORBHIP_CHECK_HIP(hipDeviceSynchronize());
   if (out) ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_prof), sizeof(unsigned long long) * 128 * 10));

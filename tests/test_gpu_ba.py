@@ -326,6 +326,25 @@ g = synth.make_ba_graph(11, ncam=40, npts=900, nobs=4500, n_fixed=1)
 a = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(40, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
 ab, poses, pts, erase, s1, s2 = optimizer.local_bundle_adjustment(*a)
 out.append({"poses": poses.tobytes().hex(), "pts": pts.tobytes().hex(), "summary": s2, "erase": erase.tobytes().hex()})
+# two-level scheme (> 1024 unknowns): 36, 41 and 57 block rows (the last outer block with 4 / 1 / 1 steps)
+for seed, ncam, npts, nobs, fixed in ((21, 193, 3000, 16000, 1), (22, 216, 3000, 17000, 2), (23, 301, 5000, 26000, 1)):
+    g = synth.make_ba_graph(seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=fixed)
+    poses, pts, s = optimizer.global_bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"],
+                                                       g["obs_inv_sigma2"], n_iterations=4)
+    out.append({"poses": poses.tobytes().hex(), "pts": pts.tobytes().hex(), "summary": s})
+# concurrent callers: more persistent factorisations than the device holds at once must fall back, not stall
+import threading
+g = synth.make_ba_graph(31, ncam=100, npts=2000, nobs=9000, n_fixed=2)
+n = len(g["obs_cam"]); w = g["obs_inv_sigma2"].astype(np.float64); rb = np.ones(n, np.uint8)
+res = [None] * 6
+def work(i):
+    for _ in range(3):
+        poses, pts, s = optimizer.bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, rb, 5)
+    res[i] = poses.tobytes().hex() + pts.tobytes().hex() + json.dumps(s)
+th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+[t.start() for t in th]; [t.join() for t in th]
+assert all(r == res[0] for r in res), "concurrent solves differ"
+out.append({"poses": res[0], "pts": "", "summary": {"iterations": 5}})
 print("RESULT " + json.dumps(out))
 """
 
@@ -335,19 +354,23 @@ def test_persistent_cholesky_is_bit_identical():
     (k_chol_persist: chain workgroup + one workgroup per block row, flags in global memory) instead of one k_chol_la launch
     per 32-column step.  Its arithmetic is the step kernels' operation for operation, so poses, points, summaries and erase
     flags must be BIT-IDENTICAL between ORBHIP_BA_PERSIST=1 and =0 (read once per process: two subprocesses) - sizes from 1 to
-    32 block rows (42 .. 1020 unknowns), incl. one that is exactly the 1024 limit, and a two-pass LocalBA."""
+    32 block rows (42 .. 1020 unknowns), incl. one that is exactly the 1024 limit, and a two-pass LocalBA.  Larger systems
+    (two-level scheme): one persistent launch per 128-column outer block (k_chol_persist_blk, =1, the default) and the
+    one-launch kernel (k_chol_persist_2l, =2, opt-in) against the step kernels.  Six threads solving at once: a solve that does
+    not get its workgroup slots takes the step kernels - same bits, no stall."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for flag in ("1", "0"):
+    for flag in ("1", "0", "2"):
         r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root], env=dict(os.environ, ORBHIP_BA_PERSIST=flag), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
-    assert len(res[0]) == 6
-    for a, b in zip(*res):
-        assert a["summary"] == b["summary"]
-        assert a["summary"]["iterations"] >= 2
-        assert a["poses"] == b["poses"] and a["pts"] == b["pts"] and a.get("erase") == b.get("erase")
+    assert len(res[0]) == 10
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert a["summary"] == b["summary"]
+            assert a["summary"]["iterations"] >= 2
+            assert a["poses"] == b["poses"] and a["pts"] == b["pts"] and a.get("erase") == b.get("erase")
 
 
 @pytest.mark.parametrize("seed", list(range(24)))

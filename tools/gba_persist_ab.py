@@ -1,5 +1,5 @@
-"""GlobalBA on the two-level Cholesky, persistent block launches (default) vs one launch per 32-column step (ORBHIP_BA_PERSIST=0):
-results must be bit-identical; prints the time per call of both.  usage: gba_persist_ab.py [ncam npts nobs iters]"""
+"""GlobalBA on the two-level Cholesky: the one-launch persistent kernel (default, ORBHIP_BA_PERSIST=2), persistent block launches
+(=1) and one launch per 32-column step (=0): results must be bit-identical; prints the time per call of each.  usage: gba_persist_ab.py [ncam npts nobs iters]"""
 import hashlib, os, subprocess, sys
 
 _CHILD = r'''
@@ -24,17 +24,18 @@ def main():
     bad = 0
     for c in cfgs:
         out = {}
-        for mode in ("1", "0"):
+        for mode in ("2", "1", "0"):
             env = dict(os.environ, ORBHIP_BA_PERSIST=mode)
             r = subprocess.run([sys.executable, "-c", _CHILD % ((root,) + c)], env=env, capture_output=True, text=True, timeout=900)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
             if not line:
                 print(c, "mode", mode, "FAILED", r.stdout[-500:], r.stderr[-1500:]); bad += 1; continue
             out[mode] = line[0].split()
-        if len(out) == 2:
-            same = out["1"][1] == out["0"][1]
+        if len(out) == 3:
+            same = out["1"][1] == out["0"][1] == out["2"][1]
             bad += not same
-            print(c, "persistent %s ms, steps %s ms, iterations %s cost %s, identical: %s" % (out["1"][2], out["0"][2], out["1"][3], out["1"][4], same))
+            print(c, "one launch %s ms, block launches %s ms, steps %s ms, iterations %s cost %s / %s / %s, identical: %s" %
+                  (out["2"][2], out["1"][2], out["0"][2], out["1"][3], out["2"][4], out["1"][4], out["0"][4], same))
     sys.exit(1 if bad else 0)
 
 if __name__ == "__main__":
