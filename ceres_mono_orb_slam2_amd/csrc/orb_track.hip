@@ -65,20 +65,38 @@ __global__ __launch_bounds__(1024) void k_trk_prepare(const TrkIn* __restrict__ 
                                                       const orbx_keypoint* __restrict__ kps, const int32_t* __restrict__ d_count, int cap,
                                                       float* __restrict__ q_uv, float* __restrict__ q_radius, int32_t* __restrict__ q_lo,
                                                       int32_t* __restrict__ q_hi, uint8_t* __restrict__ q_valid, float* __restrict__ kps4,
-                                                      uint32_t* __restrict__ cell_off, uint32_t* __restrict__ cell_idx) {
+                                                      uint32_t* __restrict__ cell_off, uint32_t* __restrict__ cell_idx, const int nq) {
   __shared__ int s_cnt[TRK_NCELL];
   __shared__ int s_off[TRK_NCELL + 1];
   __shared__ unsigned short s_cell[TRK_MAXKP];
   __shared__ int s_w[16];
+  __shared__ unsigned short s_idx[TRK_MAXKP];
   const int tid = threadIdx.x;
   const TrkIn I = *in;
   const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
+  // every global value is requested up front (a lone workgroup pays each dependent round trip in full): the last frame's points
+  // and the frame's keypoints, up to four of each per thread
+  constexpr int PT = TRK_MAXKP / 1024;
+  uint8_t lv[PT]; double lx[PT], ly[PT], lz[PT]; int lo[PT]; orbx_keypoint kp[PT];
+#pragma unroll
+  for (int k = 0; k < PT; k++) {
+    const int i = tid + 1024 * k;
+    const bool qi = i < nq;
+    lv[k] = qi ? last_valid[i] : (uint8_t)0;
+    lx[k] = qi ? last_Xw[3 * i] : 0.0; ly[k] = qi ? last_Xw[3 * i + 1] : 0.0; lz[k] = qi ? last_Xw[3 * i + 2] : 1.0;
+    lo[k] = qi ? last_octave[i] : 0;
+    if (i < n) kp[k] = kps[i];
+  }
+  for (int c = tid; c < TRK_NCELL; c += 1024) s_cnt[c] = 0;
   // projection of the last frame's map points (src/ORBmatcher.cc:1185-1212): double camera coordinates, float from there on
-  for (int i = tid; i < I.nq; i += 1024) {
-    uint8_t v = last_valid[i];
+#pragma unroll
+  for (int k = 0; k < PT; k++) {
+    const int i = tid + 1024 * k;
+    if (i >= nq) continue;
+    uint8_t v = lv[k];
     float u = 0.f, vv = 0.f, rad = 0.f; int oc = 0;
     if (v) {
-      const double X = last_Xw[3 * i], Y = last_Xw[3 * i + 1], Z = last_Xw[3 * i + 2];
+      const double X = lx[k], Y = ly[k], Z = lz[k];
       const double cx3 = (I.R[0] * X + I.R[1] * Y + I.R[2] * Z) + I.t[0], cy3 = (I.R[3] * X + I.R[4] * Y + I.R[5] * Z) + I.t[1],
                    cz3 = (I.R[6] * X + I.R[7] * Y + I.R[8] * Z) + I.t[2];
       const float xc = (float)cx3, yc = (float)cy3;
@@ -87,18 +105,20 @@ __global__ __launch_bounds__(1024) void k_trk_prepare(const TrkIn* __restrict__ 
       u = I.K4[0] * xc * invzc + I.K4[2];
       vv = I.K4[1] * yc * invzc + I.K4[3];
       if (u < I.bounds[0] || u > I.bounds[1] || vv < I.bounds[2] || vv > I.bounds[3]) v = 0;
-      oc = last_octave[i];
-      if (oc < 0 || oc >= I.nlevels) v = 0; else rad = I.th * I.scale[oc];
+      oc = lo[k];
+      if (oc < 0 || oc >= I.nlevels) v = 0; else rad = I.th * in->scale[oc];      // (in->: a dynamic index into the private copy would put the whole struct into scratch)
     }
     q_uv[2 * i] = u; q_uv[2 * i + 1] = vv; q_radius[i] = rad; q_lo[i] = oc - 1; q_hi[i] = oc + 1; q_valid[i] = v;
   }
   // the frame: {x, y, octave, angle} of the (undistorted == raw: zero distortion) keypoints and their grid cells (src/Frame.cc:158-173, :309-320)
   const float winv = (float)FRAME_GRID_COLS / (I.bounds[1] - I.bounds[0]), hinv = (float)FRAME_GRID_ROWS / (I.bounds[3] - I.bounds[2]);
-  for (int c = tid; c < TRK_NCELL; c += 1024) s_cnt[c] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const orbx_keypoint k = kps[i];
-    kps4[4 * i] = k.x; kps4[4 * i + 1] = k.y; kps4[4 * i + 2] = (float)k.octave; kps4[4 * i + 3] = k.angle;
+#pragma unroll
+  for (int kk = 0; kk < PT; kk++) {
+    const int i = tid + 1024 * kk;
+    if (i >= n) continue;
+    const orbx_keypoint k = kp[kk];
+    *(float4*)&kps4[4 * i] = make_float4(k.x, k.y, (float)k.octave, k.angle);
     const int px = (int)roundf((k.x - I.bounds[0]) * winv), py = (int)roundf((k.y - I.bounds[2]) * hinv);
     unsigned short id = 0xFFFF;
     if (!(px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS)) { id = (unsigned short)(px * FRAME_GRID_ROWS + py); atomicAdd(&s_cnt[id], 1); }
@@ -125,21 +145,25 @@ __global__ __launch_bounds__(1024) void k_trk_prepare(const TrkIn* __restrict__ 
   for (int c = tid; c <= TRK_NCELL; c += 1024) cell_off[c] = (uint32_t)s_off[c];
   for (int c = tid; c < TRK_NCELL; c += 1024) s_cnt[c] = 0;
   __syncthreads();
-  // fill: slots by atomics, then every (tiny) list sorted by keypoint index = the reference's push_back order
+  // fill: slots by atomics, then every (tiny) list sorted by keypoint index = the reference's push_back order - in LDS, written
+  // out in one coalesced pass
   for (int i = tid; i < n; i += 1024) {
     const unsigned short id = s_cell[i];
-    if (id != 0xFFFF) cell_idx[s_off[id] + atomicAdd(&s_cnt[id], 1)] = (uint32_t)i;
+    if (id != 0xFFFF) s_idx[s_off[id] + atomicAdd(&s_cnt[id], 1)] = (unsigned short)i;
   }
   __syncthreads();
   for (int c = tid; c < TRK_NCELL; c += 1024) {
     const int b = s_off[c], e = s_off[c + 1];
     for (int i = b + 1; i < e; i++) {
-      const uint32_t v = cell_idx[i];
+      const unsigned short v = s_idx[i];
       int j = i - 1;
-      while (j >= b && cell_idx[j] > v) { cell_idx[j + 1] = cell_idx[j]; j--; }
-      cell_idx[j + 1] = v;
+      while (j >= b && s_idx[j] > v) { s_idx[j + 1] = s_idx[j]; j--; }
+      s_idx[j + 1] = v;
     }
   }
+  __syncthreads();
+  const int total = s_off[TRK_NCELL];
+  for (int i = tid; i < total; i += 1024) cell_idx[i] = (uint32_t)s_idx[i];
 }
 
 // ---- distances of the window candidates, one WAVE per query: pairs[k] = {target index (written by k_area), distance}, and the
@@ -184,25 +208,29 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
                                                      uint32_t cand_cap, const float* __restrict__ kps4, const int32_t* __restrict__ d_count, int cap,
                                                      int32_t* __restrict__ match, int32_t* __restrict__ owner, int32_t* __restrict__ obs_feat,
                                                      double* __restrict__ obs_Xw, double* __restrict__ obs_uv, float* __restrict__ obs_w,
-                                                     int32_t* __restrict__ obs_off, double* __restrict__ pose7, double* __restrict__ K4d, TrkOut* __restrict__ out, int ecap) {
+                                                     int32_t* __restrict__ obs_off, double* __restrict__ pose7, double* __restrict__ K4d, TrkOut* __restrict__ out, int ecap,
+                                                     int tcap, int force_rounds, const int nq, const int check_ori) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   __shared__ int s_taken[TRK_MAXKP];                          // index of the settled claiming query that holds the target (INT_MAX: free)
   __shared__ int s_mark[TRK_MAXKP];                           // smallest index of a claimer that stays unsettled and could still take the target
   __shared__ int s_sign[TRK_MAXKP];                           // smallest index of an unsettled claimer that PROPOSES the target
   __shared__ int s_flag[3];
   __shared__ int s_hist[TRK_HISTO], s_keep[TRK_HISTO];
-  __shared__ int s_left, s_nm, s_w[16];
+  __shared__ int s_left, s_nm, s_w[16], s_big;
   const unsigned long long tkb = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x;
-  const TrkIn I = *in;
-  const int nq = I.nq;
-  const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
-  const bool overflow = off[nq] > cand_cap;                   // (the caller re-runs with a larger candidate buffer)
+  // (nq and check_ori are arguments: nothing the setup loads depends on another load - a lone workgroup right behind a launch pays
+  // ~3 us per dependent global round trip)
+  const uint32_t off_total = off[nq];
+  const int n_dev = *d_count;
+  const bool overflow = off_total > cand_cap;                   // (the caller re-runs with a larger candidate buffer; first USED behind the batch of loads below)
+  const int n = min(max(n_dev, 0), min(cap, TRK_MAXKP));
   for (int t = tid; t < TRK_MAXKP; t += TRK_GT) { s_taken[t] = INT_MAX; s_mark[t] = INT_MAX; s_sign[t] = INT_MAX; }
   if (tid < 3) s_flag[tid] = 0;
   if (tid < TRK_HISTO) s_hist[tid] = 0;
-  if (tid == 0) { s_left = 0; s_nm = 0; }
+  if (tid == 0) { s_left = 0; s_nm = 0; s_big = 0; }
   __syncthreads();
+  if (tid == 0) out->ticks[6] = (int)(__builtin_amdgcn_s_memrealtime() - tkb);
   // Only candidates within TH_HIGH can ever be chosen or block anybody, and a window holds few of those (the true match and
   // the odd look-alike; random descriptors are 128 +- 8 bits apart; k_trk_dist compacted them in list order): they go into LDS
   // as CSR lists (a query whose list does not fit any more reads its <= TRK_LMAX entries from global memory; one with more
@@ -218,11 +246,20 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
   uint32_t* s_ent = (uint32_t*)(s_wl[1] + ((nq + 1) & ~1));    // [ecap]
   // per-query counts -> offsets (block scan over <= 4 queries per thread), work list of everything that has a candidate
   {
-    int c4[TRK_QPT], mine = 0;
+    // (every global value this block needs is requested HERE, in one go: the counts, the flags and the first four entries of each
+    // list - the loads used to be issued one by one behind the scan, a dozen dependent round trips of a lone workgroup)
+    int c4[TRK_QPT], an[TRK_QPT], qv[TRK_QPT], mine = 0;
+    uint4 e4[TRK_QPT];
 #pragma unroll
     for (int k = 0; k < TRK_QPT; k++) {
       const int q = TRK_QPT * tid + k;
-      c4[k] = (q < nq && q_valid[q] && !overflow) ? min(acc_n[q], TRK_LMAX) : 0;
+      an[k] = q < nq ? acc_n[q] : 0;
+      qv[k] = q < nq ? (int)q_valid[q] : 0;
+      e4[k] = q < nq ? *(const uint4*)(acc + (size_t)q * TRK_LMAX) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < TRK_QPT; k++) {
+      c4[k] = (qv[k] && !overflow) ? min(an[k], TRK_LMAX) : 0;
       mine += c4[k];
     }
     int inc = mine;
@@ -231,20 +268,34 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     if (lane == 63) s_w[w] = inc;
     __syncthreads();
+    if (tid == 0) out->ticks[7] = (int)(__builtin_amdgcn_s_memrealtime() - tkb);
     int base = 0;
     for (int k = 0; k < w; k++) base += s_w[k];
     int at = base + inc - mine;
 #pragma unroll
     for (int k = 0; k < TRK_QPT; k++) {
       const int q = TRK_QPT * tid + k;
+      const bool live = q < nq && qv[k] && !overflow && an[k] > 0;
+      {                                                         // work list slot: one LDS atomic per wave (a same-address atomic per LANE serialises)
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&s_left, __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (live) s_wl[0][wbase + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)q;
+      }
       if (q < nq) {
         // (bit 30: the query has more than TRK_LMAX acceptable candidates; bit 29: its map point has observations, it CLAIMS its
         // target - everything a phase needs to know about a query then comes from LDS)
-        s_coff[q] = at | ((acc_n[q] > TRK_LMAX) ? (1 << 30) : 0) | ((q_valid[q] == 1) ? (1 << 29) : 0);
-        const bool live = q_valid[q] && !overflow && acc_n[q] > 0;
+        s_coff[q] = at | ((an[k] > TRK_LMAX) ? (1 << 30) : 0) | ((qv[k] == 1) ? (1 << 29) : 0);
+        if (live && an[k] > TRK_LMAX) s_big = 1;
         s_st[q] = live ? -3 : -1;
-        if (live) s_wl[0][atomicAdd(&s_left, 1)] = (unsigned short)q;
-        if (at + c4[k] <= ecap) for (int e = 0; e < c4[k]; e++) s_ent[at + e] = acc[(size_t)q * TRK_LMAX + e];
+        if (at + c4[k] <= ecap) {
+          if (c4[k] > 0) s_ent[at] = e4[k].x;
+          if (c4[k] > 1) s_ent[at + 1] = e4[k].y;
+          if (c4[k] > 2) s_ent[at + 2] = e4[k].z;
+          if (c4[k] > 3) s_ent[at + 3] = e4[k].w;
+          for (int e = 4; e < c4[k]; e++) s_ent[at + e] = acc[(size_t)q * TRK_LMAX + e];
+        }
         at += c4[k];
       }
       if (q == nq - 1) s_coff[nq] = at;                         // (s_coff[q + 1] - s_coff[q], masked, is the list length)
@@ -274,6 +325,114 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
   };
   const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
   int rounds = 0, inner_total = 0, phase = 0, cur = 0;         // phase: counter of the rotating "anything changed?" flags
+  // ---- the common case as DATAFLOW, no rounds: what query q gets depends only on EARLIER claimers (a later query cannot change it,
+  // and a query without observations closes nothing), and only on those that list q's best candidate among the ones nobody holds
+  // yet.  With the lists inverted (target -> the claimers that list it, in LDS) every thread polls exactly those for its queries
+  // and decides the moment they are all settled - the smallest unsettled query is always ready, so this terminates; the depth is
+  // the rounds' (~10 on a dense frame) times a few LDS round trips instead of ~10 workgroup barriers per round.
+  // Needs every list in LDS; otherwise (or ORBHIP_TRACK_ROUNDS=1) the rounds below - both are the exact sequential result.
+  const int total_ent = s_coff[nq] & OFFM;
+  const bool fast = !force_rounds && !overflow && !s_big && total_ent <= ecap && total_ent <= tcap && U > 0;
+  if (fast) {
+    unsigned short* s_tl = (unsigned short*)(s_ent + ecap);     // [tcap] claimers per target
+    int* s_tcnt = s_sign; int* s_toff = s_mark;                 // (free on this path) per target: number of claimers, first entry
+    for (int t = tid; t < TRK_MAXKP; t += TRK_GT) s_tcnt[t] = 0;
+    __syncthreads();
+    for (int k = 0; k < TRK_QPT; k++) {
+      const int q = tid + TRK_GT * k;
+      if (q >= nq || s_st[q] != -3 || !claims(q)) continue;
+      const int b = s_coff[q] & OFFM, cnt = (s_coff[q + 1] & OFFM) - b;
+      for (int e = 0; e < cnt; e++) atomicAdd(&s_tcnt[s_ent[b + e] & 0xFFFFu], 1);
+    }
+    __syncthreads();
+    {                                                           // exclusive scan of the 4096 counts
+      const int c0 = TRK_QPT * tid;
+      int v[TRK_QPT], mine = 0;
+#pragma unroll
+      for (int k = 0; k < TRK_QPT; k++) { v[k] = s_tcnt[c0 + k]; mine += v[k]; }
+      int inc = mine;
+      const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+      if (lane == 63) s_w[w] = inc;
+      __syncthreads();
+      int at = inc - mine;
+      for (int k = 0; k < w; k++) at += s_w[k];
+#pragma unroll
+      for (int k = 0; k < TRK_QPT; k++) { s_toff[c0 + k] = at; at += v[k]; s_tcnt[c0 + k] = 0; }
+    }
+    __syncthreads();
+    for (int k = 0; k < TRK_QPT; k++) {
+      const int q = tid + TRK_GT * k;
+      if (q >= nq || s_st[q] != -3 || !claims(q)) continue;
+      const int b = s_coff[q] & OFFM, cnt = (s_coff[q + 1] & OFFM) - b;
+      for (int e = 0; e < cnt; e++) { const int t = (int)(s_ent[b + e] & 0xFFFFu); s_tl[s_toff[t] + atomicAdd(&s_tcnt[t], 1)] = (unsigned short)q; }
+    }
+    __syncthreads();
+    auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    if (tid == 0) out->ticks[4] = (int)(__builtin_amdgcn_s_memrealtime() - tk0);      // inverted lists built
+    bool done[TRK_QPT];
+    int left = 0, blk[TRK_QPT];                                  // blk: the unsettled predecessor the query was last seen waiting for
+#pragma unroll
+    for (int k = 0; k < TRK_QPT; k++) { const int q = tid + TRK_GT * k; done[k] = !(q < nq && s_st[q] == -3); left += done[k] ? 0 : 1; blk[k] = -1; }
+    for (int it = 0; it < (1 << 20) && left > 0; it++) {
+#pragma unroll
+      for (int k = 0; k < TRK_QPT; k++) {
+        if (done[k]) continue;
+        if (blk[k] >= 0 && ld(&s_st[blk[k]]) == -3) continue;     // still waiting for the same query: one read per poll
+        const int q = tid + TRK_GT * k;
+        const int b = s_coff[q] & OFFM, cnt = (s_coff[q + 1] & OFFM) - b;
+        // the best candidate no earlier claimer HOLDS (held = by a settled query: final); q takes it as soon as no earlier claimer
+        // that lists it is still unsettled - what happens to q's other candidates cannot change that choice
+        // (the first four entries / claimers are read side by side - independent LDS reads instead of a dependent chain per entry:
+        // the latency of this block is the latency of a link of the dependency chain)
+        int best = 256, bi = -1;
+        {
+          uint32_t v4[4]; int tk[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) v4[e] = e < cnt ? s_ent[b + e] : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; e++) tk[e] = e < cnt ? ld(&s_taken[v4[e] & 0xFFFFu]) : -1;
+#pragma unroll
+          for (int e = 0; e < 4; e++) { const int d = (int)(v4[e] >> 16); if (e < cnt && tk[e] >= q && d < best) { best = d; bi = (int)(v4[e] & 0xFFFFu); } }
+        }
+        for (int e = 4; e < cnt; e++) {
+          const uint32_t v = s_ent[b + e];
+          const int t = (int)(v & 0xFFFFu), d = (int)(v >> 16);
+          if (ld(&s_taken[t]) >= q && d < best) { best = d; bi = t; }      // (taken by a LATER query: still free for q, :1220-1221)
+        }
+        bool ready = true;
+        if (bi >= 0) {
+          const int tb = s_toff[bi], tn = s_tcnt[bi];
+          {
+            int qc4[4], st4[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) qc4[c] = c < tn ? (int)s_tl[tb + c] : INT_MAX;
+#pragma unroll
+            for (int c = 0; c < 4; c++) st4[c] = qc4[c] < q ? ld(&s_st[qc4[c]]) : 0;
+#pragma unroll
+            for (int c = 3; c >= 0; c--) if (qc4[c] < q && st4[c] == -3) { ready = false; blk[k] = qc4[c]; }
+          }
+          for (int c = 4; c < tn && ready; c++) { const int qc = s_tl[tb + c]; if (qc < q && ld(&s_st[qc]) == -3) { ready = false; blk[k] = qc; } }
+          // (a claimer that settled between the two loops may have taken bi: look again)
+          if (ready && ld(&s_taken[bi]) < q) { ready = false; blk[k] = -1; }
+        }
+        if (!ready) continue;
+        if (bi >= 0 && claims(q)) {
+          // an earlier claimer cannot hold bi (tested); a later one that took it while q, without observations ... cannot be: q claims
+          __hip_atomic_fetch_min(&s_taken[bi], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
+        __hip_atomic_store(&s_st[q], bi >= 0 ? bi : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        done[k] = true; left--;
+      }
+      inner_total++;
+      if (it == 0 && tid == 0) out->ticks[5] = (int)(__builtin_amdgcn_s_memrealtime() - tk0);      // first pass over all queries
+    }
+    rounds = 1;
+    __syncthreads();
+    U = 0;
+  }
   for (; rounds < 4096 && U > 0; rounds++) {
     const unsigned short* wl = s_wl[cur];
     // (1) proposals: the best still-available candidate of every unsettled query; claimers sign their PROPOSAL
@@ -346,7 +505,7 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
     const int q = tid + TRK_GT * k;
     if (q >= nq || st[k] < 0) continue;
     atomicAdd(&s_nm, 1);
-    if (I.check_ori) {
+    if (check_ori) {
       float rot = q_angle[q] - kps4[4 * st[k] + 3];
       if (rot < 0.0) rot += 360.0f;
       int b = (int)roundf(rot * (1.0f / TRK_HISTO));
@@ -379,7 +538,7 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
     int mres = st[k] >= 0 ? st[k] : -1;
     if (st[k] >= 0) {
       atomicMax(&s_owner[st[k]], q);
-      if (I.check_ori && !s_keep[bin[k]]) { s_dead[st[k]] = 1; mres = -2 - st[k]; atomicAdd(&s_nm, -1); }
+      if (check_ori && !s_keep[bin[k]]) { s_dead[st[k]] = 1; mres = -2 - st[k]; atomicAdd(&s_nm, -1); }
     }
     match[q] = mres;
   }
@@ -411,14 +570,14 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
     obs_Xw[3 * pos] = last_Xw[3 * q]; obs_Xw[3 * pos + 1] = last_Xw[3 * q + 1]; obs_Xw[3 * pos + 2] = last_Xw[3 * q + 2];
     obs_uv[2 * pos] = (double)kps4[4 * t]; obs_uv[2 * pos + 1] = (double)kps4[4 * t + 1];
     const int oc = (int)kps4[4 * t + 2];
-    obs_w[pos] = I.inv_sigma2[oc];
+    obs_w[pos] = in->inv_sigma2[oc];
     pos++;
   }
   if (tid == TRK_GT - 1) { obs_off[0] = 0; obs_off[1] = inc; out->nobs = inc; }
-  if (tid < 7) pose7[tid] = I.pose7[tid];
-  if (tid < 4) K4d[tid] = (double)I.K4[tid];
+  if (tid < 7) pose7[tid] = in->pose7[tid];
+  if (tid < 4) K4d[tid] = (double)in->K4[tid];
   if (tid == 0) { const unsigned long long tk3 = __builtin_amdgcn_s_memrealtime(); out->ticks[0] = (int)(tk0 - tkb); out->ticks[1] = (int)(tk1 - tk0); out->ticks[2] = (int)(tk2 - tk1); out->ticks[3] = (int)(tk3 - tk2); }
-  if (tid == 0) { out->n_keypoints = *d_count; out->nmatches = overflow ? -1 : s_nm; out->rounds = rounds + 1000 * inner_total; out->cand_total = (int32_t)off[nq]; }
+  if (tid == 0) { out->n_keypoints = n_dev; out->nmatches = overflow ? -1 : s_nm; out->rounds = rounds + 1000 * inner_total; out->cand_total = (int32_t)off_total; }
 }
 
 }  // namespace orbhip
@@ -491,7 +650,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     if ((rc = orbx_extract_batch_device(ctx, d_img, w, h, stride, (long long)stride * h, 1, d_kps, d_desc, icap, d_count, (void*)W.s))) return rc;
     const TrkIn* dI = in.dev<TrkIn>(pI);
     hipLaunchKernelGGL(k_trk_prepare, dim3(1), dim3(1024), 0, W.s, dI, in.dev<double>(pX), in.dev<int32_t>(pO), in.dev<uint8_t>(pV), d_kps, d_count, icap, d_quv, d_qr,
-                       d_qlo, d_qhi, d_qv, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>());
+                       d_qlo, d_qhi, d_qv, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>(), nq);
     if (nq > 0) {
       if ((rc = frame_area_candidates_enqueue(grid, d_kps4, d_quv, d_qr, d_qlo, d_qhi, d_qv, nq, d_cnt, d_off, (uint32_t*)d_pairs, cand_cap, 2, W.s))) return rc;
       hipLaunchKernelGGL(k_trk_dist, dim3((nq + 3) / 4), dim3(256), 0, W.s, in.dev<uint8_t>(pD), nq, d_desc, d_off, d_pairs, cand_cap, d_acc, d_accn);
@@ -499,14 +658,17 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
       ORBHIP_CHECK_HIP(hipMemsetAsync(d_off, 0, 8, W.s));
     }
     // dynamic LDS of the greedy kernel: offsets, states, proposals (ints per query), two work lists, the candidate entries
+    // (+ the inverted lists of the dataflow path: two bytes per entry behind the four of the entries themselves)
     const size_t lds_fixed = (size_t)(3 * nq + 1) * 4 + 2 * (size_t)((nq + 1) & ~1) * 2;
-    const int ecap = (int)std::min<size_t>((size_t)std::max(nq, 1) * TRK_LMAX, (size_t)(100 * 1024 - lds_fixed) / 4);
-    const size_t lds_greedy = lds_fixed + (size_t)ecap * 4 + 16;
+    const int ecap = (int)std::min<size_t>((size_t)std::max(nq, 1) * TRK_LMAX, (size_t)(100 * 1024 - lds_fixed) / 6);
+    const int tcap = ecap;
+    const size_t lds_greedy = lds_fixed + (size_t)ecap * 6 + 16;
+    static const int force_rounds = []() { const char* e = std::getenv("ORBHIP_TRACK_ROUNDS"); return (e && e[0] == '1') ? 1 : 0; }();
     static const hipError_t lds_attr = hipFuncSetAttribute((const void*)k_trk_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024 + 64);
     (void)lds_attr;
     hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(TRK_GT), lds_greedy, W.s, dI, d_qv, in.dev<float>(pA), d_acc, d_accn, in.dev<double>(pX), d_off, d_pairs, cand_cap, d_kps4, d_count, icap,
                        (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow, d_ooff, (double*)(dblk + oPose), d_K4,
-                       (TrkOut*)(dblk + oOut), ecap);
+                       (TrkOut*)(dblk + oOut), ecap, tcap, force_rounds, nq, I.check_ori);
     ORBHIP_CHECK_HIP(hipGetLastError());
     if ((rc = ba_pose_optimization_batch_device(d_K4, (double*)(dblk + oPose), d_oX, d_ouv, d_ow, d_ooff, 1, dblk + oOutl, (int32_t*)(dblk + oNin),
                                                 (ba_summary*)(dblk + oSum), (void*)W.s))) return rc;
@@ -534,7 +696,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
       const double t4 = now_us();
       t_acc[0] += t1 - t0; t_acc[1] += t2 - t1; t_acc[2] += t3 - t2; t_acc[3] += t4 - t3; t_acc[4] += t4 - t0;
       if (++t_n == 100) {
-        fprintf(stderr, "k_trk_greedy ticks (10 ns): setup %d rounds %d (%d rounds, %d sweeps) rotation+owners %d observations %d\n", T->ticks[0], T->ticks[1], T->rounds % 1000, T->rounds / 1000, T->ticks[2], T->ticks[3]);
+        fprintf(stderr, "k_trk_greedy ticks (10 ns): setup %d rounds %d (%d rounds, %d sweeps; lists inverted at %d, first pass done at %d; setup: cleared at %d, counts scanned at %d) rotation+owners %d observations %d\n", T->ticks[0], T->ticks[1], T->rounds % 1000, T->rounds / 1000, T->ticks[4], T->ticks[5], T->ticks[6], T->ticks[7], T->ticks[2], T->ticks[3]);
         fprintf(stderr, "orbt_track_with_motion_model: staging + upload enqueue %.1f us, kernel launches %.1f us, wait %.1f us, unpack %.1f us, total %.1f us\n",
                 t_acc[0] / 100, t_acc[1] / 100, t_acc[2] / 100, t_acc[3] / 100, t_acc[4] / 100);
         for (double& a : t_acc) a = 0; t_n = 0;
