@@ -10,10 +10,10 @@
 //   upload   the image, and ONE packed block with the predicted pose and the last frame's map-point arrays
 //   kernels  extractor (orb_extractor.hip, on this call's stream) -> k_trk_prepare: projection of the last frame's points with
 //            the reference's float / double mix, the current frame's {x, y, octave, angle} records and its 64 x 48 grid in the
-//            reference's push_back order (one workgroup, the keypoint COUNT is read on the device) -> window candidates
-//            (orb_frame.hip k_area) -> k_trk_dist -> k_trk_greedy: the reference's sequential, order-dependent pass as a
-//            parallel fixpoint (below), rotation histogram, slot ownership, the observation list of PoseOptimization in feature
-//            order -> k_pose_lm (ba_solver.hip)
+//            reference's push_back order (one workgroup, the keypoint COUNT is read on the device) -> k_trk_windows: window
+//            candidates + descriptor distances, the acceptable ones compacted per query -> k_trk_greedy: the reference's
+//            sequential, order-dependent pass as dataflow / a parallel fixpoint (below), rotation histogram, slot ownership, the
+//            observation list of PoseOptimization in feature order -> k_pose_lm (ba_solver.hip)
 //   download ONE block: keypoints, descriptors, matches, slot owners, outlier flags, pose, counters.
 //
 // The greedy pass on the device.  The reference walks the last frame's features in index order; query q takes the closest
@@ -65,13 +65,14 @@ __global__ __launch_bounds__(1024) void k_trk_prepare(const TrkIn* __restrict__ 
                                                       const orbx_keypoint* __restrict__ kps, const int32_t* __restrict__ d_count, int cap,
                                                       float* __restrict__ q_uv, float* __restrict__ q_radius, int32_t* __restrict__ q_lo,
                                                       int32_t* __restrict__ q_hi, uint8_t* __restrict__ q_valid, float* __restrict__ kps4,
-                                                      uint32_t* __restrict__ cell_off, uint32_t* __restrict__ cell_idx, const int nq) {
+                                                      uint32_t* __restrict__ cell_off, uint32_t* __restrict__ cell_idx, const int nq, uint32_t* __restrict__ list_total) {
   __shared__ int s_cnt[TRK_NCELL];
   __shared__ int s_off[TRK_NCELL + 1];
   __shared__ unsigned short s_cell[TRK_MAXKP];
   __shared__ int s_w[16];
   __shared__ unsigned short s_idx[TRK_MAXKP];
   const int tid = threadIdx.x;
+  if (tid == 0) *list_total = 0u;                               // (k_trk_windows' allocation counter)
   const TrkIn I = *in;
   const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
   // every global value is requested up front (a lone workgroup pays each dependent round trip in full): the last frame's points
@@ -166,37 +167,91 @@ __global__ __launch_bounds__(1024) void k_trk_prepare(const TrkIn* __restrict__ 
   for (int i = tid; i < total; i += 1024) cell_idx[i] = (uint32_t)s_idx[i];
 }
 
-// ---- distances of the window candidates, one WAVE per query: pairs[k] = {target index (written by k_area), distance}, and the
-// query's ACCEPTABLE candidates (distance <= TH_HIGH: the only ones that can ever be chosen or block anybody; a window holds
-// few of them - the true match and the odd look-alike, random descriptors are 128 +- 8 bits apart) compacted in list order:
-// acc[q][r] = target | distance << 16 for the first TRK_LMAX of them, acc_n[q] = how many there are
-__global__ __launch_bounds__(256) void k_trk_dist(const uint8_t* __restrict__ q_desc, int nq, const uint8_t* __restrict__ t_desc,
-                                                  const uint32_t* __restrict__ off, uint2* __restrict__ pairs, uint32_t cap,
-                                                  uint32_t* __restrict__ acc, int32_t* __restrict__ acc_n) {
+// ---- the window search and the distances in ONE launch (three + a scan before), one WAVE per query: Frame::GetFeaturesInArea's
+// cells in the reference's loop order (ix outer, iy inner), 64 cells at a time, every lane walks the (tiny) list of its cell;
+// pass 1 counts the hits and the ACCEPTABLE ones (distance <= TH_HIGH: the only ones that can ever be chosen or block anybody; a
+// window holds few of them - the true match and the odd look-alike, random descriptors are 128 +- 8 bits apart), pass 2 writes
+// the acceptable ones compacted in list order: acc[q][r] = target | distance << 16 for the first TRK_LMAX of them, acc_n[q] = how
+// many there are.  The full list {target, distance} is written only for the rare query with more than TRK_LMAX acceptable
+// candidates (the greedy pass walks it then): its place in `pairs` comes from an atomic counter - the lists of different queries
+// need no order among each other.
+__global__ __launch_bounds__(256) void k_trk_windows(const float* __restrict__ kps4, const uint32_t* __restrict__ cell_off, const uint32_t* __restrict__ cell_idx,
+                                                     float min_x, float min_y, float winv, float hinv, const float* __restrict__ q_xy, const float* __restrict__ q_r,
+                                                     const int* __restrict__ q_minl, const int* __restrict__ q_maxl, const uint8_t* __restrict__ q_valid, int nq,
+                                                     const uint8_t* __restrict__ q_desc, const uint8_t* __restrict__ t_desc, uint32_t* __restrict__ total,
+                                                     uint32_t* __restrict__ off, uint2* __restrict__ pairs, uint32_t cap, uint32_t* __restrict__ acc,
+                                                     int32_t* __restrict__ acc_n) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (q >= nq) return;
-  const uint32_t b = min(off[q], cap), e = min(off[q + 1], cap);
-  const uint4* a = (const uint4*)(q_desc + 32 * (size_t)q);
-  const uint4 a0 = a[0], a1 = a[1];
+  uint32_t base = 0, nbig = 0;
   int found = 0;
-  for (uint32_t base = b; base < e; base += 64) {
-    const uint32_t k = base + lane;
-    int d = 256; uint32_t t = 0;
-    if (k < e) {
-      t = pairs[k].x;
-      const uint4* tb = (const uint4*)(t_desc + 32 * (size_t)t);
-      const uint4 b0 = tb[0], b1 = tb[1];
-      d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
-          __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-      pairs[k].y = (uint32_t)d;
+  if (q_valid[q]) {
+    const float x = q_xy[2 * q], y = q_xy[2 * q + 1], r = q_r[q];
+    const int minLevel = q_minl[q], maxLevel = q_maxl[q];
+    const uint4* a = (const uint4*)(q_desc + 32 * (size_t)q);
+    const uint4 a0 = a[0], a1 = a[1];
+    const int min_cx = max(0, (int)floorf((x - min_x - r) * winv));
+    const int max_cx = min(FRAME_GRID_COLS - 1, (int)ceilf((x - min_x + r) * winv));
+    const int min_cy = max(0, (int)floorf((y - min_y - r) * hinv));
+    const int max_cy = min(FRAME_GRID_ROWS - 1, (int)ceilf((y - min_y + r) * hinv));
+    if (!(min_cx >= FRAME_GRID_COLS || max_cx < 0 || min_cy >= FRAME_GRID_ROWS || max_cy < 0) && max_cx >= min_cx && max_cy >= min_cy) {
+      const bool check = (minLevel > 0) || (maxLevel >= 0);
+      const int ny = max_cy - min_cy + 1, ncell = (max_cx - min_cx + 1) * ny;
+      auto hit = [&](uint32_t j) {
+        const float4 k = ((const float4*)kps4)[j];
+        const int oct = (int)k.z;
+        if (check) {
+          if (oct < minLevel) return false;
+          if (maxLevel >= 0 && oct > maxLevel) return false;
+        }
+        return fabsf(k.x - x) < r && fabsf(k.y - y) < r;
+      };
+      auto dist = [&](uint32_t j) {
+        const uint4* tb = (const uint4*)(t_desc + 32 * (size_t)j);
+        const uint4 b0 = tb[0], b1 = tb[1];
+        return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
+               __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+      };
+      auto cell_range = [&](int w, uint32_t& lo, uint32_t& hi) {
+        lo = 0; hi = 0;
+        if (w < ncell) { const int ix = min_cx + w / ny, iy = min_cy + w % ny; const int c = ix * FRAME_GRID_ROWS + iy; lo = cell_off[c]; hi = cell_off[c + 1]; }
+      };
+      int nhit = 0, nacc = 0;
+      for (int w0 = 0; w0 < ncell; w0 += 64) {
+        uint32_t lo, hi; cell_range(w0 + lane, lo, hi);
+        for (uint32_t e = lo; e < hi; e++) { const uint32_t j = cell_idx[e]; if (hit(j)) { nhit++; nacc += dist(j) <= TRK_TH_HIGH ? 1 : 0; } }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { nhit += __shfl_xor(nhit, o); nacc += __shfl_xor(nacc, o); }
+      const bool big = nacc > TRK_LMAX;
+      if (big) {
+        if (lane == 0) base = atomicAdd(total, (uint32_t)nhit);
+        base = __shfl(base, 0); nbig = (uint32_t)nhit;
+      }
+      int tot = 0;
+      for (int w0 = 0; w0 < ncell; w0 += 64) {
+        uint32_t lo, hi; cell_range(w0 + lane, lo, hi);
+        int mine = 0, amine = 0;
+        for (uint32_t e = lo; e < hi; e++) { const uint32_t j = cell_idx[e]; if (hit(j)) { mine++; amine += dist(j) <= TRK_TH_HIGH ? 1 : 0; } }
+        int incl = mine, aincl = amine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o), ta = __shfl_up(aincl, o); if (lane >= o) { incl += t; aincl += ta; } }
+        if (amine > 0 || (big && mine > 0)) {
+          uint32_t pos = base + (uint32_t)(tot + incl - mine);
+          int ar = found + aincl - amine;
+          for (uint32_t e = lo; e < hi; e++) {
+            const uint32_t j = cell_idx[e];
+            if (!hit(j)) continue;
+            const int d = dist(j);
+            if (big) { if (pos < cap) pairs[pos] = make_uint2(j, (uint32_t)d); pos++; }
+            if (d <= TRK_TH_HIGH) { if (ar < TRK_LMAX) acc[(size_t)q * TRK_LMAX + ar] = j | ((uint32_t)d << 16); ar++; }
+          }
+        }
+        tot += __shfl(incl, 63); found += __shfl(aincl, 63);
+      }
     }
-    const bool ok = k < e && d <= TRK_TH_HIGH;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-    const int r = found + __popcll(m & ((1ull << lane) - 1ull));
-    if (ok && r < TRK_LMAX) acc[(size_t)q * TRK_LMAX + r] = t | ((uint32_t)d << 16);
-    found += __popcll(m);
   }
-  if (lane == 0) acc_n[q] = found;
+  if (lane == 0) { acc_n[q] = found; off[2 * q] = base; off[2 * q + 1] = base + nbig; }
 }
 
 struct TrkOut { int32_t n_keypoints, nmatches, nobs, rounds, cand_total, n_inliers, pad0, pad1; int32_t ticks[8]; };
@@ -204,7 +259,7 @@ struct TrkOut { int32_t n_keypoints, nmatches, nobs, rounds, cand_total, n_inlie
 // ---- one workgroup: the order-dependent pass, rotation consistency, slot owners, PoseOptimization's observation list ----
 __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__ in, const uint8_t* __restrict__ q_valid, const float* __restrict__ q_angle,
                                                      const uint32_t* __restrict__ acc, const int32_t* __restrict__ acc_n,
-                                                     const double* __restrict__ last_Xw, const uint32_t* __restrict__ off, const uint2* __restrict__ pairs,
+                                                     const double* __restrict__ last_Xw, const uint32_t* __restrict__ off, const uint32_t* __restrict__ off_total_p, const uint2* __restrict__ pairs,
                                                      uint32_t cand_cap, const float* __restrict__ kps4, const int32_t* __restrict__ d_count, int cap,
                                                      int32_t* __restrict__ match, int32_t* __restrict__ owner, int32_t* __restrict__ obs_feat,
                                                      double* __restrict__ obs_Xw, double* __restrict__ obs_uv, float* __restrict__ obs_w,
@@ -221,7 +276,7 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
   const int tid = threadIdx.x;
   // (nq and check_ori are arguments: nothing the setup loads depends on another load - a lone workgroup right behind a launch pays
   // ~3 us per dependent global round trip)
-  const uint32_t off_total = off[nq];
+  const uint32_t off_total = *off_total_p;                      // (entries of the full lists: only queries with more than TRK_LMAX acceptable candidates have one)
   const int n_dev = *d_count;
   const bool overflow = off_total > cand_cap;                   // (the caller re-runs with a larger candidate buffer; first USED behind the batch of loads below)
   const int n = min(max(n_dev, 0), min(cap, TRK_MAXKP));
@@ -232,7 +287,7 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
   __syncthreads();
   if (tid == 0) out->ticks[6] = (int)(__builtin_amdgcn_s_memrealtime() - tkb);
   // Only candidates within TH_HIGH can ever be chosen or block anybody, and a window holds few of those (the true match and
-  // the odd look-alike; random descriptors are 128 +- 8 bits apart; k_trk_dist compacted them in list order): they go into LDS
+  // the odd look-alike; random descriptors are 128 +- 8 bits apart; k_trk_windows compacted them in list order): they go into LDS
   // as CSR lists (a query whose list does not fit any more reads its <= TRK_LMAX entries from global memory; one with more
   // than TRK_LMAX acceptable candidates walks its full list), and the rounds below run over a WORK LIST of the unsettled
   // queries that is compacted after every round - after the first round a few hundred of the ~2000 queries are left, so a
@@ -312,7 +367,7 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
   auto for_candidates = [&](int q, auto fn) {
     const int cq = s_coff[q];
     if (cq & (1 << 30)) {                                        // (rare) the full window list
-      for (uint32_t c = off[q]; c < off[q + 1]; c++) { const int t = (int)pairs[c].x, d = (int)pairs[c].y; if (d <= TRK_TH_HIGH && s_taken[t] >= q) fn(t, d); }
+      for (uint32_t c = off[2 * q]; c < off[2 * q + 1]; c++) { const int t = (int)pairs[c].x, d = (int)pairs[c].y; if (d <= TRK_TH_HIGH && s_taken[t] >= q) fn(t, d); }
       return;
     }
     const int b = cq & OFFM, cnt = (s_coff[q + 1] & OFFM) - b;
@@ -638,7 +693,8 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     float* d_quv = W.d<float>(2 * (size_t)std::max(nq, 1), &rc); float* d_qr = W.d<float>(std::max(nq, 1), &rc);
     int32_t* d_qlo = W.d<int32_t>(std::max(nq, 1), &rc); int32_t* d_qhi = W.d<int32_t>(std::max(nq, 1), &rc); uint8_t* d_qv = W.d<uint8_t>(std::max(nq, 1), &rc);
     float* d_kps4 = W.d<float>(4 * (size_t)icap, &rc);
-    int* d_cnt = W.d<int>(std::max(nq, 1), &rc); uint32_t* d_off = W.d<uint32_t>((size_t)nq + 2, &rc); uint2* d_pairs = W.d<uint2>(cand_cap, &rc);
+    uint32_t* d_off = W.d<uint32_t>(2 * (size_t)nq + 4, &rc); uint2* d_pairs = W.d<uint2>(cand_cap, &rc);
+    uint32_t* d_total = d_off + 2 * (size_t)nq + 2;
     double* d_oX = W.d<double>(3 * (size_t)icap, &rc); double* d_ouv = W.d<double>(2 * (size_t)icap, &rc); float* d_ow = W.d<float>(icap, &rc);
     int32_t* d_ooff = W.d<int32_t>(2, &rc); double* d_K4 = W.d<double>(4, &rc);
     uint32_t* d_acc = W.d<uint32_t>((size_t)std::max(nq, 1) * TRK_LMAX, &rc); int32_t* d_accn = W.d<int32_t>(std::max(nq, 1), &rc);
@@ -650,12 +706,10 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     if ((rc = orbx_extract_batch_device(ctx, d_img, w, h, stride, (long long)stride * h, 1, d_kps, d_desc, icap, d_count, (void*)W.s))) return rc;
     const TrkIn* dI = in.dev<TrkIn>(pI);
     hipLaunchKernelGGL(k_trk_prepare, dim3(1), dim3(1024), 0, W.s, dI, in.dev<double>(pX), in.dev<int32_t>(pO), in.dev<uint8_t>(pV), d_kps, d_count, icap, d_quv, d_qr,
-                       d_qlo, d_qhi, d_qv, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>(), nq);
+                       d_qlo, d_qhi, d_qv, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>(), nq, d_total);
     if (nq > 0) {
-      if ((rc = frame_area_candidates_enqueue(grid, d_kps4, d_quv, d_qr, d_qlo, d_qhi, d_qv, nq, d_cnt, d_off, (uint32_t*)d_pairs, cand_cap, 2, W.s))) return rc;
-      hipLaunchKernelGGL(k_trk_dist, dim3((nq + 3) / 4), dim3(256), 0, W.s, in.dev<uint8_t>(pD), nq, d_desc, d_off, d_pairs, cand_cap, d_acc, d_accn);
-    } else {
-      ORBHIP_CHECK_HIP(hipMemsetAsync(d_off, 0, 8, W.s));
+      hipLaunchKernelGGL(k_trk_windows, dim3((nq + 3) / 4), dim3(256), 0, W.s, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>(), grid.min_x, grid.min_y, grid.winv,
+                         grid.hinv, d_quv, d_qr, d_qlo, d_qhi, d_qv, nq, in.dev<uint8_t>(pD), d_desc, d_total, d_off, d_pairs, cand_cap, d_acc, d_accn);
     }
     // dynamic LDS of the greedy kernel: offsets, states, proposals (ints per query), two work lists, the candidate entries
     // (+ the inverted lists of the dataflow path: two bytes per entry behind the four of the entries themselves)
@@ -666,7 +720,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     static const int force_rounds = []() { const char* e = std::getenv("ORBHIP_TRACK_ROUNDS"); return (e && e[0] == '1') ? 1 : 0; }();
     static const hipError_t lds_attr = hipFuncSetAttribute((const void*)k_trk_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024 + 64);
     (void)lds_attr;
-    hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(TRK_GT), lds_greedy, W.s, dI, d_qv, in.dev<float>(pA), d_acc, d_accn, in.dev<double>(pX), d_off, d_pairs, cand_cap, d_kps4, d_count, icap,
+    hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(TRK_GT), lds_greedy, W.s, dI, d_qv, in.dev<float>(pA), d_acc, d_accn, in.dev<double>(pX), d_off, d_total, d_pairs, cand_cap, d_kps4, d_count, icap,
                        (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow, d_ooff, (double*)(dblk + oPose), d_K4,
                        (TrkOut*)(dblk + oOut), ecap, tcap, force_rounds, nq, I.check_ori);
     ORBHIP_CHECK_HIP(hipGetLastError());

@@ -106,6 +106,35 @@ def test_tracking_step_vs_oracle_composition(oracle, seed, th, kw):
         assert got["nmatches"] > 200 and got["n_inliers"] > 150
 
 
+def test_tracking_step_periodic_texture_many_lookalikes(oracle):
+    """A frame tiled with ONE 20 x 20 patch: every corner has dozens of bit-identical look-alikes inside a th = 40 window, so
+    queries hold more than 16 acceptable candidates (the full-list path of k_trk_windows / k_trk_greedy, the first-minimum rule
+    among equal distances and long chains of contested targets).  Same frame as last and current one, identity motion."""
+    from ceres_mono_orb_slam2_amd import ORBextractor, tracking
+    rng = np.random.default_rng(42)
+    patch = (rng.random((20, 20)) < 0.5).astype(np.uint8) * 170 + 40
+    patch = np.kron(patch[::4, ::4], np.ones((4, 4), np.uint8))                 # 4-pixel blocks: strong corners
+    img = np.tile(patch, (H_IMG // 20 + 1, W_IMG // 20 + 1))[:H_IMG, :W_IMG].copy()
+    img[::37, ::41] ^= 0x55                                                     # a few irregularities so that not everything ties
+    E = oracle.OracleExtractor(2000)
+    k_last, d_last = E.extract(img)
+    n = len(k_last)
+    z = np.full(n, 18.0)
+    X = np.stack([(k_last["x"] - K4[2]) / K4[0] * z, (k_last["y"] - K4[3]) / K4[1] * z, z], 1).astype(np.float64)
+    valid = np.ones(n, np.uint8); valid[rng.random(n) < 0.2] = 3
+    S = dict(img=img, E=E, X=X, desc=d_last, octave=k_last["octave"].astype(np.int32), angle=k_last["angle"].astype(np.float32), valid=valid, T=np.eye(4))
+    ex = ORBextractor(2000, 1.2, 8, 20, 7)
+    for th in (40.0, 12.0):
+        got = tracking.track_with_motion_model(ex, img, K4, BOUNDS, S["T"], X, d_last, S["octave"], S["angle"], valid, th, True)
+        exp = _expected(oracle, S, th)
+        assert np.array_equal(got["kps"], exp["kps"])
+        assert got["nmatches"] == exp["nmatches"] and np.array_equal(got["match"], exp["match"])
+        assert np.array_equal(got["owner"], exp["owner"]) and got["n_correspondences"] == exp["ncorr"]
+        assert got["n_inliers"] == exp["n_inliers"] and np.array_equal(got["outlier"], exp["outlier"])
+        print("periodic texture th %.0f: %d keypoints, %d matches, %d greedy rounds" % (th, n, got["nmatches"], got["greedy_rounds"]))
+    assert n > 500
+
+
 def test_tracking_step_degenerate_inputs(oracle):
     """No last-frame features / fewer than 3 correspondences: the frame is still extracted, the pose stays the predicted one."""
     from ceres_mono_orb_slam2_amd import ORBextractor, tracking
