@@ -207,6 +207,117 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
   }
 }
 
+// ---------------------------------------------------------------------------- k_pyr_cone (single-frame latency path)
+// The pyramid is a CHAIN: level l is resized from level l-1 (src/ORBextractor.cc:1107-1132), and one launch per level costs a
+// lone frame 7 x 4.9 us although a level is ~1 us of work (a flag-linked multi-level kernel was measured too: ~5 us per hand-off
+// through memory, 62 us).  Here ALL levels are one launch without any dependency between workgroups: a workgroup owns a
+// 32 x 8 tile of the TOP level and computes the whole cone under it - per level the bounding box of (what the level above
+// needs, the workgroup's share of the level itself), from the level below held in LDS; it writes every pixel of its boxes, so
+// neighbouring workgroups write their overlap twice - the same bytes (a pixel is one fixed function of four source pixels,
+// k_resize's arithmetic).  1.7x the arithmetic of the level launches, 1/7 of the launches.  The boxes come from the host
+// (prepare(): they depend on the geometry only).
+#ifdef ORBHIP_CONE_PROF
+__device__ unsigned long long g_cone_ticks[24];
+#define CONE_MARK(i) do { if (blockIdx.x == 77 && threadIdx.x == 0) g_cone_ticks[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CONE_MARK(i) do { } while (0)
+#endif
+#define CONE_TPB 1024     /* a lone wave per SIMD issues one instruction per ~4.5 cycles: four waves per SIMD share the work of a cone */
+#define CONE_MAXL 8        /* pyramid levels the cone kernel handles (its table registers are unrolled over the levels) */
+#define CONE_SRC_PT 12      /* bytes of the level 0 box a thread loads (all requested at once) */
+struct ConeLevel { int sw, dw, dpitch, pad; long long doff; const uint2* xtab; const int* yofs; const short* ibeta; int sh, dh; };
+struct ConeArgs { ConeLevel lv[MAX_LEVELS]; int nl, spitch0, buf0, bufk; };      // buf0 / bufk: bytes of the LDS image buffers (level 0 box / larger of the others)
+__global__ __launch_bounds__(CONE_TPB) void k_pyr_cone(ConeArgs A, const short* __restrict__ boxes, const uint8_t* __restrict__ img, uint8_t* __restrict__ pyr) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_cone[];
+  const int tid = threadIdx.x, nl = A.nl;
+  CONE_MARK(0);
+  const short* B = boxes + (size_t)blockIdx.x * nl * 4;          // [level][x0, y0, x1, y1]
+  uint8_t* s_src = s_cone;                                        // level 0 box
+  uint8_t* s_buf[2] = {s_cone + A.buf0, s_cone + A.buf0 + A.bufk};
+  uint8_t* s_tab = s_cone + A.buf0 + 2 * A.bufk;                  // per level: columns {s0 | s1 << 16, a0 | a1 << 16}, rows {o0, o1, b0, b1}
+  // ---- one batch of loads: the level 0 box and every level's table segments (rebased to the boxes).  Every value is REQUESTED
+  // before the first one is stored: a load -> LDS store loop costs a lone workgroup one global round trip per iteration.
+  {
+    uint2 tc[CONE_MAXL]; int ty[CONE_MAXL], tb[CONE_MAXL];
+#pragma unroll
+    for (int l = 1; l < CONE_MAXL; l++) {
+      tc[l] = make_uint2(0u, 0u); ty[l] = 0; tb[l] = 0;
+      if (l < nl) {
+        const ConeLevel& L = A.lv[l];
+        const int x0 = B[4 * l], y0 = B[4 * l + 1], rw = B[4 * l + 2] - x0, rh = B[4 * l + 3] - y0;      // (<= 256 each: prepare())
+        if (tid < rw) tc[l] = L.xtab[x0 + tid];
+        if (tid < rh) { ty[l] = L.yofs[y0 + tid]; tb[l] = *(const int*)(L.ibeta + 2 * (y0 + tid)); }
+      }
+    }
+    const int x0 = B[0], y0 = B[1], rw = B[2] - x0, n0 = rw * (B[3] - y0);      // (<= CONE_TPB * CONE_SRC_PT bytes: prepare())
+    uint8_t v[CONE_SRC_PT];
+#pragma unroll
+    for (int u = 0; u < CONE_SRC_PT; u++) {
+      const int p = CONE_TPB * u + tid;
+      const int y = p / rw, x = p - y * rw;
+      v[u] = p < n0 ? img[(long long)(y0 + y) * A.spitch0 + x0 + x] : (uint8_t)0;
+    }
+    CONE_MARK(1);
+#pragma unroll
+    for (int u = 0; u < CONE_SRC_PT; u++) { const int p = CONE_TPB * u + tid; if (p < n0) s_src[p] = v[u]; }
+    CONE_MARK(2);
+    int toff = 0;
+#pragma unroll
+    for (int l = 1; l < CONE_MAXL; l++) {
+      if (l < nl) {
+        const ConeLevel& L = A.lv[l];
+        const int lx0 = B[4 * l], ly0 = B[4 * l + 1], lrw = B[4 * l + 2] - lx0, lrh = B[4 * l + 3] - ly0;
+        const int px0 = B[4 * l - 4], py0 = B[4 * l - 3], prw = B[4 * l - 2] - px0;      // the box of the level below
+        uint2* cols = (uint2*)(s_tab + toff);
+        int4* rows = (int4*)(s_tab + toff + 8 * lrw);
+        if (tid < lrw) {
+          const int sx = (int)(tc[l].x & 0xFFFF), s1 = min(sx + 1, L.sw - 1);
+          cols[tid] = make_uint2((uint32_t)(sx - px0) | ((uint32_t)(s1 - px0) << 16), tc[l].y);
+        }
+        if (tid < lrh) {
+          const int sy0 = min(max(ty[l], 0), L.sh - 1), sy1 = min(max(ty[l] + 1, 0), L.sh - 1);
+          rows[tid] = make_int4((sy0 - py0) * prw, (sy1 - py0) * prw, (int)(short)(tb[l] & 0xFFFF), (int)(short)(tb[l] >> 16));
+        }
+        toff += 8 * lrw + 16 * lrh;
+      }
+    }
+  }
+  __syncthreads();
+  CONE_MARK(3);
+  // ---- level by level out of LDS
+  const uint8_t* prev = s_src;
+  int toff = 0;
+  for (int l = 1; l < nl; l++) {
+    const ConeLevel& L = A.lv[l];
+    const int x0 = B[4 * l], y0 = B[4 * l + 1], rw = B[4 * l + 2] - x0, rh = B[4 * l + 3] - y0;
+    const uint2* cols = (const uint2*)(s_tab + toff);
+    const int4* rows = (const int4*)(s_tab + toff + 8 * rw);
+    uint8_t* cur = s_buf[l & 1];
+    uint8_t* dst = pyr + L.doff;
+    const int rq = rw >> 2;
+    for (int it = tid; it < rq * rh; it += CONE_TPB) {
+      const int y = it / rq, x = (it - y * rq) * 4;
+      const int4 r = rows[y];
+      uint32_t out = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint2 c = cols[x + j];
+        const int s0 = (int)(c.x & 0xFFFF), s1 = (int)(c.x >> 16), a0 = (int)(c.y & 0xFFFF), a1 = (int)(c.y >> 16);
+        const int H0 = prev[r.x + s0] * a0 + prev[r.x + s1] * a1;
+        const int H1 = prev[r.y + s0] * a0 + prev[r.y + s1] * a1;
+        const int v = (((r.z * (H0 >> 4)) >> 16) + ((r.w * (H1 >> 4)) >> 16) + 2) >> 2;
+        if (x0 + x + j < L.dw) out |= (uint32_t)(v & 255) << (8 * j);
+      }
+      *(uint32_t*)(cur + y * rw + x) = out;
+      *(uint32_t*)(dst + (long long)(y0 + y) * L.dpitch + x0 + x) = out;
+    }
+    __syncthreads();
+    CONE_MARK(3 + l);
+    prev = cur;
+    toff += 8 * rw + 16 * rh;
+  }
+}
+
 // ---------------------------------------------------------------------------- k_fast_cells
 // FAST-9 "best" of one pixel for BOTH polarities at once with packed 16-bit min/max (v_pk_min_i16), on the RAW ring values:
 // P[k] = (ring[k], -ring[k]) as two i16 (ONE v_mul_i32_i24 by -65535: r * (1 - 2^16) = r + ((-r) << 16)).  A window minimum then
@@ -1251,6 +1362,7 @@ struct orbx_ctx {
   std::vector<BlurTile> btiles;
   DevBuf d_cells, d_btiles, d_tab;      // tables
   std::vector<size_t> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // byte offsets into d_tab per level
+  size_t tab_cone = 0; int cone_wgs = 0, cone_buf0 = 0, cone_bufk = 0; size_t cone_lds = 0;      // k_pyr_cone: boxes in d_tab, grid, LDS layout (cone_wgs == 0: not available)
   DevBuf d_pyr, d_blur, d_cellcnt, d_cellkps, d_keys, d_knode, d_sel, d_selcnt, d_nkeys, d_status, d_octnodes;
   DevBuf d_img, d_out;                     // host-API staging: image; {counts | keypoints | descriptors} in one block
   void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
@@ -1320,6 +1432,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     long long pyr_off = 0, blur_off = 0;
     int key_off = 0, tile_w = 8, tile_h = 8, cell_cap = 1, max_cells = 1, node_cap = MAX_INI + 8, sel_cap = 8, desc_blocks = 0;
     std::vector<uint8_t> tab;
+    std::vector<std::vector<int>> h_xofs, h_yofs;                 // (host copies for the cone boxes below)
     c->tab_xofs.assign(nl, 0); c->tab_ialpha.assign(nl, 0); c->tab_yofs.assign(nl, 0); c->tab_ibeta.assign(nl, 0);
     for (int l = 0; l < nl; l++) {
       LevelDev& L = G.lv[l];
@@ -1389,6 +1502,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
         double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
         std::vector<int> xofs(dw), yofs(dh);
         std::vector<short> ia(2 * dw), ib(2 * dh);
+        h_xofs.resize(nl); h_yofs.resize(nl);
         auto sat = [](int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); };
         for (int dx = 0; dx < dw; dx++) {
           float fx = (float)((dx + 0.5) * scale_x - 0.5);
@@ -1423,6 +1537,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
         c->tab_ialpha[l] = 0;
         c->tab_yofs[l] = push(yofs.data(), yofs.size() * 4);
         c->tab_ibeta[l] = push(ib.data(), ib.size() * 2);
+        h_xofs[l] = xofs; h_yofs[l] = yofs;
       }
       // blur tiles
       for (int ty = 0; ty < (L.h + BLUR_TH - 1) / BLUR_TH; ty++)
@@ -1439,6 +1554,52 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
 #ifdef ORBHIP_OCT_LEVEL_EXPERIMENT
     G.oct_level_mask = std::getenv("ORBHIP_OCT_LEVELS") ? (int)strtol(std::getenv("ORBHIP_OCT_LEVELS"), nullptr, 0) : 0xFFFF;
 #endif
+    // ---- k_pyr_cone: per 32 x 8 tile of the top level, the box it computes on every level (see the kernel)
+    c->cone_wgs = 0;
+    if (nl >= 3 && nl <= CONE_MAXL) {
+      const int top = nl - 1, TW = 32, TH = 8;
+      const int ntx = (G.lv[top].w + TW - 1) / TW, nty = (G.lv[top].h + TH - 1) / TH;
+      std::vector<short> boxes((size_t)ntx * nty * nl * 4);
+      int buf0 = 0, bufk = 0; size_t tabmax = 0; bool ok = G.lv[0].w < 32000 && G.lv[0].h < 32000;
+      for (int j = 0; j < nty && ok; j++)
+        for (int i = 0; i < ntx && ok; i++) {
+          short* Bx = &boxes[((size_t)j * ntx + i) * nl * 4];
+          int bx0 = i * TW, by0 = j * TH, bx1 = std::min((i + 1) * TW, G.lv[top].w), by1 = std::min((j + 1) * TH, G.lv[top].h);
+          size_t tb = 0;
+          for (int k = top; k >= 0; k--) {
+            const int Wk = G.lv[k].w, Hk = G.lv[k].h;
+            if (k < top) {
+              // what the box of level k + 1 reads from level k ...
+              const std::vector<int>& xo = h_xofs[k + 1]; const std::vector<int>& yo = h_yofs[k + 1];
+              const int ux0 = Bx[4 * (k + 1)], ux1 = std::min<int>(Bx[4 * (k + 1) + 2], G.lv[k + 1].w), uy0 = Bx[4 * (k + 1) + 1], uy1 = Bx[4 * (k + 1) + 3];
+              auto cy = [&](int v) { return std::min(std::max(v, 0), Hk - 1); };
+              int nx0 = xo[ux0], nx1 = std::min(xo[ux1 - 1] + 1, Wk - 1) + 1, ny0 = cy(yo[uy0]), ny1 = cy(yo[uy1 - 1] + 1) + 1;
+              for (int y = uy0; y < uy1; y++) { ny0 = std::min(ny0, cy(yo[y])); ny1 = std::max(ny1, cy(yo[y] + 1) + 1); }
+              for (int x = ux0; x < ux1; x++) { nx0 = std::min(nx0, xo[x]); nx1 = std::max(nx1, std::min(xo[x] + 1, Wk - 1) + 1); }
+              bx0 = nx0; bx1 = nx1; by0 = ny0; by1 = ny1;
+              if (k >= 1) {                                       // ... and this workgroup's share of level k itself
+                bx0 = std::min(bx0, (int)((long long)i * Wk / ntx)); bx1 = std::max(bx1, (int)((long long)(i + 1) * Wk / ntx));
+                by0 = std::min(by0, (int)((long long)j * Hk / nty)); by1 = std::max(by1, (int)((long long)(j + 1) * Hk / nty));
+              }
+            }
+            if (k >= 1) { bx0 &= ~3; bx1 = std::min(round_up(bx1, 4), round_up(Wk, 4)); }      // whole dwords, as k_resize stores them
+            Bx[4 * k] = (short)bx0; Bx[4 * k + 1] = (short)by0; Bx[4 * k + 2] = (short)bx1; Bx[4 * k + 3] = (short)by1;
+            const int bytes = (bx1 - bx0) * (by1 - by0);
+            if (k >= 1 && (bx1 - bx0 > 256 || by1 - by0 > 256)) ok = false;      // (a thread loads one table entry per level)
+            if (k == 0 && bytes > CONE_TPB * CONE_SRC_PT) ok = false;
+            if (k == 0) buf0 = std::max(buf0, bytes); else { bufk = std::max(bufk, bytes); tb += 8 * (size_t)(bx1 - bx0) + 16 * (size_t)(by1 - by0); }
+          }
+          tabmax = std::max(tabmax, tb);
+        }
+      buf0 = round_up(buf0, 16); bufk = round_up(bufk, 16);
+      const size_t lds = (size_t)buf0 + 2 * (size_t)bufk + tabmax + 64;
+      if (ok && lds <= 96 * 1024) {
+        size_t off = (tab.size() + 15) / 16 * 16;
+        tab.resize(off + boxes.size() * 2);
+        std::memcpy(tab.data() + off, boxes.data(), boxes.size() * 2);
+        c->tab_cone = off; c->cone_wgs = ntx * nty; c->cone_buf0 = buf0; c->cone_bufk = bufk; c->cone_lds = lds;
+      }
+    }
     G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
     G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
     c->fast_narrow = tile_w - 6 <= 32;                      // every cell interior <= 32 px wide: k_fast_cells<true> (32-bit row masks)
@@ -1495,8 +1656,26 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   auto mark = [&]() { if (c->profiling) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_events.push_back(e); } } };
   ORBHIP_CHECK_HIP(hipMemsetAsync(c->d_status.p, 0, (size_t)nframes * 4, st));
   mark();
-  // pyramid chain
-  for (int l = 1; l < nl; l++) {
+  // pyramid chain: a single frame takes the one-launch cone kernel (latency), batches one launch per level (throughput;
+  // ORBHIP_EXTRACT_CONE=0: always per level)
+  static const bool cone_on = []() { const char* e = std::getenv("ORBHIP_EXTRACT_CONE"); return !(e && e[0] == '0'); }();
+  const bool cone = cone_on && nframes == 1 && c->cone_wgs > 0;
+  if (cone) {
+    ConeArgs ca; std::memset(&ca, 0, sizeof(ca));
+    const uint8_t* T = c->d_tab.as<uint8_t>();
+    ca.nl = nl; ca.spitch0 = G.lv[0].pitch; ca.buf0 = c->cone_buf0; ca.bufk = c->cone_bufk;
+    for (int l = 1; l < nl; l++) {
+      ConeLevel& L = ca.lv[l];
+      L.sw = G.lv[l - 1].w; L.sh = G.lv[l - 1].h; L.dw = G.lv[l].w; L.dh = G.lv[l].h; L.dpitch = G.lv[l].pitch; L.doff = G.lv[l].pyr_off;
+      L.xtab = (const uint2*)(T + c->tab_xofs[l]); L.yofs = (const int*)(T + c->tab_yofs[l]); L.ibeta = (const short*)(T + c->tab_ibeta[l]);
+    }
+    if (c->cone_lds > 64 * 1024) {
+      static thread_local size_t attr_set = 0;
+      if (attr_set < c->cone_lds) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_pyr_cone, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->cone_lds)); attr_set = c->cone_lds; }
+    }
+    hipLaunchKernelGGL(k_pyr_cone, dim3(c->cone_wgs), dim3(CONE_TPB), c->cone_lds, st, ca, (const short*)(T + c->tab_cone), d_imgs, pyr);
+  }
+  for (int l = 1; l < nl && !cone; l++) {
     const LevelDev& S = G.lv[l - 1];
     const LevelDev& D = G.lv[l];
     const uint8_t* src = (l == 1) ? d_imgs : pyr + S.pyr_off;
@@ -1807,3 +1986,10 @@ int orbx_get_level_selected(orbx_ctx* c, int frame, int level, int32_t* out, int
 }
 
 }  // extern "C"
+
+#ifdef ORBHIP_CONE_PROF
+extern "C" int orbx_debug_cone_ticks(unsigned long long* out) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cone_ticks), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1;
+}
+#endif

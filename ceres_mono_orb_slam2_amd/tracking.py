@@ -28,13 +28,22 @@ def track_with_motion_model(extractor, image, K4, bounds, Tcw_pred, last_Xw, las
     A = np.ascontiguousarray(last_angle, np.float32); V = np.ascontiguousarray(last_valid, np.uint8)
     assert len(D) == n and len(O) == n and len(A) == n and len(V) == n
     cap = extractor.max_keypoints
-    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
-    match = np.full(max(n, 1), -1, np.int32); owner = np.full(cap, -1, np.int32); outl = np.zeros(cap, np.uint8)
-    res = TrackResult()
+    # the output buffers (and their ctypes pointers) live with the extractor: a per-frame call must not spend its time in
+    # allocations (the C side writes every entry it reports; what is returned are copies of the used parts)
+    B = getattr(extractor, "_track_bufs", None)
+    if B is None or B["cap"] != cap or B["nq"] < n:
+        nq = max(n, 1, B["nq"] if B else 0)
+        B = dict(cap=cap, nq=nq, kps=np.zeros(cap, KP_DTYPE), desc=np.zeros((cap, 32), np.uint8), match=np.full(nq, -1, np.int32),
+                 owner=np.full(cap, -1, np.int32), outl=np.zeros(cap, np.uint8), res=TrackResult())
+        B["p"] = tuple(_lib.ptr(B[k]) for k in ("kps", "desc", "match", "owner", "outl"))
+        B["pres"] = C.byref(B["res"])
+        extractor._track_bufs = B
+    pk, pd, pm, po, pl = B["p"]
+    res = B["res"]
     _lib.check(L.orbt_track_with_motion_model(extractor._h, _lib.ptr(img), w, h, img.strides[0], _lib.ptr(K4), _lib.ptr(bounds), _lib.ptr(T), _lib.ptr(X),
-                                              _lib.ptr(D), _lib.ptr(O), _lib.ptr(A), _lib.ptr(V), n, float(th), int(bool(check_ori)), _lib.ptr(kps),
-                                              _lib.ptr(desc), cap, _lib.ptr(match), _lib.ptr(owner), _lib.ptr(outl), C.byref(res)), "orbt_track_with_motion_model")
+                                              _lib.ptr(D), _lib.ptr(O), _lib.ptr(A), _lib.ptr(V), n, float(th), int(bool(check_ori)), pk, pd, cap, pm, po, pl,
+                                              B["pres"]), "orbt_track_with_motion_model")
     k = res.n_keypoints
-    return dict(kps=kps[:k].copy(), desc=desc[:k].copy(), match=match[:n].copy(), owner=owner[:k].copy(), outlier=outl[:k].astype(bool),
-                pose7=np.array(res.pose7[:], np.float64), nmatches=res.nmatches, n_inliers=res.n_inliers,
+    return dict(kps=B["kps"][:k].copy(), desc=B["desc"][:k].copy(), match=B["match"][:n].copy(), owner=B["owner"][:k].copy(),
+                outlier=B["outl"][:k].astype(bool), pose7=np.array(res.pose7[:], np.float64), nmatches=res.nmatches, n_inliers=res.n_inliers,
                 n_correspondences=res.n_correspondences, greedy_rounds=res.greedy_rounds)
