@@ -1382,7 +1382,7 @@ struct orbx_ctx {
   // the blur pass only depends on the pyramid: it runs on a side stream concurrently with FAST + octree
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int overlap_blur = 0;        // 0: one stream; 1: k_blur7 on the side stream beside FAST + octree (+0.8 % only: FAST is issue-bound); 2: beside the octree only
+  int overlap_blur = -1;       // -1: by batch size (see run_batch); 0: one stream; 1: k_blur7 on the side stream beside FAST + octree; 2: beside the octree only
 };
 
 static int build_tables(orbx_ctx* c) {
@@ -1686,7 +1686,11 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
                        G.pyr_frame_bytes, D.w, D.h, (const uint2*)(T + c->tab_xofs[l]), (const int*)(T + c->tab_yofs[l]),
                        (const short*)(T + c->tab_ibeta[l]));
   }
-  const int side_mode = c->side ? c->overlap_blur : 0;
+  // (default -1: batches of >= 8 frames run the blur beside FAST + octree - the octree is a handful of long workgroups that leave
+  // most of the chip idle: +3.2 % on the one-stream bench, 112.1k -> 115.5k frames/s; starting the blur of level 0 even earlier,
+  // beside the resize chain, was measured too and adds nothing.  A lone frame stays on one stream: a fork / join costs more
+  // than it hides)
+  const int side_mode = c->side ? (c->overlap_blur >= 0 ? c->overlap_blur : (nframes >= 8 ? 1 : 0)) : 0;
   auto launch_blur_side = [&]() -> int {
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
