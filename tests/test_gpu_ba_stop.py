@@ -38,16 +38,21 @@ def test_globalba_flag_raised_mid_solve_stops_at_an_iteration_boundary():
     from ceres_mono_orb_slam2_amd import optimizer
     g = synth.make_ba_graph(21, ncam=500, npts=50000, nobs=250000, n_fixed=2)
     a = (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
-    optimizer.global_bundle_adjustment(*a, n_iterations=2)                       # warm-up: graph capture, allocations
-    t0 = time.perf_counter()
-    _, _, full = optimizer.global_bundle_adjustment(*a, n_iterations=50)
-    t_full = time.perf_counter() - t0
+    optimizer.global_bundle_adjustment(*a, n_iterations=5)                       # warm-up: allocations, the iteration graph (captured from 3 iterations on)
+    t_full = 1e9
+    for _ in range(2):                                                            # (the shorter of two: a slow first call would push the raise past the solve)
+        t0 = time.perf_counter()
+        _, _, full = optimizer.global_bundle_adjustment(*a, n_iterations=50)
+        t_full = min(t_full, time.perf_counter() - t0)
     assert full["iterations"] >= 20, full
-    flag = np.zeros(1, np.uint8)
-    th, go = _raise_after(flag, 0.25 * t_full)
-    go.set()
-    poses, pts, s = optimizer.global_bundle_adjustment(*a, n_iterations=50, stop_flag=flag)
-    th.join()
+    for frac in (0.25, 0.15, 0.4):                                                # the raise is timed: a second / third try at other points of the solve
+        flag = np.zeros(1, np.uint8)
+        th, go = _raise_after(flag, frac * t_full)
+        go.set()
+        poses, pts, s = optimizer.global_bundle_adjustment(*a, n_iterations=50, stop_flag=flag)
+        th.join()
+        if s["termination"] == 4 and 1 <= s["iterations"] < full["iterations"]:
+            break
     assert s["termination"] == 4, s                                               # SOLVER_TERMINATE_SUCCESSFULLY
     assert 1 <= s["iterations"] < full["iterations"], (s, full)
     # the state is the accepted iterate after exactly s["iterations"] iterations
