@@ -94,6 +94,14 @@ def test_dropin_test_program_and_reference_types_branch_compile(lib, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1"] + inc + [os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", str(exe), lib.LIB_PATH, "-lpthread",
                            "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
     assert exe.exists()
+    # the `#ifdef ORBCOMPAT_HAVE_OPENCV` branch of orbslam_compat.h (cv::InputArray / cv::OutputArray signature of the reference's
+    # ORBextractor::operator()) against the OpenCV API subset of tests/cpp/opencv_api_subset: compiled and linked here, run on
+    # the GPU box (tests/test_gpu_compat_cpp.py::test_opencv_signature_branch)
+    exe2 = tmp_path / "test_compat_opencv_branch"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "tests", "cpp", "opencv_api_subset"),
+                           os.path.join(ROOT, "tests", "cpp", "test_compat_opencv_branch.cpp"), "-o", str(exe2), lib.LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    assert exe2.exists()
 
 
 def test_tracking_step_validates_arguments_and_fails_loudly_without_gpu(lib):

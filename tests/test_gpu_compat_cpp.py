@@ -130,3 +130,26 @@ def test_reference_signature_dropin_classes(oracle, tmp_path):
         print("%-34s %s%s" % (c[:-4], info, "" if not fails else "   FAIL"))
         failures += ["%s: %s" % (c[:-4], f) for f in fails]
     assert not failures, "\n".join(failures[:40])
+
+
+def test_opencv_signature_branch(oracle, tmp_path):
+    """The branch of csrc/compat/orbslam_compat.h a maintainer with OpenCV builds - ORBextractor::operator()(cv::InputArray image,
+    cv::InputArray mask, std::vector<cv::KeyPoint>&, cv::OutputArray descriptors), src/ORBextractor.cc:1040 - compiled against the
+    OpenCV API subset under tests/cpp/opencv_api_subset and run: keypoints (cv::KeyPoint's 28-byte layout) and descriptors bit
+    for bit the oracle's; an empty image returns silently; the descriptor matrix is n x 32 CV_8U; mvImagePyramid is filled."""
+    from ceres_mono_orb_slam2_amd import _lib
+    exe = tmp_path / "test_compat_opencv_branch"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "tests", "cpp", "opencv_api_subset"),
+                           os.path.join(ROOT, "tests", "cpp", "test_compat_opencv_branch.cpp"), "-o", str(exe), _lib.LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    img = synth.make_frame(78, 752, 480, "blocks")
+    raw = tmp_path / "img.raw"; out = tmp_path / "out.bin"
+    img.tofile(raw)
+    subprocess.check_call([str(exe), str(raw), "752", "480", "1200", str(out)])
+    buf = open(out, "rb").read()
+    n = int(np.frombuffer(buf, np.int32, 1)[0])
+    kps = np.frombuffer(buf, np.uint8, n * 28, 4).reshape(n, 28)
+    desc = np.frombuffer(buf, np.uint8, n * 32, 4 + n * 28).reshape(n, 32)
+    okps, odesc = oracle.OracleExtractor(1200).extract(img)
+    assert n == len(okps) and n > 500
+    assert np.array_equal(kps, okps.view(np.uint8).reshape(n, 28)) and np.array_equal(desc, odesc)
