@@ -1684,6 +1684,7 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
       bool ok = true;
       if (j >= 2) ok = cp_wait(flags, CP_PROG + 4 * irow + (j % W), j - 1);                // tile (i, j) has its update j - 2
       if (ok && last && j >= 1) ok = cp_wait(flags, CP_PROG + 4 * irow + (irow % W), j);   // the diagonal tile has update j - 1
+      if (ok && last && j >= 1) ok = cp_wait(flags, CP_PROG + 4 * irow + ((irow - 1) % W), j);   // ... and tile (i, i-1), which FINAL hands to the chain (another share's when W > 1: it finished a chain step ago, but only a flag says so)
       if (ok && upd) ok = cp_wait(flags, CP_LREADY + j, j);                                // P_j is published
       double va[4], vp[4], cd[4];
 #pragma unroll
@@ -2251,21 +2252,17 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
         const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
         if (fail && tid == 0) s_fail = 1;
       } else if (next) {
+        // Row k + 1 is needed in two instalments: its tiles (k+1, k) and L(k+1, k-1) for the update beside the factor - final as
+        // soon as the row has PUBLISHED L(k+1, k-1) (the thin updates of tile (k+1, k) belong to earlier steps) -, its diagonal
+        // tile only behind the factor.  The row finishes that tile (its last thin update: a load, eight MFMAs, a store) 2 - 3 us
+        // after the publication; waiting for everything at once put that on the chain (9.1 -> 7.9 us per step).
         bool ok = true;
-        if (upd) ok = cp_wait(flags, FIN + k + 1, 1);
-        if (!ok) s_fail = 2;
+        if (upd) ok = cp_wait(flags, BP_LREADY + k + 1, k);
         const size_t rb = (size_t)(k + 1) * NB;
         for (int i = tid - 64; i < NB * NB; i += 192) {
           const int r = i / NB, c = i % NB;
           s_A1[r][c] = ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]);
           s_Lp[r][c] = upd ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
-        }
-        if (nextD) {
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
-            c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
-          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         n_grp += 3;
@@ -2287,6 +2284,15 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
 #pragma unroll
           for (int ks = 0; ks < 8; ks++) s_share[lane * 8 + ks] = a[ks];
         }
+        if (nextD) {                                            // the diagonal tile of row k + 1, behind the row's last thin update
+          if (upd && ok) ok = cp_wait(flags, FIN + k + 1, 1);
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
+            c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
+          }
+        }
+        if (!ok) s_fail = 2;
       }
       __syncthreads();
       if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }

@@ -5,6 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+export ORBHIP_OVERLAP_BLUR=0      # per-kernel counters and cycles: every kernel alone on its stream
 B=${PMC_BATCH:-256}
 run() {  # tag counters...
   tag=$1; shift 1
