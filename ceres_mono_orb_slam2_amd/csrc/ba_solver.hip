@@ -1563,10 +1563,21 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
         if (upd) ok = cp_wait(flags, CP_FINAL + k + 1, 1);
         if (!ok) s_fail = 2;
         const size_t rb = (size_t)(k + 1) * NB;
-        for (int i = tid - 64; i < NB * NB; i += 192) {
-          const int r = i / NB, c = i % NB;
-          s_A1[r][c] = ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]);
-          s_Lp[r][c] = upd ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+        {
+          // (all twelve loads of a lane are requested before the first LDS store: the load -> store loop it used to be cost the
+          // staging waves six dependent global round trips per step, most of the chain's "stall")
+          double ta[6], tl[6];
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
+            ta[u] = i < NB * NB ? ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]) : 0.0;
+            tl[u] = (upd && i < NB * NB) ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
+            if (i < NB * NB) { s_A1[r][c] = ta[u]; s_Lp[r][c] = tl[u]; }
+          }
         }
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
@@ -2246,11 +2257,13 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
     for (int k = jb0; k < kend; k++) {
       const bool upd = k > jb0, next = k + 1 < nb, nextD = next && k + 1 < kend;
       const int kr = k - jb0;
+      CHOL_PROF_BEGIN(k);
       double c2[4] = {0.0, 0.0, 0.0, 0.0};
       double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (tid < 64) {
         const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
         if (fail && tid == 0) s_fail = 1;
+        CHOL_STAMP(0);                                          // factor + inverse
       } else if (next) {
         // Row k + 1 is needed in two instalments: its tiles (k+1, k) and L(k+1, k-1) for the update beside the factor - final as
         // soon as the row has PUBLISHED L(k+1, k-1) (the thin updates of tile (k+1, k) belong to earlier steps) -, its diagonal
@@ -2259,10 +2272,21 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
         bool ok = true;
         if (upd) ok = cp_wait(flags, BP_LREADY + k + 1, k);
         const size_t rb = (size_t)(k + 1) * NB;
-        for (int i = tid - 64; i < NB * NB; i += 192) {
-          const int r = i / NB, c = i % NB;
-          s_A1[r][c] = ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]);
-          s_Lp[r][c] = upd ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+        {
+          // (all twelve loads of a lane are requested before the first LDS store: the load -> store loop it used to be cost the
+          // staging waves six dependent global round trips per step, most of the chain's "stall")
+          double ta[6], tl[6];
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
+            ta[u] = i < NB * NB ? ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]) : 0.0;
+            tl[u] = (upd && i < NB * NB) ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
+            if (i < NB * NB) { s_A1[r][c] = ta[u]; s_Lp[r][c] = tl[u]; }
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         n_grp += 3;
@@ -2295,12 +2319,14 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
         if (!ok) s_fail = 2;
       }
       __syncthreads();
+      CHOL_STAMP(1);                                            // barrier: what the staging waves are late by
       if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
       {
         double* Di = Dinv + (size_t)k * NB * NB;
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; st_sc1(&Di[i], s_X[i / NB][i % NB]); }
       }
+      CHOL_STAMP(2);                                            // X stores issued
       if (next) {
         if (w == 0) {
 #pragma unroll
@@ -2317,6 +2343,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
         __syncthreads();
+        CHOL_STAMP(3);                                          // L(k+1, k) + publication of X
         if (w >= 1 && nextD) {
           double4_t a2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -2329,6 +2356,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
         }
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * kr + 3) cp_set(flags, BP_LREADY + k + 1, k + 1);
+        CHOL_STAMP(4);                                          // D update + publication of L
       }
       if (!next) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -2336,6 +2364,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
         if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
       }
       __syncthreads();
+      CHOL_STAMP(5);                                            // barrier
     }
     return;
   }
@@ -2536,11 +2565,20 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
         if (!ok) s_fail = 2;
         if (tid == 64) P2_MARK(2, k);                           // staging waits satisfied
         const size_t rb = (size_t)(k + 1) * NB;
-        for (int i = tid - 64; i < NB * NB; i += 192) {
-          const int r = i / NB, c = i % NB;
-          s_A1[r][c] = ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]);
-          s_Lp[r][c] = upd ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
-          if (extra) s_N[r][c] = ld_sc1(&S[((size_t)kend * NB + r) * np + (size_t)(k - 1) * NB + c]);
+        {
+          double ta[6], tl[6], tn[6];                           // (every load requested before the first LDS store, as in the block chain)
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
+            ta[u] = i < NB * NB ? ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]) : 0.0;
+            tl[u] = (upd && i < NB * NB) ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+            tn[u] = (extra && i < NB * NB) ? ld_sc1(&S[((size_t)kend * NB + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
+            if (i < NB * NB) { s_A1[r][c] = ta[u]; s_Lp[r][c] = tl[u]; if (extra) s_N[r][c] = tn[u]; }
+          }
         }
         if (nextD || nearD) {
 #pragma unroll

@@ -1,6 +1,7 @@
-"""Phase timing of the chain workgroup of the persistent Cholesky (k_chol_persist) inside real C4-size LocalBA solves: builds
-ba_solver.hip with -DORBHIP_CHOL_PROF into a scratch library and prints the mean time wave 0 of the chain spends in each phase
-of a step (100 MHz s_memrealtime ticks -> ns)."""
+"""Phase timing of the chain workgroup of the persistent Cholesky inside real solves - C4-size LocalBA (k_chol_persist, default) or,
+with the argument `c5`, a 500-keyframe GlobalBA (k_chol_persist_blk: one launch per 128-column outer block): builds ba_solver.hip
+with -DORBHIP_CHOL_PROF into a scratch library and prints the mean time wave 0 of the chain spends in each phase of a step
+(100 MHz s_memrealtime ticks -> ns)."""
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +9,7 @@ import numpy as np
 out = os.path.join(ROOT, "gpurun_out", "cholprof"); os.makedirs(out, exist_ok=True)
 so = os.path.join(out, "liborbslam_hip_persist.so")
 csrc = os.path.join(ROOT, "ceres_mono_orb_slam2_amd", "csrc")
-srcs = [os.path.join(csrc, f) for f in ("ba_solver.hip", "capi_common.hip", "orb_extractor.hip", "orb_matcher.hip", "orb_frame.hip", "orb_vocab.hip")]
+srcs = [os.path.join(csrc, f) for f in ("ba_solver.hip", "capi_common.hip", "orb_extractor.hip", "orb_matcher.hip", "orb_frame.hip", "orb_vocab.hip", "orb_track.hip")]
 if not os.path.exists(so) or os.environ.get("REBUILD"):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                            "-DORBHIP_CHOL_PROF", "-I", os.path.join(ROOT, "include"), "-shared", "-o", so] + srcs)
@@ -17,11 +18,18 @@ from ceres_mono_orb_slam2_amd import _lib, optimizer, synth
 _lib.LIB_PATH = so
 L = _lib.load()
 L.ba_debug_chol_prof.argtypes = [C.c_void_p, C.c_int]
-g = synth.make_ba_graph(0, ncam=100, npts=10000, nobs=50000, n_fixed=1)
-args = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(100, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
-optimizer.local_bundle_adjustment(*args)
+c5 = "c5" in sys.argv
+if c5:
+    g = synth.make_ba_graph(1, ncam=500, npts=50000, nobs=250000, n_fixed=1)
+    args = (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+    solve = lambda: optimizer.global_bundle_adjustment(*args, n_iterations=10)
+else:
+    g = synth.make_ba_graph(0, ncam=100, npts=10000, nobs=50000, n_fixed=1)
+    args = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(100, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+    solve = lambda: optimizer.local_bundle_adjustment(*args)
+solve()
 L.ba_debug_chol_prof(None, 1)
-for _ in range(4): optimizer.local_bundle_adjustment(*args)
+for _ in range(4): solve()
 buf = (C.c_ulonglong * 1280)()
 L.ba_debug_chol_prof(buf, 0)
 a = np.array(buf, dtype=np.float64).reshape(128, 10)
@@ -33,4 +41,4 @@ for i, n in enumerate(names):
     res["per_step_ns"][n] = [round(float(a[k, i] / a[k, 9] * 10.0)) for k in steps]
 res["mean_step_ns"] = float(sum(res["ns_per_phase_mean"].values()))
 print(json.dumps(res, indent=1))
-json.dump(res, open(os.path.join(out, "chol_persist_prof.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out, "chol_persist_prof_c5.json" if c5 else "chol_persist_prof.json"), "w"), indent=1)
