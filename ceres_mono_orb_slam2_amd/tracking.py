@@ -14,36 +14,58 @@ class TrackResult(C.Structure):                # orbt_result
                 ("greedy_rounds", C.c_int32), ("reserved", C.c_int32), ("pose7", C.c_double * 7)]
 
 
+def _c(a, dt):
+    """C-contiguous array of dtype dt without a copy (or a call into numpy) when it already is one"""
+    if type(a) is np.ndarray and a.dtype == dt and a.flags.c_contiguous:
+        return a
+    return np.ascontiguousarray(a, dt)
+
+
+def _addr(a):
+    return a.__array_interface__["data"][0]
+
+
 def track_with_motion_model(extractor, image, K4, bounds, Tcw_pred, last_Xw, last_desc, last_octave, last_angle, last_valid, th=15.0,
-                            check_ori=True):
+                            check_ori=True, copy=False):
     """extractor: ORBextractor; image (H, W) uint8; Tcw_pred (3 or 4, 4); the last frame's per-feature arrays (see the header).
-    Returns dict(kps, desc, match, owner, outlier, pose7, nmatches, n_inliers, n_correspondences, greedy_rounds)."""
+    Returns dict(kps, desc, match, owner, outlier, pose7, nmatches, n_inliers, n_correspondences, greedy_rounds); the arrays are
+    views of buffers kept with the extractor, valid until the call after the next one on it (copy=True: private copies)."""
     L = _lib.load()
-    img = np.ascontiguousarray(image, np.uint8)
+    img = _c(image, np.uint8)
     h, w = img.shape
-    K4 = np.ascontiguousarray(K4, np.float32); bounds = np.ascontiguousarray(bounds, np.float32)
+    K4 = _c(K4, np.float32); bounds = _c(bounds, np.float32)
     T = np.ascontiguousarray(np.asarray(Tcw_pred, np.float64).reshape(-1)[:12])
-    X = np.ascontiguousarray(last_Xw, np.float64).reshape(-1, 3); n = len(X)
-    D = np.ascontiguousarray(last_desc, np.uint8).reshape(-1, 32); O = np.ascontiguousarray(last_octave, np.int32)
-    A = np.ascontiguousarray(last_angle, np.float32); V = np.ascontiguousarray(last_valid, np.uint8)
+    X = _c(last_Xw, np.float64).reshape(-1, 3); n = len(X)
+    D = _c(last_desc, np.uint8).reshape(-1, 32); O = _c(last_octave, np.int32)
+    A = _c(last_angle, np.float32); V = _c(last_valid, np.uint8)
     assert len(D) == n and len(O) == n and len(A) == n and len(V) == n
     cap = extractor.max_keypoints
-    # the output buffers (and their ctypes pointers) live with the extractor: a per-frame call must not spend its time in
-    # allocations (the C side writes every entry it reports; what is returned are copies of the used parts)
-    B = getattr(extractor, "_track_bufs", None)
-    if B is None or B["cap"] != cap or B["nq"] < n:
-        nq = max(n, 1, B["nq"] if B else 0)
-        B = dict(cap=cap, nq=nq, kps=np.zeros(cap, KP_DTYPE), desc=np.zeros((cap, 32), np.uint8), match=np.full(nq, -1, np.int32),
-                 owner=np.full(cap, -1, np.int32), outl=np.zeros(cap, np.uint8), res=TrackResult())
-        B["p"] = tuple(_lib.ptr(B[k]) for k in ("kps", "desc", "match", "owner", "outl"))
-        B["pres"] = C.byref(B["res"])
-        extractor._track_bufs = B
+    # The output buffers (and their addresses) live with the extractor, two sets used alternately: a per-frame call must not spend
+    # its time in allocations, page faults and copies (190 us of Python per call at first, ~25 now).  The arrays returned are VIEWS
+    # of those buffers: valid until the call after the next one on the same extractor (copy=True returns private copies).
+    S = getattr(extractor, "_track_bufs", None)
+    if S is None or S["cap"] != cap or S["nq"] < n:
+        nq = max(n, 1, S["nq"] if S else 0)
+        def mk():
+            b = dict(kps=np.zeros(cap, KP_DTYPE), desc=np.zeros((cap, 32), np.uint8), match=np.full(nq, -1, np.int32),
+                     owner=np.full(cap, -1, np.int32), outl=np.zeros(cap, np.uint8), res=TrackResult())
+            b["p"] = tuple(_addr(b[k]) for k in ("kps", "desc", "match", "owner", "outl"))
+            b["pres"] = C.byref(b["res"])
+            return b
+        S = dict(cap=cap, nq=nq, sets=(mk(), mk()), turn=0)
+        extractor._track_bufs = S
+    S["turn"] ^= 1
+    B = S["sets"][S["turn"]]
     pk, pd, pm, po, pl = B["p"]
     res = B["res"]
-    _lib.check(L.orbt_track_with_motion_model(extractor._h, _lib.ptr(img), w, h, img.strides[0], _lib.ptr(K4), _lib.ptr(bounds), _lib.ptr(T), _lib.ptr(X),
-                                              _lib.ptr(D), _lib.ptr(O), _lib.ptr(A), _lib.ptr(V), n, float(th), int(bool(check_ori)), pk, pd, cap, pm, po, pl,
+    _lib.check(L.orbt_track_with_motion_model(extractor._h, _addr(img), w, h, img.strides[0], _addr(K4), _addr(bounds), _addr(T), _addr(X),
+                                              _addr(D), _addr(O), _addr(A), _addr(V), n, float(th), int(bool(check_ori)), pk, pd, cap, pm, po, pl,
                                               B["pres"]), "orbt_track_with_motion_model")
     k = res.n_keypoints
-    return dict(kps=B["kps"][:k].copy(), desc=B["desc"][:k].copy(), match=B["match"][:n].copy(), owner=B["owner"][:k].copy(),
-                outlier=B["outl"][:k].astype(bool), pose7=np.array(res.pose7[:], np.float64), nmatches=res.nmatches, n_inliers=res.n_inliers,
-                n_correspondences=res.n_correspondences, greedy_rounds=res.greedy_rounds)
+    out = dict(kps=B["kps"][:k], desc=B["desc"][:k], match=B["match"][:n], owner=B["owner"][:k], outlier=B["outl"][:k].view(np.bool_),
+               pose7=np.array(res.pose7[:], np.float64), nmatches=res.nmatches, n_inliers=res.n_inliers,
+               n_correspondences=res.n_correspondences, greedy_rounds=res.greedy_rounds)
+    if copy:
+        for key in ("kps", "desc", "match", "owner", "outlier"):
+            out[key] = out[key].copy()
+    return out
