@@ -1045,7 +1045,7 @@ struct DiagCol {
       hxn = 0.5 * pivn;
       yn = __builtin_amdgcn_rsq(pivn);
       CHOL_PIN(yn); CHOL_PIN(hxn);
-      bad |= (!(pivn > 0.0) || !isfinite(pivn)) ? 1 : 0;
+      bad |= __builtin_isfpclass(pivn, 0x180) ? 0 : 1;          // anything but a positive (sub)normal number: <= 0, NaN, inf - one v_cmp_class
     }
     CHOL_SB();
     acc[J] = acc[J] * y;                                       // lane J: pivot * y = sqrt(pivot); lane 32 + c': x_J of column c'
@@ -1091,8 +1091,13 @@ struct DiagCol {
 __device__ __forceinline__ int diag_factor_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1], double (*s_T)[64]) {
   const int lane = threadIdx.x & 63, r = lane & 31;
   double acc[NB], lp0[NB];
+  // (every lane reads row r - lanes 32..63 throw it away: a load inside the select compiled to 32 exec-masked branches,
+  // ~250 of the factor's ~2100 instructions, and a lone wave pays ~5 cycles for each)
+  double rowv[NB];
 #pragma unroll
-  for (int c = 0; c < NB; c++) { acc[c] = (lane < 32) ? s_L[r][c] : ((c == r) ? 1.0 : 0.0); lp0[c] = 0.0; }
+  for (int c = 0; c < NB; c++) rowv[c] = s_L[r][c];
+#pragma unroll
+  for (int c = 0; c < NB; c++) { acc[c] = (lane < 32) ? rowv[c] : ((c == r) ? 1.0 : 0.0); lp0[c] = 0.0; }
   int bad = 0;
   const double piv = bcast_lane(acc[0], 0);
   bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
