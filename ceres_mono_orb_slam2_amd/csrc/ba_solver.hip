@@ -1110,6 +1110,158 @@ __device__ __forceinline__ int diag_factor_invert_wave(double (*s_L)[NB + 1], do
   }
   return bad;
 }
+#ifdef ORBHIP_CHOL_PROF
+// ---- EXPERIMENT (profiling builds only, tools/factor_ab.py): the same factor + inverse by TWO cooperating waves -------------
+// A third of the one-wave factor's instructions are the trailing updates; if the factor were issue-bound, splitting the columns
+// over two waves would shorten it by about that much.  Measured: 3.91 -> 3.60 us per factor in isolation, bit-identical - the
+// factor is bound by the pivot recurrence (y_J -> l -> pivot -> rsq -> two Newton steps -> y_J+1, ~110 ns per column with the
+// deferred updates interleaved), not by the instruction count; not worth a fifth wave in every persistent workgroup.
+// Wave A owns columns 0..15 of every row, wave B columns 16..31: A factors its columns exactly as above (its
+// updates stop at column 15), B meanwhile applies A's 16 column updates to its own columns as A publishes them (s_T holds every
+// lane's scaled entry of a column: B's own multiplier and the sixteen row entries it needs are there; s_col counts the
+// columns published) and then factors columns 16..31 the same way.  Every entry receives the same fmas in the same order as
+// in the one-wave function and the pivot chain is the same sequence of operations: the results are the same bits
+// (k_chol_la / k_chol_panel keep the one-wave function; the batched-equals-single tests compare the two).
+template <int J, int C0, int N>
+__device__ __forceinline__ void diag_prev_update_h(double (&acc)[16], const double (&lp)[16], const double mp) {
+  if constexpr (J > 0) {
+#pragma unroll
+    for (int q = 0; q < N; q++) if (C0 + q < 16) acc[C0 + q] = fma(-mp, lp[C0 + q], acc[C0 + q]);
+  }
+}
+template <int J, int OFF>
+struct DiagColH {
+  static constexpr int U = 2;
+  static __device__ __forceinline__ void run(double (&acc)[16], const double (&lp)[16], const double mp, const double y, const double sa, const double sb,
+                                             int& bad, double (*s_T)[64], const int lane, int* s_col, const int col_base) {
+    double l = 0.0, pivn = 1.0, hxn = 0.0, yn = 0.0;
+    if constexpr (J + 1 < 16) {
+      l = sa * y;
+      pivn = fma(-l, l, sb);
+      hxn = 0.5 * pivn;
+      yn = __builtin_amdgcn_rsq(pivn);
+      CHOL_PIN(yn); CHOL_PIN(hxn);
+      bad |= __builtin_isfpclass(pivn, 0x180) ? 0 : 1;
+    }
+    CHOL_SB();
+    acc[J] = acc[J] * y;
+    s_T[OFF + J][lane] = acc[J];
+    if constexpr (J + 1 < 16) acc[J + 1] = fma(-acc[J], l, acc[J + 1]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if constexpr (OFF == 0) { if (lane == 0) __hip_atomic_store(s_col, col_base + J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }   // column J is in s_T: wave B may take it
+    double san = 0.0, sbn = 0.0;
+    if constexpr (J + 2 < 16) {
+      diag_prev_update_h<J, J + 2, 1>(acc, lp, mp);
+      const double l2 = bcast_lane(acc[J], OFF + J + 2);
+      acc[J + 2] = fma(-acc[J], l2, acc[J + 2]);
+      san = bcast_lane(acc[J + 1], OFF + J + 2);
+      sbn = bcast_lane(acc[J + 2], OFF + J + 2);
+    }
+    double lpn[16];
+    if constexpr (J + 3 < 16) {
+      constexpr int ce = (J + 3) + ((J + 3) & 1);
+      if constexpr (((J + 3) & 1) != 0) lpn[J + 3] = s_T[OFF + J][OFF + J + 3];
+#pragma unroll
+      for (int c = ce; c + 1 < 16; c += 2) { const double2 v = *(const double2*)&s_T[OFF + J][OFF + c]; lpn[c] = v.x; lpn[c + 1] = v.y; }
+    }
+    if constexpr (J + 1 < 16) {
+      constexpr int c0 = J + 3;
+      CHOL_SB(); double t = hxn * yn;
+      CHOL_SB(); diag_prev_update_h<J, c0, U>(acc, lp, mp);
+      CHOL_SB(); double e = fma(-t, yn, 0.5);
+      CHOL_SB(); diag_prev_update_h<J, c0 + U, U>(acc, lp, mp);
+      CHOL_SB(); yn = fma(yn, e, yn);
+      CHOL_SB(); diag_prev_update_h<J, c0 + 2 * U, U>(acc, lp, mp);
+      CHOL_SB(); t = hxn * yn;
+      CHOL_SB(); diag_prev_update_h<J, c0 + 3 * U, U>(acc, lp, mp);
+      CHOL_SB(); e = fma(-t, yn, 0.5);
+      CHOL_SB(); diag_prev_update_h<J, c0 + 4 * U, U>(acc, lp, mp);
+      CHOL_SB(); yn = fma(yn, e, yn); CHOL_PIN(yn);
+      CHOL_SB(); diag_prev_update_h<J, c0 + 5 * U, 16>(acc, lp, mp);
+      CHOL_SB();
+      DiagColH<J + 1, OFF>::run(acc, lpn, acc[J], yn, san, sbn, bad, s_T, lane, s_col, col_base);
+    }
+  }
+};
+// half = 0: wave A, half = 1: wave B (64 lanes each, any two waves of the workgroup); s_col: an int in LDS, zero at kernel start;
+// col_base: 16 x (number of factors this workgroup has done before) - the count only grows, nothing is reset between factors.
+__device__ __forceinline__ int diag_factor_invert_2w(double (*s_L)[NB + 1], double (*s_X)[NB + 1], double (*s_T)[64], int* s_col, const int col_base, const int half) {
+  const int lane = threadIdx.x & 63, r = lane & 31;
+  const int off = half ? 16 : 0;
+  double acc[16], lp0[16], rowv[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) rowv[c] = s_L[r][off + c];
+#pragma unroll
+  for (int c = 0; c < 16; c++) { acc[c] = (lane < 32) ? rowv[c] : ((off + c == r) ? 1.0 : 0.0); lp0[c] = 0.0; }
+  int bad = 0;
+  if (half == 0) {
+    const double piv = bcast_lane(acc[0], 0);
+    bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
+    const double y0 = rsqrt_f64(piv);
+    const double sa = bcast_lane(acc[0], 1), sb = bcast_lane(acc[1], 1);
+    DiagColH<0, 0>::run(acc, lp0, 0.0, y0, sa, sb, bad, s_T, lane, s_col, col_base);
+  } else {
+    // A's columns, one by one as they are published: acc[c] -= (this lane's scaled entry of column J) * (row (16 + c)'s)
+#pragma unroll
+    for (int J = 0; J < 16; J++) {
+      for (int it = 0; it < (1 << 22) && __hip_atomic_load(s_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < col_base + J + 1; it++) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");         // (nothing below may be read before the count says so)
+      const double m = s_T[J][lane];
+      double lc[16];
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) { const double2 v = *(const double2*)&s_T[J][16 + c]; lc[c] = v.x; lc[c + 1] = v.y; }
+#pragma unroll
+      for (int c = 0; c < 16; c++) acc[c] = fma(-m, lc[c], acc[c]);
+    }
+    const double piv = bcast_lane(acc[0], 16);
+    bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
+    const double y0 = rsqrt_f64(piv);
+    const double sa = bcast_lane(acc[0], 17), sb = bcast_lane(acc[1], 17);
+    DiagColH<0, 16>::run(acc, lp0, 0.0, y0, sa, sb, bad, s_T, lane, s_col, col_base);
+  }
+  if (lane >= 32) {
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) s_X[off + rr][r] = acc[rr];
+  }
+  return bad;
+}
+// debug: both factor functions on the same block, n repetitions each, for a bitwise comparison and a timing (tools/factor_ab.py)
+__global__ __launch_bounds__(256) void k_factor_a(const double* __restrict__ A, double* __restrict__ X1, int n, unsigned long long* ticks) {
+  __shared__ double s_L[NB][NB + 1], s_X[NB][NB + 1];
+  __shared__ __attribute__((aligned(16))) double s_T[NB][64];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_bad = 0;
+  for (int i = tid; i < NB * NB; i += 256) s_L[i / NB][i % NB] = (i % NB <= i / NB) ? A[i] : 0.0;
+  __syncthreads();
+  unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int k = 0; k < n; k++) {
+    if (tid < 64) { if (diag_factor_invert_wave(s_L, s_X, s_T)) s_bad = 1; }
+    __syncthreads();
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+  for (int i = tid; i < NB * NB; i += 256) X1[i] = s_X[i / NB][i % NB];
+  if (tid == 0) { ticks[0] = t1 - t0; ticks[2] = (unsigned long long)s_bad; }
+}
+__global__ __launch_bounds__(320) void k_factor_b(const double* __restrict__ A, double* __restrict__ X2, int n, unsigned long long* ticks) {
+  __shared__ double s_L[NB][NB + 1], s_X[NB][NB + 1];
+  __shared__ __attribute__((aligned(16))) double s_T[NB][64];
+  __shared__ int s_col, s_bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_col = 0; s_bad = 0; }
+  for (int i = tid; i < NB * NB; i += 320) s_L[i / NB][i % NB] = (i % NB <= i / NB) ? A[i] : 0.0;
+  __syncthreads();
+  unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+  for (int k = 0; k < n; k++) {
+    if (tid < 64) { if (diag_factor_invert_2w(s_L, s_X, s_T, &s_col, 16 * k, 0)) s_bad = 1; }
+    else if (tid < 128) { if (diag_factor_invert_2w(s_L, s_X, s_T, &s_col, 16 * k, 1)) s_bad = 1; }
+    __syncthreads();
+  }
+  unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+  for (int i = tid; i < NB * NB; i += 320) X2[i] = s_X[i / NB][i % NB];
+  if (tid == 0) { ticks[1] = t3 - t2; ticks[3] = (unsigned long long)s_bad; }
+}
+#endif
 // G = groups of 16 L21 rows per wave.  Every workgroup repeats the diagonal factor, so a lockstep batch (throughput-bound)
 // runs G = 4 (256 rows per workgroup: 3.3x fewer repeated factors at n = 600, +8 % solves/s), while a single problem
 // (latency-bound) runs G = 1: with G = 4 its L21 loads - 16 rows x 32 bytes per instruction, the MFMA operand layout -
@@ -4563,6 +4715,18 @@ int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations) {
 }
 
 #ifdef ORBHIP_CHOL_PROF
+int ba_debug_factor_ab(const double* A, double* X1, double* X2, int n, unsigned long long* ticks3) {     // host pointers, 32 x 32 row-major; ticks: [1-wave, 2-wave, bad1, bad2]
+  double *dA = nullptr, *d1 = nullptr, *d2 = nullptr; unsigned long long* dt = nullptr;
+  ORBHIP_CHECK_HIP(hipMalloc(&dA, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&d1, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&d2, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&dt, 32));
+  ORBHIP_CHECK_HIP(hipMemcpy(dA, A, 8192, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_factor_a, dim3(1), dim3(256), 0, 0, dA, d1, n, dt);
+  hipLaunchKernelGGL(k_factor_b, dim3(1), dim3(320), 0, 0, dA, d2, n, dt);
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  ORBHIP_CHECK_HIP(hipMemcpy(X1, d1, 8192, hipMemcpyDeviceToHost)); ORBHIP_CHECK_HIP(hipMemcpy(X2, d2, 8192, hipMemcpyDeviceToHost));
+  ORBHIP_CHECK_HIP(hipMemcpy(ticks3, dt, 32, hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dt);
+  return 0;
+}
 int ba_debug_p2_prof(unsigned long long* out, int reset) {       // [8][128] absolute ticks (100 MHz)
   ORBHIP_CHECK_HIP(hipDeviceSynchronize());
   if (out) ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2_prof), sizeof(unsigned long long) * 8 * 128));
