@@ -227,7 +227,8 @@ __device__ unsigned long long g_cone_ticks[24];
 #define CONE_SRC_PT 12      /* bytes of the level 0 box a thread loads (all requested at once) */
 struct ConeLevel { int sw, dw, dpitch, pad; long long doff; const uint2* xtab; const int* yofs; const short* ibeta; int sh, dh; };
 struct ConeArgs { ConeLevel lv[MAX_LEVELS]; int nl, spitch0, buf0, bufk; };      // buf0 / bufk: bytes of the LDS image buffers (level 0 box / larger of the others)
-__global__ __launch_bounds__(CONE_TPB) void k_pyr_cone(ConeArgs A, const short* __restrict__ boxes, const uint8_t* __restrict__ img, uint8_t* __restrict__ pyr) {
+__global__ __launch_bounds__(CONE_TPB) void k_pyr_cone(ConeArgs A, const short* __restrict__ boxes, const uint8_t* __restrict__ img, uint8_t* __restrict__ pyr, int* __restrict__ status) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0;          // (the frame's status word: instead of a memset launch in front)
   extern __shared__ __attribute__((aligned(16))) uint8_t s_cone[];
   const int tid = threadIdx.x, nl = A.nl;
   CONE_MARK(0);
@@ -606,10 +607,10 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
 // workgroup adds the 100 MHz ticks between its stamps to g_oct_prof[level][phase]; [level][15] counts workgroups, [14] sweeps.
 #ifdef ORBHIP_OCT_PROF
 __device__ unsigned long long g_oct_prof[MAX_LEVELS][16];
-#define OCT_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_oct_prof[blockIdx.x][k], _t - t_prev); t_prev = _t; } } while (0)
+#define OCT_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_oct_prof[level][k], _t - t_prev); t_prev = _t; } } while (0)
 #define OCT_STAMP_INIT unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(); const unsigned long long t_begin = t_prev
-#define OCT_STAMP_END do { if (threadIdx.x == 0) { atomicMax(&g_oct_prof[blockIdx.x][13], t_prev - t_begin); atomicMax(&g_oct_prof[blockIdx.x][12], (unsigned long long)n); } } while (0)
-#define OCT_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_oct_prof[blockIdx.x][k], 1ull); } while (0)
+#define OCT_STAMP_END do { if (threadIdx.x == 0) { atomicMax(&g_oct_prof[level][13], t_prev - t_begin); atomicMax(&g_oct_prof[level][12], (unsigned long long)n); } } while (0)
+#define OCT_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_oct_prof[level][k], 1ull); } while (0)
 #else
 #define OCT_STAMP(k) do { } while (0)
 #define OCT_STAMP_INIT do { } while (0)
@@ -679,16 +680,13 @@ static size_t octree_lds_bytes(int node_cap, int max_cells_level, bool wide, boo
 // quotas whose node arrays exceed the 160 kB of LDS (about 3200 keypoints in one level, i.e. nfeatures beyond ~15000; the
 // reference has no such limit).  Same code, same order of operations, slower memory.
 template <bool WIDE, bool GMEM>
-__global__ __launch_bounds__(OCT_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
-                                                const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
-                                                unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
-                                                int* __restrict__ sel_cnt, int* __restrict__ nkeys_out,
-                                                int* __restrict__ status, uint8_t* __restrict__ gnodes, size_t gnodes_stride) {
+__device__ __forceinline__ void octree_body(const GeomDev& G, const int* __restrict__ cell_cnt,
+                                            const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
+                                            unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
+                                            int* __restrict__ sel_cnt, int* __restrict__ nkeys_out,
+                                            int* __restrict__ status, uint8_t* __restrict__ gnodes, size_t gnodes_stride, const int level, const int f) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_lds[];
-  // (frame-major order, levels fastest.  Tried: level-major, all level-0 workgroups - the longest - dispatched first: 0.163 ->
-  // 0.190 ms; the 256 long workgroups then compete with each other for the same CUs' LDS pipes instead of being interleaved
-  // with short ones.)
-  const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int tid = threadIdx.x;
 #ifdef ORBHIP_OCT_LEVEL_EXPERIMENT
   if (!((G.oct_level_mask >> level) & 1)) return;
 #endif
@@ -986,6 +984,27 @@ __global__ __launch_bounds__(OCT_TPB) __attribute__((amdgpu_waves_per_eu(8, 8)))
   }
   OCT_STAMP(7);        // best key per node + output
   OCT_STAMP_END;
+}
+// (frame-major order, levels fastest.  Tried: level-major, all level-0 workgroups - the longest - dispatched first: 0.163 ->
+// 0.190 ms; the 256 long workgroups then compete with each other for the same CUs' LDS pipes instead of being interleaved
+// with short ones.)
+template <bool WIDE, bool GMEM>
+__global__ __launch_bounds__(OCT_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_octree(GeomDev G, const int* __restrict__ cell_cnt,
+                                                const uint32_t* __restrict__ cell_kps, uint32_t* __restrict__ keys,
+                                                unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
+                                                int* __restrict__ sel_cnt, int* __restrict__ nkeys_out,
+                                                int* __restrict__ status, uint8_t* __restrict__ gnodes, size_t gnodes_stride) {
+  octree_body<WIDE, GMEM>(G, cell_cnt, cell_kps, keys, knode, sel, sel_cnt, nkeys_out, status, gnodes, gnodes_stride, (int)blockIdx.x, (int)blockIdx.y);
+}
+// A lone frame whose geometry allows more than 65535 candidates in a level needs both instantiations (the wide one leaves at once
+// unless a level really has that many): one launch of 2 x nlevels workgroups instead of two launches - 4.7 us of launch floor per
+// frame on the latency path.
+__global__ __launch_bounds__(OCT_TPB) void k_octree_pair(GeomDev G, const int* __restrict__ cell_cnt, const uint32_t* __restrict__ cell_kps,
+                                                         uint32_t* __restrict__ keys, unsigned short* __restrict__ knode, uint32_t* __restrict__ sel,
+                                                         int* __restrict__ sel_cnt, int* __restrict__ nkeys_out, int* __restrict__ status) {
+  const int bx = (int)blockIdx.x, f = (int)blockIdx.y;
+  if (bx < G.nlevels) octree_body<false, false>(G, cell_cnt, cell_kps, keys, knode, sel, sel_cnt, nkeys_out, status, nullptr, 0, bx, f);
+  else octree_body<true, false>(G, cell_cnt, cell_kps, keys, knode, sel, sel_cnt, nkeys_out, status, nullptr, 0, bx - G.nlevels, f);
 }
 
 // ---------------------------------------------------------------------------- k_blur7
@@ -1654,12 +1673,12 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   const int nl = c->nlevels;
   uint8_t* pyr = c->d_pyr.as<uint8_t>();
   auto mark = [&]() { if (c->profiling) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_events.push_back(e); } } };
-  ORBHIP_CHECK_HIP(hipMemsetAsync(c->d_status.p, 0, (size_t)nframes * 4, st));
+  static const bool cone_on = []() { const char* e = std::getenv("ORBHIP_EXTRACT_CONE"); return !(e && e[0] == '0'); }();
+  const bool cone = cone_on && nframes == 1 && c->cone_wgs > 0;
+  if (!cone) ORBHIP_CHECK_HIP(hipMemsetAsync(c->d_status.p, 0, (size_t)nframes * 4, st));
   mark();
   // pyramid chain: a single frame takes the one-launch cone kernel (latency), batches one launch per level (throughput;
   // ORBHIP_EXTRACT_CONE=0: always per level)
-  static const bool cone_on = []() { const char* e = std::getenv("ORBHIP_EXTRACT_CONE"); return !(e && e[0] == '0'); }();
-  const bool cone = cone_on && nframes == 1 && c->cone_wgs > 0;
   if (cone) {
     ConeArgs ca; std::memset(&ca, 0, sizeof(ca));
     const uint8_t* T = c->d_tab.as<uint8_t>();
@@ -1673,7 +1692,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
       static thread_local size_t attr_set = 0;
       if (attr_set < c->cone_lds) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_pyr_cone, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->cone_lds)); attr_set = c->cone_lds; }
     }
-    hipLaunchKernelGGL(k_pyr_cone, dim3(c->cone_wgs), dim3(CONE_TPB), c->cone_lds, st, ca, (const short*)(T + c->tab_cone), d_imgs, pyr);
+    hipLaunchKernelGGL(k_pyr_cone, dim3(c->cone_wgs), dim3(CONE_TPB), c->cone_lds, st, ca, (const short*)(T + c->tab_cone), d_imgs, pyr, c->d_status.as<int>());
   }
   for (int l = 1; l < nl && !cone; l++) {
     const LevelDev& S = G.lv[l - 1];
@@ -1718,7 +1737,15 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   // mode 2: the octree is one latency-bound workgroup per (frame, level) - 6 % VALU-busy, 0.6 waves per SIMD - so the
   // VALU-bound blur runs BESIDE it: the fork is taken after FAST, the octree is submitted first and keeps its slots
   if (side_mode == 2) ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
-  if (!c->octree_gmem) {
+  if (!c->octree_gmem && c->octree_wide && nframes == 1) {
+    const size_t lds2 = std::max(c->octree_lds, c->octree_lds_wide);
+    if (lds2 > 64 * 1024) {
+      static thread_local size_t pair_attr = 0;
+      if (pair_attr < lds2) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); pair_attr = lds2; }
+    }
+    hipLaunchKernelGGL(k_octree_pair, dim3(2 * nl, 1), dim3(OCT_TPB), lds2, st, G, c->d_cellcnt.as<int>(), c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(),
+                       c->d_knode.as<unsigned short>(), c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
+  } else if (!c->octree_gmem) {
     hipLaunchKernelGGL((k_octree<false, false>), dim3(nl, nframes), dim3(OCT_TPB), c->octree_lds, st, G, c->d_cellcnt.as<int>(),
                        c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(), c->d_knode.as<unsigned short>(),
                        c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>(), (uint8_t*)nullptr, (size_t)0);
