@@ -1689,8 +1689,8 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
       L.xtab = (const uint2*)(T + c->tab_xofs[l]); L.yofs = (const int*)(T + c->tab_yofs[l]); L.ibeta = (const short*)(T + c->tab_ibeta[l]);
     }
     if (c->cone_lds > 64 * 1024) {
-      static thread_local size_t attr_set = 0;
-      if (attr_set < c->cone_lds) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_pyr_cone, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->cone_lds)); attr_set = c->cone_lds; }
+      static thread_local size_t attr_set = 0; static thread_local int attr_dev = -1;        // (function attributes are per device)
+      if (attr_dev != c->device || attr_set < c->cone_lds) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_pyr_cone, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->cone_lds)); attr_set = c->cone_lds; attr_dev = c->device; }
     }
     hipLaunchKernelGGL(k_pyr_cone, dim3(c->cone_wgs), dim3(CONE_TPB), c->cone_lds, st, ca, (const short*)(T + c->tab_cone), d_imgs, pyr, c->d_status.as<int>());
   }
@@ -1740,8 +1740,8 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   if (!c->octree_gmem && c->octree_wide && nframes == 1) {
     const size_t lds2 = std::max(c->octree_lds, c->octree_lds_wide);
     if (lds2 > 64 * 1024) {
-      static thread_local size_t pair_attr = 0;
-      if (pair_attr < lds2) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); pair_attr = lds2; }
+      static thread_local size_t pair_attr = 0; static thread_local int pair_dev = -1;      // (function attributes are per device)
+      if (pair_dev != c->device || pair_attr < lds2) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); pair_attr = lds2; pair_dev = c->device; }
     }
     hipLaunchKernelGGL(k_octree_pair, dim3(2 * nl, 1), dim3(OCT_TPB), lds2, st, G, c->d_cellcnt.as<int>(), c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(),
                        c->d_knode.as<unsigned short>(), c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
