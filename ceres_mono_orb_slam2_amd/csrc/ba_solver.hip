@@ -1650,7 +1650,7 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
 // results are bit-identical to the launch-per-step kernels (tests/test_gpu_ba.py::test_persistent_cholesky_is_bit_identical)
 // and batched solves (k_chol_la<4>, throughput-bound) stay bit-identical to single calls.
 // No deadlock: a workgroup only waits for workgroups with a smaller blockIdx.x of its own problem, which are dispatched
-// first; every wait is bounded (CP_SPIN_CAP polls) and a timeout or a failed pivot raises FAIL, which ends every wait.
+// first; every wait on another workgroup is bounded in time (cp_wait) and a timeout or a failed pivot raises FAIL, which ends every wait.
 #define CP_XREADY 0
 #define CP_FAIL 1
 #define CP_LREADY 2
@@ -1658,17 +1658,23 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
 #define CP_PROG 80                 // [CP_PROG + 4 * row + share]: steps this share of the row has completed
 #define CP_NFLAGS 256
 #define CP_CH 8                    // tiles a row workgroup updates per step (their operands wait in registers together)
-#define CP_SPIN_CAP (1 << 21)
+#define CP_SPIN_CAP (1 << 21)      /* polls of the waves of ONE workgroup waiting for each other (LDS counters): never long */
 #define CP_LDS_DOUBLES ((1 + CP_CH) * NB * (NB + 1))      /* a consumer: L(i,j) + CP_CH operand tiles; the chain: 6 tiles + the factor's column buffer */
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Every wait is bounded - by TIME (s_memrealtime, 100 MHz), not by a spin count: the workgroup waited for may simply not be
+// resident yet when another stream's kernels hold the CUs, and a wait that gives up turns into a rejected LM step.  Five seconds
+// is far beyond any such delay and still ends a genuine hang; a failed pivot raises CP_FAIL, which ends every wait at once.
+#define CP_WAIT_TICKS 500000000ull
 __device__ __forceinline__ bool cp_wait(const int* flags, int which, int v) {
-  for (int it = 0; it < CP_SPIN_CAP; it++) {
+  if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (unsigned it = 0;; it++) {
     if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return true;
     if ((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    if ((it & 1023) == 1023 && __builtin_amdgcn_s_memrealtime() - t0 > CP_WAIT_TICKS) return false;
     __builtin_amdgcn_s_sleep(1);
   }
-  return false;
 }
 __device__ __forceinline__ void cp_set(int* flags, int which, int v) { __hip_atomic_store(flags + which, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1926,10 +1932,12 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
         const int ct = lane < CP_CH ? c_first + lane * W : irow;            // lane CP_CH: this row's own L(i, j)
         const bool mine = lane <= CP_CH && ct <= irow;
         bool good = true;
-        for (int it = 0; it < CP_SPIN_CAP; it++) {
+        const unsigned long long t0w = __builtin_amdgcn_s_memrealtime();
+        for (unsigned it = 0;; it++) {
           const bool ready = !mine || __hip_atomic_load(flags + CP_LREADY + ct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= j + 1;
           if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
-          if (((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) || it == CP_SPIN_CAP - 1) { good = false; break; }
+          if (((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ||
+              ((it & 1023) == 1023 && __builtin_amdgcn_s_memrealtime() - t0w > CP_WAIT_TICKS)) { good = false; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         if (!good) s_dead = 1;
@@ -2186,7 +2194,7 @@ __device__ __forceinline__ void chol_syrk_tile2_pf(const BaDev& D, int ti2, int 
   }
 }
 #define BP_LREADY 2
-struct BlkGeo { int jb0, ns, base, kend, nend, tcn, n_tiles_n, n_rhs_n, n_tiles_c; };     // (blocks of NB; host values = the largest problem of the launch)
+struct BlkGeo { int jb0, ns, base, kend, nend, tcn, n_tiles_n, n_rhs_n, n_tiles_c, blk; };     // (blocks of NB; host values = the largest problem of the launch)
 // One 64 x 64 tile of the NEXT outer block's columns: the previous outer block's K = 128 update of it (role C's share, if any),
 // then THIS block's, stage by stage as its panels are published - two chol_syrk_body passes operation for operation (the
 // intermediate tile stays in registers), so that the next launch's chain finds its columns complete when this one ends.
@@ -2366,7 +2374,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
     const int c_hi_n = min(geo.nend * NB, np);
     const int tcr = wd.tiles_c - geo.tcn;
     const int n_items = has_prev ? (tcr > 0 ? geo.n_tiles_c : 0) + wd.nrhs : 0, n_tile_items = has_prev && tcr > 0 ? geo.n_tiles_c : 0;
-    int* qctr = flags + BP_LREADY + 2 * R + jb0 / max(ns, 1);    // this launch's queue head (zeroed with the flags; one per outer block)
+    int* qctr = flags + BP_LREADY + 2 * R + geo.blk;              // this launch's queue head (zeroed with the flags; one per outer block, blk < nb)
     __shared__ int s_item;
     auto steal = [&]() -> bool {
       if (n_items <= 0) return false;
@@ -4201,7 +4209,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
           // one persistent launch per outer block: the chain, a workgroup per block row below, the previous block's K = 128 update
           const int nbm = npad / NB, nend_ = std::min(kend + OB, npad);
           BlkGeo geo;
-          geo.jb0 = k0 / NB; geo.ns = (kend - k0) / NB; geo.base = std::max(nbm - (geo.jb0 + 2), 0) + 2;
+          geo.jb0 = k0 / NB; geo.ns = (kend - k0) / NB; geo.blk = k0 / OB; geo.base = std::max(nbm - (geo.jb0 + 2), 0) + 2;
           geo.kend = kend / NB; geo.nend = nend_ / NB;
           geo.tcn = kend < npad ? (nend_ - kend + 63) / 64 : 0;
           geo.n_tiles_n = geo.tcn * ((npad - kend + 63) / 64);
