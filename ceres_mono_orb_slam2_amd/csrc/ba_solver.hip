@@ -1492,7 +1492,6 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
   double (*s_L)[NB + 1] = (double (*)[NB + 1])s_raw;
   double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_raw + NB * (NB + 1));
   double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_raw + 2 * NB * (NB + 1));
-  double (*s_M)[NB + 1] = (double (*)[NB + 1])(s_raw + 3 * NB * (NB + 1));
   double (*s_T)[64] = (double (*)[64])(s_raw + 4 * NB * (NB + 1));          // 16-byte aligned: 4 * 32 * 33 * 8 bytes
   __shared__ int s_fail;
   if (k >= np || k + NB + (int)blockIdx.x * (64 * G) > np) return;     // beyond this problem's matrix (batched launch)
@@ -1690,7 +1689,6 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
   const int ti = w >> 1, tj = w & 1;
   double* S = D.S;
   double* Dinv = D.Dinv;
-  double* Mb = D.Mb;
   int* flags = D.cflags;
   if (bx == 0) {
     // ------------------------------------------------------------------------------------------------ the chain
@@ -2104,7 +2102,11 @@ __device__ __forceinline__ void chol_syrk_tile_pf(const BaDev& D, int ti, int tj
 }
 // ... and TWO vertically adjacent tiles (128 x 64) per item: the column operand of a K stage is loaded once for both, and the
 // fixed cost of an item (first loads, C tile, store) is spread over twice the matrix-core work.
+// (SC1: the operands and the C tiles were written / will be read by other workgroups of the SAME launch - agent-scope accesses.
+// Plain cached loads behind an agent-scope acquire fence were measured too: no faster)
+template <bool SC1>
 __device__ __forceinline__ void chol_syrk_tile2_pf(const BaDev& D, int ti2, int tj, int kcol, int K, int lo, double* s_raw) {
+  auto ldg = [](const double* q) -> double { if constexpr (SC1) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *q; };
   const int np = D.npad, tid = threadIdx.x;
   if (kcol + K > np) return;
   double* S = D.S;
@@ -2129,9 +2131,9 @@ __device__ __forceinline__ void chol_syrk_tile2_pf(const BaDev& D, int ti2, int 
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int i = tid + 256 * u, r = i / NB, c = i % NB;
-      va0[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kc + c] : 0.0;
-      va1[u] = (r0 + 64 + r < np) ? S[(size_t)(r0 + 64 + r) * np + kc + c] : 0.0;
-      vb[u] = (c0 + r < np) ? S[(size_t)(c0 + r) * np + kc + c] : 0.0;
+      va0[u] = (r0 + r < np) ? ldg(&S[(size_t)(r0 + r) * np + kc + c]) : 0.0;
+      va1[u] = (r0 + 64 + r < np) ? ldg(&S[(size_t)(r0 + 64 + r) * np + kc + c]) : 0.0;
+      vb[u] = (c0 + r < np) ? ldg(&S[(size_t)(c0 + r) * np + kc + c]) : 0.0;
     }
   };
   load_stage(kcol);
@@ -2145,7 +2147,7 @@ __device__ __forceinline__ void chol_syrk_tile2_pf(const BaDev& D, int ti2, int 
         for (int rg = 0; rg < 4; rg++) {
           const int row = r0 + 64 * h + qr + 16 * i + (lane >> 4) + 4 * rg;
           const int col = c0 + qc + 16 * j + (lane & 15);
-          cpre[h][i][j][rg] = (!(h ? skip1 : skip0) && row < np && col < np && col <= row) ? S[(size_t)row * np + col] : 0.0;
+          cpre[h][i][j][rg] = (!(h ? skip1 : skip0) && row < np && col < np && col <= row) ? ldg(&S[(size_t)row * np + col]) : 0.0;
         }
   for (int k0 = 0; k0 < K; k0 += NB) {
 #pragma unroll
@@ -2189,7 +2191,7 @@ __device__ __forceinline__ void chol_syrk_tile2_pf(const BaDev& D, int ti2, int 
         for (int rg = 0; rg < 4; rg++) {
           const int row = r0 + 64 * h + qr + 16 * i + (lane >> 4) + 4 * rg;
           const int col = c0 + qc + 16 * j + (lane & 15);
-          if (row < np && col < np && col <= row) S[(size_t)row * np + col] = cpre[h][i][j][rg] - acc[h][i][j][rg];
+          if (row < np && col < np && col <= row) { if constexpr (SC1) __hip_atomic_store(&S[(size_t)row * np + col], cpre[h][i][j][rg] - acc[h][i][j][rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S[(size_t)row * np + col] = cpre[h][i][j][rg] - acc[h][i][j][rg]; }
         }
   }
 }
@@ -2383,7 +2385,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
       __syncthreads();
       const int it = s_item;
       if (it >= n_items) return false;
-      if (it < n_tile_items) { const int ti_c = it / tcr, tj_c = geo.tcn + (it - ti_c * tcr); chol_syrk_tile2_pf(D, ti_c, tj_c, wd.kcol, wd.K, wd.lo, s_dyn); }
+      if (it < n_tile_items) { const int ti_c = it / tcr, tj_c = geo.tcn + (it - ti_c * tcr); chol_syrk_tile2_pf<false>(D, ti_c, tj_c, wd.kcol, wd.K, wd.lo, s_dyn); }
       else chol_syrk_body(D, st, wd.total + (it - n_tile_items), wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B, geo.n_tiles_n > 0 ? geo.nend * NB : 0);
       return true;
     };
@@ -2837,102 +2839,44 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
     // ------------------------------------------------------------------------------------------------ a worker
     const int wk = bx - nb;
     if (wk >= nworkers) return;
-    double (*s_A)[NB + 1] = (double (*)[NB + 1])s_dyn;
-    double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + 64 * (NB + 1));
     double* s_z = s_dyn;
     double* zrow = S + (size_t)np * np;
-    const int qr = (w >> 1) * 32, qc = (w & 1) * 32;
     const int tpb = ns / 2;                                     // 64-column tiles per outer block
     for (int b = 0; (b + 1) * ns < nb; b++) {
       const int kend = (b + 1) * ns, kcol = b * ns * NB, K = ns * NB;
+      const int np2 = (nt + 1) / 2;                             // pairs of vertically adjacent tiles (128 x 64) per tile column
       for (int C = (b + 2) * tpb; C < nt; C++) {
-        const int off = C * nt - C * (C - 1) / 2;
-        const int Rr = C + (((wk - off) % nworkers) + nworkers) % nworkers;
-        if (Rr >= nt) continue;                                 // (nworkers >= nt: at most one tile of a column is this worker's)
-        const int r0 = 64 * Rr, c0 = 64 * C;
-        bool ok = cp_wait(flags, BP_LREADY + 2 * Rr, kend) && cp_wait(flags, BP_LREADY + 2 * C, kend);
-        if (ok && 2 * Rr + 1 < nb) ok = cp_wait(flags, BP_LREADY + 2 * Rr + 1, kend);
+        const int m = C / 2, off2 = C * np2 - (m * (m - 1) + (C & 1) * m);      // pairs of the columns before C
+        const int pp = m + (((wk - off2) % nworkers) + nworkers) % nworkers;
+        if (pp >= np2) continue;                                // (nworkers >= np2: at most one pair of a column is this worker's)
+        const int c0 = 64 * C;
+        const bool diag = (2 * pp == C) || (2 * pp + 1 == C);
+        bool ok = cp_wait(flags, BP_LREADY + 2 * C, kend);
         if (ok && 2 * C + 1 < nb) ok = cp_wait(flags, BP_LREADY + 2 * C + 1, kend);
-        if (ok && Rr == C) ok = cp_wait(flags, BP_LREADY + nb, kend);
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (ok && 4 * pp + q < nb) ok = cp_wait(flags, BP_LREADY + 4 * pp + q, kend);
+        if (ok && diag) ok = cp_wait(flags, BP_LREADY + nb, kend);
         if (__syncthreads_count(!ok)) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
-        const bool qskip = (r0 + qr + 31 < c0 + qc);
-        double va[8], vb[8], cpre[2][2][4];
-        double4_t acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int i = tid + 256 * u, r = i / NB, c = i % NB;
-          va[u] = (r0 + r < np) ? ld_sc1(&S[(size_t)(r0 + r) * np + kcol + c]) : 0.0;
-          vb[u] = (c0 + r < np) ? ld_sc1(&S[(size_t)(c0 + r) * np + kcol + c]) : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-              const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
-              const int col = c0 + qc + 16 * j + (lane & 15);
-              cpre[i][j][rg] = (!qskip && row < np && col < np && col <= row) ? ld_sc1(&S[(size_t)row * np + col]) : 0.0;
-            }
-        for (int k0 = 0; k0 < K; k0 += NB) {
-#pragma unroll
-          for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
+        chol_syrk_tile2_pf<true>(D, pp, C, kcol, K, 0, s_dyn);
+        if (diag) {                                             // the rhs row's entries of these 64 columns
           __syncthreads();
-          if (k0 + NB < K) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-              const int i = tid + 256 * u, r = i / NB, c = i % NB;
-              va[u] = (r0 + r < np) ? ld_sc1(&S[(size_t)(r0 + r) * np + kcol + k0 + NB + c]) : 0.0;
-              vb[u] = (c0 + r < np) ? ld_sc1(&S[(size_t)(c0 + r) * np + kcol + k0 + NB + c]) : 0.0;
-            }
-          }
-          if (!qskip) {
-#pragma unroll
-            for (int kk = 0; kk < NB; kk += 4) {
-              double a[2], bb[2];
-#pragma unroll
-              for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
-#pragma unroll
-              for (int j = 0; j < 2; j++) bb[j] = s_B[qc + 16 * j + li][kk + lk];
-#pragma unroll
-              for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-            }
-          }
-          __syncthreads();
-        }
-        if (!qskip) {
-#pragma unroll
-          for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-              for (int rg = 0; rg < 4; rg++) {
-                const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
-                const int col = c0 + qc + 16 * j + (lane & 15);
-                if (row < np && col < np && col <= row) st_sc1(&S[(size_t)row * np + col], cpre[i][j][rg] - acc[i][j][rg]);
-              }
-        }
-        if (Rr == C) {                                          // the rhs row's entries of these 64 columns
           for (int i = tid; i < K; i += 256) s_z[i] = ld_sc1(&zrow[kcol + i]);
           __syncthreads();
           const int c = c0 + tid;
           if (tid < 64 && c < np) {
             const double* L = S + (size_t)c * np + kcol;
             double sum = 0.0;
-            for (int m = 0; m < K; m++) sum += ld_sc1(&L[m]) * s_z[m];
+            for (int mm = 0; mm < K; mm++) sum += ld_sc1(&L[mm]) * s_z[mm];
             st_sc1(&zrow[c], ld_sc1(&zrow[c]) - sum);
           }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (tid == 0) cp_set(flags, WP + Rr * nt + C, b + 1);
-        if (tid == 0 && C < (b + 3) * tpb) P2_MARK(4, b);       // the tiles the next near update needs
+        if (tid == 0) {
+          cp_set(flags, WP + (2 * pp) * nt + C, b + 1);
+          if (2 * pp + 1 < nt) cp_set(flags, WP + (2 * pp + 1) * nt + C, b + 1);
+          if (C < (b + 3) * tpb) P2_MARK(4, b);                 // the tiles the next near update needs
+        }
       }
       if (tid == 0) P2_MARK(3, b);                              // all far tiles of block b
     }
