@@ -96,6 +96,12 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   v += dpp_take<0x143, 0xC>(v);     // row_bcast31 into rows 2 and 3
   return v;
 }
+// value of lane `src` (wave-uniform, a constant after unrolling: two v_readlane_b32)
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
 template <int V>
 __device__ __forceinline__ void block_reduce_dpp(double (&acc)[V], double* s_red /*[(blockDim.x/64)*V]*/, double* s_out /*[V]*/) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -132,6 +138,12 @@ __device__ bool small_chol_solve(double* A, double* b, int n) {
 // upper-triangle index of a symmetric 6x6 stored as 21 values
 __device__ __forceinline__ int sym6(int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); }
 
+#ifdef ORBHIP_CHOL_PROF
+__device__ unsigned long long g_pose_ticks[8];
+#define POSE_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); g_pose_ticks[i] += t_ - pt_; pt_ = t_; } } while (0)
+#else
+#define POSE_T(i) do { } while (0)
+#endif
 #define POSE_R 8
 __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s, double* __restrict__ poses,
                                                  const double* __restrict__ Xw, const double* __restrict__ uv,
@@ -143,6 +155,9 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
   __shared__ double s_radius, s_dec, s_xcost, s_xnorm, s_mcc, s_stepnorm, s_init;
   __shared__ int s_iter, s_term, s_done, s_valid, s_accept, s_invalid, s_succ, s_nbad;
   const int p = blockIdx.x, tid = threadIdx.x;
+#ifdef ORBHIP_CHOL_PROF
+  unsigned long long pt_ = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lo = offsets[p], n = offsets[p + 1] - lo;
   const double* K4 = K4s + 4 * p;
   double* pose = poses + 7 * p;
@@ -228,48 +243,90 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
   accumulate(s_x);
   if (tid == 0) adopt(true);
   __syncthreads();
+  POSE_T(0);                               // loads + first evaluation
   int done = s_done;
   while (!done) {
     __syncthreads();                       // every thread has consumed the previous flags
-    if (tid == 0) {
-      s_valid = 0; s_accept = 0;
-      if (s_iter >= max_iters) { s_term = 0; s_done = 1; }
-      else if (s_radius <= 1e-32) { s_term = 6; s_done = 1; }
+    if (tid < 64) {
+      // Wave 0 solves the damped 6x6 system with lanes 0..5 holding one row each: a column of the Cholesky factor costs one
+      // sqrt and ONE division latency instead of (5 - j) dependent ones (fp64 division ~ 30 dependent instructions on a
+      // lone wave; the serial thread-0 version spent 2.7 us per iteration here).  Every sum keeps the serial order of
+      // small_chol_solve, so the step is bit-identical to it; scalars are computed redundantly by all lanes, lane 0 stores.
+      const int r = min(tid, 5);
+      const int iter = s_iter;
+      const double radius = s_radius;
+      if (tid == 0) { s_valid = 0; s_accept = 0; }
+      if (iter >= max_iters) { if (tid == 0) { s_term = 0; s_done = 1; } }
+      else if (radius <= 1e-32) { if (tid == 0) { s_term = 6; s_done = 1; } }
       else {
-        s_iter++;
-        double A[36], y[6], Hs[36], gs[6];
-        for (int a = 0; a < 6; a++) {
-          gs[a] = s_g[a] * s_scale[a];
-          for (int b = 0; b < 6; b++) Hs[a * 6 + b] = s_H[sym6(a, b)] * s_scale[a] * s_scale[b];
+        if (tid == 0) s_iter = iter + 1;
+        double hs[6], L[6];
+        const double sr = s_scale[r];
+        const double gsr = s_g[r] * sr;
+        double hrr = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { hs[c] = s_H[sym6(r, c)] * sr * s_scale[c]; L[c] = hs[c]; if (c == r) hrr = hs[c]; }
+        const double damp = fmin(fmax(hrr, 1e-6), 1e32) / radius;
+#pragma unroll
+        for (int c = 0; c < 6; c++) if (c == r) L[c] += damp;
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          double t = L[j];
+#pragma unroll
+          for (int k = 0; k < j; k++) t -= L[k] * lane_bcast(L[k], j);
+          const double dj = lane_bcast(t, j);
+          if (!(dj > 0.0) || !isfinite(dj)) { ok = false; break; }
+          const double d = sqrt(dj);
+          L[j] = (r == j) ? d : t / d;
         }
-        for (int k = 0; k < 36; k++) A[k] = Hs[k];
-        for (int a = 0; a < 6; a++) A[a * 7] += fmin(fmax(Hs[a * 7], 1e-6), 1e32) / s_radius;
-        for (int a = 0; a < 6; a++) y[a] = gs[a];
-        bool ok = small_chol_solve(A, y, 6);
+        POSE_T(5);
+        double y[6];
+        if (ok) {
+          double Lu[6][6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int k = 0; k <= i; k++) Lu[i][k] = lane_bcast(L[k], i);
+          }
+#pragma unroll
+          for (int i = 0; i < 6; i++) { double t = lane_bcast(gsr, i); for (int k = 0; k < i; k++) t -= Lu[i][k] * y[k]; y[i] = t / Lu[i][i]; }
+#pragma unroll
+          for (int i = 5; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < 6; k++) t -= Lu[k][i] * y[k]; y[i] = t / Lu[i][i]; }
+        }
         double mcc = 0;
         if (ok) {
-          for (int a = 0; a < 6; a++) {
-            double hs = 0;
-            for (int b = 0; b < 6; b++) hs += Hs[a * 6 + b] * (-y[b]);
-            mcc -= (-y[a]) * (gs[a] + 0.5 * hs);
+          double hsum = 0, yr = 0;
+#pragma unroll
+          for (int c = 0; c < 6; c++) { hsum += hs[c] * (-y[c]); if (c == r) yr = y[c]; }
+          const double term = (-yr) * (gsr + 0.5 * hsum);
+#pragma unroll
+          for (int c = 0; c < 6; c++) mcc -= lane_bcast(term, c);
+        }
+        POSE_T(6);
+        if (!ok || !(mcc > 0.0)) {
+          if (tid == 0) {
+            if (++s_invalid >= 5) { s_term = 5; s_done = 1; }
+            s_radius = radius / s_dec; s_dec *= 2;
+          }
+        } else {
+          double d[3], cand[7];
+          for (int k = 0; k < 3; k++) cand[k] = s_x[k] + (-y[k]) * s_scale[k];
+          for (int k = 0; k < 3; k++) d[k] = (-y[3 + k]) * s_scale[3 + k];
+          quat_plus(s_x + 3, d, cand + 3);
+          double sn = 0;
+          for (int k = 0; k < 7; k++) { double e = s_x[k] - cand[k]; sn += e * e; }
+          if (tid == 0) {
+            s_invalid = 0; s_valid = 1; s_mcc = mcc;
+            for (int k = 0; k < 7; k++) s_cand[k] = cand[k];
+            s_stepnorm = sqrt(sn);
           }
         }
-        if (!ok || !(mcc > 0.0)) {
-          if (++s_invalid >= 5) { s_term = 5; s_done = 1; }
-          s_radius /= s_dec; s_dec *= 2;
-        } else {
-          s_invalid = 0; s_valid = 1; s_mcc = mcc;
-          double d[3];
-          for (int k = 0; k < 3; k++) s_cand[k] = s_x[k] + (-y[k]) * s_scale[k];
-          for (int k = 0; k < 3; k++) d[k] = (-y[3 + k]) * s_scale[3 + k];
-          quat_plus(s_x + 3, d, s_cand + 3);
-          double sn = 0;
-          for (int k = 0; k < 7; k++) { double e = s_x[k] - s_cand[k]; sn += e * e; }
-          s_stepnorm = sqrt(sn);
-        }
+        POSE_T(7);
       }
     }
     __syncthreads();
+    POSE_T(1);                             // thread 0: damped solve, candidate
     done = s_done;
     const int valid = s_valid;
     if (done) break;
@@ -278,6 +335,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
     // every step is accepted, and the sums are then the next iteration's state (a cost-only pass followed by a second, full
     // pass at the same pose cost a third of the kernel's 47 us at 1500 observations; a rejected step wastes the Jacobians)
     accumulate(s_cand);
+    POSE_T(2);                             // evaluation at the candidate
     if (tid == 0) {
       double cand_cost = s_sum[0];
       if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
@@ -290,7 +348,8 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
           if (rel > 1e-3) {
             s_accept = 1; s_succ++;
             for (int k = 0; k < 7; k++) s_x[k] = s_cand[k];
-            s_radius = fmin(1e16, s_radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3)));
+            const double c3 = 2.0 * rel - 1.0;               // pow(c3, 3) as two products: the generic fp64 pow costs
+            s_radius = fmin(1e16, s_radius / fmax(1.0 / 3.0, 1.0 - c3 * c3 * c3));   // ~1 us of lone-thread time per iteration
             s_dec = 2.0;
             adopt(false);
           } else {
@@ -300,6 +359,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
       }
     }
     __syncthreads();
+    POSE_T(3);                             // thread 0: decision, new state
     done = s_done;
   }
   __syncthreads();
@@ -325,6 +385,7 @@ __global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s,
       summaries[p] = s;
     }
   }
+  POSE_T(4);                               // outlier check, write-back
 }
 
 
@@ -4665,6 +4726,12 @@ int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations) {
 }
 
 #ifdef ORBHIP_CHOL_PROF
+int ba_debug_pose_ticks(unsigned long long* out, int reset) {
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  if (out) ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_ticks), 64));
+  if (reset) { static unsigned long long z[8]; ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pose_ticks), z, 64)); }
+  return 0;
+}
 int ba_debug_factor_ab(const double* A, double* X1, double* X2, int n, unsigned long long* ticks3) {     // host pointers, 32 x 32 row-major; ticks: [1-wave, 2-wave, bad1, bad2]
   double *dA = nullptr, *d1 = nullptr, *d2 = nullptr; unsigned long long* dt = nullptr;
   ORBHIP_CHECK_HIP(hipMalloc(&dA, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&d1, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&d2, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&dt, 32));
