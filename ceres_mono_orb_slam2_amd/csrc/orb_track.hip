@@ -256,6 +256,11 @@ __global__ __launch_bounds__(256) void k_trk_windows(const float* __restrict__ k
 
 struct TrkOut { int32_t n_keypoints, nmatches, nobs, rounds, cand_total, n_inliers, pad0, pad1; int32_t ticks[8]; };
 
+#ifdef ORBHIP_TRK_PROF
+// settles per microsecond since the dataflow loop started [0..63], polls of the slowest thread [64], queries left after pass one [65],
+// longest chain of waits in links [66], sum of the chain lengths [67]
+__device__ int g_trk_prof[72];
+#endif
 // ---- one workgroup: the order-dependent pass, rotation consistency, slot owners, PoseOptimization's observation list ----
 __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__ in, const uint8_t* __restrict__ q_valid, const float* __restrict__ q_angle,
                                                      const uint32_t* __restrict__ acc, const int32_t* __restrict__ acc_n,
@@ -430,11 +435,17 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
     int left = 0, blk[TRK_QPT];                                  // blk: the unsettled predecessor the query was last seen waiting for
 #pragma unroll
     for (int k = 0; k < TRK_QPT; k++) { const int q = tid + TRK_GT * k; done[k] = !(q < nq && s_st[q] == -3); left += done[k] ? 0 : 1; blk[k] = -1; }
+#ifdef ORBHIP_TRK_PROF
+    int lastblk[TRK_QPT] = {-1, -1, -1, -1};
+#endif
     for (int it = 0; it < (1 << 20) && left > 0; it++) {
 #pragma unroll
       for (int k = 0; k < TRK_QPT; k++) {
         if (done[k]) continue;
         if (blk[k] >= 0 && ld(&s_st[blk[k]]) == -3) continue;     // still waiting for the same query: one read per poll
+#ifdef ORBHIP_TRK_PROF
+        if (blk[k] >= 0) lastblk[k] = blk[k];
+#endif
         const int q = tid + TRK_GT * k;
         const int b = s_coff[q] & OFFM, cnt = (s_coff[q + 1] & OFFM) - b;
         // the best candidate no earlier claimer HOLDS (held = by a settled query: final); q takes it as soon as no earlier claimer
@@ -480,8 +491,16 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
         }
         __hip_atomic_store(&s_st[q], bi >= 0 ? bi : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         done[k] = true; left--;
+#ifdef ORBHIP_TRK_PROF
+        { const int dep = (lastblk[k] >= 0 ? s_prop[lastblk[k]] : 0) + 1; s_prop[q] = dep; atomicMax(&g_trk_prof[66], dep); atomicAdd(&g_trk_prof[67], dep); }
+        atomicAdd(&g_trk_prof[min(63, (int)((__builtin_amdgcn_s_memrealtime() - tk0) / 100))], 1);
+#endif
       }
       inner_total++;
+#ifdef ORBHIP_TRK_PROF
+      if (it == 0 && left > 0) atomicAdd(&g_trk_prof[65], left);
+      if (left == 0) atomicMax(&g_trk_prof[64], it);
+#endif
       if (it == 0 && tid == 0) out->ticks[5] = (int)(__builtin_amdgcn_s_memrealtime() - tk0);      // first pass over all queries
     }
     rounds = 1;
@@ -640,6 +659,14 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
 using namespace orbhip;
 
 extern "C" {
+#ifdef ORBHIP_TRK_PROF
+int orbt_debug_prof(int* out, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trk_prof), sizeof(int) * 72) != hipSuccess) return -1;
+  if (reset) { static int z[72]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_trk_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h, int stride, const float* K4, const float* bounds,
                                  const double* Tcw_pred, const double* last_Xw, const uint8_t* last_desc, const int32_t* last_octave,
