@@ -43,6 +43,9 @@ VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 
 MATCH_LANE_OPS_PER_PAIR = 19.5   # VALU instructions per Hamming distance in k_match_pairs (ISA-checked: 8 xor + 8 v_bcnt + v_lshl_or + v_max + v_min + half a v_min3)
 PMC_TRAFFIC = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 PMC summaries, newest first
 PMC_VALU = ("r03_pmc_valu.json", "r02_pmc_valu.json", "r01_pmc_valu.json")
+MFMA_I8_PEAK_TOPS = 5000.0     # MI355X_MICROARCH.md: I8 at twice the bf16 rate (bf16 dense ~2.5 PF); v_mfma_i32_16x16x64_i8 measured 4.7 POPS
+                               # (tools/ubench/mfma_i8.hip)
+MATCH_OPS_PER_DISTANCE = 512   # 256 bit positions x (multiply + add): the matcher's distances as an int8 matrix product
 MATCH_BYTES_PER_KP = 2 * (32 + 28) + 4      # k_match_pairs per keypoint of a pair: both frames' descriptor + keypoint record read once, match12 written
 
 
@@ -506,7 +509,8 @@ def main():
         per_call["match"] = match_ms / max(len(ev), 1)
         # the dominant kernel = the longest launch of the step, the matcher included (its bytes: both frames' records once)
         bytes_of = dict(BYTES); bytes_of["match"] = int(round(mean_kp * MATCH_BYTES_PER_KP))
-        kernel_of = dict(KERNEL_OF); kernel_of["match"] = "k_match_pairs"
+        match_mfma = os.environ.get("ORBHIP_MATCH_MFMA", "1") != "0" and cap <= 4080        # (the library's own switch and limit)
+        kernel_of = dict(KERNEL_OF); kernel_of["match"] = "k_match_pairs_mfma" if match_mfma else "k_match_pairs"
         # batches of >= 8 frames run k_blur7 on the extractor's side stream beside FAST + octree (ORBHIP_OVERLAP_BLUR, default on):
         # its event duration is then NOT an exclusive time (it shares the chip), so it cannot be the "dominant kernel" of the
         # roofline; it is reported as what it is
@@ -552,10 +556,22 @@ def main():
                       "frac": pairs_per_s * lane_ops / 1e12 / VALU_PEAK_TOPS,
                       "lane_ops_per_launch": lane_ops * B, "lane_ops_per_distance": MATCH_LANE_OPS_PER_PAIR,
                       "distances_per_pair": mean_kp * mean_kp}
-        if dom == "match":              # VALU-issue bound: its HBM fraction is tiny by construction
-            roof["limiter"] = "valu_issue"
-            roof["valu_issue"] = match_valu
-            roof["valu_issue_frac"] = match_valu["frac"]
+        # on the matrix cores the matcher is an int8 product: 512 operations per distance against the dense I8 peak
+        tops = pairs_per_s * mean_kp * mean_kp * MATCH_OPS_PER_DISTANCE / 1e12
+        match_mfma_roof = {"kernel": "k_match_pairs_mfma", "bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                           "frac": tops / MFMA_I8_PEAK_TOPS, "ops_per_launch": mean_kp * mean_kp * MATCH_OPS_PER_DISTANCE * B,
+                           "ops_per_distance": MATCH_OPS_PER_DISTANCE, "distances_per_pair": mean_kp * mean_kp, "ms_per_launch": per_call["match"],
+                           "note": "v_mfma_i32_16x16x64_i8, 4 instructions per 16 x 16 distances; the VALU kernel (ORBHIP_MATCH_MFMA=0) needs "
+                                   "19.5 lane-instructions per distance"}
+        if dom == "match":
+            if match_mfma:
+                roof.update({k: match_mfma_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")})
+                roof["limiter"] = "mfma"; roof["mfma"] = match_mfma_roof
+                roof.pop("valu_issue_frac", None); roof.pop("valu_insts_per_wave", None); roof.pop("valu_source", None)
+            else:           # VALU-issue bound: its HBM fraction is tiny by construction
+                roof["limiter"] = "valu_issue"
+                roof["valu_issue"] = match_valu
+                roof["valu_issue_frac"] = match_valu["frac"]
         # the longest HBM-streaming kernel keeps its own block (the contract's "hbm" roofline), with the PMC traffic
         hk = KERNEL_OF[hdom]
         hach = BYTES[hdom] * B / (per_call[hdom] * 1e-3) / 1e9
@@ -577,7 +593,8 @@ def main():
             except Exception:
                 continue
         roof["hbm_stream_kernel"] = hroof
-        roof["match_kernel_valu_issue"] = match_valu
+        if match_mfma: roof["match_kernel_mfma"] = match_mfma_roof
+        else: roof["match_kernel_valu_issue"] = match_valu
         if blur_concurrent:
             roof["concurrent_kernels"] = {"k_blur7": {"ms_per_launch": per_call["blur"], "stream": "the extractor's side stream, beside k_fast_cells + k_octree",
                                                        "note": "a concurrent duration, not an exclusive one: alone the launch takes ~0.40 ms (ORBHIP_OVERLAP_BLUR=0, profiles/)"}}
@@ -591,7 +608,8 @@ def main():
                 vj = json.load(open(os.path.join(ROOT, "profiles", f)))
                 per_frame = sum(v["valu_insts"] for v in vj["kernels"].values() if "valu_insts" in v and not v.get("is_match")) * 64.0 / vj["frames_per_launch"]
                 mj = vj["kernels"].get("k_match_pairs")
-                m_ops = (mj["valu_insts"] * 64.0 / vj["frames_per_launch"]) if mj and mj.get("is_match") else lane_ops
+                mj = vj["kernels"].get("k_match_pairs_mfma") if match_mfma else mj
+                m_ops = (mj["valu_insts"] * 64.0 / vj["frames_per_launch"]) if mj and mj.get("is_match") else (0.0 if match_mfma else lane_ops)
                 fe.update({"valu_lane_ops_per_frame": per_frame + m_ops, "valu_Tops": (per_frame + m_ops) * fps / world / 1e12,
                            "valu_frac": (per_frame + m_ops) * fps / world / 1e12 / VALU_PEAK_TOPS, "valu_source": "profiles/" + f})
                 break
@@ -601,8 +619,12 @@ def main():
         kernels = {k: {"ms_per_launch_batch": v} for k, v in per_call.items()}
         for k in BYTES:
             kernels[k]["algorithmic_GBps"] = BYTES[k] * B / (per_call[k] * 1e-3) / 1e9
-        kernels["match"]["valu_Tops"] = pairs_per_s * lane_ops / 1e12
-        kernels["match"]["valu_frac_of_peak"] = pairs_per_s * lane_ops / 1e12 / VALU_PEAK_TOPS
+        if match_mfma:
+            kernels["match"]["mfma_i8_Tops"] = tops
+            kernels["match"]["mfma_frac_of_peak"] = tops / MFMA_I8_PEAK_TOPS
+        else:
+            kernels["match"]["valu_Tops"] = pairs_per_s * lane_ops / 1e12
+            kernels["match"]["valu_frac_of_peak"] = pairs_per_s * lane_ops / 1e12 / VALU_PEAK_TOPS
         out = {
             "metric": "frames/sec ORB extract+match @1241x376 + LocalBA solves/sec; 1/2/4/8 GPU",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liborbslam_hip.so")
+LIB_PATH = os.environ.get("ORBHIP_LIB") or os.path.join(_HERE, "lib", "liborbslam_hip.so")   # (ORBHIP_LIB: a profiling / experiment build)
 
 # every symbol include/orbslam_hip.h declares (tests check that the library exports them all)
 SYMBOLS = [

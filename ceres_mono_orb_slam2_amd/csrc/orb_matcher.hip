@@ -260,6 +260,280 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
   if (tid == 0) nmatch[p] = s_n;
 }
 
+// ---- the same frame-pair matcher with the distances on the MATRIX cores -------------------------------------------------
+// All-pairs Hamming distance is a matrix product: d(a, b) = |a| + |b| - 2 |a & b|, and |a & b| is the dot product of the two
+// descriptors written out as 256 bytes of 0 / 1.  v_mfma_i32_16x16x64_i8 takes 16 queries x 16 targets x 64 bits per instruction
+// (~18 cycles of a SIMD, tools/ubench/mfma_i8.hip: 4.7 POPS): 4 instructions per 256 distances, against 19 VALU instructions per
+// distance and lane (xor + popcount chain + key + min / med3) that held k_match_pairs at ~73 % of the chip's VALU issue rate.
+// The packed key of the best / second-best update comes out of the product itself: query bits are bytes of {0, -128}, target
+// bits bytes of {0, 4} (a common bit contributes -512 = -2 * 256), and the accumulator of a (query, target tile) product STARTS
+// at |b| * 256 + tile index - so the result is (d - |a|) * 256 + tile: ordered like (d, target index) for the lane that owns the
+// column (its targets are 16 tile + lane & 15), |a| is a row constant that is added at the end.  What is left for the VALU is
+// one v_med3_i32 + one v_min_i32 per distance, the same update as above (signed: d - |a| may be negative).
+// Workgroup = 512 threads, 8 waves x 64 queries (four 16-row tiles, their expanded bits live in 64 VGPRs); the targets stream
+// through LDS in chunks of MM_CHUNK, expanded bit -> byte by all threads one chunk ahead of the products (two buffers, one
+// barrier per chunk); a wave reads a 16-target tile (4 x ds_read_b128 per lane + the start values) once for its four query
+// tiles.  C/D layout (col = lane & 15 = target, row = 4 (lane >> 4) + r = query): a lane sees one target column per tile and
+// keeps (k1, k2) for its 16 rows; the 16 lanes of a DPP row are merged once at the end.  The k index inside an instruction is
+// the same function of (lane >> 4, byte) for A and B, so any consistent bit -> byte order gives the full sum.
+// 256 pairs of ~1816 x 1816: 0.205 ms against 0.506 ms (tools/match_ab.py, identical match lists); the products alone would
+// take ~0.11 ms.
+#ifndef MM_THREADS
+#define MM_THREADS 512
+#endif
+#define MM_IT (MM_CHUNK * 16 / MM_THREADS)      /* 16-bit pieces a thread expands per chunk */
+#define MM_QT 4                      // 16-query tiles per wave
+#ifndef MM_CHUNK
+#define MM_CHUNK 128                 // targets per LDS chunk (one barrier per chunk: 64 -> 128 targets 0.215 -> 0.205 ms per 256 pairs)
+#endif
+#define MM_TSTRIDE 272               // bytes per expanded target in LDS (256 + 16: the 16 lanes of a tile read 16 different bank groups)
+typedef int mm_v4i __attribute__((ext_vector_type(4)));
+// 16 bits -> 16 bytes of {0, 4}: a nibble times (1 + 2^7 + 2^14 + 2^21) << 2 puts bit i at bit 8 i + 2 (the partial products do not
+// overlap; both factors fit v_mul_u32_u24)
+__device__ __forceinline__ mm_v4i mm_expand16(uint32_t h) {
+  mm_v4i r;
+  r.x = (int)(__umul24(h & 0xFu, 0x810204u) & 0x04040404u);
+  r.y = (int)(__umul24((h >> 4) & 0xFu, 0x810204u) & 0x04040404u);
+  r.z = (int)(__umul24((h >> 8) & 0xFu, 0x810204u) & 0x04040404u);
+  r.w = (int)(__umul24((h >> 12) & 0xFu, 0x810204u) & 0x04040404u);
+  return r;
+}
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+#define MM_NONE 0x3FFFFFFF            /* no candidate: tile index 255 (at most 255 target tiles: cap <= 4080) */
+__global__ __launch_bounds__(MM_THREADS) void k_match_pairs_mfma(const orbx_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                                const int* __restrict__ counts, int cap,
+                                                                const int* __restrict__ pair_a, const int* __restrict__ pair_b,
+                                                                float ratio, int th, int check_ori,
+                                                                int* __restrict__ match12, int* __restrict__ nmatch,
+                                                                int nsplit, int* __restrict__ scratch /*[npairs][32]*/) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_b[2][MM_CHUNK * MM_TSTRIDE];
+  __shared__ mm_v4i s_c0[2][MM_CHUNK];
+  __shared__ int s_key1[MM_THREADS], s_key2[MM_THREADS];
+  __shared__ int s_hist[HISTO_LENGTH], s_keep[3], s_n, s_last;
+  const int p = (int)blockIdx.x / nsplit, sp = (int)blockIdx.x % nsplit, tid = threadIdx.x;
+  const int fa = pair_a[p], fb = pair_b[p];
+  int n1 = counts[fa], n2 = counts[fb];
+  n1 = n1 < 0 ? 0 : min(n1, cap);
+  n2 = n2 < 0 ? 0 : min(n2, cap);
+  const uint8_t* Qb = desc + (size_t)fa * cap * 32;
+  const uint8_t* Tb = desc + (size_t)fb * cap * 32;
+  const unsigned short* T16 = (const unsigned short*)Tb;
+  const orbx_keypoint* KA = kps + (size_t)fa * cap;
+  const orbx_keypoint* KB = kps + (size_t)fb * cap;
+  int* M = match12 + (size_t)p * cap;
+  if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+  if (tid == 0) s_n = 0;
+  const int lane = tid & 63, wv = tid >> 6, lj = lane & 15, lg = lane >> 4;
+  const int nchunks = (n2 + MM_CHUNK - 1) / MM_CHUNK;
+  const float factor = 1.0f / HISTO_LENGTH;
+  // a thread's share of a chunk: MM_IT 16-bit pieces to expand, and (threads 0 .. MM_CHUNK - 1) one target's weight
+  auto fetch = [&](int c, uint32_t (&h)[MM_IT], uint4& w0, uint4& w1) {
+#pragma unroll
+    for (int u = 0; u < MM_IT; u++) {
+      const int item = tid + MM_THREADS * u, tg = c * MM_CHUNK + (item >> 4);
+      h[u] = tg < n2 ? (uint32_t)T16[(size_t)tg * 16 + (item & 15)] : 0u;
+    }
+    w0 = make_uint4(0, 0, 0, 0); w1 = w0;
+    if (tid < MM_CHUNK && c * MM_CHUNK + tid < n2) { const uint4* t4 = (const uint4*)(Tb + (size_t)(c * MM_CHUNK + tid) * 32); w0 = t4[0]; w1 = t4[1]; }
+  };
+  auto stage = [&](int c, const uint32_t (&h)[MM_IT], const uint4& w0, const uint4& w1) {
+    uint8_t* B = s_b[c & 1];
+#pragma unroll
+    for (int u = 0; u < MM_IT; u++) {
+      const int item = tid + MM_THREADS * u;
+      *(mm_v4i*)(B + (item >> 4) * MM_TSTRIDE + (item & 15) * 16) = mm_expand16(h[u]);
+    }
+    if (tid < MM_CHUNK) {
+      const int j = c * MM_CHUNK + tid;
+      const int nb = __popc(w0.x) + __popc(w0.y) + __popc(w0.z) + __popc(w0.w) + __popc(w1.x) + __popc(w1.y) + __popc(w1.z) + __popc(w1.w);
+      const int c0 = j < n2 ? ((nb << 8) | (c * (MM_CHUNK / 16) + (tid >> 4))) : MM_NONE;      // |b| * 256 + the tile's index
+      s_c0[c & 1][tid] = (mm_v4i){c0, c0, c0, c0};
+    }
+  };
+  // The workgroup takes the query blocks sp, sp + nsplit, ... of MM_THREADS queries each (nsplit = 1 when the launch has a pair
+  // per CU: no merge through global memory then, and the per-workgroup latencies - counts, first operands, the final pass - are
+  // paid once per pair instead of once per block; the targets are expanded again for every block, ~15 % of a block's time).
+  const int nblocks = (n1 + MM_THREADS - 1) / MM_THREADS;
+  for (int blk = sp; blk < max(nblocks, sp + 1); blk += nsplit) {
+    const int qbase = blk * MM_THREADS + wv * 64;               // this wave's 64 queries
+    const bool wave_live = qbase < n1;
+    // the queries of this wave as {0, -128} bytes: tile t, instruction s: bits [64 s + 16 lg, + 16) of query qbase + 16 t + lj
+    mm_v4i A[MM_QT][4];
+#pragma unroll
+    for (int t = 0; t < MM_QT; t++) {
+      const int qi = qbase + 16 * t + lj;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        const uint32_t h = qi < n1 ? (uint32_t)((const unsigned short*)(Qb + (size_t)qi * 32))[4 * s4 + lg] : 0u;
+        const mm_v4i e = mm_expand16(h);
+        A[t][s4].x = e.x << 5; A[t][s4].y = e.y << 5; A[t][s4].z = e.z << 5; A[t][s4].w = e.w << 5;          // 0x04 -> 0x80 = -128
+      }
+    }
+    int k1[MM_QT][4], k2[MM_QT][4];
+#pragma unroll
+    for (int t = 0; t < MM_QT; t++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { k1[t][r] = MM_NONE; k2[t][r] = MM_NONE; }
+    }
+    uint32_t hb[MM_IT]; uint4 w0, w1;
+    if (nchunks > 0) { fetch(0, hb, w0, w1); stage(0, hb, w0, w1); }
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+      if (c + 1 < nchunks) fetch(c + 1, hb, w0, w1);
+      if (wave_live) {
+        // Software pipeline over the chunk's 16-target tiles: the NEXT tile's operands (4 x ds_read_b128 + the accumulator start
+        // values) are requested before the current tile's 16 products are issued, and the key updates of the PREVIOUS tile's
+        // results (32 VALU instructions) are interleaved with them, two per product - the matrix pipe (~18 cycles per
+        // instruction) is not waited for.
+        const uint8_t* B = s_b[c & 1];
+        auto loadB = [&](int tt, mm_v4i (&Bv)[4], mm_v4i& c0) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; s4++) Bv[s4] = *(const mm_v4i*)(B + (tt * 16 + lj) * MM_TSTRIDE + (4 * s4 + lg) * 16);
+          c0 = s_c0[c & 1][tt * 16 + lj];
+        };
+        auto products = [&](const mm_v4i (&Bv)[4], const mm_v4i& c0, mm_v4i (&C)[MM_QT]) {
+#pragma unroll
+          for (int t = 0; t < MM_QT; t++) C[t] = c0;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; s4++) {
+#pragma unroll
+            for (int t = 0; t < MM_QT; t++) C[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][s4], Bv[s4], C[t], 0, 0, 0);
+          }
+        };
+        auto keys = [&](const mm_v4i (&C)[MM_QT]) {
+#pragma unroll
+          for (int t = 0; t < MM_QT; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int k = C[t][r];
+              k2[t][r] = med3_i32(k1[t][r], k2[t][r], k);
+              k1[t][r] = min(k1[t][r], k);
+            }
+          }
+        };
+        auto interleave = [&]() {
+          __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+          for (int i = 0; i < 16; i++) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 2, 0); }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int NT = MM_CHUNK / 16;                        // tiles per chunk (even)
+        mm_v4i Ba[4], Bb[4], ca, cb, Ca[MM_QT], Cb[MM_QT];
+        loadB(0, Ba, ca);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tp = 0; tp < NT; tp += 2) {
+          loadB(tp + 1, Bb, cb);
+          products(Ba, ca, Ca);
+          if (tp > 0) keys(Cb);
+          interleave();
+          if (tp + 2 < NT) loadB(tp + 2, Ba, ca);
+          products(Bb, cb, Cb);
+          keys(Ca);
+          interleave();
+        }
+        keys(Cb);
+      }
+      if (c + 1 < nchunks) stage(c + 1, hb, w0, w1);
+      __syncthreads();
+    }
+    // merge the 16 lanes that share a row (same lane >> 4): k1 = min, k2 = min(k2a, k2b, max(k1a, k1b))
+#pragma unroll
+    for (int t = 0; t < MM_QT; t++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        // (d - |a|) * 256 + tile  ->  (d - |a|) * 4096 + target index (tile * 16 + this lane's column)
+        auto widen = [&](int k) { return (k & 0xFF) == 0xFF ? MM_NONE : (((k >> 8) << 12) | ((k & 0xFF) << 4) | lj); };
+        int a1 = widen(k1[t][r]), a2 = widen(k2[t][r]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const int b1 = __shfl_xor(a1, o), b2 = __shfl_xor(a2, o);
+          a2 = min(min(a2, b2), max(a1, b1));
+          a1 = min(a1, b1);
+        }
+        if (lj == 0) { s_key1[wv * 64 + 16 * t + 4 * lg + r] = a1; s_key2[wv * 64 + 16 * t + 4 * lg + r] = a2; }
+      }
+    }
+    __syncthreads();
+    {
+      const int i = blk * MM_THREADS + tid;
+      int res = -1;
+      if (i < n1) {
+        const uint4* q4 = (const uint4*)(Qb + (size_t)i * 32);
+        const uint4 a0 = q4[0], a1 = q4[1];
+        const int na = __popc(a0.x) + __popc(a0.y) + __popc(a0.z) + __popc(a0.w) + __popc(a1.x) + __popc(a1.y) + __popc(a1.z) + __popc(a1.w);
+        const int e1 = s_key1[tid], e2 = s_key2[tid];
+        const int bi = (e1 & 0xFFF) == 0xFFF ? -1 : (e1 & 0xFFF);
+        const int b1 = (e1 >> 12) + na;
+        const int b2 = (e2 & 0xFFF) == 0xFFF ? 256 : (e2 >> 12) + na;
+        if (bi >= 0 && b1 <= th && (float)b1 < __fmul_rn(ratio, (float)b2)) {
+          res = bi;
+          int bin = 0;
+          if (check_ori) {
+            float rot = __fsub_rn(KA[i].angle, KB[bi].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == HISTO_LENGTH) bin = 0;
+            atomicAdd(&s_hist[bin], 1);
+          }
+          res |= bin << 24;
+        }
+      }
+      // (agent-scope stores and loads - written through to / read from the memory side - instead of __threadfence(): the fence
+      // writes back the XCD's whole L2, 0.19 ms of a 0.54 ms launch when 1024 workgroups do it twice each)
+      if (i < cap) { if (nsplit > 1) __hip_atomic_store(&M[i], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else M[i] = res; }
+    }
+  }
+  // (entries beyond the last block of queries)
+  if (sp == 0) for (int i = max(nblocks, 1) * MM_THREADS + tid; i < cap; i += MM_THREADS) { if (nsplit > 1) __hip_atomic_store(&M[i], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else M[i] = -1; }
+  __syncthreads();
+  if (nsplit > 1) {
+    int* sc = scratch + (size_t)p * 32;
+    if (tid < HISTO_LENGTH && s_hist[tid]) __hip_atomic_fetch_add(&sc[tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);                            // this thread's stores and atomics have reached the memory side
+    __syncthreads();
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(&sc[31], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < HISTO_LENGTH) { s_hist[tid] = __hip_atomic_load(&sc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sc[tid] = 0; }
+    if (tid == 31) sc[31] = 0;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    if (check_ori) {
+      int max1 = 0, max2 = 0, max3 = 0;
+      for (int b = 0; b < HISTO_LENGTH; b++) {
+        const int s = s_hist[b];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = b; }
+        else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = b; }
+        else if (s > max3) { max3 = s; i3 = b; }
+      }
+      if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+      else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+    }
+    s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+  }
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < cap; i += MM_THREADS) {
+    int r = nsplit > 1 ? __hip_atomic_load(&M[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : M[i];
+    if (r >= 0) {
+      int bin = r >> 24, j = r & 0xFFFFFF;
+      if (check_ori && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) j = -1;
+      M[i] = j;
+      mine += j >= 0;
+    }
+  }
+  if (mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  if (tid == 0) nmatch[p] = s_n;
+}
+
 // ---- brute force for ONE query set, split so that a single 2000 x 2000 match fills the chip ------------------------
 // 64 queries per workgroup (lane = query, descriptor in 8 VGPRs), its 16 waves take the targets j = w, w + 16, ... : the
 // target index is wave-uniform, so the descriptors arrive through the scalar unit (s_load, no LDS staging), and every wave
@@ -541,9 +815,13 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
   if (npairs == 0) return 0;
   ORBHIP_REQUIRE(d_kps && d_desc && d_counts && d_pair_a && d_pair_b && d_match12 && d_nmatch, ORBHIP_EINVAL, "NULL argument");
   const size_t lds = (size_t)cap * 32;
-  ORBHIP_REQUIRE(lds <= 150 * 1024, ORBHIP_EINVAL, "per-frame capacity too large for the LDS-resident matcher (cap <= 4800)");
+  // ORBHIP_MATCH_MFMA=0: the VALU kernel (xor + popcount), otherwise the distances come from the matrix cores (the target index
+  // takes 12 bits of the packed key there)
+  static const bool use_mfma = []() { const char* e = std::getenv("ORBHIP_MATCH_MFMA"); return !(e && e[0] == '0'); }();
+  const bool mfma = use_mfma && cap <= 4080;               // (at most 255 target tiles of 16: the tile index takes 8 bits of the packed key)
+  ORBHIP_REQUIRE(mfma || lds <= 150 * 1024, ORBHIP_EINVAL, "per-frame capacity too large for the LDS-resident matcher (cap <= 4800)");
   ORBHIP_REQUIRE(cap < (1 << 24), ORBHIP_EINVAL, "cap too large");
-  if (lds > 64 * 1024) {                                   // the dynamic-LDS opt-in is per device: cache it per device, under a lock
+  if (!mfma && lds > 64 * 1024) {                                   // the dynamic-LDS opt-in is per device: cache it per device, under a lock
     static std::mutex mu; static size_t attr_set[64] = {0};
     int dev = 0;
     ORBHIP_CHECK_HIP(hipGetDevice(&dev));
@@ -558,7 +836,7 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
   // workgroups, 0.67 ms as 512), so a launch is split until it has about one workgroup per CU - 64 pairs: 0.63 ms unsplit,
   // 0.38 / 0.28 / 0.35 ms with 2 / 4 / 8 workgroups per pair.  ORBHIP_MATCH_SPLIT forces a value.
   static const int force_split = []() { const char* e = std::getenv("ORBHIP_MATCH_SPLIT"); return e ? atoi(e) : 0; }();
-  const int nsplit = force_split > 0 ? force_split : std::min(8, std::max(1, 256 / npairs));
+  const int nsplit = mfma ? std::min((cap + MM_THREADS - 1) / MM_THREADS, force_split > 0 ? force_split : std::max(1, 320 / npairs)) : force_split > 0 ? force_split : std::min(8, std::max(1, 256 / npairs));
   int* scratch = nullptr;
   if (nsplit > 1) {
     // scratch rows {30 bins, -, ticket} per (device, stream): zero when allocated and left zero by every launch (the last
@@ -582,7 +860,10 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
     }
     scratch = R.p;
   }
-  if (nsplit > 1)
+  if (mfma)
+    hipLaunchKernelGGL(k_match_pairs_mfma, dim3(npairs * nsplit), dim3(MM_THREADS), 0, (hipStream_t)stream, d_kps, d_desc, d_counts,
+                       cap, d_pair_a, d_pair_b, ratio, th, check_ori, d_match12, d_nmatch, nsplit, scratch);
+  else if (nsplit > 1)
     hipLaunchKernelGGL(k_match_pairs<1>, dim3(npairs * nsplit), dim3(MP_THREADS), lds, (hipStream_t)stream, d_kps, d_desc, d_counts,
                        cap, d_pair_a, d_pair_b, ratio, th, check_ori, d_match12, d_nmatch, cap, nsplit, scratch);
   else

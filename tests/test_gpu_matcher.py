@@ -290,3 +290,45 @@ def test_match_frames_random_sizes_and_ties(oracle, seed):
     bi, bd, sd = _m().hamming_best2(d1, d2)
     obi, obd, osd = oracle.hamming_best2(d1, d2)
     assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+
+
+def test_match_frames_batch_one_workgroup_per_pair(oracle):
+    """A launch with a pair per CU takes the matrix-core matcher's nsplit = 1 shape (one workgroup walks all query blocks of its
+    pair, no merge through global memory): 330 ragged pairs (empty frames, one keypoint, sizes around the 512-query block and
+    the 128-target chunk) against the oracle, pair by pair."""
+    import torch
+    rng = np.random.default_rng(77)
+    nf, cap = 331, 1100
+    sizes = rng.choice([0, 1, 15, 16, 17, 127, 128, 129, 511, 512, 513, 700, 1024, 1025, 1100], nf).astype(np.int32)
+    pool = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    desc = np.zeros((nf, cap, 32), np.uint8); ang = np.zeros((nf, cap), np.float32)
+    for f in range(nf):
+        d = pool[rng.integers(0, len(pool), sizes[f])].copy()
+        flip = rng.random(sizes[f]) < 0.6
+        d[flip, rng.integers(0, 32, flip.sum())] ^= (1 << rng.integers(0, 8, flip.sum())).astype(np.uint8)
+        desc[f, :sizes[f]] = d
+        ang[f, :sizes[f]] = rng.choice([0.0, 45.0, 200.0], sizes[f]).astype(np.float32) + rng.uniform(0, 0.5, sizes[f]).astype(np.float32)
+    kps = np.zeros((nf, cap, 7), np.float32); kps[:, :, 3] = ang
+    pa = torch.arange(1, nf, dtype=torch.int32).cuda(); pb = torch.arange(0, nf - 1, dtype=torch.int32).cuda()
+    m, nm = _m(0.9, True).match_frames_batch(torch.from_numpy(kps).cuda(), torch.from_numpy(desc).cuda(), torch.from_numpy(sizes).cuda(), pa, pb)
+    torch.cuda.synchronize()
+    m = m.cpu().numpy(); nm = nm.cpu().numpy()
+    for p in range(nf - 1):
+        a, b = p + 1, p
+        om, on = oracle.match_frames(desc[a, :sizes[a]], ang[a, :sizes[a]], desc[b, :sizes[b]], ang[b, :sizes[b]], 0.9, 50, True)
+        assert nm[p] == on and np.array_equal(m[p, :sizes[a]], om), p
+        assert (m[p, sizes[a]:] == -1).all(), p
+
+
+@pytest.mark.parametrize("shape", [(40, 900, 1000), (330, 500, 520), (3, 1816, 2048), (2, 4000, 4080)])
+def test_match_frames_matrix_cores_equal_valu_kernel(shape):
+    """ORBHIP_MATCH_MFMA=1 / 0 (tools/match_ab.py, one process each: the switch is read once): identical match lists."""
+    import subprocess, sys, json
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "match_ab.py")
+    sha = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, ORBHIP_MATCH_MFMA=mode, WARM="1", REPS="2")
+        out = subprocess.run([sys.executable, tool, "--child"] + [str(x) for x in shape], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sha[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert sha["1"]["sha"] == sha["0"]["sha"] and sha["1"]["matches"] == sha["0"]["matches"] > 0

@@ -5,7 +5,8 @@ four databases hold every kernel of the front-end."""
 import sqlite3, collections, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
-NAMES = ["k_resize", "k_fast_cells", "k_octree", "k_blur7", "k_describe", "k_match_pairs"]
+MATCH = os.environ.get("PMC_MATCH_KERNEL", "k_match_pairs_mfma")      # (k_match_pairs when the passes ran with ORBHIP_MATCH_MFMA=0)
+NAMES = ["k_resize", "k_fast_cells", "k_octree", "k_blur7", "k_describe", MATCH]
 
 
 def load(tag):
@@ -58,7 +59,11 @@ for k in NAMES:
         "wait_any_frac_of_wave_cycles": a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in a else None,
         "lds_bank_conflict_cycles": a.get("SQ_LDS_BANK_CONFLICT", 0.0) * launches,
     }
-    if k == "k_match_pairs":
+    if "SQ_INSTS_MFMA" in i:
+        valu["kernels"][k]["mfma_insts"] = i["SQ_INSTS_MFMA"] * launches
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in a:            # (summed over the SIMDs: / 1024 SIMDs / kernel cycles = fraction of the matrix pipes' time)
+        valu["kernels"][k]["mfma_busy_frac"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] * launches / 1024.0 / cyc
+    if k == MATCH:
         valu["kernels"][k]["is_match"] = True
 tr = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/frontend_only.py %d 3: 3 x extract + match of one %d-frame batch, "
               "1241x376, 2000 features, this round's kernels); units KB (TCC_EA0 requests x 64 B / 1024). Calibration on gfx950 (round 1): "

@@ -14,8 +14,8 @@ run() {  # tag counters...
   f=$(find gpurun_out/pmc_x_$tag -name "*.db" | head -1); [ -n "$f" ] && [ "$f" != "gpurun_out/pmc_x_$tag/run_results.db" ] && mv "$f" gpurun_out/pmc_x_$tag/run_results.db
   ls -la gpurun_out/pmc_x_$tag | tail -2
 }
-run insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
-run active GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT
+run insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA
+run active GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 echo $B > gpurun_out/pmc_x_batch.txt
