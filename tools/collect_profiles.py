@@ -61,7 +61,7 @@ def take_kernel_csv(src, dst, must_name=()):
 
 print("collecting %s -> profiles/" % O)
 take_json("bench.json", RND + "_bench.json", ("value", "roofline"))
-take_kernel_csv("bench_kernel_stats.csv", RND + "_bench_kernel_stats.csv", ("k_fast_cells", "k_match_pairs", "k_blur7", "k_resize", "k_describe", "k_octree")      # (prefix match: k_match_pairs_mfma too))
+take_kernel_csv("bench_kernel_stats.csv", RND + "_bench_kernel_stats.csv", ("k_fast_cells", "k_match_pairs", "k_blur7", "k_resize", "k_describe", "k_octree"))      # (substring match: k_match_pairs_mfma too)
 take_json("bench_traced.json", RND + "_bench_traced.json", ("value", "kernels"))
 take_kernel_csv("localba_batch16_kernel_stats.csv", RND + "_localba_batch16_kernel_stats.csv", ("k_ba_schur",))
 take_kernel_csv("gba_c5_kernel_stats.csv", RND + "_gba_c5_kernel_stats.csv", ("k_chol",))
