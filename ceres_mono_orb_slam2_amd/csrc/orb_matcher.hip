@@ -277,7 +277,11 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
 // keeps (k1, k2) for its 16 rows; the 16 lanes of a DPP row are merged once at the end.  The k index inside an instruction is
 // the same function of (lane >> 4, byte) for A and B, so any consistent bit -> byte order gives the full sum.
 // 256 pairs of ~1816 x 1816: 0.205 ms against 0.506 ms (tools/match_ab.py, identical match lists); the products alone would
-// take ~0.11 ms.
+// take ~0.11 ms.  The VALU does NOT co-issue with this MFMA form (tools/ubench/mfma_valu_mix.hip: 19.6 cycles per product alone,
+// +4 per VALU instruction beside it), so the key updates and the expansion add to the products' time: PMC 42 % + 42 % busy.
+// Measured and not adopted: the 32x32x32 form, with which independent VALU work does co-issue in the microbenchmark - 32-query
+// tiles need 64 key registers per lane, the target operands then have to be re-read per half tile, and the kernel took 0.249 ms
+// (0.117 ms with the key updates removed: the products and the staging fit, the keys did not hide under them).
 #ifndef MM_THREADS
 #define MM_THREADS 512
 #endif

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512) void k(int* out, int iters) {
   for (int i = 0; i < 8; i++) s += k1[i] + k2[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-template <int NV, bool MF, bool CH1>
+template <int NV, bool MF, bool CH1, bool RD = false>
 __global__ __launch_bounds__(512) void k32(int* out, int iters) {
   v4i a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, (int)blockIdx.x, 7};
   v16i c[2];
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512) void k32(int* out, int iters) {
 #pragma unroll
       for (int v = 0; v < NV; v++) {
         const int j = (i * NV + v) & 7;
-        x = x * 5 + 1;
+        if (RD) x = c[1 - i][(v * 2) & 15]; else x = x * 5 + 1;      // RD: read a result of the accumulator that is NOT being accumulated
         int r;
         asm volatile("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(k1[j]), "v"(k2[j]), "v"(x));
         k2[j] = r;
@@ -68,14 +68,14 @@ __global__ __launch_bounds__(512) void k32(int* out, int iters) {
   for (int i = 0; i < 8; i++) s += k1[i] + k2[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-template <int NV, bool MF, bool CH1 = false>
+template <int NV, bool MF, bool CH1 = false, bool RD = false>
 void run32(const char* name) {
   const int nwg = 256, th = 512, iters = 2048;
   int* d; (void)hipMalloc(&d, (size_t)nwg * th * 4);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int w = 0; w < 20; w++) hipLaunchKernelGGL((k32<NV, MF, CH1>), dim3(nwg), dim3(th), 0, 0, d, iters);
+  for (int w = 0; w < 20; w++) hipLaunchKernelGGL((k32<NV, MF, CH1, RD>), dim3(nwg), dim3(th), 0, 0, d, iters);
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k32<NV, MF, CH1>), dim3(nwg), dim3(th), 0, 0, d, iters);
+  hipLaunchKernelGGL((k32<NV, MF, CH1, RD>), dim3(nwg), dim3(th), 0, 0, d, iters);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   const double slots = (double)nwg * (th / 64) * iters * 2 / 1024.0;
@@ -110,5 +110,7 @@ int main() {
   run32<8, false>("24 VALU only");
   run32<0, true, true>("MFMA only, ONE dependent chain");
   run32<2, true, true>("MFMA + 6 VALU, ONE dependent chain");
+  run32<4, true, false, true>("MFMA + 8 VALU reading the other accumulator");
+  run32<4, true, false, false>("MFMA + 12 VALU not reading results");
   return 0;
 }
