@@ -332,3 +332,31 @@ def test_match_frames_matrix_cores_equal_valu_kernel(shape):
         assert out.returncode == 0, out.stderr[-2000:]
         sha[mode] = json.loads(out.stdout.strip().splitlines()[-1])
     assert sha["1"]["sha"] == sha["0"]["sha"] and sha["1"]["matches"] == sha["0"]["matches"] > 0
+
+
+def test_match_frames_extreme_weights_and_sizes(oracle):
+    """The matrix-core matcher computes d - |a| = |b| - 2 |a & b| in the accumulator: descriptors of weight 0 and 256 (d - |a| from
+    -256 to +256), exact duplicates (distance 0 ties: the first target wins, the second-best distance is 0 too), a frame at the
+    kernel's capacity limit (4080 keypoints: 255 target tiles) and one just above it (the VALU kernel takes over)."""
+    rng = np.random.default_rng(123)
+    zeros = np.zeros((1, 32), np.uint8); ones = np.full((1, 32), 255, np.uint8)
+    rnd = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    half = np.concatenate([np.full((1, 16), 255, np.uint8), np.zeros((1, 16), np.uint8)], 1)
+    pool = np.concatenate([zeros, ones, half, 255 - half, rnd, rnd[:10], zeros, ones])
+    for n1, n2 in [(len(pool), len(pool)), (700, 4080), (4080, 33), (4081, 600)]:
+        d1 = pool[rng.integers(0, len(pool), n1)] if n1 != len(pool) else pool.copy()
+        d2 = pool[rng.integers(0, len(pool), n2)] if n2 != len(pool) else pool[::-1].copy()
+        a1 = rng.uniform(0, 360, n1).astype(np.float32); a2 = rng.uniform(0, 360, n2).astype(np.float32)
+        for ratio, th, ori in [(0.9, 50, True), (1.0, 256, False)]:
+            import torch
+            cap = max(n1, n2)                                   # (cap itself at the limit, unlike _match_pair's + 5)
+            kps = torch.zeros((2, cap, 7), dtype=torch.float32)
+            kps[0, :n1, 3] = torch.from_numpy(a1); kps[1, :n2, 3] = torch.from_numpy(a2)
+            desc = torch.zeros((2, cap, 32), dtype=torch.uint8)
+            desc[0, :n1] = torch.from_numpy(d1); desc[1, :n2] = torch.from_numpy(d2)
+            counts = torch.tensor([n1, n2], dtype=torch.int32)
+            pa = torch.tensor([0], dtype=torch.int32).cuda(); pb = torch.tensor([1], dtype=torch.int32).cuda()
+            m, nm = _m(ratio, ori).match_frames_batch(kps.cuda(), desc.cuda(), counts.cuda(), pa, pb, th=th)
+            torch.cuda.synchronize()
+            om, on = oracle.match_frames(d1, a1, d2, a2, ratio, th, ori)
+            assert int(nm[0]) == on and np.array_equal(m[0, :n1].cpu().numpy(), om), (n1, n2, ratio, th, ori)
