@@ -26,4 +26,4 @@ it = r[3]["iterations"]
 print("iterations per solve:", it)
 names += ["  (wave 0: scaled system + factor)", "  (wave 0: substitutions, model cost change)", "  (wave 0: candidate pose)"]
 for n_, v in zip(names, list(t)[:8]): print("%-42s %7.2f us per solve" % (n_, v / 100.0 / N))
-print("total %.2f us" % (sum(list(t)[:5]) / 100.0 / N))
+print("total %.2f us (the wave-0 lines are the parts of the solve phase: they add to it)" % (sum(list(t)[:8]) / 100.0 / N))
