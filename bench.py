@@ -457,6 +457,30 @@ def main():
         except Exception as e:                       # never lose the headline line to a secondary figure
             pipelined = {"error": repr(e)}
 
+    # ---- secondary figure (never `value`): the match leg at the size the metric names, 2000 x 2000 per pair (the timed frames keep
+    #      1816 keypoints on average: one canvas in eight is SURVEY 8(d)'s low-texture family, which stays below its quota)
+    match_full = None
+    if world == 1 and cap >= 2000:
+        try:
+            g = torch.Generator(device=dev); g.manual_seed(5)
+            d2k = torch.randint(0, 256, (B, cap, 32), dtype=torch.uint8, device=dev, generator=g)
+            k2k = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+            k2k[:, :, 3] = torch.rand((B, cap), device=dev, generator=g) * 360.0
+            c2k = torch.full((B,), 2000, dtype=torch.int32, device=dev)
+            mo = (torch.empty_like(match12), torch.empty_like(nmatch))
+            for _ in range(5): mt.match_frames_batch(k2k, d2k, c2k, pair_a, pair_b, out=mo)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): mt.match_frames_batch(k2k, d2k, c2k, pair_a, pair_b, out=mo)
+            e1.record(); torch.cuda.synchronize()
+            ms2k = e0.elapsed_time(e1) / 20
+            match_full = {"keypoints_per_frame": 2000, "pairs_per_launch": B, "ms_per_launch": ms2k, "distances_per_launch": 4.0e6 * B,
+                          "int8_Tops": 4.0e6 * B * MATCH_OPS_PER_DISTANCE / (ms2k * 1e-3) / 1e12,
+                          "note": "random descriptors, every frame at the full 2000 keypoints; the brute-force pass does not depend on the data"}
+            del d2k, k2k, c2k, mo
+        except Exception as e:
+            match_full = {"error": repr(e)}
+
     # ---- secondary figure (never `value`): the host-fed pipeline, rank 0 of a one-GPU run only
     pcie = None
     if S == 1 and world == 1 and not args.no_pcie:
@@ -643,6 +667,11 @@ def main():
             out["pipelined"] = pipelined
         if pcie is not None:
             out["pcie_inclusive"] = pcie
+        if match_full is not None:
+            if "ms_per_launch" in match_full:     # what the step would take with every frame at its quota: only the match leg grows
+                ms_step = dt / args.steps / M * 1e3
+                match_full["frames_per_s_if_every_frame_had_2000"] = B / ((ms_step - per_call["match"] + match_full["ms_per_launch"]) * 1e-3)
+            out["match_2000x2000"] = match_full
         if collective is not None:
             out["collective"] = collective
         if not args.no_cpu and world == 1:
