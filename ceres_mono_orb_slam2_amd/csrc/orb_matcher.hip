@@ -211,21 +211,22 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
         }
         res |= bin << 24;                                   // stash the bin (indices < 2^24)
       }
-      if (i < cap) M[i] = res;
+      // (split pairs: agent-scope stores, read back with agent-scope loads by the last workgroup - no __threadfence(), which writes
+      // back the XCD's whole L2; see k_match_pairs_mfma)
+      if (i < cap) { if (nsplit > 1) __hip_atomic_store(&M[i], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else M[i] = res; }
     }
   }
   __syncthreads();
   if (nsplit > 1) {
     // merge: partial bins -> the pair's scratch row; the last workgroup of the pair to arrive finishes it
     int* sc = scratch + (size_t)p * 32;
-    if (tid < HISTO_LENGTH && s_hist[tid]) atomicAdd(&sc[tid], s_hist[tid]);
-    __threadfence();                                        // (this workgroup's M entries and bins are visible device-wide)
+    if (tid < HISTO_LENGTH && s_hist[tid]) __hip_atomic_fetch_add(&sc[tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);                            // this thread's stores and atomics have reached the memory side
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&sc[31], 1) == nsplit - 1);
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(&sc[31], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1);
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    if (tid < HISTO_LENGTH) { s_hist[tid] = __atomic_load_n(&sc[tid], __ATOMIC_RELAXED); sc[tid] = 0; }
+    if (tid < HISTO_LENGTH) { s_hist[tid] = __hip_atomic_load(&sc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sc[tid] = 0; }
     if (tid == 31) sc[31] = 0;
     __syncthreads();
   }
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
   __syncthreads();
   int mine = 0;
   for (int i = tid; i < cap; i += MP_THREADS) {
-    int r = nsplit > 1 ? __atomic_load_n(&M[i], __ATOMIC_RELAXED) : M[i];       // (other workgroups wrote part of M)
+    int r = nsplit > 1 ? __hip_atomic_load(&M[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : M[i];       // (other workgroups wrote part of M)
     if (r >= 0) {
       int bin = r >> 24, j = r & 0xFFFFFF;
       if (check_ori && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) j = -1;
