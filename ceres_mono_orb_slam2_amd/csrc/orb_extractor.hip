@@ -1401,6 +1401,7 @@ struct orbx_ctx {
   // the blur pass only depends on the pyramid: it runs on a side stream concurrently with FAST + octree
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int lone_side_mode = 0;      // side-stream mode of a LONE frame for the next run_batch call (set by orbx_extract_chained, reset by run_batch)
   int overlap_blur = -1;       // -1: by batch size (see run_batch); 0: one stream; 1: k_blur7 on the side stream beside FAST + octree; 2: beside the octree only
 };
 
@@ -1709,7 +1710,10 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   // most of the chip idle: +3.2 % on the one-stream bench, 112.1k -> 115.5k frames/s; starting the blur of level 0 even earlier,
   // beside the resize chain, was measured too and adds nothing.  A lone frame stays on one stream: a fork / join costs more
   // than it hides)
-  const int side_mode = c->side ? (c->overlap_blur >= 0 ? c->overlap_blur : (nframes >= 8 ? 1 : 0)) : 0;
+  // (a lone frame inside a longer device chain - the Tracking step - does fork: the host is ahead of the device there, so the
+  // fork / join costs nothing on the critical path and the blur's 13.6 us run beside FAST + octree: 0.310 -> 0.297 ms per step)
+  const int side_mode = c->side ? (c->overlap_blur >= 0 ? c->overlap_blur : (nframes >= 8 ? 1 : (nframes == 1 ? c->lone_side_mode : 0))) : 0;
+  c->lone_side_mode = 0;
   auto launch_blur_side = [&]() -> int {
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -1916,6 +1920,18 @@ int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, 
   ORBHIP_REQUIRE(nframes <= 65535, ORBHIP_EINVAL, "at most 65535 frames per batch");
   return run_batch(c, d_imgs, w, h, stride, frame_stride, nframes, d_kps, d_desc, cap, d_counts, (hipStream_t)stream);
 }
+
+}  // extern "C"
+namespace orbhip {
+// orbx_extract_batch_device for ONE frame as a link of a longer device-resident chain (orb_track.hip): the blur goes to the
+// extractor's side stream.  Not part of the C ABI.
+int orbx_extract_chained(orbx_ctx* c, const uint8_t* d_img, int w, int h, int stride, orbx_keypoint* d_kps, uint8_t* d_desc, int cap,
+                         int32_t* d_count, void* stream) {
+  if (c) c->lone_side_mode = 1;
+  return orbx_extract_batch_device(c, d_img, w, h, stride, (size_t)stride * h, 1, d_kps, d_desc, cap, d_count, stream);
+}
+}  // namespace orbhip
+extern "C" {
 
 // Single-frame host path (what Frame::ExtractORB -> operator() is in the reference): latency matters more than bandwidth
 // here.  The image goes up with ONE 1-D copy through a pinned staging buffer (a 2-D pageable copy of a 1241-byte-stride

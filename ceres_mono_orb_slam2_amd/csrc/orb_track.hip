@@ -656,6 +656,10 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
 
 }  // namespace orbhip
 
+namespace orbhip {
+int orbx_extract_chained(orbx_ctx* c, const uint8_t* d_img, int w, int h, int stride, orbx_keypoint* d_kps, uint8_t* d_desc, int cap,
+                         int32_t* d_count, void* stream);      // orb_extractor.hip
+}
 using namespace orbhip;
 
 extern "C" {
@@ -730,7 +734,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     grid.min_x = bounds[0]; grid.min_y = bounds[2];
     grid.winv = static_cast<float>(FRAME_GRID_COLS) / (bounds[1] - bounds[0]); grid.hinv = static_cast<float>(FRAME_GRID_ROWS) / (bounds[3] - bounds[2]);
     orbx_keypoint* d_kps = (orbx_keypoint*)(dblk + oKps); uint8_t* d_desc = dblk + oDesc; int32_t* d_count = (int32_t*)(dblk + oCnt);
-    if ((rc = orbx_extract_batch_device(ctx, d_img, w, h, stride, (long long)stride * h, 1, d_kps, d_desc, icap, d_count, (void*)W.s))) return rc;
+    if ((rc = orbhip::orbx_extract_chained(ctx, d_img, w, h, stride, d_kps, d_desc, icap, d_count, (void*)W.s))) return rc;
     const TrkIn* dI = in.dev<TrkIn>(pI);
     hipLaunchKernelGGL(k_trk_prepare, dim3(1), dim3(1024), 0, W.s, dI, in.dev<double>(pX), in.dev<int32_t>(pO), in.dev<uint8_t>(pV), d_kps, d_count, icap, d_quv, d_qr,
                        d_qlo, d_qhi, d_qv, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>(), nq, d_total);
