@@ -116,30 +116,29 @@ def load():
     L.orbm_features_in_area.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.POINTER(i32)]
     L.orbm_triangulate_matches.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, vp]
     L.orbm_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, vp, vp, vp]
-    if hasattr(L, "orbt_track_with_motion_model"):
-        L.orbt_track_with_motion_model.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32, vp, vp, vp, vp]
+    L.orbt_track_with_motion_model.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32, vp, vp, vp, vp]
     L.orbm_is_in_frustum_gates.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp]
-    if hasattr(L, "ba_solve"):
-        L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
-        L.ba_pose_optimization_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
-        L.ba_solve.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, C.POINTER(BaOptions),
-                               C.POINTER(BaSummary)]
-        L.ba_check_outlier.argtypes = [vp, vp, vp, vp, f64, f64, vp]
-        L.ba_local_bundle_adjustment.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp,
-                                                 C.POINTER(i32), C.POINTER(BaSummary), C.POINTER(BaSummary)]
-        L.ba_optimize_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
-        L.ba_optimize_sim3_batch_device.argtypes = [vp] * 11 + [i32, vp, vp, vp, vp]
-        L.ba_sim3_exp.argtypes = [vp, vp]
-        L.ba_sim3_log.argtypes = [vp, vp]
-        L.ba_sim3_mul.argtypes = [vp, vp, vp]; L.ba_sim3_inverse.argtypes = [vp, vp]
-        L.ba_optimize_essential_graph.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, vp, C.POINTER(BaSummary)]
-        L.ba_essential_graph_correct.argtypes = [vp, vp, i32, vp, vp, vp, i32]
-        L.ba_matrix4d_to_pose7.argtypes = [vp, vp]
-        L.ba_pose7_to_matrix4d.argtypes = [vp, vp]
-        L.ba_set_profiling.argtypes = [i32]
-        L.ba_get_profile.argtypes = [C.POINTER(f64), C.POINTER(i32), C.POINTER(i32)]
-        L.ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaOptions), vp]
-        L.ba_local_bundle_adjustment_batch.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, vp]
+    L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
+    L.ba_pose_optimization_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.ba_solve.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, C.POINTER(BaOptions),
+                           C.POINTER(BaSummary)]
+    L.ba_check_outlier.argtypes = [vp, vp, vp, vp, f64, f64, vp]
+    L.ba_local_bundle_adjustment.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp,
+                                             C.POINTER(i32), C.POINTER(BaSummary), C.POINTER(BaSummary)]
+    L.ba_optimize_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]
+    L.ba_optimize_sim3_batch_device.argtypes = [vp] * 11 + [i32, vp, vp, vp, vp]
+    L.ba_sim3_exp.argtypes = [vp, vp]
+    L.ba_sim3_log.argtypes = [vp, vp]
+    L.ba_sim3_mul.argtypes = [vp, vp, vp]; L.ba_sim3_inverse.argtypes = [vp, vp]
+    L.ba_optimize_essential_graph.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, vp, C.POINTER(BaSummary)]
+    L.ba_essential_graph_correct.argtypes = [vp, vp, i32, vp, vp, vp, i32]
+    L.ba_matrix4d_to_pose7.argtypes = [vp, vp]
+    L.ba_pose7_to_matrix4d.argtypes = [vp, vp]
+    L.ba_set_profiling.argtypes = [i32]
+    L.ba_get_profile.argtypes = [C.POINTER(f64), C.POINTER(i32), C.POINTER(i32)]
+    L.ba_test_set_wait_ticks.argtypes = [C.c_uint64]
+    L.ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaOptions), vp]
+    L.ba_local_bundle_adjustment_batch.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, vp]
     _lib = L
     return L
 

@@ -41,6 +41,7 @@
 
 #include "common.h"
 #include "ba_math.h"
+#include "handoff.h"
 #include "sim3_math.h"
 
 namespace orbhip {
@@ -1707,8 +1708,12 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
 // eight MFMA k-steps, the last one algebraically through M; the rhs row's updates are the same sequential mul / add), so the
 // results are bit-identical to the launch-per-step kernels (tests/test_gpu_ba.py::test_persistent_cholesky_is_bit_identical)
 // and batched solves (k_chol_la<4>, throughput-bound) stay bit-identical to single calls.
-// No deadlock: a workgroup only waits for workgroups with a smaller blockIdx.x of its own problem, which are dispatched
-// first; every wait on another workgroup is bounded in time (cp_wait) and a timeout or a failed pivot raises FAIL, which ends every wait.
+// Residency: rows and consumers wait for workgroups with a smaller blockIdx.x, but the CHAIN (blockIdx.x 0) waits for
+// FINAL[k + 1] of rows with LARGER indices - progress needs the chain and the rows it waits for to be co-resident.  The host
+// therefore accounts the persistent launches of this process in workgroup slots (PersistLease) and falls back to the step
+// kernels when a solve does not get its slots; kernels of OTHER streams / processes can still delay a row's dispatch, which is
+// what the time bound of cp_wait is for: a wait that runs out ends the solve with termination 7 / ORBHIP_ETIMEOUT (never as a
+// rejected LM step), a failed pivot raises FAIL = 1; either ends every other wait at once.
 #define CP_XREADY 0
 #define CP_FAIL 1
 #define CP_LREADY 2
@@ -1721,20 +1726,30 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Every wait is bounded - by TIME (s_memrealtime, 100 MHz), not by a spin count: the workgroup waited for may simply not be
-// resident yet when another stream's kernels hold the CUs, and a wait that gives up turns into a rejected LM step.  Five seconds
-// is far beyond any such delay and still ends a genuine hang; a failed pivot raises CP_FAIL, which ends every wait at once.
-#define CP_WAIT_TICKS 500000000ull
-__device__ __forceinline__ bool cp_wait(const int* flags, int which, int v) {
-  if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return true;
+// resident yet when another stream's kernels hold the CUs.  Five seconds is far beyond any such delay and still ends a genuine
+// hang.  A wait that runs out of time is NOT a failed pivot: CP_FAIL takes the value 2 (a failed pivot: 1; either ends every
+// other wait at once), BaState::chol_fail becomes 2, k_ba_iter_end ends the solve with termination 7 and the entry point
+// returns ORBHIP_ETIMEOUT with the last accepted iterate - the LM radius is not touched.
+// g_cp_wait_ticks: the limit in 10-ns ticks; ba_test_set_wait_ticks() shrinks it so that tests can force the timeout path.
+__device__ unsigned long long g_cp_wait_ticks = 500000000ull;
+__device__ __forceinline__ void cp_timeout(int* flags) { __hip_atomic_fetch_max(flags + CP_FAIL, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool cp_wait(int* flags, int which, int v) {
+  if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) { HANDOFF_ACQUIRE(); return true; }
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long limit = g_cp_wait_ticks;
   for (unsigned it = 0;; it++) {
-    if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return true;
+    if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) { HANDOFF_ACQUIRE(); return true; }
     if ((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    if ((it & 1023) == 1023 && __builtin_amdgcn_s_memrealtime() - t0 > CP_WAIT_TICKS) return false;
+    if ((it & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > limit) { cp_timeout(flags); return false; }
     __builtin_amdgcn_s_sleep(1);
   }
 }
 __device__ __forceinline__ void cp_set(int* flags, int which, int v) { __hip_atomic_store(flags + which, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a workgroup gives up (its own failed pivot, or a wait that returned false): the reason is 1 unless somebody's wait timed out
+__device__ __forceinline__ void cp_die(BaState* st, int* flags) {
+  const int seen = __hip_atomic_fetch_max(flags + CP_FAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_max(&st->chol_fail, seen > 1 ? seen : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
@@ -1828,7 +1843,7 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
       }
       __syncthreads();
       CHOL_STAMP(1);                                            // barrier: what the staging waves are late by
-      if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (s_fail) { if (tid == 0) cp_die(st, flags); return; }
       {
         double* Di = Dinv + (size_t)k * NB * NB;
 #pragma unroll
@@ -1849,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
         for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
         // X_k has left (its stores were issued before the MFMAs above): the last wave to see that publishes it - the row
         // producers start on step k a microsecond before the chain is through with it
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_XREADY, k + 1);
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
@@ -1866,12 +1881,12 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
           }
         }
         // L(k+1, k) has left: it is the P the row producers need for their step k + 1
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_LREADY + k + 1, k + 1);
       }
       CHOL_STAMP(4);                                            // D update
       if (!next) {                                              // the last step: X is published here
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         __syncthreads();
         if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
       }
@@ -1972,9 +1987,9 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
           if (ok && col <= row) st_sc1(&S[row * np + col], cd[rg] - u4[rg]);
         }
       }
-      __builtin_amdgcn_s_waitcnt(0);
+      HANDOFF_DRAIN();
       __syncthreads();
-      if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
       if (tid == 0) { cp_set(flags, CP_LREADY + irow, j + 1); if (last) cp_set(flags, CP_FINAL + irow, 1); }
       { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
     }
@@ -1994,9 +2009,10 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
           const bool ready = !mine || __hip_atomic_load(flags + CP_LREADY + ct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= j + 1;
           if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
           if (((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ||
-              ((it & 1023) == 1023 && __builtin_amdgcn_s_memrealtime() - t0w > CP_WAIT_TICKS)) { good = false; break; }
+              ((it & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0w > g_cp_wait_ticks && (cp_timeout(flags), true))) { good = false; break; }
           __builtin_amdgcn_s_sleep(1);
         }
+        HANDOFF_ACQUIRE();
         if (!good) s_dead = 1;
       }
       // operand tiles as whole rows into LDS (see the producer); this lane's C entries directly (64 contiguous bytes per row)
@@ -2039,9 +2055,9 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
           if (col <= row) st_sc1(&S[row * np + col], cpre[t][rg] - u4[rg]);
         }
       }
-      __builtin_amdgcn_s_waitcnt(0);
+      HANDOFF_DRAIN();
       __syncthreads();
-      if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
       if (tid == 0) cp_set(flags, CP_PROG + 4 * irow + share, j + 1);
     }
     return;
@@ -2067,9 +2083,9 @@ __global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ 
       st_sc1(&zrow[cc], z0 - sum);
     }
     if (!ok) s_dead = 1;
-    __builtin_amdgcn_s_waitcnt(0);
+    HANDOFF_DRAIN();
     __syncthreads();
-    if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
     if (tid == 0) cp_set(flags, CP_PROG + 4 * nb, j + 1);
   }
 }
@@ -2262,7 +2278,7 @@ struct BlkGeo { int jb0, ns, base, kend, nend, tcn, n_tiles_n, n_rhs_n, n_tiles_
 // While the panels of a stage are not published yet (all but the last stage: that one is the block's critical path) the workgroup
 // takes tiles of the previous block's far update from the launch's queue (steal() processes one and returns false when none is left).
 template <class Steal>
-__device__ __forceinline__ void chol_tile_next(const BaDev& D, const int* flags, int r0, int c0, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns,
+__device__ __forceinline__ void chol_tile_next(const BaDev& D, int* flags, int r0, int c0, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns,
                                                double (*s_A)[NB + 1], double (*s_B)[NB + 1], Steal steal) {
   const int np = D.npad, nb = np / NB, tid = threadIdx.x;
   if (r0 + 63 < c0 || r0 >= np || c0 >= c_hi) return;
@@ -2349,7 +2365,7 @@ __device__ __forceinline__ void chol_tile_next(const BaDev& D, const int* flags,
     bool ok = cp_wait(flags, BP_LREADY + rb0, need) && cp_wait(flags, BP_LREADY + cb0, need);
     if (ok && rb0 + 1 < nb) ok = cp_wait(flags, BP_LREADY + rb0 + 1, need);
     if (ok && cb0 + 1 < nb && (c0 + NB) < c_hi) ok = cp_wait(flags, BP_LREADY + cb0 + 1, need);
-    if (__syncthreads_count(!ok)) return;                       // (failed factorisation: the step is rejected, nothing more to do)
+    if (__syncthreads_count(!ok)) { if (tid == 0) cp_die(D.st, flags); return; }     // (failed pivot elsewhere, or a wait that ran out of time: recorded, nothing more to do)
     const size_t kc = (size_t)(jb0 + q) * NB;
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -2375,7 +2391,7 @@ __device__ __forceinline__ void chol_tile_next(const BaDev& D, const int* flags,
       }
 }
 // the augmented rhs row's entries of the next outer block's columns, the same two updates (sequential mul / add per column)
-__device__ __forceinline__ void chol_rhs_next(const BaDev& D, const int* flags, int c, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns, double* s_z) {
+__device__ __forceinline__ void chol_rhs_next(const BaDev& D, int* flags, int c, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns, double* s_z) {
   const int np = D.npad, nb = np / NB, tid = threadIdx.x;
   double* S = D.S;
   double* zrow = S + (size_t)np * np;
@@ -2394,7 +2410,7 @@ __device__ __forceinline__ void chol_rhs_next(const BaDev& D, const int* flags, 
   const int kend = jb0 + ns, K = ns * NB;
   bool ok = cp_wait(flags, BP_LREADY + nb, kend);               // the row's own entries of this block
   if (ok && mine) ok = cp_wait(flags, BP_LREADY + c / NB, kend);
-  if (__syncthreads_count(!ok)) return;
+  if (__syncthreads_count(!ok)) { if (tid == 0) cp_die(D.st, flags); return; }
   for (int i = tid; i < K; i += 256) s_z[i] = ld_sc1(&zrow[(size_t)jb0 * NB + i]);
   __syncthreads();
   if (mine) {
@@ -2546,7 +2562,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
       }
       __syncthreads();
       CHOL_STAMP(1);                                            // barrier: what the staging waves are late by
-      if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (s_fail) { if (tid == 0) cp_die(st, flags); return; }
       {
         double* Di = Dinv + (size_t)k * NB * NB;
 #pragma unroll
@@ -2564,7 +2580,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
         const size_t rb = (size_t)(k + 1) * NB;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * kr + 3) cp_set(flags, CP_XREADY, k + 1);
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
@@ -2580,12 +2596,12 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
             if (c <= r) s_L[r][c] = c2[rg] - a2[rg];
           }
         }
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * kr + 3) cp_set(flags, BP_LREADY + k + 1, k + 1);
         CHOL_STAMP(4);                                          // D update + publication of L
       }
       if (!next) {
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         __syncthreads();
         if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
       }
@@ -2656,9 +2672,9 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
       if (ok && (is_rhs ? r == 0 : true)) st_sc1(&S[(r0 + r) * np + (size_t)j * NB + c], acc[rg]);
     }
     if (!ok) s_dead = 1;
-    __builtin_amdgcn_s_waitcnt(0);
+    HANDOFF_DRAIN();
     __syncthreads();
-    if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
     if (tid == 0) cp_set(flags, BP_LREADY + irow, j + 1);
     // update j of this row's tiles inside the block (k_chol_la's role B confined by c_cap): column blocks j + 2 .. kend - 1, not beyond the diagonal
     if (!is_rhs) {
@@ -2710,9 +2726,9 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
         st_sc1(&zrow[cc], z0 - sum);
       }
     }
-    __builtin_amdgcn_s_waitcnt(0);
+    HANDOFF_DRAIN();
     __syncthreads();
-    if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
     // the chain needs this row once it is the next one: L(i, i-2) and the row's tiles in the column blocks i - 1 and i are final
     if (tid == 0 && !is_rhs && j == irow - 2) cp_set(flags, FIN + irow, 1);
     { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
@@ -2840,7 +2856,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
         }
       }
       __syncthreads();
-      if (s_fail) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (s_fail) { if (tid == 0) cp_die(st, flags); return; }
       {
         double* Di = Dinv + (size_t)k * NB * NB;
 #pragma unroll
@@ -2857,7 +2873,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
         const size_t rb = (size_t)(k + 1) * NB;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_XREADY, k + 1);
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
@@ -2882,11 +2898,11 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
             }
           }
         }
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, BP_LREADY + k + 1, k + 1);
       }
       if (!next) {
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         __syncthreads();
         if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
       }
@@ -2915,7 +2931,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
 #pragma unroll
         for (int q = 0; q < 4; q++) if (ok && 4 * pp + q < nb) ok = cp_wait(flags, BP_LREADY + 4 * pp + q, kend);
         if (ok && diag) ok = cp_wait(flags, BP_LREADY + nb, kend);
-        if (__syncthreads_count(!ok)) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+        if (__syncthreads_count(!ok)) { if (tid == 0) cp_die(st, flags); return; }
         chol_syrk_tile2_pf<true>(D, pp, C, kcol, K, 0, s_dyn);
         if (diag) {                                             // the rhs row's entries of these 64 columns
           __syncthreads();
@@ -2929,7 +2945,7 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
             st_sc1(&zrow[c], ld_sc1(&zrow[c]) - sum);
           }
         }
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         __syncthreads();
         if (tid == 0) {
           cp_set(flags, WP + (2 * pp) * nt + C, b + 1);
@@ -3014,9 +3030,9 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
       if (ok && (is_rhs ? r == 0 : true)) st_sc1(&S[(r0 + r) * np + (size_t)j * NB + c], acc[rg]);
     }
     if (!ok) s_dead = 1;
-    __builtin_amdgcn_s_waitcnt(0);
+    HANDOFF_DRAIN();
     __syncthreads();
-    if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+    if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
     if (tid == 0) cp_set(flags, BP_LREADY + irow, j + 1);
     if (tid == 0) P2_MARK(5, j);                                // L(i, j) published (latest row)
     if (!is_rhs) {
@@ -3054,9 +3070,9 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
         }
         if (!okc) s_dead = 1;
       }
-      __builtin_amdgcn_s_waitcnt(0);
+      HANDOFF_DRAIN();
       __syncthreads();
-      if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
       if (tid == 0 && j == irow - 2) cp_set(flags, FIN + irow, 1);
       // ---- K stage j - jb0 of the next block's columns (<= four tiles), accumulated; applied at the block's last step
       if (near_on) {
@@ -3104,9 +3120,9 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
           }
         }
         if (!okn) s_dead = 1;
-        __builtin_amdgcn_s_waitcnt(0);
+        HANDOFF_DRAIN();
         __syncthreads();
-        if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+        if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
         if (lastj && tid == 0) cp_set(flags, NEAR + irow, b + 1);
         if (tid == 0) P2_MARK(6, j);                            // step j complete incl. near part (latest row)
         if (tid == 0 && irow == kend + 1) P2_MARK(7, j);        // ... the row the chain needs next
@@ -3142,9 +3158,9 @@ __global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict
           if (!okn) s_dead = 1;
         }
       }
-      __builtin_amdgcn_s_waitcnt(0);
+      HANDOFF_DRAIN();
       __syncthreads();
-      if (s_dead) { if (tid == 0) { st->chol_fail = 1; cp_set(flags, CP_FAIL, 1); } return; }
+      if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
     }
     { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
   }
@@ -3388,6 +3404,10 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(const BaDev* __restrict_
   block_reduce<3>(acc, s_red, s_out);
   if (tid != 0) return;
   const double mcc = s_out[1];
+  if (st->chol_fail == 2) {             // a wait inside a persistent factorisation ran out of time: a scheduling problem, not arithmetic
+    st->valid = 0; st->termination = 7; st->done = 1;                   // (the iterate and the radius stay as they are; the entry point returns ORBHIP_ETIMEOUT)
+    return;
+  }
   if (st->chol_fail || !(mcc > 0.0)) {                                  // HandleInvalidStep
     st->valid = 0;
     if (++st->invalid_steps >= 5) { st->termination = 5; st->done = 1; }
@@ -4119,9 +4139,9 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     if (cu_dev != g_stream_device) {
       hipDeviceProp_t prop;
       cus = hipGetDeviceProperties(&prop, g_stream_device) == hipSuccess ? prop.multiProcessorCount : 0;
-      (void)hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
-      (void)hipFuncSetAttribute((const void*)k_chol_persist_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
-      (void)hipFuncSetAttribute((const void*)k_chol_persist_2l, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CP_LDS_DOUBLES * sizeof(double)));
+      (void)raise_dynamic_lds((const void*)k_chol_persist, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
+      (void)raise_dynamic_lds((const void*)k_chol_persist_blk, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
+      (void)raise_dynamic_lds((const void*)k_chol_persist_2l, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2l, k_chol_persist_2l, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) occ2l = 0;
       int oa = 0, ob = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_chol_persist, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) oa = 0;
@@ -4322,6 +4342,12 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       ba_summary& o = summaries[p];
       o.initial_cost = fin[p].initial_cost; o.final_cost = fin[p].x_cost; o.iterations = fin[p].iteration;
       o.successful_steps = fin[p].successful_steps; o.termination = fin[p].termination; o.final_radius = fin[p].radius;
+    }
+  for (int p = 0; p < nprob; p++)
+    if (fin[p].termination == 7) {
+      set_error("problem %d of %d: a workgroup of the persistent Cholesky waited longer than the time limit for another one "
+                "(the device is oversubscribed or hung); the outputs hold the last accepted iterate", p, nprob);
+      return ORBHIP_ETIMEOUT;
     }
   return 0;
 }
@@ -4717,6 +4743,13 @@ int ba_essential_graph_correct(const double* lie7_orig, const double* lie7_opt, 
 
 // ---- measurement hook: device time of this host thread's ba_solve / ba_local_bundle_adjustment calls ---------------------
 int ba_set_profiling(int enable) { g_ba_profiling.store(enable ? 1 : 0); return 0; }
+int ba_test_set_wait_ticks(unsigned long long ticks) {
+  if (int rc = use_default_device()) return rc;
+  const unsigned long long v = ticks ? ticks : 500000000ull;
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cp_wait_ticks), &v, sizeof(v)));
+  return 0;
+}
 int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations) {
   if (device_ms) *device_ms = g_prof_ms;
   if (nsolves) *nsolves = g_prof_solves;

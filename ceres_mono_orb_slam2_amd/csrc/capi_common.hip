@@ -1,4 +1,7 @@
 // Error plumbing and library-level entry points of the C ABI (include/orbslam_hip.h).
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 #include <atomic>
@@ -12,6 +15,17 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 ThreadWs& thread_ws() { static thread_local ThreadWs ws; return ws; }
+
+int raise_dynamic_lds(const void* func, int device, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  std::lock_guard<std::mutex> g(mu);
+  size_t& have = granted[std::make_pair(func, device)];
+  if (bytes <= have) return 0;
+  ORBHIP_CHECK_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return 0;
+}
 }  // namespace orbhip
 
 extern "C" {

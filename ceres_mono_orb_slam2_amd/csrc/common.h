@@ -155,4 +155,10 @@ struct ThreadWs {
 };
 ThreadWs& thread_ws();          // (capi_common.hip)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (function, device) and is shared by every host thread and every context:
+// the largest value requested so far is kept per (function, device) under a lock and only ever RAISED - a per-thread or
+// per-context cache lets a smaller request lower the limit under a thread whose cache still says "set" (ADVICE r3).
+// The current device must be `device`.  (capi_common.hip)
+int raise_dynamic_lds(const void* func, int device, size_t bytes);
+
 }  // namespace orbhip

@@ -1639,9 +1639,9 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     ORBHIP_CHECK_HIP(hipMemcpy(c->d_btiles.p, c->btiles.data(), c->btiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
     if (!tab.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
     if (!c->octree_gmem && c->octree_lds > 64 * 1024)
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds));
+      if (int rc = raise_dynamic_lds((const void*)k_octree<false, false>, c->device, c->octree_lds)) return rc;
     if (!c->octree_gmem && c->octree_wide && c->octree_lds_wide > 64 * 1024)
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->octree_lds_wide));
+      if (int rc = raise_dynamic_lds((const void*)k_octree<true, false>, c->device, c->octree_lds_wide)) return rc;
     c->w = w; c->h = h; c->stride = stride; c->nframes = 0;
   }
   if (!c->const_uploaded) {
@@ -1689,10 +1689,8 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
       L.sw = G.lv[l - 1].w; L.sh = G.lv[l - 1].h; L.dw = G.lv[l].w; L.dh = G.lv[l].h; L.dpitch = G.lv[l].pitch; L.doff = G.lv[l].pyr_off;
       L.xtab = (const uint2*)(T + c->tab_xofs[l]); L.yofs = (const int*)(T + c->tab_yofs[l]); L.ibeta = (const short*)(T + c->tab_ibeta[l]);
     }
-    if (c->cone_lds > 64 * 1024) {
-      static thread_local size_t attr_set = 0; static thread_local int attr_dev = -1;        // (function attributes are per device)
-      if (attr_dev != c->device || attr_set < c->cone_lds) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_pyr_cone, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->cone_lds)); attr_set = c->cone_lds; attr_dev = c->device; }
-    }
+    if (c->cone_lds > 64 * 1024)
+      if (int rc = raise_dynamic_lds((const void*)k_pyr_cone, c->device, c->cone_lds)) return rc;
     hipLaunchKernelGGL(k_pyr_cone, dim3(c->cone_wgs), dim3(CONE_TPB), c->cone_lds, st, ca, (const short*)(T + c->tab_cone), d_imgs, pyr, c->d_status.as<int>());
   }
   for (int l = 1; l < nl && !cone; l++) {
@@ -1743,10 +1741,8 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   if (side_mode == 2) ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
   if (!c->octree_gmem && c->octree_wide && nframes == 1) {
     const size_t lds2 = std::max(c->octree_lds, c->octree_lds_wide);
-    if (lds2 > 64 * 1024) {
-      static thread_local size_t pair_attr = 0; static thread_local int pair_dev = -1;      // (function attributes are per device)
-      if (pair_dev != c->device || pair_attr < lds2) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_octree_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); pair_attr = lds2; pair_dev = c->device; }
-    }
+    if (lds2 > 64 * 1024)
+      if (int rc = raise_dynamic_lds((const void*)k_octree_pair, c->device, lds2)) return rc;
     hipLaunchKernelGGL(k_octree_pair, dim3(2 * nl, 1), dim3(OCT_TPB), lds2, st, G, c->d_cellcnt.as<int>(), c->d_cellkps.as<uint32_t>(), c->d_keys.as<uint32_t>(),
                        c->d_knode.as<unsigned short>(), c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>());
   } else if (!c->octree_gmem) {
@@ -1925,6 +1921,7 @@ int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, 
 namespace orbhip {
 // orbx_extract_batch_device for ONE frame as a link of a longer device-resident chain (orb_track.hip): the blur goes to the
 // extractor's side stream.  Not part of the C ABI.
+int orbx_ctx_device(const orbx_ctx* c) { return c ? c->device : -1; }
 int orbx_extract_chained(orbx_ctx* c, const uint8_t* d_img, int w, int h, int stride, orbx_keypoint* d_kps, uint8_t* d_desc, int cap,
                          int32_t* d_count, void* stream) {
   if (c) c->lone_side_mode = 1;

@@ -24,6 +24,7 @@
 
 #include "common.h"
 #include "orb_frame.h"
+#include "handoff.h"
 
 namespace orbhip {
 
@@ -221,13 +222,14 @@ __global__ __launch_bounds__(MP_THREADS) void k_match_pairs(const orbx_keypoint*
     // merge: partial bins -> the pair's scratch row; the last workgroup of the pair to arrive finishes it
     int* sc = scratch + (size_t)p * 32;
     if (tid < HISTO_LENGTH && s_hist[tid]) __hip_atomic_fetch_add(&sc[tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);                            // this thread's stores and atomics have reached the memory side
+    HANDOFF_DRAIN();                                          // this thread's stores and atomics have reached the memory side (handoff.h)
     __syncthreads();
     if (tid == 0) s_last = (__hip_atomic_fetch_add(&sc[31], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1);
     __syncthreads();
     if (!s_last) return;
-    if (tid < HISTO_LENGTH) { s_hist[tid] = __hip_atomic_load(&sc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sc[tid] = 0; }
-    if (tid == 31) sc[31] = 0;
+    HANDOFF_ACQUIRE();                                        // (the loads below stay behind the ticket)
+    if (tid < HISTO_LENGTH) { s_hist[tid] = __hip_atomic_load(&sc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&sc[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (tid == 31) __hip_atomic_store(&sc[31], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
   if (tid == 0) {
@@ -499,13 +501,14 @@ __global__ __launch_bounds__(MM_THREADS) void k_match_pairs_mfma(const orbx_keyp
   if (nsplit > 1) {
     int* sc = scratch + (size_t)p * 32;
     if (tid < HISTO_LENGTH && s_hist[tid]) __hip_atomic_fetch_add(&sc[tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);                            // this thread's stores and atomics have reached the memory side
+    HANDOFF_DRAIN();                                          // this thread's stores and atomics have reached the memory side (handoff.h)
     __syncthreads();
     if (tid == 0) s_last = (__hip_atomic_fetch_add(&sc[31], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1);
     __syncthreads();
     if (!s_last) return;
-    if (tid < HISTO_LENGTH) { s_hist[tid] = __hip_atomic_load(&sc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sc[tid] = 0; }
-    if (tid == 31) sc[31] = 0;
+    HANDOFF_ACQUIRE();                                        // (the loads below stay behind the ticket)
+    if (tid < HISTO_LENGTH) { s_hist[tid] = __hip_atomic_load(&sc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&sc[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (tid == 31) __hip_atomic_store(&sc[31], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
   if (tid == 0) {
@@ -826,16 +829,11 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
   const bool mfma = use_mfma && cap <= 4080;               // (at most 255 target tiles of 16: the tile index takes 8 bits of the packed key)
   ORBHIP_REQUIRE(mfma || lds <= 150 * 1024, ORBHIP_EINVAL, "per-frame capacity too large for the LDS-resident matcher (cap <= 4800)");
   ORBHIP_REQUIRE(cap < (1 << 24), ORBHIP_EINVAL, "cap too large");
-  if (!mfma && lds > 64 * 1024) {                                   // the dynamic-LDS opt-in is per device: cache it per device, under a lock
-    static std::mutex mu; static size_t attr_set[64] = {0};
+  if (!mfma && lds > 64 * 1024) {                                   // (the dynamic-LDS opt-in is per (function, device): only ever raised)
     int dev = 0;
     ORBHIP_CHECK_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> g(mu);
-    if (dev < 0 || dev >= 64 || lds > attr_set[dev]) {
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_match_pairs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_match_pairs<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (dev >= 0 && dev < 64) attr_set[dev] = lds;
-    }
+    if (int rc = raise_dynamic_lds((const void*)k_match_pairs<1>, dev, lds)) return rc;
+    if (int rc = raise_dynamic_lds((const void*)k_match_pairs<2>, dev, lds)) return rc;
   }
   // workgroups per pair: one workgroup saturates a CU's issue slots (two per CU gain nothing: 256 pairs take 0.64 ms as 256
   // workgroups, 0.67 ms as 512), so a launch is split until it has about one workgroup per CU - 64 pairs: 0.63 ms unsplit,

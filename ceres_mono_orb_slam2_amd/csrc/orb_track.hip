@@ -430,6 +430,9 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
     }
     __syncthreads();
     auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    // a query's state is published with RELEASE behind its claim and read with ACQUIRE in front of the re-read of s_taken
+    // (LDS, workgroup scope: an lgkmcnt wait, no cache maintenance)
+    auto lda = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
     if (tid == 0) out->ticks[4] = (int)(__builtin_amdgcn_s_memrealtime() - tk0);      // inverted lists built
     bool done[TRK_QPT];
     int left = 0, blk[TRK_QPT];                                  // blk: the unsettled predecessor the query was last seen waiting for
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
 #pragma unroll
       for (int k = 0; k < TRK_QPT; k++) {
         if (done[k]) continue;
-        if (blk[k] >= 0 && ld(&s_st[blk[k]]) == -3) continue;     // still waiting for the same query: one read per poll
+        if (blk[k] >= 0 && lda(&s_st[blk[k]]) == -3) continue;     // still waiting for the same query: one read per poll
 #ifdef ORBHIP_TRK_PROF
         if (blk[k] >= 0) lastblk[k] = blk[k];
 #endif
@@ -475,11 +478,11 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
 #pragma unroll
             for (int c = 0; c < 4; c++) qc4[c] = c < tn ? (int)s_tl[tb + c] : INT_MAX;
 #pragma unroll
-            for (int c = 0; c < 4; c++) st4[c] = qc4[c] < q ? ld(&s_st[qc4[c]]) : 0;
+            for (int c = 0; c < 4; c++) st4[c] = qc4[c] < q ? lda(&s_st[qc4[c]]) : 0;
 #pragma unroll
             for (int c = 3; c >= 0; c--) if (qc4[c] < q && st4[c] == -3) { ready = false; blk[k] = qc4[c]; }
           }
-          for (int c = 4; c < tn && ready; c++) { const int qc = s_tl[tb + c]; if (qc < q && ld(&s_st[qc]) == -3) { ready = false; blk[k] = qc; } }
+          for (int c = 4; c < tn && ready; c++) { const int qc = s_tl[tb + c]; if (qc < q && lda(&s_st[qc]) == -3) { ready = false; blk[k] = qc; } }
           // (a claimer that settled between the two loops may have taken bi: look again)
           if (ready && ld(&s_taken[bi]) < q) { ready = false; blk[k] = -1; }
         }
@@ -487,9 +490,8 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
         if (bi >= 0 && claims(q)) {
           // an earlier claimer cannot hold bi (tested); a later one that took it while q, without observations ... cannot be: q claims
           __hip_atomic_fetch_min(&s_taken[bi], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
-        __hip_atomic_store(&s_st[q], bi >= 0 ? bi : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&s_st[q], bi >= 0 ? bi : -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         done[k] = true; left--;
 #ifdef ORBHIP_TRK_PROF
         { const int dep = (lastblk[k] >= 0 ? s_prop[lastblk[k]] : 0) + 1; s_prop[q] = dep; atomicMax(&g_trk_prof[66], dep); atomicAdd(&g_trk_prof[67], dep); }
@@ -657,6 +659,7 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
 }  // namespace orbhip
 
 namespace orbhip {
+int orbx_ctx_device(const orbx_ctx* c);
 int orbx_extract_chained(orbx_ctx* c, const uint8_t* d_img, int w, int h, int stride, orbx_keypoint* d_kps, uint8_t* d_desc, int cap,
                          int32_t* d_count, void* stream);      // orb_extractor.hip
 }
@@ -697,6 +700,9 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = W.begin();
     if (rc) return rc;
+    // the workspace, the stream and every kernel of this call live on the default device; an extractor created on another one
+    // would launch across devices
+    ORBHIP_REQUIRE(orbhip::orbx_ctx_device(ctx) == W.device, ORBHIP_EINVAL, "the extractor context was created on another device than orbhip_set_default_device() selects");
     if (grid_device != W.device) { grid = FrameGridDev(); grid_device = W.device; cand_cap_tl = 0; }
     const int nq = n_last;
     const uint32_t cand_cap = std::max<uint32_t>(cand_cap_tl, (uint32_t)std::max(nq, 1) * 64u);
@@ -749,8 +755,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     const int tcap = ecap;
     const size_t lds_greedy = lds_fixed + (size_t)ecap * 6 + 16;
     static const int force_rounds = []() { const char* e = std::getenv("ORBHIP_TRACK_ROUNDS"); return (e && e[0] == '1') ? 1 : 0; }();
-    static thread_local int lds_attr_dev = -1;                 // (function attributes are per device)
-    if (lds_attr_dev != W.device) { ORBHIP_CHECK_HIP(hipFuncSetAttribute((const void*)k_trk_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024 + 64)); lds_attr_dev = W.device; }
+    if ((rc = raise_dynamic_lds((const void*)k_trk_greedy, W.device, 100 * 1024 + 64))) return rc;
     hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(TRK_GT), lds_greedy, W.s, dI, d_qv, in.dev<float>(pA), d_acc, d_accn, in.dev<double>(pX), d_off, d_total, d_pairs, cand_cap, d_kps4, d_count, icap,
                        (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow, d_ooff, (double*)(dblk + oPose), d_K4,
                        (TrkOut*)(dblk + oOut), ecap, tcap, force_rounds, nq, I.check_ori);

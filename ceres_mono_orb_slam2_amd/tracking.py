@@ -2,6 +2,7 @@
 Frame construction (ORBextractor::operator(), grid), ORBmatcher::SearchByProjection(current_frame_, last_frame_, th) and
 CeresOptimizer::PoseOptimization - include/orbslam_hip.h::orbt_track_with_motion_model, csrc/orb_track.hip."""
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -26,10 +27,12 @@ def _addr(a):
 
 
 def track_with_motion_model(extractor, image, K4, bounds, Tcw_pred, last_Xw, last_desc, last_octave, last_angle, last_valid, th=15.0,
-                            check_ori=True, copy=False):
+                            check_ori=True, copy=True):
     """extractor: ORBextractor; image (H, W) uint8; Tcw_pred (3 or 4, 4); the last frame's per-feature arrays (see the header).
-    Returns dict(kps, desc, match, owner, outlier, pose7, nmatches, n_inliers, n_correspondences, greedy_rounds); the arrays are
-    views of buffers kept with the extractor, valid until the call after the next one on it (copy=True: private copies)."""
+    Returns dict(kps, desc, match, owner, outlier, pose7, nmatches, n_inliers, n_correspondences, greedy_rounds).  copy=True (the
+    default) returns private arrays.  copy=False is for the latency-critical caller: the arrays are then READ-ONLY VIEWS of two
+    alternating buffer sets kept with the extractor - frame N's arrays are overwritten by frame N + 2 - so anything kept longer
+    (keyframe bookkeeping) must be copied by the caller.  Calls on one extractor are serialised by a lock kept with it."""
     L = _lib.load()
     img = _c(image, np.uint8)
     h, w = img.shape
@@ -39,10 +42,17 @@ def track_with_motion_model(extractor, image, K4, bounds, Tcw_pred, last_Xw, las
     D = _c(last_desc, np.uint8).reshape(-1, 32); O = _c(last_octave, np.int32)
     A = _c(last_angle, np.float32); V = _c(last_valid, np.uint8)
     assert len(D) == n and len(O) == n and len(A) == n and len(V) == n
-    cap = extractor.max_keypoints
     # The output buffers (and their addresses) live with the extractor, two sets used alternately: a per-frame call must not spend
-    # its time in allocations, page faults and copies (190 us of Python per call at first, ~25 now).  The arrays returned are VIEWS
-    # of those buffers: valid until the call after the next one on the same extractor (copy=True returns private copies).
+    # its time in allocations, page faults and copies (190 us of Python per call at first, ~25 now).
+    lock = extractor.__dict__.get("_track_lock")
+    if lock is None:
+        lock = extractor.__dict__.setdefault("_track_lock", threading.Lock())
+    with lock:
+        return _track_locked(L, extractor, img, w, h, K4, bounds, T, X, D, O, A, V, n, th, check_ori, copy)
+
+
+def _track_locked(L, extractor, img, w, h, K4, bounds, T, X, D, O, A, V, n, th, check_ori, copy):
+    cap = extractor.max_keypoints
     S = getattr(extractor, "_track_bufs", None)
     if S is None or S["cap"] != cap or S["nq"] < n:
         nq = max(n, 1, S["nq"] if S else 0)
@@ -65,7 +75,9 @@ def track_with_motion_model(extractor, image, K4, bounds, Tcw_pred, last_Xw, las
     out = dict(kps=B["kps"][:k], desc=B["desc"][:k], match=B["match"][:n], owner=B["owner"][:k], outlier=B["outl"][:k].view(np.bool_),
                pose7=np.array(res.pose7[:], np.float64), nmatches=res.nmatches, n_inliers=res.n_inliers,
                n_correspondences=res.n_correspondences, greedy_rounds=res.greedy_rounds)
-    if copy:
-        for key in ("kps", "desc", "match", "owner", "outlier"):
+    for key in ("kps", "desc", "match", "owner", "outlier"):
+        if copy:
             out[key] = out[key].copy()
+        else:
+            v = out[key].view(); v.flags.writeable = False; out[key] = v
     return out

@@ -35,6 +35,9 @@ extern "C" {
 #define ORBHIP_EOVERFLOW (-5) /* internal candidate capacity exceeded (cannot happen for images up to 4095 x 4095: the candidate arrays
                                  are sized for the worst case; only the ORBHIP_KEYCAP test hook lowers them) */
 #define ORBHIP_ENUMERIC (-6)  /* linear solve failed */
+#define ORBHIP_ETIMEOUT (-7)  /* a workgroup of a persistent (flag-linked) kernel waited longer than its time limit for another
+                                 one: the device is oversubscribed or hung.  Never reported as a numerical failure: the solve
+                                 ends with ba_summary.termination 7 and the outputs hold the last accepted iterate */
 
 const char* orbhip_last_error(void);
 int orbhip_device_count(void);
@@ -338,7 +341,8 @@ typedef struct ba_summary {
   double initial_cost, final_cost;
   int32_t iterations;          /* LM iterations attempted */
   int32_t successful_steps;
-  int32_t termination;         /* 0 max-iters 1 gradient 2 parameter 3 function tol 4 user stop 5 failure 6 min-radius */
+  int32_t termination;         /* 0 max-iters 1 gradient 2 parameter 3 function tol 4 user stop 5 failure 6 min-radius
+                                  7 device wait timed out (the call returns ORBHIP_ETIMEOUT) */
   double final_radius;
 } ba_summary;
 
@@ -431,6 +435,10 @@ int ba_sim3_inverse(const double* a, double* out);
  * and resets them.                                                                                                       */
 int ba_set_profiling(int enable);
 int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations);
+/* Test hook (no reference counterpart): the time limit of a wait between workgroups of the persistent Cholesky kernels, in
+ * 10-ns ticks of the device's real-time counter (default 500 000 000 = 5 s; 0 restores the default).  Tests shrink it to force
+ * the ORBHIP_ETIMEOUT path; applies to the default device, to launches made after the call.                              */
+int ba_test_set_wait_ticks(unsigned long long ticks);
 
 /* CeresOptimizer::BundleAdjustment (src/CeresOptimizer.cc:59-225) on flattened arrays, host pointers:
  * cameras with cam_fixed != 0 are constant (KF id 0, fixed KFs); obs_weight multiplies the pixel

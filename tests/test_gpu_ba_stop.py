@@ -106,3 +106,43 @@ def test_flag_set_before_the_call():
                                                        g["obs_inv_sigma2"], n_iterations=20, stop_flag=flag)
     assert s["termination"] == 4 and s["iterations"] == 0                        # callback after iteration 0
     assert np.array_equal(pts, g["pts0"])
+
+
+def test_wait_timeout_is_its_own_outcome_not_a_rejected_step():
+    """VERDICT r3 weak #6 / ADVICE r3: a workgroup of the persistent Cholesky that waits longer than its time limit for another
+    one used to raise chol_fail - the LM step was rejected, the radius shrank and the caller got a different, valid-looking
+    solution.  Now it is its own outcome: ba_summary.termination 7, the entry point returns ORBHIP_ETIMEOUT (-7), the LM radius is
+    untouched.  The test hook ba_test_set_wait_ticks(1) makes every wait that is not satisfied at once run out (the rows near the
+    bottom of a 600-unknown system wait ~100 us for their first panel), then restores the limit: the next solve must be
+    bit-identical to the one before the forced timeout."""
+    import ctypes as C
+    from ceres_mono_orb_slam2_amd import optimizer, _lib
+    L = _lib.load()
+    g = synth.make_ba_graph(77, ncam=101, npts=3000, nobs=15000, n_fixed=1)           # 600 unknowns: 19 block rows, k_chol_persist
+    a = (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"].astype(np.float64),
+         np.ones(len(g["obs_cam"]), np.uint8), 6)
+    poses0, pts0, s0 = optimizer.bundle_adjustment(*a)
+    assert s0["termination"] != 7 and s0["iterations"] >= 2
+    _lib.check(L.ba_test_set_wait_ticks(1), "ba_test_set_wait_ticks")
+    try:
+        K4 = np.ascontiguousarray(g["K4"], np.float64).reshape(-1, 4); poses = np.ascontiguousarray(g["poses0"], np.float64).copy()
+        pts = np.ascontiguousarray(g["pts0"], np.float64).reshape(-1, 3).copy(); cf = np.ascontiguousarray(g["cam_fixed"], np.uint8)
+        oc = np.ascontiguousarray(g["obs_cam"], np.int32); op = np.ascontiguousarray(g["obs_pt"], np.int32)
+        uv = np.ascontiguousarray(g["obs_uv"], np.float64).reshape(-1, 2); w = a[7]; rb = a[8]
+        o = _lib.BaOptions(6, float(optimizer.HUBER_DELTA), 0, None)
+        s = _lib.BaSummary()
+        rc = L.ba_solve(_lib.ptr(K4), _lib.ptr(poses), _lib.ptr(cf), len(cf), _lib.ptr(pts), len(pts), _lib.ptr(oc), _lib.ptr(op), _lib.ptr(uv),
+                        _lib.ptr(w), _lib.ptr(rb), len(oc), C.byref(o), C.byref(s))
+        d = s.as_dict()
+        assert rc == -7, (rc, d)
+        assert d["termination"] == 7 and d["successful_steps"] == 0 and d["iterations"] == 1
+        assert d["final_radius"] == 1e4                                              # initial_trust_region_radius: not shrunk
+        assert d["final_cost"] == d["initial_cost"] == s0["initial_cost"]
+        assert np.array_equal(poses, np.ascontiguousarray(g["poses0"], np.float64))  # the last accepted iterate = the start
+        assert b"time limit" in L.orbhip_last_error()
+        with pytest.raises(_lib.OrbHipError):
+            optimizer.bundle_adjustment(*a)
+    finally:
+        _lib.check(L.ba_test_set_wait_ticks(0), "ba_test_set_wait_ticks")
+    poses1, pts1, s1 = optimizer.bundle_adjustment(*a)
+    assert s1 == s0 and np.array_equal(poses1, poses0) and np.array_equal(pts1, pts0)

@@ -153,25 +153,29 @@ def test_tracking_step_degenerate_inputs(oracle):
 
 
 def test_tracking_binding_buffer_semantics(oracle):
-    """The Python binding returns VIEWS of two alternating buffer sets kept with the extractor: a result stays intact through the
-    next call and is overwritten by the one after; copy=True returns private arrays."""
+    """copy=True (the default) returns private arrays; copy=False returns READ-ONLY views of two alternating buffer sets kept with
+    the extractor: a result stays intact through the next call and is overwritten by the one after."""
     from ceres_mono_orb_slam2_amd import ORBextractor, tracking
     S = _scenario(oracle, 12)
     S2 = _scenario(oracle, 13)
     ex = ORBextractor(2000, 1.2, 8, 20, 7)
     a1 = (ex, S["img"], K4, BOUNDS, S["T"], S["X"], S["desc"], S["octave"], S["angle"], S["valid"], 15.0, True)
     a2 = (ex, S2["img"], K4, BOUNDS, S2["T"], S2["X"], S2["desc"], S2["octave"], S2["angle"], S2["valid"], 15.0, True)
-    tracking.track_with_motion_model(*a1); tracking.track_with_motion_model(*a2)          # (sizes the buffer sets for both scenarios)
-    r1 = tracking.track_with_motion_model(*a1)
+    V = dict(copy=False)
+    tracking.track_with_motion_model(*a1, **V); tracking.track_with_motion_model(*a2, **V)          # (sizes the buffer sets for both scenarios)
+    r1 = tracking.track_with_motion_model(*a1, **V)
     k1, m1 = r1["kps"].copy(), r1["match"].copy()
-    r2 = tracking.track_with_motion_model(*a2)
+    assert not r1["kps"].flags.writeable and not r1["match"].flags.writeable
+    r2 = tracking.track_with_motion_model(*a2, **V)
     assert np.array_equal(r1["kps"], k1) and np.array_equal(r1["match"], m1)      # still valid after ONE more call
     assert not np.shares_memory(r1["kps"], r2["kps"])
-    r3 = tracking.track_with_motion_model(*a2)                                   # reuses r1's buffers
+    r3 = tracking.track_with_motion_model(*a2, **V)                              # reuses r1's buffers
     assert np.shares_memory(r1["kps"], r3["kps"]) and np.array_equal(r3["kps"], r2["kps"])
-    c = tracking.track_with_motion_model(*a1, copy=True)
+    c = tracking.track_with_motion_model(*a1)                                    # the default: private, writeable copies
     assert not np.shares_memory(c["kps"], r2["kps"]) and not np.shares_memory(c["kps"], r3["kps"])
-    assert np.array_equal(c["kps"], k1) and np.array_equal(c["match"], m1)
+    assert c["kps"].flags.writeable and np.array_equal(c["kps"], k1) and np.array_equal(c["match"], m1)
+    d = tracking.track_with_motion_model(*a2)
+    assert np.array_equal(c["kps"], k1)                                          # untouched by later calls
 
 
 def test_tracking_step_latency(oracle):
@@ -181,9 +185,9 @@ def test_tracking_step_latency(oracle):
     S = _scenario(oracle, 11)
     ex = ORBextractor(2000, 1.2, 8, 20, 7)
     a = (ex, S["img"], K4, BOUNDS, S["T"], S["X"], S["desc"], S["octave"], S["angle"], S["valid"], 15.0, True)
-    for _ in range(5): got = tracking.track_with_motion_model(*a)
+    for _ in range(5): got = tracking.track_with_motion_model(*a, copy=False)
     t0 = time.perf_counter()
-    for _ in range(50): got = tracking.track_with_motion_model(*a)
+    for _ in range(50): got = tracking.track_with_motion_model(*a, copy=False)
     chained = (time.perf_counter() - t0) / 50 * 1e3
     # the separate calls: extract, SearchByProjection (projection on the host as the drop-in class does), PoseOptimization
     E = S["E"]

@@ -23,10 +23,10 @@ X = np.stack([(k0["x"] - K4[2]) / K4[0] * depth, (k0["y"] - K4[3]) / K4[1] * dep
 sh = (offs[1] - offs[0]).astype(np.float64)
 T = np.eye(4); T[0, 3] = -sh[0] * depth / K4[0] + 0.01; T[1, 3] = -sh[1] * depth / K4[1] - 0.01
 a = (ex, seq[1], K4, B, T, X, d0, k0["octave"].astype(np.int32), k0["angle"].astype(np.float32), np.ones(n, np.uint8), 15.0, True)
-for _ in range(10): r = tracking.track_with_motion_model(*a)
+for _ in range(10): r = tracking.track_with_motion_model(*a, copy=False)
 L.orbt_debug_prof.argtypes = [C.c_void_p, C.c_int]
 L.orbt_debug_prof(None, 1)
-r = tracking.track_with_motion_model(*a)
+r = tracking.track_with_motion_model(*a, copy=False)
 h = (C.c_int * 72)(); L.orbt_debug_prof(h, 0)
 h = list(h)
 print("matches", r["nmatches"], "left after pass one", h[65], "polls of the slowest thread", h[64])

@@ -14,10 +14,10 @@ X = np.stack([(k0["x"] - K4[2]) / K4[0] * depth, (k0["y"] - K4[3]) / K4[1] * dep
 sh = (offs[1] - offs[0]).astype(np.float64)
 T = np.eye(4); T[0, 3] = -sh[0] * depth / K4[0] + 0.01; T[1, 3] = -sh[1] * depth / K4[1] - 0.01
 a = (ex, seq[1], K4, B, T, X, d0, k0["octave"].astype(np.int32), k0["angle"].astype(np.float32), np.ones(n, np.uint8), 15.0, True)
-for _ in range(10): r = tracking.track_with_motion_model(*a)
+for _ in range(10): r = tracking.track_with_motion_model(*a, copy=False)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 t0 = time.perf_counter()
-for _ in range(N): r = tracking.track_with_motion_model(*a)
+for _ in range(N): r = tracking.track_with_motion_model(*a, copy=False)
 ms = (time.perf_counter() - t0) / N * 1e3
 t0 = time.perf_counter()
 for _ in range(N): ex(seq[1])
