@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256) void k_sim3_lm(const double* __restrict__ K1s,
 struct BaState {
   double radius, decrease_factor, x_cost, x_norm, initial_cost, cand_cost, model_cost_change, step_norm2, gmax;
   int iteration, successful_steps, termination, done, need_eval, first, valid, invalid_steps, chol_fail, accepted, max_iters;
+  int e_dirty;     // the iterate (or, the first time, the Jacobi scaling) changed since the E records were written: k_ba_E rewrites them
 };
 
 struct BaDev {            // device pointers of one problem
@@ -600,17 +601,18 @@ struct BaDev {            // device pointers of one problem
   const int* cam_off; const int* cam_obs; const int* cam_obs_pt;   // per-camera lists (sorted by point)
   const int* cam_pos;                // [nobs] position of an observation inside its camera's list (inverse of cam_obs)
   double* JcR;                       // [nobs][14] per-camera-ordered records {Jc (12), r (2)}: k_ba_cam_blocks streams them
-  double* r; double* Jc; double* Jp; // SoA: r[2][nobs], Jc[12][nobs], Jp[6][nobs]
+  double* r; double* Jc; double* Jp; // SoA: r[2][nobs], Jc[12][nobs], Jp[6][nobs] (the landmark blocks and the model residual of k_ba_backsub read them)
   double* B; double* gc; double* C; double* gp;       // unscaled blocks: B[nfc][21], gc[nfc][6], C[npts][6], gp[npts][3]
   double* scale_c; double* scale_p;  // Jacobi scaling [nfc][6], [npts][3]
-  double* Cinv; double* gps; double* E; double* EC;   // Cinv[npts][6], gps[npts][3], E[18][nobs], EC[18][nobs]
+  double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] records of 18 (ld_rec18): rewritten only when the iterate changes (k_ba_E)
   double* t3;                        // [nobs][3] E_i^T y_cam of the landmark back-substitution
   double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
   double* Dinv;                      // inverse of every 32x32 diagonal Cholesky block [npad/32][32][32]
   double* Mb;                        // persistent Cholesky: M_k = X_k P_k of every step [npad/32][32][32]
   int* cflags;                       // persistent Cholesky: hand-off flags of this problem [ncflags], zeroed by k_ba_iter_begin
   int ncflags;
-  const int* blk_a; const int* blk_b; const int* blk_off; const int* pair_i; const int* pair_j; int nblk;   // Schur block pair lists
+  const int* blk_a; const int* blk_b; const int* blk_off; const int* pair_i; const int* pair_j; int nblk;   // Schur block pair lists (pair_i: POSITION of the observation in its camera's list, pair_j: observation index)
+  const int* row_off;                // [nfc+1] the off-diagonal blocks (a, .) of block row a: blk indices row_off[a] .. row_off[a+1]
   const int* free_cams;              // [nfc] reduced column -> camera index
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
@@ -776,6 +778,7 @@ __global__ __launch_bounds__(AE_TPB) void k_ba_after_eval(const BaDev* __restric
     if (st->first) st->initial_cost = s_out[0];
     st->first = 0;
     st->need_eval = 0;
+    st->e_dirty = 1;
     if (st->gmax <= 1e-10) { st->termination = 1; st->done = 1; }
   }
 }
@@ -790,7 +793,7 @@ __global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
   if (F.done) return;
   if (D.cflags) for (int i = threadIdx.x; i < D.ncflags; i += blockDim.x) D.cflags[i] = 0;      // (any block size; the rest is thread 0's)
   if (threadIdx.x != 0) return;
-  st->valid = 0; st->accepted = 0; st->chol_fail = 0;
+  st->valid = 0; st->accepted = 0; st->chol_fail = 0; st->e_dirty = 0;
   // StopFlagCallback (include/CeresOptimizer.h:332-349) runs after every iteration, before the iteration-cap test: the
   // host keeps copying the caller's flag into this pinned byte while the enqueued iterations drain
   if (D.stop_dev && __atomic_load_n(D.stop_dev, __ATOMIC_RELAXED)) { st->termination = 4; st->done = 1; return; }
@@ -851,155 +854,210 @@ __device__ __forceinline__ void ld_rec18(const double* __restrict__ base, size_t
   x[16] = t.x; x[17] = t.y;
 }
 
-// per observation: E = (Jc S_c)^T (Jp S_p) (6x3) and E (C_s+D)^-1, stored AoS (18 doubles each).  Every wave transposes its
-// 64 x 18 results through LDS so that the AoS arrays are written as contiguous 512-byte runs (thread-strided 8-byte stores
-// of a 144-byte record cost 8x their bytes in write sectors - the kernel was the second most expensive of a batched solve).
-__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep_obs(const BaDev* __restrict__ Dv) {
+// per observation: E = (Jc S_c)^T (Jp S_p) (6x3), stored as 18-double records (ld_rec18).  E depends on the iterate and on the
+// Jacobi scaling only - not on the LM radius - so it is written when the iterate has changed (after_eval raises e_dirty, the
+// next k_ba_iter_begin clears it) instead of in every LM iteration, and E (C_s+D)^-1, which does depend on the radius, is no
+// longer stored at all: k_ba_schur forms it on the fly from E and the point's (C_s+D)^-1 (round 4: k_ba_schur_prep_obs read
+// Jc, Jp and wrote E AND E (C+D)^-1 in every iteration - 432 bytes per observation, the fourth most expensive kernel of a
+// batched solve).  The Jacobians are RECOMPUTED here from the observation (the same reproj_eval on the same iterate: the same
+// bits k_ba_eval saw), which is why k_ba_eval no longer stores the camera Jacobians in observation order.  Every wave
+// transposes its 64 x 18 results through LDS so that the records are written as contiguous 512-byte runs.
+__global__ __launch_bounds__(BA_TPB) void k_ba_E(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   const StFlags F = ld_flags(st);
-  if (F.done || !F.valid || D.fix_points) return;
+  const int dirty = st->e_dirty;
+  if (F.done || !dirty || D.fix_points) return;
   if ((int)blockIdx.x * BA_TPB >= D.nobs) return;
   __shared__ double s_t[BA_TPB / 64][64][19];          // + 1 pad
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i0 = blockIdx.x * BA_TPB + 64 * w;         // first observation of this wave
-  const int cc = (i < D.nobs) ? D.cam_col[D.obs_cam[i]] : -1;
+  const int c = (i < D.nobs) ? D.obs_cam[i] : 0;
+  const int cc = (i < D.nobs) ? D.cam_col[c] : -1;
   const bool act = cc >= 0;
   const unsigned long long amask = __ballot(act);
-  double e[18], ec[18];
+  double e[18];
   if (act) {
     const int p = D.obs_pt[i];
-    const size_t n = D.nobs;
+    double r[2], Jc[12], Jp[6];
+    (void)reproj_eval(D.K4 + 4 * c, D.poses + 7 * c, D.pts + 3 * (size_t)p, D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
+                      D.obs_w[i], D.obs_robust[i], D.huber, r, Jc, Jp);
     const double* sc = D.scale_c + 6 * (size_t)cc;
     const double* sp = D.scale_p + 3 * (size_t)p;
-    const double* Ci = D.Cinv + 6 * (size_t)p;
     double jp[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) jp[k] = D.Jp[k * n + i] * sp[k % 3];
+    for (int k = 0; k < 6; k++) jp[k] = Jp[k] * sp[k % 3];
 #pragma unroll
     for (int u = 0; u < 6; u++) {
-      const double j0 = D.Jc[u * n + i] * sc[u], j1 = D.Jc[(6 + u) * n + i] * sc[u];
-      const double e0 = j0 * jp[0] + j1 * jp[3], e1 = j0 * jp[1] + j1 * jp[4], e2 = j0 * jp[2] + j1 * jp[5];
-      e[3 * u] = e0; e[3 * u + 1] = e1; e[3 * u + 2] = e2;
-      ec[3 * u] = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
-      ec[3 * u + 1] = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
-      ec[3 * u + 2] = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
+      const double j0 = Jc[u] * sc[u], j1 = Jc[6 + u] * sc[u];
+      e[3 * u] = j0 * jp[0] + j1 * jp[3]; e[3 * u + 1] = j0 * jp[1] + j1 * jp[4]; e[3 * u + 2] = j0 * jp[2] + j1 * jp[5];
     }
+#pragma unroll
+    for (int k = 0; k < 18; k++) s_t[w][lane][k] = e[k];
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  double* dst = D.E + 16 * (size_t)i0;                                   // (record layout: ld_rec18)
+  double* dtail = D.E + 16 * (size_t)D.nobs + 2 * (size_t)i0;
+  const int rows = min(64, D.nobs - i0);
+  for (int idx = lane; idx < 16 * rows; idx += 64) {
+    const int r = idx >> 4, k = idx & 15;
+    if ((amask >> r) & 1ull) dst[idx] = s_t[w][r][k];
+  }
+  for (int idx = lane; idx < 2 * rows; idx += 64) {
+    const int r = idx >> 1, k = 16 + (idx & 1);
+    if ((amask >> r) & 1ull) dtail[idx] = s_t[w][r][k];
+  }
+}
+// x = E (C_s+D)^-1 of one record (the arithmetic of the former k_ba_schur_prep_obs, formed where it is used)
+__device__ __forceinline__ void e_times_cinv(const double* __restrict__ e, const double* __restrict__ Ci, double* __restrict__ x) {
+  const double c0 = Ci[0], c1 = Ci[1], c2 = Ci[2], c3 = Ci[3], c4 = Ci[4], c5 = Ci[5];
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    if (act) {
-#pragma unroll
-      for (int k = 0; k < 18; k++) s_t[w][lane][k] = pass ? ec[k] : e[k];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-    double* base = pass ? D.EC : D.E;
-    double* dst = base + 16 * (size_t)i0;                                   // (record layout: ld_rec18)
-    double* dtail = base + 16 * (size_t)D.nobs + 2 * (size_t)i0;
-    const int rows = min(64, D.nobs - i0);
-    for (int idx = lane; idx < 16 * rows; idx += 64) {
-      const int r = idx >> 4, k = idx & 15;
-      if ((amask >> r) & 1ull) dst[idx] = s_t[w][r][k];
-    }
-    for (int idx = lane; idx < 2 * rows; idx += 64) {
-      const int r = idx >> 1, k = 16 + (idx & 1);
-      if ((amask >> r) & 1ull) dtail[idx] = s_t[w][r][k];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  for (int u = 0; u < 6; u++) {
+    const double e0 = e[3 * u], e1 = e[3 * u + 1], e2 = e[3 * u + 2];
+    x[3 * u] = e0 * c0 + e1 * c1 + e2 * c2;
+    x[3 * u + 1] = e0 * c1 + e1 * c3 + e2 * c4;
+    x[3 * u + 2] = e0 * c2 + e1 * c4 + e2 * c5;
   }
 }
 
 // ---- reduced camera system S = B_s + D - sum E (C_s+D)^-1 E^T over the non-empty block pairs (a <= b) ----------------
-// One workgroup per block; the pair lists are long (C4 graph: 100 diagonal blocks of 90..600 pairs, 903 off-diagonal blocks,
-// mean 127, max 493 pairs), so the work is laid out one PAIR per thread: the 36 (diagonal: 21 lower-triangle) products
-// accumulate in registers and one fixed-order block reduction finishes the block - two dependent loads (index -> record)
-// per thread instead of a serial walk.  Workgroups 0..nfc-1 own the diagonal blocks and also build the rhs.
-// Tried: element-per-lane walks of the list (7 groups x 36 lanes: 52 us; one wave per block, 8 pairs in flight: 68 us).
+// Round 4: ONE WORKGROUP PER BLOCK ROW (free camera a).  The pair lists gather two 144-byte records per pair - x = E_i (C+D)^-1 of
+// camera a's observation and y = E_j of camera b's: 3 GB per launch of a 64-problem batch, the most expensive kernel of a batched
+// solve, bound by the gathers (4 TB/s).  Every x of a row belongs to camera a, so the workgroup forms x = E (C_s+D)^-1 ONCE per
+// observation of camera a (k_ba_schur_prep_obs used to store it for every observation in every iteration; a first version formed
+// it per PAIR inside the pair loop and was 35 % slower), keeps the records in LDS - pair_i holds the POSITION of the observation in
+// its camera's list - and only the y records are gathered: half the bytes.  The same pass over camera a's list builds the rhs
+//   rhs_a = g_s - sum over the camera's observations of EC_i * g_p.
+// Records beyond SR_CH observations of one camera do not fit the LDS and are formed from global memory where they are used.
+// The arithmetic per block is the former kernel's: diagonal block + rhs by the 256 threads (pair e of the list by thread e mod 256,
+// one fixed-order block reduction of 27 values), every off-diagonal block (a, b) by ONE WAVE (all 36 products in registers, DPP
+// wave sum) - four blocks of the row at a time.
 #define SC_TPB 256
+#define SR_CH 512                      /* records in LDS: 512 x 19 doubles = 77.8 KB, two workgroups per CU */
+#define SR_PITCH 19
 __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ Dv) {
-  const BaDev D = Dv[blockIdx.y];
-  const int* __restrict__ free_cams = D.free_cams;
+  // Workgroup -> (problem, block row).  The y records a row gathers belong to the cameras that share points with camera a - in a
+  // SLAM map mostly the next few keyframes -, i.e. to rows that run at about the same time; the dispatcher deals consecutive
+  // workgroup ids out over the 8 XCDs (one L2 each), so with the plain mapping those rows meet eight different L2s.  When the batch
+  // has a multiple of 8 problems, XCD k takes the problems k, k + 8, ... whole, row after row: a problem's E records then pass
+  // through ONE L2 and the gathers hit it.
+  int prob = blockIdx.y, a = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const int n = blockIdx.y * gridDim.x + blockIdx.x, k = n & 7, m = n >> 3;
+    prob = (m / (int)gridDim.x) * 8 + k; a = m % (int)gridDim.x;
+  }
+  const BaDev D = Dv[prob];
   const BaState* st = D.st;
   const StFlags F = ld_flags(st);
   if (F.done || !F.valid) return;
-  const int tid = threadIdx.x;
+  if (a >= D.nfc) return;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int np = D.npad;
-  __shared__ double s_red[16 * 36], s_out[36];
-  if ((int)blockIdx.x >= D.nfc) {
-    // off-diagonal blocks (a, b): ONE WAVE per block, four blocks per workgroup (mean 127 pairs: two trips of a wave), all 36
-    // products in registers and a wave-level reduction only.  (One 256-thread workgroup per block spent most of its VALU time
-    // in the reduction - 36 values x 18 DPP operations in each of four waves that held one pair per thread or none: 973 -> 774
-    // us per 64-problem launch with one wave per block; the diagonal blocks, 90..600 pairs plus the rhs, keep four waves.)
-    const int w = tid >> 6, lane = tid & 63;
-    const int blk = D.nfc + 4 * ((int)blockIdx.x - D.nfc) + w;
-    if (blk >= D.nblk) return;                                 // (wave-level exit: no workgroup barrier on this path)
-    const int a = D.blk_a[blk], b = D.blk_b[blk];
-    double acc[36];
+  const size_t nobs = (size_t)D.nobs;
+  extern __shared__ __attribute__((aligned(16))) double s_ec[];       // [SR_CH][SR_PITCH]
+  __shared__ double s_red[(SC_TPB / 64) * 27], s_out[27];
+  const int ca = D.free_cams[a];
+  const int lo_a = D.cam_off[ca], n_a = D.cam_off[ca + 1] - lo_a;
+  // (1) camera a's records -> LDS, and the rhs of camera a (its own block reduction: the six sums are not kept alive through (2))
+  {
+    double g6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (!D.fix_points) {
+      for (int t = tid; t < n_a; t += SC_TPB) {
+        const int e = lo_a + t, pt = D.cam_obs_pt[e];
+        double ei[18], ec[18];
+        ld_rec18(D.E, nobs, (size_t)D.cam_obs[e], ei);
+        e_times_cinv(ei, D.Cinv + 6 * (size_t)pt, ec);
+        if (t < SR_CH) {
 #pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+          for (int k = 0; k < 18; k++) s_ec[t * SR_PITCH + k] = ec[k];
+        }
+        const double* g = D.gps + 3 * (size_t)pt;
+#pragma unroll
+        for (int u = 0; u < 6; u++) g6[u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
+      }
+    }
+    block_reduce_dpp<6>(g6, s_red, s_out);                     // (its barriers also publish the records)
+    if (tid < 6) {
+      const double rv = D.gc[6 * (size_t)a + tid] * D.scale_c[6 * (size_t)a + tid] - s_out[tid];
+      D.rhs[6 * a + tid] = rv;
+      D.S[(size_t)np * np + 6 * a + tid] = rv;                 // augmented row: forward substitution rides the factorisation
+    }
+    __syncthreads();
+  }
+  auto get_x = [&](int pos, double* x) {                       // (a camera with more observations than the LDS holds)
+    const int e = lo_a + pos;
+    double ei[18];
+    ld_rec18(D.E, nobs, (size_t)D.cam_obs[e], ei);
+    e_times_cinv(ei, D.Cinv + 6 * (size_t)D.cam_obs_pt[e], x);
+  };
+  // (2) diagonal block (a, a): 21 lower-triangle products per pair; x row by row from LDS (not 18 values held beside y and the sums)
+  {
+    double acc[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) acc[k] = 0.0;
+    for (int e = D.blk_off[2 * a] + tid; e < D.blk_off[2 * a + 1]; e += SC_TPB) {
+      double y[18];
+      ld_rec18(D.E, nobs, (size_t)D.pair_j[e], y);
+      const int pos = D.pair_i[e];
+      if (pos < SR_CH) {
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+          const double x0 = s_ec[pos * SR_PITCH + 3 * u], x1 = s_ec[pos * SR_PITCH + 3 * u + 1], x2 = s_ec[pos * SR_PITCH + 3 * u + 2];
+#pragma unroll
+          for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x0 * y[3 * v] + x1 * y[3 * v + 1] + x2 * y[3 * v + 2];
+        }
+      } else {
+        double x[18];
+        get_x(pos, x);
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+#pragma unroll
+          for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
+      }
+    }
+    block_reduce_dpp<21>(acc, s_red, s_out);
+    if (tid < 21) {
+      int u = 0;
+      while ((u + 1) * (u + 2) / 2 <= tid) u++;
+      const int v = tid - u * (u + 1) / 2;
+      const double* sc = D.scale_c + 6 * (size_t)a;
+      double bs = D.B[21 * (size_t)a + sym6(u, v)] * sc[u] * sc[v];
+      if (u == v) bs += fmin(fmax(bs, 1e-6), 1e32) / st->radius;
+      D.S[(size_t)(6 * a + u) * np + 6 * a + v] = bs - s_out[tid];
+    }
+  }
+  // (3) off-diagonal blocks (a, b) of the row: one wave per block, four at a time
+  // (tried: 512 threads with a PAIR of waves per block, each half of the 6 x 6 product, under a 128-register cap for 16 waves per CU:
+  // 43 spilled registers, 843 us instead of 638 per 64-problem launch)
+  for (int blk = D.row_off[a] + w; blk < D.row_off[a + 1]; blk += SC_TPB / 64) {
+    const int b = D.blk_b[blk];
+    double a36[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) a36[k] = 0.0;
     for (int e = D.blk_off[2 * blk] + lane; e < D.blk_off[2 * blk + 1]; e += 64) {
       double x[18], y[18];
-      ld_rec18(D.EC, (size_t)D.nobs, (size_t)D.pair_i[e], x);
-      ld_rec18(D.E, (size_t)D.nobs, (size_t)D.pair_j[e], y);
+      ld_rec18(D.E, nobs, (size_t)D.pair_j[e], y);
+      const int pos = D.pair_i[e];
+      if (pos < SR_CH) {
+#pragma unroll
+        for (int k = 0; k < 18; k++) x[k] = s_ec[pos * SR_PITCH + k];
+      } else get_x(pos, x);
 #pragma unroll
       for (int u = 0; u < 6; u++)
 #pragma unroll
-        for (int v = 0; v < 6; v++) acc[6 * u + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
+        for (int v = 0; v < 6; v++) a36[6 * u + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
     }
+    double mine = 0.0;
 #pragma unroll
     for (int k = 0; k < 36; k++) {
-      const double t = wave_sum_dpp(acc[k]);                   // (total valid in lane 63)
-      if (lane == 63) s_red[w * 36 + k] = t;
+      const double t = lane_bcast(wave_sum_dpp(a36[k]), 63);   // (the total is valid in lane 63)
+      if (lane == k) mine = t;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
     if (lane < 36) {
       const int u = lane / 6, v = lane - 6 * u;
-      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -s_red[w * 36 + lane];       // lower triangle: block (b, a) = -(acc)^T
+      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -mine;       // lower triangle: block (b, a) = -(acc)^T
     }
-    return;
-  }
-  if ((int)blockIdx.x >= D.nblk) return;
-  // diagonal block (a, a): 21 lower-triangle products per pair, and the rhs of camera a
-  //   rhs_a = g_s - sum over the camera's observations of EC_i * g_p
-  // both sums are accumulated first and share ONE block reduction (27 values)
-  const int blk = blockIdx.x, a = blk;
-  double acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; k++) acc[k] = 0.0;
-  for (int e = D.blk_off[2 * blk] + tid; e < D.blk_off[2 * blk + 1]; e += SC_TPB) {
-    double x[18], y[18];
-    ld_rec18(D.EC, (size_t)D.nobs, (size_t)D.pair_i[e], x);
-    ld_rec18(D.E, (size_t)D.nobs, (size_t)D.pair_j[e], y);
-#pragma unroll
-    for (int u = 0; u < 6; u++)
-#pragma unroll
-      for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
-  }
-  if (!D.fix_points) {
-    const int ca = free_cams[a];
-    for (int e = D.cam_off[ca] + tid; e < D.cam_off[ca + 1]; e += SC_TPB) {
-      double ec[18];
-      ld_rec18(D.EC, (size_t)D.nobs, (size_t)D.cam_obs[e], ec);
-      const double* g = D.gps + 3 * (size_t)D.cam_obs_pt[e];
-#pragma unroll
-      for (int u = 0; u < 6; u++) acc[21 + u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
-    }
-  }
-  block_reduce_dpp<27>(acc, s_red, s_out);
-  if (tid < 21) {
-    int u = 0;
-    while ((u + 1) * (u + 2) / 2 <= tid) u++;
-    const int v = tid - u * (u + 1) / 2;
-    const double* sc = D.scale_c + 6 * (size_t)a;
-    double bs = D.B[21 * (size_t)a + sym6(u, v)] * sc[u] * sc[v];
-    if (u == v) bs += fmin(fmax(bs, 1e-6), 1e32) / st->radius;
-    D.S[(size_t)(6 * a + u) * np + 6 * a + v] = bs - s_out[tid];
-  } else if (tid < 27) {
-    const int u = tid - 21;
-    const double rv = D.gc[6 * (size_t)a + u] * D.scale_c[6 * (size_t)a + u] - s_out[tid];
-    D.rhs[6 * a + u] = rv;
-    D.S[(size_t)np * np + 6 * a + u] = rv;                          // augmented row: forward substitution rides the factorisation
   }
 }
 
@@ -3946,7 +4004,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   const int nparts = std::max(nb_obs, std::max(nb_cam, nb_pt));
   // Schur block pair lists: for every point, all ordered observation pairs (i, j) with col_i <= col_j,
   // grouped by block (col_i, col_j) with a counting sort (stable: point order, then list order).
-  std::vector<int> blk_a, blk_b, blk_off;
+  std::vector<int> blk_a, blk_b, blk_off, row_off((size_t)nfc + 1, 0);
   int* pair_i = nullptr; int* pair_j = nullptr; size_t npairs_all = 0;
   if (!opts->fix_points && nfc > 0) {
     // Per point, the free observations are first sorted by column (insertion sort, a handful of entries): the pairs with
@@ -3993,13 +4051,19 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
       const size_t k = (size_t)a * nfc + a;
       blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(cnt[k]); blk_off.push_back(cnt[k + 1]);
     }
-    for (int a = 0; a < nfc; a++)
+    for (int a = 0; a < nfc; a++) {
+      row_off[a] = (int)blk_a.size();
       for (int b2 = a + 1; b2 < nfc; b2++) {
         const size_t k = (size_t)a * nfc + b2;
         if (cnt[k + 1] > cnt[k]) { blk_a.push_back(a); blk_b.push_back(b2); blk_off.push_back(cnt[k]); blk_off.push_back(cnt[k + 1]); }
       }
+    }
+    row_off[nfc] = (int)blk_a.size();
+    // k_ba_schur keeps camera a's records in LDS by list position: pair_i = position of the observation inside its camera's list
+    for (size_t e = 0; e < npairs_all; e++) { const int i = pair_i[e]; pair_i[e] = cam_pos[i] - cam_off[oc[i]]; }
   } else {
     for (int a = 0; a < nfc; a++) { blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(0); blk_off.push_back(0); }
+    for (int a = 0; a <= nfc; a++) row_off[a] = nfc;
   }
   const int nblk = (int)blk_a.size();
   out->t_struct_ms = ba_now_ms() - t_start;
@@ -4021,6 +4085,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.cam_obs = H.arena_dev(cam_obs); D.cam_obs_pt = H.arena_dev(cam_obs_pt);
   D.cam_pos = H.arena_dev(cam_pos); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
   D.free_cams = H.upload_staged(free_cams.data(), nfc, &rc, s);
+  D.row_off = H.upload_staged(row_off.data(), (size_t)nfc + 1, &rc, s);
   D.blk_a = H.upload_staged(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload_staged(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload_staged(blk_off.data(), 2 * (size_t)nblk, &rc, s);
   D.pair_i = H.upload(pair_i, npairs_all, &rc, s); D.pair_j = H.upload(pair_j, npairs_all, &rc, s);
   D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jc = H.alloc<double>(12 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
@@ -4028,7 +4093,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.C = H.alloc<double>(6 * (size_t)npts, &rc); D.gp = H.alloc<double>(3 * (size_t)npts, &rc);
   D.scale_c = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc); D.scale_p = H.alloc<double>(3 * (size_t)npts, &rc);
   D.Cinv = H.alloc<double>(6 * (size_t)npts, &rc); D.gps = H.alloc<double>(3 * (size_t)npts, &rc);
-  D.E = H.alloc<double>(18 * (size_t)nobs, &rc); D.EC = H.alloc<double>(18 * (size_t)nobs, &rc);
+  D.E = H.alloc<double>(18 * (size_t)nobs, &rc);
   D.t3 = H.alloc<double>(3 * (size_t)std::max(nobs, 1), &rc);
   D.cam_local = in.cam_local ? H.arena_dev(H.arena_copy(in.cam_local, ncam, &rc)) : nullptr;
   D.erase = in.cam_local ? H.alloc<unsigned char>(std::max(nobs, 1), &rc) : nullptr;
@@ -4106,7 +4171,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       const BaDev& D = B.P[p].D;
       B.Dh[p] = D;
       B.g_obs = std::max(B.g_obs, B.P[p].nb_obs); B.g_cam = std::max(B.g_cam, B.P[p].nb_cam); B.g_pt = std::max(B.g_pt, B.P[p].nb_pt);
-      B.g_blk = std::max(B.g_blk, D.nfc + (D.nblk - D.nfc + 3) / 4);      /* k_ba_schur: a workgroup per diagonal block, a WAVE per off-diagonal block */
+      B.g_blk = std::max(B.g_blk, D.nfc);      /* k_ba_schur: a workgroup per block row */
       B.g_npad = std::max(B.g_npad, D.npad); B.g_pad = std::max(B.g_pad, D.npad - D.n6); B.g_n6 = std::max(B.g_n6, D.n6);
       B.g_camcount = std::max(B.g_camcount, D.ncam); B.g_apply = std::max(B.g_apply, std::max(7 * D.ncam, 3 * D.npts));
       B.g_zero = std::max(B.g_zero, (size_t)D.n6 * D.npad);
@@ -4128,6 +4193,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     ORBHIP_CHECK_HIP(hipEventRecord(g_prof_ev[0], s));
   }
   const unsigned ny = (unsigned)nprob;
+  if (int r = raise_dynamic_lds((const void*)k_ba_schur, g_stream_device, SR_CH * SR_PITCH * sizeof(double))) return r;
   const int npad_all = g_npad;
   // ---- which form of the Cholesky this solve takes (0 step kernels, 1 persistent launches, 2 the one-launch two-level kernel)
   static const int persist_max = []() { const char* e = std::getenv("ORBHIP_BA_PERSIST"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
@@ -4166,13 +4232,13 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 0);
     hipLaunchKernelGGL(k_ba_cam_blocks, dim3(g_camcount + g_pt, ny), dim3(BA_TPB), 0, s, Dv, g_camcount);      // + the landmark blocks
     hipLaunchKernelGGL(k_ba_after_eval, dim3(1, ny), dim3(AE_TPB), 0, s, Dv);
+    hipLaunchKernelGGL(k_ba_E, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);              // (does something only when the iterate has changed)
   };
   auto enqueue_iteration = [&]() {
     hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(64), 0, s, Dv);
     const int g_zs = g_n6 > 0 ? std::min(1024, (int)((g_zero + 255) / 256)) : 0;
     hipLaunchKernelGGL(k_ba_schur_prep, dim3(g_pt + g_zs, ny), dim3(BA_TPB), 0, s, Dv, g_pt);                    // + zeroing of S
-    hipLaunchKernelGGL(k_ba_schur_prep_obs, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
-    if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), 0, s, Dv);
+    if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), SR_CH * SR_PITCH * sizeof(double), s, Dv);      // one workgroup per block row
     const int npad = B.g_npad_2l;                             // (0 when every problem of the batch takes the look-ahead scheme)
     auto launch_update = [&](hipStream_t st_, int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
       if (c_hi <= c_lo || r_lo >= npad + 1) return;
