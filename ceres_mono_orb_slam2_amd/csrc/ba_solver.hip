@@ -620,6 +620,7 @@ struct BaDev {            // device pointers of one problem
   int chol_la;                       // 1: this problem's reduced system is factored by the look-ahead kernel (npad <= 1024), 0: two-level blocking
   double huber;
   const volatile unsigned char* stop_dev;   // device-visible mirror of the caller's stop flag (pinned host byte of the calling thread)
+  unsigned char* out;                // this problem's slice of the batch's output block: {BaState | poses | pts | erase}, 256-byte aligned parts (k_ba_collect)
   BaState* st;
 };
 
@@ -1228,12 +1229,13 @@ __device__ __forceinline__ int diag_factor_invert_wave(double (*s_L)[NB + 1], do
   }
   return bad;
 }
-#ifdef ORBHIP_CHOL_PROF
-// ---- EXPERIMENT (profiling builds only, tools/factor_ab.py): the same factor + inverse by TWO cooperating waves -------------
+// ---- the same factor + inverse by TWO cooperating waves (k_chol_wg; tools/factor_ab.py compares it with the one-wave form) ----
 // A third of the one-wave factor's instructions are the trailing updates; if the factor were issue-bound, splitting the columns
 // over two waves would shorten it by about that much.  Measured: 3.91 -> 3.60 us per factor in isolation, bit-identical - the
 // factor is bound by the pivot recurrence (y_J -> l -> pivot -> rsq -> two Newton steps -> y_J+1, ~110 ns per column with the
-// deferred updates interleaved), not by the instruction count; not worth a fifth wave in every persistent workgroup.
+// deferred updates interleaved), not by the instruction count; not worth a fifth wave in every persistent workgroup.  Round 4:
+// k_chol_wg (one workgroup of eight waves per problem) takes THIS form: 156 registers instead of 332, so the kernel keeps two waves
+// per SIMD.
 // Wave A owns columns 0..15 of every row, wave B columns 16..31: A factors its columns exactly as above (its
 // updates stop at column 15), B meanwhile applies A's 16 column updates to its own columns as A publishes them (s_T holds every
 // lane's scaled entry of a column: B's own multiplier and the sixteen row entries it needs are there; s_col counts the
@@ -1343,6 +1345,7 @@ __device__ __forceinline__ int diag_factor_invert_2w(double (*s_L)[NB + 1], doub
   }
   return bad;
 }
+#ifdef ORBHIP_CHOL_PROF
 // debug: both factor functions on the same block, n repetitions each, for a bitwise comparison and a timing (tools/factor_ab.py)
 __global__ __launch_bounds__(256) void k_factor_a(const double* __restrict__ A, double* __restrict__ X1, int n, unsigned long long* ticks) {
   __shared__ double s_L[NB][NB + 1], s_X[NB][NB + 1];
@@ -1744,6 +1747,268 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
     }
   }
   CHOL_STAMP(6);                                              // L11^-1 store
+}
+
+// ---- problem-parallel Cholesky for LOCKSTEP BATCHES: one workgroup factors one reduced system (<= 1024 unknowns) ------------
+// Round 4 (VERDICT r3 next #1a).  A lockstep batch used to walk one k_chol_la<4> launch per 32-column step: 19 launches per LM
+// iteration at C4 size, every one a panel + a rank-32 update that reads and writes the whole trailing matrix (18 MB per
+// factorisation), every panel workgroup repeating the diagonal factor - 24 % of a batched solve.  A batch has many systems, so
+// the parallelism can come from the PROBLEMS instead: one 512-thread workgroup per system, no flags, no co-residency
+// requirement, no launch chain.  The schedule is LEFT-looking by block column: the tiles (i, c) of column c are brought up to
+// date in registers from the finished columns j < c (read once per column: 9.4 MB per factorisation, written once: 1.5 MB),
+// eight block rows at a time - one 32 x 32 tile per wave; per step j the workgroup stages L(c, j) and the eight L(i, j) in LDS
+// (the next step's loads are in flight during the matrix-core loop).
+// The ARITHMETIC is the step kernels', operation for operation, so results are bit-identical to k_chol_la / k_chol_persist
+// and a batched solve stays bit-identical to single calls (tests/test_gpu_ba.py):
+//   tile (i, c), i > c:  T = A(i, c); for j = 0 .. c-2: T = T - (eight MFMA k-steps of L(i, j) L(c, j)^T from zero)   [chol_syrk_body]
+//                        j = c-1: T'^T accumulated on the matrix cores from T^T with P = L(c, c-1), -L(i, c-1)       [apply_prev]
+//                        L(i, c) = T' X_c^T (eight k-steps from zero), X_c = L(c, c)^-1
+//   diagonal tile:       the syrk form for every j <= c-1, lower triangle; factor + inverse by two waves (diag_factor_invert_2w:
+//                        the one-wave function's bits)
+//   rhs row (row npad):  z_c -= sum_m L(c, 32 j + m) z(32 j + m) for j <= c-2 (sequential mul / add per column, VALU), then the
+//                        row's last update and the multiplication by X_c^T on the matrix cores as a 16-row tile whose first
+//                        row is z and whose other rows are zero (k_chol_la's role A sees the row exactly like that).
+#define CW_TPB 256
+#define CW_NW (CW_TPB / 64)
+#define CW_TILE (NB * (NB + 1))
+/* LDS: L(c, j) twice (double buffer), a scratch tile for the waves 1..3, X_c, D_c (wave 0's scratch outside the factor), the
+   factor's column buffer, the rhs row's z(j) twice: 75.5 KB, two workgroups per CU */
+#define CW_LDS_DOUBLES (7 * CW_TILE + NB * 64 + 2 * NB)
+__global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv) {
+  const BaDev D = Dv[blockIdx.x];
+  if (!D.chol_la) return;
+  BaState* st = D.st;
+  const StFlags F = ld_flags(st);
+  if (F.done || !F.valid || F.chol_fail) return;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + 5 * CW_TILE);
+  double (*s_L)[NB + 1] = (double (*)[NB + 1])(s_dyn + 6 * CW_TILE);
+  double (*s_T)[64] = (double (*)[64])(s_dyn + 7 * CW_TILE);                    // 16-byte aligned: 7 * 32 * 33 * 8 bytes
+  double* s_z = s_dyn + 7 * CW_TILE + NB * 64;                                  // [2][NB]
+  __shared__ int s_fail, s_col;
+  const int np = D.npad, nb = np / NB, tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  // this wave's scratch tile (layout change of its T, parking place during the factor): wave 0 takes D_c's tile - it is the
+  // diagonal wave in the group that factors
+  double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (w == 0 ? 6 : 1 + w) * CW_TILE);
+  double* S = D.S;
+  double* zrow = S + (size_t)np * np;
+  if (tid == 0) { s_fail = 0; s_col = 0; }
+  const int lrow = tid >> 4, lcol = 2 * (tid & 15);             // this thread's entries of the staged L(c, j): rows lrow and lrow + 16
+  __syncthreads();
+  for (int c = 0; c < nb; c++) {
+    const size_t cb = (size_t)c * NB;
+    const bool upd = c > 0;
+    // rows of this column: c (the diagonal tile), c + 1 .. nb - 1, and nb = the rhs row; one per wave at a time
+    for (int g0 = 0; c + g0 <= nb; g0 += CW_NW) {
+      const int my = c + g0 + w;
+      const bool valid = my <= nb, is_diag = my == c, is_rhs = my == nb, is_row = valid && !is_diag && !is_rhs;
+      const size_t rb = (size_t)my * NB;
+      CHOL_PROF_BEGIN(c);
+      double T[2][2][4];
+      double zc = 0.0;
+#pragma unroll
+      for (int I = 0; I < 2; I++)
+#pragma unroll
+        for (int J = 0; J < 2; J++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++)
+            T[I][J][rg] = (valid && !is_rhs) ? S[(rb + 16 * I + lk + 4 * rg) * np + cb + 16 * J + li] : 0.0;
+      if (is_rhs && lane < NB) zc = zrow[cb + lane];
+      // ---- the updates j = 0 .. c-1.  L(c, j), which every row of the column needs, is staged in LDS by the whole workgroup
+      // (double buffer, ONE barrier per step); a wave's own L(i, j) comes straight from global memory in the MFMA operand layout
+      // (a first version staged the four L(i, j) in LDS as well: two barriers and an LDS round trip per step, 2.2 us per step
+      // against 0.85 us of matrix-core work).  The loads of step j + 1 are in flight during the matrix-core loop of step j.
+      // Three register sets in rotation: step j computes from set j % 3 while the loads of steps j + 1 and j + 2 are in flight (a
+      // step's matrix-core loop is 0.85 us, a load's latency about 2 us: with ONE step of look-ahead a step took 1.9 us).
+      struct Stage { double A[16]; double2 pb[2]; double z; };    // A operand: [8 I + ks] = L(i, j)[16 I + li][4 ks + lk]; this thread's share of L(c, j); z(j)
+      Stage G0, G1, G2;
+#pragma unroll
+      for (int k = 0; k < 16; k++) { G0.A[k] = 0.0; G1.A[k] = 0.0; G2.A[k] = 0.0; }
+      G0.z = G1.z = G2.z = 0.0;
+      auto issue = [&](int j, Stage& G) {
+        const size_t jb = (size_t)j * NB;
+#pragma unroll
+        for (int h = 0; h < 2; h++) G.pb[h] = *(const double2*)&S[(cb + lrow + 16 * h) * np + jb + lcol];
+        if (is_row) {
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) G.A[8 * I + ks] = S[(rb + 16 * I + li) * np + jb + 4 * ks + lk];
+        }
+        if (is_rhs && lane < NB) G.z = zrow[jb + lane];
+      };
+      auto step = [&](int j, const Stage& Gc, Stage& Gn) {
+        double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + (j & 1) * CW_TILE);
+#pragma unroll
+        for (int h = 0; h < 2; h++) { s_B[lrow + 16 * h][lcol] = Gc.pb[h].x; s_B[lrow + 16 * h][lcol + 1] = Gc.pb[h].y; }
+        if (is_rhs && lane < NB) s_z[(j & 1) * NB + lane] = Gc.z;
+        __syncthreads();                                         // (buffer j & 1 was last read in step j - 2: every wave has passed step j - 1's barrier since)
+        if (j + 2 < c) issue(j + 2, Gn);
+        const bool last = j == c - 1;
+        if (is_rhs) {
+          if (!last && lane < NB) {                              // k_chol_la's rhs role: sequential mul / add, then one subtraction
+            const double* z = s_z + (j & 1) * NB;
+            double sum = 0.0;
+#pragma unroll
+            for (int m = 0; m < NB; m++) sum += s_B[lane][m] * z[m];
+            zc -= sum;
+          }
+        } else if (is_diag || (is_row && !last)) {               // chol_syrk_body: eight k-steps from zero, then C - acc
+          double4_t acc[2][2];
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = 0; J < 2; J++) acc[I][J] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) {
+            const double b0 = s_B[li][4 * ks + lk], b1 = s_B[16 + li][4 * ks + lk];
+            const double a0 = is_diag ? b0 : Gc.A[ks], a1 = is_diag ? b1 : Gc.A[8 + ks];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+          }
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = 0; J < 2; J++)
+#pragma unroll
+              for (int rg = 0; rg < 4; rg++) T[I][J][rg] = T[I][J][rg] - acc[I][J][rg];
+        }
+      };
+      if (c > 0) issue(0, G0);
+      CHOL_STAMP(0);                                             // T requested, first loads issued
+      if (c > 1) issue(1, G1);
+      for (int j = 0; j < c; j += 3) {
+        step(j, G0, G2);
+        if (j + 1 < c) step(j + 1, G1, G0);
+        if (j + 2 < c) step(j + 2, G2, G1);
+      }
+      CHOL_STAMP(1);                                             // the update steps
+      // (after the loop: P = L(c, c-1) is in LDS buffer (c - 1) & 1, this wave's L(i, c-1) in set (c - 1) % 3, z(c-1) in s_z)
+      const double (*s_P)[NB + 1] = (const double (*)[NB + 1])(s_dyn + ((c - 1) & 1) * CW_TILE);
+      // ---- T goes from the C layout of its updates to the A-operand layout through this wave's scratch tile (the step kernels make
+      // the same trip through global memory); the tile's last update rides on the way (k_chol_la's apply_prev: the registers are
+      // rows of the C tiles of A^T).  a[I][ks]: rows 16 I .. of T', operand layout.
+      double a[2][8];
+#pragma unroll
+      for (int I = 0; I < 2; I++)
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) a[I][ks] = 0.0;
+      if (valid && !is_diag) {
+        double ap[2][8];
+        const int lset = upd ? (c - 1) % 3 : 0;
+#pragma unroll
+        for (int I = 0; I < 2; I++)
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) {
+            double v = 0.0;
+            if (upd) { if (!is_rhs) v = -(lset == 0 ? G0.A[8 * I + ks] : lset == 1 ? G1.A[8 * I + ks] : G2.A[8 * I + ks]); else if (I == 0 && li == 0) v = -s_z[((c - 1) & 1) * NB + 4 * ks + lk]; }
+            ap[I][ks] = v;
+          }
+        if (is_rhs) { if (lane < NB) s_Sw[0][lane] = zc; }
+        else {
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = 0; J < 2; J++)
+#pragma unroll
+              for (int rg = 0; rg < 4; rg++) s_Sw[16 * I + lk + 4 * rg][16 * J + li] = T[I][J][rg];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int I = 0; I < 2; I++)
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) {
+            double v = 0.0;
+            if (!is_rhs) v = s_Sw[16 * I + li][4 * ks + lk]; else if (I == 0 && li == 0) v = s_Sw[0][4 * ks + lk];
+            a[I][ks] = v;
+          }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        if (upd) {
+#pragma unroll
+          for (int I = 0; I < 2; I++) {
+            if (is_rhs && I == 1) break;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+              double4_t acc = {a[I][4 * t], a[I][4 * t + 1], a[I][4 * t + 2], a[I][4 * t + 3]};
+#pragma unroll
+              for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], ap[I][ks], acc, 0, 0, 0);
+              a[I][4 * t] = acc[0]; a[I][4 * t + 1] = acc[1]; a[I][4 * t + 2] = acc[2]; a[I][4 * t + 3] = acc[3];
+            }
+          }
+        }
+      }
+      CHOL_STAMP(2);                                             // layout change + last update
+      // ---- the diagonal tile of this column: factor + inverse (first group only).  Nothing of the rows is kept in registers
+      // across the factor (156 registers of its own): T' waits in the scratch tiles, in the layout it is read back in.
+      if (g0 == 0) {
+        if (w == 0) {
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = 0; J < 2; J++)
+#pragma unroll
+              for (int rg = 0; rg < 4; rg++) {
+                const int r = 16 * I + lk + 4 * rg, cc = 16 * J + li;
+                s_L[r][cc] = (cc <= r) ? T[I][J][rg] : 0.0;
+              }
+        } else if (valid) {
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) s_Sw[16 * I + li][4 * ks + lk] = a[I][ks];
+        }
+        __syncthreads();
+#ifndef CW_EXP_NOFACTOR
+        if (w < 2) {
+          const int fail = diag_factor_invert_2w(s_L, s_X, s_T, &s_col, 16 * c, w);
+          if (fail && lane == 0) s_fail = 1;
+        }
+#else
+        for (int i = tid; i < NB * NB; i += CW_TPB) s_X[i / NB][i % NB] = (i / NB == i % NB) ? 1.0 : 0.0;
+#endif
+        __syncthreads();
+        if (s_fail) { if (tid == 0) st->chol_fail = 1; return; }
+        double* Di = D.Dinv + (size_t)c * NB * NB;
+        for (int i = tid; i < NB * NB; i += CW_TPB) Di[i] = s_X[i / NB][i % NB];
+        {
+          const bool back = w != 0 && valid;                      // (assigned on every path: nothing is live across the factor)
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) a[I][ks] = back ? s_Sw[16 * I + li][4 * ks + lk] : 0.0;
+        }
+      }
+      CHOL_STAMP(3);                                             // factor + inverse (first group)
+      if (valid && !is_diag) {
+        // ---- L(i, c) = T' X_c^T
+#pragma unroll
+        for (int I = 0; I < 2; I++) {
+          if (is_rhs && I == 1) break;                           // (one row)
+          double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 8; ks++) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I][ks], s_X[li][4 * ks + lk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I][ks], s_X[16 + li][4 * ks + lk], acc1, 0, 0, 0);
+          }
+          if (is_rhs) {
+            if (lk == 0) { zrow[cb + li] = acc0[0]; zrow[cb + 16 + li] = acc1[0]; }
+          } else {
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+              const size_t orow = rb + 16 * I + lk + 4 * rg;
+              S[orow * np + cb + li] = acc0[rg];
+              S[orow * np + cb + 16 + li] = acc1[rg];
+            }
+          }
+        }
+      }
+      __syncthreads();                                           // (the LDS buffers and s_z are free for the next group; this group's L tiles are visible)
+      CHOL_STAMP(4);                                             // L = T' X^T, stores, barrier
+    }
+  }
 }
 
 // ---- persistent look-ahead Cholesky: ONE launch for the whole factorisation of a reduced system <= 1024 -------------------
@@ -3529,6 +3794,32 @@ __global__ void k_ba_user_stop(const BaDev* __restrict__ Dv) {
 // Sim3Parameterization, edges = EssentialGraphErrorTerm (include/CeresOptimizer.h:266-330).  The LM controller, the dense
 // Cholesky (k_chol_*) and the step logic (k_ba_iter_begin / k_ba_iter_end) are the bundle-adjustment ones, driven through a
 // BaDev "view" that only carries S / rhs / Dinv / npad / part / state; the kernels below are the graph-specific parts.
+// ---- start of a solve: the LM state, zeroed rhs / partial sums of every problem in ONE launch (a 64-problem batch issued 64
+// state copies and 128 fills), and its end: state, poses, points and erase flags of every problem gathered into one block for
+// ONE download (192 - 256 copies before) - a batched solve spent 9 % of its GPU time in 4-us copy kernels.
+__device__ __forceinline__ size_t out_align(size_t b) { return (b + 255) & ~(size_t)255; }
+__global__ __launch_bounds__(256) void k_ba_init(const BaDev* __restrict__ Dv, BaState st0) {
+  const BaDev D = Dv[blockIdx.y];
+  const int n = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
+  for (int i = i0; i < D.npad; i += n) D.rhs[i] = 0.0;
+  for (int i = i0; i < 5 * D.nparts; i += n) D.part[i] = 0.0;
+  if (i0 == 0) *D.st = st0;
+}
+__global__ __launch_bounds__(256) void k_ba_collect(const BaDev* __restrict__ Dv, int with_erase) {
+  const BaDev D = Dv[blockIdx.y];
+  const int n = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
+  unsigned char* o = D.out;
+  if (i0 < (int)(sizeof(BaState) / 4)) ((int*)o)[i0] = ((const int*)D.st)[i0];
+  o += out_align(sizeof(BaState));
+  double* op = (double*)o;
+  for (int i = i0; i < 7 * D.ncam; i += n) op[i] = D.poses[i];
+  o += out_align(7 * (size_t)D.ncam * sizeof(double));
+  double* ox = (double*)o;
+  for (int i = i0; i < 3 * D.npts; i += n) ox[i] = D.pts[i];
+  o += out_align(3 * (size_t)D.npts * sizeof(double));
+  if (with_erase && D.erase) for (int i = i0; i < D.nobs; i += n) o[i] = D.erase[i];
+}
+
 struct PgDev {
   int n, nf, n7, npad, ne, nblk, nparts;
   double* x; double* cand; const int* col;                 // [n][7] tangents, reduced column of every vertex (-1 = constant)
@@ -3928,6 +4219,31 @@ struct HostBA {
     if (ar_off && hipMemcpyAsync(ar_d, ar_h, ar_off, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); return ORBHIP_ENODEV; }
     return 0;
   }
+  // second arena of a problem: the arrays whose sizes are known only after the pair lists have been counted (block lists, pair
+  // lists) - they were seven separate copies per problem
+  uint8_t* a2_h = nullptr; uint8_t* a2_d = nullptr; size_t a2_off = 0, a2_cap = 0;
+  int begin_arena2(size_t bytes) {
+    int rc = 0;
+    a2_h = pinned<uint8_t>(bytes, &rc); a2_d = alloc<uint8_t>(bytes, &rc);
+    a2_off = 0; a2_cap = bytes;
+    return rc;
+  }
+  template <typename T> T* arena2_host(size_t count, int* rc) {
+    const size_t need = arena_need(std::max<size_t>(count, 1), sizeof(T));
+    if (a2_off + need > a2_cap) { if (!*rc) { set_error("internal: second upload arena too small"); *rc = ORBHIP_EINVAL; } return nullptr; }
+    T* h = (T*)(a2_h + a2_off); a2_off += need;
+    return h;
+  }
+  template <typename T> T* arena2_copy(const T* src, size_t count, int* rc) {
+    T* h = arena2_host<T>(count, rc);
+    if (h && count) std::memcpy(h, src, count * sizeof(T));
+    return h;
+  }
+  template <typename T> T* arena2_dev(const T* host_ptr) const { return host_ptr ? (T*)(a2_d + ((const uint8_t*)host_ptr - a2_h)) : nullptr; }
+  int flush_arena2(hipStream_t st) {
+    if (a2_off && hipMemcpyAsync(a2_d, a2_h, a2_off, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); return ORBHIP_ENODEV; }
+    return 0;
+  }
   // for host data that does NOT outlive the enqueue (function-local vectors, stack structs): an asynchronous copy from
   // pageable memory may read its source after the call returned, so the data is first copied into this thread's pinned
   // staging, which stays valid until the solve has drained
@@ -3950,6 +4266,7 @@ struct BaBatch {
   std::vector<BaPrepared> P; std::vector<BaDev> Dh; const BaDev* Dv = nullptr;
   int g_obs, g_cam, g_pt, g_blk, g_npad, g_pad, g_n6, g_camcount, g_apply; size_t g_zero;
   int g_npad_la, g_npad_2l;         // largest reduced system factored by the look-ahead kernel / by the two-level scheme (0: none)
+  unsigned char* out_d = nullptr; unsigned char* out_h = nullptr; size_t out_bytes = 0; std::vector<size_t> out_off;      // k_ba_collect's block (device, pinned host)
 };
 static thread_local BaBatch g_batch;
 
@@ -4037,7 +4354,13 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
                 for (int i = lo; i < hi; i++) { const int ci = colv[i]; if (ci < 0) continue; for (int j = lo; j < hi; j++) if (colv[j] >= ci) cnt[(size_t)ci * nfc + colv[j] + 1]++; } });
     for (size_t k = 0; k < (size_t)nfc * nfc; k++) cnt[k + 1] += cnt[k];
     npairs_all = (size_t)cnt[(size_t)nfc * nfc];
-    pair_i = H.pinned<int>(npairs_all, &rc); pair_j = H.pinned<int>(npairs_all, &rc);
+    {
+      size_t nblk_up = (size_t)nfc;                           // the diagonal blocks + the non-empty off-diagonal ones
+      for (int a = 0; a < nfc; a++) for (int b2 = a + 1; b2 < nfc; b2++) { const size_t k = (size_t)a * nfc + b2; nblk_up += cnt[k + 1] > cnt[k]; }
+      typedef HostBA A;
+      if (int r = H.begin_arena2(2 * A::arena_need(npairs_all + 1, 4) + 2 * A::arena_need((size_t)nfc + 1, 4) + 2 * A::arena_need(nblk_up, 4) + A::arena_need(2 * nblk_up, 4) + 1024)) return r;
+    }
+    pair_i = H.arena2_host<int>(npairs_all, &rc); pair_j = H.arena2_host<int>(npairs_all, &rc);
     if (rc) return rc;
     std::vector<int> pos(cnt.begin(), cnt.end() - 1);
     per_point([&](const int* sc, const int* si, int m) {
@@ -4064,6 +4387,10 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   } else {
     for (int a = 0; a < nfc; a++) { blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(0); blk_off.push_back(0); }
     for (int a = 0; a <= nfc; a++) row_off[a] = nfc;
+    typedef HostBA A;
+    if (int r = H.begin_arena2(2 * A::arena_need(1, 4) + 2 * A::arena_need((size_t)nfc + 1, 4) + 2 * A::arena_need((size_t)nfc, 4) + A::arena_need(2 * (size_t)nfc, 4) + 1024)) return r;
+    pair_i = H.arena2_host<int>(0, &rc); pair_j = H.arena2_host<int>(0, &rc);
+    if (rc) return rc;
   }
   const int nblk = (int)blk_a.size();
   out->t_struct_ms = ba_now_ms() - t_start;
@@ -4084,10 +4411,11 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.pt_off = H.arena_dev(pt_off); D.cam_off = H.arena_dev(cam_off);
   D.cam_obs = H.arena_dev(cam_obs); D.cam_obs_pt = H.arena_dev(cam_obs_pt);
   D.cam_pos = H.arena_dev(cam_pos); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
-  D.free_cams = H.upload_staged(free_cams.data(), nfc, &rc, s);
-  D.row_off = H.upload_staged(row_off.data(), (size_t)nfc + 1, &rc, s);
-  D.blk_a = H.upload_staged(blk_a.data(), nblk, &rc, s); D.blk_b = H.upload_staged(blk_b.data(), nblk, &rc, s); D.blk_off = H.upload_staged(blk_off.data(), 2 * (size_t)nblk, &rc, s);
-  D.pair_i = H.upload(pair_i, npairs_all, &rc, s); D.pair_j = H.upload(pair_j, npairs_all, &rc, s);
+  D.free_cams = H.arena2_dev(H.arena2_copy(free_cams.data(), nfc, &rc));
+  D.row_off = H.arena2_dev(H.arena2_copy(row_off.data(), (size_t)nfc + 1, &rc));
+  D.blk_a = H.arena2_dev(H.arena2_copy(blk_a.data(), nblk, &rc)); D.blk_b = H.arena2_dev(H.arena2_copy(blk_b.data(), nblk, &rc));
+  D.blk_off = H.arena2_dev(H.arena2_copy(blk_off.data(), 2 * (size_t)nblk, &rc));
+  D.pair_i = H.arena2_dev(pair_i); D.pair_j = H.arena2_dev(pair_j);
   D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jc = H.alloc<double>(12 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
   D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
   D.C = H.alloc<double>(6 * (size_t)npts, &rc); D.gp = H.alloc<double>(3 * (size_t)npts, &rc);
@@ -4103,16 +4431,9 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.part = H.alloc<double>(5 * (size_t)nparts, &rc);
   D.st = H.alloc<BaState>(1, &rc);
   if (rc) return rc;
-  BaState st0; std::memset(&st0, 0, sizeof(st0));
-  st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = opts->max_iterations;
-  BaState* h_st = H.pinned<BaState>(1, &rc);                  // (pinned: the copy may run after this function has returned)
-  if (rc) return rc;
-  *h_st = st0;
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, h_st, sizeof(st0), hipMemcpyHostToDevice, s));
-  out->h_st = h_st;
+  out->h_st = nullptr;                                        // (the LM state, rhs and partial sums are initialised by k_ba_init for the whole batch)
   if (int r = H.flush_arena(s)) return r;
-  ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)npad * sizeof(double), s));
-  ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)nparts * sizeof(double), s));
+  if (int r = H.flush_arena2(s)) return r;
   out->D = D; out->nb_obs = nb_obs; out->nb_cam = nb_cam; out->nb_pt = nb_pt; out->npairs = npairs_all;
   out->perm.swap(perm); out->h_rob = orb;
   return 0;
@@ -4152,12 +4473,6 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       BaPrepared& Pp = B.P[p];
       for (int j = 0; j < D.nobs; j++) Pp.h_rob[j] = in[p].obs_robust[Pp.perm[j]];
       if (D.nobs) ORBHIP_CHECK_HIP(hipMemcpyAsync(const_cast<unsigned char*>(D.obs_robust), Pp.h_rob, D.nobs, hipMemcpyHostToDevice, s));
-      BaState st0; std::memset(&st0, 0, sizeof(st0));
-      st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = opts->max_iterations;
-      *Pp.h_st = st0;                                       // (the pinned state block of pass 1: that solve has drained)
-      ORBHIP_CHECK_HIP(hipMemcpyAsync(D.st, Pp.h_st, sizeof(st0), hipMemcpyHostToDevice, s));
-      ORBHIP_CHECK_HIP(hipMemsetAsync(D.rhs, 0, (size_t)D.npad * sizeof(double), s));
-      ORBHIP_CHECK_HIP(hipMemsetAsync(D.part, 0, 5 * (size_t)D.nparts * sizeof(double), s));
       Pp.t_struct_ms = 0.0;
     }
   } else {
@@ -4177,9 +4492,24 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       B.g_zero = std::max(B.g_zero, (size_t)D.n6 * D.npad);
       if (D.chol_la) B.g_npad_la = std::max(B.g_npad_la, D.npad); else B.g_npad_2l = std::max(B.g_npad_2l, D.npad);
     }
-    B.Dv = H.upload(B.Dh.data(), nprob, &rc, s);
+    // the batch's output block: one slice per problem
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    B.out_off.assign(nprob, 0); B.out_bytes = 0;
+    for (int p = 0; p < nprob; p++) {
+      B.out_off[p] = B.out_bytes;
+      B.out_bytes += al(sizeof(BaState)) + al(7 * (size_t)in[p].ncam * sizeof(double)) + al(3 * (size_t)in[p].npts * sizeof(double)) + al((size_t)std::max(in[p].nobs, 1));
+    }
+    B.out_d = H.alloc<unsigned char>(B.out_bytes, &rc); B.out_h = H.pinned<unsigned char>(B.out_bytes, &rc);
+    if (rc) return rc;
+    for (int p = 0; p < nprob; p++) { B.Dh[p].out = B.out_d + B.out_off[p]; B.P[p].D.out = B.Dh[p].out; }
+    B.Dv = H.upload_staged(B.Dh.data(), nprob, &rc, s);
     if (rc) return rc;
     g_batch_valid = true;
+  }
+  {
+    BaState st0; std::memset(&st0, 0, sizeof(st0));
+    st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = opts->max_iterations;
+    hipLaunchKernelGGL(k_ba_init, dim3(4, (unsigned)nprob), dim3(256), 0, s, B.Dv, st0);
   }
   std::vector<BaPrepared>& P = B.P;
   std::vector<BaDev>& Dh = B.Dh;
@@ -4194,6 +4524,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   }
   const unsigned ny = (unsigned)nprob;
   if (int r = raise_dynamic_lds((const void*)k_ba_schur, g_stream_device, SR_CH * SR_PITCH * sizeof(double))) return r;
+  if (int r = raise_dynamic_lds((const void*)k_chol_wg, g_stream_device, CW_LDS_DOUBLES * sizeof(double))) return r;
   const int npad_all = g_npad;
   // ---- which form of the Cholesky this solve takes (0 step kernels, 1 persistent launches, 2 the one-launch two-level kernel)
   static const int persist_max = []() { const char* e = std::getenv("ORBHIP_BA_PERSIST"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
@@ -4262,11 +4593,15 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     // look-ahead scheme (reduced systems <= 1024): one launch per 32-column step, panel + the previous step's update
     // (fewer than four problems: the whole factorisation as ONE persistent launch, bit-identical to the steps; ORBHIP_BA_PERSIST=0 disables)
     const bool use_persist = persist_mode > 0;
+    static const bool wg_on = []() { const char* e = std::getenv("ORBHIP_BA_WG"); return !(e && e[0] == '0'); }();      // (0: the step kernels, for the bit-identity tests)
+    const bool use_wg = wg_on && ny >= 32;                  // (a workgroup takes ~1 ms per factorisation whatever the batch: below ~32 problems the step kernels' 19 launches are shorter; same bits either way)
     if (use_persist && B.g_npad_la > 0) {                     // (<= 32 block rows: the flag arrays; ORBHIP_BA_LA_MAX can push larger systems onto the look-ahead steps)
       const int nbm = B.g_npad_la / NB;
       int nwg = 3;                                            // the chain, producer + consumers of the rows 2 .. nb - 1, the rhs row's two
       for (int i = 2; i < nbm; i++) nwg += 1 + (i - 1 + CP_CH - 1) / CP_CH;
       hipLaunchKernelGGL(k_chol_persist, dim3(nwg, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv);
+    } else if (use_wg && B.g_npad_la > 0) {                   // lockstep batches: one workgroup per problem, the whole factorisation in one launch
+      hipLaunchKernelGGL(k_chol_wg, dim3(ny), dim3(CW_TPB), CW_LDS_DOUBLES * sizeof(double), s, Dv);
     } else
     for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) launch_la(npl, k, 0, INT_MAX, 0, no_wide);
     // two-level scheme (outer block = 4 panels of NB = 32) for the larger systems.
@@ -4381,13 +4716,21 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   std::vector<BaState> fin(nprob);
   const bool classify = erase_out != nullptr && Dh[0].erase != nullptr;
   if (classify) hipLaunchKernelGGL(k_ba_classify, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
-  for (int p = 0; p < nprob; p++) {
-    if (classify && in[p].nobs) ORBHIP_CHECK_HIP(hipMemcpyAsync(P[p].h_rob, Dh[p].erase, in[p].nobs, hipMemcpyDeviceToHost, s));   // (the pinned flag buffer is free again)
-    ORBHIP_CHECK_HIP(hipMemcpyAsync(&fin[p], Dh[p].st, sizeof(BaState), hipMemcpyDeviceToHost, s));
-    ORBHIP_CHECK_HIP(hipMemcpyAsync(in[p].poses7, Dh[p].poses, 7 * (size_t)in[p].ncam * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (in[p].npts) ORBHIP_CHECK_HIP(hipMemcpyAsync(in[p].pts3, Dh[p].pts, 3 * (size_t)in[p].npts * sizeof(double), hipMemcpyDeviceToHost, s));
-  }
+  hipLaunchKernelGGL(k_ba_collect, dim3(16, ny), dim3(256), 0, s, Dv, classify ? 1 : 0);
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  ORBHIP_CHECK_HIP(hipMemcpyAsync(B.out_h, B.out_d, B.out_bytes, hipMemcpyDeviceToHost, s));
   ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
+  {
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    for (int p = 0; p < nprob; p++) {
+      const unsigned char* o = B.out_h + B.out_off[p];
+      std::memcpy(&fin[p], o, sizeof(BaState)); o += al(sizeof(BaState));
+      std::memcpy(in[p].poses7, o, 7 * (size_t)in[p].ncam * sizeof(double)); o += al(7 * (size_t)in[p].ncam * sizeof(double));
+      if (in[p].npts) std::memcpy(in[p].pts3, o, 3 * (size_t)in[p].npts * sizeof(double));
+      o += al(3 * (size_t)in[p].npts * sizeof(double));
+      if (classify && in[p].nobs) std::memcpy(P[p].h_rob, o, in[p].nobs);
+    }
+  }
   if (prof) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, g_prof_ev[0], g_prof_ev[1]) == hipSuccess) g_prof_ms += ms;
