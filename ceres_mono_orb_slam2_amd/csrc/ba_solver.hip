@@ -1770,10 +1770,11 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
 //                        row is z and whose other rows are zero (k_chol_la's role A sees the row exactly like that).
 #define CW_TPB 256
 #define CW_NW (CW_TPB / 64)
+#define CW_RPW 2                       /* block rows per wave and group: eight rows of a column are in flight per workgroup */
 #define CW_TILE (NB * (NB + 1))
-/* LDS: L(c, j) twice (double buffer), a scratch tile for the waves 1..3, X_c, D_c (wave 0's scratch outside the factor), the
-   factor's column buffer, the rhs row's z(j) twice: 75.5 KB, two workgroups per CU */
-#define CW_LDS_DOUBLES (7 * CW_TILE + NB * 64 + 2 * NB)
+/* LDS: L(c, j) twice (double buffer), a scratch tile per (wave, row slot), X_c, D_c, the factor's column buffer, the rhs row's
+   z(j) twice: 118 KB - one workgroup per CU, which the register count (one wave per SIMD, three operand sets in flight) implies anyway */
+#define CW_LDS_DOUBLES ((4 + CW_NW * CW_RPW) * CW_TILE + NB * 64 + 2 * NB)
 __global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.x];
   if (!D.chol_la) return;
@@ -1781,16 +1782,14 @@ __global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv
   const StFlags F = ld_flags(st);
   if (F.done || !F.valid || F.chol_fail) return;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + 5 * CW_TILE);
-  double (*s_L)[NB + 1] = (double (*)[NB + 1])(s_dyn + 6 * CW_TILE);
-  double (*s_T)[64] = (double (*)[64])(s_dyn + 7 * CW_TILE);                    // 16-byte aligned: 7 * 32 * 33 * 8 bytes
-  double* s_z = s_dyn + 7 * CW_TILE + NB * 64;                                  // [2][NB]
+  constexpr int NSC = CW_NW * CW_RPW;
+  double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + NSC) * CW_TILE);
+  double (*s_L)[NB + 1] = (double (*)[NB + 1])(s_dyn + (3 + NSC) * CW_TILE);
+  double (*s_T)[64] = (double (*)[64])(s_dyn + (4 + NSC) * CW_TILE);            // 16-byte aligned: a multiple of 32 * 33 * 8 bytes
+  double* s_z = s_dyn + (4 + NSC) * CW_TILE + NB * 64;                          // [2][NB]
   __shared__ int s_fail, s_col;
   const int np = D.npad, nb = np / NB, tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  // this wave's scratch tile (layout change of its T, parking place during the factor): wave 0 takes D_c's tile - it is the
-  // diagonal wave in the group that factors
-  double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (w == 0 ? 6 : 1 + w) * CW_TILE);
   double* S = D.S;
   double* zrow = S + (size_t)np * np;
   if (tid == 0) { s_fail = 0; s_col = 0; }
@@ -1799,150 +1798,169 @@ __global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv
   for (int c = 0; c < nb; c++) {
     const size_t cb = (size_t)c * NB;
     const bool upd = c > 0;
-    // rows of this column: c (the diagonal tile), c + 1 .. nb - 1, and nb = the rhs row; one per wave at a time
-    for (int g0 = 0; c + g0 <= nb; g0 += CW_NW) {
-      const int my = c + g0 + w;
-      const bool valid = my <= nb, is_diag = my == c, is_rhs = my == nb, is_row = valid && !is_diag && !is_rhs;
-      const size_t rb = (size_t)my * NB;
+    // rows of this column: c (the diagonal tile), c + 1 .. nb - 1, and nb = the rhs row; CW_NW * CW_RPW at a time, wave w takes the
+    // rows c + g0 + w and c + g0 + w + CW_NW
+    for (int g0 = 0; c + g0 <= nb; g0 += NSC) {
       CHOL_PROF_BEGIN(c);
-      double T[2][2][4];
+      int my[CW_RPW]; bool valid[CW_RPW], is_diag[CW_RPW], is_rhs[CW_RPW], is_row[CW_RPW];
+      double T[CW_RPW][2][2][4];
       double zc = 0.0;
 #pragma unroll
-      for (int I = 0; I < 2; I++)
+      for (int t = 0; t < CW_RPW; t++) {
+        my[t] = c + g0 + w + CW_NW * t;
+        valid[t] = my[t] <= nb; is_diag[t] = my[t] == c; is_rhs[t] = my[t] == nb; is_row[t] = valid[t] && !is_diag[t] && !is_rhs[t];
+        const size_t rb = (size_t)my[t] * NB;
 #pragma unroll
-        for (int J = 0; J < 2; J++)
+        for (int I = 0; I < 2; I++)
 #pragma unroll
-          for (int rg = 0; rg < 4; rg++)
-            T[I][J][rg] = (valid && !is_rhs) ? S[(rb + 16 * I + lk + 4 * rg) * np + cb + 16 * J + li] : 0.0;
-      if (is_rhs && lane < NB) zc = zrow[cb + lane];
+          for (int J = 0; J < 2; J++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++)
+              T[t][I][J][rg] = (valid[t] && !is_rhs[t]) ? S[(rb + 16 * I + lk + 4 * rg) * np + cb + 16 * J + li] : 0.0;
+        if (is_rhs[t] && lane < NB) zc = zrow[cb + lane];
+      }
       // ---- the updates j = 0 .. c-1.  L(c, j), which every row of the column needs, is staged in LDS by the whole workgroup
-      // (double buffer, ONE barrier per step); a wave's own L(i, j) comes straight from global memory in the MFMA operand layout
-      // (a first version staged the four L(i, j) in LDS as well: two barriers and an LDS round trip per step, 2.2 us per step
-      // against 0.85 us of matrix-core work).  The loads of step j + 1 are in flight during the matrix-core loop of step j.
-      // Three register sets in rotation: step j computes from set j % 3 while the loads of steps j + 1 and j + 2 are in flight (a
-      // step's matrix-core loop is 0.85 us, a load's latency about 2 us: with ONE step of look-ahead a step took 1.9 us).
-      struct Stage { double A[16]; double2 pb[2]; double z; };    // A operand: [8 I + ks] = L(i, j)[16 I + li][4 ks + lk]; this thread's share of L(c, j); z(j)
-      Stage G0, G1, G2;
+      // (double buffer, ONE barrier per step); a wave's own L(i, j) come straight from global memory in the MFMA operand layout
+      // (a first version staged them in LDS as well: two barriers and an LDS round trip per step).  Two register sets in
+      // rotation: step j computes from set j & 1 (64 MFMAs per wave, ~1.8 us) while the loads of step j + 1 are in flight.
+      struct Stage { double A[CW_RPW][16]; double2 pb[2]; double z; };    // A operand: [8 I + ks] = L(i, j)[16 I + li][4 ks + lk]; this thread's share of L(c, j); z(j)
+      Stage G0, G1;
 #pragma unroll
-      for (int k = 0; k < 16; k++) { G0.A[k] = 0.0; G1.A[k] = 0.0; G2.A[k] = 0.0; }
-      G0.z = G1.z = G2.z = 0.0;
+      for (int t = 0; t < CW_RPW; t++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) { G0.A[t][k] = 0.0; G1.A[t][k] = 0.0; }
+      G0.z = G1.z = 0.0;
       auto issue = [&](int j, Stage& G) {
         const size_t jb = (size_t)j * NB;
 #pragma unroll
         for (int h = 0; h < 2; h++) G.pb[h] = *(const double2*)&S[(cb + lrow + 16 * h) * np + jb + lcol];
-        if (is_row) {
 #pragma unroll
-          for (int I = 0; I < 2; I++)
+        for (int t = 0; t < CW_RPW; t++) {
+          if (is_row[t]) {
+            const size_t rb = (size_t)my[t] * NB;
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) G.A[8 * I + ks] = S[(rb + 16 * I + li) * np + jb + 4 * ks + lk];
+            for (int I = 0; I < 2; I++)
+#pragma unroll
+              for (int ks = 0; ks < 8; ks++) G.A[t][8 * I + ks] = S[(rb + 16 * I + li) * np + jb + 4 * ks + lk];
+          }
+          if (is_rhs[t] && lane < NB) G.z = zrow[jb + lane];
         }
-        if (is_rhs && lane < NB) G.z = zrow[jb + lane];
       };
       auto step = [&](int j, const Stage& Gc, Stage& Gn) {
         double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + (j & 1) * CW_TILE);
 #pragma unroll
         for (int h = 0; h < 2; h++) { s_B[lrow + 16 * h][lcol] = Gc.pb[h].x; s_B[lrow + 16 * h][lcol + 1] = Gc.pb[h].y; }
-        if (is_rhs && lane < NB) s_z[(j & 1) * NB + lane] = Gc.z;
+        if ((is_rhs[0] || is_rhs[CW_RPW - 1]) && lane < NB) s_z[(j & 1) * NB + lane] = Gc.z;
         __syncthreads();                                         // (buffer j & 1 was last read in step j - 2: every wave has passed step j - 1's barrier since)
-        if (j + 2 < c) issue(j + 2, Gn);
+        if (j + 1 < c) issue(j + 1, Gn);
         const bool last = j == c - 1;
-        if (is_rhs) {
-          if (!last && lane < NB) {                              // k_chol_la's rhs role: sequential mul / add, then one subtraction
-            const double* z = s_z + (j & 1) * NB;
-            double sum = 0.0;
+        double b0[8], b1[8];
 #pragma unroll
-            for (int m = 0; m < NB; m++) sum += s_B[lane][m] * z[m];
-            zc -= sum;
+        for (int ks = 0; ks < 8; ks++) { b0[ks] = s_B[li][4 * ks + lk]; b1[ks] = s_B[16 + li][4 * ks + lk]; }
+#pragma unroll
+        for (int t = 0; t < CW_RPW; t++) {
+          if (is_rhs[t]) {
+            if (!last && lane < NB) {                            // k_chol_la's rhs role: sequential mul / add, then one subtraction
+              const double* z = s_z + (j & 1) * NB;
+              double sum = 0.0;
+#pragma unroll
+              for (int m = 0; m < NB; m++) sum += s_B[lane][m] * z[m];
+              zc -= sum;
+            }
+          } else if (is_diag[t] || (is_row[t] && !last)) {       // chol_syrk_body: eight k-steps from zero, then C - acc
+            double4_t acc[2][2];
+#pragma unroll
+            for (int I = 0; I < 2; I++)
+#pragma unroll
+              for (int J = 0; J < 2; J++) acc[I][J] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+              const double a0 = is_diag[t] ? b0[ks] : Gc.A[t][ks], a1 = is_diag[t] ? b1[ks] : Gc.A[t][8 + ks];
+              acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[ks], acc[0][0], 0, 0, 0);
+              acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1[ks], acc[0][1], 0, 0, 0);
+              acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0[ks], acc[1][0], 0, 0, 0);
+              acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[ks], acc[1][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int I = 0; I < 2; I++)
+#pragma unroll
+              for (int J = 0; J < 2; J++)
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) T[t][I][J][rg] = T[t][I][J][rg] - acc[I][J][rg];
           }
-        } else if (is_diag || (is_row && !last)) {               // chol_syrk_body: eight k-steps from zero, then C - acc
-          double4_t acc[2][2];
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-#pragma unroll
-            for (int J = 0; J < 2; J++) acc[I][J] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) {
-            const double b0 = s_B[li][4 * ks + lk], b1 = s_B[16 + li][4 * ks + lk];
-            const double a0 = is_diag ? b0 : Gc.A[ks], a1 = is_diag ? b1 : Gc.A[8 + ks];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-          }
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-#pragma unroll
-            for (int J = 0; J < 2; J++)
-#pragma unroll
-              for (int rg = 0; rg < 4; rg++) T[I][J][rg] = T[I][J][rg] - acc[I][J][rg];
         }
       };
       if (c > 0) issue(0, G0);
       CHOL_STAMP(0);                                             // T requested, first loads issued
-      if (c > 1) issue(1, G1);
-      for (int j = 0; j < c; j += 3) {
-        step(j, G0, G2);
+      for (int j = 0; j < c; j += 2) {
+        step(j, G0, G1);
         if (j + 1 < c) step(j + 1, G1, G0);
-        if (j + 2 < c) step(j + 2, G2, G1);
       }
       CHOL_STAMP(1);                                             // the update steps
-      // (after the loop: P = L(c, c-1) is in LDS buffer (c - 1) & 1, this wave's L(i, c-1) in set (c - 1) % 3, z(c-1) in s_z)
+      // (after the loop: P = L(c, c-1) is in LDS buffer (c - 1) & 1, this wave's L(i, c-1) in set (c - 1) & 1, z(c-1) in s_z)
       const double (*s_P)[NB + 1] = (const double (*)[NB + 1])(s_dyn + ((c - 1) & 1) * CW_TILE);
-      // ---- T goes from the C layout of its updates to the A-operand layout through this wave's scratch tile (the step kernels make
+      // ---- T goes from the C layout of its updates to the A-operand layout through the slot's scratch tile (the step kernels make
       // the same trip through global memory); the tile's last update rides on the way (k_chol_la's apply_prev: the registers are
-      // rows of the C tiles of A^T).  a[I][ks]: rows 16 I .. of T', operand layout.
-      double a[2][8];
+      // rows of the C tiles of A^T).  a[t][I][ks]: rows 16 I .. of T', operand layout.
+      double a[CW_RPW][2][8];
+      const int lset = upd ? (c - 1) & 1 : 0;
 #pragma unroll
-      for (int I = 0; I < 2; I++)
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) a[I][ks] = 0.0;
-      if (valid && !is_diag) {
-        double ap[2][8];
-        const int lset = upd ? (c - 1) % 3 : 0;
+      for (int t = 0; t < CW_RPW; t++) {
+        double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + CW_RPW * w + t) * CW_TILE);
 #pragma unroll
         for (int I = 0; I < 2; I++)
 #pragma unroll
-          for (int ks = 0; ks < 8; ks++) {
-            double v = 0.0;
-            if (upd) { if (!is_rhs) v = -(lset == 0 ? G0.A[8 * I + ks] : lset == 1 ? G1.A[8 * I + ks] : G2.A[8 * I + ks]); else if (I == 0 && li == 0) v = -s_z[((c - 1) & 1) * NB + 4 * ks + lk]; }
-            ap[I][ks] = v;
-          }
-        if (is_rhs) { if (lane < NB) s_Sw[0][lane] = zc; }
-        else {
+          for (int ks = 0; ks < 8; ks++) a[t][I][ks] = 0.0;
+        if (valid[t] && !is_diag[t]) {
+          double ap[2][8];
 #pragma unroll
           for (int I = 0; I < 2; I++)
 #pragma unroll
-            for (int J = 0; J < 2; J++)
+            for (int ks = 0; ks < 8; ks++) {
+              double v = 0.0;
+              if (upd) {
+                if (!is_rhs[t]) v = -(lset == 0 ? G0.A[t][8 * I + ks] : G1.A[t][8 * I + ks]);
+                else if (I == 0 && li == 0) v = -s_z[((c - 1) & 1) * NB + 4 * ks + lk];
+              }
+              ap[I][ks] = v;
+            }
+          if (is_rhs[t]) { if (lane < NB) s_Sw[0][lane] = zc; }
+          else {
 #pragma unroll
-              for (int rg = 0; rg < 4; rg++) s_Sw[16 * I + lk + 4 * rg][16 * J + li] = T[I][J][rg];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            for (int I = 0; I < 2; I++)
 #pragma unroll
-        for (int I = 0; I < 2; I++)
+              for (int J = 0; J < 2; J++)
 #pragma unroll
-          for (int ks = 0; ks < 8; ks++) {
-            double v = 0.0;
-            if (!is_rhs) v = s_Sw[16 * I + li][4 * ks + lk]; else if (I == 0 && li == 0) v = s_Sw[0][4 * ks + lk];
-            a[I][ks] = v;
+                for (int rg = 0; rg < 4; rg++) s_Sw[16 * I + lk + 4 * rg][16 * J + li] = T[t][I][J][rg];
           }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-        if (upd) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int I = 0; I < 2; I++) {
-            if (is_rhs && I == 1) break;
+          for (int I = 0; I < 2; I++)
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-              double4_t acc = {a[I][4 * t], a[I][4 * t + 1], a[I][4 * t + 2], a[I][4 * t + 3]};
+            for (int ks = 0; ks < 8; ks++) {
+              double v = 0.0;
+              if (!is_rhs[t]) v = s_Sw[16 * I + li][4 * ks + lk]; else if (I == 0 && li == 0) v = s_Sw[0][4 * ks + lk];
+              a[t][I][ks] = v;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+          if (upd) {
 #pragma unroll
-              for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], ap[I][ks], acc, 0, 0, 0);
-              a[I][4 * t] = acc[0]; a[I][4 * t + 1] = acc[1]; a[I][4 * t + 2] = acc[2]; a[I][4 * t + 3] = acc[3];
+            for (int I = 0; I < 2; I++) {
+              if (is_rhs[t] && I == 1) break;
+#pragma unroll
+              for (int q = 0; q < 2; q++) {
+                double4_t acc = {a[t][I][4 * q], a[t][I][4 * q + 1], a[t][I][4 * q + 2], a[t][I][4 * q + 3]};
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * q + li][4 * ks + lk], ap[I][ks], acc, 0, 0, 0);
+                a[t][I][4 * q] = acc[0]; a[t][I][4 * q + 1] = acc[1]; a[t][I][4 * q + 2] = acc[2]; a[t][I][4 * q + 3] = acc[3];
+              }
             }
           }
         }
       }
       CHOL_STAMP(2);                                             // layout change + last update
       // ---- the diagonal tile of this column: factor + inverse (first group only).  Nothing of the rows is kept in registers
-      // across the factor (156 registers of its own): T' waits in the scratch tiles, in the layout it is read back in.
+      // across the factor: T' waits in the scratch tiles, in the layout it is read back in.
       if (g0 == 0) {
         if (w == 0) {
 #pragma unroll
@@ -1952,13 +1970,18 @@ __global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv
 #pragma unroll
               for (int rg = 0; rg < 4; rg++) {
                 const int r = 16 * I + lk + 4 * rg, cc = 16 * J + li;
-                s_L[r][cc] = (cc <= r) ? T[I][J][rg] : 0.0;
+                s_L[r][cc] = (cc <= r) ? T[0][I][J][rg] : 0.0;
               }
-        } else if (valid) {
+        }
 #pragma unroll
-          for (int I = 0; I < 2; I++)
+        for (int t = 0; t < CW_RPW; t++) {
+          double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + CW_RPW * w + t) * CW_TILE);
+          if (valid[t] && !is_diag[t]) {
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) s_Sw[16 * I + li][4 * ks + lk] = a[I][ks];
+            for (int I = 0; I < 2; I++)
+#pragma unroll
+              for (int ks = 0; ks < 8; ks++) s_Sw[16 * I + li][4 * ks + lk] = a[t][I][ks];
+          }
         }
         __syncthreads();
 #ifndef CW_EXP_NOFACTOR
@@ -1973,27 +1996,32 @@ __global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv
         if (s_fail) { if (tid == 0) st->chol_fail = 1; return; }
         double* Di = D.Dinv + (size_t)c * NB * NB;
         for (int i = tid; i < NB * NB; i += CW_TPB) Di[i] = s_X[i / NB][i % NB];
-        {
-          const bool back = w != 0 && valid;                      // (assigned on every path: nothing is live across the factor)
+#pragma unroll
+        for (int t = 0; t < CW_RPW; t++) {
+          double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + CW_RPW * w + t) * CW_TILE);
+          const bool back = valid[t] && !is_diag[t];              // (assigned on every path: nothing is live across the factor)
 #pragma unroll
           for (int I = 0; I < 2; I++)
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) a[I][ks] = back ? s_Sw[16 * I + li][4 * ks + lk] : 0.0;
+            for (int ks = 0; ks < 8; ks++) a[t][I][ks] = back ? s_Sw[16 * I + li][4 * ks + lk] : 0.0;
         }
       }
       CHOL_STAMP(3);                                             // factor + inverse (first group)
-      if (valid && !is_diag) {
-        // ---- L(i, c) = T' X_c^T
+      // ---- L(i, c) = T' X_c^T
+#pragma unroll
+      for (int t = 0; t < CW_RPW; t++) {
+        if (!(valid[t] && !is_diag[t])) continue;
+        const size_t rb = (size_t)my[t] * NB;
 #pragma unroll
         for (int I = 0; I < 2; I++) {
-          if (is_rhs && I == 1) break;                           // (one row)
+          if (is_rhs[t] && I == 1) break;                        // (one row)
           double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int ks = 0; ks < 8; ks++) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I][ks], s_X[li][4 * ks + lk], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I][ks], s_X[16 + li][4 * ks + lk], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][I][ks], s_X[li][4 * ks + lk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][I][ks], s_X[16 + li][4 * ks + lk], acc1, 0, 0, 0);
           }
-          if (is_rhs) {
+          if (is_rhs[t]) {
             if (lk == 0) { zrow[cb + li] = acc0[0]; zrow[cb + 16 + li] = acc1[0]; }
           } else {
 #pragma unroll
