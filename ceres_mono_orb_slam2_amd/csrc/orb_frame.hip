@@ -162,36 +162,14 @@ __global__ __launch_bounds__(256) void k_area(const float* __restrict__ kps4, co
 }
 
 // ---------------------------------------------------------------------------- isInFrustum
-struct FrustumCam { double R[9], t[3], Ow[3]; float fx, fy, cx, cy, min_x, max_x, min_y, max_y, cos_limit, log_scale; int nlevels; };
-
 __global__ __launch_bounds__(256) void k_frustum(FrustumCam C, const double* __restrict__ P, const double* __restrict__ Pn,
                                                  const float* __restrict__ min_dist, const float* __restrict__ max_dist, int n,
                                                  uint8_t* __restrict__ in_view, float* __restrict__ uv, int* __restrict__ level,
                                                  float* __restrict__ view_cos, int invariance_bounds, float* __restrict__ dist_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const double X = P[3 * i], Y = P[3 * i + 1], Z = P[3 * i + 2];
-  // Pc = Rcw * P + tcw in double, then narrowed to float (":199-202")
-  const float PcX = (float)(C.R[0] * X + C.R[1] * Y + C.R[2] * Z + C.t[0]);
-  const float PcY = (float)(C.R[3] * X + C.R[4] * Y + C.R[5] * Z + C.t[1]);
-  const float PcZ = (float)(C.R[6] * X + C.R[7] * Y + C.R[8] * Z + C.t[2]);
-  bool ok = !(PcZ < 0.0f);
-  const float invz = 1.0f / PcZ;
-  const float u = C.fx * PcX * invz + C.cx;
-  const float v = C.fy * PcY * invz + C.cy;
-  if (u < C.min_x || u > C.max_x) ok = false;
-  if (v < C.min_y || v > C.max_y) ok = false;
-  // GetMax/MinDistanceInvariance (src/MapPoint.cc:379-387): applied here, or by the caller (invariance_bounds)
-  const float maxD = invariance_bounds ? max_dist[i] : 1.2f * max_dist[i], minD = invariance_bounds ? min_dist[i] : 0.8f * min_dist[i];
-  const double POx = X - C.Ow[0], POy = Y - C.Ow[1], POz = Z - C.Ow[2];
-  const float dist = (float)sqrt(POx * POx + POy * POy + POz * POz);
-  if (dist < minD || dist > maxD) ok = false;
-  const float vc = (float)((POx * Pn[3 * i] + POy * Pn[3 * i + 1] + POz * Pn[3 * i + 2]) / (double)dist);
-  if (vc < C.cos_limit) ok = false;
-  // PredictScale (src/MapPoint.cc:406-420): float ratio, float log, ceil, clamp
-  const float ratio = max_dist[i] / dist;
-  int nScale = (int)ceilf(logf(ratio) / C.log_scale);
-  if (nScale < 0) nScale = 0; else if (nScale >= C.nlevels) nScale = C.nlevels - 1;
+  float u, v, vc, dist; int nScale;
+  const bool ok = frustum_eval(C, P + 3 * (size_t)i, Pn + 3 * (size_t)i, min_dist[i], max_dist[i], invariance_bounds, u, v, nScale, vc, dist);
   in_view[i] = ok ? 1 : 0;
   uv[2 * i] = u; uv[2 * i + 1] = v;
   level[i] = nScale;

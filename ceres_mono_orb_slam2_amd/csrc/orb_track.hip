@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_trk_windows(const float* __restrict__ k
                                                      const int* __restrict__ q_minl, const int* __restrict__ q_maxl, const uint8_t* __restrict__ q_valid, int nq,
                                                      const uint8_t* __restrict__ q_desc, const uint8_t* __restrict__ t_desc, uint32_t* __restrict__ total,
                                                      uint32_t* __restrict__ off, uint2* __restrict__ pairs, uint32_t cap, uint32_t* __restrict__ acc,
-                                                     int32_t* __restrict__ acc_n) {
+                                                     int32_t* __restrict__ acc_n, const int dmax) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (q >= nq) return;
   uint32_t base = 0, nbig = 0;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_trk_windows(const float* __restrict__ k
       int nhit = 0, nacc = 0;
       for (int w0 = 0; w0 < ncell; w0 += 64) {
         uint32_t lo, hi; cell_range(w0 + lane, lo, hi);
-        for (uint32_t e = lo; e < hi; e++) { const uint32_t j = cell_idx[e]; if (hit(j)) { nhit++; nacc += dist(j) <= TRK_TH_HIGH ? 1 : 0; } }
+        for (uint32_t e = lo; e < hi; e++) { const uint32_t j = cell_idx[e]; if (hit(j)) { nhit++; nacc += dist(j) <= dmax ? 1 : 0; } }
       }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) { nhit += __shfl_xor(nhit, o); nacc += __shfl_xor(nacc, o); }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_trk_windows(const float* __restrict__ k
       for (int w0 = 0; w0 < ncell; w0 += 64) {
         uint32_t lo, hi; cell_range(w0 + lane, lo, hi);
         int mine = 0, amine = 0;
-        for (uint32_t e = lo; e < hi; e++) { const uint32_t j = cell_idx[e]; if (hit(j)) { mine++; amine += dist(j) <= TRK_TH_HIGH ? 1 : 0; } }
+        for (uint32_t e = lo; e < hi; e++) { const uint32_t j = cell_idx[e]; if (hit(j)) { mine++; amine += dist(j) <= dmax ? 1 : 0; } }
         int incl = mine, aincl = amine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o), ta = __shfl_up(aincl, o); if (lane >= o) { incl += t; aincl += ta; } }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_trk_windows(const float* __restrict__ k
             if (!hit(j)) continue;
             const int d = dist(j);
             if (big) { if (pos < cap) pairs[pos] = make_uint2(j, (uint32_t)d); pos++; }
-            if (d <= TRK_TH_HIGH) { if (ar < TRK_LMAX) acc[(size_t)q * TRK_LMAX + ar] = j | ((uint32_t)d << 16); ar++; }
+            if (d <= dmax) { if (ar < TRK_LMAX) acc[(size_t)q * TRK_LMAX + ar] = j | ((uint32_t)d << 16); ar++; }
           }
         }
         tot += __shfl(incl, 63); found += __shfl(aincl, 63);
@@ -656,6 +656,175 @@ __global__ __launch_bounds__(TRK_GT) void k_trk_greedy(const TrkIn* __restrict__
   if (tid == 0) { out->n_keypoints = n_dev; out->nmatches = overflow ? -1 : s_nm; out->rounds = rounds + 1000 * inner_total; out->cand_total = (int32_t)off_total; }
 }
 
+// ======================================================================================================================
+// Tracking::TrackLocalMap's data-parallel core (src/Tracking.cc:673-750): SearchLocalPoints (:793-842) = Frame::isInFrustum
+// (src/Frame.cc:191-241) over the local map points + ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th)
+// (src/ORBmatcher.cc:42-119) + CeresOptimizer::PoseOptimization, on the frame the motion-model step left on the device.
+// ======================================================================================================================
+struct TlmIn {
+  FrustumCam C;
+  double pose7[7];
+  float K4[4], scale[16], inv_sigma2[16];
+  float th, ratio; int n_mp, n_kp_host, dmax, pad;
+};
+#define TLM_MAXMP 16384
+
+// one thread per local map point: the frustum test and what SearchByProjection derives from it (:55-68): window radius
+// RadiusByViewingCos * th * scale_factors_[level], level range [level - 1, level]
+__global__ __launch_bounds__(256) void k_tlm_frustum(const TlmIn* __restrict__ in, const double* __restrict__ P, const double* __restrict__ Pn,
+                                                     const float* __restrict__ mind, const float* __restrict__ maxd, const uint8_t* __restrict__ state,
+                                                     uint8_t* __restrict__ in_view, float* __restrict__ q_uv, float* __restrict__ q_r, int32_t* __restrict__ q_lo,
+                                                     int32_t* __restrict__ q_hi, uint8_t* __restrict__ q_valid, uint32_t* __restrict__ list_total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *list_total = 0u;
+  const int n = in->n_mp;
+  if (i >= n) return;
+  const uint8_t stt = state[i];
+  float u = 0.f, v = 0.f, vc = 0.f, dist = 0.f; int lvl = 0;
+  bool ok = false;
+  if (stt) ok = frustum_eval(in->C, P + 3 * (size_t)i, Pn + 3 * (size_t)i, mind[i], maxd[i], 0, u, v, lvl, vc, dist);
+  float r = vc > 0.998f ? 2.5f : 4.0f;                                      // RadiusByViewingCos (:121-126)
+  const float th = in->th;
+  if (th != 1.0f) r *= th;
+  in_view[i] = ok ? 1 : 0;
+  q_uv[2 * i] = u; q_uv[2 * i + 1] = v; q_r[i] = ok ? r * in->scale[lvl] : 0.f; q_lo[i] = lvl - 1; q_hi[i] = lvl; q_valid[i] = ok ? stt : (uint8_t)0;
+}
+
+// One workgroup: the order-dependent pass of SearchByProjection(Frame&, vpMapPoints, th) and PoseOptimization's observation list.
+// The reference walks the map points in vector order; point q looks at the features of its window whose slot does not hold a point
+// with observations (:83-84: the slots filled before the call AND the ones earlier points of this loop filled), takes the best
+// and second best distance in candidate order, applies the ratio test when both are on the same pyramid level and writes itself
+// into the best feature's slot - a later point may overwrite a slot whose holder has no observations.  Exact parallel evaluation:
+// what q decides depends only on EARLIER points that share a candidate with it (best AND second best count), so in every round
+// each feature records the smallest unsettled point that lists it, and a point is settled when it is that smallest point for every
+// feature on its list (the earliest unsettled point always is: the loop ends; windows of th = 1 hold a handful of features, so the
+// chains are short).  Only candidates that can matter are listed (k_trk_windows, dmax): a distance d can be the winner if
+// d <= TH_HIGH and can veto through the ratio test only if ratio * d < TH_HIGH.
+__global__ __launch_bounds__(1024) void k_tlm_greedy(const TlmIn* __restrict__ in, const uint8_t* __restrict__ q_valid, const uint32_t* __restrict__ acc,
+                                                     const int32_t* __restrict__ acc_n, const uint32_t* __restrict__ off, const uint32_t* __restrict__ off_total_p,
+                                                     const uint2* __restrict__ pairs, uint32_t cand_cap, const float* __restrict__ kps4, const int32_t* __restrict__ d_count,
+                                                     int cap, const double* __restrict__ mp_Xw, const double* __restrict__ slot_Xw, const uint8_t* __restrict__ slot_state,
+                                                     int32_t* __restrict__ mp_match, int32_t* __restrict__ slot_owner, int32_t* __restrict__ obs_feat,
+                                                     double* __restrict__ obs_Xw, double* __restrict__ obs_uv, float* __restrict__ obs_w, int32_t* __restrict__ obs_off,
+                                                     double* __restrict__ pose7, double* __restrict__ K4d, TrkOut* __restrict__ out, const int nq) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  unsigned short* wl0 = (unsigned short*)s_dyn;                 // work lists of the unsettled points
+  unsigned short* wl1 = wl0 + TLM_MAXMP;
+  __shared__ int s_taken[TRK_MAXKP];                            // the point with observations that holds the feature's slot (-1: filled before the call; INT_MAX: open)
+  __shared__ int s_minu[TRK_MAXKP];                             // smallest unsettled point that lists the feature (this round)
+  __shared__ int s_owner[TRK_MAXKP];                            // the LAST point written into the slot (:110), -1 none
+  __shared__ unsigned char s_oct[TRK_MAXKP];
+  __shared__ int s_n[2], s_nm, s_w[16];
+  const int tid = threadIdx.x;
+  const uint32_t off_total = *off_total_p;
+  const int n_dev = *d_count;
+  const bool overflow = off_total > cand_cap;
+  const int n = min(max(n_dev, 0), min(cap, TRK_MAXKP));
+  const float ratio = in->ratio; const int dmax = in->dmax;
+  for (int t = tid; t < TRK_MAXKP; t += 1024) {
+    s_taken[t] = (t < n && slot_state[t] == 1) ? -1 : INT_MAX;
+    s_owner[t] = -1;
+    s_oct[t] = t < n ? (unsigned char)(int)kps4[4 * t + 2] : (unsigned char)0;
+  }
+  if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_nm = 0; }
+  __syncthreads();
+  // the work list: every point in view, in index order (the order inside the list does not matter)
+  for (int q0 = 0; q0 < nq; q0 += 1024) {
+    const int q = q0 + tid;
+    const bool act = q < nq && q_valid[q] != 0 && !overflow;
+    if (q < nq) mp_match[q] = -1;
+    const unsigned long long m = __ballot(act);
+    int base = 0;
+    if ((tid & 63) == 0 && m) base = atomicAdd(&s_n[0], __popcll(m));
+    base = __shfl(base, 0);
+    if (act) wl0[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)q;
+  }
+  __syncthreads();
+  // a point's candidate list: <= TRK_LMAX packed entries, or - rarely - its full list in `pairs`, filtered
+  auto for_each = [&](int q, auto&& f) {
+    const int na = acc_n[q];
+    if (na <= TRK_LMAX) { for (int e = 0; e < na; e++) { const uint32_t v = acc[(size_t)q * TRK_LMAX + e]; f((int)(v & 0xFFFFu), (int)(v >> 16)); } }
+    else { for (uint32_t e = off[2 * q]; e < off[2 * q + 1]; e++) { const uint2 pr = pairs[e]; if ((int)pr.y <= dmax) f((int)pr.x, (int)pr.y); } }
+  };
+  int rounds = 0, cur = 0;
+  unsigned short* wl[2] = {wl0, wl1};
+  while (true) {
+    const int nw = s_n[cur];
+    if (nw == 0) break;
+    rounds++;
+    for (int t = tid; t < TRK_MAXKP; t += 1024) s_minu[t] = INT_MAX;
+    if (tid == 0) s_n[cur ^ 1] = 0;
+    __syncthreads();
+    for (int i = tid; i < nw; i += 1024) { const int q = wl[cur][i]; for_each(q, [&](int t, int) { atomicMin(&s_minu[t], q); }); }
+    __syncthreads();
+    for (int i0 = 0; i0 < nw; i0 += 1024) {
+      const int i = i0 + tid;
+      bool keep = false; int q = 0;
+      if (i < nw) {
+        q = wl[cur][i];
+        bool first = true;
+        for_each(q, [&](int t, int) { first = first && s_minu[t] == q; });
+        if (!first) keep = true;
+        else {
+          int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+          for_each(q, [&](int t, int d) {
+            if (s_taken[t] < q) return;                            // (:83-84; a later point cannot have settled before q: it shares this feature)
+            const int lv = s_oct[t];
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = lv; bestIdx = t; }
+            else if (d < bestDist2) { bestLevel2 = lv; bestDist2 = d; }
+          });
+          if (bestIdx >= 0 && bestDist <= TRK_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2)) {
+            mp_match[q] = bestIdx;
+            atomicMax(&s_owner[bestIdx], q);
+            if (q_valid[q] == 1) s_taken[bestIdx] = q;               // (a point without observations does not close the slot)
+            atomicAdd(&s_nm, 1);
+          }
+        }
+      }
+      const unsigned long long m = __ballot(keep);
+      int base = 0;
+      if ((tid & 63) == 0 && m) base = atomicAdd(&s_n[cur ^ 1], __popcll(m));
+      base = __shfl(base, 0);
+      if (keep) wl[cur ^ 1][base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)q;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // PoseOptimization's observations: every slot that holds a point now - the ones filled before the call and not overwritten
+  // (slot_Xw) and the new ones (mp_Xw) - in feature order (src/CeresOptimizer.cc:297-327)
+  constexpr int FPT = TRK_MAXKP / 1024;
+  auto has_pt = [&](int t) { return t < n && (s_owner[t] >= 0 || slot_state[t] != 0); };
+  int cntv = 0;
+  for (int k = 0; k < FPT; k++) cntv += has_pt(FPT * tid + k) ? 1 : 0;
+  int inc = cntv;
+  {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; k++) base += s_w[k];
+    inc += base;
+  }
+  int pos = inc - cntv;
+  for (int k = 0; k < FPT; k++) {
+    const int t = FPT * tid + k;
+    if (t < cap) slot_owner[t] = t < n ? s_owner[t] : -1;
+    if (!has_pt(t)) continue;
+    const double* X = s_owner[t] >= 0 ? mp_Xw + 3 * (size_t)s_owner[t] : slot_Xw + 3 * (size_t)t;
+    obs_feat[pos] = t;
+    obs_Xw[3 * pos] = X[0]; obs_Xw[3 * pos + 1] = X[1]; obs_Xw[3 * pos + 2] = X[2];
+    obs_uv[2 * pos] = (double)kps4[4 * t]; obs_uv[2 * pos + 1] = (double)kps4[4 * t + 1];
+    obs_w[pos] = in->inv_sigma2[(int)kps4[4 * t + 2]];
+    pos++;
+  }
+  if (tid == 1023) { obs_off[0] = 0; obs_off[1] = inc; out->nobs = inc; }
+  if (tid < 7) pose7[tid] = in->pose7[tid];
+  if (tid < 4) K4d[tid] = (double)in->K4[tid];
+  if (tid == 0) { out->n_keypoints = n_dev; out->nmatches = overflow ? -1 : s_nm; out->rounds = rounds; out->cand_total = (int32_t)off_total; }
+}
+
 }  // namespace orbhip
 
 namespace orbhip {
@@ -664,6 +833,17 @@ int orbx_extract_chained(orbx_ctx* c, const uint8_t* d_img, int w, int h, int st
                          int32_t* d_count, void* stream);      // orb_extractor.hip
 }
 using namespace orbhip;
+
+namespace {
+// The frame the motion-model step built stays on the device for the second stage of Tracking (orbt_track_local_map): its download
+// block (keypoints, descriptors, count) and float records live in buffers of the calling thread that survive the call; the grid
+// (FrameGridDev below) always did.
+struct TrkFrame {
+  DevBuf blk, kps4; FrameGridDev grid;
+  size_t oKps = 0, oDesc = 0, oCnt = 0; int icap = 0, n_kp = 0, device = -1, nlevels = 0; float bounds[4] = {0, 0, 0, 0}; bool valid = false;
+};
+thread_local TrkFrame g_trk_frame;
+}  // namespace
 
 extern "C" {
 #ifdef ORBHIP_TRK_PROF
@@ -695,15 +875,16 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
   auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = timing ? now_us() : 0.0;
   static thread_local uint32_t cand_cap_tl = 0;
-  static thread_local FrameGridDev grid;                       // (off / idx buffers filled by k_trk_prepare)
-  static thread_local int grid_device = -1;
+  TrkFrame& TF = g_trk_frame;
+  FrameGridDev& grid = TF.grid;                                // (off / idx buffers filled by k_trk_prepare)
+  TF.valid = false;
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = W.begin();
     if (rc) return rc;
     // the workspace, the stream and every kernel of this call live on the default device; an extractor created on another one
     // would launch across devices
     ORBHIP_REQUIRE(orbhip::orbx_ctx_device(ctx) == W.device, ORBHIP_EINVAL, "the extractor context was created on another device than orbhip_set_default_device() selects");
-    if (grid_device != W.device) { grid = FrameGridDev(); grid_device = W.device; cand_cap_tl = 0; }
+    if (TF.device != W.device) { TF = TrkFrame(); TF.device = W.device; cand_cap_tl = 0; }
     const int nq = n_last;
     const uint32_t cand_cap = std::max<uint32_t>(cand_cap_tl, (uint32_t)std::max(nq, 1) * 64u);
     TrkIn I; std::memset(&I, 0, sizeof(I));
@@ -726,10 +907,11 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     const size_t oOut = take(sizeof(TrkOut)), oPose = take(56), oSum = take(sizeof(ba_summary)), oCnt = take(4), oNin = take(4), oKps = take((size_t)icap * sizeof(orbx_keypoint)),
                  oDesc = take((size_t)icap * 32), oMatch = take(4 * (size_t)std::max(nq, 1)), oOwner = take(4 * (size_t)icap), oFeat = take(4 * (size_t)icap),
                  oOutl = take((size_t)icap);
-    uint8_t* dblk = W.d<uint8_t>(o, &rc);
+    if ((rc = TF.blk.ensure(o)) || (rc = TF.kps4.ensure(16 * (size_t)icap))) return rc;
+    uint8_t* dblk = TF.blk.as<uint8_t>();
     float* d_quv = W.d<float>(2 * (size_t)std::max(nq, 1), &rc); float* d_qr = W.d<float>(std::max(nq, 1), &rc);
     int32_t* d_qlo = W.d<int32_t>(std::max(nq, 1), &rc); int32_t* d_qhi = W.d<int32_t>(std::max(nq, 1), &rc); uint8_t* d_qv = W.d<uint8_t>(std::max(nq, 1), &rc);
-    float* d_kps4 = W.d<float>(4 * (size_t)icap, &rc);
+    float* d_kps4 = TF.kps4.as<float>();
     uint32_t* d_off = W.d<uint32_t>(2 * (size_t)nq + 4, &rc); uint2* d_pairs = W.d<uint2>(cand_cap, &rc);
     uint32_t* d_total = d_off + 2 * (size_t)nq + 2;
     double* d_oX = W.d<double>(3 * (size_t)icap, &rc); double* d_ouv = W.d<double>(2 * (size_t)icap, &rc); float* d_ow = W.d<float>(icap, &rc);
@@ -746,7 +928,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
                        d_qlo, d_qhi, d_qv, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>(), nq, d_total);
     if (nq > 0) {
       hipLaunchKernelGGL(k_trk_windows, dim3((nq + 3) / 4), dim3(256), 0, W.s, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>(), grid.min_x, grid.min_y, grid.winv,
-                         grid.hinv, d_quv, d_qr, d_qlo, d_qhi, d_qv, nq, in.dev<uint8_t>(pD), d_desc, d_total, d_off, d_pairs, cand_cap, d_acc, d_accn);
+                         grid.hinv, d_quv, d_qr, d_qlo, d_qhi, d_qv, nq, in.dev<uint8_t>(pD), d_desc, d_total, d_off, d_pairs, cand_cap, d_acc, d_accn, TRK_TH_HIGH);
     }
     // dynamic LDS of the greedy kernel: offsets, states, proposals (ints per query), two work lists, the candidate entries
     // (+ the inverted lists of the dataflow path: two bytes per entry behind the four of the entries themselves)
@@ -777,6 +959,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     std::memset(outlier_out, 0, (size_t)n);
     const int32_t* feat = (const int32_t*)(hb + oFeat);
     for (int k = 0; k < T->nobs; k++) outlier_out[feat[k]] = hb[oOutl + k];
+    TF.oKps = oKps; TF.oDesc = oDesc; TF.oCnt = oCnt; TF.icap = icap; TF.n_kp = n; TF.nlevels = nlevels; std::memcpy(TF.bounds, bounds, 16); TF.valid = true;
     res->n_keypoints = n; res->nmatches = T->nmatches; res->n_correspondences = T->nobs; res->greedy_rounds = T->rounds % 1000;
     std::memcpy(res->pose7, hb + oPose, 56);
     // PoseOptimization returns 0 and leaves the pose alone with fewer than 3 correspondences (src/CeresOptimizer.cc:330)
@@ -792,6 +975,92 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
         for (double& a : t_acc) a = 0; t_n = 0;
       }
     }
+    return 0;
+  }
+  set_error("window candidate lists did not fit after regrowing");
+  return ORBHIP_ENOMEM;
+}
+
+int orbt_track_local_map(orbx_ctx* ctx, const float* K4, const float* bounds, const double* Tcw, float log_scale_factor,
+                         const double* mp_Xw, const double* mp_normal, const float* mp_min_dist, const float* mp_max_dist, const uint8_t* mp_desc,
+                         const uint8_t* mp_state, int n_mp, const double* slot_Xw, const uint8_t* slot_state, int n_kp, float th, float nnratio,
+                         uint8_t* mp_in_view, int32_t* mp_match, int32_t* slot_owner, uint8_t* outlier_out, orbt_result* res) {
+  ORBHIP_REQUIRE(ctx && K4 && bounds && Tcw && res && mp_in_view && mp_match && slot_owner && outlier_out && slot_Xw && slot_state, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(n_mp >= 0 && n_mp <= TLM_MAXMP, ORBHIP_ECAP, "more than 16384 local map points per call");
+  ORBHIP_REQUIRE(n_mp == 0 || (mp_Xw && mp_normal && mp_min_dist && mp_max_dist && mp_desc && mp_state), ORBHIP_EINVAL, "NULL map-point argument");
+  TrkFrame& TF = g_trk_frame;
+  ThreadWs& W = thread_ws();
+  static thread_local uint32_t cand_cap_tl = 0;
+  const int nlevels = orbx_get_levels(ctx);
+  ORBHIP_REQUIRE(nlevels > 0 && nlevels <= 16, ORBHIP_EINVAL, "bad level count");
+  for (int attempt = 0; attempt < 2; attempt++) {
+    int rc = W.begin();
+    if (rc) return rc;
+    ORBHIP_REQUIRE(TF.valid && TF.device == W.device, ORBHIP_EINVAL, "no frame resident on this thread's device: call orbt_track_with_motion_model first (same host thread)");
+    ORBHIP_REQUIRE(n_kp == TF.n_kp, ORBHIP_EINVAL, "n_kp differs from the resident frame's keypoint count");
+    const int icap = TF.icap, nq = n_mp;
+    TlmIn I; std::memset(&I, 0, sizeof(I));
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) I.C.R[3 * r + c] = Tcw[4 * r + c]; I.C.t[r] = Tcw[4 * r + 3]; }
+    for (int k = 0; k < 3; k++) I.C.Ow[k] = -(I.C.R[k] * I.C.t[0] + I.C.R[3 + k] * I.C.t[1] + I.C.R[6 + k] * I.C.t[2]);      // Ow = -Rcw^T tcw (src/Frame.cc:188)
+    I.C.fx = K4[0]; I.C.fy = K4[1]; I.C.cx = K4[2]; I.C.cy = K4[3];
+    I.C.min_x = bounds[0]; I.C.max_x = bounds[1]; I.C.min_y = bounds[2]; I.C.max_y = bounds[3];
+    I.C.cos_limit = 0.5f; I.C.log_scale = log_scale_factor; I.C.nlevels = nlevels;          // isInFrustum(map_point, 0.5) (src/Tracking.cc:822)
+    { double T[16]; for (int k = 0; k < 12; k++) T[k] = Tcw[k]; T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1; if (int r2 = ba_matrix4d_to_pose7(T, I.pose7)) return r2; }
+    for (int k = 0; k < 4; k++) I.K4[k] = K4[k];
+    if (int r2 = orbx_get_tables(ctx, I.scale, nullptr, nullptr, I.inv_sigma2, nullptr)) return r2;
+    I.th = th; I.ratio = nnratio; I.n_mp = n_mp; I.n_kp_host = n_kp;
+    // a distance can win only if it is <= TH_HIGH and can veto through the ratio test only if ratio * d < TH_HIGH
+    { int dm = TRK_TH_HIGH; while (dm < 255 && nnratio * (float)(dm + 1) < (float)TRK_TH_HIGH) dm++; I.dmax = dm; }
+    const uint32_t cand_cap = std::max<uint32_t>(cand_cap_tl, (uint32_t)std::max(nq, 1) * 32u);
+    ThreadWs::Pack in;
+    const int pI = in.add(&I, sizeof(I)), pX = in.add(mp_Xw, 24 * (size_t)nq), pN = in.add(mp_normal, 24 * (size_t)nq), pMi = in.add(mp_min_dist, 4 * (size_t)nq),
+              pMa = in.add(mp_max_dist, 4 * (size_t)nq), pD = in.add(mp_desc, 32 * (size_t)nq), pS = in.add(mp_state, (size_t)nq), pSX = in.add(slot_Xw, 24 * (size_t)n_kp),
+              pSS = in.add(slot_state, (size_t)n_kp);
+    if ((rc = W.commit(in))) return rc;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+    const size_t oOut = take(sizeof(TrkOut)), oPose = take(56), oSum = take(sizeof(ba_summary)), oNin = take(4), oView = take((size_t)std::max(nq, 1)),
+                 oMatch = take(4 * (size_t)std::max(nq, 1)), oOwner = take(4 * (size_t)icap), oFeat = take(4 * (size_t)icap), oOutl = take((size_t)icap);
+    uint8_t* dblk = W.d<uint8_t>(o, &rc);
+    float* d_quv = W.d<float>(2 * (size_t)std::max(nq, 1), &rc); float* d_qr = W.d<float>(std::max(nq, 1), &rc);
+    int32_t* d_qlo = W.d<int32_t>(std::max(nq, 1), &rc); int32_t* d_qhi = W.d<int32_t>(std::max(nq, 1), &rc); uint8_t* d_qv = W.d<uint8_t>(std::max(nq, 1), &rc);
+    uint32_t* d_off = W.d<uint32_t>(2 * (size_t)nq + 4, &rc); uint2* d_pairs = W.d<uint2>(cand_cap, &rc);
+    uint32_t* d_total = d_off + 2 * (size_t)nq + 2;
+    double* d_oX = W.d<double>(3 * (size_t)icap, &rc); double* d_ouv = W.d<double>(2 * (size_t)icap, &rc); float* d_ow = W.d<float>(icap, &rc);
+    int32_t* d_ooff = W.d<int32_t>(2, &rc); double* d_K4 = W.d<double>(4, &rc);
+    uint32_t* d_acc = W.d<uint32_t>((size_t)std::max(nq, 1) * TRK_LMAX, &rc); int32_t* d_accn = W.d<int32_t>(std::max(nq, 1), &rc);
+    if (rc) return rc;
+    const TlmIn* dI = in.dev<TlmIn>(pI);
+    const uint8_t* fblk = TF.blk.as<uint8_t>();
+    const float* d_kps4 = TF.kps4.as<float>();
+    const FrameGridDev& grid = TF.grid;
+    hipLaunchKernelGGL(k_tlm_frustum, dim3((std::max(nq, 1) + 255) / 256), dim3(256), 0, W.s, dI, in.dev<double>(pX), in.dev<double>(pN), in.dev<float>(pMi), in.dev<float>(pMa),
+                       in.dev<uint8_t>(pS), dblk + oView, d_quv, d_qr, d_qlo, d_qhi, d_qv, d_total);
+    if (nq > 0)
+      hipLaunchKernelGGL(k_trk_windows, dim3((nq + 3) / 4), dim3(256), 0, W.s, d_kps4, grid.off.as<uint32_t>(), grid.idx.as<uint32_t>(), grid.min_x, grid.min_y, grid.winv,
+                         grid.hinv, d_quv, d_qr, d_qlo, d_qhi, d_qv, nq, in.dev<uint8_t>(pD), fblk + TF.oDesc, d_total, d_off, d_pairs, cand_cap, d_acc, d_accn, I.dmax);
+    if ((rc = raise_dynamic_lds((const void*)k_tlm_greedy, W.device, 4 * TLM_MAXMP))) return rc;
+    hipLaunchKernelGGL(k_tlm_greedy, dim3(1), dim3(1024), 4 * TLM_MAXMP, W.s, dI, d_qv, d_acc, d_accn, d_off, d_total, d_pairs, cand_cap, d_kps4, (const int32_t*)(fblk + TF.oCnt), icap,
+                       in.dev<double>(pX), in.dev<double>(pSX), in.dev<uint8_t>(pSS), (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow,
+                       d_ooff, (double*)(dblk + oPose), d_K4, (TrkOut*)(dblk + oOut), nq);
+    ORBHIP_CHECK_HIP(hipGetLastError());
+    if ((rc = ba_pose_optimization_batch_device(d_K4, (double*)(dblk + oPose), d_oX, d_ouv, d_ow, d_ooff, 1, dblk + oOutl, (int32_t*)(dblk + oNin),
+                                                (ba_summary*)(dblk + oSum), (void*)W.s))) return rc;
+    const uint8_t* hb = W.down(dblk, o, &rc);
+    if (rc || (rc = W.sync())) return rc;
+    const TrkOut* T = (const TrkOut*)(hb + oOut);
+    if ((uint32_t)T->cand_total > cand_cap) { cand_cap_tl = (uint32_t)T->cand_total + (uint32_t)T->cand_total / 4; continue; }   // (rare) once more, larger lists
+    cand_cap_tl = std::max<uint32_t>(cand_cap_tl, (uint32_t)T->cand_total + (uint32_t)T->cand_total / 8);
+    if (nq) { std::memcpy(mp_in_view, hb + oView, (size_t)nq); std::memcpy(mp_match, hb + oMatch, 4 * (size_t)nq); }
+    std::memcpy(slot_owner, hb + oOwner, 4 * (size_t)n_kp);
+    std::memset(outlier_out, 0, (size_t)n_kp);
+    const int32_t* feat = (const int32_t*)(hb + oFeat);
+    for (int k = 0; k < T->nobs; k++) outlier_out[feat[k]] = hb[oOutl + k];
+    int nview = 0; for (int i = 0; i < nq; i++) nview += mp_in_view[i];
+    res->n_keypoints = n_kp; res->nmatches = T->nmatches; res->n_correspondences = T->nobs; res->greedy_rounds = T->rounds; res->reserved = nview;
+    std::memcpy(res->pose7, hb + oPose, 56);
+    res->n_inliers = T->nobs < 3 ? 0 : *(const int32_t*)(hb + oNin);
+    if (T->nobs < 3) std::memcpy(res->pose7, I.pose7, 56);
     return 0;
   }
   set_error("window candidate lists did not fit after regrowing");

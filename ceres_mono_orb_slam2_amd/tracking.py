@@ -81,3 +81,26 @@ def _track_locked(L, extractor, img, w, h, K4, bounds, T, X, D, O, A, V, n, th, 
         else:
             v = out[key].view(); v.flags.writeable = False; out[key] = v
     return out
+
+
+def track_local_map(extractor, K4, bounds, Tcw, log_scale_factor, mp_Xw, mp_normal, mp_min_dist, mp_max_dist, mp_desc, mp_state, slot_Xw, slot_state,
+                    th=1.0, nnratio=0.8):
+    """Tracking::TrackLocalMap's data-parallel core on the frame the last track_with_motion_model call of THIS thread left on the
+    device (include/orbslam_hip.h::orbt_track_local_map; reference src/Tracking.cc:673-750, :793-842, src/ORBmatcher.cc:42-119).
+    Returns dict(in_view, match, owner, outlier, pose7, nmatches, n_inliers, n_correspondences, n_in_view, greedy_rounds)."""
+    L = _lib.load()
+    K4 = _c(K4, np.float32); bounds = _c(bounds, np.float32)
+    T = np.ascontiguousarray(np.asarray(Tcw, np.float64).reshape(-1)[:12])
+    X = _c(mp_Xw, np.float64).reshape(-1, 3); n = len(X)
+    N = _c(mp_normal, np.float64).reshape(-1, 3); mn = _c(mp_min_dist, np.float32); mx = _c(mp_max_dist, np.float32)
+    D = _c(mp_desc, np.uint8).reshape(-1, 32); S = _c(mp_state, np.uint8)
+    SX = _c(slot_Xw, np.float64).reshape(-1, 3); SS = _c(slot_state, np.uint8); nk = len(SS)
+    assert len(N) == n and len(mn) == n and len(mx) == n and len(D) == n and len(S) == n and len(SX) == nk
+    in_view = np.zeros(max(n, 1), np.uint8); match = np.full(max(n, 1), -1, np.int32)
+    owner = np.full(max(nk, 1), -1, np.int32); outl = np.zeros(max(nk, 1), np.uint8)
+    res = TrackResult()
+    _lib.check(L.orbt_track_local_map(extractor._h, _addr(K4), _addr(bounds), _addr(T), float(log_scale_factor), _addr(X), _addr(N), _addr(mn), _addr(mx), _addr(D),
+                                      _addr(S), n, _addr(SX), _addr(SS), nk, float(th), float(nnratio), _addr(in_view), _addr(match), _addr(owner), _addr(outl),
+                                      C.byref(res)), "orbt_track_local_map")
+    return dict(in_view=in_view[:n].view(np.bool_), match=match[:n], owner=owner[:nk], outlier=outl[:nk].view(np.bool_), pose7=np.array(res.pose7[:], np.float64),
+                nmatches=res.nmatches, n_inliers=res.n_inliers, n_correspondences=res.n_correspondences, n_in_view=res.reserved, greedy_rounds=res.greedy_rounds)

@@ -315,6 +315,30 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
                                  orbx_keypoint* kps_out, uint8_t* desc_out, int cap, int32_t* match_out, int32_t* owner_out,
                                  uint8_t* outlier_out, orbt_result* res);
 
+/* ---- the second stage of Tracking on the same frame, device-resident (src/Tracking.cc:673-750 TrackLocalMap): SearchLocalPoints
+ * (:793-842) = Frame::isInFrustum(pMP, 0.5) (src/Frame.cc:191-241, MapPoint::PredictScale src/MapPoint.cc:406-420) over the local
+ * map points, ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (src/ORBmatcher.cc:42-119: window radius by viewing cosine,
+ * levels [nPredictedLevel - 1, nPredictedLevel], best / second best + level rule, nnratio, the :83-84 claim rule), then
+ * CeresOptimizer::PoseOptimization over EVERY slot that holds a point - in ONE call on the frame (keypoints, descriptors, grid)
+ * that orbt_track_with_motion_model left on the device: the same host thread must have called it for this frame.
+ *   in   Tcw = current_frame_.Tcw_ (row-major 3x4: the pose the first stage optimised); log_scale_factor = Frame::log_scale_factor_;
+ *        per local map point (n_mp <= 16384, vector order of local_map_points_): position, GetNormal(), min_distance_ /
+ *        max_distance_ (the 0.8 / 1.2 invariance factors are applied inside), GetDescriptor(), mp_state = 0 skip (isBad(), or
+ *        last_seen_frame_id_ == current_frame_.id_: it already sits in the frame, :816-817), 1 candidate with Observations() > 0,
+ *        3 candidate without (it is matched but does not close the feature, :83-84); per keypoint of the frame
+ *        (n_kp = the resident frame's count): slot_state = 0 empty, 1 holds a point with Observations() > 0 (closed), 3 holds one
+ *        without; slot_Xw = that point's position (read where slot_state != 0); th = 1 (5 right after a relocalisation,
+ *        :834-838), nnratio = 0.8.
+ *   out  mp_in_view[n_mp] = isInFrustum result (the caller's IncreaseVisible, :822-825); mp_match[n_mp] = feature the point was
+ *        written to or -1; slot_owner[n_kp] = index of the local map point the slot holds NOW if this call wrote it (the last
+ *        writer, :110), else -1 (unchanged); outlier[n_kp] = is_outliers_ after PoseOptimization; res: nmatches, correspondences,
+ *        inliers, pose (the input pose with fewer than 3 correspondences), reserved = points in view.                          */
+int orbt_track_local_map(orbx_ctx* ctx, const float* K4, const float* bounds, const double* Tcw, float log_scale_factor,
+                         const double* mp_Xw, const double* mp_normal, const float* mp_min_dist, const float* mp_max_dist,
+                         const uint8_t* mp_desc, const uint8_t* mp_state, int n_mp, const double* slot_Xw, const uint8_t* slot_state,
+                         int n_kp, float th, float nnratio, uint8_t* mp_in_view, int32_t* mp_match, int32_t* slot_owner,
+                         uint8_t* outlier, orbt_result* res);
+
 /* ------------------------------------------------------------ bundle adjust --
  * Replaces CeresOptimizer::{PoseOptimization, BundleAdjustment/GlobalBundleAdjustemnt,
  * LocalBundleAdjustment, CheckOutlier(s)} (src/CeresOptimizer.cc:49-599) and the Ceres solve

@@ -22,5 +22,31 @@ ms = (time.perf_counter() - t0) / N * 1e3
 t0 = time.perf_counter()
 for _ in range(N): ex(seq[1])
 ms_ex = (time.perf_counter() - t0) / N * 1e3
+# second stage (TrackLocalMap) on the frame the last call left on the device: a local map of the last frame's points that stage 1
+# did not match + 1500 further points around the trajectory, th = 1
+r = tracking.track_with_motion_model(*a, copy=True)
+rng = np.random.default_rng(5)
+own = r["owner"].copy(); own[r["outlier"]] = -1
+nk = len(r["kps"]); has = own >= 0
+slot_state = np.zeros(nk, np.uint8); slot_state[has] = 1
+slot_X = np.zeros((nk, 3)); slot_X[has] = X[own[has]]
+Xr = np.stack([rng.uniform(-20, 20, 1500), rng.uniform(-6, 6, 1500), rng.uniform(8, 40, 1500)], 1)
+MX = np.concatenate([X, Xr]); m = len(MX)
+MD = np.concatenate([d0, rng.integers(0, 256, (1500, 32), dtype=np.uint8)])
+oc = np.concatenate([k0["octave"].astype(int), rng.integers(0, 8, 1500)])
+scale = 1.2 ** np.arange(8)
+dist = np.linalg.norm(MX, axis=1)
+maxd = (dist * scale[oc]).astype(np.float32); mind = (maxd / scale[7]).astype(np.float32)
+Pn = MX / dist[:, None]
+state = np.ones(m, np.uint8); state[own[has]] = 0
+from oracle import pyoracle
+Tm = pyoracle.pose7_to_matrix4d(r["pose7"])
+b = (ex, K4, B, Tm, np.float32(np.log(np.float32(1.2))), MX, Pn, mind, maxd, MD, state, slot_X, slot_state, 1.0, 0.8)
+for _ in range(10): r2 = tracking.track_local_map(*b)
+t0 = time.perf_counter()
+for _ in range(N): r2 = tracking.track_local_map(*b)
+ms_lm = (time.perf_counter() - t0) / N * 1e3
+print(json.dumps({"track_local_map_ms": round(ms_lm, 4), "local_map_points": m, "in_view": int(r2["n_in_view"]), "matched": r2["nmatches"], "correspondences": r2["n_correspondences"],
+                  "inliers": r2["n_inliers"], "greedy_rounds": r2["greedy_rounds"]}))
 print(json.dumps({"tracking_step_ms": round(ms, 4), "orbx_extract_alone_ms": round(ms_ex, 4), "keypoints": len(r["kps"]), "matches": r["nmatches"], "inliers": r["n_inliers"],
                   "greedy_rounds": r["greedy_rounds"]}))
