@@ -162,6 +162,30 @@ def _free_port():
     return p
 
 
+def visible_devices():
+    """HIP devices visible to this process, counted by the library (no torch import in the launcher)."""
+    try:
+        sys.path.insert(0, ROOT)
+        from ceres_mono_orb_slam2_amd import _lib
+        return int(_lib.load().orbhip_device_count())
+    except Exception:
+        return 0
+
+
+def numa_cpus_of_rank(local_rank, n_local):
+    """CPUs a rank's host threads (the 8 LocalBA threads, the structure passes) are pinned to: the rank's share of the CPUs this
+    process may run on, contiguous - on a two-socket node with GPUs 0-3 on socket 0 and 4-7 on socket 1 that keeps a rank's threads
+    on its GPU's NUMA node (contiguous CPU numbering per socket)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if n_local <= 1 or len(cpus) < n_local:
+        return None
+    per = len(cpus) // n_local
+    return cpus[local_rank * per:(local_rank + 1) * per]
+
+
 def worker_envs(n, port, base=None):
     """Environment of each of the N ranks the launcher starts (one process per GPU; LOCAL_RANK selects the device)."""
     envs = []
@@ -175,7 +199,14 @@ def worker_envs(n, port, base=None):
 
 
 def launch(argv, n):
-    """`python bench.py --gpus N` outside torchrun: start N ranks of this script, pass rank 0's stdout through."""
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script, pass rank 0's stdout through.  Fails fast - before
+    any rank is started - when fewer than N devices are visible (ORBHIP_BENCH_SHARED_GPU=1: the dry run on one GPU; --launch-check:
+    no GPU needed)."""
+    if os.environ.get("ORBHIP_BENCH_SHARED_GPU") != "1" and "--launch-check" not in argv:
+        nvis = visible_devices()
+        if nvis < n:
+            sys.stderr.write("bench.py --gpus %d: only %d HIP device(s) visible (ORBHIP_BENCH_SHARED_GPU=1 runs the N > 1 code path on one GPU as a dry run)\n" % (n, nvis))
+            return 2
     envs = worker_envs(n, _free_port())
     procs = []
     for r, e in enumerate(envs):
@@ -289,7 +320,7 @@ def main():
     ap.add_argument("--batches-per-step", type=int, default=32, help="batches per step (distinct resident frames)")
     ap.add_argument("--cpu-sample", type=int, default=96)    # ~8 s of single-thread oracle work
     ap.add_argument("--cpu-all-seconds", type=float, default=8.0)
-    ap.add_argument("--streams", type=int, default=1, help="opt-in pipeline: batch m runs on HIP stream m %% S with its own extractor context, so the "
+    ap.add_argument("--streams", type=int, default=3, help="opt-in pipeline: batch m runs on HIP stream m %% S with its own extractor context, so the "
                     "latency-bound octree of one batch overlaps the issue-bound kernels of another (per-kernel times then include the "
                     "sharing; the default 1 keeps one stream whose kernel times add up to the step)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary 3-stream figure")
@@ -309,6 +340,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.launch_check:
         return launch_check(rank, world)
+    pinned_cpus = None
+    if world > 1:
+        pinned_cpus = numa_cpus_of_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        if pinned_cpus:
+            try:
+                os.sched_setaffinity(0, pinned_cpus)
+            except OSError:
+                pinned_cpus = None
 
     import torch
     import torch.distributed as dist
@@ -396,24 +435,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- pass 1 (not `value`): ONE stream, stage events on - the kernels of a batch run alone (the blur beside FAST + octree on the
+    #      extractor's side stream, as always), so their durations are exclusive and add up along the critical path; this pass
+    #      yields the per-kernel times of `roofline` / `kernels` and the one-stream rate
+    def step_one(events=None):
+        for m in range(M):
+            one(m, 0, events)
+    for _ in range(max(1, min(args.warmup, 2))):
+        step_one()
+    barrier()
+    ex.set_profiling(True)
+    ev = []
+    k1 = max(2, min(args.steps, 5))
+    t1 = time.perf_counter()
+    for k in range(k1):
+        step_one(ev)
+    barrier()
+    dt1 = time.perf_counter() - t1
+    stage_ms, ncalls = ex.stage_ms()
+    ex.set_profiling(False)
+    match_ms = sum(a.elapsed_time(b) for a, b in ev)
+    dt1 = sharding.max_over_ranks(dt1, device=cdev)
+    one_stream = {"value": B * M * world * k1 / dt1, "unit": "frames/s", "steps": k1, "ms_per_step": dt1 / k1 * 1e3,
+                  "note": "the same frames and kernels on ONE stream (pass 1): the per-kernel times of `roofline` and `kernels` come from here"}
+    # ---- pass 2, the timed configuration: batch m on stream m % S with its own extractor context (default S = 3).  The kernels of
+    #      consecutive batches overlap - the matcher's matrix-core products and the latency-bound octree of one batch run beside the
+    #      VALU-issue-bound pyramid / FAST / blur kernels of the next - every batch is extracted AND matched
+    #      inside the timed region, exactly K steps between barrier + synchronize
     for _ in range(args.warmup):
         step()
     barrier()
-    for e in exs:
-        e.set_profiling(True)
-    ev = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(ev)
+        step()
     barrier()
     dt = time.perf_counter() - t0
-    stage_ms, ncalls = None, 0
-    for e in exs:
-        sm, nc = e.stage_ms()
-        e.set_profiling(False)
-        stage_ms = sm if stage_ms is None else {k: stage_ms[k] + v for k, v in sm.items()}
-        ncalls += nc
-    match_ms = sum(a.elapsed_time(b) for a, b in ev)
     dt = sharding.max_over_ranks(dt, device=cdev)
 
     # sanity of the timed work (not timed): one more pass, every frame of every batch produced keypoints and matches
@@ -483,7 +539,7 @@ def main():
 
     # ---- secondary figure (never `value`): the host-fed pipeline, rank 0 of a one-GPU run only
     pcie = None
-    if S == 1 and world == 1 and not args.no_pcie:
+    if world == 1 and not args.no_pcie:
         try:
             pcie = pcie_pipeline(torch, dev, ex, mt, frames_host, B, B * M * world * args.steps / dt)
         except Exception as e:
@@ -539,10 +595,21 @@ def main():
         # its event duration is then NOT an exclusive time (it shares the chip), so it cannot be the "dominant kernel" of the
         # roofline; it is reported as what it is
         blur_concurrent = os.environ.get("ORBHIP_OVERLAP_BLUR", "1" if B >= 8 else "0") != "0"
-        excl = [k for k in ("pyramid", "fast_cells", "blur", "describe", "match") if not (blur_concurrent and k == "blur")]
-        stages = {k: per_call[k] for k in excl}
+        # The critical path of one batch on one stream: pyramid -> max(FAST + octree, blur on the side stream) -> describe -> match.
+        # `roofline` prices the LONGEST KERNEL ON THAT PATH (k_blur7 when the blur leg is the longer one: its duration beside FAST +
+        # octree is a concurrent one, and it is the time the path waits for), `critical_path` the whole path.
+        main_leg = per_call["fast_cells"] + per_call["octree"]
+        blur_leg = per_call["blur"] if blur_concurrent else 0.0
+        on_path = {"pyramid": per_call["pyramid"], "describe": per_call["describe"], "match": per_call["match"]}
+        if blur_concurrent and blur_leg >= main_leg:
+            on_path["blur"] = blur_leg
+        else:
+            on_path["fast_cells"] = per_call["fast_cells"]
+            if not blur_concurrent: on_path["blur"] = per_call["blur"]
+        crit_ms = per_call["pyramid"] + (max(main_leg, blur_leg) if blur_concurrent else main_leg + per_call["blur"]) + per_call["describe"] + per_call["match"]
+        stages = dict(on_path)
         dom = max(stages, key=stages.get)
-        hbm_stages = {k: per_call[k] for k in excl if k != "match"}
+        hbm_stages = {k: v for k, v in on_path.items() if k != "match"}
         hdom = max(hbm_stages, key=hbm_stages.get)
         kname = kernel_of[dom]
         ach = bytes_of[dom] * B / (per_call[dom] * 1e-3) / 1e9
@@ -617,11 +684,19 @@ def main():
             except Exception:
                 continue
         roof["hbm_stream_kernel"] = hroof
+        fe_bytes0 = sum(BYTES.values()) + bytes_of["match"]
+        roof["critical_path"] = {"legs_ms": {"pyramid": per_call["pyramid"], "fast_cells+octree": main_leg, "blur (side stream, concurrent)": blur_leg,
+                                             "describe": per_call["describe"], "match": per_call["match"]},
+                                 "longer_middle_leg": "k_blur7" if (blur_concurrent and blur_leg >= main_leg) else "k_fast_cells + k_octree",
+                                 "ms_per_batch": crit_ms, "one_stream_ms_per_batch_measured": dt1 / k1 / M * 1e3,
+                                 "algorithmic_GBps": fe_bytes0 * B / (crit_ms * 1e-3) / 1e9, "frac_of_hbm_peak": fe_bytes0 * B / (crit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "pyramid + max(FAST + octree, blur) + describe + match of one batch on one stream (pass 1); the timed configuration "
+                                         "overlaps the paths of consecutive batches on %d streams" % S}
         if match_mfma: roof["match_kernel_mfma"] = match_mfma_roof
         else: roof["match_kernel_valu_issue"] = match_valu
         if blur_concurrent:
             roof["concurrent_kernels"] = {"k_blur7": {"ms_per_launch": per_call["blur"], "stream": "the extractor's side stream, beside k_fast_cells + k_octree",
-                                                       "note": "a concurrent duration, not an exclusive one: alone the launch takes ~0.40 ms (ORBHIP_OVERLAP_BLUR=0, profiles/)"}}
+                                                       "note": "a concurrent duration, not an exclusive one: alone the launch takes ~0.40 ms (ORBHIP_OVERLAP_BLUR=0, profiles/); when it is longer than FAST + octree it IS the middle leg of the critical path and `roofline` prices it"}}
         # whole front-end (extract + match of one frame) against both ceilings: algorithmic bytes / frame x frames/s / HBM peak,
         # and VALU lane-ops / frame (committed PMC pass: SQ_INSTS_VALU x 64 lanes of the five extract kernels, + the matcher's
         # counted instructions) x frames/s / issue peak
@@ -663,17 +738,20 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        out["one_stream"] = one_stream
         if pipelined is not None:
             out["pipelined"] = pipelined
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if match_full is not None:
             if "ms_per_launch" in match_full:     # what the step would take with every frame at its quota: only the match leg grows
-                ms_step = dt / args.steps / M * 1e3
-                match_full["frames_per_s_if_every_frame_had_2000"] = B / ((ms_step - per_call["match"] + match_full["ms_per_launch"]) * 1e-3)
+                ms_step = dt1 / k1 / M * 1e3
+                match_full["one_stream_frames_per_s_if_every_frame_had_2000"] = B / ((ms_step - per_call["match"] + match_full["ms_per_launch"]) * 1e-3)
             out["match_2000x2000"] = match_full
         if collective is not None:
             out["collective"] = collective
+        if world > 1:
+            out["host_threads_pinned_to_cpus"] = ("%d-%d (rank 0; every rank takes its contiguous share)" % (pinned_cpus[0], pinned_cpus[-1])) if pinned_cpus else None
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_host, args.cpu_sample, args.cpu_all_seconds)
             out["cpu_baseline"]["build"] = oracle_build

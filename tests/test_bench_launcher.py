@@ -42,3 +42,13 @@ def test_rank_count_must_equal_gpus():
     e = dict(os.environ); e.update({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--launch-check"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "ranks were launched" in p.stderr
+
+
+def test_launcher_fails_fast_when_fewer_devices_than_ranks():
+    """`bench.py --gpus 8` on a box with fewer than 8 visible devices stops before any rank is started; the
+    dry run on one GPU is the explicit ORBHIP_BENCH_SHARED_GPU=1."""
+    import subprocess
+    env = dict(os.environ); env.pop("ORBHIP_BENCH_SHARED_GPU", None); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "HIP device(s) visible" in r.stderr and r.stdout.strip() == ""
