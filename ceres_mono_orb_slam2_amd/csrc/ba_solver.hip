@@ -3086,436 +3086,11 @@ __global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restric
   }
 }
 
-// ---- the two-level factorisation as ONE persistent launch (a single large problem, the GPU to itself) -------------------------
-// The block launches above still end 24 times per C5 factorisation: ~9 us per boundary (launch, first loads, the next block's
-// columns) on top of 4 x 9 us of steps.  Here the chain runs through all the steps and the K = 128 updates become dataflow too:
-//   workgroup 0, the CHAIN: as above, through all blocks.  At a block's last step it forms the NEXT block's first diagonal block
-//     itself (the K = 128 update of D(kend,kend): the stages accumulated over the block's steps beside the factor, the last one
-//     from the L(kend,kend-1) it has just computed) - the boundary costs the chain nothing;
-//   one workgroup per block row: L(i,j), the thin updates inside the block, and the K = 128 update of its tiles in the NEXT
-//     block's four column blocks ("near"): one K stage per step accumulated in registers, applied (cpre - acc) at the block's end;
-//   W WORKERS: the K = 128 updates of everything right of the next block ("far"), 64 x 64 tiles with a fixed owner each (tile
-//     index mod W, columns in ascending order: what is needed first comes first), one update per finished outer block; a tile's
-//     count of applied updates is its WPROG flag, which the near update (its last K = 128 update) waits for.  The owner of a
-//     diagonal tile also updates the rhs row's entries of its 64 columns.
-// Every element receives the operations of the step kernels in their order: bit-identical.  Rows wait for workers and workers
-// for rows, so ALL workgroups must be resident: the host launches this only when the kernel's occupancy x CUs covers the grid and
-// no other persistent factorisation is in flight on the device (otherwise the block launches above / the step kernels: same bits).
-__global__ __launch_bounds__(256) void k_chol_persist_2l(const BaDev* __restrict__ Dv, int ns, int nworkers) {
-  const BaDev D = Dv[blockIdx.y];
-  if (D.chol_la) return;
-  BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid || F.chol_fail) return;
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  const int np = D.npad, nb = np / NB, tid = threadIdx.x, bx = (int)blockIdx.x;
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int ti = w >> 1, tj = w & 1;
-  double* S = D.S;
-  double* Dinv = D.Dinv;
-  int* flags = D.cflags;
-  const int R = nb + 2, FIN = BP_LREADY + R, NEAR = BP_LREADY + 2 * R, WP = BP_LREADY + 3 * R;
-  const int nt = (nb + 1) / 2;                                  // 64-row tiles per side
-  if (bx == 0) {
-    // ------------------------------------------------------------------------------------------------ the chain
-    double (*s_L)[NB + 1] = (double (*)[NB + 1])s_dyn;
-    double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
-    double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
-    double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
-    double (*s_Lp)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
-    double* s_share = s_dyn + 5 * NB * (NB + 1);
-    double (*s_T)[64] = (double (*)[64])(s_dyn + 6 * NB * (NB + 1));                  // (2048 doubles: ends inside tile slot 7)
-    double (*s_N)[NB + 1] = (double (*)[NB + 1])(s_dyn + 8 * NB * (NB + 1));
-    __shared__ int s_fail, s_arrive, s_arrive2, s_grp;
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(size_t)r * np + c] : 0.0; }
-    if (tid == 0) { s_fail = 0; s_arrive = 0; s_arrive2 = 0; s_grp = 0; }
-    const int di = (w == 1) ? 0 : 1, dj = (w == 3) ? 1 : 0;
-    const int ai = (w <= 1) ? 0 : 1;
-    int n_grp = 0;
-    double4_t accD = {0.0, 0.0, 0.0, 0.0};                      // the next block's first diagonal block: K stages of its update
-    __syncthreads();
-    for (int k = 0; k < nb; k++) {
-      const int b = k / ns, jb0 = b * ns, kend = min(jb0 + ns, nb);
-      const bool upd = k > jb0, next = k + 1 < nb, last = (k == kend - 1);
-      const bool nextD = next && !last, nearD = next && last;
-      const bool has_n = kend < nb;
-      double c2[4] = {0.0, 0.0, 0.0, 0.0};
-      double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (!upd) accD = (double4_t){0.0, 0.0, 0.0, 0.0};
-      if (tid == 0) P2_MARK(0, k);                              // step start
-      if (tid < 64) {
-        const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
-        if (tid == 0) P2_MARK(1, k);                            // factor done
-        if (fail && tid == 0) s_fail = 1;
-      } else if (next) {
-        bool ok = true;
-        if (upd) ok = cp_wait(flags, FIN + k + 1, 1);           // row k + 1 has its thin updates
-        else if (b > 0) ok = cp_wait(flags, NEAR + k + 1, b);   // ... the previous block's K = 128 update
-        const bool extra = has_n && upd && !last;               // a K stage of D(kend,kend) that is not staged anyway: L(kend, k - 1)
-        if (ok && extra) ok = cp_wait(flags, BP_LREADY + kend, k);
-        if (ok && nearD && b > 0) ok = cp_wait(flags, WP + (kend / 2) * nt + kend / 2, b);
-        if (!ok) s_fail = 2;
-        if (tid == 64) P2_MARK(2, k);                           // staging waits satisfied
-        const size_t rb = (size_t)(k + 1) * NB;
-        {
-          double ta[6], tl[6], tn[6];                           // (every load requested before the first LDS store, as in the block chain)
-#pragma unroll
-          for (int u = 0; u < 6; u++) {
-            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
-            ta[u] = i < NB * NB ? ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]) : 0.0;
-            tl[u] = (upd && i < NB * NB) ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
-            tn[u] = (extra && i < NB * NB) ? ld_sc1(&S[((size_t)kend * NB + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < 6; u++) {
-            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
-            if (i < NB * NB) { s_A1[r][c] = ta[u]; s_Lp[r][c] = tl[u]; if (extra) s_N[r][c] = tn[u]; }
-          }
-        }
-        if (nextD || nearD) {
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
-            c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        n_grp += 3;
-        if (lane == 0) __hip_atomic_fetch_add(&s_grp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int it = 0; it < CP_SPIN_CAP && __hip_atomic_load(&s_grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_grp; it++) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) a[ks] = s_A1[16 * ai + li][4 * ks + lk];
-        if (upd) {
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], -s_Lp[16 * ai + li][4 * ks + lk], acc, 0, 0, 0);
-            a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-          }
-        }
-        if (w == 1) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) s_share[lane * 8 + ks] = a[ks];
-        }
-        if (has_n && upd) {                                     // K stage k - 1 - jb0 of D(kend,kend): L(kend, k - 1) (at the last step that IS s_Lp)
-          double (*src)[NB + 1] = last ? s_Lp : s_N;
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(src[16 * di + li][4 * ks + lk], src[16 * dj + li][4 * ks + lk], accD, 0, 0, 0);
-        }
-      }
-      __syncthreads();
-      if (s_fail) { if (tid == 0) cp_die(st, flags); return; }
-      {
-        double* Di = Dinv + (size_t)k * NB * NB;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; st_sc1(&Di[i], s_X[i / NB][i % NB]); }
-      }
-      if (next) {
-        if (w == 0) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) a[ks] = s_share[lane * 8 + ks];
-        }
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], s_X[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
-        const size_t rb = (size_t)(k + 1) * NB;
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
-        HANDOFF_DRAIN();
-        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_XREADY, k + 1);
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
-        __syncthreads();
-        if (w >= 1) {
-          if (nextD) {
-            double4_t a2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * di + li][4 * ks + lk], s_P[16 * dj + li][4 * ks + lk], a2, 0, 0, 0);
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-              const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
-              if (c <= r) s_L[r][c] = c2[rg] - a2[rg];
-            }
-          } else if (nearD) {                                   // the block's last K stage, then the whole K = 128 update at once
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * di + li][4 * ks + lk], s_P[16 * dj + li][4 * ks + lk], accD, 0, 0, 0);
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-              const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
-              if (c <= r) s_L[r][c] = c2[rg] - accD[rg];
-            }
-          }
-        }
-        HANDOFF_DRAIN();
-        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, BP_LREADY + k + 1, k + 1);
-      }
-      if (!next) {
-        HANDOFF_DRAIN();
-        __syncthreads();
-        if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
-      }
-      __syncthreads();
-    }
-    return;
-  }
-  if (bx >= nb) {
-    // ------------------------------------------------------------------------------------------------ a worker
-    const int wk = bx - nb;
-    if (wk >= nworkers) return;
-    double* s_z = s_dyn;
-    double* zrow = S + (size_t)np * np;
-    const int tpb = ns / 2;                                     // 64-column tiles per outer block
-    for (int b = 0; (b + 1) * ns < nb; b++) {
-      const int kend = (b + 1) * ns, kcol = b * ns * NB, K = ns * NB;
-      const int np2 = (nt + 1) / 2;                             // pairs of vertically adjacent tiles (128 x 64) per tile column
-      for (int C = (b + 2) * tpb; C < nt; C++) {
-        const int m = C / 2, off2 = C * np2 - (m * (m - 1) + (C & 1) * m);      // pairs of the columns before C
-        const int pp = m + (((wk - off2) % nworkers) + nworkers) % nworkers;
-        if (pp >= np2) continue;                                // (nworkers >= np2: at most one pair of a column is this worker's)
-        const int c0 = 64 * C;
-        const bool diag = (2 * pp == C) || (2 * pp + 1 == C);
-        bool ok = cp_wait(flags, BP_LREADY + 2 * C, kend);
-        if (ok && 2 * C + 1 < nb) ok = cp_wait(flags, BP_LREADY + 2 * C + 1, kend);
-#pragma unroll
-        for (int q = 0; q < 4; q++) if (ok && 4 * pp + q < nb) ok = cp_wait(flags, BP_LREADY + 4 * pp + q, kend);
-        if (ok && diag) ok = cp_wait(flags, BP_LREADY + nb, kend);
-        if (__syncthreads_count(!ok)) { if (tid == 0) cp_die(st, flags); return; }
-        chol_syrk_tile2_pf<true>(D, pp, C, kcol, K, 0, s_dyn);
-        if (diag) {                                             // the rhs row's entries of these 64 columns
-          __syncthreads();
-          for (int i = tid; i < K; i += 256) s_z[i] = ld_sc1(&zrow[kcol + i]);
-          __syncthreads();
-          const int c = c0 + tid;
-          if (tid < 64 && c < np) {
-            const double* L = S + (size_t)c * np + kcol;
-            double sum = 0.0;
-            for (int mm = 0; mm < K; mm++) sum += ld_sc1(&L[mm]) * s_z[mm];
-            st_sc1(&zrow[c], ld_sc1(&zrow[c]) - sum);
-          }
-        }
-        HANDOFF_DRAIN();
-        __syncthreads();
-        if (tid == 0) {
-          cp_set(flags, WP + (2 * pp) * nt + C, b + 1);
-          if (2 * pp + 1 < nt) cp_set(flags, WP + (2 * pp + 1) * nt + C, b + 1);
-          if (C < (b + 3) * tpb) P2_MARK(4, b);                 // the tiles the next near update needs
-        }
-      }
-      if (tid == 0) P2_MARK(3, b);                              // all far tiles of block b
-    }
-    return;
-  }
-  // -------------------------------------------------------------------------------------------------- a row
-  int irow; bool is_rhs = false;
-  if (bx <= nb - 2) irow = bx + 1;                              // bx 1 -> row 2
-  else { irow = nb; is_rhs = true; }
-  const size_t r0 = is_rhs ? (size_t)np : (size_t)irow * NB;
-  double (*s_Lc)[NB + 1] = (double (*)[NB + 1])s_dyn;
-  double (*s_Lq)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
-  double (*s_A)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
-  double (*s_Xj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
-  double (*s_Pj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
-  double* s_near = s_dyn + 5 * NB * (NB + 1);                   // up to four operand tiles L(c, j) of the next block's rows
-  __shared__ int s_dead;
-  if (tid == 0) s_dead = 0;
-  __syncthreads();
-  const int arow = 16 * ti + li;
-  const int jend = is_rhs ? nb : irow - 1;                      // j <= i - 2 (the chain forms L(i, i-1))
-  double4_t accN[4];
-  double zsum = 0.0;
-#pragma unroll
-  for (int t = 0; t < 4; t++) accN[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  double* zrow = S + (size_t)np * np;
-  for (int j = 0; j < jend; j++) {
-    const int b = j / ns, jb0 = b * ns, kend = min(jb0 + ns, nb), nend = min(kend + ns, nb);
-    const bool upd = j > jb0, lastj = (j == kend - 1);
-    const bool near_on = kend < nb && (is_rhs || irow > kend);  // (row kend's only tile of the next block is the diagonal one: the chain's)
-    if (!upd) {
-      zsum = 0.0;
-#pragma unroll
-      for (int t = 0; t < 4; t++) accN[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    }
-    bool ok = true;
-    if (upd) ok = cp_wait(flags, BP_LREADY + j, j);             // P_j = L(j, j-1) is published
-    double va[4], vp[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int idx = tid + 256 * u, r = idx / NB, c = idx % NB;
-      va[u] = (ok && (is_rhs ? r == 0 : true)) ? ld_sc1(&S[(r0 + r) * np + (size_t)j * NB + c]) : 0.0;
-      vp[u] = (ok && upd) ? ld_sc1(&S[((size_t)j * NB + r) * np + (size_t)(j - 1) * NB + c]) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u, r = idx / NB, c = idx % NB; s_A[r][c] = va[u]; s_Pj[r][c] = vp[u]; }
-    __syncthreads();
-    double a[8], bq[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) a[ks] = s_A[arow][4 * ks + lk];
-    if (upd) {
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_Pj[16 * t + li][4 * ks + lk], -s_Lq[arow][4 * ks + lk], acc, 0, 0, 0);
-        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-      }
-    }
-    if (ok) ok = cp_wait(flags, CP_XREADY, j + 1);
-    double vx[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) vx[u] = ok ? ld_sc1(&Dinv[(size_t)j * NB * NB + tid + 256 * u]) : 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vx[u]; }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) bq[ks] = s_Xj[16 * tj + li][4 * ks + lk];
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], bq[ks], acc, 0, 0, 0);
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
-      s_Lc[r][c] = acc[rg];
-      if (ok && (is_rhs ? r == 0 : true)) st_sc1(&S[(r0 + r) * np + (size_t)j * NB + c], acc[rg]);
-    }
-    if (!ok) s_dead = 1;
-    HANDOFF_DRAIN();
-    __syncthreads();
-    if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-    if (tid == 0) cp_set(flags, BP_LREADY + irow, j + 1);
-    if (tid == 0) P2_MARK(5, j);                                // L(i, j) published (latest row)
-    if (!is_rhs) {
-      double la[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) la[ks] = s_Lc[16 * ti + li][4 * ks + lk];
-      // ---- thin updates inside the block
-      for (int c = j + 2; c < kend && c <= irow; c++) {
-        const size_t cb = (size_t)c * NB;
-        bool okc = true;
-        if (c < irow) okc = cp_wait(flags, BP_LREADY + c, j + 1);
-        double vb[4], cpre[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vb[u] = (okc && c < irow) ? ld_sc1(&S[(cb + idx / NB) * np + (size_t)j * NB + idx % NB]) : 0.0; }
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) cpre[rg] = okc ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + cb + 16 * tj + (lane & 15)]) : 0.0;
-        __syncthreads();
-        if (c < irow) {
-#pragma unroll
-          for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vb[u]; }
-        }
-        __syncthreads();
-        double4_t u4 = {0.0, 0.0, 0.0, 0.0};
-        if (c < irow) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_Xj[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_Lc[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = cb + 16 * tj + (lane & 15);
-          if (okc && col <= row) st_sc1(&S[row * np + col], cpre[rg] - u4[rg]);
-        }
-        if (!okc) s_dead = 1;
-      }
-      HANDOFF_DRAIN();
-      __syncthreads();
-      if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-      if (tid == 0 && j == irow - 2) cp_set(flags, FIN + irow, 1);
-      // ---- K stage j - jb0 of the next block's columns (<= four tiles), accumulated; applied at the block's last step
-      if (near_on) {
-        const int ntile = min(nend, irow + 1) - kend;           // tiles c = kend + t <= irow
-        bool okn = true;
-        double vn[4][4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-          const int c = kend + t;
-          if (t < ntile && c < irow) {
-            if (okn) okn = cp_wait(flags, BP_LREADY + c, j + 1);
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vn[t][u] = okn ? ld_sc1(&S[((size_t)c * NB + idx / NB) * np + (size_t)j * NB + idx % NB]) : 0.0; }
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-          if (t < ntile && kend + t < irow) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_near[t * NB * (NB + 1) + (idx / NB) * (NB + 1) + idx % NB] = vn[t][u]; }
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-          if (t < ntile) {
-            const double* src = (kend + t < irow) ? s_near + t * NB * (NB + 1) : &s_Lc[0][0];
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) accN[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], src[(16 * tj + li) * (NB + 1) + 4 * ks + lk], accN[t], 0, 0, 0);
-          }
-        }
-        if (lastj) {
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            if (t < ntile) {
-              const int c = kend + t;
-              if (okn && b > 0) okn = cp_wait(flags, WP + (irow / 2) * nt + c / 2, b);      // the tile has the far updates of the blocks before
-              const size_t cb = (size_t)c * NB;
-#pragma unroll
-              for (int rg = 0; rg < 4; rg++) {
-                const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = cb + 16 * tj + (lane & 15);
-                if (okn && col <= row) st_sc1(&S[row * np + col], ld_sc1(&S[row * np + col]) - accN[t][rg]);
-              }
-            }
-          }
-        }
-        if (!okn) s_dead = 1;
-        HANDOFF_DRAIN();
-        __syncthreads();
-        if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-        if (lastj && tid == 0) cp_set(flags, NEAR + irow, b + 1);
-        if (tid == 0) P2_MARK(6, j);                            // step j complete incl. near part (latest row)
-        if (tid == 0 && irow == kend + 1) P2_MARK(7, j);        // ... the row the chain needs next
-      }
-    } else {
-      // the rhs row: thin columns, then the K stage of the next block's columns
-      for (int cc = (j + 2) * NB + tid; cc < kend * NB; cc += 256) {
-        if (!cp_wait(flags, BP_LREADY + cc / NB, j + 1)) { s_dead = 1; break; }
-        const double* L = S + (size_t)cc * np + (size_t)j * NB;
-        double lv[NB];
-#pragma unroll
-        for (int mm = 0; mm < NB; mm++) lv[mm] = ld_sc1(&L[mm]);
-        const double z0 = ld_sc1(&zrow[cc]);
-        double sum = 0.0;
-#pragma unroll
-        for (int mm = 0; mm < NB; mm++) sum += lv[mm] * s_Lc[0][mm];
-        st_sc1(&zrow[cc], z0 - sum);
-      }
-      if (near_on) {
-        const int cc = kend * NB + tid;                         // (<= 256 columns per outer block)
-        if (cc < nend * NB) {
-          bool okn = cp_wait(flags, BP_LREADY + cc / NB, j + 1);
-          const double* L = S + (size_t)cc * np + (size_t)j * NB;
-          double lv[NB];
-#pragma unroll
-          for (int mm = 0; mm < NB; mm++) lv[mm] = okn ? ld_sc1(&L[mm]) : 0.0;
-#pragma unroll
-          for (int mm = 0; mm < NB; mm++) zsum += lv[mm] * s_Lc[0][mm];
-          if (lastj) {
-            if (okn && b > 0) okn = cp_wait(flags, WP + (cc / 64) * nt + cc / 64, b);
-            if (okn) st_sc1(&zrow[cc], ld_sc1(&zrow[cc]) - zsum);
-          }
-          if (!okn) s_dead = 1;
-        }
-      }
-      HANDOFF_DRAIN();
-      __syncthreads();
-      if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-    }
-    { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
-  }
-}
+// (the one-launch two-level kernel k_chol_persist_2l - bit-identical, measured slower - lives in experiments/chol_persist_2l.inc:
+// ORBHIP_EXPERIMENTS builds, ORBHIP_BA_PERSIST=2)
+#ifdef ORBHIP_EXPERIMENTS
+#include "experiments/chol_persist_2l.inc"
+#endif
 
 // backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
 // of 256 rows processed from the bottom: k_chol_bsolve_diag solves one super-block with a single 1024-thread
@@ -4192,7 +3767,17 @@ static hipStream_t thread_stream() {
     g_batch_valid = false;
     g_stop_host = nullptr; g_stop_dev = nullptr;       // the mirror's device pointer belongs to the old device: re-derive it
   }
-  if (!g_stream) { if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) g_stream = nullptr; g_stream_device = dev; }
+  static thread_local int prio_cur = 0;
+  const int prio_want = thread_ws().prio_want;           // orbhip_set_thread_priority (the Tracking thread's PoseOptimization beside another thread's LocalBA)
+  if (g_stream && prio_cur != prio_want) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); g_stream = nullptr; g_graphs.clear(); }
+  if (!g_stream) {
+    int lo = 0, hi = 0;
+    hipError_t e;
+    if (prio_want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) e = hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, hi);
+    else e = hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) g_stream = nullptr;
+    g_stream_device = dev; prio_cur = prio_want;
+  }
   return g_stream;
 }
 
@@ -4555,8 +4140,15 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   if (int r = raise_dynamic_lds((const void*)k_chol_wg, g_stream_device, CW_LDS_DOUBLES * sizeof(double))) return r;
   const int npad_all = g_npad;
   // ---- which form of the Cholesky this solve takes (0 step kernels, 1 persistent launches, 2 the one-launch two-level kernel)
-  static const int persist_max = []() { const char* e = std::getenv("ORBHIP_BA_PERSIST"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
-  static const int OB = []() { const char* e = std::getenv("ORBHIP_BA_OB"); const int v = e ? atoi(e) : 128; return (v >= 64 && v <= 1024 && v % 32 == 0) ? v : 128; }();
+  static const int persist_max = []() {
+    const char* e = std::getenv("ORBHIP_BA_PERSIST");      // 0: the step kernels (the bit-identity tests), 1 (default): the persistent launches; 2 = the one-launch kernel, ORBHIP_EXPERIMENTS builds only
+#ifdef ORBHIP_EXPERIMENTS
+    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
+#else
+    return e && e[0] == '0' ? 0 : 1;
+#endif
+  }();
+  static const int OB = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_BA_OB"); const int v = e ? atoi(e) : 128; return (v >= 64 && v <= 1024 && v % 32 == 0) ? v : 128; }();
   PersistLease lease;
   int persist_mode = 0, p2_workers = 0, persist_cus = 0;
   if (persist_max > 0 && ny < 4 && B.g_npad_la <= 1024) {
@@ -4566,8 +4158,10 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
       cus = hipGetDeviceProperties(&prop, g_stream_device) == hipSuccess ? prop.multiProcessorCount : 0;
       (void)raise_dynamic_lds((const void*)k_chol_persist, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
       (void)raise_dynamic_lds((const void*)k_chol_persist_blk, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
+#ifdef ORBHIP_EXPERIMENTS
       (void)raise_dynamic_lds((const void*)k_chol_persist_2l, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2l, k_chol_persist_2l, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) occ2l = 0;
+#endif
       int oa = 0, ob = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_chol_persist, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) oa = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_chol_persist_blk, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) ob = 0;
@@ -4633,7 +4227,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     } else
     for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) launch_la(npl, k, 0, INT_MAX, 0, no_wide);
     // two-level scheme (outer block = 4 panels of NB = 32) for the larger systems.
-    static const bool classic = []() { const char* e = std::getenv("ORBHIP_BA_2L_CLASSIC"); return e && e[0] == '1'; }();
+    static const bool classic = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_BA_2L_CLASSIC"); return e && e[0] == '1'; }();
     if (classic) {
       // round-1 form: panel -> thin update -> panel ... -> one wide update
       for (int k0 = 0; k0 < npad; k0 += OB) {
@@ -4646,8 +4240,10 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
         }
         if (kend < npad) launch_update(s, k0, kend - k0, kend, kend, npad, INT_MAX);      // one wide update for everything to the right
       }
+#ifdef ORBHIP_EXPERIMENTS
     } else if (npad > 0 && persist_mode == 2) {
       hipLaunchKernelGGL(k_chol_persist_2l, dim3(npad / NB + p2_workers, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, OB / NB, p2_workers);
+#endif
     } else if (npad > 0) {
       // hybrid: the steps of an outer block are look-ahead launches confined to the block (the thin updates leave the serial
       // chain); of its K = 128 update only the NEXT outer block's 128 columns are a launch of their own (the chain needs
@@ -4699,7 +4295,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   enqueue_eval();                                             // iteration 0
   bool user_stop = stop && *stop;                             // StopFlagCallback after iteration 0
   hipGraphExec_t gexec = nullptr;
-  static const bool use_graph = []() { const char* e = std::getenv("ORBHIP_BA_GRAPH"); return !(e && e[0] == '0'); }();
+  static const bool use_graph = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_BA_GRAPH"); return !(e && e[0] == '0'); }();
   if (use_graph && opts->max_iterations >= 3 && !user_stop) {
     for (auto& e : g_graphs)
       if (e.exec && e.Dv == Dv && e.mode == persist_mode && e.D.size() == Dh.size() && std::memcmp(e.D.data(), Dh.data(), Dh.size() * sizeof(BaDev)) == 0) { gexec = e.exec; e.stamp = ++g_graph_clock; break; }

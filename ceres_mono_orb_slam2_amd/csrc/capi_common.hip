@@ -43,4 +43,5 @@ int orbhip_set_default_device(int device) {
   return 0;
 }
 int orbhip_get_default_device(void) { return orbhip::g_default_device.load(); }
+int orbhip_set_thread_priority(int high) { orbhip::thread_ws().prio_want = high ? 1 : 0; return 0; }
 }

@@ -42,6 +42,15 @@ inline int use_default_device() {
     }                                            \
   } while (0)
 
+// Environment switches.  The product library reads only the ones a maintainer needs (documented in INTEGRATION.md: ORBHIP_MATCH_MFMA,
+// ORBHIP_BA_PERSIST, ORBHIP_BA_WG, ORBHIP_BA_LOOKAHEAD / ORBHIP_BA_LA_MAX, the ORBHIP_*_TIMING diagnostics, ORBHIP_POISON, the
+// ORBHIP_KEYCAP test hook); the knobs of measured-and-rejected alternatives exist only in -DORBHIP_EXPERIMENTS builds (tools/).
+#ifdef ORBHIP_EXPERIMENTS
+#define ORBHIP_EXP_ENV(name) std::getenv(name)
+#else
+#define ORBHIP_EXP_ENV(name) ((const char*)nullptr)
+#endif
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // growable device buffer
@@ -83,7 +92,7 @@ struct PinnedHost {
 // costs no hipMalloc / hipFree and its copies are true asynchronous DMA; every call ends with a single stream synchronise.
 // No destructor: freeing from a thread_local destructor can run after the HIP runtime has shut down.
 struct ThreadWs {
-  hipStream_t s = nullptr; int device = -1;
+  hipStream_t s = nullptr; int device = -1; int prio_want = 0, prio_cur = 0;
   std::vector<DevBuf> dev; std::vector<PinnedHost> pin;
   size_t dnext = 0, pnext = 0;
   int begin() {                                              // select the default device, (re)create the stream, rewind the slots
@@ -92,7 +101,17 @@ struct ThreadWs {
     if (int rc = use_default_device()) return rc;
     const int d = g_default_device.load();
     if (s && device != d) { (void)hipStreamDestroy(s); s = nullptr; dev.clear(); pin.clear(); }   // (buffers of the old device are leaked on purpose)
-    if (!s) { if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; set_error("hipStreamCreate failed"); return ORBHIP_ENODEV; } device = d; }
+    if (s && prio_cur != prio_want) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); s = nullptr; }     // (orbhip_set_thread_priority since the last call)
+    if (!s) {
+      // the calling thread's stream; a thread that asked for priority (the Tracking thread: one frame's chain of ~15 short kernels
+      // beside another thread's bundle adjustment) gets the device's greatest stream priority
+      int lo = 0, hi = 0;
+      hipError_t e = hipSuccess;
+      if (prio_want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi);
+      else e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+      if (e != hipSuccess) { s = nullptr; set_error("hipStreamCreate failed"); return ORBHIP_ENODEV; }
+      device = d; prio_cur = prio_want;
+    }
     dnext = pnext = 0;
     return 0;
   }

@@ -1010,7 +1010,8 @@ __global__ __launch_bounds__(OCT_TPB) void k_octree_pair(GeomDev G, const int* _
 // ---------------------------------------------------------------------------- k_blur7
 #define BLUR_TW 128
 #define BLUR_TH 64
-#ifndef BLUR_COL_SLIDE
+#if !defined(BLUR_COL_SLIDE) || !defined(ORBHIP_EXPERIMENTS)
+#undef BLUR_COL_SLIDE
 #define BLUR_COL_SLIDE 0      // 1: a thread owns eight CONSECUTIVE output rows (14 LDS reads + 56 unpacks per thread instead of 56 + 224, bit-exact) - 0.407 ms against 0.392
 #endif
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -1087,38 +1088,7 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
     }
   }
 #else
-  // Column pass: a thread owns EIGHT CONSECUTIVE output rows of its four columns, so every intermediate row is read and unpacked
-  // once and feeds up to seven accumulators (the strided assignment read and unpacked seven rows per output row: 56 LDS reads
-  // and 224 unpacks per thread instead of 14 and 56).
-  {
-    const int rb = 8 * rr;                               // first output row of this thread inside the tile
-    const int taps[7] = {18, 34, 49, 55, 49, 34, 18};
-    int acc[8][4];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { acc[j][0] = 0; acc[j][1] = 0; acc[j][2] = 0; acc[j][3] = 0; }
-#pragma unroll
-    for (int k = 0; k < 14; k++) {
-      const uint2 m = *(const uint2*)&s_mid[rb + k][4 * cg];
-      const int v0 = (int)(m.x & 0xFFFF), v1 = (int)(m.x >> 16), v2 = (int)(m.y & 0xFFFF), v3 = (int)(m.y >> 16);
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        if (k - j >= 0 && k - j <= 6) {
-          const int t = taps[k - j];
-          acc[j][0] += t * v0; acc[j][1] += t * v1; acc[j][2] += t * v2; acc[j][3] += t * v3;
-        }
-      }
-    }
-    uint8_t* drow = dst + (uint32_t)(y0 + rb) * (uint32_t)L.bpitch + (uint32_t)xo;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      if (y0 + rb + j < L.h) {
-        uint32_t out = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) { int v = (acc[j][c] + (1 << 15)) >> 16; v = v > 255 ? 255 : v; out |= (uint32_t)v << (8 * c); }
-        *(uint32_t*)(drow + (uint32_t)j * (uint32_t)L.bpitch) = out;           // bpitch is a multiple of 64 >= w
-      }
-    }
-  }
+#include "experiments/blur_col_slide.inc"
 #endif
 }
 
@@ -1572,7 +1542,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     G.tile_w = tile_w; G.tile_h = tile_h; G.tile_pitch = round_up(tile_w, 4) + 4;
     G.node_cap = round_up(node_cap, 8); G.max_cells_level = round_up(max_cells, 8);
 #ifdef ORBHIP_OCT_LEVEL_EXPERIMENT
-    G.oct_level_mask = std::getenv("ORBHIP_OCT_LEVELS") ? (int)strtol(std::getenv("ORBHIP_OCT_LEVELS"), nullptr, 0) : 0xFFFF;
+    G.oct_level_mask = ORBHIP_EXP_ENV("ORBHIP_OCT_LEVELS") ? (int)strtol(ORBHIP_EXP_ENV("ORBHIP_OCT_LEVELS"), nullptr, 0) : 0xFFFF;
 #endif
     // ---- k_pyr_cone: per 32 x 8 tile of the top level, the box it computes on every level (see the kernel)
     c->cone_wgs = 0;
@@ -1674,7 +1644,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   const int nl = c->nlevels;
   uint8_t* pyr = c->d_pyr.as<uint8_t>();
   auto mark = [&]() { if (c->profiling) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_events.push_back(e); } } };
-  static const bool cone_on = []() { const char* e = std::getenv("ORBHIP_EXTRACT_CONE"); return !(e && e[0] == '0'); }();
+  static const bool cone_on = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_EXTRACT_CONE"); return !(e && e[0] == '0'); }();
   const bool cone = cone_on && nframes == 1 && c->cone_wgs > 0;
   if (!cone) ORBHIP_CHECK_HIP(hipMemsetAsync(c->d_status.p, 0, (size_t)nframes * 4, st));
   mark();
@@ -1804,14 +1774,21 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
   c->iniTh = ini_th_fast; c->minTh = min_th_fast; c->device = device;
   build_tables(c);
   (void)hipSetDevice(device);
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+  {
+    // (greatest priority: inside the per-frame Tracking chain the blur on this stream is on the frame's critical path, and the
+    // Tracking thread may run beside another thread's bundle adjustment - orbhip_set_thread_priority)
+    int lo = 0, hi = 0;
+    hipError_t e = (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi)
+                                                                                       : hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e != hipSuccess) c->side = nullptr;
+  }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     if (c->side) (void)hipStreamDestroy(c->side);
     c->side = nullptr;
   }
-  if (const char* e = std::getenv("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = atoi(e);
-  if (const char* e = std::getenv("ORBHIP_DESC_XCD")) c->desc_xcd = atoi(e);
-  if (const char* e = std::getenv("ORBHIP_FAST_XCD")) c->fast_xcd = atoi(e);
+  if (const char* e = ORBHIP_EXP_ENV("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = atoi(e);
+  if (const char* e = ORBHIP_EXP_ENV("ORBHIP_DESC_XCD")) c->desc_xcd = atoi(e);
+  if (const char* e = ORBHIP_EXP_ENV("ORBHIP_FAST_XCD")) c->fast_xcd = atoi(e);
   *out = c;
   return 0;
 }

@@ -838,7 +838,7 @@ int orbm_match_frames_batch_device(const orbx_keypoint* d_kps, const uint8_t* d_
   // workgroups per pair: one workgroup saturates a CU's issue slots (two per CU gain nothing: 256 pairs take 0.64 ms as 256
   // workgroups, 0.67 ms as 512), so a launch is split until it has about one workgroup per CU - 64 pairs: 0.63 ms unsplit,
   // 0.38 / 0.28 / 0.35 ms with 2 / 4 / 8 workgroups per pair.  ORBHIP_MATCH_SPLIT forces a value.
-  static const int force_split = []() { const char* e = std::getenv("ORBHIP_MATCH_SPLIT"); return e ? atoi(e) : 0; }();
+  static const int force_split = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_MATCH_SPLIT"); return e ? atoi(e) : 0; }();
   const int nsplit = mfma ? std::min((cap + MM_THREADS - 1) / MM_THREADS, force_split > 0 ? force_split : std::max(1, 320 / npairs)) : force_split > 0 ? force_split : std::min(8, std::max(1, 256 / npairs));
   int* scratch = nullptr;
   if (nsplit > 1) {

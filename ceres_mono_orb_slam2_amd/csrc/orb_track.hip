@@ -936,7 +936,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     const int ecap = (int)std::min<size_t>((size_t)std::max(nq, 1) * TRK_LMAX, (size_t)(100 * 1024 - lds_fixed) / 6);
     const int tcap = ecap;
     const size_t lds_greedy = lds_fixed + (size_t)ecap * 6 + 16;
-    static const int force_rounds = []() { const char* e = std::getenv("ORBHIP_TRACK_ROUNDS"); return (e && e[0] == '1') ? 1 : 0; }();
+    static const int force_rounds = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_TRACK_ROUNDS"); return (e && e[0] == '1') ? 1 : 0; }();
     if ((rc = raise_dynamic_lds((const void*)k_trk_greedy, W.device, 100 * 1024 + 64))) return rc;
     hipLaunchKernelGGL(k_trk_greedy, dim3(1), dim3(TRK_GT), lds_greedy, W.s, dI, d_qv, in.dev<float>(pA), d_acc, d_accn, in.dev<double>(pX), d_off, d_total, d_pairs, cand_cap, d_kps4, d_count, icap,
                        (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow, d_ooff, (double*)(dblk + oPose), d_K4,

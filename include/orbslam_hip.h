@@ -46,6 +46,11 @@ const char* orbhip_version(void);
 /* HIP device used by the entry points that take no handle (matcher host-pointer calls, all ba_* calls);
  * default 0.  hipSetDevice is per host thread, so every such call re-selects this device itself. */
 int orbhip_set_default_device(int device);
+/* The reference runs Tracking, LocalMapping and the loop closer's GlobalBundleAdjustemnt on three threads that here share ONE GPU
+ * (src/LocalMapping.cc:89, src/LoopClosing.cc:590,656).  Every host thread has its own HIP stream; a thread that calls this with
+ * high != 0 - the Tracking thread - gets the device's greatest stream priority for the calls it makes from then on (its short
+ * per-frame kernels are dispatched ahead of another thread's queued bundle-adjustment work).  Results do not depend on it.   */
+int orbhip_set_thread_priority(int high);
 int orbhip_get_default_device(void);
 
 /* ---------------------------------------------------------------- extractor --

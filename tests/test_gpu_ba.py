@@ -355,13 +355,13 @@ def test_persistent_cholesky_is_bit_identical():
     per 32-column step.  Its arithmetic is the step kernels' operation for operation, so poses, points, summaries and erase
     flags must be BIT-IDENTICAL between ORBHIP_BA_PERSIST=1 and =0 (read once per process: two subprocesses) - sizes from 1 to
     32 block rows (42 .. 1020 unknowns), incl. one that is exactly the 1024 limit, and a two-pass LocalBA.  Larger systems
-    (two-level scheme): one persistent launch per 128-column outer block (k_chol_persist_blk, =1, the default) and the
-    one-launch kernel (k_chol_persist_2l, =2, opt-in) against the step kernels.  Six threads solving at once: a solve that does
+    (two-level scheme): one persistent launch per 128-column outer block (k_chol_persist_blk, =1, the default) against the step
+    kernels (the one-launch kernel k_chol_persist_2l is an ORBHIP_EXPERIMENTS build's =2: tools/gba_persist_ab.py).  Six threads solving at once: a solve that does
     not get its workgroup slots takes the step kernels - same bits, no stall."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for flag in ("1", "0", "2"):
+    for flag in ("1", "0"):
         r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root], env=dict(os.environ, ORBHIP_BA_PERSIST=flag), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))

@@ -1,0 +1,103 @@
+"""The reference's threading on ONE GPU (VERDICT r3 next #3a): Tracking runs per frame on its thread while LocalMapping runs
+CeresOptimizer::LocalBundleAdjustment on another (src/LocalMapping.cc:89) and the loop closer's GlobalBundleAdjustemnt on a detached
+third (src/LoopClosing.cc:590,656).  Here: three host threads share the device - the device-resident Tracking step (motion model +
+local map) frame after frame on a high-priority stream, single LocalBA solves (C4 size: the persistent, flag-linked Cholesky) in
+a loop, one GlobalBA at C5 size (persistent block launches).  Every result must be BIT-IDENTICAL to the same call made alone, no
+call may time out, and the Tracking latency under that load is reported (p50 / p99) next to the solo latency."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from ceres_mono_orb_slam2_amd import synth
+from tests.test_gpu_track import _scenario, K4, BOUNDS, F32
+from tests.test_gpu_track_local_map import _local_map
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(*arrs):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def test_tracking_localba_globalba_share_one_gpu(oracle):
+    from ceres_mono_orb_slam2_amd import ORBextractor, tracking, optimizer, _lib
+    L = _lib.load()
+    S = _scenario(oracle, 21)
+    ex = ORBextractor(2000, 1.2, 8, 20, 7)
+    a1 = (ex, S["img"], K4, BOUNDS, S["T"], S["X"], S["desc"], S["octave"], S["angle"], S["valid"], 15.0, True)
+    g1 = tracking.track_with_motion_model(*a1)
+    T1 = oracle.pose7_to_matrix4d(g1["pose7"])
+    M = _local_map(oracle, S, g1, 21)
+    a2 = (ex, K4, BOUNDS, T1, F32(np.log(F32(1.2))), M["X"], M["Pn"], M["mind"], M["maxd"], M["D"], M["state"], M["slot_X"], M["slot_state"], 1.0, 0.8)
+
+    def track_once():
+        r1 = tracking.track_with_motion_model(*a1)
+        r2 = tracking.track_local_map(*a2)
+        return _digest(r1["kps"], r1["desc"], r1["match"], r1["owner"], r1["outlier"], r1["pose7"], r2["in_view"], r2["match"], r2["owner"], r2["outlier"], r2["pose7"])
+
+    gl = synth.make_ba_graph(3, ncam=100, npts=10000, nobs=50000, n_fixed=1)
+    la = (gl["K4"], gl["poses0"], gl["cam_fixed"], np.ones(100, np.uint8), gl["pts0"], gl["obs_cam"], gl["obs_pt"], gl["obs_uv"], gl["obs_inv_sigma2"])
+
+    def lba_once():
+        ab, poses, pts, er, s1, s2 = optimizer.local_bundle_adjustment(*la)
+        return _digest(poses, pts, er) + str((s1["iterations"], s1["termination"], s2["iterations"], s2["termination"], s2["final_cost"]))
+
+    gg = synth.make_ba_graph(21, ncam=500, npts=50000, nobs=250000, n_fixed=2)
+    ga = (gg["K4"], gg["poses0"], gg["cam_fixed"], gg["pts0"], gg["obs_cam"], gg["obs_pt"], gg["obs_uv"], gg["obs_inv_sigma2"])
+
+    def gba_once():
+        poses, pts, s = optimizer.global_bundle_adjustment(*ga, n_iterations=6)
+        return _digest(poses, pts) + str((s["iterations"], s["termination"], s["final_cost"]))
+
+    # solo references (and solo Tracking latency)
+    ref_t, ref_l, ref_g = track_once(), lba_once(), gba_once()
+    solo = []
+    for _ in range(100):
+        t0 = time.perf_counter(); d = track_once(); solo.append(time.perf_counter() - t0)
+        assert d == ref_t, "solo Tracking step %d differs from the first one" % len(solo)
+    # the three threads
+    out = {"t": [], "l": [], "g": [], "lat": [], "err": []}
+    stop = threading.Event()
+
+    def tracker():
+        try:
+            _lib.check(L.orbhip_set_thread_priority(1), "orbhip_set_thread_priority")
+            track_once()                                     # (this thread's own workspace and resident frame)
+            while not stop.is_set():
+                t0 = time.perf_counter(); d = track_once(); out["lat"].append(time.perf_counter() - t0); out["t"].append(d)
+        except Exception as e:
+            out["err"].append(repr(e))
+
+    def local_mapper():
+        try:
+            while not stop.is_set():
+                out["l"].append(lba_once())
+        except Exception as e:
+            out["err"].append(repr(e))
+
+    def loop_closer():
+        try:
+            for _ in range(3):
+                out["g"].append(gba_once())
+        except Exception as e:
+            out["err"].append(repr(e))
+        finally:
+            stop.set()
+
+    th = [threading.Thread(target=f) for f in (tracker, local_mapper, loop_closer)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not out["err"], out["err"]
+    assert len(out["t"]) >= 5 and len(out["l"]) >= 1 and len(out["g"]) == 3, (len(out["t"]), len(out["l"]), len(out["g"]))
+    assert all(d == ref_t for d in out["t"]), "%d of %d Tracking steps differ from the solo run" % (sum(d != ref_t for d in out["t"]), len(out["t"]))
+    assert all(d == ref_l for d in out["l"]), "%d of %d LocalBA solves differ from the solo run" % (sum(d != ref_l for d in out["l"]), len(out["l"]))
+    assert all(d == ref_g for d in out["g"]), "%d of %d GlobalBA solves differ from the solo run" % (sum(d != ref_g for d in out["g"]), len(out["g"]))
+    q = lambda v, p: float(np.percentile(np.array(v) * 1e3, p))
+    print("Tracking (motion model + local map) alone: p50 %.3f ms, p99 %.3f ms; beside LocalBA + GlobalBA on the same GPU: p50 %.3f ms, p99 %.3f ms over %d frames "
+          "(%d LocalBA, %d GlobalBA solves meanwhile, all bit-identical to their solo runs)" % (q(solo, 50), q(solo, 99), q(out["lat"], 50), q(out["lat"], 99), len(out["lat"]),
+                                                                                             len(out["l"]), len(out["g"])))

@@ -2,6 +2,8 @@
 -DORBHIP_CHOL_PROF into a scratch library; the kernel's roles stamp s_memrealtime (100 MHz) at fixed points of the LAST
 factorisation run; prints per step: chain step length, factor, how late the staging waves' waits were satisfied, when the latest row
 published L(.,j) / finished step j, and per outer block when the workers finished its far tiles."""
+import os as _os
+_os.environ.setdefault("ORBHIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "exp_lib", "liborbslam_hip.so"))   # ORBHIP_BA_PERSIST=2 exists in experiments builds only (bash tools/build_experiments.sh)
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,7 @@
 """GlobalBA on the two-level Cholesky: the one-launch persistent kernel (default, ORBHIP_BA_PERSIST=2), persistent block launches
 (=1) and one launch per 32-column step (=0): results must be bit-identical; prints the time per call of each.  usage: gba_persist_ab.py [ncam npts nobs iters]"""
+import os as _os
+_os.environ.setdefault("ORBHIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "exp_lib", "liborbslam_hip.so"))   # ORBHIP_BA_PERSIST=2 exists in experiments builds only (bash tools/build_experiments.sh)
 import hashlib, os, subprocess, sys
 
 _CHILD = r'''

@@ -5,6 +5,9 @@
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+# (ORBHIP_OVERLAP_BLUR is an experiments-build knob: the product library always overlaps the blur)
+[ -f tools/exp_lib/liborbslam_hip.so ] || bash tools/build_experiments.sh > /dev/null
+export ORBHIP_LIB=$PWD/tools/exp_lib/liborbslam_hip.so
 export ORBHIP_OVERLAP_BLUR=0      # per-kernel counters and cycles: every kernel alone on its stream
 B=${PMC_BATCH:-256}
 run() {  # tag counters...
