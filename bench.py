@@ -373,7 +373,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if shared else "nccl"
         if shared:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # (gloo's C++ side prints "[Gloo] Rank r is connected to ..." on STDOUT: rank 0's stdout must carry the JSON line only)
+            sys.stdout.flush(); saved = os.dup(1); os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()
+            finally:
+                sys.stdout.flush(); os.dup2(saved, 1); os.close(saved)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("ORBHIP_LIB") or os.path.join(_HERE, "lib", "liborbsla
 # every symbol include/orbslam_hip.h declares (tests check that the library exports them all)
 SYMBOLS = [
     "orbhip_last_error", "orbhip_device_count", "orbhip_version", "orbhip_set_default_device", "orbhip_get_default_device", "orbhip_set_thread_priority",
-    "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_tables", "orbx_max_keypoints", "orbx_extract",
+    "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_set_opencv_variant", "orbx_get_tables", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_set_profiling", "orbx_get_stage_ms", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",
     "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_sim3", "orbm_search_by_bow", "orbm_search_for_triangulation",
@@ -117,6 +117,7 @@ def load():
     L.orbm_triangulate_matches.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, vp]
     L.orbm_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, vp, vp, vp]
     L.orbt_track_with_motion_model.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32, vp, vp, vp, vp]
+    L.orbx_set_opencv_variant.argtypes = [vp, i32]
     L.orbt_track_local_map.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp]
     L.orbm_is_in_frustum_gates.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp]
     L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, vp, C.POINTER(i32), C.POINTER(BaSummary)]

@@ -1022,6 +1022,10 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // 128 x 32 output tile per workgroup.  Row pass straight from global memory (each thread: 4 outputs
 // from 10 source bytes = 3 aligned dwords when the row pitch allows) into a u16 LDS plane
 // (255*257 fits 16 bits); column pass reads 7 x ds_read_b64 per 4 outputs and stores one dword.
+// VAR: which OpenCV fixed-point Gaussian the taps restate (orbx_set_opencv_variant): 0 = cvRound(g * 256) = {18,34,49,55,49,34,18}
+// (sum 257: OpenCV <= 3.4.1, i.e. the 2.4.11 / 3.2 the reference names), 1 = the error-diffused 8.8 taps {18,34,48,56,48,34,18} (sum 256)
+// of the "bit-exact" ufixedpoint16 path of later versions.  Same two passes, same final (sum + 2^15) >> 16.
+template <int VAR>
 __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __restrict__ tiles,
                                                const uint8_t* __restrict__ img0, long long img_frame_bytes,
                                                const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
@@ -1060,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
       unsigned short o[4];
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        o[j] = (unsigned short)(18 * (b[j] + b[j + 6]) + 34 * (b[j + 1] + b[j + 5]) + 49 * (b[j + 2] + b[j + 4]) + 55 * b[j + 3]);
+        o[j] = (unsigned short)(18 * (b[j] + b[j + 6]) + 34 * (b[j + 1] + b[j + 5]) + (VAR ? 48 : 49) * (b[j + 2] + b[j + 4]) + (VAR ? 56 : 55) * b[j + 3]);
       *(uint2*)&s_mid[yy][4 * cg] = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
     }
   }
@@ -1074,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
       const int y = y0 + yy;
       if (y >= L.h) break;
       int acc[4] = {0, 0, 0, 0};
-      const int taps[7] = {18, 34, 49, 55, 49, 34, 18};
+      const int taps[7] = {18, 34, VAR ? 48 : 49, VAR ? 56 : 55, VAR ? 48 : 49, 34, 18};
 #pragma unroll
       for (int k = 0; k < 7; k++) {
         const uint2 m = *(const uint2*)&s_mid[yy + k][4 * cg];
@@ -1372,6 +1376,7 @@ struct orbx_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int lone_side_mode = 0;      // side-stream mode of a LONE frame for the next run_batch call (set by orbx_extract_chained, reset by run_batch)
+  int blur_variant = 0;        // orbx_set_opencv_variant: which OpenCV GaussianBlur the taps restate (k_blur7)
   int overlap_blur = -1;       // -1: by batch size (see run_batch); 0: one stream; 1: k_blur7 on the side stream beside FAST + octree; 2: beside the octree only
 };
 
@@ -1638,6 +1643,8 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
 static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int stride, size_t frame_stride,
                      int nframes, orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts,
                      hipStream_t st) {
+  void (*blur_k)(GeomDev, const BlurTile*, const uint8_t*, long long, const uint8_t*, uint8_t*) = (c && c->blur_variant) ? k_blur7<1> : k_blur7<0>;
+
   ORBHIP_CHECK_HIP(hipSetDevice(c->device));
   if (int rc = prepare(c, w, h, stride, nframes)) return rc;
   const GeomDev& G = c->G;
@@ -1687,7 +1694,7 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
     if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, c->side); }
-    hipLaunchKernelGGL(k_blur7, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, c->side, G,
+    hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, c->side, G,
                        c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
     if (c->profiling) { (void)hipEventRecord(se, c->side); c->side_events.push_back(sb); c->side_events.push_back(se); }
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, c->side));
@@ -1736,13 +1743,13 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
     if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, c->side); }
-    hipLaunchKernelGGL(k_blur7, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, c->side, G,
+    hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, c->side, G,
                        c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
     if (c->profiling) { (void)hipEventRecord(se, c->side); c->side_events.push_back(sb); c->side_events.push_back(se); }
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, c->side));
   }
   mark();
-  if (side_mode == 0) hipLaunchKernelGGL(k_blur7, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, st, G,
+  if (side_mode == 0) hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, st, G,
                                          c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
   else ORBHIP_CHECK_HIP(hipStreamWaitEvent(st, c->ev_join, 0));       // join: describe needs the blurred levels
   mark();
@@ -1861,6 +1868,11 @@ int orbx_get_stage_ms(orbx_ctx* c, float* ms, int* ncalls) {
 }
 
 int orbx_get_levels(const orbx_ctx* c) { return c ? c->nlevels : ORBHIP_EINVAL; }
+int orbx_set_opencv_variant(orbx_ctx* c, int blur_variant) {
+  ORBHIP_REQUIRE(c && (blur_variant == ORBX_CV_BLUR_8BIT || blur_variant == ORBX_CV_BLUR_FIXED16), ORBHIP_EINVAL, "unknown OpenCV variant");
+  c->blur_variant = blur_variant;
+  return 0;
+}
 
 int orbx_get_tables(const orbx_ctx* c, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
                     int32_t* fpl) {

@@ -104,6 +104,10 @@ class ORBextractor:
     def set_profiling(self, enable=True):
         _lib.check(self._L.orbx_set_profiling(self._h, int(enable)))
 
+    def set_opencv_variant(self, blur_variant):
+        """0: OpenCV <= 3.4.1 GaussianBlur (8-bit taps, default), 1: the ufixedpoint16 path of later versions (orbx_set_opencv_variant)"""
+        _lib.check(self._L.orbx_set_opencv_variant(self._h, int(blur_variant)), "orbx_set_opencv_variant")
+
     def stage_ms(self):
         ms = np.zeros(5, np.float32); n = C.c_int()
         _lib.check(self._L.orbx_get_stage_ms(self._h, _lib.ptr(ms), C.byref(n)))

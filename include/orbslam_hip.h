@@ -113,6 +113,19 @@ int orbx_get_level_selected(orbx_ctx* ctx, int frame, int level, int32_t* out, i
  * its stream around its five stages {pyramid, FAST cells, octree, blur, orientation+BRIEF};
  * orbx_get_stage_ms synchronises on the last event, returns the per-stage sums (ms) over the calls
  * made since enabling and the number of calls, then resets.                           */
+/* Which OpenCV the pixel arithmetic restates.  The reference's front-end arithmetic lives in OpenCV (cv::resize, cv::GaussianBlur,
+ * cv::FAST), whose fixed-point rounding differs between versions; the library's default is what OpenCV 2.4.x / 3.0 - 3.4.1 compute
+ * (the reference's README names 2.4.11 and 3.2).  An integrator whose OpenCV is newer selects its GaussianBlur here - tools/pin
+ * (pin_extractor) tells which one the installed OpenCV implements:
+ *   ORBX_CV_BLUR_8BIT    7x7 sigma-2 taps cvRound(g * 256) = {18,34,49,55,49,34,18} (sum 257), two passes, (sum + 2^15) >> 16
+ *   ORBX_CV_BLUR_FIXED16 the "bit-exact" ufixedpoint16 path (OpenCV >= 3.4.2 / 4.x): 8.8 fixed-point taps, error-diffused so that they
+ *                        sum to 256: {18,34,48,56,48,34,18}; same two passes and final rounding.  Restated from the published
+ *                        algorithm, NOT verified against a build of that OpenCV here: run tools/pin before relying on it.
+ * Applies to the calls made after it; the oracle has the same switch (orc_set_blur_variant).                                 */
+#define ORBX_CV_BLUR_8BIT 0
+#define ORBX_CV_BLUR_FIXED16 1
+int orbx_set_opencv_variant(orbx_ctx* ctx, int blur_variant);
+
 #define ORBX_NSTAGES 5
 int orbx_set_profiling(orbx_ctx* ctx, int enable);
 int orbx_get_stage_ms(orbx_ctx* ctx, float* ms /*[ORBX_NSTAGES]*/, int* ncalls);

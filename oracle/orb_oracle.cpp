@@ -492,7 +492,11 @@ inline int reflect101(int i, int n) {
   while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
   return i;
 }
+// which OpenCV GaussianBlur is restated: 0 = the 8-bit taps of OpenCV <= 3.4.1 (below), 1 = the 8.8 fixed-point taps of the
+// "bit-exact" ufixedpoint16 path of later versions, error-diffused to sum 256 (include/orbslam_hip.h: orbx_set_opencv_variant)
+static int g_blur_variant = 0;
 void gauss7_taps(int taps[7]) {
+  if (g_blur_variant == 1) { const int t[7] = {18, 34, 48, 56, 48, 34, 18}; for (int i = 0; i < 7; i++) taps[i] = t[i]; return; }
   // getGaussianKernel(7, 2, CV_32F): float taps normalised by the float sum; then
   // convertTo(CV_32S, 256) = cvRound(tap*256)  ->  {18,34,49,55,49,34,18}
   float cf[7]; double sum = 0;
@@ -583,6 +587,7 @@ int extract(Extractor& E, const uint8_t* img, int w, int h, int stride, KeyPoint
 
 // ============================ C entry points ================================
 extern "C" {
+int orc_set_blur_variant(int v) { if (v != 0 && v != 1) return -1; g_blur_variant = v; return 0; }
 
 void* orc_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) {
   return new Extractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);

@@ -288,6 +288,12 @@ def descriptor_distance(a, b):
     return lib().orc_descriptor_distance(_p(a), _p(b))
 
 
+def set_blur_variant(v):
+    """0: OpenCV <= 3.4.1 GaussianBlur taps (default), 1: the ufixedpoint16 taps of later versions (process-wide)"""
+    r = lib().orc_set_blur_variant(int(v))
+    assert r == 0
+
+
 def hamming_best2(q, t, cand_offsets=None, cand_idx=None):
     q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
     nq, nt = len(q), len(t)
