@@ -11,12 +11,19 @@ for spec in sys.argv[1:]:
     n_each = max(2, 48 // (B * T))
     bar = threading.Barrier(T + 1)
     def work():
-        for _ in range(2): optimizer.local_bundle_adjustment_batch(probs)
+        try:
+            for _ in range(2): optimizer.local_bundle_adjustment_batch(probs)
+        except BaseException:
+            bar.abort()                      # (a worker that dies must not leave the others waiting at the barrier for ever)
+            raise
         bar.wait()
         for _ in range(n_each): optimizer.local_bundle_adjustment_batch(probs)
     ths = [threading.Thread(target=work) for _ in range(T)]
     for t in ths: t.start()
-    bar.wait()
+    try:
+        bar.wait(timeout=600)
+    except threading.BrokenBarrierError:
+        sys.exit("a worker thread failed")
     t0 = time.perf_counter()
     for t in ths: t.join()
     dt = time.perf_counter() - t0

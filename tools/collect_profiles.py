@@ -7,7 +7,7 @@ SKIPPED - the tracked file of an earlier, good run is never overwritten by a mis
 headline kernel stats exactly that way).  Files are written to a temporary name and renamed.  Exit code 1 if anything was skipped."""
 import csv, json, os, sqlite3, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G = os.path.join(ROOT, "gpurun_out"); O = os.path.join(G, RND); P = os.path.join(ROOT, "profiles")
 skipped = []
 
@@ -63,7 +63,7 @@ print("collecting %s -> profiles/" % O)
 take_json("bench.json", RND + "_bench.json", ("value", "roofline"))
 take_kernel_csv("bench_kernel_stats.csv", RND + "_bench_kernel_stats.csv", ("k_fast_cells", "k_match_pairs", "k_blur7", "k_resize", "k_describe", "k_octree"))      # (substring match: k_match_pairs_mfma too)
 take_json("bench_traced.json", RND + "_bench_traced.json", ("value", "kernels"))
-take_kernel_csv("localba_batch16_kernel_stats.csv", RND + "_localba_batch16_kernel_stats.csv", ("k_ba_schur",))
+take_kernel_csv("localba_batch64_kernel_stats.csv", RND + "_localba_batch64_kernel_stats.csv", ("k_ba_schur", "k_chol_wg"))
 take_kernel_csv("gba_c5_kernel_stats.csv", RND + "_gba_c5_kernel_stats.csv", ("k_chol",))
 take_json("bench_2rank_shared.json", RND + "_bench_2rank_shared_gpu.json", ("value", "collective"))
 take_json("bench_rccl_ws1.json", RND + "_bench_rccl_ws1.json", ("collective",))
@@ -74,6 +74,21 @@ try:
     put(RND + "_api_latency.json", json.dumps(api, indent=1) + "\n")
 except Exception as e:
     skipped.append("api_latency: %s" % e)
+for src, dst, why in (("mfma_batch.json", "_mfma_localba_batch64.json", "FP64-MFMA counters (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) of 64 C4-size LocalBA problems per lockstep batch: k_chol_wg, one workgroup per problem (tools/run_mfma_pmc.sh; experiments build, ORBHIP_BA_GRAPH=0)"),
+                      ("mfma_single.json", "_mfma_localba_single.json", "the same counters over single C4-size LocalBA solves: the persistent, flag-linked k_chol_persist"),
+                      ("mfma_c5.json", "_mfma_gba_c5.json", "the same counters over one GlobalBA at C5 size (500 keyframes, 2994-unknown reduced system), 10 iterations: k_chol_persist_blk")):
+    path = os.path.join(O, src)
+    try:
+        j = json.load(open(path)); j = dict(workload=why, **j)
+        put(RND + dst, json.dumps(j, indent=1) + "\n")
+    except Exception as e:
+        skipped.append("%s: %s" % (src, e))
+for txt in ("localba_throughput.txt", "track_latency.txt", "concurrency.txt", "mfma_f64_ubench.txt"):
+    path = os.path.join(O, txt)
+    if os.path.exists(path) and os.path.getsize(path) > 0:
+        put(RND + "_" + txt, open(path).read())
+    else:
+        skipped.append(txt + ": missing or empty")
 for extra in ("fast_phase_prof.json", "chol_phase_prof.json", "octree_phase_prof.json", "gba_c5_mfma.json", "pcie_pipeline.json", "tracking_step.json"):
     path = os.path.join(O, extra)
     if os.path.exists(path):

@@ -9,11 +9,12 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O
-[ -f tools/exp_lib/liborbslam_hip.so ] || bash tools/build_experiments.sh > /dev/null
+# (the experiments build must be as new as the sources: a stale one lacks symbols the Python mirror binds)
+if [ ! -f tools/exp_lib/liborbslam_hip.so ] || [ -n "$(find ceres_mono_orb_slam2_amd/csrc include -newer tools/exp_lib/liborbslam_hip.so -type f | head -1)" ]; then bash tools/build_experiments.sh > /dev/null || exit 1; fi
 export ORBHIP_LIB=$PWD/tools/exp_lib/liborbslam_hip.so ORBHIP_BA_GRAPH=0
 run() { tag=$1; shift
   rm -rf $O/mfma_$tag
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format rocpd -d $O/mfma_$tag -o run -- "$@" > $O/mfma_$tag.log 2>&1 || tail -5 $O/mfma_$tag.log
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format rocpd -d $O/mfma_$tag -o run -- timeout 300 "$@" > $O/mfma_$tag.log 2>&1 || tail -5 $O/mfma_$tag.log
   db=$(find $O/mfma_$tag -name "*.db" | head -1)
   [ -n "$db" ] && python tools/mfma_c5.py $db $O/mfma_$tag.json | grep -A7 "k_chol_wg\|k_chol_persist\"\|k_chol_persist_blk\|factorisation_and" | head -40
   rm -rf $O/mfma_$tag

@@ -6,7 +6,8 @@ set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 # (ORBHIP_OVERLAP_BLUR is an experiments-build knob: the product library always overlaps the blur)
-[ -f tools/exp_lib/liborbslam_hip.so ] || bash tools/build_experiments.sh > /dev/null
+# (the experiments build must be as new as the sources: a stale one lacks symbols the Python mirror binds)
+if [ ! -f tools/exp_lib/liborbslam_hip.so ] || [ -n "$(find ceres_mono_orb_slam2_amd/csrc include -newer tools/exp_lib/liborbslam_hip.so -type f | head -1)" ]; then bash tools/build_experiments.sh > /dev/null || exit 1; fi
 export ORBHIP_LIB=$PWD/tools/exp_lib/liborbslam_hip.so
 export ORBHIP_OVERLAP_BLUR=0      # per-kernel counters and cycles: every kernel alone on its stream
 B=${PMC_BATCH:-256}

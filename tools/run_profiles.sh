@@ -3,36 +3,45 @@
 # configuration, no BA / CPU / pipelined legs in the traced process: the batched LocalBA leg crashed rocprofv3 in round 2), of
 # the LocalBA batch and of GlobalBA at C5 size, API latencies, the RCCL world-size-1 run, the 2-rank shared-GPU dry run, the PMC
 # passes.  Everything lands under gpurun_out/<round>/ ; tools/collect_profiles.py <round> copies what is judged into profiles/.
-# usage: bash tools/run_profiles.sh r03 [quick]
+# usage: bash tools/run_profiles.sh r04 [quick]   (every leg is wrapped in `timeout`: a hung leg costs its limit, not the GPU budget)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/$R; mkdir -p $O
 step() { echo "== $*"; }
-step bench;      python bench.py > $O/bench.json 2> $O/bench.err || tail -5 $O/bench.err
+step bench;      timeout 900 python bench.py > $O/bench.json 2> $O/bench.err || tail -5 $O/bench.err
 step bench trace
 rm -rf $O/benchprof
-rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/benchprof -o run -- python bench.py --no-cpu --no-ba --no-pipelined --steps 3 --warmup 1 > $O/bench_traced.json 2> $O/benchprof.log || tail -5 $O/benchprof.log
+rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/benchprof -o run -- timeout 600 python bench.py --no-cpu --no-ba --no-pcie --streams 1 --no-pipelined --steps 3 --warmup 1 > $O/bench_traced.json 2> $O/benchprof.log || tail -5 $O/benchprof.log
 db=$(find $O/benchprof -name "*.db" 2>/dev/null | head -1)
 if [ -n "$db" ]; then python tools/rocpd_stats.py $db $O/bench_kernel_stats.csv && python tools/kstats_print.py $O/bench_kernel_stats.csv | head -14; else echo "no trace database"; fi
 [ "$2" = quick ] && exit 0
 step localba trace
 rm -rf $O/lbaprof
-rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/lbaprof -o run -- python tools/ba_batch_thr.py 16:1 > $O/lbaprof.log 2>&1 || tail -5 $O/lbaprof.log
+rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/lbaprof -o run -- timeout 600 python tools/ba_batch_thr.py 64:1 > $O/lbaprof.log 2>&1 || tail -5 $O/lbaprof.log
 db=$(find $O/lbaprof -name "*.db" 2>/dev/null | head -1)
-[ -n "$db" ] && python tools/rocpd_stats.py $db $O/localba_batch16_kernel_stats.csv && python tools/kstats_print.py $O/localba_batch16_kernel_stats.csv | head -12
+[ -n "$db" ] && python tools/rocpd_stats.py $db $O/localba_batch64_kernel_stats.csv && python tools/kstats_print.py $O/localba_batch64_kernel_stats.csv | head -14
+timeout 600 python tools/ba_batch_thr.py 64:8 16:8 > $O/localba_throughput.txt 2>&1; cat $O/localba_throughput.txt
 step gba c5 trace
 rm -rf $O/gbaprof
-rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/gbaprof -o run -- python tools/gba_c5_check.py 10 > $O/gbaprof.log 2>&1 || tail -5 $O/gbaprof.log
+rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/gbaprof -o run -- timeout 600 python tools/gba_c5_check.py 10 > $O/gbaprof.log 2>&1 || tail -5 $O/gbaprof.log
 db=$(find $O/gbaprof -name "*.db" 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocpd_stats.py $db $O/gba_c5_kernel_stats.csv && python tools/kstats_print.py $O/gba_c5_kernel_stats.csv | head -12
 step api latency
 g++ -O2 -std=c++17 -I include tools/cpp/api_latency.cpp -o /tmp/api_latency -L ceres_mono_orb_slam2_amd/lib -lorbslam_hip && \
 LD_LIBRARY_PATH=ceres_mono_orb_slam2_amd/lib:/opt/rocm/lib /tmp/api_latency > $O/api_latency_cpp.json; cat $O/api_latency_cpp.json
-python tools/api_latency.py 2>/dev/null | tail -1 > $O/api_latency_py.json; cat $O/api_latency_py.json
+timeout 300 python tools/api_latency.py 2>/dev/null | tail -1 > $O/api_latency_py.json; cat $O/api_latency_py.json
+step tracking latency
+ORBHIP_TRACK_TIMING=1 timeout 300 python tools/track_latency.py 400 > $O/track_latency.txt 2>&1; tail -4 $O/track_latency.txt
+step concurrency
+timeout 600 python -m pytest tests/test_gpu_concurrency.py -q -s 2>&1 | grep -E "Tracking|passed|failed" > $O/concurrency.txt; cat $O/concurrency.txt
+step mfma ubench
+[ -x tools/ubench/bin/mfma_f64 ] && timeout 120 tools/ubench/bin/mfma_f64 > $O/mfma_f64_ubench.txt 2>&1; tail -4 $O/mfma_f64_ubench.txt
 step rccl world size 1
-ORBHIP_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --no-pipelined > $O/bench_rccl_ws1.json 2> $O/bench_rccl_ws1.err || tail -5 $O/bench_rccl_ws1.err
+ORBHIP_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --no-pipelined > $O/bench_rccl_ws1.json 2> $O/bench_rccl_ws1.err || tail -5 $O/bench_rccl_ws1.err
 step 2 ranks shared gpu
-ORBHIP_BENCH_SHARED_GPU=1 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu > $O/bench_2rank_shared.json 2> $O/bench_2rank.err || tail -5 $O/bench_2rank.err
+ORBHIP_BENCH_SHARED_GPU=1 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu > $O/bench_2rank_shared.json 2> $O/bench_2rank.err || tail -5 $O/bench_2rank.err
 step pmc
-bash tools/run_pmc.sh > $O/pmc.log 2>&1 || tail -5 $O/pmc.log
+timeout 1200 bash tools/run_pmc.sh > $O/pmc.log 2>&1 || tail -5 $O/pmc.log
+step mfma pmc
+timeout 1100 bash tools/run_mfma_pmc.sh $R > $O/mfma_pmc.log 2>&1 || tail -5 $O/mfma_pmc.log
