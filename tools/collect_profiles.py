@@ -8,7 +8,8 @@ headline kernel stats exactly that way).  Files are written to a temporary name 
 import csv, json, os, sqlite3, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
-G = os.path.join(ROOT, "gpurun_out"); O = os.path.join(G, RND); P = os.path.join(ROOT, "profiles")
+G = os.path.join(ROOT, "gpurun_out"); O = os.path.join(G, RND); P = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")      # (PROFILES_OUT: collect on the GPU box into gpurun_out/, the raw databases exceed what travels back)
+os.makedirs(P, exist_ok=True)
 skipped = []
 
 

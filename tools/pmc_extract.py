@@ -74,7 +74,7 @@ for k in NAMES:
     mult = 7 if k == "k_resize" else 1                      # 7 pyramid launches per batch
     f, w = fe[k]["FETCH_SIZE"] * mult, wr[k]["WRITE_SIZE"] * mult
     tr["kernels"][k] = {"FETCH_SIZE_KB_per_batch": f, "WRITE_SIZE_KB_per_batch": w, "hbm_bytes_per_frame": (f + w) * 1024.0 / B}
-P = os.path.join(ROOT, "profiles")
+P = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")
 for name, obj in ((RND + "_pmc_valu.json", valu), (RND + "_pmc_traffic.json", tr)):
     tmp = os.path.join(P, name + ".tmp")
     json.dump(obj, open(tmp, "w"), indent=1)

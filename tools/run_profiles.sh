@@ -45,3 +45,8 @@ step pmc
 timeout 1200 bash tools/run_pmc.sh > $O/pmc.log 2>&1 || tail -5 $O/pmc.log
 step mfma pmc
 timeout 1100 bash tools/run_mfma_pmc.sh $R > $O/mfma_pmc.log 2>&1 || tail -5 $O/mfma_pmc.log
+step collect
+# the raw rocpd databases (PMC passes ~50 MB, traces) exceed what gpurun copies back: collect on the box, keep the summaries only
+PROFILES_OUT=$PWD/$O/collected python tools/collect_profiles.py $R | tail -30
+rm -rf gpurun_out/pmc_x_insts gpurun_out/pmc_x_active gpurun_out/pmc_x_fetch gpurun_out/pmc_x_write $O/benchprof $O/lbaprof $O/gbaprof
+du -sh gpurun_out
