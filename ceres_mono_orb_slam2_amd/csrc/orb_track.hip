@@ -825,9 +825,154 @@ __global__ __launch_bounds__(1024) void k_tlm_greedy(const TlmIn* __restrict__ i
   if (tid == 0) { out->n_keypoints = n_dev; out->nmatches = overflow ? -1 : s_nm; out->rounds = rounds; out->cand_total = (int32_t)off_total; }
 }
 
+// ======================================================================================================================
+// Tracking::TrackReferenceKeyFrame's data-parallel core (src/Tracking.cc:566-615): Frame::ComputeBoW (the vocabulary descent,
+// orb_vocab.hip) + ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:151-256) + CeresOptimizer::PoseOptimization.
+// SearchByBoW is sequential only INSIDE a vocabulary node: the keyframe's features of a node, in list order, each take the closest
+// still unmatched frame feature of the same node (best < ratio * second, best <= TH_LOW).  A feature belongs to one node, so
+// the nodes are independent: one WAVE per node walks the keyframe's list while its lanes hold the node's frame features.
+// ======================================================================================================================
+#define TRF_TH_LOW 50
+struct TrfIn { double pose7[7]; float K4[4], inv_sigma2[16]; float ratio; int check_ori, nn, n_kf; };
+
+__global__ __launch_bounds__(256) void k_trf_init(int32_t* __restrict__ match_kf, int n_kf, int32_t* __restrict__ f_owner, int32_t* __restrict__ f_bin, int cap, int* __restrict__ hist) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_kf) match_kf[i] = -1;
+  if (i < cap) { f_owner[i] = -1; f_bin[i] = 0; }
+  if (i < TRK_HISTO + 2) hist[i] = 0;
+}
+
+__device__ __forceinline__ void two_smallest_merge(unsigned& k1, unsigned& k2, unsigned o1, unsigned o2) {     // {k1 <= k2} and {o1 <= o2} -> the two smallest of the four
+  const unsigned a = min(k1, o1), b = max(k1, o1);
+  k2 = min(b, min(k2, o2)); k1 = a;
+}
+
+__global__ __launch_bounds__(256) void k_trf_bow(const TrfIn* __restrict__ in, const uint32_t* __restrict__ fv_node, const uint32_t* __restrict__ fv_off,
+                                                 const uint32_t* __restrict__ fv_idx, const uint8_t* __restrict__ kf_desc, const uint8_t* __restrict__ kf_valid,
+                                                 const float* __restrict__ kf_angle, const uint8_t* __restrict__ f_desc, const uint32_t* __restrict__ f_node,
+                                                 const double* __restrict__ f_wt, const float* __restrict__ kps4, const int32_t* __restrict__ d_count, int cap,
+                                                 int32_t* __restrict__ match_kf, int32_t* __restrict__ f_owner, int32_t* __restrict__ f_bin, int* __restrict__ hist) {
+  __shared__ unsigned short s_list[4][TRK_MAXKP];               // the node's frame features, ascending index (FeatureVector order)
+  __shared__ unsigned char s_taken[4][TRK_MAXKP];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + w;
+  if (m >= in->nn) return;
+  const uint32_t node = fv_node[m];
+  const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
+  const float ratio = in->ratio; const int check_ori = in->check_ori;
+  int cnt = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool hit = i < n && f_node[i] == node && f_wt[i] > 0.0;      // (a stopped word - weight 0 - is not in the FeatureVector, TemplatedVocabulary.h:1156)
+    const unsigned long long mk = __ballot(hit);
+    if (hit) { const int p = cnt + __popcll(mk & ((1ull << lane) - 1ull)); s_list[w][p] = (unsigned short)i; s_taken[w][p] = 0; }
+    cnt += __popcll(mk);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  if (cnt == 0) return;
+  for (uint32_t e = fv_off[m]; e < fv_off[m + 1]; e++) {
+    const int q = (int)fv_idx[e];
+    if (q >= in->n_kf || !kf_valid[q]) continue;                      // no map point, or isBad() (:184-188)
+    const uint4* a = (const uint4*)(kf_desc + 32 * (size_t)q);
+    const uint4 a0 = a[0], a1 = a[1];
+    unsigned k1 = 256u << 16, k2 = 256u << 16;                        // (distance << 16 | list position): first minimum in list order
+    for (int p = lane; p < cnt; p += 64) {
+      if (s_taken[w][p]) continue;                                     // vpMapPointMatches[realIdxF] (:200)
+      const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][p]);
+      const uint4 b0 = tb[0], b1 = tb[1];
+      const unsigned d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
+                         __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+      const unsigned key = (d << 16) | (unsigned)p;
+      if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o); two_smallest_merge(k1, k2, o1, o2); }
+    const int bestDist1 = (int)(k1 >> 16), bestDist2 = (int)(k2 >> 16), pos1 = (int)(k1 & 0xFFFFu);
+    if (bestDist1 <= TRF_TH_LOW && (float)bestDist1 < ratio * (float)bestDist2) {
+      const int f = s_list[w][pos1];
+      if (lane == 0) {
+        s_taken[w][pos1] = 1;
+        match_kf[q] = f; f_owner[f] = q;
+        if (check_ori) {
+          float rot = kf_angle[q] - kps4[4 * f + 3];
+          if (rot < 0.0) rot += 360.0f;
+          int b = (int)roundf(rot * (1.0f / TRK_HISTO));
+          if (b == TRK_HISTO) b = 0;
+          f_bin[f] = b; atomicAdd(&hist[b], 1);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// one workgroup: the rotation check (ComputeThreeMaxima :1386-1418, the other bins' matches removed :240-251), PoseOptimization's
+// observation list in feature order
+__global__ __launch_bounds__(1024) void k_trf_finish(const TrfIn* __restrict__ in, const int* __restrict__ hist, const float* __restrict__ kps4, const int32_t* __restrict__ d_count,
+                                                     int cap, const double* __restrict__ kf_Xw, int32_t* __restrict__ match_kf, int32_t* __restrict__ f_owner,
+                                                     const int32_t* __restrict__ f_bin, int32_t* __restrict__ obs_feat, double* __restrict__ obs_Xw, double* __restrict__ obs_uv,
+                                                     float* __restrict__ obs_w, int32_t* __restrict__ obs_off, double* __restrict__ pose7, double* __restrict__ K4d, TrkOut* __restrict__ out) {
+  __shared__ int s_keep[TRK_HISTO], s_w[16], s_nm;
+  const int tid = threadIdx.x;
+  const int n_dev = *d_count;
+  const int n = min(max(n_dev, 0), min(cap, TRK_MAXKP));
+  if (tid == 0) {
+    s_nm = 0;
+    int top[3] = {-1, -1, -1}, pop[3] = {0, 0, 0};
+    for (int b = 0; b < TRK_HISTO; b++) {                    // strict '>': the earlier bin wins ties
+      const int h = hist[b];
+      int r = 3;
+      while (r > 0 && h > pop[r - 1]) r--;
+      if (r == 3) continue;
+      for (int mm = 2; mm > r; mm--) { top[mm] = top[mm - 1]; pop[mm] = pop[mm - 1]; }
+      top[r] = b; pop[r] = h;
+    }
+    if ((float)pop[1] < 0.1f * (float)pop[0]) { top[1] = -1; top[2] = -1; }
+    else if ((float)pop[2] < 0.1f * (float)pop[0]) { top[2] = -1; }
+    for (int b = 0; b < TRK_HISTO; b++) s_keep[b] = (!in->check_ori || b == top[0] || b == top[1] || b == top[2]) ? 1 : 0;
+  }
+  __syncthreads();
+  constexpr int FPT = TRK_MAXKP / 1024;
+  int own[FPT]; int cntv = 0;
+  for (int k = 0; k < FPT; k++) {
+    const int t = FPT * tid + k;
+    int o = t < n ? f_owner[t] : -1;
+    if (o >= 0 && !s_keep[f_bin[t]]) { match_kf[o] = -1; o = -1; }
+    if (t < cap) f_owner[t] = o;
+    own[k] = o; cntv += o >= 0 ? 1 : 0;
+  }
+  int inc = cntv;
+  {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; k++) base += s_w[k];
+    inc += base;
+  }
+  int pos = inc - cntv;
+  for (int k = 0; k < FPT; k++) {
+    const int t = FPT * tid + k;
+    if (own[k] < 0) continue;
+    const double* X = kf_Xw + 3 * (size_t)own[k];
+    obs_feat[pos] = t;
+    obs_Xw[3 * pos] = X[0]; obs_Xw[3 * pos + 1] = X[1]; obs_Xw[3 * pos + 2] = X[2];
+    obs_uv[2 * pos] = (double)kps4[4 * t]; obs_uv[2 * pos + 1] = (double)kps4[4 * t + 1];
+    obs_w[pos] = in->inv_sigma2[(int)kps4[4 * t + 2]];
+    pos++;
+  }
+  if (tid == 1023) { obs_off[0] = 0; obs_off[1] = inc; out->nobs = inc; out->nmatches = inc; out->n_keypoints = n_dev; out->rounds = 0; out->cand_total = 0; }
+  if (tid < 7) pose7[tid] = in->pose7[tid];
+  if (tid < 4) K4d[tid] = (double)in->K4[tid];
+}
+
 }  // namespace orbhip
 
 namespace orbhip {
+void orbv_merge_host(const int32_t* word, const double* wt, const uint32_t* node, int n, uint32_t* bow_word, double* bow_value, int* n_words,
+                     uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes);      // orb_vocab.hip
 int orbx_ctx_device(const orbx_ctx* c);
 int orbx_extract_chained(orbx_ctx* c, const uint8_t* d_img, int w, int h, int stride, orbx_keypoint* d_kps, uint8_t* d_desc, int cap,
                          int32_t* d_count, void* stream);      // orb_extractor.hip
@@ -1065,6 +1210,112 @@ int orbt_track_local_map(orbx_ctx* ctx, const float* K4, const float* bounds, co
   }
   set_error("window candidate lists did not fit after regrowing");
   return ORBHIP_ENOMEM;
+}
+
+int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* img, int w, int h, int stride, const float* K4, const float* bounds, const double* Tcw_last,
+                                  const uint8_t* kf_desc, const uint8_t* kf_valid, const float* kf_angle, const double* kf_Xw, int n_kf,
+                                  const uint32_t* kf_fv_node, const uint32_t* kf_fv_off, const uint32_t* kf_fv_idx, int kf_fv_n, float nnratio, int check_ori,
+                                  orbx_keypoint* kps_out, uint8_t* desc_out, int cap, uint32_t* bow_word, double* bow_value, int* n_words, uint32_t* fv_node,
+                                  uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes, int32_t* match_kf, int32_t* slot_owner, uint8_t* outlier_out, orbt_result* res) {
+  ORBHIP_REQUIRE(ctx && voc && K4 && bounds && Tcw_last && res && match_kf && slot_owner && outlier_out && n_words && n_fv_nodes && fv_off, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(n_kf >= 0 && kf_fv_n >= 0 && (n_kf == 0 || (kf_desc && kf_valid && kf_angle && kf_Xw)) && (kf_fv_n == 0 || (kf_fv_node && kf_fv_off && kf_fv_idx)), ORBHIP_EINVAL, "NULL keyframe argument");
+  const int icap = orbx_max_keypoints(ctx);
+  ORBHIP_REQUIRE(icap <= TRK_MAXKP, ORBHIP_ECAP, "more than 4096 features per frame");
+  const int nlevels = orbx_get_levels(ctx);
+  ORBHIP_REQUIRE(nlevels > 0 && nlevels <= 16, ORBHIP_EINVAL, "bad level count");
+  TrkFrame& TF = g_trk_frame;
+  ThreadWs& W = thread_ws();
+  int rc = W.begin();
+  if (rc) return rc;
+  ORBHIP_REQUIRE(orbhip::orbx_ctx_device(ctx) == W.device, ORBHIP_EINVAL, "the extractor context was created on another device than orbhip_set_default_device() selects");
+  if (TF.device != W.device) { TF = TrkFrame(); TF.device = W.device; }
+  TrfIn I; std::memset(&I, 0, sizeof(I));
+  { double T[16]; for (int k = 0; k < 12; k++) T[k] = Tcw_last[k]; T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1; if (int r2 = ba_matrix4d_to_pose7(T, I.pose7)) return r2; }
+  float scale[16];
+  for (int k = 0; k < 4; k++) I.K4[k] = K4[k];
+  if (int r2 = orbx_get_tables(ctx, scale, nullptr, nullptr, I.inv_sigma2, nullptr)) return r2;
+  I.ratio = nnratio; I.check_ori = check_ori ? 1 : 0; I.nn = kf_fv_n; I.n_kf = n_kf;
+  const uint32_t n_fv_idx = kf_fv_n ? kf_fv_off[kf_fv_n] : 0u;
+  ThreadWs::Pack in;
+  TrkIn PI; std::memset(&PI, 0, sizeof(PI));                   // k_trk_prepare's constants (no queries: it builds the frame's records and grid)
+  for (int k = 0; k < 4; k++) { PI.K4[k] = K4[k]; PI.bounds[k] = bounds[k]; }
+  PI.nlevels = nlevels; std::memcpy(PI.scale, scale, sizeof(scale));
+  const int pI = in.add(&I, sizeof(I)), pP = in.add(&PI, sizeof(PI)), pD = in.add(kf_desc, 32 * (size_t)n_kf), pV = in.add(kf_valid, (size_t)n_kf), pA = in.add(kf_angle, 4 * (size_t)n_kf),
+            pX = in.add(kf_Xw, 24 * (size_t)n_kf), pFn = in.add(kf_fv_node, 4 * (size_t)kf_fv_n), pFo = in.add(kf_fv_off, 4 * ((size_t)kf_fv_n + 1)), pFi = in.add(kf_fv_idx, 4 * (size_t)n_fv_idx);
+  uint8_t* d_img = nullptr;
+  if (img) {
+    ORBHIP_REQUIRE(kps_out && desc_out && cap >= icap, ORBHIP_ECAP, "output capacity below orbx_max_keypoints(ctx)");
+    d_img = W.up<uint8_t>(img, (size_t)stride * (h - 1) + w, &rc);
+  } else {
+    ORBHIP_REQUIRE(TF.valid, ORBHIP_EINVAL, "img == NULL needs the frame of an earlier orbt_* call of this thread on the device");
+  }
+  if (rc || (rc = W.commit(in))) return rc;
+  if (img) {
+    // the same frame block orbt_track_with_motion_model leaves behind: [.. | count | keypoints | descriptors | ..]
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+    const size_t oCnt = take(4), oKps = take((size_t)icap * sizeof(orbx_keypoint)), oDesc = take((size_t)icap * 32);
+    TF.valid = false;
+    if ((rc = TF.blk.ensure(o)) || (rc = TF.kps4.ensure(16 * (size_t)icap)) || (rc = TF.grid.off.ensure((size_t)(TRK_NCELL + 1) * 4)) || (rc = TF.grid.idx.ensure((size_t)icap * 4))) return rc;
+    TF.oCnt = oCnt; TF.oKps = oKps; TF.oDesc = oDesc; TF.icap = icap; TF.nlevels = nlevels; std::memcpy(TF.bounds, bounds, 16);
+    TF.grid.min_x = bounds[0]; TF.grid.min_y = bounds[2];
+    TF.grid.winv = static_cast<float>(FRAME_GRID_COLS) / (bounds[1] - bounds[0]); TF.grid.hinv = static_cast<float>(FRAME_GRID_ROWS) / (bounds[3] - bounds[2]);
+    uint8_t* fb = TF.blk.as<uint8_t>();
+    if ((rc = orbhip::orbx_extract_chained(ctx, d_img, w, h, stride, (orbx_keypoint*)(fb + oKps), fb + oDesc, icap, (int32_t*)(fb + oCnt), (void*)W.s))) return rc;
+    float* d_dummy = W.d<float>(4, &rc); int32_t* d_di = W.d<int32_t>(4, &rc); uint8_t* d_db = W.d<uint8_t>(4, &rc); uint32_t* d_tot = W.d<uint32_t>(1, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_trk_prepare, dim3(1), dim3(1024), 0, W.s, in.dev<TrkIn>(pP), (const double*)nullptr, (const int32_t*)nullptr, (const uint8_t*)nullptr,
+                       (const orbx_keypoint*)(fb + oKps), (const int32_t*)(fb + oCnt), icap, d_dummy, d_dummy, d_di, d_di, d_db, TF.kps4.as<float>(),
+                       TF.grid.off.as<uint32_t>(), TF.grid.idx.as<uint32_t>(), 0, d_tot);
+  }
+  const uint8_t* fblk = TF.blk.as<uint8_t>();
+  const float* d_kps4 = TF.kps4.as<float>();
+  const int32_t* d_count = (const int32_t*)(fblk + TF.oCnt);
+  const uint8_t* d_fdesc = fblk + TF.oDesc;
+  const int fcap = TF.icap;
+  // output block: [TrkOut | pose7 | summary | n_inliers | word | weight | node | match_kf | owner | obs_feat | outlier]
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+  const size_t oOut = take(sizeof(TrkOut)), oPose = take(56), oSum = take(sizeof(ba_summary)), oNin = take(4), oWord = take(4 * (size_t)fcap), oWt = take(8 * (size_t)fcap),
+               oNode = take(4 * (size_t)fcap), oMatch = take(4 * (size_t)std::max(n_kf, 1)), oOwner = take(4 * (size_t)fcap), oFeat = take(4 * (size_t)fcap), oOutl = take((size_t)fcap);
+  uint8_t* dblk = W.d<uint8_t>(o, &rc);
+  int32_t* d_bin = W.d<int32_t>(fcap, &rc); int* d_hist = W.d<int>(TRK_HISTO + 2, &rc);
+  double* d_oX = W.d<double>(3 * (size_t)fcap, &rc); double* d_ouv = W.d<double>(2 * (size_t)fcap, &rc); float* d_ow = W.d<float>(fcap, &rc);
+  int32_t* d_ooff = W.d<int32_t>(2, &rc); double* d_K4 = W.d<double>(4, &rc);
+  if (rc) return rc;
+  // Frame::ComputeBoW (src/Frame.cc:322-327: levelsup 4); the rows behind the keypoint count are descended too and ignored
+  if ((rc = orbv_descend_device(voc, d_fdesc, fcap, 4, (int32_t*)(dblk + oWord), (double*)(dblk + oWt), (uint32_t*)(dblk + oNode), (void*)W.s))) return rc;
+  const TrfIn* dI = in.dev<TrfIn>(pI);
+  hipLaunchKernelGGL(k_trf_init, dim3((std::max(std::max(n_kf, fcap), 64) + 255) / 256), dim3(256), 0, W.s, (int32_t*)(dblk + oMatch), n_kf, (int32_t*)(dblk + oOwner), d_bin, fcap, d_hist);
+  if (kf_fv_n > 0)
+    hipLaunchKernelGGL(k_trf_bow, dim3((kf_fv_n + 3) / 4), dim3(256), 0, W.s, dI, in.dev<uint32_t>(pFn), in.dev<uint32_t>(pFo), in.dev<uint32_t>(pFi), in.dev<uint8_t>(pD),
+                       in.dev<uint8_t>(pV), in.dev<float>(pA), d_fdesc, (const uint32_t*)(dblk + oNode), (const double*)(dblk + oWt), d_kps4, d_count, fcap,
+                       (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), d_bin, d_hist);
+  hipLaunchKernelGGL(k_trf_finish, dim3(1), dim3(1024), 0, W.s, dI, d_hist, d_kps4, d_count, fcap, in.dev<double>(pX), (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), d_bin,
+                     (int32_t*)(dblk + oFeat), d_oX, d_ouv, d_ow, d_ooff, (double*)(dblk + oPose), d_K4, (TrkOut*)(dblk + oOut));
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  if ((rc = ba_pose_optimization_batch_device(d_K4, (double*)(dblk + oPose), d_oX, d_ouv, d_ow, d_ooff, 1, dblk + oOutl, (int32_t*)(dblk + oNin), (ba_summary*)(dblk + oSum), (void*)W.s))) return rc;
+  const uint8_t* hb = W.down(dblk, o, &rc);
+  const uint8_t* hf = img ? W.down(fblk, TF.oDesc + (size_t)fcap * 32, &rc) : nullptr;
+  if (rc || (rc = W.sync())) return rc;
+  const TrkOut* T = (const TrkOut*)(hb + oOut);
+  if (T->n_keypoints < 0) { set_error("extractor capacity exceeded"); return ORBHIP_EOVERFLOW; }
+  const int n = std::min(T->n_keypoints, fcap);
+  if (img) { TF.n_kp = n; TF.valid = true; std::memcpy(kps_out, hf + TF.oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hf + TF.oDesc, (size_t)n * 32); }
+  if (n != TF.n_kp) { set_error("resident frame changed"); return ORBHIP_EINVAL; }
+  if (bow_word && bow_value && fv_node && fv_idx)
+    orbhip::orbv_merge_host((const int32_t*)(hb + oWord), (const double*)(hb + oWt), (const uint32_t*)(hb + oNode), n, bow_word, bow_value, n_words, fv_node, fv_off, fv_idx, n_fv_nodes);
+  else { *n_words = 0; *n_fv_nodes = 0; fv_off[0] = 0; }
+  if (n_kf) std::memcpy(match_kf, hb + oMatch, 4 * (size_t)n_kf);
+  std::memcpy(slot_owner, hb + oOwner, 4 * (size_t)n);
+  std::memset(outlier_out, 0, (size_t)n);
+  const int32_t* feat = (const int32_t*)(hb + oFeat);
+  for (int k = 0; k < T->nobs; k++) outlier_out[feat[k]] = hb[oOutl + k];
+  res->n_keypoints = n; res->nmatches = T->nmatches; res->n_correspondences = T->nobs; res->greedy_rounds = 0; res->reserved = 0;
+  std::memcpy(res->pose7, hb + oPose, 56);
+  res->n_inliers = T->nobs < 3 ? 0 : *(const int32_t*)(hb + oNin);
+  if (T->nobs < 3) std::memcpy(res->pose7, I.pose7, 56);
+  return 0;
 }
 
 }  // extern "C"

@@ -82,6 +82,41 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint4* __restrict__ n
 using namespace orbhip;
 #define VCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return ORBHIP_ENODEV; } } while (0)
 
+namespace orbhip {
+// The host half of TemplatedVocabulary::transform (:1166-1200): the per-feature (word, weight, node) triples of the descent merged
+// into the BowVector (std::map order, weights of equal words added in feature order, L1 norm) and the FeatureVector (CSR).
+// Shared by orbv_transform and the device-resident TrackReferenceKeyFrame step (orb_track.hip).
+void orbv_merge_host(const int32_t* word, const double* wt, const uint32_t* node, int n, uint32_t* bow_word, double* bow_value, int* n_words,
+                     uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes) {
+  // ---- BowVector: std::map order (ascending word id); equal ids add their weights in feature order (:1158, BowVector.cpp:34-46)
+  std::vector<int> live;
+  for (int i = 0; i < n; i++) if (wt[i] > 0) live.push_back(i);            // "not stopped" (:1156)
+  std::vector<int> byword(live);
+  std::stable_sort(byword.begin(), byword.end(), [&](int a, int b) { return (uint32_t)word[a] < (uint32_t)word[b]; });
+  int nw = 0;
+  for (size_t k = 0; k < byword.size(); k++) {
+    const int i = byword[k];
+    if (nw && bow_word[nw - 1] == (uint32_t)word[i]) bow_value[nw - 1] += wt[i];
+    else { bow_word[nw] = (uint32_t)word[i]; bow_value[nw] = wt[i]; nw++; }
+  }
+  double norm = 0.0;                                                          // L1 (BowVector.cpp:62-84)
+  for (int k = 0; k < nw; k++) norm += std::fabs(bow_value[k]);
+  if (norm > 0.0) for (int k = 0; k < nw; k++) bow_value[k] /= norm;
+  *n_words = nw;
+  // ---- FeatureVector: ascending node id, feature indices ascending inside a node
+  std::vector<int> bynode(live);
+  std::stable_sort(bynode.begin(), bynode.end(), [&](int a, int b) { return node[a] < node[b]; });
+  int m = 0; uint32_t pos = 0;
+  for (size_t k = 0; k < bynode.size(); k++) {
+    const int i = bynode[k];
+    if (!m || fv_node[m - 1] != node[i]) { fv_node[m] = node[i]; fv_off[m] = pos; m++; }
+    fv_idx[pos++] = (uint32_t)i;
+  }
+  fv_off[m] = pos;
+  *n_fv_nodes = m;
+}
+}  // namespace orbhip
+
 extern "C" {
 
 int orbv_destroy(orbv_ctx* c);
@@ -243,32 +278,7 @@ int orbv_transform(orbv_ctx* c, const uint8_t* desc, int n, int levelsup, uint32
   if (e == hipSuccess) e = hipMemcpy(node.data(), dn.p, (size_t)n * 4, hipMemcpyDeviceToHost);
   cleanup();
   if (e != hipSuccess) { set_error("orbv_transform: %s", hipGetErrorString(e)); return ORBHIP_ENODEV; }
-  // ---- BowVector: std::map order (ascending word id); equal ids add their weights in feature order (:1158, BowVector.cpp:34-46)
-  std::vector<int> live;
-  for (int i = 0; i < n; i++) if (wt[i] > 0) live.push_back(i);            // "not stopped" (:1156)
-  std::vector<int> byword(live);
-  std::stable_sort(byword.begin(), byword.end(), [&](int a, int b) { return (uint32_t)word[a] < (uint32_t)word[b]; });
-  int nw = 0;
-  for (size_t k = 0; k < byword.size(); k++) {
-    const int i = byword[k];
-    if (nw && bow_word[nw - 1] == (uint32_t)word[i]) bow_value[nw - 1] += wt[i];
-    else { bow_word[nw] = (uint32_t)word[i]; bow_value[nw] = wt[i]; nw++; }
-  }
-  double norm = 0.0;                                                          // L1 (BowVector.cpp:62-84)
-  for (int k = 0; k < nw; k++) norm += std::fabs(bow_value[k]);
-  if (norm > 0.0) for (int k = 0; k < nw; k++) bow_value[k] /= norm;
-  *n_words = nw;
-  // ---- FeatureVector: ascending node id, feature indices ascending inside a node
-  std::vector<int> bynode(live);
-  std::stable_sort(bynode.begin(), bynode.end(), [&](int a, int b) { return node[a] < node[b]; });
-  int m = 0; uint32_t pos = 0;
-  for (size_t k = 0; k < bynode.size(); k++) {
-    const int i = bynode[k];
-    if (!m || fv_node[m - 1] != node[i]) { fv_node[m] = node[i]; fv_off[m] = pos; m++; }
-    fv_idx[pos++] = (uint32_t)i;
-  }
-  fv_off[m] = pos;
-  *n_fv_nodes = m;
+  orbhip::orbv_merge_host(word.data(), wt.data(), node.data(), n, bow_word, bow_value, n_words, fv_node, fv_off, fv_idx, n_fv_nodes);
   return 0;
 }
 

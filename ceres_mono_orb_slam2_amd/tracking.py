@@ -104,3 +104,34 @@ def track_local_map(extractor, K4, bounds, Tcw, log_scale_factor, mp_Xw, mp_norm
                                       C.byref(res)), "orbt_track_local_map")
     return dict(in_view=in_view[:n].view(np.bool_), match=match[:n], owner=owner[:nk], outlier=outl[:nk].view(np.bool_), pose7=np.array(res.pose7[:], np.float64),
                 nmatches=res.nmatches, n_inliers=res.n_inliers, n_correspondences=res.n_correspondences, n_in_view=res.reserved, greedy_rounds=res.greedy_rounds)
+
+
+def track_reference_keyframe(extractor, vocabulary, image, K4, bounds, Tcw_last, kf_desc, kf_valid, kf_angle, kf_Xw, kf_fv, nnratio=0.7, check_ori=True):
+    """Tracking::TrackReferenceKeyFrame's data-parallel core (include/orbslam_hip.h::orbt_track_reference_keyframe; reference
+    src/Tracking.cc:566-615).  image None: the frame of the last orbt_* call of this thread.  kf_fv = (node ids, offsets, indices).
+    Returns dict(kps, desc (None without image), bow=(words, values), fv=(nodes, offsets, indices), match, owner, outlier, pose7, ...)."""
+    L = _lib.load()
+    K4 = _c(K4, np.float32); bounds = _c(bounds, np.float32)
+    T = np.ascontiguousarray(np.asarray(Tcw_last, np.float64).reshape(-1)[:12])
+    D = _c(kf_desc, np.uint8).reshape(-1, 32); n = len(D)
+    V = _c(kf_valid, np.uint8); A = _c(kf_angle, np.float32); X = _c(kf_Xw, np.float64).reshape(-1, 3)
+    fn, fo, fi = [_c(x, np.uint32) for x in kf_fv]
+    assert len(V) == n and len(A) == n and len(X) == n and len(fo) == len(fn) + 1
+    cap = extractor.max_keypoints
+    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+    bw = np.zeros(cap, np.uint32); bv = np.zeros(cap, np.float64); nw = C.c_int(0)
+    on = np.zeros(cap, np.uint32); oo = np.zeros(cap + 2, np.uint32); oi = np.zeros(cap, np.uint32); nf = C.c_int(0)
+    match = np.full(max(n, 1), -1, np.int32); owner = np.full(cap, -1, np.int32); outl = np.zeros(cap, np.uint8)
+    res = TrackResult()
+    if image is not None:
+        img = _c(image, np.uint8); h, w = img.shape; ip, st = _addr(img), img.strides[0]
+    else:
+        img, h, w, ip, st = None, 0, 0, None, 0
+    _lib.check(L.orbt_track_reference_keyframe(extractor._h, vocabulary._h, ip, w, h, st, _addr(K4), _addr(bounds), _addr(T), _addr(D), _addr(V), _addr(A), _addr(X), n,
+                                               _addr(fn), _addr(fo), _addr(fi), len(fn), float(nnratio), int(bool(check_ori)), _addr(kps), _addr(desc), cap,
+                                               _addr(bw), _addr(bv), C.byref(nw), _addr(on), _addr(oo), _addr(oi), C.byref(nf), _addr(match), _addr(owner), _addr(outl),
+                                               C.byref(res)), "orbt_track_reference_keyframe")
+    k = res.n_keypoints
+    return dict(kps=kps[:k] if img is not None else None, desc=desc[:k] if img is not None else None, bow=(bw[:nw.value], bv[:nw.value]),
+                fv=(on[:nf.value], oo[:nf.value + 1], oi[:oo[nf.value]]), match=match[:n], owner=owner[:k], outlier=outl[:k].view(np.bool_),
+                pose7=np.array(res.pose7[:], np.float64), nmatches=res.nmatches, n_inliers=res.n_inliers, n_correspondences=res.n_correspondences, n_keypoints=k)

@@ -357,6 +357,25 @@ int orbt_track_local_map(orbx_ctx* ctx, const float* K4, const float* bounds, co
                          int n_kp, float th, float nnratio, uint8_t* mp_in_view, int32_t* mp_match, int32_t* slot_owner,
                          uint8_t* outlier, orbt_result* res);
 
+/* ---- Tracking::TrackReferenceKeyFrame's data-parallel core in one call (src/Tracking.cc:566-615): Frame::ComputeBoW (src/Frame.cc:
+ * 322-327, the vocabulary descent), ORBmatcher::SearchByBoW(reference_keyframe_, current_frame_, ...) (src/ORBmatcher.cc:151-256,
+ * nnratio 0.7, TH_LOW 50, rotation histogram) and CeresOptimizer::PoseOptimization from last_frame_.Tcw_.
+ *   in   img != NULL: the frame is extracted first (as in orbt_track_with_motion_model; kps / desc [cap] receive it) and stays on
+ *        the device for a following orbt_track_local_map; img == NULL: the frame an earlier orbt_* call of this thread left there.
+ *        Per keyframe feature i < n_kf: descriptor, kf_valid = it holds a map point that is not bad, undistort_keypoints_[i].angle,
+ *        the point's position; the keyframe's feature_vector_ as CSR (ascending node ids, as orbv_transform returns it).
+ *   out  the frame's BowVector / FeatureVector in orbv_transform's layout (pass NULL for bow_word to skip them);
+ *        match_kf[n_kf] = frame feature matched to keyframe feature i or -1; slot_owner[n_kp] = keyframe feature whose map point
+ *        current_frame_.map_points_[f] holds, or -1; outlier[n_kp]; res->nmatches (the caller returns false below 15, :582),
+ *        pose.  PoseOptimization runs whatever nmatches is.                                                                   */
+int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* img, int w, int h, int stride, const float* K4,
+                                  const float* bounds, const double* Tcw_last, const uint8_t* kf_desc, const uint8_t* kf_valid,
+                                  const float* kf_angle, const double* kf_Xw, int n_kf, const uint32_t* kf_fv_node,
+                                  const uint32_t* kf_fv_off, const uint32_t* kf_fv_idx, int kf_fv_n, float nnratio, int check_ori,
+                                  orbx_keypoint* kps, uint8_t* desc, int cap, uint32_t* bow_word, double* bow_value, int* n_words,
+                                  uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes, int32_t* match_kf,
+                                  int32_t* slot_owner, uint8_t* outlier, orbt_result* res);
+
 /* ------------------------------------------------------------ bundle adjust --
  * Replaces CeresOptimizer::{PoseOptimization, BundleAdjustment/GlobalBundleAdjustemnt,
  * LocalBundleAdjustment, CheckOutlier(s)} (src/CeresOptimizer.cc:49-599) and the Ceres solve

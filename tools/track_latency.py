@@ -48,5 +48,21 @@ for _ in range(N): r2 = tracking.track_local_map(*b)
 ms_lm = (time.perf_counter() - t0) / N * 1e3
 print(json.dumps({"track_local_map_ms": round(ms_lm, 4), "local_map_points": m, "in_view": int(r2["n_in_view"]), "matched": r2["nmatches"], "correspondences": r2["n_correspondences"],
                   "inliers": r2["n_inliers"], "greedy_rounds": r2["greedy_rounds"]}))
+# TrackReferenceKeyFrame on an ORBvoc-shaped tree (k = 10, L = 6: 100 nodes at levelsup 4), the last frame as the reference keyframe
+from ceres_mono_orb_slam2_amd.vocabulary import ORBVocabulary
+voc = synth.make_vocabulary(1, k=10, L=6)
+V = ORBVocabulary(*[voc[x] for x in ("node_desc", "child_off", "children", "word_id", "weight", "L")])
+kbw, kbv, kfv = V.transform(d0, 4)
+c = (ex, V, seq[1], K4, B, T, d0, np.ones(n, np.uint8), k0["angle"].astype(np.float32), X, kfv, 0.7, True)
+for _ in range(10): r3 = tracking.track_reference_keyframe(*c)
+t0 = time.perf_counter()
+for _ in range(N): r3 = tracking.track_reference_keyframe(*c)
+ms_rk = (time.perf_counter() - t0) / N * 1e3
+c2 = (ex, V, None) + c[3:]
+t0 = time.perf_counter()
+for _ in range(N): r4 = tracking.track_reference_keyframe(*c2)
+ms_rk2 = (time.perf_counter() - t0) / N * 1e3
+print(json.dumps({"track_reference_keyframe_ms": round(ms_rk, 4), "without_extraction_ms": round(ms_rk2, 4), "vocabulary": "k=10 L=6 synthetic", "keyframe_nodes": int(len(kfv[0])),
+                  "matches": r3["nmatches"], "inliers": r3["n_inliers"]}))
 print(json.dumps({"tracking_step_ms": round(ms, 4), "orbx_extract_alone_ms": round(ms_ex, 4), "keypoints": len(r["kps"]), "matches": r["nmatches"], "inliers": r["n_inliers"],
                   "greedy_rounds": r["greedy_rounds"]}))
