@@ -870,16 +870,27 @@ __global__ __launch_bounds__(256) void k_trf_bow(const TrfIn* __restrict__ in, c
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   if (cnt == 0) return;
-  for (uint32_t e = fv_off[m]; e < fv_off[m + 1]; e++) {
-    const int q = (int)fv_idx[e];
-    if (q >= in->n_kf || !kf_valid[q]) continue;                      // no map point, or isBad() (:184-188)
-    const uint4* a = (const uint4*)(kf_desc + 32 * (size_t)q);
-    const uint4 a0 = a[0], a1 = a[1];
+  // the node's first 64 frame descriptors stay in registers (a node of the ORB vocabulary holds ~20 features of a frame: a lone wave
+  // would otherwise pay a global round trip per keyframe feature); the keyframe's descriptor of the NEXT list entry is requested
+  // before the current one is used
+  uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+  if (lane < cnt) { const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][lane]); c0 = tb[0]; c1 = tb[1]; }
+  const uint32_t e_lo = fv_off[m], e_hi = fv_off[m + 1];
+  auto kf_of = [&](uint32_t e) { const int q = e < e_hi ? (int)fv_idx[e] : -1; return (q >= 0 && q < in->n_kf && kf_valid[q]) ? q : -1; };
+  int qn = kf_of(e_lo);
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+  if (qn >= 0) { const uint4* a = (const uint4*)(kf_desc + 32 * (size_t)qn); n0 = a[0]; n1 = a[1]; }
+  for (uint32_t e = e_lo; e < e_hi; e++) {
+    const int q = qn;
+    const uint4 a0 = n0, a1 = n1;
+    qn = kf_of(e + 1);
+    if (qn >= 0) { const uint4* a = (const uint4*)(kf_desc + 32 * (size_t)qn); n0 = a[0]; n1 = a[1]; }
+    if (q < 0) continue;                                              // no map point, or isBad() (:184-188)
     unsigned k1 = 256u << 16, k2 = 256u << 16;                        // (distance << 16 | list position): first minimum in list order
     for (int p = lane; p < cnt; p += 64) {
       if (s_taken[w][p]) continue;                                     // vpMapPointMatches[realIdxF] (:200)
-      const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][p]);
-      const uint4 b0 = tb[0], b1 = tb[1];
+      uint4 b0 = c0, b1 = c1;
+      if (p >= 64) { const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][p]); b0 = tb[0]; b1 = tb[1]; }
       const unsigned d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
                          __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
       const unsigned key = (d << 16) | (unsigned)p;

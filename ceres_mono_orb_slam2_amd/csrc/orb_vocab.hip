@@ -91,11 +91,13 @@ void orbv_merge_host(const int32_t* word, const double* wt, const uint32_t* node
   // ---- BowVector: std::map order (ascending word id); equal ids add their weights in feature order (:1158, BowVector.cpp:34-46)
   std::vector<int> live;
   for (int i = 0; i < n; i++) if (wt[i] > 0) live.push_back(i);            // "not stopped" (:1156)
-  std::vector<int> byword(live);
-  std::stable_sort(byword.begin(), byword.end(), [&](int a, int b) { return (uint32_t)word[a] < (uint32_t)word[b]; });
+  // (sorted as packed (id << 32 | feature index) keys: the order of a stable sort by id, without its indirect comparisons)
+  std::vector<uint64_t> keys(live.size());
+  for (size_t k = 0; k < live.size(); k++) keys[k] = ((uint64_t)(uint32_t)word[live[k]] << 32) | (uint32_t)live[k];
+  std::sort(keys.begin(), keys.end());
   int nw = 0;
-  for (size_t k = 0; k < byword.size(); k++) {
-    const int i = byword[k];
+  for (size_t k = 0; k < keys.size(); k++) {
+    const int i = (int)(uint32_t)keys[k];
     if (nw && bow_word[nw - 1] == (uint32_t)word[i]) bow_value[nw - 1] += wt[i];
     else { bow_word[nw] = (uint32_t)word[i]; bow_value[nw] = wt[i]; nw++; }
   }
@@ -104,11 +106,11 @@ void orbv_merge_host(const int32_t* word, const double* wt, const uint32_t* node
   if (norm > 0.0) for (int k = 0; k < nw; k++) bow_value[k] /= norm;
   *n_words = nw;
   // ---- FeatureVector: ascending node id, feature indices ascending inside a node
-  std::vector<int> bynode(live);
-  std::stable_sort(bynode.begin(), bynode.end(), [&](int a, int b) { return node[a] < node[b]; });
+  for (size_t k = 0; k < live.size(); k++) keys[k] = ((uint64_t)node[live[k]] << 32) | (uint32_t)live[k];
+  std::sort(keys.begin(), keys.end());
   int m = 0; uint32_t pos = 0;
-  for (size_t k = 0; k < bynode.size(); k++) {
-    const int i = bynode[k];
+  for (size_t k = 0; k < keys.size(); k++) {
+    const int i = (int)(uint32_t)keys[k];
     if (!m || fv_node[m - 1] != node[i]) { fv_node[m] = node[i]; fv_off[m] = pos; m++; }
     fv_idx[pos++] = (uint32_t)i;
   }
