@@ -1043,6 +1043,9 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
   // Row pass.  (Tried again in round 2, with the kernel 100 % VALU-busy: two v_dot4_u32_u8 per output on v_alignbyte windows of
   // the 12-byte block - 14 instructions per four outputs instead of ~40, bit-exact - runs 0.450 ms against 0.392: the dot
   // instructions cost more issue time than the SDWA byte-select multiply-adds they replace.)
+  // (Round 4: the row sums fit 16 bits exactly - 255 x 257 = 65535 - so the interior was rewritten on PACKED u16: nine v_perm byte pairs,
+  // three v_pk_add_u16 + four v_pk_mul / v_pk_mad_u16 per output pair, 23 instructions per four outputs, stored as they come; bit-exact,
+  // and slower: 1.01 ms against 0.92 beside FAST + octree, 137.2 k against 140.8 k frames/s pipelined on the same box.)
   for (int yy = rr; yy < BLUR_TH + 6; yy += 8) {
     const int sy = reflect101(y0 + yy - 3, L.h);
     const uint8_t* row = src + (uint32_t)sy * (uint32_t)L.pitch;      // (32-bit unsigned row offset on the wave-uniform level base: no per-lane 64-bit multiply)
