@@ -601,7 +601,7 @@ struct BaDev {            // device pointers of one problem
   const int* cam_off; const int* cam_obs; const int* cam_obs_pt;   // per-camera lists (sorted by point)
   const int* cam_pos;                // [nobs] position of an observation inside its camera's list (inverse of cam_obs)
   double* JcR;                       // [nobs][14] per-camera-ordered records {Jc (12), r (2)}: k_ba_cam_blocks streams them
-  double* r; double* Jc; double* Jp; // SoA: r[2][nobs], Jc[12][nobs], Jp[6][nobs] (the landmark blocks and the model residual of k_ba_backsub read them)
+  double* r; double* Jp;             // SoA: r[2][nobs], Jp[6][nobs] (the landmark blocks read them; the camera Jacobians live in JcR only)
   double* B; double* gc; double* C; double* gp;       // unscaled blocks: B[nfc][21], gc[nfc][6], C[npts][6], gp[npts][3]
   double* scale_c; double* scale_p;  // Jacobi scaling [nfc][6], [npts][3]
   double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] records of 18 (ld_rec18): rewritten only when the iterate changes (k_ba_E)
@@ -660,7 +660,6 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
       const size_t n = D.nobs;
       D.r[i] = r[0]; D.r[n + i] = r[1];
       if (wantc) {
-        for (int k = 0; k < 12; k++) D.Jc[k * n + i] = Jc[k];
         double* rec = D.JcR + 14 * (size_t)D.cam_pos[i];            // the same values, grouped by camera (contiguous 112-byte records)
         for (int k = 0; k < 12; k++) rec[k] = Jc[k];
         rec[12] = r[0]; rec[13] = r[1];
@@ -3197,13 +3196,13 @@ __global__ __launch_bounds__(1024) void k_chol_bsolve_update(const BaDev* __rest
 // ---- candidate cameras: x+ = Plus(x, -y * scale); partial |dx|^2 -------------------------------------------
 __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
-  __shared__ double s_red[4], s_out[1];
+  __shared__ double s_red[4 * 2], s_out[2];
   const BaState* st = D.st;
   const StFlags F = ld_flags(st);
   if (F.done || !F.valid) return;
   if ((int)blockIdx.x * BA_TPB >= D.ncam) return;
   const int c = blockIdx.x * BA_TPB + threadIdx.x;
-  double acc[1] = {0.0};
+  double acc[2] = {0.0, 0.0};                 // |dx|^2 of the cameras; their share of the model cost change (see k_ba_backsub)
   if (c < D.ncam) {
     const double* x = D.poses + 7 * c;
     double* xc = D.cand_poses + 7 * c;
@@ -3216,10 +3215,24 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restric
       double d[3] = {(-y[3]) * sc[3], (-y[4]) * sc[4], (-y[5]) * sc[5]};
       quat_plus(x + 3, d, xc + 3);
       for (int k = 0; k < 7; k++) { double e = x[k] - xc[k]; acc[0] += e * e; }
+      // -(g_c . s + s^T B_s s / 2) with the scaled step s = -y, the scaled gradient and the scaled block WITHOUT the damping
+      const double* Bu = D.B + 21 * (size_t)cc;
+      const double* g = D.gc + 6 * (size_t)cc;
+      double gs = 0.0, q = 0.0;
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+        const double su = -y[u];
+        gs += g[u] * sc[u] * su;
+        double row = 0.0;
+#pragma unroll
+        for (int v = 0; v < 6; v++) row += Bu[sym6(u, v)] * sc[u] * sc[v] * (-y[v]);
+        q += su * row;
+      }
+      acc[1] = -(gs + q / 2);
     }
   }
-  block_reduce<1>(acc, s_red, s_out);
-  if (threadIdx.x == 0) D.part[2 * D.nparts + blockIdx.x] = s_out[0];
+  block_reduce<2>(acc, s_red, s_out);
+  if (threadIdx.x == 0) { D.part[2 * D.nparts + blockIdx.x] = s_out[0]; D.part[5 * D.nparts + blockIdx.x] = s_out[1]; }
 }
 
 // ---- landmark back-substitution, candidate points, model cost change and |dx|^2 partials ---------------------
@@ -3233,7 +3246,6 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restric
 __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__ Dv, int part_off) {
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[16 * 2], s_out[2];
-  __shared__ double s_step[BS_PTS][3];
   const BaState* st = D.st;
   const StFlags F = ld_flags(st);
   if (F.done || !F.valid) return;
@@ -3265,51 +3277,45 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
   __syncthreads();
   if (tid < BS_PTS) {
     const int p = p0 + tid;
-    double sx = 0.0, sy = 0.0, sz = 0.0;
     if (p < p1) {
       const int lo = D.pt_off[p], hi = D.pt_off[p + 1];
       if (ok && !D.fix_points && lo < hi) {
-        double t[3] = {D.gps[3 * (size_t)p], D.gps[3 * (size_t)p + 1], D.gps[3 * (size_t)p + 2]};
-        for (int i = lo; i < hi; i++) { t[0] -= D.t3[3 * (size_t)i]; t[1] -= D.t3[3 * (size_t)i + 1]; t[2] -= D.t3[3 * (size_t)i + 2]; }
+        const double g0 = D.gps[3 * (size_t)p], g1 = D.gps[3 * (size_t)p + 1], g2 = D.gps[3 * (size_t)p + 2];
+        double T0 = 0.0, T1 = 0.0, T2 = 0.0;                    // sum over the point's observations of E_i^T y_cam, in observation order
+        double t[3] = {g0, g1, g2};                             // g_p - sum: subtracted one by one, as before
+        for (int i = lo; i < hi; i++) {
+          const double a0 = D.t3[3 * (size_t)i], a1 = D.t3[3 * (size_t)i + 1], a2 = D.t3[3 * (size_t)i + 2];
+          t[0] -= a0; t[1] -= a1; t[2] -= a2; T0 += a0; T1 += a1; T2 += a2;
+        }
         const double* Ci = D.Cinv + 6 * (size_t)p;
         const double yp0 = Ci[0] * t[0] + Ci[1] * t[1] + Ci[2] * t[2];
         const double yp1 = Ci[1] * t[0] + Ci[3] * t[1] + Ci[4] * t[2];
         const double yp2 = Ci[2] * t[0] + Ci[4] * t[1] + Ci[5] * t[2];
         const double stp[3] = {-yp0, -yp1, -yp2};
-        double st3[3];
+        const double* sp = D.scale_p + 3 * (size_t)p;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          st3[k] = stp[k] * D.scale_p[3 * (size_t)p + k];
-          const double xo = D.pts[3 * (size_t)p + k], xn = xo + st3[k];
+          const double xo = D.pts[3 * (size_t)p + k], xn = xo + stp[k] * sp[k];
           D.cand_pts[3 * (size_t)p + k] = xn;
           const double e = xo - xn; acc[1] += e * e;
         }
-        sx = st3[0]; sy = st3[1]; sz = st3[2];
+        // The point's share of the model cost change -(g . s + s^T H s / 2) (Ceres: -sum over the residual blocks of
+        // m . (r + m / 2), m = J s - the same quadratic form; round 4: it was summed per observation from 160 bytes of stored
+        // Jacobians each): g_p . s_p + s_p^T C_s s_p / 2 + s_p . sum_i E_i^T s_c(i), with the scaled step s_p, the scaled landmark
+        // block WITHOUT the damping and s_c = -y, i.e. the last term is -s_p . T.  The cameras' share comes from k_ba_cam_update.
+        const double* Cu = D.C + 6 * (size_t)p;
+        const double c00 = Cu[0] * sp[0] * sp[0], c01 = Cu[1] * sp[0] * sp[1], c02 = Cu[2] * sp[0] * sp[2], c11 = Cu[3] * sp[1] * sp[1], c12 = Cu[4] * sp[1] * sp[2],
+                     c22 = Cu[5] * sp[2] * sp[2];
+        const double gs = g0 * stp[0] + g1 * stp[1] + g2 * stp[2];
+        const double q = stp[0] * (c00 * stp[0] + c01 * stp[1] + c02 * stp[2]) + stp[1] * (c01 * stp[0] + c11 * stp[1] + c12 * stp[2]) +
+                         stp[2] * (c02 * stp[0] + c12 * stp[1] + c22 * stp[2]);
+        const double cross = -(stp[0] * T0 + stp[1] * T1 + stp[2] * T2);
+        acc[0] = -(gs + q / 2 + cross);
       } else {
         for (int k = 0; k < 3; k++) D.cand_pts[3 * (size_t)p + k] = D.pts[3 * (size_t)p + k];
       }
     }
-    s_step[tid][0] = sx; s_step[tid][1] = sy; s_step[tid][2] = sz;
   }
-  __syncthreads();
-  // model residual of every observation: m = Jc_s step_c + Jp_s step_p
-  if (ok)
-    for (int i = olo + tid; i < ohi; i += BS_TPB) {
-      const int cc = D.cam_col[D.obs_cam[i]];
-      double m0 = 0, m1 = 0;
-      if (cc >= 0) {
-        const double* y = D.rhs + 6 * cc;
-        const double* sc = D.scale_c + 6 * (size_t)cc;
-#pragma unroll
-        for (int u = 0; u < 6; u++) { const double sv = -y[u] * sc[u]; m0 += D.Jc[u * n + i] * sv; m1 += D.Jc[(6 + u) * n + i] * sv; }
-      }
-      if (!D.fix_points) {
-        const double* sp = s_step[D.obs_pt[i] - p0];
-#pragma unroll
-        for (int v = 0; v < 3; v++) { m0 += D.Jp[v * n + i] * sp[v]; m1 += D.Jp[(3 + v) * n + i] * sp[v]; }
-      }
-      acc[0] -= m0 * (D.r[i] + m0 / 2) + m1 * (D.r[n + i] + m1 / 2);
-    }
   block_reduce_wide<2>(acc, s_red, s_out);
   if (tid == 0) { D.part[3 * D.nparts + blockIdx.x] = s_out[0]; D.part[4 * D.nparts + blockIdx.x] = s_out[1]; }
 }
@@ -3326,7 +3332,7 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(const BaDev* __restrict_
   double acc[3] = {0.0, 0.0, 0.0};           // candidate cost, model cost change, |dx|^2
   for (int b = tid; b < nb_obs; b += BA_TPB) acc[0] += D.part[D.nparts + b];
   for (int b = tid; b < nb_pt; b += BA_TPB) { acc[1] += D.part[3 * D.nparts + b]; acc[2] += D.part[4 * D.nparts + b]; }
-  for (int b = tid; b < nb_cam; b += BA_TPB) acc[2] += D.part[2 * D.nparts + b];
+  for (int b = tid; b < nb_cam; b += BA_TPB) { acc[2] += D.part[2 * D.nparts + b]; acc[1] += D.part[5 * D.nparts + b]; }
   block_reduce<3>(acc, s_red, s_out);
   if (tid != 0) return;
   const double mcc = s_out[1];
@@ -3405,7 +3411,7 @@ __global__ __launch_bounds__(256) void k_ba_init(const BaDev* __restrict__ Dv, B
   const BaDev D = Dv[blockIdx.y];
   const int n = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
   for (int i = i0; i < D.npad; i += n) D.rhs[i] = 0.0;
-  for (int i = i0; i < 5 * D.nparts; i += n) D.part[i] = 0.0;
+  for (int i = i0; i < 6 * D.nparts; i += n) D.part[i] = 0.0;
   if (i0 == 0) *D.st = st0;
 }
 __global__ __launch_bounds__(256) void k_ba_collect(const BaDev* __restrict__ Dv, int with_erase) {
@@ -4029,7 +4035,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.blk_a = H.arena2_dev(H.arena2_copy(blk_a.data(), nblk, &rc)); D.blk_b = H.arena2_dev(H.arena2_copy(blk_b.data(), nblk, &rc));
   D.blk_off = H.arena2_dev(H.arena2_copy(blk_off.data(), 2 * (size_t)nblk, &rc));
   D.pair_i = H.arena2_dev(pair_i); D.pair_j = H.arena2_dev(pair_j);
-  D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jc = H.alloc<double>(12 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
+  D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
   D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
   D.C = H.alloc<double>(6 * (size_t)npts, &rc); D.gp = H.alloc<double>(3 * (size_t)npts, &rc);
   D.scale_c = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc); D.scale_p = H.alloc<double>(3 * (size_t)npts, &rc);
@@ -4041,7 +4047,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
   D.Dinv = H.alloc<double>((size_t)npad * NB, &rc);
   D.Mb = H.alloc<double>((size_t)npad * NB, &rc); { const int nbm = npad / NB, ntm = (nbm + 1) / 2; D.ncflags = std::max(256 /* CP_NFLAGS */, 2 + 3 * (nbm + 2) + ntm * ntm + 8); D.cflags = H.alloc<int>(D.ncflags, &rc); }
-  D.part = H.alloc<double>(5 * (size_t)nparts, &rc);
+  D.part = H.alloc<double>(6 * (size_t)nparts, &rc);
   D.st = H.alloc<BaState>(1, &rc);
   if (rc) return rc;
   out->h_st = nullptr;                                        // (the LM state, rhs and partial sums are initialised by k_ba_init for the whole batch)
