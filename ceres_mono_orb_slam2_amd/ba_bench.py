@@ -65,7 +65,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     # in flight from host threads (one HIP stream + device workspace per thread)
     # (64 per call since round 2: the lockstep launches are bound by the sum of their kernels' exclusive times - ~0.85 ms of GPU
     # per solve - and larger launches fill the chip better: 16 x 8 -> 1110, 32 x 8 -> 1170, 64 x 8 -> 1270 solves/s)
-    nbatch, nthreads, n_each = 64, 8, 3
+    nbatch, nthreads, n_each = 64, 12, 2      # (12 threads x 64 problems: 1737 - 1791 solves/s against 1552 - 1698 with 8, tools/ba_batch_thr.py)
     gs = [g] + [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(1, nbatch)]   # 64 distinct local maps
     probs = [(q["K4"], q["poses0"], q["cam_fixed"], local, q["pts0"], q["obs_cam"], q["obs_pt"], q["obs_uv"], q["obs_inv_sigma2"]) for q in gs]
     fl_batch = sum(sum(reduced_solve_flops(q)) for q in gs)

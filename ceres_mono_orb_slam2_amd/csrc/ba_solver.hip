@@ -1029,7 +1029,8 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
   }
   // (3) off-diagonal blocks (a, b) of the row: one wave per block, four at a time
   // (tried: 512 threads with a PAIR of waves per block, each half of the 6 x 6 product, under a 128-register cap for 16 waves per CU:
-  // 43 spilled registers, 843 us instead of 638 per 64-problem launch)
+  // 43 spilled registers, 843 us instead of 638 per 64-problem launch; HALF a wave per block, eight blocks at a time, the 36 sums
+  // over 32 lanes serving two blocks: 682 us against 652 - the four gather trips of 32 lanes cost more than the cheaper reduction saves)
   for (int blk = D.row_off[a] + w; blk < D.row_off[a + 1]; blk += SC_TPB / 64) {
     const int b = D.blk_b[blk];
     double a36[36];
