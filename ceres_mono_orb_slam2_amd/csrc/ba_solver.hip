@@ -959,6 +959,26 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
   __shared__ double s_red[(SC_TPB / 64) * 27], s_out[27];
   const int ca = D.free_cams[a];
   const int lo_a = D.cam_off[ca], n_a = D.cam_off[ca + 1] - lo_a;
+  // Every list index the phases below gather through is requested HERE, in one batch: a phase then costs one dependent round trip
+  // (index -> record) less - the kernel is bound by those round trips, not by bytes.  Diagonal block: three trips of the 256 threads;
+  // off-diagonal blocks: this wave's first SR_KB blocks, two trips of 64 lanes each (longer lists / more blocks load on the fly).
+  constexpr int SR_KB = 3;
+  const int d_lo = D.blk_off[2 * a], d_hi = D.blk_off[2 * a + 1];
+  const int r_lo = D.row_off[a], r_hi = D.row_off[a + 1];
+  int dj[3], di[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) { const int e = d_lo + tid + SC_TPB * t; dj[t] = e < d_hi ? D.pair_j[e] : -1; di[t] = e < d_hi ? D.pair_i[e] : 0; }
+  int ob[SR_KB], oe0[SR_KB], oe1[SR_KB], oj[SR_KB][2], oi[SR_KB][2];
+#pragma unroll
+  for (int k = 0; k < SR_KB; k++) {
+    const int blk = r_lo + w + (SC_TPB / 64) * k;
+    const bool vb = blk < r_hi;
+    ob[k] = vb ? D.blk_b[blk] : 0; oe0[k] = vb ? D.blk_off[2 * blk] : 0; oe1[k] = vb ? D.blk_off[2 * blk + 1] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < SR_KB; k++)
+#pragma unroll
+    for (int t = 0; t < 2; t++) { const int e = oe0[k] + lane + 64 * t; oj[k][t] = e < oe1[k] ? D.pair_j[e] : -1; oi[k][t] = e < oe1[k] ? D.pair_i[e] : 0; }
   // (1) camera a's records -> LDS, and the rhs of camera a (its own block reduction: the six sums are not kept alive through (2))
   {
     double g6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -996,10 +1016,9 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
     double acc[21];
 #pragma unroll
     for (int k = 0; k < 21; k++) acc[k] = 0.0;
-    for (int e = D.blk_off[2 * a] + tid; e < D.blk_off[2 * a + 1]; e += SC_TPB) {
+    auto diag_pair = [&](int pj, int pos) {
       double y[18];
-      ld_rec18(D.E, nobs, (size_t)D.pair_j[e], y);
-      const int pos = D.pair_i[e];
+      ld_rec18(D.E, nobs, (size_t)pj, y);
       if (pos < SR_CH) {
 #pragma unroll
         for (int u = 0; u < 6; u++) {
@@ -1015,7 +1034,10 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
 #pragma unroll
           for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
       }
-    }
+    };
+#pragma unroll
+    for (int t = 0; t < 3; t++) if (dj[t] >= 0) diag_pair(dj[t], di[t]);
+    for (int e = d_lo + tid + 3 * SC_TPB; e < d_hi; e += SC_TPB) diag_pair(D.pair_j[e], D.pair_i[e]);
     block_reduce_dpp<21>(acc, s_red, s_out);
     if (tid < 21) {
       int u = 0;
@@ -1031,15 +1053,19 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
   // (tried: 512 threads with a PAIR of waves per block, each half of the 6 x 6 product, under a 128-register cap for 16 waves per CU:
   // 43 spilled registers, 843 us instead of 638 per 64-problem launch; HALF a wave per block, eight blocks at a time, the 36 sums
   // over 32 lanes serving two blocks: 682 us against 652 - the four gather trips of 32 lanes cost more than the cheaper reduction saves)
-  for (int blk = D.row_off[a] + w; blk < D.row_off[a + 1]; blk += SC_TPB / 64) {
-    const int b = D.blk_b[blk];
+  int kb = 0;
+  for (int blk = r_lo + w; blk < r_hi; blk += SC_TPB / 64, kb++) {
+    const bool pre = kb < SR_KB;
+    int b = 0, e0 = 0, e1 = 0, pj0 = -1, pj1 = -1, pi0 = 0, pi1 = 0;
+#pragma unroll
+    for (int k = 0; k < SR_KB; k++) if (kb == k) { b = ob[k]; e0 = oe0[k]; e1 = oe1[k]; pj0 = oj[k][0]; pj1 = oj[k][1]; pi0 = oi[k][0]; pi1 = oi[k][1]; }
+    if (!pre) { b = D.blk_b[blk]; e0 = D.blk_off[2 * blk]; e1 = D.blk_off[2 * blk + 1]; }
     double a36[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) a36[k] = 0.0;
-    for (int e = D.blk_off[2 * blk] + lane; e < D.blk_off[2 * blk + 1]; e += 64) {
+    auto off_pair = [&](int pj, int pos) {
       double x[18], y[18];
-      ld_rec18(D.E, nobs, (size_t)D.pair_j[e], y);
-      const int pos = D.pair_i[e];
+      ld_rec18(D.E, nobs, (size_t)pj, y);
       if (pos < SR_CH) {
 #pragma unroll
         for (int k = 0; k < 18; k++) x[k] = s_ec[pos * SR_PITCH + k];
@@ -1048,6 +1074,13 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
       for (int u = 0; u < 6; u++)
 #pragma unroll
         for (int v = 0; v < 6; v++) a36[6 * u + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
+    };
+    if (pre) {
+      if (pj0 >= 0) off_pair(pj0, pi0);
+      if (pj1 >= 0) off_pair(pj1, pi1);
+      for (int e = e0 + lane + 128; e < e1; e += 64) off_pair(D.pair_j[e], D.pair_i[e]);
+    } else {
+      for (int e = e0 + lane; e < e1; e += 64) off_pair(D.pair_j[e], D.pair_i[e]);
     }
     double mine = 0.0;
 #pragma unroll
