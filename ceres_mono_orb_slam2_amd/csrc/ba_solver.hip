@@ -4500,7 +4500,7 @@ int pg_solve_impl(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* e
   P.vpart = H.alloc<double>(2 * (size_t)n, &rc);
   P.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); P.rhs = H.alloc<double>(npad, &rc);
   double* Dinv = H.alloc<double>((size_t)npad * NB, &rc);
-  P.part = H.alloc<double>(5 * (size_t)nparts, &rc);
+  P.part = H.alloc<double>(6 * (size_t)nparts, &rc);      // (row 5: the cameras' share of the model cost change in the BA kernels; k_ba_iter_end reads it - zero here)
   P.st = H.alloc<BaState>(1, &rc);
   if (rc) return rc;
   // the view through which the shared Cholesky / controller kernels see this problem (sizes chosen so that k_ba_iter_end
@@ -4517,7 +4517,7 @@ int pg_solve_impl(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* e
   st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = max_iterations;
   ORBHIP_CHECK_HIP(hipMemcpyAsync(P.st, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
   ORBHIP_CHECK_HIP(hipMemsetAsync(P.rhs, 0, (size_t)npad * sizeof(double), s));
-  ORBHIP_CHECK_HIP(hipMemsetAsync(P.part, 0, 5 * (size_t)nparts * sizeof(double), s));
+  ORBHIP_CHECK_HIP(hipMemsetAsync(P.part, 0, 6 * (size_t)nparts * sizeof(double), s));
   if (npad > n7) hipLaunchKernelGGL(k_pg_pad, dim3(npad - n7), dim3(64), 0, s, P);
   auto enqueue_eval = [&]() {
     hipLaunchKernelGGL(k_pg_eval, dim3(nb_e), dim3(128), 0, s, P, 0);
