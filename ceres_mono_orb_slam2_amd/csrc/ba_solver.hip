@@ -1803,23 +1803,31 @@ __global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, i
 //                        row is z and whose other rows are zero (k_chol_la's role A sees the row exactly like that).
 #define CW_TPB 256
 #define CW_NW (CW_TPB / 64)
+#ifndef CW_RPW
 #define CW_RPW 2                       /* block rows per wave and group: eight rows of a column are in flight per workgroup */
+#endif
+#define CW_NSCA (CW_RPW == 1 ? CW_NW - 1 : CW_NW * CW_RPW)      /* scratch tiles: with one row per wave, wave 0 borrows D_c's tile (it is the diagonal wave in the group that factors) */
 #define CW_TILE (NB * (NB + 1))
 /* LDS: L(c, j) twice (double buffer), a scratch tile per (wave, row slot), X_c, D_c, the factor's column buffer, the rhs row's
    z(j) twice: 118 KB - one workgroup per CU, which the register count (one wave per SIMD, three operand sets in flight) implies anyway */
-#define CW_LDS_DOUBLES ((4 + CW_NW * CW_RPW) * CW_TILE + NB * 64 + 2 * NB)
-__global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv) {
+#define CW_LDS_DOUBLES ((4 + CW_NSCA) * CW_TILE + NB * 64 + 2 * NB)
+#if CW_RPW == 1
+#define CW_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define CW_ATTR
+#endif
+__global__ __launch_bounds__(CW_TPB) CW_ATTR void k_chol_wg(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.x];
   if (!D.chol_la) return;
   BaState* st = D.st;
   const StFlags F = ld_flags(st);
   if (F.done || !F.valid || F.chol_fail) return;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  constexpr int NSC = CW_NW * CW_RPW;
-  double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + NSC) * CW_TILE);
-  double (*s_L)[NB + 1] = (double (*)[NB + 1])(s_dyn + (3 + NSC) * CW_TILE);
-  double (*s_T)[64] = (double (*)[64])(s_dyn + (4 + NSC) * CW_TILE);            // 16-byte aligned: a multiple of 32 * 33 * 8 bytes
-  double* s_z = s_dyn + (4 + NSC) * CW_TILE + NB * 64;                          // [2][NB]
+  constexpr int NSC = CW_NW * CW_RPW, NSCA = CW_NSCA;
+  double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + NSCA) * CW_TILE);
+  double (*s_L)[NB + 1] = (double (*)[NB + 1])(s_dyn + (3 + NSCA) * CW_TILE);
+  double (*s_T)[64] = (double (*)[64])(s_dyn + (4 + NSCA) * CW_TILE);           // 16-byte aligned: a multiple of 32 * 33 * 8 bytes
+  double* s_z = s_dyn + (4 + NSCA) * CW_TILE + NB * 64;                         // [2][NB]
   __shared__ int s_fail, s_col;
   const int np = D.npad, nb = np / NB, tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
@@ -1939,7 +1947,7 @@ __global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv
       const int lset = upd ? (c - 1) & 1 : 0;
 #pragma unroll
       for (int t = 0; t < CW_RPW; t++) {
-        double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + CW_RPW * w + t) * CW_TILE);
+        double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (CW_RPW == 1 ? (w == 0 ? 3 + NSCA : 1 + w) : 2 + CW_RPW * w + t) * CW_TILE);
 #pragma unroll
         for (int I = 0; I < 2; I++)
 #pragma unroll
@@ -2008,7 +2016,7 @@ __global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv
         }
 #pragma unroll
         for (int t = 0; t < CW_RPW; t++) {
-          double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + CW_RPW * w + t) * CW_TILE);
+          double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (CW_RPW == 1 ? (w == 0 ? 3 + NSCA : 1 + w) : 2 + CW_RPW * w + t) * CW_TILE);
           if (valid[t] && !is_diag[t]) {
 #pragma unroll
             for (int I = 0; I < 2; I++)
@@ -2031,7 +2039,7 @@ __global__ __launch_bounds__(CW_TPB) void k_chol_wg(const BaDev* __restrict__ Dv
         for (int i = tid; i < NB * NB; i += CW_TPB) Di[i] = s_X[i / NB][i % NB];
 #pragma unroll
         for (int t = 0; t < CW_RPW; t++) {
-          double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + CW_RPW * w + t) * CW_TILE);
+          double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (CW_RPW == 1 ? (w == 0 ? 3 + NSCA : 1 + w) : 2 + CW_RPW * w + t) * CW_TILE);
           const bool back = valid[t] && !is_diag[t];              // (assigned on every path: nothing is live across the factor)
 #pragma unroll
           for (int I = 0; I < 2; I++)
