@@ -42,6 +42,7 @@
 #include "common.h"
 #include "ba_math.h"
 #include "handoff.h"
+#include "wave_reduce.h"
 #include "sim3_math.h"
 
 namespace orbhip {
@@ -611,8 +612,9 @@ struct BaDev {            // device pointers of one problem
   double* Mb;                        // persistent Cholesky: M_k = X_k P_k of every step [npad/32][32][32]
   int* cflags;                       // persistent Cholesky: hand-off flags of this problem [ncflags], zeroed by k_ba_iter_begin
   int ncflags;
-  const int* blk_a; const int* blk_b; const int* blk_off; const int* pair_i; const int* pair_j; int nblk;   // Schur block pair lists (pair_i: POSITION of the observation in its camera's list, pair_j: observation index)
-  const int* row_off;                // [nfc+1] the off-diagonal blocks (a, .) of block row a: blk indices row_off[a] .. row_off[a+1]
+  const int* pair_i; const int* pair_j;   // Schur pair lists, block after block in (a, b) order, a <= b (pair_i: POSITION of camera a's observation in its camera's list, pair_j: camera b's observation as its index in camera-major order = E record)
+  const int4* row_meta;              // [nfc][2] block row a: {first, end of the diagonal block's pairs, first, end of the row's segments}, {first entry, length of camera a's list, -, -}
+  const int4* seg;                   // the off-diagonal blocks cut into SEGMENTS of <= SR_SEG pairs: {first pair, end, column b, 1 = first | 2 = last segment of its block}
   const int* free_cams;              // [nfc] reduced column -> camera index
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
@@ -854,14 +856,15 @@ __device__ __forceinline__ void ld_rec18(const double* __restrict__ base, size_t
   x[16] = t.x; x[17] = t.y;
 }
 
-// per observation: E = (Jc S_c)^T (Jp S_p) (6x3), stored as 18-double records (ld_rec18).  E depends on the iterate and on the
-// Jacobi scaling only - not on the LM radius - so it is written when the iterate has changed (after_eval raises e_dirty, the
-// next k_ba_iter_begin clears it) instead of in every LM iteration, and E (C_s+D)^-1, which does depend on the radius, is no
-// longer stored at all: k_ba_schur forms it on the fly from E and the point's (C_s+D)^-1 (round 4: k_ba_schur_prep_obs read
-// Jc, Jp and wrote E AND E (C+D)^-1 in every iteration - 432 bytes per observation, the fourth most expensive kernel of a
-// batched solve).  The Jacobians are RECOMPUTED here from the observation (the same reproj_eval on the same iterate: the same
-// bits k_ba_eval saw), which is why k_ba_eval no longer stores the camera Jacobians in observation order.  Every wave
-// transposes its 64 x 18 results through LDS so that the records are written as contiguous 512-byte runs.
+// per observation: E = (Jc S_c)^T (Jp S_p) (6x3), stored as 18-double records (ld_rec18) in CAMERA-MAJOR order (record index =
+// cam_pos[i], the position of the observation in the concatenated per-camera lists): k_ba_schur then streams camera a's records and
+// the records it gathers from a camera b ascend inside b's contiguous run (neighbouring keyframes share most of their points: nearly
+// sequential).  E depends on the iterate and on the Jacobi scaling only - not on the LM radius - so it is written when the iterate has
+// changed (after_eval raises e_dirty, the next k_ba_iter_begin clears it) instead of in every LM iteration, and E (C_s+D)^-1, which
+// does depend on the radius, is not stored at all: k_ba_schur forms it on the fly from E and the point's (C_s+D)^-1 (round 4:
+// k_ba_schur_prep_obs read Jc, Jp and wrote E AND E (C+D)^-1 in every iteration - 432 bytes per observation).  The Jacobians are
+// RECOMPUTED here from the observation (the same reproj_eval on the same iterate: the same bits k_ba_eval saw), which is why
+// k_ba_eval does not store the camera Jacobians in observation order.
 __global__ __launch_bounds__(BA_TPB) void k_ba_E(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
@@ -870,17 +873,16 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_E(const BaDev* __restrict__ Dv) {
   if (F.done || !dirty || D.fix_points) return;
   if ((int)blockIdx.x * BA_TPB >= D.nobs) return;
   __shared__ double s_t[BA_TPB / 64][64][19];          // + 1 pad
+  __shared__ int s_q[BA_TPB / 64][64];                 // record index of the wave's observations (-1: fixed camera / beyond the end)
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i0 = blockIdx.x * BA_TPB + 64 * w;         // first observation of this wave
   const int c = (i < D.nobs) ? D.obs_cam[i] : 0;
   const int cc = (i < D.nobs) ? D.cam_col[c] : -1;
   const bool act = cc >= 0;
-  const unsigned long long amask = __ballot(act);
-  double e[18];
+  s_q[w][lane] = act ? D.cam_pos[i] : -1;
   if (act) {
     const int p = D.obs_pt[i];
-    double r[2], Jc[12], Jp[6];
+    double r[2], Jc[12], Jp[6], e[18];
     (void)reproj_eval(D.K4 + 4 * c, D.poses + 7 * c, D.pts + 3 * (size_t)p, D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
                       D.obs_w[i], D.obs_robust[i], D.huber, r, Jc, Jp);
     const double* sc = D.scale_c + 6 * (size_t)cc;
@@ -897,17 +899,16 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_E(const BaDev* __restrict__ Dv) {
     for (int k = 0; k < 18; k++) s_t[w][lane][k] = e[k];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-  double* dst = D.E + 16 * (size_t)i0;                                   // (record layout: ld_rec18)
-  double* dtail = D.E + 16 * (size_t)D.nobs + 2 * (size_t)i0;
-  const int rows = min(64, D.nobs - i0);
-  for (int idx = lane; idx < 16 * rows; idx += 64) {
-    const int r = idx >> 4, k = idx & 15;
-    if ((amask >> r) & 1ull) dst[idx] = s_t[w][r][k];
+  // The records go to scattered places (camera-major order, the wave's observations are a run of the point-major order): eight
+  // lanes write one record's 128-byte line per store instruction - whole lines, not 64 sixteen-byte pieces of 64 lines.
+  double* tail = D.E + 16 * (size_t)D.nobs;
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const int idx = lane + 64 * t, rr = idx >> 3, part = idx & 7;
+    const int q = s_q[w][rr];
+    if (q >= 0) *(double2*)(D.E + 16 * (size_t)q + 2 * part) = make_double2(s_t[w][rr][2 * part], s_t[w][rr][2 * part + 1]);
   }
-  for (int idx = lane; idx < 2 * rows; idx += 64) {
-    const int r = idx >> 1, k = 16 + (idx & 1);
-    if ((amask >> r) & 1ull) dtail[idx] = s_t[w][r][k];
-  }
+  { const int q = s_q[w][lane]; if (q >= 0) *(double2*)(tail + 2 * (size_t)q) = make_double2(s_t[w][lane][16], s_t[w][lane][17]); }
 }
 // x = E (C_s+D)^-1 of one record (the arithmetic of the former k_ba_schur_prep_obs, formed where it is used)
 __device__ __forceinline__ void e_times_cinv(const double* __restrict__ e, const double* __restrict__ Ci, double* __restrict__ x) {
@@ -922,21 +923,37 @@ __device__ __forceinline__ void e_times_cinv(const double* __restrict__ e, const
 }
 
 // ---- reduced camera system S = B_s + D - sum E (C_s+D)^-1 E^T over the non-empty block pairs (a <= b) ----------------
-// Round 4: ONE WORKGROUP PER BLOCK ROW (free camera a).  The pair lists gather two 144-byte records per pair - x = E_i (C+D)^-1 of
-// camera a's observation and y = E_j of camera b's: 3 GB per launch of a 64-problem batch, the most expensive kernel of a batched
-// solve, bound by the gathers (4 TB/s).  Every x of a row belongs to camera a, so the workgroup forms x = E (C_s+D)^-1 ONCE per
-// observation of camera a (k_ba_schur_prep_obs used to store it for every observation in every iteration; a first version formed
-// it per PAIR inside the pair loop and was 35 % slower), keeps the records in LDS - pair_i holds the POSITION of the observation in
-// its camera's list - and only the y records are gathered: half the bytes.  The same pass over camera a's list builds the rhs
-//   rhs_a = g_s - sum over the camera's observations of EC_i * g_p.
+// ONE WORKGROUP PER BLOCK ROW (free camera a).  Every pair of the row multiplies x = E_i (C+D)^-1 of an observation i of camera a
+// with y = E_j of the observation j of the same point by a camera b >= a.  The workgroup forms x ONCE per observation of camera a
+// (camera a's records are a contiguous run: streamed), keeps the 18 values in LDS by list position (pair_i) and gathers only y.
+//
+// The kernel is bound by the latency of its dependent loads - at 78 KB of LDS per workgroup a SIMD holds two waves, and a gather of
+// 64 scattered records takes ~3 us under load (tools/schur_prof.py, in-kernel stamps of a 64-problem C4 batch: 52 us per workgroup,
+// of which 16 the pass over camera a's list, 8 the diagonal block, 26 the off-diagonal blocks on the wave that drew the longest
+// lists - the pair lists of a SLAM graph are skewed: half of C4's blocks hold <= 67 pairs, the neighbouring keyframes' 350 ... 490).
+// So the structure follows the round trips, not the flops:
+//  (1) the pass over camera a's list builds the records, the rhs  rhs_a = g_s - sum EC_i g_p  AND the diagonal block (x and y of a
+//      diagonal pair belong to the SAME observation - the pair list of block (a, a) is the camera's list unless the camera sees a
+//      point twice; such rows walk the literal list afterwards), two list entries per thread in flight, one reduction of 27 sums;
+//  (2) the off-diagonal blocks are cut into SEGMENTS of <= SR_SEG = 128 pairs (host: seg[]), dealt round-robin to the four waves:
+//      round r, wave w takes segment 4 r + w - a 490-pair block is four waves' work, not one's.  Both gathers of a segment
+//      (2 x 64 lanes) are in flight together, the next round's are issued before this round's 36 wave sums, the indices two
+//      rounds ahead; lanes without a pair read a zero record from LDS and a valid y (no branches around the loads).
+//      A wave leaves its 36 sums in a mailbox; behind the round's barrier wave 0 adds the segments of a block in list order
+//      (fixed order: the result does not depend on timing) and stores block (b, a) = -(sum)^T.
 // Records beyond SR_CH observations of one camera do not fit the LDS and are formed from global memory where they are used.
-// The arithmetic per block is the former kernel's: diagonal block + rhs by the 256 threads (pair e of the list by thread e mod 256,
-// one fixed-order block reduction of 27 values), every off-diagonal block (a, b) by ONE WAVE (all 36 products in registers, DPP
-// wave sum) - four blocks of the row at a time.
+#ifdef ORBHIP_SCHUR_PROF
+extern __device__ unsigned long long g_chol_prof[128][10];
+#define SR_STAMP(col, cond) do { if (sr_prof && (cond)) g_chol_prof[a & 127][col] += __builtin_amdgcn_s_memrealtime() - sr_t0; } while (0)
+#else
+#define SR_STAMP(col, cond) do { } while (0)
+#endif
 #define SC_TPB 256
-#define SR_CH 512                      /* records in LDS: 512 x 19 doubles = 77.8 KB, two workgroups per CU */
+#define SR_CH 512                      /* records in LDS: (512 + 1) x 19 doubles = 78.0 KB, two workgroups per CU */
 #define SR_PITCH 19
-__global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ Dv) {
+#define SR_SEG 128                     /* pairs per segment: two gathers of 64 lanes (host: the seg[] list) */
+#define SR_LDS_BYTES ((SR_CH + 1) * SR_PITCH * sizeof(double))
+__global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_schur(const BaDev* __restrict__ Dv) {
   // Workgroup -> (problem, block row).  The y records a row gathers belong to the cameras that share points with camera a - in a
   // SLAM map mostly the next few keyframes -, i.e. to rows that run at about the same time; the dispatcher deals consecutive
   // workgroup ids out over the 8 XCDs (one L2 each), so with the plain mapping those rows meet eight different L2s.  When the batch
@@ -952,120 +969,131 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
   const StFlags F = ld_flags(st);
   if (F.done || !F.valid) return;
   if (a >= D.nfc) return;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int np = D.npad;
   const size_t nobs = (size_t)D.nobs;
-  extern __shared__ __attribute__((aligned(16))) double s_ec[];       // [SR_CH][SR_PITCH]
-  __shared__ double s_red[(SC_TPB / 64) * 27], s_out[27];
-  const int ca = D.free_cams[a];
-  const int lo_a = D.cam_off[ca], n_a = D.cam_off[ca + 1] - lo_a;
-  // Every list index the phases below gather through is requested HERE, in one batch: a phase then costs one dependent round trip
-  // (index -> record) less - the kernel is bound by those round trips, not by bytes.  Diagonal block: three trips of the 256 threads;
-  // off-diagonal blocks: this wave's first SR_KB blocks, two trips of 64 lanes each (longer lists / more blocks load on the fly).
-  constexpr int SR_KB = 3;
-  const int d_lo = D.blk_off[2 * a], d_hi = D.blk_off[2 * a + 1];
-  const int r_lo = D.row_off[a], r_hi = D.row_off[a + 1];
-  int dj[3], di[3];
-#pragma unroll
-  for (int t = 0; t < 3; t++) { const int e = d_lo + tid + SC_TPB * t; dj[t] = e < d_hi ? D.pair_j[e] : -1; di[t] = e < d_hi ? D.pair_i[e] : 0; }
-  int ob[SR_KB], oe0[SR_KB], oe1[SR_KB], oj[SR_KB][2], oi[SR_KB][2];
-#pragma unroll
-  for (int k = 0; k < SR_KB; k++) {
-    const int blk = r_lo + w + (SC_TPB / 64) * k;
-    const bool vb = blk < r_hi;
-    ob[k] = vb ? D.blk_b[blk] : 0; oe0[k] = vb ? D.blk_off[2 * blk] : 0; oe1[k] = vb ? D.blk_off[2 * blk + 1] : 0;
-  }
-#pragma unroll
-  for (int k = 0; k < SR_KB; k++)
-#pragma unroll
-    for (int t = 0; t < 2; t++) { const int e = oe0[k] + lane + 64 * t; oj[k][t] = e < oe1[k] ? D.pair_j[e] : -1; oi[k][t] = e < oe1[k] ? D.pair_i[e] : 0; }
-  // (1) camera a's records -> LDS, and the rhs of camera a (its own block reduction: the six sums are not kept alive through (2))
-  {
-    double g6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (!D.fix_points) {
-      for (int t = tid; t < n_a; t += SC_TPB) {
-        const int e = lo_a + t, pt = D.cam_obs_pt[e];
-        double ei[18], ec[18];
-        ld_rec18(D.E, nobs, (size_t)D.cam_obs[e], ei);
-        e_times_cinv(ei, D.Cinv + 6 * (size_t)pt, ec);
-        if (t < SR_CH) {
-#pragma unroll
-          for (int k = 0; k < 18; k++) s_ec[t * SR_PITCH + k] = ec[k];
-        }
-        const double* g = D.gps + 3 * (size_t)pt;
-#pragma unroll
-        for (int u = 0; u < 6; u++) g6[u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
-      }
+#ifdef ORBHIP_SCHUR_PROF
+  const bool sr_prof = prob == 0 && lane == 0; const unsigned long long sr_t0 = __builtin_amdgcn_s_memrealtime();
+  if (sr_prof && w == 0) g_chol_prof[a & 127][9] += 1;
+#endif
+  extern __shared__ __attribute__((aligned(16))) double s_ec[];       // [SR_CH + 1][SR_PITCH]; record SR_CH = zeros
+  __shared__ double s_w[2 * 4 * 36];                                  // (1): s_red [4][27], s_out [27]; (2): the mailboxes [2][4][36]
+  __shared__ int s_mf[2][4][2];                                       // mailbox labels: {column b or -1, segment flags}
+  double* s_red = s_w; double* s_out = s_w + 4 * 27;
+  const int4 rm = D.row_meta[2 * a], rm2 = D.row_meta[2 * a + 1];   // (one round trip: not free_cams -> cam_off -> list)
+  const int lo_a = rm2.x, n_a = rm2.y;
+  const int d_lo = rm.x, d_hi = rm.y, s_lo = rm.z, s_hi = rm.w;
+  const bool fuse = (d_hi - d_lo) == n_a;                              // the diagonal block's pair list IS the camera's list
+  const int R = (s_hi - s_lo + 3) >> 2;                                // rounds of (2)
+  if (tid < SR_PITCH) s_ec[SR_CH * SR_PITCH + tid] = 0.0;
+  // ---- segment bookkeeping of (2); the first requests go out before (1) so that their round trips overlap it ----
+  struct Idx { int pj0, pj1, pi0, pi1; };
+  auto ld_meta = [&](int r) -> int4 {
+    const int g = s_lo + w + 4 * r;
+    return (g < s_hi) ? D.seg[g] : make_int4(0, 0, -1, 0);
+  };
+  auto ld_idx = [&](const int4& m) -> Idx {
+    Idx x; x.pj0 = x.pj1 = 0; x.pi0 = x.pi1 = -1;
+    if (m.z >= 0) {                                                    // (wave-uniform)
+      const int e0 = m.x + lane, e1 = m.x + 64 + lane;
+      const bool v0 = e0 < m.y, v1 = e1 < m.y;
+      x.pj0 = D.pair_j[v0 ? e0 : m.x]; x.pj1 = D.pair_j[v1 ? e1 : m.x];   // (a lane without a pair gathers the segment's first y: finite wherever the block is)
+      const int p0 = D.pair_i[v0 ? e0 : m.x], p1 = D.pair_i[v1 ? e1 : m.x];
+      x.pi0 = v0 ? p0 : -1; x.pi1 = v1 ? p1 : -1;
     }
-    block_reduce_dpp<6>(g6, s_red, s_out);                     // (its barriers also publish the records)
-    if (tid < 6) {
-      const double rv = D.gc[6 * (size_t)a + tid] * D.scale_c[6 * (size_t)a + tid] - s_out[tid];
-      D.rhs[6 * a + tid] = rv;
-      D.S[(size_t)np * np + 6 * a + tid] = rv;                 // augmented row: forward substitution rides the factorisation
-    }
-    __syncthreads();
-  }
+    return x;
+  };
   auto get_x = [&](int pos, double* x) {                       // (a camera with more observations than the LDS holds)
     const int e = lo_a + pos;
     double ei[18];
-    ld_rec18(D.E, nobs, (size_t)D.cam_obs[e], ei);
+    ld_rec18(D.E, nobs, (size_t)e, ei);
     e_times_cinv(ei, D.Cinv + 6 * (size_t)D.cam_obs_pt[e], x);
   };
-  // (2) diagonal block (a, a): 21 lower-triangle products per pair; x row by row from LDS (not 18 values held beside y and the sums)
-  {
-    double acc[21];
+  // ---- (1) camera a's records -> LDS, the rhs of camera a and the diagonal block (a, a) ----
+  double acc[27];                                              // 21 lower-triangle sums of the diagonal block, 6 of the rhs
 #pragma unroll
-    for (int k = 0; k < 21; k++) acc[k] = 0.0;
-    auto diag_pair = [&](int pj, int pos) {
-      double y[18];
-      ld_rec18(D.E, nobs, (size_t)pj, y);
-      if (pos < SR_CH) {
+  for (int k = 0; k < 27; k++) acc[k] = 0.0;
+  auto one_obs = [&](int t, bool v, const double* ei, const double* Ci, const double* g) {
+    double ec[18];
+    e_times_cinv(ei, Ci, ec);
+    if (v && t < SR_CH) {
 #pragma unroll
-        for (int u = 0; u < 6; u++) {
-          const double x0 = s_ec[pos * SR_PITCH + 3 * u], x1 = s_ec[pos * SR_PITCH + 3 * u + 1], x2 = s_ec[pos * SR_PITCH + 3 * u + 2];
+      for (int k = 0; k < 18; k++) s_ec[t * SR_PITCH + k] = ec[k];
+    }
+    // a thread without a list entry has loaded entry 0 (no branch around the loads): its x becomes 0, the sums keep their bits
 #pragma unroll
-          for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x0 * y[3 * v] + x1 * y[3 * v + 1] + x2 * y[3 * v + 2];
-        }
-      } else {
-        double x[18];
-        get_x(pos, x);
+    for (int k = 0; k < 18; k++) ec[k] = v ? ec[k] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 6; u++)
+    for (int u = 0; u < 6; u++) acc[21 + u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
+    if (fuse) {
 #pragma unroll
-          for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
-      }
-    };
+      for (int u = 0; u < 6; u++)
 #pragma unroll
-    for (int t = 0; t < 3; t++) if (dj[t] >= 0) diag_pair(dj[t], di[t]);
-    for (int e = d_lo + tid + 3 * SC_TPB; e < d_hi; e += SC_TPB) diag_pair(D.pair_j[e], D.pair_i[e]);
-    block_reduce_dpp<21>(acc, s_red, s_out);
-    if (tid < 21) {
-      int u = 0;
-      while ((u + 1) * (u + 2) / 2 <= tid) u++;
-      const int v = tid - u * (u + 1) / 2;
-      const double* sc = D.scale_c + 6 * (size_t)a;
-      double bs = D.B[21 * (size_t)a + sym6(u, v)] * sc[u] * sc[v];
-      if (u == v) bs += fmin(fmax(bs, 1e-6), 1e32) / st->radius;
-      D.S[(size_t)(6 * a + u) * np + 6 * a + v] = bs - s_out[tid];
+        for (int v2 = 0; v2 <= u; v2++) acc[u * (u + 1) / 2 + v2] += ec[3 * u] * ei[3 * v2] + ec[3 * u + 1] * ei[3 * v2 + 1] + ec[3 * u + 2] * ei[3 * v2 + 2];
+    }
+  };
+  // Request order = dependence depth: camera a's first two list entries per thread (record + point index) leave first, then the
+  // segment labels of (2), then what hangs off the point indices, then the pair indices of the first two rounds.
+  const bool p1 = !D.fix_points && n_a > 0;
+  const bool v0 = p1 && tid < n_a, v1 = p1 && tid + SC_TPB < n_a;
+  int pt0 = 0, pt1 = 0;
+  double ea[18], eb[18], Ca[6], Cb[6], ga[3], gb[3];
+  if (p1) {
+    const int e0 = lo_a + (v0 ? tid : 0), e1 = lo_a + (v1 ? tid + SC_TPB : 0);
+    pt0 = D.cam_obs_pt[e0]; pt1 = D.cam_obs_pt[e1];
+    ld_rec18(D.E, nobs, (size_t)e0, ea);
+    ld_rec18(D.E, nobs, (size_t)e1, eb);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  int4 m0 = ld_meta(0), m1 = ld_meta(1), m2 = ld_meta(2);
+  if (p1) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) { Ca[k] = D.Cinv[6 * (size_t)pt0 + k]; Cb[k] = D.Cinv[6 * (size_t)pt1 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ga[k] = D.gps[3 * (size_t)pt0 + k]; gb[k] = D.gps[3 * (size_t)pt1 + k]; }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (p1) one_obs(tid, v0, ea, Ca, ga);
+  __builtin_amdgcn_sched_barrier(0);
+  Idx i0 = ld_idx(m0);                                         // (into the registers the first entry has left)
+  __builtin_amdgcn_sched_barrier(0);
+  if (p1) one_obs(tid + SC_TPB, v1, eb, Cb, gb);
+  __builtin_amdgcn_sched_barrier(0);
+  Idx i1 = ld_idx(m1);
+  if (p1) {
+    for (int t = tid + 2 * SC_TPB; t < n_a; t += SC_TPB) {
+      const int e = lo_a + t, pt = D.cam_obs_pt[e];
+      double ei[18];
+      ld_rec18(D.E, nobs, (size_t)e, ei);
+      one_obs(t, true, ei, D.Cinv + 6 * (size_t)pt, D.gps + 3 * (size_t)pt);
     }
   }
-  // (3) off-diagonal blocks (a, b) of the row: one wave per block, four at a time
-  // (tried: 512 threads with a PAIR of waves per block, each half of the 6 x 6 product, under a 128-register cap for 16 waves per CU:
-  // 43 spilled registers, 843 us instead of 638 per 64-problem launch; HALF a wave per block, eight blocks at a time, the 36 sums
-  // over 32 lanes serving two blocks: 682 us against 652 - the four gather trips of 32 lanes cost more than the cheaper reduction saves)
-  int kb = 0;
-  for (int blk = r_lo + w; blk < r_hi; blk += SC_TPB / 64, kb++) {
-    const bool pre = kb < SR_KB;
-    int b = 0, e0 = 0, e1 = 0, pj0 = -1, pj1 = -1, pi0 = 0, pi1 = 0;
-#pragma unroll
-    for (int k = 0; k < SR_KB; k++) if (kb == k) { b = ob[k]; e0 = oe0[k]; e1 = oe1[k]; pj0 = oj[k][0]; pj1 = oj[k][1]; pi0 = oi[k][0]; pi1 = oi[k][1]; }
-    if (!pre) { b = D.blk_b[blk]; e0 = D.blk_off[2 * blk]; e1 = D.blk_off[2 * blk + 1]; }
-    double a36[36];
-#pragma unroll
-    for (int k = 0; k < 36; k++) a36[k] = 0.0;
-    auto off_pair = [&](int pj, int pos) {
+  SR_STAMP(0, w == 0);
+  // what the stores behind the reduction need (21 threads a diagonal entry, 6 an rhs entry): requested here, used behind the reduction
+  double o_b = 0.0, o_s = 1.0, o_s2 = 1.0, o_r = 1.0;
+  int o_u = 0, o_v = 0;
+  if (tid < 21) {
+    while ((o_u + 1) * (o_u + 2) / 2 <= tid) o_u++;
+    o_v = tid - o_u * (o_u + 1) / 2;
+    const double* sc = D.scale_c + 6 * (size_t)a;
+    o_b = D.B[21 * (size_t)a + sym6(o_u, o_v)]; o_s = sc[o_u]; o_s2 = sc[o_v]; o_r = st->radius;
+  } else if (tid < 27) {
+    o_u = tid - 21;
+    o_b = D.gc[6 * (size_t)a + o_u]; o_s = D.scale_c[6 * (size_t)a + o_u];
+  }
+  // the y records of round 0 (requested here: the reduction below hides their round trip)
+  double y0[18], y1[18];
+  auto ld_y = [&](const int4& m, const Idx& ix) {
+    if (m.z >= 0) { ld_rec18(D.E, nobs, (size_t)ix.pj0, y0); ld_rec18(D.E, nobs, (size_t)ix.pj1, y1); }
+  };
+  ld_y(m0, i0);
+  if (!fuse) {                                                 // a camera that sees a point twice: the literal pair list (cross terms)
+    __syncthreads();
+    for (int e = d_lo + tid; e < d_hi; e += SC_TPB) {
+      const int pos = D.pair_i[e];
       double x[18], y[18];
-      ld_rec18(D.E, nobs, (size_t)pj, y);
+      ld_rec18(D.E, nobs, (size_t)D.pair_j[e], y);
       if (pos < SR_CH) {
 #pragma unroll
         for (int k = 0; k < 18; k++) x[k] = s_ec[pos * SR_PITCH + k];
@@ -1073,26 +1101,86 @@ __global__ __launch_bounds__(SC_TPB) void k_ba_schur(const BaDev* __restrict__ D
 #pragma unroll
       for (int u = 0; u < 6; u++)
 #pragma unroll
-        for (int v = 0; v < 6; v++) a36[6 * u + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
-    };
-    if (pre) {
-      if (pj0 >= 0) off_pair(pj0, pi0);
-      if (pj1 >= 0) off_pair(pj1, pi1);
-      for (int e = e0 + lane + 128; e < e1; e += 64) off_pair(D.pair_j[e], D.pair_i[e]);
-    } else {
-      for (int e = e0 + lane; e < e1; e += 64) off_pair(D.pair_j[e], D.pair_i[e]);
-    }
-    double mine = 0.0;
-#pragma unroll
-    for (int k = 0; k < 36; k++) {
-      const double t = lane_bcast(wave_sum_dpp(a36[k]), 63);   // (the total is valid in lane 63)
-      if (lane == k) mine = t;
-    }
-    if (lane < 36) {
-      const int u = lane / 6, v = lane - 6 * u;
-      D.S[(size_t)(6 * b + v) * np + 6 * a + u] = -mine;       // lower triangle: block (b, a) = -(acc)^T
+        for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
     }
   }
+  {                                                            // the 27 sums of the workgroup (the barriers also publish the records)
+    double a36[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) a36[k] = k < 27 ? acc[k] : 0.0;
+    const double t = wave_reduce36(a36, lane);
+    const int sl = wave_reduce36_slot(lane);
+    if (sl >= 0 && sl < 27) s_red[w * 27 + sl] = t;
+    __syncthreads();
+    if (tid < 27) s_out[tid] = (s_red[tid] + s_red[27 + tid]) + (s_red[2 * 27 + tid] + s_red[3 * 27 + tid]);
+    __syncthreads();
+  }
+  SR_STAMP(1, w == 0);
+  if (tid < 21) {
+    double bs = o_b * o_s * o_s2;
+    if (o_u == o_v) bs += fmin(fmax(bs, 1e-6), 1e32) / o_r;
+    D.S[(size_t)(6 * a + o_u) * np + 6 * a + o_v] = bs - s_out[tid];
+  } else if (tid < 27) {
+    const double rv = o_b * o_s - s_out[tid];
+    D.rhs[6 * a + o_u] = rv;
+    D.S[(size_t)np * np + 6 * a + o_u] = rv;                   // augmented row: forward substitution rides the factorisation
+  }
+  __syncthreads();                                             // (s_out is read; the mailboxes share its memory)
+  SR_STAMP(2, w == 0);
+  // ---- (2) the off-diagonal blocks, a segment per wave and round ----
+  const int slot = wave_reduce36_slot(lane);                   // which of a segment's 36 sums this lane ends up holding (or -1)
+  double carry = 0.0;                                          // wave 0, lanes < 36: the running sum of the block whose segments are arriving
+  for (int r = 0; r < R; r++) {
+    const int buf = r & 1;
+    double mine = 0.0;
+    if (m0.z >= 0) {
+      double a36[36];
+#pragma unroll
+      for (int k = 0; k < 36; k++) a36[k] = 0.0;
+      auto pair_prod = [&](int pos, const double* y) {
+        double x[18];
+        if (pos < SR_CH) {
+          const int rec = (pos < 0 ? SR_CH : pos) * SR_PITCH;
+#pragma unroll
+          for (int k = 0; k < 18; k++) x[k] = s_ec[rec + k];
+        } else get_x(pos, x);
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+#pragma unroll
+          for (int v = 0; v < 6; v++) a36[6 * u + v] = fma(x[3 * u + 2], y[3 * v + 2], fma(x[3 * u + 1], y[3 * v + 1], fma(x[3 * u], y[3 * v], a36[6 * u + v])));
+      };
+      pair_prod(i0.pi0, y0);
+      pair_prod(i0.pi1, y1);
+      mine = wave_reduce36(a36, lane);                           // (the lane with slot k holds the total of sum k)
+      // next round's gathers (their indices arrived a round ago) and the indices of the round after it go out here, into the registers
+      // the sums have just left; the barrier and wave 0's additions below run under their round trip
+      __builtin_amdgcn_sched_barrier(0);
+      ld_y(m1, i1);
+      const Idx i2 = ld_idx(m2);
+      const int4 m3 = ld_meta(r + 3);
+      if (lane == 0) { s_mf[buf][w][0] = m0.z; s_mf[buf][w][1] = m0.w; }
+      m0 = m1; m1 = m2; m2 = m3; i0 = i1; i1 = i2;
+    } else {
+      if (lane == 0) { s_mf[buf][w][0] = -1; s_mf[buf][w][1] = 0; }
+      m0 = m1; m1 = m2; m2 = make_int4(0, 0, -1, 0);          // (a wave's segments end at most one round before the row's)
+    }
+    if (slot >= 0) s_w[(buf * 4 + w) * 36 + slot] = mine;
+    __syncthreads();
+    if (w == 0 && lane < 36) {
+#pragma unroll
+      for (int sl = 0; sl < 4; sl++) {
+        const int b = s_mf[buf][sl][0], fl = s_mf[buf][sl][1];
+        if (b < 0) continue;
+        const double v = s_w[(buf * 4 + sl) * 36 + lane];
+        carry = (fl & 1) ? v : carry + v;
+        if (fl & 2) {
+          const int u = lane / 6, vv = lane - 6 * u;
+          D.S[(size_t)(6 * b + vv) * np + 6 * a + u] = -carry;     // lower triangle: block (b, a) = -(sum)^T
+        }
+      }
+    }
+  }
+  SR_STAMP(4 + w, true);
 }
 
 // zero the lower triangle rows of the real block (the factorisation overwrote S in place)
@@ -1119,6 +1207,10 @@ __global__ void k_ba_pad(const BaDev* __restrict__ Dv) {
 #define NB 32
 // Phase timing of the factorisation step kernels (tools/chol_phase_prof.py builds a scratch library with -DORBHIP_CHOL_PROF):
 // wave 0 of workgroup 0 of problem 0 stamps s_memrealtime (100 MHz) at the phase boundaries; sums per step index.
+#if defined(ORBHIP_SCHUR_PROF) && !defined(ORBHIP_CHOL_PROF)
+__device__ unsigned long long g_p2_prof[8][128];
+__device__ unsigned long long g_chol_prof[128][10];
+#endif
 #ifdef ORBHIP_CHOL_PROF
 __device__ unsigned long long g_p2_prof[8][128];       // k_chol_persist_2l timeline (absolute s_memrealtime): see tools/chol_p2_timeline.py
 #define P2_MARK(row, idx) do { if ((threadIdx.x & 63) == 0) atomicMax(&g_p2_prof[row][(idx) & 127], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
@@ -3305,7 +3397,7 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
       if (cc >= 0) {
         const double* y = D.rhs + 6 * cc;
         double E[18];
-        ld_rec18(D.E, n, (size_t)i, E);
+        ld_rec18(D.E, n, (size_t)D.cam_pos[i], E);            // (camera-major records)
 #pragma unroll
         for (int v = 0; v < 3; v++) {
           double sacc = 0;
@@ -3982,7 +4074,8 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   const int nparts = std::max(nb_obs, std::max(nb_cam, nb_pt));
   // Schur block pair lists: for every point, all ordered observation pairs (i, j) with col_i <= col_j,
   // grouped by block (col_i, col_j) with a counting sort (stable: point order, then list order).
-  std::vector<int> blk_a, blk_b, blk_off, row_off((size_t)nfc + 1, 0);
+  std::vector<int4> row_meta((size_t)2 * std::max(nfc, 1), make_int4(0, 0, 0, 0)), segs;
+  for (int a = 0; a < nfc; a++) { const int ca = free_cams[a]; row_meta[2 * (size_t)a + 1] = make_int4(cam_off[ca], cam_off[ca + 1] - cam_off[ca], 0, 0); }
   int* pair_i = nullptr; int* pair_j = nullptr; size_t npairs_all = 0;
   if (!opts->fix_points && nfc > 0) {
     // Per point, the free observations are first sorted by column (insertion sort, a handful of entries): the pairs with
@@ -4015,11 +4108,19 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
                 for (int i = lo; i < hi; i++) { const int ci = colv[i]; if (ci < 0) continue; for (int j = lo; j < hi; j++) if (colv[j] >= ci) cnt[(size_t)ci * nfc + colv[j] + 1]++; } });
     for (size_t k = 0; k < (size_t)nfc * nfc; k++) cnt[k + 1] += cnt[k];
     npairs_all = (size_t)cnt[(size_t)nfc * nfc];
+    // segment list: the off-diagonal blocks of a row, in (a, b) order, cut into runs of <= SR_SEG pairs (k_ba_schur: one wave each)
+    for (int a = 0; a < nfc; a++) {
+      const size_t kd = (size_t)a * nfc + a;
+      const int s_lo = (int)segs.size();
+      for (int b2 = a + 1; b2 < nfc; b2++) {
+        const size_t k = (size_t)a * nfc + b2;
+        for (int e = cnt[k]; e < cnt[k + 1]; e += SR_SEG) segs.push_back(make_int4(e, std::min(e + SR_SEG, cnt[k + 1]), b2, (e == cnt[k] ? 1 : 0) | (e + SR_SEG >= cnt[k + 1] ? 2 : 0)));
+      }
+      row_meta[2 * (size_t)a] = make_int4(cnt[kd], cnt[kd + 1], s_lo, (int)segs.size());
+    }
     {
-      size_t nblk_up = (size_t)nfc;                           // the diagonal blocks + the non-empty off-diagonal ones
-      for (int a = 0; a < nfc; a++) for (int b2 = a + 1; b2 < nfc; b2++) { const size_t k = (size_t)a * nfc + b2; nblk_up += cnt[k + 1] > cnt[k]; }
       typedef HostBA A;
-      if (int r = H.begin_arena2(2 * A::arena_need(npairs_all + 1, 4) + 2 * A::arena_need((size_t)nfc + 1, 4) + 2 * A::arena_need(nblk_up, 4) + A::arena_need(2 * nblk_up, 4) + 1024)) return r;
+      if (int r = H.begin_arena2(2 * A::arena_need(npairs_all + 1, 4) + 2 * A::arena_need((size_t)nfc + 1, 4) + A::arena_need(2 * (size_t)nfc + 1, 16) + A::arena_need(segs.size() + 1, 16) + 1024)) return r;
     }
     pair_i = H.arena2_host<int>(npairs_all, &rc); pair_j = H.arena2_host<int>(npairs_all, &rc);
     if (rc) return rc;
@@ -4029,35 +4130,19 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
               [&](int lo, int hi) {
                 for (int i = lo; i < hi; i++) { const int ci = colv[i]; if (ci < 0) continue;
                   for (int j = lo; j < hi; j++) if (colv[j] >= ci) { const int e = pos[(size_t)ci * nfc + colv[j]]++; pair_i[e] = i; pair_j[e] = j; } } });
-    // block list: the nfc diagonal blocks first (one workgroup each), then the non-empty off-diagonal blocks in (a, b) order
-    // (one wave each); blk_off holds {lo, hi} of every block's run in the pair arrays
-    for (int a = 0; a < nfc; a++) {
-      const size_t k = (size_t)a * nfc + a;
-      blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(cnt[k]); blk_off.push_back(cnt[k + 1]);
-    }
-    for (int a = 0; a < nfc; a++) {
-      row_off[a] = (int)blk_a.size();
-      for (int b2 = a + 1; b2 < nfc; b2++) {
-        const size_t k = (size_t)a * nfc + b2;
-        if (cnt[k + 1] > cnt[k]) { blk_a.push_back(a); blk_b.push_back(b2); blk_off.push_back(cnt[k]); blk_off.push_back(cnt[k + 1]); }
-      }
-    }
-    row_off[nfc] = (int)blk_a.size();
-    // k_ba_schur keeps camera a's records in LDS by list position: pair_i = position of the observation inside its camera's list
-    for (size_t e = 0; e < npairs_all; e++) { const int i = pair_i[e]; pair_i[e] = cam_pos[i] - cam_off[oc[i]]; }
+    // k_ba_schur keeps camera a's records in LDS by list position: pair_i = position of the observation inside its camera's list;
+    // the E records are stored in camera-major order: pair_j = position of the observation in the concatenated lists
+    for (size_t e = 0; e < npairs_all; e++) { const int i = pair_i[e]; pair_i[e] = cam_pos[i] - cam_off[oc[i]]; pair_j[e] = cam_pos[pair_j[e]]; }
   } else {
-    for (int a = 0; a < nfc; a++) { blk_a.push_back(a); blk_b.push_back(a); blk_off.push_back(0); blk_off.push_back(0); }
-    for (int a = 0; a <= nfc; a++) row_off[a] = nfc;
     typedef HostBA A;
-    if (int r = H.begin_arena2(2 * A::arena_need(1, 4) + 2 * A::arena_need((size_t)nfc + 1, 4) + 2 * A::arena_need((size_t)nfc, 4) + A::arena_need(2 * (size_t)nfc, 4) + 1024)) return r;
+    if (int r = H.begin_arena2(2 * A::arena_need(1, 4) + 2 * A::arena_need((size_t)nfc + 1, 4) + A::arena_need(2 * (size_t)nfc + 1, 16) + A::arena_need(1, 16) + 1024)) return r;
     pair_i = H.arena2_host<int>(0, &rc); pair_j = H.arena2_host<int>(0, &rc);
     if (rc) return rc;
   }
-  const int nblk = (int)blk_a.size();
   out->t_struct_ms = ba_now_ms() - t_start;
 
   BaDev D; std::memset(&D, 0, sizeof(D));
-  D.ncam = ncam; D.npts = npts; D.nobs = nobs; D.nfc = nfc; D.n6 = n6; D.npad = npad; D.nparts = nparts; D.nblk = nblk;
+  D.ncam = ncam; D.npts = npts; D.nobs = nobs; D.nfc = nfc; D.n6 = n6; D.npad = npad; D.nparts = nparts;
   D.fix_points = opts->fix_points ? 1 : 0; D.huber = opts->huber_delta;
   static const bool use_la = []() { const char* e = std::getenv("ORBHIP_BA_LOOKAHEAD"); return !(e && e[0] == '0'); }();
   static const int la_max = []() { const char* e = std::getenv("ORBHIP_BA_LA_MAX"); return e ? atoi(e) : 1024; }();
@@ -4073,9 +4158,8 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.cam_obs = H.arena_dev(cam_obs); D.cam_obs_pt = H.arena_dev(cam_obs_pt);
   D.cam_pos = H.arena_dev(cam_pos); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
   D.free_cams = H.arena2_dev(H.arena2_copy(free_cams.data(), nfc, &rc));
-  D.row_off = H.arena2_dev(H.arena2_copy(row_off.data(), (size_t)nfc + 1, &rc));
-  D.blk_a = H.arena2_dev(H.arena2_copy(blk_a.data(), nblk, &rc)); D.blk_b = H.arena2_dev(H.arena2_copy(blk_b.data(), nblk, &rc));
-  D.blk_off = H.arena2_dev(H.arena2_copy(blk_off.data(), 2 * (size_t)nblk, &rc));
+  D.row_meta = H.arena2_dev(H.arena2_copy(row_meta.data(), row_meta.size(), &rc));
+  D.seg = H.arena2_dev(H.arena2_copy(segs.data(), segs.size(), &rc));
   D.pair_i = H.arena2_dev(pair_i); D.pair_j = H.arena2_dev(pair_j);
   D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
   D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
@@ -4184,7 +4268,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     ORBHIP_CHECK_HIP(hipEventRecord(g_prof_ev[0], s));
   }
   const unsigned ny = (unsigned)nprob;
-  if (int r = raise_dynamic_lds((const void*)k_ba_schur, g_stream_device, SR_CH * SR_PITCH * sizeof(double))) return r;
+  if (int r = raise_dynamic_lds((const void*)k_ba_schur, g_stream_device, SR_LDS_BYTES)) return r;
   if (int r = raise_dynamic_lds((const void*)k_chol_wg, g_stream_device, CW_LDS_DOUBLES * sizeof(double))) return r;
   const int npad_all = g_npad;
   // ---- which form of the Cholesky this solve takes (0 step kernels, 1 persistent launches, 2 the one-launch two-level kernel)
@@ -4239,7 +4323,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(64), 0, s, Dv);
     const int g_zs = g_n6 > 0 ? std::min(1024, (int)((g_zero + 255) / 256)) : 0;
     hipLaunchKernelGGL(k_ba_schur_prep, dim3(g_pt + g_zs, ny), dim3(BA_TPB), 0, s, Dv, g_pt);                    // + zeroing of S
-    if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), SR_CH * SR_PITCH * sizeof(double), s, Dv);      // one workgroup per block row
+    if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), SR_LDS_BYTES, s, Dv);      // one workgroup per block row
     const int npad = B.g_npad_2l;                             // (0 when every problem of the batch takes the look-ahead scheme)
     auto launch_update = [&](hipStream_t st_, int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
       if (c_hi <= c_lo || r_lo >= npad + 1) return;
@@ -4865,6 +4949,15 @@ int ba_debug_p2_prof(unsigned long long* out, int reset) {       // [8][128] abs
   return 0;
 }
 int ba_debug_chol_prof(unsigned long long* out, int reset) {     // [128][10]: ticks per phase summed over launches, [9] = launches
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  if (out) ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_prof), sizeof(unsigned long long) * 128 * 10));
+  if (reset) { static unsigned long long z[128 * 10]; ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_chol_prof), z, sizeof(z))); }
+  return 0;
+}
+#endif
+
+#if defined(ORBHIP_SCHUR_PROF) && !defined(ORBHIP_CHOL_PROF)
+int ba_debug_chol_prof(unsigned long long* out, int reset) {     // k_ba_schur phase stamps of problem 0: [row a][column], [9] = launches
   ORBHIP_CHECK_HIP(hipDeviceSynchronize());
   if (out) ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_prof), sizeof(unsigned long long) * 128 * 10));
   if (reset) { static unsigned long long z[128 * 10]; ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_chol_prof), z, sizeof(z))); }
