@@ -605,7 +605,8 @@ struct BaDev {            // device pointers of one problem
   double* r; double* Jp;             // SoA: r[2][nobs], Jp[6][nobs] (the landmark blocks read them; the camera Jacobians live in JcR only)
   double* B; double* gc; double* C; double* gp;       // unscaled blocks: B[nfc][21], gc[nfc][6], C[npts][6], gp[npts][3]
   double* scale_c; double* scale_p;  // Jacobi scaling [nfc][6], [npts][3]
-  double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] records of 18 (ld_rec18): rewritten only when the iterate changes (k_ba_E)
+  double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] factored 64-byte records in camera-major order (ld_rec8): rewritten only when the iterate changes (k_ba_E)
+  double* Ng;                        // [npts][9] {N = S_p (C_s+D)^-1 S_p (6, symmetric), g_p (3)}: what k_ba_schur needs of a point, one gather
   double* t3;                        // [nobs][3] E_i^T y_cam of the landmark back-substitution
   double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
   double* Dinv;                      // inverse of every 32x32 diagonal Cholesky block [npad/32][32][32]
@@ -613,8 +614,8 @@ struct BaDev {            // device pointers of one problem
   int* cflags;                       // persistent Cholesky: hand-off flags of this problem [ncflags], zeroed by k_ba_iter_begin
   int ncflags;
   const int* pair_i; const int* pair_j;   // Schur pair lists, block after block in (a, b) order, a <= b (pair_i: POSITION of camera a's observation in its camera's list, pair_j: camera b's observation as its index in camera-major order = E record)
-  const int4* row_meta;              // [nfc][2] block row a: {first, end of the diagonal block's pairs, first, end of the row's segments}, {first entry, length of camera a's list, -, -}
-  const int4* seg;                   // the off-diagonal blocks cut into SEGMENTS of <= SR_SEG pairs: {first pair, end, column b, 1 = first | 2 = last segment of its block}
+  const int4* row_meta;              // [nfc][2] block row a: {first, end of the diagonal block's pairs, first, end of the row's segments}, {first entry, length of camera a's list, camera index, -}
+  const int4* seg;                   // the off-diagonal blocks cut into SEGMENTS of <= SR_SEG pairs: {first pair, end, column b, 1 = first | 2 = last segment of its block | camera index of b << 2}
   const int* free_cams;              // [nfc] reduced column -> camera index
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
@@ -842,105 +843,137 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restric
   if (!inv3_sym6(Cs, Ci)) { st->chol_fail = 1; for (int k = 0; k < 6; k++) Ci[k] = 0.0; }
   for (int k = 0; k < 6; k++) D.Cinv[6 * (size_t)p + k] = Ci[k];
   for (int k = 0; k < 3; k++) D.gps[3 * (size_t)p + k] = D.gp[3 * (size_t)p + k] * sp[k];
+  double* ng = D.Ng + 9 * (size_t)p;
+  ng[0] = Ci[0] * sp[0] * sp[0]; ng[1] = Ci[1] * sp[0] * sp[1]; ng[2] = Ci[2] * sp[0] * sp[2];
+  ng[3] = Ci[3] * sp[1] * sp[1]; ng[4] = Ci[4] * sp[1] * sp[2]; ng[5] = Ci[5] * sp[2] * sp[2];
+  for (int k = 0; k < 3; k++) ng[6 + k] = D.gp[3 * (size_t)p + k];
 }
 
-// Layout of the per-observation 6x3 records E and E (C+D)^-1 (18 doubles = 144 bytes): the first 16 doubles of record i are ONE
-// aligned 128-byte line at base + 16 i, the last two live in a tail array at base + 16 nobs + 2 i.  As plain 144-byte AoS every
-// record straddled two or three 128-byte lines, and k_ba_schur - which gathers two records per pair, 3 GB per launch of a
-// 64-problem batch - moved about twice its useful bytes over the fabric (it ran at 2.85 TB/s of useful bytes).
-__device__ __forceinline__ void ld_rec18(const double* __restrict__ base, size_t nobs, size_t i, double* x) {
-  const double2* m = (const double2*)(base + 16 * i);
+// The per-observation block E = (Jc S_c)^T (Jp S_p) (6x3) is never stored: it FACTORS.  With Q = sqrt(rho') w dpi/dX_c (2x3, four
+// non-zero entries), the rotated point RX and the camera's rotation R (ba_math.h: Jc = Q [I | -2 [RX]x], Jp = Q R),
+//     E = S_c [W; [r]x W] R S_p,    W = Q^T Q (symmetric 3x3 with W01 = 0: five numbers),  r = 2 RX,
+// so an observation keeps {w00, w11, w02, w12, w22, r0, r1, r2}: 64 bytes - half a cache line, aligned - instead of the 144 of the
+// 18 products, and what depends on the camera only (R, S_c) or on the point only (S_p) is applied once per block / per point:
+//     E_a (C_s+D)^-1 E_b^T = S_c,a [ G_a (R_a N R_b^T) G_b^T ] S_c,b,   G = [W; [r]x W] (6x3),  N = S_p (C_s+D)^-1 S_p.
+// (Round 4: 18-double records made k_ba_schur move 2 GB per launch of a 64-problem batch through a 4 MB L2 per XCD; a problem's
+// records are now 3.2 MB.)  The algebra is exact whatever the norm of the quaternion (Jc and Jp are built from the same RX and R).
+// Records are stored in CAMERA-MAJOR order (record index = cam_pos[i], the position of the observation in the concatenated
+// per-camera lists): k_ba_schur streams camera a's records, and those it gathers from a camera b ascend inside b's contiguous run.
+// They depend on the iterate only - not on the LM radius, not on the scaling - and are rewritten when the iterate has changed
+// (after_eval raises e_dirty, the next k_ba_iter_begin clears it).
+__device__ __forceinline__ void ld_rec8(const double* __restrict__ base, size_t q, double* c) {
+  const double2* m = (const double2*)(base + 8 * q);
 #pragma unroll
-  for (int k = 0; k < 8; k++) { const double2 v = m[k]; x[2 * k] = v.x; x[2 * k + 1] = v.y; }
-  const double2 t = *(const double2*)(base + 16 * nobs + 2 * i);
-  x[16] = t.x; x[17] = t.y;
+  for (int k = 0; k < 4; k++) { const double2 v = m[k]; c[2 * k] = v.x; c[2 * k + 1] = v.y; }
 }
-
-// per observation: E = (Jc S_c)^T (Jp S_p) (6x3), stored as 18-double records (ld_rec18) in CAMERA-MAJOR order (record index =
-// cam_pos[i], the position of the observation in the concatenated per-camera lists): k_ba_schur then streams camera a's records and
-// the records it gathers from a camera b ascend inside b's contiguous run (neighbouring keyframes share most of their points: nearly
-// sequential).  E depends on the iterate and on the Jacobi scaling only - not on the LM radius - so it is written when the iterate has
-// changed (after_eval raises e_dirty, the next k_ba_iter_begin clears it) instead of in every LM iteration, and E (C_s+D)^-1, which
-// does depend on the radius, is not stored at all: k_ba_schur forms it on the fly from E and the point's (C_s+D)^-1 (round 4:
-// k_ba_schur_prep_obs read Jc, Jp and wrote E AND E (C+D)^-1 in every iteration - 432 bytes per observation).  The Jacobians are
-// RECOMPUTED here from the observation (the same reproj_eval on the same iterate: the same bits k_ba_eval saw), which is why
-// k_ba_eval does not store the camera Jacobians in observation order.
 __global__ __launch_bounds__(BA_TPB) void k_ba_E(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   const StFlags F = ld_flags(st);
   const int dirty = st->e_dirty;
   if (F.done || !dirty || D.fix_points) return;
-  if ((int)blockIdx.x * BA_TPB >= D.nobs) return;
-  __shared__ double s_t[BA_TPB / 64][64][19];          // + 1 pad
-  __shared__ int s_q[BA_TPB / 64][64];                 // record index of the wave's observations (-1: fixed camera / beyond the end)
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c = (i < D.nobs) ? D.obs_cam[i] : 0;
-  const int cc = (i < D.nobs) ? D.cam_col[c] : -1;
-  const bool act = cc >= 0;
-  s_q[w][lane] = act ? D.cam_pos[i] : -1;
-  if (act) {
-    const int p = D.obs_pt[i];
-    double r[2], Jc[12], Jp[6], e[18];
-    (void)reproj_eval(D.K4 + 4 * c, D.poses + 7 * c, D.pts + 3 * (size_t)p, D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
-                      D.obs_w[i], D.obs_robust[i], D.huber, r, Jc, Jp);
-    const double* sc = D.scale_c + 6 * (size_t)cc;
-    const double* sp = D.scale_p + 3 * (size_t)p;
-    double jp[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) jp[k] = Jp[k] * sp[k % 3];
-#pragma unroll
-    for (int u = 0; u < 6; u++) {
-      const double j0 = Jc[u] * sc[u], j1 = Jc[6 + u] * sc[u];
-      e[3 * u] = j0 * jp[0] + j1 * jp[3]; e[3 * u + 1] = j0 * jp[1] + j1 * jp[4]; e[3 * u + 2] = j0 * jp[2] + j1 * jp[5];
-    }
-#pragma unroll
-    for (int k = 0; k < 18; k++) s_t[w][lane][k] = e[k];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-  // The records go to scattered places (camera-major order, the wave's observations are a run of the point-major order): eight
-  // lanes write one record's 128-byte line per store instruction - whole lines, not 64 sixteen-byte pieces of 64 lines.
-  double* tail = D.E + 16 * (size_t)D.nobs;
-#pragma unroll
-  for (int t = 0; t < 8; t++) {
-    const int idx = lane + 64 * t, rr = idx >> 3, part = idx & 7;
-    const int q = s_q[w][rr];
-    if (q >= 0) *(double2*)(D.E + 16 * (size_t)q + 2 * part) = make_double2(s_t[w][rr][2 * part], s_t[w][rr][2 * part + 1]);
-  }
-  { const int q = s_q[w][lane]; if (q >= 0) *(double2*)(tail + 2 * (size_t)q) = make_double2(s_t[w][lane][16], s_t[w][lane][17]); }
+  if (i >= D.nobs) return;
+  const int c = D.obs_cam[i];
+  if (D.cam_col[c] < 0) return;
+  const int p = D.obs_pt[i];
+  double r[2], Jc[12], RX[3];
+  (void)reproj_eval(D.K4 + 4 * c, D.poses + 7 * c, D.pts + 3 * (size_t)p, D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
+                    D.obs_w[i], D.obs_robust[i], D.huber, r, Jc, nullptr);
+  quat_rotate(D.poses + 7 * c + 3, D.pts + 3 * (size_t)p, RX);            // (the RX reproj_eval used)
+  const double q00 = Jc[0], q02 = Jc[2], q11 = Jc[7], q12 = Jc[8];
+  double2* m = (double2*)(D.E + 8 * (size_t)D.cam_pos[i]);
+  m[0] = make_double2(q00 * q00, q11 * q11);
+  m[1] = make_double2(q00 * q02, q11 * q12);
+  m[2] = make_double2(q02 * q02 + q12 * q12, 2.0 * RX[0]);
+  m[3] = make_double2(2.0 * RX[1], 2.0 * RX[2]);
 }
-// x = E (C_s+D)^-1 of one record (the arithmetic of the former k_ba_schur_prep_obs, formed where it is used)
-__device__ __forceinline__ void e_times_cinv(const double* __restrict__ e, const double* __restrict__ Ci, double* __restrict__ x) {
-  const double c0 = Ci[0], c1 = Ci[1], c2 = Ci[2], c3 = Ci[3], c4 = Ci[4], c5 = Ci[5];
+// X' = G (R_a N) of one observation of camera a is [Y; [r]x Y] with Y = W (R_a N) (3x3): twelve numbers {Y, r} stand for the 6x3 block.
+// c = the observation's record, Ra row-major, N6 = {n00,n01,n02,n11,n12,n22}; out: yr[0..8] = Y (row-major), yr[9..11] = r
+__device__ __forceinline__ void make_yr(const double* __restrict__ c, const double* __restrict__ Ra, const double* __restrict__ N6, double* __restrict__ yr) {
+  const double w00 = c[0], w11 = c[1], w02 = c[2], w12 = c[3], w22 = c[4];
+  double M[9];
 #pragma unroll
-  for (int u = 0; u < 6; u++) {
-    const double e0 = e[3 * u], e1 = e[3 * u + 1], e2 = e[3 * u + 2];
-    x[3 * u] = e0 * c0 + e1 * c1 + e2 * c2;
-    x[3 * u + 1] = e0 * c1 + e1 * c3 + e2 * c4;
-    x[3 * u + 2] = e0 * c2 + e1 * c4 + e2 * c5;
+  for (int i = 0; i < 3; i++) {
+    const double a0 = Ra[3 * i], a1 = Ra[3 * i + 1], a2 = Ra[3 * i + 2];
+    M[3 * i] = fma(a2, N6[2], fma(a1, N6[1], a0 * N6[0]));
+    M[3 * i + 1] = fma(a2, N6[4], fma(a1, N6[3], a0 * N6[1]));
+    M[3 * i + 2] = fma(a2, N6[5], fma(a1, N6[4], a0 * N6[2]));
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double m0 = M[k], m1 = M[3 + k], m2 = M[6 + k];
+    yr[k] = fma(w02, m2, w00 * m0);
+    yr[3 + k] = fma(w12, m2, w11 * m1);
+    yr[6 + k] = fma(w22, m2, fma(w12, m1, w02 * m0));
+  }
+  yr[9] = c[5]; yr[10] = c[6]; yr[11] = c[7];
+}
+// P = Y R_b^T G_b^T (3x6) of one pair: the upper three rows of the pair's 6x6 contribution; the lower three are [r_a]x P
+__device__ __forceinline__ void pair_P(const double* __restrict__ yr, const double* __restrict__ Rb, const double* __restrict__ c, double (&P)[3][6]) {
+  const double w00 = c[0], w11 = c[1], w02 = c[2], w12 = c[3], w22 = c[4], r0 = c[5], r1 = c[6], r2 = c[7];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double x0 = yr[3 * i], x1 = yr[3 * i + 1], x2 = yr[3 * i + 2];
+    const double t0 = fma(x2, Rb[2], fma(x1, Rb[1], x0 * Rb[0]));
+    const double t1 = fma(x2, Rb[5], fma(x1, Rb[4], x0 * Rb[3]));
+    const double t2 = fma(x2, Rb[8], fma(x1, Rb[7], x0 * Rb[6]));
+    const double z0 = fma(t2, w02, t0 * w00), z1 = fma(t2, w12, t1 * w11), z2 = fma(t2, w22, fma(t1, w12, t0 * w02));
+    P[i][0] = z0; P[i][1] = z1; P[i][2] = z2;
+    P[i][3] = fma(z2, r1, -(z1 * r2)); P[i][4] = fma(z0, r2, -(z2 * r0)); P[i][5] = fma(z1, r0, -(z0 * r1));
+  }
+}
+// a36[6u+v] += the pair's 6x6 contribution (u = parameter of camera a, v = parameter of camera b)
+__device__ __forceinline__ void pair_acc(const double* __restrict__ yr, const double* __restrict__ Rb, const double* __restrict__ c, double* __restrict__ a36) {
+  double P[3][6];
+  pair_P(yr, Rb, c, P);
+  const double r0 = yr[9], r1 = yr[10], r2 = yr[11];
+#pragma unroll
+  for (int v = 0; v < 6; v++) {
+    a36[v] += P[0][v]; a36[6 + v] += P[1][v]; a36[12 + v] += P[2][v];
+    a36[18 + v] = fma(r1, P[2][v], fma(-r2, P[1][v], a36[18 + v]));
+    a36[24 + v] = fma(r2, P[0][v], fma(-r0, P[2][v], a36[24 + v]));
+    a36[30 + v] = fma(r0, P[1][v], fma(-r1, P[0][v], a36[30 + v]));
+  }
+}
+// the lower triangle (21 sums, row u, column v <= u) of one diagonal pair
+__device__ __forceinline__ void pair_acc_lower(const double* __restrict__ yr, const double* __restrict__ Ra, const double* __restrict__ c, double* __restrict__ acc) {
+  double P[3][6];
+  pair_P(yr, Ra, c, P);
+  const double r0 = yr[9], r1 = yr[10], r2 = yr[11];
+#pragma unroll
+  for (int u = 0; u < 3; u++)
+#pragma unroll
+    for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += P[u][v];
+#pragma unroll
+  for (int v = 0; v < 6; v++) {
+    if (v <= 3) acc[6 + v] = fma(r1, P[2][v], fma(-r2, P[1][v], acc[6 + v]));
+    if (v <= 4) acc[10 + v] = fma(r2, P[0][v], fma(-r0, P[2][v], acc[10 + v]));
+    acc[15 + v] = fma(r0, P[1][v], fma(-r1, P[0][v], acc[15 + v]));
   }
 }
 
 // ---- reduced camera system S = B_s + D - sum E (C_s+D)^-1 E^T over the non-empty block pairs (a <= b) ----------------
-// ONE WORKGROUP PER BLOCK ROW (free camera a).  Every pair of the row multiplies x = E_i (C+D)^-1 of an observation i of camera a
-// with y = E_j of the observation j of the same point by a camera b >= a.  The workgroup forms x ONCE per observation of camera a
-// (camera a's records are a contiguous run: streamed), keeps the 18 values in LDS by list position (pair_i) and gathers only y.
+// ONE WORKGROUP PER BLOCK ROW (free camera a).  Every pair of the row couples an observation i of camera a with the observation j of
+// the same point by a camera b >= a:  block (a, b) += X'_i R_b^T G_j^T  with  X'_i = G_i (R_a N_p)  (the factored records above).
+// The workgroup forms X' ONCE per observation of camera a (camera a's records are a contiguous run: streamed), keeps the 18 values
+// in LDS by list position (pair_i) and gathers only the 64-byte records of the partners.
 //
 // The kernel is bound by the latency of its dependent loads - at 78 KB of LDS per workgroup a SIMD holds two waves, and a gather of
-// 64 scattered records takes ~3 us under load (tools/schur_prof.py, in-kernel stamps of a 64-problem C4 batch: 52 us per workgroup,
-// of which 16 the pass over camera a's list, 8 the diagonal block, 26 the off-diagonal blocks on the wave that drew the longest
-// lists - the pair lists of a SLAM graph are skewed: half of C4's blocks hold <= 67 pairs, the neighbouring keyframes' 350 ... 490).
-// So the structure follows the round trips, not the flops:
-//  (1) the pass over camera a's list builds the records, the rhs  rhs_a = g_s - sum EC_i g_p  AND the diagonal block (x and y of a
-//      diagonal pair belong to the SAME observation - the pair list of block (a, a) is the camera's list unless the camera sees a
-//      point twice; such rows walk the literal list afterwards), two list entries per thread in flight, one reduction of 27 sums;
+// 64 scattered records takes ~3 us under load (tools/schur_prof.py, in-kernel stamps of a 64-problem C4 batch; the first version of
+// this kernel: 52 us per workgroup, of which 16 the pass over camera a's list, 8 the diagonal block, 26 the off-diagonal blocks on
+// the wave that drew the longest lists - the pair lists of a SLAM graph are skewed: half of C4's blocks hold <= 67 pairs, the
+// neighbouring keyframes' 350 ... 490).  So the structure follows the round trips, not the flops:
+//  (1) the pass over camera a's list builds the X' records, the rhs  rhs_a = g_s - S_c sum X'_i g_p  AND the diagonal block (both
+//      records of a diagonal pair belong to the SAME observation - the pair list of block (a, a) is the camera's list unless the
+//      camera sees a point twice; such rows walk the literal list afterwards), three list entries per thread in flight, one
+//      reduction of 27 sums;
 //  (2) the off-diagonal blocks are cut into SEGMENTS of <= SR_SEG = 128 pairs (host: seg[]), dealt round-robin to the four waves:
 //      round r, wave w takes segment 4 r + w - a 490-pair block is four waves' work, not one's.  Both gathers of a segment
-//      (2 x 64 lanes) are in flight together, the next round's are issued before this round's 36 wave sums, the indices two
-//      rounds ahead; lanes without a pair read a zero record from LDS and a valid y (no branches around the loads).
-//      A wave leaves its 36 sums in a mailbox; behind the round's barrier wave 0 adds the segments of a block in list order
-//      (fixed order: the result does not depend on timing) and stores block (b, a) = -(sum)^T.
+//      (2 x 64 lanes) are in flight together, the next round's go out before this round's arithmetic, the indices two rounds
+//      ahead; lanes without a pair read a zero record from LDS and a valid partner (no branches around the loads).
+//      A wave leaves its 36 sums (transposing wave reduction, wave_reduce.h) in a mailbox; behind the round's barrier wave 0 adds
+//      the segments of a block in list order (fixed order: the result does not depend on timing) and stores block (b, a) = -(sum)^T.
 // Records beyond SR_CH observations of one camera do not fit the LDS and are formed from global memory where they are used.
 #ifdef ORBHIP_SCHUR_PROF
 extern __device__ unsigned long long g_chol_prof[128][10];
@@ -949,15 +982,16 @@ extern __device__ unsigned long long g_chol_prof[128][10];
 #define SR_STAMP(col, cond) do { } while (0)
 #endif
 #define SC_TPB 256
-#define SR_CH 512                      /* records in LDS: (512 + 1) x 19 doubles = 78.0 KB, two workgroups per CU */
-#define SR_PITCH 19
+#define SR_CH 736                      /* records in LDS: (736 + 1) x 13 doubles = 76.6 KB, two workgroups per CU */
+#define SR_PITCH 13                    /* {Y (9), r (3)} + 1: an odd pitch spreads the lanes' records over the banks */
+#define SR_REC 12
 #define SR_SEG 128                     /* pairs per segment: two gathers of 64 lanes (host: the seg[] list) */
 #define SR_LDS_BYTES ((SR_CH + 1) * SR_PITCH * sizeof(double))
 __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_schur(const BaDev* __restrict__ Dv) {
-  // Workgroup -> (problem, block row).  The y records a row gathers belong to the cameras that share points with camera a - in a
+  // Workgroup -> (problem, block row).  The records a row gathers belong to the cameras that share points with camera a - in a
   // SLAM map mostly the next few keyframes -, i.e. to rows that run at about the same time; the dispatcher deals consecutive
   // workgroup ids out over the 8 XCDs (one L2 each), so with the plain mapping those rows meet eight different L2s.  When the batch
-  // has a multiple of 8 problems, XCD k takes the problems k, k + 8, ... whole, row after row: a problem's E records then pass
+  // has a multiple of 8 problems, XCD k takes the problems k, k + 8, ... whole, row after row: a problem's records then pass
   // through ONE L2 and the gathers hit it.
   int prob = blockIdx.y, a = blockIdx.x;
   if ((gridDim.y & 7) == 0) {
@@ -972,7 +1006,6 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int np = D.npad;
-  const size_t nobs = (size_t)D.nobs;
 #ifdef ORBHIP_SCHUR_PROF
   const bool sr_prof = prob == 0 && lane == 0; const unsigned long long sr_t0 = __builtin_amdgcn_s_memrealtime();
   if (sr_prof && w == 0) g_chol_prof[a & 127][9] += 1;
@@ -982,13 +1015,16 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   __shared__ int s_mf[2][4][2];                                       // mailbox labels: {column b or -1, segment flags}
   double* s_red = s_w; double* s_out = s_w + 4 * 27;
   const int4 rm = D.row_meta[2 * a], rm2 = D.row_meta[2 * a + 1];   // (one round trip: not free_cams -> cam_off -> list)
-  const int lo_a = rm2.x, n_a = rm2.y;
+  const int lo_a = rm2.x, n_a = rm2.y, ca = rm2.z;
   const int d_lo = rm.x, d_hi = rm.y, s_lo = rm.z, s_hi = rm.w;
   const bool fuse = (d_hi - d_lo) == n_a;                              // the diagonal block's pair list IS the camera's list
   const int R = (s_hi - s_lo + 3) >> 2;                                // rounds of (2)
   if (tid < SR_PITCH) s_ec[SR_CH * SR_PITCH + tid] = 0.0;
-  // ---- segment bookkeeping of (2); the first requests go out before (1) so that their round trips overlap it ----
-  struct Idx { int pj0, pj1, pi0, pi1; };
+  // ---- segment bookkeeping of (2) ----
+  struct Idx { int pj0, pj1, pi0, pi1; };                              // pair indices of a segment (two per lane)
+  struct Cam { double qb[4]; double sb; };                             // camera b of a segment: quaternion, S_c,b of this lane's sum
+  const int slot = wave_reduce36_slot(lane);                   // which of a segment's 36 sums this lane ends up holding (or -1)
+  const int slot_u = (slot < 0 ? 0 : slot) / 6, slot_v = (slot < 0 ? 0 : slot) - 6 * slot_u;
   auto ld_meta = [&](int r) -> int4 {
     const int g = s_lo + w + 4 * r;
     return (g < s_hi) ? D.seg[g] : make_int4(0, 0, -1, 0);
@@ -998,78 +1034,90 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (m.z >= 0) {                                                    // (wave-uniform)
       const int e0 = m.x + lane, e1 = m.x + 64 + lane;
       const bool v0 = e0 < m.y, v1 = e1 < m.y;
-      x.pj0 = D.pair_j[v0 ? e0 : m.x]; x.pj1 = D.pair_j[v1 ? e1 : m.x];   // (a lane without a pair gathers the segment's first y: finite wherever the block is)
+      x.pj0 = D.pair_j[v0 ? e0 : m.x]; x.pj1 = D.pair_j[v1 ? e1 : m.x];   // (a lane without a pair gathers the segment's first partner: finite wherever the block is)
       const int p0 = D.pair_i[v0 ? e0 : m.x], p1 = D.pair_i[v1 ? e1 : m.x];
       x.pi0 = v0 ? p0 : -1; x.pi1 = v1 ? p1 : -1;
     }
     return x;
   };
+  auto ld_cam = [&](const int4& m) -> Cam {
+    Cam x; x.sb = 0.0; x.qb[0] = x.qb[1] = x.qb[2] = 0.0; x.qb[3] = 1.0;
+    if (m.z >= 0) {
+      const double* qb = D.poses + 7 * (size_t)(m.w >> 2) + 3;
+#pragma unroll
+      for (int k = 0; k < 4; k++) x.qb[k] = qb[k];
+      x.sb = D.scale_c[6 * (size_t)m.z + slot_v];
+    }
+    return x;
+  };
+  double Ra[9];
+  quat_to_R(D.poses + 7 * (size_t)ca + 3, Ra);
   auto get_x = [&](int pos, double* x) {                       // (a camera with more observations than the LDS holds)
     const int e = lo_a + pos;
-    double ei[18];
-    ld_rec18(D.E, nobs, (size_t)e, ei);
-    e_times_cinv(ei, D.Cinv + 6 * (size_t)D.cam_obs_pt[e], x);
+    double c[8];
+    ld_rec8(D.E, (size_t)e, c);
+    make_yr(c, Ra, D.Ng + 9 * (size_t)D.cam_obs_pt[e], x);
   };
   // ---- (1) camera a's records -> LDS, the rhs of camera a and the diagonal block (a, a) ----
   double acc[27];                                              // 21 lower-triangle sums of the diagonal block, 6 of the rhs
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
-  auto one_obs = [&](int t, bool v, const double* ei, const double* Ci, const double* g) {
-    double ec[18];
-    e_times_cinv(ei, Ci, ec);
+  auto one_obs = [&](int t, bool v, const double* c, const double* ng) {
+    double x[SR_REC];
+    make_yr(c, Ra, ng, x);
     if (v && t < SR_CH) {
 #pragma unroll
-      for (int k = 0; k < 18; k++) s_ec[t * SR_PITCH + k] = ec[k];
+      for (int k = 0; k < SR_REC; k++) s_ec[t * SR_PITCH + k] = x[k];
     }
-    // a thread without a list entry has loaded entry 0 (no branch around the loads): its x becomes 0, the sums keep their bits
+    // a thread without a list entry has loaded entry 0 (no branch around the loads): its Y becomes 0, the sums keep their bits
 #pragma unroll
-    for (int k = 0; k < 18; k++) ec[k] = v ? ec[k] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 6; u++) acc[21 + u] += ec[3 * u] * g[0] + ec[3 * u + 1] * g[1] + ec[3 * u + 2] * g[2];
-    if (fuse) {
-#pragma unroll
-      for (int u = 0; u < 6; u++)
-#pragma unroll
-        for (int v2 = 0; v2 <= u; v2++) acc[u * (u + 1) / 2 + v2] += ec[3 * u] * ei[3 * v2] + ec[3 * u + 1] * ei[3 * v2 + 1] + ec[3 * u + 2] * ei[3 * v2 + 2];
-    }
+    for (int k = 0; k < 9; k++) x[k] = v ? x[k] : 0.0;
+    // rhs: X' g_p = [Y g; r x (Y g)]
+    const double h0 = fma(x[2], ng[8], fma(x[1], ng[7], x[0] * ng[6])), h1 = fma(x[5], ng[8], fma(x[4], ng[7], x[3] * ng[6])), h2 = fma(x[8], ng[8], fma(x[7], ng[7], x[6] * ng[6]));
+    acc[21] += h0; acc[22] += h1; acc[23] += h2;
+    acc[24] += fma(x[10], h2, -(x[11] * h1)); acc[25] += fma(x[11], h0, -(x[9] * h2)); acc[26] += fma(x[9], h1, -(x[10] * h0));
+    if (fuse) pair_acc_lower(x, Ra, c, acc);
   };
-  // Request order = dependence depth: camera a's first two list entries per thread (record + point index) leave first, then the
+  // Request order = dependence depth: camera a's first three list entries per thread (record + point index) leave first, then the
   // segment labels of (2), then what hangs off the point indices, then the pair indices of the first two rounds.
   const bool p1 = !D.fix_points && n_a > 0;
-  const bool v0 = p1 && tid < n_a, v1 = p1 && tid + SC_TPB < n_a;
-  int pt0 = 0, pt1 = 0;
-  double ea[18], eb[18], Ca[6], Cb[6], ga[3], gb[3];
+  const bool v0 = p1 && tid < n_a, v1 = p1 && tid + SC_TPB < n_a, v2 = p1 && tid + 2 * SC_TPB < n_a;
+  double c0[8], c1[8], c2[8], g0[9], g1[9], g2[9];
+  int pt0 = 0, pt1 = 0, pt2 = 0;
   if (p1) {
-    const int e0 = lo_a + (v0 ? tid : 0), e1 = lo_a + (v1 ? tid + SC_TPB : 0);
-    pt0 = D.cam_obs_pt[e0]; pt1 = D.cam_obs_pt[e1];
-    ld_rec18(D.E, nobs, (size_t)e0, ea);
-    ld_rec18(D.E, nobs, (size_t)e1, eb);
+    const int e0 = lo_a + (v0 ? tid : 0), e1 = lo_a + (v1 ? tid + SC_TPB : 0), e2 = lo_a + (v2 ? tid + 2 * SC_TPB : 0);
+    pt0 = D.cam_obs_pt[e0]; pt1 = D.cam_obs_pt[e1]; pt2 = D.cam_obs_pt[e2];
+    ld_rec8(D.E, (size_t)e0, c0); ld_rec8(D.E, (size_t)e1, c1); ld_rec8(D.E, (size_t)e2, c2);
   }
   __builtin_amdgcn_sched_barrier(0);
   int4 m0 = ld_meta(0), m1 = ld_meta(1), m2 = ld_meta(2);
   if (p1) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) { Ca[k] = D.Cinv[6 * (size_t)pt0 + k]; Cb[k] = D.Cinv[6 * (size_t)pt1 + k]; }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { ga[k] = D.gps[3 * (size_t)pt0 + k]; gb[k] = D.gps[3 * (size_t)pt1 + k]; }
+    for (int k = 0; k < 9; k++) { g0[k] = D.Ng[9 * (size_t)pt0 + k]; g1[k] = D.Ng[9 * (size_t)pt1 + k]; }
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (p1) one_obs(tid, v0, ea, Ca, ga);
+  Idx i0 = ld_idx(m0);
   __builtin_amdgcn_sched_barrier(0);
-  Idx i0 = ld_idx(m0);                                         // (into the registers the first entry has left)
-  __builtin_amdgcn_sched_barrier(0);
-  if (p1) one_obs(tid + SC_TPB, v1, eb, Cb, gb);
-  __builtin_amdgcn_sched_barrier(0);
-  Idx i1 = ld_idx(m1);
   if (p1) {
-    for (int t = tid + 2 * SC_TPB; t < n_a; t += SC_TPB) {
-      const int e = lo_a + t, pt = D.cam_obs_pt[e];
-      double ei[18];
-      ld_rec18(D.E, nobs, (size_t)e, ei);
-      one_obs(t, true, ei, D.Cinv + 6 * (size_t)pt, D.gps + 3 * (size_t)pt);
+    one_obs(tid, v0, c0, g0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 9; k++) g2[k] = D.Ng[9 * (size_t)pt2 + k];         // (into the registers the first entry has left)
+    __builtin_amdgcn_sched_barrier(0);
+    one_obs(tid + SC_TPB, v1, c1, g1);
+    one_obs(tid + 2 * SC_TPB, v2, c2, g2);
+    for (int t = tid + 3 * SC_TPB; t < n_a; t += SC_TPB) {
+      const int e = lo_a + t;
+      double c[8], ng[9];
+      ld_rec8(D.E, (size_t)e, c);
+      const double* gp = D.Ng + 9 * (size_t)D.cam_obs_pt[e];
+#pragma unroll
+      for (int k = 0; k < 9; k++) ng[k] = gp[k];
+      one_obs(t, true, c, ng);
     }
   }
   SR_STAMP(0, w == 0);
+  __builtin_amdgcn_sched_barrier(0);
   // what the stores behind the reduction need (21 threads a diagonal entry, 6 an rhs entry): requested here, used behind the reduction
   double o_b = 0.0, o_s = 1.0, o_s2 = 1.0, o_r = 1.0;
   int o_u = 0, o_v = 0;
@@ -1082,26 +1130,26 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     o_u = tid - 21;
     o_b = D.gc[6 * (size_t)a + o_u]; o_s = D.scale_c[6 * (size_t)a + o_u];
   }
-  // the y records of round 0 (requested here: the reduction below hides their round trip)
-  double y0[18], y1[18];
-  auto ld_y = [&](const int4& m, const Idx& ix) {
-    if (m.z >= 0) { ld_rec18(D.E, nobs, (size_t)ix.pj0, y0); ld_rec18(D.E, nobs, (size_t)ix.pj1, y1); }
+  const double sa = D.scale_c[6 * (size_t)a + slot_u];          // S_c,a of this lane's sum in (2)
+  // the partner records of round 0 (requested here: the reduction below hides their round trip)
+  double y0[8], y1[8];
+  auto ld_y = [&](const int4& m, const Idx& ix, double* ya, double* yb) {
+    if (m.z >= 0) { ld_rec8(D.E, (size_t)ix.pj0, ya); ld_rec8(D.E, (size_t)ix.pj1, yb); }
   };
-  ld_y(m0, i0);
+  ld_y(m0, i0, y0, y1);
+  Cam k0 = ld_cam(m0);
+  Idx i1 = ld_idx(m1);
   if (!fuse) {                                                 // a camera that sees a point twice: the literal pair list (cross terms)
     __syncthreads();
     for (int e = d_lo + tid; e < d_hi; e += SC_TPB) {
       const int pos = D.pair_i[e];
-      double x[18], y[18];
-      ld_rec18(D.E, nobs, (size_t)D.pair_j[e], y);
+      double x[SR_REC], y[8];
+      ld_rec8(D.E, (size_t)D.pair_j[e], y);
       if (pos < SR_CH) {
 #pragma unroll
-        for (int k = 0; k < 18; k++) x[k] = s_ec[pos * SR_PITCH + k];
+        for (int k = 0; k < SR_REC; k++) x[k] = s_ec[pos * SR_PITCH + k];
       } else get_x(pos, x);
-#pragma unroll
-      for (int u = 0; u < 6; u++)
-#pragma unroll
-        for (int v = 0; v <= u; v++) acc[u * (u + 1) / 2 + v] += x[3 * u] * y[3 * v] + x[3 * u + 1] * y[3 * v + 1] + x[3 * u + 2] * y[3 * v + 2];
+      pair_acc_lower(x, Ra, y, acc);
     }
   }
   {                                                            // the 27 sums of the workgroup (the barriers also publish the records)
@@ -1109,8 +1157,7 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int k = 0; k < 36; k++) a36[k] = k < 27 ? acc[k] : 0.0;
     const double t = wave_reduce36(a36, lane);
-    const int sl = wave_reduce36_slot(lane);
-    if (sl >= 0 && sl < 27) s_red[w * 27 + sl] = t;
+    if (slot >= 0 && slot < 27) s_red[w * 27 + slot] = t;
     __syncthreads();
     if (tid < 27) s_out[tid] = (s_red[tid] + s_red[27 + tid]) + (s_red[2 * 27 + tid] + s_red[3 * 27 + tid]);
     __syncthreads();
@@ -1119,47 +1166,48 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   if (tid < 21) {
     double bs = o_b * o_s * o_s2;
     if (o_u == o_v) bs += fmin(fmax(bs, 1e-6), 1e32) / o_r;
-    D.S[(size_t)(6 * a + o_u) * np + 6 * a + o_v] = bs - s_out[tid];
+    D.S[(size_t)(6 * a + o_u) * np + 6 * a + o_v] = bs - o_s * o_s2 * s_out[tid];
   } else if (tid < 27) {
-    const double rv = o_b * o_s - s_out[tid];
+    const double rv = o_b * o_s - o_s * s_out[tid];
     D.rhs[6 * a + o_u] = rv;
     D.S[(size_t)np * np + 6 * a + o_u] = rv;                   // augmented row: forward substitution rides the factorisation
   }
   __syncthreads();                                             // (s_out is read; the mailboxes share its memory)
   SR_STAMP(2, w == 0);
   // ---- (2) the off-diagonal blocks, a segment per wave and round ----
-  const int slot = wave_reduce36_slot(lane);                   // which of a segment's 36 sums this lane ends up holding (or -1)
-  double carry = 0.0;                                          // wave 0, lanes < 36: the running sum of the block whose segments are arriving
+  double carry = 0.0;                                          // wave 0: the running sum of the block whose segments are arriving
   for (int r = 0; r < R; r++) {
     const int buf = r & 1;
     double mine = 0.0;
     if (m0.z >= 0) {
+      // next round's gathers (their indices arrived a round ago) and the indices of the round after it go out first
+      double z0[8], z1[8];
+      ld_y(m1, i1, z0, z1);
+      const Cam k1 = ld_cam(m1);
+      const Idx i2 = ld_idx(m2);
+      const int4 m3 = ld_meta(r + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      double Rb[9];
+      quat_to_R(k0.qb, Rb);
       double a36[36];
 #pragma unroll
       for (int k = 0; k < 36; k++) a36[k] = 0.0;
       auto pair_prod = [&](int pos, const double* y) {
-        double x[18];
+        double x[SR_REC];
         if (pos < SR_CH) {
           const int rec = (pos < 0 ? SR_CH : pos) * SR_PITCH;
 #pragma unroll
-          for (int k = 0; k < 18; k++) x[k] = s_ec[rec + k];
+          for (int k = 0; k < SR_REC; k++) x[k] = s_ec[rec + k];
         } else get_x(pos, x);
-#pragma unroll
-        for (int u = 0; u < 6; u++)
-#pragma unroll
-          for (int v = 0; v < 6; v++) a36[6 * u + v] = fma(x[3 * u + 2], y[3 * v + 2], fma(x[3 * u + 1], y[3 * v + 1], fma(x[3 * u], y[3 * v], a36[6 * u + v])));
+        pair_acc(x, Rb, y, a36);
       };
       pair_prod(i0.pi0, y0);
       pair_prod(i0.pi1, y1);
-      mine = wave_reduce36(a36, lane);                           // (the lane with slot k holds the total of sum k)
-      // next round's gathers (their indices arrived a round ago) and the indices of the round after it go out here, into the registers
-      // the sums have just left; the barrier and wave 0's additions below run under their round trip
-      __builtin_amdgcn_sched_barrier(0);
-      ld_y(m1, i1);
-      const Idx i2 = ld_idx(m2);
-      const int4 m3 = ld_meta(r + 3);
+      mine = wave_reduce36(a36, lane) * (sa * k0.sb);            // (the lane with slot k holds the total of sum k)
       if (lane == 0) { s_mf[buf][w][0] = m0.z; s_mf[buf][w][1] = m0.w; }
-      m0 = m1; m1 = m2; m2 = m3; i0 = i1; i1 = i2;
+      m0 = m1; m1 = m2; m2 = m3; i0 = i1; i1 = i2; k0 = k1;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { y0[k] = z0[k]; y1[k] = z1[k]; }
     } else {
       if (lane == 0) { s_mf[buf][w][0] = -1; s_mf[buf][w][1] = 0; }
       m0 = m1; m1 = m2; m2 = make_int4(0, 0, -1, 0);          // (a wave's segments end at most one round before the row's)
@@ -3392,19 +3440,21 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
   double acc[2] = {0.0, 0.0};              // model cost change, |dx|^2
   if (ok && !D.fix_points)
     for (int i = olo + tid; i < ohi; i += BS_TPB) {
-      const int cc = D.cam_col[D.obs_cam[i]];
+      const int c = D.obs_cam[i], cc = D.cam_col[c];
       double t[3] = {0.0, 0.0, 0.0};
       if (cc >= 0) {
+        // E^T y of the factored record (k_ba_E): S_p R^T W (yt - r x yw), y~ = S_c y; the S_p factor is applied per point below
         const double* y = D.rhs + 6 * cc;
-        double E[18];
-        ld_rec18(D.E, n, (size_t)D.cam_pos[i], E);            // (camera-major records)
+        const double* sc = D.scale_c + 6 * (size_t)cc;
+        double e[8], Rc[9];
+        ld_rec8(D.E, (size_t)D.cam_pos[i], e);
+        quat_to_R(D.poses + 7 * (size_t)c + 3, Rc);
+        const double yt0 = y[0] * sc[0], yt1 = y[1] * sc[1], yt2 = y[2] * sc[2], yw0 = y[3] * sc[3], yw1 = y[4] * sc[4], yw2 = y[5] * sc[5];
+        const double r0 = e[5], r1 = e[6], r2 = e[7];
+        const double d0 = yt0 - (r1 * yw2 - r2 * yw1), d1 = yt1 - (r2 * yw0 - r0 * yw2), d2 = yt2 - (r0 * yw1 - r1 * yw0);
+        const double q0 = fma(e[2], d2, e[0] * d0), q1 = fma(e[3], d2, e[1] * d1), q2 = fma(e[4], d2, fma(e[3], d1, e[2] * d0));
 #pragma unroll
-        for (int v = 0; v < 3; v++) {
-          double sacc = 0;
-#pragma unroll
-          for (int u = 0; u < 6; u++) sacc += E[3 * u + v] * y[u];
-          t[v] = sacc;
-        }
+        for (int v = 0; v < 3; v++) t[v] = fma(Rc[6 + v], q2, fma(Rc[3 + v], q1, Rc[v] * q0));
       }
       D.t3[3 * (size_t)i] = t[0]; D.t3[3 * (size_t)i + 1] = t[1]; D.t3[3 * (size_t)i + 2] = t[2];
     }
@@ -3417,8 +3467,9 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
         const double g0 = D.gps[3 * (size_t)p], g1 = D.gps[3 * (size_t)p + 1], g2 = D.gps[3 * (size_t)p + 2];
         double T0 = 0.0, T1 = 0.0, T2 = 0.0;                    // sum over the point's observations of E_i^T y_cam, in observation order
         double t[3] = {g0, g1, g2};                             // g_p - sum: subtracted one by one, as before
+        const double* spp = D.scale_p + 3 * (size_t)p;
         for (int i = lo; i < hi; i++) {
-          const double a0 = D.t3[3 * (size_t)i], a1 = D.t3[3 * (size_t)i + 1], a2 = D.t3[3 * (size_t)i + 2];
+          const double a0 = D.t3[3 * (size_t)i] * spp[0], a1 = D.t3[3 * (size_t)i + 1] * spp[1], a2 = D.t3[3 * (size_t)i + 2] * spp[2];
           t[0] -= a0; t[1] -= a1; t[2] -= a2; T0 += a0; T1 += a1; T2 += a2;
         }
         const double* Ci = D.Cinv + 6 * (size_t)p;
@@ -4075,7 +4126,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   // Schur block pair lists: for every point, all ordered observation pairs (i, j) with col_i <= col_j,
   // grouped by block (col_i, col_j) with a counting sort (stable: point order, then list order).
   std::vector<int4> row_meta((size_t)2 * std::max(nfc, 1), make_int4(0, 0, 0, 0)), segs;
-  for (int a = 0; a < nfc; a++) { const int ca = free_cams[a]; row_meta[2 * (size_t)a + 1] = make_int4(cam_off[ca], cam_off[ca + 1] - cam_off[ca], 0, 0); }
+  for (int a = 0; a < nfc; a++) { const int ca = free_cams[a]; row_meta[2 * (size_t)a + 1] = make_int4(cam_off[ca], cam_off[ca + 1] - cam_off[ca], ca, 0); }
   int* pair_i = nullptr; int* pair_j = nullptr; size_t npairs_all = 0;
   if (!opts->fix_points && nfc > 0) {
     // Per point, the free observations are first sorted by column (insertion sort, a handful of entries): the pairs with
@@ -4114,7 +4165,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
       const int s_lo = (int)segs.size();
       for (int b2 = a + 1; b2 < nfc; b2++) {
         const size_t k = (size_t)a * nfc + b2;
-        for (int e = cnt[k]; e < cnt[k + 1]; e += SR_SEG) segs.push_back(make_int4(e, std::min(e + SR_SEG, cnt[k + 1]), b2, (e == cnt[k] ? 1 : 0) | (e + SR_SEG >= cnt[k + 1] ? 2 : 0)));
+        for (int e = cnt[k]; e < cnt[k + 1]; e += SR_SEG) segs.push_back(make_int4(e, std::min(e + SR_SEG, cnt[k + 1]), b2, (e == cnt[k] ? 1 : 0) | (e + SR_SEG >= cnt[k + 1] ? 2 : 0) | (free_cams[b2] << 2)));
       }
       row_meta[2 * (size_t)a] = make_int4(cnt[kd], cnt[kd + 1], s_lo, (int)segs.size());
     }
@@ -4165,8 +4216,8 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
   D.C = H.alloc<double>(6 * (size_t)npts, &rc); D.gp = H.alloc<double>(3 * (size_t)npts, &rc);
   D.scale_c = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc); D.scale_p = H.alloc<double>(3 * (size_t)npts, &rc);
-  D.Cinv = H.alloc<double>(6 * (size_t)npts, &rc); D.gps = H.alloc<double>(3 * (size_t)npts, &rc);
-  D.E = H.alloc<double>(18 * (size_t)nobs, &rc);
+  D.Cinv = H.alloc<double>(6 * (size_t)npts, &rc); D.gps = H.alloc<double>(3 * (size_t)npts, &rc); D.Ng = H.alloc<double>(9 * (size_t)npts, &rc);
+  D.E = H.alloc<double>(8 * (size_t)std::max(nobs, 1), &rc);
   D.t3 = H.alloc<double>(3 * (size_t)std::max(nobs, 1), &rc);
   D.cam_local = in.cam_local ? H.arena_dev(H.arena_copy(in.cam_local, ncam, &rc)) : nullptr;
   D.erase = in.cam_local ? H.alloc<unsigned char>(std::max(nobs, 1), &rc) : nullptr;
