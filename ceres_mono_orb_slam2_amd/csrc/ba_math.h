@@ -47,13 +47,15 @@ BA_HD void quat_plus(const double* q, const double* d, double* out) {
 
 // r = sqrt(rho') * w * (uv - pi(K (q X + t))); returns rho (cost = rho/2).
 // Jc (2x6, [t | half-angle delta]) and Jp (2x3) may be NULL.  robust: 0 = no loss, 1 = Huber(delta), 2 = Huber block + its loss-free twin.
+// RX_out (may be NULL): the rotated point R X the Jacobians are built from (Jc = Q [I | -2 [RX]x], Jp = Q R).
 BA_HD double reproj_eval(const double* K4, const double* pose7, const double* X, double u_obs, double v_obs,
-                         double w, int robust, double huber, double* r, double* Jc, double* Jp) {
+                         double w, int robust, double huber, double* r, double* Jc, double* Jp, double* RX_out = nullptr) {
   const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
   const double* t = pose7;
   const double* q = pose7 + 3;
   double RX[3];
   quat_rotate(q, X, RX);
+  if (RX_out) { RX_out[0] = RX[0]; RX_out[1] = RX[1]; RX_out[2] = RX[2]; }
   const double p0 = RX[0] + t[0], p1 = RX[1] + t[1], p2 = RX[2] + t[2];
   const double u = (fx * p0 + cx * p2) / p2;
   const double v = (fy * p1 + cy * p2) / p2;

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_sim3_lm(const double* __restrict__ K1s,
 struct BaState {
   double radius, decrease_factor, x_cost, x_norm, initial_cost, cand_cost, model_cost_change, step_norm2, gmax;
   int iteration, successful_steps, termination, done, need_eval, first, valid, invalid_steps, chol_fail, accepted, max_iters;
-  int e_dirty;     // the iterate (or, the first time, the Jacobi scaling) changed since the E records were written: k_ba_E rewrites them
+  int e_dirty;     // (unused since the factored records are written by k_ba_eval; kept for the layout of the collected state)
 };
 
 struct BaDev {            // device pointers of one problem
@@ -601,11 +601,11 @@ struct BaDev {            // device pointers of one problem
   const int* pt_off;                 // [npts+1] observations grouped by point
   const int* cam_off; const int* cam_obs; const int* cam_obs_pt;   // per-camera lists (sorted by point)
   const int* cam_pos;                // [nobs] position of an observation inside its camera's list (inverse of cam_obs)
-  double* JcR;                       // [nobs][14] per-camera-ordered records {Jc (12), r (2)}: k_ba_cam_blocks streams them
-  double* r; double* Jp;             // SoA: r[2][nobs], Jp[6][nobs] (the landmark blocks read them; the camera Jacobians live in JcR only)
+  double* Hc;                        // [nobs][3] camera-major: h = Q^T r of every observation (with the E record: all k_ba_cam_blocks needs)
+  double* r; double* Jp;             // SoA: r[2][nobs], Jp[6][nobs] (the landmark blocks read them; the camera Jacobians live factored in E / Hc)
   double* B; double* gc; double* C; double* gp;       // unscaled blocks: B[nfc][21], gc[nfc][6], C[npts][6], gp[npts][3]
   double* scale_c; double* scale_p;  // Jacobi scaling [nfc][6], [npts][3]
-  double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] factored 64-byte records in camera-major order (ld_rec8): rewritten only when the iterate changes (k_ba_E)
+  double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] factored 64-byte records in camera-major order (ld_rec8), written by k_ba_eval
   double* Ng;                        // [npts][9] {N = S_p (C_s+D)^-1 S_p (6, symmetric), g_p (3)}: what k_ba_schur needs of a point, one gather
   double* t3;                        // [nobs][3] E_i^T y_cam of the landmark back-substitution
   double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
@@ -638,6 +638,24 @@ __device__ __forceinline__ StFlags ld_flags(const BaState* st) {
 
 #define BA_TPB 256
 
+// The per-observation block E = (Jc S_c)^T (Jp S_p) (6x3) is never stored: it FACTORS.  With Q = sqrt(rho') w dpi/dX_c (2x3, four
+// non-zero entries), the rotated point RX and the camera's rotation R (ba_math.h: Jc = Q [I | -2 [RX]x], Jp = Q R),
+//     E = S_c [W; [r]x W] R S_p,    W = Q^T Q (symmetric 3x3 with W01 = 0: five numbers),  r = 2 RX,
+// so an observation keeps {w00, w11, w02, w12, w22, r0, r1, r2}: 64 bytes - half a cache line, aligned - instead of the 144 of the
+// 18 products, and what depends on the camera only (R, S_c) or on the point only (S_p) is applied once per block / per point:
+//     E_a (C_s+D)^-1 E_b^T = S_c,a [ G_a (R_a N R_b^T) G_b^T ] S_c,b,   G = [W; [r]x W] (6x3),  N = S_p (C_s+D)^-1 S_p.
+// (Round 4: 18-double records made k_ba_schur move 2 GB per launch of a 64-problem batch through a 4 MB L2 per XCD; a problem's
+// records are now 3.2 MB.)  The algebra is exact whatever the norm of the quaternion (Jc and Jp are built from the same RX and R).
+// Records are stored in CAMERA-MAJOR order (record index = cam_pos[i], the position of the observation in the concatenated
+// per-camera lists): k_ba_schur streams camera a's records, and those it gathers from a camera b ascend inside b's contiguous run.
+// They depend on the iterate only - not on the LM radius, not on the scaling: k_ba_eval writes them with the Jacobians (mode 0), beside
+// h = Q^T r (Hc), and k_ba_cam_blocks forms Jc^T Jc and Jc^T r from the same records (round 4 kept 14 doubles of Jc and r per
+// observation for it, and a kernel of its own, k_ba_E, rewrote 18-double E records whenever the iterate had changed).
+__device__ __forceinline__ void ld_rec8(const double* __restrict__ base, size_t q, double* c) {
+  const double2* m = (const double2*)(base + 8 * q);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const double2 v = m[k]; c[2 * k] = v.x; c[2 * k + 1] = v.y; }
+}
 // ---- residuals + Jacobians at x (mode 0) or cost only at the candidate (mode 1) -------------------
 __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv, int mode) {
   const BaDev D = Dv[blockIdx.y];
@@ -654,18 +672,26 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
     const int c = D.obs_cam[i], p = D.obs_pt[i];
     const double* poses = mode ? D.cand_poses : D.poses;
     const double* pts = mode ? D.cand_pts : D.pts;
-    double r[2], Jc[12], Jp[6];
+    double r[2], Jc[12], Jp[6], RX[3];
     const bool wantc = (mode == 0) && D.cam_col[c] >= 0, wantp = (mode == 0) && !D.fix_points;
     double rho = reproj_eval(D.K4 + 4 * c, poses + 7 * c, pts + 3 * (size_t)p, D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
-                             D.obs_w[i], D.obs_robust[i], D.huber, r, wantc ? Jc : nullptr, wantp ? Jp : nullptr);
+                             D.obs_w[i], D.obs_robust[i], D.huber, r, wantc ? Jc : nullptr, wantp ? Jp : nullptr, RX);
     acc[0] = 0.5 * rho;
     if (mode == 0) {
       const size_t n = D.nobs;
       D.r[i] = r[0]; D.r[n + i] = r[1];
       if (wantc) {
-        double* rec = D.JcR + 14 * (size_t)D.cam_pos[i];            // the same values, grouped by camera (contiguous 112-byte records)
-        for (int k = 0; k < 12; k++) rec[k] = Jc[k];
-        rec[12] = r[0]; rec[13] = r[1];
+        // the camera Jacobian leaves in FACTORED form, grouped by camera (the comment above ld_rec8): {W = Q^T Q, r = 2 RX} is the record
+        // k_ba_schur / k_ba_backsub / k_ba_cam_blocks work from, h = Q^T r the gradient's share
+        const size_t q = (size_t)D.cam_pos[i];
+        const double q00 = Jc[0], q02 = Jc[2], q11 = Jc[7], q12 = Jc[8];
+        double2* m = (double2*)(D.E + 8 * q);
+        m[0] = make_double2(q00 * q00, q11 * q11);
+        m[1] = make_double2(q00 * q02, q11 * q12);
+        m[2] = make_double2(q02 * q02 + q12 * q12, 2.0 * RX[0]);
+        m[3] = make_double2(2.0 * RX[1], 2.0 * RX[2]);
+        double* h = D.Hc + 3 * q;
+        h[0] = q00 * r[0]; h[1] = q11 * r[1]; h[2] = q02 * r[0] + q12 * r[1];
       }
       if (wantp) for (int k = 0; k < 6; k++) D.Jp[k * n + i] = Jp[k];
     }
@@ -693,17 +719,29 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
   for (int e = D.cam_off[c] + threadIdx.x; e < D.cam_off[c + 1]; e += BA_TPB) {
-    const double* rec = D.JcR + 14 * (size_t)e;           // streamed: the list order is the record order
-    double J[12];
+    // streamed: the list order is the record order.  Jc = Q [I | -[r]x]:  Jc^T Jc = [W, -K; -K^T, L] with K = W [r]x, L = -[r]x K;  Jc^T res = [h; r x h]
+    double c8[8];
+    ld_rec8(D.E, (size_t)e, c8);
+    const double* hp = D.Hc + 3 * (size_t)e;
+    const double h0 = hp[0], h1 = hp[1], h2 = hp[2];
+    const double w00 = c8[0], w11 = c8[1], w02 = c8[2], w12 = c8[3], w22 = c8[4], r0 = c8[5], r1 = c8[6], r2 = c8[7];
+    const double W[3][3] = {{w00, 0.0, w02}, {0.0, w11, w12}, {w02, w12, w22}};
+    double K[3][3];
 #pragma unroll
-    for (int k = 0; k < 12; k++) J[k] = rec[k];
-    const double r0 = rec[12], r1 = rec[13];
+    for (int i = 0; i < 3; i++) { K[i][0] = W[i][1] * r2 - W[i][2] * r1; K[i][1] = W[i][2] * r0 - W[i][0] * r2; K[i][2] = W[i][0] * r1 - W[i][1] * r0; }
+    acc[sym6(0, 0)] += w00; acc[sym6(0, 2)] += w02; acc[sym6(1, 1)] += w11; acc[sym6(1, 2)] += w12; acc[sym6(2, 2)] += w22;
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
-      acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
+    for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int b = a; b < 6; b++) acc[sym6(a, b)] += J[a] * J[b] + J[6 + a] * J[6 + b];
+      for (int j = 0; j < 3; j++) acc[sym6(i, 3 + j)] -= K[i][j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      acc[sym6(3, 3 + j)] += r2 * K[1][j] - r1 * K[2][j];              // L = -[r]x K, upper triangle
+      if (j >= 1) acc[sym6(4, 3 + j)] += r0 * K[2][j] - r2 * K[0][j];
+      if (j >= 2) acc[sym6(5, 3 + j)] += r1 * K[0][j] - r0 * K[1][j];
     }
+    acc[21] += h0; acc[22] += h1; acc[23] += h2;
+    acc[24] += r1 * h2 - r2 * h1; acc[25] += r2 * h0 - r0 * h2; acc[26] += r0 * h1 - r1 * h0;
   }
   block_reduce_dpp<27>(acc, s_red, s_out);
   if (threadIdx.x < 21) D.B[21 * (size_t)cc + threadIdx.x] = s_out[threadIdx.x];
@@ -849,45 +887,6 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restric
   for (int k = 0; k < 3; k++) ng[6 + k] = D.gp[3 * (size_t)p + k];
 }
 
-// The per-observation block E = (Jc S_c)^T (Jp S_p) (6x3) is never stored: it FACTORS.  With Q = sqrt(rho') w dpi/dX_c (2x3, four
-// non-zero entries), the rotated point RX and the camera's rotation R (ba_math.h: Jc = Q [I | -2 [RX]x], Jp = Q R),
-//     E = S_c [W; [r]x W] R S_p,    W = Q^T Q (symmetric 3x3 with W01 = 0: five numbers),  r = 2 RX,
-// so an observation keeps {w00, w11, w02, w12, w22, r0, r1, r2}: 64 bytes - half a cache line, aligned - instead of the 144 of the
-// 18 products, and what depends on the camera only (R, S_c) or on the point only (S_p) is applied once per block / per point:
-//     E_a (C_s+D)^-1 E_b^T = S_c,a [ G_a (R_a N R_b^T) G_b^T ] S_c,b,   G = [W; [r]x W] (6x3),  N = S_p (C_s+D)^-1 S_p.
-// (Round 4: 18-double records made k_ba_schur move 2 GB per launch of a 64-problem batch through a 4 MB L2 per XCD; a problem's
-// records are now 3.2 MB.)  The algebra is exact whatever the norm of the quaternion (Jc and Jp are built from the same RX and R).
-// Records are stored in CAMERA-MAJOR order (record index = cam_pos[i], the position of the observation in the concatenated
-// per-camera lists): k_ba_schur streams camera a's records, and those it gathers from a camera b ascend inside b's contiguous run.
-// They depend on the iterate only - not on the LM radius, not on the scaling - and are rewritten when the iterate has changed
-// (after_eval raises e_dirty, the next k_ba_iter_begin clears it).
-__device__ __forceinline__ void ld_rec8(const double* __restrict__ base, size_t q, double* c) {
-  const double2* m = (const double2*)(base + 8 * q);
-#pragma unroll
-  for (int k = 0; k < 4; k++) { const double2 v = m[k]; c[2 * k] = v.x; c[2 * k + 1] = v.y; }
-}
-__global__ __launch_bounds__(BA_TPB) void k_ba_E(const BaDev* __restrict__ Dv) {
-  const BaDev D = Dv[blockIdx.y];
-  const BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  const int dirty = st->e_dirty;
-  if (F.done || !dirty || D.fix_points) return;
-  const int i = blockIdx.x * BA_TPB + threadIdx.x;
-  if (i >= D.nobs) return;
-  const int c = D.obs_cam[i];
-  if (D.cam_col[c] < 0) return;
-  const int p = D.obs_pt[i];
-  double r[2], Jc[12], RX[3];
-  (void)reproj_eval(D.K4 + 4 * c, D.poses + 7 * c, D.pts + 3 * (size_t)p, D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
-                    D.obs_w[i], D.obs_robust[i], D.huber, r, Jc, nullptr);
-  quat_rotate(D.poses + 7 * c + 3, D.pts + 3 * (size_t)p, RX);            // (the RX reproj_eval used)
-  const double q00 = Jc[0], q02 = Jc[2], q11 = Jc[7], q12 = Jc[8];
-  double2* m = (double2*)(D.E + 8 * (size_t)D.cam_pos[i]);
-  m[0] = make_double2(q00 * q00, q11 * q11);
-  m[1] = make_double2(q00 * q02, q11 * q12);
-  m[2] = make_double2(q02 * q02 + q12 * q12, 2.0 * RX[0]);
-  m[3] = make_double2(2.0 * RX[1], 2.0 * RX[2]);
-}
 // X' = G (R_a N) of one observation of camera a is [Y; [r]x Y] with Y = W (R_a N) (3x3): twelve numbers {Y, r} stand for the 6x3 block.
 // c = the observation's record, Ra row-major, N6 = {n00,n01,n02,n11,n12,n22}; out: yr[0..8] = Y (row-major), yr[9..11] = r
 __device__ __forceinline__ void make_yr(const double* __restrict__ c, const double* __restrict__ Ra, const double* __restrict__ N6, double* __restrict__ yr) {
@@ -3443,7 +3442,7 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
       const int c = D.obs_cam[i], cc = D.cam_col[c];
       double t[3] = {0.0, 0.0, 0.0};
       if (cc >= 0) {
-        // E^T y of the factored record (k_ba_E): S_p R^T W (yt - r x yw), y~ = S_c y; the S_p factor is applied per point below
+        // E^T y of the factored record (k_ba_eval): S_p R^T W (yt - r x yw), y~ = S_c y; the S_p factor is applied per point below
         const double* y = D.rhs + 6 * cc;
         const double* sc = D.scale_c + 6 * (size_t)cc;
         double e[8], Rc[9];
@@ -4207,7 +4206,7 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.obs_w = H.arena_dev(ow); D.obs_robust = H.arena_dev(orb);
   D.pt_off = H.arena_dev(pt_off); D.cam_off = H.arena_dev(cam_off);
   D.cam_obs = H.arena_dev(cam_obs); D.cam_obs_pt = H.arena_dev(cam_obs_pt);
-  D.cam_pos = H.arena_dev(cam_pos); D.JcR = H.alloc<double>(14 * (size_t)std::max(nobs, 1), &rc);
+  D.cam_pos = H.arena_dev(cam_pos); D.Hc = H.alloc<double>(3 * (size_t)std::max(nobs, 1), &rc);
   D.free_cams = H.arena2_dev(H.arena2_copy(free_cams.data(), nfc, &rc));
   D.row_meta = H.arena2_dev(H.arena2_copy(row_meta.data(), row_meta.size(), &rc));
   D.seg = H.arena2_dev(H.arena2_copy(segs.data(), segs.size(), &rc));
@@ -4368,7 +4367,6 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 0);
     hipLaunchKernelGGL(k_ba_cam_blocks, dim3(g_camcount + g_pt, ny), dim3(BA_TPB), 0, s, Dv, g_camcount);      // + the landmark blocks
     hipLaunchKernelGGL(k_ba_after_eval, dim3(1, ny), dim3(AE_TPB), 0, s, Dv);
-    hipLaunchKernelGGL(k_ba_E, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);              // (does something only when the iterate has changed)
   };
   auto enqueue_iteration = [&]() {
     hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(64), 0, s, Dv);
