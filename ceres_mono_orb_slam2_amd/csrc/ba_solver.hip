@@ -601,8 +601,7 @@ struct BaDev {            // device pointers of one problem
   const int* pt_off;                 // [npts+1] observations grouped by point
   const int* cam_off; const int* cam_obs; const int* cam_obs_pt;   // per-camera lists (sorted by point)
   const int* cam_pos;                // [nobs] position of an observation inside its camera's list (inverse of cam_obs)
-  double* Hc;                        // [nobs][3] camera-major: h = Q^T r of every observation (with the E record: all k_ba_cam_blocks needs)
-  double* r; double* Jp;             // SoA: r[2][nobs], Jp[6][nobs] (the landmark blocks read them; the camera Jacobians live factored in E / Hc)
+  double* Hc;                        // [nobs][3] camera-major: h = Q^T res of every observation (with the E record: all the block kernels need)
   double* B; double* gc; double* C; double* gp;       // unscaled blocks: B[nfc][21], gc[nfc][6], C[npts][6], gp[npts][3]
   double* scale_c; double* scale_p;  // Jacobi scaling [nfc][6], [npts][3]
   double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] factored 64-byte records in camera-major order (ld_rec8), written by k_ba_eval
@@ -667,33 +666,51 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
   if (mode == 1 && !F.valid) return;
   if ((int)blockIdx.x * BA_TPB >= max(D.nobs, 1)) return;               // batched launch: grid.x is the maximum over the problems
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ double s_rec[BA_TPB / 64][64][13];        // mode 0: the wave's records {W (5), r (3), h (3)} on their way out (+ pad: odd pitch)
+  __shared__ int s_q[BA_TPB / 64][64];                 // ... and their places (camera-major position, -1: none)
+  int q_mine = -1;
   double acc[1] = {0.0};
   if (i < D.nobs) {
     const int c = D.obs_cam[i], p = D.obs_pt[i];
     const double* poses = mode ? D.cand_poses : D.poses;
     const double* pts = mode ? D.cand_pts : D.pts;
-    double r[2], Jc[12], Jp[6], RX[3];
-    const bool wantc = (mode == 0) && D.cam_col[c] >= 0, wantp = (mode == 0) && !D.fix_points;
+    double r[2], Jc[12], RX[3];
+    // (an observation by a FIXED camera still feeds its landmark's block: its record is written too unless the landmarks are fixed)
+    const bool want = (mode == 0) && (D.cam_col[c] >= 0 || !D.fix_points);
     double rho = reproj_eval(D.K4 + 4 * c, poses + 7 * c, pts + 3 * (size_t)p, D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
-                             D.obs_w[i], D.obs_robust[i], D.huber, r, wantc ? Jc : nullptr, wantp ? Jp : nullptr, RX);
+                             D.obs_w[i], D.obs_robust[i], D.huber, r, want ? Jc : nullptr, nullptr, RX);
     acc[0] = 0.5 * rho;
     if (mode == 0) {
-      const size_t n = D.nobs;
-      D.r[i] = r[0]; D.r[n + i] = r[1];
-      if (wantc) {
-        // the camera Jacobian leaves in FACTORED form, grouped by camera (the comment above ld_rec8): {W = Q^T Q, r = 2 RX} is the record
-        // k_ba_schur / k_ba_backsub / k_ba_cam_blocks work from, h = Q^T r the gradient's share
-        const size_t q = (size_t)D.cam_pos[i];
+      if (want) {
+        q_mine = D.cam_pos[i];
+        // The Jacobians leave in FACTORED form, grouped by camera (the comment above ld_rec8): {W = Q^T Q, r = 2 RX} is the record
+        // k_ba_schur / k_ba_backsub / the block kernels work from, h = Q^T res the gradients' share - 88 bytes per observation, the
+        // only thing this kernel writes (it is bound by the HBM WRITE rate, ~2 TB/s: the 2x6 and 2x3 Jacobians were 160 bytes)
         const double q00 = Jc[0], q02 = Jc[2], q11 = Jc[7], q12 = Jc[8];
-        double2* m = (double2*)(D.E + 8 * q);
-        m[0] = make_double2(q00 * q00, q11 * q11);
-        m[1] = make_double2(q00 * q02, q11 * q12);
-        m[2] = make_double2(q02 * q02 + q12 * q12, 2.0 * RX[0]);
-        m[3] = make_double2(2.0 * RX[1], 2.0 * RX[2]);
-        double* h = D.Hc + 3 * q;
-        h[0] = q00 * r[0]; h[1] = q11 * r[1]; h[2] = q02 * r[0] + q12 * r[1];
+        double* t = s_rec[w][lane];
+        t[0] = q00 * q00; t[1] = q11 * q11; t[2] = q00 * q02; t[3] = q11 * q12; t[4] = q02 * q02 + q12 * q12;
+        t[5] = 2.0 * RX[0]; t[6] = 2.0 * RX[1]; t[7] = 2.0 * RX[2];
+        t[8] = q00 * r[0]; t[9] = q11 * r[1]; t[10] = q02 * r[0] + q12 * r[1];
       }
-      if (wantp) for (int k = 0; k < 6; k++) D.Jp[k * n + i] = Jp[k];
+    }
+  }
+  if (mode == 0) {
+    // The records go to scattered places (the wave's observations are a run of the point-major order): four lanes write one record's
+    // 64 bytes per store instruction, three its h - whole runs, not 64 sixteen-byte pieces of 64 lines (the L2 sees a third of the requests)
+    s_q[w][lane] = q_mine;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int idx = lane + 64 * t, rr = idx >> 2, part = idx & 3;
+      const int q = s_q[w][rr];
+      if (q >= 0) *(double2*)(D.E + 8 * (size_t)q + 2 * part) = make_double2(s_rec[w][rr][2 * part], s_rec[w][rr][2 * part + 1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int idx = lane + 64 * t, rr = idx / 3, part = idx - 3 * rr;
+      const int q = s_q[w][rr];
+      if (q >= 0) D.Hc[3 * (size_t)q + part] = s_rec[w][rr][8 + part];
     }
   }
   block_reduce<1>(acc, s_red, s_out);
@@ -753,16 +770,26 @@ __device__ __forceinline__ void ba_pt_blocks_body(const BaDev& D, int bx) {
   if (D.fix_points) return;
   const int p = bx * BA_TPB + threadIdx.x;
   if (p >= D.npts) return;
-  const size_t n = D.nobs;
+  // Jp = Q R:  Jp^T Jp = R^T W R,  Jp^T res = R^T h  from the observation's factored record (camera-major: gathered) and its camera's rotation
   double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
   for (int i = D.pt_off[p]; i < D.pt_off[p + 1]; i++) {
-    double J[6];
+    const size_t q = (size_t)D.cam_pos[i];
+    double c8[8], Rc[9];
+    ld_rec8(D.E, q, c8);
+    const double h0 = D.Hc[3 * q], h1 = D.Hc[3 * q + 1], h2 = D.Hc[3 * q + 2];
+    quat_to_R(D.poses + 7 * (size_t)D.obs_cam[i] + 3, Rc);
+    const double w00 = c8[0], w11 = c8[1], w02 = c8[2], w12 = c8[3], w22 = c8[4];
+    double V[9];                                                          // V = W R
 #pragma unroll
-    for (int k = 0; k < 6; k++) J[k] = D.Jp[k * n + i];
-    const double r0 = D.r[i], r1 = D.r[n + i];
-    C[0] += J[0] * J[0] + J[3] * J[3]; C[1] += J[0] * J[1] + J[3] * J[4]; C[2] += J[0] * J[2] + J[3] * J[5];
-    C[3] += J[1] * J[1] + J[4] * J[4]; C[4] += J[1] * J[2] + J[4] * J[5]; C[5] += J[2] * J[2] + J[5] * J[5];
-    g[0] += J[0] * r0 + J[3] * r1; g[1] += J[1] * r0 + J[4] * r1; g[2] += J[2] * r0 + J[5] * r1;
+    for (int k = 0; k < 3; k++) {
+      V[k] = fma(w02, Rc[6 + k], w00 * Rc[k]);
+      V[3 + k] = fma(w12, Rc[6 + k], w11 * Rc[3 + k]);
+      V[6 + k] = fma(w22, Rc[6 + k], fma(w12, Rc[3 + k], w02 * Rc[k]));
+    }
+    C[0] += fma(Rc[6], V[6], fma(Rc[3], V[3], Rc[0] * V[0])); C[1] += fma(Rc[6], V[7], fma(Rc[3], V[4], Rc[0] * V[1])); C[2] += fma(Rc[6], V[8], fma(Rc[3], V[5], Rc[0] * V[2]));
+    C[3] += fma(Rc[7], V[7], fma(Rc[4], V[4], Rc[1] * V[1])); C[4] += fma(Rc[7], V[8], fma(Rc[4], V[5], Rc[1] * V[2]));
+    C[5] += fma(Rc[8], V[8], fma(Rc[5], V[5], Rc[2] * V[2]));
+    g[0] += fma(Rc[6], h2, fma(Rc[3], h1, Rc[0] * h0)); g[1] += fma(Rc[7], h2, fma(Rc[4], h1, Rc[1] * h0)); g[2] += fma(Rc[8], h2, fma(Rc[5], h1, Rc[2] * h0));
   }
   for (int k = 0; k < 6; k++) D.C[6 * (size_t)p + k] = C[k];
   for (int k = 0; k < 3; k++) D.gp[3 * (size_t)p + k] = g[k];
@@ -4211,7 +4238,6 @@ static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_opt
   D.row_meta = H.arena2_dev(H.arena2_copy(row_meta.data(), row_meta.size(), &rc));
   D.seg = H.arena2_dev(H.arena2_copy(segs.data(), segs.size(), &rc));
   D.pair_i = H.arena2_dev(pair_i); D.pair_j = H.arena2_dev(pair_j);
-  D.r = H.alloc<double>(2 * (size_t)nobs, &rc); D.Jp = H.alloc<double>(6 * (size_t)nobs, &rc);
   D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
   D.C = H.alloc<double>(6 * (size_t)npts, &rc); D.gp = H.alloc<double>(3 * (size_t)npts, &rc);
   D.scale_c = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc); D.scale_p = H.alloc<double>(3 * (size_t)npts, &rc);

@@ -14,7 +14,10 @@ What "parity" can mean at these sizes (measured, tools/explore_ba_fullsize.py; D
        must agree to the ordinary bars (cost 1e-9, poses 1e-7, points 1e-5 of their norm).  Measured: 2e-10 / 7e-9.
     2. TRAJECTORIES (3 and 10 iterations; LocalBA's 5 + 10) must have identical discrete outputs (iteration counts, accepted
        steps, termination, erase flags) and continuous outputs inside `CLOUD` x the oracle's own rounding cloud, which the
-       test measures live by re-running the oracle on 1-ulp-perturbed inputs.
+       test measures live by re-running the oracle on 1-ulp-perturbed inputs.  One exception, C5 at 10 iterations: once that
+       cloud is wider than `DECORRELATED` (the oracle's perturbed runs end 1.4 ... 1.8 % apart in cost: the trajectories have
+       separated by iteration 8) the number of ACCEPTED steps may differ by one - which step lands near the acceptance
+       threshold is then a property of the rounding, not of the algorithm; iteration count and termination must still agree.
 * With the gauge fixed at both ends of a short window (C4 with two fixed keyframes) the ordinary bars hold for the whole
   two-pass solve; that case is asserted flat.
 
@@ -32,6 +35,7 @@ from ceres_mono_orb_slam2_amd import synth
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL_COST, RTOL_X, RTOL_PT = 1e-9, 1e-7, 1e-5
+DECORRELATED = 1e-3   # relative width of the oracle's own 1-ulp cost cloud beyond which its trajectories no longer coincide step for step
 CLOUD = 10.0          # a trajectory may differ from the oracle's by at most this multiple of the oracle's own 1-ulp rounding cloud
 
 
@@ -97,7 +101,6 @@ def test_globalba_c5_trajectory_inside_the_oracles_rounding_cloud(oracle, iters)
     g, base = _c5()
     poses, pts, s = optimizer.bundle_adjustment(*base, iters)
     oposes, opts, os_ = oracle.ba_solve(*base, iters)
-    assert _discrete(s) == _discrete(os_)
     assert abs(s["initial_cost"] - os_["initial_cost"]) <= RTOL_COST * os_["initial_cost"]
     cloud_cost, cloud_pose = 0.0, 0.0
     for seed in (1, 2):
@@ -107,6 +110,15 @@ def test_globalba_c5_trajectory_inside_the_oracles_rounding_cloud(oracle, iters)
     d_cost = abs(s["final_cost"] - os_["final_cost"]) / os_["final_cost"]
     d_pose = np.abs(poses - oposes).max()
     print("C5 %d iterations: GPU-oracle cost %.2e pose %.2e | oracle 1-ulp cloud cost %.2e pose %.2e" % (iters, d_cost, d_pose, cloud_cost, cloud_pose))
+    # The accept / reject sequence is compared while the oracle's own trajectories still coincide.  Once a 1-ulp change of the input
+    # moves the oracle's final cost by more than DECORRELATED (C5 after ~8 iterations: 2e-4 at iteration 7, 2.5e-2 at 8, measured
+    # with both arithmetic orders the HIP path has had), a step near the acceptance threshold legitimately flips: the iteration
+    # count and the termination must still agree, the number of accepted steps may differ by one.
+    if cloud_cost <= DECORRELATED:
+        assert _discrete(s) == _discrete(os_)
+    else:
+        assert (s["iterations"], s["termination"]) == (os_["iterations"], os_["termination"])
+        assert abs(s["successful_steps"] - os_["successful_steps"]) <= 1
     assert d_cost <= max(RTOL_COST, CLOUD * cloud_cost)
     assert d_pose <= max(RTOL_X, CLOUD * cloud_pose)
     assert s["final_cost"] < 0.7 * s["initial_cost"]                          # and it is a descent, not a stall
