@@ -656,7 +656,8 @@ __device__ __forceinline__ void ld_rec8(const double* __restrict__ base, size_t 
   for (int k = 0; k < 4; k++) { const double2 v = m[k]; c[2 * k] = v.x; c[2 * k + 1] = v.y; }
 }
 // ---- residuals + Jacobians at x (mode 0) or cost only at the candidate (mode 1) -------------------
-__global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv, int mode) {
+template <int mode>      // (a template parameter: the cost-only instance carries neither the staging LDS nor the Jacobian registers)
+__global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4], s_out[1];
   const BaState* st = D.st;
@@ -667,8 +668,8 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
   if ((int)blockIdx.x * BA_TPB >= max(D.nobs, 1)) return;               // batched launch: grid.x is the maximum over the problems
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __shared__ double s_rec[BA_TPB / 64][64][13];        // mode 0: the wave's records {W (5), r (3), h (3)} on their way out (+ pad: odd pitch)
-  __shared__ int s_q[BA_TPB / 64][64];                 // ... and their places (camera-major position, -1: none)
+  __shared__ double s_rec[mode == 0 ? BA_TPB / 64 : 1][mode == 0 ? 64 : 1][13];   // mode 0: the wave's records {W (5), r (3), h (3)} on their way out (+ pad: odd pitch)
+  __shared__ int s_q[mode == 0 ? BA_TPB / 64 : 1][mode == 0 ? 64 : 1];            // ... and their places (camera-major position, -1: none)
   int q_mine = -1;
   double acc[1] = {0.0};
   if (i < D.nobs) {
@@ -4390,7 +4391,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
   }
   if (g_pad > 0) hipLaunchKernelGGL(k_ba_pad, dim3(g_pad, ny), dim3(64), 0, s, Dv);
   auto enqueue_eval = [&]() {
-    hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 0);
+    hipLaunchKernelGGL(k_ba_eval<0>, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
     hipLaunchKernelGGL(k_ba_cam_blocks, dim3(g_camcount + g_pt, ny), dim3(BA_TPB), 0, s, Dv, g_camcount);      // + the landmark blocks
     hipLaunchKernelGGL(k_ba_after_eval, dim3(1, ny), dim3(AE_TPB), 0, s, Dv);
   };
@@ -4493,7 +4494,7 @@ static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* 
     }
     hipLaunchKernelGGL(k_ba_cam_update, dim3(g_cam, ny), dim3(BA_TPB), 0, s, Dv);
     hipLaunchKernelGGL(k_ba_backsub, dim3(g_pt, ny), dim3(BS_TPB), 0, s, Dv, 0);
-    hipLaunchKernelGGL(k_ba_eval, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv, 1);
+    hipLaunchKernelGGL(k_ba_eval<1>, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
     hipLaunchKernelGGL(k_ba_iter_end, dim3(1, ny), dim3(BA_TPB), 0, s, Dv);
     hipLaunchKernelGGL(k_ba_apply, dim3((g_apply + BA_TPB - 1) / BA_TPB, ny), dim3(BA_TPB), 0, s, Dv);
     enqueue_eval();
