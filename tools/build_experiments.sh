@@ -13,3 +13,9 @@ for f in capi_common orb_extractor orb_matcher orb_frame orb_vocab ba_solver orb
   objs="$objs $O/$f.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/liborbslam_hip.so $objs && echo "built $O/liborbslam_hip.so"
+# the product sources with k_ba_schur's in-kernel phase stamps (tools/schur_prof.py): only ba_solver differs, no experiment switches
+L=ceres_mono_orb_slam2_amd/lib
+if [ -f $L/capi_common.o ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DORBHIP_SCHUR_PROF -c $C/ba_solver.hip -o $O/ba_solver_sprof.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/liborbslam_hip_sprof.so $L/capi_common.o $L/orb_extractor.o $L/orb_matcher.o $L/orb_frame.o $L/orb_vocab.o $O/ba_solver_sprof.o $L/orb_track.o && echo "built $O/liborbslam_hip_sprof.so"
+fi

@@ -84,7 +84,7 @@ for src, dst, why in (("mfma_batch.json", "_mfma_localba_batch64.json", "FP64-MF
         put(RND + dst, json.dumps(j, indent=1) + "\n")
     except Exception as e:
         skipped.append("%s: %s" % (src, e))
-for txt in ("localba_throughput.txt", "track_latency.txt", "concurrency.txt", "mfma_f64_ubench.txt"):
+for txt in ("localba_throughput.txt", "track_latency.txt", "concurrency.txt", "mfma_f64_ubench.txt", "schur_phase_prof.txt"):
     path = os.path.join(O, txt)
     if os.path.exists(path) and os.path.getsize(path) > 0:
         put(RND + "_" + txt, open(path).read())

@@ -21,7 +21,8 @@ rm -rf $O/lbaprof
 rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/lbaprof -o run -- timeout 600 python tools/ba_batch_thr.py 64:1 > $O/lbaprof.log 2>&1 || tail -5 $O/lbaprof.log
 db=$(find $O/lbaprof -name "*.db" 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocpd_stats.py $db $O/localba_batch64_kernel_stats.csv && python tools/kstats_print.py $O/localba_batch64_kernel_stats.csv | head -14
-timeout 600 python tools/ba_batch_thr.py 64:8 16:8 > $O/localba_throughput.txt 2>&1; cat $O/localba_throughput.txt
+timeout 600 python tools/ba_batch_thr.py 64:12 64:8 16:8 > $O/localba_throughput.txt 2>&1; cat $O/localba_throughput.txt
+[ -f tools/exp_lib/liborbslam_hip_sprof.so ] && { step schur phase stamps; timeout 300 python tools/schur_prof.py > $O/schur_phase_prof.txt 2>&1; cat $O/schur_phase_prof.txt; }
 step gba c5 trace
 rm -rf $O/gbaprof
 rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/gbaprof -o run -- timeout 600 python tools/gba_c5_check.py 10 > $O/gbaprof.log 2>&1 || tail -5 $O/gbaprof.log

@@ -1,12 +1,12 @@
-"""Phase timing of k_ba_schur inside a 64-problem batched LocalBA (tools/scratch/exp_build.sh sprof -DORBHIP_SCHUR_PROF must have
-run): lane 0 of the waves of problem 0 stamps s_memrealtime (100 MHz) at the phase boundaries, per block row, relative to the
+"""Phase timing of k_ba_schur inside a 64-problem batched LocalBA (tools/build_experiments.sh builds the product sources with
+-DORBHIP_SCHUR_PROF into tools/exp_lib/liborbslam_hip_sprof.so): lane 0 of the waves of problem 0 stamps s_memrealtime (100 MHz) at the phase boundaries, per block row, relative to the
 workgroup's start.  Prints the mean over rows and launches, and the rows with the longest workgroups."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from ceres_mono_orb_slam2_amd import _lib, optimizer, synth
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "scratch", "lib_sprof", "liborbslam_hip.so")
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "exp_lib", "liborbslam_hip_sprof.so")
 L = _lib.load()
 L.ba_debug_chol_prof.argtypes = [C.c_void_p, C.c_int]
 gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(16)]
