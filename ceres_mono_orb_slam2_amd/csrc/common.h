@@ -67,7 +67,14 @@ struct DevBuf {
     // debugging aid: ORBHIP_POISON=ff (or 00) fills every new device buffer with that byte, so that a kernel reading
     // memory nobody wrote shows up as NaNs (ff) instead of depending on what the allocator handed out
     static const int poison = []() { const char* v = std::getenv("ORBHIP_POISON"); return v ? (int)std::strtol(v, nullptr, 16) : -1; }();
-    if (poison >= 0) { (void)hipMemset(p, poison, want); (void)hipDeviceSynchronize(); }
+    // (on a non-blocking stream of its own: hipMemset on the legacy stream + a device synchronise break another host thread's
+    // hipGraph capture - "operation would make the legacy stream depend on a capturing blocking stream")
+    if (poison >= 0) {
+      hipStream_t ps = nullptr;
+      if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) == hipSuccess) {
+        (void)hipMemsetAsync(p, poison, want, ps); (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps);
+      }
+    }
     return 0;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
