@@ -17,7 +17,7 @@ SYMBOLS = [
     "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_search_by_sim3", "orbm_search_by_bow", "orbm_search_for_triangulation",
     "orbv_create", "orbv_destroy", "orbv_load_text", "orbv_parse_text", "orbv_free_parsed", "orbv_transform", "orbv_descend_device", "orbv_score_l1",
     "orbm_undistort_keypoints", "orbm_assign_features_to_grid", "orbm_features_in_area", "orbm_is_in_frustum", "orbm_is_in_frustum_gates",
-    "orbm_triangulate_matches", "orbt_track_with_motion_model", "orbt_track_local_map", "orbt_track_reference_keyframe",
+    "orbm_triangulate_matches", "orbt_track_with_motion_model", "orbt_track_local_map", "orbt_track_reference_keyframe", "orbt_last_call_ms",
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log", "ba_sim3_mul", "ba_sim3_inverse",
     "ba_solve_batch", "ba_local_bundle_adjustment_batch", "ba_optimize_essential_graph", "ba_essential_graph_correct",
@@ -116,6 +116,7 @@ def load():
     L.orbm_features_in_area.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, C.POINTER(i32)]
     L.orbm_triangulate_matches.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, vp]
     L.orbm_is_in_frustum.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, vp, vp, vp]
+    L.orbt_last_call_ms.argtypes = []; L.orbt_last_call_ms.restype = C.c_double
     L.orbt_track_with_motion_model.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32, vp, vp, vp, vp]
     L.orbx_set_opencv_variant.argtypes = [vp, i32]
     L.orbt_track_reference_keyframe.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp, vp, i32, vp, vp, C.POINTER(i32), vp, vp, vp,

@@ -16,6 +16,18 @@ void set_error(const char* fmt, ...) {
 }
 ThreadWs& thread_ws() { static thread_local ThreadWs ws; return ws; }
 
+// 16 bytes per thread and step; both pointers are 256-byte aligned workspace blocks, the tail goes byte by byte
+__global__ void k_ws_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t bytes) {
+  const size_t n16 = bytes >> 4, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+  if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) dst[(n16 << 4) + threadIdx.x] = src[(n16 << 4) + threadIdx.x];
+}
+int ws_copy_kernel(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (!bytes) return 0;
+  const int blocks = (int)std::min<size_t>(((bytes >> 4) + 255) / 256 + 1, 1024);
+  hipLaunchKernelGGL(k_ws_copy, dim3(blocks), dim3(256), 0, s, (uint8_t*)dst, (const uint8_t*)src, bytes);
+  return hipGetLastError() == hipSuccess ? 0 : ORBHIP_ENODEV;
+}
 int raise_dynamic_lds(const void* func, int device, size_t bytes) {
   static std::mutex mu;
   static std::map<std::pair<const void*, int>, size_t> granted;

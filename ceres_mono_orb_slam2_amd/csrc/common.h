@@ -53,6 +53,23 @@ inline int use_default_device() {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Copies between PINNED host staging and device memory are done BY A KERNEL on the call's stream (k_ws_copy, capi_common.hip: pinned
+// host memory is mapped into the device's address space), not by hipMemcpyAsync.  Measured (tools/scratch: rocprofv3 --hip-trace of
+// tests/test_gpu_concurrency.py): with two or three host threads issuing asynchronous copies, a hipMemcpyAsync of a few hundred
+// kilobytes now and then takes 7-10 ms ON THE HOST, in two threads at once, with the GPU idle (the copy itself: 60 us) - the copy-
+// engine path of the runtime serialises the threads.  It was the whole p99 of a Tracking step beside LocalBA + GlobalBA: 8.4 ms with
+// hipMemcpyAsync, 0.61 ms with the kernel (and the step alone went from 0.414 to 0.386 ms: no copy-engine hand-off in the chain).
+// ORBHIP_WS_COPY_KERNEL=0 restores hipMemcpyAsync (A/B).
+int ws_copy_kernel(void* dst, const void* src, size_t bytes, hipStream_t s);
+inline bool ws_copy_by_kernel() {
+  static const bool on = []() { const char* e = std::getenv("ORBHIP_WS_COPY_KERNEL"); return !(e && e[0] == '0'); }();
+  return on;
+}
+inline hipError_t ws_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {      // one side is pinned host memory
+  if (ws_copy_by_kernel()) return ws_copy_kernel(dst, src, bytes, s) ? hipErrorUnknown : hipSuccess;
+  return hipMemcpyAsync(dst, src, bytes, kind, s);
+}
+
 // growable device buffer
 struct DevBuf {
   void* p = nullptr;
@@ -141,14 +158,14 @@ struct ThreadWs {
     if (*rc) return dp;
     if (count) {
       std::memcpy(hp, src, count * sizeof(T));
-      if (hipMemcpyAsync(dp, hp, count * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) { set_error("hipMemcpyAsync H2D failed"); *rc = ORBHIP_ENODEV; }
+      if (copy(dp, hp, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpyAsync H2D failed"); *rc = ORBHIP_ENODEV; }
     }
     return dp;
   }
   template <typename T> T* down(const T* dp, size_t count, int* rc) {        // device -> pinned (valid after sync())
     T* hp = h<T>(count, rc);
     if (*rc) return hp;
-    if (count && hipMemcpyAsync(hp, dp, count * sizeof(T), hipMemcpyDeviceToHost, s) != hipSuccess) { set_error("hipMemcpyAsync D2H failed"); *rc = ORBHIP_ENODEV; }
+    if (count && copy(hp, dp, count * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpyAsync D2H failed"); *rc = ORBHIP_ENODEV; }
     return hp;
   }
   // several host arrays in ONE pinned block and ONE asynchronous copy (a copy costs microseconds of fixed overhead, the
@@ -169,9 +186,10 @@ struct ThreadWs {
     uint8_t* hp = h<uint8_t>(P.total, &rc); P.dbase = d<uint8_t>(P.total, &rc);
     if (rc) return rc;
     for (const Pack::Piece& q : P.pieces) if (q.bytes) std::memcpy(hp + q.off, q.src, q.bytes);
-    if (P.total && hipMemcpyAsync(P.dbase, hp, P.total, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("hipMemcpyAsync H2D failed"); return ORBHIP_ENODEV; }
+    if (P.total && copy(P.dbase, hp, P.total, hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpyAsync H2D failed"); return ORBHIP_ENODEV; }
     return 0;
   }
+  hipError_t copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) { return ws_copy(dst, src, bytes, kind, s); }
   int sync() {
     hipError_t e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();

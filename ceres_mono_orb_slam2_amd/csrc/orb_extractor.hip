@@ -1945,12 +1945,12 @@ int orbx_extract(orbx_ctx* c, const uint8_t* img, int w, int h, int stride, orbx
     c->h_bytes = want;
   }
   std::memcpy(c->h_pin, img, img_bytes);
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(c->d_img.p, c->h_pin, img_bytes, hipMemcpyHostToDevice, 0));
+  ORBHIP_CHECK_HIP(orbhip::ws_copy(c->d_img.p, c->h_pin, img_bytes, hipMemcpyHostToDevice, 0));        // (copy kernel on pinned staging: common.h)
   uint8_t* dout = c->d_out.as<uint8_t>();
   if (int rc = run_batch(c, c->d_img.as<uint8_t>(), w, h, stride, (size_t)stride * h, 1, (orbx_keypoint*)(dout + off_kps), dout + off_desc, icap,
                          (int32_t*)dout, 0))
     return rc;
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(c->h_pin, dout, out_bytes, hipMemcpyDeviceToHost, 0));
+  ORBHIP_CHECK_HIP(orbhip::ws_copy(c->h_pin, dout, out_bytes, hipMemcpyDeviceToHost, 0));
   ORBHIP_CHECK_HIP(hipStreamSynchronize(0));
   const int32_t cnt = *(const int32_t*)c->h_pin;
   if (cnt == -1) { set_error("candidate capacity exceeded (ORBHIP_KEYCAP test hook, or more than %d FAST corners in one pyramid level)", KEYCAP_MAX); return ORBHIP_EOVERFLOW; }

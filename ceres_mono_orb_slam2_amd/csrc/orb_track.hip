@@ -1001,7 +1001,15 @@ struct TrkFrame {
 thread_local TrkFrame g_trk_frame;
 }  // namespace
 
+// host wall time of the calling thread's most recent orbt_* call (orbt_last_call_ms): what a latency figure should be made of when
+// the caller is an interpreter whose own locks add milliseconds around the call
+static thread_local double g_last_call_ms = 0.0;
+struct CallClock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~CallClock() { g_last_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 extern "C" {
+double orbt_last_call_ms(void) { return g_last_call_ms; }
 #ifdef ORBHIP_TRK_PROF
 int orbt_debug_prof(int* out, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
@@ -1016,6 +1024,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
                                  const float* last_angle, const uint8_t* last_valid, int n_last, float th, int check_ori,
                                  orbx_keypoint* kps_out, uint8_t* desc_out, int cap, int32_t* match_out, int32_t* owner_out,
                                  uint8_t* outlier_out, orbt_result* res) {
+  CallClock call_clock;
   ORBHIP_REQUIRE(ctx && img && w > 0 && h > 0 && stride >= w && K4 && bounds && Tcw_pred && res && kps_out && desc_out && owner_out && outlier_out,
                  ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE(n_last >= 0 && n_last <= 4096 && (n_last == 0 || (last_Xw && last_desc && last_octave && last_angle && last_valid && match_out)), ORBHIP_EINVAL,
@@ -1124,6 +1133,9 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     if (timing) {
       const double t4 = now_us();
       t_acc[0] += t1 - t0; t_acc[1] += t2 - t1; t_acc[2] += t3 - t2; t_acc[3] += t4 - t3; t_acc[4] += t4 - t0;
+      if (t4 - t0 > 2000.0)                 // an outlier: which phase waited?
+        fprintf(stderr, "orbt_track_with_motion_model SLOW CALL: staging + upload enqueue %.1f us, kernel launches %.1f us, wait %.1f us, unpack %.1f us, total %.1f us\n",
+                t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0);
       if (++t_n == 100) {
         fprintf(stderr, "k_trk_greedy ticks (10 ns): setup %d rounds %d (%d rounds, %d sweeps; lists inverted at %d, first pass done at %d; setup: cleared at %d, counts scanned at %d) rotation+owners %d observations %d\n", T->ticks[0], T->ticks[1], T->rounds % 1000, T->rounds / 1000, T->ticks[4], T->ticks[5], T->ticks[6], T->ticks[7], T->ticks[2], T->ticks[3]);
         fprintf(stderr, "orbt_track_with_motion_model: staging + upload enqueue %.1f us, kernel launches %.1f us, wait %.1f us, unpack %.1f us, total %.1f us\n",
@@ -1141,6 +1153,7 @@ int orbt_track_local_map(orbx_ctx* ctx, const float* K4, const float* bounds, co
                          const double* mp_Xw, const double* mp_normal, const float* mp_min_dist, const float* mp_max_dist, const uint8_t* mp_desc,
                          const uint8_t* mp_state, int n_mp, const double* slot_Xw, const uint8_t* slot_state, int n_kp, float th, float nnratio,
                          uint8_t* mp_in_view, int32_t* mp_match, int32_t* slot_owner, uint8_t* outlier_out, orbt_result* res) {
+  CallClock call_clock;
   ORBHIP_REQUIRE(ctx && K4 && bounds && Tcw && res && mp_in_view && mp_match && slot_owner && outlier_out && slot_Xw && slot_state, ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE(n_mp >= 0 && n_mp <= TLM_MAXMP, ORBHIP_ECAP, "more than 16384 local map points per call");
   ORBHIP_REQUIRE(n_mp == 0 || (mp_Xw && mp_normal && mp_min_dist && mp_max_dist && mp_desc && mp_state), ORBHIP_EINVAL, "NULL map-point argument");
@@ -1228,6 +1241,7 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
                                   const uint32_t* kf_fv_node, const uint32_t* kf_fv_off, const uint32_t* kf_fv_idx, int kf_fv_n, float nnratio, int check_ori,
                                   orbx_keypoint* kps_out, uint8_t* desc_out, int cap, uint32_t* bow_word, double* bow_value, int* n_words, uint32_t* fv_node,
                                   uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes, int32_t* match_kf, int32_t* slot_owner, uint8_t* outlier_out, orbt_result* res) {
+  CallClock call_clock;
   ORBHIP_REQUIRE(ctx && voc && K4 && bounds && Tcw_last && res && match_kf && slot_owner && outlier_out && n_words && n_fv_nodes && fv_off, ORBHIP_EINVAL, "NULL argument");
   ORBHIP_REQUIRE(n_kf >= 0 && kf_fv_n >= 0 && (n_kf == 0 || (kf_desc && kf_valid && kf_angle && kf_Xw)) && (kf_fv_n == 0 || (kf_fv_node && kf_fv_off && kf_fv_idx)), ORBHIP_EINVAL, "NULL keyframe argument");
   const int icap = orbx_max_keypoints(ctx);

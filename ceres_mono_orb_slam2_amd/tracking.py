@@ -135,3 +135,9 @@ def track_reference_keyframe(extractor, vocabulary, image, K4, bounds, Tcw_last,
     return dict(kps=kps[:k] if img is not None else None, desc=desc[:k] if img is not None else None, bow=(bw[:nw.value], bv[:nw.value]),
                 fv=(on[:nf.value], oo[:nf.value + 1], oi[:oo[nf.value]]), match=match[:n], owner=owner[:k], outlier=outl[:k].view(np.bool_),
                 pose7=np.array(res.pose7[:], np.float64), nmatches=res.nmatches, n_inliers=res.n_inliers, n_correspondences=res.n_correspondences, n_keypoints=k)
+
+
+def last_call_ms():
+    """orbt_last_call_ms: wall time of this thread's most recent track_* call inside the library (a Python caller adds its own
+    interpreter-lock waits around the call when other threads are busy)."""
+    return float(_lib.load().orbt_last_call_ms())

@@ -376,6 +376,10 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
                                   uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes, int32_t* match_kf,
                                   int32_t* slot_owner, uint8_t* outlier, orbt_result* res);
 
+/* Host wall time (ms) of the calling thread's most recent orbt_* call, measured inside the library (entry to return): the latency
+ * of a Tracking step as the reference's C++ caller would see it, free of what a scripting host adds around the call.       */
+double orbt_last_call_ms(void);
+
 /* ------------------------------------------------------------ bundle adjust --
  * Replaces CeresOptimizer::{PoseOptimization, BundleAdjustment/GlobalBundleAdjustemnt,
  * LocalBundleAdjustment, CheckOutlier(s)} (src/CeresOptimizer.cc:49-599) and the Ceres solve

@@ -36,9 +36,11 @@ def test_tracking_localba_globalba_share_one_gpu(oracle):
     M = _local_map(oracle, S, g1, 21)
     a2 = (ex, K4, BOUNDS, T1, F32(np.log(F32(1.2))), M["X"], M["Pn"], M["mind"], M["maxd"], M["D"], M["state"], M["slot_X"], M["slot_state"], 1.0, 0.8)
 
+    lib_ms = [0.0]
+
     def track_once():
-        r1 = tracking.track_with_motion_model(*a1)
-        r2 = tracking.track_local_map(*a2)
+        r1 = tracking.track_with_motion_model(*a1); m1 = tracking.last_call_ms()
+        r2 = tracking.track_local_map(*a2); lib_ms[0] = m1 + tracking.last_call_ms()       # (time spent inside the two C calls)
         return _digest(r1["kps"], r1["desc"], r1["match"], r1["owner"], r1["outlier"], r1["pose7"], r2["in_view"], r2["match"], r2["owner"], r2["outlier"], r2["pose7"])
 
     gl = synth.make_ba_graph(3, ncam=100, npts=10000, nobs=50000, n_fixed=1)
@@ -57,25 +59,28 @@ def test_tracking_localba_globalba_share_one_gpu(oracle):
 
     # solo references (and solo Tracking latency)
     ref_t, ref_l, ref_g = track_once(), lba_once(), gba_once()
-    solo = []
+    solo, solo_lib = [], []
     for _ in range(100):
-        t0 = time.perf_counter(); d = track_once(); solo.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); d = track_once(); solo.append(time.perf_counter() - t0); solo_lib.append(lib_ms[0] * 1e-3)
         assert d == ref_t, "solo Tracking step %d differs from the first one" % len(solo)
     # the three threads
-    out = {"t": [], "l": [], "g": [], "lat": [], "err": []}
+    out = {"t": [], "l": [], "g": [], "lat": [], "lib": [], "err": []}
     stop = threading.Event()
+    ready = threading.Barrier(3)          # the latency figures are steady-state: every thread has made its first call (allocations) before the clock runs
 
     def tracker():
         try:
             _lib.check(L.orbhip_set_thread_priority(1), "orbhip_set_thread_priority")
             track_once()                                     # (this thread's own workspace and resident frame)
+            ready.wait(timeout=120)
             while not stop.is_set():
-                t0 = time.perf_counter(); d = track_once(); out["lat"].append(time.perf_counter() - t0); out["t"].append(d)
+                t0 = time.perf_counter(); d = track_once(); out["lat"].append(time.perf_counter() - t0); out["lib"].append(lib_ms[0] * 1e-3); out["t"].append(d)
         except Exception as e:
             out["err"].append(repr(e))
 
     def local_mapper():
         try:
+            out["l"].append(lba_once()); ready.wait(timeout=120)  # (first call of this thread: workspace allocation - hipMalloc / hipHostMalloc hold runtime locks for milliseconds)
             while not stop.is_set():
                 out["l"].append(lba_once())
         except Exception as e:
@@ -83,6 +88,7 @@ def test_tracking_localba_globalba_share_one_gpu(oracle):
 
     def loop_closer():
         try:
+            out["g"].append(gba_once()); ready.wait(timeout=120)
             for _ in range(3):
                 out["g"].append(gba_once())
         except Exception as e:
@@ -90,14 +96,22 @@ def test_tracking_localba_globalba_share_one_gpu(oracle):
         finally:
             stop.set()
 
+    # Latency is taken INSIDE the library (orbt_last_call_ms): these are Python threads, and what the interpreter lock adds around a
+    # call is not the library's.  Round 4 found the 7-10 ms p99 of this test inside hipMemcpyAsync (rocprofv3 --hip-trace: two threads'
+    # asynchronous copies of a few hundred kilobytes each blocked on the host for 8 ms, the GPU idle); the per-frame calls now move their
+    # staging blocks with a copy kernel (csrc/common.h) and the p99 is that of the kernels.
     th = [threading.Thread(target=f) for f in (tracker, local_mapper, loop_closer)]
     [t.start() for t in th]; [t.join() for t in th]
     assert not out["err"], out["err"]
-    assert len(out["t"]) >= 5 and len(out["l"]) >= 1 and len(out["g"]) == 3, (len(out["t"]), len(out["l"]), len(out["g"]))
+    assert len(out["t"]) >= 5 and len(out["l"]) >= 1 and len(out["g"]) == 4, (len(out["t"]), len(out["l"]), len(out["g"]))
     assert all(d == ref_t for d in out["t"]), "%d of %d Tracking steps differ from the solo run" % (sum(d != ref_t for d in out["t"]), len(out["t"]))
     assert all(d == ref_l for d in out["l"]), "%d of %d LocalBA solves differ from the solo run" % (sum(d != ref_l for d in out["l"]), len(out["l"]))
     assert all(d == ref_g for d in out["g"]), "%d of %d GlobalBA solves differ from the solo run" % (sum(d != ref_g for d in out["g"]), len(out["g"]))
     q = lambda v, p: float(np.percentile(np.array(v) * 1e3, p))
-    print("Tracking (motion model + local map) alone: p50 %.3f ms, p99 %.3f ms; beside LocalBA + GlobalBA on the same GPU: p50 %.3f ms, p99 %.3f ms over %d frames "
-          "(%d LocalBA, %d GlobalBA solves meanwhile, all bit-identical to their solo runs)" % (q(solo, 50), q(solo, 99), q(out["lat"], 50), q(out["lat"], 99), len(out["lat"]),
-                                                                                             len(out["l"]), len(out["g"])))
+    # (a loose bar: 0.6 - 1.3 ms measured; the copy-engine path it guards against showed 7 - 10 ms)
+    assert q(out["lib"], 99) < 4.0, "Tracking p99 inside the library beside LocalBA + GlobalBA: %.2f ms" % q(out["lib"], 99)
+    print("Tracking (motion model + local map) alone: p50 %.3f ms, p99 %.3f ms (inside the library: %.3f / %.3f); beside LocalBA + GlobalBA on the same GPU: "
+          "p50 %.3f ms, p99 %.3f ms seen from Python, p50 %.3f ms, p99 %.3f ms, max %.3f ms inside the library (orbt_last_call_ms), over %d frames "
+          "(%d LocalBA, %d GlobalBA solves meanwhile, all bit-identical to their solo runs)" % (q(solo, 50), q(solo, 99), q(solo_lib, 50), q(solo_lib, 99),
+                                                                                             q(out["lat"], 50), q(out["lat"], 99), q(out["lib"], 50), q(out["lib"], 99), q(out["lib"], 100),
+                                                                                             len(out["lat"]), len(out["l"]), len(out["g"])))
