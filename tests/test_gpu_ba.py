@@ -86,7 +86,9 @@ def test_golden_ba_fixture():
 
 
 @pytest.mark.parametrize("seed,ncam,npts,nobs,robust,iters", [(0, 6, 120, 500, 1, 20), (1, 12, 400, 2000, 0, 30),
-                                                              (2, 3, 40, 110, 1, 10), (3, 25, 1500, 7000, 1, 15)])
+                                                              (2, 3, 40, 110, 1, 10), (3, 25, 1500, 7000, 1, 15),
+                                                              # 1000 - 2000 observations per camera: more than the 736 records k_ba_schur keeps in LDS per block row
+                                                              (4, 6, 2400, 9600, 1, 8)])
 def test_ba_solve_vs_oracle(oracle, seed, ncam, npts, nobs, robust, iters):
     from ceres_mono_orb_slam2_amd import optimizer
     g = synth.make_ba_graph(seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=2)
