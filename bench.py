@@ -28,9 +28,10 @@ import threading
 import time
 
 # The LocalBA leg keeps 12 host threads' HIP streams busy; the runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware
-# queues (default 4: streams that share a queue serialise).  8 queues: +5 % solves/s.  Read by the
+# queues (default 4: streams that share a queue serialise).  8 queues: +5 % solves/s, one per thread another ~2 % (same-box sweeps of
+# tools/ba_batch_thr.py 64:12: 8 -> 2573, 12 -> 2631, 16 -> 2612, 24 -> 2520 solves/s).  Read by the
 # HIP runtime when it initialises, hence set before anything imports it; a value the caller exported wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 import numpy as np
 
