@@ -3475,8 +3475,12 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restric
 // dependent chain obs_cam -> cam_col -> y in flight at once), (2) per point the ordered sum over its t_i, the 3x3 solve and
 // the candidate point, (3) per observation the model residual.  (The first version walked each point's observations in a
 // serial loop of dependent loads: 33 us per launch at C4 size.)
+#ifndef BS_PTS
 #define BS_PTS 256
+#endif
+#ifndef BS_TPB
 #define BS_TPB 1024
+#endif
 __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__ Dv, int part_off) {
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[16 * 2], s_out[2];
