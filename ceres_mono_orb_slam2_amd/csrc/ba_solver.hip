@@ -12,17 +12,18 @@
 //                    equations reduced in LDS, 6x6 Cholesky, step test) - no host
 //                    round trip per iteration; batched one workgroup per frame.
 //   BA (poses+points) per LM iteration, all on device, LM control in a device-side state:
-//     k_ba_eval        residuals + analytic SE(3) Jacobians per observation
-//     k_ba_cam_blocks  6x6 pose blocks  (one workgroup per camera, LDS reduction)
-//     k_ba_pt_blocks   3x3 landmark blocks
-//     k_ba_schur_prep  per point: (C+D)^-1, E, E (C+D)^-1
-//     k_ba_schur       reduced camera system S = B + D - E (C+D)^-1 E^T, one wave per block pair
-//     k_chol_panel / k_chol_syrk   dense blocked Cholesky of S; the trailing update
-//                      runs on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) - the
-//                      only MFMA user, as the dense reduced block is the only GEMM here
-//     k_chol_solve     forward / backward substitution
+//     k_ba_eval<mode>  residuals + the analytic SE(3) Jacobians per observation, stored FACTORED: {W = Q^T Q, r = 2 RX} (64 bytes,
+//                      camera-major) and h = Q^T res - the comment above ld_rec8
+//     k_ba_cam_blocks  6x6 pose blocks from a camera's records (one workgroup per camera), 3x3 landmark blocks behind them
+//     k_ba_schur_prep  per point: (C+D)^-1, N = S_p (C+D)^-1 S_p; zero fill of S
+//     k_ba_schur       reduced camera system S = B + D - E (C+D)^-1 E^T, one workgroup per block row, 128-pair segments per wave
+//     k_chol_*         dense blocked Cholesky of S on the FP64 matrix cores (v_mfma_f64_16x16x4_f64 - the only MFMA user, as the
+//                      dense reduced block is the only GEMM here): k_chol_la (one launch per 32-column step), k_chol_persist /
+//                      k_chol_persist_blk (flag-linked persistent launches of single solves), k_chol_wg (one workgroup per
+//                      problem of a lockstep batch); forward substitution rides the factorisation (augmented row)
+//     k_chol_bsolve_*  backward substitution
 //     k_ba_backsub     landmark back-substitution, candidate point, model cost change
-//     k_ba_control_*   Ceres' step acceptance / radius update / convergence tests
+//     k_ba_iter_begin / k_ba_after_eval / k_ba_iter_end   Ceres' step acceptance / radius update / convergence tests
 // The exact Schur solve is mathematically identical to the reference's
 // SPARSE_NORMAL_CHOLESKY.  No CPU fallback exists in this file.
 // ============================================================================
