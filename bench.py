@@ -312,7 +312,9 @@ def pcie_pipeline(torch, dev, ex, mt, frames_host, B, resident_fps, n_batches=24
             "pipeline_h2d_GBps": fps * in_bytes / B / 1e9, "pipeline_d2h_GBps": fps * out_bytes / B / 1e9,
             "bound_frames_per_s": bound, "frac_of_bound": fps / bound, "downloaded_counts_equal_resident_run": same,
             "note": "frames from pinned host memory, keypoints + descriptors + counts + matches back to pinned host memory; upload, "
-                    "extract + match and download of consecutive batches overlap on three HIP streams; bound = min(H2D rate / bytes "
+                    "extract + match and download of consecutive batches overlap on three HIP streams (measured in THIS process: 12 hardware queues for "
+                    "the LocalBA leg and the extractor's high-priority blur stream cost the copy / compute overlap - the same pipeline reaches 110 - 114 k "
+                    "frames/s = 0.91 of the bound with GPU_MAX_HW_QUEUES=4 ORBHIP_SIDE_PRIORITY=0, DESIGN.md section 6); bound = min(H2D rate / bytes "
                     "per frame in, D2H rate / bytes per frame out, resident rate)"}
 
 
@@ -326,10 +328,13 @@ def main():
     ap.add_argument("--batches-per-step", type=int, default=32, help="batches per step (distinct resident frames)")
     ap.add_argument("--cpu-sample", type=int, default=96)    # ~8 s of single-thread oracle work
     ap.add_argument("--cpu-all-seconds", type=float, default=8.0)
-    ap.add_argument("--streams", type=int, default=3, help="opt-in pipeline: batch m runs on HIP stream m %% S with its own extractor context, so the "
-                    "latency-bound octree of one batch overlaps the issue-bound kernels of another (per-kernel times then include the "
-                    "sharing; the default 1 keeps one stream whose kernel times add up to the step)")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary 3-stream figure")
+    ap.add_argument("--streams", type=int, default=2, help="pipeline of the timed pass: batch m runs on HIP stream m %% S with its own extractor context, so the "
+                    "latency-bound octree of one batch overlaps the issue-bound kernels of another.  Same-box sweeps at the end of round 4 (one stream "
+                    "130.3 k frames/s): S = 2 -> 148.1 k, 3 -> 141.1 k, 4 -> 131.1 k, 5 -> 135.5 k, 7 -> 126.7 k, the same for GPU_MAX_HW_QUEUES 4 ... 24.  "
+                    "Streams that merely EXIST count too (four contexts alive, two in use: 115 k; contexts re-created after a trial run: 113 k) - the "
+                    "hardware queues of a process share a few dispatch pipes -, which is why the count is a fixed default and not tuned at run time.  "
+                    "1 = the timed pass on one stream")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary pipelined figure (only with --streams 1)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-fed (PCIe-inclusive) figure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
@@ -470,7 +475,7 @@ def main():
     dt1 = sharding.max_over_ranks(dt1, device=cdev)
     one_stream = {"value": B * M * world * k1 / dt1, "unit": "frames/s", "steps": k1, "ms_per_step": dt1 / k1 * 1e3,
                   "note": "the same frames and kernels on ONE stream (pass 1): the per-kernel times of `roofline` and `kernels` come from here"}
-    # ---- pass 2, the timed configuration: batch m on stream m % S with its own extractor context (default S = 3).  The kernels of
+    # ---- pass 2, the timed configuration: batch m on stream m % S with its own extractor context (default S = 2).  The kernels of
     #      consecutive batches overlap - the matcher's matrix-core products and the latency-bound octree of one batch run beside the
     #      VALU-issue-bound pyramid / FAST / blur kernels of the next - every batch is extracted AND matched
     #      inside the timed region, exactly K steps between barrier + synchronize
@@ -493,12 +498,12 @@ def main():
     assert int(bad.item()) == 0, "extractor produced an empty/overflowed frame"
     mean_kp, mean_match = float(kp_sum.item()) / (B * M), float(nm_sum.item()) / (B * M)
 
-    # ---- secondary figure (never `value`): the same work pipelined over 3 HIP streams / extractor contexts, rank 0 only, a
+    # ---- secondary figure (never `value`): the same work pipelined over 2 HIP streams / extractor contexts, rank 0 only, a
     #      few steps.  The default run keeps ONE stream so that the per-kernel event times are exclusive and add up to the step.
     pipelined = None
     if S == 1 and world == 1 and not args.no_pipelined:
         try:
-            S3 = 3
+            S3 = 2
             ex3 = exs + [ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank) for _ in range(S3 - 1)]
             out3 = outs + [tuple(torch.empty_like(t) for t in (kps, desc, counts, match12, nmatch)) for _ in range(S3 - 1)]
             st3 = [torch.cuda.Stream(device=dev) for _ in range(S3)]
@@ -518,7 +523,7 @@ def main():
             d3 = time.perf_counter() - t3
             same = all(bool(torch.equal(out3[k][4], out3[0][4])) for k in range(1, S3)) if M % S3 == 0 else None
             pipelined = {"streams": S3, "value": B * M * k3 / d3, "unit": "frames/s", "steps": k3, "ms_per_step": d3 / k3 * 1e3,
-                         "note": "same frames and kernels, batch m on stream m % 3 with its own extractor context (bench.py --streams 3 "
+                         "note": "same frames and kernels, batch m on stream m % 2 with its own extractor context (bench.py --streams 2 "
                                  "makes it the timed configuration); kernel times then overlap, so the roofline above is taken from the "
                                  "one-stream run"}
             del ex3, out3

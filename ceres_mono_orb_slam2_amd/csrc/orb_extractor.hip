@@ -1786,9 +1786,13 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
   (void)hipSetDevice(device);
   {
     // (greatest priority: inside the per-frame Tracking chain the blur on this stream is on the frame's critical path, and the
-    // Tracking thread may run beside another thread's bundle adjustment - orbhip_set_thread_priority)
+    // Tracking thread may run beside another thread's bundle adjustment - orbhip_set_thread_priority.  Batches pay or gain by it:
+    // two pipelined streams of 256-frame batches 148.0 k frames/s with it, 142.4 k without; ONE stream 130.4 k with, 136.2 k
+    // without; batches fed from pinned host memory beside their uploads and downloads 73 k with, 112 k without (GPU_MAX_HW_QUEUES
+    // <= 4).  ORBHIP_SIDE_PRIORITY=0 creates the stream with normal priority.)
     int lo = 0, hi = 0;
-    hipError_t e = (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi)
+    static const bool side_prio = []() { const char* v = std::getenv("ORBHIP_SIDE_PRIORITY"); return !(v && v[0] == '0'); }();
+    hipError_t e = (side_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi)
                                                                                        : hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e != hipSuccess) c->side = nullptr;
   }
