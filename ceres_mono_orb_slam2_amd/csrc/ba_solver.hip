@@ -137,455 +137,7 @@ __device__ bool small_chol_solve(double* A, double* b, int n) {
   return true;
 }
 
-// ============================================================================ PoseOptimization
-// upper-triangle index of a symmetric 6x6 stored as 21 values
-__device__ __forceinline__ int sym6(int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); }
-
-#ifdef ORBHIP_CHOL_PROF
-__device__ unsigned long long g_pose_ticks[8];
-#define POSE_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); g_pose_ticks[i] += t_ - pt_; pt_ = t_; } } while (0)
-#else
-#define POSE_T(i) do { } while (0)
-#endif
-#define POSE_R 8
-__global__ __launch_bounds__(256) void k_pose_lm(const double* __restrict__ K4s, double* __restrict__ poses,
-                                                 const double* __restrict__ Xw, const double* __restrict__ uv,
-                                                 const float* __restrict__ inv_sigma2, const int* __restrict__ offsets,
-                                                 uint8_t* __restrict__ outlier, int* __restrict__ n_inliers,
-                                                 ba_summary* __restrict__ summaries, int max_iters, double huber) {
-  __shared__ double s_red[4 * 28], s_sum[28];
-  __shared__ double s_x[7], s_cand[7], s_scale[6], s_H[21], s_g[6];
-  __shared__ double s_radius, s_dec, s_xcost, s_xnorm, s_mcc, s_stepnorm, s_init;
-  __shared__ int s_iter, s_term, s_done, s_valid, s_accept, s_invalid, s_succ, s_nbad;
-  const int p = blockIdx.x, tid = threadIdx.x;
-#ifdef ORBHIP_CHOL_PROF
-  unsigned long long pt_ = __builtin_amdgcn_s_memrealtime();
-#endif
-  const int lo = offsets[p], n = offsets[p + 1] - lo;
-  const double* K4 = K4s + 4 * p;
-  double* pose = poses + 7 * p;
-  if (n < 3) {                                              // src/CeresOptimizer.cc:330
-    if (tid == 0) {
-      n_inliers[p] = 0;
-      if (summaries) { ba_summary s; memset(&s, 0, sizeof(s)); summaries[p] = s; }
-    }
-    return;
-  }
-  if (tid < 7) s_x[tid] = pose[tid];
-  if (tid == 0) { s_radius = 1e4; s_dec = 2.0; s_iter = 0; s_term = 0; s_done = 0; s_invalid = 0; s_succ = 0; s_nbad = 0; }
-  // The observations never change during the solve: up to POSE_R per thread (frames of up to 2048 map points) are read
-  // ONCE into registers; every evaluation of the LM loop - two passes over the observations per iteration - then runs
-  // without a global load.  (One workgroup per frame = one wave per SIMD: the per-iteration loads were pure exposed latency.)
-  const bool in_regs = n <= 256 * POSE_R;
-  double oX[POSE_R][3], oU[POSE_R][2], oW[POSE_R];
-  if (in_regs) {
-#pragma unroll
-    for (int u = 0; u < POSE_R; u++) {
-      const int i = tid + 256 * u;
-      const size_t g = (size_t)lo + (size_t)min(i, n - 1);
-      oX[u][0] = Xw[3 * g]; oX[u][1] = Xw[3 * g + 1]; oX[u][2] = Xw[3 * g + 2];
-      oU[u][0] = uv[2 * g]; oU[u][1] = uv[2 * g + 1];
-      oW[u] = (double)inv_sigma2[g];
-    }
-  }
-  const double k4r[4] = {K4[0], K4[1], K4[2], K4[3]};
-  // f(i, X, u, v, w) over this thread's observations
-  auto for_obs = [&](auto f) {
-    if (in_regs) {
-#pragma unroll
-      for (int u = 0; u < POSE_R; u++) { const int i = tid + 256 * u; if (i < n) f(i, oX[u], oU[u][0], oU[u][1], oW[u]); }
-    } else {
-      for (int i = tid; i < n; i += 256) {
-        const size_t g = (size_t)lo + i;
-        const double X[3] = {Xw[3 * g], Xw[3 * g + 1], Xw[3 * g + 2]};
-        f(i, X, uv[2 * g], uv[2 * g + 1], (double)inv_sigma2[g]);
-      }
-    }
-  };
-  __syncthreads();
-
-  // cost, gradient and Gauss-Newton block of the residuals at pose xe, reduced into s_sum[0 .. 27] (all threads)
-  auto accumulate = [&](const double* xe) {
-    double acc[28];
-#pragma unroll
-    for (int k = 0; k < 28; k++) acc[k] = 0.0;
-    for_obs([&](int, const double* X, double u0, double v0, double w) {
-      double r[2], Jc[12];
-      double rho = reproj_eval(k4r, xe, X, u0, v0, w, 1, huber, r, Jc, nullptr);
-      acc[0] += 0.5 * rho;
-#pragma unroll
-      for (int a = 0; a < 6; a++) {
-        acc[1 + a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
-#pragma unroll
-        for (int b = a; b < 6; b++) acc[7 + sym6(a, b)] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
-      }
-    });
-    block_reduce_dpp<28>(acc, s_red, s_sum);
-  };
-  // thread 0: the sums become the state at s_x (the iterate they were evaluated at)
-  auto adopt = [&](bool first) {
-    s_xcost = s_sum[0];
-    for (int a = 0; a < 6; a++) s_g[a] = s_sum[1 + a];
-    for (int k = 0; k < 21; k++) s_H[k] = s_sum[7 + k];
-    if (first) {
-      for (int a = 0; a < 6; a++) s_scale[a] = 1.0 / (1.0 + sqrt(s_H[sym6(a, a)]));
-      s_init = s_xcost;
-    }
-    double xn = 0;
-    for (int k = 0; k < 7; k++) xn += s_x[k] * s_x[k];
-    s_xnorm = sqrt(xn);
-    // gradient max norm = || x - Plus(x, -g) ||_inf
-    double gmax = 0;
-    for (int k = 0; k < 3; k++) gmax = fmax(gmax, fabs(s_g[k]));
-    double d[3] = {-s_g[3], -s_g[4], -s_g[5]}, qn[4];
-    quat_plus(s_x + 3, d, qn);
-    for (int k = 0; k < 4; k++) gmax = fmax(gmax, fabs(s_x[3 + k] - qn[k]));
-    if (gmax <= 1e-10) { s_term = 1; s_done = 1; }
-  };
-
-  accumulate(s_x);
-  if (tid == 0) adopt(true);
-  __syncthreads();
-  POSE_T(0);                               // loads + first evaluation
-  int done = s_done;
-  while (!done) {
-    __syncthreads();                       // every thread has consumed the previous flags
-    if (tid < 64) {
-      // Wave 0 solves the damped 6x6 system with lanes 0..5 holding one row each: a column of the Cholesky factor costs one
-      // sqrt and ONE division latency instead of (5 - j) dependent ones (fp64 division ~ 30 dependent instructions on a
-      // lone wave; the serial thread-0 version spent 2.7 us per iteration here).  Every sum keeps the serial order of
-      // small_chol_solve, so the step is bit-identical to it; scalars are computed redundantly by all lanes, lane 0 stores.
-      const int r = min(tid, 5);
-      const int iter = s_iter;
-      const double radius = s_radius;
-      if (tid == 0) { s_valid = 0; s_accept = 0; }
-      if (iter >= max_iters) { if (tid == 0) { s_term = 0; s_done = 1; } }
-      else if (radius <= 1e-32) { if (tid == 0) { s_term = 6; s_done = 1; } }
-      else {
-        if (tid == 0) s_iter = iter + 1;
-        double hs[6], L[6];
-        const double sr = s_scale[r];
-        const double gsr = s_g[r] * sr;
-        double hrr = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; c++) { hs[c] = s_H[sym6(r, c)] * sr * s_scale[c]; L[c] = hs[c]; if (c == r) hrr = hs[c]; }
-        const double damp = fmin(fmax(hrr, 1e-6), 1e32) / radius;
-#pragma unroll
-        for (int c = 0; c < 6; c++) if (c == r) L[c] += damp;
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          double t = L[j];
-#pragma unroll
-          for (int k = 0; k < j; k++) t -= L[k] * lane_bcast(L[k], j);
-          const double dj = lane_bcast(t, j);
-          if (!(dj > 0.0) || !isfinite(dj)) { ok = false; break; }
-          const double d = sqrt(dj);
-          L[j] = (r == j) ? d : t / d;
-        }
-        POSE_T(5);
-        double y[6];
-        if (ok) {
-          double Lu[6][6];
-#pragma unroll
-          for (int i = 0; i < 6; i++) {
-#pragma unroll
-            for (int k = 0; k <= i; k++) Lu[i][k] = lane_bcast(L[k], i);
-          }
-#pragma unroll
-          for (int i = 0; i < 6; i++) { double t = lane_bcast(gsr, i); for (int k = 0; k < i; k++) t -= Lu[i][k] * y[k]; y[i] = t / Lu[i][i]; }
-#pragma unroll
-          for (int i = 5; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < 6; k++) t -= Lu[k][i] * y[k]; y[i] = t / Lu[i][i]; }
-        }
-        double mcc = 0;
-        if (ok) {
-          double hsum = 0, yr = 0;
-#pragma unroll
-          for (int c = 0; c < 6; c++) { hsum += hs[c] * (-y[c]); if (c == r) yr = y[c]; }
-          const double term = (-yr) * (gsr + 0.5 * hsum);
-#pragma unroll
-          for (int c = 0; c < 6; c++) mcc -= lane_bcast(term, c);
-        }
-        POSE_T(6);
-        if (!ok || !(mcc > 0.0)) {
-          if (tid == 0) {
-            if (++s_invalid >= 5) { s_term = 5; s_done = 1; }
-            s_radius = radius / s_dec; s_dec *= 2;
-          }
-        } else {
-          double d[3], cand[7];
-          for (int k = 0; k < 3; k++) cand[k] = s_x[k] + (-y[k]) * s_scale[k];
-          for (int k = 0; k < 3; k++) d[k] = (-y[3 + k]) * s_scale[3 + k];
-          quat_plus(s_x + 3, d, cand + 3);
-          double sn = 0;
-          for (int k = 0; k < 7; k++) { double e = s_x[k] - cand[k]; sn += e * e; }
-          if (tid == 0) {
-            s_invalid = 0; s_valid = 1; s_mcc = mcc;
-            for (int k = 0; k < 7; k++) s_cand[k] = cand[k];
-            s_stepnorm = sqrt(sn);
-          }
-        }
-        POSE_T(7);
-      }
-    }
-    __syncthreads();
-    POSE_T(1);                             // thread 0: damped solve, candidate
-    done = s_done;
-    const int valid = s_valid;
-    if (done) break;
-    if (!valid) continue;
-    // The candidate is evaluated IN FULL - cost, gradient and Gauss-Newton block in one pass over the observations: nearly
-    // every step is accepted, and the sums are then the next iteration's state (a cost-only pass followed by a second, full
-    // pass at the same pose cost a third of the kernel's 47 us at 1500 observations; a rejected step wastes the Jacobians)
-    accumulate(s_cand);
-    POSE_T(2);                             // evaluation at the candidate
-    if (tid == 0) {
-      double cand_cost = s_sum[0];
-      if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
-      if (s_stepnorm <= 1e-8 * (s_xnorm + 1e-8)) { s_term = 2; s_done = 1; }
-      else {
-        double cost_change = s_xcost - cand_cost;
-        if (fabs(cost_change) <= 1e-6 * s_xcost) { s_term = 3; s_done = 1; }
-        else {
-          double rel = cost_change / s_mcc;
-          if (rel > 1e-3) {
-            s_accept = 1; s_succ++;
-            for (int k = 0; k < 7; k++) s_x[k] = s_cand[k];
-            const double c3 = 2.0 * rel - 1.0;               // pow(c3, 3) as two products: the generic fp64 pow costs
-            s_radius = fmin(1e16, s_radius / fmax(1.0 / 3.0, 1.0 - c3 * c3 * c3));   // ~1 us of lone-thread time per iteration
-            s_dec = 2.0;
-            adopt(false);
-          } else {
-            s_radius /= s_dec; s_dec *= 2.0;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    POSE_T(3);                             // thread 0: decision, new state
-    done = s_done;
-  }
-  __syncthreads();
-  // CheckOutliers with the un-normalised quaternion (:333), then normalise for SetPose (:336)
-  int bad = 0;
-  for_obs([&](int i, const double* X, double u0, double v0, double w) {
-    int o = check_outlier(k4r, s_x, X, u0, v0, w, 5.991, nullptr);
-    outlier[lo + i] = (uint8_t)o;
-    bad += o;
-  });
-  if (bad) atomicAdd(&s_nbad, bad);
-  __syncthreads();
-  if (tid == 0) {
-    double* q = s_x + 3;
-    double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int k = 0; k < 3; k++) pose[k] = s_x[k];
-    for (int k = 0; k < 4; k++) pose[3 + k] = q[k] / nq;
-    n_inliers[p] = n - s_nbad;
-    if (summaries) {
-      ba_summary s;
-      s.initial_cost = s_init; s.final_cost = s_xcost; s.iterations = s_iter; s.successful_steps = s_succ;
-      s.termination = s_term; s.final_radius = s_radius;
-      summaries[p] = s;
-    }
-  }
-  POSE_T(4);                               // outlier check, write-back
-}
-
-
-// ============================================================================ OptimizeSim3
-// The WHOLE solve of one keyframe pair inside one workgroup, as k_pose_lm: 2n Sim3ErrorTerm residual blocks on a single
-// 7-parameter block (tangent of S12), HuberLoss(sqrt(th2)), Sim3Parameterization::Plus, <= 100 iterations
-// (src/CeresOptimizer.cc:601-735).  One workgroup per problem; offsets[] delimits the correspondences.
-__device__ __forceinline__ int sym7(int a, int b) { return a <= b ? a * 7 - a * (a - 1) / 2 + (b - a) : b * 7 - b * (b - 1) / 2 + (a - b); }
-
-__device__ bool chol7_solve(double* A, double* b) {
-  const int n = 7;
-  for (int j = 0; j < n; j++) {
-    double d = A[j * n + j];
-    for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
-    if (!(d > 0.0) || !isfinite(d)) return false;
-    d = sqrt(d);
-    A[j * n + j] = d;
-    for (int i = j + 1; i < n; i++) {
-      double s = A[i * n + j];
-      for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
-      A[i * n + j] = s / d;
-    }
-  }
-  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i * n + k] * b[k]; b[i] = s / A[i * n + i]; }
-  for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= A[k * n + i] * b[k]; b[i] = s / A[i * n + i]; }
-  return true;
-}
-
-__global__ __launch_bounds__(256) void k_sim3_lm(const double* __restrict__ K1s, const double* __restrict__ K2s, double* __restrict__ s12s,
-                                                 const double* __restrict__ P3D2c, const double* __restrict__ obs1,
-                                                 const float* __restrict__ w1, const double* __restrict__ P3D1c,
-                                                 const double* __restrict__ obs2, const float* __restrict__ w2,
-                                                 const int* __restrict__ offsets, const double* __restrict__ th2s,
-                                                 uint8_t* __restrict__ outlier, int* __restrict__ n_inliers,
-                                                 ba_summary* __restrict__ summaries, int max_iters) {
-  __shared__ double s_red[4 * 36], s_sum[36];
-  __shared__ double s_x[7], s_cand[7], s_S[7], s_Si[7], s_scale[7], s_H[28], s_g[7];
-  __shared__ double s_radius, s_dec, s_xcost, s_xnorm, s_mcc, s_stepnorm, s_init;
-  __shared__ int s_iter, s_term, s_done, s_valid, s_accept, s_invalid, s_succ, s_nbad;
-  const int p = blockIdx.x, tid = threadIdx.x;
-  const int lo = offsets[p], n = offsets[p + 1] - lo;
-  const double* K1 = K1s + 4 * p;
-  const double* K2 = K2s + 4 * p;
-  const double huber = sqrt(th2s[p]);                         // :619
-  if (tid == 0) {
-    s3_log(s12s + 7 * p, s_x);                                // :605
-    s3_exp(s_x, s_S); s3_inverse(s_S, s_Si);
-    s_radius = 1e4; s_dec = 2.0; s_iter = 0; s_term = 0; s_done = (n == 0); s_invalid = 0; s_succ = 0; s_nbad = 0;
-    s_xcost = 0.0; s_init = 0.0;
-  }
-  __syncthreads();
-
-  auto evaluate = [&](bool first) {          // expects s_S / s_Si = exp(s_x) and its inverse
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    for (int i = tid; i < 2 * n; i += 256) {
-      const int g = lo + (i >> 1), inv = i & 1;              // residual-block order: forward then inverse term per match
-      double r[2], J[14];
-      const double rho = inv ? s3_term_eval(K2, s_Si, P3D1c + 3 * (size_t)g, obs2[2 * (size_t)g], obs2[2 * (size_t)g + 1], (double)w2[g], huber, r, J)
-                             : s3_term_eval(K1, s_S, P3D2c + 3 * (size_t)g, obs1[2 * (size_t)g], obs1[2 * (size_t)g + 1], (double)w1[g], huber, r, J);
-      acc[0] += 0.5 * rho;
-#pragma unroll
-      for (int a = 0; a < 7; a++) {
-        acc[1 + a] += J[a] * r[0] + J[7 + a] * r[1];
-#pragma unroll
-        for (int b = a; b < 7; b++) acc[8 + sym7(a, b)] += J[a] * J[b] + J[7 + a] * J[7 + b];
-      }
-    }
-    block_reduce<36>(acc, s_red, s_sum);
-    if (tid == 0) {
-      s_xcost = s_sum[0];
-      for (int a = 0; a < 7; a++) s_g[a] = s_sum[1 + a];
-      for (int k = 0; k < 28; k++) s_H[k] = s_sum[8 + k];
-      if (first) {
-        for (int a = 0; a < 7; a++) s_scale[a] = 1.0 / (1.0 + sqrt(s_H[sym7(a, a)]));
-        s_init = s_xcost;
-      }
-      double xn = 0;
-      for (int k = 0; k < 7; k++) xn += s_x[k] * s_x[k];
-      s_xnorm = sqrt(xn);
-      double mg[7], xp[7], gmax = 0;                          // gradient max norm = || x - Plus(x, -g) ||_inf
-      for (int k = 0; k < 7; k++) mg[k] = -s_g[k];
-      s3_plus(s_x, mg, xp);
-      for (int k = 0; k < 7; k++) gmax = fmax(gmax, fabs(s_x[k] - xp[k]));
-      if (gmax <= 1e-10) { s_term = 1; s_done = 1; }
-    }
-    __syncthreads();
-  };
-
-  int done = s_done;
-  if (!done) { evaluate(true); done = s_done; }
-  while (!done) {
-    __syncthreads();
-    if (tid == 0) {
-      s_valid = 0; s_accept = 0;
-      if (s_iter >= max_iters) { s_term = 0; s_done = 1; }
-      else if (s_radius <= 1e-32) { s_term = 6; s_done = 1; }
-      else {
-        s_iter++;
-        double A[49], y[7], Hs[49], gs[7];
-        for (int a = 0; a < 7; a++) {
-          gs[a] = s_g[a] * s_scale[a];
-          for (int b = 0; b < 7; b++) Hs[a * 7 + b] = s_H[sym7(a, b)] * s_scale[a] * s_scale[b];
-        }
-        for (int k = 0; k < 49; k++) A[k] = Hs[k];
-        for (int a = 0; a < 7; a++) A[a * 8] += fmin(fmax(Hs[a * 8], 1e-6), 1e32) / s_radius;
-        for (int a = 0; a < 7; a++) y[a] = gs[a];
-        bool ok = chol7_solve(A, y);
-        double mcc = 0;
-        if (ok) {
-          for (int a = 0; a < 7; a++) {
-            double hs = 0;
-            for (int b = 0; b < 7; b++) hs += Hs[a * 7 + b] * (-y[b]);
-            mcc -= (-y[a]) * (gs[a] + 0.5 * hs);
-          }
-        }
-        if (!ok || !(mcc > 0.0)) {
-          if (++s_invalid >= 5) { s_term = 5; s_done = 1; }
-          s_radius /= s_dec; s_dec *= 2;
-        } else {
-          s_invalid = 0; s_valid = 1; s_mcc = mcc;
-          double d[7];
-          for (int k = 0; k < 7; k++) d[k] = (-y[k]) * s_scale[k];
-          s3_plus(s_x, d, s_cand);
-          double sn = 0;
-          for (int k = 0; k < 7; k++) { double e = s_x[k] - s_cand[k]; sn += e * e; }
-          s_stepnorm = sqrt(sn);
-          s3_exp(s_cand, s_S); s3_inverse(s_S, s_Si);        // candidate transform for the cost pass
-        }
-      }
-    }
-    __syncthreads();
-    done = s_done;
-    const int valid = s_valid;
-    if (done) break;
-    if (!valid) continue;
-    double acc[1] = {0.0};
-    for (int i = tid; i < 2 * n; i += 256) {
-      const int g = lo + (i >> 1), inv = i & 1;
-      double r[2];
-      acc[0] += 0.5 * (inv ? s3_term_eval(K2, s_Si, P3D1c + 3 * (size_t)g, obs2[2 * (size_t)g], obs2[2 * (size_t)g + 1], (double)w2[g], huber, r, nullptr)
-                           : s3_term_eval(K1, s_S, P3D2c + 3 * (size_t)g, obs1[2 * (size_t)g], obs1[2 * (size_t)g + 1], (double)w1[g], huber, r, nullptr));
-    }
-    block_reduce<1>(acc, s_red, s_sum);
-    if (tid == 0) {
-      double cand_cost = s_sum[0];
-      if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
-      if (s_stepnorm <= 1e-8 * (s_xnorm + 1e-8)) { s_term = 2; s_done = 1; }
-      else {
-        const double cost_change = s_xcost - cand_cost;
-        if (fabs(cost_change) <= 1e-6 * s_xcost) { s_term = 3; s_done = 1; }
-        else {
-          const double rel = cost_change / s_mcc;
-          if (rel > 1e-3) {
-            s_accept = 1; s_succ++;
-            for (int k = 0; k < 7; k++) s_x[k] = s_cand[k];   // s_S / s_Si already hold exp(cand)
-            s_radius = fmin(1e16, s_radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3)));
-            s_dec = 2.0;
-          } else {
-            s_radius /= s_dec; s_dec *= 2.0;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    done = s_done;
-    const int accept = s_accept;
-    if (done) break;
-    if (accept) { evaluate(false); done = s_done; }
-  }
-  __syncthreads();
-  if (tid == 0) { s3_exp(s_x, s_S); s3_inverse(s_S, s_Si); }  // S12 = exp(sim12) (:691), S21 (:703)
-  __syncthreads();
-  const double thres = huber * huber;                         // deltaHuber * deltaHuber (:701)
-  int bad = 0;
-  for (int i = tid; i < n; i += 256) {
-    const int g = lo + i;
-    const int o12 = s3_check_outlier(K1, s_S, P3D2c + 3 * (size_t)g, obs1[2 * (size_t)g], obs1[2 * (size_t)g + 1], w1[g], thres);
-    const int o21 = s3_check_outlier(K2, s_Si, P3D1c + 3 * (size_t)g, obs2[2 * (size_t)g], obs2[2 * (size_t)g + 1], w2[g], thres);
-    if (outlier) outlier[g] = (uint8_t)(o12 | o21);
-    bad += (o12 | o21);
-  }
-  if (bad) atomicAdd(&s_nbad, bad);
-  __syncthreads();
-  if (tid == 0) {
-    for (int k = 0; k < 7; k++) s12s[7 * p + k] = s_S[k];
-    const int good = n - s_nbad;
-    n_inliers[p] = good < 10 ? 0 : good;                      // :731
-    if (summaries) {
-      ba_summary s;
-      s.initial_cost = s_init; s.final_cost = s_xcost; s.iterations = s_iter; s.successful_steps = s_succ;
-      s.termination = s_term; s.final_radius = s_radius;
-      summaries[p] = s;
-    }
-  }
-}
+#include "ba_small_lm.inc"   // PoseOptimization and OptimizeSim3
 
 // ============================================================================ general BA
 struct BaState {
@@ -1304,2129 +856,7 @@ __global__ void k_ba_pad(const BaDev* __restrict__ Dv) {
   if (threadIdx.x == 0) { D.rhs[i] = 0.0; D.S[(size_t)np * np + i] = 0.0; }
 }
 
-// ---- dense blocked Cholesky (lower, in place), NB = 32 ---------------------------------------------------
-#define NB 32
-// Phase timing of the factorisation step kernels (tools/chol_phase_prof.py builds a scratch library with -DORBHIP_CHOL_PROF):
-// wave 0 of workgroup 0 of problem 0 stamps s_memrealtime (100 MHz) at the phase boundaries; sums per step index.
-#if defined(ORBHIP_SCHUR_PROF) && !defined(ORBHIP_CHOL_PROF)
-__device__ unsigned long long g_p2_prof[8][128];
-__device__ unsigned long long g_chol_prof[128][10];
-#endif
-#ifdef ORBHIP_CHOL_PROF
-__device__ unsigned long long g_p2_prof[8][128];       // k_chol_persist_2l timeline (absolute s_memrealtime): see tools/chol_p2_timeline.py
-#define P2_MARK(row, idx) do { if ((threadIdx.x & 63) == 0) atomicMax(&g_p2_prof[row][(idx) & 127], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
-__device__ unsigned long long g_chol_prof[128][10];
-#define CHOL_STAMP(i) do { if (prof_on) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
-                              if (threadIdx.x == 0) g_chol_prof[prof_step][i] += t_ - prof_t; prof_t = t_; } } while (0)
-#define CHOL_PROF_BEGIN(step) const bool prof_on = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64; const int prof_step = (step) & 127; \
-                              unsigned long long prof_t = __builtin_amdgcn_s_memrealtime(); if (prof_on && threadIdx.x == 0) g_chol_prof[prof_step][9] += 1
-#else
-#define CHOL_STAMP(i) do { } while (0)
-#define CHOL_PROF_BEGIN(step) do { } while (0)
-#define P2_MARK(row, idx) do { } while (0)
-#endif
-// panel: every workgroup factors and inverts the 32x32 diagonal block redundantly in ONE wave
-// (diag_factor_invert_wave below), workgroup 0 stores L11^-1; then every wave
-// forms 16 rows of L21 = A21 * L11^-T on the FP64 matrix cores (2 column tiles x 8 k-steps of
-// v_mfma_f64_16x16x4_f64).  Rows run to npad INCLUSIVE: row npad is the augmented rhs row.
-typedef double double4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double bcast_lane(double v, int lane) {      // lane is a compile-time constant after unrolling
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
-  return __hiloint2double(hi, lo);
-}
-// 1/sqrt(x) in fp64: hardware v_rsq_f64 estimate + two Newton steps (~1 ulp); avoids the long fp64 sqrt + divide
-// sequences on the 32-step critical path of the diagonal factorisation.
-__device__ __forceinline__ double rsqrt_f64(double x) {
-  // y += y * (0.5 - (x/2) y^2) with explicit fmas: 3 dependent operations per step (the file is built with
-  // -ffp-contract=off, so the textbook y * (1.5 - 0.5 x y y) would be 5 dependent multiplies / subtracts)
-  const double hx = 0.5 * x;
-  double y = __builtin_amdgcn_rsq(x);
-  double r = fma(-(hx * y), y, 0.5);
-  y = fma(y, r, y);
-  r = fma(-(hx * y), y, 0.5);
-  y = fma(y, r, y);
-  return y;
-}
-// ---- 32x32 diagonal block: Cholesky factor AND its inverse by ONE wave in ONE pass -----------------------------------
-// Right-looking factor, lane r (< 32) keeps row r of the block in registers: per column j, scale entry j by 1/sqrt(pivot j)
-// and subtract l(c, j) times it from every entry c > j.  Forward substitution of L x = e_c' does EXACTLY the same to the
-// entries of a column of the identity (x_j = sum_j / l(j, j), sum_c -= l(c, j) x_j), so lanes 32..63 - idle in the factor -
-// each carry one column of I through the same instructions and end up holding L^-1: there is no inverse phase (round 2:
-// factor 4.8 us + blocked inverse 1.8 us per step of k_chol_la; this: see DESIGN.md section 4).
-// One wave alone on its SIMD issues one instruction per ~4.5 cycles whatever it is (tools/ubench/f64_latency.hip), and it
-// stalls in order, so the body is arranged around that:
-//   * the loop-carried chain never touches a lane: the next pivot is formed from two uniform values read ahead of time
-//     (sa = a(j+1, j), sb = a(j+1, j+1) by v_readlane while the previous rsqrt chain runs), pivot' = sb - (sa y)^2 - bit for
-//     bit what lane j+1 computes for itself;
-//   * column j, once scaled, goes to LDS (s_T[j][lane]) and comes back to every lane as b128 broadcast reads - a 105-cycle
-//     round trip, so the reads are consumed ONE BODY LATER (entries j+1 and j+2, which the next two pivots need, get column
-//     j's update through v_readlane instead);
-//   * those deferred updates are placed between the Newton steps of the next pivot's rsqrt (sched_barriers pin the machine
-//     scheduler; PIN - an empty volatile asm with the value as in/out operand - keeps the IR from moving a pure operation
-//     across them; no conditional store inside the loop: it would split the basic block and the code sinker then collects
-//     every update behind the whole chain).
-// A non-positive / non-finite pivot poisons the rest of the block (NaN) and is reported; the caller discards the step.
-#define CHOL_SB() __builtin_amdgcn_sched_barrier(0)
-#define CHOL_PIN(x) asm volatile("" : "+v"(x))
-template <int J, int C0, int N>
-__device__ __forceinline__ void diag_prev_update(double (&acc)[NB], const double (&lp)[NB], const double mp) {     // column J-1 applied to entries C0 .. C0+N-1
-  if constexpr (J > 0) {
-#pragma unroll
-    for (int q = 0; q < N; q++) if (C0 + q < NB) acc[C0 + q] = fma(-mp, lp[C0 + q], acc[C0 + q]);
-  }
-}
-// body J: y = 1/sqrt(pivot J); sa, sb as above; lp[c] = l(c, J-1) for c >= J+2 (requested one body earlier), mp = this
-// lane's scaled entry J-1
-template <int J>
-struct DiagCol {
-  static constexpr int U = 4;                                  // deferred updates per Newton operation
-  static __device__ __forceinline__ void run(double (&acc)[NB], const double (&lp)[NB], const double mp, const double y, const double sa, const double sb,
-                                             int& bad, double (*s_T)[64], const int lane) {
-    double l = 0.0, pivn = 1.0, hxn = 0.0, yn = 0.0;
-    if constexpr (J + 1 < NB) {
-      l = sa * y;
-      pivn = fma(-l, l, sb);
-      hxn = 0.5 * pivn;
-      yn = __builtin_amdgcn_rsq(pivn);
-      CHOL_PIN(yn); CHOL_PIN(hxn);
-      bad |= __builtin_isfpclass(pivn, 0x180) ? 0 : 1;          // anything but a positive (sub)normal number: <= 0, NaN, inf - one v_cmp_class
-    }
-    CHOL_SB();
-    acc[J] = acc[J] * y;                                       // lane J: pivot * y = sqrt(pivot); lane 32 + c': x_J of column c'
-    s_T[J][lane] = acc[J];                                     // (lanes 32..63 write the half of the row nobody reads)
-    if constexpr (J + 1 < NB) acc[J + 1] = fma(-acc[J], l, acc[J + 1]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    double san = 0.0, sbn = 0.0;
-    if constexpr (J + 2 < NB) {
-      diag_prev_update<J, J + 2, 1>(acc, lp, mp);
-      const double l2 = bcast_lane(acc[J], J + 2);
-      acc[J + 2] = fma(-acc[J], l2, acc[J + 2]);
-      san = bcast_lane(acc[J + 1], J + 2);
-      sbn = bcast_lane(acc[J + 2], J + 2);
-    }
-    double lpn[NB];
-    if constexpr (J + 3 < NB) {
-      constexpr int ce = (J + 3) + ((J + 3) & 1);              // first even (16-byte aligned) entry
-      if constexpr (((J + 3) & 1) != 0) lpn[J + 3] = s_T[J][J + 3];
-#pragma unroll
-      for (int c = ce; c + 1 < NB; c += 2) { const double2 v = *(const double2*)&s_T[J][c]; lpn[c] = v.x; lpn[c + 1] = v.y; }
-    }
-    if constexpr (J + 1 < NB) {
-      constexpr int c0 = J + 3;
-      CHOL_SB(); double t = hxn * yn;
-      CHOL_SB(); diag_prev_update<J, c0, U>(acc, lp, mp);
-      CHOL_SB(); double e = fma(-t, yn, 0.5);
-      CHOL_SB(); diag_prev_update<J, c0 + U, U>(acc, lp, mp);
-      CHOL_SB(); yn = fma(yn, e, yn);
-      CHOL_SB(); diag_prev_update<J, c0 + 2 * U, U>(acc, lp, mp);
-      CHOL_SB(); t = hxn * yn;
-      CHOL_SB(); diag_prev_update<J, c0 + 3 * U, U>(acc, lp, mp);
-      CHOL_SB(); e = fma(-t, yn, 0.5);
-      CHOL_SB(); diag_prev_update<J, c0 + 4 * U, U>(acc, lp, mp);
-      CHOL_SB(); yn = fma(yn, e, yn); CHOL_PIN(yn);
-      CHOL_SB(); diag_prev_update<J, c0 + 5 * U, NB>(acc, lp, mp);
-      CHOL_SB();
-      DiagCol<J + 1>::run(acc, lpn, acc[J], yn, san, sbn, bad, s_T, lane);
-    }
-  }
-};
-// in: s_L = the block (lower triangle, zeros above); out: s_X = L^-1 (full 32x32, zeros above the diagonal).  L itself stays
-// in registers and is dropped: nothing downstream reads it (the L21 rows and the substitutions use L^-1).  One wave (64 lanes).
-__device__ __forceinline__ int diag_factor_invert_wave(double (*s_L)[NB + 1], double (*s_X)[NB + 1], double (*s_T)[64]) {
-  const int lane = threadIdx.x & 63, r = lane & 31;
-  double acc[NB], lp0[NB];
-  // (every lane reads row r - lanes 32..63 throw it away: a load inside the select compiled to 32 exec-masked branches,
-  // ~250 of the factor's ~2100 instructions, and a lone wave pays ~5 cycles for each)
-  double rowv[NB];
-#pragma unroll
-  for (int c = 0; c < NB; c++) rowv[c] = s_L[r][c];
-#pragma unroll
-  for (int c = 0; c < NB; c++) { acc[c] = (lane < 32) ? rowv[c] : ((c == r) ? 1.0 : 0.0); lp0[c] = 0.0; }
-  int bad = 0;
-  const double piv = bcast_lane(acc[0], 0);
-  bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
-  const double y0 = rsqrt_f64(piv);
-  const double sa = bcast_lane(acc[0], 1), sb = bcast_lane(acc[1], 1);
-  DiagCol<0>::run(acc, lp0, 0.0, y0, sa, sb, bad, s_T, lane);
-  if (lane >= 32) {
-#pragma unroll
-    for (int rr = 0; rr < NB; rr++) s_X[rr][r] = acc[rr];      // column r of L^-1 (the zeros above the diagonal come out by themselves)
-  }
-  return bad;
-}
-// ---- the same factor + inverse by TWO cooperating waves (k_chol_wg; tools/factor_ab.py compares it with the one-wave form) ----
-// A third of the one-wave factor's instructions are the trailing updates; if the factor were issue-bound, splitting the columns
-// over two waves would shorten it by about that much.  Measured: 3.91 -> 3.60 us per factor in isolation, bit-identical - the
-// factor is bound by the pivot recurrence (y_J -> l -> pivot -> rsq -> two Newton steps -> y_J+1, ~110 ns per column with the
-// deferred updates interleaved), not by the instruction count; not worth a fifth wave in every persistent workgroup.  Round 4:
-// k_chol_wg (one workgroup of eight waves per problem) takes THIS form: 156 registers instead of 332, so the kernel keeps two waves
-// per SIMD.
-// Wave A owns columns 0..15 of every row, wave B columns 16..31: A factors its columns exactly as above (its
-// updates stop at column 15), B meanwhile applies A's 16 column updates to its own columns as A publishes them (s_T holds every
-// lane's scaled entry of a column: B's own multiplier and the sixteen row entries it needs are there; s_col counts the
-// columns published) and then factors columns 16..31 the same way.  Every entry receives the same fmas in the same order as
-// in the one-wave function and the pivot chain is the same sequence of operations: the results are the same bits
-// (k_chol_la / k_chol_panel keep the one-wave function; the batched-equals-single tests compare the two).
-template <int J, int C0, int N>
-__device__ __forceinline__ void diag_prev_update_h(double (&acc)[16], const double (&lp)[16], const double mp) {
-  if constexpr (J > 0) {
-#pragma unroll
-    for (int q = 0; q < N; q++) if (C0 + q < 16) acc[C0 + q] = fma(-mp, lp[C0 + q], acc[C0 + q]);
-  }
-}
-template <int J, int OFF>
-struct DiagColH {
-  static constexpr int U = 2;
-  static __device__ __forceinline__ void run(double (&acc)[16], const double (&lp)[16], const double mp, const double y, const double sa, const double sb,
-                                             int& bad, double (*s_T)[64], const int lane, int* s_col, const int col_base) {
-    double l = 0.0, pivn = 1.0, hxn = 0.0, yn = 0.0;
-    if constexpr (J + 1 < 16) {
-      l = sa * y;
-      pivn = fma(-l, l, sb);
-      hxn = 0.5 * pivn;
-      yn = __builtin_amdgcn_rsq(pivn);
-      CHOL_PIN(yn); CHOL_PIN(hxn);
-      bad |= __builtin_isfpclass(pivn, 0x180) ? 0 : 1;
-    }
-    CHOL_SB();
-    acc[J] = acc[J] * y;
-    s_T[OFF + J][lane] = acc[J];
-    if constexpr (J + 1 < 16) acc[J + 1] = fma(-acc[J], l, acc[J + 1]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if constexpr (OFF == 0) { if (lane == 0) __hip_atomic_store(s_col, col_base + J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }   // column J is in s_T: wave B may take it
-    double san = 0.0, sbn = 0.0;
-    if constexpr (J + 2 < 16) {
-      diag_prev_update_h<J, J + 2, 1>(acc, lp, mp);
-      const double l2 = bcast_lane(acc[J], OFF + J + 2);
-      acc[J + 2] = fma(-acc[J], l2, acc[J + 2]);
-      san = bcast_lane(acc[J + 1], OFF + J + 2);
-      sbn = bcast_lane(acc[J + 2], OFF + J + 2);
-    }
-    double lpn[16];
-    if constexpr (J + 3 < 16) {
-      constexpr int ce = (J + 3) + ((J + 3) & 1);
-      if constexpr (((J + 3) & 1) != 0) lpn[J + 3] = s_T[OFF + J][OFF + J + 3];
-#pragma unroll
-      for (int c = ce; c + 1 < 16; c += 2) { const double2 v = *(const double2*)&s_T[OFF + J][OFF + c]; lpn[c] = v.x; lpn[c + 1] = v.y; }
-    }
-    if constexpr (J + 1 < 16) {
-      constexpr int c0 = J + 3;
-      CHOL_SB(); double t = hxn * yn;
-      CHOL_SB(); diag_prev_update_h<J, c0, U>(acc, lp, mp);
-      CHOL_SB(); double e = fma(-t, yn, 0.5);
-      CHOL_SB(); diag_prev_update_h<J, c0 + U, U>(acc, lp, mp);
-      CHOL_SB(); yn = fma(yn, e, yn);
-      CHOL_SB(); diag_prev_update_h<J, c0 + 2 * U, U>(acc, lp, mp);
-      CHOL_SB(); t = hxn * yn;
-      CHOL_SB(); diag_prev_update_h<J, c0 + 3 * U, U>(acc, lp, mp);
-      CHOL_SB(); e = fma(-t, yn, 0.5);
-      CHOL_SB(); diag_prev_update_h<J, c0 + 4 * U, U>(acc, lp, mp);
-      CHOL_SB(); yn = fma(yn, e, yn); CHOL_PIN(yn);
-      CHOL_SB(); diag_prev_update_h<J, c0 + 5 * U, 16>(acc, lp, mp);
-      CHOL_SB();
-      DiagColH<J + 1, OFF>::run(acc, lpn, acc[J], yn, san, sbn, bad, s_T, lane, s_col, col_base);
-    }
-  }
-};
-// half = 0: wave A, half = 1: wave B (64 lanes each, any two waves of the workgroup); s_col: an int in LDS, zero at kernel start;
-// col_base: 16 x (number of factors this workgroup has done before) - the count only grows, nothing is reset between factors.
-__device__ __forceinline__ int diag_factor_invert_2w(double (*s_L)[NB + 1], double (*s_X)[NB + 1], double (*s_T)[64], int* s_col, const int col_base, const int half) {
-  const int lane = threadIdx.x & 63, r = lane & 31;
-  const int off = half ? 16 : 0;
-  double acc[16], lp0[16], rowv[16];
-#pragma unroll
-  for (int c = 0; c < 16; c++) rowv[c] = s_L[r][off + c];
-#pragma unroll
-  for (int c = 0; c < 16; c++) { acc[c] = (lane < 32) ? rowv[c] : ((off + c == r) ? 1.0 : 0.0); lp0[c] = 0.0; }
-  int bad = 0;
-  if (half == 0) {
-    const double piv = bcast_lane(acc[0], 0);
-    bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
-    const double y0 = rsqrt_f64(piv);
-    const double sa = bcast_lane(acc[0], 1), sb = bcast_lane(acc[1], 1);
-    DiagColH<0, 0>::run(acc, lp0, 0.0, y0, sa, sb, bad, s_T, lane, s_col, col_base);
-  } else {
-    // A's columns, one by one as they are published: acc[c] -= (this lane's scaled entry of column J) * (row (16 + c)'s)
-#pragma unroll
-    for (int J = 0; J < 16; J++) {
-      for (int it = 0; it < (1 << 22) && __hip_atomic_load(s_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < col_base + J + 1; it++) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");         // (nothing below may be read before the count says so)
-      const double m = s_T[J][lane];
-      double lc[16];
-#pragma unroll
-      for (int c = 0; c < 16; c += 2) { const double2 v = *(const double2*)&s_T[J][16 + c]; lc[c] = v.x; lc[c + 1] = v.y; }
-#pragma unroll
-      for (int c = 0; c < 16; c++) acc[c] = fma(-m, lc[c], acc[c]);
-    }
-    const double piv = bcast_lane(acc[0], 16);
-    bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
-    const double y0 = rsqrt_f64(piv);
-    const double sa = bcast_lane(acc[0], 17), sb = bcast_lane(acc[1], 17);
-    DiagColH<0, 16>::run(acc, lp0, 0.0, y0, sa, sb, bad, s_T, lane, s_col, col_base);
-  }
-  if (lane >= 32) {
-#pragma unroll
-    for (int rr = 0; rr < 16; rr++) s_X[off + rr][r] = acc[rr];
-  }
-  return bad;
-}
-#ifdef ORBHIP_CHOL_PROF
-// debug: both factor functions on the same block, n repetitions each, for a bitwise comparison and a timing (tools/factor_ab.py)
-__global__ __launch_bounds__(256) void k_factor_a(const double* __restrict__ A, double* __restrict__ X1, int n, unsigned long long* ticks) {
-  __shared__ double s_L[NB][NB + 1], s_X[NB][NB + 1];
-  __shared__ __attribute__((aligned(16))) double s_T[NB][64];
-  __shared__ int s_bad;
-  const int tid = threadIdx.x;
-  if (tid == 0) s_bad = 0;
-  for (int i = tid; i < NB * NB; i += 256) s_L[i / NB][i % NB] = (i % NB <= i / NB) ? A[i] : 0.0;
-  __syncthreads();
-  unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  for (int k = 0; k < n; k++) {
-    if (tid < 64) { if (diag_factor_invert_wave(s_L, s_X, s_T)) s_bad = 1; }
-    __syncthreads();
-  }
-  unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-  for (int i = tid; i < NB * NB; i += 256) X1[i] = s_X[i / NB][i % NB];
-  if (tid == 0) { ticks[0] = t1 - t0; ticks[2] = (unsigned long long)s_bad; }
-}
-__global__ __launch_bounds__(320) void k_factor_b(const double* __restrict__ A, double* __restrict__ X2, int n, unsigned long long* ticks) {
-  __shared__ double s_L[NB][NB + 1], s_X[NB][NB + 1];
-  __shared__ __attribute__((aligned(16))) double s_T[NB][64];
-  __shared__ int s_col, s_bad;
-  const int tid = threadIdx.x;
-  if (tid == 0) { s_col = 0; s_bad = 0; }
-  for (int i = tid; i < NB * NB; i += 320) s_L[i / NB][i % NB] = (i % NB <= i / NB) ? A[i] : 0.0;
-  __syncthreads();
-  unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
-  for (int k = 0; k < n; k++) {
-    if (tid < 64) { if (diag_factor_invert_2w(s_L, s_X, s_T, &s_col, 16 * k, 0)) s_bad = 1; }
-    else if (tid < 128) { if (diag_factor_invert_2w(s_L, s_X, s_T, &s_col, 16 * k, 1)) s_bad = 1; }
-    __syncthreads();
-  }
-  unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
-  for (int i = tid; i < NB * NB; i += 320) X2[i] = s_X[i / NB][i % NB];
-  if (tid == 0) { ticks[1] = t3 - t2; ticks[3] = (unsigned long long)s_bad; }
-}
-#endif
-// G = groups of 16 L21 rows per wave.  Every workgroup repeats the diagonal factor, so a lockstep batch (throughput-bound)
-// runs G = 4 (256 rows per workgroup: 3.3x fewer repeated factors at n = 600, +8 % solves/s), while a single problem
-// (latency-bound) runs G = 1: with G = 4 its L21 loads - 16 rows x 32 bytes per instruction, the MFMA operand layout -
-// concentrate on 3 CUs instead of 10 and the panel takes 18 us instead of 9.8.  Same arithmetic per row either way.
-template <int G>
-__global__ __launch_bounds__(256) void k_chol_panel(const BaDev* __restrict__ Dv, int k) {
-  const BaDev D = Dv[blockIdx.y];
-  if (D.chol_la) return;                                      // factored by k_chol_la
-  BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  __shared__ double s_L[NB][NB + 1];
-  __shared__ double s_X[NB][NB + 1];
-  __shared__ __attribute__((aligned(16))) double s_T[NB][64];   // column broadcast buffer of the factor
-  __shared__ int s_fail;
-  const int np = D.npad, tid = threadIdx.x;
-  if (k >= np || k + NB + (int)blockIdx.x * (64 * G) > np) return;     // beyond this problem's matrix (batched launch)
-  double* S = D.S;
-  // this wave's G x 16 rows of A21 do not depend on the diagonal factor: their loads are issued first and land while wave 0 factors
-  const int w = tid >> 6, lane = tid & 63;
-  const int row0 = k + NB + (blockIdx.x * 4 + w) * (16 * G);
-  const int li = lane & 15, lk = lane >> 4;
-  double a[G][8];
-#pragma unroll
-  for (int g = 0; g < G; g++) {
-    const int arow = row0 + 16 * g + li;
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) a[g][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
-  }
-  double d4[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; d4[u] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0; }
-  // (the state flags are read AFTER the matrix loads are in flight: one dependent global round trip less per launch;
-  // S is a valid allocation for finished problems too)
-  if (F.done || !F.valid || F.chol_fail) return;
-#pragma unroll
-  for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; s_L[i / NB][i % NB] = d4[u]; }
-  if (tid == 0) s_fail = 0;
-  __syncthreads();
-  if (tid < 64) {
-    const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
-    if (fail && tid == 0) s_fail = 1;
-  }
-  __syncthreads();
-  if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
-  if (blockIdx.x == 0) {
-    double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
-    for (int i = tid; i < NB * NB; i += 256) {
-      int r = i / NB, c = i % NB;
-      // (L11 itself is NOT written back: nothing downstream reads it - the substitutions use L11^-1 - and the other
-      // workgroups of this launch, which factor the same block redundantly, may still be reading the unfactored one)
-      Di[i] = s_X[r][c];
-    }
-  }
-  // ---- L21 rows: X = A * Linv^T on the matrix cores --------------------------------------------------
-  double b0[8], b1[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ks++) { b0[ks] = s_X[li][4 * ks + lk]; b1[ks] = s_X[16 + li][4 * ks + lk]; }     // B[k][j] = Linv[j][k]
-#pragma unroll
-  for (int g = 0; g < G; g++) {
-    const int rg0 = row0 + 16 * g;
-    if (rg0 > np) break;
-    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][ks], b0[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][ks], b1[ks], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const int orow = rg0 + (lane >> 4) + 4 * rg;
-      if (orow <= np) {
-        S[(size_t)orow * np + k + (lane & 15)] = acc0[rg];
-        S[(size_t)orow * np + k + 16 + (lane & 15)] = acc1[rg];
-      }
-    }
-  }
-}
-
-// trailing update C -= L[:, kcol:kcol+K] * L[:, kcol:kcol+K]^T on the FP64 matrix cores for the rows >= r_lo and the
-// columns [c_lo, c_hi) of the lower triangle; one 64x64 tile per workgroup, each of the 4 waves owns a 32x32 quadrant
-// as 2x2 v_mfma_f64_16x16x4_f64 tiles, K (32..128) is walked in 32-wide LDS stages.  Two-level blocking: the four
-// 32-wide panels of a 128-wide outer block only update the rest of that block ("thin" launches, K=32); everything to
-// the right of the outer block is updated ONCE with K=128 (4x the flops per byte of C moved).  Workgroups with
-// blockIdx.x >= ntiles update the augmented rhs row (row npad) over the same column range.
-__device__ __forceinline__ void chol_syrk_body(const BaDev& D, const BaState* st, const int bx, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles,
-                                               double (*s_A)[NB + 1], double (*s_B)[NB + 1], int c_rhs_min = 0) {
-  const StFlags F = ld_flags(st);
-  const int np = D.npad, tid = threadIdx.x;
-  // batched launch: the grid and (kcol, K, r_lo, c_lo, c_hi_cap) are laid out for the LARGEST reduced system of the batch;
-  // this problem clips the column range to its own size and drops the steps / tiles that fall outside
-  const int c_hi = min(c_hi_cap, np);
-  if (kcol + K > np || c_hi <= c_lo) return;
-  double* S = D.S;
-  if (bx >= ntiles) {           // augmented rhs row
-    if (F.done || !F.valid || F.chol_fail) return;
-    double* zrow = S + (size_t)np * np;
-    double* s_z = &s_A[0][0];
-    for (int i = tid; i < K; i += 256) s_z[i] = zrow[kcol + i];
-    __syncthreads();
-    const int c = c_lo + (bx - ntiles) * 256 + tid;
-    if (c < c_hi && c >= c_rhs_min) {
-      const double* L = S + (size_t)c * np + kcol;
-      double sum = 0.0;
-      for (int m = 0; m < K; m++) sum += L[m] * s_z[m];
-      zrow[c] -= sum;
-    }
-    return;
-  }
-  const int ti = bx / tiles_c, tj = bx - ti * tiles_c;
-  const int r0 = r_lo + ti * 64, c0 = c_lo + tj * 64;
-  if (r0 + 63 < c0 || r0 >= np || c0 >= c_hi) return;         // tile entirely above the diagonal / outside this problem
-  const int w = tid >> 6, lane = tid & 63;
-  const int qr = (w >> 1) * 32, qc = (w & 1) * 32;            // quadrant origin inside the 64x64 tile
-  const bool qskip = (r0 + qr + 31 < c0 + qc);                // quadrant entirely above the diagonal
-  double4_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const int li = lane & 15, lk = lane >> 4;                   // A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15]
-  // the first K stage and this lane's C entries are requested before the state flags are looked at (one dependent
-  // global round trip less per launch), and C no longer waits for the matrix-core loop to finish
-  double va[8], vb[8], cpre[2][2][4];
-#pragma unroll
-  for (int u = 0; u < 8; u++) {
-    const int i = tid + 256 * u, r = i / NB, c = i % NB;
-    va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + c] : 0.0;
-    vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol + c] : 0.0;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
-        const int col = c0 + qc + 16 * j + (lane & 15);
-        cpre[i][j][rg] = (!qskip && row < np && col < c_hi && col <= row) ? S[(size_t)row * np + col] : 0.0;
-      }
-  if (F.done || !F.valid || F.chol_fail) return;
-  for (int k0 = 0; k0 < K; k0 += NB) {
-    __syncthreads();
-    if (k0 > 0) {
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = tid + 256 * u, r = i / NB, c = i % NB;
-        va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + k0 + c] : 0.0;
-        vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol + k0 + c] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
-    __syncthreads();
-    if (!qskip) {
-#pragma unroll
-      for (int kk = 0; kk < NB; kk += 4) {
-        double a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
-#pragma unroll
-        for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-    }
-  }
-  if (qskip) return;
-  // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
-        const int col = c0 + qc + 16 * j + (lane & 15);
-        if (row < np && col < c_hi && col <= row) S[(size_t)row * np + col] = cpre[i][j][rg] - acc[i][j][rg];
-      }
-}
-
-__global__ __launch_bounds__(256) void k_chol_syrk(const BaDev* __restrict__ Dv, int kcol, int K, int r_lo, int c_lo, int c_hi_cap, int tiles_c, int ntiles) {
-  const BaDev D = Dv[blockIdx.y];
-  if (D.chol_la) return;                                      // factored by k_chol_la
-  __shared__ double s_A[64][NB + 1], s_B[64][NB + 1];
-  chol_syrk_body(D, D.st, (int)blockIdx.x, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles, s_A, s_B);
-}
-
-// ---- look-ahead Cholesky step for reduced systems up to 1024 unknowns (LocalBA: 600) -----------------------------------
-// The two-level scheme above is a chain of panel -> update -> panel ... launches; at n = 600 every launch is latency-bound
-// (9.8 + 6.1 us per step).  Here ONE launch per 32-column step carries both roles:
-//   role A (first nA workgroups): panel k.  The rank-32 update of the PREVIOUS step is applied to this column block inside
-//     the kernel: the diagonal block as D -= P P^T before it is factored (P = the previous panel's rows of the diagonal
-//     block), and the rows below algebraically, L21 = A21 X^T - Lprev (X P)^T with X = L11^-1 - both operand sets are
-//     loaded straight into the MFMA layout before the factor starts, M = X P costs 8 MFMAs per wave after the inverse;
-//   role B (remaining workgroups): the previous step's update of everything to the RIGHT of this column block (and of the
-//     augmented rhs row) - the old k_chol_syrk body, now off the critical path because it runs beside the factor.
-// Same launch count as panels alone; deterministic (fixed MFMA order).
-// Larger systems (hybrid = 1: the problems with chol_la == 0) run the same kernel INSIDE each 128-column outer block of the
-// two-level scheme: k0 = first column of the outer block (its first step has no pending update: everything older was applied
-// by the K = 128 updates), c_cap = its end (role B stops there; the rest of the matrix gets the four panels at once).
-//   role C (workgroups behind role B): a share of the PREVIOUS outer block's K = 128 update of everything to the right of
-//     this outer block.  That update is needed only after this block's steps, so it is taken off the serial chain and dealt
-//     out over this block's launches (tile t goes to step t mod nq), beside the latency-bound panel work.  (A second stream
-//     joined by events inside the captured graph was tried first: ~40 us per fork / join, slower than no overlap at all.)
-struct CholWide { int kcol, K, lo, tiles_c, total, nrhs, q, nq; };     // total = tiles of the whole update; nq = 0: no role C
-template <int G>
-__global__ __launch_bounds__(256) void k_chol_la(const BaDev* __restrict__ Dv, int k, int k0, int c_cap, int nA, int tiles_c, int ntiles, int nB, int hybrid, CholWide wd) {
-  const BaDev D = Dv[blockIdx.y];
-  if ((D.chol_la != 0) == (hybrid != 0)) return;
-  BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  __shared__ __attribute__((aligned(16))) double s_raw[4 * NB * (NB + 1) + NB * 64];
-  const int np = D.npad, tid = threadIdx.x;
-  if ((int)blockIdx.x >= nA) {
-    double (*s_A)[NB + 1] = (double (*)[NB + 1])s_raw;
-    double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_raw + 64 * (NB + 1));
-    const int bb = (int)blockIdx.x - nA;
-    if (bb < nB) chol_syrk_body(D, st, bb, k - NB, NB, k + NB, k + NB, c_cap, tiles_c, ntiles, s_A, s_B);
-    else {
-      const int wi = bb - nB, cnt = (wd.total - wd.q + wd.nq - 1) / wd.nq;          // this step's tiles: q, q + nq, q + 2 nq, ...
-      const int bx = wi < cnt ? wd.q + wi * wd.nq : wd.total + (wi - cnt);           // behind them (step 0 only): the rhs-row workgroups
-      chol_syrk_body(D, st, bx, wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B);
-    }
-    return;
-  }
-  double (*s_L)[NB + 1] = (double (*)[NB + 1])s_raw;
-  double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_raw + NB * (NB + 1));
-  double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_raw + 2 * NB * (NB + 1));
-  double (*s_T)[64] = (double (*)[64])(s_raw + 4 * NB * (NB + 1));          // 16-byte aligned: 4 * 32 * 33 * 8 bytes
-  __shared__ int s_fail;
-  if (k >= np || k + NB + (int)blockIdx.x * (64 * G) > np) return;     // beyond this problem's matrix (batched launch)
-  CHOL_PROF_BEGIN(k / NB);
-  double* S = D.S;
-  const bool upd = k > k0;
-  const int kp = k - NB;
-  const int w = tid >> 6, lane = tid & 63;
-  const int row0 = k + NB + (blockIdx.x * 4 + w) * (16 * G);
-  const int li = lane & 15, lk = lane >> 4;
-  // request order = need order: the two 32x32 blocks the factor waits for first, the L21 operands behind them
-  double d4[4], p4[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int i = tid + 256 * u, r = i / NB, c = i % NB;
-    d4[u] = (c <= r) ? S[(size_t)(k + r) * np + k + c] : 0.0;
-    p4[u] = upd ? S[(size_t)(k + r) * np + kp + c] : 0.0;
-  }
-  // G = 1 (one problem at a time: latency): the L21 operands of this wave's rows are requested HERE, before the factor, and
-  // wait in registers.  G = 4 (lockstep batches: throughput): they are loaded where they are used instead - 128 registers
-  // less, so that the kernel fits two waves per SIMD (338 -> <= 256 registers; the trailing-update workgroups of the same
-  // launch, which are the majority, were held to one workgroup per CU by the panel role's register count).
-  constexpr bool EARLY = (G == 1);
-  double a[EARLY ? G : 1][8], ap[EARLY ? G : 1][8];
-  if constexpr (EARLY) {
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      const int arow = row0 + 16 * g + li;
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) {
-        a[g][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
-        ap[g][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;      // negated: A21 + P (-Lprev)^T
-      }
-    }
-  }
-  if (F.done || !F.valid || F.chol_fail) return;
-#pragma unroll
-  for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; s_L[i / NB][i % NB] = d4[u]; s_P[i / NB][i % NB] = p4[u]; }
-  if (tid == 0) s_fail = 0;
-  __syncthreads();
-  CHOL_STAMP(0);                                              // loads landed
-  const int ti = w >> 1, tj = w & 1;                         // this wave's 16x16 tile of the 32x32 products
-  // The previous step's rank-32 update of THIS column block's rows below the diagonal, A21 <- A21 - Lprev P^T, on the matrix
-  // cores before the factor starts (round 3: it used to be folded algebraically into the product behind the factor,
-  // L21 = A21 X^T - Lprev (X P)^T, which put M = X P and a barrier on the serial chain).  a[ks] is at once the MFMA A operand
-  // of k-step ks and - the same register - row (lane >> 4) + 4 (ks & 3) of the 16 x 16 C tile ks >> 2 of A21^T, so the update
-  // accumulates INTO it: tile t of A21'^T = A21^T + P (-Lprev)^T with P's rows 16 t .. as the A operand and ap as the B operand.
-  auto apply_prev = [&](double (&av)[8], const double (&apv)[8]) {
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-      double4_t acc = {av[4 * t], av[4 * t + 1], av[4 * t + 2], av[4 * t + 3]};
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], apv[ks], acc, 0, 0, 0);
-      av[4 * t] = acc[0]; av[4 * t + 1] = acc[1]; av[4 * t + 2] = acc[2]; av[4 * t + 3] = acc[3];
-    }
-  };
-  if (upd) {
-    if (tj <= ti) {                                           // D -= P P^T on the lower tiles
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * ti + li][4 * ks + lk], s_P[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
-        if (c <= r) s_L[r][c] -= acc[rg];
-      }
-    }
-    __syncthreads();
-  }
-  CHOL_STAMP(1);                                              // D -= P P^T
-  if (tid < 64) {
-    const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
-    if (fail && tid == 0) s_fail = 1;
-    CHOL_STAMP(2);                                            // factor + inverse
-  } else if (upd) {                                           // waves 1..3 bring their rows up to date beside the factor ...
-    if constexpr (EARLY) {
-#pragma unroll
-      for (int g = 0; g < G; g++) apply_prev(a[g], ap[g]);
-    }
-  }
-  __syncthreads();
-  CHOL_STAMP(3);
-  if (s_fail) { if (tid == 0 && blockIdx.x == 0) st->chol_fail = 1; return; }
-  if (tid < 64 && upd) {                                      // ... wave 0 behind it
-    if constexpr (EARLY) {
-#pragma unroll
-      for (int g = 0; g < G; g++) apply_prev(a[g], ap[g]);
-    }
-  }
-  // ---- L21 rows on the matrix cores: A21' X^T ----------------------------------------------------------------------------
-  double b0[8], b1[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ks++) { b0[ks] = s_X[li][4 * ks + lk]; b1[ks] = s_X[16 + li][4 * ks + lk]; }     // B[k][j] = X[j][k]
-  CHOL_STAMP(4);                                              // operand reads
-#pragma unroll
-  for (int g = 0; g < G; g++) {
-    const int rg0 = row0 + 16 * g;
-    if (rg0 > np) break;
-    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    const int gi = EARLY ? g : 0;
-    if constexpr (!EARLY) {
-      const int arow = rg0 + li;
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) {
-        a[0][ks] = (arow <= np) ? S[(size_t)arow * np + k + 4 * ks + lk] : 0.0;
-        ap[0][ks] = (upd && arow <= np) ? -S[(size_t)arow * np + kp + 4 * ks + lk] : 0.0;
-      }
-    }
-    if constexpr (!EARLY) { if (upd) apply_prev(a[0], ap[0]); }
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gi][ks], b0[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[gi][ks], b1[ks], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const int orow = rg0 + (lane >> 4) + 4 * rg;
-      if (orow <= np) {
-        S[(size_t)orow * np + k + (lane & 15)] = acc0[rg];
-        S[(size_t)orow * np + k + 16 + (lane & 15)] = acc1[rg];
-      }
-    }
-  }
-  CHOL_STAMP(5);                                              // L21 on the matrix cores + stores
-  if (blockIdx.x == 0) {                                      // L11 and L11^-1 leave last: nothing in this launch waits for them
-    double* Di = D.Dinv + (size_t)(k / NB) * NB * NB;
-    for (int i = tid; i < NB * NB; i += 256) {
-      int r = i / NB, c = i % NB;
-      // (L11 itself is NOT written back: nothing downstream reads it - the substitutions use L11^-1 - and the other
-      // workgroups of this launch, which factor the same block redundantly, may still be reading the unfactored one)
-      Di[i] = s_X[r][c];
-    }
-  }
-  CHOL_STAMP(6);                                              // L11^-1 store
-}
-
-// ---- problem-parallel Cholesky for LOCKSTEP BATCHES: one workgroup factors one reduced system (<= 1024 unknowns) ------------
-// Round 4 (VERDICT r3 next #1a).  A lockstep batch used to walk one k_chol_la<4> launch per 32-column step: 19 launches per LM
-// iteration at C4 size, every one a panel + a rank-32 update that reads and writes the whole trailing matrix (18 MB per
-// factorisation), every panel workgroup repeating the diagonal factor - 24 % of a batched solve.  A batch has many systems, so
-// the parallelism can come from the PROBLEMS instead: one 512-thread workgroup per system, no flags, no co-residency
-// requirement, no launch chain.  The schedule is LEFT-looking by block column: the tiles (i, c) of column c are brought up to
-// date in registers from the finished columns j < c (read once per column: 9.4 MB per factorisation, written once: 1.5 MB),
-// eight block rows at a time - one 32 x 32 tile per wave; per step j the workgroup stages L(c, j) and the eight L(i, j) in LDS
-// (the next step's loads are in flight during the matrix-core loop).
-// The ARITHMETIC is the step kernels', operation for operation, so results are bit-identical to k_chol_la / k_chol_persist
-// and a batched solve stays bit-identical to single calls (tests/test_gpu_ba.py):
-//   tile (i, c), i > c:  T = A(i, c); for j = 0 .. c-2: T = T - (eight MFMA k-steps of L(i, j) L(c, j)^T from zero)   [chol_syrk_body]
-//                        j = c-1: T'^T accumulated on the matrix cores from T^T with P = L(c, c-1), -L(i, c-1)       [apply_prev]
-//                        L(i, c) = T' X_c^T (eight k-steps from zero), X_c = L(c, c)^-1
-//   diagonal tile:       the syrk form for every j <= c-1, lower triangle; factor + inverse by two waves (diag_factor_invert_2w:
-//                        the one-wave function's bits)
-//   rhs row (row npad):  z_c -= sum_m L(c, 32 j + m) z(32 j + m) for j <= c-2 (sequential mul / add per column, VALU), then the
-//                        row's last update and the multiplication by X_c^T on the matrix cores as a 16-row tile whose first
-//                        row is z and whose other rows are zero (k_chol_la's role A sees the row exactly like that).
-#define CW_TPB 256
-#define CW_NW (CW_TPB / 64)
-#ifndef CW_RPW
-#define CW_RPW 2                       /* block rows per wave and group: eight rows of a column are in flight per workgroup */
-#endif
-#define CW_NSCA (CW_RPW == 1 ? CW_NW - 1 : CW_NW * CW_RPW)      /* scratch tiles: with one row per wave, wave 0 borrows D_c's tile (it is the diagonal wave in the group that factors) */
-#define CW_TILE (NB * (NB + 1))
-/* LDS: L(c, j) twice (double buffer), a scratch tile per (wave, row slot), X_c, D_c, the factor's column buffer, the rhs row's
-   z(j) twice: 118 KB - one workgroup per CU, which the register count (one wave per SIMD, three operand sets in flight) implies anyway */
-#define CW_LDS_DOUBLES ((4 + CW_NSCA) * CW_TILE + NB * 64 + 2 * NB)
-#if CW_RPW == 1
-#define CW_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#else
-#define CW_ATTR
-#endif
-__global__ __launch_bounds__(CW_TPB) CW_ATTR void k_chol_wg(const BaDev* __restrict__ Dv) {
-  const BaDev D = Dv[blockIdx.x];
-  if (!D.chol_la) return;
-  BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid || F.chol_fail) return;
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  constexpr int NSC = CW_NW * CW_RPW, NSCA = CW_NSCA;
-  double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + (2 + NSCA) * CW_TILE);
-  double (*s_L)[NB + 1] = (double (*)[NB + 1])(s_dyn + (3 + NSCA) * CW_TILE);
-  double (*s_T)[64] = (double (*)[64])(s_dyn + (4 + NSCA) * CW_TILE);           // 16-byte aligned: a multiple of 32 * 33 * 8 bytes
-  double* s_z = s_dyn + (4 + NSCA) * CW_TILE + NB * 64;                         // [2][NB]
-  __shared__ int s_fail, s_col;
-  const int np = D.npad, nb = np / NB, tid = threadIdx.x;
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  double* S = D.S;
-  double* zrow = S + (size_t)np * np;
-  if (tid == 0) { s_fail = 0; s_col = 0; }
-  const int lrow = tid >> 4, lcol = 2 * (tid & 15);             // this thread's entries of the staged L(c, j): rows lrow and lrow + 16
-  __syncthreads();
-  for (int c = 0; c < nb; c++) {
-    const size_t cb = (size_t)c * NB;
-    const bool upd = c > 0;
-    // rows of this column: c (the diagonal tile), c + 1 .. nb - 1, and nb = the rhs row; CW_NW * CW_RPW at a time, wave w takes the
-    // rows c + g0 + w and c + g0 + w + CW_NW
-    for (int g0 = 0; c + g0 <= nb; g0 += NSC) {
-      CHOL_PROF_BEGIN(c);
-      int my[CW_RPW]; bool valid[CW_RPW], is_diag[CW_RPW], is_rhs[CW_RPW], is_row[CW_RPW];
-      double T[CW_RPW][2][2][4];
-      double zc = 0.0;
-#pragma unroll
-      for (int t = 0; t < CW_RPW; t++) {
-        my[t] = c + g0 + w + CW_NW * t;
-        valid[t] = my[t] <= nb; is_diag[t] = my[t] == c; is_rhs[t] = my[t] == nb; is_row[t] = valid[t] && !is_diag[t] && !is_rhs[t];
-        const size_t rb = (size_t)my[t] * NB;
-#pragma unroll
-        for (int I = 0; I < 2; I++)
-#pragma unroll
-          for (int J = 0; J < 2; J++)
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++)
-              T[t][I][J][rg] = (valid[t] && !is_rhs[t]) ? S[(rb + 16 * I + lk + 4 * rg) * np + cb + 16 * J + li] : 0.0;
-        if (is_rhs[t] && lane < NB) zc = zrow[cb + lane];
-      }
-      // ---- the updates j = 0 .. c-1.  L(c, j), which every row of the column needs, is staged in LDS by the whole workgroup
-      // (double buffer, ONE barrier per step); a wave's own L(i, j) come straight from global memory in the MFMA operand layout
-      // (a first version staged them in LDS as well: two barriers and an LDS round trip per step).  Two register sets in
-      // rotation: step j computes from set j & 1 (64 MFMAs per wave, ~1.8 us) while the loads of step j + 1 are in flight.
-      struct Stage { double A[CW_RPW][16]; double2 pb[2]; double z; };    // A operand: [8 I + ks] = L(i, j)[16 I + li][4 ks + lk]; this thread's share of L(c, j); z(j)
-      Stage G0, G1;
-#pragma unroll
-      for (int t = 0; t < CW_RPW; t++)
-#pragma unroll
-        for (int k = 0; k < 16; k++) { G0.A[t][k] = 0.0; G1.A[t][k] = 0.0; }
-      G0.z = G1.z = 0.0;
-      auto issue = [&](int j, Stage& G) {
-        const size_t jb = (size_t)j * NB;
-#pragma unroll
-        for (int h = 0; h < 2; h++) G.pb[h] = *(const double2*)&S[(cb + lrow + 16 * h) * np + jb + lcol];
-#pragma unroll
-        for (int t = 0; t < CW_RPW; t++) {
-          if (is_row[t]) {
-            const size_t rb = (size_t)my[t] * NB;
-#pragma unroll
-            for (int I = 0; I < 2; I++)
-#pragma unroll
-              for (int ks = 0; ks < 8; ks++) G.A[t][8 * I + ks] = S[(rb + 16 * I + li) * np + jb + 4 * ks + lk];
-          }
-          if (is_rhs[t] && lane < NB) G.z = zrow[jb + lane];
-        }
-      };
-      auto step = [&](int j, const Stage& Gc, Stage& Gn) {
-        double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + (j & 1) * CW_TILE);
-#pragma unroll
-        for (int h = 0; h < 2; h++) { s_B[lrow + 16 * h][lcol] = Gc.pb[h].x; s_B[lrow + 16 * h][lcol + 1] = Gc.pb[h].y; }
-        if ((is_rhs[0] || is_rhs[CW_RPW - 1]) && lane < NB) s_z[(j & 1) * NB + lane] = Gc.z;
-        __syncthreads();                                         // (buffer j & 1 was last read in step j - 2: every wave has passed step j - 1's barrier since)
-        if (j + 1 < c) issue(j + 1, Gn);
-        const bool last = j == c - 1;
-        double b0[8], b1[8];
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) { b0[ks] = s_B[li][4 * ks + lk]; b1[ks] = s_B[16 + li][4 * ks + lk]; }
-#pragma unroll
-        for (int t = 0; t < CW_RPW; t++) {
-          if (is_rhs[t]) {
-            if (!last && lane < NB) {                            // k_chol_la's rhs role: sequential mul / add, then one subtraction
-              const double* z = s_z + (j & 1) * NB;
-              double sum = 0.0;
-#pragma unroll
-              for (int m = 0; m < NB; m++) sum += s_B[lane][m] * z[m];
-              zc -= sum;
-            }
-          } else if (is_diag[t] || (is_row[t] && !last)) {       // chol_syrk_body: eight k-steps from zero, then C - acc
-            double4_t acc[2][2];
-#pragma unroll
-            for (int I = 0; I < 2; I++)
-#pragma unroll
-              for (int J = 0; J < 2; J++) acc[I][J] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-              const double a0 = is_diag[t] ? b0[ks] : Gc.A[t][ks], a1 = is_diag[t] ? b1[ks] : Gc.A[t][8 + ks];
-              acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[ks], acc[0][0], 0, 0, 0);
-              acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1[ks], acc[0][1], 0, 0, 0);
-              acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0[ks], acc[1][0], 0, 0, 0);
-              acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[ks], acc[1][1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int I = 0; I < 2; I++)
-#pragma unroll
-              for (int J = 0; J < 2; J++)
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++) T[t][I][J][rg] = T[t][I][J][rg] - acc[I][J][rg];
-          }
-        }
-      };
-      if (c > 0) issue(0, G0);
-      CHOL_STAMP(0);                                             // T requested, first loads issued
-      for (int j = 0; j < c; j += 2) {
-        step(j, G0, G1);
-        if (j + 1 < c) step(j + 1, G1, G0);
-      }
-      CHOL_STAMP(1);                                             // the update steps
-      // (after the loop: P = L(c, c-1) is in LDS buffer (c - 1) & 1, this wave's L(i, c-1) in set (c - 1) & 1, z(c-1) in s_z)
-      const double (*s_P)[NB + 1] = (const double (*)[NB + 1])(s_dyn + ((c - 1) & 1) * CW_TILE);
-      // ---- T goes from the C layout of its updates to the A-operand layout through the slot's scratch tile (the step kernels make
-      // the same trip through global memory); the tile's last update rides on the way (k_chol_la's apply_prev: the registers are
-      // rows of the C tiles of A^T).  a[t][I][ks]: rows 16 I .. of T', operand layout.
-      double a[CW_RPW][2][8];
-      const int lset = upd ? (c - 1) & 1 : 0;
-#pragma unroll
-      for (int t = 0; t < CW_RPW; t++) {
-        double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (CW_RPW == 1 ? (w == 0 ? 3 + NSCA : 1 + w) : 2 + CW_RPW * w + t) * CW_TILE);
-#pragma unroll
-        for (int I = 0; I < 2; I++)
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) a[t][I][ks] = 0.0;
-        if (valid[t] && !is_diag[t]) {
-          double ap[2][8];
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-              double v = 0.0;
-              if (upd) {
-                if (!is_rhs[t]) v = -(lset == 0 ? G0.A[t][8 * I + ks] : G1.A[t][8 * I + ks]);
-                else if (I == 0 && li == 0) v = -s_z[((c - 1) & 1) * NB + 4 * ks + lk];
-              }
-              ap[I][ks] = v;
-            }
-          if (is_rhs[t]) { if (lane < NB) s_Sw[0][lane] = zc; }
-          else {
-#pragma unroll
-            for (int I = 0; I < 2; I++)
-#pragma unroll
-              for (int J = 0; J < 2; J++)
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++) s_Sw[16 * I + lk + 4 * rg][16 * J + li] = T[t][I][J][rg];
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-              double v = 0.0;
-              if (!is_rhs[t]) v = s_Sw[16 * I + li][4 * ks + lk]; else if (I == 0 && li == 0) v = s_Sw[0][4 * ks + lk];
-              a[t][I][ks] = v;
-            }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-          if (upd) {
-#pragma unroll
-            for (int I = 0; I < 2; I++) {
-              if (is_rhs[t] && I == 1) break;
-#pragma unroll
-              for (int q = 0; q < 2; q++) {
-                double4_t acc = {a[t][I][4 * q], a[t][I][4 * q + 1], a[t][I][4 * q + 2], a[t][I][4 * q + 3]};
-#pragma unroll
-                for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * q + li][4 * ks + lk], ap[I][ks], acc, 0, 0, 0);
-                a[t][I][4 * q] = acc[0]; a[t][I][4 * q + 1] = acc[1]; a[t][I][4 * q + 2] = acc[2]; a[t][I][4 * q + 3] = acc[3];
-              }
-            }
-          }
-        }
-      }
-      CHOL_STAMP(2);                                             // layout change + last update
-      // ---- the diagonal tile of this column: factor + inverse (first group only).  Nothing of the rows is kept in registers
-      // across the factor: T' waits in the scratch tiles, in the layout it is read back in.
-      if (g0 == 0) {
-        if (w == 0) {
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-#pragma unroll
-            for (int J = 0; J < 2; J++)
-#pragma unroll
-              for (int rg = 0; rg < 4; rg++) {
-                const int r = 16 * I + lk + 4 * rg, cc = 16 * J + li;
-                s_L[r][cc] = (cc <= r) ? T[0][I][J][rg] : 0.0;
-              }
-        }
-#pragma unroll
-        for (int t = 0; t < CW_RPW; t++) {
-          double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (CW_RPW == 1 ? (w == 0 ? 3 + NSCA : 1 + w) : 2 + CW_RPW * w + t) * CW_TILE);
-          if (valid[t] && !is_diag[t]) {
-#pragma unroll
-            for (int I = 0; I < 2; I++)
-#pragma unroll
-              for (int ks = 0; ks < 8; ks++) s_Sw[16 * I + li][4 * ks + lk] = a[t][I][ks];
-          }
-        }
-        __syncthreads();
-#ifndef CW_EXP_NOFACTOR
-        if (w < 2) {
-          const int fail = diag_factor_invert_2w(s_L, s_X, s_T, &s_col, 16 * c, w);
-          if (fail && lane == 0) s_fail = 1;
-        }
-#else
-        for (int i = tid; i < NB * NB; i += CW_TPB) s_X[i / NB][i % NB] = (i / NB == i % NB) ? 1.0 : 0.0;
-#endif
-        __syncthreads();
-        if (s_fail) { if (tid == 0) st->chol_fail = 1; return; }
-        double* Di = D.Dinv + (size_t)c * NB * NB;
-        for (int i = tid; i < NB * NB; i += CW_TPB) Di[i] = s_X[i / NB][i % NB];
-#pragma unroll
-        for (int t = 0; t < CW_RPW; t++) {
-          double (*s_Sw)[NB + 1] = (double (*)[NB + 1])(s_dyn + (CW_RPW == 1 ? (w == 0 ? 3 + NSCA : 1 + w) : 2 + CW_RPW * w + t) * CW_TILE);
-          const bool back = valid[t] && !is_diag[t];              // (assigned on every path: nothing is live across the factor)
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) a[t][I][ks] = back ? s_Sw[16 * I + li][4 * ks + lk] : 0.0;
-        }
-      }
-      CHOL_STAMP(3);                                             // factor + inverse (first group)
-      // ---- L(i, c) = T' X_c^T
-#pragma unroll
-      for (int t = 0; t < CW_RPW; t++) {
-        if (!(valid[t] && !is_diag[t])) continue;
-        const size_t rb = (size_t)my[t] * NB;
-#pragma unroll
-        for (int I = 0; I < 2; I++) {
-          if (is_rhs[t] && I == 1) break;                        // (one row)
-          double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][I][ks], s_X[li][4 * ks + lk], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][I][ks], s_X[16 + li][4 * ks + lk], acc1, 0, 0, 0);
-          }
-          if (is_rhs[t]) {
-            if (lk == 0) { zrow[cb + li] = acc0[0]; zrow[cb + 16 + li] = acc1[0]; }
-          } else {
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-              const size_t orow = rb + 16 * I + lk + 4 * rg;
-              S[orow * np + cb + li] = acc0[rg];
-              S[orow * np + cb + 16 + li] = acc1[rg];
-            }
-          }
-        }
-      }
-      __syncthreads();                                           // (the LDS buffers and s_z are free for the next group; this group's L tiles are visible)
-      CHOL_STAMP(4);                                             // L = T' X^T, stores, barrier
-    }
-  }
-}
-
-// ---- persistent look-ahead Cholesky: ONE launch for the whole factorisation of a reduced system <= 1024 -------------------
-// k_chol_la is one launch per 32-column step, and a step's kernel spends 2.5 of its 10.8 us waiting for its first loads and
-// ~1 us outside the kernel (profiles/r02_chol_phase_prof_fused.json): the chain of 19 (C4) steps is launch- and
-// load-latency on top of the 5.1 us diagonal factor.  Here the steps are iterations of a loop inside ONE kernel and the
-// dependencies between workgroups are flags in global memory (tools/ubench/flag_hop.hip: a flag + 8 KB hand-off between two
-// workgroups costs 1.1 - 1.4 us with agent-scope (sc1) data accesses, 2.7 - 3.6 us with __threadfence on both sides, so every
-// access to data another workgroup wrote or will read is an agent-scope relaxed atomic and no fence is used):
-//   workgroup 0, the CHAIN: all diagonal blocks and the sub-diagonal tile of every step.  Per step k: wave 0 factors and
-//     inverts D_k; meanwhile waves 1..3 wait for row k+1 to be final and stage its three tiles; then M_k = X_k P_k,
-//     L(k+1,k) = A(k+1,k) X_k^T - L(k+1,k-1) M_k^T, D_(k+1) = A(k+1,k+1) - L(k+1,k) L(k+1,k)^T in LDS - the chain never waits
-//     for a kernel boundary or for its own stores - and X_k, M_k, L(k+1,k) are published (flag XREADY = k + 1);
-//   ROW i (2 <= i < nb), its PRODUCER: for j = 0 .. i - 2: waits for X_j / M_j, L(i,j) = A(i,j) X_j^T - L(i,j-1) M_j^T, flag
-//     LREADY[i] = j + 1; in its last step also the row's diagonal tile, flag FINAL[i];
-//   ROW i, its ceil((i-1)/8) CONSUMERS: update j of their tiles (i, c), c = j + 2 .. i, with L(i,j) and L(c,j) of the rows above:
-//     all flags of the step, then all loads of the step, then the MFMAs; flag PROG[i][share] = j + 1;
-//   the last workgroup, the augmented rhs ROW: the same with one row, to the last block (forward substitution).
-// The ARITHMETIC is k_chol_la's, operation for operation (tile (i,c) receives the updates 0 .. c-2 one by one as cpre - acc of
-// eight MFMA k-steps, the last one algebraically through M; the rhs row's updates are the same sequential mul / add), so the
-// results are bit-identical to the launch-per-step kernels (tests/test_gpu_ba.py::test_persistent_cholesky_is_bit_identical)
-// and batched solves (k_chol_la<4>, throughput-bound) stay bit-identical to single calls.
-// Residency: rows and consumers wait for workgroups with a smaller blockIdx.x, but the CHAIN (blockIdx.x 0) waits for
-// FINAL[k + 1] of rows with LARGER indices - progress needs the chain and the rows it waits for to be co-resident.  The host
-// therefore accounts the persistent launches of this process in workgroup slots (PersistLease) and falls back to the step
-// kernels when a solve does not get its slots; kernels of OTHER streams / processes can still delay a row's dispatch, which is
-// what the time bound of cp_wait is for: a wait that runs out ends the solve with termination 7 / ORBHIP_ETIMEOUT (never as a
-// rejected LM step), a failed pivot raises FAIL = 1; either ends every other wait at once.
-#define CP_XREADY 0
-#define CP_FAIL 1
-#define CP_LREADY 2
-#define CP_FINAL 40
-#define CP_PROG 80                 // [CP_PROG + 4 * row + share]: steps this share of the row has completed
-#define CP_NFLAGS 256
-#define CP_CH 8                    // tiles a row workgroup updates per step (their operands wait in registers together)
-#define CP_SPIN_CAP (1 << 21)      /* polls of the waves of ONE workgroup waiting for each other (LDS counters): never long */
-#define CP_LDS_DOUBLES ((1 + CP_CH) * NB * (NB + 1))      /* a consumer: L(i,j) + CP_CH operand tiles; the chain: 6 tiles + the factor's column buffer */
-__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Every wait is bounded - by TIME (s_memrealtime, 100 MHz), not by a spin count: the workgroup waited for may simply not be
-// resident yet when another stream's kernels hold the CUs.  Five seconds is far beyond any such delay and still ends a genuine
-// hang.  A wait that runs out of time is NOT a failed pivot: CP_FAIL takes the value 2 (a failed pivot: 1; either ends every
-// other wait at once), BaState::chol_fail becomes 2, k_ba_iter_end ends the solve with termination 7 and the entry point
-// returns ORBHIP_ETIMEOUT with the last accepted iterate - the LM radius is not touched.
-// g_cp_wait_ticks: the limit in 10-ns ticks; ba_test_set_wait_ticks() shrinks it so that tests can force the timeout path.
-__device__ unsigned long long g_cp_wait_ticks = 500000000ull;
-__device__ __forceinline__ void cp_timeout(int* flags) { __hip_atomic_fetch_max(flags + CP_FAIL, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool cp_wait(int* flags, int which, int v) {
-  if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) { HANDOFF_ACQUIRE(); return true; }
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  const unsigned long long limit = g_cp_wait_ticks;
-  for (unsigned it = 0;; it++) {
-    if (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) { HANDOFF_ACQUIRE(); return true; }
-    if ((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    if ((it & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > limit) { cp_timeout(flags); return false; }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-__device__ __forceinline__ void cp_set(int* flags, int which, int v) { __hip_atomic_store(flags + which, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// a workgroup gives up (its own failed pivot, or a wait that returned false): the reason is 1 unless somebody's wait timed out
-__device__ __forceinline__ void cp_die(BaState* st, int* flags) {
-  const int seen = __hip_atomic_fetch_max(flags + CP_FAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_max(&st->chol_fail, seen > 1 ? seen : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(256) void k_chol_persist(const BaDev* __restrict__ Dv) {
-  const BaDev D = Dv[blockIdx.y];
-  if (!D.chol_la) return;
-  BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid || F.chol_fail) return;
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  const int np = D.npad, nb = np / NB, tid = threadIdx.x, bx = (int)blockIdx.x;
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int ti = w >> 1, tj = w & 1;
-  double* S = D.S;
-  double* Dinv = D.Dinv;
-  int* flags = D.cflags;
-  if (bx == 0) {
-    // ------------------------------------------------------------------------------------------------ the chain
-    double (*s_L)[NB + 1] = (double (*)[NB + 1])s_dyn;                                  // D_k
-    double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));                // X_k = L_kk^-1
-    double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));            // P_k = L(k, k-1); after the L phase L(k+1, k)
-    double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));           // A(k+1, k), updates 0 .. k-2 applied
-    double (*s_Lp)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));           // L(k+1, k-1)
-    double* s_share = s_dyn + 5 * NB * (NB + 1);                                        // wave 1 -> wave 0: the updated rows 0..15 of A(k+1, k) [lane][8]
-    double (*s_T)[64] = (double (*)[64])(s_dyn + 6 * NB * (NB + 1));                    // 16-byte aligned: 6 * 32 * 33 * 8 bytes
-    __shared__ int s_fail, s_arrive, s_arrive2, s_grp;
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(size_t)r * np + c] : 0.0; }
-    if (tid == 0) { s_fail = 0; s_arrive = 0; s_arrive2 = 0; s_grp = 0; }
-    // waves 1..3 own the lower 16x16 tiles of the NEXT diagonal block: (0,0), (1,0), (1,1)
-    const int di = (w == 1) ? 0 : 1, dj = (w == 3) ? 1 : 0;
-    const int ai = (w <= 1) ? 0 : 1;                            // the 16 rows of A(k+1, k) this wave multiplies: waves 0, 1 the upper, 2, 3 the lower
-    int n_grp = 0;
-    __syncthreads();
-    for (int k = 0; k < nb; k++) {
-      const bool upd = k > 0, next = k + 1 < nb;
-      CHOL_PROF_BEGIN(k);
-      double c2[4] = {0.0, 0.0, 0.0, 0.0};
-      double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (tid < 64) {
-        const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
-        if (fail && tid == 0) s_fail = 1;
-        CHOL_STAMP(0);                                          // factor + inverse
-      } else if (next) {
-        // stage row k + 1: its tile in column block k (updates 0 .. k-2 applied), L(k+1, k-1), and this wave's entries of its
-        // diagonal tile (updates 0 .. k-1 applied); then the tile's last update, A <- A - L(k+1, k-1) P_k^T, beside the factor
-        bool ok = true;
-        if (upd) ok = cp_wait(flags, CP_FINAL + k + 1, 1);
-        if (!ok) s_fail = 2;
-        const size_t rb = (size_t)(k + 1) * NB;
-        {
-          // (all twelve loads of a lane are requested before the first LDS store: the load -> store loop it used to be cost the
-          // staging waves six dependent global round trips per step, most of the chain's "stall")
-          double ta[6], tl[6];
-#pragma unroll
-          for (int u = 0; u < 6; u++) {
-            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
-            ta[u] = i < NB * NB ? ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]) : 0.0;
-            tl[u] = (upd && i < NB * NB) ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < 6; u++) {
-            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
-            if (i < NB * NB) { s_A1[r][c] = ta[u]; s_Lp[r][c] = tl[u]; }
-          }
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
-          c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
-        }
-        // the three staging waves meet (wave 0 is in the factor: no __syncthreads here)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        n_grp += 3;
-        if (lane == 0) __hip_atomic_fetch_add(&s_grp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int it = 0; it < CP_SPIN_CAP && __hip_atomic_load(&s_grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_grp; it++) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) a[ks] = s_A1[16 * ai + li][4 * ks + lk];
-        if (upd) {
-#pragma unroll
-          for (int t = 0; t < 2; t++) {                         // (k_chol_la's apply_prev: the registers are rows of the C tiles of A^T)
-            double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], -s_Lp[16 * ai + li][4 * ks + lk], acc, 0, 0, 0);
-            a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-          }
-        }
-        if (w == 1) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) s_share[lane * 8 + ks] = a[ks];
-        }
-      }
-      __syncthreads();
-      CHOL_STAMP(1);                                            // barrier: what the staging waves are late by
-      if (s_fail) { if (tid == 0) cp_die(st, flags); return; }
-      {
-        double* Di = Dinv + (size_t)k * NB * NB;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; st_sc1(&Di[i], s_X[i / NB][i % NB]); }
-      }
-      CHOL_STAMP(2);                                            // X stores issued
-      if (next) {
-        if (w == 0) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) a[ks] = s_share[lane * 8 + ks];
-        }
-        // L(k+1, k) = A' X^T on the matrix cores: the new P
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], s_X[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
-        const size_t rb = (size_t)(k + 1) * NB;
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
-        // X_k has left (its stores were issued before the MFMAs above): the last wave to see that publishes it - the row
-        // producers start on step k a microsecond before the chain is through with it
-        HANDOFF_DRAIN();
-        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_XREADY, k + 1);
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
-        __syncthreads();
-        CHOL_STAMP(3);                                          // L(k+1, k)
-        if (w >= 1) {                                           // D_(k+1) = A(k+1,k+1) - P P^T on the lower tiles
-          double4_t a2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * di + li][4 * ks + lk], s_P[16 * dj + li][4 * ks + lk], a2, 0, 0, 0);
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
-            if (c <= r) s_L[r][c] = c2[rg] - a2[rg];
-          }
-        }
-        // L(k+1, k) has left: it is the P the row producers need for their step k + 1
-        HANDOFF_DRAIN();
-        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * k + 3) cp_set(flags, CP_LREADY + k + 1, k + 1);
-      }
-      CHOL_STAMP(4);                                            // D update
-      if (!next) {                                              // the last step: X is published here
-        HANDOFF_DRAIN();
-        __syncthreads();
-        if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
-      }
-      __syncthreads();
-      CHOL_STAMP(5);                                            // barrier
-    }
-    return;
-  }
-  // -------------------------------------------------------------------------------------------------- a row
-  // workgroups behind the chain, row by row (i = 2 .. nb - 1, then the rhs row nb): one PRODUCER - L(i, j) for every step - and
-  // W_i = ceil((i - 1) / CP_CH) CONSUMERS - share g applies update j to the tiles (i, c), c % W_i == g, at most CP_CH per step.
-  // Two short pipelines instead of one long step: a row keeps up with the chain when each stage fits a chain step.
-  int irow = -1, share = -1, W = 1;                             // share -1: the producer
-  bool is_rhs = false;
-  {
-    int b = 1;
-    for (int i = 2; i < nb && irow < 0; i++) {
-      const int wi = (i - 1 + CP_CH - 1) / CP_CH;
-      if (bx < b + 1 + wi) { irow = i; share = bx - b - 1; W = wi; }
-      b += 1 + wi;
-    }
-    if (irow < 0) { if (bx == b || bx == b + 1) { irow = nb; is_rhs = true; share = bx - b - 1; } else return; }
-  }
-  const size_t r0 = is_rhs ? (size_t)np : (size_t)irow * NB;
-  double (*s_Lc)[NB + 1] = (double (*)[NB + 1])s_dyn;           // L(i, j) of the current step
-  double (*s_Lq)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));      // L(i, j-1)
-  __shared__ int s_dead;
-  if (tid == 0) s_dead = 0;
-  __syncthreads();
-  if (share < 0) {
-    // ---- producer: L(i, j) = A(i, j) X_j^T - L(i, j-1) M_j^T; in its last step (j = i - 2) also the row's diagonal tile
-    const int jend = is_rhs ? nb : irow - 1;
-    const int arow = 16 * ti + li;                              // this lane's row of the A operand
-    double (*s_A)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
-    double (*s_Xj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
-    double (*s_Mj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
-    for (int j = 0; j < jend; j++) {
-      const bool upd = j > 0, last = !is_rhs && j == jend - 1;
-      // before X_j exists: the tile (i, j) with its last update, A' = A - L(i, j-1) P_j^T (P_j = L(j, j-1), the chain's tile of
-      // the previous step); all its inputs are one chain step old
-      bool ok = true;
-      if (j >= 2) ok = cp_wait(flags, CP_PROG + 4 * irow + (j % W), j - 1);                // tile (i, j) has its update j - 2
-      if (ok && last && j >= 1) ok = cp_wait(flags, CP_PROG + 4 * irow + (irow % W), j);   // the diagonal tile has update j - 1
-      if (ok && last && j >= 1) ok = cp_wait(flags, CP_PROG + 4 * irow + ((irow - 1) % W), j);   // ... and tile (i, i-1), which FINAL hands to the chain (another share's when W > 1: it finished a chain step ago, but only a flag says so)
-      if (ok && upd) ok = cp_wait(flags, CP_LREADY + j, j);                                // P_j is published
-      double va[4], vp[4], cd[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int idx = tid + 256 * u, r = idx / NB, c = idx % NB;
-        va[u] = (ok && (is_rhs ? r == 0 : true)) ? ld_sc1(&S[(r0 + r) * np + (size_t)j * NB + c]) : 0.0;
-        vp[u] = (ok && upd) ? ld_sc1(&S[((size_t)j * NB + r) * np + (size_t)(j - 1) * NB + c]) : 0.0;
-      }
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) cd[rg] = (ok && last) ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + r0 + 16 * tj + (lane & 15)]) : 0.0;
-#pragma unroll
-      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u, r = idx / NB, c = idx % NB; s_A[r][c] = va[u]; s_Mj[r][c] = vp[u]; }
-      __syncthreads();
-      double a[8], b[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) a[ks] = s_A[arow][4 * ks + lk];
-      if (upd) {
-#pragma unroll
-        for (int t = 0; t < 2; t++) {                           // (k_chol_la's apply_prev)
-          double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_Mj[16 * t + li][4 * ks + lk], -s_Lq[arow][4 * ks + lk], acc, 0, 0, 0);
-          a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-        }
-      }
-      // X_j: the only thing this step waits for on the chain
-      if (ok) ok = cp_wait(flags, CP_XREADY, j + 1);
-      double vx[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) vx[u] = ok ? ld_sc1(&Dinv[(size_t)j * NB * NB + tid + 256 * u]) : 0.0;
-#pragma unroll
-      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vx[u]; }
-      __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) b[ks] = s_Xj[16 * tj + li][4 * ks + lk];
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
-        s_Lc[r][c] = acc[rg];
-        if (ok && (is_rhs ? r == 0 : true)) st_sc1(&S[(r0 + r) * np + (size_t)j * NB + c], acc[rg]);
-      }
-      if (!ok) s_dead = 1;
-      if (last) {
-        __syncthreads();
-        double4_t u4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_Lc[16 * ti + li][4 * ks + lk], s_Lc[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = r0 + 16 * tj + (lane & 15);
-          if (ok && col <= row) st_sc1(&S[row * np + col], cd[rg] - u4[rg]);
-        }
-      }
-      HANDOFF_DRAIN();
-      __syncthreads();
-      if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-      if (tid == 0) { cp_set(flags, CP_LREADY + irow, j + 1); if (last) cp_set(flags, CP_FINAL + irow, 1); }
-      { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
-    }
-    return;
-  }
-  if (!is_rhs) {
-    // ---- consumer: update j of this share's tiles (i, c), c = j + 2 .. i: C = C - L(i,j) L(c,j)^T, one 16x16 tile of every 32x32
-    // tile per wave.  All flags of the step first (one lane per tile), then EVERY load of the step, then the matrix cores.
-    for (int j = 0; j + 3 <= irow; j++) {
-      const int c_first = j + 2 + ((share - (j + 2)) % W + W) % W;         // smallest c >= j + 2 with c % W == share
-      {
-        const int ct = lane < CP_CH ? c_first + lane * W : irow;            // lane CP_CH: this row's own L(i, j)
-        const bool mine = lane <= CP_CH && ct <= irow;
-        bool good = true;
-        const unsigned long long t0w = __builtin_amdgcn_s_memrealtime();
-        for (unsigned it = 0;; it++) {
-          const bool ready = !mine || __hip_atomic_load(flags + CP_LREADY + ct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= j + 1;
-          if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
-          if (((it & 7) == 7 && __hip_atomic_load(flags + CP_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ||
-              ((it & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0w > g_cp_wait_ticks && (cp_timeout(flags), true))) { good = false; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        HANDOFF_ACQUIRE();
-        if (!good) s_dead = 1;
-      }
-      // operand tiles as whole rows into LDS (see the producer); this lane's C entries directly (64 contiguous bytes per row)
-      double vl[4], vb[CP_CH][4], cpre[CP_CH][4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vl[u] = ld_sc1(&S[(r0 + idx / NB) * np + (size_t)j * NB + idx % NB]); }
-#pragma unroll
-      for (int t = 0; t < CP_CH; t++) {
-        const int c = c_first + t * W;
-        const size_t cb = (size_t)c * NB;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vb[t][u] = (c <= irow) ? ld_sc1(&S[(cb + idx / NB) * np + (size_t)j * NB + idx % NB]) : 0.0; }
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) cpre[t][rg] = (c <= irow) ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + cb + 16 * tj + (lane & 15)]) : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Lc[idx / NB][idx % NB] = vl[u]; }
-#pragma unroll
-      for (int t = 0; t < CP_CH; t++) {
-        double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + (1 + t) * NB * (NB + 1));
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_B[idx / NB][idx % NB] = vb[t][u]; }
-      }
-      __syncthreads();
-      double la[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) la[ks] = s_Lc[16 * ti + li][4 * ks + lk];
-#pragma unroll
-      for (int t = 0; t < CP_CH; t++) {
-        const int c = c_first + t * W;
-        if (c > irow) break;
-        const size_t cb = (size_t)c * NB;
-        const double (*s_B)[NB + 1] = (const double (*)[NB + 1])(s_dyn + (1 + t) * NB * (NB + 1));
-        double4_t u4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_B[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = cb + 16 * tj + (lane & 15);
-          if (col <= row) st_sc1(&S[row * np + col], cpre[t][rg] - u4[rg]);
-        }
-      }
-      HANDOFF_DRAIN();
-      __syncthreads();
-      if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-      if (tid == 0) cp_set(flags, CP_PROG + 4 * irow + share, j + 1);
-    }
-    return;
-  }
-  // ---- the rhs row's consumer: z_c -= sum_m L(c, 32 j + m) z_(32 j + m) for the columns from block j + 2 on (sequential mul / add
-  // per column, as k_chol_la's rhs role; the 32 loads of a column are in flight together)
-  double* zrow = S + (size_t)np * np;
-  double* s_z = &s_Lc[0][0];
-  for (int j = 0; j + 2 < nb; j++) {
-    bool ok = cp_wait(flags, CP_LREADY + nb, j + 1);
-    if (tid < NB) s_z[tid] = ok ? ld_sc1(&zrow[(size_t)j * NB + tid]) : 0.0;
-    __syncthreads();
-    for (int cc = (j + 2) * NB + tid; ok && cc < np; cc += 256) {
-      if (!cp_wait(flags, CP_LREADY + cc / NB, j + 1)) { ok = false; break; }
-      const double* L = S + (size_t)cc * np + (size_t)j * NB;
-      double lv[NB];
-#pragma unroll
-      for (int mm = 0; mm < NB; mm++) lv[mm] = ld_sc1(&L[mm]);
-      const double z0 = ld_sc1(&zrow[cc]);
-      double sum = 0.0;
-#pragma unroll
-      for (int mm = 0; mm < NB; mm++) sum += lv[mm] * s_z[mm];
-      st_sc1(&zrow[cc], z0 - sum);
-    }
-    if (!ok) s_dead = 1;
-    HANDOFF_DRAIN();
-    __syncthreads();
-    if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-    if (tid == 0) cp_set(flags, CP_PROG + 4 * nb, j + 1);
-  }
-}
-
-// ---- the same for the LARGE reduced systems (two-level scheme, GlobalBA): ONE persistent launch per 128-column outer block --
-// k_chol_la steps an outer block with one launch per 32-column step (panel + thin updates confined to the block + a share of
-// the previous block's K = 128 update); here the <= 4 steps of a block are a loop inside one launch, with the roles of
-// k_chol_persist reduced to what a block needs:
-//   workgroup 0, the CHAIN (as above; the first step of a block has no pending update - everything older came with the K = 128
-//     updates -, and the last one leaves the next diagonal block alone: that is the next launch's first load);
-//   one workgroup per block row below (row jb0 + 2 .. nb - 1, then the rhs row): L(i, j) for the steps of this block, and the
-//     thin updates of its tiles INSIDE the block (at most two per step), in the step kernels' order;
-//   behind them the workgroups of the previous outer block's K = 128 update (role C of k_chol_la: every tile once).
-// Flags carry ABSOLUTE step numbers and are never reset between the launches of a factorisation.  Arithmetic = the step
-// kernels' operation for operation: batched calls (>= 4 problems, k_chol_la) stay bit-identical to single ones.
-// chol_syrk_body's tile part with the next K stage's loads issued BEFORE the matrix-core loop of the current one: the persistent
-// kernels hold one workgroup per CU (the chain role's registers), so no other workgroup hides a stage's load latency.  Same
-// operations in the same order.
-__device__ __forceinline__ void chol_syrk_tile_pf(const BaDev& D, int ti, int tj, int kcol, int K, int lo, double (*s_A)[NB + 1], double (*s_B)[NB + 1]) {
-  const int np = D.npad, tid = threadIdx.x;
-  if (kcol + K > np) return;
-  double* S = D.S;
-  const int r0 = lo + ti * 64, c0 = lo + tj * 64;
-  if (r0 + 63 < c0 || r0 >= np || c0 >= np) return;
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int qr = (w >> 1) * 32, qc = (w & 1) * 32;
-  const bool qskip = (r0 + qr + 31 < c0 + qc);
-  double4_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  double va[8], vb[8], cpre[2][2][4];
-#pragma unroll
-  for (int u = 0; u < 8; u++) {
-    const int i = tid + 256 * u, r = i / NB, c = i % NB;
-    va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + c] : 0.0;
-    vb[u] = (c0 + r < np) ? S[(size_t)(c0 + r) * np + kcol + c] : 0.0;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
-        const int col = c0 + qc + 16 * j + (lane & 15);
-        cpre[i][j][rg] = (!qskip && row < np && col < np && col <= row) ? S[(size_t)row * np + col] : 0.0;
-      }
-  for (int k0 = 0; k0 < K; k0 += NB) {
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
-    __syncthreads();
-    if (k0 + NB < K) {
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = tid + 256 * u, r = i / NB, c = i % NB;
-        va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol + k0 + NB + c] : 0.0;
-        vb[u] = (c0 + r < np) ? S[(size_t)(c0 + r) * np + kcol + k0 + NB + c] : 0.0;
-      }
-    }
-    if (!qskip) {
-#pragma unroll
-      for (int kk = 0; kk < NB; kk += 4) {
-        double a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
-#pragma unroll
-        for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-  if (qskip) return;
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
-        const int col = c0 + qc + 16 * j + (lane & 15);
-        if (row < np && col < np && col <= row) S[(size_t)row * np + col] = cpre[i][j][rg] - acc[i][j][rg];
-      }
-}
-// ... and TWO vertically adjacent tiles (128 x 64) per item: the column operand of a K stage is loaded once for both, and the
-// fixed cost of an item (first loads, C tile, store) is spread over twice the matrix-core work.
-// (SC1: the operands and the C tiles were written / will be read by other workgroups of the SAME launch - agent-scope accesses.
-// Plain cached loads behind an agent-scope acquire fence were measured too: no faster)
-template <bool SC1>
-__device__ __forceinline__ void chol_syrk_tile2_pf(const BaDev& D, int ti2, int tj, int kcol, int K, int lo, double* s_raw) {
-  auto ldg = [](const double* q) -> double { if constexpr (SC1) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *q; };
-  const int np = D.npad, tid = threadIdx.x;
-  if (kcol + K > np) return;
-  double* S = D.S;
-  const int r0 = lo + ti2 * 128, c0 = lo + tj * 64;
-  if (r0 + 127 < c0 || r0 >= np || c0 >= np) return;
-  double (*s_A0)[NB + 1] = (double (*)[NB + 1])s_raw;
-  double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_raw + 64 * (NB + 1));
-  double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_raw + 128 * (NB + 1));
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int qr = (w >> 1) * 32, qc = (w & 1) * 32;
-  const bool live1 = r0 + 64 < np;                              // the lower tile exists
-  const bool skip0 = (r0 + qr + 31 < c0 + qc), skip1 = !live1 || (r0 + 64 + qr + 31 < c0 + qc);
-  double4_t acc[2][2][2];
-#pragma unroll
-  for (int h = 0; h < 2; h++)
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) acc[h][i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  double va0[8], va1[8], vb[8], cpre[2][2][2][4];
-  auto load_stage = [&](int kc) {
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = tid + 256 * u, r = i / NB, c = i % NB;
-      va0[u] = (r0 + r < np) ? ldg(&S[(size_t)(r0 + r) * np + kc + c]) : 0.0;
-      va1[u] = (r0 + 64 + r < np) ? ldg(&S[(size_t)(r0 + 64 + r) * np + kc + c]) : 0.0;
-      vb[u] = (c0 + r < np) ? ldg(&S[(size_t)(c0 + r) * np + kc + c]) : 0.0;
-    }
-  };
-  load_stage(kcol);
-#pragma unroll
-  for (int h = 0; h < 2; h++)
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const int row = r0 + 64 * h + qr + 16 * i + (lane >> 4) + 4 * rg;
-          const int col = c0 + qc + 16 * j + (lane & 15);
-          cpre[h][i][j][rg] = (!(h ? skip1 : skip0) && row < np && col < np && col <= row) ? ldg(&S[(size_t)row * np + col]) : 0.0;
-        }
-  for (int k0 = 0; k0 < K; k0 += NB) {
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A0[i / NB][i % NB] = va0[u]; s_A1[i / NB][i % NB] = va1[u]; s_B[i / NB][i % NB] = vb[u]; }
-    __syncthreads();
-    if (k0 + NB < K) load_stage(kcol + k0 + NB);
-#pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) {
-      double b[2];
-#pragma unroll
-      for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
-      if (!skip0) {
-        double a[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) a[i] = s_A0[qr + 16 * i + li][kk + lk];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[0][i][j], 0, 0, 0);
-      }
-      if (!skip1) {
-        double a[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) a[i] = s_A1[qr + 16 * i + li][kk + lk];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[1][i][j], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    if (h ? skip1 : skip0) continue;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const int row = r0 + 64 * h + qr + 16 * i + (lane >> 4) + 4 * rg;
-          const int col = c0 + qc + 16 * j + (lane & 15);
-          if (row < np && col < np && col <= row) { if constexpr (SC1) __hip_atomic_store(&S[(size_t)row * np + col], cpre[h][i][j][rg] - acc[h][i][j][rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S[(size_t)row * np + col] = cpre[h][i][j][rg] - acc[h][i][j][rg]; }
-        }
-  }
-}
-#define BP_LREADY 2
-struct BlkGeo { int jb0, ns, base, kend, nend, tcn, n_tiles_n, n_rhs_n, n_tiles_c, blk; };     // (blocks of NB; host values = the largest problem of the launch)
-// One 64 x 64 tile of the NEXT outer block's columns: the previous outer block's K = 128 update of it (role C's share, if any),
-// then THIS block's, stage by stage as its panels are published - two chol_syrk_body passes operation for operation (the
-// intermediate tile stays in registers), so that the next launch's chain finds its columns complete when this one ends.
-// While the panels of a stage are not published yet (all but the last stage: that one is the block's critical path) the workgroup
-// takes tiles of the previous block's far update from the launch's queue (steal() processes one and returns false when none is left).
-template <class Steal>
-__device__ __forceinline__ void chol_tile_next(const BaDev& D, int* flags, int r0, int c0, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns,
-                                               double (*s_A)[NB + 1], double (*s_B)[NB + 1], Steal steal) {
-  const int np = D.npad, nb = np / NB, tid = threadIdx.x;
-  if (r0 + 63 < c0 || r0 >= np || c0 >= c_hi) return;
-  double* S = D.S;
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int qr = (w >> 1) * 32, qc = (w & 1) * 32;
-  const bool qskip = (r0 + qr + 31 < c0 + qc);
-  double cpre[2][2][4];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
-        const int col = c0 + qc + 16 * j + (lane & 15);
-        cpre[i][j][rg] = (!qskip && row < np && col < c_hi && col <= row) ? S[(size_t)row * np + col] : 0.0;
-      }
-  double4_t acc[2][2];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  };
-  auto stage_mma = [&]() {
-    if (qskip) return;
-#pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) {
-      double a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; i++) a[i] = s_A[qr + 16 * i + li][kk + lk];
-#pragma unroll
-      for (int j = 0; j < 2; j++) b[j] = s_B[qc + 16 * j + li][kk + lk];
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  };
-  double va[8], vb[8];
-  if (has_prev) {
-    zero_acc();
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = tid + 256 * u, r = i / NB, c = i % NB;
-      va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol_prev + c] : 0.0;
-      vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol_prev + c] : 0.0;
-    }
-    for (int k0 = 0; k0 < k_prev; k0 += NB) {
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
-      __syncthreads();
-      if (k0 + NB < k_prev) {                                   // the next stage's loads fly during this stage's matrix-core loop
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int i = tid + 256 * u, r = i / NB, c = i % NB;
-          va[u] = (r0 + r < np) ? S[(size_t)(r0 + r) * np + kcol_prev + k0 + NB + c] : 0.0;
-          vb[u] = (c0 + r < c_hi) ? S[(size_t)(c0 + r) * np + kcol_prev + k0 + NB + c] : 0.0;
-        }
-      }
-      stage_mma();
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) cpre[i][j][rg] = cpre[i][j][rg] - acc[i][j][rg];
-  }
-  zero_acc();
-  const int rb0 = r0 / NB, cb0 = c0 / NB;
-  for (int q = 0; q < ns; q++) {
-    const int need = jb0 + q + 1;                               // L(x, jb0 + q) is published
-    while (q + 1 < ns) {
-      bool up = __hip_atomic_load(flags + BP_LREADY + rb0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need &&
-                __hip_atomic_load(flags + BP_LREADY + cb0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-      if (up && rb0 + 1 < nb) up = __hip_atomic_load(flags + BP_LREADY + rb0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-      if (up && cb0 + 1 < nb && (c0 + NB) < c_hi) up = __hip_atomic_load(flags + BP_LREADY + cb0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-      if (__syncthreads_and(up)) break;
-      if (!steal()) break;                                      // (nothing left to take: wait below)
-    }
-    bool ok = cp_wait(flags, BP_LREADY + rb0, need) && cp_wait(flags, BP_LREADY + cb0, need);
-    if (ok && rb0 + 1 < nb) ok = cp_wait(flags, BP_LREADY + rb0 + 1, need);
-    if (ok && cb0 + 1 < nb && (c0 + NB) < c_hi) ok = cp_wait(flags, BP_LREADY + cb0 + 1, need);
-    if (__syncthreads_count(!ok)) { if (tid == 0) cp_die(D.st, flags); return; }     // (failed pivot elsewhere, or a wait that ran out of time: recorded, nothing more to do)
-    const size_t kc = (size_t)(jb0 + q) * NB;
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = tid + 256 * u, r = i / NB, c = i % NB;
-      va[u] = (r0 + r < np) ? ld_sc1(&S[(size_t)(r0 + r) * np + kc + c]) : 0.0;
-      vb[u] = (c0 + r < c_hi) ? ld_sc1(&S[(size_t)(c0 + r) * np + kc + c]) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; s_A[i / NB][i % NB] = va[u]; s_B[i / NB][i % NB] = vb[u]; }
-    __syncthreads();
-    stage_mma();
-  }
-  if (qskip) return;
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int row = r0 + qr + 16 * i + (lane >> 4) + 4 * rg;
-        const int col = c0 + qc + 16 * j + (lane & 15);
-        if (row < np && col < c_hi && col <= row) S[(size_t)row * np + col] = cpre[i][j][rg] - acc[i][j][rg];
-      }
-}
-// the augmented rhs row's entries of the next outer block's columns, the same two updates (sequential mul / add per column)
-__device__ __forceinline__ void chol_rhs_next(const BaDev& D, int* flags, int c, int c_hi, bool has_prev, int kcol_prev, int k_prev, int jb0, int ns, double* s_z) {
-  const int np = D.npad, nb = np / NB, tid = threadIdx.x;
-  double* S = D.S;
-  double* zrow = S + (size_t)np * np;
-  const bool mine = c < c_hi;
-  double zv = mine ? zrow[c] : 0.0;
-  if (has_prev) {
-    for (int i = tid; i < k_prev; i += 256) s_z[i] = zrow[kcol_prev + i];
-    __syncthreads();
-    if (mine) {
-      const double* L = S + (size_t)c * np + kcol_prev;
-      double sum = 0.0;
-      for (int m = 0; m < k_prev; m++) sum += L[m] * s_z[m];
-      zv -= sum;
-    }
-  }
-  const int kend = jb0 + ns, K = ns * NB;
-  bool ok = cp_wait(flags, BP_LREADY + nb, kend);               // the row's own entries of this block
-  if (ok && mine) ok = cp_wait(flags, BP_LREADY + c / NB, kend);
-  if (__syncthreads_count(!ok)) { if (tid == 0) cp_die(D.st, flags); return; }
-  for (int i = tid; i < K; i += 256) s_z[i] = ld_sc1(&zrow[(size_t)jb0 * NB + i]);
-  __syncthreads();
-  if (mine) {
-    const double* L = S + (size_t)c * np + (size_t)jb0 * NB;
-    double sum = 0.0;
-    for (int m = 0; m < K; m++) sum += ld_sc1(&L[m]) * s_z[m];
-    zrow[c] = zv - sum;
-  }
-}
-__global__ __launch_bounds__(256) void k_chol_persist_blk(const BaDev* __restrict__ Dv, BlkGeo geo, CholWide wd) {
-  const int jb0 = geo.jb0, ns = geo.ns, rolec_base = geo.base;
-  const BaDev D = Dv[blockIdx.y];
-  if (D.chol_la) return;
-  BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid || F.chol_fail) return;
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  const int np = D.npad, nb = np / NB, tid = threadIdx.x, bx = (int)blockIdx.x;
-  if (jb0 >= nb) return;
-  const int kend = min(jb0 + ns, nb);                           // steps jb0 .. kend - 1; thin updates touch the column blocks < kend
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int ti = w >> 1, tj = w & 1;
-  double* S = D.S;
-  double* Dinv = D.Dinv;
-  int* flags = D.cflags;
-  const int R = nb + 2;
-  const int FIN = BP_LREADY + R;                                // FINAL flags behind the LREADY flags
-  if (bx >= rolec_base) {
-    // ---- the previous outer block's K = 128 update of everything right of this block (role C of k_chol_la)
-    double (*s_A)[NB + 1] = (double (*)[NB + 1])s_dyn;
-    double (*s_B)[NB + 1] = (double (*)[NB + 1])(s_dyn + 64 * (NB + 1));
-    // ---- the pool: the owners of the next outer block's tiles, and whoever else fits on the device.  The rest of the previous
-    // block's K = 128 update (the columns right of the next outer block; every tile once, any order) is a QUEUE all of them draw
-    // from - the owners while their panels are not published yet, everybody until it is empty: with one workgroup per CU (the
-    // chain role's registers) a workgroup that only spins is a CU that does nothing.
-    const int wi = bx - rolec_base;
-    const bool has_prev = wd.total > 0;
-    const int c_hi_n = min(geo.nend * NB, np);
-    const int tcr = wd.tiles_c - geo.tcn;
-    const int n_items = has_prev ? (tcr > 0 ? geo.n_tiles_c : 0) + wd.nrhs : 0, n_tile_items = has_prev && tcr > 0 ? geo.n_tiles_c : 0;
-    int* qctr = flags + BP_LREADY + 2 * R + geo.blk;              // this launch's queue head (zeroed with the flags; one per outer block, blk < nb)
-    __shared__ int s_item;
-    auto steal = [&]() -> bool {
-      if (n_items <= 0) return false;
-      __syncthreads();
-      if (tid == 0) s_item = __hip_atomic_fetch_add(qctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const int it = s_item;
-      if (it >= n_items) return false;
-      if (it < n_tile_items) { const int ti_c = it / tcr, tj_c = geo.tcn + (it - ti_c * tcr); chol_syrk_tile2_pf<false>(D, ti_c, tj_c, wd.kcol, wd.K, wd.lo, s_dyn); }
-      else chol_syrk_body(D, st, wd.total + (it - n_tile_items), wd.kcol, wd.K, wd.lo, wd.lo, INT_MAX, wd.tiles_c, wd.total, s_A, s_B, geo.n_tiles_n > 0 ? geo.nend * NB : 0);
-      return true;
-    };
-    if (geo.kend == kend) {                                     // (else a smaller problem of the launch: this is its last block)
-      if (wi < geo.n_tiles_n) {                                 // the next outer block's columns: the previous block's update, then this one's
-        const int ti_n = wi / geo.tcn, tj_n = wi - ti_n * geo.tcn;
-        chol_tile_next(D, flags, geo.kend * NB + 64 * ti_n, geo.kend * NB + 64 * tj_n, c_hi_n, has_prev, wd.kcol, wd.K, jb0, ns, s_A, s_B, steal);
-      } else if (wi < geo.n_tiles_n + geo.n_rhs_n) {
-        __syncthreads();
-        chol_rhs_next(D, flags, geo.kend * NB + 256 * (wi - geo.n_tiles_n) + tid, c_hi_n, has_prev, wd.kcol, wd.K, jb0, ns, &s_A[0][0]);
-      }
-    }
-    while (steal()) {}
-    return;
-  }
-  if (bx == 0) {
-    // ------------------------------------------------------------------------------------------------ the chain
-    double (*s_L)[NB + 1] = (double (*)[NB + 1])s_dyn;
-    double (*s_X)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
-    double (*s_P)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
-    double (*s_A1)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
-    double (*s_Lp)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
-    double* s_share = s_dyn + 5 * NB * (NB + 1);
-    double (*s_T)[64] = (double (*)[64])(s_dyn + 6 * NB * (NB + 1));
-    __shared__ int s_fail, s_arrive, s_arrive2, s_grp;
-    {
-      const size_t d0 = (size_t)jb0 * NB;
-#pragma unroll
-      for (int u = 0; u < 4; u++) { const int i = tid + 256 * u, r = i / NB, c = i % NB; s_L[r][c] = (c <= r) ? S[(d0 + r) * np + d0 + c] : 0.0; }
-    }
-    if (tid == 0) { s_fail = 0; s_arrive = 0; s_arrive2 = 0; s_grp = 0; }
-    const int di = (w == 1) ? 0 : 1, dj = (w == 3) ? 1 : 0;
-    const int ai = (w <= 1) ? 0 : 1;
-    int n_grp = 0;
-    __syncthreads();
-    for (int k = jb0; k < kend; k++) {
-      const bool upd = k > jb0, next = k + 1 < nb, nextD = next && k + 1 < kend;
-      const int kr = k - jb0;
-      CHOL_PROF_BEGIN(k);
-      double c2[4] = {0.0, 0.0, 0.0, 0.0};
-      double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (tid < 64) {
-        const int fail = diag_factor_invert_wave(s_L, s_X, s_T);
-        if (fail && tid == 0) s_fail = 1;
-        CHOL_STAMP(0);                                          // factor + inverse
-      } else if (next) {
-        // Row k + 1 is needed in two instalments: its tiles (k+1, k) and L(k+1, k-1) for the update beside the factor - final as
-        // soon as the row has PUBLISHED L(k+1, k-1) (the thin updates of tile (k+1, k) belong to earlier steps) -, its diagonal
-        // tile only behind the factor.  The row finishes that tile (its last thin update: a load, eight MFMAs, a store) 2 - 3 us
-        // after the publication; waiting for everything at once put that on the chain (9.1 -> 7.9 us per step).
-        bool ok = true;
-        if (upd) ok = cp_wait(flags, BP_LREADY + k + 1, k);
-        const size_t rb = (size_t)(k + 1) * NB;
-        {
-          // (all twelve loads of a lane are requested before the first LDS store: the load -> store loop it used to be cost the
-          // staging waves six dependent global round trips per step, most of the chain's "stall")
-          double ta[6], tl[6];
-#pragma unroll
-          for (int u = 0; u < 6; u++) {
-            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
-            ta[u] = i < NB * NB ? ld_sc1(&S[(rb + r) * np + (size_t)k * NB + c]) : 0.0;
-            tl[u] = (upd && i < NB * NB) ? ld_sc1(&S[(rb + r) * np + (size_t)(k - 1) * NB + c]) : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < 6; u++) {
-            const int i = tid - 64 + 192 * u, r = i / NB, c = i % NB;
-            if (i < NB * NB) { s_A1[r][c] = ta[u]; s_Lp[r][c] = tl[u]; }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        n_grp += 3;
-        if (lane == 0) __hip_atomic_fetch_add(&s_grp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int it = 0; it < CP_SPIN_CAP && __hip_atomic_load(&s_grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_grp; it++) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) a[ks] = s_A1[16 * ai + li][4 * ks + lk];
-        if (upd) {
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * t + li][4 * ks + lk], -s_Lp[16 * ai + li][4 * ks + lk], acc, 0, 0, 0);
-            a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-          }
-        }
-        if (w == 1) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) s_share[lane * 8 + ks] = a[ks];
-        }
-        if (nextD) {                                            // the diagonal tile of row k + 1, behind the row's last thin update
-          if (upd && ok) ok = cp_wait(flags, FIN + k + 1, 1);
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
-            c2[rg] = (c <= r) ? ld_sc1(&S[(rb + r) * np + rb + c]) : 0.0;
-          }
-        }
-        if (!ok) s_fail = 2;
-      }
-      __syncthreads();
-      CHOL_STAMP(1);                                            // barrier: what the staging waves are late by
-      if (s_fail) { if (tid == 0) cp_die(st, flags); return; }
-      {
-        double* Di = Dinv + (size_t)k * NB * NB;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = tid + 256 * u; st_sc1(&Di[i], s_X[i / NB][i % NB]); }
-      }
-      CHOL_STAMP(2);                                            // X stores issued
-      if (next) {
-        if (w == 0) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) a[ks] = s_share[lane * 8 + ks];
-        }
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], s_X[16 * tj + li][4 * ks + lk], acc, 0, 0, 0);
-        const size_t rb = (size_t)(k + 1) * NB;
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) s_P[16 * ti + (lane >> 4) + 4 * rg][16 * tj + (lane & 15)] = acc[rg];
-        HANDOFF_DRAIN();
-        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * kr + 3) cp_set(flags, CP_XREADY, k + 1);
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) st_sc1(&S[(rb + 16 * ti + (lane >> 4) + 4 * rg) * np + (size_t)k * NB + 16 * tj + (lane & 15)], acc[rg]);
-        __syncthreads();
-        CHOL_STAMP(3);                                          // L(k+1, k) + publication of X
-        if (w >= 1 && nextD) {
-          double4_t a2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s_P[16 * di + li][4 * ks + lk], s_P[16 * dj + li][4 * ks + lk], a2, 0, 0, 0);
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const int r = 16 * di + (lane >> 4) + 4 * rg, c = 16 * dj + (lane & 15);
-            if (c <= r) s_L[r][c] = c2[rg] - a2[rg];
-          }
-        }
-        HANDOFF_DRAIN();
-        if (lane == 0 && __hip_atomic_fetch_add(&s_arrive2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 4 * kr + 3) cp_set(flags, BP_LREADY + k + 1, k + 1);
-        CHOL_STAMP(4);                                          // D update + publication of L
-      }
-      if (!next) {
-        HANDOFF_DRAIN();
-        __syncthreads();
-        if (tid == 0) cp_set(flags, CP_XREADY, k + 1);
-      }
-      __syncthreads();
-      CHOL_STAMP(5);                                            // barrier
-    }
-    return;
-  }
-  // -------------------------------------------------------------------------------------------------- a row
-  const int nrow = max(nb - (jb0 + 2), 0);
-  int irow; bool is_rhs = false;
-  if (bx <= nrow) irow = jb0 + 1 + bx;                          // bx 1 -> row jb0 + 2
-  else if (bx == nrow + 1) { irow = nb; is_rhs = true; }
-  else return;
-  const size_t r0 = is_rhs ? (size_t)np : (size_t)irow * NB;
-  double (*s_Lc)[NB + 1] = (double (*)[NB + 1])s_dyn;
-  double (*s_Lq)[NB + 1] = (double (*)[NB + 1])(s_dyn + NB * (NB + 1));
-  double (*s_A)[NB + 1] = (double (*)[NB + 1])(s_dyn + 2 * NB * (NB + 1));
-  double (*s_Xj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 3 * NB * (NB + 1));
-  double (*s_Pj)[NB + 1] = (double (*)[NB + 1])(s_dyn + 4 * NB * (NB + 1));
-  __shared__ int s_dead;
-  if (tid == 0) s_dead = 0;
-  __syncthreads();
-  const int arow = 16 * ti + li;
-  const int jend = is_rhs ? kend : min(kend, irow - 1);         // the producer's steps of this block: j <= i - 2 (the chain forms L(i, i-1))
-  for (int j = jb0; j < jend; j++) {
-    const bool upd = j > jb0;
-    bool ok = true;
-    if (upd) ok = cp_wait(flags, BP_LREADY + j, j);             // P_j = L(j, j-1) is published
-    double va[4], vp[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int idx = tid + 256 * u, r = idx / NB, c = idx % NB;
-      va[u] = (ok && (is_rhs ? r == 0 : true)) ? ld_sc1(&S[(r0 + r) * np + (size_t)j * NB + c]) : 0.0;
-      vp[u] = (ok && upd) ? ld_sc1(&S[((size_t)j * NB + r) * np + (size_t)(j - 1) * NB + c]) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u, r = idx / NB, c = idx % NB; s_A[r][c] = va[u]; s_Pj[r][c] = vp[u]; }
-    __syncthreads();
-    double a[8], b[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) a[ks] = s_A[arow][4 * ks + lk];
-    if (upd) {
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        double4_t acc = {a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]};
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_Pj[16 * t + li][4 * ks + lk], -s_Lq[arow][4 * ks + lk], acc, 0, 0, 0);
-        a[4 * t] = acc[0]; a[4 * t + 1] = acc[1]; a[4 * t + 2] = acc[2]; a[4 * t + 3] = acc[3];
-      }
-    }
-    if (ok) ok = cp_wait(flags, CP_XREADY, j + 1);
-    double vx[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) vx[u] = ok ? ld_sc1(&Dinv[(size_t)j * NB * NB + tid + 256 * u]) : 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vx[u]; }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) b[ks] = s_Xj[16 * tj + li][4 * ks + lk];
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const int r = 16 * ti + (lane >> 4) + 4 * rg, c = 16 * tj + (lane & 15);
-      s_Lc[r][c] = acc[rg];
-      if (ok && (is_rhs ? r == 0 : true)) st_sc1(&S[(r0 + r) * np + (size_t)j * NB + c], acc[rg]);
-    }
-    if (!ok) s_dead = 1;
-    HANDOFF_DRAIN();
-    __syncthreads();
-    if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-    if (tid == 0) cp_set(flags, BP_LREADY + irow, j + 1);
-    // update j of this row's tiles inside the block (k_chol_la's role B confined by c_cap): column blocks j + 2 .. kend - 1, not beyond the diagonal
-    if (!is_rhs) {
-      double la[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) la[ks] = s_Lc[16 * ti + li][4 * ks + lk];
-      for (int c = j + 2; c < kend && c <= irow; c++) {
-        const size_t cb = (size_t)c * NB;
-        bool okc = true;
-        if (c < irow) okc = cp_wait(flags, BP_LREADY + c, j + 1);
-        double vb[4], cpre[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; vb[u] = (okc && c < irow) ? ld_sc1(&S[(cb + idx / NB) * np + (size_t)j * NB + idx % NB]) : 0.0; }
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) cpre[rg] = okc ? ld_sc1(&S[(r0 + 16 * ti + (lane >> 4) + 4 * rg) * np + cb + 16 * tj + (lane & 15)]) : 0.0;
-        __syncthreads();                                        // (s_Xj is free again: everybody has its X operands)
-        if (c < irow) {
-#pragma unroll
-          for (int u = 0; u < 4; u++) { const int idx = tid + 256 * u; s_Xj[idx / NB][idx % NB] = vb[u]; }
-        }
-        __syncthreads();
-        double4_t u4 = {0.0, 0.0, 0.0, 0.0};
-        if (c < irow) {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_Xj[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < 8; ks++) u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], s_Lc[16 * tj + li][4 * ks + lk], u4, 0, 0, 0);
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const size_t row = r0 + 16 * ti + (lane >> 4) + 4 * rg, col = cb + 16 * tj + (lane & 15);
-          if (okc && col <= row) st_sc1(&S[row * np + col], cpre[rg] - u4[rg]);
-        }
-        if (!okc) s_dead = 1;
-      }
-    } else {
-      double* zrow = S + (size_t)np * np;
-      for (int cc = (j + 2) * NB + tid; cc < kend * NB; cc += 256) {
-        if (!cp_wait(flags, BP_LREADY + cc / NB, j + 1)) { s_dead = 1; break; }
-        const double* L = S + (size_t)cc * np + (size_t)j * NB;
-        double lv[NB];
-#pragma unroll
-        for (int mm = 0; mm < NB; mm++) lv[mm] = ld_sc1(&L[mm]);
-        const double z0 = ld_sc1(&zrow[cc]);
-        double sum = 0.0;
-#pragma unroll
-        for (int mm = 0; mm < NB; mm++) sum += lv[mm] * s_Lc[0][mm];
-        st_sc1(&zrow[cc], z0 - sum);
-      }
-    }
-    HANDOFF_DRAIN();
-    __syncthreads();
-    if (s_dead) { if (tid == 0) cp_die(st, flags); return; }
-    // the chain needs this row once it is the next one: L(i, i-2) and the row's tiles in the column blocks i - 1 and i are final
-    if (tid == 0 && !is_rhs && j == irow - 2) cp_set(flags, FIN + irow, 1);
-    { double (*t)[NB + 1] = s_Lc; s_Lc = s_Lq; s_Lq = t; }
-  }
-}
-
-// (the one-launch two-level kernel k_chol_persist_2l - bit-identical, measured slower - lives in experiments/chol_persist_2l.inc:
-// ORBHIP_EXPERIMENTS builds, ORBHIP_BA_PERSIST=2)
-#ifdef ORBHIP_EXPERIMENTS
-#include "experiments/chol_persist_2l.inc"
-#endif
-
-// backward substitution L^T x = z (z = augmented row, produced by the factorisation itself), in super-blocks
-// of 256 rows processed from the bottom: k_chol_bsolve_diag solves one super-block with a single 1024-thread
-// workgroup, then k_chol_bsolve_update subtracts its contribution from every earlier entry with many workgroups
-// (fixed-order LDS reductions -> deterministic).
-// Everything k_chol_bsolve_diag reads from the factor - the <= 8 stored L11^-1 blocks and the <= 28 off-diagonal 32x32
-// blocks of the super-block - is independent of the running solution, so it is requested up front, one element of every
-// block per thread (28 + 8 doubles in registers); the <= 8 sequential block steps then run on LDS and registers only
-// (35 us -> see DESIGN.md; the first version re-read global memory twice per step).
-#define SBLK 256
-#define SB_NBLK (SBLK / NB)
-__global__ __launch_bounds__(1024) void k_chol_bsolve_diag(const BaDev* __restrict__ Dv, int kb) {
-  const BaDev D = Dv[blockIdx.y];
-  const BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  __shared__ double s_y[SBLK], s_x[NB];
-  __shared__ double s_p[NB][SBLK - NB];                             // partial products, [row of the block][column above the block]
-  const int np = D.npad, tid = threadIdx.x;
-  if (kb >= np) return;                                             // batched launch: super-block beyond this problem
-  const int ke = min(kb + SBLK, np), first = (kb + SBLK >= np);
-  const int nblk = (ke - kb) / NB;
-  const int r = tid >> 5, c = tid & 31;
-  const double* S = D.S;
-  double di[SB_NBLK], sv[SB_NBLK * (SB_NBLK - 1) / 2];
-#pragma unroll
-  for (int bb = 0; bb < SB_NBLK; bb++)
-    di[bb] = (bb < nblk) ? D.Dinv[((size_t)(kb / NB + bb) * NB + r) * NB + c] : 0.0;
-#pragma unroll
-  for (int bb = 1; bb < SB_NBLK; bb++)
-#pragma unroll
-    for (int cb = 0; cb < bb; cb++)
-      sv[bb * (bb - 1) / 2 + cb] = (bb < nblk) ? S[(size_t)(kb + NB * bb + r) * np + kb + NB * cb + c] : 0.0;
-  if (F.done || !F.valid || F.chol_fail) return;
-  const double* src = first ? (D.S + (size_t)np * np) : D.rhs;      // the first (bottom) super-block starts from z
-  if (first) for (int i = tid; i < kb; i += 1024) D.rhs[i] = src[i];  // seed the running vector for the rows above
-  if (tid < ke - kb) s_y[tid] = src[kb + tid];
-  __syncthreads();
-#pragma unroll
-  for (int bb = SB_NBLK - 1; bb >= 0; bb--) {
-    if (bb < nblk) {                                                // (uniform)
-      // x = Linv^T y_b : x[c] = sum_r Linv[r][c] y[r]   (Linv is lower triangular: the r < c terms are exact zeros)
-      s_p[r][c] = di[bb] * s_y[NB * bb + r];
-      __syncthreads();
-      if (tid < NB) {
-        double sum = 0.0;
-#pragma unroll
-        for (int rr = 0; rr < NB; rr++) sum += s_p[rr][tid];
-        s_x[tid] = sum;
-        s_y[NB * bb + tid] = sum;
-      }
-      __syncthreads();
-      if (bb > 0) {
-        // rows of this super-block above block bb: y[cc] -= sum_r L[block bb row r][cc] x[r]
-        const double xr = s_x[r];
-#pragma unroll
-        for (int cb = 0; cb < bb; cb++) s_p[r][NB * cb + c] = sv[bb * (bb - 1) / 2 + cb] * xr;
-        __syncthreads();
-        if (tid < NB * bb) {
-          double sum = 0.0;
-#pragma unroll
-          for (int rr = 0; rr < NB; rr++) sum += s_p[rr][tid];
-          s_y[tid] -= sum;
-        }
-        __syncthreads();
-      }
-    }
-  }
-  if (tid < ke - kb) D.rhs[kb + tid] = s_y[tid];
-}
-
-__global__ __launch_bounds__(1024) void k_chol_bsolve_update(const BaDev* __restrict__ Dv, int kb) {
-  const BaDev D = Dv[blockIdx.y];
-  const BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  __shared__ double s_x[SBLK], s_p[16][64];
-  const int np = D.npad, tid = threadIdx.x;
-  if (kb >= np || (int)blockIdx.x * 64 >= kb) return;
-  const int ke = min(kb + SBLK, np);
-  const int nr = ke - kb;
-  const int cl = tid & 63, rg = tid >> 6;                           // 64 columns x 16 row groups, 16 rows each, all loads in flight
-  const int c = blockIdx.x * 64 + cl;
-  double lv[SBLK / 16];
-#pragma unroll
-  for (int u = 0; u < SBLK / 16; u++) {
-    const int rr = rg + 16 * u;
-    lv[u] = (c < kb && rr < nr) ? D.S[(size_t)(kb + rr) * np + c] : 0.0;
-  }
-  if (F.done || !F.valid || F.chol_fail) return;
-  if (tid < nr) s_x[tid] = D.rhs[kb + tid];
-  __syncthreads();
-  double sum = 0.0;
-#pragma unroll
-  for (int u = 0; u < SBLK / 16; u++) { const int rr = rg + 16 * u; if (rr < nr) sum += lv[u] * s_x[rr]; }
-  s_p[rg][cl] = sum;
-  __syncthreads();
-  if (tid < 64 && c < kb) {
-    double t = 0.0;
-#pragma unroll
-    for (int g = 0; g < 16; g++) t += s_p[g][tid];
-    D.rhs[c] -= t;
-  }
-}
+#include "ba_cholesky.inc"   // dense blocked Cholesky of the reduced camera system
 
 // ---- candidate cameras: x+ = Plus(x, -y * scale); partial |dx|^2 -------------------------------------------
 __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restrict__ Dv) {
@@ -3640,1147 +1070,13 @@ __global__ void k_ba_user_stop(const BaDev* __restrict__ Dv) {
 }
 
 
-// ============================================================================ OptimizeEssentialGraph (pose graph over Sim(3))
-// CeresOptimizer::OptimizeEssentialGraph (src/CeresOptimizer.cc:737-957): vertices = Sim(3) tangents under
-// Sim3Parameterization, edges = EssentialGraphErrorTerm (include/CeresOptimizer.h:266-330).  The LM controller, the dense
-// Cholesky (k_chol_*) and the step logic (k_ba_iter_begin / k_ba_iter_end) are the bundle-adjustment ones, driven through a
-// BaDev "view" that only carries S / rhs / Dinv / npad / part / state; the kernels below are the graph-specific parts.
-// ---- start of a solve: the LM state, zeroed rhs / partial sums of every problem in ONE launch (a 64-problem batch issued 64
-// state copies and 128 fills), and its end: state, poses, points and erase flags of every problem gathered into one block for
-// ONE download (192 - 256 copies before) - a batched solve spent 9 % of its GPU time in 4-us copy kernels.
-__device__ __forceinline__ size_t out_align(size_t b) { return (b + 255) & ~(size_t)255; }
-__global__ __launch_bounds__(256) void k_ba_init(const BaDev* __restrict__ Dv, BaState st0) {
-  const BaDev D = Dv[blockIdx.y];
-  const int n = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
-  for (int i = i0; i < D.npad; i += n) D.rhs[i] = 0.0;
-  for (int i = i0; i < 6 * D.nparts; i += n) D.part[i] = 0.0;
-  if (i0 == 0) *D.st = st0;
-}
-__global__ __launch_bounds__(256) void k_ba_collect(const BaDev* __restrict__ Dv, int with_erase) {
-  const BaDev D = Dv[blockIdx.y];
-  const int n = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
-  unsigned char* o = D.out;
-  if (i0 < (int)(sizeof(BaState) / 4)) ((int*)o)[i0] = ((const int*)D.st)[i0];
-  o += out_align(sizeof(BaState));
-  double* op = (double*)o;
-  for (int i = i0; i < 7 * D.ncam; i += n) op[i] = D.poses[i];
-  o += out_align(7 * (size_t)D.ncam * sizeof(double));
-  double* ox = (double*)o;
-  for (int i = i0; i < 3 * D.npts; i += n) ox[i] = D.pts[i];
-  o += out_align(3 * (size_t)D.npts * sizeof(double));
-  if (with_erase && D.erase) for (int i = i0; i < D.nobs; i += n) o[i] = D.erase[i];
-}
-
-struct PgDev {
-  int n, nf, n7, npad, ne, nblk, nparts;
-  double* x; double* cand; const int* col;                 // [n][7] tangents, reduced column of every vertex (-1 = constant)
-  const int* ej; const int* ei; const double* Sji;          // edges: vertex j, vertex i, measurement (qt7)
-  double* r; double* J;                                     // [ne][7], [ne][49] (J_i; J_j = -J_i)
-  double* g; double* scale;                                 // [n7] gradient (unscaled), Jacobi scaling
-  const int* v_off; const int* v_edge; const signed char* v_sign;   // per vertex: incident edges in insertion order, +1 = it is i, -1 = it is j
-  const int* blk_a; const int* blk_b; const int* blk_off; const int* blk_edge;    // off-diagonal blocks (col_a > col_b) and their edges
-  double* vpart;                                            // per vertex: |x|^2, gmax
-  double* S; double* rhs; double* part; BaState* st;
-};
-
-// residuals (+ Jacobians) of every edge: mode 0 at x, mode 1 cost only at the candidate
-__global__ __launch_bounds__(128) void k_pg_eval(PgDev P, int mode) {
-  __shared__ double s_red[4], s_out[1];
-  const BaState* st = P.st;
-  const StFlags F = ld_flags(st);
-  if (F.done) return;
-  if (mode == 0 && !F.need_eval) return;
-  if (mode == 1 && !F.valid) return;
-  const int e = blockIdx.x * 128 + threadIdx.x;
-  double acc = 0.0;
-  if (e < P.ne) {
-    const double* X = mode ? P.cand : P.x;
-    double r[7];
-    s3_graph_edge(X + 7 * (size_t)P.ej[e], X + 7 * (size_t)P.ei[e], P.Sji + 7 * (size_t)e, r, mode == 0 ? P.J + 49 * (size_t)e : nullptr);
-#pragma unroll
-    for (int k = 0; k < 7; k++) acc += 0.5 * r[k] * r[k];
-    if (mode == 0)
-#pragma unroll
-      for (int k = 0; k < 7; k++) P.r[7 * (size_t)e + k] = r[k];
-  }
-  // 128-thread block sum (2 waves)
-  double v = acc;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) { s_out[0] = s_red[0] + s_red[1]; P.part[(mode ? 1 : 0) * P.nparts + blockIdx.x] = s_out[0]; }
-}
-
-// per free vertex (thread): gradient, (first time) Jacobi scale, |x|^2 and its gradient-max-norm term
-__global__ __launch_bounds__(128) void k_pg_vertex(PgDev P) {
-  const BaState* st = P.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.need_eval) return;
-  const int v = blockIdx.x * 128 + threadIdx.x;
-  if (v >= P.n) return;
-  const int c = P.col[v];
-  if (c < 0) { P.vpart[2 * v] = 0.0; P.vpart[2 * v + 1] = 0.0; return; }
-  double g[7] = {0, 0, 0, 0, 0, 0, 0}, n2[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int q = P.v_off[v]; q < P.v_off[v + 1]; q++) {
-    const int e = P.v_edge[q];
-    const double sgn = (double)P.v_sign[q];
-    const double* J = P.J + 49 * (size_t)e; const double* r = P.r + 7 * (size_t)e;
-    for (int a = 0; a < 7; a++) {
-      double s = 0, m = 0;
-      for (int k = 0; k < 7; k++) { s += J[k * 7 + a] * r[k]; m += J[k * 7 + a] * J[k * 7 + a]; }
-      g[a] += sgn * s; n2[a] += m;
-    }
-  }
-  double xn = 0, mg[7], xp[7], gmax = 0;
-  for (int a = 0; a < 7; a++) {
-    P.g[7 * c + a] = g[a];
-    if (st->first) P.scale[7 * c + a] = 1.0 / (1.0 + sqrt(n2[a]));
-    const double xv = P.x[7 * (size_t)v + a];
-    xn += xv * xv; mg[a] = -g[a];
-  }
-  s3_plus(P.x + 7 * (size_t)v, mg, xp);
-  for (int a = 0; a < 7; a++) gmax = fmax(gmax, fabs(P.x[7 * (size_t)v + a] - xp[a]));
-  P.vpart[2 * v] = xn; P.vpart[2 * v + 1] = gmax;
-}
-
-__global__ __launch_bounds__(256) void k_pg_after_eval(PgDev P) {
-  __shared__ double s_red[4 * 2], s_out[2], s_max[4];
-  BaState* st = P.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.need_eval) return;
-  const int tid = threadIdx.x;
-  double acc[2] = {0.0, 0.0};
-  double m = 0.0;
-  for (int b = tid; b < P.nparts; b += 256) acc[0] += P.part[b];
-  for (int v = tid; v < P.n; v += 256) { acc[1] += P.vpart[2 * v]; m = fmax(m, P.vpart[2 * v + 1]); }
-  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((tid & 63) == 0) s_max[tid >> 6] = m;
-  block_reduce<2>(acc, s_red, s_out);
-  if (tid == 0) {
-    st->x_cost = s_out[0]; st->x_norm = sqrt(s_out[1]);
-    st->gmax = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
-    if (st->first) st->initial_cost = s_out[0];
-    st->first = 0; st->need_eval = 0;
-    if (st->gmax <= 1e-10) { st->termination = 1; st->done = 1; }
-  }
-}
-
-// scaled normal equations into the dense lower triangle: one 64-thread workgroup per diagonal block (free vertex) and per
-// off-diagonal block; every block sums its edges in list order (deterministic), element (u, v) per lane
-__global__ __launch_bounds__(64) void k_pg_build(PgDev P) {
-  const BaState* st = P.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid) return;
-  const int np = P.npad, tid = threadIdx.x;
-  const int u = tid / 7, w = tid - 7 * u;
-  if ((int)blockIdx.x < P.n) {                         // diagonal block + rhs of vertex v
-    const int v = blockIdx.x, c = P.col[v];
-    if (c < 0) return;
-    if (tid < 49) {
-      double acc = 0.0;
-      for (int q = P.v_off[v]; q < P.v_off[v + 1]; q++) {
-        const double* J = P.J + 49 * (size_t)P.v_edge[q];
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) s += J[k * 7 + u] * J[k * 7 + w];
-        acc += s;
-      }
-      double hs = acc * P.scale[7 * c + u] * P.scale[7 * c + w];
-      if (u == w) hs += fmin(fmax(hs, 1e-6), 1e32) / st->radius;
-      if (w <= u) P.S[(size_t)(7 * c + u) * np + 7 * c + w] = hs;
-    }
-    if (tid < 7) {
-      const double gs = P.g[7 * c + tid] * P.scale[7 * c + tid];
-      P.rhs[7 * c + tid] = gs;
-      P.S[(size_t)np * np + 7 * c + tid] = gs;           // augmented row: forward substitution rides the factorisation
-    }
-  } else {                                              // off-diagonal block (a, b), col_a > col_b:  - sum_e J_e^T J_e
-    const int blk = blockIdx.x - P.n;
-    if (blk >= P.nblk || tid >= 49) return;
-    const int ca = P.blk_a[blk], cb = P.blk_b[blk];
-    double acc = 0.0;
-    for (int q = P.blk_off[blk]; q < P.blk_off[blk + 1]; q++) {
-      const double* J = P.J + 49 * (size_t)P.blk_edge[q];
-      double s = 0;
-#pragma unroll
-      for (int k = 0; k < 7; k++) s += J[k * 7 + u] * J[k * 7 + w];
-      acc += s;
-    }
-    P.S[(size_t)(7 * ca + u) * np + 7 * cb + w] = -acc * P.scale[7 * ca + u] * P.scale[7 * cb + w];
-  }
-}
-
-// padding rows (identity) of the reduced system, written once per solve
-__global__ void k_pg_pad(PgDev P) {
-  const int np = P.npad, i = P.n7 + blockIdx.x;
-  if (i >= np) return;
-  for (int j = threadIdx.x; j < np; j += blockDim.x) P.S[(size_t)i * np + j] = (i == j) ? 1.0 : 0.0;
-  if (threadIdx.x == 0) { P.rhs[i] = 0.0; P.S[(size_t)np * np + i] = 0.0; }
-}
-
-// candidate x+ = Plus(x, -y * scale) per vertex, partial |dx|^2 -> part[2 * nparts + block]
-__global__ __launch_bounds__(128) void k_pg_step(PgDev P) {
-  __shared__ double s_red[2];
-  const BaState* st = P.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid) return;
-  const int v = blockIdx.x * 128 + threadIdx.x;
-  double acc = 0.0;
-  if (v < P.n) {
-    const int c = P.col[v];
-    const double* x = P.x + 7 * (size_t)v; double* xc = P.cand + 7 * (size_t)v;
-    if (c < 0 || st->chol_fail) { for (int k = 0; k < 7; k++) xc[k] = x[k]; }
-    else {
-      double d[7];
-      for (int k = 0; k < 7; k++) d[k] = (-P.rhs[7 * c + k]) * P.scale[7 * c + k];
-      s3_plus(x, d, xc);
-      for (int k = 0; k < 7; k++) { const double e = x[k] - xc[k]; acc += e * e; }
-    }
-  }
-  double vv = acc;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) vv += __shfl_xor(vv, o);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = vv;
-  __syncthreads();
-  if (threadIdx.x == 0) P.part[2 * P.nparts + blockIdx.x] = s_red[0] + s_red[1];
-}
-
-// model cost change -(J s).(r + J s / 2) per edge -> part[3 * nparts + block]; part[4 * nparts + block] = 0
-__global__ __launch_bounds__(128) void k_pg_mcc(PgDev P) {
-  __shared__ double s_red[2];
-  const BaState* st = P.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid) return;
-  const int e = blockIdx.x * 128 + threadIdx.x;
-  double acc = 0.0;
-  if (e < P.ne && !st->chol_fail) {
-    const int ci = P.col[P.ei[e]], cj = P.col[P.ej[e]];
-    double d[7];
-    for (int a = 0; a < 7; a++) {
-      double di = 0, dj = 0;
-      if (ci >= 0) di = (-P.rhs[7 * ci + a]) * P.scale[7 * ci + a];
-      if (cj >= 0) dj = (-P.rhs[7 * cj + a]) * P.scale[7 * cj + a];
-      d[a] = di - dj;
-    }
-    const double* J = P.J + 49 * (size_t)e; const double* r = P.r + 7 * (size_t)e;
-    for (int k = 0; k < 7; k++) {
-      double m = 0;
-      for (int a = 0; a < 7; a++) m += J[k * 7 + a] * d[a];
-      acc -= m * (r[k] + m / 2);
-    }
-  }
-  double vv = acc;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) vv += __shfl_xor(vv, o);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = vv;
-  __syncthreads();
-  if (threadIdx.x == 0) { P.part[3 * P.nparts + blockIdx.x] = s_red[0] + s_red[1]; P.part[4 * P.nparts + blockIdx.x] = 0.0; }
-}
-
-__global__ __launch_bounds__(256) void k_pg_apply(PgDev P) {
-  const BaState* st = P.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.accepted) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < 7 * P.n) P.x[i] = P.cand[i];
-}
-
-// write-back arithmetic (src/CeresOptimizer.cc:916-956): Tiw = [R | t / s] per keyframe; P' = Swr_corrected * (Srw_original * P)
-__global__ __launch_bounds__(128) void k_pg_poses(const double* __restrict__ lie_opt, int n, double* __restrict__ Tiw) {
-  const int v = blockIdx.x * 128 + threadIdx.x;
-  if (v >= n) return;
-  double S[7];
-  s3_exp(lie_opt + 7 * (size_t)v, S);
-  const double s = S[0] * S[0] + S[1] * S[1] + S[2] * S[2] + S[3] * S[3];
-  const double inv = 1.0 / sqrt(s);
-  const double q[4] = {S[0] * inv, S[1] * inv, S[2] * inv, S[3] * inv};
-  double R[9];
-  quat_to_R(q, R);
-  const double inv_s = 1. / s;
-  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tiw[12 * (size_t)v + 4 * i + j] = R[3 * i + j]; Tiw[12 * (size_t)v + 4 * i + 3] = inv_s * S[4 + i]; }
-}
-__global__ __launch_bounds__(256) void k_pg_points(const double* __restrict__ lie_orig, const double* __restrict__ lie_opt,
-                                                   const int* __restrict__ pt_ref, double* __restrict__ pts, int npts) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= npts) return;
-  const int rk = pt_ref[p];
-  double S0[7], S1[7], S1i[7], Pc[3], Pw[3];
-  s3_exp(lie_orig + 7 * (size_t)rk, S0);
-  s3_exp(lie_opt + 7 * (size_t)rk, S1);
-  s3_inverse(S1, S1i);
-  s3_act(S0, pts + 3 * (size_t)p, Pc);
-  s3_act(S1i, Pc, Pw);
-  pts[3 * (size_t)p] = Pw[0]; pts[3 * (size_t)p + 1] = Pw[1]; pts[3 * (size_t)p + 2] = Pw[2];
-}
+#include "ba_posegraph.inc"   // OptimizeEssentialGraph and the batch bookkeeping kernels
 
 }  // namespace orbhip
 
 using namespace orbhip;
 
-// ============================================================================ host driver
-namespace {
-
-// growable device workspace, reused across calls on the same host thread (slot order = allocation order)
-struct PinnedBuf {
-  void* p = nullptr; size_t bytes = 0;
-  int ensure(size_t need) {
-    if (need <= bytes) return 0;
-    if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
-    size_t want = need + need / 4;
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; set_error("hipHostMalloc(%zu) failed", want); return ORBHIP_ENOMEM; }
-    bytes = want;
-    return 0;
-  }
-};
-struct BaWorkspace {
-  std::vector<DevBuf> slots;
-  std::vector<PinnedBuf> hslots;
-  // no destructor: freeing device memory from a thread_local destructor can run after the HIP runtime has
-  // shut down (observed as a hang at process exit under rocprofv3); the process teardown reclaims it.
-};
-static thread_local BaWorkspace g_ws;
-// the workspace of this thread still holds the complete prepared batch of the last ba_solve_batch_impl call (structure
-// arrays, block lists, workspace, final poses / points): LocalBA's second pass solves the SAME observation set and
-// reuses it.  Every new walk over the workspace slots (any HostBA) invalidates it.
-static thread_local bool g_batch_valid = false;
-// one non-blocking stream per host thread: independent solves issued from different threads overlap on the GPU
-static thread_local hipStream_t g_stream = nullptr;
-static thread_local int g_stream_device = -1;
-struct GraphCacheEntry { std::vector<BaDev> D; const BaDev* Dv = nullptr; hipGraphExec_t exec = nullptr; unsigned long long stamp = 0; int mode = 0; };
-// Persistent factorisations need their waiting workgroups RESIDENT (the chain waits for rows with larger block indices; the
-// one-launch two-level kernel needs its whole grid): the launches in flight on a device are accounted in workgroup slots, and a
-// solve that does not get its slots takes the step kernels instead - the results are the same bits either way.
-static std::atomic<int> g_persist_used[16];
-struct PersistLease {
-  int n = 0, dev = 0;
-  bool take(int device, int need, int cap) {
-    dev = device & 15;
-    int cur = g_persist_used[dev].load();
-    while (cur + need <= cap)
-      if (g_persist_used[dev].compare_exchange_weak(cur, cur + need)) { n = need; return true; }
-    return false;
-  }
-  ~PersistLease() { if (n) g_persist_used[dev].fetch_sub(n); }
-};
-static thread_local std::vector<GraphCacheEntry> g_graphs;      // instantiated per-iteration graphs of this thread (<= 4, LRU)
-static thread_local unsigned long long g_graph_clock = 0;
-// pinned, device-mapped byte through which the kernels see the caller's stop flag (a plain bool somewhere in host memory):
-// the host copies *stop_flag into it while it waits for the stream, k_ba_iter_begin reads it before every iteration
-static thread_local unsigned char* g_stop_host = nullptr;
-static thread_local unsigned char* g_stop_dev = nullptr;
-static int stop_mirror(unsigned char** host, const volatile unsigned char** dev) {
-  if (!g_stop_host) {
-    void* h = nullptr; void* d = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
-      set_error("hipHostMalloc(stop flag mirror) failed"); return ORBHIP_ENOMEM;
-    }
-    g_stop_host = (unsigned char*)h; g_stop_dev = (unsigned char*)d;
-  }
-  *host = g_stop_host; *dev = g_stop_dev;
-  return 0;
-}
-// wait for the stream; while waiting, forward the caller's stop flag to the device mirror
-static hipError_t wait_stream_forwarding_stop(hipStream_t s, const volatile uint8_t* stop, unsigned char* mirror) {
-  if (!stop || !mirror) return hipStreamSynchronize(s);
-  // the first 150 us are polled with yield (PoseOptimization-sized solves end inside them), after that the thread sleeps
-  // ~50 us between polls: a LocalBA / GlobalBA no longer burns a host core for its whole duration, and the stop flag still
-  // reaches the device within one LM iteration
-  const auto t0 = std::chrono::steady_clock::now();
-  bool spin = true;
-  for (;;) {
-    if (*stop) __atomic_store_n(mirror, (unsigned char)1, __ATOMIC_RELEASE);
-    const hipError_t q = hipStreamQuery(s);
-    if (q == hipSuccess) return hipSuccess;
-    if (q != hipErrorNotReady) return q;
-    if (spin) {
-      std::this_thread::yield();
-      spin = std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(150);
-    } else {
-      std::this_thread::sleep_for(std::chrono::microseconds(50));
-    }
-  }
-}
-// measurement hook (ba_set_profiling / ba_get_profile): device time of the solves of this host thread, HIP events on its stream
-static std::atomic<int> g_ba_profiling{0};
-static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
-static thread_local double g_prof_ms = 0.0;
-static thread_local int g_prof_solves = 0, g_prof_iters = 0;
-static hipStream_t thread_stream() {
-  const int dev = g_default_device.load();
-  if (g_stream && g_stream_device != dev) {            // the default device changed: drop the old stream and workspace
-    (void)hipStreamDestroy(g_stream); g_stream = nullptr;
-    g_ws.slots.clear(); g_ws.hslots.clear();           // (buffers of the previous device are intentionally leaked)
-    g_graphs.clear();
-    g_batch_valid = false;
-    g_stop_host = nullptr; g_stop_dev = nullptr;       // the mirror's device pointer belongs to the old device: re-derive it
-  }
-  static thread_local int prio_cur = 0;
-  const int prio_want = thread_ws().prio_want;           // orbhip_set_thread_priority (the Tracking thread's PoseOptimization beside another thread's LocalBA)
-  if (g_stream && prio_cur != prio_want) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); g_stream = nullptr; g_graphs.clear(); }
-  if (!g_stream) {
-    int lo = 0, hi = 0;
-    hipError_t e;
-    if (prio_want && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) e = hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, hi);
-    else e = hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) g_stream = nullptr;
-    g_stream_device = dev; prio_cur = prio_want;
-  }
-  return g_stream;
-}
-
-struct HostBA {
-  HostBA() { g_batch_valid = false; }
-  size_t next = 0, hnext = 0;
-  // pinned host staging (reused across calls): structure arrays are built straight into it so that the
-  // H2D copies are true async DMA and never touch freshly mmap'ed pageable pages
-  template <typename T> T* pinned(size_t count, int* rc) {
-    if (hnext >= g_ws.hslots.size()) g_ws.hslots.resize(hnext + 1);
-    PinnedBuf& b = g_ws.hslots[hnext++];
-    int r = b.ensure(std::max<size_t>(count * sizeof(T), 16));
-    if (r && !*rc) *rc = r;
-    return (T*)b.p;
-  }
-  template <typename T> T* alloc(size_t count, int* rc) {
-    if (next >= g_ws.slots.size()) g_ws.slots.resize(next + 1);
-    DevBuf& b = g_ws.slots[next++];
-    int r = b.ensure(std::max<size_t>(count * sizeof(T), 16));
-    if (r && !*rc) *rc = r;
-    return b.as<T>();
-  }
-  template <typename T> T* upload(const T* src, size_t count, int* rc, hipStream_t st = 0) {
-    T* d = alloc<T>(count, rc);
-    if (!*rc && count) { if (hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); *rc = ORBHIP_ENODEV; } }
-    return d;
-  }
-  // Upload arena: the arrays of one problem whose sizes are known up front are built (or copied) into ONE pinned block at
-  // 256-byte-aligned offsets and reach the device with ONE copy into a device block of the same layout - a problem used to
-  // issue ~23 small H2D copies (a batched solve spent 10 % of its GPU time in 4-us copy kernels).
-  uint8_t* ar_h = nullptr; uint8_t* ar_d = nullptr; size_t ar_off = 0, ar_cap = 0;
-  int begin_arena(size_t bytes) {
-    int rc = 0;
-    ar_h = pinned<uint8_t>(bytes, &rc); ar_d = alloc<uint8_t>(bytes, &rc);
-    ar_off = 0; ar_cap = bytes;
-    return rc;
-  }
-  static size_t arena_need(size_t count, size_t elem) { return (count * elem + 255) & ~(size_t)255; }
-  template <typename T> T* arena_host(size_t count, int* rc) {
-    const size_t need = arena_need(std::max<size_t>(count, 1), sizeof(T));
-    if (ar_off + need > ar_cap) { if (!*rc) { set_error("internal: upload arena too small"); *rc = ORBHIP_EINVAL; } return nullptr; }
-    T* h = (T*)(ar_h + ar_off); ar_off += need;
-    return h;
-  }
-  template <typename T> T* arena_copy(const T* src, size_t count, int* rc) {       // caller memory -> arena (host side)
-    T* h = arena_host<T>(count, rc);
-    if (h && count) std::memcpy(h, src, count * sizeof(T));
-    return h;
-  }
-  template <typename T> T* arena_dev(const T* host_ptr) const { return host_ptr ? (T*)(ar_d + ((const uint8_t*)host_ptr - ar_h)) : nullptr; }
-  int flush_arena(hipStream_t st) {
-    if (ar_off && hipMemcpyAsync(ar_d, ar_h, ar_off, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); return ORBHIP_ENODEV; }
-    return 0;
-  }
-  // second arena of a problem: the arrays whose sizes are known only after the pair lists have been counted (block lists, pair
-  // lists) - they were seven separate copies per problem
-  uint8_t* a2_h = nullptr; uint8_t* a2_d = nullptr; size_t a2_off = 0, a2_cap = 0;
-  int begin_arena2(size_t bytes) {
-    int rc = 0;
-    a2_h = pinned<uint8_t>(bytes, &rc); a2_d = alloc<uint8_t>(bytes, &rc);
-    a2_off = 0; a2_cap = bytes;
-    return rc;
-  }
-  template <typename T> T* arena2_host(size_t count, int* rc) {
-    const size_t need = arena_need(std::max<size_t>(count, 1), sizeof(T));
-    if (a2_off + need > a2_cap) { if (!*rc) { set_error("internal: second upload arena too small"); *rc = ORBHIP_EINVAL; } return nullptr; }
-    T* h = (T*)(a2_h + a2_off); a2_off += need;
-    return h;
-  }
-  template <typename T> T* arena2_copy(const T* src, size_t count, int* rc) {
-    T* h = arena2_host<T>(count, rc);
-    if (h && count) std::memcpy(h, src, count * sizeof(T));
-    return h;
-  }
-  template <typename T> T* arena2_dev(const T* host_ptr) const { return host_ptr ? (T*)(a2_d + ((const uint8_t*)host_ptr - a2_h)) : nullptr; }
-  int flush_arena2(hipStream_t st) {
-    if (a2_off && hipMemcpyAsync(a2_d, a2_h, a2_off, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy H2D failed"); return ORBHIP_ENODEV; }
-    return 0;
-  }
-  // for host data that does NOT outlive the enqueue (function-local vectors, stack structs): an asynchronous copy from
-  // pageable memory may read its source after the call returned, so the data is first copied into this thread's pinned
-  // staging, which stays valid until the solve has drained
-  template <typename T> T* upload_staged(const T* src, size_t count, int* rc, hipStream_t st) {
-    T* h = pinned<T>(count, rc);
-    if (*rc) return nullptr;
-    if (count) std::memcpy(h, src, count * sizeof(T));
-    return upload(h, count, rc, st);
-  }
-};
-
-// ---- one problem: validation, structure (host, O(nobs)), uploads, device workspace -----------------------------------
-struct BaInputs {
-  const double* K4; double* poses7; const uint8_t* cam_fixed; int ncam; double* pts3; int npts;
-  const int32_t* obs_cam; const int32_t* obs_pt; const double* obs_uv; const double* obs_w; const uint8_t* obs_robust; int nobs;
-  const uint8_t* cam_local = nullptr;   // LocalBA only: cameras whose observations are classified after the solve
-};
-struct BaPrepared { BaDev D; int nb_obs, nb_cam, nb_pt; size_t npairs; double t_struct_ms; std::vector<int> perm; uint8_t* h_rob; BaState* h_st; };
-struct BaBatch {
-  std::vector<BaPrepared> P; std::vector<BaDev> Dh; const BaDev* Dv = nullptr;
-  int g_obs, g_cam, g_pt, g_blk, g_npad, g_pad, g_n6, g_camcount, g_apply; size_t g_zero;
-  int g_npad_la, g_npad_2l;         // largest reduced system factored by the look-ahead kernel / by the two-level scheme (0: none)
-  unsigned char* out_d = nullptr; unsigned char* out_h = nullptr; size_t out_bytes = 0; std::vector<size_t> out_off;      // k_ba_collect's block (device, pinned host)
-};
-static thread_local BaBatch g_batch;
-
-static double ba_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-static int ba_prepare(HostBA& H, hipStream_t s, const BaInputs& in, const ba_options* opts, BaPrepared* out) {
-  const int ncam = in.ncam, npts = in.npts, nobs = in.nobs;
-  ORBHIP_REQUIRE(ncam > 0 && npts >= 0 && nobs >= 0, ORBHIP_EINVAL, "bad sizes");
-  ORBHIP_REQUIRE(in.K4 && in.poses7 && in.cam_fixed && (npts == 0 || in.pts3), ORBHIP_EINVAL, "NULL argument");
-  ORBHIP_REQUIRE(nobs == 0 || (in.obs_cam && in.obs_pt && in.obs_uv && in.obs_w && in.obs_robust), ORBHIP_EINVAL, "NULL observation arrays");
-  for (int i = 0; i < nobs; i++)
-    ORBHIP_REQUIRE(in.obs_cam[i] >= 0 && in.obs_cam[i] < ncam && in.obs_pt[i] >= 0 && in.obs_pt[i] < npts, ORBHIP_EINVAL, "observation index out of range");
-  const double t_start = ba_now_ms();
-  // group observations by point (stable), per-camera lists
-  int rc = 0;
-  {
-    typedef HostBA A;
-    const size_t no = (size_t)nobs, nc = (size_t)ncam, npt = (size_t)npts;
-    const size_t bytes = A::arena_need(npt + 1, 4) + 5 * A::arena_need(no, 4) + A::arena_need(2 * no, 8) + A::arena_need(no, 8) + A::arena_need(no, 1) +
-                         A::arena_need(nc + 1, 4) + A::arena_need(4 * nc, 8) + 2 * A::arena_need(nc, 1) + A::arena_need(nc, 4) + A::arena_need(7 * nc, 8) +
-                         A::arena_need(3 * npt, 8) + A::arena_need(1, sizeof(BaState)) + 16 * 256;
-    if (int r = H.begin_arena(bytes)) return r;
-  }
-  int* pt_off = H.arena_host<int>(npts + 1, &rc);
-  int* oc = H.arena_host<int>(nobs, &rc); int* op = H.arena_host<int>(nobs, &rc);
-  double* ouv = H.arena_host<double>(2 * (size_t)nobs, &rc); double* ow = H.arena_host<double>(nobs, &rc);
-  uint8_t* orb = H.arena_host<uint8_t>(nobs, &rc);
-  int* cam_off = H.arena_host<int>(ncam + 1, &rc); int* cam_obs = H.arena_host<int>(nobs, &rc); int* cam_obs_pt = H.arena_host<int>(nobs, &rc);
-  if (rc) return rc;
-  for (int p = 0; p <= npts; p++) pt_off[p] = 0;
-  for (int i = 0; i < nobs; i++) pt_off[in.obs_pt[i] + 1]++;
-  for (int p = 0; p < npts; p++) pt_off[p + 1] += pt_off[p];
-  std::vector<int> perm(nobs), fill(pt_off, pt_off + npts);
-  for (int i = 0; i < nobs; i++) perm[fill[in.obs_pt[i]]++] = i;
-  for (int j = 0; j < nobs; j++) {
-    const int i = perm[j];
-    oc[j] = in.obs_cam[i]; op[j] = in.obs_pt[i]; ouv[2 * (size_t)j] = in.obs_uv[2 * (size_t)i]; ouv[2 * (size_t)j + 1] = in.obs_uv[2 * (size_t)i + 1];
-    ow[j] = in.obs_w[i]; orb[j] = in.obs_robust[i];
-  }
-  for (int c = 0; c <= ncam; c++) cam_off[c] = 0;
-  for (int j = 0; j < nobs; j++) cam_off[oc[j] + 1]++;
-  for (int c = 0; c < ncam; c++) cam_off[c + 1] += cam_off[c];
-  std::vector<int> cfill(cam_off, cam_off + ncam);
-  int* cam_pos = H.arena_host<int>(nobs, &rc);
-  if (rc) return rc;
-  for (int j = 0; j < nobs; j++) { int e = cfill[oc[j]]++; cam_obs[e] = j; cam_obs_pt[e] = op[j]; cam_pos[j] = e; }
-  std::vector<int> cam_col(ncam, -1), free_cams;
-  for (int c = 0; c < ncam; c++) if (!in.cam_fixed[c] && cam_off[c + 1] > cam_off[c]) { cam_col[c] = (int)free_cams.size(); free_cams.push_back(c); }
-  const int nfc = (int)free_cams.size();
-  const int n6 = 6 * nfc, npad = std::max(round_up(n6, NB), NB);
-  const int nb_obs = std::max((nobs + BA_TPB - 1) / BA_TPB, 1), nb_cam = (ncam + BA_TPB - 1) / BA_TPB, nb_pt = std::max((npts + BA_TPB - 1) / BA_TPB, 1);
-  const int nparts = std::max(nb_obs, std::max(nb_cam, nb_pt));
-  // Schur block pair lists: for every point, all ordered observation pairs (i, j) with col_i <= col_j,
-  // grouped by block (col_i, col_j) with a counting sort (stable: point order, then list order).
-  std::vector<int4> row_meta((size_t)2 * std::max(nfc, 1), make_int4(0, 0, 0, 0)), segs;
-  for (int a = 0; a < nfc; a++) { const int ca = free_cams[a]; row_meta[2 * (size_t)a + 1] = make_int4(cam_off[ca], cam_off[ca + 1] - cam_off[ca], ca, 0); }
-  int* pair_i = nullptr; int* pair_j = nullptr; size_t npairs_all = 0;
-  if (!opts->fix_points && nfc > 0) {
-    // Per point, the free observations are first sorted by column (insertion sort, a handful of entries): the pairs with
-    // col_i <= col_j are then simply the positions i <= j of the sorted run - no data-dependent branch in the pair loops
-    // (the all-pairs test `cj >= ci` mispredicted every other time: 2.9 -> 1.9 ms for the C4 graph on this host).  A point
-    // that a camera observes twice (degenerate inputs) keeps the literal all-pairs form, whose order within a block the
-    // sorted form would change; for every other point both forms emit the same pairs in the same order.
-    std::vector<int> colv(std::max(nobs, 1));
-    for (int j = 0; j < nobs; j++) colv[j] = cam_col[oc[j]];
-    auto per_point = [&](auto&& sorted_run, auto&& generic) {
-      int sc[64], si[64];
-      for (int p = 0; p < npts; p++) {
-        const int lo = pt_off[p], hi = pt_off[p + 1];
-        int m = 0; bool dup = false; const bool small = (hi - lo) <= 64;
-        if (small)
-          for (int i = lo; i < hi; i++) {
-            const int c = colv[i];
-            if (c < 0) continue;
-            int k = m++;
-            while (k > 0 && sc[k - 1] > c) { sc[k] = sc[k - 1]; si[k] = si[k - 1]; k--; }
-            if (k > 0 && sc[k - 1] == c) dup = true;
-            sc[k] = c; si[k] = i;
-          }
-        if (small && !dup) sorted_run(sc, si, m); else generic(lo, hi);
-      }
-    };
-    std::vector<int> cnt((size_t)nfc * nfc + 1, 0);
-    per_point([&](const int* sc, const int*, int m) { for (int i = 0; i < m; i++) { int* row = cnt.data() + (size_t)sc[i] * nfc + 1; for (int j = i; j < m; j++) row[sc[j]]++; } },
-              [&](int lo, int hi) {
-                for (int i = lo; i < hi; i++) { const int ci = colv[i]; if (ci < 0) continue; for (int j = lo; j < hi; j++) if (colv[j] >= ci) cnt[(size_t)ci * nfc + colv[j] + 1]++; } });
-    for (size_t k = 0; k < (size_t)nfc * nfc; k++) cnt[k + 1] += cnt[k];
-    npairs_all = (size_t)cnt[(size_t)nfc * nfc];
-    // segment list: the off-diagonal blocks of a row, in (a, b) order, cut into runs of <= SR_SEG pairs (k_ba_schur: one wave each)
-    for (int a = 0; a < nfc; a++) {
-      const size_t kd = (size_t)a * nfc + a;
-      const int s_lo = (int)segs.size();
-      for (int b2 = a + 1; b2 < nfc; b2++) {
-        const size_t k = (size_t)a * nfc + b2;
-        for (int e = cnt[k]; e < cnt[k + 1]; e += SR_SEG) segs.push_back(make_int4(e, std::min(e + SR_SEG, cnt[k + 1]), b2, (e == cnt[k] ? 1 : 0) | (e + SR_SEG >= cnt[k + 1] ? 2 : 0) | (free_cams[b2] << 2)));
-      }
-      row_meta[2 * (size_t)a] = make_int4(cnt[kd], cnt[kd + 1], s_lo, (int)segs.size());
-    }
-    {
-      typedef HostBA A;
-      if (int r = H.begin_arena2(2 * A::arena_need(npairs_all + 1, 4) + 2 * A::arena_need((size_t)nfc + 1, 4) + A::arena_need(2 * (size_t)nfc + 1, 16) + A::arena_need(segs.size() + 1, 16) + 1024)) return r;
-    }
-    pair_i = H.arena2_host<int>(npairs_all, &rc); pair_j = H.arena2_host<int>(npairs_all, &rc);
-    if (rc) return rc;
-    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-    per_point([&](const int* sc, const int* si, int m) {
-                for (int i = 0; i < m; i++) { int* row = pos.data() + (size_t)sc[i] * nfc; for (int j = i; j < m; j++) { const int e = row[sc[j]]++; pair_i[e] = si[i]; pair_j[e] = si[j]; } } },
-              [&](int lo, int hi) {
-                for (int i = lo; i < hi; i++) { const int ci = colv[i]; if (ci < 0) continue;
-                  for (int j = lo; j < hi; j++) if (colv[j] >= ci) { const int e = pos[(size_t)ci * nfc + colv[j]]++; pair_i[e] = i; pair_j[e] = j; } } });
-    // k_ba_schur keeps camera a's records in LDS by list position: pair_i = position of the observation inside its camera's list;
-    // the E records are stored in camera-major order: pair_j = position of the observation in the concatenated lists
-    for (size_t e = 0; e < npairs_all; e++) { const int i = pair_i[e]; pair_i[e] = cam_pos[i] - cam_off[oc[i]]; pair_j[e] = cam_pos[pair_j[e]]; }
-  } else {
-    typedef HostBA A;
-    if (int r = H.begin_arena2(2 * A::arena_need(1, 4) + 2 * A::arena_need((size_t)nfc + 1, 4) + A::arena_need(2 * (size_t)nfc + 1, 16) + A::arena_need(1, 16) + 1024)) return r;
-    pair_i = H.arena2_host<int>(0, &rc); pair_j = H.arena2_host<int>(0, &rc);
-    if (rc) return rc;
-  }
-  out->t_struct_ms = ba_now_ms() - t_start;
-
-  BaDev D; std::memset(&D, 0, sizeof(D));
-  D.ncam = ncam; D.npts = npts; D.nobs = nobs; D.nfc = nfc; D.n6 = n6; D.npad = npad; D.nparts = nparts;
-  D.fix_points = opts->fix_points ? 1 : 0; D.huber = opts->huber_delta;
-  static const bool use_la = []() { const char* e = std::getenv("ORBHIP_BA_LOOKAHEAD"); return !(e && e[0] == '0'); }();
-  static const int la_max = []() { const char* e = std::getenv("ORBHIP_BA_LA_MAX"); return e ? atoi(e) : 1024; }();
-  D.chol_la = (use_la && npad <= la_max) ? 1 : 0;
-  // (arena: host images of these arrays sit in one pinned block; ONE copy below moves them all)
-  D.K4 = H.arena_dev(H.arena_copy(in.K4, 4 * (size_t)ncam, &rc)); D.cam_fixed = H.arena_dev(H.arena_copy(in.cam_fixed, ncam, &rc));
-  D.cam_col = H.arena_dev(H.arena_copy(cam_col.data(), ncam, &rc));
-  D.poses = H.arena_dev(H.arena_copy(in.poses7, 7 * (size_t)ncam, &rc)); D.pts = H.arena_dev(H.arena_copy(in.pts3, 3 * (size_t)npts, &rc));
-  D.cand_poses = H.alloc<double>(7 * (size_t)ncam, &rc); D.cand_pts = H.alloc<double>(3 * (size_t)npts, &rc);
-  D.obs_cam = H.arena_dev(oc); D.obs_pt = H.arena_dev(op); D.obs_uv = H.arena_dev(ouv);
-  D.obs_w = H.arena_dev(ow); D.obs_robust = H.arena_dev(orb);
-  D.pt_off = H.arena_dev(pt_off); D.cam_off = H.arena_dev(cam_off);
-  D.cam_obs = H.arena_dev(cam_obs); D.cam_obs_pt = H.arena_dev(cam_obs_pt);
-  D.cam_pos = H.arena_dev(cam_pos); D.Hc = H.alloc<double>(3 * (size_t)std::max(nobs, 1), &rc);
-  D.free_cams = H.arena2_dev(H.arena2_copy(free_cams.data(), nfc, &rc));
-  D.row_meta = H.arena2_dev(H.arena2_copy(row_meta.data(), row_meta.size(), &rc));
-  D.seg = H.arena2_dev(H.arena2_copy(segs.data(), segs.size(), &rc));
-  D.pair_i = H.arena2_dev(pair_i); D.pair_j = H.arena2_dev(pair_j);
-  D.B = H.alloc<double>(21 * (size_t)std::max(nfc, 1), &rc); D.gc = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc);
-  D.C = H.alloc<double>(6 * (size_t)npts, &rc); D.gp = H.alloc<double>(3 * (size_t)npts, &rc);
-  D.scale_c = H.alloc<double>(6 * (size_t)std::max(nfc, 1), &rc); D.scale_p = H.alloc<double>(3 * (size_t)npts, &rc);
-  D.Cinv = H.alloc<double>(6 * (size_t)npts, &rc); D.gps = H.alloc<double>(3 * (size_t)npts, &rc); D.Ng = H.alloc<double>(9 * (size_t)npts, &rc);
-  D.E = H.alloc<double>(8 * (size_t)std::max(nobs, 1), &rc);
-  D.t3 = H.alloc<double>(3 * (size_t)std::max(nobs, 1), &rc);
-  D.cam_local = in.cam_local ? H.arena_dev(H.arena_copy(in.cam_local, ncam, &rc)) : nullptr;
-  D.erase = in.cam_local ? H.alloc<unsigned char>(std::max(nobs, 1), &rc) : nullptr;
-  D.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); D.rhs = H.alloc<double>(npad, &rc);
-  D.Dinv = H.alloc<double>((size_t)npad * NB, &rc);
-  D.Mb = H.alloc<double>((size_t)npad * NB, &rc); { const int nbm = npad / NB, ntm = (nbm + 1) / 2; D.ncflags = std::max(256 /* CP_NFLAGS */, 2 + 3 * (nbm + 2) + ntm * ntm + 8); D.cflags = H.alloc<int>(D.ncflags, &rc); }
-  D.part = H.alloc<double>(6 * (size_t)nparts, &rc);
-  D.st = H.alloc<BaState>(1, &rc);
-  if (rc) return rc;
-  out->h_st = nullptr;                                        // (the LM state, rhs and partial sums are initialised by k_ba_init for the whole batch)
-  if (int r = H.flush_arena(s)) return r;
-  if (int r = H.flush_arena2(s)) return r;
-  out->D = D; out->nb_obs = nb_obs; out->nb_cam = nb_cam; out->nb_pt = nb_pt; out->npairs = npairs_all;
-  out->perm.swap(perm); out->h_rob = orb;
-  return 0;
-}
-
-// ---- a batch of independent problems solved in lockstep: every launch covers all of them (grid.y = problem) --------------
-// The LM control flow of each problem lives in its own device-side BaState, so finished problems simply fall through.
-// One LM iteration is a fixed sequence of ~60 launches: it is captured once into a hipGraph and replayed (one graph
-// launch per iteration); instantiated graphs are cached per host thread, keyed by the full kernel-argument blocks
-// (sizes and workspace pointers), so repeated solves of the same shape skip the capture too.  ORBHIP_BA_GRAPH=0 = direct.
-static int ba_solve_batch_impl(const BaInputs* in, int nprob, const ba_options* opts, ba_summary* summaries, bool reuse_structure = false,
-                               uint8_t* const* erase_out = nullptr) {
-  ORBHIP_REQUIRE(in && opts && nprob > 0, ORBHIP_EINVAL, "NULL argument");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
-  if (int rcd = use_default_device()) return rcd;
-  const bool timing = std::getenv("ORBHIP_BA_TIMING") != nullptr;
-  const double t_start = ba_now_ms();
-  hipStream_t s = thread_stream();
-  int rc = 0;
-  unsigned char* stop_host = nullptr; const volatile unsigned char* stop_devp = nullptr;
-  if (int r = stop_mirror(&stop_host, &stop_devp)) return r;
-  *stop_host = 0;                                         // (no solve of this thread is in flight: every call drains its stream)
-  BaBatch& B = g_batch;
-  bool reused = false;
-  if (reuse_structure && g_batch_valid && (int)B.P.size() == nprob) {
-    // same cameras, points and observation lists as the batch still resident in this thread's workspace (the caller
-    // guarantees it; sizes are re-checked): only the loss flags and the iteration cap change, the solve starts from the
-    // poses / points the previous solve left on the device.  No structure pass, no pair lists, no uploads but the flags.
-    reused = true;
-    for (int p = 0; p < nprob; p++)
-      reused = reused && B.Dh[p].ncam == in[p].ncam && B.Dh[p].npts == in[p].npts && B.Dh[p].nobs == in[p].nobs && B.Dh[p].fix_points == (opts->fix_points ? 1 : 0);
-  }
-  if (reused) {
-    for (int p = 0; p < nprob; p++) {
-      const BaDev& D = B.Dh[p];
-      BaPrepared& Pp = B.P[p];
-      for (int j = 0; j < D.nobs; j++) Pp.h_rob[j] = in[p].obs_robust[Pp.perm[j]];
-      if (D.nobs) ORBHIP_CHECK_HIP(hipMemcpyAsync(const_cast<unsigned char*>(D.obs_robust), Pp.h_rob, D.nobs, hipMemcpyHostToDevice, s));
-      Pp.t_struct_ms = 0.0;
-    }
-  } else {
-    HostBA H;                                             // (invalidates the resident batch)
-    B.P.assign(nprob, BaPrepared()); B.Dh.assign(nprob, BaDev());
-    B.g_npad_la = 0; B.g_npad_2l = 0;
-    B.g_obs = 1; B.g_cam = 1; B.g_pt = 1; B.g_blk = 0; B.g_npad = NB; B.g_pad = 0; B.g_n6 = 0; B.g_camcount = 1; B.g_apply = 1; B.g_zero = 0;
-    for (int p = 0; p < nprob; p++) {
-      if (int r = ba_prepare(H, s, in[p], opts, &B.P[p])) return r;
-      B.P[p].D.stop_dev = stop_devp;
-      const BaDev& D = B.P[p].D;
-      B.Dh[p] = D;
-      B.g_obs = std::max(B.g_obs, B.P[p].nb_obs); B.g_cam = std::max(B.g_cam, B.P[p].nb_cam); B.g_pt = std::max(B.g_pt, B.P[p].nb_pt);
-      B.g_blk = std::max(B.g_blk, D.nfc);      /* k_ba_schur: a workgroup per block row */
-      B.g_npad = std::max(B.g_npad, D.npad); B.g_pad = std::max(B.g_pad, D.npad - D.n6); B.g_n6 = std::max(B.g_n6, D.n6);
-      B.g_camcount = std::max(B.g_camcount, D.ncam); B.g_apply = std::max(B.g_apply, std::max(7 * D.ncam, 3 * D.npts));
-      B.g_zero = std::max(B.g_zero, (size_t)D.n6 * D.npad);
-      if (D.chol_la) B.g_npad_la = std::max(B.g_npad_la, D.npad); else B.g_npad_2l = std::max(B.g_npad_2l, D.npad);
-    }
-    // the batch's output block: one slice per problem
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    B.out_off.assign(nprob, 0); B.out_bytes = 0;
-    for (int p = 0; p < nprob; p++) {
-      B.out_off[p] = B.out_bytes;
-      B.out_bytes += al(sizeof(BaState)) + al(7 * (size_t)in[p].ncam * sizeof(double)) + al(3 * (size_t)in[p].npts * sizeof(double)) + al((size_t)std::max(in[p].nobs, 1));
-    }
-    B.out_d = H.alloc<unsigned char>(B.out_bytes, &rc); B.out_h = H.pinned<unsigned char>(B.out_bytes, &rc);
-    if (rc) return rc;
-    for (int p = 0; p < nprob; p++) { B.Dh[p].out = B.out_d + B.out_off[p]; B.P[p].D.out = B.Dh[p].out; }
-    B.Dv = H.upload_staged(B.Dh.data(), nprob, &rc, s);
-    if (rc) return rc;
-    g_batch_valid = true;
-  }
-  {
-    BaState st0; std::memset(&st0, 0, sizeof(st0));
-    st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = opts->max_iterations;
-    hipLaunchKernelGGL(k_ba_init, dim3(4, (unsigned)nprob), dim3(256), 0, s, B.Dv, st0);
-  }
-  std::vector<BaPrepared>& P = B.P;
-  std::vector<BaDev>& Dh = B.Dh;
-  const BaDev* Dv = B.Dv;
-  const int g_obs = B.g_obs, g_cam = B.g_cam, g_pt = B.g_pt, g_blk = B.g_blk, g_npad = B.g_npad, g_pad = B.g_pad, g_n6 = B.g_n6, g_camcount = B.g_camcount, g_apply = B.g_apply;
-  const size_t g_zero = B.g_zero;
-  const double t_upload = ba_now_ms();
-  const bool prof = g_ba_profiling.load() != 0;
-  if (prof) {
-    for (int k = 0; k < 2; k++) if (!g_prof_ev[k]) ORBHIP_CHECK_HIP(hipEventCreate(&g_prof_ev[k]));
-    ORBHIP_CHECK_HIP(hipEventRecord(g_prof_ev[0], s));
-  }
-  const unsigned ny = (unsigned)nprob;
-  if (int r = raise_dynamic_lds((const void*)k_ba_schur, g_stream_device, SR_LDS_BYTES)) return r;
-  if (int r = raise_dynamic_lds((const void*)k_chol_wg, g_stream_device, CW_LDS_DOUBLES * sizeof(double))) return r;
-  const int npad_all = g_npad;
-  // ---- which form of the Cholesky this solve takes (0 step kernels, 1 persistent launches, 2 the one-launch two-level kernel)
-  static const int persist_max = []() {
-    const char* e = std::getenv("ORBHIP_BA_PERSIST");      // 0: the step kernels (the bit-identity tests), 1 (default): the persistent launches; 2 = the one-launch kernel, ORBHIP_EXPERIMENTS builds only
-#ifdef ORBHIP_EXPERIMENTS
-    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
-#else
-    return e && e[0] == '0' ? 0 : 1;
-#endif
-  }();
-  static const int OB = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_BA_OB"); const int v = e ? atoi(e) : 128; return (v >= 64 && v <= 1024 && v % 32 == 0) ? v : 128; }();
-  PersistLease lease;
-  int persist_mode = 0, p2_workers = 0, persist_cus = 0;
-  if (persist_max > 0 && ny < 4 && B.g_npad_la <= 1024) {
-    static thread_local int cus = 0, occ2l = 0, occ1 = 0, cu_dev = -1;
-    if (cu_dev != g_stream_device) {
-      hipDeviceProp_t prop;
-      cus = hipGetDeviceProperties(&prop, g_stream_device) == hipSuccess ? prop.multiProcessorCount : 0;
-      (void)raise_dynamic_lds((const void*)k_chol_persist, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
-      (void)raise_dynamic_lds((const void*)k_chol_persist_blk, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
-#ifdef ORBHIP_EXPERIMENTS
-      (void)raise_dynamic_lds((const void*)k_chol_persist_2l, g_stream_device, CP_LDS_DOUBLES * sizeof(double));
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2l, k_chol_persist_2l, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) occ2l = 0;
-#endif
-      int oa = 0, ob = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&oa, k_chol_persist, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) oa = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ob, k_chol_persist_blk, 256, CP_LDS_DOUBLES * sizeof(double)) != hipSuccess) ob = 0;
-      occ1 = std::min(oa, ob);
-      (void)hipGetLastError();
-      cu_dev = g_stream_device;
-    }
-    persist_cus = cus * std::max(occ1, 1);
-    const int cap = cus * std::min(occ1, 2) * 9 / 10;         // resident workgroups of the persistent kernels the device holds (registers / 76 KB LDS), with a margin
-    int need = 0;
-    if (B.g_npad_la > 0) { const int nbm = B.g_npad_la / NB; int nwg = 3; for (int i = 2; i < nbm; i++) nwg += 1 + (i - 1 + CP_CH - 1) / CP_CH; need += nwg * (int)ny; }
-    if (B.g_npad_2l > 0) need += (B.g_npad_2l / NB + 2) * (int)ny;
-    // the one-launch kernel: a single large problem, outer blocks of 2 or 4 panels, the whole device
-    const int nbm2 = B.g_npad_2l / NB, ntm2 = (nbm2 + 1) / 2, cap2 = occ2l * cus * 9 / 10;
-    if (persist_max >= 2 && ny == 1 && B.g_npad_la == 0 && nbm2 >= 8 && (OB == 64 || OB == 128) && cap2 - nbm2 >= std::max(64, ntm2) && lease.take(g_stream_device, std::max(cap, 1), std::max(cap, 1))) {
-      persist_mode = 2; p2_workers = std::min(384, cap2 - nbm2);
-    } else if (need > 0 && lease.take(g_stream_device, need, cap)) persist_mode = 1;
-  }
-  if (g_pad > 0) hipLaunchKernelGGL(k_ba_pad, dim3(g_pad, ny), dim3(64), 0, s, Dv);
-  auto enqueue_eval = [&]() {
-    hipLaunchKernelGGL(k_ba_eval<0>, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
-    hipLaunchKernelGGL(k_ba_cam_blocks, dim3(g_camcount + g_pt, ny), dim3(BA_TPB), 0, s, Dv, g_camcount);      // + the landmark blocks
-    hipLaunchKernelGGL(k_ba_after_eval, dim3(1, ny), dim3(AE_TPB), 0, s, Dv);
-  };
-  auto enqueue_iteration = [&]() {
-    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(64), 0, s, Dv);
-    const int g_zs = g_n6 > 0 ? std::min(1024, (int)((g_zero + 255) / 256)) : 0;
-    hipLaunchKernelGGL(k_ba_schur_prep, dim3(g_pt + g_zs, ny), dim3(BA_TPB), 0, s, Dv, g_pt);                    // + zeroing of S
-    if (g_blk > 0) hipLaunchKernelGGL(k_ba_schur, dim3(g_blk, ny), dim3(SC_TPB), SR_LDS_BYTES, s, Dv);      // one workgroup per block row
-    const int npad = B.g_npad_2l;                             // (0 when every problem of the batch takes the look-ahead scheme)
-    auto launch_update = [&](hipStream_t st_, int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
-      if (c_hi <= c_lo || r_lo >= npad + 1) return;
-      const int tiles_r = (npad - r_lo + 63) / 64, tiles_c = (c_hi - c_lo + 63) / 64;
-      const int ntiles = std::max(tiles_r, 0) * tiles_c;
-      const int nrhs = (c_hi - c_lo + 255) / 256;
-      hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs, ny), dim3(256), 0, st_, Dv, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles);
-    };
-    // one look-ahead step: panel k + the previous step's update of the columns [k + 32, c_end) (c_end = min(cap, n))
-    // + (hybrid) this step's share of the previous outer block's wide update
-    auto launch_la = [&](int np_, int k, int k0, int c_cap, int hybrid, CholWide w) {
-      const int rows_below = np_ - k - NB;
-      const int r_lo = k + NB, c_end = std::min(c_cap, np_);
-      int tiles_c = 1, ntiles = 0, nrhs = 0;
-      if (k > k0 && r_lo < c_end) { tiles_c = (c_end - r_lo + 63) / 64; ntiles = ((np_ - r_lo + 63) / 64) * tiles_c; nrhs = (c_end - r_lo + 255) / 256; }
-      const int nC = w.nq > 0 ? (w.total - w.q + w.nq - 1) / w.nq + (w.q == 0 ? w.nrhs : 0) : 0;
-      if (ny >= 4 && np_ <= 1024) { const int nA = (rows_below + 1 + 255) / 256; hipLaunchKernelGGL(k_chol_la<4>, dim3(nA + ntiles + nrhs + nC, ny), dim3(256), 0, s, Dv, k, k0, c_cap, nA, tiles_c, ntiles, ntiles + nrhs, hybrid, w); }
-      else { const int nA = (rows_below + 1 + 63) / 64; hipLaunchKernelGGL(k_chol_la<1>, dim3(nA + ntiles + nrhs + nC, ny), dim3(256), 0, s, Dv, k, k0, c_cap, nA, tiles_c, ntiles, ntiles + nrhs, hybrid, w); }
-    };
-    const CholWide no_wide = {0, 0, 0, 1, 0, 0, 0, 0};
-    // look-ahead scheme (reduced systems <= 1024): one launch per 32-column step, panel + the previous step's update
-    // (fewer than four problems: the whole factorisation as ONE persistent launch, bit-identical to the steps; ORBHIP_BA_PERSIST=0 disables)
-    const bool use_persist = persist_mode > 0;
-    static const bool wg_on = []() { const char* e = std::getenv("ORBHIP_BA_WG"); return !(e && e[0] == '0'); }();      // (0: the step kernels, for the bit-identity tests)
-    const bool use_wg = wg_on && ny >= 32;                  // (a workgroup takes ~1 ms per factorisation whatever the batch: below ~32 problems the step kernels' 19 launches are shorter; same bits either way)
-    if (use_persist && B.g_npad_la > 0) {                     // (<= 32 block rows: the flag arrays; ORBHIP_BA_LA_MAX can push larger systems onto the look-ahead steps)
-      const int nbm = B.g_npad_la / NB;
-      int nwg = 3;                                            // the chain, producer + consumers of the rows 2 .. nb - 1, the rhs row's two
-      for (int i = 2; i < nbm; i++) nwg += 1 + (i - 1 + CP_CH - 1) / CP_CH;
-      hipLaunchKernelGGL(k_chol_persist, dim3(nwg, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv);
-    } else if (use_wg && B.g_npad_la > 0) {                   // lockstep batches: one workgroup per problem, the whole factorisation in one launch
-      hipLaunchKernelGGL(k_chol_wg, dim3(ny), dim3(CW_TPB), CW_LDS_DOUBLES * sizeof(double), s, Dv);
-    } else
-    for (int k = 0, npl = B.g_npad_la; k < npl; k += NB) launch_la(npl, k, 0, INT_MAX, 0, no_wide);
-    // two-level scheme (outer block = 4 panels of NB = 32) for the larger systems.
-    static const bool classic = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_BA_2L_CLASSIC"); return e && e[0] == '1'; }();
-    if (classic) {
-      // round-1 form: panel -> thin update -> panel ... -> one wide update
-      for (int k0 = 0; k0 < npad; k0 += OB) {
-        const int kend = std::min(k0 + OB, npad);
-        for (int k = k0; k < kend; k += NB) {
-          const int rows_below = npad - k - NB;
-          if (ny >= 4 && npad <= 1024) hipLaunchKernelGGL(k_chol_panel<4>, dim3((rows_below + 1 + 255) / 256, ny), dim3(256), 0, s, Dv, k);
-          else hipLaunchKernelGGL(k_chol_panel<1>, dim3((rows_below + 1 + 63) / 64, ny), dim3(256), 0, s, Dv, k);   // +1: augmented rhs row
-          if (k + NB < kend) launch_update(s, k, NB, k + NB, k + NB, kend, k0 + OB);      // thin update inside the outer block
-        }
-        if (kend < npad) launch_update(s, k0, kend - k0, kend, kend, npad, INT_MAX);      // one wide update for everything to the right
-      }
-#ifdef ORBHIP_EXPERIMENTS
-    } else if (npad > 0 && persist_mode == 2) {
-      hipLaunchKernelGGL(k_chol_persist_2l, dim3(npad / NB + p2_workers, ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, OB / NB, p2_workers);
-#endif
-    } else if (npad > 0) {
-      // hybrid: the steps of an outer block are look-ahead launches confined to the block (the thin updates leave the serial
-      // chain); of its K = 128 update only the NEXT outer block's 128 columns are a launch of their own (the chain needs
-      // them), everything further right rides along with the next block's steps (role C).  One stream: every entry still
-      // receives its updates in one fixed order.
-      CholWide w = no_wide;
-      for (int k0 = 0; k0 < npad; k0 += OB) {
-        const int kend = std::min(k0 + OB, npad);
-        w.nq = w.total > 0 ? (kend - k0) / NB : 0;
-        if (use_persist) {
-          // one persistent launch per outer block: the chain, a workgroup per block row below, the previous block's K = 128 update
-          const int nbm = npad / NB, nend_ = std::min(kend + OB, npad);
-          BlkGeo geo;
-          geo.jb0 = k0 / NB; geo.ns = (kend - k0) / NB; geo.blk = k0 / OB; geo.base = std::max(nbm - (geo.jb0 + 2), 0) + 2;
-          geo.kend = kend / NB; geo.nend = nend_ / NB;
-          geo.tcn = kend < npad ? (nend_ - kend + 63) / 64 : 0;
-          geo.n_tiles_n = geo.tcn * ((npad - kend + 63) / 64);
-          geo.n_rhs_n = kend < npad ? (nend_ - kend + 255) / 256 : 0;
-          geo.n_tiles_c = w.total > 0 ? ((w.tiles_c + 1) / 2) * std::max(w.tiles_c - geo.tcn, 0) : 0;      // items of two vertically adjacent tiles
-          // the pool behind the rows: the owners of the next block's tiles + as many workgroups as the device holds besides (they
-          // all draw from the queue of the previous block's far tiles)
-          const int n_items = w.total > 0 ? geo.n_tiles_c + w.nrhs : 0;
-          const int n_pool = std::max(geo.n_tiles_n + geo.n_rhs_n, std::min(n_items, persist_cus - geo.base));
-          hipLaunchKernelGGL(k_chol_persist_blk, dim3(geo.base + std::max(n_pool, 0), ny), dim3(256), CP_LDS_DOUBLES * sizeof(double), s, Dv, geo, w);
-        } else
-        for (int k = k0, q = 0; k < kend; k += NB, q++) { w.q = q; launch_la(npad, k, k0, k0 + OB, 1, w); }
-        w = no_wide;
-        if (kend >= npad) break;
-        const int nend = std::min(kend + OB, npad);
-        if (!use_persist) launch_update(s, k0, kend - k0, kend, kend, nend, kend + OB);      // (the persistent launch did it itself)
-        if (nend < npad) {
-          const int t = (npad - nend + 63) / 64;
-          w.kcol = k0; w.K = kend - k0; w.lo = nend; w.tiles_c = t; w.total = t * t; w.nrhs = (npad - nend + 255) / 256;
-        }
-      }
-    }
-    for (int kb = ((npad_all - 1) / SBLK) * SBLK; kb >= 0; kb -= SBLK) {
-      hipLaunchKernelGGL(k_chol_bsolve_diag, dim3(1, ny), dim3(1024), 0, s, Dv, kb);
-      if (kb > 0) hipLaunchKernelGGL(k_chol_bsolve_update, dim3((kb + 63) / 64, ny), dim3(1024), 0, s, Dv, kb);
-    }
-    hipLaunchKernelGGL(k_ba_cam_update, dim3(g_cam, ny), dim3(BA_TPB), 0, s, Dv);
-    hipLaunchKernelGGL(k_ba_backsub, dim3(g_pt, ny), dim3(BS_TPB), 0, s, Dv, 0);
-    hipLaunchKernelGGL(k_ba_eval<1>, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
-    hipLaunchKernelGGL(k_ba_iter_end, dim3(1, ny), dim3(BA_TPB), 0, s, Dv);
-    hipLaunchKernelGGL(k_ba_apply, dim3((g_apply + BA_TPB - 1) / BA_TPB, ny), dim3(BA_TPB), 0, s, Dv);
-    enqueue_eval();
-  };
-  const volatile uint8_t* stop = opts->stop_flag;
-  enqueue_eval();                                             // iteration 0
-  bool user_stop = stop && *stop;                             // StopFlagCallback after iteration 0
-  hipGraphExec_t gexec = nullptr;
-  static const bool use_graph = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_BA_GRAPH"); return !(e && e[0] == '0'); }();
-  if (use_graph && opts->max_iterations >= 3 && !user_stop) {
-    for (auto& e : g_graphs)
-      if (e.exec && e.Dv == Dv && e.mode == persist_mode && e.D.size() == Dh.size() && std::memcmp(e.D.data(), Dh.data(), Dh.size() * sizeof(BaDev)) == 0) { gexec = e.exec; e.stamp = ++g_graph_clock; break; }
-    if (!gexec) {
-      hipGraph_t graph = nullptr;
-      ORBHIP_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      enqueue_iteration();
-      ORBHIP_CHECK_HIP(hipStreamEndCapture(s, &graph));
-      hipError_t ge = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (ge != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ge)); return ORBHIP_ENODEV; }
-      GraphCacheEntry* slot = nullptr;
-      if (g_graphs.size() < 4) { g_graphs.emplace_back(); slot = &g_graphs.back(); }
-      else { slot = &g_graphs[0]; for (auto& e : g_graphs) if (e.stamp < slot->stamp) slot = &e; }
-      if (slot->exec) { ORBHIP_CHECK_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(slot->exec); }
-      slot->D = Dh; slot->Dv = Dv; slot->mode = persist_mode; slot->exec = gexec; slot->stamp = ++g_graph_clock;
-    }
-  }
-  for (int it = 0; it < opts->max_iterations + 1 && !user_stop; it++) {
-    // the pass after the last iteration only has to record "iteration cap reached": its first kernel does that, the other
-    // ~60 launches of the graph would all fall through (0.2 ms per solve at C4 size)
-    if (it == opts->max_iterations) hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, ny), dim3(64), 0, s, Dv);
-    else if (gexec) ORBHIP_CHECK_HIP(hipGraphLaunch(gexec, s));
-    else enqueue_iteration();
-    if (stop && *stop) { __atomic_store_n(stop_host, (unsigned char)1, __ATOMIC_RELEASE); user_stop = true; }   // the device stops at its next iteration boundary
-    if ((it & 7) == 7 && it + 8 < opts->max_iterations) {     // all converged early? (poll every 8 iterations of long solves)
-      std::vector<BaState> cur(nprob);
-      for (int p = 0; p < nprob; p++) ORBHIP_CHECK_HIP(hipMemcpyAsync(&cur[p], Dh[p].st, sizeof(BaState), hipMemcpyDeviceToHost, s));
-      ORBHIP_CHECK_HIP(wait_stream_forwarding_stop(s, stop, stop_host));
-      bool all = true;
-      for (int p = 0; p < nprob; p++) all = all && cur[p].done;
-      if (all) break;
-    }
-  }
-  const double t_enq = ba_now_ms();
-  if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1, ny), dim3(1), 0, s, Dv);
-  ORBHIP_CHECK_HIP(hipGetLastError());
-  if (prof) ORBHIP_CHECK_HIP(hipEventRecord(g_prof_ev[1], s));
-  // the iterations are all enqueued: a flag raised from now on reaches the device through the mirror (StopFlagCallback is
-  // polled after EVERY iteration, include/CeresOptimizer.h:332-349), the iterations behind it fall through
-  if (stop) ORBHIP_CHECK_HIP(wait_stream_forwarding_stop(s, stop, stop_host));
-  std::vector<BaState> fin(nprob);
-  const bool classify = erase_out != nullptr && Dh[0].erase != nullptr;
-  if (classify) hipLaunchKernelGGL(k_ba_classify, dim3(g_obs, ny), dim3(BA_TPB), 0, s, Dv);
-  hipLaunchKernelGGL(k_ba_collect, dim3(16, ny), dim3(256), 0, s, Dv, classify ? 1 : 0);
-  ORBHIP_CHECK_HIP(hipGetLastError());
-  // (the megabyte-sized blocks of a solve stay on the copy engines: by kernel - as the per-frame calls' small blocks go, common.h - a
-  // 12-thread batched LocalBA lost 4 %: 2545-2608 against 2689-2726 solves/s)
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(B.out_h, B.out_d, B.out_bytes, hipMemcpyDeviceToHost, s));
-  ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
-  {
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    for (int p = 0; p < nprob; p++) {
-      const unsigned char* o = B.out_h + B.out_off[p];
-      std::memcpy(&fin[p], o, sizeof(BaState)); o += al(sizeof(BaState));
-      std::memcpy(in[p].poses7, o, 7 * (size_t)in[p].ncam * sizeof(double)); o += al(7 * (size_t)in[p].ncam * sizeof(double));
-      if (in[p].npts) std::memcpy(in[p].pts3, o, 3 * (size_t)in[p].npts * sizeof(double));
-      o += al(3 * (size_t)in[p].npts * sizeof(double));
-      if (classify && in[p].nobs) std::memcpy(P[p].h_rob, o, in[p].nobs);
-    }
-  }
-  if (prof) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_prof_ev[0], g_prof_ev[1]) == hipSuccess) g_prof_ms += ms;
-    g_prof_solves += nprob;
-    for (int p = 0; p < nprob; p++) g_prof_iters += fin[p].iteration;
-  }
-  if (timing) {
-    double ts = 0; size_t pairs = 0; long nobs = 0;
-    for (int p = 0; p < nprob; p++) { ts += P[p].t_struct_ms; pairs += P[p].npairs; nobs += in[p].nobs; }
-    fprintf(stderr, "[ba_solve] problems=%d nobs=%ld pairs=%zu | structure %.2f ms, prepare+upload %.2f ms, enqueue %.2f ms, drain+download %.2f ms\n",
-            nprob, nobs, pairs, ts, t_upload - t_start, t_enq - t_upload, ba_now_ms() - t_enq);
-  }
-  if (classify)
-    for (int p = 0; p < nprob; p++)
-      for (int j = 0; j < in[p].nobs; j++) erase_out[p][P[p].perm[j]] = P[p].h_rob[j];
-  if (summaries)
-    for (int p = 0; p < nprob; p++) {
-      ba_summary& o = summaries[p];
-      o.initial_cost = fin[p].initial_cost; o.final_cost = fin[p].x_cost; o.iterations = fin[p].iteration;
-      o.successful_steps = fin[p].successful_steps; o.termination = fin[p].termination; o.final_radius = fin[p].radius;
-    }
-  for (int p = 0; p < nprob; p++)
-    if (fin[p].termination == 7) {
-      set_error("problem %d of %d: a workgroup of the persistent Cholesky waited longer than the time limit for another one "
-                "(the device is oversubscribed or hung); the outputs hold the last accepted iterate", p, nprob);
-      return ORBHIP_ETIMEOUT;
-    }
-  return 0;
-}
-
-int ba_solve_impl(const double* K4, double* poses7, const uint8_t* cam_fixed, int ncam, double* pts3, int npts,
-                  const int32_t* obs_cam_in, const int32_t* obs_pt_in, const double* obs_uv_in, const double* obs_w_in,
-                  const uint8_t* obs_robust_in, int nobs, const ba_options* opts, ba_summary* summary) {
-  ORBHIP_REQUIRE(opts, ORBHIP_EINVAL, "NULL options");
-  BaInputs in{K4, poses7, cam_fixed, ncam, pts3, npts, obs_cam_in, obs_pt_in, obs_uv_in, obs_w_in, obs_robust_in, nobs};
-  return ba_solve_batch_impl(&in, 1, opts, summary);
-}
-
-}  // namespace
-
-namespace {
-
-int pg_solve_impl(double* lie7, const uint8_t* kf_fixed, int n, const int32_t* edge_j, const int32_t* edge_i, const double* edge_Sji, int ne,
-                  int max_iterations, const volatile uint8_t* stop, ba_summary* summary) {
-  ORBHIP_REQUIRE(lie7 && kf_fixed && n > 0 && ne >= 0 && max_iterations >= 0, ORBHIP_EINVAL, "NULL argument");
-  ORBHIP_REQUIRE(ne == 0 || (edge_j && edge_i && edge_Sji), ORBHIP_EINVAL, "NULL edge arrays");
-  for (int e = 0; e < ne; e++)
-    ORBHIP_REQUIRE(edge_j[e] >= 0 && edge_j[e] < n && edge_i[e] >= 0 && edge_i[e] < n && edge_i[e] != edge_j[e], ORBHIP_EINVAL, "edge vertex out of range");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (the HIP path has no CPU fallback)"); return ORBHIP_ENODEV; }
-  if (int rcd = use_default_device()) return rcd;
-  std::vector<int> col(n, -1);
-  int nf = 0;
-  for (int v = 0; v < n; v++) if (!kf_fixed[v]) col[v] = nf++;
-  const int n7 = 7 * nf, npad = std::max(round_up(std::max(n7, 1), NB), NB);
-  // The reduced system is dense: (npad + 1) * npad doubles.  Round 1 refused more than 2340 free keyframes (npad > 16384); the
-  // factorisation itself has no size limit (all offsets are 64-bit), so the only bound is device memory: 4700 keyframes need
-  // 8.7 GB, 10000 keyframes 39 GB of the 288 GB.  (The reference's sparse Cholesky has no limit either.)
-  { size_t free_b = 0, total_b = 0;
-    const size_t need = ((size_t)(npad + 1) * npad + (size_t)npad * NB) * sizeof(double);
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b) {
-      set_error("essential graph with %d free keyframes needs %.1f GB for the dense reduced system, %.1f GB free on the device", nf, need / 1e9, free_b / 1e9);
-      return ORBHIP_ECAP;
-    } }
-  // incident edge lists (insertion order) and off-diagonal block lists
-  std::vector<int> v_off(n + 1, 0), v_edge(2 * (size_t)ne); std::vector<signed char> v_sign(2 * (size_t)ne);
-  for (int e = 0; e < ne; e++) { v_off[edge_i[e] + 1]++; v_off[edge_j[e] + 1]++; }
-  for (int v = 0; v < n; v++) v_off[v + 1] += v_off[v];
-  { std::vector<int> fill(v_off.begin(), v_off.end() - 1);
-    for (int e = 0; e < ne; e++) { int q = fill[edge_i[e]]++; v_edge[q] = e; v_sign[q] = 1; q = fill[edge_j[e]]++; v_edge[q] = e; v_sign[q] = -1; } }
-  std::vector<std::pair<long long, int>> keyed;
-  for (int e = 0; e < ne; e++) {
-    const int ci = col[edge_i[e]], cj = col[edge_j[e]];
-    if (ci < 0 || cj < 0) continue;
-    const int a = std::max(ci, cj), b = std::min(ci, cj);
-    keyed.push_back({(long long)a * nf + b, e});
-  }
-  std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<long long, int>& x, const std::pair<long long, int>& y) { return x.first < y.first; });
-  std::vector<int> blk_a, blk_b, blk_off(1, 0), blk_edge;
-  for (size_t k = 0; k < keyed.size(); k++) {
-    if (k == 0 || keyed[k].first != keyed[k - 1].first) {
-      if (k) blk_off.push_back((int)blk_edge.size());
-      blk_a.push_back((int)(keyed[k].first / nf)); blk_b.push_back((int)(keyed[k].first % nf));
-    }
-    blk_edge.push_back(keyed[k].second);
-  }
-  if (!keyed.empty()) blk_off.push_back((int)blk_edge.size());
-  const int nblk = (int)blk_a.size();
-  const int nb_e = std::max((ne + 127) / 128, 1), nb_v = (n + 127) / 128;
-  const int nparts = std::max(std::max(nb_e, nb_v), std::max((ne + BA_TPB - 1) / BA_TPB, (n + BA_TPB - 1) / BA_TPB));
-
-  hipStream_t s = thread_stream();
-  HostBA H; int rc = 0;
-  PgDev P; std::memset(&P, 0, sizeof(P));
-  P.n = n; P.nf = nf; P.n7 = n7; P.npad = npad; P.ne = ne; P.nblk = nblk; P.nparts = nparts;
-  P.x = H.upload(lie7, 7 * (size_t)n, &rc, s); P.cand = H.alloc<double>(7 * (size_t)n, &rc); P.col = H.upload(col.data(), n, &rc, s);
-  P.ej = H.upload(edge_j, ne, &rc, s); P.ei = H.upload(edge_i, ne, &rc, s); P.Sji = H.upload(edge_Sji, 7 * (size_t)ne, &rc, s);
-  P.r = H.alloc<double>(7 * (size_t)std::max(ne, 1), &rc); P.J = H.alloc<double>(49 * (size_t)std::max(ne, 1), &rc);
-  P.g = H.alloc<double>(std::max(n7, 1), &rc); P.scale = H.alloc<double>(std::max(n7, 1), &rc);
-  P.v_off = H.upload(v_off.data(), n + 1, &rc, s); P.v_edge = H.upload(v_edge.data(), v_edge.size(), &rc, s); P.v_sign = H.upload(v_sign.data(), v_sign.size(), &rc, s);
-  P.blk_a = H.upload(blk_a.data(), nblk, &rc, s); P.blk_b = H.upload(blk_b.data(), nblk, &rc, s); P.blk_off = H.upload(blk_off.data(), blk_off.size(), &rc, s);
-  P.blk_edge = H.upload(blk_edge.data(), blk_edge.size(), &rc, s);
-  P.vpart = H.alloc<double>(2 * (size_t)n, &rc);
-  P.S = H.alloc<double>((size_t)(npad + 1) * npad, &rc); P.rhs = H.alloc<double>(npad, &rc);
-  double* Dinv = H.alloc<double>((size_t)npad * NB, &rc);
-  P.part = H.alloc<double>(6 * (size_t)nparts, &rc);      // (row 5: the cameras' share of the model cost change in the BA kernels; k_ba_iter_end reads it - zero here)
-  P.st = H.alloc<BaState>(1, &rc);
-  if (rc) return rc;
-  // the view through which the shared Cholesky / controller kernels see this problem (sizes chosen so that k_ba_iter_end
-  // sums exactly the partial slots written above: candidate cost and model change per 256 edges ... see nparts)
-  BaDev F; std::memset(&F, 0, sizeof(F));
-  F.npad = npad; F.n6 = n7; F.nparts = nparts; F.S = P.S; F.rhs = P.rhs; F.Dinv = Dinv; F.part = P.part; F.st = P.st;
-  F.nobs = nb_e * BA_TPB; F.npts = nb_e * BA_TPB; F.ncam = nb_v * BA_TPB;     // -> nb_obs = nb_pt = nb_e blocks, nb_cam = nb_v blocks
-  unsigned char* stop_host = nullptr;
-  if (int r = stop_mirror(&stop_host, &F.stop_dev)) return r;
-  *stop_host = 0;
-  const BaDev* Fv = H.upload(&F, 1, &rc, s);
-  if (rc) return rc;
-  BaState st0; std::memset(&st0, 0, sizeof(st0));
-  st0.radius = 1e4; st0.decrease_factor = 2.0; st0.need_eval = 1; st0.first = 1; st0.max_iters = max_iterations;
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(P.st, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
-  ORBHIP_CHECK_HIP(hipMemsetAsync(P.rhs, 0, (size_t)npad * sizeof(double), s));
-  ORBHIP_CHECK_HIP(hipMemsetAsync(P.part, 0, 6 * (size_t)nparts * sizeof(double), s));
-  if (npad > n7) hipLaunchKernelGGL(k_pg_pad, dim3(npad - n7), dim3(64), 0, s, P);
-  auto enqueue_eval = [&]() {
-    hipLaunchKernelGGL(k_pg_eval, dim3(nb_e), dim3(128), 0, s, P, 0);
-    hipLaunchKernelGGL(k_pg_vertex, dim3(nb_v), dim3(128), 0, s, P);
-    hipLaunchKernelGGL(k_pg_after_eval, dim3(1), dim3(256), 0, s, P);
-  };
-  enqueue_eval();
-  bool user_stop = stop && *stop;
-  for (int it = 0; it < max_iterations + 1 && !user_stop && n7 > 0; it++) {
-    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1, 1), dim3(1), 0, s, Fv);
-    if (it == max_iterations) break;                          // (only records "iteration cap reached")
-    hipLaunchKernelGGL(k_ba_zero_S, dim3(std::min(1024, (int)(((size_t)n7 * npad + 255) / 256)), 1), dim3(256), 0, s, Fv);
-    hipLaunchKernelGGL(k_pg_build, dim3(n + nblk), dim3(64), 0, s, P);
-    auto launch_update = [&](int kcol, int K, int r_lo, int c_lo, int c_hi, int c_hi_cap) {
-      if (c_hi <= c_lo || r_lo >= npad + 1) return;
-      const int tiles_r = (npad - r_lo + 63) / 64, tiles_c = (c_hi - c_lo + 63) / 64;
-      const int ntiles = std::max(tiles_r, 0) * tiles_c;
-      const int nrhs = (c_hi - c_lo + 255) / 256;
-      hipLaunchKernelGGL(k_chol_syrk, dim3(ntiles + nrhs, 1), dim3(256), 0, s, Fv, kcol, K, r_lo, c_lo, c_hi_cap, tiles_c, ntiles);
-    };
-    const int OB = 128;
-    for (int k0 = 0; k0 < npad; k0 += OB) {
-      const int kend = std::min(k0 + OB, npad);
-      for (int k = k0; k < kend; k += NB) {
-        const int rows_below = npad - k - NB;
-        hipLaunchKernelGGL(k_chol_panel<1>, dim3((rows_below + 1 + 63) / 64, 1), dim3(256), 0, s, Fv, k);
-        if (k + NB < kend) launch_update(k, NB, k + NB, k + NB, kend, k0 + OB);
-      }
-      if (kend < npad) launch_update(k0, kend - k0, kend, kend, npad, INT_MAX);
-    }
-    for (int kb = ((npad - 1) / SBLK) * SBLK; kb >= 0; kb -= SBLK) {
-      hipLaunchKernelGGL(k_chol_bsolve_diag, dim3(1, 1), dim3(1024), 0, s, Fv, kb);
-      if (kb > 0) hipLaunchKernelGGL(k_chol_bsolve_update, dim3((kb + 63) / 64, 1), dim3(1024), 0, s, Fv, kb);
-    }
-    hipLaunchKernelGGL(k_pg_step, dim3(nb_v), dim3(128), 0, s, P);
-    hipLaunchKernelGGL(k_pg_mcc, dim3(nb_e), dim3(128), 0, s, P);
-    hipLaunchKernelGGL(k_pg_eval, dim3(nb_e), dim3(128), 0, s, P, 1);
-    hipLaunchKernelGGL(k_ba_iter_end, dim3(1, 1), dim3(BA_TPB), 0, s, Fv);
-    hipLaunchKernelGGL(k_pg_apply, dim3((7 * n + 255) / 256), dim3(256), 0, s, P);
-    enqueue_eval();
-    if (stop && *stop) { __atomic_store_n(stop_host, (unsigned char)1, __ATOMIC_RELEASE); user_stop = true; }
-    if ((it & 3) == 3) {                                       // converged early? (pose graphs usually need ~10 of the 100 iterations)
-      BaState cur;
-      ORBHIP_CHECK_HIP(hipMemcpyAsync(&cur, P.st, sizeof(cur), hipMemcpyDeviceToHost, s));
-      ORBHIP_CHECK_HIP(wait_stream_forwarding_stop(s, stop, stop_host));
-      if (cur.done) break;
-    }
-  }
-  if (user_stop) hipLaunchKernelGGL(k_ba_user_stop, dim3(1, 1), dim3(1), 0, s, Fv);
-  ORBHIP_CHECK_HIP(hipGetLastError());
-  if (stop) ORBHIP_CHECK_HIP(wait_stream_forwarding_stop(s, stop, stop_host));
-  BaState fin;
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(&fin, P.st, sizeof(fin), hipMemcpyDeviceToHost, s));
-  ORBHIP_CHECK_HIP(hipMemcpyAsync(lie7, P.x, 7 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-  ORBHIP_CHECK_HIP(hipStreamSynchronize(s));
-  if (summary) {
-    summary->initial_cost = fin.initial_cost; summary->final_cost = fin.x_cost; summary->iterations = fin.iteration;
-    summary->successful_steps = fin.successful_steps; summary->termination = fin.termination; summary->final_radius = fin.radius;
-  }
-  return 0;
-}
-
-}  // namespace
+#include "ba_host.inc"   // host driver
 
 extern "C" {
 
