@@ -163,3 +163,46 @@ def test_thread_count_does_not_change_results(oracle):
             assert out[4] == ref[4] and out[5] == ref[5]
     finally:
         po.set_ba_threads(1)
+
+
+def test_factored_jacobian_records_reproduce_the_oracles_blocks(oracle):
+    """The HIP path never stores Jc (2x6) and Jp (2x3): an observation keeps {W = Q^T Q, r = 2 RX} and h = Q^T res
+    (csrc/ba_solver.hip, the comment above ld_rec8) and every block of the normal equations is rebuilt from them and the camera's
+    rotation.  This checks that algebra against the oracle's own Jacobians - including the Huber corrector's scale inside Q and a
+    quaternion that is NOT normalised (Jc and Jp are built from the same RX and R, so the factorisation does not need it)."""
+    rng = np.random.default_rng(5)
+    K4 = synth.KITTI_K4
+    skew = lambda v: np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+    for k in range(40):
+        q = synth.quat_from_rotvec(rng.normal(0, 0.5, 3)) * (1.0 if k % 2 else 1.0 + 3e-3 * rng.normal()); t = rng.normal(0, 1, 3)
+        pose = np.concatenate([t, q])
+        Xc = np.array([rng.normal(0, 3), rng.normal(0, 2), rng.uniform(5, 40)])
+        X = synth.quat_to_R(q / np.linalg.norm(q)).T @ (Xc - t)
+        uv = rng.uniform(0, 500, 2) if k % 3 else np.array([3000.0, -2000.0])          # (far off: the Huber branch)
+        w = rng.uniform(0.1, 1.0)
+        res, Jc, Jp, _ = oracle.ba_eval_obs(K4, pose, X, uv, w, robust=bool(k % 3 == 0))
+        RX = oracle.quat_rotate(q, X)
+        # R as ba_math.h's quat_to_R builds it (no normalisation)
+        x, y, z, ww = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww)],
+                      [2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)],
+                      [2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)]])
+        Q = Jc[:, :3]                                                   # Jc = Q [I | -2 [RX]x]
+        W = Q.T @ Q; r = 2.0 * RX; h = Q.T @ res
+        assert abs(W[0, 1]) <= 1e-300                                    # the record keeps five numbers of W
+        tol = lambda ref: 1e-12 * max(1.0, np.abs(ref).max())
+        assert np.abs(Q @ np.hstack([np.eye(3), -skew(r)]) - Jc).max() <= tol(Jc)
+        assert np.abs(Q @ R - Jp).max() <= tol(Jp)
+        G = np.vstack([W, skew(r) @ W])                                  # E = Jc^T Jp = [W; [r]x W] R
+        assert np.abs(G @ R - Jc.T @ Jp).max() <= tol(Jc.T @ Jp)
+        K = W @ skew(r)
+        B = np.block([[W, -K], [-K.T, -skew(r) @ K]])                    # Jc^T Jc
+        assert np.abs(B - Jc.T @ Jc).max() <= tol(Jc.T @ Jc)
+        assert np.abs(np.concatenate([h, np.cross(r, h)]) - Jc.T @ res).max() <= tol(Jc.T @ res)
+        assert np.abs(R.T @ W @ R - Jp.T @ Jp).max() <= tol(Jp.T @ Jp)
+        assert np.abs(R.T @ h - Jp.T @ res).max() <= tol(Jp.T @ res)
+        # the Schur cross term of two observations of one point: X' R_b^T G_b^T with X' = [Y; [r_a]x Y], Y = W_a (R_a N)
+        N = np.diag(rng.uniform(0.5, 2.0, 3)); N = N + 0.1 * np.ones((3, 3))
+        Y = W @ (R @ N)
+        Xp = np.vstack([Y, skew(r) @ Y])
+        assert np.abs(Xp @ R.T @ G.T - (Jc.T @ Jp) @ N @ (Jc.T @ Jp).T).max() <= tol((Jc.T @ Jp) @ N @ (Jc.T @ Jp).T)
