@@ -141,7 +141,8 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
                                 flops_per_iteration=f5_schur + f5_chol, cholesky_n=6 * 499)
     # ---- C5 as BASELINE config 5 words it, on ONE GPU: the eight 500-KF sub-maps as one lockstep batch (ba_solve_batch: what a node
     #      with fewer GPUs than sub-maps does).  A single GlobalBA is bound by the latency chain of its factorisation (c5 above);
-    #      eight in lockstep share every launch of the chain.  (Eight host threads with one solve each: 464 ms against 379.)
+    #      eight in lockstep share every launch of the chain.  (Eight host threads with one solve each: 464 ms against 379; 323 with the
+    #      structure passes of the eight problems on four host threads.)
     def _sub(g):
         w = np.asarray(g["obs_inv_sigma2"], np.float32).astype(np.float64)          # F7: weight = invSigma2 (a float in the reference)
         return (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, np.ones(len(w), np.uint8))
@@ -153,7 +154,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     it8 = sum(int(r8[2]["iterations"]) for r8 in res8)
     roof["cases"]["c5_batched8"] = _roof((f5_schur + f5_chol) * it8, dt8,
                                          "eight distinct 500-KF GlobalBA sub-maps as one lockstep batch on this GPU; wall time of their %d LM "
-                                         "iterations, copies and host structure setup (one host thread) included" % it8)
+                                         "iterations, copies and host structure setup (the calling thread and its helpers, ORBHIP_BA_PREP_THREADS) included" % it8)
     out["globalba_8_submaps_ms"] = dt8 * 1e3
     out["roofline"] = roof
     out["globalba_500kf_ms"] = dt * 1e3

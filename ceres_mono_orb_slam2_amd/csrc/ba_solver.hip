@@ -36,6 +36,9 @@
 #include <numeric>
 #include <chrono>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <string>
 #include <atomic>
 #include <cstdlib>
 #include <climits>
