@@ -203,7 +203,9 @@ def test_batched_solves_equal_single_solves():
     """ba_solve_batch / ba_local_bundle_adjustment_batch: heterogeneous problems (different camera counts -> different
     reduced-system sizes, panel counts and super-block counts) in one lockstep batch give exactly the single-call results."""
     from ceres_mono_orb_slam2_amd import optimizer
-    shapes = [(10, 300, 1400, 2), (23, 500, 2600, 1), (6, 120, 500, 2), (48, 900, 4500, 1), (100, 2000, 9000, 2), (3, 60, 200, 1)]
+    # (nine problems: from eight on, the structure passes run on the calling thread AND its helper threads, csrc/ba_host.inc BaPrepPool)
+    shapes = [(10, 300, 1400, 2), (23, 500, 2600, 1), (6, 120, 500, 2), (48, 900, 4500, 1), (100, 2000, 9000, 2), (3, 60, 200, 1),
+              (17, 350, 1500, 1), (5, 90, 400, 2), (31, 700, 3300, 1)]
     gs = [synth.make_ba_graph(30 + i, ncam=c, npts=p, nobs=o, n_fixed=f) for i, (c, p, o, f) in enumerate(shapes)]
     probs = [(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"].astype(np.float64),
               np.ones(len(g["obs_cam"]), np.uint8)) for g in gs]
@@ -221,6 +223,13 @@ def test_batched_solves_equal_single_solves():
     stop = np.array([1], np.uint8)
     ab, lres = optimizer.local_bundle_adjustment_batch(lprobs[:2], stop_flag=stop)
     assert ab == 1 and np.array_equal(lres[0][0], gs[0]["poses0"])
+    # an invalid problem that a HELPER thread prepares: its error code and message reach the caller, the batch is not solved
+    from ceres_mono_orb_slam2_amd import _lib
+    bad = list(probs[7]); oc = bad[4].copy(); oc[3] = 10 ** 6; bad[4] = oc
+    with pytest.raises(_lib.OrbHipError, match="observation index out of range"):
+        optimizer.bundle_adjustment_batch(probs[:7] + [tuple(bad)] + probs[8:], n_iterations=3)
+    res2 = optimizer.bundle_adjustment_batch(probs, n_iterations=12)              # (and the next valid batch is the first one again)
+    assert all(a[2] == b[2] and np.array_equal(a[0], b[0]) for a, b in zip(res, res2))
 
 
 def test_folded_twin_blocks_equal_literal_duplicates(oracle):
