@@ -617,7 +617,9 @@ __device__ unsigned long long g_oct_prof[MAX_LEVELS][16];
 #define OCT_STAMP_END do { } while (0)
 #define OCT_COUNT(k) do { } while (0)
 #endif
-#define OCT_TPB 256     // threads per (frame, level) workgroup: 64 / 128 / 256 / 512 / 1024 -> 0.390 / 0.234 / 0.158 / 0.198 / 0.393 ms
+#ifndef OCT_TPB
+#define OCT_TPB 256
+#endif                  // threads per (frame, level) workgroup: 64 / 128 / 256 / 512 / 1024 -> 0.390 / 0.234 / 0.158 / 0.198 / 0.393 ms
 // exclusive scan of a[0..n) in place by an OCT_TPB-thread block; returns the total.
 template <typename T>
 __device__ int block_excl_scan(T* a, int n, int* s_tmp) {
