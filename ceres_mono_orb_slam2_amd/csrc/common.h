@@ -59,10 +59,10 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // kilobytes now and then takes 7-10 ms ON THE HOST, in two threads at once, with the GPU idle (the copy itself: 60 us) - the copy-
 // engine path of the runtime serialises the threads.  It was the whole p99 of a Tracking step beside LocalBA + GlobalBA: 8.4 ms with
 // hipMemcpyAsync, 0.61 ms with the kernel (and the step alone went from 0.414 to 0.386 ms: no copy-engine hand-off in the chain).
-// ORBHIP_WS_COPY_KERNEL=0 restores hipMemcpyAsync (A/B).
+// ORBHIP_WS_COPY_KERNEL=0 in an experiments build (tools/build_experiments.sh) restores hipMemcpyAsync for the A/B (tools/trace_concurrency.sh).
 int ws_copy_kernel(void* dst, const void* src, size_t bytes, hipStream_t s);
 inline bool ws_copy_by_kernel() {
-  static const bool on = []() { const char* e = std::getenv("ORBHIP_WS_COPY_KERNEL"); return !(e && e[0] == '0'); }();
+  static const bool on = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_WS_COPY_KERNEL"); return !(e && e[0] == '0'); }();   // (the A/B switch exists in experiments builds only)
   return on;
 }
 inline hipError_t ws_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {      // one side is pinned host memory
