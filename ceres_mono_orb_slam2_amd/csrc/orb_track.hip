@@ -854,65 +854,121 @@ __global__ __launch_bounds__(256) void k_trf_bow(const TrfIn* __restrict__ in, c
                                                  int32_t* __restrict__ match_kf, int32_t* __restrict__ f_owner, int32_t* __restrict__ f_bin, int* __restrict__ hist) {
   __shared__ unsigned short s_list[4][TRK_MAXKP];               // the node's frame features, ascending index (FeatureVector order)
   __shared__ unsigned char s_taken[4][TRK_MAXKP];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (visibly wave-uniform: the node's list bounds and the walk's counter live in scalar registers)
   const int m = blockIdx.x * 4 + w;
   if (m >= in->nn) return;
   const uint32_t node = fv_node[m];
   const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
   const float ratio = in->ratio; const int check_ori = in->check_ori;
+  // The node's frame features, ascending index: four 64-feature slices per trip, their loads requested together (a lone wave per
+  // node paid 32 dependent trips over the 2000 features one slice at a time).
   int cnt = 0;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const bool hit = i < n && f_node[i] == node && f_wt[i] > 0.0;      // (a stopped word - weight 0 - is not in the FeatureVector, TemplatedVocabulary.h:1156)
-    const unsigned long long mk = __ballot(hit);
-    if (hit) { const int p = cnt + __popcll(mk & ((1ull << lane) - 1ull)); s_list[w][p] = (unsigned short)i; s_taken[w][p] = 0; }
-    cnt += __popcll(mk);
+  for (int base = 0; base < n; base += 256) {
+    uint32_t nd[4]; double wt[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = base + 64 * u + lane; nd[u] = i < n ? f_node[i] : 0xFFFFFFFFu; wt[u] = i < n ? f_wt[i] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + 64 * u + lane;
+      const bool hit = i < n && nd[u] == node && wt[u] > 0.0;          // (a stopped word - weight 0 - is not in the FeatureVector, TemplatedVocabulary.h:1156)
+      const unsigned long long mk = __ballot(hit);
+      if (hit) { const int p = cnt + __popcll(mk & ((1ull << lane) - 1ull)); s_list[w][p] = (unsigned short)i; s_taken[w][p] = 0; }
+      cnt += __popcll(mk);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   if (cnt == 0) return;
-  // the node's first 64 frame descriptors stay in registers (a node of the ORB vocabulary holds ~20 features of a frame: a lone wave
-  // would otherwise pay a global round trip per keyframe feature); the keyframe's descriptor of the NEXT list entry is requested
-  // before the current one is used
-  uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-  if (lane < cnt) { const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][lane]); c0 = tb[0]; c1 = tb[1]; }
-  const uint32_t e_lo = fv_off[m], e_hi = fv_off[m + 1];
-  auto kf_of = [&](uint32_t e) { const int q = e < e_hi ? (int)fv_idx[e] : -1; return (q >= 0 && q < in->n_kf && kf_valid[q]) ? q : -1; };
-  int qn = kf_of(e_lo);
-  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
-  if (qn >= 0) { const uint4* a = (const uint4*)(kf_desc + 32 * (size_t)qn); n0 = a[0]; n1 = a[1]; }
-  for (uint32_t e = e_lo; e < e_hi; e++) {
-    const int q = qn;
-    const uint4 a0 = n0, a1 = n1;
-    qn = kf_of(e + 1);
-    if (qn >= 0) { const uint4* a = (const uint4*)(kf_desc + 32 * (size_t)qn); n0 = a[0]; n1 = a[1]; }
-    if (q < 0) continue;                                              // no map point, or isBad() (:184-188)
-    unsigned k1 = 256u << 16, k2 = 256u << 16;                        // (distance << 16 | list position): first minimum in list order
-    for (int p = lane; p < cnt; p += 64) {
-      if (s_taken[w][p]) continue;                                     // vpMapPointMatches[realIdxF] (:200)
-      uint4 b0 = c0, b1 = c1;
-      if (p >= 64) { const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][p]); b0 = tb[0]; b1 = tb[1]; }
-      const unsigned d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
-                         __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-      const unsigned key = (d << 16) | (unsigned)p;
-      if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
-    }
+  // The node's first 256 frame descriptors stay in registers, four per lane (list positions lane, lane + 64, ...), with their angles
+  // and their "taken" bits: a node of the ORB vocabulary holds ~20 features of a frame, but the distribution has a tail (183 in the
+  // synthetic vocabulary of tools/track_latency.py), and the walk below is sequential - 0.3 us per keyframe entry when it touches
+  // registers only, 2.2 us when every entry re-reads descriptors and flags from memory.
+  uint4 c0[4], c1[4];
+  float fa_l[4];
+  unsigned taken = 0;                                          // bit t: list position lane + 64 t is matched (vpMapPointMatches[realIdxF], :200)
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const unsigned o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o); two_smallest_merge(k1, k2, o1, o2); }
-    const int bestDist1 = (int)(k1 >> 16), bestDist2 = (int)(k2 >> 16), pos1 = (int)(k1 & 0xFFFFu);
-    if (bestDist1 <= TRF_TH_LOW && (float)bestDist1 < ratio * (float)bestDist2) {
-      const int f = s_list[w][pos1];
-      if (lane == 0) {
-        s_taken[w][pos1] = 1;
-        match_kf[q] = f; f_owner[f] = q;
-        if (check_ori) {
-          float rot = kf_angle[q] - kps4[4 * f + 3];
-          if (rot < 0.0) rot += 360.0f;
-          int b = (int)roundf(rot * (1.0f / TRK_HISTO));
-          if (b == TRK_HISTO) b = 0;
-          f_bin[f] = b; atomicAdd(&hist[b], 1);
-        }
+  for (int t = 0; t < 4; t++) {
+    c0[t] = make_uint4(0, 0, 0, 0); c1[t] = c0[t]; fa_l[t] = 0.f;
+    const int p = lane + 64 * t;
+    if (p < cnt) { const int fi = s_list[w][p]; const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)fi); c0[t] = tb[0]; c1[t] = tb[1]; fa_l[t] = kps4[4 * fi + 3]; }
+  }
+  const uint32_t e_lo = fv_off[m], e_hi = fv_off[m + 1];
+  auto dppu = [](unsigned v, auto ctrl) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xF, 0xF, false); };
+  // The keyframe's list entries of the node, 64 at a time: lane l fetches entry l - index, validity, descriptor, angle: one chain of
+  // dependent loads for the whole slice - and the walk takes entry j's values from lane j (v_readlane with the scalar loop counter).
+  for (uint32_t e0 = e_lo; e0 < e_hi; e0 += 64) {
+    const int ne = (int)min(64u, e_hi - e0);
+    int q_l = -1;
+    uint4 k0 = make_uint4(0, 0, 0, 0), k1v = k0;
+    float ka_l = 0.f;
+    if (lane < ne) {
+      const int q = (int)fv_idx[e0 + lane];
+      if (q >= 0 && q < in->n_kf && kf_valid[q]) { q_l = q; const uint4* a = (const uint4*)(kf_desc + 32 * (size_t)q); k0 = a[0]; k1v = a[1]; ka_l = kf_angle[q]; }   // no map point, or isBad() (:184-188): skipped
+    }
+    for (int j = 0; j < ne; j++) {
+      const int q = __builtin_amdgcn_readlane(q_l, j);
+      if (q < 0) continue;
+      uint4 a0, a1;
+      a0.x = __builtin_amdgcn_readlane(k0.x, j); a0.y = __builtin_amdgcn_readlane(k0.y, j); a0.z = __builtin_amdgcn_readlane(k0.z, j); a0.w = __builtin_amdgcn_readlane(k0.w, j);
+      a1.x = __builtin_amdgcn_readlane(k1v.x, j); a1.y = __builtin_amdgcn_readlane(k1v.y, j); a1.z = __builtin_amdgcn_readlane(k1v.z, j); a1.w = __builtin_amdgcn_readlane(k1v.w, j);
+      unsigned k1 = 256u << 16, k2 = 256u << 16;                        // (distance << 16 | list position): first minimum in list order
+      auto offer = [&](unsigned d, int p) { const unsigned key = (d << 16) | (unsigned)p; if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key; };
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int p = lane + 64 * t;
+        if (p < cnt && !((taken >> t) & 1u))
+          offer(__popc(a0.x ^ c0[t].x) + __popc(a0.y ^ c0[t].y) + __popc(a0.z ^ c0[t].z) + __popc(a0.w ^ c0[t].w) + __popc(a1.x ^ c1[t].x) + __popc(a1.y ^ c1[t].y) +
+                __popc(a1.z ^ c1[t].z) + __popc(a1.w ^ c1[t].w), p);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+      for (int p = lane + 256; p < cnt; p += 64) {                     // (a node with more than 256 frame features: from memory)
+        if (s_taken[w][p]) continue;
+        const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][p]);
+        const uint4 b0 = tb[0], b1 = tb[1];
+        offer(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) +
+              __popc(a1.w ^ b1.w), p);
+      }
+      // The two smallest keys of the wave as TWO wave minima on DPP only (no LDS crossbar on the sequential path: the ds_bpermute
+      // butterfly of the first version cost four dependent ~120-cycle round trips per entry): the smallest key, then the smallest of
+      // what every lane has left without it (keys are unique: the list position is part of them).  Results leave through lane 63.
+      auto wave_min = [&](unsigned v) -> unsigned {
+        v = min(v, dppu(v, std::integral_constant<int, 0xB1>()));       // quad_perm [1,0,3,2]
+        v = min(v, dppu(v, std::integral_constant<int, 0x4E>()));       // quad_perm [2,3,0,1]
+        v = min(v, dppu(v, std::integral_constant<int, 0x141>()));      // row_half_mirror
+        v = min(v, dppu(v, std::integral_constant<int, 0x140>()));      // row_mirror: every lane of a row holds the row's minimum
+        v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x142, 0xA, 0xF, false));     // row_bcast15 into rows 1 and 3
+        v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xC, 0xF, false));     // row_bcast31 into rows 2 and 3
+        return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+      };
+      const unsigned K1 = wave_min(k1);
+      const unsigned K2 = wave_min(k1 == K1 ? k2 : k1);
+      k1 = K1; k2 = K2;
+      const int bestDist1 = (int)(k1 >> 16), bestDist2 = (int)(k2 >> 16), pos1 = (int)(k1 & 0xFFFFu);
+      if (bestDist1 <= TRF_TH_LOW && (float)bestDist1 < ratio * (float)bestDist2) {
+        const int f = s_list[w][pos1];
+        // (both angles came with the slices: no load on the walk)
+        const float ka = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ka_l), j));
+        float fa;
+        if (pos1 < 256) {
+          const int t = pos1 >> 6, l = pos1 & 63;
+          const float v = t == 0 ? fa_l[0] : (t == 1 ? fa_l[1] : (t == 2 ? fa_l[2] : fa_l[3]));
+          fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+          if (lane == l) taken |= 1u << t;
+        } else {
+          fa = kps4[4 * f + 3];
+          if (lane == 0) s_taken[w][pos1] = 1;
+        }
+        if (lane == 0) {
+          match_kf[q] = f; f_owner[f] = q;
+          if (check_ori) {
+            float rot = ka - fa;
+            if (rot < 0.0) rot += 360.0f;
+            int b = (int)roundf(rot * (1.0f / TRK_HISTO));
+            if (b == TRK_HISTO) b = 0;
+            f_bin[f] = b; atomicAdd(&hist[b], 1);
+          }
+        }
+        // (s_taken is touched by nodes beyond 256 features only: LDS operations of one wave execute in order, the compiler is told)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+      }
     }
   }
 }
