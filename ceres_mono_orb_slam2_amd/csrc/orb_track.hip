@@ -830,7 +830,7 @@ __global__ __launch_bounds__(1024) void k_tlm_greedy(const TlmIn* __restrict__ i
 // orb_vocab.hip) + ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:151-256) + CeresOptimizer::PoseOptimization.
 // SearchByBoW is sequential only INSIDE a vocabulary node: the keyframe's features of a node, in list order, each take the closest
 // still unmatched frame feature of the same node (best < ratio * second, best <= TH_LOW).  A feature belongs to one node, so
-// the nodes are independent: one WAVE per node walks the keyframe's list while its lanes hold the node's frame features.
+// the nodes are independent: one WAVE (= one workgroup) per node walks the keyframe's list while its lanes hold the node's frame features.
 // ======================================================================================================================
 #define TRF_TH_LOW 50
 struct TrfIn { double pose7[7]; float K4[4], inv_sigma2[16]; float ratio; int check_ori, nn, n_kf; };
@@ -847,15 +847,17 @@ __device__ __forceinline__ void two_smallest_merge(unsigned& k1, unsigned& k2, u
   k2 = min(b, min(k2, o2)); k1 = a;
 }
 
-__global__ __launch_bounds__(256) void k_trf_bow(const TrfIn* __restrict__ in, const uint32_t* __restrict__ fv_node, const uint32_t* __restrict__ fv_off,
+__global__ __launch_bounds__(64) void k_trf_bow(const TrfIn* __restrict__ in, const uint32_t* __restrict__ fv_node, const uint32_t* __restrict__ fv_off,
                                                  const uint32_t* __restrict__ fv_idx, const uint8_t* __restrict__ kf_desc, const uint8_t* __restrict__ kf_valid,
                                                  const float* __restrict__ kf_angle, const uint8_t* __restrict__ f_desc, const uint32_t* __restrict__ f_node,
                                                  const double* __restrict__ f_wt, const float* __restrict__ kps4, const int32_t* __restrict__ d_count, int cap,
                                                  int32_t* __restrict__ match_kf, int32_t* __restrict__ f_owner, int32_t* __restrict__ f_bin, int* __restrict__ hist) {
-  __shared__ unsigned short s_list[4][TRK_MAXKP];               // the node's frame features, ascending index (FeatureVector order)
-  __shared__ unsigned char s_taken[4][TRK_MAXKP];
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (visibly wave-uniform: the node's list bounds and the walk's counter live in scalar registers)
-  const int m = blockIdx.x * 4 + w;
+  __shared__ unsigned short s_list[1][TRK_MAXKP];               // the node's frame features, ascending index (FeatureVector order); one wave per workgroup: [w] = [0]
+  __shared__ unsigned char s_taken[1][TRK_MAXKP];
+  __shared__ unsigned s_dj[64][64];                             // [entry of the slice][lane]: four distances, one byte each
+  __shared__ int s_mf[64], s_mb[64];                            // per entry of the slice: matched frame feature (or -1), its rotation bin
+  const int w = 0, lane = threadIdx.x & 63;
+  const int m = blockIdx.x;
   if (m >= in->nn) return;
   const uint32_t node = fv_node[m];
   const int n = min(max(*d_count, 0), min(cap, TRK_MAXKP));
@@ -883,13 +885,13 @@ __global__ __launch_bounds__(256) void k_trf_bow(const TrfIn* __restrict__ in, c
   // synthetic vocabulary of tools/track_latency.py), and the walk below is sequential - 0.3 us per keyframe entry when it touches
   // registers only, 2.2 us when every entry re-reads descriptors and flags from memory.
   uint4 c0[4], c1[4];
-  float fa_l[4];
+  float fa_l[4]; int fi_l[4];
   unsigned taken = 0;                                          // bit t: list position lane + 64 t is matched (vpMapPointMatches[realIdxF], :200)
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    c0[t] = make_uint4(0, 0, 0, 0); c1[t] = c0[t]; fa_l[t] = 0.f;
+    c0[t] = make_uint4(0, 0, 0, 0); c1[t] = c0[t]; fa_l[t] = 0.f; fi_l[t] = 0;
     const int p = lane + 64 * t;
-    if (p < cnt) { const int fi = s_list[w][p]; const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)fi); c0[t] = tb[0]; c1[t] = tb[1]; fa_l[t] = kps4[4 * fi + 3]; }
+    if (p < cnt) { const int fi = s_list[w][p]; const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)fi); c0[t] = tb[0]; c1[t] = tb[1]; fa_l[t] = kps4[4 * fi + 3]; fi_l[t] = fi; }
   }
   const uint32_t e_lo = fv_off[m], e_hi = fv_off[m + 1];
   auto dppu = [](unsigned v, auto ctrl) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xF, 0xF, false); };
@@ -904,31 +906,57 @@ __global__ __launch_bounds__(256) void k_trf_bow(const TrfIn* __restrict__ in, c
       const int q = (int)fv_idx[e0 + lane];
       if (q >= 0 && q < in->n_kf && kf_valid[q]) { q_l = q; const uint4* a = (const uint4*)(kf_desc + 32 * (size_t)q); k0 = a[0]; k1v = a[1]; ka_l = kf_angle[q]; }   // no map point, or isBad() (:184-188): skipped
     }
+    s_mf[lane] = -1;
+    // (A) every distance of the slice first - entry j against this lane's (<= 4) register-resident features, one byte each
+    // (saturated at 255: only distances <= TH_LOW can win, and 255 or 256 as the runner-up passes the same ratio test) -: 64
+    // independent entries, throughput-bound.  (B) the walk, which is sequential by definition (:200 - an entry takes the closest
+    // frame feature no earlier entry took), then has per entry only: mask, two wave minima, the decision.  (The first versions
+    // computed the distances inside the walk: ~0.9 us of exposed instruction latency per entry on a lone wave, 175 us for the
+    // 183-entry node of tools/track_latency.py's vocabulary.)
+    for (int j = 0; j < ne; j++) {
+      {
+        uint4 a0, a1;
+        a0.x = __builtin_amdgcn_readlane(k0.x, j); a0.y = __builtin_amdgcn_readlane(k0.y, j); a0.z = __builtin_amdgcn_readlane(k0.z, j); a0.w = __builtin_amdgcn_readlane(k0.w, j);
+        a1.x = __builtin_amdgcn_readlane(k1v.x, j); a1.y = __builtin_amdgcn_readlane(k1v.y, j); a1.z = __builtin_amdgcn_readlane(k1v.z, j); a1.w = __builtin_amdgcn_readlane(k1v.w, j);
+        unsigned pk = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const unsigned d = __popc(a0.x ^ c0[t].x) + __popc(a0.y ^ c0[t].y) + __popc(a0.z ^ c0[t].z) + __popc(a0.w ^ c0[t].w) + __popc(a1.x ^ c1[t].x) + __popc(a1.y ^ c1[t].y) +
+                             __popc(a1.z ^ c1[t].z) + __popc(a1.w ^ c1[t].w);
+          pk |= min(d, 255u) << (8 * t);
+        }
+        s_dj[j][lane] = pk;
+      }
+    }
+    const unsigned have = (lane < cnt ? 1u : 0u) | (lane + 64 < cnt ? 2u : 0u) | (lane + 128 < cnt ? 4u : 0u) | (lane + 192 < cnt ? 8u : 0u);   // this lane's list positions that exist
     for (int j = 0; j < ne; j++) {
       const int q = __builtin_amdgcn_readlane(q_l, j);
       if (q < 0) continue;
-      uint4 a0, a1;
-      a0.x = __builtin_amdgcn_readlane(k0.x, j); a0.y = __builtin_amdgcn_readlane(k0.y, j); a0.z = __builtin_amdgcn_readlane(k0.z, j); a0.w = __builtin_amdgcn_readlane(k0.w, j);
-      a1.x = __builtin_amdgcn_readlane(k1v.x, j); a1.y = __builtin_amdgcn_readlane(k1v.y, j); a1.z = __builtin_amdgcn_readlane(k1v.z, j); a1.w = __builtin_amdgcn_readlane(k1v.w, j);
+      const unsigned dq = s_dj[j][lane];
       unsigned k1 = 256u << 16, k2 = 256u << 16;                        // (distance << 16 | list position): first minimum in list order
       auto offer = [&](unsigned d, int p) { const unsigned key = (d << 16) | (unsigned)p; if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key; };
+      const unsigned avail = have & ~taken;
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int p = lane + 64 * t;
-        if (p < cnt && !((taken >> t) & 1u))
-          offer(__popc(a0.x ^ c0[t].x) + __popc(a0.y ^ c0[t].y) + __popc(a0.z ^ c0[t].z) + __popc(a0.w ^ c0[t].w) + __popc(a1.x ^ c1[t].x) + __popc(a1.y ^ c1[t].y) +
-                __popc(a1.z ^ c1[t].z) + __popc(a1.w ^ c1[t].w), p);
+      for (int t = 0; t < 4; t++) {                                   // (selects, no branches: this is the sequential path)
+        const unsigned key = ((avail >> t) & 1u) ? ((((dq >> (8 * t)) & 255u) << 16) | (unsigned)(lane + 64 * t)) : 0xFFFFFFFFu;
+        const unsigned lo = min(key, k1), hi = max(key, k1);
+        k1 = lo; k2 = min(k2, hi);
       }
-      for (int p = lane + 256; p < cnt; p += 64) {                     // (a node with more than 256 frame features: from memory)
-        if (s_taken[w][p]) continue;
-        const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][p]);
-        const uint4 b0 = tb[0], b1 = tb[1];
-        offer(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) +
-              __popc(a1.w ^ b1.w), p);
+      if (cnt > 256) {                                                // (a node with more than 256 frame features: the rest from memory)
+        uint4 a0, a1;
+        a0.x = __builtin_amdgcn_readlane(k0.x, j); a0.y = __builtin_amdgcn_readlane(k0.y, j); a0.z = __builtin_amdgcn_readlane(k0.z, j); a0.w = __builtin_amdgcn_readlane(k0.w, j);
+        a1.x = __builtin_amdgcn_readlane(k1v.x, j); a1.y = __builtin_amdgcn_readlane(k1v.y, j); a1.z = __builtin_amdgcn_readlane(k1v.z, j); a1.w = __builtin_amdgcn_readlane(k1v.w, j);
+        for (int p = lane + 256; p < cnt; p += 64) {
+          if (s_taken[w][p]) continue;
+          const uint4* tb = (const uint4*)(f_desc + 32 * (size_t)s_list[w][p]);
+          const uint4 b0 = tb[0], b1 = tb[1];
+          offer(min(255u, (unsigned)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
+                                     __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w))), p);
+        }
       }
-      // The two smallest keys of the wave as TWO wave minima on DPP only (no LDS crossbar on the sequential path: the ds_bpermute
-      // butterfly of the first version cost four dependent ~120-cycle round trips per entry): the smallest key, then the smallest of
-      // what every lane has left without it (keys are unique: the list position is part of them).  Results leave through lane 63.
+      // The two smallest keys of the wave as TWO wave minima on DPP only (no LDS crossbar on the sequential path): the smallest key,
+      // then the smallest of what every lane has left without it (keys are unique: the list position is part of them).  Results
+      // leave through lane 63.
       auto wave_min = [&](unsigned v) -> unsigned {
         v = min(v, dppu(v, std::integral_constant<int, 0xB1>()));       // quad_perm [1,0,3,2]
         v = min(v, dppu(v, std::integral_constant<int, 0x4E>()));       // quad_perm [2,3,0,1]
@@ -940,36 +968,46 @@ __global__ __launch_bounds__(256) void k_trf_bow(const TrfIn* __restrict__ in, c
       };
       const unsigned K1 = wave_min(k1);
       const unsigned K2 = wave_min(k1 == K1 ? k2 : k1);
-      k1 = K1; k2 = K2;
-      const int bestDist1 = (int)(k1 >> 16), bestDist2 = (int)(k2 >> 16), pos1 = (int)(k1 & 0xFFFFu);
+      const int bestDist1 = (int)(K1 >> 16), bestDist2 = (int)(K2 >> 16), pos1 = (int)(K1 & 0xFFFFu);
       if (bestDist1 <= TRF_TH_LOW && (float)bestDist1 < ratio * (float)bestDist2) {
-        const int f = s_list[w][pos1];
-        // (both angles came with the slices: no load on the walk)
+        // (feature index and both angles came with the slices: no load on the walk)
         const float ka = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ka_l), j));
-        float fa;
+        float fa; int f;
         if (pos1 < 256) {
           const int t = pos1 >> 6, l = pos1 & 63;
           const float v = t == 0 ? fa_l[0] : (t == 1 ? fa_l[1] : (t == 2 ? fa_l[2] : fa_l[3]));
+          const int vi = t == 0 ? fi_l[0] : (t == 1 ? fi_l[1] : (t == 2 ? fi_l[2] : fi_l[3]));
           fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+          f = __builtin_amdgcn_readlane(vi, l);
           if (lane == l) taken |= 1u << t;
         } else {
+          f = s_list[w][pos1];
           fa = kps4[4 * f + 3];
           if (lane == 0) s_taken[w][pos1] = 1;
         }
-        if (lane == 0) {
-          match_kf[q] = f; f_owner[f] = q;
-          if (check_ori) {
+        if (lane == 0) {                                             // (recorded in LDS, written out behind the walk: a global store or atomic
+          int b = 0;                                                  //  here puts a memory round trip on the sequential path - the compiler's
+          if (check_ori) {                                            //  next vmcnt(0) wait - for every match)
             float rot = ka - fa;
             if (rot < 0.0) rot += 360.0f;
-            int b = (int)roundf(rot * (1.0f / TRK_HISTO));
+            b = (int)roundf(rot * (1.0f / TRK_HISTO));
             if (b == TRK_HISTO) b = 0;
-            f_bin[f] = b; atomicAdd(&hist[b], 1);
           }
+          s_mf[j] = f; s_mb[j] = b;
         }
         // (s_taken is touched by nodes beyond 256 features only: LDS operations of one wave execute in order, the compiler is told)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+    if (lane < ne && q_l >= 0) {                                      // the slice's matches, one lane each
+      const int f = s_mf[lane];
+      if (f >= 0) {
+        match_kf[q_l] = f; f_owner[f] = q_l;
+        if (check_ori) { const int b = s_mb[lane]; f_bin[f] = b; atomicAdd(&hist[b], 1); }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1369,7 +1407,7 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
   const TrfIn* dI = in.dev<TrfIn>(pI);
   hipLaunchKernelGGL(k_trf_init, dim3((std::max(std::max(n_kf, fcap), 64) + 255) / 256), dim3(256), 0, W.s, (int32_t*)(dblk + oMatch), n_kf, (int32_t*)(dblk + oOwner), d_bin, fcap, d_hist);
   if (kf_fv_n > 0)
-    hipLaunchKernelGGL(k_trf_bow, dim3((kf_fv_n + 3) / 4), dim3(256), 0, W.s, dI, in.dev<uint32_t>(pFn), in.dev<uint32_t>(pFo), in.dev<uint32_t>(pFi), in.dev<uint8_t>(pD),
+    hipLaunchKernelGGL(k_trf_bow, dim3(std::max(kf_fv_n, 1)), dim3(64), 0, W.s, dI, in.dev<uint32_t>(pFn), in.dev<uint32_t>(pFo), in.dev<uint32_t>(pFi), in.dev<uint8_t>(pD),
                        in.dev<uint8_t>(pV), in.dev<float>(pA), d_fdesc, (const uint32_t*)(dblk + oNode), (const double*)(dblk + oWt), d_kps4, d_count, fcap,
                        (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), d_bin, d_hist);
   hipLaunchKernelGGL(k_trf_finish, dim3(1), dim3(1024), 0, W.s, dI, d_hist, d_kps4, d_count, fcap, in.dev<double>(pX), (int32_t*)(dblk + oMatch), (int32_t*)(dblk + oOwner), d_bin,
