@@ -924,7 +924,6 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
   if ((int)blockIdx.x * BS_PTS >= max(D.npts, 1)) return;
   const int tid = threadIdx.x;
   const int p0 = blockIdx.x * BS_PTS, p1 = min(p0 + BS_PTS, D.npts);
-  const size_t n = D.nobs;
   const bool ok = !st->chol_fail;
   const int olo = (p1 > p0) ? D.pt_off[p0] : 0, ohi = (p1 > p0) ? D.pt_off[p1] : 0;
   double acc[2] = {0.0, 0.0};              // model cost change, |dx|^2
