@@ -29,9 +29,11 @@ import time
 
 # The LocalBA leg keeps 12 host threads' HIP streams busy; the runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware
 # queues (default 4: streams that share a queue serialise).  8 queues: +5 % solves/s, one per thread another ~2 % (same-box sweeps of
-# tools/ba_batch_thr.py 64:12: 8 -> 2573, 12 -> 2631, 16 -> 2612, 24 -> 2520 solves/s).  Read by the
-# HIP runtime when it initialises, hence set before anything imports it; a value the caller exported wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+# tools/ba_batch_thr.py 64:12: 8 -> 2573, 12 -> 2631, 16 -> 2612, 24 -> 2520 solves/s).  The runtime
+# reads it once per process, and more than 4 queues cost the front-end's host-fed pipeline its copy / compute overlap (round 4:
+# 110 k -> 50 k frames/s) - so the BA legs run in a process of their own with this value (run_ba_leg below; a value the caller
+# exported wins) and the front-end process keeps the runtime's default.
+BA_LEG_HW_QUEUES = "12"
 
 import numpy as np
 
@@ -42,13 +44,18 @@ W_IMG, H_IMG, NFEAT = 1241, 376, 2000
 # algorithmic bytes per 1241x376 frame (DESIGN.md "Kernels")
 PX_TOTAL = 1444097
 BYTES = {"pyramid": 1407767 + 977481, "fast_cells": 1444097, "blur": 2 * 1444097, "describe": 2000 * (32 + 28)}
-KERNEL_OF = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur7", "describe": "k_describe"}
+# k_octree: the candidate keys it reads (4 B each, ~33 k per frame on the bench's frames), the per-cell counts, the keys' node ids
+# written and read once, the selected keys written: 149 KB per frame (profiles/r04_pmc_traffic.json agrees) - a latency-bound
+# kernel (one workgroup per (frame, level), a serial split loop): its HBM fraction is tiny by construction, the line reports its
+# VALU-busy and waiting fractions beside it
+OCTREE_BYTES = 149000
+KERNEL_OF = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur7", "describe": "k_describe", "octree": "k_octree"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer VALU instruction issues over 4 cycles;
                                # measured 35-39 T lane-instr/s for xor/bcnt/pk_*16/dot4/dot2/sad/alignbyte (tools/ubench/valu_rate.hip)
 MATCH_LANE_OPS_PER_PAIR = 19.5   # VALU instructions per Hamming distance in k_match_pairs (ISA-checked: 8 xor + 8 v_bcnt + v_lshl_or + v_max + v_min + half a v_min3)
-PMC_TRAFFIC = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 PMC summaries, newest first
-PMC_VALU = ("r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json", "r01_pmc_valu.json")
+PMC_TRAFFIC = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 PMC summaries, newest first
+PMC_VALU = ("r05_pmc_valu.json", "r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json", "r01_pmc_valu.json")
 MFMA_I8_PEAK_TOPS = 5000.0     # MI355X_MICROARCH.md: I8 at twice the bf16 rate (bf16 dense ~2.5 PF); v_mfma_i32_16x16x64_i8 measured 4.7 POPS
                                # (tools/ubench/mfma_i8.hip)
 MATCH_OPS_PER_DISTANCE = 512   # 256 bit positions x (multiply + add): the matcher's distances as an int8 matrix product
@@ -122,7 +129,7 @@ def prepare_cpu_oracle(frames):
         po.use_library(None)
         info["note"] = "native build is NOT bit-identical to the canonical one on this host: canonical build timed"
         return info
-    info.update({"flags": po.NATIVE_FLAGS, "native": True,
+    info.update({"flags": po.NATIVE_FLAGS, "native": True, "library": so,
                  "bit_identical_to_canonical": "2 frames (keypoints, descriptors, matches) + 1 small LocalBA (poses, points, erase flags, iterations)"})
     return info
 
@@ -311,11 +318,32 @@ def pcie_pipeline(torch, dev, ex, mt, frames_host, B, resident_fps, n_batches=24
             "h2d_GBps": h2d, "d2h_GBps": d2h, "h2d_bytes_per_frame": in_bytes // B, "d2h_bytes_per_frame": out_bytes // B,
             "pipeline_h2d_GBps": fps * in_bytes / B / 1e9, "pipeline_d2h_GBps": fps * out_bytes / B / 1e9,
             "bound_frames_per_s": bound, "frac_of_bound": fps / bound, "downloaded_counts_equal_resident_run": same,
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
             "note": "frames from pinned host memory, keypoints + descriptors + counts + matches back to pinned host memory; upload, "
-                    "extract + match and download of consecutive batches overlap on three HIP streams (measured in THIS process: 12 hardware queues for "
-                    "the LocalBA leg and the extractor's high-priority blur stream cost the copy / compute overlap - the same pipeline reaches 110 - 114 k "
-                    "frames/s = 0.91 of the bound with GPU_MAX_HW_QUEUES=4 ORBHIP_SIDE_PRIORITY=0, DESIGN.md section 6); bound = min(H2D rate / bytes "
-                    "per frame in, D2H rate / bytes per frame out, resident rate)"}
+                    "extract + match and download of consecutive batches overlap on three HIP streams (round 5: the BA legs run in a process "
+                    "of their own, so this process keeps the runtime's default hardware-queue count, and batch contexts no longer use a "
+                    "prioritised blur stream - the two settings that halved this figure in round 4); bound = min(H2D rate / bytes per frame in, "
+                    "D2H rate / bytes per frame out, resident rate)"}
+
+
+def run_ba_leg(local_rank, rank, cpu, oracle_lib):
+    """The LocalBA / PoseOptimization / GlobalBA legs (bench_ba.py) in a process of their own, on this
+    rank's device; returns bench_ba.run's dictionary (with `_final_points`)."""
+    import tempfile
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", BA_LEG_HW_QUEUES)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):     # (not a rank of the job: no rendezvous)
+        env.pop(k, None)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    with tempfile.TemporaryDirectory(prefix="orbhip_ba_") as d:
+        cmd = [sys.executable, os.path.join(ROOT, "bench_ba.py"), "--device", str(local_rank), "--rank", str(rank),
+               "--cpu", "1" if cpu else "0", "--oracle-lib", oracle_lib or "", "--out", d]
+        p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("BA leg failed (rc %d): %s" % (p.returncode, (p.stderr or p.stdout)[-1500:]))
+        res = json.load(open(os.path.join(d, "result.json")))
+        res["_final_points"] = np.load(os.path.join(d, "final_points.npy"))
+    return res
 
 
 # ------------------------------------------------------------------------------------------ the benchmark
@@ -496,6 +524,29 @@ def main():
         kp_sum += counts.sum(); nm_sum += nmatch.sum(); bad += (counts <= 0).sum()
     torch.cuda.synchronize()
     assert int(bad.item()) == 0, "extractor produced an empty/overflowed frame"
+    # ... and, when the CPU oracle is in play anyway (cpu_baseline), the LAST batch of that pass against it: two frames' keypoints
+    # and descriptors and their match list, bit for bit (the checker, not the thing measured)
+    oracle_check = None
+    if not args.no_cpu and world == 1 and rank == 0:
+        try:
+            from oracle import pyoracle as po
+            po.use_library(None)
+            last = batches[M - 1][B - 2:B].cpu().numpy()
+            E = po.OracleExtractor(NFEAT)
+            ref = [E.extract(last[i]) for i in range(2)]
+            cn = counts[B - 2:B].cpu().numpy()
+            same = True
+            for i in range(2):
+                n = int(cn[i])
+                same = same and n == len(ref[i][0]) and np.array_equal(kps[B - 2 + i, :n].cpu().numpy().view(np.uint8).reshape(n, 28), ref[i][0].view(np.uint8).reshape(n, 28)) \
+                    and np.array_equal(desc[B - 2 + i, :n].cpu().numpy(), ref[i][1])
+            om, on = po.match_frames(ref[1][1], ref[1][0]["angle"], ref[0][1], ref[0][0]["angle"], 0.9, 50, True)
+            same = same and int(nmatch[B - 1].item()) == on and np.array_equal(match12[B - 1, :int(cn[1])].cpu().numpy(), om)
+            oracle_check = {"frames": 2, "pairs": 1, "bit_identical_to_oracle": bool(same),
+                            "what": "frames %d and %d of the last batch of the untimed sanity pass: keypoints, descriptors, match list" % (B - 2, B - 1)}
+            assert same, "bench.py: the extractor / matcher output of the benchmarked configuration differs from the oracle"
+        except ImportError as e:
+            oracle_check = {"error": repr(e)}
     mean_kp, mean_match = float(kp_sum.item()) / (B * M), float(nm_sum.item()) / (B * M)
 
     # ---- secondary figure (never `value`): the same work pipelined over 2 HIP streams / extractor contexts, rank 0 only, a
@@ -574,8 +625,8 @@ def main():
     if not args.no_ba:
         ok = 1
         try:
-            from ceres_mono_orb_slam2_amd import ba_bench
-            localba = ba_bench.run(dev, cpu=(not args.no_cpu) and world == 1, rank=rank)
+            nat = oracle_build.get("library") if isinstance(oracle_build, dict) and oracle_build.get("native") else None
+            localba = run_ba_leg(local_rank, rank, (not args.no_cpu) and world == 1, nat)
         except Exception as e:                       # never lose the headline line to the secondary leg
             localba, ok = {"error": repr(e)}, 0
         if use_dist:
@@ -605,7 +656,7 @@ def main():
         per_call = {k: v / max(ncalls, 1) for k, v in stage_ms.items()}
         per_call["match"] = match_ms / max(len(ev), 1)
         # the dominant kernel = the longest launch of the step, the matcher included (its bytes: both frames' records once)
-        bytes_of = dict(BYTES); bytes_of["match"] = int(round(mean_kp * MATCH_BYTES_PER_KP))
+        bytes_of = dict(BYTES); bytes_of["match"] = int(round(mean_kp * MATCH_BYTES_PER_KP)); bytes_of["octree"] = OCTREE_BYTES
         match_mfma = os.environ.get("ORBHIP_MATCH_MFMA", "1") != "0" and cap <= 4080        # (the library's own switch and limit)
         kernel_of = dict(KERNEL_OF); kernel_of["match"] = "k_match_pairs_mfma" if match_mfma else "k_match_pairs"
         # batches of >= 8 frames run k_blur7 on the extractor's side stream beside FAST + octree (ORBHIP_OVERLAP_BLUR, default on):
@@ -622,11 +673,12 @@ def main():
             on_path["blur"] = blur_leg
         else:
             on_path["fast_cells"] = per_call["fast_cells"]
+            on_path["octree"] = per_call["octree"]               # (round 5, VERDICT r4 weak #5: k_octree is on the path and may be its longest kernel)
             if not blur_concurrent: on_path["blur"] = per_call["blur"]
         crit_ms = per_call["pyramid"] + (max(main_leg, blur_leg) if blur_concurrent else main_leg + per_call["blur"]) + per_call["describe"] + per_call["match"]
         stages = dict(on_path)
         dom = max(stages, key=stages.get)
-        hbm_stages = {k: v for k, v in on_path.items() if k != "match"}
+        hbm_stages = {k: v for k, v in on_path.items() if k not in ("match", "octree")}
         hdom = max(hbm_stages, key=hbm_stages.get)
         kname = kernel_of[dom]
         ach = bytes_of[dom] * B / (per_call[dom] * 1e-3) / 1e9
@@ -651,9 +703,11 @@ def main():
         for f in PMC_VALU:
             try:
                 vp = json.load(open(os.path.join(ROOT, "profiles", f)))["kernels"][kname]
-                roof["limiter"] = "valu_issue"
+                roof["limiter"] = "valu_issue" if dom != "octree" else "latency (one workgroup per (frame, level), serial node splits)"
                 roof["valu_issue_frac"] = vp["valu_busy_frac"]
                 roof["valu_insts_per_wave"] = vp["valu_insts_per_wave"]
+                for kk in ("wait_any_frac_of_wave_cycles", "avg_waves_per_simd"):
+                    if kk in vp: roof[kk] = vp[kk]
                 roof["valu_source"] = "profiles/" + f
                 break
             except Exception:
@@ -733,8 +787,8 @@ def main():
                 continue
         roof["front_end"] = fe
         kernels = {k: {"ms_per_launch_batch": v} for k, v in per_call.items()}
-        for k in BYTES:
-            kernels[k]["algorithmic_GBps"] = BYTES[k] * B / (per_call[k] * 1e-3) / 1e9
+        for k in list(BYTES) + ["octree"]:
+            kernels[k]["algorithmic_GBps"] = bytes_of[k] * B / (per_call[k] * 1e-3) / 1e9
         if match_mfma:
             kernels["match"]["mfma_i8_Tops"] = tops
             kernels["match"]["mfma_frac_of_peak"] = tops / MFMA_I8_PEAK_TOPS
@@ -756,6 +810,8 @@ def main():
             "kernels": kernels,
         }
         out["one_stream"] = one_stream
+        if oracle_check is not None:
+            out["oracle_check"] = oracle_check
         if pipelined is not None:
             out["pipelined"] = pipelined
         if pcie is not None:

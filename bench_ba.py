@@ -1,11 +1,21 @@
-"""LocalBA / PoseOptimization throughput legs of bench.py (BASELINE.json configs[2], configs[3])."""
+"""LocalBA / PoseOptimization / GlobalBA legs of bench.py (BASELINE.json configs[2], configs[3], configs[4]).
+
+bench.py runs this module in a PROCESS OF ITS OWN (`python bench_ba.py --out DIR ...`, round 5): the twelve
+host threads of the batched LocalBA leg want GPU_MAX_HW_QUEUES=12 (one hardware queue per stream, +7 % solves/s), which the HIP
+runtime reads once per process and which costs the front-end's host-fed pipeline its copy / compute overlap (110 k -> 50 k frames/s,
+VERDICT r4 weak #7).  The child writes `result.json` and `final_points.npy` into DIR."""
 import os
+import sys
 import threading
 import time
 
 import numpy as np
 
-from . import optimizer, synth
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ceres_mono_orb_slam2_amd import optimizer, synth  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD datasheet; the in-container guide does not state it)
 
@@ -200,3 +210,32 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
         out["cpu_localba_solves_per_s"] = 1.0 / dt1
         out["cpu_poseopt_solves_per_s"] = len(pprobs) / dtp
     return out
+
+
+def main(argv=None):
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--cpu", type=int, default=0)
+    ap.add_argument("--oracle-lib", default="", help="the -march=native oracle build bench.py verified (empty: the canonical build)")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args(argv)
+    import torch
+    from ceres_mono_orb_slam2_amd import _lib
+    torch.cuda.set_device(a.device)
+    _lib.check(_lib.load().orbhip_set_default_device(a.device), "orbhip_set_default_device")
+    if a.cpu and a.oracle_lib:
+        from oracle import pyoracle as po
+        po.use_library(a.oracle_lib)
+    res = run(torch.device("cuda", a.device), cpu=bool(a.cpu), rank=a.rank)
+    pts = res.pop("_final_points")
+    res["process"] = {"own_process": True, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+    np.save(os.path.join(a.out, "final_points.npy"), pts)
+    with open(os.path.join(a.out, "result.json"), "w") as f:
+        json.dump(res, f)
+
+
+if __name__ == "__main__":
+    main()

@@ -1314,9 +1314,9 @@ int ba_essential_graph_correct(const double* lie7_orig, const double* lie7_opt, 
 
 // ---- measurement hook: device time of this host thread's ba_solve / ba_local_bundle_adjustment calls ---------------------
 int ba_set_profiling(int enable) { g_ba_profiling.store(enable ? 1 : 0); return 0; }
-int ba_test_set_wait_ticks(unsigned long long ticks) {
+int ba_set_wait_limit_ms(double ms) {
   if (int rc = use_default_device()) return rc;
-  const unsigned long long v = ticks ? ticks : 500000000ull;
+  const unsigned long long v = (ms > 0.0 && ms < 1e9) ? std::max<unsigned long long>(1ull, (unsigned long long)(ms * 1e5)) : 500000000ull;      // 10-ns ticks
   ORBHIP_CHECK_HIP(hipDeviceSynchronize());
   ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cp_wait_ticks), &v, sizeof(v)));
   return 0;

@@ -1378,7 +1378,8 @@ struct orbx_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> prof_events, side_events;
   // the blur pass only depends on the pyramid: it runs on a side stream concurrently with FAST + octree
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr;        // batches: normal priority
+  hipStream_t side_hi = nullptr;     // a lone frame inside the Tracking chain: greatest priority (created on first use)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int lone_side_mode = 0;      // side-stream mode of a LONE frame for the next run_batch call (set by orbx_extract_chained, reset by run_batch)
   int blur_variant = 0;        // orbx_set_opencv_variant: which OpenCV GaussianBlur the taps restate (k_blur7)
@@ -1692,17 +1693,37 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   // than it hides)
   // (a lone frame inside a longer device chain - the Tracking step - does fork: the host is ahead of the device there, so the
   // fork / join costs nothing on the critical path and the blur's 13.6 us run beside FAST + octree: 0.310 -> 0.297 ms per step)
-  const int side_mode = c->side ? (c->overlap_blur >= 0 ? c->overlap_blur : (nframes >= 8 ? 1 : (nframes == 1 ? c->lone_side_mode : 0))) : 0;
+  int side_mode = c->ev_fork ? (c->overlap_blur >= 0 ? c->overlap_blur : (nframes >= 8 ? 1 : (nframes == 1 ? c->lone_side_mode : 0))) : 0;
+  // The blur of a lone frame inside the per-frame Tracking chain is on that frame's critical path, and the Tracking thread may run
+  // beside another thread's bundle adjustment (orbhip_set_thread_priority): it gets a stream of the greatest priority.  Batches do
+  // NOT (round 5): a prioritised blur starves the latency-bound octree of its own batch (k_octree 0.40 -> 0.55 ms) and
+  // the copy / compute overlap of a host-fed pipeline (112 k -> 73 k frames/s).  ORBHIP_SIDE_PRIORITY=1 restores round 4's behaviour.
+  // Either stream is created on first use: streams that merely exist cost dispatch slots.
+  static const bool side_prio_all = []() { const char* v = std::getenv("ORBHIP_SIDE_PRIORITY"); return v && v[0] == '1'; }();
+  hipStream_t side_st = nullptr;
+  if (side_mode) {
+    const bool want_hi = (nframes == 1 && c->lone_side_mode) || side_prio_all;
+    if (want_hi && !c->side_hi) {
+      int lo = 0, hi = 0;
+      if (!(hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo && hipStreamCreateWithPriority(&c->side_hi, hipStreamNonBlocking, hi) == hipSuccess)) c->side_hi = nullptr;
+    }
+    if (want_hi && c->side_hi) side_st = c->side_hi;
+    else {
+      if (!c->side && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+      side_st = c->side;
+    }
+    if (!side_st) side_mode = 0;
+  }
   c->lone_side_mode = 0;
   auto launch_blur_side = [&]() -> int {
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_fork, st));
-    ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    ORBHIP_CHECK_HIP(hipStreamWaitEvent(side_st, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
-    if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, c->side); }
-    hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, c->side, G,
+    if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, side_st); }
+    hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, side_st, G,
                        c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
-    if (c->profiling) { (void)hipEventRecord(se, c->side); c->side_events.push_back(sb); c->side_events.push_back(se); }
-    ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, c->side));
+    if (c->profiling) { (void)hipEventRecord(se, side_st); c->side_events.push_back(sb); c->side_events.push_back(se); }
+    ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, side_st));
     return 0;
   };
   if (side_mode == 1) { if (int rc = launch_blur_side()) return rc; }
@@ -1745,13 +1766,13 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
                          c->d_sel.as<uint32_t>(), c->d_selcnt.as<int>(), c->d_nkeys.as<int>(), c->d_status.as<int>(), c->d_octnodes.as<uint8_t>(), c->octree_row);
   }
   if (side_mode == 2) {
-    ORBHIP_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    ORBHIP_CHECK_HIP(hipStreamWaitEvent(side_st, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
-    if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, c->side); }
-    hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, c->side, G,
+    if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, side_st); }
+    hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, side_st, G,
                        c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
-    if (c->profiling) { (void)hipEventRecord(se, c->side); c->side_events.push_back(sb); c->side_events.push_back(se); }
-    ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, c->side));
+    if (c->profiling) { (void)hipEventRecord(se, side_st); c->side_events.push_back(sb); c->side_events.push_back(se); }
+    ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, side_st));
   }
   mark();
   if (side_mode == 0) hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, st, G,
@@ -1786,22 +1807,9 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
   c->iniTh = ini_th_fast; c->minTh = min_th_fast; c->device = device;
   build_tables(c);
   (void)hipSetDevice(device);
-  {
-    // (greatest priority: inside the per-frame Tracking chain the blur on this stream is on the frame's critical path, and the
-    // Tracking thread may run beside another thread's bundle adjustment - orbhip_set_thread_priority.  Batches pay or gain by it:
-    // two pipelined streams of 256-frame batches 148.0 k frames/s with it, 142.4 k without; ONE stream 130.4 k with, 136.2 k
-    // without; batches fed from pinned host memory beside their uploads and downloads 73 k with, 112 k without (GPU_MAX_HW_QUEUES
-    // <= 4).  ORBHIP_SIDE_PRIORITY=0 creates the stream with normal priority.)
-    int lo = 0, hi = 0;
-    static const bool side_prio = []() { const char* v = std::getenv("ORBHIP_SIDE_PRIORITY"); return !(v && v[0] == '0'); }();
-    hipError_t e = (side_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi)
-                                                                                       : hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-    if (e != hipSuccess) c->side = nullptr;
-  }
-  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-    if (c->side) (void)hipStreamDestroy(c->side);
-    c->side = nullptr;
-  }
+  // (fork / join events of the blur's side stream; the streams themselves are created by run_batch on first use)
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) c->ev_fork = nullptr;
+  if (c->ev_fork && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(c->ev_fork); c->ev_fork = nullptr; c->ev_join = nullptr; }
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = atoi(e);
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_DESC_XCD")) c->desc_xcd = atoi(e);
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_FAST_XCD")) c->fast_xcd = atoi(e);
@@ -1817,6 +1825,7 @@ int orbx_destroy(orbx_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->side_hi) { (void)hipStreamSynchronize(c->side_hi); (void)hipStreamDestroy(c->side_hi); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;

@@ -1091,6 +1091,7 @@ namespace {
 struct TrkFrame {
   DevBuf blk, kps4; FrameGridDev grid;
   size_t oKps = 0, oDesc = 0, oCnt = 0; int icap = 0, n_kp = 0, device = -1, nlevels = 0; float bounds[4] = {0, 0, 0, 0}; bool valid = false;
+  const orbx_ctx* producer = nullptr;      // the extractor that produced the resident frame: its level count / scale tables / capacity are the frame's
 };
 thread_local TrkFrame g_trk_frame;
 }  // namespace
@@ -1218,7 +1219,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     std::memset(outlier_out, 0, (size_t)n);
     const int32_t* feat = (const int32_t*)(hb + oFeat);
     for (int k = 0; k < T->nobs; k++) outlier_out[feat[k]] = hb[oOutl + k];
-    TF.oKps = oKps; TF.oDesc = oDesc; TF.oCnt = oCnt; TF.icap = icap; TF.n_kp = n; TF.nlevels = nlevels; std::memcpy(TF.bounds, bounds, 16); TF.valid = true;
+    TF.oKps = oKps; TF.oDesc = oDesc; TF.oCnt = oCnt; TF.icap = icap; TF.n_kp = n; TF.nlevels = nlevels; std::memcpy(TF.bounds, bounds, 16); TF.valid = true; TF.producer = ctx;
     res->n_keypoints = n; res->nmatches = T->nmatches; res->n_correspondences = T->nobs; res->greedy_rounds = T->rounds % 1000;
     std::memcpy(res->pose7, hb + oPose, 56);
     // PoseOptimization returns 0 and leaves the pose alone with fewer than 3 correspondences (src/CeresOptimizer.cc:330)
@@ -1260,6 +1261,7 @@ int orbt_track_local_map(orbx_ctx* ctx, const float* K4, const float* bounds, co
     int rc = W.begin();
     if (rc) return rc;
     ORBHIP_REQUIRE(TF.valid && TF.device == W.device, ORBHIP_EINVAL, "no frame resident on this thread's device: call orbt_track_with_motion_model first (same host thread)");
+    ORBHIP_REQUIRE(TF.producer == ctx && TF.nlevels == nlevels, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
     ORBHIP_REQUIRE(n_kp == TF.n_kp, ORBHIP_EINVAL, "n_kp differs from the resident frame's keypoint count");
     const int icap = TF.icap, nq = n_mp;
     TlmIn I; std::memset(&I, 0, sizeof(I));
@@ -1337,6 +1339,7 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
                                   uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes, int32_t* match_kf, int32_t* slot_owner, uint8_t* outlier_out, orbt_result* res) {
   CallClock call_clock;
   ORBHIP_REQUIRE(ctx && voc && K4 && bounds && Tcw_last && res && match_kf && slot_owner && outlier_out && n_words && n_fv_nodes && fv_off, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(!img || (w > 0 && h > 0 && stride >= w), ORBHIP_EINVAL, "bad image dimensions");
   ORBHIP_REQUIRE(n_kf >= 0 && kf_fv_n >= 0 && (n_kf == 0 || (kf_desc && kf_valid && kf_angle && kf_Xw)) && (kf_fv_n == 0 || (kf_fv_node && kf_fv_off && kf_fv_idx)), ORBHIP_EINVAL, "NULL keyframe argument");
   const int icap = orbx_max_keypoints(ctx);
   ORBHIP_REQUIRE(icap <= TRK_MAXKP, ORBHIP_ECAP, "more than 4096 features per frame");
@@ -1367,6 +1370,7 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
     d_img = W.up<uint8_t>(img, (size_t)stride * (h - 1) + w, &rc);
   } else {
     ORBHIP_REQUIRE(TF.valid, ORBHIP_EINVAL, "img == NULL needs the frame of an earlier orbt_* call of this thread on the device");
+    ORBHIP_REQUIRE(TF.producer == ctx && TF.nlevels == nlevels && TF.icap == icap, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
   }
   if (rc || (rc = W.commit(in))) return rc;
   if (img) {
@@ -1420,7 +1424,7 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
   const TrkOut* T = (const TrkOut*)(hb + oOut);
   if (T->n_keypoints < 0) { set_error("extractor capacity exceeded"); return ORBHIP_EOVERFLOW; }
   const int n = std::min(T->n_keypoints, fcap);
-  if (img) { TF.n_kp = n; TF.valid = true; std::memcpy(kps_out, hf + TF.oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hf + TF.oDesc, (size_t)n * 32); }
+  if (img) { TF.n_kp = n; TF.valid = true; TF.producer = ctx; std::memcpy(kps_out, hf + TF.oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hf + TF.oDesc, (size_t)n * 32); }
   if (n != TF.n_kp) { set_error("resident frame changed"); return ORBHIP_EINVAL; }
   if (bow_word && bow_value && fv_node && fv_idx)
     orbhip::orbv_merge_host((const int32_t*)(hb + oWord), (const double*)(hb + oWt), (const uint32_t*)(hb + oNode), n, bow_word, bow_value, n_words, fv_node, fv_off, fv_idx, n_fv_nodes);

@@ -44,11 +44,17 @@ def track_with_motion_model(extractor, image, K4, bounds, Tcw_pred, last_Xw, las
     assert len(D) == n and len(O) == n and len(A) == n and len(V) == n
     # The output buffers (and their addresses) live with the extractor, two sets used alternately: a per-frame call must not spend
     # its time in allocations, page faults and copies (190 us of Python per call at first, ~25 now).
+    with _extractor_lock(extractor):
+        return _track_locked(L, extractor, img, w, h, K4, bounds, T, X, D, O, A, V, n, th, check_ori, copy)
+
+
+def _extractor_lock(extractor):
+    """One lock per extractor: every entry point that runs an extraction on it (pyramid / blur buffers, side stream and events of
+    the context are per-extractor state) takes it, so calls on one extractor from several Python threads are serialised."""
     lock = extractor.__dict__.get("_track_lock")
     if lock is None:
         lock = extractor.__dict__.setdefault("_track_lock", threading.Lock())
-    with lock:
-        return _track_locked(L, extractor, img, w, h, K4, bounds, T, X, D, O, A, V, n, th, check_ori, copy)
+    return lock
 
 
 def _track_locked(L, extractor, img, w, h, K4, bounds, T, X, D, O, A, V, n, th, check_ori, copy):
@@ -127,10 +133,12 @@ def track_reference_keyframe(extractor, vocabulary, image, K4, bounds, Tcw_last,
         img = _c(image, np.uint8); h, w = img.shape; ip, st = _addr(img), img.strides[0]
     else:
         img, h, w, ip, st = None, 0, 0, None, 0
-    _lib.check(L.orbt_track_reference_keyframe(extractor._h, vocabulary._h, ip, w, h, st, _addr(K4), _addr(bounds), _addr(T), _addr(D), _addr(V), _addr(A), _addr(X), n,
-                                               _addr(fn), _addr(fo), _addr(fi), len(fn), float(nnratio), int(bool(check_ori)), _addr(kps), _addr(desc), cap,
-                                               _addr(bw), _addr(bv), C.byref(nw), _addr(on), _addr(oo), _addr(oi), C.byref(nf), _addr(match), _addr(owner), _addr(outl),
-                                               C.byref(res)), "orbt_track_reference_keyframe")
+    import contextlib
+    with (_extractor_lock(extractor) if img is not None else contextlib.nullcontext()):      # (with an image the call runs an extraction on this extractor)
+        _lib.check(L.orbt_track_reference_keyframe(extractor._h, vocabulary._h, ip, w, h, st, _addr(K4), _addr(bounds), _addr(T), _addr(D), _addr(V), _addr(A), _addr(X), n,
+                                                   _addr(fn), _addr(fo), _addr(fi), len(fn), float(nnratio), int(bool(check_ori)), _addr(kps), _addr(desc), cap,
+                                                   _addr(bw), _addr(bv), C.byref(nw), _addr(on), _addr(oo), _addr(oi), C.byref(nf), _addr(match), _addr(owner), _addr(outl),
+                                                   C.byref(res)), "orbt_track_reference_keyframe")
     k = res.n_keypoints
     return dict(kps=kps[:k] if img is not None else None, desc=desc[:k] if img is not None else None, bow=(bw[:nw.value], bv[:nw.value]),
                 fv=(on[:nf.value], oo[:nf.value + 1], oi[:oo[nf.value]]), match=match[:n], owner=owner[:k], outlier=outl[:k].view(np.bool_),

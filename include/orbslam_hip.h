@@ -500,10 +500,12 @@ int ba_sim3_inverse(const double* a, double* out);
  * and resets them.                                                                                                       */
 int ba_set_profiling(int enable);
 int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations);
-/* Test hook (no reference counterpart): the time limit of a wait between workgroups of the persistent Cholesky kernels, in
- * 10-ns ticks of the device's real-time counter (default 500 000 000 = 5 s; 0 restores the default).  Tests shrink it to force
- * the ORBHIP_ETIMEOUT path; applies to the default device, to launches made after the call.                              */
-int ba_test_set_wait_ticks(unsigned long long ticks);
+/* Configuration (no reference counterpart): the time limit, in milliseconds, after which a workgroup of the persistent Cholesky
+ * kernels stops waiting for another one and the solve ends with ORBHIP_ETIMEOUT / ba_summary.termination 7 (default 5000 ms;
+ * ms <= 0 restores the default; resolution 10 ns).  A deployment with a frame deadline may want tens of milliseconds.  Process-wide,
+ * for the default device, for launches made after the call; NOT thread-safe: it synchronises the device - call it at start-up,
+ * not while other threads are solving.                                                                                    */
+int ba_set_wait_limit_ms(double ms);
 
 /* CeresOptimizer::BundleAdjustment (src/CeresOptimizer.cc:59-225) on flattened arrays, host pointers:
  * cameras with cam_fixed != 0 are constant (KF id 0, fixed KFs); obs_weight multiplies the pixel

@@ -9,7 +9,7 @@ O=tools/exp_lib; mkdir -p $O
 C=ceres_mono_orb_slam2_amd/csrc
 objs=""
 for f in capi_common orb_extractor orb_matcher orb_frame orb_vocab ba_solver orb_track; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DORBHIP_EXPERIMENTS "$@" -c $C/$f.hip -o $O/$f.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DORBHIP_EXPERIMENTS -Itools "$@" -c $C/$f.hip -o $O/$f.o || exit 1
   objs="$objs $O/$f.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/liborbslam_hip.so $objs && echo "built $O/liborbslam_hip.so"
