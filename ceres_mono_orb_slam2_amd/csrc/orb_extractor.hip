@@ -1101,6 +1101,113 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
 #endif
 }
 
+// ---------------------------------------------------------------------------- k_blur7_mfma (round 5)
+// The same 7 x 7 Gaussian on the MATRIX cores (VERDICT r4 next #5a): the extract kernels bind on the VALU issue slots (k_blur7: 43
+// lane-instructions per pixel, 29 % of the front-end's VALU work) while the matrix pipes idle.  A separable filter is two banded
+// matrix products, and every product here is exact in integers, so the result is bit for bit k_blur7's:
+//   row pass     Mid = Src x Tr      v_mfma_i32_16x16x64_i8: A = 16 rows x 64 source bytes (a lane: 16 consecutive bytes of one row,
+//                                    pixel - 128 as int8), B = Toeplitz band of the taps (int8, <= 56), C starts at 128 x sum(taps):
+//                                    the accumulators ARE the 16-bit row sums of k_blur7
+//   column pass  Out^T = Mid^T x Tc  Mid split into high and low bytes (each - 128 as int8): two products per 16 x 16 outputs,
+//                                    Out = (256 H + L + (256 x 128 + 128) x sum(taps) + 2^15) >> 16, clamped to 255
+// One wave blurs 58 rows x 48 columns from 64 rows x 64 columns of source with NO LDS and no barrier: the row-to-lane and
+// column-to-lane assignments of the products are chosen so that every result lands where its next use wants it -
+//   * row-pass product b (of 4) takes the source rows R0 + 16 (m >> 2) + 4 b + (m & 3) as its 16 M-rows: lane (i, g) then holds in
+//     acc[b][r] the row sums of source rows R0 + 16 g + 4 b + r of ONE column - sixteen consecutive rows = its 16 K-bytes of the
+//     column pass, in K order;
+//   * row-pass column block cb (of 3) produces the output columns c + 12 (n >> 2) + 4 cb + (n & 3): in the column pass (A = Mid^T: M =
+//     the block's columns) lane (i, g) receives rows m = 4 g + r = columns c + 12 g + 4 cb + r of output row 16 s + i, so the three
+//     blocks give it TWELVE CONSECUTIVE output bytes of one row: one 12-byte store.
+// The index k inside an instruction pairs byte j of lane group g of A with byte j of lane group g of B (csrc/orb_matcher.hip), so
+// "k = 16 g + j" below is a convention the Toeplitz tables (host-built, g_blur_toep) share with the source operand.
+// VALU per wave: ~16 per source operand, 6 per four row sums (pack + sign), 11 per four outputs: ~7 lane-instructions per pixel.
+#define BM_TW 192                   /* output columns per workgroup (4 waves x 48) */
+#define BM_TH 58                    /* output rows per workgroup */
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(1))) bm_u128 { uint32_t x, y, z, w; };     // a 16-byte load with no alignment promise
+__device__ bm_v4i g_blur_toep[2][7][64];   // [variant][3 row-pass blocks | 4 column-pass blocks][lane]: the lane's 16 K-bytes of the Toeplitz operand
+template <int VAR>
+__global__ __launch_bounds__(256) void k_blur7_mfma(GeomDev G, const BlurTile* __restrict__ tiles,
+                                                    const uint8_t* __restrict__ img0, long long img_frame_bytes,
+                                                    const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+  const BlurTile t = tiles[blockIdx.x];
+  const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const LevelDev& L = G.lv[t.level];
+  const int c = t.tx * BM_TW + 48 * wv;                 // first output column of this wave
+  if (c >= L.w) return;
+  const uint8_t* src = level_ptr(G, t.level, f, img0, img_frame_bytes, pyr);
+  uint8_t* dst = blur + (long long)f * G.blur_frame_bytes + L.blur_off;
+  const int li = lane & 15, g = lane >> 4;
+  const int R0 = t.ty * BM_TH - 3;                      // first source row of the wave's 64
+  const int cb0 = c - 4 + 16 * g;                       // this lane's 16 source bytes: columns cb0 .. cb0 + 15 (k = 16 g + j)
+  constexpr int SUM = VAR ? 256 : 257;
+  bm_v4i Tr[3], Tc[4];
+#pragma unroll
+  for (int q = 0; q < 3; q++) Tr[q] = g_blur_toep[VAR][q][lane];
+#pragma unroll
+  for (int q = 0; q < 4; q++) Tc[q] = g_blur_toep[VAR][3 + q][lane];
+  // ---- source operands: product b, M-row li = source row R0 + 16 (li >> 2) + 4 b + (li & 3) (reflect-101 outside the image)
+  const bool inside = cb0 >= 0 && cb0 + 16 <= L.w;      // (bytes beyond the columns a tap reaches multiply zeros, but must be readable)
+  bm_v4i A[4];
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int sy = reflect101(R0 + 16 * (li >> 2) + 4 * b + (li & 3), L.h);
+    const uint8_t* row = src + (uint32_t)sy * (uint32_t)L.pitch;
+    uint32_t v[4];
+    if (inside) {
+      const bm_u128 u = *(const bm_u128*)(row + cb0);
+      v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        v[q] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[q] |= (uint32_t)row[reflect101(cb0 + 4 * q + j, L.w)] << (8 * j);
+      }
+    }
+    A[b] = (bm_v4i){(int)(v[0] ^ 0x80808080u), (int)(v[1] ^ 0x80808080u), (int)(v[2] ^ 0x80808080u), (int)(v[3] ^ 0x80808080u)};
+  }
+  // ---- row pass: the row sums of this lane's column of block cb, rows R0 + 16 g .. + 15, split into sign-flipped high / low bytes
+  bm_v4i Bhi[3], Blo[3];
+#pragma unroll
+  for (int cb = 0; cb < 3; cb++) {
+    int hi[4], lo[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const bm_v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b], Tr[cb], (bm_v4i){128 * SUM, 128 * SUM, 128 * SUM, 128 * SUM}, 0, 0, 0);
+      const uint32_t p01 = (uint32_t)acc[0] | ((uint32_t)acc[1] << 16), p23 = (uint32_t)acc[2] | ((uint32_t)acc[3] << 16);     // (sums <= 65535)
+      lo[b] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
+      hi[b] = (int)(__builtin_amdgcn_perm(p23, p01, 0x07050301u) ^ 0x80808080u);
+    }
+    Blo[cb] = (bm_v4i){lo[0], lo[1], lo[2], lo[3]};
+    Bhi[cb] = (bm_v4i){hi[0], hi[1], hi[2], hi[3]};
+  }
+  // ---- column pass + store: output row R0 + 3 + 16 s + li, columns c + 12 g .. + 11
+  constexpr int K1 = (256 * 128 + 128) * SUM + (1 << 15);
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    uint32_t o[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; cb++) {
+      const bm_v4i H = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bhi[cb], Tc[s], (bm_v4i){0, 0, 0, 0}, 0, 0, 0);
+      const bm_v4i Lq = __builtin_amdgcn_mfma_i32_16x16x64_i8(Blo[cb], Tc[s], (bm_v4i){K1, K1, K1, K1}, 0, 0, 0);
+      uint32_t tv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const uint32_t x = ((uint32_t)H[r] << 8) + (uint32_t)Lq[r]; tv[r] = x < 0x00FFFFFFu ? x : 0x00FFFFFFu; }     // byte 2 = min(value >> 16, 255)
+      o[cb] = __builtin_amdgcn_perm(tv[1], tv[0], 0x0c0c0602u) | __builtin_amdgcn_perm(tv[3], tv[2], 0x06020c0cu);
+    }
+    const int orow = R0 + 3 + 16 * s + li, ocol = c + 12 * g;
+    if (16 * s + li < BM_TH && orow < L.h) {
+      uint8_t* d = dst + (uint32_t)orow * (uint32_t)L.bpitch + (uint32_t)ocol;      // bpitch and ocol are multiples of 4
+      if (ocol + 12 <= L.bpitch) { *(uint32_t*)d = o[0]; *(uint32_t*)(d + 4) = o[1]; *(uint32_t*)(d + 8) = o[2]; }
+      else {
+#pragma unroll
+        for (int q = 0; q < 3; q++) if (ocol + 4 * q + 4 <= L.bpitch) *(uint32_t*)(d + 4 * q) = o[q];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- k_describe
 __constant__ __attribute__((aligned(16))) signed char c_pattern[1024];
 __constant__ int c_umax[16];
@@ -1357,8 +1464,9 @@ struct orbx_ctx {
   int w = 0, h = 0, stride = 0, nframes = 0;
   GeomDev G;
   std::vector<CellDesc> cells;
-  std::vector<BlurTile> btiles;
-  DevBuf d_cells, d_btiles, d_tab;      // tables
+  std::vector<BlurTile> btiles, mtiles;      // k_blur7's 128 x 64 tiles, k_blur7_mfma's 192 x 58 tiles
+  DevBuf d_cells, d_btiles, d_mtiles, d_tab;      // tables
+  int blur_mfma = 1;                  // k_blur7_mfma (default) / k_blur7 (ORBHIP_BLUR_MFMA=0: the VALU kernel, for A/B runs)
   std::vector<size_t> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // byte offsets into d_tab per level
   size_t tab_cone = 0; int cone_wgs = 0, cone_buf0 = 0, cone_bufk = 0; size_t cone_lds = 0;      // k_pyr_cone: boxes in d_tab, grid, LDS layout (cone_wgs == 0: not available)
   DevBuf d_pyr, d_blur, d_cellcnt, d_cellkps, d_keys, d_knode, d_sel, d_selcnt, d_nkeys, d_status, d_octnodes;
@@ -1429,7 +1537,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
   if (!same_shape) {
     std::memset(&G, 0, sizeof(G));
     G.nlevels = nl;
-    c->cells.clear(); c->btiles.clear();
+    c->cells.clear(); c->btiles.clear(); c->mtiles.clear();
     long long pyr_off = 0, blur_off = 0;
     int key_off = 0, tile_w = 8, tile_h = 8, cell_cap = 1, max_cells = 1, node_cap = MAX_INI + 8, sel_cap = 8, desc_blocks = 0;
     std::vector<uint8_t> tab;
@@ -1546,6 +1654,11 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
           BlurTile bt; bt.level = (short)l; bt.tx = (short)tx; bt.ty = (short)ty; bt.pad = 0;
           c->btiles.push_back(bt);
         }
+      for (int ty = 0; ty < (L.h + BM_TH - 1) / BM_TH; ty++)
+        for (int tx = 0; tx < (L.w + BM_TW - 1) / BM_TW; tx++) {
+          BlurTile bt; bt.level = (short)l; bt.tx = (short)tx; bt.ty = (short)ty; bt.pad = 0;
+          c->mtiles.push_back(bt);
+        }
     }
     G.ncells_total = (int)c->cells.size();
     G.cell_cap = cell_cap; G.sel_cap = sel_cap; G.keys_per_frame = key_off; G.desc_blocks = desc_blocks;
@@ -1615,9 +1728,11 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     ORBHIP_REQUIRE(G.node_cap <= 32760, ORBHIP_EINVAL, "nfeatures too large: more than 32752 keypoints in one level (16-bit node indices)");
     if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
     if (int rc = c->d_btiles.ensure(c->btiles.size() * sizeof(BlurTile))) return rc;
+    if (int rc = c->d_mtiles.ensure(c->mtiles.size() * sizeof(BlurTile))) return rc;
     if (int rc = c->d_tab.ensure(std::max<size_t>(tab.size(), 16))) return rc;
     if (!c->cells.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_cells.p, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
     ORBHIP_CHECK_HIP(hipMemcpy(c->d_btiles.p, c->btiles.data(), c->btiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
+    ORBHIP_CHECK_HIP(hipMemcpy(c->d_mtiles.p, c->mtiles.data(), c->mtiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
     if (!tab.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
     if (!c->octree_gmem && c->octree_lds > 64 * 1024)
       if (int rc = raise_dynamic_lds((const void*)k_octree<false, false>, c->device, c->octree_lds)) return rc;
@@ -1628,6 +1743,22 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
   if (!c->const_uploaded) {
     ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORB_BIT_PATTERN_31, 1024));
     ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), c->umax.data(), 16 * sizeof(int)));
+    {
+      // k_blur7_mfma's Toeplitz operands (see the kernel): lane (n, g), byte j <-> k = 16 g + j
+      std::vector<int8_t> T((size_t)2 * 7 * 64 * 16, 0);
+      for (int var = 0; var < 2; var++) {
+        const int taps[7] = {18, 34, var ? 48 : 49, var ? 56 : 55, var ? 48 : 49, 34, 18};
+        for (int q = 0; q < 7; q++)
+          for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 16; j++) {
+              const int n = lane & 15, kk = 16 * (lane >> 4) + j;
+              const int ti = q < 3 ? kk - (12 * (n >> 2) + 4 * q + (n & 3)) - 1      // row pass, block q: output column c + 12 (n >> 2) + 4 q + (n & 3), source column c - 4 + kk
+                                   : kk - (16 * (q - 3) + n);                         // column pass, block s = q - 3: output row R0 + 3 + 16 s + n, source row R0 + kk
+              T[(((size_t)var * 7 + q) * 64 + lane) * 16 + j] = (int8_t)((ti >= 0 && ti <= 6) ? taps[ti] : 0);
+            }
+      }
+      ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_blur_toep), T.data(), T.size()));
+    }
     c->const_uploaded = true;
   }
   const size_t B = (size_t)nframes;
@@ -1649,13 +1780,16 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
 static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int stride, size_t frame_stride,
                      int nframes, orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts,
                      hipStream_t st) {
-  void (*blur_k)(GeomDev, const BlurTile*, const uint8_t*, long long, const uint8_t*, uint8_t*) = (c && c->blur_variant) ? k_blur7<1> : k_blur7<0>;
+  void (*blur_k)(GeomDev, const BlurTile*, const uint8_t*, long long, const uint8_t*, uint8_t*) =
+      c->blur_mfma ? (c->blur_variant ? k_blur7_mfma<1> : k_blur7_mfma<0>) : (c->blur_variant ? k_blur7<1> : k_blur7<0>);
 
   ORBHIP_CHECK_HIP(hipSetDevice(c->device));
   if (int rc = prepare(c, w, h, stride, nframes)) return rc;
   const GeomDev& G = c->G;
   const int nl = c->nlevels;
   uint8_t* pyr = c->d_pyr.as<uint8_t>();
+  const unsigned n_btiles = (unsigned)(c->blur_mfma ? c->mtiles.size() : c->btiles.size());
+  const BlurTile* d_btl = c->blur_mfma ? c->d_mtiles.as<BlurTile>() : c->d_btiles.as<BlurTile>();
   auto mark = [&]() { if (c->profiling) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_events.push_back(e); } } };
   static const bool cone_on = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_EXTRACT_CONE"); return !(e && e[0] == '0'); }();
   const bool cone = cone_on && nframes == 1 && c->cone_wgs > 0;
@@ -1720,8 +1854,8 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(side_st, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
     if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, side_st); }
-    hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, side_st, G,
-                       c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
+    hipLaunchKernelGGL(blur_k, dim3(n_btiles, nframes), dim3(256), 0, side_st, G,
+                       d_btl, d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
     if (c->profiling) { (void)hipEventRecord(se, side_st); c->side_events.push_back(sb); c->side_events.push_back(se); }
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, side_st));
     return 0;
@@ -1769,14 +1903,14 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
     ORBHIP_CHECK_HIP(hipStreamWaitEvent(side_st, c->ev_fork, 0));
     hipEvent_t sb = nullptr, se = nullptr;
     if (c->profiling) { (void)hipEventCreate(&sb); (void)hipEventCreate(&se); (void)hipEventRecord(sb, side_st); }
-    hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, side_st, G,
-                       c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
+    hipLaunchKernelGGL(blur_k, dim3(n_btiles, nframes), dim3(256), 0, side_st, G,
+                       d_btl, d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
     if (c->profiling) { (void)hipEventRecord(se, side_st); c->side_events.push_back(sb); c->side_events.push_back(se); }
     ORBHIP_CHECK_HIP(hipEventRecord(c->ev_join, side_st));
   }
   mark();
-  if (side_mode == 0) hipLaunchKernelGGL(blur_k, dim3((unsigned)c->btiles.size(), nframes), dim3(256), 0, st, G,
-                                         c->d_btiles.as<BlurTile>(), d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
+  if (side_mode == 0) hipLaunchKernelGGL(blur_k, dim3(n_btiles, nframes), dim3(256), 0, st, G,
+                                         d_btl, d_imgs, (long long)frame_stride, pyr, c->d_blur.as<uint8_t>());
   else ORBHIP_CHECK_HIP(hipStreamWaitEvent(st, c->ev_join, 0));       // join: describe needs the blurred levels
   mark();
   hipLaunchKernelGGL(k_describe, dim3(G.desc_blocks, nframes), dim3(64 * DESC_WPB), 0, st, G, c->d_sel.as<uint32_t>(),
@@ -1810,6 +1944,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
   // (fork / join events of the blur's side stream; the streams themselves are created by run_batch on first use)
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) c->ev_fork = nullptr;
   if (c->ev_fork && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(c->ev_fork); c->ev_fork = nullptr; c->ev_join = nullptr; }
+  if (const char* e = std::getenv("ORBHIP_BLUR_MFMA")) c->blur_mfma = atoi(e) != 0;
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = atoi(e);
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_DESC_XCD")) c->desc_xcd = atoi(e);
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_FAST_XCD")) c->fast_xcd = atoi(e);
@@ -1819,7 +1954,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
 
 int orbx_destroy(orbx_ctx* c) {
   if (!c) return 0;
-  DevBuf* bufs[] = {&c->d_cells, &c->d_btiles, &c->d_tab, &c->d_pyr, &c->d_blur, &c->d_cellcnt, &c->d_cellkps,
+  DevBuf* bufs[] = {&c->d_cells, &c->d_btiles, &c->d_mtiles, &c->d_tab, &c->d_pyr, &c->d_blur, &c->d_cellcnt, &c->d_cellkps,
                     &c->d_keys, &c->d_knode, &c->d_sel, &c->d_selcnt, &c->d_nkeys, &c->d_status, &c->d_img,
                     &c->d_out, &c->d_octnodes};
   for (DevBuf* b : bufs) b->release();

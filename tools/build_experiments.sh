@@ -9,7 +9,8 @@ O=tools/exp_lib; mkdir -p $O
 C=ceres_mono_orb_slam2_amd/csrc
 objs=""
 for f in capi_common orb_extractor orb_matcher orb_frame orb_vocab ba_solver orb_track; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DORBHIP_EXPERIMENTS -Itools "$@" -c $C/$f.hip -o $O/$f.o || exit 1
+  X=""; [ $f = orb_extractor ] && X="-mllvm -amdgpu-mfma-vgpr-form"      # (as __graft_entry__.EXTRA_FLAGS)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DORBHIP_EXPERIMENTS -Itools $X "$@" -c $C/$f.hip -o $O/$f.o || exit 1
   objs="$objs $O/$f.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/liborbslam_hip.so $objs && echo "built $O/liborbslam_hip.so"
