@@ -34,6 +34,10 @@ import time
 # 110 k -> 50 k frames/s) - so the BA legs run in a process of their own with this value (run_ba_leg below; a value the caller
 # exported wins) and the front-end process keeps the runtime's default.
 BA_LEG_HW_QUEUES = "12"
+# The front-end process: two pipelined extract + match streams, each with a side stream for its blur, must not share a hardware
+# queue (with the default 4 they alias: 156 k frames/s against 170 k with 6, 8 or 12; round-5 sweep).  The
+# host-fed pipeline no longer cares (pcie_pipeline below: its stage hand-offs are made on the host).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 
@@ -49,7 +53,7 @@ BYTES = {"pyramid": 1407767 + 977481, "fast_cells": 1444097, "blur": 2 * 1444097
 # kernel (one workgroup per (frame, level), a serial split loop): its HBM fraction is tiny by construction, the line reports its
 # VALU-busy and waiting fractions beside it
 OCTREE_BYTES = 149000
-KERNEL_OF = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur7", "describe": "k_describe", "octree": "k_octree"}
+KERNEL_OF = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur7_mfma", "describe": "k_describe", "octree": "k_octree"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer VALU instruction issues over 4 cycles;
                                # measured 35-39 T lane-instr/s for xor/bcnt/pk_*16/dot4/dot2/sad/alignbyte (tools/ubench/valu_rate.hip)
@@ -252,10 +256,16 @@ def launch_check(rank, world):
 
 def pcie_pipeline(torch, dev, ex, mt, frames_host, B, resident_fps, n_batches=24):
     """Host-fed figure (never `value`): frames start in PINNED HOST memory and keypoints + descriptors + matches end there
-    (what a drop-in operator() fed by src/Frame.cc:116 sees).  Three HIP streams: upload of batch m + 1, extract + match of batch
-    m and download of batch m - 1 overlap (triple-buffered device inputs / outputs, events between the streams; one host
-    thread enqueues everything).  Also measures the bare H2D / D2H rates of the same buffers, which bound the pipeline."""
-    import numpy as np
+    (what a drop-in operator() fed by src/Frame.cc:116 sees).  Upload of batch m + 1, extract + match of batch m and download of
+    batch m - 1 overlap on three HIP streams (triple-buffered device inputs / outputs).  Round 5: the stage hand-offs are made on
+    the HOST - an upload, a run and a download thread wait for each other's events with hipEventSynchronize; no stream ever holds a
+    cross-stream dependency.  The earlier form (one host thread, hipStreamWaitEvent between the streams) ran at 0.93 of its bound
+    for exactly one stream-to-hardware-queue mapping (GPU_MAX_HW_QUEUES = number of streams, created in one order) and at 0.42 - 0.55
+    for every other one (tools/hostfed_sweep.py, 30 settings: queue counts 2 ... 8, creation order, idle extra streams) - upload,
+    kernels and download simply ran one after the other; S independent upload -> run -> download chains gave 0.65 - 0.79, copies by
+    the library's copy kernel 0.65 - 0.77.  This form: 0.87 - 0.91 for 4 and 8 queues, with or without idle extra streams.
+    Also measures the bare H2D / D2H rates of the same buffers, which bound the pipeline."""
+    import queue as _q
     NBUF = 3
     cap = ex.max_keypoints
     H, W = frames_host.shape[1:]
@@ -268,15 +278,12 @@ def pcie_pipeline(torch, dev, ex, mt, frames_host, B, resident_fps, n_batches=24
     hout = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in dout[0]) for _ in range(2)]
     pa = torch.arange(B, dtype=torch.int32, device=dev); pb = (pa + B - 1) % B
     s_up, s_run, s_dn = (torch.cuda.Stream(device=dev) for _ in range(3))
-    up_done = [torch.cuda.Event() for _ in range(NBUF)]
-    run_done = [torch.cuda.Event() for _ in range(NBUF)]
-    dn_done = [torch.cuda.Event() for _ in range(NBUF)]
     in_bytes = B * H * W
     out_bytes = sum(t.numel() * t.element_size() for t in dout[0])
-    # bare copy rates of these very buffers
+
     def rate(fn, nbytes, reps=4, trials=4):
         best = 0.0
-        for _ in range(trials):                                 # (the first passes over freshly pinned pages run at a fraction of the link rate)
+        for _ in range(trials):
             fn(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -288,42 +295,80 @@ def pcie_pipeline(torch, dev, ex, mt, frames_host, B, resident_fps, n_batches=24
     d2h = rate(lambda: [h.copy_(d, non_blocking=True) for h, d in zip(hout[0], dout[0])], out_bytes)
 
     def run(n):
-        for m in range(n):
-            b = m % NBUF
-            with torch.cuda.stream(s_up):
-                s_up.wait_event(run_done[b])                   # the extractor has finished reading this input buffer (batch m - NBUF)
-                din[b].copy_(pin_in[m % 2], non_blocking=True)
-                up_done[b].record(s_up)
-            with torch.cuda.stream(s_run):
-                s_run.wait_event(up_done[b]); s_run.wait_event(dn_done[b])      # input there, output buffers downloaded
-                ex.extract_batch(din[b], out=dout[b][:3])
-                mt.match_frames_batch(dout[b][0], dout[b][1], dout[b][2], pa, pb, out=dout[b][3:])
-                run_done[b].record(s_run)
-            with torch.cuda.stream(s_dn):
-                s_dn.wait_event(run_done[b])
-                for h, d in zip(hout[m % 2], dout[b]):
-                    h.copy_(d, non_blocking=True)
-                dn_done[b].record(s_dn)
-    run(NBUF); torch.cuda.synchronize()
+        # hand-offs: queues of (batch index, event); free-lists bound the buffers in flight
+        q_up, q_run = _q.Queue(), _q.Queue()
+        free_in, free_out = _q.Queue(), _q.Queue()
+        for b in range(NBUF):
+            free_in.put((b, None)); free_out.put((b, None))
+        err = []
+
+        def uploader():
+            try:
+                torch.cuda.set_device(dev)
+                for m in range(n):
+                    b, ev = free_in.get()
+                    if ev is not None: ev.synchronize()                  # the extractor has finished reading this input buffer
+                    with torch.cuda.stream(s_up):
+                        din[b].copy_(pin_in[m % 2], non_blocking=True)
+                        e = torch.cuda.Event(); e.record(s_up)
+                    q_up.put((m, b, e))
+            except Exception as ex_:
+                err.append(repr(ex_)); q_up.put(None)
+
+        def runner():
+            try:
+                torch.cuda.set_device(dev)
+                for m in range(n):
+                    it = q_up.get()
+                    if it is None: break
+                    _, b, e = it
+                    ob, oev = free_out.get()
+                    e.synchronize()
+                    if oev is not None: oev.synchronize()                # output buffers downloaded
+                    with torch.cuda.stream(s_run):
+                        ex.extract_batch(din[b], out=dout[ob][:3])
+                        e_in = torch.cuda.Event(); e_in.record(s_run)
+                        mt.match_frames_batch(dout[ob][0], dout[ob][1], dout[ob][2], pa, pb, out=dout[ob][3:])
+                        e_out = torch.cuda.Event(); e_out.record(s_run)
+                    free_in.put((b, e_in))
+                    q_run.put((m, ob, e_out))
+            except Exception as ex_:
+                err.append(repr(ex_))
+            q_run.put(None)
+
+        def downloader():
+            try:
+                torch.cuda.set_device(dev)
+                while True:
+                    it = q_run.get()
+                    if it is None: break
+                    m, ob, e = it
+                    e.synchronize()
+                    with torch.cuda.stream(s_dn):
+                        for h, d in zip(hout[m % 2], dout[ob]):
+                            h.copy_(d, non_blocking=True)
+                        e2 = torch.cuda.Event(); e2.record(s_dn)
+                    free_out.put((ob, e2))
+            except Exception as ex_:
+                err.append(repr(ex_))
+        ths = [threading.Thread(target=f) for f in (uploader, runner, downloader)]
+        for t in ths: t.start()
+        for t in ths: t.join()
+        torch.cuda.synchronize()
+        if err: raise RuntimeError("; ".join(err))
+    run(NBUF)
     t0 = time.perf_counter()
     run(n_batches)
-    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fps = B * n_batches / dt
-    # the download really carries the results: batch n - 1's counts on the host equal a resident run of the same frames
     k, d, c = ex.extract_batch(din[(n_batches - 1) % NBUF]); torch.cuda.synchronize()
     same = bool(torch.equal(hout[(n_batches - 1) % 2][2], c.cpu()))
     bound = min(h2d * 1e9 / (in_bytes / B), d2h * 1e9 / (out_bytes / B), resident_fps)
-    return {"value": fps, "unit": "frames/s", "batches": n_batches, "ms_per_batch": dt / n_batches * 1e3,
+    return {"value": fps, "unit": "frames/s", "batches": n_batches, "ms_per_batch": dt / n_batches * 1e3, "form": "three host threads, host-side hand-offs",
             "h2d_GBps": h2d, "d2h_GBps": d2h, "h2d_bytes_per_frame": in_bytes // B, "d2h_bytes_per_frame": out_bytes // B,
             "pipeline_h2d_GBps": fps * in_bytes / B / 1e9, "pipeline_d2h_GBps": fps * out_bytes / B / 1e9,
             "bound_frames_per_s": bound, "frac_of_bound": fps / bound, "downloaded_counts_equal_resident_run": same,
-            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
-            "note": "frames from pinned host memory, keypoints + descriptors + counts + matches back to pinned host memory; upload, "
-                    "extract + match and download of consecutive batches overlap on three HIP streams (round 5: the BA legs run in a process "
-                    "of their own, so this process keeps the runtime's default hardware-queue count, and batch contexts no longer use a "
-                    "prioritised blur stream - the two settings that halved this figure in round 4); bound = min(H2D rate / bytes per frame in, "
-                    "D2H rate / bytes per frame out, resident rate)"}
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")}
 
 
 def run_ba_leg(local_rank, rank, cpu, oracle_lib):
@@ -388,12 +433,33 @@ def main():
             except OSError:
                 pinned_cpus = None
 
+    # ---- the BA legs run in a process of their own (12 hardware queues) and go FIRST, before this process creates its HIP context
+    shared = os.environ.get("ORBHIP_BENCH_SHARED_GPU") == "1"
+    B, M = args.batch, args.batches_per_step
+    nbase = min(2, M)
+    nvar = (M + nbase - 1) // nbase
+    base_host = [make_frames(B, seed=rank * 16 + b, pad_w=3 * (nvar - 1), pad_h=2 * (nvar - 1)) for b in range(nbase)]
+    frames_host = np.ascontiguousarray(base_host[0][:, :H_IMG, :W_IMG])          # = batches[0] below
+    dev_ord = 0 if shared else local_rank
+    oracle_build = None
+    if not args.no_cpu and world == 1 and rank == 0:
+        try:
+            oracle_build = prepare_cpu_oracle(frames_host)
+        except Exception as e:
+            oracle_build = {"error": repr(e)}
+    localba, ba_ok = None, 1
+    if not args.no_ba:
+        try:
+            nat = oracle_build.get("library") if isinstance(oracle_build, dict) and oracle_build.get("native") else None
+            localba = run_ba_leg(dev_ord, rank, (not args.no_cpu) and world == 1, nat)
+        except Exception as e:                       # never lose the headline line to the secondary leg
+            localba, ba_ok = {"error": repr(e)}, 0
+
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     # ORBHIP_BENCH_SHARED_GPU=1: dry run of the N > 1 code path on a box with fewer GPUs than ranks (every rank uses
     # device 0, gloo carries the collectives on host tensors); the real multi-GPU run is one rank per GPU over RCCL
-    shared = os.environ.get("ORBHIP_BENCH_SHARED_GPU") == "1"
     ndev = torch.cuda.device_count()
     if shared:
         local_rank = 0
@@ -425,19 +491,15 @@ def main():
 
     from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher, _lib, sharding
     _lib.check(_lib.load().orbhip_set_default_device(local_rank), "orbhip_set_default_device")
-    B, M = args.batch, args.batches_per_step
     # M distinct batches resident in HBM: two synthetic base batches per rank (its own frames: frame sharding), generated
-    # a little larger than 1241x376, and crops of them at offsets (3v, 2v) px: a crop keeps the <=8 px frame-to-frame
+    # a little larger than 1241x376 (base_host above), and crops of them at offsets (3v, 2v) px: a crop keeps the <=8 px frame-to-frame
     # chains and moves every corner relative to the cell grid, so no two batches repeat work
-    nbase = min(2, M)
-    nvar = (M + nbase - 1) // nbase
-    base = [torch.from_numpy(make_frames(B, seed=rank * 16 + b, pad_w=3 * (nvar - 1), pad_h=2 * (nvar - 1))).to(dev) for b in range(nbase)]
+    base = [torch.from_numpy(b).to(dev) for b in base_host]
     batches = []
     for m in range(M):
         v = m // nbase
         batches.append(base[m % nbase][:, 2 * v:2 * v + H_IMG, 3 * v:3 * v + W_IMG].contiguous())
-    frames_host = batches[0].cpu().numpy()
-    del base
+    del base, base_host
     S = max(1, args.streams)
     exs = [ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank) for _ in range(S)]
     ex = exs[0]
@@ -615,20 +677,10 @@ def main():
 
     # ---- LocalBA / PoseOptimization / GlobalBA legs: every rank solves its own independent problems (sub-map sharding,
     #      no collective in the solve); for N > 1 the landmark updates are merged with ONE all-gather.
-    localba, collective = None, None
-    oracle_build = None
-    if not args.no_cpu and world == 1 and rank == 0:
-        try:
-            oracle_build = prepare_cpu_oracle(frames_host)
-        except Exception as e:
-            oracle_build = {"error": repr(e)}
+    #      (the legs themselves ran first, above)
+    collective = None
     if not args.no_ba:
-        ok = 1
-        try:
-            nat = oracle_build.get("library") if isinstance(oracle_build, dict) and oracle_build.get("native") else None
-            localba = run_ba_leg(local_rank, rank, (not args.no_cpu) and world == 1, nat)
-        except Exception as e:                       # never lose the headline line to the secondary leg
-            localba, ok = {"error": repr(e)}, 0
+        ok = ba_ok
         if use_dist:
             flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # collectives below only if EVERY rank's leg succeeded

@@ -48,6 +48,17 @@ int orbhip_device_count(void) {
   return n;
 }
 const char* orbhip_version(void) { return "orbslam_hip 0.1 (gfx950)"; }
+int orbhip_copy_pinned_async(void* dst, const void* src, size_t bytes, void* stream) {
+  if (!bytes) return 0;
+  if (!dst || !src) { orbhip::set_error("orbhip_copy_pinned_async: NULL pointer"); return ORBHIP_EINVAL; }
+  // (a bulk copy over the host link needs latency x bandwidth ~ 80 KB in flight: 8 workgroups of 16-byte lanes reach 25 GB/s, 20 reach
+  // 55, 28 or more 57 GB/s; more than that only delays the memory traffic of the kernels the copy overlaps with - a host-fed extract
+  // pipeline ran at 0.77 of its bound with 28 - 32 workgroups, 0.53 with 128, 0.48 with 512; round-5 sweeps)
+  const int blocks = (int)std::min<size_t>(((bytes >> 4) + 255) / 256 + 1, (size_t)32);
+  hipLaunchKernelGGL(orbhip::k_ws_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint8_t*)dst, (const uint8_t*)src, bytes);
+  if (hipGetLastError() != hipSuccess) { orbhip::set_error("orbhip_copy_pinned_async: launch failed"); return ORBHIP_ENODEV; }
+  return 0;
+}
 int orbhip_set_default_device(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { orbhip::set_error("device ordinal %d out of range", device); return ORBHIP_EINVAL; }

@@ -1122,15 +1122,19 @@ __global__ __launch_bounds__(256) void k_blur7(GeomDev G, const BlurTile* __rest
 // "k = 16 g + j" below is a convention the Toeplitz tables (host-built, g_blur_toep) share with the source operand.
 // VALU per wave: ~16 per source operand, 6 per four row sums (pack + sign), 11 per four outputs: ~7 lane-instructions per pixel.
 #define BM_TW 192                   /* output columns per workgroup (4 waves x 48) */
-#define BM_TH 58                    /* output rows per workgroup */
+#define BM_TH 58                    /* output rows per chunk */
+#define BM_RC 4                     /* chunks (of 58 rows) a wave walks down its 48 columns: the Toeplitz operands are loaded once, the next
+                                       chunk's source is in flight during the products (one-chunk waves were dispatch- and latency-bound:
+                                       0.425 ms per 256 frames at 26 % VALU-busy) */
 typedef int bm_v4i __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) bm_u128 { uint32_t x, y, z, w; };     // a 16-byte load with no alignment promise
+typedef uint32_t bm_u32x3 __attribute__((ext_vector_type(3), aligned(4)));        // 12 bytes, 4-byte aligned: one global_store_dwordx3
 __device__ bm_v4i g_blur_toep[2][7][64];   // [variant][3 row-pass blocks | 4 column-pass blocks][lane]: the lane's 16 K-bytes of the Toeplitz operand
 template <int VAR>
 __global__ __launch_bounds__(256) void k_blur7_mfma(GeomDev G, const BlurTile* __restrict__ tiles,
                                                     const uint8_t* __restrict__ img0, long long img_frame_bytes,
                                                     const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-  const BlurTile t = tiles[blockIdx.x];
+  const BlurTile t = tiles[blockIdx.x];                 // (level, tx = 192-column strip, ty = first chunk, pad = chunks)
   const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const LevelDev& L = G.lv[t.level];
   const int c = t.tx * BM_TW + 48 * wv;                 // first output column of this wave
@@ -1138,73 +1142,90 @@ __global__ __launch_bounds__(256) void k_blur7_mfma(GeomDev G, const BlurTile* _
   const uint8_t* src = level_ptr(G, t.level, f, img0, img_frame_bytes, pyr);
   uint8_t* dst = blur + (long long)f * G.blur_frame_bytes + L.blur_off;
   const int li = lane & 15, g = lane >> 4;
-  const int R0 = t.ty * BM_TH - 3;                      // first source row of the wave's 64
   const int cb0 = c - 4 + 16 * g;                       // this lane's 16 source bytes: columns cb0 .. cb0 + 15 (k = 16 g + j)
+  const int rsub = 16 * (li >> 2) + (li & 3);           // product b, M-row li = source row R0 + rsub + 4 b
   constexpr int SUM = VAR ? 256 : 257;
   bm_v4i Tr[3], Tc[4];
 #pragma unroll
   for (int q = 0; q < 3; q++) Tr[q] = g_blur_toep[VAR][q][lane];
 #pragma unroll
   for (int q = 0; q < 4; q++) Tc[q] = g_blur_toep[VAR][3 + q][lane];
-  // ---- source operands: product b, M-row li = source row R0 + 16 (li >> 2) + 4 b + (li & 3) (reflect-101 outside the image)
-  const bool inside = cb0 >= 0 && cb0 + 16 <= L.w;      // (bytes beyond the columns a tap reaches multiply zeros, but must be readable)
-  bm_v4i A[4];
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    const int sy = reflect101(R0 + 16 * (li >> 2) + 4 * b + (li & 3), L.h);
-    const uint8_t* row = src + (uint32_t)sy * (uint32_t)L.pitch;
-    uint32_t v[4];
-    if (inside) {
-      const bm_u128 u = *(const bm_u128*)(row + cb0);
-      v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        v[q] = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) v[q] |= (uint32_t)row[reflect101(cb0 + 4 * q + j, L.w)] << (8 * j);
-      }
-    }
-    A[b] = (bm_v4i){(int)(v[0] ^ 0x80808080u), (int)(v[1] ^ 0x80808080u), (int)(v[2] ^ 0x80808080u), (int)(v[3] ^ 0x80808080u)};
-  }
-  // ---- row pass: the row sums of this lane's column of block cb, rows R0 + 16 g .. + 15, split into sign-flipped high / low bytes
-  bm_v4i Bhi[3], Blo[3];
-#pragma unroll
-  for (int cb = 0; cb < 3; cb++) {
-    int hi[4], lo[4];
+  const bool cols_inside = c - 4 >= 0 && c + 60 <= L.w;               // wave-uniform: every lane's 16 bytes lie inside the row
+  // (bytes beyond the columns a tap reaches multiply zeros, but must be readable: the slow path reflects them too)
+  auto load_src = [&](int R0, uint32_t (&v)[4][4]) {
+    const bool rows_inside = R0 >= 0 && R0 + 64 <= L.h;               // wave-uniform
 #pragma unroll
     for (int b = 0; b < 4; b++) {
-      const bm_v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b], Tr[cb], (bm_v4i){128 * SUM, 128 * SUM, 128 * SUM, 128 * SUM}, 0, 0, 0);
-      const uint32_t p01 = (uint32_t)acc[0] | ((uint32_t)acc[1] << 16), p23 = (uint32_t)acc[2] | ((uint32_t)acc[3] << 16);     // (sums <= 65535)
-      lo[b] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
-      hi[b] = (int)(__builtin_amdgcn_perm(p23, p01, 0x07050301u) ^ 0x80808080u);
-    }
-    Blo[cb] = (bm_v4i){lo[0], lo[1], lo[2], lo[3]};
-    Bhi[cb] = (bm_v4i){hi[0], hi[1], hi[2], hi[3]};
-  }
-  // ---- column pass + store: output row R0 + 3 + 16 s + li, columns c + 12 g .. + 11
-  constexpr int K1 = (256 * 128 + 128) * SUM + (1 << 15);
+      const int ry = R0 + rsub + 4 * b;
+      const int sy = rows_inside ? ry : reflect101(ry, L.h);
+      const uint8_t* row = src + (uint32_t)sy * (uint32_t)L.pitch;
+      if (cols_inside) {
+        const bm_u128 u = *(const bm_u128*)(row + cb0);
+        v[b][0] = u.x; v[b][1] = u.y; v[b][2] = u.z; v[b][3] = u.w;
+      } else {
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
-    uint32_t o[3];
+        for (int q = 0; q < 4; q++) {
+          v[b][q] = 0;
 #pragma unroll
-    for (int cb = 0; cb < 3; cb++) {
-      const bm_v4i H = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bhi[cb], Tc[s], (bm_v4i){0, 0, 0, 0}, 0, 0, 0);
-      const bm_v4i Lq = __builtin_amdgcn_mfma_i32_16x16x64_i8(Blo[cb], Tc[s], (bm_v4i){K1, K1, K1, K1}, 0, 0, 0);
-      uint32_t tv[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) { const uint32_t x = ((uint32_t)H[r] << 8) + (uint32_t)Lq[r]; tv[r] = x < 0x00FFFFFFu ? x : 0x00FFFFFFu; }     // byte 2 = min(value >> 16, 255)
-      o[cb] = __builtin_amdgcn_perm(tv[1], tv[0], 0x0c0c0602u) | __builtin_amdgcn_perm(tv[3], tv[2], 0x06020c0cu);
-    }
-    const int orow = R0 + 3 + 16 * s + li, ocol = c + 12 * g;
-    if (16 * s + li < BM_TH && orow < L.h) {
-      uint8_t* d = dst + (uint32_t)orow * (uint32_t)L.bpitch + (uint32_t)ocol;      // bpitch and ocol are multiples of 4
-      if (ocol + 12 <= L.bpitch) { *(uint32_t*)d = o[0]; *(uint32_t*)(d + 4) = o[1]; *(uint32_t*)(d + 8) = o[2]; }
-      else {
-#pragma unroll
-        for (int q = 0; q < 3; q++) if (ocol + 4 * q + 4 <= L.bpitch) *(uint32_t*)(d + 4 * q) = o[q];
+          for (int j = 0; j < 4; j++) v[b][q] |= (uint32_t)row[reflect101(cb0 + 4 * q + j, L.w)] << (8 * j);
+        }
       }
     }
+  };
+  uint32_t cur[4][4], nxt[4][4];
+  load_src(t.ty * BM_TH - 3, cur);
+  for (int ch = 0; ch < t.pad; ch++) {
+    const int R0 = (t.ty + ch) * BM_TH - 3;             // first source row of the chunk's 64
+    if (ch + 1 < t.pad) load_src(R0 + BM_TH, nxt);
+    // ---- row pass: the row sums of this lane's column of block cb, rows R0 + 16 g .. + 15, split into sign-flipped high / low bytes
+    bm_v4i A[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      A[b] = (bm_v4i){(int)(cur[b][0] ^ 0x80808080u), (int)(cur[b][1] ^ 0x80808080u), (int)(cur[b][2] ^ 0x80808080u), (int)(cur[b][3] ^ 0x80808080u)};
+    bm_v4i Bhi[3], Blo[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; cb++) {
+      int hi[4], lo[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const bm_v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[b], Tr[cb], (bm_v4i){128 * SUM, 128 * SUM, 128 * SUM, 128 * SUM}, 0, 0, 0);
+        const uint32_t p01 = (uint32_t)acc[0] | ((uint32_t)acc[1] << 16), p23 = (uint32_t)acc[2] | ((uint32_t)acc[3] << 16);     // (sums <= 65535)
+        lo[b] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
+        hi[b] = (int)(__builtin_amdgcn_perm(p23, p01, 0x07050301u) ^ 0x80808080u);
+      }
+      Blo[cb] = (bm_v4i){lo[0], lo[1], lo[2], lo[3]};
+      Bhi[cb] = (bm_v4i){hi[0], hi[1], hi[2], hi[3]};
+    }
+    // ---- column pass + store: output row R0 + 3 + 16 s + li, columns c + 12 g .. + 11
+    constexpr int K1 = (256 * 128 + 128) * SUM + (1 << 15);
+    const int ocol = c + 12 * g;
+    const bool whole = ocol + 12 <= L.bpitch;           // (bpitch and ocol are multiples of 4)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      uint32_t o[3];
+#pragma unroll
+      for (int cb = 0; cb < 3; cb++) {
+        const bm_v4i H = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bhi[cb], Tc[s], (bm_v4i){0, 0, 0, 0}, 0, 0, 0);
+        const bm_v4i Lq = __builtin_amdgcn_mfma_i32_16x16x64_i8(Blo[cb], Tc[s], (bm_v4i){K1, K1, K1, K1}, 0, 0, 0);
+        uint32_t tv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const uint32_t x = ((uint32_t)H[r] << 8) + (uint32_t)Lq[r]; tv[r] = x < 0x00FFFFFFu ? x : 0x00FFFFFFu; }     // byte 2 = min(value >> 16, 255)
+        o[cb] = __builtin_amdgcn_perm(tv[1], tv[0], 0x0c0c0602u) | __builtin_amdgcn_perm(tv[3], tv[2], 0x06020c0cu);
+      }
+      const int orow = R0 + 3 + 16 * s + li;
+      if (16 * s + li < BM_TH && orow < L.h) {
+        uint8_t* d = dst + (uint32_t)orow * (uint32_t)L.bpitch + (uint32_t)ocol;
+        if (whole) *(bm_u32x3*)d = (bm_u32x3){o[0], o[1], o[2]};      // (lanes g = 0..3 of a row: 48 contiguous bytes)
+        else {
+#pragma unroll
+          for (int q = 0; q < 3; q++) if (ocol + 4 * q + 4 <= L.bpitch) *(uint32_t*)(d + 4 * q) = o[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) cur[b][q] = nxt[b][q];
   }
 }
 
@@ -1654,9 +1675,9 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
           BlurTile bt; bt.level = (short)l; bt.tx = (short)tx; bt.ty = (short)ty; bt.pad = 0;
           c->btiles.push_back(bt);
         }
-      for (int ty = 0; ty < (L.h + BM_TH - 1) / BM_TH; ty++)
+      for (int ty = 0, nty = (L.h + BM_TH - 1) / BM_TH; ty < nty; ty += BM_RC)       // k_blur7_mfma: ty = first 58-row chunk, pad = chunks of the workgroup
         for (int tx = 0; tx < (L.w + BM_TW - 1) / BM_TW; tx++) {
-          BlurTile bt; bt.level = (short)l; bt.tx = (short)tx; bt.ty = (short)ty; bt.pad = 0;
+          BlurTile bt; bt.level = (short)l; bt.tx = (short)tx; bt.ty = (short)ty; bt.pad = (short)std::min(BM_RC, nty - ty);
           c->mtiles.push_back(bt);
         }
     }

@@ -52,6 +52,13 @@ int orbhip_set_default_device(int device);
  * per-frame kernels are dispatched ahead of another thread's queued bundle-adjustment work).  Results do not depend on it.   */
 int orbhip_set_thread_priority(int high);
 int orbhip_get_default_device(void);
+/* Copy between PINNED host memory (hipHostMalloc / hipHostRegister: mapped into the device's address space) and device memory by a
+ * KERNEL on `stream` - the way the library's own host-pointer entry points move their staging blocks.  For callers that feed
+ * orbx_extract_batch_device from host frames (src/Frame.cc:116 hands operator() a host cv::Mat): upload, extract + match and download
+ * of consecutive batches then overlap as ordinary concurrent kernels on three streams, without the runtime's copy-engine path
+ * (which stalls host threads that copy concurrently, and whose overlap with compute depends on the process's hardware-queue count:
+ * DESIGN.md section 6).  Either pointer may be the host one; no synchronisation.                                               */
+int orbhip_copy_pinned_async(void* dst, const void* src, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------- extractor --
  * Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-111,

@@ -6,7 +6,8 @@ import sqlite3, collections, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 MATCH = os.environ.get("PMC_MATCH_KERNEL", "k_match_pairs_mfma")      # (k_match_pairs when the passes ran with ORBHIP_MATCH_MFMA=0)
-NAMES = ["k_resize", "k_fast_cells", "k_octree", "k_blur7", "k_describe", MATCH]
+BLUR = os.environ.get("PMC_BLUR_KERNEL", "k_blur7_mfma")      # (k_blur7 when the passes ran with ORBHIP_BLUR_MFMA=0)
+NAMES = ["k_resize", "k_fast_cells", "k_octree", BLUR, "k_describe", MATCH]
 
 
 def load(tag):
