@@ -450,6 +450,80 @@ class ORBmatcherT {
     return nFused;
   }
 
+  // ---- LocalMapping::SearchInNeighbors, the loop `for (target keyframes) matcher.Fuse(neighbor_keyframe, map_point_matches)`
+  //      (src/LocalMapping.cc:437-442) with the candidate selection of ALL target keyframes in ONE call (orbl_fuse_batch, round 5).
+  // The projection and its gates are evaluated per (keyframe, point) up front - they read only what no Fuse changes (poses,
+  // positions, normals, distance bounds) - the validity tests (NULL / isBad / IsInKeyFrame) and the Replace / AddObservation
+  // mutation run keyframe after keyframe in the reference's order.  What a mutation CAN change for a later keyframe is a point's
+  // descriptor (MapPoint::Replace ends with ComputeDistinctiveDescriptors on the survivor, src/MapPoint.cc:230): a point whose
+  // descriptor no longer equals the one the batch searched with is searched again, alone, for the keyframe at hand.
+  // Returns the per-keyframe return values of Fuse.
+  std::vector<int> Fuse(const std::vector<KeyFrame*>& targets, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0) {
+    using namespace dropin;
+    const size_t nt = targets.size(), nq = vpMapPoints.size();
+    std::vector<int> ret(nt, 0);
+    if (!nt || !nq) return ret;
+    std::vector<float> uv(2 * nt * nq, 0.f), radius(nt * nq, 0.f); std::vector<int32_t> level(nt * nq, -1);
+    std::vector<uint8_t> desc(32 * nq, 0);
+    for (size_t i = 0; i < nq; i++) if (vpMapPoints[i]) std::memcpy(&desc[32 * i], vpMapPoints[i]->GetDescriptor().ptr(0), 32);
+    std::vector<Flat> T(nt); std::vector<orbl_fuse_keyframe> kf(nt);
+    for (size_t t = 0; t < nt; t++) {
+      KeyFrame* pKF = targets[t];
+      Sim3Cam C;
+      C.R = block33(pKF->GetRotation()); C.t = p3(pKF->GetTranslation()); C.Ow = p3(pKF->GetCameraCenter());
+      for (size_t i = 0; i < nq; i++) {
+        MapPoint* pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        float u, v, dist; int lv;
+        if (!project_with_gates(pKF, C, pMP, 0.0f, true, &u, &v, &dist, &lv)) continue;
+        const size_t e = t * nq + i;
+        uv[2 * e] = u; uv[2 * e + 1] = v; radius[e] = th * pKF->scale_factors_[lv]; level[e] = lv;
+      }
+      flatten(*pKF, &T[t]);
+      kf[t].kps = T[t].kps4.data(); kf[t].desc = T[t].desc; kf[t].n = T[t].n;
+      for (int k = 0; k < 4; k++) kf[t].bounds[k] = T[t].bounds[k];
+    }
+    std::vector<int32_t> best_idx(nt * nq, -1), best_dist(nt * nq, 256);
+    check(orbl_fuse_batch(kf.data(), (int)nt, uv.data(), radius.data(), level.data(), (int)nq, desc.data(), targets[0]->inv_level_sigma2s_.data(),
+                          (int)targets[0]->inv_level_sigma2s_.size(), best_idx.data(), best_dist.data()), "orbl_fuse_batch");
+    for (size_t t = 0; t < nt; t++) {
+      KeyFrame* pKF = targets[t];
+      int nFused = 0;
+      for (size_t i = 0; i < nq; i++) {
+        MapPoint* pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        const size_t e = t * nq + i;
+        if (level[e] < 0) continue;
+        int bestIdx = best_idx[e], bestDist = best_dist[e];
+        if (std::memcmp(&desc[32 * i], pMP->GetDescriptor().ptr(0), 32) != 0) {      // the descriptor changed since the batch: this point, this keyframe, again
+          Queries Q(1);
+          Q.valid[0] = 1; Q.uv[0] = uv[2 * e]; Q.uv[1] = uv[2 * e + 1]; Q.radius[0] = radius[e]; Q.pred[0] = level[e];
+          Q.set_desc(0, pMP->GetDescriptor());
+          int32_t m1 = -1, d1 = 256; int n1 = 0;
+          check(orbm_search_by_projection(T[t].kps4.data(), T[t].desc, T[t].n, T[t].bounds, Q.uv.data(), Q.radius.data(), nullptr, nullptr, Q.pred.data(), Q.desc.data(),
+                                          Q.valid.data(), nullptr, 1, pKF->inv_level_sigma2s_.data(), 5.99f, nullptr, 0, mfNNratio, 256, 0, &m1, &d1, &n1),
+                "orbm_search_by_projection");
+          bestIdx = m1; bestDist = d1;
+        }
+        if (bestIdx < 0 || bestDist > TH_LOW) continue;
+        MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+        if (pMPinKF) {
+          if (!pMPinKF->isBad()) {
+            if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+            else pMPinKF->Replace(pMP);
+          }
+        } else {
+          pMP->AddObservation(pKF, bestIdx);
+          pKF->AddMapPoint(pMP, bestIdx);
+        }
+        nFused++;
+      }
+      ret[t] = nFused;
+    }
+    return ret;
+  }
+
   // ---- LoopClosing::SearchAndFuse (src/LoopClosing.cc:611), src/ORBmatcher.cc:844-954 ------------------------------------
   int Fuse(KeyFrame* pKF, Matrix4d Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) {
     using namespace dropin;
@@ -1061,6 +1135,68 @@ struct FrameOpsT {
     dropin::check(orbm_triangulate_matches(T1, T2, K1, K2, kp1.data(), kp2.data(), (int)n, current_keyframe->level_sigma2s_.data(), current_keyframe->scale_factors_.data(),
                                            (int)current_keyframe->scale_factors_.size(), ratioFactor, X.data(), good.data()), "orbm_triangulate_matches");
     for (size_t k = 0; k < n; k++) { (*ok)[k] = good[k] != 0; for (int c = 0; c < 3; c++) (*x3D)[k][c] = X[3 * k + c]; }
+  }
+
+  // LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:196-396), everything between the baseline test and the MapPoint construction
+  // for ALL neighbours in ONE call (orbl_create_new_map_points): per neighbour k the accepted triangulations {idx1, idx2, x3D} in
+  // idx1 order - SearchForTriangulation with ORBmatcher(0.6, false) (:203, :250), the per-match body (:267-378), and the hand-over
+  // between neighbours (a keypoint of the current keyframe that got a point is not searched again: AddMapPoint :383 /
+  // src/ORBmatcher.cc:621-623).  `neighbours` = the keyframes that passed the baseline test (:231-244), F12s[k] =
+  // ComputeF12(current_keyframe_, neighbours[k]) (:247); abort (nullable) = the flag CheckNewKeyFrames() reads (:227): looked at
+  // before every neighbour after the first; *n_processed neighbours are complete.  The caller's loop over the result keeps the
+  // reference's lines :380-393 (new MapPoint, AddObservation x 2, AddMapPoint x 2, ComputeDistinctiveDescriptors, UpdateNormalAndDepth).
+  struct NewPoint { int idx1, idx2; Vector3d x3D; };
+  static std::vector<std::vector<NewPoint> > CreateNewMapPoints(KeyFrame* current_keyframe, const std::vector<KeyFrame*>& neighbours, const std::vector<Matrix3d>& F12s,
+                                                                const float ratioFactor, const volatile bool* abort = nullptr, int* n_processed = nullptr) {
+    using namespace dropin;
+    const size_t nn = neighbours.size();
+    std::vector<std::vector<NewPoint> > out(nn);
+    if (n_processed) *n_processed = 0;
+    if (!nn) return out;
+    Flat A; flatten(*current_keyframe, &A);
+    FlatFV f1; flatten_fv(current_keyframe->feature_vector_, &f1);
+    std::vector<uint8_t> um1((size_t)std::max(A.n, 1));
+    for (int i = 0; i < A.n; i++) um1[i] = current_keyframe->GetMapPoint(i) ? 0 : 1;
+    double T1[12];
+    const Matrix3d R1 = current_keyframe->GetRotation(); const Vector3d t1 = current_keyframe->GetTranslation();
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T1[4 * r + c] = R1(r, c); T1[4 * r + 3] = t1[r]; }
+    const float K1[4] = {current_keyframe->fx_, current_keyframe->fy_, current_keyframe->cx_, current_keyframe->cy_};
+    const P3 Cw = p3(current_keyframe->GetCameraCenter());
+    std::vector<Flat> B(nn); std::vector<FlatFV> f2(nn); std::vector<std::vector<uint8_t> > um2(nn);
+    std::vector<orbl_keyframe> nb(nn);
+    for (size_t k = 0; k < nn; k++) {
+      KeyFrame* o = neighbours[k];
+      flatten(*o, &B[k]); flatten_fv(o->feature_vector_, &f2[k]);
+      um2[k].resize((size_t)std::max(B[k].n, 1));
+      for (int i = 0; i < B[k].n; i++) um2[k][i] = o->GetMapPoint(i) ? 0 : 1;
+      orbl_keyframe& q = nb[k];
+      q.kps = B[k].kps4.data(); q.desc = B[k].desc; q.unmapped = um2[k].data(); q.n = B[k].n;
+      q.fv_node = f2[k].node.data(); q.fv_off = f2[k].off.data(); q.fv_idx = f2[k].idx.data(); q.fv_n = (int)f2[k].node.size();
+      const Matrix3d R2 = o->GetRotation(); const Vector3d t2 = o->GetTranslation();
+      for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { q.Tcw[4 * r + c] = R2(r, c); q.F12[3 * r + c] = F12s[k](r, c); } q.Tcw[4 * r + 3] = t2[r]; }
+      q.K4[0] = o->fx_; q.K4[1] = o->fy_; q.K4[2] = o->cx_; q.K4[3] = o->cy_;
+      // epipole in the neighbour's image (src/ORBmatcher.cc:589-596)
+      const P3 C2 = add(rot(R2, Cw), p3(t2));
+      const float invz = 1.0f / C2.z;
+      q.ex = o->fx_ * C2.x * invz + o->cx_; q.ey = o->fy_ * C2.y * invz + o->cy_;
+    }
+    std::vector<int32_t> m12(nn * (size_t)std::max(A.n, 1)); std::vector<uint8_t> ok(nn * (size_t)std::max(A.n, 1)); std::vector<double> X(3 * nn * (size_t)std::max(A.n, 1));
+    // (a bool the reference's thread sets is read as a byte: sizeof(bool) == 1 on every ABI this builds for)
+    static_assert(sizeof(bool) == 1, "the abort flag is read as one byte");
+    int npr = 0;
+    check(orbl_create_new_map_points(A.kps4.data(), A.desc, um1.data(), A.n, f1.node.data(), f1.off.data(), f1.idx.data(), (int)f1.node.size(), T1, K1, nb.data(), (int)nn,
+                                     current_keyframe->scale_factors_.data(), current_keyframe->level_sigma2s_.data(), (int)current_keyframe->scale_factors_.size(), ratioFactor,
+                                     (const volatile uint8_t*)abort, m12.data(), ok.data(), X.data(), &npr), "orbl_create_new_map_points");
+    if (n_processed) *n_processed = npr;
+    for (size_t k = 0; k < (size_t)npr; k++)
+      for (int i = 0; i < A.n; i++) {
+        const size_t e = k * (size_t)A.n + i;
+        if (!ok[e]) continue;
+        NewPoint np; np.idx1 = i; np.idx2 = m12[e];
+        for (int c = 0; c < 3; c++) np.x3D[c] = X[3 * e + c];
+        out[k].push_back(np);
+      }
+    return out;
   }
 };
 

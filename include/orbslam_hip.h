@@ -312,6 +312,51 @@ int orbm_search_for_triangulation(const float* kps1, const uint8_t* desc1, const
                                   const double* F12, float ex, float ey, const float* scale_factors,
                                   const float* level_sigma2, int check_ori, int32_t* match12, int* nmatches);
 
+/* ---- LocalMapping::CreateNewMapPoints, device-resident across the neighbour keyframes (src/LocalMapping.cc:196-396; round 5) ----
+ * For every neighbour keyframe IN ORDER: ORBmatcher::SearchForTriangulation(current, neighbour, F12, pairs, false) with the matcher of
+ * that call site, ORBmatcher(0.6, false) (:203: no orientation check; src/ORBmatcher.cc:582-722), then the per-match body (:267-378:
+ * ray parallax, linear triangulation, depth / chi-square / scale gates) - and what makes the neighbours depend on each other: a
+ * triangulated match gives the current keyframe's keypoint a map point (AddMapPoint, :383), so the next neighbour's search skips it
+ * (src/ORBmatcher.cc:621-623).  One upload, one kernel per neighbour on the calling thread's stream, one download; the map mutation
+ * (:380-393) is the caller's loop over the accepted entries (csrc/compat/orbslam_dropin.h: CreateNewMapPoints).
+ *   current keyframe: kps1[n1][4] = {x, y, octave, angle} undistorted keypoints, desc1[n1][32], unmapped1[n1] (1 = GetMapPoint(idx) ==
+ *     NULL; NULL = all), its FeatureVector as ascending node ids + CSR lists (orbv_transform's layout), Tcw1 row-major 3x4, K1 = {fx, fy,
+ *     cx, cy}.  Neighbours that fail the baseline test (:231-244) are left out by the caller.
+ *   scale_factors / level_sigma2 [n_levels]: the extractor's tables (every keyframe copies them from the same ORBextractor);
+ *     ratio_factor = 1.5f * current_keyframe_->scale_factor_ (:221).
+ *   stop (nullable): a byte the caller may raise while the call runs = CheckNewKeyFrames() (:227): it is looked at ONCE before every
+ *     neighbour after the first; the neighbours before it are complete, *n_processed says how many.
+ *   out, per neighbour k and keypoint i of the current keyframe: match12[k][i] = SearchForTriangulation's partner or -1,
+ *     ok[k][i] = 1 when the triangulation passed every gate, x3D[k][i] = the new point (zeros otherwise).                       */
+typedef struct orbl_keyframe {
+  const float* kps; const uint8_t* desc; const uint8_t* unmapped; int n;           /* as kps1 / desc1 / unmapped1 */
+  const uint32_t* fv_node; const uint32_t* fv_off; const uint32_t* fv_idx; int fv_n;
+  double Tcw[12]; float K4[4];
+  double F12[9];              /* LocalMapping::ComputeF12(current, this) (:507-523), row-major */
+  float ex, ey;               /* the epipole of the current keyframe's centre in this keyframe (src/ORBmatcher.cc:588-595) */
+} orbl_keyframe;
+int orbl_create_new_map_points(const float* kps1, const uint8_t* desc1, const uint8_t* unmapped1, int n1, const uint32_t* fv1_node,
+                               const uint32_t* fv1_off, const uint32_t* fv1_idx, int fv1_n, const double* Tcw1, const float* K1,
+                               const orbl_keyframe* neighbours, int n_neighbours, const float* scale_factors, const float* level_sigma2,
+                               int n_levels, float ratio_factor, const volatile uint8_t* stop, int32_t* match12, uint8_t* ok, double* x3D,
+                               int* n_processed);
+/* ---- LocalMapping::SearchInNeighbors (:398-505): the candidate selection of ORBmatcher::Fuse (src/ORBmatcher.cc:724-842) for ALL
+ * target keyframes of one loop in ONE call.  The caller keeps the reference's own projection (Rcw p + tcw, IsInImage, the distance
+ * and viewing-angle gates, PredictScale: :739-778) and passes, per (keyframe t, map point m), q_uv[t][m] = (u, v), q_radius[t][m] =
+ * th * scale_factors_[level], q_level[t][m] = nPredictedLevel or -1 when a gate failed; mp_desc[m] = pMP->GetDescriptor().  The call
+ * does KeyFrame::GetFeaturesInArea on every keyframe's own 64 x 48 grid (src/KeyFrame.cc:575-622), the level window (:781), the
+ * chi-square gate (:789) and the descriptor distances: best_idx[t][m] = the keypoint (-1: none), best_dist[t][m] (256: none); the
+ * caller applies `bestDist <= TH_LOW` and the Replace / AddObservation mutation in the reference's order (:806-823).  A map point
+ * whose descriptor changes through such a mutation (MapPoint::Replace recomputes it) is re-queried by the caller for the keyframes
+ * that follow (csrc/compat/orbslam_dropin.h).                                                                                    */
+typedef struct orbl_fuse_keyframe {
+  const float* kps; const uint8_t* desc; int n;      /* undistorted keypoints {x, y, octave, angle}, descriptors */
+  float bounds[4];                                   /* {min_x_, max_x_, min_y_, max_y_} */
+} orbl_fuse_keyframe;
+int orbl_fuse_batch(const orbl_fuse_keyframe* keyframes, int n_keyframes, const float* q_uv, const float* q_radius, const int32_t* q_level,
+                    int n_map_points, const uint8_t* mp_desc, const float* inv_level_sigma2, int n_levels, int32_t* best_idx,
+                    int32_t* best_dist);
+
 /* ---- the per-frame Tracking step with the motion model, device-resident (src/Tracking.cc:616-646): Frame construction
  * (ORBextractor::operator(), AssignFeaturesToGrid; zero distortion: the undistorted keypoints are the raw ones, as for the
  * KITTI configurations), ORBmatcher::SearchByProjection(current_frame_, last_frame_, th) (src/ORBmatcher.cc:1161-1271,

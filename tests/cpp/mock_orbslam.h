@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <climits>
 #include <map>
 #include <mutex>
 #include <random>
@@ -78,6 +79,7 @@ struct MapPoint {
   bool IsInKeyFrame(KeyFrame* kf) { return observations_.count(kf) != 0; }
   bool isBad() { return is_bad_; }
   void Replace(MapPoint* pMP);
+  void ComputeDistinctiveDescriptors();                      // src/MapPoint.cc:256-315
   Mat GetDescriptor() { return descriptor_; }
   void UpdateNormalAndDepth() { n_update_normal_calls_++; }
   float GetMinDistanceInvariance() { return 0.8f * min_distance_; } float GetMaxDistanceInvariance() { return 1.2f * max_distance_; }
@@ -206,6 +208,30 @@ inline void MapPoint::Replace(MapPoint* pMP) {                // src/MapPoint.cc
     if (!pMP->IsInKeyFrame(kf)) { kf->ReplaceMapPointMatch(o.second, pMP); pMP->AddObservation(kf, o.second); }
     else kf->EraseMapPointMatch(o.second);
   }
+  pMP->ComputeDistinctiveDescriptors();                       // (:230): the survivor's descriptor may change - later searches see the new one
+}
+
+inline void MapPoint::ComputeDistinctiveDescriptors() {       // src/MapPoint.cc:256-315: the observed descriptor with the least median distance to the others
+  if (is_bad_ || observations_.empty()) return;
+  std::vector<const uint8_t*> ds;
+  for (auto& o : observations_) if (!o.first->isBad()) ds.push_back(o.first->descriptors_.ptr((int)o.second));
+  if (ds.empty()) return;
+  const size_t N = ds.size();
+  std::vector<std::vector<int> > dist(N, std::vector<int>(N, 0));
+  for (size_t i = 0; i < N; i++)
+    for (size_t j = i + 1; j < N; j++) {
+      int d = 0;
+      for (int k = 0; k < 32; k++) d += __builtin_popcount((unsigned)(ds[i][k] ^ ds[j][k]));
+      dist[i][j] = d; dist[j][i] = d;
+    }
+  int best_median = INT_MAX, best_index = 0;
+  for (size_t i = 0; i < N; i++) {
+    std::vector<int> v(dist[i]);
+    std::sort(v.begin(), v.end());
+    const int median = v[(size_t)(0.5 * (N - 1))];
+    if (median < best_median) { best_median = median; best_index = (int)i; }
+  }
+  std::memcpy(descriptor_.ptr(0), ds[best_index], 32);
 }
 
 struct Map {

@@ -286,6 +286,46 @@ int main(int argc, char** argv) {
     printf("CreateNewMapPoints: %d new points from %zu neighbours\n", nnew, neighbor_keyframes.size());
   });
 
+  // ---- the same function with everything between the baseline test and the MapPoint construction in ONE call for all neighbours
+  //      (FrameOps::CreateNewMapPoints -> orbl_create_new_map_points, round 5): same scene, same replay on the Python side
+  run_case("create_new_map_points_batched", 26, 6, [&](Scene& S) {
+    for (KeyFrame& kf : S.kfs) for (int i = 0; i < kf.N_; i++) if (i % 5 < 2 && kf.map_points_[i]) { kf.map_points_[i]->EraseObservation(&kf); kf.map_points_[i] = nullptr; }
+    for (MapPoint& mp : S.mps) mp.reference_keyframe_ = mp.observations_.empty() ? nullptr : mp.observations_.begin()->first;
+  }, [&](Scene& S, Writer& W, std::vector<MapPoint*>& created) {
+    KeyFrame* current_keyframe_ = &S.kfs[5]; Map* map_ = &S.map;
+    W.iscalar("arg.kf", 5);
+    const std::vector<KeyFrame*> neighbor_keyframes = current_keyframe_->GetBestCovisibilityKeyFrames(20);
+    const Vector3d Ow1 = current_keyframe_->GetCameraCenter();
+    const float ratioFactor = 1.5f * current_keyframe_->scale_factor_;
+    std::vector<KeyFrame*> kept; std::vector<Matrix3d> F12s;
+    for (size_t i = 0; i < neighbor_keyframes.size(); i++) {                 // the baseline test and F12 of every neighbour (:229-247)
+      KeyFrame* neighbor_keyframe = neighbor_keyframes[i];
+      const Vector3d vBaseline = neighbor_keyframe->GetCameraCenter() - Ow1;
+      const float baseline = vBaseline.norm();
+      const float medianDepthKF2 = neighbor_keyframe->ComputeSceneMedianDepth(2);
+      if (baseline / medianDepthKF2 < 0.01) continue;
+      kept.push_back(neighbor_keyframe); F12s.push_back(ComputeF12(current_keyframe_, neighbor_keyframe));
+    }
+    volatile bool abort_flag = false; int processed = 0;
+    const auto res = FrameOps::CreateNewMapPoints(current_keyframe_, kept, F12s, ratioFactor, &abort_flag, &processed);
+    int nnew = 0;
+    for (size_t k = 0; k < res.size(); k++)
+      for (const auto& e : res[k]) {                                           // (:380-393)
+        MapPoint* map_point = new MapPoint;
+        map_point->id_ = MapPoint::next_id_++; map_point->world_pose_ = e.x3D; map_point->reference_keyframe_ = current_keyframe_;
+        created.push_back(map_point);
+        map_point->AddObservation(current_keyframe_, e.idx1);
+        map_point->AddObservation(kept[k], e.idx2);
+        current_keyframe_->AddMapPoint(map_point, e.idx1);
+        kept[k]->AddMapPoint(map_point, e.idx2);
+        map_point->UpdateNormalAndDepth();
+        map_->AddMapPoint(map_point);
+        nnew++;
+      }
+    W.iscalar("ret", nnew);
+    printf("CreateNewMapPoints (one call for %zu neighbours, %d processed): %d new points\n", kept.size(), processed, nnew);
+  });
+
   // ---- LoopClosing::ComputeSim3: matcher.SearchBySim3(current_keyframe_, keyframe, map_point_matches, s, R, t, 7.5) followed by
   //      CeresOptimizer::OptimizeSim3(current_keyframe_, keyframe, map_point_matches, gScm, 10, is_fix_scale_)  (src/LoopClosing.cc:313-326)
   run_case("sim3_search_and_optimize", 19, 6, [&](Scene&) {}, [&](Scene& S, Writer& W, std::vector<MapPoint*>&) {
@@ -327,6 +367,33 @@ int main(int argc, char** argv) {
     const int ret = matcher.Fuse(neighbor_keyframe, map_point_matches);
     W.iscalar("ret", ret);
     printf("Fuse(KF, points): %d fused\n", ret);
+  });
+
+  // ---- LocalMapping::SearchInNeighbors, first loop: matcher.Fuse(neighbor_keyframe, map_point_matches) for every target keyframe
+  //      (src/LocalMapping.cc:437-442) through the batched form (one orbl_fuse_batch call for all targets).  Every neighbour lost some
+  //      matches and holds duplicate points: Replace runs, the survivors' descriptors are recomputed, and a later keyframe must be
+  //      searched with the NEW descriptor
+  run_case("fuse_many", 31, 6, [&](Scene& S) {
+    KeyFrame* current_keyframe_ = &S.kfs[5];
+    for (int k : {1, 2, 3, 4}) {
+      KeyFrame* neighbor_keyframe = &S.kfs[k];
+      for (int i = 0; i < neighbor_keyframe->N_; i++) {
+        MapPoint* p = neighbor_keyframe->map_points_[i];
+        if (!p) continue;
+        if ((i + k) % 4 == 0) { neighbor_keyframe->map_points_[i] = nullptr; p->EraseObservation(neighbor_keyframe); }
+        else if ((i + k) % 4 == 1 && p->IsInKeyFrame(current_keyframe_)) make_duplicate(S, neighbor_keyframe, i, ((i + k) % 8 == 1) ? 1 : 4);
+      }
+    }
+  }, [&](Scene& S, Writer& W, std::vector<MapPoint*>&) {
+    const sceneio::Index I(S);
+    KeyFrame* current_keyframe_ = &S.kfs[5];
+    std::vector<KeyFrame*> target_keyframes_ = {&S.kfs[3], &S.kfs[1], &S.kfs[4], &S.kfs[2]};
+    std::vector<MapPoint*> map_point_matches = current_keyframe_->GetMapPointMatches();
+    W.i32("arg.kfs", std::vector<int32_t>{3, 1, 4, 2}); W.i32("arg.points", I.mps(map_point_matches));
+    ORBmatcher matcher;
+    const std::vector<int> ret = matcher.Fuse(target_keyframes_, map_point_matches);
+    W.i32("ret", std::vector<int32_t>(ret.begin(), ret.end()));
+    printf("Fuse(%zu KFs, points): %d %d %d %d fused\n", ret.size(), ret[0], ret[1], ret[2], ret[3]);
   });
 
   // ---- LoopClosing::SearchAndFuse: matcher.Fuse(keyframe, eig_Scw, loop_map_points_, 4, replace_map_points)  (src/LoopClosing.cc:611)

@@ -154,6 +154,22 @@ class Scene:
                 self.kfs[kf].mp[idx] = q; self.add_observation(q, kf, idx)
             else:
                 self.kfs[kf].mp[idx] = -1
+        self.compute_distinctive_descriptors(q)                # (:230)
+
+    def compute_distinctive_descriptors(self, p):              # MapPoint::ComputeDistinctiveDescriptors (:256-315)
+        if self.mp_bad[p] or not self.obs[p]:
+            return
+        ds = [self.kfs[kf].desc[idx] for kf, idx in sorted(self.obs[p].items()) if not self.kfs[kf].bad]
+        if not ds:
+            return
+        N = len(ds)
+        D = [[int(np.unpackbits(ds[i] ^ ds[j]).sum()) for j in range(N)] for i in range(N)]
+        best_median, best = 1 << 30, 0
+        for i in range(N):
+            median = sorted(D[i])[int(0.5 * (N - 1))]
+            if median < best_median:
+                best_median, best = median, i
+        self.mp_desc[p] = ds[best]
 
 
 def _rt(T):
@@ -995,6 +1011,7 @@ def compare(A, B, pose_tol=0.0, point_tol=0.0, mp_rows=None):
     close("mp.pos", A.pos[:m] / scale, B.pos[:m] / scale, point_tol)
     gs = np.maximum(1.0, np.linalg.norm(B.gba_pos[:m], axis=1))[:, None]
     close("mp.gba_pos", A.gba_pos[:m] / gs, B.gba_pos[:m] / gs, point_tol)
+    close("mp.desc", A.mp_desc[:m], B.mp_desc[:m], 0.0)          # (MapPoint::Replace recomputes the survivor's descriptor)
     eq("map.kfs", A.map_kfs, B.map_kfs)
     return diffs
 
@@ -1081,6 +1098,14 @@ def check_case(path, oracle):
         ret = fuse_keyframe(S, ki, S.kfs[ki], [int(p) for p in R["arg.points"]])
         expect("ret", int(_sc(R, "ret")), ret); info = "%d fused, %d replaced" % (ret, sum(1 for a, b in zip(S.mp_bad, Scene(R, "before").mp_bad) if a and not b))
         if ret < 30: fails.append("weak case: %d fused" % ret)
+    elif name == "fuse_many":                                   # LocalMapping::SearchInNeighbors, first loop (src/LocalMapping.cc:437-442)
+        pts = [int(p) for p in R["arg.points"]]
+        rets = [fuse_keyframe(S, int(ki), S.kfs[int(ki)], pts) for ki in R["arg.kfs"]]
+        expect("ret", [int(v) for v in R["ret"]], rets)
+        before = Scene(R, "before")
+        changed = sum(1 for a, b in zip(S.mp_desc, before.mp_desc) if not np.array_equal(a, b))
+        info = "%s fused per keyframe, %d replaced, %d descriptors recomputed" % (rets, sum(1 for a, b in zip(S.mp_bad, before.mp_bad) if a and not b), changed)
+        if sum(rets) < 60 or changed < 3: fails.append("weak case: %s fused, %d descriptors changed" % (rets, changed))
     elif name == "fuse_sim3":
         ki = int(_sc(R, "arg.kf"))
         ret, rep = fuse_sim3(S, ki, S.kfs[ki], R["arg.Scw"].reshape(4, 4), [int(p) for p in R["arg.points"]], 4.0)
@@ -1140,7 +1165,7 @@ def check_case(path, oracle):
             expect("query %d" % k, idx[off[k]:off[k + 1]].tolist(), want); tot += len(want)
         info = "%d candidates" % tot
         if tot < 200: fails.append("weak case")
-    elif name == "create_new_map_points":
+    elif name in ("create_new_map_points", "create_new_map_points_batched"):
         ki = int(_sc(R, "arg.kf")); kf = S.kfs[ki]
         nnew = 0
         n0 = len(S.mp_id)

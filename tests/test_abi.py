@@ -26,7 +26,7 @@ def _declared_functions():
     txt = open(os.path.join(ROOT, "include", "orbslam_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+)?(?:int|double|char\*|void)\s*\*?\s*([a-z_0-9]+)\s*\(", txt, flags=re.M)
-    return sorted(set(n for n in names if n.startswith(("orbx_", "orbm_", "orbv_", "orbt_", "ba_", "orbhip_"))))
+    return sorted(set(n for n in names if n.startswith(("orbx_", "orbm_", "orbv_", "orbt_", "orbl_", "ba_", "orbhip_"))))
 
 
 def test_header_symbols_are_exported(lib):
