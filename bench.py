@@ -371,7 +371,28 @@ def pcie_pipeline(torch, dev, ex, mt, frames_host, B, resident_fps, n_batches=24
             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")}
 
 
-def run_ba_leg(local_rank, rank, cpu, oracle_lib):
+def rccl_summary(path):
+    """A few facts out of RCCL's NCCL_DEBUG=INFO log of this rank: the communicator line (rank / nranks / device), how many channels
+    it built and over which transports the peers are reached."""
+    import re
+    out = {"log": path}
+    try:
+        txt = open(path, errors="replace").read()
+    except OSError as e:
+        out["error"] = repr(e); return out
+    m = re.findall(r"comm \S+ rank (\d+) nranks (\d+) cudaDev (\d+)[^\n]*", txt)
+    if m: out["rank"], out["nranks"], out["device"] = (int(v) for v in m[-1])
+    init = [l.strip() for l in txt.splitlines() if "Init COMPLETE" in l]
+    if init: out["init_complete"] = init[-1][-200:]
+    out["channel_lines"] = sum(1 for l in txt.splitlines() if re.search(r"Channel \d+", l))
+    via = re.findall(r"via (\S+)", txt)
+    out["transports"] = {k: via.count(k) for k in sorted(set(via))}
+    ver = re.search(r"(RCCL version [^\n]+|NCCL version [^\n]+)", txt)
+    if ver: out["version"] = ver.group(1).strip()
+    return out
+
+
+def run_ba_leg(local_rank, rank, cpu, oracle_lib, quick=False):
     """The LocalBA / PoseOptimization / GlobalBA legs (bench_ba.py) in a process of their own, on this
     rank's device; returns bench_ba.run's dictionary (with `_final_points`)."""
     import tempfile
@@ -382,7 +403,7 @@ def run_ba_leg(local_rank, rank, cpu, oracle_lib):
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     with tempfile.TemporaryDirectory(prefix="orbhip_ba_") as d:
         cmd = [sys.executable, os.path.join(ROOT, "bench_ba.py"), "--device", str(local_rank), "--rank", str(rank),
-               "--cpu", "1" if cpu else "0", "--oracle-lib", oracle_lib or "", "--out", d]
+               "--cpu", "1" if cpu else "0", "--oracle-lib", oracle_lib or "", "--quick", "1" if quick else "0", "--out", d]
         p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if p.returncode != 0:
             raise RuntimeError("BA leg failed (rc %d): %s" % (p.returncode, (p.stderr or p.stdout)[-1500:]))
@@ -411,6 +432,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-fed (PCIe-inclusive) figure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--ba-quick", action="store_true", help="shortened BA legs (tests of the N > 1 plumbing; not benchmark figures)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous of the N ranks only (CPU, gloo)")
     args = ap.parse_args()
 
@@ -424,6 +446,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.launch_check:
         return launch_check(rank, world)
+    nccl_log_dir = None
     pinned_cpus = None
     if world > 1:
         pinned_cpus = numa_cpus_of_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
@@ -451,7 +474,7 @@ def main():
     if not args.no_ba:
         try:
             nat = oracle_build.get("library") if isinstance(oracle_build, dict) and oracle_build.get("native") else None
-            localba = run_ba_leg(dev_ord, rank, (not args.no_cpu) and world == 1, nat)
+            localba = run_ba_leg(dev_ord, rank, (not args.no_cpu) and world == 1, nat, quick=args.ba_quick)
         except Exception as e:                       # never lose the headline line to the secondary leg
             localba, ba_ok = {"error": repr(e)}, 0
 
@@ -477,6 +500,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if shared else "nccl"
+        if not shared and "NCCL_DEBUG_FILE" not in os.environ and os.environ.get("NCCL_DEBUG", "").upper() not in ("TRACE",):
+            # RCCL's own account of the communicator (ranks, channels, transports) goes to a file per rank; rank 0 summarises it into
+            # `collective.rccl` so that the first real N-GPU run shows its topology at a glance
+            import tempfile
+            nccl_log_dir = tempfile.mkdtemp(prefix="orbhip_rccl_")
+            os.environ["NCCL_DEBUG"] = "INFO"; os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH"
+            os.environ["NCCL_DEBUG_FILE"] = os.path.join(nccl_log_dir, "rccl_rank%d.log" % rank)
         if shared:
             # (gloo's C++ side prints "[Gloo] Rank r is connected to ..." on STDOUT: rank 0's stdout must carry the JSON line only)
             sys.stdout.flush(); saved = os.dup(1); os.dup2(2, 1)
@@ -695,11 +725,17 @@ def main():
                 barrier(); tg = time.perf_counter()
                 allp, _, cnts = sharding.allgather_landmarks(pts)
                 torch.cuda.synchronize()
+                dump = os.environ.get("ORBHIP_BENCH_DUMP_DIR")          # (tests: every rank's own points and rank 0's merged array)
+                if dump:
+                    np.save(os.path.join(dump, "final_points_rank%d.npy" % rank), localba["_final_points"])
+                    if rank == 0: np.save(os.path.join(dump, "merged_points.npy"), allp.cpu().numpy())
                 collective = {"backend": backend + (" (RCCL)" if backend == "nccl" else " (shared-GPU dry run)"),
                               "world_size": dist.get_world_size(), "op": "all_gather of every rank's GlobalBA landmarks",
                               "landmark_allgather_ms": (time.perf_counter() - tg) * 1e3,
                               "points_per_rank": cnts, "merged_points": int(allp.shape[0]),
                               "payload_bytes": int(allp.shape[0]) * 24}
+                if nccl_log_dir:
+                    collective["rccl"] = rccl_summary(os.path.join(nccl_log_dir, "rccl_rank%d.log" % rank))
         if isinstance(localba, dict):
             localba.pop("_final_points", None)
     if rank == 0:
@@ -880,6 +916,13 @@ def main():
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_host, args.cpu_sample, args.cpu_all_seconds)
             out["cpu_baseline"]["build"] = oracle_build
+        elif not args.no_cpu:
+            # N > 1: the contract asks for the CPU baseline at N = 1 only; rank 0 still times a REDUCED sample (its share of the host
+            # cores is a fraction of the box) so that the line carries the field - the figure to quote is the N = 1 run's
+            from oracle import pyoracle as po
+            po.use_library(None)
+            out["cpu_baseline"] = cpu_baseline(frames_host, min(args.cpu_sample, 12), min(args.cpu_all_seconds, 2.0))
+            out["cpu_baseline"]["note"] = "reduced sample on rank 0 of an N = %d run (canonical oracle build, this rank's share of the host cores): quote the N = 1 run" % world
         if localba is not None:
             if isinstance(localba.get("cpu_baseline"), dict):
                 localba["cpu_baseline"]["build"] = oracle_build

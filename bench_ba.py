@@ -44,9 +44,13 @@ def _ncores():
         return os.cpu_count() or 1
 
 
-def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
+def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
+    """quick: a shortened leg for tests of the N > 1 plumbing (one single solve, a small lockstep batch, ten GlobalBA iterations, no
+    eight-sub-map batch) - its figures are not benchmark numbers and the record says so."""
     import torch
     out = {}
+    if quick:
+        n_localba = 1; out["quick"] = True
     roof = {"bound": "mfma", "kernel": "reduced camera system: Schur complement (k_ba_schur) + dense FP64-MFMA Cholesky (k_chol_*)",
             "definition": "(Schur GEMM flops + n^3/3) x LM iterations / solve time / FP64 matrix peak (SURVEY 8(d))",
             "peak_source": "AMD MI355X datasheet, FP64 matrix 78.6 TFLOP/s", "cases": {}}
@@ -75,7 +79,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     # in flight from host threads (one HIP stream + device workspace per thread)
     # (64 per call since round 2: the lockstep launches are bound by the sum of their kernels' exclusive times - ~0.85 ms of GPU
     # per solve - and larger launches fill the chip better: 16 x 8 -> 1110, 32 x 8 -> 1170, 64 x 8 -> 1270 solves/s)
-    nbatch, nthreads, n_each = 64, 12, 2      # (12 threads x 64 problems: 1737 - 1791 solves/s against 1552 - 1698 with 8, tools/ba_batch_thr.py)
+    nbatch, nthreads, n_each = (8, 2, 1) if quick else (64, 12, 2)      # (12 threads x 64 problems: 1737 - 1791 solves/s against 1552 - 1698 with 8, tools/ba_batch_thr.py)
     gs = [g] + [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(1, nbatch)]   # 64 distinct local maps
     probs = [(q["K4"], q["poses0"], q["cam_fixed"], local, q["pts0"], q["obs_cam"], q["obs_pt"], q["obs_uv"], q["obs_inv_sigma2"]) for q in gs]
     fl_batch = sum(sum(reduced_solve_flops(q)) for q in gs)
@@ -141,7 +145,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     optimizer.global_bundle_adjustment(*gargs, n_iterations=2)     # warm-up
     optimizer.get_profile()
     t0 = time.perf_counter()
-    gposes, gpts, gsum = optimizer.global_bundle_adjustment(*gargs, n_iterations=50)
+    gposes, gpts, gsum = optimizer.global_bundle_adjustment(*gargs, n_iterations=10 if quick else 50)
     dt = time.perf_counter() - t0
     dev_ms, _, nit = optimizer.get_profile()
     optimizer.set_profiling(False)
@@ -156,16 +160,17 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0):
     def _sub(g):
         w = np.asarray(g["obs_inv_sigma2"], np.float32).astype(np.float64)          # F7: weight = invSigma2 (a float in the reference)
         return (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, np.ones(len(w), np.uint8))
-    subs = [_sub(gg)] + [_sub(synth.make_ba_graph(2000 + 8 * rank + k, ncam=500, npts=50000, nobs=250000, n_fixed=1)) for k in range(1, 8)]
-    optimizer.bundle_adjustment_batch(subs, n_iterations=2)                           # warm-up (workspace, graph capture)
-    t0 = time.perf_counter()
-    res8 = optimizer.bundle_adjustment_batch(subs, n_iterations=50)
-    dt8 = time.perf_counter() - t0
-    it8 = sum(int(r8[2]["iterations"]) for r8 in res8)
-    roof["cases"]["c5_batched8"] = _roof((f5_schur + f5_chol) * it8, dt8,
-                                         "eight distinct 500-KF GlobalBA sub-maps as one lockstep batch on this GPU; wall time of their %d LM "
-                                         "iterations, copies and host structure setup (the calling thread and its helpers, ORBHIP_BA_PREP_THREADS) included" % it8)
-    out["globalba_8_submaps_ms"] = dt8 * 1e3
+    if not quick:
+        subs = [_sub(gg)] + [_sub(synth.make_ba_graph(2000 + 8 * rank + k, ncam=500, npts=50000, nobs=250000, n_fixed=1)) for k in range(1, 8)]
+        optimizer.bundle_adjustment_batch(subs, n_iterations=2)                           # warm-up (workspace, graph capture)
+        t0 = time.perf_counter()
+        res8 = optimizer.bundle_adjustment_batch(subs, n_iterations=50)
+        dt8 = time.perf_counter() - t0
+        it8 = sum(int(r8[2]["iterations"]) for r8 in res8)
+        roof["cases"]["c5_batched8"] = _roof((f5_schur + f5_chol) * it8, dt8,
+                                             "eight distinct 500-KF GlobalBA sub-maps as one lockstep batch on this GPU; wall time of their %d LM "
+                                             "iterations, copies and host structure setup (the calling thread and its helpers, ORBHIP_BA_PREP_THREADS) included" % it8)
+        out["globalba_8_submaps_ms"] = dt8 * 1e3
     out["roofline"] = roof
     out["globalba_500kf_ms"] = dt * 1e3
     out["globalba_500kf_iterations"] = int(gsum["iterations"])
@@ -220,6 +225,7 @@ def main(argv=None):
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--cpu", type=int, default=0)
     ap.add_argument("--oracle-lib", default="", help="the -march=native oracle build bench.py verified (empty: the canonical build)")
+    ap.add_argument("--quick", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args(argv)
     import torch
@@ -229,7 +235,7 @@ def main(argv=None):
     if a.cpu and a.oracle_lib:
         from oracle import pyoracle as po
         po.use_library(a.oracle_lib)
-    res = run(torch.device("cuda", a.device), cpu=bool(a.cpu), rank=a.rank)
+    res = run(torch.device("cuda", a.device), cpu=bool(a.cpu), rank=a.rank, quick=bool(a.quick))
     pts = res.pop("_final_points")
     res["process"] = {"own_process": True, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
     np.save(os.path.join(a.out, "final_points.npy"), pts)
