@@ -360,3 +360,35 @@ def test_match_frames_extreme_weights_and_sizes(oracle):
             torch.cuda.synchronize()
             om, on = oracle.match_frames(d1, a1, d2, a2, ratio, th, ori)
             assert int(nm[0]) == on and np.array_equal(m[0, :n1].cpu().numpy(), om), (n1, n2, ratio, th, ori)
+
+
+def test_rotation_pass_keeps_the_three_maxima_bins(oracle):
+    """The construction tools/pin/pin_matcher.cpp uses to pin ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1386-1418) through the
+    library's fused rotation-consistency pass, checked here against the oracle's three_maxima: one vocabulary node, every query an exact
+    copy of one target, angle differences with prescribed bin counts (clear maxima, the `< 0.1 max1` cut-offs, ties).  The reference's
+    bins are 30 DEGREES wide (factor = 1.0f / HISTO_LENGTH, bin = round(rot * factor): only bins 0 .. 12 of the 30 are ever used)."""
+    rng = np.random.default_rng(21)
+    cases = []
+    for spec in ({3: 40, 4: 30, 7: 20, 10: 5}, {0: 50, 11: 4, 10: 4}, {5: 50, 6: 30, 7: 4}, {2: 10, 9: 10, 1: 10, 5: 10}, {8: 12, 1: 12, 11: 7, 4: 7}):
+        c = np.zeros(30, np.int32)
+        for b, v in spec.items(): c[b] = v
+        cases.append(c)
+    for _ in range(20):
+        c = np.zeros(30, np.int32); c[:12] = np.where(rng.random(12) < 0.5, rng.integers(0, 25, 12), 0)
+        cases.append(c)
+    for c in cases:
+        n = int(c.sum())
+        if n == 0: continue
+        desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        bin_of = np.repeat(np.arange(30), c)
+        rot = 30.0 * bin_of + np.where(bin_of == 0, rng.integers(0, 11, n), rng.integers(-10, 11, n))      # (bin 0: -10 degrees would wrap to 350 = bin 12)
+        a2 = rng.integers(0, 360, n).astype(np.float32)
+        a1 = np.mod(a2 + rot, 360.0).astype(np.float32)
+        fv = (np.array([7], np.uint32), np.array([0, n], np.uint32), np.arange(n, dtype=np.uint32))
+        nm, m = _m(0.99, True).SearchByBoW(desc, None, a1, desc, None, a2, fv, fv, strict=False, th=50)
+        assert ((m == np.arange(n)) | (m == -1)).all()
+        kept = set(bin_of[m >= 0].tolist())
+        realised = np.bincount([oracle.rot_bin(x, y) for x, y in zip(a1, a2)], minlength=30).astype(np.int32)
+        assert np.array_equal(realised, c)                          # the angles really fall into the prescribed bins
+        want = set(int(b) for b in oracle.three_maxima(c) if b >= 0 and c[b] > 0)
+        assert kept == want, (c.tolist(), sorted(kept), sorted(want))

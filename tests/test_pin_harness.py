@@ -39,4 +39,4 @@ def test_pin_cases_have_the_layout_the_harness_reads(tmp_path):
     assert os.path.getsize(os.path.join(out, "ba_000.bin")) == 16 + 8 * (4 * ncam + 7 * ncam + 3 * npts + 2 * nobs) + ncam + 8 * nobs + 4 * nobs
     # nothing of the reference is stored under tools/pin
     for fn in os.listdir(os.path.join(ROOT, "tools", "pin")):
-        assert fn in ("CMakeLists.txt", "pin_extractor.cpp", "pin_solver.cpp", "make_cases.py", "README.md"), fn
+        assert fn in ("CMakeLists.txt", "pin_extractor.cpp", "pin_solver.cpp", "pin_matcher.cpp", "make_cases.py", "README.md"), fn
