@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("ORBHIP_LIB") or os.path.join(_HERE, "lib", "liborbsla
 
 # every symbol include/orbslam_hip.h declares (tests check that the library exports them all)
 SYMBOLS = [
-    "orbhip_last_error", "orbhip_device_count", "orbhip_version", "orbhip_set_default_device", "orbhip_get_default_device", "orbhip_set_thread_priority", "orbhip_copy_pinned_async", "orbl_create_new_map_points", "orbl_fuse_batch",
+    "orbhip_last_error", "orbhip_device_count", "orbhip_version", "orbhip_set_default_device", "orbhip_get_default_device", "orbhip_set_thread_priority", "orbhip_copy_pinned_async", "orbl_create_new_map_points", "orbl_fuse_batch", "orbt_relocalization_search_by_bow",
     "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_set_opencv_variant", "orbx_get_tables", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_set_profiling", "orbx_get_stage_ms", "orbx_get_level_image", "orbx_get_level_candidates", "orbx_get_level_selected",
     "orbm_descriptor_distance", "orbm_hamming_best2_device", "orbm_hamming_best2", "orbm_match_frames_batch_device",

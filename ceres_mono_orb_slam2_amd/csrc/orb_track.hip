@@ -1441,4 +1441,135 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
   return 0;
 }
 
+
+// ---- Tracking::Relocalization, first stage (src/Tracking.cc:979-1029): current_frame_.ComputeBoW() and, for EVERY candidate keyframe,
+// matcher.SearchByBoW(keyframe, current_frame_, map_point_matches_vector[i]) with ORBmatcher(0.75, true) - in ONE call: the frame's
+// vocabulary descent once, then the three kernels of the reference-keyframe step per candidate (k_trf_init, k_trf_bow: one wave per
+// vocabulary node, k_trf_finish: the rotation histogram), all on the calling thread's stream, one upload, one download.  The
+// candidates are independent (each fills its own vpMapPointMatches).  What follows in the reference - PnPsolver RANSAC per candidate,
+// then PoseOptimization / SearchByProjection(F, KF, found, th, ORBdist) rounds - starts from a PnP pose and stays with the caller
+// (PnP is out of scope; the rounds are ba_pose_optimization and orbm_search_by_projection's reloc_kf form).
+int orbt_relocalization_search_by_bow(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* img, int w, int h, int stride, const float* K4, const float* bounds,
+                                      const orbt_reloc_keyframe* cand, int n_cand, float nnratio, int check_ori, orbx_keypoint* kps_out, uint8_t* desc_out, int cap,
+                                      uint32_t* bow_word, double* bow_value, int* n_words, uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes,
+                                      int32_t* slot_owner, int32_t* nmatches, int* n_keypoints) {
+  CallClock call_clock;
+  ORBHIP_REQUIRE(ctx && voc && K4 && bounds && n_words && n_fv_nodes && fv_off && n_keypoints && n_cand >= 0 && (n_cand == 0 || (cand && slot_owner && nmatches)), ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(!img || (w > 0 && h > 0 && stride >= w), ORBHIP_EINVAL, "bad image dimensions");
+  const int icap = orbx_max_keypoints(ctx);
+  ORBHIP_REQUIRE(icap <= TRK_MAXKP, ORBHIP_ECAP, "more than 4096 features per frame");
+  ORBHIP_REQUIRE(cap >= icap, ORBHIP_ECAP, "output capacity below orbx_max_keypoints(ctx)");
+  const int nlevels = orbx_get_levels(ctx);
+  ORBHIP_REQUIRE(nlevels > 0 && nlevels <= 16, ORBHIP_EINVAL, "bad level count");
+  for (int i = 0; i < n_cand; i++)
+    ORBHIP_REQUIRE(cand[i].n >= 0 && cand[i].fv_n >= 0 && (cand[i].n == 0 || (cand[i].desc && cand[i].valid && cand[i].angle)) &&
+                   (cand[i].fv_n == 0 || (cand[i].fv_node && cand[i].fv_off && cand[i].fv_idx)), ORBHIP_EINVAL, "NULL candidate argument");
+  TrkFrame& TF = g_trk_frame;
+  ThreadWs& W = thread_ws();
+  int rc = W.begin();
+  if (rc) return rc;
+  ORBHIP_REQUIRE(orbhip::orbx_ctx_device(ctx) == W.device, ORBHIP_EINVAL, "the extractor context was created on another device than orbhip_set_default_device() selects");
+  if (TF.device != W.device) { TF = TrkFrame(); TF.device = W.device; }
+  float scale[16], inv_sigma2[16];
+  if (int r2 = orbx_get_tables(ctx, scale, nullptr, nullptr, inv_sigma2, nullptr)) return r2;
+  ThreadWs::Pack in;
+  TrkIn PI; std::memset(&PI, 0, sizeof(PI));
+  for (int k = 0; k < 4; k++) { PI.K4[k] = K4[k]; PI.bounds[k] = bounds[k]; }
+  PI.nlevels = nlevels; std::memcpy(PI.scale, scale, sizeof(scale));
+  const int pP = in.add(&PI, sizeof(PI));
+  std::vector<TrfIn> h_in((size_t)std::max(n_cand, 1));
+  struct Pieces { int d, v, a, fn, fo, fi; };
+  std::vector<Pieces> pc((size_t)std::max(n_cand, 1));
+  for (int i = 0; i < n_cand; i++) {
+    const orbt_reloc_keyframe& q = cand[i];
+    TrfIn& I = h_in[i]; std::memset(&I, 0, sizeof(I));
+    I.pose7[6] = 1.0;
+    for (int k = 0; k < 4; k++) I.K4[k] = K4[k];
+    std::memcpy(I.inv_sigma2, inv_sigma2, sizeof(inv_sigma2));
+    I.ratio = nnratio; I.check_ori = check_ori ? 1 : 0; I.nn = q.fv_n; I.n_kf = q.n;
+    const uint32_t nidx = q.fv_n ? q.fv_off[q.fv_n] : 0u;
+    pc[i].d = in.add(q.desc, 32 * (size_t)q.n); pc[i].v = in.add(q.valid, (size_t)q.n); pc[i].a = in.add(q.angle, 4 * (size_t)q.n);
+    pc[i].fn = in.add(q.fv_node, 4 * (size_t)q.fv_n); pc[i].fo = in.add(q.fv_off, 4 * ((size_t)q.fv_n + 1)); pc[i].fi = in.add(q.fv_idx, 4 * (size_t)nidx);
+  }
+  const int pI = in.add(h_in.data(), sizeof(TrfIn) * (size_t)std::max(n_cand, 1));
+  uint8_t* d_img = nullptr;
+  if (img) d_img = W.up<uint8_t>(img, (size_t)stride * (h - 1) + w, &rc);
+  else {
+    ORBHIP_REQUIRE(TF.valid, ORBHIP_EINVAL, "img == NULL needs the frame of an earlier orbt_* call of this thread on the device");
+    ORBHIP_REQUIRE(TF.producer == ctx && TF.nlevels == nlevels && TF.icap == icap, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
+  }
+  if (rc || (rc = W.commit(in))) return rc;
+  if (img) {
+    ORBHIP_REQUIRE(kps_out && desc_out, ORBHIP_EINVAL, "NULL output");
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+    const size_t oCnt = take(4), oKps = take((size_t)icap * sizeof(orbx_keypoint)), oDesc = take((size_t)icap * 32);
+    TF.valid = false;
+    if ((rc = TF.blk.ensure(o)) || (rc = TF.kps4.ensure(16 * (size_t)icap)) || (rc = TF.grid.off.ensure((size_t)(TRK_NCELL + 1) * 4)) || (rc = TF.grid.idx.ensure((size_t)icap * 4))) return rc;
+    TF.oCnt = oCnt; TF.oKps = oKps; TF.oDesc = oDesc; TF.icap = icap; TF.nlevels = nlevels; std::memcpy(TF.bounds, bounds, 16);
+    TF.grid.min_x = bounds[0]; TF.grid.min_y = bounds[2];
+    TF.grid.winv = static_cast<float>(FRAME_GRID_COLS) / (bounds[1] - bounds[0]); TF.grid.hinv = static_cast<float>(FRAME_GRID_ROWS) / (bounds[3] - bounds[2]);
+    uint8_t* fb = TF.blk.as<uint8_t>();
+    if ((rc = orbhip::orbx_extract_chained(ctx, d_img, w, h, stride, (orbx_keypoint*)(fb + oKps), fb + oDesc, icap, (int32_t*)(fb + oCnt), (void*)W.s))) return rc;
+    float* d_dummy = W.d<float>(4, &rc); int32_t* d_di = W.d<int32_t>(4, &rc); uint8_t* d_db = W.d<uint8_t>(4, &rc); uint32_t* d_tot = W.d<uint32_t>(1, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_trk_prepare, dim3(1), dim3(1024), 0, W.s, in.dev<TrkIn>(pP), (const double*)nullptr, (const int32_t*)nullptr, (const uint8_t*)nullptr,
+                       (const orbx_keypoint*)(fb + oKps), (const int32_t*)(fb + oCnt), icap, d_dummy, d_dummy, d_di, d_di, d_db, TF.kps4.as<float>(),
+                       TF.grid.off.as<uint32_t>(), TF.grid.idx.as<uint32_t>(), 0, d_tot);
+  }
+  const uint8_t* fblk = TF.blk.as<uint8_t>();
+  const float* d_kps4 = TF.kps4.as<float>();
+  const int32_t* d_count = (const int32_t*)(fblk + TF.oCnt);
+  const uint8_t* d_fdesc = fblk + TF.oDesc;
+  const int fcap = TF.icap;
+  int max_kf = 1;
+  for (int i = 0; i < n_cand; i++) max_kf = std::max(max_kf, cand[i].n);
+  // output block: [word | weight | node | per candidate {TrkOut, owner[fcap]}]; scratch shared by the candidates (they run one after the other)
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+  const size_t oWord = take(4 * (size_t)fcap), oWt = take(8 * (size_t)fcap), oNode = take(4 * (size_t)fcap);
+  const size_t oOut = take(sizeof(TrkOut) * (size_t)std::max(n_cand, 1)), oOwner = take(4 * (size_t)fcap * std::max(n_cand, 1));
+  uint8_t* dblk = W.d<uint8_t>(o, &rc);
+  int32_t* d_match = W.d<int32_t>((size_t)max_kf, &rc); int32_t* d_bin = W.d<int32_t>(fcap, &rc); int* d_hist = W.d<int>(TRK_HISTO + 2, &rc);
+  int32_t* d_feat = W.d<int32_t>(fcap, &rc); double* d_oX = W.d<double>(3 * (size_t)fcap, &rc); double* d_ouv = W.d<double>(2 * (size_t)fcap, &rc); float* d_ow = W.d<float>(fcap, &rc);
+  int32_t* d_ooff = W.d<int32_t>(2, &rc); double* d_K4 = W.d<double>(4, &rc); double* d_pose = W.d<double>(7, &rc);
+  double* d_kfX = W.d<double>(3 * (size_t)max_kf, &rc);        // (k_trf_finish gathers PoseOptimization's points: not used here, any readable memory)
+  if (rc) return rc;
+  ORBHIP_CHECK_HIP(hipMemsetAsync(d_kfX, 0, 24 * (size_t)max_kf, W.s));
+  // Frame::ComputeBoW (src/Frame.cc:322-327: levelsup 4)
+  if ((rc = orbv_descend_device(voc, d_fdesc, fcap, 4, (int32_t*)(dblk + oWord), (double*)(dblk + oWt), (uint32_t*)(dblk + oNode), (void*)W.s))) return rc;
+  for (int i = 0; i < n_cand; i++) {
+    const orbt_reloc_keyframe& q = cand[i];
+    const TrfIn* dI = in.dev<TrfIn>(pI) + i;
+    int32_t* d_owner = (int32_t*)(dblk + oOwner) + (size_t)i * fcap;
+    hipLaunchKernelGGL(k_trf_init, dim3((std::max(std::max(q.n, fcap), 64) + 255) / 256), dim3(256), 0, W.s, d_match, q.n, d_owner, d_bin, fcap, d_hist);
+    if (q.fv_n > 0)
+      hipLaunchKernelGGL(k_trf_bow, dim3(q.fv_n), dim3(64), 0, W.s, dI, in.dev<uint32_t>(pc[i].fn), in.dev<uint32_t>(pc[i].fo), in.dev<uint32_t>(pc[i].fi), in.dev<uint8_t>(pc[i].d),
+                         in.dev<uint8_t>(pc[i].v), in.dev<float>(pc[i].a), d_fdesc, (const uint32_t*)(dblk + oNode), (const double*)(dblk + oWt), d_kps4, d_count, fcap,
+                         d_match, d_owner, d_bin, d_hist);
+    hipLaunchKernelGGL(k_trf_finish, dim3(1), dim3(1024), 0, W.s, dI, d_hist, d_kps4, d_count, fcap, (const double*)d_kfX, d_match, d_owner, d_bin, d_feat, d_oX, d_ouv, d_ow, d_ooff,
+                       d_pose, d_K4, (TrkOut*)(dblk + oOut) + i);
+  }
+  ORBHIP_CHECK_HIP(hipGetLastError());
+  const uint8_t* hb = W.down(dblk, o, &rc);
+  const uint8_t* hf = img ? W.down(fblk, TF.oDesc + (size_t)fcap * 32, &rc) : W.down(fblk, 256, &rc);
+  if (rc || (rc = W.sync())) return rc;
+  const int n_dev = *(const int32_t*)(hf + TF.oCnt);
+  if (n_dev < 0) { set_error("extractor capacity exceeded"); return ORBHIP_EOVERFLOW; }
+  const int n = std::min(n_dev, fcap);
+  if (img) { TF.n_kp = n; TF.valid = true; TF.producer = ctx; std::memcpy(kps_out, hf + TF.oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hf + TF.oDesc, (size_t)n * 32); }
+  if (n != TF.n_kp) { set_error("resident frame changed"); return ORBHIP_EINVAL; }
+  *n_keypoints = n;
+  if (bow_word && bow_value && fv_node && fv_idx)
+    orbhip::orbv_merge_host((const int32_t*)(hb + oWord), (const double*)(hb + oWt), (const uint32_t*)(hb + oNode), n, bow_word, bow_value, n_words, fv_node, fv_off, fv_idx, n_fv_nodes);
+  else { *n_words = 0; *n_fv_nodes = 0; fv_off[0] = 0; }
+  for (int i = 0; i < n_cand; i++) {
+    const TrkOut* T = (const TrkOut*)(hb + oOut) + i;
+    nmatches[i] = T->nmatches;
+    std::memcpy(slot_owner + (size_t)i * cap, hb + oOwner + 4 * (size_t)i * fcap, 4 * (size_t)n);
+    for (int k = n; k < cap; k++) slot_owner[(size_t)i * cap + k] = -1;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -149,3 +149,47 @@ def last_call_ms():
     """orbt_last_call_ms: wall time of this thread's most recent track_* call inside the library (a Python caller adds its own
     interpreter-lock waits around the call when other threads are busy)."""
     return float(_lib.load().orbt_last_call_ms())
+
+
+class _RelocKF(C.Structure):         # orbt_reloc_keyframe
+    _fields_ = [("desc", C.c_void_p), ("valid", C.c_void_p), ("angle", C.c_void_p), ("n", C.c_int),
+                ("fv_node", C.c_void_p), ("fv_off", C.c_void_p), ("fv_idx", C.c_void_p), ("fv_n", C.c_int)]
+
+
+def relocalization_search_by_bow(extractor, vocabulary, image, K4, bounds, candidates, nnratio=0.75, check_ori=True):
+    """Tracking::Relocalization, first stage (include/orbslam_hip.h::orbt_relocalization_search_by_bow; reference src/Tracking.cc:979-1029):
+    ComputeBoW of the frame + SearchByBoW(keyframe, frame) for every candidate keyframe in one call.  candidates: dicts(desc[n,32],
+    valid[n], angle[n], fv=(nodes, offsets, indices)).  image None: the frame of the last orbt_* call of this thread.
+    Returns dict(kps, desc (None without image), bow, fv, owner[n_cand, n_keypoints], nmatches[n_cand])."""
+    import contextlib
+    L = _lib.load()
+    K4 = _c(K4, np.float32); bounds = _c(bounds, np.float32)
+    keep = []
+    nc = len(candidates)
+    cs = (_RelocKF * max(nc, 1))()
+    for i, q in enumerate(candidates):
+        D = _c(q["desc"], np.uint8).reshape(-1, 32); V = _c(q["valid"], np.uint8); A = _c(q["angle"], np.float32)
+        fn, fo, fi = [_c(x, np.uint32) for x in q["fv"]]
+        assert len(V) == len(D) and len(A) == len(D) and len(fo) == len(fn) + 1
+        keep += [D, V, A, fn, fo, fi]
+        cs[i].desc, cs[i].valid, cs[i].angle, cs[i].n = D.ctypes.data, V.ctypes.data, A.ctypes.data, len(D)
+        cs[i].fv_node, cs[i].fv_off, cs[i].fv_idx, cs[i].fv_n = fn.ctypes.data, fo.ctypes.data, fi.ctypes.data, len(fn)
+    cap = extractor.max_keypoints
+    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+    bw = np.zeros(cap, np.uint32); bv = np.zeros(cap, np.float64); nw = C.c_int(0)
+    on = np.zeros(cap, np.uint32); oo = np.zeros(cap + 2, np.uint32); oi = np.zeros(cap, np.uint32); nf = C.c_int(0)
+    owner = np.full((max(nc, 1), cap), -1, np.int32); nm = np.zeros(max(nc, 1), np.int32); nk = C.c_int(0)
+    if image is not None:
+        img = _c(image, np.uint8); h, w = img.shape; ip, st = _addr(img), img.strides[0]
+    else:
+        img, h, w, ip, st = None, 0, 0, None, 0
+    L.orbt_relocalization_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                                    C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    with (_extractor_lock(extractor) if img is not None else contextlib.nullcontext()):
+        _lib.check(L.orbt_relocalization_search_by_bow(extractor._h, vocabulary._h, ip, w, h, st, _addr(K4), _addr(bounds), C.cast(cs, C.c_void_p), nc, float(nnratio),
+                                                       int(bool(check_ori)), _addr(kps), _addr(desc), cap, _addr(bw), _addr(bv), C.byref(nw), _addr(on), _addr(oo), _addr(oi),
+                                                       C.byref(nf), _addr(owner), _addr(nm), C.byref(nk)), "orbt_relocalization_search_by_bow")
+    k = nk.value
+    return dict(kps=kps[:k] if img is not None else None, desc=desc[:k] if img is not None else None, bow=(bw[:nw.value], bv[:nw.value]),
+                fv=(on[:nf.value], oo[:nf.value + 1], oi[:oo[nf.value]]), owner=owner[:nc, :k], nmatches=nm[:nc], n_keypoints=k)

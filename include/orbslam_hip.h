@@ -312,6 +312,25 @@ int orbm_search_for_triangulation(const float* kps1, const uint8_t* desc1, const
                                   const double* F12, float ex, float ey, const float* scale_factors,
                                   const float* level_sigma2, int check_ori, int32_t* match12, int* nmatches);
 
+/* ---- Tracking::Relocalization, first stage (src/Tracking.cc:979-1029; round 5): current_frame_.ComputeBoW() and
+ * matcher.SearchByBoW(keyframe, current_frame_, map_point_matches_vector[i]) - ORBmatcher(0.75, true) - for EVERY candidate keyframe of
+ * KeyFrameDatabase::DetectRelocalizationCandidates in ONE call (the candidates are independent; the vocabulary descent of the frame
+ * runs once).  img != NULL: the frame is extracted first and stays on the device (as orbt_track_reference_keyframe); NULL: the
+ * frame an earlier orbt_* call of this thread left there.  Per candidate i: slot_owner[i][f] = the keyframe feature whose map
+ * point vpMapPointMatches[f] holds (-1: none) after the rotation check, nmatches[i] = the return value (the caller discards the
+ * candidate below 15, :1019).  What follows - PnPsolver::iterate per candidate, then PoseOptimization /
+ * SearchByProjection(F, KF, found, th, ORBdist) rounds (:1040-1120) - starts from a PnP pose and stays with the caller: PnP is out of
+ * scope, the rounds are ba_pose_optimization and the reloc_kf form of orbm_search_by_projection.             */
+typedef struct orbt_reloc_keyframe {
+  const uint8_t* desc; const uint8_t* valid; const float* angle; int n;      /* descriptors, 1 = usable map point (not NULL, not isBad()), keypoint angles */
+  const uint32_t* fv_node; const uint32_t* fv_off; const uint32_t* fv_idx; int fv_n;      /* the keyframe's FeatureVector (orbv_transform's layout) */
+} orbt_reloc_keyframe;
+int orbt_relocalization_search_by_bow(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* img, int w, int h, int stride, const float* K4, const float* bounds,
+                                      const orbt_reloc_keyframe* candidates, int n_candidates, float nnratio, int check_ori, orbx_keypoint* kps_out,
+                                      uint8_t* desc_out, int cap, uint32_t* bow_word, double* bow_value, int* n_words, uint32_t* fv_node, uint32_t* fv_off,
+                                      uint32_t* fv_idx, int* n_fv_nodes, int32_t* slot_owner /*[n_candidates][cap]*/, int32_t* nmatches /*[n_candidates]*/,
+                                      int* n_keypoints);
+
 /* ---- LocalMapping::CreateNewMapPoints, device-resident across the neighbour keyframes (src/LocalMapping.cc:196-396; round 5) ----
  * For every neighbour keyframe IN ORDER: ORBmatcher::SearchForTriangulation(current, neighbour, F12, pairs, false) with the matcher of
  * that call site, ORBmatcher(0.6, false) (:203: no orientation check; src/ORBmatcher.cc:582-722), then the per-match body (:267-378:

@@ -59,3 +59,50 @@ def test_track_reference_keyframe_vs_oracle_composition(oracle, seed, k, L, chec
     again = tracking.track_reference_keyframe(ex, V, None, K4, BOUNDS, S["T"], S["desc"], kf_valid, S["angle"], S["X"], want["kf_fv"], 0.7, check_ori)
     assert np.array_equal(again["match"], got["match"]) and np.array_equal(again["owner"], got["owner"]) and np.array_equal(again["pose7"], got["pose7"])
     print("TrackReferenceKeyFrame: %d keypoints, %d keyframe features in %d nodes, %d matches, %d inliers" % (len(got["kps"]), len(kf_valid), len(want["kf_fv"][0]), got["nmatches"], got["n_inliers"]))
+
+
+def test_relocalization_search_by_bow_all_candidates_in_one_call(oracle):
+    """Tracking::Relocalization's first stage (src/Tracking.cc:979-1029): ComputeBoW + SearchByBoW(keyframe, frame) with ORBmatcher(0.75,
+    true) for five candidate keyframes in ONE call (orbt_relocalization_search_by_bow) against the oracle, candidate by candidate; the
+    candidates differ (other validity masks, perturbed descriptors, one without usable points, one empty)."""
+    from ceres_mono_orb_slam2_amd import ORBextractor, tracking
+    from ceres_mono_orb_slam2_amd.vocabulary import ORBVocabulary
+    S = _scenario(oracle, 8)
+    voc = synth.make_vocabulary(8, k=6, L=6)
+    V = ORBVocabulary(*[voc[x] for x in KEYS])
+    rng = np.random.default_rng(8)
+    E = S["E"]
+    kps, desc = E.extract(S["img"])
+    bw, bv, fn, fo, fi = oracle.bow_transform(voc, desc, 4)
+    cands = []
+    for i in range(5):
+        d = S["desc"].copy(); valid = (S["valid"] != 0).astype(np.uint8); ang = S["angle"].copy()
+        if i == 1: valid &= (rng.random(len(valid)) < 0.6).astype(np.uint8)
+        if i == 2:
+            flip = rng.random(len(d)) < 0.5
+            d[flip, rng.integers(0, 32, flip.sum())] ^= (1 << rng.integers(0, 8, flip.sum())).astype(np.uint8); ang = (ang + 40.0 * (rng.random(len(ang)) < 0.2)).astype(np.float32) % 360
+        if i == 3: valid[:] = 0
+        if i == 4: d = d[:0]; valid = valid[:0]; ang = ang[:0]
+        _, _, kfn, kfo, kfi = oracle.bow_transform(voc, d, 4) if len(d) else (None, None, np.zeros(0, np.uint32), np.zeros(1, np.uint32), np.zeros(0, np.uint32))
+        cands.append(dict(desc=d, valid=valid, angle=ang, fv=(kfn, kfo, kfi)))
+    ex = ORBextractor(2000, 1.2, 8, 20, 7)
+    got = tracking.relocalization_search_by_bow(ex, V, S["img"], K4, BOUNDS, cands, 0.75, True)
+    assert np.array_equal(got["kps"], kps) and np.array_equal(got["desc"], desc)
+    assert np.array_equal(got["bow"][0], bw) and np.array_equal(got["bow"][1].view(np.uint64), bv.view(np.uint64))
+    assert all(np.array_equal(a, b) for a, b in zip(got["fv"], (fn, fo, fi)))
+    total = 0
+    for i, q in enumerate(cands):
+        if len(q["desc"]):
+            nm, m = oracle.search_by_bow(q["desc"], q["valid"], q["angle"], desc, None, kps["angle"].astype(np.float32), q["fv"], (fn, fo, fi), ratio=0.75, th=50, strict=False, check_ori=True)
+        else:
+            nm, m = 0, np.zeros(0, np.int32)
+        owner = np.full(len(kps), -1, np.int32)
+        for k in range(len(m)):
+            if m[k] >= 0: owner[m[k]] = k
+        assert int(got["nmatches"][i]) == nm, (i, int(got["nmatches"][i]), nm)
+        assert np.array_equal(got["owner"][i], owner), "candidate %d" % i
+        total += nm
+    assert got["nmatches"][0] > 100 and got["nmatches"][3] == 0 and got["nmatches"][4] == 0 and got["nmatches"][1] < got["nmatches"][0]
+    # the same on the resident frame
+    again = tracking.relocalization_search_by_bow(ex, V, None, K4, BOUNDS, cands, 0.75, True)
+    assert np.array_equal(again["owner"], got["owner"]) and np.array_equal(again["nmatches"], got["nmatches"])
