@@ -7,7 +7,7 @@ SKIPPED - the tracked file of an earlier, good run is never overwritten by a mis
 headline kernel stats exactly that way).  Files are written to a temporary name and renamed.  Exit code 1 if anything was skipped."""
 import csv, json, os, sqlite3, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G = os.path.join(ROOT, "gpurun_out"); O = os.path.join(G, RND); P = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")      # (PROFILES_OUT: collect on the GPU box into gpurun_out/, the raw databases exceed what travels back)
 os.makedirs(P, exist_ok=True)
 skipped = []
@@ -67,6 +67,7 @@ take_json("bench_traced.json", RND + "_bench_traced.json", ("value", "kernels"))
 take_kernel_csv("localba_batch64_kernel_stats.csv", RND + "_localba_batch64_kernel_stats.csv", ("k_ba_schur", "k_chol_wg"))
 take_kernel_csv("gba_c5_kernel_stats.csv", RND + "_gba_c5_kernel_stats.csv", ("k_chol",))
 take_json("bench_2rank_shared.json", RND + "_bench_2rank_shared_gpu.json", ("value", "collective"))
+take_json("bench_8rank_shared.json", RND + "_bench_8rank_shared_gpu.json", ("value", "collective"))
 take_json("bench_rccl_ws1.json", RND + "_bench_rccl_ws1.json", ("collective",))
 try:
     api = {"note": "wall latency of the per-frame host-pointer entry points on one MI355X (C++ through the C ABI, tools/cpp/api_latency.cpp; "

@@ -4,7 +4,7 @@ batch size written to gpurun_out/pmc_x_batch.txt: the bench's 256 frames).  Noth
 four databases hold every kernel of the front-end."""
 import sqlite3, collections, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 MATCH = os.environ.get("PMC_MATCH_KERNEL", "k_match_pairs_mfma")      # (k_match_pairs when the passes ran with ORBHIP_MATCH_MFMA=0)
 BLUR = os.environ.get("PMC_BLUR_KERNEL", "k_blur7_mfma")      # (k_blur7 when the passes ran with ORBHIP_BLUR_MFMA=0)
 NAMES = ["k_resize", "k_fast_cells", "k_octree", BLUR, "k_describe", MATCH]

@@ -6,7 +6,7 @@
 # usage: bash tools/run_profiles.sh r04 [quick]   (every leg is wrapped in `timeout`: a hung leg costs its limit, not the GPU budget)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/$R; mkdir -p $O
 step() { echo "== $*"; }
 step bench;      timeout 900 python bench.py > $O/bench.json 2> $O/bench.err || tail -5 $O/bench.err
@@ -31,7 +31,7 @@ db=$(find $O/gbaprof -name "*.db" 2>/dev/null | head -1)
 step api latency
 g++ -O2 -std=c++17 -I include tools/cpp/api_latency.cpp -o /tmp/api_latency -L ceres_mono_orb_slam2_amd/lib -lorbslam_hip && \
 LD_LIBRARY_PATH=ceres_mono_orb_slam2_amd/lib:/opt/rocm/lib /tmp/api_latency > $O/api_latency_cpp.json; cat $O/api_latency_cpp.json
-timeout 300 python tools/api_latency.py 2>/dev/null | tail -1 > $O/api_latency_py.json; cat $O/api_latency_py.json
+timeout 600 python tools/api_latency.py 2>/dev/null | tail -1 > $O/api_latency_py.json; cat $O/api_latency_py.json
 step tracking latency
 ORBHIP_TRACK_TIMING=1 timeout 300 python tools/track_latency.py 400 > $O/track_latency.txt 2>&1; tail -4 $O/track_latency.txt
 step concurrency
@@ -42,6 +42,10 @@ step rccl world size 1
 ORBHIP_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --no-pipelined > $O/bench_rccl_ws1.json 2> $O/bench_rccl_ws1.err || tail -5 $O/bench_rccl_ws1.err
 step 2 ranks shared gpu
 ORBHIP_BENCH_SHARED_GPU=1 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu > $O/bench_2rank_shared.json 2> $O/bench_2rank.err || tail -5 $O/bench_2rank.err
+step 8 ranks shared gpu
+ORBHIP_BENCH_SHARED_GPU=1 timeout 1500 python bench.py --gpus 8 --batches-per-step 4 --batch 64 --steps 3 --warmup 1 --no-cpu > $O/bench_8rank_shared.json 2> $O/bench_8rank.err || tail -5 $O/bench_8rank.err
+step fast phase profile
+timeout 600 python tools/fast_phase_prof.py 2>/dev/null | python -c "import sys,json; t=sys.stdin.read(); i=t.index('{'); print(json.dumps(json.loads(t[i:])))" > $O/fast_phase_prof.json; cat $O/fast_phase_prof.json
 step pmc
 timeout 1200 bash tools/run_pmc.sh > $O/pmc.log 2>&1 || tail -5 $O/pmc.log
 step mfma pmc
