@@ -53,7 +53,7 @@ BYTES = {"pyramid": 1407767 + 977481, "fast_cells": 1444097, "blur": 2 * 1444097
 # kernel (one workgroup per (frame, level), a serial split loop): its HBM fraction is tiny by construction, the line reports its
 # VALU-busy and waiting fractions beside it
 OCTREE_BYTES = 149000
-KERNEL_OF = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur7_mfma", "describe": "k_describe", "octree": "k_octree"}
+KERNEL_OF = {"pyramid": "k_resize_mfma", "fast_cells": "k_fast_cells", "blur": "k_blur7_mfma", "describe": "k_describe", "octree": "k_octree"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer VALU instruction issues over 4 cycles;
                                # measured 35-39 T lane-instr/s for xor/bcnt/pk_*16/dot4/dot2/sad/alignbyte (tools/ubench/valu_rate.hip)

@@ -1229,6 +1229,97 @@ __global__ __launch_bounds__(256) void k_blur7_mfma(GeomDev G, const BlurTile* _
   }
 }
 
+// ---------------------------------------------------------------------------- k_resize_mfma (round 5)
+// cv::resize INTER_LINEAR with the HORIZONTAL pass on the matrix cores (k_resize above is the VALU kernel and the fallback
+// for geometries this one does not cover).  H[sy][dx] = S[sy][sx] a0 + S[sy][sx + 1] a1 is a product of the source rows with a
+// two-banded weight matrix; the weights (0 .. 2048) go in as two int8 digits, a = 32 ah + al, the pixels as int8 (pixel - 128):
+//   H^T = Wh^T S'^T * 32 + Wl^T S'^T + 128 (a0 + a1)        (exact in integers: H is k_resize's H bit for bit)
+// as v_mfma_i32_16x16x64_i8 with A = the weight digits (M = 16 output columns, K = 64 source columns; host tables, one set per
+// 48-column chunk of a level) and B = the source (K = 64 source bytes of N = 16 consecutive source rows; a lane: 16 consecutive
+// bytes of one row).  C[m][n]: lane (n, g) holds output columns 4 g .. 4 g + 3 of block cb for SOURCE ROW n - and the block's
+// columns are assigned c + 12 (m >> 2) + 4 cb + (m & 3), so the three blocks give a lane twelve consecutive output bytes.
+// The vertical pass, v = (((b0 (H0 >> 4)) >> 16) + ((b1 (H1 >> 4)) >> 16) + 2) >> 2, truncates per term and stays on the VALU:
+// source row sy0 = the lane's own row, sy1 = sy0 + 1 = the NEXT LANE's (one DPP row shift; the row index is clamped at load time,
+// so the bottom edge's sy1 = sy0 comes out by itself); a source row is sy0 of at most one output row (scale > 1), which the row
+// table names.  Lane 15 of a block has no next lane: blocks advance by 15 source rows.  A wave walks RM_RB blocks down its 48
+// columns with the next block's source in flight.  ~10 VALU instructions per output pixel instead of ~40.
+#define RM_RB 4                      /* 15-row blocks per wave */
+struct RmLevel { const uint8_t* tab; size_t oW, oC, oC0, oRow; int nchunks, nblocks, sw, sh, dw, dh; };
+struct alignas(8) RmRow { int32_t dy; uint32_t b01; };       // output row whose yofs is this source row (-1: none), b0 | b1 << 16
+__global__ __launch_bounds__(256) void k_resize_mfma(RmLevel R, const uint8_t* __restrict__ src, int spitch, long long sframe, uint8_t* __restrict__ dst, int dpitch,
+                                                     long long dframe, int ntx) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tx = blockIdx.x % ntx, tb = blockIdx.x / ntx;                 // 192-column strip, first block of RM_RB
+  const int t = tx * 4 + wv;                                              // 48-column chunk of this wave
+  if (t >= R.nchunks) return;
+  const int li = lane & 15, g = lane >> 4;
+  const uint8_t* S = src + (long long)f * sframe;
+  uint8_t* D = dst + (long long)f * dframe;
+  const int C0 = ((const int*)(R.tab + R.oC0))[t];
+  bm_v4i Wh[3], Wl[3], Ci[3];
+  {
+    const bm_v4i* W = (const bm_v4i*)(R.tab + R.oW) + (size_t)t * 6 * 64;
+    const bm_v4i* Cc = (const bm_v4i*)(R.tab + R.oC) + (size_t)t * 3 * 4;
+#pragma unroll
+    for (int cb = 0; cb < 3; cb++) { Wh[cb] = W[(2 * cb) * 64 + lane]; Wl[cb] = W[(2 * cb + 1) * 64 + lane]; Ci[cb] = Cc[cb * 4 + g]; }
+  }
+  const RmRow* rows = (const RmRow*)(R.tab + R.oRow);
+  const int cb0 = C0 + 16 * g;                                            // this lane's 16 source bytes
+  const bool cols_inside = C0 >= 0 && C0 + 64 <= R.sw;                    // wave-uniform
+  auto load_src = [&](int R0, uint32_t (&v)[4]) {
+    const int sy = min(max(R0 + li, 0), R.sh - 1);
+    const uint8_t* row = S + (long long)sy * spitch;
+    if (cols_inside) {
+      const bm_u128 u = *(const bm_u128*)(row + cb0);
+      v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        v[q] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[q] |= (uint32_t)row[min(max(cb0 + 4 * q + j, 0), R.sw - 1)] << (8 * j);      // (columns no weight reaches: any readable byte)
+      }
+    }
+  };
+  const int b_lo = tb * RM_RB, b_hi = min(b_lo + RM_RB, R.nblocks);
+  uint32_t cur[4], nxt[4] = {0, 0, 0, 0};
+  load_src(15 * b_lo, cur);
+  const int ocol = 48 * t + 12 * g;
+  const bool whole = ocol + 12 <= dpitch;
+  for (int b = b_lo; b < b_hi; b++) {
+    const int R0 = 15 * b;
+    if (b + 1 < b_hi) load_src(R0 + 15, nxt);
+    const RmRow ri = rows[R0 + li];                                       // (the table is padded to 15 nblocks + 1 entries)
+    const bm_v4i Bs = {(int)(cur[0] ^ 0x80808080u), (int)(cur[1] ^ 0x80808080u), (int)(cur[2] ^ 0x80808080u), (int)(cur[3] ^ 0x80808080u)};
+    const uint32_t b0 = ri.b01 & 0xFFFFu, b1 = ri.b01 >> 16;
+    uint32_t o[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; cb++) {
+      const bm_v4i Ph = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wh[cb], Bs, (bm_v4i){0, 0, 0, 0}, 0, 0, 0);
+      const bm_v4i Pl = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wl[cb], Bs, Ci[cb], 0, 0, 0);
+      uint32_t px[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int H0 = (Ph[r] << 5) + Pl[r];                              // this lane's source row
+        const int H1 = __builtin_amdgcn_update_dpp(0, H0, 0x101, 0xF, 0xF, false);      // row_shl:1 - the next lane's (next source row's) H
+        const uint32_t v = (((b0 * (uint32_t)(H0 >> 4)) >> 16) + ((b1 * (uint32_t)(H1 >> 4)) >> 16) + 2u) >> 2;
+        px[r] = v & 255u;
+      }
+      o[cb] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    }
+    if (li < 15 && ri.dy >= 0) {
+      uint8_t* d = D + (long long)ri.dy * dpitch + ocol;
+      if (whole) *(bm_u32x3*)d = (bm_u32x3){o[0], o[1], o[2]};
+      else {
+#pragma unroll
+        for (int q = 0; q < 3; q++) if (ocol + 4 * q + 4 <= dpitch) *(uint32_t*)(d + 4 * q) = o[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+  }
+}
+
 // ---------------------------------------------------------------------------- k_describe
 __constant__ __attribute__((aligned(16))) signed char c_pattern[1024];
 __constant__ int c_umax[16];
@@ -1489,6 +1580,9 @@ struct orbx_ctx {
   DevBuf d_cells, d_btiles, d_mtiles, d_tab;      // tables
   int blur_mfma = 1;                  // k_blur7_mfma (default) / k_blur7 (ORBHIP_BLUR_MFMA=0: the VALU kernel, for A/B runs)
   std::vector<size_t> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // byte offsets into d_tab per level
+  struct RmHost { size_t oW = 0, oC = 0, oC0 = 0, oRow = 0; int nchunks = 0, nblocks = 0; bool ok = false; };
+  std::vector<RmHost> rm;              // k_resize_mfma's tables per level (ok = false: the level takes k_resize)
+  int resize_mfma = 1;                 // ORBHIP_RESIZE_MFMA=0: every level on the VALU kernel k_resize (A/B runs)
   size_t tab_cone = 0; int cone_wgs = 0, cone_buf0 = 0, cone_bufk = 0; size_t cone_lds = 0;      // k_pyr_cone: boxes in d_tab, grid, LDS layout (cone_wgs == 0: not available)
   DevBuf d_pyr, d_blur, d_cellcnt, d_cellkps, d_keys, d_knode, d_sel, d_selcnt, d_nkeys, d_status, d_octnodes;
   DevBuf d_img, d_out;                     // host-API staging: image; {counts | keypoints | descriptors} in one block
@@ -1668,6 +1762,53 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
         c->tab_yofs[l] = push(yofs.data(), yofs.size() * 4);
         c->tab_ibeta[l] = push(ib.data(), ib.size() * 2);
         h_xofs[l] = xofs; h_yofs[l] = yofs;
+        // ---- k_resize_mfma's tables (see the kernel): per 48-column chunk the weight digits as MFMA A operands + the accumulator
+        // start values, per source row the output row it is sy0 of.  Conditions, checked here: a chunk's source span fits 64 columns
+        // (true for scale factors up to ~1.3), yofs strictly increasing and non-negative (true for every downscale).
+        {
+          if (c->rm.size() != (size_t)nl) c->rm.assign(nl, orbx_ctx::RmHost());
+          orbx_ctx::RmHost& M = c->rm[l];
+          M = orbx_ctx::RmHost();
+          const int nchunks = (dw + 47) / 48;
+          bool ok = true;
+          std::vector<int> c0(nchunks);
+          for (int t = 0; t < nchunks && ok; t++) {
+            const int lo = xofs[48 * t], hi = std::min(xofs[std::min(48 * t + 47, dw - 1)] + 1, sw - 1);
+            c0[t] = lo & ~3;
+            if (hi - c0[t] > 63) ok = false;
+          }
+          for (int dy = 0; dy < dh && ok; dy++) if (yofs[dy] < 0 || (dy > 0 && yofs[dy] <= yofs[dy - 1])) ok = false;
+          for (int dx = 0; dx < 2 * dw && ok; dx++) if (ia[dx] < 0 || ia[dx] > 2048) ok = false;
+          for (int dy = 0; dy < 2 * dh && ok; dy++) if (ib[dy] < 0 || ib[dy] > 2048) ok = false;
+          if (ok) {
+            std::vector<int8_t> W((size_t)nchunks * 6 * 64 * 16, 0);
+            std::vector<int32_t> Cc((size_t)nchunks * 3 * 16, 0);
+            for (int t = 0; t < nchunks; t++)
+              for (int cb = 0; cb < 3; cb++)
+                for (int m = 0; m < 16; m++) {
+                  const int dx = 48 * t + 12 * (m >> 2) + 4 * cb + (m & 3);
+                  if (dx >= dw) continue;
+                  const int s0 = xofs[dx], s1 = std::min(xofs[dx] + 1, sw - 1);
+                  const int wgt[2] = {ia[2 * dx], ia[2 * dx + 1]}, col[2] = {s0, s1};
+                  Cc[((size_t)t * 3 + cb) * 16 + m] = 128 * (wgt[0] + wgt[1]);
+                  for (int e = 0; e < 2; e++) {
+                    const int k = col[e] - c0[t];                       // (0 .. 63: checked above)
+                    const size_t lane = (size_t)m + 16 * (k >> 4), byte = (size_t)(k & 15);
+                    int8_t* wh = &W[(((size_t)t * 6 + 2 * cb) * 64 + lane) * 16 + byte];
+                    int8_t* wl = &W[(((size_t)t * 6 + 2 * cb + 1) * 64 + lane) * 16 + byte];
+                    // (s1 == s0 at the right border: the two weights meet in one column and add up - a1 is 0 there)
+                    const int tot = 32 * (int)*wh + (int)*wl + wgt[e];
+                    *wh = (int8_t)(tot >> 5); *wl = (int8_t)(tot & 31);
+                  }
+                }
+            const int smax = yofs[dh - 1], nblocks = (smax + 1 + 14) / 15;
+            std::vector<uint32_t> rowtab(2 * ((size_t)15 * nblocks + 1), 0);
+            for (size_t s2 = 0; s2 < rowtab.size() / 2; s2++) rowtab[2 * s2] = 0xFFFFFFFFu;        // dy = -1
+            for (int dy = 0; dy < dh; dy++) { rowtab[2 * (size_t)yofs[dy]] = (uint32_t)dy; rowtab[2 * (size_t)yofs[dy] + 1] = (uint32_t)(uint16_t)ib[2 * dy] | ((uint32_t)(uint16_t)ib[2 * dy + 1] << 16); }
+            M.oW = push(W.data(), W.size()); M.oC = push(Cc.data(), Cc.size() * 4); M.oC0 = push(c0.data(), c0.size() * 4); M.oRow = push(rowtab.data(), rowtab.size() * 4);
+            M.nchunks = nchunks; M.nblocks = nblocks; M.ok = true;
+          }
+        }
       }
       // blur tiles
       for (int ty = 0; ty < (L.h + BLUR_TH - 1) / BLUR_TH; ty++)
@@ -1836,8 +1977,15 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
     const LevelDev& D = G.lv[l];
     const uint8_t* src = (l == 1) ? d_imgs : pyr + S.pyr_off;
     long long sframe = (l == 1) ? (long long)frame_stride : G.pyr_frame_bytes;
-    dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nframes), block(64, 4);
     const uint8_t* T = c->d_tab.as<uint8_t>();
+    if (c->resize_mfma && (size_t)l < c->rm.size() && c->rm[l].ok && nframes <= 65535) {
+      const orbx_ctx::RmHost& M = c->rm[l];
+      RmLevel R; R.tab = T; R.oW = M.oW; R.oC = M.oC; R.oC0 = M.oC0; R.oRow = M.oRow; R.nchunks = M.nchunks; R.nblocks = M.nblocks; R.sw = S.w; R.sh = S.h; R.dw = D.w; R.dh = D.h;
+      const int ntx = (M.nchunks + 3) / 4, ntb = (M.nblocks + RM_RB - 1) / RM_RB;
+      hipLaunchKernelGGL(k_resize_mfma, dim3(ntx * ntb, nframes), dim3(256), 0, st, R, src, S.pitch, sframe, pyr + D.pyr_off, D.pitch, G.pyr_frame_bytes, ntx);
+      continue;
+    }
+    dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nframes), block(64, 4);
     hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, S.pitch, sframe, S.w, S.h, pyr + D.pyr_off, D.pitch,
                        G.pyr_frame_bytes, D.w, D.h, (const uint2*)(T + c->tab_xofs[l]), (const int*)(T + c->tab_yofs[l]),
                        (const short*)(T + c->tab_ibeta[l]));
@@ -1966,6 +2114,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) c->ev_fork = nullptr;
   if (c->ev_fork && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(c->ev_fork); c->ev_fork = nullptr; c->ev_join = nullptr; }
   if (const char* e = std::getenv("ORBHIP_BLUR_MFMA")) c->blur_mfma = atoi(e) != 0;
+  if (const char* e = std::getenv("ORBHIP_RESIZE_MFMA")) c->resize_mfma = atoi(e) != 0;
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_OVERLAP_BLUR")) c->overlap_blur = atoi(e);
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_DESC_XCD")) c->desc_xcd = atoi(e);
   if (const char* e = ORBHIP_EXP_ENV("ORBHIP_FAST_XCD")) c->fast_xcd = atoi(e);

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 MATCH = os.environ.get("PMC_MATCH_KERNEL", "k_match_pairs_mfma")      # (k_match_pairs when the passes ran with ORBHIP_MATCH_MFMA=0)
 BLUR = os.environ.get("PMC_BLUR_KERNEL", "k_blur7_mfma")      # (k_blur7 when the passes ran with ORBHIP_BLUR_MFMA=0)
-NAMES = ["k_resize", "k_fast_cells", "k_octree", BLUR, "k_describe", MATCH]
+RESIZE = os.environ.get("PMC_RESIZE_KERNEL", "k_resize_mfma")  # (k_resize when the passes ran with ORBHIP_RESIZE_MFMA=0)
+NAMES = [RESIZE, "k_fast_cells", "k_octree", BLUR, "k_describe", MATCH]
 
 
 def load(tag):
@@ -48,7 +49,7 @@ valu = {"note": "rocprofv3 --pmc passes over tools/frontend_only.py %d 3 (extrac
         "frames_per_launch": B, "kernels": {}}
 for k in NAMES:
     i, a = ins[k], act[k]
-    launches = 7 if k == "k_resize" else 1
+    launches = 7 if k in ("k_resize", "k_resize_mfma") else 1
     cyc = a["GRBM_GUI_ACTIVE"] / 8.0 * launches
     valu["kernels"][k] = {
         "waves": i["SQ_WAVES"] * launches, "valu_insts": i["SQ_INSTS_VALU"] * launches, "salu_insts": i["SQ_INSTS_SALU"] * launches,
@@ -72,7 +73,7 @@ tr = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools
               "is applied to these 1-4 B/lane kernels (the guide's x2 applies to 16 B/lane streams)." % (B, B),
       "frames_per_launch": B, "kernels": {}}
 for k in NAMES:
-    mult = 7 if k == "k_resize" else 1                      # 7 pyramid launches per batch
+    mult = 7 if k in ("k_resize", "k_resize_mfma") else 1                      # 7 pyramid launches per batch
     f, w = fe[k]["FETCH_SIZE"] * mult, wr[k]["WRITE_SIZE"] * mult
     tr["kernels"][k] = {"FETCH_SIZE_KB_per_batch": f, "WRITE_SIZE_KB_per_batch": w, "hbm_bytes_per_frame": (f + w) * 1024.0 / B}
 P = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")
