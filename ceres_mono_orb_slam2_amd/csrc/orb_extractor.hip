@@ -1576,8 +1576,8 @@ struct orbx_ctx {
   int w = 0, h = 0, stride = 0, nframes = 0;
   GeomDev G;
   std::vector<CellDesc> cells;
-  std::vector<BlurTile> btiles, mtiles;      // k_blur7's 128 x 64 tiles, k_blur7_mfma's 192 x 58 tiles
-  DevBuf d_cells, d_btiles, d_mtiles, d_tab;      // tables
+  std::vector<BlurTile> btiles, mtiles, mtiles1;      // k_blur7's 128 x 64 tiles, k_blur7_mfma's strips of BM_RC chunks (batches) / of one chunk (a lone frame: latency)
+  DevBuf d_cells, d_btiles, d_mtiles, d_mtiles1, d_tab;      // tables
   int blur_mfma = 1;                  // k_blur7_mfma (default) / k_blur7 (ORBHIP_BLUR_MFMA=0: the VALU kernel, for A/B runs)
   std::vector<size_t> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // byte offsets into d_tab per level
   struct RmHost { size_t oW = 0, oC = 0, oC0 = 0, oRow = 0; int nchunks = 0, nblocks = 0; bool ok = false; };
@@ -1652,7 +1652,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
   if (!same_shape) {
     std::memset(&G, 0, sizeof(G));
     G.nlevels = nl;
-    c->cells.clear(); c->btiles.clear(); c->mtiles.clear();
+    c->cells.clear(); c->btiles.clear(); c->mtiles.clear(); c->mtiles1.clear();
     long long pyr_off = 0, blur_off = 0;
     int key_off = 0, tile_w = 8, tile_h = 8, cell_cap = 1, max_cells = 1, node_cap = MAX_INI + 8, sel_cap = 8, desc_blocks = 0;
     std::vector<uint8_t> tab;
@@ -1820,6 +1820,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
         for (int tx = 0; tx < (L.w + BM_TW - 1) / BM_TW; tx++) {
           BlurTile bt; bt.level = (short)l; bt.tx = (short)tx; bt.ty = (short)ty; bt.pad = (short)std::min(BM_RC, nty - ty);
           c->mtiles.push_back(bt);
+          for (int q = 0; q < bt.pad; q++) { BlurTile b1 = bt; b1.ty = (short)(ty + q); b1.pad = 1; c->mtiles1.push_back(b1); }
         }
     }
     G.ncells_total = (int)c->cells.size();
@@ -1891,10 +1892,12 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     if (int rc = c->d_cells.ensure(std::max<size_t>(c->cells.size(), 1) * sizeof(CellDesc))) return rc;
     if (int rc = c->d_btiles.ensure(c->btiles.size() * sizeof(BlurTile))) return rc;
     if (int rc = c->d_mtiles.ensure(c->mtiles.size() * sizeof(BlurTile))) return rc;
+    if (int rc = c->d_mtiles1.ensure(c->mtiles1.size() * sizeof(BlurTile))) return rc;
     if (int rc = c->d_tab.ensure(std::max<size_t>(tab.size(), 16))) return rc;
     if (!c->cells.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_cells.p, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
     ORBHIP_CHECK_HIP(hipMemcpy(c->d_btiles.p, c->btiles.data(), c->btiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
     ORBHIP_CHECK_HIP(hipMemcpy(c->d_mtiles.p, c->mtiles.data(), c->mtiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
+    ORBHIP_CHECK_HIP(hipMemcpy(c->d_mtiles1.p, c->mtiles1.data(), c->mtiles1.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
     if (!tab.empty()) ORBHIP_CHECK_HIP(hipMemcpy(c->d_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
     if (!c->octree_gmem && c->octree_lds > 64 * 1024)
       if (int rc = raise_dynamic_lds((const void*)k_octree<false, false>, c->device, c->octree_lds)) return rc;
@@ -1950,8 +1953,10 @@ static int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int w, int h, int strid
   const GeomDev& G = c->G;
   const int nl = c->nlevels;
   uint8_t* pyr = c->d_pyr.as<uint8_t>();
-  const unsigned n_btiles = (unsigned)(c->blur_mfma ? c->mtiles.size() : c->btiles.size());
-  const BlurTile* d_btl = c->blur_mfma ? c->d_mtiles.as<BlurTile>() : c->d_btiles.as<BlurTile>();
+  // (a lone frame: one 58-row chunk per wave - four times the workgroups, a quarter of the chain per wave)
+  const bool blur_short = c->blur_mfma && nframes < 4;
+  const unsigned n_btiles = (unsigned)(c->blur_mfma ? (blur_short ? c->mtiles1.size() : c->mtiles.size()) : c->btiles.size());
+  const BlurTile* d_btl = c->blur_mfma ? (blur_short ? c->d_mtiles1.as<BlurTile>() : c->d_mtiles.as<BlurTile>()) : c->d_btiles.as<BlurTile>();
   auto mark = [&]() { if (c->profiling) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_events.push_back(e); } } };
   static const bool cone_on = []() { const char* e = ORBHIP_EXP_ENV("ORBHIP_EXTRACT_CONE"); return !(e && e[0] == '0'); }();
   const bool cone = cone_on && nframes == 1 && c->cone_wgs > 0;
@@ -2124,7 +2129,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
 
 int orbx_destroy(orbx_ctx* c) {
   if (!c) return 0;
-  DevBuf* bufs[] = {&c->d_cells, &c->d_btiles, &c->d_mtiles, &c->d_tab, &c->d_pyr, &c->d_blur, &c->d_cellcnt, &c->d_cellkps,
+  DevBuf* bufs[] = {&c->d_cells, &c->d_btiles, &c->d_mtiles, &c->d_mtiles1, &c->d_tab, &c->d_pyr, &c->d_blur, &c->d_cellcnt, &c->d_cellkps,
                     &c->d_keys, &c->d_knode, &c->d_sel, &c->d_selcnt, &c->d_nkeys, &c->d_status, &c->d_img,
                     &c->d_out, &c->d_octnodes};
   for (DevBuf* b : bufs) b->release();
