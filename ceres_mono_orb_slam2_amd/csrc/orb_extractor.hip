@@ -405,9 +405,10 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   const int plane = (G.tile_h * TP + 15) & ~15;       // multiple of 16 (the score plane is cleared with 16-byte stores)
   const int lane = threadIdx.x & 63;
   typedef typename FastMask<NARROW>::type mask_t;
-  // Cell order = plain grid order.  (Measured on MI355X: an XCD-contiguous remap ci = (b%8)*chunk + b/8 cuts
-  // this kernel's FETCH_SIZE 4.9x - neighbouring cells then share one L2 - but makes it 40 % SLOWER; it is
-  // latency/issue-bound, not HBM-bound, so the faster mapping is kept.  DESIGN.md section 4.)
+  // Cell order inside a frame = plain grid order; xcd_map (batches of a multiple of 8 frames, the default since round 5) deals the
+  // FRAMES to the XCDs: a frame's cells - whose 36-byte tile rows share 128-byte lines with their neighbours' - then meet in one L2
+  // (FETCH_SIZE 5.2 x lower, same speed now that the kernel is VALU-bound; a remap of the CELLS, ci = (b % 8) * chunk + b / 8, was
+  // 40 % slower when the kernel was latency-bound in rounds 1-2).
   int f = blockIdx.y, bxi = blockIdx.x;
   if (xcd_map) {                                              // frame f on XCD f % 8 (as k_describe; host: frame count multiple of 8)
     const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, x = lin & 7u, i = lin >> 3;
@@ -1589,7 +1590,10 @@ struct orbx_ctx {
   void* h_pin = nullptr; size_t h_bytes = 0;   // pinned host mirror of both
   size_t fast_lds = 0, octree_lds = 0, octree_lds_wide = 0;
   bool octree_wide = false;           // some level can hold > 65535 candidates: 32-bit node counters (k_octree<true, .>)
-  int fast_xcd = 0;                   // ORBHIP_FAST_XCD=1: k_fast_cells with frame f on XCD f % 8 (experiment)
+  int fast_xcd = 1;                   // k_fast_cells with frame f on XCD f % 8 (batches of a multiple of 8 frames).  Round 5: default - with the kernel
+                                      // VALU-bound the mapping costs nothing any more (176.3 k against 175.2 k frames/s) and its 36-byte tile rows
+                                      // meet their 128-byte lines in ONE L2: FETCH_SIZE 860 -> 164 MB per 256-frame launch (ORBHIP_FAST_XCD=0 in
+                                      // an experiments build restores the plain order; rounds 1-2 measured it 40 % slower, latency-bound then)
   bool fast_narrow = false;           // k_fast_cells<true>: all cell interiors <= 32 px wide
   int desc_xcd = 1;                   // k_describe: frame f on XCD f % 8 (ORBHIP_DESC_XCD=0 restores the plain order)
   bool octree_gmem = false;           // node arrays larger than the LDS: global scratch rows (k_octree<., true>)

@@ -25,11 +25,9 @@ def _addr(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
 
 
-def create_new_map_points(cur, neighbours, scale_factors, level_sigma2, ratio_factor, stop=None):
-    """LocalMapping::CreateNewMapPoints for the current keyframe and its neighbours, in order, in one call.
-    cur = dict(kps[n1,4] {x, y, octave, angle}, desc[n1,32], unmapped[n1] (or None), fv=(nodes, offsets, indices), Tcw[3,4], K4);
-    each neighbour the same plus F12[3,3] and epipole=(ex, ey).  stop: optional 1-element uint8 array (CheckNewKeyFrames).
-    Returns (match12[nb, n1] int32, ok[nb, n1] bool, x3D[nb, n1, 3] float64, n_processed)."""
+def prepare_create_new_map_points(cur, neighbours, scale_factors, level_sigma2, ratio_factor, stop=None):
+    """Marshals the arguments of orbl_create_new_map_points once and returns call() -> (match12, ok, x3D, n_processed): what a C++
+    caller holds anyway (tools/api_latency.py times call() alone)."""
     L = _lib.load()
     keep = []                                                   # the arrays the structs point at
 
@@ -62,10 +60,22 @@ def create_new_map_points(cur, neighbours, scale_factors, level_sigma2, ratio_fa
         st = C.c_void_p(stop.ctypes.data)
     L.orbl_create_new_map_points.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
-    _lib.check(L.orbl_create_new_map_points(_addr(k1), _addr(d1), _addr(u1), n1, _addr(f1[0]), _addr(f1[1]), _addr(f1[2]), len(f1[0]), _addr(T1), _addr(K1),
-                                            C.cast(nb, C.c_void_p), nn, _addr(sf), _addr(ls), len(sf), float(ratio_factor), st, _addr(m), _addr(ok), _addr(X),
-                                            C.byref(npr)), "orbl_create_new_map_points")
-    return m[:nn, :n1], ok[:nn, :n1].view(np.bool_), X[:nn, :n1], npr.value
+    a = (_addr(k1), _addr(d1), _addr(u1), n1, _addr(f1[0]), _addr(f1[1]), _addr(f1[2]), len(f1[0]), _addr(T1), _addr(K1), C.cast(nb, C.c_void_p), nn, _addr(sf), _addr(ls),
+         len(sf), float(ratio_factor), st, _addr(m), _addr(ok), _addr(X), C.byref(npr))
+
+    def call():
+        _lib.check(L.orbl_create_new_map_points(*a), "orbl_create_new_map_points")
+        return m[:nn, :n1], ok[:nn, :n1].view(np.bool_), X[:nn, :n1], npr.value
+    call._keep = (keep, nb)
+    return call
+
+
+def create_new_map_points(cur, neighbours, scale_factors, level_sigma2, ratio_factor, stop=None):
+    """LocalMapping::CreateNewMapPoints for the current keyframe and its neighbours, in order, in one call.
+    cur = dict(kps[n1,4] {x, y, octave, angle}, desc[n1,32], unmapped[n1] (or None), fv=(nodes, offsets, indices), Tcw[3,4], K4);
+    each neighbour the same plus F12[3,3] and epipole=(ex, ey).  stop: optional 1-element uint8 array (CheckNewKeyFrames).
+    Returns (match12[nb, n1] int32, ok[nb, n1] bool, x3D[nb, n1, 3] float64, n_processed)."""
+    return prepare_create_new_map_points(cur, neighbours, scale_factors, level_sigma2, ratio_factor, stop)()
 
 
 def fuse_batch(keyframes, q_uv, q_radius, q_level, mp_desc, inv_level_sigma2):

@@ -30,6 +30,7 @@ cur, nbs = make_scene(2, n_nb=20)
 ratio = np.float32(1.8)
 lm = {}
 lm["orbl_create_new_map_points_20_neighbours_ms"] = lat(lambda: localmapping.create_new_map_points(cur, nbs, SF, LS, ratio), 20)
+lm["orbl_create_new_map_points_20_neighbours_c_call_only_ms"] = lat(localmapping.prepare_create_new_map_points(cur, nbs, SF, LS, ratio), 30)      # arguments marshalled once: what a C++ caller pays
 mm = ORBmatcher(0.6, False)
 def per_neighbour():
     mask = cur["unmapped"].copy()
