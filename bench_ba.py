@@ -79,7 +79,12 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
     # in flight from host threads (one HIP stream + device workspace per thread)
     # (64 per call since round 2: the lockstep launches are bound by the sum of their kernels' exclusive times - ~0.85 ms of GPU
     # per solve - and larger launches fill the chip better: 16 x 8 -> 1110, 32 x 8 -> 1170, 64 x 8 -> 1270 solves/s)
-    nbatch, nthreads, n_each = (8, 2, 1) if quick else (64, 12, 2)      # (12 threads x 64 problems: 1737 - 1791 solves/s against 1552 - 1698 with 8, tools/ba_batch_thr.py)
+    # (12 threads x 64 problems: 1737 - 1791 solves/s against 1552 - 1698 with 8 in round 3, tools/ba_batch_thr.py.  Round 5: EIGHT timed
+    # batches per thread instead of two - the threads leave the barrier together, so the window opens with every one of them in its host
+    # structure pass and the GPU idle, and closes with the stragglers alone: with two batches per thread that ramp was 16 % of the window
+    # (tools/ba_batch_thr.py 64:12:N, N = 2 / 4 / 8 / 16: 2848 / 3151 / 3312 / 3294 solves/s; a kernel trace of the steady part shows one
+    # batch iteration per 1.2 ms = 3555 solves/s))
+    nbatch, nthreads, n_each = (8, 2, 1) if quick else (64, 12, 8)
     gs = [g] + [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(1, nbatch)]   # 64 distinct local maps
     probs = [(q["K4"], q["poses0"], q["cam_fixed"], local, q["pts0"], q["obs_cam"], q["obs_pt"], q["obs_uv"], q["obs_inv_sigma2"]) for q in gs]
     fl_batch = sum(sum(reduced_solve_flops(q)) for q in gs)

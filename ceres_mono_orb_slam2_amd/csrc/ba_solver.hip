@@ -172,6 +172,7 @@ struct BaDev {            // device pointers of one problem
   const int4* row_meta;              // [nfc][2] block row a: {first, end of the diagonal block's pairs, first, end of the row's segments}, {first entry, length of camera a's list, camera index, -}
   const int4* seg;                   // the off-diagonal blocks cut into SEGMENTS of <= SR_SEG pairs: {first pair, end, column b, 1 = first | 2 = last segment of its block | camera index of b << 2}
   const int* free_cams;              // [nfc] reduced column -> camera index
+  const int* tile_first;             // [npad / 32 + 1] skyline of S by 32-row tiles: first tile column with a structural non-zero (entry npad / 32: the rhs row, 0)
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
   const unsigned char* cam_local; unsigned char* erase;   // LocalBA classification (k_ba_classify): local flags [ncam], result [nobs] (device order)
@@ -1187,6 +1188,8 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
                                      int duplicate_blocks, int* aborted, ba_summary* pass1, ba_summary* pass2) {
   ORBHIP_REQUIRE(problems && aborted && nproblems > 0, ORBHIP_EINVAL, "NULL argument");
   *aborted = 0;
+  const bool timing = std::getenv("ORBHIP_BA_TIMING") != nullptr;
+  const double tt0 = ba_now_ms();
   struct Work {
     std::vector<double> P0, X0, uv, w; std::vector<int32_t> oc, op; std::vector<uint8_t> rob, erase;
   };
@@ -1239,8 +1242,10 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
   if (stop_flag && *stop_flag) { *aborted = 1; return 0; }                  // :509-512
   ba_options o1; o1.max_iterations = 5; o1.huber_delta = sqrt(5.991); o1.fix_points = 0; o1.stop_flag = stop_flag;
   bind();
+  const double tt1 = ba_now_ms();
   int rc = ba_solve_batch_impl(in.data(), nproblems, &o1, pass1, false, erase_dev);
   if (rc) return rc;
+  const double tt2 = ba_now_ms();
   for (int q = 0; q < nproblems; q++) {
     const ba_local_problem& L = problems[q]; Work& w = W[q];
     if (!duplicate_blocks) classify(q);
@@ -1260,8 +1265,10 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
   if (stop_flag && *stop_flag) { *aborted = 1; return 0; }
   ba_options o2 = o1; o2.max_iterations = 10;
   bind();
+  const double tt3 = ba_now_ms();
   rc = ba_solve_batch_impl(in.data(), nproblems, &o2, pass2, duplicate_blocks != 0, erase_dev);      // same observation set: structure reused
   if (rc) return rc;
+  const double tt4 = ba_now_ms();
   for (int q = 0; q < nproblems; q++) {
     const ba_local_problem& L = problems[q]; Work& w = W[q];
     if (!duplicate_blocks) classify(q);
@@ -1274,6 +1281,7 @@ int ba_local_bundle_adjustment_batch(const ba_local_problem* problems, int nprob
     std::memcpy(L.poses7, w.P0.data(), sizeof(double) * 7 * L.ncam);
     if (L.npts) std::memcpy(L.pts3, w.X0.data(), sizeof(double) * 3 * L.npts);
   }
+  if (timing) fprintf(stderr, "[ba_local_batch] setup %.2f ms, pass 1 %.2f, between %.2f, pass 2 %.2f, write-back %.2f\n", tt1 - tt0, tt2 - tt1, tt3 - tt2, tt4 - tt3, ba_now_ms() - tt4);
   return 0;
 }
 

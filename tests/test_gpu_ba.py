@@ -232,6 +232,69 @@ def test_batched_solves_equal_single_solves():
     assert all(a[2] == b[2] and np.array_equal(a[0], b[0]) for a, b in zip(res, res2))
 
 
+def _with_long_range_links(g, seed, kind):
+    """Adds observations that change the ENVELOPE of the reduced system: kind 1 - the LAST camera sees points of the first ones (a dense
+    last block row), 2 - the first FREE camera sees points everywhere (a dense first column: every row's envelope starts at 0),
+    3 - random far links (a ragged, non-monotone skyline).  Only points in front of the extra camera are linked."""
+    if kind == 0:
+        return g
+    rng = np.random.default_rng(1000 + seed)
+    ncam, npts = len(g["cam_fixed"]), len(g["pts0"])
+    free = np.flatnonzero(g["cam_fixed"] == 0)
+    extra_c, extra_p = [], []
+    if kind == 1:
+        pts = rng.choice(npts, max(npts // 6, 8), replace=False); extra_c = [ncam - 1] * len(pts); extra_p = list(pts)
+    elif kind == 2:
+        pts = rng.choice(npts, max(npts // 6, 8), replace=False); extra_c = [int(free[0])] * len(pts); extra_p = list(pts)
+    else:
+        n = max(npts // 5, 8); extra_c = list(rng.integers(0, ncam, n)); extra_p = list(rng.integers(0, npts, n))
+    have = set(zip(g["obs_cam"].tolist(), g["obs_pt"].tolist()))
+    oc, op, uv, w = [], [], [], []
+    for c, p in zip(extra_c, extra_p):
+        if (int(c), int(p)) in have:
+            continue
+        x, ok = synth.project(g["K4"][0], g["poses_gt"][c], g["pts_gt"][p][None])
+        zc = (synth.quat_to_R(g["poses_gt"][c, 3:]) @ g["pts_gt"][p] + g["poses_gt"][c, :3])[2]
+        if zc < 1.0:
+            continue
+        have.add((int(c), int(p))); oc.append(c); op.append(p); uv.append(x[0] + rng.normal(0, 1.0, 2)); w.append(1.0)
+    if not oc:
+        return g
+    g = dict(g)
+    g["obs_cam"] = np.concatenate([g["obs_cam"], np.array(oc, np.int32)]); g["obs_pt"] = np.concatenate([g["obs_pt"], np.array(op, np.int32)])
+    g["obs_uv"] = np.concatenate([g["obs_uv"], np.array(uv)]); g["obs_inv_sigma2"] = np.concatenate([g["obs_inv_sigma2"], np.array(w, g["obs_inv_sigma2"].dtype)])
+    return g
+
+
+def test_lockstep_batch_of_36_workgroup_cholesky_equals_single_solves():
+    """Batches of >= 32 problems factor every reduced system in ONE workgroup (k_chol_wg), which walks only the tiles inside the
+    system's SKYLINE (csrc/ba_host.inc tile_first): 36 problems of 2 .. 19 block rows whose envelopes are banded (consecutive-view
+    tracks), have a dense last row, a dense first column (= no tile to skip) or ragged far links - every one BIT-IDENTICAL to its
+    single call (k_chol_persist: the dense walk), for ba_solve and for the two-pass LocalBA."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    shapes = [(12, 300, 1300), (18, 420, 1900), (25, 500, 2400), (33, 700, 3200), (40, 800, 3900), (52, 1000, 4800), (64, 1300, 6200), (77, 1500, 7300),
+              (100, 2000, 9000)]
+    gs = []
+    for i in range(36):
+        c, p, o = shapes[i % len(shapes)]
+        gs.append(_with_long_range_links(synth.make_ba_graph(500 + i, ncam=c, npts=p, nobs=o, n_fixed=1 + (i % 2)), i, i % 4))
+    probs = [(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"].astype(np.float64),
+              np.ones(len(g["obs_cam"]), np.uint8)) for g in gs]
+    res = optimizer.bundle_adjustment_batch(probs, n_iterations=6)
+    assert all(r[2]["iterations"] >= 2 for r in res)
+    for q, (pr, (poses, pts, s)) in enumerate(zip(probs, res)):
+        p1, x1, s1 = optimizer.bundle_adjustment(*pr, n_iterations=6)
+        assert s == s1 and np.array_equal(poses, p1) and np.array_equal(pts, x1), q
+    lprobs = [(g["K4"], g["poses0"], g["cam_fixed"], np.ones(len(g["cam_fixed"]), np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"],
+               g["obs_inv_sigma2"]) for g in gs]
+    ab, lres = optimizer.local_bundle_adjustment_batch(lprobs)
+    assert ab == 0
+    for q in (0, 1, 2, 3, 9, 18, 27, 34, 35):
+        poses, pts, er, s1, s2 = lres[q]
+        ab1, p1, x1, e1, t1, t2 = optimizer.local_bundle_adjustment(*lprobs[q])
+        assert (s1, s2) == (t1, t2) and np.array_equal(er, e1) and np.array_equal(poses, p1) and np.array_equal(pts, x1), q
+
+
 def test_folded_twin_blocks_equal_literal_duplicates(oracle):
     """obs_robust = 2 (a Huber block + its loss-free twin folded into one block, the form LocalBA's second pass uses for
     the reference's re-added blocks, F6) against the oracle solving the LITERAL duplicated list."""

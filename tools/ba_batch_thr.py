@@ -1,4 +1,4 @@
-"""LocalBA (C4 size) throughput: batch size B per call x T host threads.  usage: ba_batch_thr.py B:T [B:T ...]"""
+"""LocalBA (C4 size) throughput: batch size B per call x T host threads.  usage: ba_batch_thr.py B:T[:N] [B:T[:N] ...]"""
 import numpy as np, sys, time, os, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ceres_mono_orb_slam2_amd import synth, optimizer
@@ -6,9 +6,10 @@ gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s 
 local = np.ones(100, np.uint8)
 def prob(g): return (g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
 for spec in sys.argv[1:]:
-    B, T = [int(x) for x in spec.split(":")]
+    f = [int(x) for x in spec.split(":")]
+    B, T = f[0], f[1]
     probs = [prob(gs[i % 16]) for i in range(B)]
-    n_each = max(2, 48 // (B * T))
+    n_each = f[2] if len(f) > 2 else max(2, 48 // (B * T))      # B:T:N = N batches per thread in the timed part
     bar = threading.Barrier(T + 1)
     def work():
         try:
@@ -17,7 +18,9 @@ for spec in sys.argv[1:]:
             bar.abort()                      # (a worker that dies must not leave the others waiting at the barrier for ever)
             raise
         bar.wait()
-        for _ in range(n_each): optimizer.local_bundle_adjustment_batch(probs)
+        for _ in range(n_each):
+            t1 = time.perf_counter(); optimizer.local_bundle_adjustment_batch(probs)
+            if os.environ.get('ORBHIP_BA_TIMING'): print('[python] call %.2f ms' % ((time.perf_counter() - t1) * 1e3), file=sys.stderr, flush=True)
     ths = [threading.Thread(target=work) for _ in range(T)]
     for t in ths: t.start()
     try:
