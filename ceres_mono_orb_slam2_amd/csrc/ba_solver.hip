@@ -193,6 +193,7 @@ __device__ __forceinline__ StFlags ld_flags(const BaState* st) {
 }
 
 #define BA_TPB 256
+#define NB 32                          /* tile edge of the reduced system's factorisation (ba_cholesky.inc) */
 
 // The per-observation block E = (Jc S_c)^T (Jp S_p) (6x3) is never stored: it FACTORS.  With Q = sqrt(rho') w dpi/dX_c (2x3, four
 // non-zero entries), the rotated point RX and the camera's rotation R (ba_math.h: Jc = Q [I | -2 [RX]x], Jp = Q R),
@@ -466,12 +467,26 @@ __device__ __forceinline__ bool inv3_sym6(const double* C, double* Ci) {   // C 
 }
 
 // (the workgroups behind the `npt_grid` landmark workgroups zero the reduced system: k_ba_zero_S was a launch of its own)
-__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restrict__ Dv, int npt_grid) {
+// envelope != 0 (lockstep batches factored by k_chol_wg, which never writes a tile outside the skyline - tile_first): only the tiles
+// INSIDE the envelope are cleared; the rest was zeroed once at the start of the solve (k_ba_zero_S) and nothing has touched it since.
+// At C4 size that is 55 tiles of 8 KB per problem instead of 2.9 MB (185 MB per 64-problem launch).
+__global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restrict__ Dv, int npt_grid, int envelope) {
   const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
   const StFlags F = ld_flags(st);
   if (F.done || !F.valid) return;
   if ((int)blockIdx.x >= npt_grid) {
+    if (envelope && D.chol_la) {
+      const int nbz = D.npad / NB, np = D.npad;
+      for (int i = (int)blockIdx.x - npt_grid; i < nbz; i += (int)gridDim.x - npt_grid) {
+        const int f = min(D.tile_first[i], i), wd = (i - f + 1) * NB;
+        for (int e = threadIdx.x; e < NB * wd; e += BA_TPB) {
+          const int r = NB * i + e / wd, c = NB * f + e % wd;
+          if (r < D.n6) D.S[(size_t)r * np + c] = 0.0;
+        }
+      }
+      return;
+    }
     const size_t tot = (size_t)D.n6 * D.npad, nz = (size_t)(gridDim.x - npt_grid) * BA_TPB;
     for (size_t i = (size_t)((int)blockIdx.x - npt_grid) * BA_TPB + threadIdx.x; i < tot; i += nz) D.S[i] = 0.0;
     return;
@@ -841,11 +856,11 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 // zero the lower triangle rows of the real block (the factorisation overwrote S in place)
-__global__ __launch_bounds__(256) void k_ba_zero_S(const BaDev* __restrict__ Dv) {
+__global__ __launch_bounds__(256) void k_ba_zero_S(const BaDev* __restrict__ Dv, int always) {      // always: at the start of a solve (the state is not valid yet)
   const BaDev D = Dv[blockIdx.y];
   const BaState* st = D.st;
   const StFlags F = ld_flags(st);
-  if (F.done || !F.valid) return;
+  if (!always && (F.done || !F.valid)) return;
   const size_t tot = (size_t)D.n6 * D.npad;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) D.S[i] = 0.0;
 }
@@ -916,6 +931,7 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restric
 #ifndef BS_TPB
 #define BS_TPB 1024
 #endif
+#define BS_LDS_OBS 2048                /* observations of a workgroup's 256 points whose t_i fit its LDS (48 KB) */
 __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__ Dv, int part_off) {
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[16 * 2], s_out[2];
@@ -927,6 +943,10 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
   const int p0 = blockIdx.x * BS_PTS, p1 = min(p0 + BS_PTS, D.npts);
   const bool ok = !st->chol_fail;
   const int olo = (p1 > p0) ? D.pt_off[p0] : 0, ohi = (p1 > p0) ? D.pt_off[p1] : 0;
+  // t_i waits for phase (2) in LDS when the workgroup's observations fit (round 5: it went through global memory - 77 MB written and
+  // read back per 64-problem launch at C4 size); the same doubles either way
+  __shared__ double s_t3[3 * BS_LDS_OBS];
+  const bool in_lds = ohi - olo <= BS_LDS_OBS;
   double acc[2] = {0.0, 0.0};              // model cost change, |dx|^2
   if (ok && !D.fix_points)
     for (int i = olo + tid; i < ohi; i += BS_TPB) {
@@ -946,7 +966,8 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
 #pragma unroll
         for (int v = 0; v < 3; v++) t[v] = fma(Rc[6 + v], q2, fma(Rc[3 + v], q1, Rc[v] * q0));
       }
-      D.t3[3 * (size_t)i] = t[0]; D.t3[3 * (size_t)i + 1] = t[1]; D.t3[3 * (size_t)i + 2] = t[2];
+      if (in_lds) { s_t3[3 * (i - olo)] = t[0]; s_t3[3 * (i - olo) + 1] = t[1]; s_t3[3 * (i - olo) + 2] = t[2]; }
+      else { D.t3[3 * (size_t)i] = t[0]; D.t3[3 * (size_t)i + 1] = t[1]; D.t3[3 * (size_t)i + 2] = t[2]; }
     }
   __syncthreads();
   if (tid < BS_PTS) {
@@ -959,7 +980,8 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
         double t[3] = {g0, g1, g2};                             // g_p - sum: subtracted one by one, as before
         const double* spp = D.scale_p + 3 * (size_t)p;
         for (int i = lo; i < hi; i++) {
-          const double a0 = D.t3[3 * (size_t)i] * spp[0], a1 = D.t3[3 * (size_t)i + 1] * spp[1], a2 = D.t3[3 * (size_t)i + 2] * spp[2];
+          const double* tq = in_lds ? s_t3 + 3 * (i - olo) : D.t3 + 3 * (size_t)i;
+          const double a0 = tq[0] * spp[0], a1 = tq[1] * spp[1], a2 = tq[2] * spp[2];
           t[0] -= a0; t[1] -= a1; t[2] -= a2; T0 += a0; T1 += a1; T2 += a2;
         }
         const double* Ci = D.Cinv + 6 * (size_t)p;
