@@ -176,6 +176,7 @@ struct BaDev {            // device pointers of one problem
   double* part;                      // partial sums: [3][nparts]
   int nparts; int fix_points;
   const unsigned char* cam_local; unsigned char* erase;   // LocalBA classification (k_ba_classify): local flags [ncam], result [nobs] (device order)
+  int pt_in_eval;                    // 1: the 3x3 landmark blocks are summed by k_ba_eval<0> itself (every point has <= PT_MAXRUN observations), 0: by k_ba_cam_blocks' landmark workgroups
   int chol_la;                       // 1: this problem's reduced system is factored by the look-ahead kernel (npad <= 1024), 0: two-level blocking
   double huber;
   const volatile unsigned char* stop_dev;   // device-visible mirror of the caller's stop flag (pinned host byte of the calling thread)
@@ -213,6 +214,23 @@ __device__ __forceinline__ void ld_rec8(const double* __restrict__ base, size_t 
 #pragma unroll
   for (int k = 0; k < 4; k++) { const double2 v = m[k]; c[2 * k] = v.x; c[2 * k + 1] = v.y; }
 }
+// One observation's share of its landmark's blocks, Jp = Q R:  Jp^T Jp = R^T W R (6 numbers),  Jp^T res = R^T h (3), from the factored
+// record {w00, w11, w02, w12, w22} / h and the camera's rotation.  ONE function for both places that form it (ba_pt_blocks_body from the
+// stored record, k_ba_eval<0> from the registers the record was written from): the same operations on the same doubles.
+__device__ __forceinline__ void pt_terms(double w00, double w11, double w02, double w12, double w22, double h0, double h1, double h2, const double* Rc, double* o) {
+  double V[9];                                                          // V = W R
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    V[k] = fma(w02, Rc[6 + k], w00 * Rc[k]);
+    V[3 + k] = fma(w12, Rc[6 + k], w11 * Rc[3 + k]);
+    V[6 + k] = fma(w22, Rc[6 + k], fma(w12, Rc[3 + k], w02 * Rc[k]));
+  }
+  o[0] = fma(Rc[6], V[6], fma(Rc[3], V[3], Rc[0] * V[0])); o[1] = fma(Rc[6], V[7], fma(Rc[3], V[4], Rc[0] * V[1])); o[2] = fma(Rc[6], V[8], fma(Rc[3], V[5], Rc[0] * V[2]));
+  o[3] = fma(Rc[7], V[7], fma(Rc[4], V[4], Rc[1] * V[1])); o[4] = fma(Rc[7], V[8], fma(Rc[4], V[5], Rc[1] * V[2]));
+  o[5] = fma(Rc[8], V[8], fma(Rc[5], V[5], Rc[2] * V[2]));
+  o[6] = fma(Rc[6], h2, fma(Rc[3], h1, Rc[0] * h0)); o[7] = fma(Rc[7], h2, fma(Rc[4], h1, Rc[1] * h0)); o[8] = fma(Rc[8], h2, fma(Rc[5], h1, Rc[2] * h0));
+}
+#define PT_MAXRUN 112                  /* observations of one landmark up to which k_ba_eval<0> sums its blocks: (256 + 111) x 9 doubles fit the record staging area */
 // ---- residuals + Jacobians at x (mode 0) or cost only at the candidate (mode 1) -------------------
 template <int mode>      // (a template parameter: the cost-only instance carries neither the staging LDS nor the Jacobian registers)
 __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv) {
@@ -230,8 +248,11 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
   __shared__ int s_q[mode == 0 ? BA_TPB / 64 : 1][mode == 0 ? 64 : 1];            // ... and their places (camera-major position, -1: none)
   int q_mine = -1;
   double acc[1] = {0.0};
+  double rec[11] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};        // this observation's record {W (5), r (3), h (3)}
+  int c_mine = 0, p_mine = -1;
   if (i < D.nobs) {
     const int c = D.obs_cam[i], p = D.obs_pt[i];
+    c_mine = c; p_mine = p;
     const double* poses = mode ? D.cand_poses : D.poses;
     const double* pts = mode ? D.cand_pts : D.pts;
     double r[2], Jc[12], RX[3];
@@ -247,10 +268,12 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
         // k_ba_schur / k_ba_backsub / the block kernels work from, h = Q^T res the gradients' share - 88 bytes per observation, the
         // only thing this kernel writes (it is bound by the HBM WRITE rate, ~2 TB/s: the 2x6 and 2x3 Jacobians were 160 bytes)
         const double q00 = Jc[0], q02 = Jc[2], q11 = Jc[7], q12 = Jc[8];
+        rec[0] = q00 * q00; rec[1] = q11 * q11; rec[2] = q00 * q02; rec[3] = q11 * q12; rec[4] = q02 * q02 + q12 * q12;
+        rec[5] = 2.0 * RX[0]; rec[6] = 2.0 * RX[1]; rec[7] = 2.0 * RX[2];
+        rec[8] = q00 * r[0]; rec[9] = q11 * r[1]; rec[10] = q02 * r[0] + q12 * r[1];
         double* t = s_rec[w][lane];
-        t[0] = q00 * q00; t[1] = q11 * q11; t[2] = q00 * q02; t[3] = q11 * q12; t[4] = q02 * q02 + q12 * q12;
-        t[5] = 2.0 * RX[0]; t[6] = 2.0 * RX[1]; t[7] = 2.0 * RX[2];
-        t[8] = q00 * r[0]; t[9] = q11 * r[1]; t[10] = q02 * r[0] + q12 * r[1];
+#pragma unroll
+        for (int k = 0; k < 11; k++) t[k] = rec[k];
       }
     }
   }
@@ -270,6 +293,49 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
       const int idx = lane + 64 * t, rr = idx / 3, part = idx - 3 * rr;
       const int q = s_q[w][rr];
       if (q >= 0) D.Hc[3 * (size_t)q + part] = s_rec[w][rr][8 + part];
+    }
+    // ---- the 3x3 landmark blocks (round 5; they were a pass of their own over the records, gathered by point: ba_pt_blocks_body).  The
+    // observations of a landmark are consecutive, so the workgroup that holds a landmark's FIRST observation sums its run in order from
+    // the nine terms every thread leaves in LDS (the staging area, free once the records are out); a run that continues behind the
+    // workgroup's last observation is evaluated again by the first threads (<= PT_MAXRUN - 1 observations).  Same terms, same order as
+    // the separate pass: the bits of C and g_p do not change.
+    if (D.pt_in_eval && !D.fix_points && D.nobs > 0) {
+      __syncthreads();                                          // every wave's records have left the staging area
+      double* s_pt = &s_rec[0][0][0];                           // [256 + PT_MAXRUN - 1][9]
+      const int b0 = blockIdx.x * BA_TPB, iend = min(b0 + BA_TPB, D.nobs);
+      if (i < D.nobs) {
+        double Rc[9], o[9];
+        quat_to_R(D.poses + 7 * (size_t)c_mine + 3, Rc);
+        pt_terms(rec[0], rec[1], rec[2], rec[3], rec[4], rec[8], rec[9], rec[10], Rc, o);
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_pt[9 * threadIdx.x + k] = o[k];
+      }
+      const int run_end = D.pt_off[D.obs_pt[iend - 1] + 1];     // (uniform) where the run of the workgroup's last landmark ends
+      if ((int)threadIdx.x < run_end - iend) {
+        const int i2 = iend + threadIdx.x, c2 = D.obs_cam[i2];
+        double r2[2], J2[12], RX2[3], Rc[9], o[9];
+        reproj_eval(D.K4 + 4 * c2, D.poses + 7 * c2, D.pts + 3 * (size_t)D.obs_pt[i2], D.obs_uv[2 * (size_t)i2], D.obs_uv[2 * (size_t)i2 + 1],
+                    D.obs_w[i2], D.obs_robust[i2], D.huber, r2, J2, nullptr, RX2);
+        const double q00 = J2[0], q02 = J2[2], q11 = J2[7], q12 = J2[8];
+        quat_to_R(D.poses + 7 * (size_t)c2 + 3, Rc);
+        pt_terms(q00 * q00, q11 * q11, q00 * q02, q11 * q12, q02 * q02 + q12 * q12, q00 * r2[0], q11 * r2[1], q02 * r2[0] + q12 * r2[1], Rc, o);
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_pt[9 * (BA_TPB + threadIdx.x) + k] = o[k];
+      }
+      __syncthreads();
+      if (i < D.nobs && i == D.pt_off[p_mine]) {
+        const int hi = D.pt_off[p_mine + 1];
+        double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        for (int ii = i; ii < hi; ii++) {
+          const double* tq = s_pt + 9 * (ii - b0);
+#pragma unroll
+          for (int k = 0; k < 6; k++) C[k] += tq[k];
+#pragma unroll
+          for (int k = 0; k < 3; k++) g[k] += tq[6 + k];
+        }
+        for (int k = 0; k < 6; k++) D.C[6 * (size_t)p_mine + k] = C[k];
+        for (int k = 0; k < 3; k++) D.gp[3 * (size_t)p_mine + k] = g[k];
+      }
     }
   }
   block_reduce<1>(acc, s_red, s_out);
@@ -349,7 +415,7 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
 
 // ---- 3x3 landmark blocks ------------------------------------------------------------------------------
 __device__ __forceinline__ void ba_pt_blocks_body(const BaDev& D, int bx) {
-  if (D.fix_points) return;
+  if (D.fix_points || D.pt_in_eval) return;                            // (pt_in_eval: k_ba_eval<0> has summed them)
   const int p = bx * BA_TPB + threadIdx.x;
   if (p >= D.npts) return;
   // Jp = Q R:  Jp^T Jp = R^T W R,  Jp^T res = R^T h  from the observation's factored record (camera-major: gathered) and its camera's rotation
@@ -362,18 +428,12 @@ __device__ __forceinline__ void ba_pt_blocks_body(const BaDev& D, int bx) {
     ld_rec8(D.E, q, c8);
     const double h0 = D.Hc[3 * q], h1 = D.Hc[3 * q + 1], h2 = D.Hc[3 * q + 2];
     quat_to_R(D.poses + 7 * (size_t)D.obs_cam[i] + 3, Rc);
-    const double w00 = c8[0], w11 = c8[1], w02 = c8[2], w12 = c8[3], w22 = c8[4];
-    double V[9];                                                          // V = W R
+    double o[9];
+    pt_terms(c8[0], c8[1], c8[2], c8[3], c8[4], h0, h1, h2, Rc, o);
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      V[k] = fma(w02, Rc[6 + k], w00 * Rc[k]);
-      V[3 + k] = fma(w12, Rc[6 + k], w11 * Rc[3 + k]);
-      V[6 + k] = fma(w22, Rc[6 + k], fma(w12, Rc[3 + k], w02 * Rc[k]));
-    }
-    C[0] += fma(Rc[6], V[6], fma(Rc[3], V[3], Rc[0] * V[0])); C[1] += fma(Rc[6], V[7], fma(Rc[3], V[4], Rc[0] * V[1])); C[2] += fma(Rc[6], V[8], fma(Rc[3], V[5], Rc[0] * V[2]));
-    C[3] += fma(Rc[7], V[7], fma(Rc[4], V[4], Rc[1] * V[1])); C[4] += fma(Rc[7], V[8], fma(Rc[4], V[5], Rc[1] * V[2]));
-    C[5] += fma(Rc[8], V[8], fma(Rc[5], V[5], Rc[2] * V[2]));
-    g[0] += fma(Rc[6], h2, fma(Rc[3], h1, Rc[0] * h0)); g[1] += fma(Rc[7], h2, fma(Rc[4], h1, Rc[1] * h0)); g[2] += fma(Rc[8], h2, fma(Rc[5], h1, Rc[2] * h0));
+    for (int k = 0; k < 6; k++) C[k] += o[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) g[k] += o[6 + k];
   }
   for (int k = 0; k < 6; k++) D.C[6 * (size_t)p + k] = C[k];
   for (int k = 0; k < 3; k++) D.gp[3 * (size_t)p + k] = g[k];

@@ -22,7 +22,7 @@ L.ba_debug_chol_prof(buf, 0)
 a = np.array(buf, dtype=np.float64).reshape(128, 10)
 names = ["prologue (T, first loads)", "update steps", "layout change + last update", "factor + inverse", "L = T' X^T + stores + barrier"]
 cols = [k for k in range(128) if a[k, 9] > 0]
-nf = a[0, 9] / 3.0          # column 0 of a 19-block-row system has 3 groups of 8 rows -> factorisations profiled
+nf = a[0, 9] / float(os.environ.get("CW_GROUPS0", "1"))          # groups of column 0 per factorisation (skyline walk of the bench graph: 1; the dense walk of a 19-block-row system had 3)
 tot = a[cols, :5].sum(0) * 10.0 / nf
 print("factorisations profiled: %.0f" % nf)
 for i, n in enumerate(names): print("%-34s %8.1f us per factorisation" % (n, tot[i] / 1e3))
