@@ -108,6 +108,31 @@ def test_ba_solve_vs_oracle(oracle, seed, ncam, npts, nobs, robust, iters):
     assert np.array_equal(poses[:2], g["poses0"][:2])                 # constant blocks untouched
 
 
+def test_landmark_seen_by_130_keyframes_vs_oracle(oracle):
+    """A landmark with more observations than k_ba_eval<0> sums in place (PT_MAXRUN = 112, csrc/ba_solver.hip) sends its problem through
+    the separate landmark-block pass (ba_pt_blocks_body): a far point ahead of a 130-keyframe track, seen by every keyframe, beside the
+    ordinary short tracks - against the oracle at the usual tolerances, and next to it a landmark of exactly 112 views (the in-place sum's
+    longest run, one that crosses workgroup boundaries)."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    for views in (130, 112):
+        g = synth.make_ba_graph(77, ncam=130, npts=600, nobs=3000, n_fixed=2)
+        rng = np.random.default_rng(5)
+        X = np.array([1.5, -0.8, 0.8 * 130 + 25.0])                         # ahead of the last camera: in front of all of them
+        cams = np.arange(130 - views, 130)
+        uv = np.stack([synth.project(g["K4"][0], g["poses_gt"][c], X[None])[0][0] for c in cams]) + rng.normal(0, 1.0, (views, 2))
+        p_new = len(g["pts0"])
+        pts0 = np.vstack([g["pts0"], X * 1.01])
+        oc = np.concatenate([g["obs_cam"], cams.astype(np.int32)]); op = np.concatenate([g["obs_pt"], np.full(views, p_new, np.int32)])
+        ouv = np.vstack([g["obs_uv"], uv]); w = np.concatenate([g["obs_inv_sigma2"].astype(np.float64), np.ones(views)])
+        rb = np.ones(len(oc), np.uint8)
+        perm = rng.permutation(len(oc))
+        poses, pts, s = optimizer.bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], pts0, oc[perm], op[perm], ouv[perm], w[perm], rb[perm], 8)
+        oposes, opts, os_ = oracle.ba_solve(g["K4"], g["poses0"], g["cam_fixed"], pts0, oc, op, ouv, w, rb, 8)
+        assert (s["iterations"], s["successful_steps"], s["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"]), views
+        assert abs(s["final_cost"] - os_["final_cost"]) <= RTOL_COST * os_["final_cost"], views
+        assert _close(poses, oposes, RTOL_X) and _close_pts(pts, opts), views
+
+
 def test_ba_zero_noise_converges_to_truth():
     from ceres_mono_orb_slam2_amd import optimizer
     g = synth.make_ba_graph(5, ncam=8, npts=200, nobs=900, outlier_frac=0.0, noise=0.0, n_fixed=2)
