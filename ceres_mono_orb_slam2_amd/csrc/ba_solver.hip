@@ -163,6 +163,7 @@ struct BaDev {            // device pointers of one problem
   double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] factored 64-byte records in camera-major order (ld_rec8), written by k_ba_eval
   double* Ng;                        // [npts][9] {N = S_p (C_s+D)^-1 S_p (6, symmetric), g_p (3)}: what k_ba_schur needs of a point, one gather
   double* t3;                        // [nobs][3] E_i^T y_cam of the landmark back-substitution
+  double* camrec;                    // [ncam][16] what k_ba_backsub needs of a camera in ONE 128-byte line: {R (9), S_c y (6), 1 = free camera with a valid step | 0} (k_ba_cam_update)
   double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
   double* Dinv;                      // inverse of every 32x32 diagonal Cholesky block [npad/32][32][32]
   double* Mb;                        // persistent Cholesky: M_k = X_k P_k of every step [npad/32][32][32]
@@ -951,6 +952,21 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restric
     const double* x = D.poses + 7 * c;
     double* xc = D.cand_poses + 7 * c;
     const int cc = D.cam_col[c];
+    // the camera's record for k_ba_backsub (round 5: every observation used to walk obs_cam -> cam_col -> {y, S_c, quaternion} and
+    // rebuild R and S_c y itself - one dependent level and ~40 instructions more per observation); the same products, formed once
+    double* cr = D.camrec + 16 * (size_t)c;
+    if (cc < 0 || st->chol_fail) cr[15] = 0.0;
+    else {
+      double Rc[9];
+      quat_to_R(x + 3, Rc);
+      const double* y = D.rhs + 6 * cc;
+      const double* sc = D.scale_c + 6 * (size_t)cc;
+#pragma unroll
+      for (int k = 0; k < 9; k++) cr[k] = Rc[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cr[9 + k] = y[k] * sc[k];
+      cr[15] = 1.0;
+    }
     if (cc < 0 || st->chol_fail) { for (int k = 0; k < 7; k++) xc[k] = x[k]; }
     else {
       const double* y = D.rhs + 6 * cc;
@@ -1010,16 +1026,19 @@ __global__ __launch_bounds__(BS_TPB) void k_ba_backsub(const BaDev* __restrict__
   double acc[2] = {0.0, 0.0};              // model cost change, |dx|^2
   if (ok && !D.fix_points)
     for (int i = olo + tid; i < ohi; i += BS_TPB) {
-      const int c = D.obs_cam[i], cc = D.cam_col[c];
+      const int c = D.obs_cam[i];
       double t[3] = {0.0, 0.0, 0.0};
-      if (cc >= 0) {
-        // E^T y of the factored record (k_ba_eval): S_p R^T W (yt - r x yw), y~ = S_c y; the S_p factor is applied per point below
-        const double* y = D.rhs + 6 * cc;
-        const double* sc = D.scale_c + 6 * (size_t)cc;
-        double e[8], Rc[9];
+      double cr[16], e[8];
+      {                                                       // the camera's record (one line) and the observation's, requested together
+        const double2* m = (const double2*)(D.camrec + 16 * (size_t)c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const double2 v = m[k]; cr[2 * k] = v.x; cr[2 * k + 1] = v.y; }
         ld_rec8(D.E, (size_t)D.cam_pos[i], e);
-        quat_to_R(D.poses + 7 * (size_t)c + 3, Rc);
-        const double yt0 = y[0] * sc[0], yt1 = y[1] * sc[1], yt2 = y[2] * sc[2], yw0 = y[3] * sc[3], yw1 = y[4] * sc[4], yw2 = y[5] * sc[5];
+      }
+      if (cr[15] != 0.0) {
+        // E^T y of the factored record (k_ba_eval): S_p R^T W (yt - r x yw), y~ = S_c y; the S_p factor is applied per point below
+        const double* Rc = cr;
+        const double yt0 = cr[9], yt1 = cr[10], yt2 = cr[11], yw0 = cr[12], yw1 = cr[13], yw2 = cr[14];
         const double r0 = e[5], r1 = e[6], r2 = e[7];
         const double d0 = yt0 - (r1 * yw2 - r2 * yw1), d1 = yt1 - (r2 * yw0 - r0 * yw2), d2 = yt2 - (r0 * yw1 - r1 * yw0);
         const double q0 = fma(e[2], d2, e[0] * d0), q1 = fma(e[3], d2, e[1] * d1), q2 = fma(e[4], d2, fma(e[3], d1, e[2] * d0));
