@@ -431,6 +431,19 @@ for seed, ncam, npts, nobs, fixed in ((21, 193, 3000, 16000, 1), (22, 216, 3000,
     poses, pts, s = optimizer.global_bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"],
                                                        g["obs_inv_sigma2"], n_iterations=4)
     out.append({"poses": poses.tobytes().hex(), "pts": pts.tobytes().hex(), "summary": s})
+# ... and the same sizes with a WIDE skyline (the first free keyframe also sees 150 far landmarks: a dense first column, every row's
+# envelope starts at 0): these stay on the two-level scheme - one persistent launch per 128-column outer block against its step kernels
+for seed, ncam, npts, nobs, fixed in ((21, 193, 3000, 16000, 1), (23, 301, 5000, 26000, 1)):
+    g = synth.make_ba_graph(seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=fixed)
+    rng = np.random.default_rng(seed); c0 = fixed; have = set(zip(g["obs_cam"].tolist(), g["obs_pt"].tolist()))
+    oc, op, uv, w = list(g["obs_cam"]), list(g["obs_pt"]), list(g["obs_uv"]), list(g["obs_inv_sigma2"])
+    for p in rng.choice(npts, 400, replace=False):
+        x, z = synth.project(g["K4"][0], g["poses_gt"][c0], g["pts_gt"][p][None])
+        if z[0] > 1.0 and (c0, int(p)) not in have and len(oc) < nobs + 150:
+            oc.append(c0); op.append(int(p)); uv.append(x[0] + rng.normal(0, 1.0, 2)); w.append(1.0)
+    poses, pts, s = optimizer.global_bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], np.array(oc, np.int32), np.array(op, np.int32), np.array(uv),
+                                                       np.array(w, np.float32), n_iterations=4)
+    out.append({"poses": poses.tobytes().hex(), "pts": pts.tobytes().hex(), "summary": s})
 # concurrent callers: more persistent factorisations than the device holds at once must fall back, not stall
 import threading
 g = synth.make_ba_graph(31, ncam=100, npts=2000, nobs=9000, n_fixed=2)
@@ -453,7 +466,9 @@ def test_persistent_cholesky_is_bit_identical():
     (k_chol_persist: chain workgroup + one workgroup per block row, flags in global memory) instead of one k_chol_la launch
     per 32-column step.  Its arithmetic is the step kernels' operation for operation, so poses, points, summaries and erase
     flags must be BIT-IDENTICAL between ORBHIP_BA_PERSIST=1 and =0 (read once per process: two subprocesses) - sizes from 1 to
-    32 block rows (42 .. 1020 unknowns), incl. one that is exactly the 1024 limit, and a two-pass LocalBA.  Larger systems
+    32 block rows (42 .. 1020 unknowns), incl. one that is exactly the 1024 limit, and a two-pass LocalBA.  Larger systems with a
+    NARROW skyline (36, 41, 57 block rows, band 3: round 5) take the same persistent kernel, walking only their envelope, against the
+    dense step kernels; larger systems with a WIDE skyline
     (two-level scheme): one persistent launch per 128-column outer block (k_chol_persist_blk, =1, the default) against the step
     kernels (the one-launch kernel k_chol_persist_2l is an ORBHIP_EXPERIMENTS build's =2: tools/gba_persist_ab.py).  Six threads solving at once: a solve that does
     not get its workgroup slots takes the step kernels - same bits, no stall."""
@@ -464,7 +479,7 @@ def test_persistent_cholesky_is_bit_identical():
         r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root], env=dict(os.environ, ORBHIP_BA_PERSIST=flag), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
-    assert len(res[0]) == 10
+    assert len(res[0]) == 12
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert a["summary"] == b["summary"]
