@@ -72,7 +72,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
     out = {}
     if quick:
         n_localba = 1; out["quick"] = True
-    roof = {"bound": "mfma", "kernel": "reduced camera system: Schur complement (k_ba_schur) + dense FP64-MFMA Cholesky (k_chol_*)",
+    roof = {"bound": "mfma", "kernel": "reduced camera system: Schur complement (k_ba_schur) + FP64-MFMA block Cholesky (k_chol_*), which skips the tiles outside the system's skyline",
             "definition": "(Schur GEMM flops + n^3/3) x LM iterations / solve time / FP64 matrix peak (SURVEY 8(d))",
             "peak_source": "AMD MI355X datasheet, FP64 matrix 78.6 TFLOP/s", "cases": {}}
     # ---- C4: LocalBundleAdjustment, 100 KF x 10k pts x 50k obs (all free except the gauge keyframe 0), reference two-pass
@@ -186,6 +186,11 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
     roof["cases"]["c5"] = _roof((f5_schur + f5_chol) * nit, dev_ms * 1e-3,
                                 "one 500-KF GlobalBA; device time of its %d LM iterations (HIP events on the solve stream)" % nit,
                                 flops_per_iteration=f5_schur + f5_chol, cholesky_n=6 * 499)
+    t5_in, t5_all, u5_in, u5_all = skyline_tiles(gg)
+    roof["cases"]["c5"]["cholesky"] = {
+        "form": "k_chol_persist walks the skyline (one persistent launch, two workgroups per block row); k_chol_bsolve_sky: the backward substitution in one launch",
+        "tiles_inside_envelope": t5_in, "lower_triangle_tiles": t5_all, "tile_updates_inside": u5_in, "dense_tile_updates": u5_all,
+        "note": "dense-equivalent rate (SURVEY 8(d)'s algorithmic flops / time), as for c4_batched: the time is the chain of 94 diagonal factors, not matrix-pipe work"}
     # ---- C5 as BASELINE config 5 words it, on ONE GPU: the eight 500-KF sub-maps as one lockstep batch (ba_solve_batch: what a node
     #      with fewer GPUs than sub-maps does).  A single GlobalBA is bound by the latency chain of its factorisation (c5 above);
     #      eight in lockstep share every launch of the chain.  (Eight host threads with one solve each: 464 ms against 379; 323 with the
