@@ -30,6 +30,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -708,8 +709,12 @@ class CeresOptimizerT {
     std::map<KeyFrame*, int> cam_of;                               // ided_keyframe_pose: non-bad keyframes
     std::vector<KeyFrame*> cams;
     std::vector<double> K4, poses7; std::vector<uint8_t> cam_fixed;
-    for (size_t i = 0; i < keyframes.size(); i++) {
-      KeyFrame* keyframe = keyframes[i];
+    // (cameras by keyframe id - Map::GetAllKeyFrames() hands over a std::set<KeyFrame*>'s pointer order, i.e. whatever the allocator did;
+    // by id an odometry-like map gives a banded reduced system, which the library factors at the cost of the band: see LocalBundleAdjustment)
+    std::vector<KeyFrame*> kf_by_id(keyframes);
+    std::stable_sort(kf_by_id.begin(), kf_by_id.end(), [](const KeyFrame* a, const KeyFrame* b) { return a->id_ < b->id_; });
+    for (size_t i = 0; i < kf_by_id.size(); i++) {
+      KeyFrame* keyframe = kf_by_id[i];
       if (keyframe->isBad()) continue;
       if (cam_of.count(keyframe)) continue;
       double p7[7];
@@ -813,7 +818,15 @@ class CeresOptimizerT {
       cam_local.push_back(local ? 1 : 0);
       cam_fixed.push_back((!local || kf->id_ == 0) ? 1 : 0);      // (":476-481", ":499-502")
     };
-    for (KeyFrame* kf : local_kfs) push_cam(kf, true);
+    // Camera ORDER (round 5).  The reference keeps the local keyframes in an unordered_map keyed by pointer (":348") and Ceres orders the
+    // parameter blocks itself, so there is no order to reproduce; the library factors the reduced system in the order given and skips
+    // the tiles outside its skyline (INTEGRATION.md "What the keyframe order means for the solver").  By keyframe id - the current
+    // keyframe, which shares landmarks with every other one, is the newest and comes LAST - a window along an odometry chain is a band
+    // with one dense block row; with the current keyframe first (rounds 1-4) the first block column was dense and so the whole envelope.
+    // Deterministic whatever the allocator does; the results are the same to rounding.
+    std::vector<KeyFrame*> by_id(local_kfs);
+    std::stable_sort(by_id.begin(), by_id.end(), [](const KeyFrame* a, const KeyFrame* b) { return a->id_ < b->id_; });
+    for (KeyFrame* kf : by_id) push_cam(kf, true);
     for (auto it = fixed_set.begin(); it != fixed_set.end(); ++it) push_cam(it->first, false);
     std::vector<MapPoint*> pts; std::vector<double> pts3, obs_uv; std::vector<float> obs_isg; std::vector<int32_t> obs_cam, obs_pt;
     std::vector<std::pair<KeyFrame*, MapPoint*>> obs_edge;
@@ -846,7 +859,7 @@ class CeresOptimizerT {
     std::unique_lock<std::mutex> lock(map->mutex_map_update_);     // (":573")
     for (size_t i = 0; i < obs_edge.size(); i++)
       if (erase[i]) { obs_edge[i].first->EraseMapPointMatch(obs_edge[i].second); obs_edge[i].second->EraseObservation(obs_edge[i].first); }
-    for (size_t c = 0; c < local_kfs.size(); c++) local_kfs[c]->SetPose(Matrix_7_1_ToMatrix4d(&poses7[7 * c]));          // (":584-590")
+    for (KeyFrame* kf : local_kfs) kf->SetPose(Matrix_7_1_ToMatrix4d(&poses7[7 * (size_t)cam_of[kf]]));          // (":584-590"; the calls in the collection order, the poses from the cameras' places)
     for (size_t p = 0; p < pts.size(); p++) {                      // (":592-598")
       Vector3d X;
       for (int k = 0; k < 3; k++) X[k] = pts3[3 * p + k];
