@@ -180,6 +180,7 @@ struct BaDev {            // device pointers of one problem
   int pt_in_eval;                    // 1: the 3x3 landmark blocks are summed by k_ba_eval<0> itself (every point has <= PT_MAXRUN observations), 0: by k_ba_cam_blocks' landmark workgroups
   int chol_la;                       // 1: this problem's reduced system is factored by the look-ahead family (npad <= 1024, or larger with a narrow skyline), 0: two-level blocking
   int band;                          // widest envelope of a tile row, in tiles (max over i of i - tile_first[i])
+  int persist_ring;                  // > 0: k_chol_persist's row workgroups walk the rows slot, slot + ring, ... (narrow skyline: 2 ring + 3 workgroups in all)
   int persist_nwg;                   // workgroups of k_chol_persist for this system (the chain, a producer and its consumers per block row, the rhs row's two)
   double huber;
   const volatile unsigned char* stop_dev;   // device-visible mirror of the caller's stop flag (pinned host byte of the calling thread)

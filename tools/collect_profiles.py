@@ -76,22 +76,23 @@ try:
     put(RND + "_api_latency.json", json.dumps(api, indent=1) + "\n")
 except Exception as e:
     skipped.append("api_latency: %s" % e)
-for src, dst, why in (("mfma_batch.json", "_mfma_localba_batch64.json", "FP64-MFMA counters (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) of 64 C4-size LocalBA problems per lockstep batch: k_chol_wg, one workgroup per problem (tools/run_mfma_pmc.sh; experiments build, ORBHIP_BA_GRAPH=0)"),
-                      ("mfma_single.json", "_mfma_localba_single.json", "the same counters over single C4-size LocalBA solves: the persistent, flag-linked k_chol_persist"),
-                      ("mfma_c5.json", "_mfma_gba_c5.json", "the same counters over one GlobalBA at C5 size (500 keyframes, 2994-unknown reduced system), 10 iterations: k_chol_persist_blk")):
+for src, dst, why in (("mfma_batch.json", "_mfma_localba_batch64.json", "FP64-MFMA counters (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) of 64 C4-size LocalBA problems per lockstep batch: k_chol_wg, one workgroup per problem, walking the skyline - the EXECUTED matrix flops (tools/run_mfma_pmc.sh; experiments build, ORBHIP_BA_GRAPH=0)"),
+                      ("mfma_single.json", "_mfma_localba_single.json", "the same counters over single C4-size LocalBA solves: the persistent, flag-linked k_chol_persist (skyline walk)"),
+                      ("mfma_c5.json", "_mfma_gba_c5.json", "the same counters over one GlobalBA at C5 size (500 keyframes, 2994-unknown reduced system, band 3), 10 iterations: k_chol_persist walking the skyline (round 5; k_chol_persist_blk before)")):
     path = os.path.join(O, src)
     try:
         j = json.load(open(path)); j = dict(workload=why, **j)
         put(RND + dst, json.dumps(j, indent=1) + "\n")
     except Exception as e:
         skipped.append("%s: %s" % (src, e))
-for txt in ("localba_throughput.txt", "track_latency.txt", "concurrency.txt", "mfma_f64_ubench.txt", "schur_phase_prof.txt"):
+for txt in ("localba_throughput.txt", "track_latency.txt", "concurrency.txt", "mfma_f64_ubench.txt", "schur_phase_prof.txt", "chol_wg_phase_prof.txt",
+            "localba_trace_overlap_12_callers.txt", "pt_fuse_ab.txt"):
     path = os.path.join(O, txt)
     if os.path.exists(path) and os.path.getsize(path) > 0:
         put(RND + "_" + txt, open(path).read())
     else:
         skipped.append(txt + ": missing or empty")
-for extra in ("fast_phase_prof.json", "chol_phase_prof.json", "octree_phase_prof.json", "gba_c5_mfma.json", "pcie_pipeline.json", "tracking_step.json"):
+for extra in ("ba_batch64_pmc.json", "fast_phase_prof.json", "chol_phase_prof.json", "octree_phase_prof.json", "gba_c5_mfma.json", "pcie_pipeline.json", "tracking_step.json"):
     path = os.path.join(O, extra)
     if os.path.exists(path):
         try:

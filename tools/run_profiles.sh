@@ -21,7 +21,18 @@ rm -rf $O/lbaprof
 rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/lbaprof -o run -- timeout 600 python tools/ba_batch_thr.py 64:1 > $O/lbaprof.log 2>&1 || tail -5 $O/lbaprof.log
 db=$(find $O/lbaprof -name "*.db" 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocpd_stats.py $db $O/localba_batch64_kernel_stats.csv && python tools/kstats_print.py $O/localba_batch64_kernel_stats.csv | head -14
-timeout 600 python tools/ba_batch_thr.py 64:12 64:8 16:8 > $O/localba_throughput.txt 2>&1; cat $O/localba_throughput.txt
+timeout 600 python tools/ba_batch_thr.py 64:12:8 64:8:8 64:12:2 16:8:8 64:1:4 > $O/localba_throughput.txt 2>&1; cat $O/localba_throughput.txt
+step 12 callers: kernel trace, concurrency
+rm -rf $O/lba12
+rocprofv3 --kernel-trace --output-format rocpd -d $O/lba12 -o run -- timeout 600 python tools/ba_batch_thr.py 64:12:6 > $O/lba12.log 2>&1 || tail -5 $O/lba12.log
+db=$(find $O/lba12 -name "*.db" 2>/dev/null | head -1)
+[ -n "$db" ] && { grep solves $O/lba12.log; python tools/trace_overlap.py $db 0.5 0.9; } > $O/localba_trace_overlap_12_callers.txt 2>&1; cat $O/localba_trace_overlap_12_callers.txt
+rm -rf $O/lba12
+step ba pmc
+timeout 900 bash tools/run_ba_pmc.sh $R 2>&1 | tail -18
+step pt fuse a/b
+timeout 600 python tools/pt_fuse_ab.py > $O/pt_fuse_ab.txt 2>&1; cat $O/pt_fuse_ab.txt
+[ -f tools/scratch/lib_prof/liborbslam_hip.so ] && { step chol_wg phase stamps; timeout 300 python tools/chol_wg_prof.py 2>/dev/null | grep -v amdgpu.ids > $O/chol_wg_phase_prof.txt; cat $O/chol_wg_phase_prof.txt; }
 [ -f tools/exp_lib/liborbslam_hip_sprof.so ] && { step schur phase stamps; timeout 300 python tools/schur_prof.py > $O/schur_phase_prof.txt 2>&1; cat $O/schur_phase_prof.txt; }
 step gba c5 trace
 rm -rf $O/gbaprof
