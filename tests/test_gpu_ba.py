@@ -238,6 +238,11 @@ def test_batched_solves_equal_single_solves():
     for pr, (poses, pts, s) in zip(probs, res):
         p1, x1, s1 = optimizer.bundle_adjustment(*pr, n_iterations=12)
         assert s == s1 and np.array_equal(poses, p1) and np.array_equal(pts, x1)
+    # (round 5: up to 16 problems per call take the persistent launch, 17 .. 31 the step kernels k_chol_la<4>, from 32 on k_chol_wg:
+    # the same nine problems as a batch of 20 - the middle form - must give the same bits again)
+    res20 = optimizer.bundle_adjustment_batch(probs + probs + probs[:2], n_iterations=12)
+    for q, (poses, pts, s) in enumerate(res20):
+        assert s == res[q % 9][2] and np.array_equal(poses, res[q % 9][0]) and np.array_equal(pts, res[q % 9][1]), q
     lprobs = [(g["K4"], g["poses0"], g["cam_fixed"], np.ones(len(g["cam_fixed"]), np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"],
                g["obs_inv_sigma2"]) for g in gs]
     ab, lres = optimizer.local_bundle_adjustment_batch(lprobs)
