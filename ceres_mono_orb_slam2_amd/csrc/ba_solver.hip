@@ -179,7 +179,9 @@ struct BaDev {            // device pointers of one problem
   const unsigned char* cam_local; unsigned char* erase;   // LocalBA classification (k_ba_classify): local flags [ncam], result [nobs] (device order)
   int pt_in_eval;                    // 1: the 3x3 landmark blocks are summed by k_ba_eval<0> itself (every point has <= PT_MAXRUN observations), 0: by k_ba_cam_blocks' landmark workgroups
   int chol_la;                       // 1: this problem's reduced system is factored by the look-ahead family (npad <= 1024, or larger with a narrow skyline), 0: two-level blocking
+  int wg_rows;                       // most active rows (+ the rhs row) any column has: k_chol_wg's list holds NB + 2
   int band;                          // widest envelope of a tile row, in tiles (max over i of i - tile_first[i])
+  int persist_ring_rows;             // first row that is NOT walked by the ring (rows from here on keep a workgroup set each: the wide envelopes of a loop-closed map)
   int persist_ring;                  // > 0: k_chol_persist's row workgroups walk the rows slot, slot + ring, ... (narrow skyline: 2 ring + 3 workgroups in all)
   int persist_nwg;                   // workgroups of k_chol_persist for this system (the chain, a producer and its consumers per block row, the rhs row's two)
   double huber;

@@ -296,6 +296,54 @@ def _with_long_range_links(g, seed, kind):
     return g
 
 
+def _loop_closed(seed, ncam, npts, nobs, n_far=150, n_end=4):
+    """An odometry chain whose LAST keyframes also see landmarks of the FIRST ones - what a map looks like after a loop closure: far
+    landmarks ahead of the whole track (positive depth for every keyframe) observed by the first n_end free and the last n_end keyframes.
+    The reduced system keeps its band and gets dense last block rows."""
+    g = synth.make_ba_graph(seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=1, max_depth=30.0, min_len=3)      # (the well-conditioned variant: the bars below are the ordinary ones)
+    rng = np.random.default_rng(seed + 7)
+    X = np.stack([rng.uniform(-20, 20, n_far), rng.uniform(-4, 4, n_far), 0.8 * ncam + rng.uniform(30, 80, n_far)], 1)
+    cams = list(range(1, 1 + n_end)) + list(range(ncam - n_end, ncam))
+    oc, op, uv = [], [], []
+    for k in range(n_far):
+        for c in cams:
+            x, z = synth.project(g["K4"][0], g["poses_gt"][c], X[k][None])
+            oc.append(c); op.append(npts + k); uv.append(x[0] + rng.normal(0, 1.0, 2))
+    g = dict(g)
+    g["pts0"] = np.vstack([g["pts0"], X * (1 + rng.normal(0, 0.01, (n_far, 1)))])
+    g["obs_cam"] = np.concatenate([g["obs_cam"], np.array(oc, np.int32)]); g["obs_pt"] = np.concatenate([g["obs_pt"], np.array(op, np.int32)])
+    g["obs_uv"] = np.vstack([g["obs_uv"], np.array(uv)]); g["obs_inv_sigma2"] = np.concatenate([g["obs_inv_sigma2"], np.ones(len(oc), g["obs_inv_sigma2"].dtype)])
+    return g
+
+
+def test_loop_closed_map_vs_oracle_and_across_batch_forms(oracle):
+    """A 230-keyframe chain with a loop closure (43 block rows: more than 32, a band of 3 and four dense last rows).  Its reduced system
+    belongs to the look-ahead family (round 5): alone it is ONE persistent launch - the ring over the narrow rows, a workgroup set for
+    each wide one -, four of them per call likewise, 36 per call one workgroup each (k_chol_wg).  Against the oracle at the usual bars,
+    and bit-identical across the three call forms."""
+    from ceres_mono_orb_slam2_amd import optimizer
+    g = _loop_closed(91, 230, 3000, 14000)
+    n = len(g["obs_cam"]); w = g["obs_inv_sigma2"].astype(np.float64); rb = np.ones(n, np.uint8)
+    a = (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], w, rb)
+    # ONE iteration at the ordinary bars: the linear algebra of the step (7e-13 on the cost); the far landmarks - 200 m from the keyframes
+    # that close the loop - make the iterates of later iterations sensitive to the last bit in BOTH factorisation families and in the
+    # oracle alike (measured: 9e-10, 7e-10, 5e-9 on the cost after 2, 3, 4 iterations; the two-level scheme 4e-10, 3e-10, 2e-9), so the
+    # four-iteration run is compared across the call forms, bit for bit, not with the oracle
+    p1, x1, s1 = optimizer.bundle_adjustment(*a, 1)
+    oposes, opts, os_ = oracle.ba_solve(*a, 1)
+    assert (s1["iterations"], s1["successful_steps"], s1["termination"]) == (os_["iterations"], os_["successful_steps"], os_["termination"])
+    assert abs(s1["final_cost"] - os_["final_cost"]) <= RTOL_COST * os_["final_cost"]
+    assert _close(p1, oposes, RTOL_X) and _close_pts(x1, opts)
+    poses, pts, s = optimizer.bundle_adjustment(*a, 4)
+    assert s["iterations"] == 4 and s["final_cost"] < 0.5 * s["initial_cost"]
+    small = synth.make_ba_graph(92, ncam=20, npts=300, nobs=1400, n_fixed=1)
+    b = (small["K4"], small["poses0"], small["cam_fixed"], small["pts0"], small["obs_cam"], small["obs_pt"], small["obs_uv"], small["obs_inv_sigma2"].astype(np.float64),
+         np.ones(len(small["obs_cam"]), np.uint8))
+    for batch in ([a, b, a, b], [a] + [b] * 35):
+        res = optimizer.bundle_adjustment_batch(batch, n_iterations=4)
+        assert res[0][2] == s and np.array_equal(res[0][0], poses) and np.array_equal(res[0][1], pts), len(batch)
+
+
 def test_lockstep_batch_of_36_workgroup_cholesky_equals_single_solves():
     """Batches of >= 32 problems factor every reduced system in ONE workgroup (k_chol_wg), which walks only the tiles inside the
     system's SKYLINE (csrc/ba_host.inc tile_first): 36 problems of 2 .. 19 block rows whose envelopes are banded (consecutive-view
@@ -449,6 +497,19 @@ for seed, ncam, npts, nobs, fixed in ((21, 193, 3000, 16000, 1), (23, 301, 5000,
     poses, pts, s = optimizer.global_bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], np.array(oc, np.int32), np.array(op, np.int32), np.array(uv),
                                                        np.array(w, np.float32), n_iterations=4)
     out.append({"poses": poses.tobytes().hex(), "pts": pts.tobytes().hex(), "summary": s})
+# ... and a loop-closed chain (230 keyframes: 43 block rows, a band of 3 and dense last rows): the ring over the narrow rows + a workgroup
+# set per wide row against the step kernels
+g = synth.make_ba_graph(91, ncam=230, npts=3000, nobs=14000, n_fixed=1)
+rng = np.random.default_rng(98); nf = 150
+X = np.stack([rng.uniform(-20, 20, nf), rng.uniform(-4, 4, nf), 0.8 * 230 + rng.uniform(30, 80, nf)], 1)
+oc, op, uv = list(g["obs_cam"]), list(g["obs_pt"]), list(g["obs_uv"])
+for k in range(nf):
+    for c in (1, 2, 3, 4, 226, 227, 228, 229):
+        x, z = synth.project(g["K4"][0], g["poses_gt"][c], X[k][None])
+        oc.append(c); op.append(3000 + k); uv.append(x[0] + rng.normal(0, 1.0, 2))
+poses, pts, s = optimizer.global_bundle_adjustment(g["K4"], g["poses0"], g["cam_fixed"], np.vstack([g["pts0"], X * 1.01]), np.array(oc, np.int32), np.array(op, np.int32), np.array(uv),
+                                                   np.concatenate([g["obs_inv_sigma2"], np.ones(8 * nf, np.float32)]), n_iterations=4)
+out.append({"poses": poses.tobytes().hex(), "pts": pts.tobytes().hex(), "summary": s})
 # concurrent callers: more persistent factorisations than the device holds at once must fall back, not stall
 import threading
 g = synth.make_ba_graph(31, ncam=100, npts=2000, nobs=9000, n_fixed=2)
@@ -484,7 +545,7 @@ def test_persistent_cholesky_is_bit_identical():
         r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root], env=dict(os.environ, ORBHIP_BA_PERSIST=flag), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
-    assert len(res[0]) == 12
+    assert len(res[0]) == 13
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert a["summary"] == b["summary"]
