@@ -447,13 +447,17 @@ __device__ __forceinline__ void ba_pt_blocks_body(const BaDev& D, int bx) {
 
 // ---- start of an evaluation: x_cost, Jacobi scaling (first time), gradient max-norm, |x| ----------
 #define AE_TPB 1024     // one workgroup per problem walks every camera and point: 16 waves keep more loads in flight (29 -> ~10 us)
+__device__ __forceinline__ void ba_iter_begin_body(const BaDev& D);
+// (round 5) ... and the BEGINNING of the next iteration (k_ba_iter_begin's body: flag reset, stop flag, iteration cap, minimum radius):
+// the two were back-to-back one-workgroup launches on every solve's dependent chain.
 __global__ __launch_bounds__(AE_TPB) void k_ba_after_eval(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[16 * 3], s_out[3];
   BaState* st = D.st;
   const StFlags F = ld_flags(st);
-  if (F.done || !F.need_eval) return;
+  if (F.done) return;
   const int tid = threadIdx.x;
+  if (F.need_eval) {
   if (st->first) {
     for (int j = tid; j < 6 * D.nfc; j += AE_TPB) D.scale_c[j] = 1.0 / (1.0 + sqrt(D.B[21 * (size_t)(j / 6) + sym6(j % 6, j % 6)]));
     if (!D.fix_points) {
@@ -499,18 +503,18 @@ __global__ __launch_bounds__(AE_TPB) void k_ba_after_eval(const BaDev* __restric
     st->e_dirty = 1;
     if (st->gmax <= 1e-10) { st->termination = 1; st->done = 1; }
   }
+  }                                                             // need_eval
+  ba_iter_begin_body(D);
 }
 
 // ---- iteration begin: iteration cap / minimum radius ------------------------------------------------
-__global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
-  const BaDev D = Dv[blockIdx.y];
+__device__ __forceinline__ void ba_iter_begin_body(const BaDev& D) {
   BaState* st = D.st;
-  const StFlags F = ld_flags(st);
   const int iteration = st->iteration, max_iters = st->max_iters;      // (all reads first: one round trip)
   const double radius = st->radius;
-  if (F.done) return;
-  if (D.cflags) for (int i = threadIdx.x; i < D.ncflags; i += blockDim.x) D.cflags[i] = 0;      // (any block size; the rest is thread 0's)
+  if (D.cflags) for (int i = threadIdx.x; i < D.ncflags; i += blockDim.x) D.cflags[i] = 0;      // (any block size; the rest is thread 0's; harmless when the solve has just ended)
   if (threadIdx.x != 0) return;
+  if (st->done) return;                                         // (thread 0's own write when the evaluation above has just ended the solve)
   st->valid = 0; st->accepted = 0; st->chol_fail = 0; st->e_dirty = 0;
   // StopFlagCallback (include/CeresOptimizer.h:332-349) runs after every iteration, before the iteration-cap test: the
   // host keeps copying the caller's flag into this pinned byte while the enqueued iterations drain
@@ -519,6 +523,11 @@ __global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {
   if (radius <= 1e-32) { st->termination = 6; st->done = 1; return; }
   st->iteration = iteration + 1;
   st->valid = 1;          // provisional; cleared by a failed factorisation / non-positive model change
+}
+__global__ void k_ba_iter_begin(const BaDev* __restrict__ Dv) {      // (the pose-graph solver's launch; bundle adjustment: inside k_ba_after_eval)
+  const BaDev D = Dv[blockIdx.y];
+  if (ld_flags(D.st).done) return;
+  ba_iter_begin_body(D);
 }
 
 // ---- per point: (C_s + D)^-1, scaled gradient, E and E (C_s+D)^-1 per observation -----------------
@@ -1172,10 +1181,12 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_classify(const BaDev* __restrict_
   D.erase[i] = e;
 }
 
-__global__ void k_ba_user_stop(const BaDev* __restrict__ Dv) {
+// launched: the iterations the host has enqueued - the beginning of the NEXT one is the tail of an iteration's last kernel (k_ba_after_eval),
+// so a solve stopped by the host may have begun an iteration that never ran: it does not count
+__global__ void k_ba_user_stop(const BaDev* __restrict__ Dv, int launched) {
   const BaDev D = Dv[blockIdx.y];
   BaState* st = D.st;
-  if (!st->done) { st->termination = 4; st->done = 1; }
+  if (!st->done) { if (st->iteration > launched) st->iteration = launched; st->termination = 4; st->done = 1; }
 }
 
 
