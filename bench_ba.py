@@ -73,7 +73,9 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
     if quick:
         n_localba = 1; out["quick"] = True
     roof = {"bound": "mfma", "kernel": "reduced camera system: Schur complement (k_ba_schur) + FP64-MFMA block Cholesky (k_chol_*), which skips the tiles outside the system's skyline",
-            "definition": "(Schur GEMM flops + n^3/3) x LM iterations / solve time / FP64 matrix peak (SURVEY 8(d))",
+            "definition": "(Schur GEMM flops + n^3/3) x LM iterations / solve time / FP64 matrix peak (SURVEY 8(d)): `frac`; the factorisation skips the tiles "
+                          "outside the reduced system's skyline (exact zeros), so `frac` is a DENSE-EQUIVALENT rate and `frac_executed` prices only the flops that run "
+                          "(Schur GEMMs + 2 x 32^3 per tile update / tile solve inside the envelope)",
             "peak_source": "AMD MI355X datasheet, FP64 matrix 78.6 TFLOP/s", "cases": {}}
     # ---- C4: LocalBundleAdjustment, 100 KF x 10k pts x 50k obs (all free except the gauge keyframe 0), reference two-pass
     #      schedule (5 + 10 iterations)
@@ -136,6 +138,8 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
                                         "%d distinct local maps per lockstep batch x %d host threads; wall time of %d solves (copies and host structure setup included)"
                                         % (nbatch, nthreads, nbatch * nthreads * n_each), lm_iterations_per_solve=mean_it)
     t_in, t_all, u_in, u_all = skyline_tiles(g)
+    exe4 = (f_schur + 65536.0 * (t_in + u_in)) / (f_schur + f_chol)      # executed / algorithmic flops: a tile update or a tile times X is 2 x 32^3 flops
+    roof["cases"]["c4_batched"]["frac_executed"] = roof["cases"]["c4_batched"]["frac"] * exe4
     roof["cases"]["c4_batched"]["cholesky"] = {
         "form": "k_chol_wg walks the skyline of the reduced system (tiles outside the envelope are exact zeros: skipped, bit-identical to the dense walk)",
         "tiles_inside_envelope": t_in, "lower_triangle_tiles": t_all, "tile_updates_inside": u_in, "dense_tile_updates": u_all,
@@ -187,6 +191,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
                                 "one 500-KF GlobalBA; device time of its %d LM iterations (HIP events on the solve stream)" % nit,
                                 flops_per_iteration=f5_schur + f5_chol, cholesky_n=6 * 499)
     t5_in, t5_all, u5_in, u5_all = skyline_tiles(gg)
+    roof["cases"]["c5"]["frac_executed"] = roof["cases"]["c5"]["frac"] * (f5_schur + 65536.0 * (t5_in + u5_in)) / (f5_schur + f5_chol)
     roof["cases"]["c5"]["cholesky"] = {
         "form": "k_chol_persist walks the skyline (one persistent launch, two workgroups per block row); k_chol_bsolve_sky: the backward substitution in one launch",
         "tiles_inside_envelope": t5_in, "lower_triangle_tiles": t5_all, "tile_updates_inside": u5_in, "dense_tile_updates": u5_all,
@@ -276,6 +281,7 @@ def main(argv=None):
     res = run(torch.device("cuda", a.device), cpu=bool(a.cpu), rank=a.rank, quick=bool(a.quick))
     pts = res.pop("_final_points")
     res["process"] = {"own_process": True, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+    os.makedirs(a.out, exist_ok=True)
     np.save(os.path.join(a.out, "final_points.npy"), pts)
     with open(os.path.join(a.out, "result.json"), "w") as f:
         json.dump(res, f)
