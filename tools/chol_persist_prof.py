@@ -1,19 +1,12 @@
 """Phase timing of the chain workgroup of the persistent Cholesky inside real solves - C4-size LocalBA (k_chol_persist, default) or,
-with the argument `c5`, a 500-keyframe GlobalBA (k_chol_persist_blk: one launch per 128-column outer block): builds ba_solver.hip
-with -DORBHIP_CHOL_PROF into a scratch library and prints the mean time wave 0 of the chain spends in each phase of a step
+with the argument `c5`, a 500-keyframe GlobalBA (since round 5 also k_chol_persist, walking the skyline; before: k_chol_persist_blk, one
+launch per 128-column outer block): loads the scratch library built with -DORBHIP_CHOL_PROF and prints the mean time wave 0 of the chain spends in each phase of a step
 (100 MHz s_memrealtime ticks -> ns)."""
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-out = os.path.join(ROOT, "gpurun_out", "cholprof"); os.makedirs(out, exist_ok=True)
-so = os.path.join(out, "liborbslam_hip_persist.so")
-csrc = os.path.join(ROOT, "ceres_mono_orb_slam2_amd", "csrc")
-srcs = [os.path.join(csrc, f) for f in ("ba_solver.hip", "capi_common.hip", "orb_extractor.hip", "orb_matcher.hip", "orb_frame.hip", "orb_vocab.hip", "orb_track.hip")]
-if not os.path.exists(so) or os.environ.get("REBUILD"):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-                           "-DORBHIP_CHOL_PROF", "-I", os.path.join(ROOT, "include"), "-shared", "-o", so] + srcs)
-if "--build-only" in sys.argv: sys.exit(0)
+so = os.path.join(ROOT, "tools", "scratch", "lib_prof", "liborbslam_hip.so")      # bash tools/scratch/exp_build.sh prof -DORBHIP_CHOL_PROF (as tools/chol_wg_prof.py)
 from ceres_mono_orb_slam2_amd import _lib, optimizer, synth
 _lib.LIB_PATH = so
 L = _lib.load()
@@ -40,5 +33,6 @@ for i, n in enumerate(names):
     res["ns_per_phase_mean"][n] = float(np.mean([a[k, i] / a[k, 9] for k in steps]) * 10.0)
     res["per_step_ns"][n] = [round(float(a[k, i] / a[k, 9] * 10.0)) for k in steps]
 res["mean_step_ns"] = float(sum(res["ns_per_phase_mean"].values()))
-print(json.dumps(res, indent=1))
+print(json.dumps({k: v for k, v in res.items() if k != "per_step_ns"}, indent=1))
+out = os.path.join(ROOT, "gpurun_out", "cholprof"); os.makedirs(out, exist_ok=True)
 json.dump(res, open(os.path.join(out, "chol_persist_prof_c5.json" if c5 else "chol_persist_prof.json"), "w"), indent=1)
