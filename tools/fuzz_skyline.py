@@ -2,7 +2,8 @@
 inside a lockstep batch of >= 32 (k_chol_wg, walking its skyline) and - a second process with ORBHIP_BA_PERSIST=0 ORBHIP_BA_WG=0 - through the
 dense step kernels: poses, points and summaries must be BIT-IDENTICAL.  Graphs: 6 .. 210 keyframes (2 .. 39 block rows: both sides of
 the 32-row limit), consecutive-view tracks plus random far links (a dense last row, a dense first column, ragged links, several at once),
-one or two fixed keyframes, keyframes without observations.  usage: python tools/fuzz_skyline.py [first_seed=0] [batches=4]"""
+one or two fixed keyframes, keyframes without observations, loop closures (far landmarks seen by the first and the last keyframes: a narrow
+prefix of block rows under dense last ones - the ring + workgroup-set form of k_chol_persist), up to 300 keyframes (56 block rows).  usage: python tools/fuzz_skyline.py [first_seed=0] [batches=4]"""
 import hashlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -12,7 +13,7 @@ from ceres_mono_orb_slam2_amd import optimizer, synth
 first, nbatch = int(sys.argv[2]), int(sys.argv[3])
 def graph(seed):
     rng = np.random.default_rng(seed)
-    ncam = int(rng.choice([6, 11, 17, 24, 40, 64, 90, 120, 160, 175, 210]))
+    ncam = int(rng.choice([6, 11, 17, 24, 40, 64, 90, 120, 160, 175, 210, 260, 300]))
     npts = int(ncam * rng.integers(8, 20)); nobs = int(npts * rng.uniform(3.0, 6.0))
     g = synth.make_ba_graph(seed, ncam=ncam, npts=npts, nobs=nobs, n_fixed=int(rng.integers(1, 3)))
     oc, op, uv, w = list(g["obs_cam"]), list(g["obs_pt"]), list(g["obs_uv"]), list(g["obs_inv_sigma2"])
@@ -30,11 +31,20 @@ def graph(seed):
             x, z = synth.project(g["K4"][0], g["poses_gt"][c], g["pts_gt"][p][None])
             if z[0] < 1.0: continue
             have.add((c, p)); oc.append(c); op.append(p); uv.append(x[0] + rng.normal(0, 1.0, 2)); w.append(1.0)
+    pts0 = g["pts0"]
+    if rng.random() < 0.35:                                     # a loop closure: far landmarks seen by the first free and the last keyframes (dense LAST block rows)
+        nf, ne = int(rng.integers(20, 120)), int(rng.integers(1, 7))
+        X = np.stack([rng.uniform(-20, 20, nf), rng.uniform(-4, 4, nf), 0.8 * ncam + rng.uniform(30, 80, nf)], 1)
+        for k in range(nf):
+            for c in list(free[:ne]) + list(range(ncam - ne, ncam)):
+                x, z = synth.project(g["K4"][0], g["poses_gt"][int(c)], X[k][None])
+                oc.append(int(c)); op.append(npts + k); uv.append(x[0] + rng.normal(0, 1.0, 2)); w.append(1.0)
+        pts0 = np.vstack([pts0, X * 1.01])
     oc = np.array(oc, np.int32); op = np.array(op, np.int32); uv = np.array(uv); w = np.array(w, np.float64)
     if rng.random() < 0.3:                                      # a keyframe that loses all its observations (not in the reduced system)
         drop = int(rng.integers(1, ncam)); m = oc != drop
         oc, op, uv, w = oc[m], op[m], uv[m], w[m]
-    return (g["K4"], g["poses0"], g["cam_fixed"], g["pts0"], oc, op, uv, w, np.ones(len(oc), np.uint8))
+    return (g["K4"], g["poses0"], g["cam_fixed"], pts0, oc, op, uv, w, np.ones(len(oc), np.uint8))
 out = {}
 for b in range(nbatch):
     probs = [graph(first + 36 * b + k) for k in range(36)]
