@@ -163,6 +163,7 @@ struct BaDev {            // device pointers of one problem
   double* Cinv; double* gps; double* E;   // Cinv[npts][6], gps[npts][3], E[nobs] factored 64-byte records in camera-major order (ld_rec8), written by k_ba_eval
   double* Ng;                        // [npts][9] {N = S_p (C_s+D)^-1 S_p (6, symmetric), g_p (3)}: what k_ba_schur needs of a point, one gather
   double* t3;                        // [nobs][3] E_i^T y_cam of the landmark back-substitution
+  double* ae_part; unsigned int* ae_ticket;      // k_ba_after_eval: [AE_NS][4] slice results {cost (slice 0), |x|^2, gradient max-norm} and the arrival counter of its workgroups
   double* camrec;                    // [ncam][16] what k_ba_backsub needs of a camera in ONE 128-byte line: {R (9), S_c y (6), 1 = free camera with a valid step | 0} (k_ba_cam_update)
   double* S; double* rhs;            // reduced system S[npad+1][npad] (lower; row npad = rhs^T), rhs/yc [npad]
   double* Dinv;                      // inverse of every 32x32 diagonal Cholesky block [npad/32][32][32]
@@ -446,64 +447,102 @@ __device__ __forceinline__ void ba_pt_blocks_body(const BaDev& D, int bx) {
 }
 
 // ---- start of an evaluation: x_cost, Jacobi scaling (first time), gradient max-norm, |x| ----------
-#define AE_TPB 1024     // one workgroup per problem walks every camera and point: 16 waves keep more loads in flight (29 -> ~10 us)
+#define AE_TPB 1024
+#define AE_NS 8         // workgroups per problem: one 1024-thread workgroup walking every camera and landmark was bound by ONE CU's bandwidth (38 us at C5 size)
 __device__ __forceinline__ void ba_iter_begin_body(const BaDev& D);
-// (round 5) ... and the BEGINNING of the next iteration (k_ba_iter_begin's body: flag reset, stop flag, iteration cap, minimum radius):
-// the two were back-to-back one-workgroup launches on every solve's dependent chain.
+// AE_NS workgroups per problem take a slice of the cameras and landmarks each (slice s: indices tid + 1024 s, + 1024 AE_NS, ...); the LAST
+// one to arrive (a ticket per problem) adds the slices' |x|^2 in slice order - the same partition whatever the batch, so a problem's bits do
+// not depend on how it is called -, takes the maximum of the gradient norms and the cost that slice 0 summed exactly as the one-workgroup
+// kernel did, and then does the BEGINNING of the next iteration (k_ba_iter_begin's body: flag reset, stop flag, iteration cap, minimum
+// radius: the two were back-to-back one-workgroup launches on every solve's dependent chain).
+// (gridDim.x == 1 - lockstep batches of >= 8 problems, which fill the device by themselves: ONE workgroup walks the AE_NS slices one after
+// the other - the same slices, the same per-slice sums, the same order of adding them: the same bits)
 __global__ __launch_bounds__(AE_TPB) void k_ba_after_eval(const BaDev* __restrict__ Dv) {
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[16 * 3], s_out[3];
+  __shared__ double s_max[16];
+  __shared__ int s_last;
   BaState* st = D.st;
   const StFlags F = ld_flags(st);
   if (F.done) return;
-  const int tid = threadIdx.x;
-  if (F.need_eval) {
-  if (st->first) {
-    for (int j = tid; j < 6 * D.nfc; j += AE_TPB) D.scale_c[j] = 1.0 / (1.0 + sqrt(D.B[21 * (size_t)(j / 6) + sym6(j % 6, j % 6)]));
-    if (!D.fix_points) {
-      const int dg[3] = {0, 3, 5};
-      for (int j = tid; j < 3 * D.npts; j += AE_TPB) D.scale_p[j] = 1.0 / (1.0 + sqrt(D.C[6 * (size_t)(j / 3) + dg[j % 3]]));
+  const int tid = threadIdx.x, stride = AE_TPB * AE_NS;
+  const bool solo = gridDim.x == 1;
+  if (!F.need_eval) { if (blockIdx.x == 0) ba_iter_begin_body(D); return; }      // (a rejected step: nothing to evaluate, the next iteration still begins)
+  const bool first = st->first != 0;
+  double cost = 0.0, x2 = 0.0, gm_all = 0.0;                   // thread 0 of a solo workgroup: the slices' results as they come
+  for (int sl = solo ? 0 : (int)blockIdx.x; sl < (solo ? AE_NS : (int)blockIdx.x + 1); sl++) {
+    if (first) {
+      for (int j = tid + AE_TPB * sl; j < 6 * D.nfc; j += stride) D.scale_c[j] = 1.0 / (1.0 + sqrt(D.B[21 * (size_t)(j / 6) + sym6(j % 6, j % 6)]));
+      if (!D.fix_points) {
+        const int dg[3] = {0, 3, 5};
+        for (int j = tid + AE_TPB * sl; j < 3 * D.npts; j += stride) D.scale_p[j] = 1.0 / (1.0 + sqrt(D.C[6 * (size_t)(j / 3) + dg[j % 3]]));
+      }
+    }
+    double acc[3] = {0.0, 0.0, 0.0};                  // cost (slice 0), |x|^2 of the slice, (unused)
+    if (sl == 0) for (int b = tid; b < D.nparts; b += AE_TPB) acc[0] += D.part[b];
+    double gmax = 0.0;
+    for (int c = tid + AE_TPB * sl; c < D.ncam; c += stride) {
+      const int cc = D.cam_col[c];
+      if (cc < 0) continue;
+      const double* x = D.poses + 7 * c;
+      const double* g = D.gc + 6 * (size_t)cc;
+      for (int k = 0; k < 7; k++) acc[1] += x[k] * x[k];
+      for (int k = 0; k < 3; k++) gmax = fmax(gmax, fabs(g[k]));
+      double d[3] = {-g[3], -g[4], -g[5]}, qn[4];
+      quat_plus(x + 3, d, qn);
+      for (int k = 0; k < 4; k++) gmax = fmax(gmax, fabs(x[3 + k] - qn[k]));
+    }
+    if (!D.fix_points)
+      for (int p = tid + AE_TPB * sl; p < D.npts; p += stride) {
+        if (D.pt_off[p + 1] == D.pt_off[p]) continue;       // unused point: not in the reduced program
+        for (int k = 0; k < 3; k++) { double v = D.pts[3 * (size_t)p + k]; acc[1] += v * v; gmax = fmax(gmax, fabs(D.gp[3 * (size_t)p + k])); }
+      }
+    acc[2] = 0.0;
+    // max-reduce gmax through the sum tree by bit tricks is not possible: do a separate max tree
+    double m = gmax;
+    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) s_max[tid >> 6] = m;
+    block_reduce_wide<3>(acc, s_red, s_out);
+    if (tid == 0) {
+      double gm = 0.0;
+      for (int i = 0; i < AE_TPB / 64; i++) gm = fmax(gm, s_max[i]);
+      if (solo) { if (sl == 0) cost = s_out[0]; x2 += s_out[1]; gm_all = fmax(gm_all, gm); }
+      else {
+        double* mine = D.ae_part + 4 * sl;
+        __hip_atomic_store(mine + 0, s_out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, s_out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 2, gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();                                          // (s_max, s_red, s_out are free for the next slice)
+  }
+  if (!solo) {
+    if (tid == 0) {
+      __threadfence();
+      s_last = (__hip_atomic_fetch_add(D.ae_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == AE_NS - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+      __threadfence();
+      cost = __hip_atomic_load(D.ae_part + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int q = 0; q < AE_NS; q++) {
+        x2 += __hip_atomic_load(D.ae_part + 4 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gm_all = fmax(gm_all, __hip_atomic_load(D.ae_part + 4 * q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+      __hip_atomic_store(D.ae_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  double acc[3] = {0.0, 0.0, 0.0};                  // cost, |x|^2, (unused)
-  for (int b = tid; b < D.nparts; b += AE_TPB) acc[0] += D.part[b];
-  double gmax = 0.0;
-  for (int c = tid; c < D.ncam; c += AE_TPB) {
-    const int cc = D.cam_col[c];
-    if (cc < 0) continue;
-    const double* x = D.poses + 7 * c;
-    const double* g = D.gc + 6 * (size_t)cc;
-    for (int k = 0; k < 7; k++) acc[1] += x[k] * x[k];
-    for (int k = 0; k < 3; k++) gmax = fmax(gmax, fabs(g[k]));
-    double d[3] = {-g[3], -g[4], -g[5]}, qn[4];
-    quat_plus(x + 3, d, qn);
-    for (int k = 0; k < 4; k++) gmax = fmax(gmax, fabs(x[3 + k] - qn[k]));
-  }
-  if (!D.fix_points)
-    for (int p = tid; p < D.npts; p += AE_TPB) {
-      if (D.pt_off[p + 1] == D.pt_off[p]) continue;       // unused point: not in the reduced program
-      for (int k = 0; k < 3; k++) { double v = D.pts[3 * (size_t)p + k]; acc[1] += v * v; gmax = fmax(gmax, fabs(D.gp[3 * (size_t)p + k])); }
-    }
-  acc[2] = 0.0;
-  // max-reduce gmax through the sum tree by bit tricks is not possible: do a separate max tree
-  __shared__ double s_max[16];
-  double m = gmax;
-  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((tid & 63) == 0) s_max[tid >> 6] = m;
-  block_reduce_wide<3>(acc, s_red, s_out);
   if (tid == 0) {
-    st->x_cost = s_out[0];
-    st->x_norm = sqrt(s_out[1]);
-    double gm = 0.0;
-    for (int i = 0; i < AE_TPB / 64; i++) gm = fmax(gm, s_max[i]);
-    st->gmax = gm;
-    if (st->first) st->initial_cost = s_out[0];
+    st->x_cost = cost;
+    st->x_norm = sqrt(x2);
+    st->gmax = gm_all;
+    if (first) st->initial_cost = cost;
     st->first = 0;
     st->need_eval = 0;
     st->e_dirty = 1;
     if (st->gmax <= 1e-10) { st->termination = 1; st->done = 1; }
   }
-  }                                                             // need_eval
   ba_iter_begin_body(D);
 }
 
