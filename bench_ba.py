@@ -65,7 +65,7 @@ def _ncores():
         return os.cpu_count() or 1
 
 
-def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
+def run(dev, cpu=True, n_localba=12, n_pose_batch=256, rank=0, quick=False):
     """quick: a shortened leg for tests of the N > 1 plumbing (one single solve, a small lockstep batch, ten GlobalBA iterations, no
     eight-sub-map batch) - its figures are not benchmark numbers and the record says so."""
     import torch
@@ -83,7 +83,8 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
     local = np.ones(100, np.uint8)
     args = (g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
     f_schur, f_chol = reduced_solve_flops(g)
-    optimizer.local_bundle_adjustment(*args)                       # warm-up (module load, allocator)
+    for _ in range(1 if quick else 3):
+        optimizer.local_bundle_adjustment(*args)                   # warm-up (module load, allocator, pinned staging: the first calls on a fresh box run 1 - 2 ms long)
     torch.cuda.synchronize()
     optimizer.set_profiling(True); optimizer.get_profile()
     t0 = time.perf_counter()
@@ -193,7 +194,7 @@ def run(dev, cpu=True, n_localba=6, n_pose_batch=256, rank=0, quick=False):
     t5_in, t5_all, u5_in, u5_all = skyline_tiles(gg)
     roof["cases"]["c5"]["frac_executed"] = roof["cases"]["c5"]["frac"] * (f5_schur + 65536.0 * (t5_in + u5_in)) / (f5_schur + f5_chol)
     roof["cases"]["c5"]["cholesky"] = {
-        "form": "k_chol_persist walks the skyline (one persistent launch, two workgroups per block row); k_chol_bsolve_sky: the backward substitution in one launch",
+        "form": "k_chol_persist walks the skyline (one persistent launch, a ring of 11 workgroups); k_chol_bsolve_sky: the backward substitution in one launch",
         "tiles_inside_envelope": t5_in, "lower_triangle_tiles": t5_all, "tile_updates_inside": u5_in, "dense_tile_updates": u5_all,
         "note": "dense-equivalent rate (SURVEY 8(d)'s algorithmic flops / time), as for c4_batched: the time is the chain of 94 diagonal factors, not matrix-pipe work"}
     # ---- C5 as BASELINE config 5 words it, on ONE GPU: the eight 500-KF sub-maps as one lockstep batch (ba_solve_batch: what a node
