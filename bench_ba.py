@@ -51,9 +51,31 @@ def skyline_tiles(g, nb_tile=32):
     return inside, nb * (nb + 1) // 2, upd, dense_upd
 
 
-def _roof(flops, seconds, what, **extra):
-    ach = flops / seconds / 1e12
-    d = {"achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "ms": seconds * 1e3, "what": what}
+TILE_FLOPS = 2.0 * 32 ** 3        # one 32 x 32 x 32 tile product on the matrix cores: a tile update, or a tile times the inverse of a diagonal block
+
+
+def executed_flops(g, skyline=True):
+    """What ONE LM iteration EXECUTES in the reduced solve: (matrix-core flops of the factorisation, Schur-complement flops).
+    Factorisation: TILE_FLOPS per tile update and per tile solve that the kernels run - inside the skyline when the look-ahead family
+    factors (k_chol_wg / k_chol_persist), every tile of the lower triangle otherwise.  The Schur GEMMs (k_ba_schur) run on the VALU."""
+    f_schur, _ = reduced_solve_flops(g)
+    t_in, t_all, u_in, u_all = skyline_tiles(g)
+    return (TILE_FLOPS * ((t_in + u_in) if skyline else (t_all + u_all)), f_schur, (t_in, t_all, u_in, u_all))
+
+
+def _roof(g, lm_iterations, seconds, what, skyline=True, **extra):
+    """`frac` = flops the MATRIX CORES execute (tile updates + tile solves of the factorisation) / time / FP64 matrix peak.
+    `executed_incl_schur` adds the Schur GEMMs (VALU) - round 5's `frac_executed`; `dense_equiv_rate` is SURVEY 8(d)'s algorithmic
+    figure (Schur + n^3/3 whatever the structure) - round 5's `frac`, kept under a name that says what it is."""
+    f_mfma, f_schur, (t_in, t_all, u_in, u_all) = executed_flops(g, skyline)
+    _, f_chol_dense = reduced_solve_flops(g)
+    ach = f_mfma * lm_iterations / seconds / 1e12
+    d = {"achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "ms": seconds * 1e3, "what": what,
+         "executed_incl_schur": (f_mfma + f_schur) * lm_iterations / seconds / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+         "dense_equiv_rate": (f_schur + f_chol_dense) * lm_iterations / seconds / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+         "mfma_flops_per_iteration": f_mfma, "schur_flops_per_iteration": f_schur, "lm_iterations": lm_iterations,
+         "skyline": {"tiles_inside_envelope": t_in, "lower_triangle_tiles": t_all, "tile_updates_inside": u_in, "dense_tile_updates": u_all,
+                     "walked": "envelope" if skyline else "dense"}}
     d.update(extra)
     return d
 
@@ -72,10 +94,14 @@ def run(dev, cpu=True, n_localba=12, n_pose_batch=256, rank=0, quick=False):
     out = {}
     if quick:
         n_localba = 1; out["quick"] = True
-    roof = {"bound": "mfma", "kernel": "reduced camera system: Schur complement (k_ba_schur) + FP64-MFMA block Cholesky (k_chol_*), which skips the tiles outside the system's skyline",
-            "definition": "(Schur GEMM flops + n^3/3) x LM iterations / solve time / FP64 matrix peak (SURVEY 8(d)): `frac`; the factorisation skips the tiles "
-                          "outside the reduced system's skyline (exact zeros), so `frac` is a DENSE-EQUIVALENT rate and `frac_executed` prices only the flops that run "
-                          "(Schur GEMMs + 2 x 32^3 per tile update / tile solve inside the envelope)",
+    roof = {"bound": "mfma", "kernel": "FP64-MFMA block Cholesky of the reduced camera system (k_chol_wg / k_chol_persist / k_chol_persist_blk), which walks the system's skyline",
+            "definition": "`frac` = flops the matrix cores EXECUTE (2 x 32^3 per tile update and per tile solve that runs: inside the skyline for the look-ahead "
+                          "family, the whole lower triangle for the two-level scheme) x LM iterations / time / FP64 matrix peak.  `executed_incl_schur` adds the "
+                          "Schur-complement GEMMs, which run on the VALU (round 5's `frac_executed`); `dense_equiv_rate` is SURVEY 8(d)'s algorithmic figure "
+                          "(Schur + n^3/3 whatever the structure: round 5's `frac`).  Cases: c4_* = LocalBA 100 KF x 10 k pts x 50 k obs, c5* = GlobalBA 500 KF x 50 k x "
+                          "250 k; plain = SURVEY 8(d)'s odometry band (consecutive-view tracks), covis = windowed tracks with gaps + a current keyframe that shares "
+                          ">= 15 landmarks with every local keyframe (src/CeresOptimizer.cc:353-363), dense = every keyframe pair shares landmarks, loop = a chain whose "
+                          "ends are tied by a loop closure (synth.make_ba_graph_covis)",
             "peak_source": "AMD MI355X datasheet, FP64 matrix 78.6 TFLOP/s", "cases": {}}
     # ---- C4: LocalBundleAdjustment, 100 KF x 10k pts x 50k obs (all free except the gauge keyframe 0), reference two-pass
     #      schedule (5 + 10 iterations)
@@ -95,9 +121,9 @@ def run(dev, cpu=True, n_localba=12, n_pose_batch=256, rank=0, quick=False):
     out["localba_single_stream_solves_per_s"] = n_localba / dt
     out["localba_ms_per_solve_latency"] = dt / n_localba * 1e3
     out["localba_ms_per_solve_device"] = dev_ms / n_localba
-    roof["cases"]["c4_single"] = _roof((f_schur + f_chol) * nit, dev_ms * 1e-3,
+    roof["cases"]["c4_single"] = _roof(g, nit, dev_ms * 1e-3,
                                        "one LocalBA at a time; device time of the %d LM iterations of %d solves (HIP events on the solve stream)" % (nit, n_localba),
-                                       flops_per_iteration=f_schur + f_chol, cholesky_n=600 - 6)
+                                       cholesky_n=600 - 6, plan=optimizer.get_last_plan())
     # throughput: independent LocalBA problems (the sub-map sharding of SURVEY 8(e) inside one GPU): `nbatch` problems
     # per call solved in lockstep (ba_local_bundle_adjustment_batch: one grid row per problem), `nthreads` such calls
     # in flight from host threads (one HIP stream + device workspace per thread)
@@ -109,44 +135,58 @@ def run(dev, cpu=True, n_localba=12, n_pose_batch=256, rank=0, quick=False):
     # (tools/ba_batch_thr.py 64:12:N, N = 2 / 4 / 8 / 16: 2848 / 3151 / 3312 / 3294 solves/s; a kernel trace of the steady part shows one
     # batch iteration per 1.2 ms = 3555 solves/s))
     nbatch, nthreads, n_each = (8, 2, 1) if quick else (64, 12, 8)
-    gs = [g] + [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(1, nbatch)]   # 64 distinct local maps
-    probs = [(q["K4"], q["poses0"], q["cam_fixed"], local, q["pts0"], q["obs_cam"], q["obs_pt"], q["obs_uv"], q["obs_inv_sigma2"]) for q in gs]
-    fl_batch = sum(sum(reduced_solve_flops(q)) for q in gs)
-    bar = threading.Barrier(nthreads + 1)
-    iters = [0] * nthreads
 
-    def work(k):
-        for _ in range(2):
-            optimizer.local_bundle_adjustment_batch(probs)
-        optimizer.get_profile()
+    def batched_leg(gs, what):
+        """`nthreads` host threads, each solving the lockstep batch `gs` n_each times; returns (solves/s, roofline case)."""
+        probs = [(q["K4"], q["poses0"], q["cam_fixed"], local, q["pts0"], q["obs_cam"], q["obs_pt"], q["obs_uv"], q["obs_inv_sigma2"]) for q in gs]
+        bar = threading.Barrier(nthreads + 1)
+        iters = [0] * nthreads
+        plans = [None] * nthreads
+
+        def work(k):
+            for _ in range(2):
+                optimizer.local_bundle_adjustment_batch(probs)
+            optimizer.get_profile()
+            bar.wait()
+            for _ in range(n_each):
+                optimizer.local_bundle_adjustment_batch(probs)
+            iters[k] = optimizer.get_profile()[2]
+            plans[k] = optimizer.get_last_plan()
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(nthreads)]
+        for t in ths:
+            t.start()
         bar.wait()
-        for _ in range(n_each):
-            optimizer.local_bundle_adjustment_batch(probs)
-        iters[k] = optimizer.get_profile()[2]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        nsolves = len(gs) * nthreads * n_each
+        mean_it = sum(iters) / float(nsolves)
+        # (the problems of a batch differ in their skylines by a tile or two: the executed flops of problem 0 stand for all)
+        case = _roof(gs[0], mean_it * nsolves, dt,
+                     "%d distinct local maps (%s) per lockstep batch x %d host threads; wall time of %d solves (copies and host structure setup included)"
+                     % (len(gs), what, nthreads, nsolves), lm_iterations_per_solve=mean_it, solves_per_s=nsolves / dt, plan=plans[0])
+        return nsolves / dt, case
 
-    ths = [threading.Thread(target=work, args=(k,)) for k in range(nthreads)]
-    for t in ths:
-        t.start()
-    bar.wait()
-    t0 = time.perf_counter()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
-    out["localba_solves_per_s"] = nbatch * nthreads * n_each / dt
+    gs = [g] + [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(1, nbatch)]   # 64 distinct local maps
+    out["localba_solves_per_s"], roof["cases"]["c4_batched"] = batched_leg(gs, "odometry band")
     out["localba_concurrency"] = nbatch * nthreads
-    mean_it = sum(iters) / float(nbatch * nthreads * n_each)
-    roof["cases"]["c4_batched"] = _roof(fl_batch / nbatch * mean_it * nbatch * nthreads * n_each, dt,
-                                        "%d distinct local maps per lockstep batch x %d host threads; wall time of %d solves (copies and host structure setup included)"
-                                        % (nbatch, nthreads, nbatch * nthreads * n_each), lm_iterations_per_solve=mean_it)
-    t_in, t_all, u_in, u_all = skyline_tiles(g)
-    exe4 = (f_schur + 65536.0 * (t_in + u_in)) / (f_schur + f_chol)      # executed / algorithmic flops: a tile update or a tile times X is 2 x 32^3 flops
-    roof["cases"]["c4_batched"]["frac_executed"] = roof["cases"]["c4_batched"]["frac"] * exe4
-    roof["cases"]["c4_batched"]["cholesky"] = {
-        "form": "k_chol_wg walks the skyline of the reduced system (tiles outside the envelope are exact zeros: skipped, bit-identical to the dense walk)",
-        "tiles_inside_envelope": t_in, "lower_triangle_tiles": t_all, "tile_updates_inside": u_in, "dense_tile_updates": u_all,
-        "note": "`achieved` keeps SURVEY 8(d)'s ALGORITHMIC flops (Schur GEMMs + dense n^3/3) so that the figure stays comparable across rounds; "
-                "the matrix cores execute only the share inside the envelope (this synthetic map: consecutive-view tracks, a band of <= 3 tiles), "
-                "so the fraction is a dense-equivalent rate, not matrix-pipe utilisation - profiles/*_mfma_localba_batch64.json has the counters"}
+    # the same size with the structures a map of the reference has (VERDICT r5 next #1): windowed tracks + the current keyframe's shared
+    # landmarks (an arrowhead over a band of 30 keyframes), and a full reduced system
+    for st in ("covis", "dense"):
+        gq = [synth.make_ba_graph_covis(100 + s, ncam=100, npts=10000, nobs=50000, structure=st) for s in range(nbatch)]
+        out["localba_%s_solves_per_s" % st], roof["cases"]["c4_%s" % st] = batched_leg(gq, st)
+        if not quick:                                              # and one solve at a time
+            qa = (gq[0]["K4"], gq[0]["poses0"], gq[0]["cam_fixed"], local, gq[0]["pts0"], gq[0]["obs_cam"], gq[0]["obs_pt"], gq[0]["obs_uv"], gq[0]["obs_inv_sigma2"])
+            optimizer.local_bundle_adjustment(*qa); optimizer.get_profile()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                optimizer.local_bundle_adjustment(*qa)
+            dts = time.perf_counter() - t0
+            dms, _, nits = optimizer.get_profile()
+            roof["cases"]["c4_%s_single" % st] = _roof(gq[0], nits, dms * 1e-3, "one LocalBA (%s) at a time; device time of the %d LM iterations of 6 solves" % (st, nits),
+                                                       ms_per_solve_latency=dts / 6 * 1e3, plan=optimizer.get_last_plan())
     out["localba_note"] = ("100 KF x 10000 pts x 50000 obs, reference two-pass schedule (5 Huber + 10 iterations with the "
                            "re-added blocks), host-pointer C ABI end to end (H2D/D2H copies and host structure setup "
                            "included); %d distinct problems per lockstep batch x %d host threads; all keyframes free except "
@@ -186,17 +226,23 @@ def run(dev, cpu=True, n_localba=12, n_pose_batch=256, rank=0, quick=False):
     gposes, gpts, gsum = optimizer.global_bundle_adjustment(*gargs, n_iterations=10 if quick else 50)
     dt = time.perf_counter() - t0
     dev_ms, _, nit = optimizer.get_profile()
+    plan5 = optimizer.get_last_plan()
+    roof["cases"]["c5"] = _roof(gg, nit, dev_ms * 1e-3, "one 500-KF GlobalBA (odometry band); device time of its %d LM iterations (HIP events on the solve stream)" % nit,
+                                skyline=plan5["lookahead_form"] != "none", cholesky_n=6 * 499, plan=plan5)
+    # a LOOP-CLOSED 500-keyframe map: what GlobalBundleAdjustemnt runs on (src/LoopClosing.cc:656) - a chain whose last block rows reach back to column 0
+    gl = synth.make_ba_graph_covis(3000 + rank, ncam=500, npts=50000, nobs=250000, structure="loop")
+    largs = (gl["K4"], gl["poses0"], gl["cam_fixed"], gl["pts0"], gl["obs_cam"], gl["obs_pt"], gl["obs_uv"], gl["obs_inv_sigma2"])
+    optimizer.set_profiling(True)
+    optimizer.global_bundle_adjustment(*largs, n_iterations=2); optimizer.get_profile()
+    t0 = time.perf_counter()
+    _, _, lsum = optimizer.global_bundle_adjustment(*largs, n_iterations=5 if quick else 20)
+    dtl = time.perf_counter() - t0
+    lms, _, lnit = optimizer.get_profile()
     optimizer.set_profiling(False)
-    f5_schur, f5_chol = reduced_solve_flops(gg)
-    roof["cases"]["c5"] = _roof((f5_schur + f5_chol) * nit, dev_ms * 1e-3,
-                                "one 500-KF GlobalBA; device time of its %d LM iterations (HIP events on the solve stream)" % nit,
-                                flops_per_iteration=f5_schur + f5_chol, cholesky_n=6 * 499)
-    t5_in, t5_all, u5_in, u5_all = skyline_tiles(gg)
-    roof["cases"]["c5"]["frac_executed"] = roof["cases"]["c5"]["frac"] * (f5_schur + 65536.0 * (t5_in + u5_in)) / (f5_schur + f5_chol)
-    roof["cases"]["c5"]["cholesky"] = {
-        "form": "k_chol_persist walks the skyline (one persistent launch, a ring of 11 workgroups); k_chol_bsolve_sky: the backward substitution in one launch",
-        "tiles_inside_envelope": t5_in, "lower_triangle_tiles": t5_all, "tile_updates_inside": u5_in, "dense_tile_updates": u5_all,
-        "note": "dense-equivalent rate (SURVEY 8(d)'s algorithmic flops / time), as for c4_batched: the time is the chain of 94 diagonal factors, not matrix-pipe work"}
+    planl = optimizer.get_last_plan()
+    roof["cases"]["c5_loop"] = _roof(gl, lnit, lms * 1e-3, "one loop-closed 500-KF GlobalBA; device time of its %d LM iterations" % lnit,
+                                     skyline=planl["lookahead_form"] != "none", ms_per_iteration=lms / max(lnit, 1), wall_ms=dtl * 1e3, plan=planl)
+    out["globalba_loop_500kf_ms_per_iteration"] = lms / max(lnit, 1)
     # ---- C5 as BASELINE config 5 words it, on ONE GPU: the eight 500-KF sub-maps as one lockstep batch (ba_solve_batch: what a node
     #      with fewer GPUs than sub-maps does).  A single GlobalBA is bound by the latency chain of its factorisation (c5 above);
     #      eight in lockstep share every launch of the chain.  (Eight host threads with one solve each: 464 ms against 379; 323 with the
@@ -211,9 +257,10 @@ def run(dev, cpu=True, n_localba=12, n_pose_batch=256, rank=0, quick=False):
         res8 = optimizer.bundle_adjustment_batch(subs, n_iterations=50)
         dt8 = time.perf_counter() - t0
         it8 = sum(int(r8[2]["iterations"]) for r8 in res8)
-        roof["cases"]["c5_batched8"] = _roof((f5_schur + f5_chol) * it8, dt8,
+        roof["cases"]["c5_batched8"] = _roof(gg, it8, dt8,
                                              "eight distinct 500-KF GlobalBA sub-maps as one lockstep batch on this GPU; wall time of their %d LM "
-                                             "iterations, copies and host structure setup (the calling thread and its helpers, ORBHIP_BA_PREP_THREADS) included" % it8)
+                                             "iterations, copies and host structure setup (the calling thread and its helpers, ORBHIP_BA_PREP_THREADS) included" % it8,
+                                             plan=optimizer.get_last_plan())
         out["globalba_8_submaps_ms"] = dt8 * 1e3
     out["roofline"] = roof
     out["globalba_500kf_ms"] = dt * 1e3

@@ -21,7 +21,7 @@ SYMBOLS = [
     "ba_pose_optimization", "ba_pose_optimization_batch_device", "ba_solve", "ba_check_outlier",
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log", "ba_sim3_mul", "ba_sim3_inverse",
     "ba_solve_batch", "ba_local_bundle_adjustment_batch", "ba_optimize_essential_graph", "ba_essential_graph_correct",
-    "ba_matrix4d_to_pose7", "ba_pose7_to_matrix4d", "ba_set_profiling", "ba_get_profile", "ba_set_wait_limit_ms",
+    "ba_matrix4d_to_pose7", "ba_pose7_to_matrix4d", "ba_set_profiling", "ba_get_profile", "ba_get_last_plan", "ba_set_wait_limit_ms",
 ]
 
 
@@ -141,6 +141,7 @@ def load():
     L.ba_pose7_to_matrix4d.argtypes = [vp, vp]
     L.ba_set_profiling.argtypes = [i32]
     L.ba_get_profile.argtypes = [C.POINTER(f64), C.POINTER(i32), C.POINTER(i32)]
+    L.ba_get_last_plan.argtypes = [C.POINTER(i32)]
     L.ba_set_wait_limit_ms.argtypes = [C.c_double]
     L.orbhip_copy_pinned_async.argtypes = [vp, vp, C.c_size_t, vp]
     L.ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaOptions), vp]

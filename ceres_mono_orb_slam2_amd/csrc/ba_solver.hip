@@ -1485,6 +1485,13 @@ int ba_set_wait_limit_ms(double ms) {
   ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cp_wait_ticks), &v, sizeof(v)));
   return 0;
 }
+int ba_get_last_plan(int32_t* out12) {
+  ORBHIP_REQUIRE(out12, ORBHIP_EINVAL, "NULL argument");
+  const BaPlan& p = g_last_plan;
+  const int32_t v[12] = {p.ny, p.la_form, p.tl_form, p.bsolve_form, p.npad_la, p.npad_2l, p.band, p.persist_nwg, p.persist_mode, p.la_large, p.wg_ok, 0};
+  std::memcpy(out12, v, sizeof(v));
+  return 0;
+}
 int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations) {
   if (device_ms) *device_ms = g_prof_ms;
   if (nsolves) *nsolves = g_prof_solves;

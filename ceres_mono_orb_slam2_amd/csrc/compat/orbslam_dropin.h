@@ -464,6 +464,13 @@ class ORBmatcherT {
     const size_t nt = targets.size(), nq = vpMapPoints.size();
     std::vector<int> ret(nt, 0);
     if (!nt || !nq) return ret;
+    // orbl_fuse_batch takes ONE inv_level_sigma2 table; keyframes of differently configured extractors (the reference reads each
+    // keyframe's own table, src/ORBmatcher.cc:789) keep the reference's loop of single calls
+    for (size_t t = 1; t < nt; t++)
+      if (targets[t]->inv_level_sigma2s_ != targets[0]->inv_level_sigma2s_) {
+        for (size_t k = 0; k < nt; k++) ret[k] = Fuse(targets[k], vpMapPoints, th);
+        return ret;
+      }
     std::vector<float> uv(2 * nt * nq, 0.f), radius(nt * nq, 0.f); std::vector<int32_t> level(nt * nq, -1);
     std::vector<uint8_t> desc(32 * nq, 0);
     for (size_t i = 0; i < nq; i++) if (vpMapPoints[i]) std::memcpy(&desc[32 * i], vpMapPoints[i]->GetDescriptor().ptr(0), 32);

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <atomic>
 #include <vector>
 #include <algorithm>
 #include <new>
@@ -1567,7 +1568,9 @@ inline int cv_round(double v) { return (int)std::nearbyint(v); }
 
 using namespace orbhip;
 
+static std::atomic<unsigned long long> g_ctx_generation{0};
 struct orbx_ctx {
+  const unsigned long long generation = ++g_ctx_generation;      // a resident frame remembers (pointer, generation): a context re-created at the same address is another producer
   int nfeatures, nlevels, iniTh, minTh, device;
   double scaleFactor;
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
@@ -2243,6 +2246,7 @@ namespace orbhip {
 // orbx_extract_batch_device for ONE frame as a link of a longer device-resident chain (orb_track.hip): the blur goes to the
 // extractor's side stream.  Not part of the C ABI.
 int orbx_ctx_device(const orbx_ctx* c) { return c ? c->device : -1; }
+unsigned long long orbx_ctx_generation(const orbx_ctx* c) { return c ? c->generation : 0ull; }
 int orbx_extract_chained(orbx_ctx* c, const uint8_t* d_img, int w, int h, int stride, orbx_keypoint* d_kps, uint8_t* d_desc, int cap,
                          int32_t* d_count, void* stream) {
   if (c) c->lone_side_mode = 1;

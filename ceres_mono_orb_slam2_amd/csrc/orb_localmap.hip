@@ -213,6 +213,15 @@ __global__ __launch_bounds__(256) void k_lf_select(const uint8_t* __restrict__ b
 
 using namespace orbhip;
 
+// a FeatureVector as CSR: fv_off[0] = 0, non-decreasing; fv_off[fv_n] is the length of fv_idx (the kernels walk fv_idx[fv_off[m] .. fv_off[m + 1]))
+static int lm_check_feature_vector(const uint32_t* fv_off, int fv_n, const char* who) {
+  if (fv_n == 0) return 0;
+  bool ok = fv_off[0] == 0 && fv_off[fv_n] <= 0x7fffffffu;
+  for (int m = 0; m < fv_n && ok; m++) ok = fv_off[m] <= fv_off[m + 1];
+  if (!ok) { set_error("%s: FeatureVector offsets must start at 0 and must not decrease", who); return ORBHIP_EINVAL; }
+  return 0;
+}
+
 extern "C" {
 
 int orbl_create_new_map_points(const float* kps1, const uint8_t* desc1, const uint8_t* unmapped1, int n1, const uint32_t* fv1_node, const uint32_t* fv1_off,
@@ -229,7 +238,9 @@ int orbl_create_new_map_points(const float* kps1, const uint8_t* desc1, const ui
     const orbl_keyframe& q = nb[k];
     ORBHIP_REQUIRE(q.n >= 0 && q.fv_n >= 0 && (q.n == 0 || (q.kps && q.desc)) && (q.fv_n == 0 || (q.fv_node && q.fv_off && q.fv_idx)), ORBHIP_EINVAL, "NULL neighbour argument");
     for (int i = 0; i < q.n; i++) ORBHIP_REQUIRE(q.kps[4 * (size_t)i + 2] >= 0 && q.kps[4 * (size_t)i + 2] < n_levels, ORBHIP_EINVAL, "octave out of range");
+    if (int r = lm_check_feature_vector(q.fv_off, q.fv_n, "neighbour")) return r;
   }
+  if (int r = lm_check_feature_vector(fv1_off, fv1_n, "current keyframe")) return r;
   ThreadWs& W = thread_ws();
   int rc = W.begin();
   if (rc) return rc;
@@ -271,7 +282,11 @@ int orbl_create_new_map_points(const float* kps1, const uint8_t* desc1, const ui
   uint32_t* d_node_of = W.d<uint32_t>((size_t)n1, &rc);
   unsigned char* h_stop = W.h<unsigned char>(16, &rc);            // pinned, device-visible mirror of the caller's flag
   if (rc || (rc = W.commit(in))) return rc;
-  *h_stop = 0;
+  // the mirror starts from the caller's flag: a flag that is already up when the call begins stops the chain after neighbour 0, every time
+  // (src/LocalMapping.cc:227 `if (i > 0 && CheckNewKeyFrames()) return;` - ADVICE r5: it used to start at 0 and be raised only after the enqueues)
+  *(volatile unsigned char*)h_stop = (stop && *stop) ? 1 : 0;
+  hipEvent_t done = nullptr;
+  if (stop) ORBHIP_CHECK_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   ORBHIP_CHECK_HIP(hipMemsetAsync(dblk + oState, 0, 8, W.s));
   ORBHIP_CHECK_HIP(hipMemsetAsync(d_node_of, 0xFF, 4 * (size_t)n1, W.s));
   if (fv1_n) hipLaunchKernelGGL(k_lm_node_of, dim3((fv1_n + 255) / 256), dim3(256), 0, W.s, in.dev<uint32_t>(pFn), in.dev<uint32_t>(pFo), in.dev<uint32_t>(pFi), fv1_n, n1, d_node_of);
@@ -280,17 +295,15 @@ int orbl_create_new_map_points(const float* kps1, const uint8_t* desc1, const ui
     hipLaunchKernelGGL(k_lm_neighbour, dim3((n1 + LM_QPB - 1) / LM_QPB), dim3(16 * LM_QPB), 0, W.s, (const uint8_t*)in.dbase, in.dev<LmNb>(pN), k, in.dev<float>(pK),
                        in.dev<uint32_t>(pD), in.dev<uint8_t>(pU), d_node_of, n1, in.dev<float>(pS), in.dev<float>(pL), (const int*)(dblk + oState),
                        (int32_t*)(dblk + oM), dblk + oOk, (double*)(dblk + oX));
+    if (stop && *stop) *(volatile unsigned char*)h_stop = 1;     // (between the enqueues too: the gates of the neighbours behind see it)
   }
-  ORBHIP_CHECK_HIP(hipGetLastError());
+  if (hipGetLastError() != hipSuccess) { if (done) (void)hipEventDestroy(done); set_error("orbl_create_new_map_points: a launch failed"); return ORBHIP_ENODEV; }
   const uint8_t* hb = W.down(dblk, o, &rc);
-  if (rc) return rc;
+  if (rc) { if (done) (void)hipEventDestroy(done); return rc; }
   if (stop) {                                                    // forward the caller's flag while the chain runs (the kernels read the pinned mirror)
-    hipEvent_t done = nullptr;
-    if (hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) {
-      (void)hipEventRecord(done, W.s);
-      while (hipEventQuery(done) == hipErrorNotReady) { if (*stop) *(volatile unsigned char*)h_stop = 1; }
-      (void)hipEventDestroy(done);
-    }
+    (void)hipEventRecord(done, W.s);
+    while (hipEventQuery(done) == hipErrorNotReady) { if (*stop) *(volatile unsigned char*)h_stop = 1; }
+    (void)hipEventDestroy(done);
   }
   if ((rc = W.sync())) return rc;
   const int* st = (const int*)(hb + oState);

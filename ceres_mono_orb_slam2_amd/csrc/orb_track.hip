@@ -1079,6 +1079,7 @@ namespace orbhip {
 void orbv_merge_host(const int32_t* word, const double* wt, const uint32_t* node, int n, uint32_t* bow_word, double* bow_value, int* n_words,
                      uint32_t* fv_node, uint32_t* fv_off, uint32_t* fv_idx, int* n_fv_nodes);      // orb_vocab.hip
 int orbx_ctx_device(const orbx_ctx* c);
+unsigned long long orbx_ctx_generation(const orbx_ctx* c);
 int orbx_extract_chained(orbx_ctx* c, const uint8_t* d_img, int w, int h, int stride, orbx_keypoint* d_kps, uint8_t* d_desc, int cap,
                          int32_t* d_count, void* stream);      // orb_extractor.hip
 }
@@ -1092,6 +1093,8 @@ struct TrkFrame {
   DevBuf blk, kps4; FrameGridDev grid;
   size_t oKps = 0, oDesc = 0, oCnt = 0; int icap = 0, n_kp = 0, device = -1, nlevels = 0; float bounds[4] = {0, 0, 0, 0}; bool valid = false;
   const orbx_ctx* producer = nullptr;      // the extractor that produced the resident frame: its level count / scale tables / capacity are the frame's
+  unsigned long long producer_gen = 0;     // ... and its generation: a context destroyed and re-created at the same address is NOT that extractor
+  bool made_by(const orbx_ctx* c) const { return producer == c && producer_gen == orbhip::orbx_ctx_generation(c); }
 };
 thread_local TrkFrame g_trk_frame;
 }  // namespace
@@ -1219,7 +1222,7 @@ int orbt_track_with_motion_model(orbx_ctx* ctx, const uint8_t* img, int w, int h
     std::memset(outlier_out, 0, (size_t)n);
     const int32_t* feat = (const int32_t*)(hb + oFeat);
     for (int k = 0; k < T->nobs; k++) outlier_out[feat[k]] = hb[oOutl + k];
-    TF.oKps = oKps; TF.oDesc = oDesc; TF.oCnt = oCnt; TF.icap = icap; TF.n_kp = n; TF.nlevels = nlevels; std::memcpy(TF.bounds, bounds, 16); TF.valid = true; TF.producer = ctx;
+    TF.oKps = oKps; TF.oDesc = oDesc; TF.oCnt = oCnt; TF.icap = icap; TF.n_kp = n; TF.nlevels = nlevels; std::memcpy(TF.bounds, bounds, 16); TF.valid = true; TF.producer = ctx; TF.producer_gen = orbhip::orbx_ctx_generation(ctx);
     res->n_keypoints = n; res->nmatches = T->nmatches; res->n_correspondences = T->nobs; res->greedy_rounds = T->rounds % 1000;
     std::memcpy(res->pose7, hb + oPose, 56);
     // PoseOptimization returns 0 and leaves the pose alone with fewer than 3 correspondences (src/CeresOptimizer.cc:330)
@@ -1261,7 +1264,7 @@ int orbt_track_local_map(orbx_ctx* ctx, const float* K4, const float* bounds, co
     int rc = W.begin();
     if (rc) return rc;
     ORBHIP_REQUIRE(TF.valid && TF.device == W.device, ORBHIP_EINVAL, "no frame resident on this thread's device: call orbt_track_with_motion_model first (same host thread)");
-    ORBHIP_REQUIRE(TF.producer == ctx && TF.nlevels == nlevels, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
+    ORBHIP_REQUIRE(TF.made_by(ctx) && TF.nlevels == nlevels, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
     ORBHIP_REQUIRE(n_kp == TF.n_kp, ORBHIP_EINVAL, "n_kp differs from the resident frame's keypoint count");
     const int icap = TF.icap, nq = n_mp;
     TlmIn I; std::memset(&I, 0, sizeof(I));
@@ -1370,7 +1373,7 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
     d_img = W.up<uint8_t>(img, (size_t)stride * (h - 1) + w, &rc);
   } else {
     ORBHIP_REQUIRE(TF.valid, ORBHIP_EINVAL, "img == NULL needs the frame of an earlier orbt_* call of this thread on the device");
-    ORBHIP_REQUIRE(TF.producer == ctx && TF.nlevels == nlevels && TF.icap == icap, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
+    ORBHIP_REQUIRE(TF.made_by(ctx) && TF.nlevels == nlevels && TF.icap == icap, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
   }
   if (rc || (rc = W.commit(in))) return rc;
   if (img) {
@@ -1424,7 +1427,7 @@ int orbt_track_reference_keyframe(orbx_ctx* ctx, orbv_ctx* voc, const uint8_t* i
   const TrkOut* T = (const TrkOut*)(hb + oOut);
   if (T->n_keypoints < 0) { set_error("extractor capacity exceeded"); return ORBHIP_EOVERFLOW; }
   const int n = std::min(T->n_keypoints, fcap);
-  if (img) { TF.n_kp = n; TF.valid = true; TF.producer = ctx; std::memcpy(kps_out, hf + TF.oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hf + TF.oDesc, (size_t)n * 32); }
+  if (img) { TF.n_kp = n; TF.valid = true; TF.producer = ctx; TF.producer_gen = orbhip::orbx_ctx_generation(ctx); std::memcpy(kps_out, hf + TF.oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hf + TF.oDesc, (size_t)n * 32); }
   if (n != TF.n_kp) { set_error("resident frame changed"); return ORBHIP_EINVAL; }
   if (bow_word && bow_value && fv_node && fv_idx)
     orbhip::orbv_merge_host((const int32_t*)(hb + oWord), (const double*)(hb + oWt), (const uint32_t*)(hb + oNode), n, bow_word, bow_value, n_words, fv_node, fv_off, fv_idx, n_fv_nodes);
@@ -1496,7 +1499,7 @@ int orbt_relocalization_search_by_bow(orbx_ctx* ctx, orbv_ctx* voc, const uint8_
   if (img) d_img = W.up<uint8_t>(img, (size_t)stride * (h - 1) + w, &rc);
   else {
     ORBHIP_REQUIRE(TF.valid, ORBHIP_EINVAL, "img == NULL needs the frame of an earlier orbt_* call of this thread on the device");
-    ORBHIP_REQUIRE(TF.producer == ctx && TF.nlevels == nlevels && TF.icap == icap, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
+    ORBHIP_REQUIRE(TF.made_by(ctx) && TF.nlevels == nlevels && TF.icap == icap, ORBHIP_EINVAL, "ctx is not the extractor that produced the resident frame");
   }
   if (rc || (rc = W.commit(in))) return rc;
   if (img) {
@@ -1557,7 +1560,7 @@ int orbt_relocalization_search_by_bow(orbx_ctx* ctx, orbv_ctx* voc, const uint8_
   const int n_dev = *(const int32_t*)(hf + TF.oCnt);
   if (n_dev < 0) { set_error("extractor capacity exceeded"); return ORBHIP_EOVERFLOW; }
   const int n = std::min(n_dev, fcap);
-  if (img) { TF.n_kp = n; TF.valid = true; TF.producer = ctx; std::memcpy(kps_out, hf + TF.oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hf + TF.oDesc, (size_t)n * 32); }
+  if (img) { TF.n_kp = n; TF.valid = true; TF.producer = ctx; TF.producer_gen = orbhip::orbx_ctx_generation(ctx); std::memcpy(kps_out, hf + TF.oKps, (size_t)n * sizeof(orbx_keypoint)); std::memcpy(desc_out, hf + TF.oDesc, (size_t)n * 32); }
   if (n != TF.n_kp) { set_error("resident frame changed"); return ORBHIP_EINVAL; }
   *n_keypoints = n;
   if (bow_word && bow_value && fv_node && fv_idx)

@@ -186,6 +186,19 @@ def get_profile():
     return ms.value, n.value, it.value
 
 
+LA_FORMS = {0: "none", 1: "k_chol_persist", 2: "k_chol_wg", 3: "k_chol_la steps"}
+TL_FORMS = {0: "none", 1: "k_chol_persist_blk", 2: "hybrid step kernels", 3: "classic", 4: "one launch"}
+
+
+def get_last_plan():
+    """Which member of the factorisation family THIS host thread's last solve took (ba_get_last_plan)."""
+    v = (C.c_int32 * 12)()
+    _lib.check(_lib.load().ba_get_last_plan(v))
+    return {"problems": v[0], "lookahead_form": LA_FORMS.get(v[1], v[1]), "two_level_form": TL_FORMS.get(v[2], v[2]),
+            "backward_substitution": {1: "k_chol_bsolve_sky", 2: "per super-block"}.get(v[3], v[3]), "npad_lookahead": v[4], "npad_two_level": v[5],
+            "band_tiles": v[6], "persist_workgroups": v[7], "persist_mode": v[8], "lookahead_above_1024": bool(v[9]), "fits_k_chol_wg": bool(v[10])}
+
+
 def _addr(a):
     return a.ctypes.data if a is not None and a.size else None
 

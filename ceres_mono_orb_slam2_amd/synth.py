@@ -260,6 +260,129 @@ def make_ba_graph(seed, ncam=100, npts=10000, nobs=50000, outlier_frac=0.05, noi
 
 
 
+def _quat_from_R(R):
+    """[x,y,z,w] of a rotation matrix (largest-component branch)."""
+    m = R; tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2; q = [(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s]
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2; q = [0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s, (m[2, 1] - m[1, 2]) / s]
+    elif m[1, 1] > m[2, 2]:
+        s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2; q = [(m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s, (m[0, 2] - m[2, 0]) / s]
+    else:
+        s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2; q = [(m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s, (m[1, 0] - m[0, 1]) / s]
+    q = np.array(q); return q / np.linalg.norm(q)
+
+
+BA_STRUCTURES = ("covis", "dense", "loop")
+
+
+def make_ba_graph_covis(seed, ncam=100, npts=10000, nobs=50000, structure="covis", window=(15, 30), cur_share=15,
+                        outlier_frac=0.05, noise=1.0, perturb=True, n_fixed=1, w=1241, h=376):
+    """BA graphs whose REDUCED CAMERA SYSTEM has the structure a map of the reference has, beside make_ba_graph's odometry band.
+
+    The reference's local window is the current keyframe plus ALL its covisible keyframes (src/CeresOptimizer.cc:353-363: every
+    local keyframe shares >= 15 map points with the current one) and a landmark is matched across a neighbourhood of keyframes
+    with gaps (a keyframe that missed the match does not end the track).  Keyframes are numbered by id, the current keyframe is
+    the LAST one (the drop-in flattens keyframes by id, csrc/compat/orbslam_dropin.h).
+
+      structure "covis": a landmark is seen by k >= 2 keyframes drawn at random (gaps) inside a window of window[0]..window[1]
+                         consecutive keyframes; on top the current keyframe (ncam - 1) shares `cur_share` landmarks with EVERY
+                         other keyframe - a band of window[1] keyframes plus a dense last block row (an arrowhead).
+                "dense": a landmark is seen by k random keyframes out of all of them: every keyframe pair shares landmarks, the
+                         reduced system is full.
+                 "loop": "covis" windows that wrap around (keyframe ncam - 1 is a neighbour of keyframe 0): a chain whose ends
+                         are tied by a loop closure - the LAST block rows reach back to column 0 (src/LoopClosing.cc:656 runs
+                         GlobalBundleAdjustemnt on exactly such a map); no current-keyframe landmarks.
+
+    Geometry: KITTI intrinsics; the keyframes stand on an arc (a full circle for "loop") of radius 12 m and look at its centre,
+    the landmarks fill a flat ellipsoid around the centre, so every landmark is in front of and inside the image of every
+    keyframe and WHO sees it is the structure's choice alone.  Noise, octaves, gross outliers and the perturbed start as in
+    make_ba_graph.  nobs is met exactly; the mean track length is nobs / npts.  Returns make_ba_graph's dict plus `current`."""
+    assert structure in BA_STRUCTURES
+    rng = np.random.default_rng(seed)
+    K4 = KITTI_K4.copy()
+    rho = 12.0
+    span = 2 * np.pi * (1.0 - 1.0 / ncam) if structure == "loop" else np.deg2rad(min(1.0 * (ncam - 1), 150.0))
+    ang = -0.5 * span + span * np.arange(ncam) / max(ncam - 1, 1) + rng.normal(0, 0.1 * span / max(ncam, 2), ncam)
+    poses_gt = np.zeros((ncam, 7))
+    for c in range(ncam):
+        C = np.array([rho * np.sin(ang[c]), rng.normal(0, 0.05), -rho * np.cos(ang[c])]) * (1.0 + rng.normal(0, 0.01))
+        f = -C / np.linalg.norm(C)
+        f = quat_to_R(quat_from_rotvec(rng.normal(0, 0.01, 3))) @ f          # not exactly at the centre
+        d = np.array([0.0, 1.0, 0.0]); r = np.cross(d, f); r /= np.linalg.norm(r); d = np.cross(f, r)
+        R = np.stack([r, d, f])                                              # p_c = R X + t
+        poses_gt[c, :3] = -R @ C; poses_gt[c, 3:] = _quat_from_R(R)
+    wrap = structure == "loop"
+    cur = ncam - 1
+    # ---- who sees what
+    n_cur_pts = 0 if structure != "covis" else min(cur_share * (ncam - 1), npts // 3)
+    per_kf = n_cur_pts // max(ncam - 1, 1) if structure == "covis" else 0
+    n_cur_pts = per_kf * (ncam - 1)
+    n_win = npts - n_cur_pts
+    budget = nobs - 2 * n_cur_pts                                            # a current-keyframe landmark: the current keyframe + one other
+    wmax = ncam if structure == "dense" else min(window[1], ncam)
+    lens = np.clip(rng.poisson(max(budget / n_win - 2.0, 0.0), n_win) + 2, 2, min(wmax, ncam))
+    diff = int(lens.sum() - budget)
+    order = rng.permutation(n_win); i = 0
+    while diff != 0 and i < 50 * n_win:
+        p = order[i % n_win]
+        if diff > 0 and lens[p] > 2:
+            lens[p] -= 1; diff -= 1
+        elif diff < 0 and lens[p] < min(wmax, ncam):
+            lens[p] += 1; diff += 1
+        i += 1
+    assert diff == 0, "nobs cannot be met with these sizes"
+    oc, op = [], []
+    for p in range(n_win):
+        k = int(lens[p])
+        if structure == "dense":
+            cams = np.sort(rng.choice(ncam, k, replace=False))
+        else:
+            W = int(min(max(rng.integers(window[0], window[1] + 1), k), ncam))
+            s = int(rng.integers(0, ncam if wrap else ncam - W + 1))
+            cams = np.sort((s + rng.choice(W, k, replace=False)) % ncam)
+        oc.extend(cams.tolist()); op.extend([p] * k)
+    for j in range(ncam - 1 if n_cur_pts else 0):                            # the current keyframe's shared landmarks, keyframe by keyframe
+        for q in range(per_kf):
+            p = n_win + j * per_kf + q
+            oc.extend([j, cur]); op.extend([p, p])
+    oc = np.array(oc, np.int32); op = np.array(op, np.int32)
+    assert len(oc) == nobs
+    # ---- landmarks: inside every keyframe's image (checked), in front of every keyframe
+    pts = np.zeros((npts, 3)); todo = np.arange(npts)
+    Rs = np.stack([quat_to_R(poses_gt[c, 3:]) for c in range(ncam)]); ts = poses_gt[:, :3]
+    for _ in range(50):
+        if len(todo) == 0:
+            break
+        u = rng.normal(0, 1, (len(todo), 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+        X = u * (rng.uniform(0, 1, (len(todo), 1)) ** (1 / 3)) * np.array([4.5, 1.4, 4.5])
+        ok = np.ones(len(todo), bool)
+        for n0 in range(0, len(todo), 4096):                                  # (chunks: ncam x points x 3 doubles)
+            pc = np.einsum("cij,nj->cni", Rs, X[n0:n0 + 4096]) + ts[:, None, :]
+            uu = K4[0] * pc[..., 0] / pc[..., 2] + K4[2]; vv = K4[1] * pc[..., 1] / pc[..., 2] + K4[3]
+            ok[n0:n0 + 4096] = ((pc[..., 2] > 4.0) & (uu > 60) & (uu < w - 60) & (vv > 30) & (vv < h - 30)).all(0)
+        pts[todo[ok]] = X[ok]; todo = todo[~ok]
+    assert len(todo) == 0
+    pc = np.einsum("nij,nj->ni", Rs[oc], pts[op]) + ts[oc]
+    uv = np.stack([K4[0] * pc[:, 0] / pc[:, 2] + K4[2], K4[1] * pc[:, 1] / pc[:, 2] + K4[3]], 1)
+    octv, sc, inv_sigma2 = _octave_inv_sigma2(rng, nobs)
+    obs = uv + rng.normal(0, noise, (nobs, 2)) * sc[:, None]
+    nout = int(round(outlier_frac * nobs))
+    if nout:
+        idx = rng.choice(nobs, nout, replace=False)
+        obs[idx] += rng.choice([-1, 1], (nout, 2)) * rng.uniform(30, 50, (nout, 2))
+    poses0 = poses_gt.copy(); pts0 = pts.copy()
+    if perturb:
+        for c in range(n_fixed, ncam):
+            poses0[c, 3:] = quat_mul(quat_from_rotvec(rng.normal(0, np.deg2rad(0.5) / np.sqrt(3), 3)), poses_gt[c, 3:])
+            poses0[c, :3] += rng.normal(0, 0.05 / np.sqrt(3), 3)
+        pts0 += rng.normal(0, 0.05, (npts, 3))
+    cam_fixed = np.zeros(ncam, np.uint8); cam_fixed[:n_fixed] = 1
+    return dict(K4=np.tile(K4, (ncam, 1)), poses0=poses0, poses_gt=poses_gt, cam_fixed=cam_fixed, pts0=pts0, pts_gt=pts,
+                obs_cam=oc, obs_pt=op, obs_uv=obs, obs_inv_sigma2=inv_sigma2, octave=octv, current=cur, structure=structure)
+
+
 def make_vocabulary(seed, k=10, L=4, flip=40, ragged=0.0, stop_frac=0.02):
     """Synthetic ORB vocabulary tree in the flattened form of include/orbslam_hip.h::orbv_create (stands in for the
     un-shipped ORBvoc.txt, k = 10, L = 6): children descriptors are their parent's with up to `flip` random bits toggled

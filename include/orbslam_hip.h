@@ -571,6 +571,14 @@ int ba_sim3_inverse(const double* a, double* out);
  * and resets them.                                                                                                       */
 int ba_set_profiling(int enable);
 int ba_get_profile(double* device_ms, int* nsolves, int* lm_iterations);
+/* Measurement hook (no reference counterpart): which member of the factorisation family the LAST ba_solve(_batch) /
+ * ba_local_bundle_adjustment(_batch) call of THIS host thread took (INTEGRATION.md section 7 has the decision table).  out12 =
+ * { problems in the call, look-ahead form (0 none, 1 persistent launch k_chol_persist, 2 one workgroup per system k_chol_wg, 3 one
+ * launch per 32-column step k_chol_la), two-level form (0 none, 1 persistent block launches k_chol_persist_blk, 2 hybrid step
+ * kernels, 3 classic, 4 one launch), backward substitution (1 k_chol_bsolve_sky, 2 per super-block), largest padded system of the
+ * look-ahead family, of the two-level family, widest skyline in 32-column tiles, workgroups of the persistent launch per problem,
+ * persistent mode granted by the lease (0 none), a look-ahead system has > 1024 unknowns, every look-ahead system fits k_chol_wg, 0 }. */
+int ba_get_last_plan(int32_t* out12);
 /* Configuration (no reference counterpart): the time limit, in milliseconds, after which a workgroup of the persistent Cholesky
  * kernels stops waiting for another one and the solve ends with ORBHIP_ETIMEOUT / ba_summary.termination 7 (default 5000 ms;
  * ms <= 0 restores the default; resolution 10 ns).  A deployment with a frame deadline may want tens of milliseconds.  Process-wide,

@@ -541,8 +541,11 @@ def test_persistent_cholesky_is_bit_identical():
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for flag in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root], env=dict(os.environ, ORBHIP_BA_PERSIST=flag), capture_output=True, text=True, timeout=600)
+    # "1": the persistent launches; "0" + ORBHIP_BA_WG=0: one launch per 32-column step for every system; "0" alone: the form a solve falls back to
+    # when the lease refuses the persistent launch - step kernels for the systems of <= 32 block rows, ONE k_chol_wg workgroup for the larger
+    # narrow-skyline ones (round 6: the step kernels would walk their dense trailing matrix once per column)
+    for env in ({"ORBHIP_BA_PERSIST": "1"}, {"ORBHIP_BA_PERSIST": "0", "ORBHIP_BA_WG": "0"}, {"ORBHIP_BA_PERSIST": "0"}):
+        r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
     assert len(res[0]) == 13
