@@ -1507,16 +1507,23 @@ int ba_debug_pose_ticks(unsigned long long* out, int reset) {
   if (reset) { static unsigned long long z[8]; ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pose_ticks), z, 64)); }
   return 0;
 }
-int ba_debug_factor_ab(const double* A, double* X1, double* X2, int n, unsigned long long* ticks3) {     // host pointers, 32 x 32 row-major; ticks: [1-wave, 2-wave, bad1, bad2]
-  double *dA = nullptr, *d1 = nullptr, *d2 = nullptr; unsigned long long* dt = nullptr;
-  ORBHIP_CHECK_HIP(hipMalloc(&dA, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&d1, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&d2, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&dt, 32));
-  ORBHIP_CHECK_HIP(hipMemcpy(dA, A, 8192, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_factor_a, dim3(1), dim3(256), 0, 0, dA, d1, n, dt);
-  hipLaunchKernelGGL(k_factor_b, dim3(1), dim3(320), 0, 0, dA, d2, n, dt);
+int ba_debug_df_stamps(unsigned long long* out16, int reset) {      // g_df_stamp[4][4]
   ORBHIP_CHECK_HIP(hipDeviceSynchronize());
-  ORBHIP_CHECK_HIP(hipMemcpy(X1, d1, 8192, hipMemcpyDeviceToHost)); ORBHIP_CHECK_HIP(hipMemcpy(X2, d2, 8192, hipMemcpyDeviceToHost));
-  ORBHIP_CHECK_HIP(hipMemcpy(ticks3, dt, 32, hipMemcpyDeviceToHost));
-  (void)hipFree(dA); (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dt);
+  if (out16) ORBHIP_CHECK_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_df_stamp), 128));
+  if (reset) { static unsigned long long z[16]; ORBHIP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_df_stamp), z, 128)); }
+  return 0;
+}
+int ba_debug_factor_nw(const double* A, double* X, int n, int nw, unsigned long long* ticks2) {     // host pointers, 32 x 32 row-major; ticks2: [10-ns ticks of n factors, bad flag]
+  double *dA = nullptr, *dX = nullptr; unsigned long long* dt = nullptr;
+  ORBHIP_CHECK_HIP(hipMalloc(&dA, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&dX, 8192)); ORBHIP_CHECK_HIP(hipMalloc(&dt, 16));
+  ORBHIP_CHECK_HIP(hipMemcpy(dA, A, 8192, hipMemcpyHostToDevice));
+  if (nw == 1) hipLaunchKernelGGL(k_factor_nw<1>, dim3(1), dim3(256), 0, 0, dA, dX, n, dt);
+  else if (nw == 2) hipLaunchKernelGGL(k_factor_nw<2>, dim3(1), dim3(256), 0, 0, dA, dX, n, dt);
+  else hipLaunchKernelGGL(k_factor_nw<4>, dim3(1), dim3(256), 0, 0, dA, dX, n, dt);
+  ORBHIP_CHECK_HIP(hipDeviceSynchronize());
+  ORBHIP_CHECK_HIP(hipMemcpy(X, dX, 8192, hipMemcpyDeviceToHost));
+  ORBHIP_CHECK_HIP(hipMemcpy(ticks2, dt, 16, hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(dX); (void)hipFree(dt);
   return 0;
 }
 int ba_debug_p2_prof(unsigned long long* out, int reset) {       // [8][128] absolute ticks (100 MHz)
