@@ -736,6 +736,23 @@ def main():
                               "payload_bytes": int(allp.shape[0]) * 24}
                 if nccl_log_dir:
                     collective["rccl"] = rccl_summary(os.path.join(nccl_log_dir, "rccl_rank%d.log" % rank))
+                # the same merge through the C ABI (orbhip_comm_create / orbhip_allgather_landmarks: RCCL directly, what a C++ embedding
+                # of the reference calls) - on real RCCL communicators only (two ranks cannot share a GPU there); never fatal to the line
+                if backend == "nccl" and os.environ.get("ORBHIP_BENCH_CABI_MERGE", "1") != "0":
+                    try:
+                        lc = sharding.LandmarkCommunicator(rank, dist.get_world_size(), dev_ord)
+                        cap_t = torch.tensor([pts.shape[0]], dtype=torch.int64, device=cdev)
+                        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+                        cap_r = int(cap_t.item())
+                        lc.allgather_landmarks(pts, cap_per_rank=cap_r)                  # warm-up
+                        barrier(); tc = time.perf_counter()
+                        cp, _, ccnt = lc.allgather_landmarks(pts, cap_per_rank=cap_r)
+                        tcabi = (time.perf_counter() - tc) * 1e3
+                        collective["c_abi"] = {"entry_point": "orbhip_allgather_landmarks (one ncclAllGather of fixed-size slots)", "ms": tcabi,
+                                               "points_per_rank": [int(x) for x in ccnt], "equals_torch_distributed": bool(torch.equal(cp, allp))}
+                        lc.close()
+                    except Exception as e:
+                        collective["c_abi"] = {"error": repr(e)}
         if isinstance(localba, dict):
             localba.pop("_final_points", None)
     if rank == 0:

@@ -22,6 +22,7 @@ SYMBOLS = [
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log", "ba_sim3_mul", "ba_sim3_inverse",
     "ba_solve_batch", "ba_local_bundle_adjustment_batch", "ba_optimize_essential_graph", "ba_essential_graph_correct",
     "ba_matrix4d_to_pose7", "ba_pose7_to_matrix4d", "ba_set_profiling", "ba_get_profile", "ba_get_last_plan", "ba_set_wait_limit_ms",
+    "orbhip_comm_get_unique_id", "orbhip_comm_create", "orbhip_comm_adopt", "orbhip_comm_info", "orbhip_comm_destroy", "orbhip_allgather_landmarks",
 ]
 
 
@@ -142,6 +143,12 @@ def load():
     L.ba_set_profiling.argtypes = [i32]
     L.ba_get_profile.argtypes = [C.POINTER(f64), C.POINTER(i32), C.POINTER(i32)]
     L.ba_get_last_plan.argtypes = [C.POINTER(i32)]
+    L.orbhip_comm_get_unique_id.argtypes = [vp]
+    L.orbhip_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.orbhip_comm_adopt.argtypes = [vp, i32, C.POINTER(vp)]
+    L.orbhip_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.orbhip_comm_destroy.argtypes = [vp]
+    L.orbhip_allgather_landmarks.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(i32), vp]
     L.ba_set_wait_limit_ms.argtypes = [C.c_double]
     L.orbhip_copy_pinned_async.argtypes = [vp, vp, C.c_size_t, vp]
     L.ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaOptions), vp]

@@ -50,3 +50,58 @@ def allgather_landmarks(local_pts, local_ids=None):
     if local_ids is not None:
         ids = torch.cat([out[r, :counts[r], 3].contiguous().view(torch.int64) for r in range(world)])
     return pts, ids, counts
+
+
+class LandmarkCommunicator:
+    """The C-ABI form of the landmark merge (include/orbslam_hip.h: orbhip_comm_create / orbhip_allgather_landmarks): what a C++
+    embedding of the reference calls - RCCL directly, no torch.distributed in the data path.  The 128-byte RCCL id is made by rank 0
+    and reaches the other ranks through `exchange` (default: torch.distributed's object broadcast, whatever its backend - the id is
+    128 bytes of host data); the collective itself is ONE ncclAllGather of fixed-size slots of `cap_per_rank` landmarks."""
+
+    def __init__(self, rank, world, device, exchange=None):
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        self._lib = _lib; self._C = C; self._L = _lib.load()
+        ident = np.zeros(128, np.uint8)
+        if rank == 0:
+            _lib.check(self._L.orbhip_comm_get_unique_id(_lib.ptr(ident)), "orbhip_comm_get_unique_id")
+        if world > 1:
+            if exchange is None:
+                box = [ident.tobytes()]
+                dist.broadcast_object_list(box, src=0)
+                ident = np.frombuffer(box[0], np.uint8).copy()
+            else:
+                ident = np.frombuffer(exchange(ident.tobytes()), np.uint8).copy()
+        h = C.c_void_p()
+        _lib.check(self._L.orbhip_comm_create(_lib.ptr(ident), world, rank, device, C.byref(h)), "orbhip_comm_create")
+        self._h = h; self.rank = rank; self.world = world; self.device = device
+
+    def allgather_landmarks(self, local_pts, local_ids=None, cap_per_rank=None, cap_all=None):
+        """local_pts (n, 3) float64 CUDA tensor, local_ids optional (n,) int64.  Returns (pts_all, ids_all or None, counts per rank)."""
+        _lib, C = self._lib, self._C
+        n = int(local_pts.shape[0])
+        cap = int(cap_per_rank if cap_per_rank is not None else max(n, 1))
+        cap_all = int(cap_all if cap_all is not None else cap * self.world)
+        dev = local_pts.device
+        pts = local_pts.contiguous()
+        out = torch.empty((cap_all, 3), dtype=torch.float64, device=dev)
+        ids = local_ids.contiguous() if local_ids is not None else None
+        ids_out = torch.empty((cap_all,), dtype=torch.int64, device=dev) if local_ids is not None else None
+        counts = (C.c_int32 * self.world)(); total = C.c_int(0)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self._L.orbhip_allgather_landmarks(self._h, _lib.ptr(pts), _lib.ptr(ids) if ids is not None else None, n, cap, _lib.ptr(out),
+                                                      _lib.ptr(ids_out) if ids_out is not None else None, cap_all, counts, C.byref(total), C.c_void_p(st)),
+                   "orbhip_allgather_landmarks")
+        m = total.value
+        return out[:m], (ids_out[:m] if ids_out is not None else None), list(counts)
+
+    def close(self):
+        if self._h:
+            self._L.orbhip_comm_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

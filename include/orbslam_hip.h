@@ -613,6 +613,29 @@ int ba_local_bundle_adjustment(const double* K4_per_cam, double* poses7, const u
                                int duplicate_blocks, uint8_t* obs_erase, int* aborted, ba_summary* pass1,
                                ba_summary* pass2);
 
+/* ---- multi-GPU: the landmark merge (north_star: "a single RCCL all-gather over xGMI to merge landmark updates") ----
+ * One process per GPU, one sub-map per rank; frames and BA sub-problems shard with NO data-path collective.  The one exchange is the
+ * merge of the landmark updates after a batched GlobalBA, so that every rank holds the whole map (the reference is one process,
+ * src/MonoORBSlam.cc:52-100, src/System.cc: a multi-GPU embedding calls this from the thread that owns the map - LoopClosing's
+ * RunGlobalBundleAdjustment, src/LoopClosing.cc:656-740, is where a sub-map's GlobalBA ends).
+ * RCCL is looked up at run time (dlopen "librccl.so" or $ORBHIP_RCCL_LIB): liborbslam_hip.so does not link against it.
+ *   orbhip_comm_get_unique_id   rank 0 makes the 128-byte id and hands it to the other ranks by whatever the embedding uses (MPI, a file, a socket)
+ *   orbhip_comm_create          ncclCommInitRank on `device`; collective: every rank calls it with the same id and world size (<= 64)
+ *   orbhip_comm_adopt           wraps an ncclComm_t the caller already owns (not destroyed by orbhip_comm_destroy)
+ *   orbhip_allgather_landmarks  ONE ncclAllGather: every rank contributes a slot { count, cap_per_rank x (X, Y, Z[, id]) } - the sub-maps
+ *                               are ragged, cap_per_rank is the bound the ranks agree on (ORBHIP_ECAP when n_local exceeds it) - and gets
+ *                               the landmarks of all ranks, dense, in rank order: d_pts3_all [cap_all x 3], d_ids_all [cap_all] (NULL on
+ *                               both sides when the landmarks carry no ids), counts_out [world size] (host), *n_all = their sum.
+ *                               Device pointers; runs on `stream` and synchronises it.  ORBHIP_ECAP when n_all > cap_all.            */
+typedef struct orbhip_comm orbhip_comm;
+int orbhip_comm_get_unique_id(uint8_t* id128);
+int orbhip_comm_create(const uint8_t* id128, int world_size, int rank, int device, orbhip_comm** out);
+int orbhip_comm_adopt(void* nccl_comm, int device, orbhip_comm** out);
+int orbhip_comm_info(const orbhip_comm* comm, int* world_size, int* rank);
+int orbhip_comm_destroy(orbhip_comm* comm);
+int orbhip_allgather_landmarks(orbhip_comm* comm, const double* d_pts3_local, const int64_t* d_ids_local, int n_local, int cap_per_rank,
+                               double* d_pts3_all, int64_t* d_ids_all, int cap_all, int32_t* counts_out, int* n_all, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,24 @@ def test_header_symbols_are_exported(lib):
     assert set(declared) <= exported
 
 
+def test_landmark_merge_entry_points_validate_their_arguments(lib):
+    """orbhip_comm_* / orbhip_allgather_landmarks (multi-GPU, csrc/orb_comm.hip): argument errors are reported before any device or RCCL
+    call; without a GPU the communicator cannot be created (no CPU fallback)."""
+    L = lib.load()
+    h = C.c_void_p()
+    ident = np.zeros(128, np.uint8)
+    assert L.orbhip_comm_create(None, 1, 0, 0, C.byref(h)) == -1                       # ORBHIP_EINVAL
+    assert L.orbhip_comm_create(lib.ptr(ident), 0, 0, 0, C.byref(h)) == -1
+    assert L.orbhip_comm_create(lib.ptr(ident), 2, 2, 0, C.byref(h)) == -1
+    assert L.orbhip_comm_create(lib.ptr(ident), 65, 0, 0, C.byref(h)) == -1
+    assert L.orbhip_allgather_landmarks(None, None, None, 0, 1, None, None, 0, None, None, None) == -1
+    assert L.orbhip_comm_info(None, None, None) == -1
+    assert L.orbhip_comm_destroy(None) == 0
+    if not os.path.exists("/dev/kfd"):
+        assert L.orbhip_comm_create(lib.ptr(ident), 1, 0, 0, C.byref(h)) == -2               # ORBHIP_ENODEV
+        assert b"no HIP device" in L.orbhip_last_error()
+
+
 def test_struct_layouts(lib):
     from ceres_mono_orb_slam2_amd import KP_DTYPE
     assert KP_DTYPE.itemsize == 28                            # cv::KeyPoint

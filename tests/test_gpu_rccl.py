@@ -33,6 +33,55 @@ def test_allgather_landmarks_on_rccl_world_size_1():
         dist.destroy_process_group()
 
 
+_CABI_SCRIPT = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from ceres_mono_orb_slam2_amd import sharding
+from ceres_mono_orb_slam2_amd._lib import OrbHipError
+dev = torch.device("cuda", 0)
+lc = sharding.LandmarkCommunicator(0, 1, 0)
+rng = np.random.default_rng(3)
+pts = torch.from_numpy(rng.normal(size=(4321, 3))).to(dev); ids = torch.arange(4321, dtype=torch.int64, device=dev) * 3 + 11
+out = {}
+p, i, c = lc.allgather_landmarks(pts, ids, cap_per_rank=5000)
+out["with_ids"] = bool(c == [4321] and torch.equal(p, pts) and torch.equal(i, ids) and p.is_cuda)
+p, i, c = lc.allgather_landmarks(pts, None, cap_per_rank=4321)
+out["no_ids"] = bool(c == [4321] and torch.equal(p, pts) and i is None)
+p, i, c = lc.allgather_landmarks(pts[:0], None, cap_per_rank=16)
+out["empty"] = bool(c == [0] and p.shape[0] == 0)
+try:
+    lc.allgather_landmarks(pts, ids, cap_per_rank=100); out["cap_refused"] = False
+except OrbHipError as e:
+    out["cap_refused"] = "cap_per_rank" in str(e)
+try:
+    lc.allgather_landmarks(pts, ids, cap_per_rank=5000, cap_all=1000); out["cap_all_refused"] = False
+except OrbHipError as e:
+    out["cap_all_refused"] = True
+# the torch.distributed twin on the same data (RCCL at world size 1)
+import os, torch.distributed as dist
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29541"
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+tp, ti, tc = sharding.allgather_landmarks(pts, ids)
+p, i, c = lc.allgather_landmarks(pts, ids, cap_per_rank=4321)
+out["equals_torch_distributed"] = bool(torch.equal(tp, p) and torch.equal(ti, i) and tc == c)
+dist.destroy_process_group()
+lc.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_c_abi_landmark_merge_on_rccl_world_size_1():
+    """orbhip_comm_create + orbhip_allgather_landmarks (csrc/orb_comm.hip): the one collective of the hot path from the C ABI - RCCL
+    looked up at run time, ONE ncclAllGather of fixed-size slots, a dense rank-ordered output - against sharding.allgather_landmarks on
+    the same data; ragged / empty / over-capacity inputs.  (World size 1: the GPU box has one GPU and RCCL refuses two ranks on a device;
+    bench.py runs the same entry point at N > 1 beside the torch.distributed merge and records whether they agree.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _CABI_SCRIPT, ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert all(out.values()), out
+
+
 def test_bench_under_torchrun_uses_rccl():
     env = dict(os.environ, ORBHIP_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29537",
@@ -45,6 +94,7 @@ def test_bench_under_torchrun_uses_rccl():
     c = j["collective"]
     assert c["backend"] == "nccl (RCCL)" and c["world_size"] == 1 and c["merged_points"] == c["points_per_rank"][0] > 0
     assert "rccl" in c and (c["rccl"].get("nranks") == 1 or "error" in c["rccl"] or c["rccl"]["channel_lines"] >= 0), c.get("rccl")
+    assert c["c_abi"].get("equals_torch_distributed") is True and c["c_abi"]["points_per_rank"] == c["points_per_rank"], c["c_abi"]
 
 
 def test_bench_two_ranks_shared_gpu_merges_both_ranks_landmarks(tmp_path):

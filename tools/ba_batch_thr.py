@@ -1,8 +1,10 @@
-"""LocalBA (C4 size) throughput: batch size B per call x T host threads.  usage: ba_batch_thr.py B:T[:N] [B:T[:N] ...]"""
+"""LocalBA (C4 size) throughput: batch size B per call x T host threads.  usage: [ORBHIP_BENCH_STRUCTURE=band|covis|dense] ba_batch_thr.py B:T[:N] [B:T[:N] ...]"""
 import numpy as np, sys, time, os, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ceres_mono_orb_slam2_amd import synth, optimizer
-gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(16)]      # as bench.py: gauge keyframe only, 16 distinct local maps
+ST = os.environ.get("ORBHIP_BENCH_STRUCTURE", "band")      # band (SURVEY 8(d)'s odometry band, as bench.py's c4_batched) | covis | dense (synth.make_ba_graph_covis)
+gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) if ST == "band" else
+      synth.make_ba_graph_covis(100 + s, ncam=100, npts=10000, nobs=50000, structure=ST) for s in range(16)]      # as bench.py: gauge keyframe only, 16 distinct local maps
 local = np.ones(100, np.uint8)
 def prob(g): return (g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
 for spec in sys.argv[1:]:

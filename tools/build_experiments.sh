@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 O=tools/exp_lib; mkdir -p $O
 C=ceres_mono_orb_slam2_amd/csrc
 objs=""
-for f in capi_common orb_extractor orb_matcher orb_frame orb_vocab ba_solver orb_track orb_localmap; do
+for f in capi_common orb_extractor orb_matcher orb_frame orb_vocab ba_solver orb_track orb_localmap orb_comm; do
   X=""; [ $f = orb_extractor ] && X="-mllvm -amdgpu-mfma-vgpr-form"      # (as __graft_entry__.EXTRA_FLAGS)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DORBHIP_EXPERIMENTS -Itools $X "$@" -c $C/$f.hip -o $O/$f.o || exit 1
   objs="$objs $O/$f.o"
@@ -18,5 +18,5 @@ done
 L=ceres_mono_orb_slam2_amd/lib
 if [ -f $L/capi_common.o ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DORBHIP_SCHUR_PROF -c $C/ba_solver.hip -o $O/ba_solver_sprof.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/liborbslam_hip_sprof.so $L/capi_common.o $L/orb_extractor.o $L/orb_matcher.o $L/orb_frame.o $L/orb_vocab.o $O/ba_solver_sprof.o $L/orb_track.o $L/orb_localmap.o && echo "built $O/liborbslam_hip_sprof.so"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/liborbslam_hip_sprof.so $L/capi_common.o $L/orb_extractor.o $L/orb_matcher.o $L/orb_frame.o $L/orb_vocab.o $O/ba_solver_sprof.o $L/orb_track.o $L/orb_localmap.o $L/orb_comm.o && echo "built $O/liborbslam_hip_sprof.so"
 fi

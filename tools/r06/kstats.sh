@@ -1,0 +1,10 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06; mkdir -p $O
+for st in covis dense; do
+  rm -rf $O/lbaprof_$st
+  ORBHIP_BENCH_STRUCTURE=$st rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/lbaprof_$st -o run -- timeout 600 python tools/ba_batch_thr.py 64:1 > $O/lbaprof_$st.log 2>&1 || tail -5 $O/lbaprof_$st.log
+  db=$(find $O/lbaprof_$st -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocpd_stats.py $db $O/localba_batch64_${st}_kernel_stats.csv && python tools/kstats_print.py $O/localba_batch64_${st}_kernel_stats.csv | head -12
+  rm -rf $O/lbaprof_$st
+done
