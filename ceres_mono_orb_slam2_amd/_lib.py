@@ -22,7 +22,7 @@ SYMBOLS = [
     "ba_local_bundle_adjustment", "ba_optimize_sim3", "ba_optimize_sim3_batch_device", "ba_sim3_exp", "ba_sim3_log", "ba_sim3_mul", "ba_sim3_inverse",
     "ba_solve_batch", "ba_local_bundle_adjustment_batch", "ba_optimize_essential_graph", "ba_essential_graph_correct",
     "ba_matrix4d_to_pose7", "ba_pose7_to_matrix4d", "ba_set_profiling", "ba_get_profile", "ba_get_last_plan", "ba_set_wait_limit_ms",
-    "orbhip_comm_get_unique_id", "orbhip_comm_create", "orbhip_comm_adopt", "orbhip_comm_info", "orbhip_comm_destroy", "orbhip_allgather_landmarks",
+    "orbl_fuse_batch_sim3", "orbhip_comm_get_unique_id", "orbhip_comm_create", "orbhip_comm_adopt", "orbhip_comm_info", "orbhip_comm_destroy", "orbhip_allgather_landmarks",
 ]
 
 

@@ -103,6 +103,7 @@ class ORBmatcherT {
   typedef typename Types::Frame Frame;
   typedef typename Types::KeyFrame KeyFrame;
   typedef typename Types::MapPoint MapPoint;
+  typedef typename Types::Map Map;
   typedef typename Types::Matrix3d Matrix3d;
   typedef typename Types::Matrix4d Matrix4d;
   typedef typename Types::Vector3d Vector3d;
@@ -569,6 +570,82 @@ class ORBmatcherT {
       nFused++;
     }
     return nFused;
+  }
+
+  // ---- LoopClosing::SearchAndFuse, the whole loop (src/LoopClosing.cc:599-630):
+  //        for (corrected keyframes) { matcher.Fuse(keyframe, Scw, loop_map_points_, 4, replace); lock map; for (i) if (replace[i]) replace[i]->Replace(loop_map_points_[i]); }
+  //      with the candidate selection of ALL keyframes in ONE call (orbl_fuse_batch_sim3, round 6).  Projection and gates are evaluated per
+  //      (keyframe, point) up front - they read what no Fuse / Replace changes (the corrected Sim(3), positions, normals, distance bounds) -;
+  //      what a keyframe's turn CAN see of the turns before it is re-read when its turn comes: isBad (a loop point that was itself some
+  //      keyframe's duplicate has been replaced), GetMapPoints() (Replace hands the replaced point's observations to the loop point: a
+  //      later keyframe may already hold it), GetMapPoint(bestIdx), and the loop point's descriptor (Replace ends with
+  //      ComputeDistinctiveDescriptors on the survivor, src/MapPoint.cc:230): a point whose descriptor no longer equals the one the
+  //      batch searched with is searched again, alone, for the keyframe at hand.  `corrected` in the reference's iteration order
+  //      (KeyFrameAndSim3 is a std::map ordered by keyframe pointer), Scw as Sophus::Sim3d::matrix().  Returns Fuse's value per keyframe.
+  std::vector<int> SearchAndFuse(const std::vector<std::pair<KeyFrame*, Matrix4d>>& corrected, const std::vector<MapPoint*>& loop_map_points, Map* map, const float th = 4.0) {
+    using namespace dropin;
+    const size_t nt = corrected.size(), nq = loop_map_points.size();
+    std::vector<int> ret(nt, 0);
+    if (!nt || !nq) return ret;
+    std::vector<float> uv(2 * nt * nq, 0.f), radius(nt * nq, 0.f); std::vector<int32_t> level(nt * nq, -1);
+    std::vector<uint8_t> desc(32 * nq, 0);
+    for (size_t i = 0; i < nq; i++) std::memcpy(&desc[32 * i], loop_map_points[i]->GetDescriptor().ptr(0), 32);
+    std::vector<Flat> T(nt); std::vector<orbl_fuse_keyframe> kf(nt);
+    int n_levels = 1;
+    for (size_t t = 0; t < nt; t++) {
+      KeyFrame* pKF = corrected[t].first;
+      const Sim3Cam C = decompose(corrected[t].second);
+      n_levels = std::max(n_levels, (int)pKF->scale_factors_.size());
+      for (size_t i = 0; i < nq; i++) {
+        float u, v, dist; int lv;
+        if (!project_with_gates(pKF, C, loop_map_points[i], 0.0f, true, &u, &v, &dist, &lv)) continue;
+        const size_t e = t * nq + i;
+        uv[2 * e] = u; uv[2 * e + 1] = v; radius[e] = th * pKF->scale_factors_[lv]; level[e] = lv;
+      }
+      flatten(*pKF, &T[t]);
+      kf[t].kps = T[t].kps4.data(); kf[t].desc = T[t].desc; kf[t].n = T[t].n;
+      for (int k = 0; k < 4; k++) kf[t].bounds[k] = T[t].bounds[k];
+    }
+    std::vector<int32_t> best_idx(nt * nq, -1), best_dist(nt * nq, 256);
+    check(orbl_fuse_batch_sim3(kf.data(), (int)nt, uv.data(), radius.data(), level.data(), (int)nq, desc.data(), n_levels, best_idx.data(), best_dist.data()),
+          "orbl_fuse_batch_sim3");
+    for (size_t t = 0; t < nt; t++) {
+      KeyFrame* pKF = corrected[t].first;
+      std::vector<MapPoint*> replace_map_points(nq, static_cast<MapPoint*>(nullptr));
+      const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+      int nFused = 0;
+      for (size_t i = 0; i < nq; i++) {
+        MapPoint* pMP = loop_map_points[i];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        const size_t e = t * nq + i;
+        if (level[e] < 0) continue;
+        int bestIdx = best_idx[e], bestDist = best_dist[e];
+        if (std::memcmp(&desc[32 * i], pMP->GetDescriptor().ptr(0), 32) != 0) {      // the descriptor changed since the batch: this point, this keyframe, again
+          Queries Q(1);
+          Q.valid[0] = 1; Q.uv[0] = uv[2 * e]; Q.uv[1] = uv[2 * e + 1]; Q.radius[0] = radius[e]; Q.pred[0] = level[e];
+          Q.set_desc(0, pMP->GetDescriptor());
+          int32_t m1 = -1, d1 = 256; int n1 = 0;
+          check(orbm_search_by_projection(T[t].kps4.data(), T[t].desc, T[t].n, T[t].bounds, Q.uv.data(), Q.radius.data(), nullptr, nullptr, Q.pred.data(), Q.desc.data(),
+                                          Q.valid.data(), nullptr, 1, nullptr, 0.f, nullptr, 0, mfNNratio, 256, 0, &m1, &d1, &n1),
+                "orbm_search_by_projection");
+          bestIdx = m1; bestDist = d1;
+        }
+        if (bestIdx < 0 || bestDist > TH_LOW) continue;
+        MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+        if (pMPinKF) {
+          if (!pMPinKF->isBad()) replace_map_points[i] = pMPinKF;
+        } else {
+          pMP->AddObservation(pKF, bestIdx);
+          pKF->AddMapPoint(pMP, bestIdx);
+        }
+        nFused++;
+      }
+      ret[t] = nFused;
+      std::unique_lock<std::mutex> lock(map->mutex_map_update_);     // "Get Map Mutex" (:617)
+      for (size_t i = 0; i < nq; i++)
+        if (replace_map_points[i]) replace_map_points[i]->Replace(loop_map_points[i]);
+    }
+    return ret;
   }
 
  protected:

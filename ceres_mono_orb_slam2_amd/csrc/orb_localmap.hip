@@ -145,8 +145,9 @@ struct alignas(8) LfQuery { float u, v, radius; int32_t level; };       // level
 // one wave per (keyframe, map point): KeyFrame::GetFeaturesInArea(u, v, r) over the keyframe's grid (src/KeyFrame.cc:575-622: cells in
 // (ix, iy) order, a cell's features in list order), level in [pred - 1, pred], chi-square gate e2 * inv_level_sigma2 <= 5.99, least
 // descriptor distance, the FIRST of equal ones in that order (:799 `dist < bestDist`)
+// chi2_gate = 0: the Sim(3) form of LoopClosing::SearchAndFuse (src/ORBmatcher.cc:844-954), which has no reprojection gate
 __global__ __launch_bounds__(256) void k_lf_select(const uint8_t* __restrict__ base, const LfKf* __restrict__ kfs, int M, const uint32_t* __restrict__ mp_desc,
-                                                   const float* __restrict__ inv_level_sigma2, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist) {
+                                                   const float* __restrict__ inv_level_sigma2, int chi2_gate, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist) {
   const int t = blockIdx.y, lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= M) return;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void k_lf_select(const uint8_t* __restrict__ b
             if (in && !(lvl < Q.level - 1 || lvl > Q.level)) {   // (:781)
               const float ex = Q.u - kx, ey = Q.v - ky;
               const float e2 = ex * ex + ey * ey;
-              if (!((double)(e2 * inv_level_sigma2[lvl]) > 5.99)) {                   // (:789)
+              if (!chi2_gate || !((double)(e2 * inv_level_sigma2[lvl]) > 5.99)) {     // (:789)
                 const unsigned long long key = ((unsigned long long)(unsigned)lm_hamming(d1, desc + 8 * (size_t)idx) << 32) |
                                                (unsigned long long)(order + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)));
                 if (key < mine) { mine = key; mine_idx = idx; }
@@ -314,11 +315,13 @@ int orbl_create_new_map_points(const float* kps1, const uint8_t* desc1, const ui
   return 0;
 }
 
-int orbl_fuse_batch(const orbl_fuse_keyframe* kf, int n_kf, const float* q_uv, const float* q_radius, const int32_t* q_level, int n_mp, const uint8_t* mp_desc,
-                    const float* inv_level_sigma2, int n_levels, int32_t* best_idx, int32_t* best_dist) {
+static int fuse_batch_impl(const orbl_fuse_keyframe* kf, int n_kf, const float* q_uv, const float* q_radius, const int32_t* q_level, int n_mp, const uint8_t* mp_desc,
+                           const float* inv_level_sigma2, int n_levels, int chi2_gate, int32_t* best_idx, int32_t* best_dist) {
   ORBHIP_REQUIRE(n_kf >= 0 && n_mp >= 0 && n_levels > 0, ORBHIP_EINVAL, "bad size");
   if (n_kf == 0 || n_mp == 0) return 0;
-  ORBHIP_REQUIRE(kf && q_uv && q_radius && q_level && mp_desc && inv_level_sigma2 && best_idx && best_dist, ORBHIP_EINVAL, "NULL argument");
+  ORBHIP_REQUIRE(kf && q_uv && q_radius && q_level && mp_desc && (inv_level_sigma2 || !chi2_gate) && best_idx && best_dist, ORBHIP_EINVAL, "NULL argument");
+  std::vector<float> no_gate;
+  if (!inv_level_sigma2) { no_gate.assign((size_t)n_levels, 0.f); inv_level_sigma2 = no_gate.data(); }
   ThreadWs& W = thread_ws();
   int rc = W.begin();
   if (rc) return rc;
@@ -362,13 +365,23 @@ int orbl_fuse_batch(const orbl_fuse_keyframe* kf, int n_kf, const float* q_uv, c
   int32_t* d_out = W.d<int32_t>(2 * (size_t)n_kf * n_mp, &rc);
   if (rc || (rc = W.commit(in))) return rc;
   hipLaunchKernelGGL(k_lf_select, dim3((n_mp + 3) / 4, n_kf), dim3(256), 0, W.s, (const uint8_t*)in.dbase, in.dev<LfKf>(pF), n_mp, in.dev<uint32_t>(pD), in.dev<float>(pS),
-                     d_out, d_out + (size_t)n_kf * n_mp);
+                     chi2_gate, d_out, d_out + (size_t)n_kf * n_mp);
   ORBHIP_CHECK_HIP(hipGetLastError());
   const int32_t* h = W.down(d_out, 2 * (size_t)n_kf * n_mp, &rc);
   if (rc || (rc = W.sync())) return rc;
   std::memcpy(best_idx, h, 4 * (size_t)n_kf * n_mp);
   std::memcpy(best_dist, h + (size_t)n_kf * n_mp, 4 * (size_t)n_kf * n_mp);
   return 0;
+}
+
+int orbl_fuse_batch(const orbl_fuse_keyframe* kf, int n_kf, const float* q_uv, const float* q_radius, const int32_t* q_level, int n_mp, const uint8_t* mp_desc,
+                    const float* inv_level_sigma2, int n_levels, int32_t* best_idx, int32_t* best_dist) {
+  return fuse_batch_impl(kf, n_kf, q_uv, q_radius, q_level, n_mp, mp_desc, inv_level_sigma2, n_levels, 1, best_idx, best_dist);
+}
+
+int orbl_fuse_batch_sim3(const orbl_fuse_keyframe* kf, int n_kf, const float* q_uv, const float* q_radius, const int32_t* q_level, int n_mp, const uint8_t* mp_desc,
+                         int n_levels, int32_t* best_idx, int32_t* best_dist) {
+  return fuse_batch_impl(kf, n_kf, q_uv, q_radius, q_level, n_mp, mp_desc, nullptr, n_levels, 0, best_idx, best_dist);
 }
 
 }  // extern "C"

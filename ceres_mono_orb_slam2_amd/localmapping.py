@@ -78,8 +78,9 @@ def create_new_map_points(cur, neighbours, scale_factors, level_sigma2, ratio_fa
     return prepare_create_new_map_points(cur, neighbours, scale_factors, level_sigma2, ratio_factor, stop)()
 
 
-def fuse_batch(keyframes, q_uv, q_radius, q_level, mp_desc, inv_level_sigma2):
-    """ORBmatcher::Fuse candidate selection for T keyframes x M map points (orbl_fuse_batch).  keyframes: dicts(kps[n,4], desc[n,32],
+def fuse_batch(keyframes, q_uv, q_radius, q_level, mp_desc, inv_level_sigma2, sim3=False, n_levels=8):
+    """ORBmatcher::Fuse candidate selection for T keyframes x M map points (orbl_fuse_batch; sim3=True: orbl_fuse_batch_sim3, the form of
+    LoopClosing::SearchAndFuse without the chi-square gate, inv_level_sigma2 unused).  keyframes: dicts(kps[n,4], desc[n,32],
     bounds[4]); q_uv[T,M,2], q_radius[T,M], q_level[T,M] (-1: not projected), mp_desc[M,32].  Returns (best_idx[T,M], best_dist[T,M])."""
     L = _lib.load()
     keep = []
@@ -93,8 +94,14 @@ def fuse_batch(keyframes, q_uv, q_radius, q_level, mp_desc, inv_level_sigma2):
         kf[t].bounds[:] = _c(q["bounds"], np.float32).tolist()
     uv = _c(q_uv, np.float32).reshape(T, -1, 2); M = uv.shape[1]
     rad = _c(q_radius, np.float32).reshape(T, M); lvl = _c(q_level, np.int32).reshape(T, M)
-    md = _c(mp_desc, np.uint8).reshape(M, 32); ils = _c(inv_level_sigma2, np.float32)
+    md = _c(mp_desc, np.uint8).reshape(M, 32)
     bi = np.full((max(T, 1), max(M, 1)), -1, np.int32); bd = np.full((max(T, 1), max(M, 1)), 256, np.int32)
+    if sim3:
+        L.orbl_fuse_batch_sim3.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.check(L.orbl_fuse_batch_sim3(C.cast(kf, C.c_void_p), T, _addr(uv), _addr(rad), _addr(lvl), M, _addr(md), int(n_levels), _addr(bi), _addr(bd)),
+                   "orbl_fuse_batch_sim3")
+        return bi[:T, :M], bd[:T, :M]
+    ils = _c(inv_level_sigma2, np.float32)
     L.orbl_fuse_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib.check(L.orbl_fuse_batch(C.cast(kf, C.c_void_p), T, _addr(uv), _addr(rad), _addr(lvl), M, _addr(md), _addr(ils), len(ils), _addr(bi), _addr(bd)),
                "orbl_fuse_batch")

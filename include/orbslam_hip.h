@@ -375,6 +375,14 @@ typedef struct orbl_fuse_keyframe {
 int orbl_fuse_batch(const orbl_fuse_keyframe* keyframes, int n_keyframes, const float* q_uv, const float* q_radius, const int32_t* q_level,
                     int n_map_points, const uint8_t* mp_desc, const float* inv_level_sigma2, int n_levels, int32_t* best_idx,
                     int32_t* best_dist);
+/* ---- LoopClosing::SearchAndFuse (src/LoopClosing.cc:599-630): the candidate selection of ORBmatcher::Fuse(KeyFrame*, Scw, points, th,
+ * replace) (src/ORBmatcher.cc:844-954) for ALL corrected keyframes of a loop closure in ONE call.  As orbl_fuse_batch, without the
+ * chi-square gate (the Sim(3) form has none): the caller projects with the CORRECTED Sim(3) of every keyframe (Rcw = sRcw / s,
+ * tcw = t / s, :854-859) and keeps the gates :873-906; best_idx / best_dist as above; `bestDist <= TH_LOW`, vpReplacePoint /
+ * AddObservation and the Replace loop under the map mutex stay with the caller, keyframe after keyframe (csrc/compat/orbslam_dropin.h:
+ * ORBmatcher::SearchAndFuse re-queries a point whose descriptor a Replace recomputed and re-reads GetMapPoints() per keyframe).   */
+int orbl_fuse_batch_sim3(const orbl_fuse_keyframe* keyframes, int n_keyframes, const float* q_uv, const float* q_radius, const int32_t* q_level,
+                         int n_points, const uint8_t* mp_desc, int n_levels, int32_t* best_idx, int32_t* best_dist);
 
 /* ---- the per-frame Tracking step with the motion model, device-resident (src/Tracking.cc:616-646): Frame construction
  * (ORBextractor::operator(), AssignFeaturesToGrid; zero distortion: the undistorted keypoints are the raw ones, as for the

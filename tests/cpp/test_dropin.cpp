@@ -97,6 +97,7 @@ template <class Setup, class Call> static void run_case(const std::string& name,
 int main(int argc, char** argv) {
   if (argc < 2) { printf("usage: test_dropin <outdir>\n"); return 2; }
   g_out = argv[1];
+  setvbuf(stdout, nullptr, _IOLBF, 0);                           // (a crash must not take the log of the cases before it along)
   printf("device count %d\n", orbhip_device_count());
   if (orbhip_device_count() <= 0) { printf("no HIP device: the drop-in shims have no CPU fallback\n"); return 2; }
 
@@ -418,6 +419,44 @@ int main(int argc, char** argv) {
     const int ret = matcher.Fuse(keyframe, eig_Scw, loop_map_points_, 4, replace_map_points);
     W.iscalar("ret", ret); W.i32("out.replace", I.mps(replace_map_points));
     printf("Fuse(KF, Scw, points, 4, replace): %d fused\n", ret);
+  });
+
+  // ---- LoopClosing::SearchAndFuse, the whole loop over the corrected keyframes (src/LoopClosing.cc:599-630) through the batched form (one
+  //      orbl_fuse_batch_sim3 call): every keyframe lost some matches and holds duplicates of loop points, so Replace runs between the
+  //      keyframes - the loop points take over observations in LATER keyframes (spAlreadyFound must be re-read) and their descriptors
+  //      are recomputed (those points are searched again)
+  run_case("search_and_fuse", 32, 6, [&](Scene& S) {
+    int n_dup = 0;                                                 // (make_duplicate takes its spare points from the end of the scene's vector: a bounded number)
+    for (int k : {1, 2, 3, 4}) {
+      KeyFrame* keyframe = &S.kfs[k];
+      for (int i = 0; i < keyframe->N_; i++) {
+        MapPoint* p = keyframe->map_points_[i];
+        if (!p) continue;
+        if ((i + k) % 3 == 0) { keyframe->map_points_[i] = nullptr; p->EraseObservation(keyframe); }
+        else if ((i + k) % 6 == 1 && p->n_observations_ > 1 && n_dup < 80) { make_duplicate(S, keyframe, i, ((i + k) % 12 == 1) ? 1 : 4); n_dup++; }
+      }
+    }
+  }, [&](Scene& S, Writer& W, std::vector<MapPoint*>&) {
+    const sceneio::Index I(S);
+    Map* map_ = &S.map;
+    std::vector<std::pair<KeyFrame*, Matrix4d>> CorrectedPosesMap;
+    std::vector<int32_t> order = {2, 4, 1, 3};
+    std::vector<double> scws;
+    for (int k : order) {
+      KeyFrame* keyframe = &S.kfs[k];
+      Matrix4d eig_Scw = keyframe->GetPose();
+      const double sc = 0.95 + 0.01 * k;
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) eig_Scw(r, c) *= sc;
+      CorrectedPosesMap.push_back(std::make_pair(keyframe, eig_Scw));
+      for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) scws.push_back(eig_Scw(r, c));
+    }
+    std::vector<MapPoint*> loop_map_points_;
+    for (MapPoint& mp : S.mps) if (mp.n_observations_ > 0 && !mp.isBad() && (mp.id_ % 3) != 2) loop_map_points_.push_back(&mp);
+    W.i32("arg.kfs", order); W.f64("arg.Scws", scws); W.i32("arg.points", I.mps(loop_map_points_));
+    ORBmatcher matcher(0.8);
+    const std::vector<int> ret = matcher.SearchAndFuse(CorrectedPosesMap, loop_map_points_, map_);
+    W.i32("ret", std::vector<int32_t>(ret.begin(), ret.end()));
+    printf("SearchAndFuse(%zu KFs, %zu loop points): %d %d %d %d fused\n", ret.size(), loop_map_points_.size(), ret[0], ret[1], ret[2], ret[3]);
   });
 
   // ---- Tracking: CeresOptimizer::PoseOptimization(&current_frame_)  (src/Tracking.cc:587,646,684,1074)

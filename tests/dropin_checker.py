@@ -1111,6 +1111,21 @@ def check_case(path, oracle):
         ret, rep = fuse_sim3(S, ki, S.kfs[ki], R["arg.Scw"].reshape(4, 4), [int(p) for p in R["arg.points"]], 4.0)
         expect("ret", int(_sc(R, "ret")), ret); expect("replace", R["out.replace"].tolist(), rep); info = "%d fused, %d to replace" % (ret, sum(r >= 0 for r in rep))
         if ret < 20: fails.append("weak case: %d fused" % ret)
+    elif name == "search_and_fuse":                             # LoopClosing::SearchAndFuse (src/LoopClosing.cc:599-630): Fuse, then the Replace loop, keyframe after keyframe
+        pts = [int(p) for p in R["arg.points"]]
+        Scws = R["arg.Scws"].reshape(-1, 4, 4)
+        rets = []; nrep = 0
+        for ki, Scw in zip(R["arg.kfs"], Scws):
+            ret, rep = fuse_sim3(S, int(ki), S.kfs[int(ki)], Scw, pts, 4.0)
+            rets.append(ret)
+            for k, q in enumerate(rep):
+                if q >= 0:
+                    S.replace(q, pts[k]); nrep += 1
+        expect("ret", [int(v) for v in R["ret"]], rets)
+        before = Scene(R, "before")
+        changed = sum(1 for a, b in zip(S.mp_desc, before.mp_desc) if not np.array_equal(a, b))
+        info = "%s fused per keyframe, %d replaced, %d descriptors recomputed" % (rets, nrep, changed)
+        if sum(rets) < 60 or nrep < 10 or changed < 3: fails.append("weak case: %s fused, %d replaced, %d descriptors changed" % (rets, nrep, changed))
     elif name.startswith("pose_optimization"):
         F = S.frames[int(_sc(R, "arg.frame"))]
         ret = pose_optimization(S, oracle, F)

@@ -123,7 +123,7 @@ def test_reference_signature_dropin_classes(oracle, tmp_path):
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     cases = sorted(os.listdir(out))
-    assert len(cases) == 25, cases
+    assert len(cases) == 26, cases
     failures = []
     for c in cases:
         fails, info = dropin_checker.check_case(str(out / c), oracle)

@@ -194,6 +194,14 @@ def test_fuse_batch_vs_oracle(oracle, seed):
         assert np.array_equal(bd[t], obd), "keyframe %d: candidate distances" % t
         hits += int((om >= 0).sum())
     assert hits > 12 * 300 and (bd[0] <= 50).sum() > 100
+    # the Sim(3) form of LoopClosing::SearchAndFuse (src/ORBmatcher.cc:844-954): the same selection WITHOUT the chi-square gate
+    bi3, bd3 = localmapping.fuse_batch(kfs, uv, rad, lvl, mp_desc, None, sim3=True)
+    more = 0
+    for t, q in enumerate(kfs):
+        n, om, obd, _ = oracle.search_by_projection(q["kps"], q["desc"], q["bounds"], uv[t], rad[t], mp_desc, q_pred_level=lvl[t], q_valid=(lvl[t] >= 0).astype(np.uint8), th=256)
+        assert np.array_equal(bi3[t], om) and np.array_equal(bd3[t], obd), "keyframe %d: Sim(3) form" % t
+        more += int((bi3[t] != bi[t]).sum())
+    assert more > 50                                                    # (the gate does decide some of the candidates)
     # empty inputs
     bi0, bd0 = localmapping.fuse_batch([], np.zeros((0, 5, 2), np.float32), np.zeros((0, 5), np.float32), np.zeros((0, 5), np.int32), mp_desc[:5], inv_ls)
     assert bi0.shape[0] == 0
