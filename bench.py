@@ -58,8 +58,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 VALU_PEAK_TOPS = 39.3          # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer VALU instruction issues over 4 cycles;
                                # measured 35-39 T lane-instr/s for xor/bcnt/pk_*16/dot4/dot2/sad/alignbyte (tools/ubench/valu_rate.hip)
 MATCH_LANE_OPS_PER_PAIR = 19.5   # VALU instructions per Hamming distance in k_match_pairs (ISA-checked: 8 xor + 8 v_bcnt + v_lshl_or + v_max + v_min + half a v_min3)
-PMC_TRAFFIC = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 PMC summaries, newest first
-PMC_VALU = ("r05_pmc_valu.json", "r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json", "r01_pmc_valu.json")
+PMC_TRAFFIC = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 PMC summaries, newest first
+PMC_VALU = ("r06_pmc_valu.json", "r05_pmc_valu.json", "r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json", "r01_pmc_valu.json")
 MFMA_I8_PEAK_TOPS = 5000.0     # MI355X_MICROARCH.md: I8 at twice the bf16 rate (bf16 dense ~2.5 PF); v_mfma_i32_16x16x64_i8 measured 4.7 POPS
                                # (tools/ubench/mfma_i8.hip)
 MATCH_OPS_PER_DISTANCE = 512   # 256 bit positions x (multiply + add): the matcher's distances as an int8 matrix product

@@ -466,27 +466,6 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   // min(max(c0, c8), max(c4, c12)) - v > t; darker likewise with min / max swapped.  6 min/max + 2 sub + max + 1 compare
   // per pixel, and tighter than ">= 2 of the 4 compass points" (which also admits the opposite pairs).
   int qn = 0;
-  unsigned long long saved = 0ull;                              // this lane's pixels that pass the pre-test at minTh but not at iniTh: bit 4 * iteration + k
-  // lanes of the pre-test = (row, column group of 4): 8 groups x 8 rows when the interior is <= 32 px wide, else 16 groups x 4 rows
-  const bool narrow = NARROW || iw <= 32;
-  const int RW = narrow ? 8 : 4;
-  const int g = narrow ? (lane & 7) : (lane & 15), lr = narrow ? (lane >> 3) : (lane >> 4);
-  const int ix4 = 4 * g;
-  const uint32_t qaddr = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)qcnt;      // LDS byte address of the queue counter
-  // queue slots from an LDS counter (the order of the queue is irrelevant: scores go to their pixel, survivors to row masks): one
-  // ds_add_rtn by the lanes that have something, instead of a 6-step DPP prefix sum by all of them (inline asm: written as atomicAdd,
-  // the compiler's atomic optimizer serialises the active lanes with a readlane / writelane loop to issue ONE atomic per wave - ~8
-  // scalar steps per lane, far more than the LDS unit's own conflict handling)
-  auto enqueue = [&](uint32_t pm, const int iyl) {
-    int pos;
-    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(qaddr), "v"(__popc(pm)) : "memory");
-    const uint32_t rowbits = ((uint32_t)iyl << 8) | (uint32_t)ix4;
-    do {
-      const int k = __ffs((int)pm) - 1;
-      pm &= pm - 1;
-      queue[pos++] = (unsigned short)(rowbits + (uint32_t)k);
-    } while (pm);
-  };
   {
     // FOUR horizontally adjacent pixels per lane, from dword LDS reads: lanes = (row, column group of 4); 8 groups x 8 rows
     // when the interior is <= 32 px wide (every KITTI / VGA level), else 16 groups x 4 rows.  With D[k] = the aligned dword at
@@ -496,12 +475,17 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     // - seven dword reads instead of twenty byte reads per four pixels.  The bytes are split into even / odd pixels as u16
     // pairs and the min / max network runs on v_pk_{min,max,sub}_*16: ~10 VALU per pixel instead of ~18, and one prefix sum
     // + enqueue per FOUR pixels (most lanes have nothing to enqueue: 8 % of the pixels pass).
+    const bool narrow = NARROW || iw <= 32;
+    const int RW = narrow ? 8 : 4;
+    const int g = narrow ? (lane & 7) : (lane & 15), lr = narrow ? (lane >> 3) : (lane >> 4);
+    const int ix4 = 4 * g;
     // validity of this lane's four columns (bit k = column ix4 + k is inside the interior)
     const uint32_t colmask = ix4 + 3 < iw ? 15u : (ix4 < iw ? ((1u << (iw - ix4)) - 1u) : 0u);
-    const uint32_t T0 = (uint32_t)minTh * 0x00010001u, T1 = (uint32_t)iniTh * 0x00010001u;
+    const uint32_t T0 = (uint32_t)minTh * 0x00010001u;
+    const uint32_t qaddr = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)qcnt;      // LDS byte address of the queue counter
     const int qv = (int)((3u + bsh) >> 2), q4 = 1 + (int)((2u + bsh) >> 2);       // (wave-uniform dword offsets / byte shifts)
     const uint32_t sv = (3u + bsh) & 3u, s4 = (2u + bsh) & 3u;
-    for (int iy0 = 0, itc = 0; iy0 < ih; iy0 += RW, itc++) {
+    for (int iy0 = 0; iy0 < ih; iy0 += RW) {
       const int iyl = iy0 + lr;
       const int iy = min(iyl, ih - 1);                          // (clamped: rows outside are masked, their reads stay inside the tile)
       // byte offsets of the three quads inside the (shifted) LDS row: c12 at 4g + bsh, v / c0 / c8 at 4g + 3 + bsh, c4 at 4g + 6 + bsh
@@ -512,7 +496,7 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
       const uint32_t e0 = rc[0], e1 = rc[1], v0 = rc[qv], v1 = rc[qv + 1], f0 = rc[q4], f1 = rc[q4 + 1], u0 = ru[0], u1 = ru[1], b0 = rd[0], b1 = rd[1];
       const uint32_t vq = __builtin_amdgcn_alignbyte(v1, v0, sv), c8q = __builtin_amdgcn_alignbyte(u1, u0, sv), c0q = __builtin_amdgcn_alignbyte(b1, b0, sv);
       const uint32_t c12q = __builtin_amdgcn_alignbyte(e1, e0, bsh), c4q = __builtin_amdgcn_alignbyte(f1, f0, s4);
-      uint32_t sg[2], sh[2];                                    // per parity: bit 15 / 31 set where the pixel passes at minTh / at iniTh
+      uint32_t sg[2];                                           // per parity: bit 15 / 31 set where the pixel passes
 #pragma unroll
       for (int par = 0; par < 2; par++) {                       // even pixels (bytes 0, 2), odd pixels (bytes 1, 3) as u16 pairs
         // ONE instruction per quad and parity: v_and for the even bytes, v_perm (bytes 1 and 3 to the low halves, 0x0c = constant
@@ -526,86 +510,68 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
         const ushort2_v lo = __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12));
         const short2_t up = S(__builtin_bit_cast(uint32_t, hi)) - S(__builtin_bit_cast(uint32_t, v2));     // (values 0..255: no overflow in 16 bits)
         const short2_t dn = S(__builtin_bit_cast(uint32_t, v2)) - S(__builtin_bit_cast(uint32_t, lo));
-        const short2_t ud = __builtin_elementwise_max(up, dn);
-        sg[par] = __builtin_bit_cast(uint32_t, S(T0) - ud);                                                 // < 0  <=>  max(..) > minTh
-        sh[par] = __builtin_bit_cast(uint32_t, S(T1) - ud);                                                 // < 0  <=>  max(..) > iniTh
+        const short2_t m = S(T0) - __builtin_elementwise_max(up, dn);                                       // < 0  <=>  max(..) > minTh
+        sg[par] = __builtin_bit_cast(uint32_t, m);
       }
       // pixel k of the lane = byte k: pixels 0 / 2 are the sign bits 15 / 31 of the even parity, pixels 1 / 3 those of the odd one;
       // t carries them at bits 14, 15, 30, 31 (one shift + one bit-field insert), two field extracts bring them to bits 0..3
       const uint32_t t = (sg[1] & 0x80008000u) | ((sg[0] >> 1) & ~0x80008000u);
-      const uint32_t t20 = (sh[1] & 0x80008000u) | ((sh[0] >> 1) & ~0x80008000u);
-      const uint32_t vm = (iyl < ih) ? colmask : 0u;
-      const uint32_t pm7 = (((t >> 14) & 3u) | ((t >> 28) & 0xCu)) & vm;
-      uint32_t pm = (((t20 >> 14) & 3u) | ((t20 >> 28) & 0xCu)) & vm;
-      // Two stages (round 6).  A cell's output is K20 - the corners of score >= iniTh that survive the 3x3 suppression - unless that set is
-      // empty (src/ORBextractor.cc:812-816), and a corner of score >= iniTh can only be suppressed by a neighbour of score >= iniTh, which
-      // itself passes THIS test at iniTh: scoring the pixels that pass at iniTh decides K20 exactly.  The pixels that pass only at minTh
-      // (5 of 8 in a textured frame: noise) are remembered as four bits per lane and iteration and are expanded, scored and suppressed
-      // only when the cell turns out to have no K20.
-      saved |= (unsigned long long)(pm7 & ~pm) << (4 * itc);
-      if (pm) enqueue(pm, iyl);
+      uint32_t pm = ((t >> 14) & 3u) | ((t >> 28) & 0xCu);
+      pm &= (iyl < ih) ? colmask : 0u;
+      if (pm) {
+        // queue slots from an LDS counter (the order of the queue is irrelevant: scores go to their pixel, survivors to row
+        // masks): one ds_add_rtn by the lanes that have something, instead of a 6-step DPP prefix sum by all of them
+        // (inline asm: written as atomicAdd, the compiler's atomic optimizer serialises the active lanes with a readlane /
+        // writelane loop to issue ONE atomic per wave - ~8 scalar steps per lane, far more than the LDS unit's own conflict handling)
+        int pos;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(qaddr), "v"(__popc(pm)) : "memory");
+        const uint32_t rowbits = ((uint32_t)iyl << 8) | (uint32_t)ix4;
+        do {
+          const int k = __ffs((int)pm) - 1;
+          pm &= pm - 1;
+          queue[pos++] = (unsigned short)(rowbits + (uint32_t)k);
+        } while (pm);
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   qn = __builtin_amdgcn_readfirstlane(*qcnt);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   FAST_STAMP(1);       // pre-test + queue
-  // ---- pass B: FAST-9 score of the queued pixels [k0, k1); one map serves both thresholds --------
-  auto score_pass = [&](const int k0, const int k1) {
-    for (int k = k0 + lane; k < k1; k += 64) {
-      const int q = queue[k], iy = q >> 8, ix = q & 255;
-      const uint8_t* p = tileb + __mul24(iy + 3, TP) + ix + 3;
-      const int v = p[0];
-      short2_t d[16];
-      auto mk = [&](int r) { return ring_pair(r); };
-      d[0] = mk(p[3 * TP]);         d[1] = mk(p[3 * TP + 1]);   d[2] = mk(p[2 * TP + 2]);   d[3] = mk(p[TP + 3]);
-      d[4] = mk(p[3]);              d[5] = mk(p[-TP + 3]);      d[6] = mk(p[-2 * TP + 2]);  d[7] = mk(p[-3 * TP + 1]);
-      d[8] = mk(p[-3 * TP]);        d[9] = mk(p[-3 * TP - 1]);  d[10] = mk(p[-2 * TP - 2]); d[11] = mk(p[-TP - 3]);
-      d[12] = mk(p[-3]);            d[13] = mk(p[TP - 3]);      d[14] = mk(p[2 * TP - 2]);  d[15] = mk(p[3 * TP - 1]);
-      const int best = arc9_best_packed(d, v);             // corner at t  <=>  best > t ; score = best - 1
-      if (best > minTh) score[__mul24(iy + 3, TP) + ix + 3] = (uint8_t)(best - 1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-  };
-  // ---- 3x3 non-max suppression inside the cell (frame pixels score 0) on the queued pixels [0, k1); returns "a survivor has score >= iniTh"
-  auto nms_pass = [&](const int k1) {
-    int any20 = 0;
-    for (int k = lane; k < k1; k += 64) {
-      const int q = queue[k], iy = q >> 8, ix = q & 255;
-      const uint8_t* sp = score + __mul24(iy + 3, TP) + ix + 3;
-      const int v = sp[0];
-      // (all nine reads unconditional and the comparison without short-circuit: one LDS round trip per queued pixel)
-      const int n0 = sp[-TP - 1], n1 = sp[-TP], n2 = sp[-TP + 1], n3 = sp[-1], n4 = sp[1], n5 = sp[TP - 1], n6 = sp[TP], n7 = sp[TP + 1];
-      const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-      const bool kp = v != 0 && v > nmax;
-      if (kp) {
-        atomicOr(&keep[iy], (mask_t)1 << ix);
-        if (v >= iniTh) { atomicOr(&k20[iy], (mask_t)1 << ix); any20 = 1; }
-      }
-    }
-    any20 = __any(any20);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-    return any20;
-  };
-  score_pass(0, qn);                                            // stage 1: the pixels that pass the pre-test at iniTh
-  FAST_STAMP(2);       // 9-arc score
-  int any20 = nms_pass(qn);
-  if (!any20) {
-    // stage 2 (no K20 in this cell): the pixels that pass only at minTh join the queue, are scored, and the suppression runs again over
-    // all of them - stage 1 compared its pixels with an incomplete score map, so its survivors are dropped first (k20 is empty)
-    keep[lane] = 0;
-    const int qn1 = qn;
-    for (int iy0 = 0, itc = 0; iy0 < ih; iy0 += RW, itc++) {
-      const uint32_t pm = (uint32_t)(saved >> (4 * itc)) & 15u;
-      if (pm) enqueue(pm, iy0 + lr);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-    qn = __builtin_amdgcn_readfirstlane(*qcnt);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-    score_pass(qn1, qn);
-    any20 = nms_pass(qn);                                       // (stays 0: more scored neighbours can only suppress more)
+  // ---- pass B: FAST-9 score at the LOW threshold; one map serves both thresholds --------
+  for (int k = lane; k < qn; k += 64) {
+    const int q = queue[k], iy = q >> 8, ix = q & 255;
+    const uint8_t* p = tileb + __mul24(iy + 3, TP) + ix + 3;
+    const int v = p[0];
+    short2_t d[16];
+    auto mk = [&](int r) { return ring_pair(r); };
+    d[0] = mk(p[3 * TP]);         d[1] = mk(p[3 * TP + 1]);   d[2] = mk(p[2 * TP + 2]);   d[3] = mk(p[TP + 3]);
+    d[4] = mk(p[3]);              d[5] = mk(p[-TP + 3]);      d[6] = mk(p[-2 * TP + 2]);  d[7] = mk(p[-3 * TP + 1]);
+    d[8] = mk(p[-3 * TP]);        d[9] = mk(p[-3 * TP - 1]);  d[10] = mk(p[-2 * TP - 2]); d[11] = mk(p[-TP - 3]);
+    d[12] = mk(p[-3]);            d[13] = mk(p[TP - 3]);      d[14] = mk(p[2 * TP - 2]);  d[15] = mk(p[3 * TP - 1]);
+    const int best = arc9_best_packed(d, v);             // corner at t  <=>  best > t ; score = best - 1
+    if (best > minTh) score[__mul24(iy + 3, TP) + ix + 3] = (uint8_t)(best - 1);
   }
-  FAST_STAMP(3);       // NMS (+ the second stage of the cells without K20)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  FAST_STAMP(2);       // 9-arc score
+  // ---- 3x3 non-max suppression inside the cell (frame pixels score 0), only on queued pixels --------
+  int any20 = 0;
+  for (int k = lane; k < qn; k += 64) {
+    const int q = queue[k], iy = q >> 8, ix = q & 255;
+    const uint8_t* sp = score + __mul24(iy + 3, TP) + ix + 3;
+    const int v = sp[0];
+    // (all nine reads unconditional and the comparison without short-circuit: one LDS round trip per queued pixel)
+    const int n0 = sp[-TP - 1], n1 = sp[-TP], n2 = sp[-TP + 1], n3 = sp[-1], n4 = sp[1], n5 = sp[TP - 1], n6 = sp[TP], n7 = sp[TP + 1];
+    const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+    const bool kp = v != 0 && v > nmax;
+    if (kp) {
+      atomicOr(&keep[iy], (mask_t)1 << ix);
+      if (v >= iniTh) { atomicOr(&k20[iy], (mask_t)1 << ix); any20 = 1; }
+    }
+  }
+  any20 = __any(any20);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  FAST_STAMP(3);       // NMS
   // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816), row by row -----------
   const mask_t* mask = any20 ? k20 : keep;
   uint32_t* out = cell_kps + ((long long)f * G.ncells_total + ci) * G.cell_cap;

@@ -7,7 +7,7 @@ SKIPPED - the tracked file of an earlier, good run is never overwritten by a mis
 headline kernel stats exactly that way).  Files are written to a temporary name and renamed.  Exit code 1 if anything was skipped."""
 import csv, json, os, sqlite3, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 G = os.path.join(ROOT, "gpurun_out"); O = os.path.join(G, RND); P = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")      # (PROFILES_OUT: collect on the GPU box into gpurun_out/, the raw databases exceed what travels back)
 os.makedirs(P, exist_ok=True)
 skipped = []
@@ -66,6 +66,8 @@ take_kernel_csv("bench_kernel_stats.csv", RND + "_bench_kernel_stats.csv", ("k_f
 take_json("bench_traced.json", RND + "_bench_traced.json", ("value", "kernels"))
 take_kernel_csv("localba_batch64_kernel_stats.csv", RND + "_localba_batch64_kernel_stats.csv", ("k_ba_schur", "k_chol_wg"))
 take_kernel_csv("gba_c5_kernel_stats.csv", RND + "_gba_c5_kernel_stats.csv", ("k_chol",))
+for st in ("covis", "dense"):
+    take_kernel_csv("localba_batch64_%s_kernel_stats.csv" % st, RND + "_localba_batch64_%s_kernel_stats.csv" % st, ("k_ba_schur", "k_chol_wg"))
 take_json("bench_2rank_shared.json", RND + "_bench_2rank_shared_gpu.json", ("value", "collective"))
 take_json("bench_8rank_shared.json", RND + "_bench_8rank_shared_gpu.json", ("value", "collective"))
 take_json("bench_rccl_ws1.json", RND + "_bench_rccl_ws1.json", ("collective",))
@@ -78,6 +80,8 @@ except Exception as e:
     skipped.append("api_latency: %s" % e)
 for src, dst, why in (("mfma_batch.json", "_mfma_localba_batch64.json", "FP64-MFMA counters (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) of 64 C4-size LocalBA problems per lockstep batch: k_chol_wg, one workgroup per problem, walking the skyline - the EXECUTED matrix flops (tools/run_mfma_pmc.sh; experiments build, ORBHIP_BA_GRAPH=0)"),
                       ("mfma_single.json", "_mfma_localba_single.json", "the same counters over single C4-size LocalBA solves: the persistent, flag-linked k_chol_persist (skyline walk)"),
+                      ("mfma_batch_covis.json", "_mfma_localba_batch64_covis.json", "the same counters, 64 C4-size local maps with covisibility-window tracks + a current keyframe sharing landmarks with every keyframe (synth.make_ba_graph_covis 'covis': a band of ~6 tiles under a dense last block row)"),
+                      ("mfma_batch_dense.json", "_mfma_localba_batch64_dense.json", "the same counters, 64 C4-size local maps whose every keyframe pair shares landmarks: a FULL reduced system, every tile update of the factorisation runs"),
                       ("mfma_c5.json", "_mfma_gba_c5.json", "the same counters over one GlobalBA at C5 size (500 keyframes, 2994-unknown reduced system, band 3), 10 iterations: k_chol_persist walking the skyline (round 5; k_chol_persist_blk before)")):
     path = os.path.join(O, src)
     try:
@@ -86,13 +90,13 @@ for src, dst, why in (("mfma_batch.json", "_mfma_localba_batch64.json", "FP64-MF
     except Exception as e:
         skipped.append("%s: %s" % (src, e))
 for txt in ("localba_throughput.txt", "track_latency.txt", "concurrency.txt", "mfma_f64_ubench.txt", "schur_phase_prof.txt", "chol_wg_phase_prof.txt",
-            "localba_trace_overlap_12_callers.txt", "pt_fuse_ab.txt"):
+            "localba_trace_overlap_12_callers.txt", "pt_fuse_ab.txt", "factor_ab.txt", "f64_latency.txt"):
     path = os.path.join(O, txt)
     if os.path.exists(path) and os.path.getsize(path) > 0:
         put(RND + "_" + txt, open(path).read())
     else:
         skipped.append(txt + ": missing or empty")
-for extra in ("ba_batch64_pmc.json", "fast_phase_prof.json", "chol_phase_prof.json", "octree_phase_prof.json", "gba_c5_mfma.json", "pcie_pipeline.json", "tracking_step.json"):
+for extra in ("ba_batch64_pmc.json", "fast_phase_prof.json", "chol_persist_chain_c4.json", "chol_persist_chain_c5.json", "chol_phase_prof.json", "octree_phase_prof.json", "gba_c5_mfma.json", "pcie_pipeline.json", "tracking_step.json"):
     path = os.path.join(O, extra)
     if os.path.exists(path):
         try:

@@ -8,7 +8,12 @@ from ceres_mono_orb_slam2_amd import ORBextractor, ORBmatcher
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device("cuda:0")
-frames = torch.from_numpy(bench.make_frames(B, seed=0)).to(dev)
+_fr = bench.make_frames(B, seed=0)
+if os.environ.get("ORBHIP_AB_CONTRAST"):      # A/B aid: the same frames with their contrast scaled (0.25: most edges fall below iniTh = 20, as in low-texture real scenes) + fresh sigma-2 noise
+    import numpy as np
+    _c = float(os.environ["ORBHIP_AB_CONTRAST"]); _rng = np.random.default_rng(1)
+    _fr = np.clip(np.rint(128.0 + (_fr.astype(np.float32) - 128.0) * _c + _rng.normal(0, 2.0, _fr.shape).astype(np.float32)), 0, 255).astype(np.uint8)
+frames = torch.from_numpy(_fr).to(dev)
 ex = ORBextractor(bench.NFEAT, 1.2, 8, 20, 7)
 mt = ORBmatcher(0.9, True)
 cap = ex.max_keypoints

@@ -6,7 +6,7 @@
 # usage: bash tools/run_profiles.sh r04 [quick]   (every leg is wrapped in `timeout`: a hung leg costs its limit, not the GPU budget)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/$R; mkdir -p $O
 step() { echo "== $*"; }
 step bench;      timeout 900 python bench.py > $O/bench.json 2> $O/bench.err || tail -5 $O/bench.err
@@ -22,6 +22,14 @@ rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/lbaprof -o run -- t
 db=$(find $O/lbaprof -name "*.db" 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocpd_stats.py $db $O/localba_batch64_kernel_stats.csv && python tools/kstats_print.py $O/localba_batch64_kernel_stats.csv | head -14
 timeout 600 python tools/ba_batch_thr.py 64:12:8 64:8:8 64:12:2 16:8:8 64:1:4 > $O/localba_throughput.txt 2>&1; cat $O/localba_throughput.txt
+step localba trace, covisibility-structured and dense reduced systems
+for st in covis dense; do
+  rm -rf $O/lbaprof_$st
+  ORBHIP_BENCH_STRUCTURE=$st rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/lbaprof_$st -o run -- timeout 600 python tools/ba_batch_thr.py 64:1 > $O/lbaprof_$st.log 2>&1 || tail -5 $O/lbaprof_$st.log
+  db=$(find $O/lbaprof_$st -name "*.db" 2>/dev/null | head -1)
+  [ -n "$db" ] && python tools/rocpd_stats.py $db $O/localba_batch64_${st}_kernel_stats.csv && python tools/kstats_print.py $O/localba_batch64_${st}_kernel_stats.csv | head -6
+  rm -rf $O/lbaprof_$st
+done
 step 12 callers: kernel trace, concurrency
 rm -rf $O/lba12
 rocprofv3 --kernel-trace --output-format rocpd -d $O/lba12 -o run -- timeout 600 python tools/ba_batch_thr.py 64:12:6 > $O/lba12.log 2>&1 || tail -5 $O/lba12.log
@@ -34,6 +42,10 @@ step pt fuse a/b
 timeout 600 python tools/pt_fuse_ab.py > $O/pt_fuse_ab.txt 2>&1; cat $O/pt_fuse_ab.txt
 [ -f tools/scratch/lib_prof/liborbslam_hip.so ] && { step chol_wg phase stamps; timeout 300 python tools/chol_wg_prof.py 2>/dev/null | grep -v amdgpu.ids > $O/chol_wg_phase_prof.txt; cat $O/chol_wg_phase_prof.txt; }
 [ -f tools/exp_lib/liborbslam_hip_sprof.so ] && { step schur phase stamps; timeout 300 python tools/schur_prof.py > $O/schur_phase_prof.txt 2>&1; cat $O/schur_phase_prof.txt; }
+step diagonal factor: 1 / 2 / 4 waves, f64 latency table
+REBUILD=1 timeout 600 python tools/factor_ab.py 2>/dev/null | grep -v "warning\|note:" > $O/factor_ab.txt; tail -5 $O/factor_ab.txt
+[ -x tools/ubench/f64_latency ] && timeout 120 tools/ubench/f64_latency > $O/f64_latency.txt 2>&1; tail -3 $O/f64_latency.txt
+[ -f tools/scratch/lib_prof/liborbslam_hip.so ] && { step chain phase stamps; timeout 300 python tools/chol_persist_prof.py > /dev/null 2>&1; cp gpurun_out/cholprof/chol_persist_prof.json $O/chol_persist_chain_c4.json; timeout 300 python tools/chol_persist_prof.py c5 > /dev/null 2>&1; cp gpurun_out/cholprof/chol_persist_prof_c5.json $O/chol_persist_chain_c5.json; }
 step gba c5 trace
 rm -rf $O/gbaprof
 rocprofv3 --kernel-trace --stats --output-format rocpd -d $O/gbaprof -o run -- timeout 600 python tools/gba_c5_check.py 10 > $O/gbaprof.log 2>&1 || tail -5 $O/gbaprof.log
