@@ -243,6 +243,20 @@ def run(dev, cpu=True, n_localba=12, n_pose_batch=256, rank=0, quick=False):
     roof["cases"]["c5_loop"] = _roof(gl, lnit, lms * 1e-3, "one loop-closed 500-KF GlobalBA; device time of its %d LM iterations" % lnit,
                                      skyline=planl["lookahead_form"] != "none", ms_per_iteration=lms / max(lnit, 1), wall_ms=dtl * 1e3, plan=planl)
     out["globalba_loop_500kf_ms_per_iteration"] = lms / max(lnit, 1)
+    if not quick:
+        # a DENSE 2994 x 2994 reduced system (every keyframe pair of 500 shares landmarks): the two-level family (k_chol_persist_blk), every tile runs
+        gd = synth.make_ba_graph_covis(3100 + rank, ncam=500, npts=50000, nobs=250000, structure="dense")
+        dargs = (gd["K4"], gd["poses0"], gd["cam_fixed"], gd["pts0"], gd["obs_cam"], gd["obs_pt"], gd["obs_uv"], gd["obs_inv_sigma2"])
+        optimizer.set_profiling(True)
+        optimizer.global_bundle_adjustment(*dargs, n_iterations=2); optimizer.get_profile()
+        optimizer.global_bundle_adjustment(*dargs, n_iterations=8)
+        dms, _, dnit = optimizer.get_profile()
+        optimizer.set_profiling(False)
+        pland = optimizer.get_last_plan()
+        roof["cases"]["c5_dense"] = _roof(gd, dnit, dms * 1e-3, "one 500-KF GlobalBA whose every keyframe pair shares landmarks (a dense 2994 x 2994 reduced system); device time of "
+                                          "its %d LM iterations - the Schur complement's 124 750 blocks of ~4 pairs each included, which is most of it" % dnit,
+                                          skyline=pland["lookahead_form"] != "none", ms_per_iteration=dms / max(dnit, 1), plan=pland)
+        out["globalba_dense_500kf_ms_per_iteration"] = dms / max(dnit, 1)
     # ---- C5 as BASELINE config 5 words it, on ONE GPU: the eight 500-KF sub-maps as one lockstep batch (ba_solve_batch: what a node
     #      with fewer GPUs than sub-maps does).  A single GlobalBA is bound by the latency chain of its factorisation (c5 above);
     #      eight in lockstep share every launch of the chain.  (Eight host threads with one solve each: 464 ms against 379; 323 with the
