@@ -197,6 +197,9 @@ struct BaDev {            // device pointers of one problem
 struct StFlags { int done, need_eval, valid, chol_fail, accepted; };
 __device__ __forceinline__ StFlags ld_flags(const BaState* st) {
   StFlags f; f.done = st->done; f.need_eval = st->need_eval; f.valid = st->valid; f.chol_fail = st->chol_fail; f.accepted = st->accepted;
+  // (all five requested together and waited for HERE: left alone, the compiler loads `done` and `valid`, waits, branches, and fetches the
+  // others behind the branch where they are used - a round trip each on kernels that are made of round trips)
+  asm volatile("" : "+v"(f.done), "+v"(f.need_eval), "+v"(f.valid), "+v"(f.chol_fail), "+v"(f.accepted));
   return f;
 }
 
@@ -216,6 +219,14 @@ __device__ __forceinline__ StFlags ld_flags(const BaState* st) {
 // They depend on the iterate only - not on the LM radius, not on the scaling: k_ba_eval writes them with the Jacobians (mode 0), beside
 // h = Q^T r (Hc), and k_ba_cam_blocks forms Jc^T Jc and Jc^T r from the same records (round 4 kept 14 doubles of Jc and r per
 // observation for it, and a kernel of its own, k_ba_E, rewrote 18-double E records whenever the iterate had changed).
+// "These doubles are needed HERE": an empty asm the values pass through.  The compiler otherwise moves a load down to its first use - behind
+// a branch, a select it turns into a branch, a barrier - and ends every divergent block with a wait for what the block requested; pinned,
+// the loads issued before the pin leave together and are waited for once.
+__device__ __forceinline__ void pin8(double* x) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+}
+__device__ __forceinline__ void pin4(double* x) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])); }
+__device__ __forceinline__ void pin4i(int& a, int& b, int& c, int& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 __device__ __forceinline__ void ld_rec8(const double* __restrict__ base, size_t q, double* c) {
   const double2* m = (const double2*)(base + 8 * q);
 #pragma unroll
@@ -244,36 +255,82 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4], s_out[1];
   const BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  if (F.done) return;
-  if (mode == 0 && !F.need_eval) return;
-  if (mode == 1 && !F.valid) return;
   if ((int)blockIdx.x * BA_TPB >= max(D.nobs, 1)) return;               // batched launch: grid.x is the maximum over the problems
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ double s_rec[mode == 0 ? BA_TPB / 64 : 1][mode == 0 ? 64 : 1][13];   // mode 0: the wave's records {W (5), r (3), h (3)} on their way out (+ pad: odd pitch)
   __shared__ int s_q[mode == 0 ? BA_TPB / 64 : 1][mode == 0 ? 64 : 1];            // ... and their places (camera-major position, -1: none)
-  int q_mine = -1;
+  const bool have = i < D.nobs;
+  const bool ptphase = mode == 0 && D.pt_in_eval && !D.fix_points && D.nobs > 0;
+  const int b0 = blockIdx.x * BA_TPB, iend = min(b0 + BA_TPB, D.nobs);
+  // Round 6: the loads leave in TWO groups, each waited for once (pin4 / pin8).  (A) what hangs off the observation index: camera, landmark,
+  // camera-major place, measurement, weight - and the same of the observation this thread re-evaluates when the last landmark's run
+  // continues behind the workgroup (i2), and the last landmark's index; (B) what hangs off those: intrinsics, pose, point, the camera's
+  // column, the landmark's range.  Requested at their uses they made eleven dependent round trips (cam_pos behind `want`, the landmark phase
+  // four of its own behind the barrier).
+  // No branches around the loads - the compiler ends a divergent block with a wait for everything it requested: a thread without an
+  // observation reads the workgroup's first one, always there when the problem has any, and its indices are zeroed behind the pin.
+  const int i2 = iend + (int)threadIdx.x;
+  const bool have2 = ptphase && (int)threadIdx.x < PT_MAXRUN - 1 && i2 < D.nobs;
+  int c_mine = 0, p_mine = 0, q_mine = -1, rob = 0, c2 = 0, p2 = 0, rob2 = 0, plast = 0;
+  double m4[4] = {0.0, 0.0, 0.0, 0.0}, n4[4] = {0.0, 0.0, 0.0, 0.0};           // {u, v, weight, -} of i and of i2
+  const int ia = have ? i : b0, ib = have2 ? i2 : b0;
+  c_mine = D.obs_cam[ia]; p_mine = D.obs_pt[ia]; rob = D.obs_robust[ia];
+  if (mode == 0) q_mine = D.cam_pos[ia];
+  m4[0] = D.obs_uv[2 * (size_t)ia]; m4[1] = D.obs_uv[2 * (size_t)ia + 1]; m4[2] = D.obs_w[ia];
+  if (mode == 0) {
+    c2 = D.obs_cam[ib]; p2 = D.obs_pt[ib]; rob2 = D.obs_robust[ib];
+    n4[0] = D.obs_uv[2 * (size_t)ib]; n4[1] = D.obs_uv[2 * (size_t)ib + 1]; n4[2] = D.obs_w[ib];
+    plast = D.obs_pt[max(iend - 1, 0)];
+  }
+  const StFlags F = ld_flags(st);
+  pin4i(c_mine, p_mine, q_mine, rob); pin4(m4);
+  if (mode == 0) { pin4i(c2, p2, rob2, plast); pin4(n4); }
+  if (F.done) return;
+  if (mode == 0 && !F.need_eval) return;
+  if (mode == 1 && !F.valid) return;
+  if (!have) { c_mine = 0; p_mine = 0; q_mine = -1; }
+  if (!have2) { c2 = 0; p2 = 0; }
+  if (!ptphase) plast = 0;
+  const double* poses = mode ? D.cand_poses : D.poses;
+  const double* pts = mode ? D.cand_pts : D.pts;
+  double kp[16] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};       // K4 (4), pose (7), X (3), -, -
+  double kp2[16] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int col = -1, po0 = 0, po1 = 0, run_end = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) kp[k] = D.K4[4 * (size_t)c_mine + k];
+#pragma unroll
+  for (int k = 0; k < 7; k++) kp[4 + k] = poses[7 * (size_t)c_mine + k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) kp[11 + k] = pts[3 * (size_t)p_mine + k];
+  if (mode == 0) {
+    col = D.cam_col[c_mine]; po0 = D.pt_off[p_mine]; po1 = D.pt_off[p_mine + 1];
+#pragma unroll
+    for (int k = 0; k < 4; k++) kp2[k] = D.K4[4 * (size_t)c2 + k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) kp2[4 + k] = D.poses[7 * (size_t)c2 + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) kp2[11 + k] = D.pts[3 * (size_t)p2 + k];
+    run_end = D.pt_off[plast + 1];                              // (uniform) where the run of the workgroup's last landmark ends
+  }
+  pin8(kp); pin8(kp + 8);
+  if (mode == 0) { pin8(kp2); pin8(kp2 + 8); pin4i(col, po0, po1, run_end); }
   double acc[1] = {0.0};
   double rec[11] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};        // this observation's record {W (5), r (3), h (3)}
-  int c_mine = 0, p_mine = -1;
-  if (i < D.nobs) {
-    const int c = D.obs_cam[i], p = D.obs_pt[i];
-    c_mine = c; p_mine = p;
-    const double* poses = mode ? D.cand_poses : D.poses;
-    const double* pts = mode ? D.cand_pts : D.pts;
+  if (have) {
     double r[2], Jc[12], RX[3];
     // (an observation by a FIXED camera still feeds its landmark's block: its record is written too unless the landmarks are fixed)
-    const bool want = (mode == 0) && (D.cam_col[c] >= 0 || !D.fix_points);
-    double rho = reproj_eval(D.K4 + 4 * c, poses + 7 * c, pts + 3 * (size_t)p, D.obs_uv[2 * (size_t)i], D.obs_uv[2 * (size_t)i + 1],
-                             D.obs_w[i], D.obs_robust[i], D.huber, r, want ? Jc : nullptr, nullptr, RX);
+    const bool want = (mode == 0) && (col >= 0 || !D.fix_points);
+    // (Jc as a compile-time choice: `want ? Jc : nullptr` kept Jc and r in SCRATCH memory, 112 bytes per lane written and read back - 40 % of
+    // what this kernel wrote to HBM; 171 -> 127 us per launch of a 64-problem C4 batch)
+    double rho = reproj_eval(kp, kp + 4, kp + 11, m4[0], m4[1], m4[2], rob, D.huber, r, mode == 0 ? Jc : nullptr, nullptr, RX);
     acc[0] = 0.5 * rho;
     if (mode == 0) {
       if (want) {
-        q_mine = D.cam_pos[i];
         // The Jacobians leave in FACTORED form, grouped by camera (the comment above ld_rec8): {W = Q^T Q, r = 2 RX} is the record
         // k_ba_schur / k_ba_backsub / the block kernels work from, h = Q^T res the gradients' share - 88 bytes per observation, the
-        // only thing this kernel writes (it is bound by the HBM WRITE rate, ~2 TB/s: the 2x6 and 2x3 Jacobians were 160 bytes)
+        // only thing this kernel writes (it is bound by the HBM WRITE rate, ~2.7 TB/s of scattered 64- and 24-byte pieces: the 2x6 and
+        // 2x3 Jacobians were 160 bytes)
         const double q00 = Jc[0], q02 = Jc[2], q11 = Jc[7], q12 = Jc[8];
         rec[0] = q00 * q00; rec[1] = q11 * q11; rec[2] = q00 * q02; rec[3] = q11 * q12; rec[4] = q02 * q02 + q12 * q12;
         rec[5] = 2.0 * RX[0]; rec[6] = 2.0 * RX[1]; rec[7] = 2.0 * RX[2];
@@ -281,7 +338,7 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
         double* t = s_rec[w][lane];
 #pragma unroll
         for (int k = 0; k < 11; k++) t[k] = rec[k];
-      }
+      } else q_mine = -1;
     }
   }
   if (mode == 0) {
@@ -306,32 +363,28 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
     // the nine terms every thread leaves in LDS (the staging area, free once the records are out); a run that continues behind the
     // workgroup's last observation is evaluated again by the first threads (<= PT_MAXRUN - 1 observations).  Same terms, same order as
     // the separate pass: the bits of C and g_p do not change.
-    if (D.pt_in_eval && !D.fix_points && D.nobs > 0) {
+    if (ptphase) {
       __syncthreads();                                          // every wave's records have left the staging area
       double* s_pt = &s_rec[0][0][0];                           // [256 + PT_MAXRUN - 1][9]
-      const int b0 = blockIdx.x * BA_TPB, iend = min(b0 + BA_TPB, D.nobs);
-      if (i < D.nobs) {
+      if (have) {
         double Rc[9], o[9];
-        quat_to_R(D.poses + 7 * (size_t)c_mine + 3, Rc);
+        quat_to_R(kp + 7, Rc);
         pt_terms(rec[0], rec[1], rec[2], rec[3], rec[4], rec[8], rec[9], rec[10], Rc, o);
 #pragma unroll
         for (int k = 0; k < 9; k++) s_pt[9 * threadIdx.x + k] = o[k];
       }
-      const int run_end = D.pt_off[D.obs_pt[iend - 1] + 1];     // (uniform) where the run of the workgroup's last landmark ends
-      if ((int)threadIdx.x < run_end - iend) {
-        const int i2 = iend + threadIdx.x, c2 = D.obs_cam[i2];
+      if ((int)threadIdx.x < run_end - iend) {                  // (have2 holds: the run ends inside the observations and is <= PT_MAXRUN long)
         double r2[2], J2[12], RX2[3], Rc[9], o[9];
-        reproj_eval(D.K4 + 4 * c2, D.poses + 7 * c2, D.pts + 3 * (size_t)D.obs_pt[i2], D.obs_uv[2 * (size_t)i2], D.obs_uv[2 * (size_t)i2 + 1],
-                    D.obs_w[i2], D.obs_robust[i2], D.huber, r2, J2, nullptr, RX2);
+        reproj_eval(kp2, kp2 + 4, kp2 + 11, n4[0], n4[1], n4[2], rob2, D.huber, r2, J2, nullptr, RX2);
         const double q00 = J2[0], q02 = J2[2], q11 = J2[7], q12 = J2[8];
-        quat_to_R(D.poses + 7 * (size_t)c2 + 3, Rc);
+        quat_to_R(kp2 + 7, Rc);
         pt_terms(q00 * q00, q11 * q11, q00 * q02, q11 * q12, q02 * q02 + q12 * q12, q00 * r2[0], q11 * r2[1], q02 * r2[0] + q12 * r2[1], Rc, o);
 #pragma unroll
         for (int k = 0; k < 9; k++) s_pt[9 * (BA_TPB + threadIdx.x) + k] = o[k];
       }
       __syncthreads();
-      if (i < D.nobs && i == D.pt_off[p_mine]) {
-        const int hi = D.pt_off[p_mine + 1];
+      if (have && i == po0) {
+        const int hi = po1;
         double C[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
         for (int ii = i; ii < hi; ii++) {
           const double* tq = s_pt + 9 * (ii - b0);
