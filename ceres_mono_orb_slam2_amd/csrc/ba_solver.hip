@@ -1049,41 +1049,57 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restric
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4 * 2], s_out[2];
   const BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid) return;
   if ((int)blockIdx.x * BA_TPB >= D.ncam) return;
   const int c = blockIdx.x * BA_TPB + threadIdx.x;
+  const bool have = c < D.ncam;
+  // Two groups of loads, each waited for once (round 6): the pose and the camera's column with the state flags; then the step, the scaling,
+  // the block and the gradient of that column.  Everything is computed in registers and stored at the end: with the stores to cand_poses
+  // between the reads of poses (pointers the compiler cannot tell apart) every quantity was re-read behind them - ~30 waits in an 8.6 us
+  // kernel on every iteration's chain.  Same operations on the same doubles.
+  double x[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int cc = -1;
+  {
+    const size_t ca = have ? c : 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) x[k] = D.poses[7 * ca + k];
+    cc = D.cam_col[ca];
+  }
+  const StFlags F = ld_flags(st);
+  pin8(x); asm volatile("" : "+v"(cc));
+  if (F.done || !F.valid) return;
+  const bool live = have && cc >= 0 && !F.chol_fail;
+  double v[40];                                       // y (6), S_c (6), g_c (6), -, -, B (21), -
+#pragma unroll
+  for (int k = 0; k < 40; k++) v[k] = 0.0;
+  {
+    const size_t cz = live ? cc : 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { v[k] = D.rhs[6 * cz + k]; v[6 + k] = D.scale_c[6 * cz + k]; v[12 + k] = D.gc[6 * cz + k]; }
+#pragma unroll
+    for (int k = 0; k < 21; k++) v[18 + k] = D.B[21 * cz + k];
+  }
+  pin8(v); pin8(v + 8); pin8(v + 16); pin8(v + 24); pin8(v + 32);
   double acc[2] = {0.0, 0.0};                 // |dx|^2 of the cameras; their share of the model cost change (see k_ba_backsub)
-  if (c < D.ncam) {
-    const double* x = D.poses + 7 * c;
+  if (have) {
     double* xc = D.cand_poses + 7 * c;
-    const int cc = D.cam_col[c];
     // the camera's record for k_ba_backsub (round 5: every observation used to walk obs_cam -> cam_col -> {y, S_c, quaternion} and
     // rebuild R and S_c y itself - one dependent level and ~40 instructions more per observation); the same products, formed once
     double* cr = D.camrec + 16 * (size_t)c;
-    if (cc < 0 || st->chol_fail) cr[15] = 0.0;
-    else {
-      double Rc[9];
+    if (!live) {
+      cr[15] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) xc[k] = x[k];
+    } else {
+      const double* y = v; const double* sc = v + 6; const double* g = v + 12; const double* Bu = v + 18;
+      double Rc[9], xn[7];
       quat_to_R(x + 3, Rc);
-      const double* y = D.rhs + 6 * cc;
-      const double* sc = D.scale_c + 6 * (size_t)cc;
 #pragma unroll
-      for (int k = 0; k < 9; k++) cr[k] = Rc[k];
-#pragma unroll
-      for (int k = 0; k < 6; k++) cr[9 + k] = y[k] * sc[k];
-      cr[15] = 1.0;
-    }
-    if (cc < 0 || st->chol_fail) { for (int k = 0; k < 7; k++) xc[k] = x[k]; }
-    else {
-      const double* y = D.rhs + 6 * cc;
-      const double* sc = D.scale_c + 6 * (size_t)cc;
-      for (int k = 0; k < 3; k++) xc[k] = x[k] + (-y[k]) * sc[k];
+      for (int k = 0; k < 3; k++) xn[k] = x[k] + (-y[k]) * sc[k];
       double d[3] = {(-y[3]) * sc[3], (-y[4]) * sc[4], (-y[5]) * sc[5]};
-      quat_plus(x + 3, d, xc + 3);
-      for (int k = 0; k < 7; k++) { double e = x[k] - xc[k]; acc[0] += e * e; }
+      quat_plus(x + 3, d, xn + 3);
+#pragma unroll
+      for (int k = 0; k < 7; k++) { double e = x[k] - xn[k]; acc[0] += e * e; }
       // -(g_c . s + s^T B_s s / 2) with the scaled step s = -y, the scaled gradient and the scaled block WITHOUT the damping
-      const double* Bu = D.B + 21 * (size_t)cc;
-      const double* g = D.gc + 6 * (size_t)cc;
       double gs = 0.0, q = 0.0;
 #pragma unroll
       for (int u = 0; u < 6; u++) {
@@ -1091,10 +1107,17 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_update(const BaDev* __restric
         gs += g[u] * sc[u] * su;
         double row = 0.0;
 #pragma unroll
-        for (int v = 0; v < 6; v++) row += Bu[sym6(u, v)] * sc[u] * sc[v] * (-y[v]);
+        for (int w = 0; w < 6; w++) row += Bu[sym6(u, w)] * sc[u] * sc[w] * (-y[w]);
         q += su * row;
       }
       acc[1] = -(gs + q / 2);
+#pragma unroll
+      for (int k = 0; k < 9; k++) cr[k] = Rc[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cr[9 + k] = y[k] * sc[k];
+      cr[15] = 1.0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) xc[k] = xn[k];
     }
   }
   block_reduce<2>(acc, s_red, s_out);
@@ -1208,7 +1231,12 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(const BaDev* __restrict_
   const int nb_obs = max((D.nobs + BA_TPB - 1) / BA_TPB, 1), nb_cam = (D.ncam + BA_TPB - 1) / BA_TPB, nb_pt = max((D.npts + BA_TPB - 1) / BA_TPB, 1);
   __shared__ double s_red[4 * 3], s_out[3];
   BaState* st = D.st;
+  // (round 6: what thread 0 needs of the state is requested with the flags - read where it was used, behind the stores to the same
+  // struct, every field was a round trip of its own: twelve in a 4.8 us kernel on every iteration's chain)
+  int invalid_steps = st->invalid_steps, successful_steps = st->successful_steps;
+  double sv[4] = {st->radius, st->decrease_factor, st->x_norm, st->x_cost};
   const StFlags F = ld_flags(st);
+  asm volatile("" : "+v"(invalid_steps), "+v"(successful_steps)); pin4(sv);
   if (F.done || !F.valid) return;
   const int tid = threadIdx.x;
   double acc[3] = {0.0, 0.0, 0.0};           // candidate cost, model cost change, |dx|^2
@@ -1217,31 +1245,33 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_iter_end(const BaDev* __restrict_
   for (int b = tid; b < nb_cam; b += BA_TPB) { acc[2] += D.part[2 * D.nparts + b]; acc[1] += D.part[5 * D.nparts + b]; }
   block_reduce<3>(acc, s_red, s_out);
   if (tid != 0) return;
+  const double radius = sv[0], decrease_factor = sv[1], x_norm = sv[2], x_cost = sv[3];
   const double mcc = s_out[1];
-  if (st->chol_fail == 2) {             // a wait inside a persistent factorisation ran out of time: a scheduling problem, not arithmetic
+  if (F.chol_fail == 2) {               // a wait inside a persistent factorisation ran out of time: a scheduling problem, not arithmetic
     st->valid = 0; st->termination = 7; st->done = 1;                   // (the iterate and the radius stay as they are; the entry point returns ORBHIP_ETIMEOUT)
     return;
   }
-  if (st->chol_fail || !(mcc > 0.0)) {                                  // HandleInvalidStep
+  if (F.chol_fail || !(mcc > 0.0)) {                                    // HandleInvalidStep
     st->valid = 0;
-    if (++st->invalid_steps >= 5) { st->termination = 5; st->done = 1; }
-    st->radius /= st->decrease_factor; st->decrease_factor *= 2;
+    st->invalid_steps = invalid_steps + 1;
+    if (invalid_steps + 1 >= 5) { st->termination = 5; st->done = 1; }
+    st->radius = radius / decrease_factor; st->decrease_factor = decrease_factor * 2;
     return;
   }
   st->invalid_steps = 0;
   double cand_cost = s_out[0];
   if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
   st->cand_cost = cand_cost; st->model_cost_change = mcc; st->step_norm2 = s_out[2];
-  if (sqrt(s_out[2]) <= 1e-8 * (st->x_norm + 1e-8)) { st->termination = 2; st->done = 1; return; }
-  const double cost_change = st->x_cost - cand_cost;
-  if (fabs(cost_change) <= 1e-6 * st->x_cost) { st->termination = 3; st->done = 1; return; }
+  if (sqrt(s_out[2]) <= 1e-8 * (x_norm + 1e-8)) { st->termination = 2; st->done = 1; return; }
+  const double cost_change = x_cost - cand_cost;
+  if (fabs(cost_change) <= 1e-6 * x_cost) { st->termination = 3; st->done = 1; return; }
   const double rel = cost_change / mcc;
   if (rel > 1e-3) {
-    st->accepted = 1; st->successful_steps++; st->need_eval = 1;
-    st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3)));
+    st->accepted = 1; st->successful_steps = successful_steps + 1; st->need_eval = 1;
+    st->radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3)));
     st->decrease_factor = 2.0;
   } else {
-    st->radius /= st->decrease_factor; st->decrease_factor *= 2.0;
+    st->radius = radius / decrease_factor; st->decrease_factor = decrease_factor * 2.0;
   }
 }
 
