@@ -556,6 +556,24 @@ def test_persistent_cholesky_is_bit_identical():
             assert a["poses"] == b["poses"] and a["pts"] == b["pts"] and a.get("erase") == b.get("erase")
 
 
+def test_four_wave_backward_substitution_is_bit_identical():
+    """Systems with a skyline of <= 4 tiles take the whole backward substitution as one launch.  k_chol_bsolve_sky4 (round 6: a step is
+    two matrix-vector products by single waves, the 32 x 32 blocks copied into LDS two steps ahead) makes every entry from the same
+    products in the same order as the 1024-thread k_chol_bsolve_sky (ORBHIP_BA_BSOLVE_WAVES=0): poses, points, summaries and erase flags
+    of the persistent-Cholesky cases (1 .. 57 block rows: a partial top super-block, exactly one, several) must be BIT-IDENTICAL."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for env in ({"ORBHIP_BA_BSOLVE_WAVES": "1"}, {"ORBHIP_BA_BSOLVE_WAVES": "0"}):
+        r = subprocess.run([sys.executable, "-c", _PERSIST_SCRIPT, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
+    assert len(res[0]) == 13
+    for a, b in zip(res[0], res[1]):
+        assert a["summary"] == b["summary"] and a["summary"]["iterations"] >= 2
+        assert a["poses"] == b["poses"] and a["pts"] == b["pts"] and a.get("erase") == b.get("erase")
+
+
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_degenerate_graphs_vs_oracle(oracle, seed):
     """Structural degeneracies (single-observation cameras, duplicated observations, zero weights, points seen once, gross
