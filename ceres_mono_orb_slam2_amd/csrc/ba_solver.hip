@@ -791,9 +791,17 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
   const BaDev D = Dv[prob];
   const BaState* st = D.st;
-  const StFlags F = ld_flags(st);
-  if (F.done || !F.valid) return;
   if (a >= D.nfc) return;
+  // (round 6) NO BRANCHES AROUND LOADS in this kernel.  The compiler closes every `if` block that requested something with a wait for all
+  // of it - `if (m.z >= 0) { indices of the round after next }` behind "next round's gathers" made every round wait for those gathers
+  // BEFORE its arithmetic, the prologue's groups each waited for themselves (seven round trips where the dependence depth is four).  Every
+  // load below is unconditional on a clamped index (a segment that does not exist reads the entry behind the list, a lane without a pair
+  // its segment's first one), what it returned is sanitised where it is USED, a round or a phase later, and a group is waited for once
+  // (pin8 / pin4i).  The arithmetic is untouched.
+  int4 rm = D.row_meta[2 * a], rm2 = D.row_meta[2 * a + 1];          // (one round trip: not free_cams -> cam_off -> list; with the state flags)
+  const StFlags F = ld_flags(st);
+  pin4i(rm.x, rm.y, rm.z, rm.w); pin4i(rm2.x, rm2.y, rm2.z, rm2.w);
+  if (F.done || !F.valid) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int np = D.npad;
@@ -805,51 +813,71 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   __shared__ double s_w[2 * 4 * 36];                                  // (1): s_red [4][27], s_out [27]; (2): the mailboxes [2][4][36]
   __shared__ int s_mf[2][4][2];                                       // mailbox labels: {column b or -1, segment flags}
   double* s_red = s_w; double* s_out = s_w + 4 * 27;
-  const int4 rm = D.row_meta[2 * a], rm2 = D.row_meta[2 * a + 1];   // (one round trip: not free_cams -> cam_off -> list)
-  const int lo_a = rm2.x, n_a = rm2.y, ca = rm2.z;
-  const int d_lo = rm.x, d_hi = rm.y, s_lo = rm.z, s_hi = rm.w;
+  // (the row's labels are the same for every thread: scalars, so that what depends on them alone is a scalar decision)
+  const int lo_a = __builtin_amdgcn_readfirstlane(rm2.x), n_a = __builtin_amdgcn_readfirstlane(rm2.y), ca = __builtin_amdgcn_readfirstlane(rm2.z);
+  const int d_lo = __builtin_amdgcn_readfirstlane(rm.x), d_hi = __builtin_amdgcn_readfirstlane(rm.y), s_lo = __builtin_amdgcn_readfirstlane(rm.z),
+            s_hi = __builtin_amdgcn_readfirstlane(rm.w);
   const bool fuse = (d_hi - d_lo) == n_a;                              // the diagonal block's pair list IS the camera's list
   const int R = (s_hi - s_lo + 3) >> 2;                                // rounds of (2)
   if (tid < SR_PITCH) s_ec[SR_CH * SR_PITCH + tid] = 0.0;
   // ---- segment bookkeeping of (2) ----
-  struct Idx { int pj0, pj1, pi0, pi1; };                              // pair indices of a segment (two per lane)
+  struct Meta { int4 v; bool ok; };                                    // a segment's label as loaded; ok (a scalar): the segment exists
+  struct Idx { int pj0, pj1, pi0, pi1; bool v0, v1; };                 // pair indices of a segment (two per lane) as loaded; v: the lane has that pair
   struct Cam { double qb[4]; double sb; };                             // camera b of a segment: quaternion, S_c,b of this lane's sum
   const int slot = wave_reduce36_slot(lane);                   // which of a segment's 36 sums this lane ends up holding (or -1)
   const int slot_u = (slot < 0 ? 0 : slot) / 6, slot_v = (slot < 0 ? 0 : slot) - 6 * slot_u;
-  auto ld_meta = [&](int r) -> int4 {
+  auto ld_meta = [&](int r) -> Meta {
     const int g = s_lo + w + 4 * r;
-    return (g < s_hi) ? D.seg[g] : make_int4(0, 0, -1, 0);
+    Meta m; m.ok = g < s_hi;
+    m.v = D.seg[m.ok ? g : s_lo];                                      // (s_lo <= the list's length: the entry behind the list is allocated)
+    return m;
   };
-  auto ld_idx = [&](const int4& m) -> Idx {
-    Idx x; x.pj0 = x.pj1 = 0; x.pi0 = x.pi1 = -1;
-    if (m.z >= 0) {                                                    // (wave-uniform)
-      const int e0 = m.x + lane, e1 = m.x + 64 + lane;
-      const bool v0 = e0 < m.y, v1 = e1 < m.y;
-      x.pj0 = D.pair_j[v0 ? e0 : m.x]; x.pj1 = D.pair_j[v1 ? e1 : m.x];   // (a lane without a pair gathers the segment's first partner: finite wherever the block is)
-      const int p0 = D.pair_i[v0 ? e0 : m.x], p1 = D.pair_i[v1 ? e1 : m.x];
-      x.pi0 = v0 ? p0 : -1; x.pi1 = v1 ? p1 : -1;
-    }
+  auto ld_idx = [&](const Meta& m) -> Idx {
+    const int mx = m.ok ? m.v.x : 0, my = m.ok ? m.v.y : 0;
+    const int e0 = mx + lane, e1 = mx + 64 + lane;
+    Idx x; x.v0 = e0 < my; x.v1 = e1 < my;
+    x.pj0 = D.pair_j[x.v0 ? e0 : mx]; x.pj1 = D.pair_j[x.v1 ? e1 : mx];     // (a lane without a pair gathers the segment's first partner: finite wherever the block is)
+    x.pi0 = D.pair_i[x.v0 ? e0 : mx]; x.pi1 = D.pair_i[x.v1 ? e1 : mx];
     return x;
   };
-  auto ld_cam = [&](const int4& m) -> Cam {
-    Cam x; x.sb = 0.0; x.qb[0] = x.qb[1] = x.qb[2] = 0.0; x.qb[3] = 1.0;
-    if (m.z >= 0) {
-      const double* qb = D.poses + 7 * (size_t)(m.w >> 2) + 3;
+  auto ld_cam = [&](const Meta& m) -> Cam {
+    Cam x;
+    const double* qb = D.poses + 7 * (size_t)(m.ok ? (m.v.w >> 2) : 0) + 3;
 #pragma unroll
-      for (int k = 0; k < 4; k++) x.qb[k] = qb[k];
-      x.sb = D.scale_c[6 * (size_t)m.z + slot_v];
-    }
+    for (int k = 0; k < 4; k++) x.qb[k] = qb[k];
+    x.sb = D.scale_c[6 * (size_t)(m.ok ? m.v.z : 0) + slot_v];
     return x;
   };
+  auto ld_y = [&](const Meta& m, const Idx& ix, double* ya, double* yb) {
+    ld_rec8(D.E, (size_t)(m.ok ? ix.pj0 : 0), ya); ld_rec8(D.E, (size_t)(m.ok ? ix.pj1 : 0), yb);
+  };
+  // ---- (1) camera a's records -> LDS, the rhs of camera a and the diagonal block (a, a) ----
+  // Request order = dependence depth.  Group A hangs off the row's labels: camera a's first three list entries per thread (record + point
+  // index), its quaternion, the segment labels of (2).  Group B off those: the landmarks' N and g of the first two entries, the pair indices
+  // of round 0.
+  const bool p1 = !D.fix_points && n_a > 0;
+  const bool v0 = p1 && tid < n_a, v1 = p1 && tid + SC_TPB < n_a, v2 = p1 && tid + 2 * SC_TPB < n_a;
+  double c0[8], c1[8], c2[8], g0[9], g1[9], g2[9], qa[4];
+  int pt0, pt1, pt2;
+  {
+    const int e0 = lo_a + (v0 ? tid : 0), e1 = lo_a + (v1 ? tid + SC_TPB : 0), e2 = lo_a + (v2 ? tid + 2 * SC_TPB : 0);
+    pt0 = D.cam_obs_pt[e0]; pt1 = D.cam_obs_pt[e1]; pt2 = D.cam_obs_pt[e2];
+    ld_rec8(D.E, (size_t)e0, c0); ld_rec8(D.E, (size_t)e1, c1); ld_rec8(D.E, (size_t)e2, c2);
+#pragma unroll
+    for (int k = 0; k < 4; k++) qa[k] = D.poses[7 * (size_t)ca + 3 + k];
+  }
+  Meta m0 = ld_meta(0), m1 = ld_meta(1), m2 = ld_meta(2);
+  { int z = 0; pin4i(pt0, pt1, pt2, z); }
+  pin8(c0); pin8(c1); pin8(c2); pin4(qa);
+  pin4i(m0.v.x, m0.v.y, m0.v.z, m0.v.w); pin4i(m1.v.x, m1.v.y, m1.v.z, m1.v.w); pin4i(m2.v.x, m2.v.y, m2.v.z, m2.v.w);
   double Ra[9];
-  quat_to_R(D.poses + 7 * (size_t)ca + 3, Ra);
+  quat_to_R(qa, Ra);
   auto get_x = [&](int pos, double* x) {                       // (a camera with more observations than the LDS holds)
     const int e = lo_a + pos;
     double c[8];
     ld_rec8(D.E, (size_t)e, c);
     make_yr(c, Ra, D.Ng + 9 * (size_t)D.cam_obs_pt[e], x);
   };
-  // ---- (1) camera a's records -> LDS, the rhs of camera a and the diagonal block (a, a) ----
   double acc[27];                                              // 21 lower-triangle sums of the diagonal block, 6 of the rhs
 #pragma unroll
   for (int k = 0; k < 27; k++) acc[k] = 0.0;
@@ -869,26 +897,10 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     acc[24] += fma(x[10], h2, -(x[11] * h1)); acc[25] += fma(x[11], h0, -(x[9] * h2)); acc[26] += fma(x[9], h1, -(x[10] * h0));
     if (fuse) pair_acc_lower(x, Ra, c, acc);
   };
-  // Request order = dependence depth: camera a's first three list entries per thread (record + point index) leave first, then the
-  // segment labels of (2), then what hangs off the point indices, then the pair indices of the first two rounds.
-  const bool p1 = !D.fix_points && n_a > 0;
-  const bool v0 = p1 && tid < n_a, v1 = p1 && tid + SC_TPB < n_a, v2 = p1 && tid + 2 * SC_TPB < n_a;
-  double c0[8], c1[8], c2[8], g0[9], g1[9], g2[9];
-  int pt0 = 0, pt1 = 0, pt2 = 0;
-  if (p1) {
-    const int e0 = lo_a + (v0 ? tid : 0), e1 = lo_a + (v1 ? tid + SC_TPB : 0), e2 = lo_a + (v2 ? tid + 2 * SC_TPB : 0);
-    pt0 = D.cam_obs_pt[e0]; pt1 = D.cam_obs_pt[e1]; pt2 = D.cam_obs_pt[e2];
-    ld_rec8(D.E, (size_t)e0, c0); ld_rec8(D.E, (size_t)e1, c1); ld_rec8(D.E, (size_t)e2, c2);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  int4 m0 = ld_meta(0), m1 = ld_meta(1), m2 = ld_meta(2);
-  if (p1) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) { g0[k] = D.Ng[9 * (size_t)pt0 + k]; g1[k] = D.Ng[9 * (size_t)pt1 + k]; }
-  }
-  __builtin_amdgcn_sched_barrier(0);
+  for (int k = 0; k < 9; k++) { g0[k] = D.Ng[9 * (size_t)pt0 + k]; g1[k] = D.Ng[9 * (size_t)pt1 + k]; }
   Idx i0 = ld_idx(m0);
-  __builtin_amdgcn_sched_barrier(0);
+  pin8(g0); pin8(g1); { double t4[4] = {g0[8], g1[8], 0.0, 0.0}; pin4(t4); g0[8] = t4[0]; g1[8] = t4[1]; }
   if (p1) {
     one_obs(tid, v0, c0, g0);
     __builtin_amdgcn_sched_barrier(0);
@@ -910,26 +922,19 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   SR_STAMP(0, w == 0);
   __builtin_amdgcn_sched_barrier(0);
   // what the stores behind the reduction need (21 threads a diagonal entry, 6 an rhs entry): requested here, used behind the reduction
-  double o_b = 0.0, o_s = 1.0, o_s2 = 1.0, o_r = 1.0;
   int o_u = 0, o_v = 0;
-  if (tid < 21) {
-    while ((o_u + 1) * (o_u + 2) / 2 <= tid) o_u++;
-    o_v = tid - o_u * (o_u + 1) / 2;
-    const double* sc = D.scale_c + 6 * (size_t)a;
-    o_b = D.B[21 * (size_t)a + sym6(o_u, o_v)]; o_s = sc[o_u]; o_s2 = sc[o_v]; o_r = st->radius;
-  } else if (tid < 27) {
-    o_u = tid - 21;
-    o_b = D.gc[6 * (size_t)a + o_u]; o_s = D.scale_c[6 * (size_t)a + o_u];
-  }
-  const double sa = D.scale_c[6 * (size_t)a + slot_u];          // S_c,a of this lane's sum in (2)
+  if (tid < 21) { while ((o_u + 1) * (o_u + 2) / 2 <= tid) o_u++; o_v = tid - o_u * (o_u + 1) / 2; }
+  else if (tid < 27) o_u = tid - 21;
+  const double* sca = D.scale_c + 6 * (size_t)a;
+  const double ld_B = D.B[21 * (size_t)a + (tid < 21 ? sym6(o_u, o_v) : 0)], ld_g = D.gc[6 * (size_t)a + o_u];     // (both, every thread: no branch)
+  const double ld_s = sca[o_u], ld_s2 = sca[o_v], ld_r = st->radius;
+  const double sa = sca[slot_u];                                // S_c,a of this lane's sum in (2)
   // the partner records of round 0 (requested here: the reduction below hides their round trip)
   double y0[8], y1[8];
-  auto ld_y = [&](const int4& m, const Idx& ix, double* ya, double* yb) {
-    if (m.z >= 0) { ld_rec8(D.E, (size_t)ix.pj0, ya); ld_rec8(D.E, (size_t)ix.pj1, yb); }
-  };
   ld_y(m0, i0, y0, y1);
   Cam k0 = ld_cam(m0);
   Idx i1 = ld_idx(m1);
+  const double o_b = tid < 21 ? ld_B : ld_g, o_s = ld_s, o_s2 = tid < 21 ? ld_s2 : 1.0, o_r = ld_r;
   if (!fuse) {                                                 // a camera that sees a point twice: the literal pair list (cross terms)
     __syncthreads();
     for (int e = d_lo + tid; e < d_hi; e += SC_TPB) {
@@ -970,13 +975,13 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   for (int r = 0; r < R; r++) {
     const int buf = r & 1;
     double mine = 0.0;
-    if (m0.z >= 0) {
+    if (m0.ok) {                                               // (a scalar)
       // next round's gathers (their indices arrived a round ago) and the indices of the round after it go out first
       double z0[8], z1[8];
       ld_y(m1, i1, z0, z1);
       const Cam k1 = ld_cam(m1);
       const Idx i2 = ld_idx(m2);
-      const int4 m3 = ld_meta(r + 3);
+      const Meta m3 = ld_meta(r + 3);
       __builtin_amdgcn_sched_barrier(0);
       double Rb[9];
       quat_to_R(k0.qb, Rb);
@@ -992,16 +997,16 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         } else get_x(pos, x);
         pair_acc(x, Rb, y, a36);
       };
-      pair_prod(i0.pi0, y0);
-      pair_prod(i0.pi1, y1);
+      pair_prod(i0.v0 ? i0.pi0 : -1, y0);
+      pair_prod(i0.v1 ? i0.pi1 : -1, y1);
       mine = wave_reduce36(a36, lane) * (sa * k0.sb);            // (the lane with slot k holds the total of sum k)
-      if (lane == 0) { s_mf[buf][w][0] = m0.z; s_mf[buf][w][1] = m0.w; }
+      if (lane == 0) { s_mf[buf][w][0] = m0.v.z; s_mf[buf][w][1] = m0.v.w; }
       m0 = m1; m1 = m2; m2 = m3; i0 = i1; i1 = i2; k0 = k1;
 #pragma unroll
       for (int k = 0; k < 8; k++) { y0[k] = z0[k]; y1[k] = z1[k]; }
     } else {
       if (lane == 0) { s_mf[buf][w][0] = -1; s_mf[buf][w][1] = 0; }
-      m0 = m1; m1 = m2; m2 = make_int4(0, 0, -1, 0);          // (a wave's segments end at most one round before the row's)
+      m0 = m1; m1 = m2; m2.ok = false;                         // (a wave's segments end at most one round before the row's)
     }
     if (slot >= 0) s_w[(buf * 4 + w) * 36 + slot] = mine;
     __syncthreads();
