@@ -381,11 +381,7 @@ __device__ __forceinline__ void fast_tile_load(const uint8_t* base, uint8_t* til
 // walked sequentially; the ordered (row-major) emit needs only a running wave-uniform offset.
 #define FAST_WPB 1      // waves per workgroup
 #ifndef FAST_CPW
-#define FAST_CPW 1      // cells per wave.  2, one after the other (round 4): 0.4858 vs 0.4827 ms - workgroup dispatch is not the limiter.  2, MERGED
-                        // (round 6: tiles requested together, one survivor queue for both cells so that the score / non-maximum passes run on full
-                        // lanes; exact, 607 instead of 2 x 369 VALU instructions of code): 0.84 vs 0.60 ms under the profiler, value 155.0 k vs
-                        // 173.7 k (tools/r06/ab_mq.sh, 4 alternating pairs) - half as many waves, each with a chain 1.7 x as long: the kernel
-                        // follows its waves' dependent round trips, not its instruction count
+#define FAST_CPW 1      // cells per wave, processed one after the other (2: 0.4858 vs 0.4827 ms - workgroup dispatch is not the limiter)
 #endif
 // NARROW: every cell interior of the geometry is <= 32 px wide (all KITTI / VGA levels: 30-px cells): the per-row survivor masks
 // are 32-bit (one v_ffbl / v_bcnt / ds_or_b32 instead of pairs) and the pre-test's lane layout is a constant.
@@ -422,40 +418,34 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   }
   const int wv = FAST_WPB == 1 ? 0 : (int)(threadIdx.x >> 6);       // (one wave per workgroup: the cell index is visibly uniform, its descriptor comes by scalar loads)
   uint8_t* smem = smem_all + (size_t)wv * lds_per_wave;
-  // FAST_CPW cells per wave, MERGED: their tiles are requested together, their pre-test survivors share one queue (bit 14 of an
-  // entry = which cell) and the score / non-maximum passes run over that one queue - the passes whose lanes are half empty on an
-  // average cell (about 75 survivors: 64 + 11) fill up; staging, pre-test and emit run per cell.
-  const int ci0 = (bxi * FAST_WPB + wv) * FAST_CPW;
-  if (ci0 >= G.ncells_total) return;                  // (no workgroup-wide barrier below: waves are independent)
-  const int blk = 2 * plane + 2 * 64 * (int)sizeof(mask_t);           // per cell: tile [tile_h][TP], score [tile_h][TP], keep[64], k20[64]
-  int* qcnt = (int*)(smem + FAST_CPW * blk);          // queue length (LDS atomic counter; 16 bytes reserved)
-  unsigned short* queue = (unsigned short*)(qcnt + 4);                // pixels that passed the pre-test
+  // FAST_CPW cells per wave, one after the other on the same LDS (a wave's LDS operations execute in order, so the next cell's
+  // clears cannot overtake this cell's emit reads)
+  for (int rep = 0; rep < FAST_CPW; rep++) {
+  const int ci = (bxi * FAST_WPB + wv) * FAST_CPW + rep;
+  if (ci >= G.ncells_total) return;                   // (no workgroup-wide barrier below: waves are independent)
+  uint8_t* tile = smem;                               // [tile_h][TP]
+  uint8_t* score = smem + plane;                      // [tile_h][TP]
+  mask_t* keep = (mask_t*)(score + plane);            // [64] NMS survivors per interior row (bit = ix)
+  mask_t* k20 = keep + 64;                            // [64] survivors with score >= iniTh
+  int* qcnt = (int*)(k20 + 64);                       // queue length (LDS atomic counter; 16 bytes reserved)
+  unsigned short* queue = (unsigned short*)(qcnt + 4);                 // pixels that passed the pre-test
   FAST_STAMP_INIT;
-  CellDesc cv[FAST_CPW];
-  int iwv[FAST_CPW], ihv[FAST_CPW];
-  uint32_t bshv[FAST_CPW];
-  if (lane == 0) *qcnt = 0;
-  // ---- stage the cells (incl. their 3-px aprons) in LDS ---------------------------------------------
+  const CellDesc c = cells[ci];
+  const LevelDev& L = G.lv[c.level];
+  const uint8_t* src = level_ptr(G, c.level, f, img0, img_frame_bytes, pyr);
+  const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
+  const int iw = tw - 6, ih = th - 6;
+  // ---- stage the cell (incl. its 3-px apron) in LDS -------------------------------------------------
   // LDS-direct loads move ALIGNED dwords: the tile is fetched from the 4-byte boundary at or before its first pixel, so tile
   // byte (row, x) lives at LDS byte row * TP + x + bsh (TP = round_up(tw, 4) + 4 leaves room for the <= 3 extra bytes)
-#pragma unroll
-  for (int rep = 0; rep < FAST_CPW; rep++) {
-    iwv[rep] = 0; ihv[rep] = 0; bshv[rep] = 0;
-    if (ci0 + rep >= G.ncells_total) continue;        // (wave-uniform)
-    cv[rep] = cells[ci0 + rep];
-    const CellDesc& c = cv[rep];
-    const LevelDev& L = G.lv[c.level];
-    const uint8_t* src = level_ptr(G, c.level, f, img0, img_frame_bytes, pyr);
-    const int tw = c.x1 - c.x0, th = c.y1 - c.y0;
-    iwv[rep] = tw - 6; ihv[rep] = th - 6;
-    const uint8_t* cell_base = src + (long long)c.y0 * L.pitch + c.x0;
-    bshv[rep] = (uint32_t)((size_t)cell_base & 3);
-    const uint8_t* base_al = cell_base - bshv[rep];
-    uint8_t* tile = smem + rep * blk;
-    uint8_t* score = tile + plane;
-    mask_t* keep = (mask_t*)(score + plane);
-    for (int i = lane; i < plane >> 4; i += 64) ((uint4*)score)[i] = make_uint4(0u, 0u, 0u, 0u);
-    keep[lane] = 0; keep[64 + lane] = 0;
+  const uint8_t* cell_base = src + (long long)c.y0 * L.pitch + c.x0;
+  const uint32_t bsh = (uint32_t)((size_t)cell_base & 3);
+  const uint8_t* base_al = cell_base - bsh;
+  const uint8_t* tileb = tile + bsh;
+  for (int i = lane; i < plane >> 4; i += 64) ((uint4*)score)[i] = make_uint4(0u, 0u, 0u, 0u);
+  keep[lane] = 0; k20[lane] = 0;
+  if (lane == 0) *qcnt = 0;
+  {
     // The tile goes from global memory STRAIGHT into LDS (global_load_lds_dword: no VGPR staging, no re-alignment, no LDS
     // store instructions): a wave instruction writes 64 consecutive LDS dwords, so lane l of instruction j owns tile dword
     // k = l + 64 j = (row k / W4, column word k % W4) and reads it from row * pitch + 4 * (k % W4) - an unaligned dword when
@@ -466,18 +456,17 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     const int W4 = TP >> 2, ndw = th * W4;
     const uint32_t inv = (65536u + (uint32_t)W4 - 1u) / (uint32_t)W4;          // k / W4 = (k * inv) >> 16 for k < 4096, W4 <= 17
     fast_tile_load<0>(base_al, tile, lane, ndw, W4, inv, (uint32_t)L.pitch);
+    __builtin_amdgcn_s_waitcnt(0);                            // vmcnt(0): the tile has landed in LDS
   }
-  __builtin_amdgcn_s_waitcnt(0);                              // vmcnt(0): the tiles have landed in LDS
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-  FAST_STAMP(0);       // tiles staged
+  FAST_STAMP(0);       // tile staged
   // ---- pass A: compass pre-test; survivors are queued so that the expensive score runs on dense lanes ---------
   // A 9-arc of the 16-ring always contains two ADJACENT compass points (ring 0/4/8/12), i.e. one of {0, 8} and one of
   // {4, 12}.  Necessary for a brighter corner: max(c0, c8) > v + t and max(c4, c12) > v + t, i.e.
   // min(max(c0, c8), max(c4, c12)) - v > t; darker likewise with min / max swapped.  6 min/max + 2 sub + max + 1 compare
   // per pixel, and tighter than ">= 2 of the 4 compass points" (which also admits the opposite pairs).
   int qn = 0;
-#pragma unroll
-  for (int rep = 0; rep < FAST_CPW; rep++) {
+  {
     // FOUR horizontally adjacent pixels per lane, from dword LDS reads: lanes = (row, column group of 4); 8 groups x 8 rows
     // when the interior is <= 32 px wide (every KITTI / VGA level), else 16 groups x 4 rows.  With D[k] = the aligned dword at
     // tile columns 4k .. 4k+3, the interior pixels 4g .. 4g+3 (tile columns 4g+3 .. 4g+6) need
@@ -486,9 +475,6 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     // - seven dword reads instead of twenty byte reads per four pixels.  The bytes are split into even / odd pixels as u16
     // pairs and the min / max network runs on v_pk_{min,max,sub}_*16: ~10 VALU per pixel instead of ~18, and one prefix sum
     // + enqueue per FOUR pixels (most lanes have nothing to enqueue: 8 % of the pixels pass).
-    const int iw = iwv[rep], ih = ihv[rep];
-    const uint32_t bsh = bshv[rep];
-    const uint8_t* tile = smem + rep * blk;
     const bool narrow = NARROW || iw <= 32;
     const int RW = narrow ? 8 : 4;
     const int g = narrow ? (lane & 7) : (lane & 15), lr = narrow ? (lane >> 3) : (lane >> 4);
@@ -539,7 +525,7 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
         // writelane loop to issue ONE atomic per wave - ~8 scalar steps per lane, far more than the LDS unit's own conflict handling)
         int pos;
         asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(qaddr), "v"(__popc(pm)) : "memory");
-        const uint32_t rowbits = ((uint32_t)rep << 14) | ((uint32_t)iyl << 8) | (uint32_t)ix4;
+        const uint32_t rowbits = ((uint32_t)iyl << 8) | (uint32_t)ix4;
         do {
           const int k = __ffs((int)pm) - 1;
           pm &= pm - 1;
@@ -553,13 +539,9 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   FAST_STAMP(1);       // pre-test + queue
   // ---- pass B: FAST-9 score at the LOW threshold; one map serves both thresholds --------
-  // (entry = cell << 14 | iy << 8 | ix; iy <= 63, ix <= 63)
   for (int k = lane; k < qn; k += 64) {
-    const int q = queue[k], r = FAST_CPW > 1 ? (q >> 14) : 0, iy = (q >> 8) & 63, ix = q & 255;
-    uint32_t boff = bshv[0];
-#pragma unroll
-    for (int rr = 1; rr < FAST_CPW; rr++) boff = r == rr ? (uint32_t)(rr * blk) + bshv[rr] : boff;
-    const uint8_t* p = smem + boff + __mul24(iy + 3, TP) + ix + 3;
+    const int q = queue[k], iy = q >> 8, ix = q & 255;
+    const uint8_t* p = tileb + __mul24(iy + 3, TP) + ix + 3;
     const int v = p[0];
     short2_t d[16];
     auto mk = [&](int r) { return ring_pair(r); };
@@ -568,16 +550,15 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     d[8] = mk(p[-3 * TP]);        d[9] = mk(p[-3 * TP - 1]);  d[10] = mk(p[-2 * TP - 2]); d[11] = mk(p[-TP - 3]);
     d[12] = mk(p[-3]);            d[13] = mk(p[TP - 3]);      d[14] = mk(p[2 * TP - 2]);  d[15] = mk(p[3 * TP - 1]);
     const int best = arc9_best_packed(d, v);             // corner at t  <=>  best > t ; score = best - 1
-    if (best > minTh) smem[__mul24(r, blk) + plane + __mul24(iy + 3, TP) + ix + 3] = (uint8_t)(best - 1);
+    if (best > minTh) score[__mul24(iy + 3, TP) + ix + 3] = (uint8_t)(best - 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   FAST_STAMP(2);       // 9-arc score
   // ---- 3x3 non-max suppression inside the cell (frame pixels score 0), only on queued pixels --------
-  int any20 = 0;                                       // bit r: cell r has a survivor at the high threshold
+  int any20 = 0;
   for (int k = lane; k < qn; k += 64) {
-    const int q = queue[k], r = FAST_CPW > 1 ? (q >> 14) : 0, iy = (q >> 8) & 63, ix = q & 255;
-    const uint8_t* sp = smem + __mul24(r, blk) + plane + __mul24(iy + 3, TP) + ix + 3;
-    mask_t* keep = (mask_t*)(smem + __mul24(r, blk) + 2 * plane);
+    const int q = queue[k], iy = q >> 8, ix = q & 255;
+    const uint8_t* sp = score + __mul24(iy + 3, TP) + ix + 3;
     const int v = sp[0];
     // (all nine reads unconditional and the comparison without short-circuit: one LDS round trip per queued pixel)
     const int n0 = sp[-TP - 1], n1 = sp[-TP], n2 = sp[-TP + 1], n3 = sp[-1], n4 = sp[1], n5 = sp[TP - 1], n6 = sp[TP], n7 = sp[TP + 1];
@@ -585,48 +566,42 @@ __global__ __launch_bounds__(64 * FAST_WPB) void k_fast_cells(GeomDev G, const C
     const bool kp = v != 0 && v > nmax;
     if (kp) {
       atomicOr(&keep[iy], (mask_t)1 << ix);
-      if (v >= iniTh) { atomicOr(&keep[64 + iy], (mask_t)1 << ix); any20 |= 1 << r; }
+      if (v >= iniTh) { atomicOr(&k20[iy], (mask_t)1 << ix); any20 = 1; }
     }
   }
+  any20 = __any(any20);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
   FAST_STAMP(3);       // NMS
   // ---- ordered emit: K20 if non-empty else K7 (src/ORBextractor.cc:812-816), row by row -----------
-#pragma unroll
-  for (int rep = 0; rep < FAST_CPW; rep++) {
-    const int ci = ci0 + rep;
-    if (ci >= G.ncells_total) break;                  // (wave-uniform)
-    const CellDesc& c = cv[rep];
-    const int iw = iwv[rep], ih = ihv[rep];
-    const uint8_t* score = smem + rep * blk + plane;
-    const mask_t* keep = (const mask_t*)(score + plane);
-    const mask_t* mask = __any(any20 & (1 << rep)) ? keep + 64 : keep;
-    uint32_t* out = cell_kps + ((long long)f * G.ncells_total + ci) * G.cell_cap;
-    // lane r holds row r's mask; exclusive wave scan of the row populations gives every row's base offset
-    const mask_t mrow = (lane < ih) ? mask[lane] : (mask_t)0;
-    const int cnt = FastMask<NARROW>::popc(mrow);
-    const int incl = wave_incl_scan_i32(cnt);
-    const int base = __builtin_amdgcn_readlane(incl, 63);
-    // lane r writes row r's survivors itself, left to right, starting at the row's base offset: the loop runs for the
-    // LARGEST row population of the cell (a handful) instead of once per non-empty row, without cross-lane traffic
-    {
-      mask_t m = mrow;
-      int pos = incl - cnt;
-      const uint32_t yv = (uint32_t)(lane + 3 + c.offy) << 12;
-      const uint8_t* srow = score + __mul24(lane + 3, TP) + 3;
-      while (m) {
-        const int ix = FastMask<NARROW>::ffs0(m);
-        m &= m - 1;
-        if (pos < G.cell_cap) out[pos] = (uint32_t)(ix + 3 + c.offx) | yv | ((uint32_t)srow[ix] << 24);
-        pos++;
-      }
+  const mask_t* mask = any20 ? k20 : keep;
+  uint32_t* out = cell_kps + ((long long)f * G.ncells_total + ci) * G.cell_cap;
+  // lane r holds row r's mask; exclusive wave scan of the row populations gives every row's base offset
+  const mask_t mrow = (lane < ih) ? mask[lane] : (mask_t)0;
+  const int cnt = FastMask<NARROW>::popc(mrow);
+  const int incl = wave_incl_scan_i32(cnt);
+  const int base = __builtin_amdgcn_readlane(incl, 63);
+  // lane r writes row r's survivors itself, left to right, starting at the row's base offset: the loop runs for the
+  // LARGEST row population of the cell (a handful) instead of once per non-empty row, without cross-lane traffic
+  {
+    mask_t m = mrow;
+    int pos = incl - cnt;
+    const uint32_t yv = (uint32_t)(lane + 3 + c.offy) << 12;
+    const uint8_t* srow = score + __mul24(lane + 3, TP) + 3;
+    while (m) {
+      const int ix = FastMask<NARROW>::ffs0(m);
+      m &= m - 1;
+      if (pos < G.cell_cap) out[pos] = (uint32_t)(ix + 3 + c.offx) | yv | ((uint32_t)srow[ix] << 24);
+      pos++;
     }
-    if (lane == 0) cell_cnt[(long long)f * G.ncells_total + ci] = (ih > 0 && iw > 0) ? base : 0;
   }
+  if (lane == 0) cell_cnt[(long long)f * G.ncells_total + ci] = (ih > 0 && iw > 0) ? base : 0;
   FAST_STAMP(4);       // ordered emit
 #ifdef ORBHIP_FAST_PROF
-  { const long long wid = (long long)f * G.ncells_total + ci0;
+  { const long long wid = (long long)f * G.ncells_total + ci;
     if (lane == 0 && wid < FAST_PROF_WAVES) { for (int k = 0; k < 5; k++) g_fast_prof[wid][k] = t_ph[k]; g_fast_prof[wid][7] = 1u; } }
 #endif
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+  }   // cells of this wave
 }
 
 // ---------------------------------------------------------------------------- k_octree
@@ -830,8 +805,10 @@ __device__ __forceinline__ void octree_body(const GeomDev& G, const int* __restr
   while (true) {
     OCT_COUNT(14);
     const int prev = L;
-    const Rect16* R = rect[cur];
-    const cnt_t* C = cnt[cur];
+    // (round 6: offsets from ONE base, not `rect[cur]` / `cnt[cur]` - through an array of pointers indexed at run time the compiler lost the
+    // address space, and every read of a node's rectangle or count in the key loops was a FLAT load into the LDS aperture, waited for alone)
+    const Rect16* R = rect[0] + (size_t)cur * NC;
+    const cnt_t* C = cnt[0] + (size_t)cur * NC;
     // ---- A: candidates = nodes holding > 1 key, in list order ---------------------------------
     for (int p = tid; p < L; p += OCT_TPB) { sA[p] = C[p] > 1; cc[p] = OctT<WIDE>::zero(); rankOf[p] = -1; }
     if (tid == 0) { s_m = -1; s_nexp = 0; }
@@ -928,8 +905,8 @@ __device__ __forceinline__ void octree_body(const GeomDev& G, const int* __restr
     __syncthreads();
     block_excl_scan(sB, L, s_tmp);                         // sB[p] = #split nodes before p
     // ---- G: new list = reverse(children in creation order) ++ (old list minus split nodes) -------
-    Rect16* Rn = rect[cur ^ 1];
-    cnt_t* Cn = cnt[cur ^ 1];
+    Rect16* Rn = rect[0] + (size_t)(cur ^ 1) * NC;
+    cnt_t* Cn = cnt[0] + (size_t)(cur ^ 1) * NC;
     int nexp = 0;
     for (int p = tid; p < L; p += OCT_TPB) {
       int r = rankOf[p];
@@ -999,9 +976,11 @@ __device__ __forceinline__ void octree_body(const GeomDev& G, const int* __restr
   for (int k0 = tid; k0 < n; k0 += OCT_TPB * OCT_U) {
     uint32_t keyv[OCT_U]; int pv[OCT_U];
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) { const int k = k0 + OCT_TPB * u; const bool in = k < n; pv[u] = in ? (int)KN[k] : -1; keyv[u] = in ? K[k] : 0u; }
+    for (int u = 0; u < OCT_U; u++) { const int k = min(k0 + OCT_TPB * u, n - 1); pv[u] = (int)KN[k]; keyv[u] = K[k]; }      // (no branch around the loads: the compiler requested them pair by pair, each pair waited for before its atomic)
+    asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]),
+                      "+v"(keyv[0]), "+v"(keyv[1]), "+v"(keyv[2]), "+v"(keyv[3]), "+v"(keyv[4]), "+v"(keyv[5]), "+v"(keyv[6]), "+v"(keyv[7]));
 #pragma unroll
-    for (int u = 0; u < OCT_U; u++) if (pv[u] >= 0) atomicMax(&best[pv[u]], ((keyv[u] >> 24) << 24) | (0xFFFFFFu - (unsigned)(k0 + OCT_TPB * u)));
+    for (int u = 0; u < OCT_U; u++) if (k0 + OCT_TPB * u < n) atomicMax(&best[pv[u]], ((keyv[u] >> 24) << 24) | (0xFFFFFFu - (unsigned)(k0 + OCT_TPB * u)));
   }
   __syncthreads();
   for (int p = tid; p < L; p += OCT_TPB) {
@@ -1912,7 +1891,7 @@ static int prepare(orbx_ctx* c, int w, int h, int stride, int nframes) {
     G.pyr_frame_bytes = (pyr_off + 255) / 256 * 256;
     G.blur_frame_bytes = (blur_off + 255) / 256 * 256;
     c->fast_narrow = tile_w - 6 <= 32;                      // every cell interior <= 32 px wide: k_fast_cells<true> (32-bit row masks)
-    c->fast_lds = (size_t)round_up((int)((size_t)FAST_CPW * (2 * round_up(G.tile_h * G.tile_pitch, 16) + 2 * 64 * (c->fast_narrow ? 4 : 8)) + 16 + (size_t)FAST_CPW * 2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // per cell: tile + score (u8) + row masks; queue counter + queue (u16)
+    c->fast_lds = (size_t)round_up((int)((size_t)2 * round_up(G.tile_h * G.tile_pitch, 16) + 2 * 64 * (c->fast_narrow ? 4 : 8) + 16 + (size_t)2 * std::max(tile_w - 6, 1) * std::max(tile_h - 6, 1) + 16), 16);   // tile + score (u8) + row masks + queue counter + queue (u16)
     c->octree_wide = false;
     for (int l = 0; l < c->nlevels; l++) c->octree_wide = c->octree_wide || G.lv[l].kcap > 65535;
     c->octree_lds = octree_lds_bytes(G.node_cap, G.max_cells_level, false, false);

@@ -10,7 +10,8 @@ from ceres_mono_orb_slam2_amd import _lib, optimizer, synth
 _lib.LIB_PATH = so
 L = _lib.load()
 L.ba_debug_chol_prof.argtypes = [C.c_void_p, C.c_int]
-gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) for s in range(2)]
+ST = os.environ.get("ORBHIP_BENCH_STRUCTURE", "band")      # band | covis | dense (synth.make_ba_graph_covis)
+gs = [synth.make_ba_graph(s, ncam=100, npts=10000, nobs=50000, n_fixed=1) if ST == "band" else synth.make_ba_graph_covis(3000 + s, ncam=100, npts=10000, nobs=50000, structure=ST) for s in range(2)]
 local = np.ones(100, np.uint8)
 probs = [(g["K4"], g["poses0"], g["cam_fixed"], local, g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"]) for g in gs] * 16
 optimizer.local_bundle_adjustment_batch(probs)

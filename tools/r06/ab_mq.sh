@@ -1,5 +1,5 @@
 #!/bin/bash
-# k_fast_cells with two cells per wave sharing one survivor queue (tools/scratch/lib_fastmq: orb_extractor.hip with -DFAST_CPW=2) against
+# k_fast_cells with two cells per wave sharing one survivor queue (tools/scratch/lib_fastmq: orb_extractor.hip + tools/experiments/fast_shared_queue.patch, -DFAST_CPW=2) against
 # the product (one cell per wave): exactness on the extractor tests, then alternating bench.py front-end legs on one box
 export GPU_MAX_HW_QUEUES=8
 ORBHIP_LIB=$PWD/tools/scratch/lib_fastmq/liborbslam_hip.so timeout 900 python -m pytest tests/test_gpu_extractor.py -q -m gpu -x 2>&1 | tail -3
