@@ -410,12 +410,15 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
   const BaDev D = Dv[blockIdx.y];
   __shared__ double s_red[4 * 27], s_out[27];
   const BaState* st = D.st;
+  // (the camera's column and list range travel with the state flags: one round trip, they were three)
+  const int c = blockIdx.x;
+  const bool camwg = (int)blockIdx.x < ncam_grid && c < D.ncam;
+  int cc = D.cam_col[camwg ? c : 0], lo = D.cam_off[camwg ? c : 0], hi = D.cam_off[camwg ? c + 1 : 0], pad_ = 0;
   const StFlags F = ld_flags(st);
+  pin4i(cc, lo, hi, pad_);
   if (F.done || !F.need_eval) return;
   if ((int)blockIdx.x >= ncam_grid) { ba_pt_blocks_body(D, (int)blockIdx.x - ncam_grid); return; }
-  const int c = blockIdx.x;
   if (c >= D.ncam) return;
-  const int cc = D.cam_col[c];
   if (cc < 0) return;
   double acc[27];
 #pragma unroll
@@ -442,7 +445,6 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_cam_blocks(const BaDev* __restric
     acc[21] += h0; acc[22] += h1; acc[23] += h2;
     acc[24] += r1 * h2 - r2 * h1; acc[25] += r2 * h0 - r0 * h2; acc[26] += r0 * h1 - r1 * h0;
   };
-  const int lo = D.cam_off[c], hi = D.cam_off[c + 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (hi > lo) {                                                          // two list entries per thread requested before either is used
     const int e0 = lo + tid, e1 = lo + tid + BA_TPB;
@@ -661,22 +663,44 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_schur_prep(const BaDev* __restric
   if (D.fix_points) return;
   const int p = blockIdx.x * BA_TPB + threadIdx.x;
   if (p >= D.npts) return;
-  if (D.pt_off[p] == D.pt_off[p + 1]) return;
-  const double* sp = D.scale_p + 3 * (size_t)p;
-  const double* Cu = D.C + 6 * (size_t)p;
+  // (round 6: every input into registers first - one group, waited for once -, the stores at the end.  Written as loads and stores
+  // interleaved, the compiler re-read scale_p behind every store - pointers out of the same struct may alias -: sixteen dependent round
+  // trips per thread in a kernel that is 6 % of a batched iteration.  Same operations on the same doubles.)
+  int po[4] = {D.pt_off[p], D.pt_off[p + 1], 0, 0};
+  double in[16];                                               // scale_p (3), C (6), g_p (3), radius, -
+#pragma unroll
+  for (int k = 0; k < 16; k++) in[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { in[k] = D.scale_p[3 * (size_t)p + k]; in[9 + k] = D.gp[3 * (size_t)p + k]; }
+#pragma unroll
+  for (int k = 0; k < 6; k++) in[3 + k] = D.C[6 * (size_t)p + k];
+  in[12] = st->radius;
+  pin4i(po[0], po[1], po[2], po[3]); pin8(in); pin8(in + 8);
+  if (po[0] == po[1]) return;
+  const double* sp = in; const double* Cu = in + 3; const double* gpv = in + 9;
   double Cs[6] = {Cu[0] * sp[0] * sp[0], Cu[1] * sp[0] * sp[1], Cu[2] * sp[0] * sp[2], Cu[3] * sp[1] * sp[1], Cu[4] * sp[1] * sp[2], Cu[5] * sp[2] * sp[2]};
-  const double radius = st->radius;
+  const double radius = in[12];
   Cs[0] += fmin(fmax(Cs[0], 1e-6), 1e32) / radius;
   Cs[3] += fmin(fmax(Cs[3], 1e-6), 1e32) / radius;
   Cs[5] += fmin(fmax(Cs[5], 1e-6), 1e32) / radius;
   double Ci[6];
   if (!inv3_sym6(Cs, Ci)) { st->chol_fail = 1; for (int k = 0; k < 6; k++) Ci[k] = 0.0; }
-  for (int k = 0; k < 6; k++) D.Cinv[6 * (size_t)p + k] = Ci[k];
-  for (int k = 0; k < 3; k++) D.gps[3 * (size_t)p + k] = D.gp[3 * (size_t)p + k] * sp[k];
+  double o[18];                                                // Cinv (6), scaled g_p (3), N (6) + g_p (3)
+#pragma unroll
+  for (int k = 0; k < 6; k++) o[k] = Ci[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) o[6 + k] = gpv[k] * sp[k];
+  o[9] = Ci[0] * sp[0] * sp[0]; o[10] = Ci[1] * sp[0] * sp[1]; o[11] = Ci[2] * sp[0] * sp[2];
+  o[12] = Ci[3] * sp[1] * sp[1]; o[13] = Ci[4] * sp[1] * sp[2]; o[14] = Ci[5] * sp[2] * sp[2];
+#pragma unroll
+  for (int k = 0; k < 3; k++) o[15 + k] = gpv[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) D.Cinv[6 * (size_t)p + k] = o[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) D.gps[3 * (size_t)p + k] = o[6 + k];
   double* ng = D.Ng + 9 * (size_t)p;
-  ng[0] = Ci[0] * sp[0] * sp[0]; ng[1] = Ci[1] * sp[0] * sp[1]; ng[2] = Ci[2] * sp[0] * sp[2];
-  ng[3] = Ci[3] * sp[1] * sp[1]; ng[4] = Ci[4] * sp[1] * sp[2]; ng[5] = Ci[5] * sp[2] * sp[2];
-  for (int k = 0; k < 3; k++) ng[6 + k] = D.gp[3 * (size_t)p + k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) ng[k] = o[9 + k];
 }
 
 // X' = G (R_a N) of one observation of camera a is [Y; [r]x Y] with Y = W (R_a N) (3x3): twelve numbers {Y, r} stand for the 6x3 block.
