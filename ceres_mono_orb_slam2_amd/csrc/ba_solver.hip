@@ -536,11 +536,20 @@ __global__ __launch_bounds__(AE_TPB) void k_ba_after_eval(const BaDev* __restric
     double acc[3] = {0.0, 0.0, 0.0};                  // cost (slice 0), |x|^2 of the slice, (unused)
     if (sl == 0) for (int b = tid; b < D.nparts; b += AE_TPB) acc[0] += D.part[b];
     double gmax = 0.0;
+    // (round 6: a camera's column and pose in one group, its gradient in a second; a landmark's range, position and gradient in one - read
+    // where they were used, behind the `continue`s, they were four dependent round trips per camera and per landmark, and a lockstep
+    // batch's one workgroup per problem walks eight slices of them one after the other)
     for (int c = tid + AE_TPB * sl; c < D.ncam; c += stride) {
-      const int cc = D.cam_col[c];
+      int cc = D.cam_col[c];
+      double x[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 7; k++) x[k] = D.poses[7 * (size_t)c + k];
+      asm volatile("" : "+v"(cc)); pin8(x);
+      double g[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 6; k++) g[k] = D.gc[6 * (size_t)max(cc, 0) + k];
+      pin8(g);
       if (cc < 0) continue;
-      const double* x = D.poses + 7 * c;
-      const double* g = D.gc + 6 * (size_t)cc;
       for (int k = 0; k < 7; k++) acc[1] += x[k] * x[k];
       for (int k = 0; k < 3; k++) gmax = fmax(gmax, fabs(g[k]));
       double d[3] = {-g[3], -g[4], -g[5]}, qn[4];
@@ -549,8 +558,13 @@ __global__ __launch_bounds__(AE_TPB) void k_ba_after_eval(const BaDev* __restric
     }
     if (!D.fix_points)
       for (int p = tid + AE_TPB * sl; p < D.npts; p += stride) {
-        if (D.pt_off[p + 1] == D.pt_off[p]) continue;       // unused point: not in the reduced program
-        for (int k = 0; k < 3; k++) { double v = D.pts[3 * (size_t)p + k]; acc[1] += v * v; gmax = fmax(gmax, fabs(D.gp[3 * (size_t)p + k])); }
+        int o0 = D.pt_off[p], o1 = D.pt_off[p + 1], z0_ = 0, z1_ = 0;
+        double pg[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pg[k] = D.pts[3 * (size_t)p + k]; pg[4 + k] = D.gp[3 * (size_t)p + k]; }
+        pin4i(o0, o1, z0_, z1_); pin8(pg);
+        if (o1 == o0) continue;                             // unused point: not in the reduced program
+        for (int k = 0; k < 3; k++) { double v = pg[k]; acc[1] += v * v; gmax = fmax(gmax, fabs(pg[4 + k])); }
       }
     acc[2] = 0.0;
     // max-reduce gmax through the sum tree by bit tricks is not possible: do a separate max tree
@@ -1310,8 +1324,11 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_apply(const BaDev* __restrict__ D
   const StFlags F = ld_flags(st);
   if (F.done || !F.accepted) return;
   const int i = blockIdx.x * BA_TPB + threadIdx.x;
-  if (i < 7 * D.ncam) D.poses[i] = D.cand_poses[i];
-  if (i < 3 * D.npts) D.pts[i] = D.cand_pts[i];
+  const bool a = i < 7 * D.ncam, b = i < 3 * D.npts;
+  double v2[4] = {D.cand_poses[a ? i : 0], (D.npts > 0) ? D.cand_pts[b ? i : 0] : 0.0, 0.0, 0.0};      // (both loads before either store)
+  pin4(v2);
+  if (a) D.poses[i] = v2[0];
+  if (b) D.pts[i] = v2[1];
 }
 
 // ---- LocalBA outlier classification on the final poses / points (src/CeresOptimizer.cc:529-567): chi2 > 5.991 or
