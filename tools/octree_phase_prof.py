@@ -7,7 +7,7 @@ import numpy as np, torch
 out = os.path.join(ROOT, "gpurun_out", "octprof"); os.makedirs(out, exist_ok=True)
 so = os.path.join(out, "liborbx_octp.so")
 csrc = os.path.join(ROOT, "ceres_mono_orb_slam2_amd", "csrc")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DORBHIP_OCT_PROF",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DORBHIP_OCT_PROF", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + os.path.join(ROOT, "include"),
                        "-shared", "-o", so, os.path.join(csrc, "orb_extractor.hip"), os.path.join(csrc, "capi_common.hip")])
 import bench
 L = C.CDLL(so)
