@@ -305,16 +305,10 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
   for (int k = 0; k < 3; k++) kp[11 + k] = pts[3 * (size_t)p_mine + k];
   if (mode == 0) {
     col = D.cam_col[c_mine]; po0 = D.pt_off[p_mine]; po1 = D.pt_off[p_mine + 1];
-#pragma unroll
-    for (int k = 0; k < 4; k++) kp2[k] = D.K4[4 * (size_t)c2 + k];
-#pragma unroll
-    for (int k = 0; k < 7; k++) kp2[4 + k] = D.poses[7 * (size_t)c2 + k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) kp2[11 + k] = D.pts[3 * (size_t)p2 + k];
     run_end = D.pt_off[plast + 1];                              // (uniform) where the run of the workgroup's last landmark ends
   }
   pin8(kp); pin8(kp + 8);
-  if (mode == 0) { pin8(kp2); pin8(kp2 + 8); pin4i(col, po0, po1, run_end); }
+  if (mode == 0) pin4i(col, po0, po1, run_end);
   double acc[1] = {0.0};
   double rec[11] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};        // this observation's record {W (5), r (3), h (3)}
   if (have) {
@@ -342,6 +336,14 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
     }
   }
   if (mode == 0) {
+    // (the re-evaluated observation's intrinsics, pose and point: requested here, behind the first evaluation - 32 registers that would
+    // otherwise be live through it and cost the kernel a wave per SIMD -, in flight while the records leave)
+#pragma unroll
+    for (int k = 0; k < 4; k++) kp2[k] = D.K4[4 * (size_t)c2 + k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) kp2[4 + k] = D.poses[7 * (size_t)c2 + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) kp2[11 + k] = D.pts[3 * (size_t)p2 + k];
     // The records go to scattered places (the wave's observations are a run of the point-major order): four lanes write one record's
     // 64 bytes per store instruction, three its h - whole runs, not 64 sixteen-byte pieces of 64 lines (the L2 sees a third of the requests)
     s_q[w][lane] = q_mine;
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(BA_TPB) void k_ba_eval(const BaDev* __restrict__ Dv
 #pragma unroll
         for (int k = 0; k < 9; k++) s_pt[9 * threadIdx.x + k] = o[k];
       }
+      pin8(kp2); pin8(kp2 + 8);
       if ((int)threadIdx.x < run_end - iend) {                  // (have2 holds: the run ends inside the observations and is <= PT_MAXRUN long)
         double r2[2], J2[12], RX2[3], Rc[9], o[9];
         reproj_eval(kp2, kp2 + 4, kp2 + 11, n4[0], n4[1], n4[2], rob2, D.huber, r2, J2, nullptr, RX2);
