@@ -227,6 +227,19 @@ __device__ __forceinline__ void pin8(double* x) {
 }
 __device__ __forceinline__ void pin4(double* x) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])); }
 __device__ __forceinline__ void pin4i(int& a, int& b, int& c, int& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+// Loads through ADDRESS-SPACE-1 pointers (round 6).  The pointers of the BaDev struct are generic, so the compiler emits FLAT loads, and a
+// flat load counts as LDS traffic too (lgkmcnt): in a kernel that gathers records while it reads its LDS - k_ba_schur - every wait for an
+// LDS read also waited for the gathers in flight.  ldg / ld_rec8g are global_load instructions: vmcnt only.
+#define ORB_AS1 __attribute__((address_space(1)))
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ T ldg(const T* p) { return *(const T ORB_AS1*)p; }
+__device__ __forceinline__ int4 ldg4(const int4* p) { const v4i_t v = *(const v4i_t ORB_AS1*)p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void ld_rec8g(const double* base, size_t q, double* c) {
+  const v2d_t ORB_AS1* m = (const v2d_t ORB_AS1*)(base + 8 * q);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const v2d_t v = m[k]; c[2 * k] = v.x; c[2 * k + 1] = v.y; }
+}
 __device__ __forceinline__ void ld_rec8(const double* __restrict__ base, size_t q, double* c) {
   const double2* m = (const double2*)(base + 8 * q);
 #pragma unroll
@@ -839,7 +852,7 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // load below is unconditional on a clamped index (a segment that does not exist reads the entry behind the list, a lane without a pair
   // its segment's first one), what it returned is sanitised where it is USED, a round or a phase later, and a group is waited for once
   // (pin8 / pin4i).  The arithmetic is untouched.
-  int4 rm = D.row_meta[2 * a], rm2 = D.row_meta[2 * a + 1];          // (one round trip: not free_cams -> cam_off -> list; with the state flags)
+  int4 rm = ldg4(D.row_meta + 2 * a), rm2 = ldg4(D.row_meta + 2 * a + 1);          // (one round trip: not free_cams -> cam_off -> list; with the state flags)
   const StFlags F = ld_flags(st);
   pin4i(rm.x, rm.y, rm.z, rm.w); pin4i(rm2.x, rm2.y, rm2.z, rm2.w);
   if (F.done || !F.valid) return;
@@ -870,27 +883,27 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   auto ld_meta = [&](int r) -> Meta {
     const int g = s_lo + w + 4 * r;
     Meta m; m.ok = g < s_hi;
-    m.v = D.seg[m.ok ? g : s_lo];                                      // (s_lo <= the list's length: the entry behind the list is allocated)
+    m.v = ldg4(D.seg + (m.ok ? g : s_lo));                                      // (s_lo <= the list's length: the entry behind the list is allocated)
     return m;
   };
   auto ld_idx = [&](const Meta& m) -> Idx {
     const int mx = m.ok ? m.v.x : 0, my = m.ok ? m.v.y : 0;
     const int e0 = mx + lane, e1 = mx + 64 + lane;
     Idx x; x.v0 = e0 < my; x.v1 = e1 < my;
-    x.pj0 = D.pair_j[x.v0 ? e0 : mx]; x.pj1 = D.pair_j[x.v1 ? e1 : mx];     // (a lane without a pair gathers the segment's first partner: finite wherever the block is)
-    x.pi0 = D.pair_i[x.v0 ? e0 : mx]; x.pi1 = D.pair_i[x.v1 ? e1 : mx];
+    x.pj0 = ldg(D.pair_j + (x.v0 ? e0 : mx)); x.pj1 = ldg(D.pair_j + (x.v1 ? e1 : mx));     // (a lane without a pair gathers the segment's first partner: finite wherever the block is)
+    x.pi0 = ldg(D.pair_i + (x.v0 ? e0 : mx)); x.pi1 = ldg(D.pair_i + (x.v1 ? e1 : mx));
     return x;
   };
   auto ld_cam = [&](const Meta& m) -> Cam {
     Cam x;
     const double* qb = D.poses + 7 * (size_t)(m.ok ? (m.v.w >> 2) : 0) + 3;
 #pragma unroll
-    for (int k = 0; k < 4; k++) x.qb[k] = qb[k];
-    x.sb = D.scale_c[6 * (size_t)(m.ok ? m.v.z : 0) + slot_v];
+    for (int k = 0; k < 4; k++) x.qb[k] = ldg(qb + k);
+    x.sb = ldg(D.scale_c + 6 * (size_t)(m.ok ? m.v.z : 0) + slot_v);
     return x;
   };
   auto ld_y = [&](const Meta& m, const Idx& ix, double* ya, double* yb) {
-    ld_rec8(D.E, (size_t)(m.ok ? ix.pj0 : 0), ya); ld_rec8(D.E, (size_t)(m.ok ? ix.pj1 : 0), yb);
+    ld_rec8g(D.E, (size_t)(m.ok ? ix.pj0 : 0), ya); ld_rec8g(D.E, (size_t)(m.ok ? ix.pj1 : 0), yb);
   };
   // ---- (1) camera a's records -> LDS, the rhs of camera a and the diagonal block (a, a) ----
   // Request order = dependence depth.  Group A hangs off the row's labels: camera a's first three list entries per thread (record + point
@@ -902,10 +915,10 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   int pt0, pt1, pt2;
   {
     const int e0 = lo_a + (v0 ? tid : 0), e1 = lo_a + (v1 ? tid + SC_TPB : 0), e2 = lo_a + (v2 ? tid + 2 * SC_TPB : 0);
-    pt0 = D.cam_obs_pt[e0]; pt1 = D.cam_obs_pt[e1]; pt2 = D.cam_obs_pt[e2];
-    ld_rec8(D.E, (size_t)e0, c0); ld_rec8(D.E, (size_t)e1, c1); ld_rec8(D.E, (size_t)e2, c2);
+    pt0 = ldg(D.cam_obs_pt + e0); pt1 = ldg(D.cam_obs_pt + e1); pt2 = ldg(D.cam_obs_pt + e2);
+    ld_rec8g(D.E, (size_t)e0, c0); ld_rec8g(D.E, (size_t)e1, c1); ld_rec8g(D.E, (size_t)e2, c2);
 #pragma unroll
-    for (int k = 0; k < 4; k++) qa[k] = D.poses[7 * (size_t)ca + 3 + k];
+    for (int k = 0; k < 4; k++) qa[k] = ldg(D.poses + 7 * (size_t)ca + 3 + k);
   }
   Meta m0 = ld_meta(0), m1 = ld_meta(1), m2 = ld_meta(2);
   { int z = 0; pin4i(pt0, pt1, pt2, z); }
@@ -939,14 +952,14 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (fuse) pair_acc_lower(x, Ra, c, acc);
   };
 #pragma unroll
-  for (int k = 0; k < 9; k++) { g0[k] = D.Ng[9 * (size_t)pt0 + k]; g1[k] = D.Ng[9 * (size_t)pt1 + k]; }
+  for (int k = 0; k < 9; k++) { g0[k] = ldg(D.Ng + 9 * (size_t)pt0 + k); g1[k] = ldg(D.Ng + 9 * (size_t)pt1 + k); }
   Idx i0 = ld_idx(m0);
   pin8(g0); pin8(g1); { double t4[4] = {g0[8], g1[8], 0.0, 0.0}; pin4(t4); g0[8] = t4[0]; g1[8] = t4[1]; }
   if (p1) {
     one_obs(tid, v0, c0, g0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 9; k++) g2[k] = D.Ng[9 * (size_t)pt2 + k];         // (into the registers the first entry has left)
+    for (int k = 0; k < 9; k++) g2[k] = ldg(D.Ng + 9 * (size_t)pt2 + k);         // (into the registers the first entry has left)
     __builtin_amdgcn_sched_barrier(0);
     one_obs(tid + SC_TPB, v1, c1, g1);
     one_obs(tid + 2 * SC_TPB, v2, c2, g2);
@@ -967,9 +980,9 @@ __global__ __launch_bounds__(SC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   if (tid < 21) { while ((o_u + 1) * (o_u + 2) / 2 <= tid) o_u++; o_v = tid - o_u * (o_u + 1) / 2; }
   else if (tid < 27) o_u = tid - 21;
   const double* sca = D.scale_c + 6 * (size_t)a;
-  const double ld_B = D.B[21 * (size_t)a + (tid < 21 ? sym6(o_u, o_v) : 0)], ld_g = D.gc[6 * (size_t)a + o_u];     // (both, every thread: no branch)
-  const double ld_s = sca[o_u], ld_s2 = sca[o_v], ld_r = st->radius;
-  const double sa = sca[slot_u];                                // S_c,a of this lane's sum in (2)
+  const double ld_B = ldg(D.B + 21 * (size_t)a + (tid < 21 ? sym6(o_u, o_v) : 0)), ld_g = ldg(D.gc + 6 * (size_t)a + o_u);     // (both, every thread: no branch)
+  const double ld_s = ldg(sca + o_u), ld_s2 = ldg(sca + o_v), ld_r = ldg(&st->radius);
+  const double sa = ldg(sca + slot_u);                                // S_c,a of this lane's sum in (2)
   // the partner records of round 0 (requested here: the reduction below hides their round trip)
   double y0[8], y1[8];
   ld_y(m0, i0, y0, y1);
