@@ -260,6 +260,22 @@ def make_ba_graph(seed, ncam=100, npts=10000, nobs=50000, outlier_frac=0.05, noi
 
 
 
+def shuffle_keyframes(g, seed):
+    """The same graph with its keyframes listed in a random order (a merged or re-indexed map: ids that do not follow the covisibility
+    chain).  The reduced camera system of make_ba_graph's band then fills its whole triangle unless the solver reorders it
+    (ORBHIP_BA_ORDER=rcm).  Returns a new dict; `kf_perm[new] = old`."""
+    rng = np.random.default_rng(seed)
+    ncam = len(g["cam_fixed"])
+    perm = rng.permutation(ncam)                      # new position -> old keyframe
+    inv = np.empty(ncam, np.int64); inv[perm] = np.arange(ncam)
+    h = dict(g)
+    for k in ("K4", "poses0", "poses_gt", "cam_fixed"):
+        if k in g: h[k] = np.ascontiguousarray(g[k][perm])
+    h["obs_cam"] = inv[g["obs_cam"]].astype(g["obs_cam"].dtype)
+    h["kf_perm"] = perm
+    return h
+
+
 def _quat_from_R(R):
     """[x,y,z,w] of a rotation matrix (largest-component branch)."""
     m = R; tr = m[0, 0] + m[1, 1] + m[2, 2]

@@ -140,3 +140,44 @@ def test_c5_loop_closed_one_iteration_vs_oracle(oracle):
     cloud = abs(ps["final_cost"] - os_["final_cost"]) / os_["final_cost"]
     assert abs(s["final_cost"] - os_["final_cost"]) / os_["final_cost"] <= max(RTOL_COST, CLOUD * cloud)
     assert s["final_cost"] < 0.8 * s["initial_cost"]
+
+
+_ORDER_SCRIPT = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+from ceres_mono_orb_slam2_amd import optimizer, synth
+g = synth.shuffle_keyframes(synth.make_ba_graph(31, ncam=60, npts=3000, nobs=15000, n_fixed=1, max_depth=25.0, min_len=4), 9)
+a = (g["K4"], g["poses0"], g["cam_fixed"], np.ones(60, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["obs_inv_sigma2"])
+ab, poses, pts, er, s1, s2 = optimizer.local_bundle_adjustment(*a)
+print("RESULT " + json.dumps({"poses": poses.tolist(), "pts": pts.tolist(), "erase": er.tolist(), "s1": s1, "s2": s2, "plan": optimizer.get_last_plan()}))
+"""
+
+
+def test_rcm_order_narrows_the_skyline_of_a_shuffled_map(oracle):
+    """ORBHIP_BA_ORDER=rcm (round 6; read once per process: two subprocesses): the free keyframes are eliminated in reverse Cuthill - McKee
+    order of their covisibility graph instead of the caller's.  On SURVEY 8(d)'s odometry graph with its keyframes SHUFFLED the caller's
+    order fills the reduced system's triangle (a band of >= 8 tiles of 12), the reordered one is the band again (<= 4: the one-launch
+    backward substitution).  Only the order of elimination changes: both runs reproduce the oracle's two-pass LocalBA - erase flags,
+    iteration counts, termination identical, cost 1e-9, poses 1e-7, landmarks 1e-7 of their depth - on this well-conditioned graph."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for v in ("id", "rcm"):
+        r = subprocess.run([sys.executable, "-c", _ORDER_SCRIPT, root], env=dict(os.environ, ORBHIP_BA_ORDER=v), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[v] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert res["id"]["plan"]["band_tiles"] >= 8, res["id"]["plan"]
+    assert res["rcm"]["plan"]["band_tiles"] <= 4, res["rcm"]["plan"]
+    assert res["rcm"]["plan"]["backward_substitution"] == "k_chol_bsolve_sky"
+    g = synth.shuffle_keyframes(synth.make_ba_graph(31, ncam=60, npts=3000, nobs=15000, n_fixed=1, max_depth=25.0, min_len=4), 9)
+    _threads(oracle)
+    oab, oposes, opts, oer, o1, o2 = oracle.local_ba(g["K4"], g["poses0"], g["cam_fixed"], np.ones(60, np.uint8), g["pts0"], g["obs_cam"], g["obs_pt"],
+                                                     g["obs_uv"], g["obs_inv_sigma2"])
+    for v in ("id", "rcm"):
+        d = res[v]
+        assert d["erase"] == oer.tolist(), v
+        for s, o in ((d["s1"], o1), (d["s2"], o2)):
+            assert s["iterations"] == o["iterations"] and s["successful_steps"] == o["successful_steps"] and s["termination"] == o["termination"], (v, s, o)
+            assert abs(s["final_cost"] - o["final_cost"]) <= 1e-9 * o["final_cost"], (v, s, o)
+        np.testing.assert_allclose(np.array(d["poses"]), oposes, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(np.array(d["pts"]), opts, rtol=1e-7, atol=1e-5)        # (landmarks 30 - 60 m away: 1e-7 of their depth)

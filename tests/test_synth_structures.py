@@ -59,3 +59,14 @@ def test_generator_is_deterministic():
     a = synth.make_ba_graph_covis(5, 20, 200, 1000, structure="covis", window=(4, 8))
     b = synth.make_ba_graph_covis(5, 20, 200, 1000, structure="covis", window=(4, 8))
     assert all(np.array_equal(a[k], b[k]) for k in ("obs_cam", "obs_pt", "obs_uv", "poses0", "pts0"))
+
+
+def test_shuffle_keyframes_is_a_relabelling():
+    g = synth.make_ba_graph(3, ncam=40, npts=800, nobs=4000, n_fixed=1)
+    h = synth.shuffle_keyframes(g, 7)
+    perm = h["kf_perm"]
+    assert sorted(perm.tolist()) == list(range(40)) and not np.array_equal(perm, np.arange(40))
+    assert np.array_equal(h["poses0"], g["poses0"][perm]) and np.array_equal(h["cam_fixed"], g["cam_fixed"][perm])
+    assert np.array_equal(perm[h["obs_cam"]], g["obs_cam"])                       # every observation still names the same keyframe
+    assert np.array_equal(h["obs_pt"], g["obs_pt"]) and np.array_equal(h["obs_uv"], g["obs_uv"])
+    assert int(h["cam_fixed"].sum()) == 1
